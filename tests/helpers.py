@@ -1,0 +1,44 @@
+"""Shared builders for the tests: oracle objects from the product's robot tables, synthetic
+scenes, small problem instances.  (The oracle is the checker; see oracle/vgpmp_oracle.py.)"""
+import math
+
+import numpy as np
+
+from oracle import vgpmp_oracle as orc
+from vgpmp_amd import robots as rb
+from vgpmp_amd import scenes
+
+
+def oracle_robot(spec: rb.RobotSpec) -> orc.RobotTable:
+    return orc.RobotTable(name=spec.name, dh=spec.dh.copy(), twist=spec.twist.copy(), craig=spec.craig,
+                          base_pose=spec.base_pose.copy(), fk_slice=spec.fk_slice.copy(),
+                          spheres_per_link=spec.num_spheres_per_link.copy(),
+                          sphere_offsets=spec.sphere_offsets.copy(), radii=spec.sphere_radii.copy(),
+                          joint_limits=spec.joint_limits.copy())
+
+
+def oracle_scene(spec, grid, offset, sigma_obs=0.005, epsilon=0.05) -> orc.Scene:
+    data, origin, delta = grid
+    return orc.Scene(robot=oracle_robot(spec), sdf=orc.SDFGrid(np.asarray(data, np.float64), np.asarray(origin, np.float64), float(delta)),
+                     offset=np.asarray(offset, dtype=np.float64),
+                     sigma_obs=np.full(spec.num_spheres, sigma_obs), epsilon=epsilon)
+
+
+def small_problem(robot="franka", S=6, N=9, M=5, B=64, seed=0, n_grid=24, problem="industrial"):
+    """A tiny planning instance with obstacles close enough that the hinge is active."""
+    ps = rb.load_problemset(robot, problem)
+    spec = rb.load_robot(robot, *ps.robot_pos_and_orn)
+    grid = scenes.synthetic_boxes_sdf(n=n_grid, delta=2.4 / n_grid, origin=(-1.2, -1.2, -0.6), seed=seed)
+    scene = oracle_scene(spec, grid, ps.object_positions[0])
+    y = np.array([ps.states[0], ps.states[1]], dtype=np.float64)
+    D = spec.dof
+    pp = ps.planner_params
+    params = orc.init_params(scene.robot, y, M, pp["lengthscales"], pp["variance"])
+    rng = np.random.default_rng(seed + 1)
+    params.q_sqrt = np.tril(params.q_sqrt + 0.05 * rng.standard_normal(params.q_sqrt.shape))
+    params.q_mu = params.q_mu + 0.05 * rng.standard_normal(params.q_mu.shape)
+    X = orc.init_trainset(N, D)
+    Zy = orc.inducing_Zy(M, D)
+    noise = orc.draw_noise(rng, S, D, D, B, M + 2)
+    return dict(spec=spec, scene=scene, grid=grid, y=y, params=params, X=X, Zy=Zy, noise=noise,
+                alpha=float(pp["alpha"]), lr=float(pp["learning_rate"]), offset=np.array(ps.object_positions[0]))

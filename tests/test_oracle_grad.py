@@ -1,0 +1,89 @@
+"""The oracle's forward pass and analytic reverse pass against torch.autograd (float64) on an
+independent restatement (tests/torch_ref.py).  Parity with GPflow/TF itself is unpinned (no TF here)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vgpmp_oracle as orc
+import torch_ref
+from helpers import small_problem
+
+
+@pytest.mark.parametrize("robot,problem", [("franka", "industrial"), ("wam", "industrial"), ("ur10", "industrial")])
+def test_elbo_and_gradient_match_autograd(robot, problem):
+    pb = small_problem(robot=robot, problem=problem, S=5, N=8, M=4, B=32, seed=3)
+    fw = orc.elbo_forward(pb["params"], pb["scene"], pb["X"], pb["Zy"], pb["y"], pb["noise"], pb["alpha"])
+    grads, _ = orc.elbo_backward(pb["params"], pb["scene"], pb["X"], pb["Zy"], pb["noise"], pb["alpha"], fw)
+    e, leaves, aux = torch_ref.elbo(pb["params"], pb["scene"], pb["X"], pb["Zy"], pb["y"], pb["noise"], pb["alpha"])
+    assert (fw["logp"] < 0).any(), "fixture must have active hinge terms"
+    np.testing.assert_allclose(fw["g"], aux["g"].detach().numpy(), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(fw["logp"], aux["logp"].detach().numpy(), rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(fw["cv"]["kl"], float(aux["kl"].detach()), rtol=1e-9)
+    np.testing.assert_allclose(fw["elbo"], float(e), rtol=1e-9)
+    (-e).backward()
+    for name in ("q_mu", "q_sqrt", "raw_ell", "raw_var"):
+        want = leaves[name].grad.numpy()
+        got = getattr(grads, name)
+        if name == "q_sqrt":
+            want = np.tril(want)
+        scale = np.abs(want).max() + 1e-30
+        assert np.abs(got - want).max() / scale < 2e-6, (name, np.abs(got - want).max(), scale)
+
+
+def test_fk_backward_is_the_chain_derivative():
+    pb = small_problem(robot="wam", S=3, N=4, M=3, B=8, seed=5)
+    rb = pb["scene"].robot
+    rng = np.random.default_rng(0)
+    q = rng.uniform(rb.low, rb.high, (11, rb.dof))
+    gpos = rng.standard_normal((11, rb.num_spheres, 3))
+    frames = orc.forward_kinematics(rb, q)
+    pos = orc.sphere_positions(rb, q, frames)
+    got = orc.fk_backward(rb, frames, pos, gpos)
+    h = 1e-6
+    for j in range(rb.dof):
+        dq = np.zeros(rb.dof); dq[j] = h
+        num = ((orc.sphere_positions(rb, q + dq) - orc.sphere_positions(rb, q - dq)) / (2 * h) * gpos).sum((-1, -2))
+        np.testing.assert_allclose(got[:, j], num, rtol=1e-6, atol=1e-7)
+
+
+def test_adam_matches_torch_adam_modulo_epsilon_placement():
+    """Keras Adam: x -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps).  torch.optim.Adam puts eps
+    after the bias correction; with eps -> 0 both coincide, which pins the moment recursions."""
+    rng = np.random.default_rng(1)
+    x0 = rng.standard_normal(7)
+    p = orc.Params(q_mu=x0.reshape(7, 1).copy(), q_sqrt=np.eye(1)[None].repeat(1, 0), raw_ell=np.zeros(1), raw_var=np.zeros(1))
+    st = orc.adam_init(p)
+    xt = torch.tensor(x0, dtype=torch.float64, requires_grad=True)
+    opt = torch.optim.Adam([xt], lr=0.02, betas=(0.8, 0.95), eps=0.0)
+    for t in range(5):
+        g = rng.standard_normal(7)
+        orc.adam_step(p, orc.Params(g.reshape(7, 1), np.zeros((1, 1, 1)), np.zeros(1), np.zeros(1)), st, 0.02,
+                      dict(q_mu=True, q_sqrt=False, lengthscales=False, kernel_variance=False), eps=0.0)
+        xt.grad = torch.tensor(g)
+        opt.step()
+    np.testing.assert_allclose(p.q_mu[:, 0], xt.detach().numpy(), rtol=1e-10)
+
+
+def test_philox_known_answer_and_moments():
+    """Random123 KAT for philox4x32-10: counter=0,key=0 and the all-ones vector."""
+    z = orc.philox4x32(np.zeros((1, 4), dtype=np.uint32), (0, 0))[0]
+    assert [int(v) for v in z] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    o = orc.philox4x32(np.full((1, 4), 0xFFFFFFFF, dtype=np.uint32), (0xFFFFFFFF, 0xFFFFFFFF))[0]
+    assert [int(v) for v in o] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    n = orc.philox_normals(200000, orc.philox_key(7, 3, 11), orc.STREAM_W)
+    assert abs(n.mean()) < 0.01 and abs(n.std() - 1.0) < 0.01
+    nz = orc.philox_noise(7, 0, 0, S=64, L=3, D=3, B=256, Mz=6)
+    # Student-t(5) spectral draw: variance nu/(nu-2) = 5/3
+    assert abs(nz.omega.var() - 5.0 / 3.0) < 0.25 and 0 <= nz.beta.min() and nz.beta.max() <= 2 * np.pi
+
+
+def test_optimization_reduces_loss():
+    pb = small_problem(S=8, N=12, M=5, B=64, seed=2)
+    p = pb["params"].copy(); st = orc.adam_init(p)
+    rng = np.random.default_rng(0)
+    losses = []
+    for step in range(12):
+        noise = orc.draw_noise(rng, 8, 7, 7, 64, 7)
+        losses.append(orc.optimization_step(p, st, pb["scene"], pb["X"], pb["Zy"], pb["y"], noise, pb["alpha"], 0.02))
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-3:]) < np.mean(losses[:3])
