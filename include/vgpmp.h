@@ -1,0 +1,192 @@
+/*
+ * vgpmp.h -- C ABI of the MI355X-native vGPMP hot path (libvgpmp_hip.so).
+ *
+ * The reference (luke-ck/vgpmp) is pure Python on TensorFlow/GPflow and has no FFI; the entry
+ * points below are what a binding for its ELBO inner loop would call.  Each one names the
+ * reference code it stands in for (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer marked `dev` is DEVICE memory owned by the caller (PyTorch-ROCm tensors in
+ *     the Python host); the library never allocates or frees caller memory; scratch comes from
+ *     the caller-provided workspace (vgpmp_workspace_bytes).
+ *   - return value: 0 = ok, negative = argument/shape error (VGPMP_E_*), positive = hipError_t.
+ *   - thread-compatible; every launch goes to the explicit `stream`; no hidden global state.
+ *   - arrays are dense, C order, leading dimension = problem index for batched buffers.
+ */
+#ifndef VGPMP_H
+#define VGPMP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGPMP_MAX_DOF 16
+#define VGPMP_MAX_FRAMES 17
+#define VGPMP_MAX_SPHERES 64
+#define VGPMP_MAX_MZ 64          /* inducing points + 2 conditioned end points */
+
+#define VGPMP_E_ARG (-1)         /* null pointer / inconsistent argument */
+#define VGPMP_E_SHAPE (-2)       /* dimension outside the supported range */
+#define VGPMP_E_WORKSPACE (-3)   /* workspace too small */
+
+typedef void* vgpmp_stream;      /* hipStream_t */
+
+/* Robot + likelihood constants: what utils/sampler.py:28-56 and likelihoods/likelihood.py:22-55
+ * keep (DH table, twist, convention, base pose, frame of each sphere, sphere offsets and radii,
+ * sigma_obs per sphere, epsilon, joint limits, scene offset).  Plain host struct; upload it with
+ * vgpmp_robot_upload and pass the device copy to the kernels. */
+typedef struct vgpmp_robot {
+    int32_t dof;
+    int32_t num_spheres;
+    int32_t craig;                         /* 1 = modified (Craig) DH, 0 = classic */
+    int32_t reserved;
+    float dh_d[VGPMP_MAX_DOF];
+    float dh_a[VGPMP_MAX_DOF];
+    float cos_alpha[VGPMP_MAX_DOF];        /* cos/sin of the constant link twists (float64 -> float32) */
+    float sin_alpha[VGPMP_MAX_DOF];
+    float twist[VGPMP_MAX_DOF];
+    float low[VGPMP_MAX_DOF];
+    float high[VGPMP_MAX_DOF];
+    float base[12];                        /* base pose, 3x4 row major */
+    int32_t sphere_frame[VGPMP_MAX_SPHERES]; /* frame (0..dof) of each sphere, non-decreasing */
+    float sphere_off[VGPMP_MAX_SPHERES][3];
+    float radius[VGPMP_MAX_SPHERES];
+    float sigma_obs[VGPMP_MAX_SPHERES];
+    float epsilon;
+    float reserved2;
+    double scene_offset[3];                /* subtracted from sphere centres before the lookup */
+} vgpmp_robot;
+
+/* Signed distance field prepared by vgpmp_sdf_pack: one float4 {d, gx, gy, gz} per voxel,
+ * index (x*ny + y)*nz + z  (the reference's data[x, y, z], utils/sdf_utils.py:25-33). */
+typedef struct vgpmp_sdf {
+    const void* table;                     /* dev float4[nx*ny*nz] */
+    int32_t nx, ny, nz, reserved;
+    double origin[3];
+    double delta;
+} vgpmp_sdf;
+
+/* Problem-batch dimensions. */
+typedef struct vgpmp_dims {
+    int32_t num_problems;
+    int32_t S;             /* Monte-Carlo samples handled by this rank */
+    int32_t S_total;       /* samples over all ranks (== S unless the sample axis is sharded) */
+    int32_t N;             /* time points */
+    int32_t M;             /* trainable inducing points (Mz = M + 2) */
+    int32_t L;             /* latent GPs == dof */
+    int32_t B;             /* Fourier bases, multiple of 16 */
+    int32_t split_k;       /* K-slices of the prior GEMM (1, 2, 4 or 8) */
+} vgpmp_dims;
+
+/* Variational + kernel parameters in UNCONSTRAINED space, float64, with their Adam moments
+ * (models/vgpmp.py:255-263, utils/miscellaneous.py:324-343).  q_sqrt keeps the M x M lower
+ * triangle per latent (FillTriangular is a fixed permutation of these entries). */
+typedef struct vgpmp_params {
+    double* q_mu;          /* dev [P, L, M]       */
+    double* q_sqrt;        /* dev [P, L, M, M]    */
+    double* raw_ell;       /* dev [P, L]  lengthscale = softplus(raw)        */
+    double* raw_var;       /* dev [P, L]  variance = 0.1 + softplus(raw)     */
+} vgpmp_params;
+
+/* Injected randomness of one ELBO evaluation (float32).  Same layout the generator fills. */
+typedef struct vgpmp_noise {
+    float* omega;          /* dev [P, L, B, D]  Student-t spectral frequencies  */
+    float* beta;           /* dev [P, L, B]     phases U(0, 2 pi)               */
+    float* w;              /* dev [P, S, L, B]  prior weights N(0,1)            */
+    float* eps;            /* dev [P, S, Mz, L] N(0,1) for u = q_mu + q_sqrt eps */
+    float* eps2;           /* dev [P, S, Mz, L] N(0,1) jitter perturbation      */
+} vgpmp_noise;
+
+typedef struct vgpmp_problem {
+    const double* X;       /* dev [N, D]   time grid (utils/miscellaneous.py:115-127)        */
+    const double* Zy;      /* dev [Mz, D]  conditioned + inducing times (inducing_variables.py:73-82) */
+    const double* y_u;     /* dev [P, 2, L] start/goal in unconstrained space (vgpmp.py:75-76) */
+    double alpha;          /* likelihood temperature (vgpmp.py:82) */
+    double jitter;         /* 1e-6 */
+    double kl_scale;       /* 1 on the rank that owns the KL term, 0 elsewhere */
+} vgpmp_problem;
+
+/* Outputs of an ELBO evaluation. */
+typedef struct vgpmp_outputs {
+    float* f;              /* dev [P, S, L, N]  latent paths (before the joint sigmoid)    */
+    float* logp;           /* dev [P, S, N]     log p(e|f) per sample and time             */
+    double* lik;           /* dev [P]           alpha/S_total * sum_{s,n} logp             */
+    double* kl;            /* dev [P]           KL(q||p) * kl_scale                         */
+    vgpmp_params grad;     /* dev, gradient of loss = -(lik - kl) wrt the unconstrained variables */
+} vgpmp_outputs;
+
+#define VGPMP_TRAIN_Q_MU 1
+#define VGPMP_TRAIN_Q_SQRT 2
+#define VGPMP_TRAIN_LENGTHSCALES 4
+#define VGPMP_TRAIN_KERNEL_VARIANCE 8
+
+#define VGPMP_DO_FORWARD 1      /* ELBO forward only (models/vgpmp.py:265-289)               */
+#define VGPMP_DO_BACKWARD 2     /* + gradient of -ELBO (utils/miscellaneous.py:77-80)        */
+#define VGPMP_DO_ADAM 4         /* + Adam.apply_gradients (utils/miscellaneous.py:82)        */
+#define VGPMP_GEN_NOISE 8       /* draw the noise with the device Philox generator first     */
+
+/* ---- set-up -------------------------------------------------------------------------------- */
+
+/* Copies the host struct to device memory (`dev_robot` has sizeof(vgpmp_robot) bytes). */
+int vgpmp_robot_upload(const vgpmp_robot* host_robot, void* dev_robot, vgpmp_stream stream);
+
+/* Builds the per-voxel {d, gx, gy, gz} table from a float64 grid data[x,y,z] on the device:
+ * clamped central differences with exact zeros replaced by 0.1 (utils/sdf_utils.py:100-136). */
+int vgpmp_sdf_pack(const double* dev_grid, int32_t nx, int32_t ny, int32_t nz, double delta,
+                   void* dev_table, vgpmp_stream stream);
+
+/* ---- stand-alone pieces (parity tests, debugging) ------------------------------------------ */
+
+/* Sampler.forward_kinematics_cost (utils/sampler.py:216-235): q [n, dof] -> sphere centres
+ * pos [n, P, 3]; optional frames [n, dof+1, 12] (3x4 row major) of forward_kinematics (:103-120). */
+int vgpmp_fk_spheres(const vgpmp_robot* dev_robot, const float* dev_q, int64_t n,
+                     float* dev_pos, float* dev_frames, vgpmp_stream stream);
+
+/* SignedDistanceField.get_distance_tf / get_distance_grad_tf (utils/sdf_utils.py:62-136) on
+ * positions already relative to the scene: idx [n,3] int32, dist [n], grad [n,3] (any may be NULL). */
+int vgpmp_sdf_query(const vgpmp_sdf* sdf, const double* dev_rel_pos, int64_t n,
+                    int32_t* dev_idx, float* dev_dist, float* dev_grad, vgpmp_stream stream);
+
+/* VariationalMonteCarloLikelihood.log_prob (likelihoods/likelihood.py:57-176) on joint angles
+ * g [n, dof]: logp [n] and, if dev_dlogp_dg != NULL, its gradient [n, dof]. */
+int vgpmp_log_prob(const vgpmp_robot* dev_robot, int32_t dof, const vgpmp_sdf* sdf, const float* dev_g,
+                   int64_t n, float* dev_logp, float* dev_dlogp_dg, vgpmp_stream stream);
+
+/* ---- the ELBO step ------------------------------------------------------------------------- */
+
+int vgpmp_workspace_bytes(const vgpmp_dims* dims, size_t* bytes);
+
+/* Fills `noise` with the Philox-4x32-10 draws of (seed, problem index, step). */
+int vgpmp_generate_noise(const vgpmp_dims* dims, const vgpmp_noise* noise, uint32_t seed,
+                         uint32_t problem_base, uint32_t step, vgpmp_stream stream);
+
+/* One evaluation of VGPMP.elbo (models/vgpmp.py:265-289) for every problem of the batch and,
+ * depending on `what` (VGPMP_DO_*), its reverse pass and the Adam update of
+ * utils/miscellaneous.py:68-84.  `adam_t` is the 1-based step count after this update. */
+int vgpmp_elbo_step(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,
+                    const vgpmp_problem* problem, const vgpmp_params* params,
+                    const vgpmp_params* adam_m, const vgpmp_params* adam_v,
+                    const vgpmp_noise* noise, const vgpmp_outputs* out,
+                    void* dev_workspace, size_t workspace_bytes,
+                    int32_t what, int32_t trainable, double learning_rate, int32_t adam_t,
+                    uint32_t seed, uint32_t problem_base, uint32_t step, vgpmp_stream stream);
+
+/* Adam.apply_gradients alone (after an external all-reduce of out->grad when samples are sharded). */
+int vgpmp_adam_step(const vgpmp_dims* dims, const vgpmp_params* params, const vgpmp_params* grad,
+                    const vgpmp_params* adam_m, const vgpmp_params* adam_v, int32_t trainable,
+                    double learning_rate, int32_t adam_t, vgpmp_stream stream);
+
+/* Reads back intermediates of the last vgpmp_elbo_step from the workspace (parity tests):
+ * name in {"A","C","m","F0","H","R","G","Phi"}; returns pointer and element count. */
+int vgpmp_workspace_view(const vgpmp_dims* dims, void* dev_workspace, const char* name,
+                         void** dev_ptr, size_t* count, int32_t* is_double);
+
+const char* vgpmp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VGPMP_H */

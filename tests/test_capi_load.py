@@ -1,0 +1,51 @@
+"""CPU-side checks of the drop-in boundary: the shared library builds for gfx950, loads, and
+exports every entry point include/vgpmp.h declares (no compute call without a GPU)."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+from vgpmp_amd import build, capi
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_builds_loads_and_exports_header_symbols():
+    lib = build.build(force=False, verbose=False)
+    assert lib.exists()
+    handle = capi.load(require=True)
+    header = (ROOT / "include" / "vgpmp.h").read_text()
+    declared = set(re.findall(r"\b(vgpmp_[a-z_]+)\s*\(", header))
+    assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert b"gfx950" in handle.vgpmp_version()
+
+
+def test_struct_sizes_match_header_layout():
+    # sizes implied by include/vgpmp.h (natural alignment, 8-byte tail for the doubles)
+    assert ctypes.sizeof(capi.Robot) == 4 * 4 + 7 * 16 * 4 + 12 * 4 + 64 * 4 + 64 * 12 + 64 * 4 + 64 * 4 + 8 + 24
+    assert ctypes.sizeof(capi.Sdf) == 8 + 16 + 24 + 8
+    assert ctypes.sizeof(capi.Dims) == 32
+    assert ctypes.sizeof(capi.Params) == 32 and ctypes.sizeof(capi.Noise) == 40
+    assert ctypes.sizeof(capi.Problem) == 48 and ctypes.sizeof(capi.Outputs) == 64
+
+
+def test_argument_errors_without_gpu():
+    handle = capi.load(require=True)
+    n = ctypes.c_size_t(0)
+    bad = capi.Dims(1, 8, 8, 10, 70, 7, 64, 1)          # M + 2 > VGPMP_MAX_MZ
+    assert handle.vgpmp_workspace_bytes(ctypes.byref(bad), ctypes.byref(n)) == -2
+    bad = capi.Dims(1, 8, 8, 10, 5, 7, 60, 1)           # B not a multiple of 16
+    assert handle.vgpmp_workspace_bytes(ctypes.byref(bad), ctypes.byref(n)) == -2
+    ok = capi.Dims(1, 128, 128, 100, 30, 7, 1024, 4)
+    assert handle.vgpmp_workspace_bytes(ctypes.byref(ok), ctypes.byref(n)) == 0 and n.value > 0
+    assert handle.vgpmp_workspace_bytes(None, ctypes.byref(n)) == -1
+
+
+def test_product_path_fails_loudly_without_library(monkeypatch, tmp_path):
+    monkeypatch.setenv("VGPMP_HIP_LIB", str(tmp_path / "missing.so"))
+    monkeypatch.setattr(capi, "_lib", None)
+    with pytest.raises(capi.VgpmpError):
+        capi.load(require=True)

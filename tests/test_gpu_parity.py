@@ -1,0 +1,271 @@
+"""Parity of the HIP path (through the C ABI) with the float64 oracle.  Run with -m gpu on MI355X.
+
+Tolerances: integer voxel indices bit-exact on identical float64 inputs; float32 quantities within
+the tolerance written at each assertion.  The SDF is nearest-voxel (piecewise constant), so an
+end-to-end float32 path may land a handful of sphere queries in the neighbouring voxel; tests that
+go through float32 positions therefore bound the FRACTION of affected (sample, time) pairs instead
+of demanding every element.
+"""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vgpmp_oracle as orc
+from helpers import oracle_robot, oracle_scene, small_problem
+from vgpmp_amd import robots as rb
+from vgpmp_amd import scenes
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+def _engine():
+    from vgpmp_amd import engine
+    return engine
+
+
+def _scene(spec, grid, offset, sigma_obs=0.005, epsilon=0.05):
+    return _engine().DeviceScene(spec, grid, offset, sigma_obs=sigma_obs, epsilon=epsilon)
+
+
+POSES = {"franka": ((0, 0, 0), (0, 0, 0, 1)), "wam": ((0, 0, 0.346), (0, 0, 0, 1)),
+         "ur10": ((0, 0, 0), (0, 0, -1, 0)), "kuka": ((0.1, -0.2, 0.3), (0, 0, 0.38268343, 0.92387953))}
+
+
+@pytest.mark.parametrize("name", sorted(POSES))
+def test_fk_matches_reference_golden_and_oracle(name):
+    spec = rb.load_robot(name, *POSES[name])
+    grid = scenes.synthetic_boxes_sdf(n=8, delta=0.3, origin=(-1.2, -1.2, -1.2))
+    sc = _scene(spec, grid, (0, 0, 0))
+    z = np.load(GOLD / "fk_reference.npz")
+    q = z[f"{name}_q"]
+    pos, frames = sc.fk_spheres(torch.tensor(q), want_frames=True)
+    # float32 FK vs the reference's own float64 numpy FK (golden): abs 5e-6 m on a ~1 m arm
+    np.testing.assert_allclose(frames.cpu().numpy(), z[f"{name}_frames"][:, :, :3, :], atol=5e-6, rtol=0)
+    rng = np.random.default_rng(0)
+    q2 = rng.uniform(spec.low, spec.high, (257, spec.dof))
+    want = orc.sphere_positions(oracle_robot(spec), q2.astype(np.float32).astype(np.float64))
+    got = sc.fk_spheres(torch.tensor(q2, dtype=torch.float32)).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=5e-6, rtol=0)
+
+
+def test_sdf_indices_bit_exact_and_golden():
+    z = np.load(GOLD / "sdf_reference.npz")
+    spec = rb.load_robot("franka")
+    grid = (z["data"], z["origin"], float(z["delta"]))
+    sc = _scene(spec, grid, (0, 0, 0))
+    idx, dist, grad = sc.sdf_query(torch.tensor(z["pos"]))
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), z["idx"])          # reference numpy twin, bit-exact
+    assert np.array_equal(dist.cpu().numpy(), z["dist"].astype(np.float32))
+    want_g = np.where(z["grad"] == 0, 0.1, z["grad"]).astype(np.float32)
+    assert np.array_equal(grad.cpu().numpy(), want_g)
+    # a large random sweep against the oracle, including cell boundaries hit exactly
+    big = scenes.synthetic_boxes_sdf(n=40, delta=0.05, origin=(-1.0, -1.0, -1.0), seed=4)
+    sc2 = _scene(spec, big, (0, 0, 0))
+    rng = np.random.default_rng(1)
+    pos = rng.uniform(-1.3, 1.3, (200000, 3))
+    pos[:5000] = -1.0 + 0.05 * rng.integers(-2, 43, (5000, 3))                    # exact lattice points
+    og = orc.SDFGrid(*big)
+    idx2, dist2, grad2 = sc2.sdf_query(torch.tensor(pos))
+    assert np.array_equal(idx2.cpu().numpy().astype(np.int64), orc.sdf_index(og, pos))
+    assert np.array_equal(dist2.cpu().numpy(), orc.sdf_distance(og, pos).astype(np.float32))
+    assert np.array_equal(grad2.cpu().numpy(), orc.sdf_gradient(og, pos).astype(np.float32))
+
+
+@pytest.mark.parametrize("name,problem", [("franka", "industrial"), ("wam", "industrial"), ("ur10", "industrial")])
+def test_log_prob_and_gradient(name, problem):
+    ps = rb.load_problemset(name, problem)
+    spec = rb.load_robot(name, *ps.robot_pos_and_orn)
+    grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
+    off = ps.object_positions[0]
+    sc = _scene(spec, grid, off)
+    osc = oracle_scene(spec, grid, off)
+    rng = np.random.default_rng(2)
+    g = rng.uniform(spec.low, spec.high, (4096, spec.dof)).astype(np.float32)
+    logp, dl = sc.log_prob(torch.tensor(g), want_grad=True)
+    want_lp, want_dl = orc.log_prob(osc, g.astype(np.float64), want_grad=True)
+    logp, dl = logp.cpu().numpy(), dl.cpu().numpy()
+    assert (want_lp < 0).mean() > 0.2, "scene must put spheres inside the hinge band"
+    ok = np.isclose(logp, want_lp, rtol=2e-4, atol=1e-5)
+    assert ok.mean() > 0.995, f"only {ok.mean():.4f} of configurations agree"       # voxel flips are rare
+    scale = np.abs(want_dl).max(axis=1, keepdims=True) + 1e-6
+    okg = (np.abs(dl - want_dl) / scale).max(axis=1) < 5e-4
+    assert (okg | ~ok).mean() > 0.995
+    # forward-only entry gives the same values
+    lp2 = sc.log_prob(torch.tensor(g)).cpu().numpy()
+    assert np.array_equal(lp2, logp)
+
+
+def _planner(pb, sc, S, N, M, B, split_k=None, trainable=None):
+    eng = _engine()
+    pp = dict(num_samples=S, num_inducing=M, num_data=N, num_bases=B, alpha=pb["alpha"], learning_rate=pb["lr"])
+    ps = rb.load_problemset(pb["spec"].name if pb["spec"].name in rb.AVAILABLE_ROBOTS else "franka", "industrial")
+    pl = eng.PlannerBatch(sc, pb["y"][None], lengthscales=ps.planner_params["lengthscales"],
+                          variance=ps.planner_params["variance"], split_k=split_k, trainable=trainable, **pp)
+    p = pb["params"]
+    pl.q_mu.copy_(torch.tensor(p.q_mu.T[None]))
+    pl.q_sqrt.copy_(torch.tensor(p.q_sqrt[None]))
+    pl.raw_ell.copy_(torch.tensor(p.raw_ell[None]))
+    pl.raw_var.copy_(torch.tensor(p.raw_var[None]))
+    return pl
+
+
+def _inject(pl, noise):
+    pl.set_noise(noise.omega[None], noise.beta[None], noise.w[None], noise.eps[None], noise.eps2[None])
+
+
+def _noise32(noise):
+    r = lambda a: a.astype(np.float32).astype(np.float64)
+    return orc.Noise(r(noise.omega), r(noise.beta), r(noise.w), r(noise.eps), r(noise.eps2))
+
+
+@pytest.mark.parametrize("robot,S,N,M,B,split_k", [("franka", 6, 9, 5, 64, 1), ("franka", 37, 50, 10, 256, 4),
+                                                    ("wam", 20, 33, 12, 128, 2), ("ur10", 16, 20, 6, 64, 1)])
+def test_elbo_forward_backward_against_oracle(robot, S, N, M, B, split_k):
+    pb = small_problem(robot=robot, S=S, N=N, M=M, B=B, seed=11, n_grid=48)
+    sc = _scene(pb["spec"], pb["grid"], pb["offset"])
+    pl = _planner(pb, sc, S, N, M, B, split_k=split_k)
+    noise = _noise32(pb["noise"])
+    _inject(pl, noise)
+    loss, grads = pl.loss_and_grad(generate=False)
+    fw = orc.elbo_forward(pb["params"], pb["scene"], pb["X"], pb["Zy"], pb["y"], noise, pb["alpha"])
+    og, G = orc.elbo_backward(pb["params"], pb["scene"], pb["X"], pb["Zy"], noise, pb["alpha"], fw)
+    L, Mz, J = pb["spec"].dof, M + 2, N + M + 2
+    cv = fw["cv"]
+    # covariance path is float64 on the device, rounded to float32 at the hand-over
+    np.testing.assert_allclose(pl.view("A").reshape(L, N, Mz).cpu().numpy(), cv["A"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(pl.view("C").reshape(L, Mz, Mz).cpu().numpy(), cv["C"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(pl.view("Kinv").reshape(L, Mz, Mz).cpu().numpy(), cv["Kinv"], rtol=1e-6, atol=1e-3)
+    np.testing.assert_allclose(pl.view("kl_l").cpu().numpy().sum(), cv["kl"], rtol=1e-9)
+    F0 = pl.view("F0").reshape(split_k, S, L, J).sum(0).cpu().numpy()
+    np.testing.assert_allclose(F0, fw["F0"], rtol=0, atol=2e-5 * np.abs(fw["F0"]).max())
+    H = pl.view("H").reshape(split_k, S, L, J).sum(0).cpu().numpy()
+    np.testing.assert_allclose(H, fw["H"], rtol=0, atol=2e-5 * (np.abs(fw["H"]).max() + 1e-9))
+    np.testing.assert_allclose(pl.view("R").reshape(S, L, Mz).cpu().numpy(), fw["R"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(pl.f[0].cpu().numpy(), fw["f"], rtol=0, atol=1e-4)
+    logp = pl.logp[0].cpu().numpy()
+    assert (fw["logp"] < 0).any()
+    ok = np.isclose(logp, fw["logp"], rtol=2e-3, atol=1e-4)
+    assert ok.mean() >= 0.97, f"logp agreement {ok.mean():.3f}"
+    if ok.all():
+        # no voxel flips: the end-to-end numbers must agree to float32 accuracy
+        np.testing.assert_allclose(float(pl.kl[0]), cv["kl"], rtol=1e-9)
+        np.testing.assert_allclose(float(pl.lik[0]), fw["lik"], rtol=2e-4)
+        np.testing.assert_allclose(float(loss[0]), -fw["elbo"], rtol=2e-4)
+        for got, name in zip(grads, ("q_mu", "q_sqrt", "raw_ell", "raw_var")):
+            want = getattr(og, name)
+            got = got[0].cpu().numpy()
+            if name == "q_mu":
+                got = got.T
+            scale = np.abs(want).max() + 1e-12
+            assert np.abs(got - want).max() / scale < 3e-3, (name, np.abs(got - want).max(), scale)
+
+
+def test_kl_only_gradient_is_float64_exact():
+    """With alpha = 0 the likelihood drops out and the whole reverse pass is the float64 covariance
+    path: gradients must match the oracle to 1e-9 relative."""
+    pb = small_problem(robot="franka", S=4, N=7, M=9, B=32, seed=5, n_grid=24)
+    pb["alpha"] = 0.0
+    sc = _scene(pb["spec"], pb["grid"], pb["offset"])
+    pl = _planner(pb, sc, 4, 7, 9, 32, split_k=1)
+    noise = _noise32(pb["noise"])
+    _inject(pl, noise)
+    loss, grads = pl.loss_and_grad(generate=False)
+    fw = orc.elbo_forward(pb["params"], pb["scene"], pb["X"], pb["Zy"], pb["y"], noise, 0.0)
+    og, _ = orc.elbo_backward(pb["params"], pb["scene"], pb["X"], pb["Zy"], noise, 0.0, fw)
+    np.testing.assert_allclose(float(loss[0]), fw["cv"]["kl"], rtol=1e-10)
+    np.testing.assert_allclose(grads[0][0].cpu().numpy().T, og.q_mu, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(grads[1][0].cpu().numpy(), og.q_sqrt, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(grads[2][0].cpu().numpy(), og.raw_ell, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(grads[3][0].cpu().numpy(), og.raw_var, rtol=1e-6, atol=1e-9)
+
+
+def test_adam_trajectory_matches_oracle():
+    """Five optimisation steps with injected noise: parameters track the oracle's Keras-Adam."""
+    S, N, M, B = 8, 12, 6, 64
+    pb = small_problem(robot="franka", S=S, N=N, M=M, B=B, seed=7, n_grid=48)
+    sc = _scene(pb["spec"], pb["grid"], pb["offset"])
+    pl = _planner(pb, sc, S, N, M, B, split_k=1)
+    p = pb["params"].copy(); st = orc.adam_init(p)
+    rng = np.random.default_rng(3)
+    for step in range(5):
+        noise = _noise32(orc.draw_noise(rng, S, 7, 7, B, M + 2))
+        _inject(pl, noise)
+        pl.step(generate=False)
+        orc.optimization_step(p, st, pb["scene"], pb["X"], pb["Zy"], pb["y"], noise, pb["alpha"], pb["lr"])
+    # Adam normalises the gradient, so a float32-level gradient difference moves a parameter by
+    # ~lr * 1e-3 per step at most; anything larger is a real disagreement.
+    tol = 5 * pb["lr"] * 2e-2
+    assert np.abs(pl.q_mu[0].cpu().numpy().T - p.q_mu).max() < tol
+    assert np.abs(pl.q_sqrt[0].cpu().numpy() - p.q_sqrt).max() < tol
+    assert np.abs(pl.raw_ell[0].cpu().numpy() - p.raw_ell).max() < tol
+    assert np.abs(pl.raw_var[0].cpu().numpy() - p.raw_var).max() < tol
+
+
+def test_device_philox_matches_oracle_stream():
+    S, N, M, B = 5, 6, 4, 32
+    pb = small_problem(robot="franka", S=S, N=N, M=M, B=B, seed=1, n_grid=16)
+    sc = _scene(pb["spec"], pb["grid"], pb["offset"])
+    eng = _engine()
+    pl = eng.PlannerBatch(sc, np.stack([pb["y"], pb["y"][::-1]]), num_samples=S, num_inducing=M, num_data=N,
+                          num_bases=B, lengthscales=[2.0] * 7, variance=0.2, seed=123, problem_base=40)
+    pl.generate_noise(step=9)
+    for p in range(2):
+        nz = orc.philox_noise(123, 40 + p, 9, S, 7, 7, B, M + 2)
+        np.testing.assert_allclose(pl.w[p].cpu().numpy(), nz.w, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(pl.eps[p].cpu().numpy(), nz.eps, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(pl.eps2[p].cpu().numpy(), nz.eps2, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(pl.beta[p].cpu().numpy(), nz.beta, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(pl.omega[p].cpu().numpy(), nz.omega, rtol=2e-4, atol=2e-5)
+
+
+def test_problem_batch_is_independent_and_generated_noise_runs():
+    """Three problems in one batch: each equals the same problem solved alone (no cross-talk)."""
+    S, N, M, B = 8, 10, 5, 64
+    ps = rb.load_problemset("franka", "industrial")
+    spec = rb.load_robot("franka")
+    grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
+    sc = _scene(spec, grid, ps.object_positions[0])
+    qs = np.array([[ps.states[0], ps.states[1]], [ps.states[2], ps.states[3]], [ps.states[4], ps.states[6]]])
+    eng = _engine()
+    kw = dict(num_samples=S, num_inducing=M, num_data=N, num_bases=B, lengthscales=[2.0] * 7, variance=0.2, seed=5)
+    batch = eng.PlannerBatch(sc, qs, **kw)
+    for _ in range(3):
+        batch.step()
+    for p in range(3):
+        solo = eng.PlannerBatch(sc, qs[p:p + 1], problem_base=p, **kw)
+        for _ in range(3):
+            solo.step()
+        assert torch.equal(solo.q_mu[0], batch.q_mu[p]) and torch.equal(solo.q_sqrt[0], batch.q_sqrt[p])
+        assert torch.equal(solo.raw_ell[0], batch.raw_ell[p])
+    assert torch.isfinite(batch.elbo()).all()
+
+
+def test_full_size_properties():
+    """BASELINE config 2 shape (S=128, M=30, N=100, B=1024): size-independent properties --
+    deterministic replay, finite outputs, KL non-negative, loss decreases over 30 steps."""
+    ps = rb.load_problemset("franka", "industrial")
+    spec = rb.load_robot("franka")
+    grid = scenes.synthetic_boxes_sdf(n=128, delta=0.0125, origin=(-0.8, -0.8, -0.2), seed=0)
+    sc = _scene(spec, grid, ps.object_positions[0])
+    eng = _engine()
+    kw = dict(num_samples=128, num_inducing=30, num_data=100, num_bases=1024, lengthscales=[2.0] * 7, variance=0.2,
+              learning_rate=0.02, seed=1)
+    q = np.array([[ps.states[0], ps.states[1]]])
+    a = eng.PlannerBatch(sc, q, **kw)
+    b = eng.PlannerBatch(sc, q, **kw)
+    l0 = float(-a.elbo(step=10**6)[0])
+    for _ in range(30):
+        a.step(); b.step()
+    assert torch.equal(a.q_mu, b.q_mu) and torch.equal(a.q_sqrt, b.q_sqrt)     # bitwise replay
+    l1 = float(-a.elbo(step=10**6)[0])
+    assert np.isfinite([l0, l1]).all() and float(a.kl[0]) >= 0.0
+    assert l1 < l0
+    g = a.samples()
+    lo, hi = torch.tensor(spec.low, device=g.device), torch.tensor(spec.high, device=g.device)
+    assert bool(((g >= lo) & (g <= hi)).all())
+    # paths are pinned to start/goal by the 1e-6 conditioning: sample spread at t=0 and t=1 is tiny
+    y = torch.tensor(q[0], device=g.device, dtype=g.dtype)
+    assert float((g[0, :, 0, :] - y[0]).abs().max()) < 5e-2 and float((g[0, :, -1, :] - y[1]).abs().max()) < 5e-2

@@ -1,0 +1,156 @@
+"""ctypes binding of libvgpmp_hip.so (include/vgpmp.h).
+
+PyTorch-ROCm tensors are only the memory container: every wrapper hands raw device pointers
+and sizes to the C ABI on torch's current HIP stream.  There is NO fallback: if the library is
+missing or cannot be loaded, importing the compute path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+
+MAX_DOF, MAX_SPHERES, MAX_MZ = 16, 64, 64
+TRAIN_Q_MU, TRAIN_Q_SQRT, TRAIN_LENGTHSCALES, TRAIN_KERNEL_VARIANCE = 1, 2, 4, 8
+DO_FORWARD, DO_BACKWARD, DO_ADAM, GEN_NOISE = 1, 2, 4, 8
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvgpmp_hip.so"
+
+EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_pack", "vgpmp_fk_spheres", "vgpmp_sdf_query",
+           "vgpmp_log_prob", "vgpmp_workspace_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
+           "vgpmp_adam_step", "vgpmp_workspace_view")
+
+
+class VgpmpError(RuntimeError):
+    pass
+
+
+class Robot(C.Structure):
+    _fields_ = [("dof", C.c_int32), ("num_spheres", C.c_int32), ("craig", C.c_int32), ("reserved", C.c_int32),
+                ("dh_d", C.c_float * MAX_DOF), ("dh_a", C.c_float * MAX_DOF),
+                ("cos_alpha", C.c_float * MAX_DOF), ("sin_alpha", C.c_float * MAX_DOF),
+                ("twist", C.c_float * MAX_DOF), ("low", C.c_float * MAX_DOF), ("high", C.c_float * MAX_DOF),
+                ("base", C.c_float * 12), ("sphere_frame", C.c_int32 * MAX_SPHERES),
+                ("sphere_off", (C.c_float * 3) * MAX_SPHERES), ("radius", C.c_float * MAX_SPHERES),
+                ("sigma_obs", C.c_float * MAX_SPHERES), ("epsilon", C.c_float), ("reserved2", C.c_float),
+                ("scene_offset", C.c_double * 3)]
+
+
+class Sdf(C.Structure):
+    _fields_ = [("table", C.c_void_p), ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
+                ("reserved", C.c_int32), ("origin", C.c_double * 3), ("delta", C.c_double)]
+
+
+class Dims(C.Structure):
+    _fields_ = [("num_problems", C.c_int32), ("S", C.c_int32), ("S_total", C.c_int32), ("N", C.c_int32),
+                ("M", C.c_int32), ("L", C.c_int32), ("B", C.c_int32), ("split_k", C.c_int32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("q_mu", C.c_void_p), ("q_sqrt", C.c_void_p), ("raw_ell", C.c_void_p), ("raw_var", C.c_void_p)]
+
+
+class Noise(C.Structure):
+    _fields_ = [("omega", C.c_void_p), ("beta", C.c_void_p), ("w", C.c_void_p), ("eps", C.c_void_p),
+                ("eps2", C.c_void_p)]
+
+
+class Problem(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("Zy", C.c_void_p), ("y_u", C.c_void_p), ("alpha", C.c_double),
+                ("jitter", C.c_double), ("kl_scale", C.c_double)]
+
+
+class Outputs(C.Structure):
+    _fields_ = [("f", C.c_void_p), ("logp", C.c_void_p), ("lik", C.c_void_p), ("kl", C.c_void_p), ("grad", Params)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def library_path() -> Path:
+    return Path(os.environ.get("VGPMP_HIP_LIB", str(LIB_PATH)))
+
+
+def load(require: bool = True) -> Optional[C.CDLL]:
+    """Loads the shared library.  With require=True (the product path) a missing library is fatal."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not path.exists():
+        if require:
+            raise VgpmpError(f"{path} not found: build it with `python -m vgpmp_amd.build` "
+                             "(the HIP path has no CPU fallback)")
+        return None
+    lib = C.CDLL(str(path))
+    lib.vgpmp_version.restype = C.c_char_p
+    P = C.POINTER
+    vp, i32, i64, u32, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_double
+    sigs = {
+        "vgpmp_robot_upload": [P(Robot), vp, vp],
+        "vgpmp_sdf_pack": [vp, i32, i32, i32, dbl, vp, vp],
+        "vgpmp_fk_spheres": [vp, vp, i64, vp, vp, vp],
+        "vgpmp_sdf_query": [P(Sdf), vp, i64, vp, vp, vp, vp],
+        "vgpmp_log_prob": [vp, i32, P(Sdf), vp, i64, vp, vp, vp],
+        "vgpmp_workspace_bytes": [P(Dims), P(C.c_size_t)],
+        "vgpmp_generate_noise": [P(Dims), P(Noise), u32, u32, u32, vp],
+        "vgpmp_elbo_step": [P(Dims), vp, P(Sdf), P(Problem), P(Params), P(Params), P(Params), P(Noise), P(Outputs),
+                            vp, C.c_size_t, i32, i32, dbl, i32, u32, u32, u32, vp],
+        "vgpmp_adam_step": [P(Dims), P(Params), P(Params), P(Params), P(Params), i32, dbl, i32, vp],
+        "vgpmp_workspace_view": [P(Dims), vp, C.c_char_p, P(vp), P(C.c_size_t), P(i32)],
+    }
+    for name, args in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    names = {-1: "VGPMP_E_ARG", -2: "VGPMP_E_SHAPE", -3: "VGPMP_E_WORKSPACE"}
+    if rc < 0:
+        raise ValueError(f"{what}: {names.get(rc, rc)}")
+    raise VgpmpError(f"{what}: hipError_t {rc}")
+
+
+def make_robot(spec, sigma_obs, epsilon: float, scene_offset) -> Robot:
+    """RobotSpec (+ likelihood constants) -> the POD of include/vgpmp.h."""
+    D, P = spec.dof, spec.num_spheres
+    if D > MAX_DOF or P > MAX_SPHERES:
+        raise ValueError(f"robot {spec.name}: dof {D} / spheres {P} beyond {MAX_DOF}/{MAX_SPHERES}")
+    r = Robot()
+    r.dof, r.num_spheres, r.craig = D, P, int(bool(spec.craig))
+    for i in range(D):
+        r.dh_d[i], r.dh_a[i] = float(spec.dh[i, 0]), float(spec.dh[i, 1])
+        r.cos_alpha[i], r.sin_alpha[i] = float(np.cos(spec.dh[i, 2])), float(np.sin(spec.dh[i, 2]))
+        r.twist[i] = float(spec.twist[i])
+        r.low[i], r.high[i] = float(spec.low[i]), float(spec.high[i])
+    for i, v in enumerate(np.asarray(spec.base_pose)[:3, :].reshape(-1)):
+        r.base[i] = float(v)
+    frames = spec.sphere_frame
+    sig = np.broadcast_to(np.asarray(sigma_obs, dtype=np.float64), (P,))
+    for p in range(P):
+        r.sphere_frame[p] = int(frames[p])
+        for k in range(3):
+            r.sphere_off[p][k] = float(spec.sphere_offsets[p, k])
+        r.radius[p] = float(spec.sphere_radii[p])
+        r.sigma_obs[p] = float(sig[p])
+    r.epsilon = float(epsilon)
+    for k in range(3):
+        r.scene_offset[k] = float(scene_offset[k])
+    return r
+
+
+def stream_ptr() -> int:
+    import torch
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t) -> Optional[int]:
+    return None if t is None else int(t.data_ptr())

@@ -1,0 +1,121 @@
+// extern "C" entry points of libvgpmp_hip.so (see include/vgpmp.h for the contract).
+#include "vgpmp_device.h"
+#include "gp_path.h"
+
+extern "C" {
+
+const char* vgpmp_version(void) { return "vgpmp-hip 0.1 (gfx950)"; }
+
+int vgpmp_robot_upload(const vgpmp_robot* host_robot, void* dev_robot, vgpmp_stream stream) {
+    if (!host_robot || !dev_robot) return VGPMP_E_ARG;
+    if (host_robot->dof < 1 || host_robot->dof > VGPMP_MAX_DOF || host_robot->num_spheres < 0 ||
+        host_robot->num_spheres > VGPMP_MAX_SPHERES)
+        return VGPMP_E_SHAPE;
+    for (int p = 1; p < host_robot->num_spheres; ++p)
+        if (host_robot->sphere_frame[p] < host_robot->sphere_frame[p - 1]) return VGPMP_E_ARG;
+    for (int p = 0; p < host_robot->num_spheres; ++p)
+        if (host_robot->sphere_frame[p] < 0 || host_robot->sphere_frame[p] > host_robot->dof) return VGPMP_E_ARG;
+    VG_CHECK_HIP(hipMemcpyAsync(dev_robot, host_robot, sizeof(vgpmp_robot), hipMemcpyHostToDevice, (hipStream_t)stream));
+    // the host struct may be a temporary of the caller: make the copy complete before returning
+    VG_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int vgpmp_sdf_pack(const double* dev_grid, int32_t nx, int32_t ny, int32_t nz, double delta, void* dev_table,
+                   vgpmp_stream stream) {
+    if (!dev_grid || !dev_table) return VGPMP_E_ARG;
+    if (nx < 1 || ny < 1 || nz < 1 || !(delta > 0.0)) return VGPMP_E_SHAPE;
+    return vg_launch_sdf_pack(dev_grid, nx, ny, nz, delta, (float4*)dev_table, (hipStream_t)stream);
+}
+
+int vgpmp_fk_spheres(const vgpmp_robot* dev_robot, const float* dev_q, int64_t n, float* dev_pos, float* dev_frames,
+                     vgpmp_stream stream) {
+    if (!dev_robot || (!dev_q && n > 0) || n < 0) return VGPMP_E_ARG;
+    return vg_launch_fk_spheres(dev_robot, dev_q, n, dev_pos, dev_frames, (hipStream_t)stream);
+}
+
+static int check_sdf(const vgpmp_sdf* sdf) {
+    if (!sdf || !sdf->table) return VGPMP_E_ARG;
+    if (sdf->nx < 1 || sdf->ny < 1 || sdf->nz < 1 || !(sdf->delta > 0.0)) return VGPMP_E_SHAPE;
+    return 0;
+}
+
+int vgpmp_sdf_query(const vgpmp_sdf* sdf, const double* dev_rel_pos, int64_t n, int32_t* dev_idx, float* dev_dist,
+                    float* dev_grad, vgpmp_stream stream) {
+    int rc = check_sdf(sdf);
+    if (rc) return rc;
+    if ((!dev_rel_pos && n > 0) || n < 0) return VGPMP_E_ARG;
+    return vg_launch_sdf_query(sdf, dev_rel_pos, n, dev_idx, dev_dist, dev_grad, (hipStream_t)stream);
+}
+
+int vgpmp_log_prob(const vgpmp_robot* dev_robot, int32_t dof, const vgpmp_sdf* sdf, const float* dev_g, int64_t n,
+                   float* dev_logp, float* dev_dlogp_dg, vgpmp_stream stream) {
+    int rc = check_sdf(sdf);
+    if (rc) return rc;
+    if (!dev_robot || (!dev_g && n > 0) || (!dev_logp && n > 0) || n < 0) return VGPMP_E_ARG;
+    if (dof < 1 || dof > VGPMP_MAX_DOF) return VGPMP_E_SHAPE;
+    return vg_launch_log_prob_impl(dev_robot, dof, sdf, dev_g, n, dev_logp, dev_dlogp_dg, (hipStream_t)stream);
+}
+
+int vgpmp_workspace_bytes(const vgpmp_dims* dims, size_t* bytes) {
+    if (!dims || !bytes) return VGPMP_E_ARG;
+    int rc = vg_check_dims(dims);
+    if (rc) return rc;
+    vg_workspace ws;
+    *bytes = vg_layout_workspace(dims, nullptr, &ws);
+    return 0;
+}
+
+int vgpmp_generate_noise(const vgpmp_dims* dims, const vgpmp_noise* noise, uint32_t seed, uint32_t problem_base,
+                         uint32_t step, vgpmp_stream stream) {
+    if (!dims || !noise || !noise->omega || !noise->beta || !noise->w || !noise->eps || !noise->eps2) return VGPMP_E_ARG;
+    int rc = vg_check_dims(dims);
+    if (rc) return rc;
+    return vg_launch_rng(dims, noise, seed, problem_base, step, (hipStream_t)stream);
+}
+
+int vgpmp_elbo_step(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,
+                    const vgpmp_problem* problem, const vgpmp_params* params, const vgpmp_params* adam_m,
+                    const vgpmp_params* adam_v, const vgpmp_noise* noise, const vgpmp_outputs* out,
+                    void* dev_workspace, size_t workspace_bytes, int32_t what, int32_t trainable,
+                    double learning_rate, int32_t adam_t, uint32_t seed, uint32_t problem_base, uint32_t step,
+                    vgpmp_stream stream) {
+    if (!dims || !dev_robot || !problem || !params || !noise || !out || !dev_workspace) return VGPMP_E_ARG;
+    int rc = vg_check_dims(dims);
+    if (rc) return rc;
+    rc = check_sdf(sdf);
+    if (rc) return rc;
+    if (!problem->X || !problem->Zy || !problem->y_u) return VGPMP_E_ARG;
+    if (!params->q_mu || !params->q_sqrt || !params->raw_ell || !params->raw_var) return VGPMP_E_ARG;
+    if (!out->f || !out->logp || !out->lik || !out->kl) return VGPMP_E_ARG;
+    if ((what & VGPMP_DO_BACKWARD) &&
+        (!out->grad.q_mu || !out->grad.q_sqrt || !out->grad.raw_ell || !out->grad.raw_var))
+        return VGPMP_E_ARG;
+    if ((what & VGPMP_DO_ADAM) && (!(what & VGPMP_DO_BACKWARD) || !adam_m || !adam_v || adam_t < 1)) return VGPMP_E_ARG;
+    vg_workspace ws;
+    size_t need = vg_layout_workspace(dims, dev_workspace, &ws);
+    if (workspace_bytes < need) return VGPMP_E_WORKSPACE;
+    return vg_elbo_step(dims, dev_robot, sdf, problem, params, adam_m, adam_v, noise, out, &ws, what, trainable,
+                        learning_rate, adam_t, seed, problem_base, step, (hipStream_t)stream);
+}
+
+int vgpmp_adam_step(const vgpmp_dims* dims, const vgpmp_params* params, const vgpmp_params* grad,
+                    const vgpmp_params* adam_m, const vgpmp_params* adam_v, int32_t trainable, double learning_rate,
+                    int32_t adam_t, vgpmp_stream stream) {
+    if (!dims || !params || !grad || !adam_m || !adam_v || adam_t < 1) return VGPMP_E_ARG;
+    int rc = vg_check_dims(dims);
+    if (rc) return rc;
+    return vg_launch_adam(dims, params, grad, adam_m, adam_v, trainable, learning_rate, adam_t, (hipStream_t)stream);
+}
+
+int vgpmp_workspace_view(const vgpmp_dims* dims, void* dev_workspace, const char* name, void** dev_ptr, size_t* count,
+                         int32_t* is_double) {
+    if (!dims || !dev_workspace || !name || !dev_ptr || !count || !is_double) return VGPMP_E_ARG;
+    int rc = vg_check_dims(dims);
+    if (rc) return rc;
+    vg_workspace ws;
+    vg_layout_workspace(dims, dev_workspace, &ws);
+    return vg_workspace_lookup(dims, &ws, name, dev_ptr, count, is_double);
+}
+
+}  // extern "C"

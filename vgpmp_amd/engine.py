@@ -1,0 +1,261 @@
+"""Batched planning engine over the C ABI: device-resident scene (robot + voxel table) and a batch
+of independent start-goal problems with their variational parameters, Adam state, noise buffers
+and workspace.  Host logic only (allocation, argument packing, step counter); all arithmetic of
+the ELBO step runs in libvgpmp_hip.so.
+
+Reference roles: `DeviceScene` ~ the (Sampler, SignedDistanceField, likelihood constants) triple that
+VGPMP.initialize wires together (models/vgpmp.py:154-159); `PlannerBatch` ~ one VGPMP model per
+problem plus its tf.optimizers.Adam (models/vgpmp.py:71-82), `step()` ~ utils/miscellaneous.py:68-84.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import capi
+from .robots import RobotSpec
+
+JITTER = 1e-6
+VARIANCE_FLOOR = 0.1
+DEFAULT_TRAINABLE = dict(q_mu=True, q_sqrt=True, lengthscales=True, kernel_variance=True)
+
+
+def _require_gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise capi.VgpmpError("no HIP device visible: the vGPMP hot path has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def trainable_mask(flags: Dict[str, bool]) -> int:
+    m = 0
+    if flags.get("q_mu", True):
+        m |= capi.TRAIN_Q_MU
+    if flags.get("q_sqrt", True):
+        m |= capi.TRAIN_Q_SQRT
+    if flags.get("lengthscales", True):
+        m |= capi.TRAIN_LENGTHSCALES
+    if flags.get("kernel_variance", True):
+        m |= capi.TRAIN_KERNEL_VARIANCE
+    return m
+
+
+def softplus_inverse(y):
+    y = np.asarray(y, dtype=np.float64)
+    return np.log(np.expm1(y))
+
+
+class DeviceScene:
+    """Robot tables + signed distance field resident in HBM."""
+
+    def __init__(self, spec: RobotSpec, grid, scene_offset: Sequence[float], sigma_obs=0.005,
+                 epsilon: float = 0.05, device: Optional[torch.device] = None):
+        self.lib = capi.load(require=True)
+        self.device = device or _require_gpu()
+        self.spec = spec
+        data, origin, delta = grid
+        data = np.ascontiguousarray(np.asarray(data, dtype=np.float64))
+        self.shape = tuple(int(v) for v in data.shape)
+        self.origin = np.asarray(origin, dtype=np.float64).copy()
+        self.delta = float(delta)
+        self.scene_offset = np.asarray(scene_offset, dtype=np.float64).copy()
+        self.sigma_obs = np.broadcast_to(np.asarray(sigma_obs, dtype=np.float64), (spec.num_spheres,)).copy()
+        self.epsilon = float(epsilon)
+        self.host_robot = capi.make_robot(spec, self.sigma_obs, epsilon, self.scene_offset)
+        self.dev_robot = torch.empty(C.sizeof(capi.Robot), dtype=torch.uint8, device=self.device)
+        capi.check(self.lib.vgpmp_robot_upload(C.byref(self.host_robot), capi.ptr(self.dev_robot), capi.stream_ptr()),
+                   "vgpmp_robot_upload")
+        nx, ny, nz = self.shape
+        self.table = torch.empty((nx, ny, nz, 4), dtype=torch.float32, device=self.device)
+        # upload in slabs so a 512^3 float64 source never needs a second full-size device copy
+        src = torch.from_numpy(data).to(self.device)
+        capi.check(self.lib.vgpmp_sdf_pack(capi.ptr(src), nx, ny, nz, self.delta, capi.ptr(self.table),
+                                           capi.stream_ptr()), "vgpmp_sdf_pack")
+        torch.cuda.current_stream().synchronize()
+        del src
+        self.sdf = capi.Sdf()
+        self.sdf.table = capi.ptr(self.table)
+        self.sdf.nx, self.sdf.ny, self.sdf.nz = nx, ny, nz
+        for k in range(3):
+            self.sdf.origin[k] = float(self.origin[k])
+        self.sdf.delta = self.delta
+
+    # ---- stand-alone pieces -------------------------------------------------------------------
+    def fk_spheres(self, q: torch.Tensor, want_frames: bool = False):
+        """Sampler.forward_kinematics_cost: q [n, dof] float32 -> sphere centres [n, P, 3]."""
+        q = q.to(self.device, torch.float32).contiguous()
+        n = q.shape[0]
+        pos = torch.empty((n, self.spec.num_spheres, 3), dtype=torch.float32, device=self.device)
+        frames = torch.empty((n, self.spec.dof + 1, 3, 4), dtype=torch.float32, device=self.device) if want_frames else None
+        capi.check(self.lib.vgpmp_fk_spheres(capi.ptr(self.dev_robot), capi.ptr(q), n, capi.ptr(pos), capi.ptr(frames),
+                                             capi.stream_ptr()), "vgpmp_fk_spheres")
+        return (pos, frames) if want_frames else pos
+
+    def sdf_query(self, rel_pos: torch.Tensor):
+        """get_distance_tf / get_distance_grad_tf on float64 positions relative to the scene."""
+        rel = rel_pos.to(self.device, torch.float64).contiguous().reshape(-1, 3)
+        n = rel.shape[0]
+        idx = torch.empty((n, 3), dtype=torch.int32, device=self.device)
+        dist = torch.empty(n, dtype=torch.float32, device=self.device)
+        grad = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        capi.check(self.lib.vgpmp_sdf_query(C.byref(self.sdf), capi.ptr(rel), n, capi.ptr(idx), capi.ptr(dist),
+                                            capi.ptr(grad), capi.stream_ptr()), "vgpmp_sdf_query")
+        return idx, dist, grad
+
+    def log_prob(self, g: torch.Tensor, want_grad: bool = False):
+        """VariationalMonteCarloLikelihood.log_prob on joint angles g [..., dof]."""
+        shape = g.shape[:-1]
+        g2 = g.to(self.device, torch.float32).contiguous().reshape(-1, self.spec.dof)
+        n = g2.shape[0]
+        logp = torch.empty(n, dtype=torch.float32, device=self.device)
+        dl = torch.empty_like(g2) if want_grad else None
+        capi.check(self.lib.vgpmp_log_prob(capi.ptr(self.dev_robot), self.spec.dof, C.byref(self.sdf), capi.ptr(g2), n,
+                                           capi.ptr(logp), capi.ptr(dl), capi.stream_ptr()), "vgpmp_log_prob")
+        logp = logp.reshape(shape)
+        return (logp, dl.reshape(g.shape)) if want_grad else logp
+
+    def joint_sigmoid(self, f: torch.Tensor) -> torch.Tensor:
+        low = torch.as_tensor(self.spec.low, dtype=f.dtype, device=f.device)
+        high = torch.as_tensor(self.spec.high, dtype=f.dtype, device=f.device)
+        return low + (high - low) * torch.sigmoid(f)
+
+    def joint_sigmoid_inverse(self, g) -> np.ndarray:
+        x = (np.asarray(g, dtype=np.float64) - self.spec.low) / (self.spec.high - self.spec.low)
+        return np.log(x) - np.log1p(-x)
+
+
+class PlannerBatch:
+    """`num_problems` independent VGPMP models sharing one scene, optimised in lock step."""
+
+    def __init__(self, scene: DeviceScene, queries: np.ndarray, *, num_samples: int, num_inducing: int,
+                 num_data: int, lengthscales: Sequence[float], variance: float, alpha: float = 100.0,
+                 learning_rate: float = 0.02, num_bases: int = 1024, trainable: Optional[Dict[str, bool]] = None,
+                 seed: int = 0, problem_base: int = 0, split_k: Optional[int] = None,
+                 samples_total: Optional[int] = None, kl_scale: float = 1.0, X: Optional[np.ndarray] = None):
+        self.scene, self.lib, self.device = scene, scene.lib, scene.device
+        spec = scene.spec
+        q = np.asarray(queries, dtype=np.float64).reshape(-1, 2, spec.dof)
+        P, L, M, S, N, B = q.shape[0], spec.dof, int(num_inducing), int(num_samples), int(num_data), int(num_bases)
+        self.P, self.L, self.M, self.S, self.N, self.B, self.Mz = P, L, M, S, N, B, M + 2
+        self.alpha, self.lr = float(alpha), float(learning_rate)
+        self.trainable = dict(DEFAULT_TRAINABLE if trainable is None else trainable)
+        self.seed, self.problem_base, self.t = int(seed), int(problem_base), 0
+        if split_k is None:   # K-slices of the prior GEMM: few problems -> more slices to fill the chip
+            split_k = 8 if P * L <= 16 else (4 if P * L <= 64 else (2 if P * L <= 256 else 1))
+            while (B // split_k) % 16:
+                split_k //= 2
+        self.dims = capi.Dims(P, S, int(samples_total or S), N, M, L, B, int(split_k))
+        dev, f64, f32 = self.device, torch.float64, torch.float32
+        # ---- unconstrained variables (models/vgpmp.py:166-171, 255-263)
+        y_u = scene.joint_sigmoid_inverse(q)                                       # [P, 2, L]
+        lin = np.stack([q[:, 0] + (q[:, 1] - q[:, 0]) * i / M for i in range(M)], axis=1)   # [P, M, L]
+        q_mu = scene.joint_sigmoid_inverse(lin).transpose(0, 2, 1)                  # [P, L, M]
+        var = max(float(variance), VARIANCE_FLOOR + 1e-6)    # 0.1 sits on the positive(lower=0.1) floor
+        self.q_mu = torch.tensor(q_mu, dtype=f64, device=dev).contiguous()
+        self.q_sqrt = torch.eye(M, dtype=f64, device=dev).repeat(P, L, 1, 1).contiguous()
+        self.raw_ell = torch.tensor(np.tile(softplus_inverse(lengthscales), (P, 1)), dtype=f64, device=dev)
+        self.raw_var = torch.full((P, L), float(softplus_inverse(var - VARIANCE_FLOOR)), dtype=f64, device=dev)
+        self.y_u = torch.tensor(y_u, dtype=f64, device=dev).contiguous()
+        Xn = np.tile(np.linspace(0.0, 1.0, N)[:, None], (1, L)) if X is None else np.asarray(X, dtype=np.float64)
+        Zy = np.tile(np.concatenate([[0.0, 1.0], np.linspace(0.1, 0.9, M)])[:, None], (1, L))
+        self.X = torch.tensor(Xn, dtype=f64, device=dev).contiguous()
+        self.Zy = torch.tensor(Zy, dtype=f64, device=dev).contiguous()
+        z = lambda t: torch.zeros_like(t)
+        self.adam_m = [z(self.q_mu), z(self.q_sqrt), z(self.raw_ell), z(self.raw_var)]
+        self.adam_v = [z(self.q_mu), z(self.q_sqrt), z(self.raw_ell), z(self.raw_var)]
+        self.grad = [z(self.q_mu), z(self.q_sqrt), z(self.raw_ell), z(self.raw_var)]
+        # ---- noise, outputs, workspace
+        self.omega = torch.empty((P, L, B, L), dtype=f32, device=dev)
+        self.beta = torch.empty((P, L, B), dtype=f32, device=dev)
+        self.w = torch.empty((P, S, L, B), dtype=f32, device=dev)
+        self.eps = torch.empty((P, S, self.Mz, L), dtype=f32, device=dev)
+        self.eps2 = torch.empty((P, S, self.Mz, L), dtype=f32, device=dev)
+        self.f = torch.empty((P, S, L, N), dtype=f32, device=dev)
+        self.logp = torch.empty((P, S, N), dtype=f32, device=dev)
+        self.lik = torch.zeros(P, dtype=f64, device=dev)
+        self.kl = torch.zeros(P, dtype=f64, device=dev)
+        nbytes = C.c_size_t(0)
+        capi.check(self.lib.vgpmp_workspace_bytes(C.byref(self.dims), C.byref(nbytes)), "vgpmp_workspace_bytes")
+        self.workspace = torch.empty(int(nbytes.value), dtype=torch.uint8, device=dev)
+        self.kl_scale = float(kl_scale)
+        self._pack()
+
+    def _params_struct(self, tensors) -> capi.Params:
+        return capi.Params(*(capi.ptr(t) for t in tensors))
+
+    def _pack(self) -> None:
+        self._params = self._params_struct([self.q_mu, self.q_sqrt, self.raw_ell, self.raw_var])
+        self._am = self._params_struct(self.adam_m)
+        self._av = self._params_struct(self.adam_v)
+        self._noise = capi.Noise(capi.ptr(self.omega), capi.ptr(self.beta), capi.ptr(self.w), capi.ptr(self.eps),
+                                 capi.ptr(self.eps2))
+        self._problem = capi.Problem(capi.ptr(self.X), capi.ptr(self.Zy), capi.ptr(self.y_u), self.alpha, JITTER,
+                                     self.kl_scale)
+        self._out = capi.Outputs(capi.ptr(self.f), capi.ptr(self.logp), capi.ptr(self.lik), capi.ptr(self.kl),
+                                 self._params_struct(self.grad))
+
+    # ---- randomness -----------------------------------------------------------------------------
+    def set_noise(self, omega, beta, w, eps, eps2) -> None:
+        """Inject the random tensors of one ELBO evaluation (parity tests)."""
+        for dst, src in ((self.omega, omega), (self.beta, beta), (self.w, w), (self.eps, eps), (self.eps2, eps2)):
+            dst.copy_(torch.as_tensor(np.asarray(src), dtype=torch.float32).reshape(dst.shape))
+
+    def generate_noise(self, step: int) -> None:
+        capi.check(self.lib.vgpmp_generate_noise(C.byref(self.dims), C.byref(self._noise), self.seed, self.problem_base,
+                                                 int(step), capi.stream_ptr()), "vgpmp_generate_noise")
+
+    # ---- the ELBO step --------------------------------------------------------------------------
+    def _run(self, what: int, step: int) -> None:
+        capi.check(self.lib.vgpmp_elbo_step(
+            C.byref(self.dims), capi.ptr(self.scene.dev_robot), C.byref(self.scene.sdf), C.byref(self._problem),
+            C.byref(self._params), C.byref(self._am), C.byref(self._av), C.byref(self._noise), C.byref(self._out),
+            capi.ptr(self.workspace), self.workspace.numel(), what, trainable_mask(self.trainable), self.lr,
+            max(self.t, 1), self.seed, self.problem_base, int(step), capi.stream_ptr()), "vgpmp_elbo_step")
+
+    def elbo(self, generate: bool = True, step: Optional[int] = None) -> torch.Tensor:
+        """VGPMP.elbo (models/vgpmp.py:265-289) for every problem: alpha * sum_n mean_s logp - KL."""
+        self._run(capi.DO_FORWARD | (capi.GEN_NOISE if generate else 0), self.t if step is None else step)
+        return self.lik - self.kl
+
+    def loss_and_grad(self, generate: bool = True, step: Optional[int] = None):
+        """loss = -ELBO and its gradient wrt the unconstrained variables (no update)."""
+        self._run(capi.DO_FORWARD | capi.DO_BACKWARD | (capi.GEN_NOISE if generate else 0),
+                  self.t if step is None else step)
+        return -(self.lik - self.kl), self.grad
+
+    def step(self, generate: bool = True) -> None:
+        """optimization_step (utils/miscellaneous.py:68-84): forward, reverse, Adam; no host sync."""
+        step = self.t
+        self.t += 1
+        self._run(capi.DO_FORWARD | capi.DO_BACKWARD | capi.DO_ADAM | (capi.GEN_NOISE if generate else 0), step)
+
+    def adam_only(self) -> None:
+        """Adam.apply_gradients on self.grad (after an external all-reduce)."""
+        self.t += 1
+        capi.check(self.lib.vgpmp_adam_step(C.byref(self.dims), C.byref(self._params), C.byref(self._out.grad),
+                                            C.byref(self._am), C.byref(self._av), trainable_mask(self.trainable),
+                                            self.lr, self.t, capi.stream_ptr()), "vgpmp_adam_step")
+
+    def view(self, name: str) -> torch.Tensor:
+        """Intermediate of the last evaluation, copied out of the workspace (tests only)."""
+        p, n, dbl = C.c_void_p(), C.c_size_t(), C.c_int32()
+        capi.check(self.lib.vgpmp_workspace_view(C.byref(self.dims), capi.ptr(self.workspace), name.encode(),
+                                                 C.byref(p), C.byref(n), C.byref(dbl)), "vgpmp_workspace_view")
+        off = p.value - self.workspace.data_ptr()
+        nbytes = n.value * (8 if dbl.value else 4)
+        raw = self.workspace[off:off + nbytes]
+        return raw.view(torch.float64 if dbl.value else torch.float32).clone()
+
+    # ---- results --------------------------------------------------------------------------------
+    def samples(self) -> torch.Tensor:
+        """Joint-space paths of the last evaluation: joint_sigmoid(f) as [P, S, N, L]."""
+        return self.scene.joint_sigmoid(self.f.permute(0, 1, 3, 2))
+
+    def lengthscales(self) -> torch.Tensor:
+        return torch.nn.functional.softplus(self.raw_ell)
+
+    def variances(self) -> torch.Tensor:
+        return VARIANCE_FLOOR + torch.nn.functional.softplus(self.raw_var)
