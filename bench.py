@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""ELBO iterations/sec of the MI355X-native vGPMP hot path (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full optimisation step of one planning problem: fresh Philox noise, ELBO forward
+(Kuu/Kuf + Cholesky, RFF prior, Matheron update, FK, SDF lookup, hinge likelihood, KL), its reverse
+pass and the Adam update (reference utils/miscellaneous.py:68-84).  Workload at every N: BASELINE
+config 2 -- Franka 7-DoF, industrial offset, ONE start-goal problem per GPU, S=128, M=30, T=100,
+B=1024 on a synthetic 128^3 SDF (the reference's .sdf blobs are missing from its checkout).  Ranks
+hold independent problems (no data-path collective): weak scaling, value = total steps / max time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from vgpmp_amd import engine, robots, scenes  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F32_MFMA_PEAK_TFLOPS = 157.3    # v_mfma_f32_16x16x4_f32 dense peak
+
+
+def build_problem(rank: int, args):
+    ps = robots.load_problemset("franka", "industrial")
+    spec = robots.load_robot("franka", *ps.robot_pos_and_orn)
+    grid = scenes.synthetic_boxes_sdf(n=args.grid, delta=1.6 / args.grid, origin=(-0.8, -0.8, -0.2), seed=0)
+    pp = ps.planner_params
+    scene = engine.DeviceScene(spec, grid, ps.object_positions[0], sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"])
+    queries = ps.queries
+    qs = np.array([queries[(rank * args.problems + i) % len(queries)] for i in range(args.problems)])
+    planner = engine.PlannerBatch(scene, qs, num_samples=args.samples, num_inducing=args.inducing,
+                                  num_data=args.timesteps, num_bases=1024, lengthscales=pp["lengthscales"],
+                                  variance=pp["variance"], alpha=pp["alpha"], learning_rate=pp["learning_rate"],
+                                  seed=1234, problem_base=rank * args.problems)
+    return ps, spec, grid, scene, planner
+
+
+def cpu_baseline(ps, spec, grid, args, budget_s: float = 12.0):
+    """The float64 NumPy oracle (a restatement, not the GPflow/TF stack) timed on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_scene
+    from oracle import vgpmp_oracle as orc
+    pp = ps.planner_params
+    sc = oracle_scene(spec, grid, ps.object_positions[0], sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"])
+    y = np.array(ps.queries[0], dtype=np.float64)
+    S, N, M, B, D = args.samples, args.timesteps, args.inducing, 1024, spec.dof
+    p = orc.init_params(sc.robot, y, M, pp["lengthscales"], pp["variance"])
+    st = orc.adam_init(p)
+    X, Zy = orc.init_trainset(N, D), orc.inducing_Zy(M, D)
+    rng = np.random.default_rng(0)
+    one = lambda: orc.optimization_step(p, st, sc, X, Zy, y, orc.draw_noise(rng, S, D, D, B, M + 2),
+                                        float(pp["alpha"]), float(pp["learning_rate"]))
+    one()                                   # warm caches / BLAS threads
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one(); n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s and n >= 3:
+            break
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return {"value": n / el, "unit": "ELBO iters/sec", "cores": int(threads), "kind": "port",
+            "sample": f"{n} full optimisation steps of the same workload (noise draw + forward + reverse + Adam) "
+                      f"by the float64 NumPy oracle in {el:.1f} s; host has {os.cpu_count()} logical cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--inducing", type=int, default=30)
+    ap.add_argument("--timesteps", type=int, default=100)
+    ap.add_argument("--problems", type=int, default=1, help="problems per GPU (config 2: 1)")
+    ap.add_argument("--grid", type=int, default=128, help="SDF voxels per axis")
+    ap.add_argument("--unroll", type=int, default=10, help="steps per captured hipGraph (0 = eager launches)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=40)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    ps, spec, grid, scene, planner = build_problem(rank, args)
+    for _ in range(args.warmup):
+        planner.step()
+    if args.unroll > 0:
+        planner.capture(args.unroll)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    planner.run_steps(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    assert torch.isfinite(planner.q_mu).all(), "optimisation diverged"
+
+    # ---- per-kernel durations with HIP events (separate pass so the timed region stays clean)
+    stage_ms = planner.profile_steps(max(1, args.profile_steps))
+    S, N, M, D, P, B = args.samples, args.timesteps, args.inducing, spec.dof, spec.num_spheres, 1024
+    npb = args.problems
+    sdf_bytes = npb * S * N * (28 * P + 8 * D + 4)                 # 7 fp32 voxels per sphere query
+    gemm_flops = npb * 2 * (2.0 * S * (N + M + 2) * D * B)         # F0 and H (lengthscales trainable)
+    t_sdf, t_gemm = stage_ms["loglik_fk_sdf"] * 1e-3, stage_ms["prior_gemm"] * 1e-3
+    roof_sdf = {"kernel": "loglik_paths_kernel", "bound": "hbm", "achieved": sdf_bytes / t_sdf / 1e9,
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sdf_bytes / t_sdf / 1e9 / HBM_PEAK_GBPS,
+                "traffic": None, "algorithmic_bytes_per_launch": sdf_bytes, "avg_launch_ms": stage_ms["loglik_fk_sdf"]}
+    roof_gemm = {"kernel": "prior_gemm_kernel", "bound": "mfma", "achieved": gemm_flops / t_gemm / 1e12,
+                 "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_flops / t_gemm / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                 "traffic": None, "algorithmic_flops_per_launch": gemm_flops, "avg_launch_ms": stage_ms["prior_gemm"]}
+    dominant = max(stage_ms, key=stage_ms.get)
+
+    if rank == 0:
+        line = {
+            "metric": "ELBO iters/sec + plans/sec, Franka-7DoF industrial S=128 M=30 T=100, 1/2/4/8 GPU",
+            "value": world * npb * args.steps / elapsed, "unit": "ELBO iters/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: Franka 7-DoF, industrial offset, synthetic "
+                                   f"{args.grid}^3 SDF, {npb} start-goal problem(s) per GPU, S={S} M={M} T={N} B={B}, "
+                                   "q_mu/q_sqrt/lengthscales/kernel_variance trainable",
+                       "parallelism": f"problems sharded x{world}, no collective",
+                       "launch": f"hipGraph x{args.unroll} steps" if args.unroll else "eager"},
+            "plans_per_sec": world * npb * args.steps / elapsed / float(ps.planner_params["num_steps"]),
+            "roofline": roof_sdf, "roofline_secondary": roof_gemm,
+            "dominant_stage": dominant, "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(ps, spec, grid, args)
+            line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

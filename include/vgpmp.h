@@ -107,6 +107,9 @@ typedef struct vgpmp_problem {
     double alpha;          /* likelihood temperature (vgpmp.py:82) */
     double jitter;         /* 1e-6 */
     double kl_scale;       /* 1 on the rank that owns the KL term, 0 elsewhere */
+    uint32_t* step_counter; /* dev, optional: when set, the noise key uses *step_counter and the Adam
+                             * step count is *step_counter + 1; a VGPMP_DO_ADAM step increments it on
+                             * the device, so a captured hipGraph of the step can be replayed */
 } vgpmp_problem;
 
 /* Outputs of an ELBO evaluation. */
@@ -173,6 +176,19 @@ int vgpmp_elbo_step(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const 
                     void* dev_workspace, size_t workspace_bytes,
                     int32_t what, int32_t trainable, double learning_rate, int32_t adam_t,
                     uint32_t seed, uint32_t problem_base, uint32_t step, vgpmp_stream stream);
+
+/* Same launch sequence with a HIP event recorded on `stream` around every kernel; synchronises the
+ * stream and ADDS the elapsed milliseconds of the 8 stages {noise, cov_fwd, features, prior_gemm,
+ * paths_fwd, loglik(FK+SDF), paths_bwd, cov_bwd+adam} to host_stage_ms[8].  Measurement only. */
+#define VGPMP_NUM_STAGES 8
+int vgpmp_elbo_step_profiled(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,
+                             const vgpmp_problem* problem, const vgpmp_params* params,
+                             const vgpmp_params* adam_m, const vgpmp_params* adam_v,
+                             const vgpmp_noise* noise, const vgpmp_outputs* out,
+                             void* dev_workspace, size_t workspace_bytes,
+                             int32_t what, int32_t trainable, double learning_rate, int32_t adam_t,
+                             uint32_t seed, uint32_t problem_base, uint32_t step, vgpmp_stream stream,
+                             float* host_stage_ms);
 
 /* Adam.apply_gradients alone (after an external all-reduce of out->grad when samples are sharded). */
 int vgpmp_adam_step(const vgpmp_dims* dims, const vgpmp_params* params, const vgpmp_params* grad,

@@ -21,7 +21,9 @@ LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvgpmp_hip.so"
 
 EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_pack", "vgpmp_fk_spheres", "vgpmp_sdf_query",
            "vgpmp_log_prob", "vgpmp_workspace_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
-           "vgpmp_adam_step", "vgpmp_workspace_view")
+           "vgpmp_elbo_step_profiled", "vgpmp_adam_step", "vgpmp_workspace_view")
+NUM_STAGES = 8
+STAGE_NAMES = ("noise", "cov_fwd", "features", "prior_gemm", "paths_fwd", "loglik_fk_sdf", "paths_bwd", "cov_bwd_adam")
 
 
 class VgpmpError(RuntimeError):
@@ -60,7 +62,7 @@ class Noise(C.Structure):
 
 class Problem(C.Structure):
     _fields_ = [("X", C.c_void_p), ("Zy", C.c_void_p), ("y_u", C.c_void_p), ("alpha", C.c_double),
-                ("jitter", C.c_double), ("kl_scale", C.c_double)]
+                ("jitter", C.c_double), ("kl_scale", C.c_double), ("step_counter", C.c_void_p)]
 
 
 class Outputs(C.Structure):
@@ -85,6 +87,10 @@ def load(require: bool = True) -> Optional[C.CDLL]:
             raise VgpmpError(f"{path} not found: build it with `python -m vgpmp_amd.build` "
                              "(the HIP path has no CPU fallback)")
         return None
+    # PyTorch bundles its own libamdhip64.so.7; it must be the process's HIP runtime BEFORE this
+    # library is mapped, otherwise two runtimes coexist and torch's streams/pointers are foreign
+    # to ours (hipErrorNoDevice on the first call).
+    import torch  # noqa: F401
     lib = C.CDLL(str(path))
     lib.vgpmp_version.restype = C.c_char_p
     P = C.POINTER
@@ -99,6 +105,9 @@ def load(require: bool = True) -> Optional[C.CDLL]:
         "vgpmp_generate_noise": [P(Dims), P(Noise), u32, u32, u32, vp],
         "vgpmp_elbo_step": [P(Dims), vp, P(Sdf), P(Problem), P(Params), P(Params), P(Params), P(Noise), P(Outputs),
                             vp, C.c_size_t, i32, i32, dbl, i32, u32, u32, u32, vp],
+        "vgpmp_elbo_step_profiled": [P(Dims), vp, P(Sdf), P(Problem), P(Params), P(Params), P(Params), P(Noise),
+                                     P(Outputs), vp, C.c_size_t, i32, i32, dbl, i32, u32, u32, u32, vp,
+                                     P(C.c_float)],
         "vgpmp_adam_step": [P(Dims), P(Params), P(Params), P(Params), P(Params), i32, dbl, i32, vp],
         "vgpmp_workspace_view": [P(Dims), vp, C.c_char_p, P(vp), P(C.c_size_t), P(i32)],
     }

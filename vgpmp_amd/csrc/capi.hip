@@ -71,15 +71,15 @@ int vgpmp_generate_noise(const vgpmp_dims* dims, const vgpmp_noise* noise, uint3
     if (!dims || !noise || !noise->omega || !noise->beta || !noise->w || !noise->eps || !noise->eps2) return VGPMP_E_ARG;
     int rc = vg_check_dims(dims);
     if (rc) return rc;
-    return vg_launch_rng(dims, noise, seed, problem_base, step, (hipStream_t)stream);
+    return vg_launch_rng(dims, noise, seed, problem_base, step, nullptr, (hipStream_t)stream);
 }
 
-int vgpmp_elbo_step(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,
-                    const vgpmp_problem* problem, const vgpmp_params* params, const vgpmp_params* adam_m,
-                    const vgpmp_params* adam_v, const vgpmp_noise* noise, const vgpmp_outputs* out,
-                    void* dev_workspace, size_t workspace_bytes, int32_t what, int32_t trainable,
-                    double learning_rate, int32_t adam_t, uint32_t seed, uint32_t problem_base, uint32_t step,
-                    vgpmp_stream stream) {
+static int elbo_step_impl(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,
+                          const vgpmp_problem* problem, const vgpmp_params* params, const vgpmp_params* adam_m,
+                          const vgpmp_params* adam_v, const vgpmp_noise* noise, const vgpmp_outputs* out,
+                          void* dev_workspace, size_t workspace_bytes, int32_t what, int32_t trainable,
+                          double learning_rate, int32_t adam_t, uint32_t seed, uint32_t problem_base, uint32_t step,
+                          vgpmp_stream stream, hipEvent_t* ev) {
     if (!dims || !dev_robot || !problem || !params || !noise || !out || !dev_workspace) return VGPMP_E_ARG;
     int rc = vg_check_dims(dims);
     if (rc) return rc;
@@ -91,12 +91,48 @@ int vgpmp_elbo_step(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const 
     if ((what & VGPMP_DO_BACKWARD) &&
         (!out->grad.q_mu || !out->grad.q_sqrt || !out->grad.raw_ell || !out->grad.raw_var))
         return VGPMP_E_ARG;
-    if ((what & VGPMP_DO_ADAM) && (!(what & VGPMP_DO_BACKWARD) || !adam_m || !adam_v || adam_t < 1)) return VGPMP_E_ARG;
+    if ((what & VGPMP_DO_ADAM) &&
+        (!(what & VGPMP_DO_BACKWARD) || !adam_m || !adam_v || (adam_t < 1 && !problem->step_counter)))
+        return VGPMP_E_ARG;
     vg_workspace ws;
     size_t need = vg_layout_workspace(dims, dev_workspace, &ws);
     if (workspace_bytes < need) return VGPMP_E_WORKSPACE;
     return vg_elbo_step(dims, dev_robot, sdf, problem, params, adam_m, adam_v, noise, out, &ws, what, trainable,
-                        learning_rate, adam_t, seed, problem_base, step, (hipStream_t)stream);
+                        learning_rate, adam_t, seed, problem_base, step, (hipStream_t)stream, ev);
+}
+
+int vgpmp_elbo_step(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,
+                    const vgpmp_problem* problem, const vgpmp_params* params, const vgpmp_params* adam_m,
+                    const vgpmp_params* adam_v, const vgpmp_noise* noise, const vgpmp_outputs* out,
+                    void* dev_workspace, size_t workspace_bytes, int32_t what, int32_t trainable,
+                    double learning_rate, int32_t adam_t, uint32_t seed, uint32_t problem_base, uint32_t step,
+                    vgpmp_stream stream) {
+    return elbo_step_impl(dims, dev_robot, sdf, problem, params, adam_m, adam_v, noise, out, dev_workspace,
+                          workspace_bytes, what, trainable, learning_rate, adam_t, seed, problem_base, step, stream,
+                          nullptr);
+}
+
+int vgpmp_elbo_step_profiled(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,
+                             const vgpmp_problem* problem, const vgpmp_params* params, const vgpmp_params* adam_m,
+                             const vgpmp_params* adam_v, const vgpmp_noise* noise, const vgpmp_outputs* out,
+                             void* dev_workspace, size_t workspace_bytes, int32_t what, int32_t trainable,
+                             double learning_rate, int32_t adam_t, uint32_t seed, uint32_t problem_base,
+                             uint32_t step, vgpmp_stream stream, float* host_stage_ms) {
+    if (!host_stage_ms) return VGPMP_E_ARG;
+    hipEvent_t ev[VGPMP_NUM_STAGES + 1];
+    for (int i = 0; i <= VGPMP_NUM_STAGES; ++i) VG_CHECK_HIP(hipEventCreate(&ev[i]));
+    int rc = elbo_step_impl(dims, dev_robot, sdf, problem, params, adam_m, adam_v, noise, out, dev_workspace,
+                            workspace_bytes, what, trainable, learning_rate, adam_t, seed, problem_base, step, stream,
+                            ev);
+    if (rc == 0) rc = (int)hipStreamSynchronize((hipStream_t)stream);
+    if (rc == 0 && (what & VGPMP_DO_BACKWARD)) {
+        for (int i = 0; i < VGPMP_NUM_STAGES; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) host_stage_ms[i] += ms;
+        }
+    }
+    for (int i = 0; i <= VGPMP_NUM_STAGES; ++i) (void)hipEventDestroy(ev[i]);
+    return rc;
 }
 
 int vgpmp_adam_step(const vgpmp_dims* dims, const vgpmp_params* params, const vgpmp_params* grad,

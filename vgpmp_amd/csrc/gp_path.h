@@ -40,10 +40,11 @@ size_t vg_layout_workspace(const vgpmp_dims* d, void* base, vg_workspace* ws);
 int vg_workspace_lookup(const vgpmp_dims* d, const vg_workspace* ws, const char* name, void** ptr, size_t* count,
                         int32_t* is_double);
 int vg_launch_rng(const vgpmp_dims* d, const vgpmp_noise* noise, uint32_t seed, uint32_t problem_base, uint32_t step,
-                  hipStream_t st);
+                  const uint32_t* ctr, hipStream_t st);
 int vg_launch_adam(const vgpmp_dims* d, const vgpmp_params* params, const vgpmp_params* grad, const vgpmp_params* am,
                    const vgpmp_params* av, int trainable, double lr, int t, hipStream_t st);
 int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sdf, const vgpmp_problem* pb,
                  const vgpmp_params* params, const vgpmp_params* am, const vgpmp_params* av, const vgpmp_noise* noise,
                  const vgpmp_outputs* out, const vg_workspace* ws, int what, int trainable, double lr, int adam_t,
-                 uint32_t seed, uint32_t problem_base, uint32_t step, hipStream_t st);
+                 uint32_t seed, uint32_t problem_base, uint32_t step, hipStream_t st, hipEvent_t* ev);
+constexpr int VG_NUM_STAGES = 8;   // rng, cov_fwd, features, prior_gemm, paths_fwd, loglik, paths_bwd, cov_bwd

@@ -46,8 +46,10 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 // omega [P,L,B,D] (Student-t, nu = 5: N(0,1) * rsqrt(chi2_5 / 5)) and beta [P,L,B]
 __global__ __launch_bounds__(kBlock) void rng_basis_kernel(int L, int B, int D, float* __restrict__ omega,
                                                             float* __restrict__ beta, uint32_t seed,
-                                                            uint32_t problem_base, uint32_t step) {
+                                                            uint32_t problem_base, uint32_t step,
+                                                            const uint32_t* __restrict__ ctr) {
     const int p = blockIdx.y;
+    if (ctr) step = *ctr;
     const uint32_t lb = blockIdx.x * kBlock + threadIdx.x;
     if (lb >= (uint32_t)(L * B)) return;
     const uint2 key = vg_key(seed, problem_base + p, step);
@@ -71,8 +73,10 @@ __global__ __launch_bounds__(kBlock) void rng_basis_kernel(int L, int B, int D, 
 // w [P, nW], eps [P, nE], eps2 [P, nE]: counter i of a stream yields elements 4i..4i+3
 __global__ __launch_bounds__(kBlock) void rng_normals_kernel(uint32_t nW, uint32_t nE, float* __restrict__ w,
                                                               float* __restrict__ eps, float* __restrict__ eps2,
-                                                              uint32_t seed, uint32_t problem_base, uint32_t step) {
+                                                              uint32_t seed, uint32_t problem_base, uint32_t step,
+                                                              const uint32_t* __restrict__ ctr) {
     const int p = blockIdx.y;
+    if (ctr) step = *ctr;
     const uint32_t cW = (nW + 3u) >> 2, cE = (nE + 3u) >> 2;
     uint32_t c = blockIdx.x * kBlock + threadIdx.x;
     if (c >= cW + 2u * cE) return;
@@ -248,7 +252,8 @@ __global__ __launch_bounds__(kBlock) void features_kernel(int N, int Mz, int L, 
                                                            const double* __restrict__ raw_var,
                                                            const float* __restrict__ omega,
                                                            const float* __restrict__ beta, float* __restrict__ Phi,
-                                                           float* __restrict__ dPhi) {
+                                                           float* __restrict__ dPhi, uint32_t* __restrict__ tick) {
+    if (tick && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *tick += 1u;
     const int b = blockIdx.x * kBlock + threadIdx.x;
     const int j = blockIdx.y;
     const int l = blockIdx.z % L, p = blockIdx.z / L;
@@ -488,6 +493,8 @@ struct CovBwdArgs {
     double *g_qmu, *g_qsqrt, *g_ell, *g_var;
     int do_adam, trainable, want_dell;
     double lr_t;              // lr * sqrt(1 - b2^t) / (1 - b1^t)
+    double lr;
+    const uint32_t* ctr;      // device step counter (1-based Adam step after the tick) or null
     double *mq_mu, *mq_sqrt, *m_ell, *m_var;      // Adam first moments (alias of params layout)
     double *vq_mu, *vq_sqrt, *v_ell, *v_var;
     double *pq_mu, *pq_sqrt, *p_ell, *p_var;      // parameters (updated in place)
@@ -504,7 +511,7 @@ __device__ __forceinline__ void adam_update(double* x, double* m, double* v, dou
 __global__ __launch_bounds__(kBlock) void cov_bwd_kernel(CovBwdArgs b) {
     extern __shared__ double sm[];
     __shared__ double red[kBlock / VG_WAVE];
-    const CovArgs& a = b.c;
+    const CovArgs a = b.c;
     const int l = blockIdx.x, p = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
     const int M = a.M, Mz = M + 2, N = a.N, L = a.L, D = a.D, ld = Mz + 1;
     const size_t pl = (size_t)p * L + l;
@@ -678,6 +685,10 @@ __global__ __launch_bounds__(kBlock) void cov_bwd_kernel(CovBwdArgs b) {
     }
     if (!b.do_adam) return;
     __syncthreads();
+    if (b.ctr) {
+        const double t = (double)*b.ctr;
+        b.lr_t = b.lr * sqrt(1.0 - pow(0.95, t)) / (1.0 - pow(0.8, t));
+    }
     if (b.trainable & VGPMP_TRAIN_Q_MU)
         for (int i = tid; i < M; i += nt)
             adam_update(b.pq_mu + pl * M + i, b.mq_mu + pl * M + i, b.vq_mu + pl * M + i, gm[i], b.lr_t);
@@ -794,14 +805,14 @@ int vg_workspace_lookup(const vgpmp_dims* d, const vg_workspace* ws, const char*
 }
 
 int vg_launch_rng(const vgpmp_dims* d, const vgpmp_noise* nz, uint32_t seed, uint32_t problem_base, uint32_t step,
-                  hipStream_t st) {
+                  const uint32_t* ctr, hipStream_t st) {
     const int P = d->num_problems, L = d->L, B = d->B, D = d->L, Mz = vg_mz(d);
     hipLaunchKernelGGL(rng_basis_kernel, dim3((L * B + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, L, B, D, nz->omega,
-                       nz->beta, seed, problem_base, step);
+                       nz->beta, seed, problem_base, step, ctr);
     const uint32_t nW = (uint32_t)d->S * L * B, nE = (uint32_t)d->S * Mz * L;
-    const uint32_t ctr = ((nW + 3) >> 2) + 2 * ((nE + 3) >> 2);
-    hipLaunchKernelGGL(rng_normals_kernel, dim3((ctr + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, nW, nE, nz->w,
-                       nz->eps, nz->eps2, seed, problem_base, step);
+    const uint32_t nctr = ((nW + 3) >> 2) + 2 * ((nE + 3) >> 2);
+    hipLaunchKernelGGL(rng_normals_kernel, dim3((nctr + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, nW, nE, nz->w,
+                       nz->eps, nz->eps2, seed, problem_base, step, ctr);
     return (int)hipGetLastError();
 }
 
@@ -828,19 +839,25 @@ static int set_dyn_lds(const void* fn, size_t bytes) {
     return 0;
 }
 
+
 int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sdf, const vgpmp_problem* pb,
                  const vgpmp_params* params, const vgpmp_params* am, const vgpmp_params* av, const vgpmp_noise* nz,
                  const vgpmp_outputs* out, const vg_workspace* ws, int what, int trainable, double lr, int adam_t,
-                 uint32_t seed, uint32_t problem_base, uint32_t step, hipStream_t st) {
+                 uint32_t seed, uint32_t problem_base, uint32_t step, hipStream_t st, hipEvent_t* ev) {
     const int P = d->num_problems, S = d->S, N = d->N, M = d->M, L = d->L, B = d->B, Mz = M + 2, J = N + Mz;
+    int evi = 0;
+    auto mark = [&]() { if (ev) (void)hipEventRecord(ev[evi++], st); };
+    uint32_t* ctr = pb->step_counter;
+    mark();
     const int SK = d->split_k, NC = vg_chunks(d);
     const bool backward = (what & VGPMP_DO_BACKWARD) != 0;
     const bool want_dell = backward && (trainable & VGPMP_TRAIN_LENGTHSCALES);
     int rc;
     if (what & VGPMP_GEN_NOISE) {
-        rc = vg_launch_rng(d, nz, seed, problem_base, step, st);
+        rc = vg_launch_rng(d, nz, seed, problem_base, step, ctr, st);
         if (rc) return rc;
     }
+    mark();
     // ---- covariance path (float64)
     CovArgs ca;
     ca.N = N; ca.M = M; ca.L = L; ca.D = L;
@@ -852,14 +869,17 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
     rc = set_dyn_lds((const void*)cov_fwd_kernel, lds_cov);
     if (rc) return rc;
     hipLaunchKernelGGL(cov_fwd_kernel, dim3(L, P), dim3(kBlock), lds_cov, st, ca);
+    mark();
     // ---- features and prior GEMM
     hipLaunchKernelGGL(features_kernel, dim3((B + kBlock - 1) / kBlock, J, P * L), dim3(kBlock), 0, st, N, Mz, L, L, B,
                        pb->X, pb->Zy, params->raw_ell, params->raw_var, nz->omega, nz->beta, ws->Phi,
-                       want_dell ? ws->dPhi : (float*)nullptr);
+                       want_dell ? ws->dPhi : (float*)nullptr, (what & VGPMP_DO_ADAM) ? ctr : (uint32_t*)nullptr);
+    mark();
     const size_t slab = (size_t)P * S * L * J;
     const int nsel = want_dell ? 2 : 1;
     hipLaunchKernelGGL(prior_gemm_kernel, dim3((J + 16 * kNT - 1) / (16 * kNT), (S + 63) / 64, P * L * SK * nsel),
                        dim3(kBlock), 0, st, S, L, J, B, SK, nsel, nz->w, ws->Phi, ws->dPhi, ws->F0, ws->H, slab);
+    mark();
     // ---- path assembly
     PathArgs pa;
     pa.S = S; pa.N = N; pa.Mz = Mz; pa.L = L; pa.SK = SK; pa.slab = slab;
@@ -871,12 +891,14 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
     rc = set_dyn_lds((const void*)paths_fwd_kernel, lds_pf);
     if (rc) return rc;
     hipLaunchKernelGGL(paths_fwd_kernel, dim3(NC, L, P), dim3(kBlock), lds_pf, st, pa);
+    mark();
     // ---- likelihood forward + reverse (fk_sdf.hip)
     const double lik_scale = pb->alpha / (double)d->S_total;
     int nblk = 0;
     rc = vg_launch_loglik_paths(rb, sdf, out->f, P, S, L, N, (float)(-lik_scale), ws->G, out->logp, ws->lik_partial,
                                 &nblk, st);
     if (rc) return rc;
+    mark();
     if (!backward) {
         hipLaunchKernelGGL(elbo_pieces_kernel, dim3(P), dim3(64), 0, st, L, nblk, ws->lik_partial, ws->kl_l, lik_scale,
                            pb->kl_scale, out->lik, out->kl);
@@ -887,12 +909,14 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
     rc = set_dyn_lds((const void*)paths_bwd_kernel, lds_pb);
     if (rc) return rc;
     hipLaunchKernelGGL(paths_bwd_kernel, dim3(NC, L, P), dim3(kBlock), lds_pb, st, pa);
+    mark();
     CovBwdArgs cb;
     cb.c = ca; cb.NC = NC; cb.part_len = vg_part_len(d); cb.nblk = nblk; cb.lik_scale = lik_scale;
     cb.out_lik = out->lik; cb.out_kl = out->kl;
     cb.g_qmu = out->grad.q_mu; cb.g_qsqrt = out->grad.q_sqrt; cb.g_ell = out->grad.raw_ell; cb.g_var = out->grad.raw_var;
     cb.do_adam = (what & VGPMP_DO_ADAM) ? 1 : 0; cb.trainable = trainable; cb.want_dell = want_dell ? 1 : 0;
     cb.lr_t = cb.do_adam ? adam_lr_t(lr, adam_t) : 0.0;
+    cb.lr = lr; cb.ctr = ctr;
     cb.mq_mu = am ? am->q_mu : nullptr; cb.mq_sqrt = am ? am->q_sqrt : nullptr;
     cb.m_ell = am ? am->raw_ell : nullptr; cb.m_var = am ? am->raw_var : nullptr;
     cb.vq_mu = av ? av->q_mu : nullptr; cb.vq_sqrt = av ? av->q_sqrt : nullptr;
@@ -902,5 +926,6 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
     rc = set_dyn_lds((const void*)cov_bwd_kernel, lds_cb);
     if (rc) return rc;
     hipLaunchKernelGGL(cov_bwd_kernel, dim3(L, P), dim3(kBlock), lds_cb, st, cb);
+    mark();
     return (int)hipGetLastError();
 }

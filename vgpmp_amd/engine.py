@@ -181,6 +181,10 @@ class PlannerBatch:
         capi.check(self.lib.vgpmp_workspace_bytes(C.byref(self.dims), C.byref(nbytes)), "vgpmp_workspace_bytes")
         self.workspace = torch.empty(int(nbytes.value), dtype=torch.uint8, device=dev)
         self.kl_scale = float(kl_scale)
+        # device-resident step counter: lets a captured hipGraph of the step be replayed
+        self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._graph = None
+        self._graph_unroll = 0
         self._pack()
 
     def _params_struct(self, tensors) -> capi.Params:
@@ -193,7 +197,9 @@ class PlannerBatch:
         self._noise = capi.Noise(capi.ptr(self.omega), capi.ptr(self.beta), capi.ptr(self.w), capi.ptr(self.eps),
                                  capi.ptr(self.eps2))
         self._problem = capi.Problem(capi.ptr(self.X), capi.ptr(self.Zy), capi.ptr(self.y_u), self.alpha, JITTER,
-                                     self.kl_scale)
+                                     self.kl_scale, None)
+        self._problem_ctr = capi.Problem(capi.ptr(self.X), capi.ptr(self.Zy), capi.ptr(self.y_u), self.alpha, JITTER,
+                                         self.kl_scale, capi.ptr(self.step_counter))
         self._out = capi.Outputs(capi.ptr(self.f), capi.ptr(self.logp), capi.ptr(self.lik), capi.ptr(self.kl),
                                  self._params_struct(self.grad))
 
@@ -231,6 +237,54 @@ class PlannerBatch:
         step = self.t
         self.t += 1
         self._run(capi.DO_FORWARD | capi.DO_BACKWARD | capi.DO_ADAM | (capi.GEN_NOISE if generate else 0), step)
+
+    # ---- hipGraph replay of the training step ----------------------------------------------------
+    def _run_counter(self, fn=None, stage_ms=None) -> None:
+        """One training step whose noise key / Adam step count come from the device counter."""
+        what = capi.DO_FORWARD | capi.DO_BACKWARD | capi.DO_ADAM | capi.GEN_NOISE
+        args = (C.byref(self.dims), capi.ptr(self.scene.dev_robot), C.byref(self.scene.sdf),
+                C.byref(self._problem_ctr), C.byref(self._params), C.byref(self._am), C.byref(self._av),
+                C.byref(self._noise), C.byref(self._out), capi.ptr(self.workspace), self.workspace.numel(), what,
+                trainable_mask(self.trainable), self.lr, 0, self.seed, self.problem_base, 0, capi.stream_ptr())
+        if stage_ms is None:
+            capi.check(self.lib.vgpmp_elbo_step(*args), "vgpmp_elbo_step")
+        else:
+            capi.check(self.lib.vgpmp_elbo_step_profiled(*args, stage_ms), "vgpmp_elbo_step_profiled")
+
+    def capture(self, unroll: int = 10) -> None:
+        """Capture `unroll` consecutive training steps into one hipGraph (torch.cuda.CUDAGraph is the
+        capture plumbing; every node is one of our kernels)."""
+        self.step_counter.fill_(self.t)
+        self._run_counter()                       # warm-up outside capture (module load, LDS attributes)
+        self.t += 1
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(unroll):
+                self._run_counter()
+        self._graph, self._graph_unroll = g, int(unroll)
+
+    def run_steps(self, steps: int) -> None:
+        """`steps` optimisation steps: whole graphs while they fit, eager launches for the rest."""
+        if self._graph is not None:
+            while steps >= self._graph_unroll:
+                self._graph.replay()
+                self.t += self._graph_unroll
+                steps -= self._graph_unroll
+        if steps > 0:
+            self.step_counter.fill_(self.t)
+            for _ in range(steps):
+                self._run_counter()
+                self.t += 1
+
+    def profile_steps(self, steps: int):
+        """`steps` training steps with a HIP event around every kernel: mean milliseconds per stage."""
+        ms = (C.c_float * capi.NUM_STAGES)()
+        self.step_counter.fill_(self.t)
+        for _ in range(steps):
+            self._run_counter(stage_ms=ms)
+            self.t += 1
+        return {name: ms[i] / steps for i, name in enumerate(capi.STAGE_NAMES)}
 
     def adam_only(self) -> None:
         """Adam.apply_gradients on self.grad (after an external all-reduce)."""
