@@ -26,7 +26,7 @@ extern "C" {
 #define VGPMP_MAX_DOF 16
 #define VGPMP_MAX_FRAMES 17
 #define VGPMP_MAX_SPHERES 64
-#define VGPMP_MAX_MZ 64          /* inducing points + 2 conditioned end points */
+#define VGPMP_MAX_MZ 48          /* inducing points + 2 conditioned end points (LDS-resident float64 algebra) */
 
 #define VGPMP_E_ARG (-1)         /* null pointer / inconsistent argument */
 #define VGPMP_E_SHAPE (-2)       /* dimension outside the supported range */
@@ -110,6 +110,9 @@ typedef struct vgpmp_problem {
     uint32_t* step_counter; /* dev, optional: when set, the noise key uses *step_counter and the Adam
                              * step count is *step_counter + 1; a VGPMP_DO_ADAM step increments it on
                              * the device, so a captured hipGraph of the step can be replayed */
+    vgpmp_stream side_stream; /* optional second stream + two events (hipEvent_t) owned by the caller: */
+    void* fork_event;         /* the float64 covariance kernel then runs on side_stream, concurrently  */
+    void* join_event;         /* with the noise / feature / GEMM kernels of `stream`                    */
 } vgpmp_problem;
 
 /* Outputs of an ELBO evaluation. */
@@ -178,8 +181,8 @@ int vgpmp_elbo_step(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const 
                     uint32_t seed, uint32_t problem_base, uint32_t step, vgpmp_stream stream);
 
 /* Same launch sequence with a HIP event recorded on `stream` around every kernel; synchronises the
- * stream and ADDS the elapsed milliseconds of the 8 stages {noise, cov_fwd, features, prior_gemm,
- * paths_fwd, loglik(FK+SDF), paths_bwd, cov_bwd+adam} to host_stage_ms[8].  Measurement only. */
+ * stream and ADDS the elapsed milliseconds of the 8 stages {cov_fwd, noise, features, prior_gemm,
+ * paths_fwd, loglik(FK+SDF), paths_bwd, final+adam} to host_stage_ms[8].  Measurement only. */
 #define VGPMP_NUM_STAGES 8
 int vgpmp_elbo_step_profiled(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,
                              const vgpmp_problem* problem, const vgpmp_params* params,

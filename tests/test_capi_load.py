@@ -29,13 +29,13 @@ def test_struct_sizes_match_header_layout():
     assert ctypes.sizeof(capi.Sdf) == 8 + 16 + 24 + 8
     assert ctypes.sizeof(capi.Dims) == 32
     assert ctypes.sizeof(capi.Params) == 32 and ctypes.sizeof(capi.Noise) == 40
-    assert ctypes.sizeof(capi.Problem) == 56 and ctypes.sizeof(capi.Outputs) == 64
+    assert ctypes.sizeof(capi.Problem) == 80 and ctypes.sizeof(capi.Outputs) == 64
 
 
 def test_argument_errors_without_gpu():
     handle = capi.load(require=True)
     n = ctypes.c_size_t(0)
-    bad = capi.Dims(1, 8, 8, 10, 70, 7, 64, 1)          # M + 2 > VGPMP_MAX_MZ
+    bad = capi.Dims(1, 8, 8, 10, 47, 7, 64, 1)          # M + 2 > VGPMP_MAX_MZ
     assert handle.vgpmp_workspace_bytes(ctypes.byref(bad), ctypes.byref(n)) == -2
     bad = capi.Dims(1, 8, 8, 10, 5, 7, 60, 1)           # B not a multiple of 16
     assert handle.vgpmp_workspace_bytes(ctypes.byref(bad), ctypes.byref(n)) == -2

@@ -13,7 +13,7 @@ from typing import Optional
 
 import numpy as np
 
-MAX_DOF, MAX_SPHERES, MAX_MZ = 16, 64, 64
+MAX_DOF, MAX_SPHERES, MAX_MZ = 16, 64, 48
 TRAIN_Q_MU, TRAIN_Q_SQRT, TRAIN_LENGTHSCALES, TRAIN_KERNEL_VARIANCE = 1, 2, 4, 8
 DO_FORWARD, DO_BACKWARD, DO_ADAM, GEN_NOISE = 1, 2, 4, 8
 
@@ -23,7 +23,7 @@ EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_pack", "vgpmp_fk_sp
            "vgpmp_log_prob", "vgpmp_workspace_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
            "vgpmp_elbo_step_profiled", "vgpmp_adam_step", "vgpmp_workspace_view")
 NUM_STAGES = 8
-STAGE_NAMES = ("noise", "cov_fwd", "features", "prior_gemm", "paths_fwd", "loglik_fk_sdf", "paths_bwd", "cov_bwd_adam")
+STAGE_NAMES = ("cov_fwd", "noise", "features", "prior_gemm", "paths_fwd", "loglik_fk_sdf", "paths_bwd", "final_adam")
 
 
 class VgpmpError(RuntimeError):
@@ -62,7 +62,8 @@ class Noise(C.Structure):
 
 class Problem(C.Structure):
     _fields_ = [("X", C.c_void_p), ("Zy", C.c_void_p), ("y_u", C.c_void_p), ("alpha", C.c_double),
-                ("jitter", C.c_double), ("kl_scale", C.c_double), ("step_counter", C.c_void_p)]
+                ("jitter", C.c_double), ("kl_scale", C.c_double), ("step_counter", C.c_void_p),
+                ("side_stream", C.c_void_p), ("fork_event", C.c_void_p), ("join_event", C.c_void_p)]
 
 
 class Outputs(C.Structure):

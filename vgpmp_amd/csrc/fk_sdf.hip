@@ -32,10 +32,8 @@ __device__ __forceinline__ vg_float3 lin2(float a, vg_float3 x, float b, vg_floa
     return vg_make3(fmaf(a, x.x, b * y.x), fmaf(a, x.y, b * y.y), fmaf(a, x.z, b * y.z));
 }
 
-// T_i = T_{i-1} * A_i(theta) for joint j = i-1 (0-based table index)
-__device__ __forceinline__ void dh_step(const vgpmp_robot* __restrict__ rb, int j, float theta, Frame& T) {
-    float st, ct;
-    sincosf(theta + rb->twist[j], &st, &ct);
+// T_i = T_{i-1} * A_i for joint j = i-1 (0-based table index), given sin/cos of theta_j + twist_j
+__device__ __forceinline__ void dh_apply(const vgpmp_robot* __restrict__ rb, int j, float st, float ct, Frame& T) {
     const float ca = rb->cos_alpha[j], sa = rb->sin_alpha[j], d = rb->dh_d[j], a = rb->dh_a[j];
     if (rb->craig) {
         // Rx(alpha) Tx(a) Rz(theta) Tz(d)      (utils/sampler.py:190-214)
@@ -57,6 +55,12 @@ __device__ __forceinline__ void dh_step(const vgpmp_robot* __restrict__ rb, int 
     }
 }
 
+__device__ __forceinline__ void dh_step(const vgpmp_robot* __restrict__ rb, int j, float theta, Frame& T) {
+    float st, ct;
+    sincosf(theta + rb->twist[j], &st, &ct);
+    dh_apply(rb, j, st, ct, T);
+}
+
 __device__ __forceinline__ Frame base_frame(const vgpmp_robot* __restrict__ rb) {
     Frame T;
     T.cx = vg_make3(rb->base[0], rb->base[4], rb->base[8]);
@@ -66,118 +70,176 @@ __device__ __forceinline__ Frame base_frame(const vgpmp_robot* __restrict__ rb) 
     return T;
 }
 
-// log p(e | g) of one configuration and (GRAD) d logp / d g.   g, dg: register arrays.
-template <int DMAX, bool GRAD>
+// ---- voxel index: float32 fast path, exact float64 fallback near cell boundaries -----------------
+// The reference computes trunc(((p - offset) - origin) / delta) in float64.  A float64 division costs
+// ~600 issue cycles per sphere on this part, so the quotient is first formed in float32 from a
+// hi/lo split of (offset + origin): its error is < 1e-6 (|q| + 1), and whenever q is farther than that
+// from an integer the truncated float32 value IS the reference index.  Otherwise (a few 1e-4 of the
+// queries) the reference's float64 expression is evaluated, so indices stay bit-identical.
+struct SdfFast {
+    float chx, chy, chz, clx, cly, clz, inv_delta;
+};
+
+__device__ __forceinline__ SdfFast make_fast(const vg_sdf_dev& s, double offx, double offy, double offz) {
+    SdfFast f;
+    const double cx = offx + s.ox, cy = offy + s.oy, cz = offz + s.oz;
+    f.chx = (float)cx; f.clx = (float)(cx - (double)f.chx);
+    f.chy = (float)cy; f.cly = (float)(cy - (double)f.chy);
+    f.chz = (float)cz; f.clz = (float)(cz - (double)f.chz);
+    f.inv_delta = (float)(1.0 / s.delta);
+    return f;
+}
+
+__device__ __forceinline__ int voxel_axis(float pos, float ch, float cl, float inv_delta, int n, double off,
+                                          double origin, double delta) {
+    const float q = ((pos - ch) - cl) * inv_delta;
+    const int hi = n - 1;
+    int idx = q < 0.f ? 0 : (q > (float)hi ? hi : (int)q);
+    if (fabsf(q - rintf(q)) < 1e-6f * (fabsf(q) + 1.f))
+        idx = vg_voxel_axis((double)pos - off, origin, delta, n);      // exact reference expression
+    return idx;
+}
+
+// Per-thread scratch in LDS ([slot][thread], conflict free): the frame loop stays ROLLED (small code:
+// these launches are instruction-fetch bound), so per-frame data cannot live in indexed registers.
+struct LikScratch {
+    float* base;
+    int stride;
+    __device__ __forceinline__ float& at(int slot) const { return base[slot * stride]; }
+};
+// slots: [0, D) sin, [D, 2D) cos, then 6 per frame (F, M)
+__device__ __forceinline__ int lik_scratch_slots(int D) { return 2 * D + 6 * (D + 1); }
+
+// log p(e | g) of one configuration; with GRAD, d logp / d g_j is handed to `emit(j, value)`.
+template <bool GRAD, typename GetG, typename Emit>
 __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ rb, const vg_sdf_dev& sdf,
-                                               const float (&g)[DMAX], float (&dg)[DMAX]) {
+                                               const LikScratch sc, GetG get_g, Emit emit) {
     const int D = rb->dof, P = rb->num_spheres;
     const float eps = rb->epsilon;
     const double offx = rb->scene_offset[0], offy = rb->scene_offset[1], offz = rb->scene_offset[2];
-    vg_float3 az[DMAX + 1], ao[DMAX + 1], Fk[DMAX + 1], Mk[DMAX + 1];
+    const SdfFast fs = make_fast(sdf, offx, offy, offz);
     Frame T = base_frame(rb);
+    vg_float3 Ft = vg_make3(0.f, 0.f, 0.f), Mt = vg_make3(0.f, 0.f, 0.f);
     float acc = 0.f;
     int p = 0;
+#pragma nounroll
+    for (int i = 0; i <= D; ++i) {
+        if (i > 0) {
+            float st, ct;
+            sincosf(get_g(i - 1) + rb->twist[i - 1], &st, &ct);
+            if (GRAD) { sc.at(i - 1) = st; sc.at(D + i - 1) = ct; }
+            dh_apply(rb, i - 1, st, ct, T);
+        }
+        vg_float3 F = vg_make3(0.f, 0.f, 0.f), Mo = vg_make3(0.f, 0.f, 0.f);
+        int pe = p;
+        while (pe < P && rb->sphere_frame[pe] == i) ++pe;        // spheres [p, pe) ride on frame i
+        // four spheres per pass: positions, voxel indices and the four 16-byte gathers are issued
+        // unconditionally (tail entries repeat the last sphere with weight 0), then consumed
+#pragma nounroll
+        for (; p < pe; p += 4) {
+            float4 v[4];
+            vg_float3 pos[4];
 #pragma unroll
-    for (int i = 0; i <= DMAX; ++i) {
-        if (i <= D) {
-            if (i > 0) dh_step(rb, i - 1, g[i - 1], T);
-            vg_float3 F = vg_make3(0.f, 0.f, 0.f), Mo = vg_make3(0.f, 0.f, 0.f);
-            while (p < P && rb->sphere_frame[p] == i) {
-                const float ox = rb->sphere_off[p][0], oy = rb->sphere_off[p][1], oz = rb->sphere_off[p][2];
-                vg_float3 pos = axpy(ox, T.cx, axpy(oy, T.cy, axpy(oz, T.cz, T.t)));
-                int ix, iy, iz;
-                size_t vi = vg_voxel_index(sdf, (double)pos.x - offx, (double)pos.y - offy, (double)pos.z - offz,
-                                           ix, iy, iz);
-                float4 v = sdf.table[vi];
-                float c = fmaxf(eps - (v.x - rb->radius[p]), 0.f);     // likelihood.py:131-143
-                float cs = c / rb->sigma_obs[p];
-                acc = fmaf(cs, c, acc);                                // likelihood.py:99
+            for (int u = 0; u < 4; ++u) {
+                const int q = min(p + u, pe - 1);
+                pos[u] = axpy(rb->sphere_off[q][0], T.cx, axpy(rb->sphere_off[q][1], T.cy,
+                              axpy(rb->sphere_off[q][2], T.cz, T.t)));
+                const int ix = voxel_axis(pos[u].x, fs.chx, fs.clx, fs.inv_delta, sdf.nx, offx, sdf.ox, sdf.delta);
+                const int iy = voxel_axis(pos[u].y, fs.chy, fs.cly, fs.inv_delta, sdf.ny, offy, sdf.oy, sdf.delta);
+                const int iz = voxel_axis(pos[u].z, fs.chz, fs.clz, fs.inv_delta, sdf.nz, offz, sdf.oz, sdf.delta);
+                v[u] = sdf.table[((size_t)ix * sdf.ny + iy) * sdf.nz + iz];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = min(p + u, pe - 1);
+                const float wgt = (p + u < pe) ? 1.f : 0.f;
+                float c = fmaxf(eps - (v[u].x - rb->radius[q]), 0.f) * wgt;     // likelihood.py:131-143
+                float cs = c / rb->sigma_obs[q];
+                acc = fmaf(cs, c, acc);                                          // likelihood.py:99
                 if (GRAD) {
-                    vg_float3 gp = vg_make3(cs * v.y, cs * v.z, cs * v.w);   // d logp / d pos
+                    vg_float3 gp = vg_make3(cs * v[u].y, cs * v[u].z, cs * v[u].w);   // d logp / d pos
                     F = vg_make3(F.x + gp.x, F.y + gp.y, F.z + gp.z);
-                    vg_float3 m = vg_cross(pos, gp);
+                    vg_float3 m = vg_cross(pos[u], gp);
                     Mo = vg_make3(Mo.x + m.x, Mo.y + m.y, Mo.z + m.z);
                 }
-                ++p;
             }
-            if (GRAD) { az[i] = T.cz; ao[i] = T.t; Fk[i] = F; Mk[i] = Mo; }
+        }
+        p = pe;
+        if (GRAD) {
+            const int o = 2 * D + 6 * i;
+            sc.at(o) = F.x; sc.at(o + 1) = F.y; sc.at(o + 2) = F.z;
+            sc.at(o + 3) = Mo.x; sc.at(o + 4) = Mo.y; sc.at(o + 5) = Mo.z;
+            Ft = vg_make3(Ft.x + F.x, Ft.y + F.y, Ft.z + F.z);
+            Mt = vg_make3(Mt.x + Mo.x, Mt.y + Mo.y, Mt.z + Mo.z);
         }
     }
     if (GRAD) {
-        vg_float3 Fs = vg_make3(0.f, 0.f, 0.f), Ms = vg_make3(0.f, 0.f, 0.f);
+        // second sweep over the chain (sin/cos kept): joint i turns about z of frame i (Craig) or frame
+        // i-1 (classic) and moves every sphere on frames >= i, i.e. the totals minus the prefix < i
         const bool craig = rb->craig != 0;
-#pragma unroll
-        for (int i = DMAX; i >= 1; --i) {
-            if (i <= D) {
-                Fs = vg_make3(Fs.x + Fk[i].x, Fs.y + Fk[i].y, Fs.z + Fk[i].z);
-                Ms = vg_make3(Ms.x + Mk[i].x, Ms.y + Mk[i].y, Ms.z + Mk[i].z);
-                // joint i turns about z of frame i (Craig) / frame i-1 (classic), through that frame's origin
-                vg_float3 z = craig ? az[i] : az[i - 1];
-                vg_float3 o = craig ? ao[i] : ao[i - 1];
-                vg_float3 oxF = vg_cross(o, Fs);
-                dg[i - 1] = vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z));
-            } else {
-                dg[i - 1] = 0.f;
-            }
+        T = base_frame(rb);
+        vg_float3 Fs = Ft, Ms = Mt;
+#pragma nounroll
+        for (int i = 1; i <= D; ++i) {
+            const int o = 2 * D + 6 * (i - 1);
+            Fs = vg_make3(Fs.x - sc.at(o), Fs.y - sc.at(o + 1), Fs.z - sc.at(o + 2));
+            Ms = vg_make3(Ms.x - sc.at(o + 3), Ms.y - sc.at(o + 4), Ms.z - sc.at(o + 5));
+            vg_float3 z = T.cz, org = T.t;
+            dh_apply(rb, i - 1, sc.at(i - 1), sc.at(D + i - 1), T);
+            if (craig) { z = T.cz; org = T.t; }
+            const vg_float3 oxF = vg_cross(org, Fs);
+            emit(i - 1, vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)));
         }
     }
     return -0.5f * acc;
 }
 
+constexpr int kLikBlock = 128;
+
 // ---- stand-alone log_prob: g [n, dof] row major ------------------------------------------------
-template <int DMAX, bool GRAD>
-__global__ __launch_bounds__(kBlock) void log_prob_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
-                                                           const float* __restrict__ gq, int64_t n,
-                                                           float* __restrict__ logp, float* __restrict__ dlogp) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+template <bool GRAD>
+__global__ __launch_bounds__(kLikBlock) void log_prob_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
+                                                              const float* __restrict__ gq, int64_t n,
+                                                              float* __restrict__ logp, float* __restrict__ dlogp) {
+    extern __shared__ float lik_lds[];
+    const int64_t i = (int64_t)blockIdx.x * kLikBlock + threadIdx.x;
     if (i >= n) return;
     const vg_sdf_dev sdf = load_sdf(sdfh);
     const int D = rb->dof;
-    float g[DMAX], dg[DMAX];
-#pragma unroll
-    for (int j = 0; j < DMAX; ++j) g[j] = j < D ? gq[i * D + j] : 0.f;
-    float lp = loglik_config<DMAX, GRAD>(rb, sdf, g, dg);
-    logp[i] = lp;
-    if (GRAD) {
-#pragma unroll
-        for (int j = 0; j < DMAX; ++j)
-            if (j < D) dlogp[i * D + j] = dg[j];
-    }
+    const LikScratch sc{lik_lds + threadIdx.x, kLikBlock};
+    const float* g = gq + i * D;
+    float* dg = dlogp + i * D;
+    logp[i] = loglik_config<GRAD>(rb, sdf, sc, [&](int j) { return g[j]; }, [&](int j, float v) { dg[j] = v; });
 }
 
 // ---- ELBO path: f [P,S,L,N] -> logp [P,S,N], G = dloss/df [P,S,L,N], block partial sums ----------
-template <int DMAX>
-__global__ __launch_bounds__(kBlock) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
-                                                               const float* __restrict__ f, int S, int L, int N,
-                                                               float scale, float* __restrict__ G,
-                                                               float* __restrict__ logp,
-                                                               float* __restrict__ lik_partial) {
-    __shared__ float red[kBlock / VG_WAVE];
+__global__ __launch_bounds__(kLikBlock) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
+                                                                  const float* __restrict__ f, int S, int L, int N,
+                                                                  float scale, float* __restrict__ G,
+                                                                  float* __restrict__ logp,
+                                                                  float* __restrict__ lik_partial) {
+    extern __shared__ float lik_lds[];
+    __shared__ float red[kLikBlock / VG_WAVE];
     const int pb = blockIdx.y;
-    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    const int idx = blockIdx.x * kLikBlock + threadIdx.x;
     const bool live = idx < S * N;
     float lp = 0.f;
     if (live) {
         const vg_sdf_dev sdf = load_sdf(sdfh);
         const int s = idx / N, n = idx - s * N;
         const size_t base = ((size_t)pb * S + s) * L * N + n;
-        float g[DMAX], dg[DMAX], dgdf[DMAX];
-#pragma unroll
-        for (int j = 0; j < DMAX; ++j) {
-            if (j < L) {
-                float sg = 1.0f / (1.0f + expf(-f[base + (size_t)j * N]));      // likelihood.py:49-52
-                float span = rb->high[j] - rb->low[j];
-                g[j] = fmaf(span, sg, rb->low[j]);
-                dgdf[j] = span * sg * (1.0f - sg);
-            } else {
-                g[j] = 0.f; dgdf[j] = 0.f;
-            }
-        }
-        lp = loglik_config<DMAX, true>(rb, sdf, g, dg);
+        const LikScratch sc{lik_lds + threadIdx.x, kLikBlock};
+        float* dgdf = lik_lds + (size_t)lik_scratch_slots(L) * kLikBlock + threadIdx.x;   // [L][block]
+        lp = loglik_config<true>(
+            rb, sdf, sc,
+            [&](int j) {
+                const float sg = 1.0f / (1.0f + __expf(-f[base + (size_t)j * N]));       // likelihood.py:49-52
+                const float span = rb->high[j] - rb->low[j];
+                dgdf[j * kLikBlock] = span * sg * (1.0f - sg);
+                return fmaf(span, sg, rb->low[j]);
+            },
+            [&](int j, float v) { G[base + (size_t)j * N] = scale * v * dgdf[j * kLikBlock]; });
         logp[((size_t)pb * S + s) * N + n] = lp;
-#pragma unroll
-        for (int j = 0; j < DMAX; ++j)
-            if (j < L) G[base + (size_t)j * N] = scale * dg[j] * dgdf[j];
     }
     float w = vg_wave_sum(lp);
     if ((threadIdx.x & (VG_WAVE - 1)) == 0) red[threadIdx.x / VG_WAVE] = w;
@@ -185,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void loglik_paths_kernel(const vgpmp_robot*
     if (threadIdx.x == 0) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < kBlock / VG_WAVE; ++k) t += red[k];
+        for (int k = 0; k < kLikBlock / VG_WAVE; ++k) t += red[k];
         lik_partial[(size_t)pb * gridDim.x + blockIdx.x] = t;
     }
 }
@@ -258,7 +320,19 @@ __global__ __launch_bounds__(kBlock) void sdf_pack_kernel(const double* __restri
 
 }  // namespace
 
-int vg_loglik_blocks_per_problem(int S, int N) { return (S * N + kBlock - 1) / kBlock; }
+int vg_loglik_blocks_per_problem(int S, int N) { return (S * N + kLikBlock - 1) / kLikBlock; }
+
+static size_t lik_lds_bytes(int dof, bool with_dgdf) {
+    return (size_t)(2 * dof + 6 * (dof + 1) + (with_dgdf ? dof : 0)) * kLikBlock * sizeof(float);
+}
+
+// dynamic LDS above 48 KB needs the attribute once per kernel (slow host call: remember what was granted)
+static int lik_grant_lds(const void* fn, size_t bytes, size_t* granted) {
+    if (bytes <= 48 * 1024 || *granted >= bytes) return 0;
+    VG_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    *granted = bytes;
+    return 0;
+}
 
 int vg_launch_sdf_pack(const double* grid, int nx, int ny, int nz, double delta, float4* table, hipStream_t st) {
     size_t total = (size_t)nx * ny * nz;
@@ -284,18 +358,17 @@ int vg_launch_sdf_query(const vgpmp_sdf* sdf, const double* rel, int64_t n, int3
     return (int)hipGetLastError();
 }
 
-// dof <= 8 and dof <= 16 instantiations (register arrays are sized by the template bound)
 int vg_launch_log_prob_impl(const vgpmp_robot* rb, int dof, const vgpmp_sdf* sdf, const float* g, int64_t n,
                             float* logp, float* dlogp, hipStream_t st) {
     if (n == 0) return 0;
-    dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
-    if (dof <= 8) {
-        if (dlogp) hipLaunchKernelGGL((log_prob_kernel<8, true>), grid, block, 0, st, rb, *sdf, g, n, logp, dlogp);
-        else hipLaunchKernelGGL((log_prob_kernel<8, false>), grid, block, 0, st, rb, *sdf, g, n, logp, dlogp);
-    } else {
-        if (dlogp) hipLaunchKernelGGL((log_prob_kernel<16, true>), grid, block, 0, st, rb, *sdf, g, n, logp, dlogp);
-        else hipLaunchKernelGGL((log_prob_kernel<16, false>), grid, block, 0, st, rb, *sdf, g, n, logp, dlogp);
-    }
+    dim3 grid((unsigned)((n + kLikBlock - 1) / kLikBlock)), block(kLikBlock);
+    const size_t lds = lik_lds_bytes(dof, false);
+    static size_t granted_g = 0, granted_n = 0;
+    int rc = dlogp ? lik_grant_lds((const void*)log_prob_kernel<true>, lds, &granted_g)
+                   : lik_grant_lds((const void*)log_prob_kernel<false>, lds, &granted_n);
+    if (rc) return rc;
+    if (dlogp) hipLaunchKernelGGL((log_prob_kernel<true>), grid, block, lds, st, rb, *sdf, g, n, logp, dlogp);
+    else hipLaunchKernelGGL((log_prob_kernel<false>), grid, block, lds, st, rb, *sdf, g, n, logp, dlogp);
     return (int)hipGetLastError();
 }
 
@@ -304,12 +377,10 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
     const int nblk = vg_loglik_blocks_per_problem(S, N);
     if (nblk_out) *nblk_out = nblk;
     if (P == 0 || nblk == 0) return 0;
-    dim3 grid(nblk, P), block(kBlock);
-    if (L <= 8)
-        hipLaunchKernelGGL((loglik_paths_kernel<8>), grid, block, 0, st, rb, *sdf, f, S, L, N, scale, G, logp,
-                           lik_partial);
-    else
-        hipLaunchKernelGGL((loglik_paths_kernel<16>), grid, block, 0, st, rb, *sdf, f, S, L, N, scale, G, logp,
-                           lik_partial);
+    static size_t granted = 0;
+    int rc = lik_grant_lds((const void*)loglik_paths_kernel, lik_lds_bytes(L, true), &granted);
+    if (rc) return rc;
+    hipLaunchKernelGGL(loglik_paths_kernel, dim3(nblk, P), dim3(kLikBlock), lik_lds_bytes(L, true), st, rb, *sdf, f, S,
+                       L, N, scale, G, logp, lik_partial);
     return (int)hipGetLastError();
 }

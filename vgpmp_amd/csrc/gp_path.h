@@ -2,23 +2,24 @@
 #pragma once
 #include "vgpmp_device.h"
 
-constexpr int VG_SC = 16;   // samples per chunk of the path kernels
+constexpr int VG_SC = 8;    // samples per chunk of the path kernels
 
 struct vg_workspace {
     // float64 covariance path, per (problem, latent)
-    double *ell, *var;       // [P,L]
-    double *K;               // [P,L,Mz,Mz]   Matern Kuu without jitter
-    double *Lk;              // [P,L,Mz,Mz]   chol(Kuu + jitter I)
-    double *Linv;            // [P,L,Mz,Mz]   Lk^-1
+    double *ell, *var, *sig_ell, *sig_var;   // [P,L] constrained values and d(constrained)/d(raw)
     double *Kinv;            // [P,L,Mz,Mz]   (Kuu + jitter I)^-1
-    double *Kuf;             // [P,L,Mz,N]
-    double *A64;             // [P,L,N,Mz]    Kfu Kinv
-    double *afull;           // [P,L,Mz]      Lk^-1 (q_mu - p_mu)
-    double *cvec;            // [P,L,2]       Kyy^-1 y
+    double *Kd_ell;          // [P,L,Mz,Mz]   dKuu / d lengthscale
     double *kl_l;            // [P,L]
-    double *dA64;            // [P,L,N,Mz]    reverse-pass scratch
+    double *gkl_qmu;         // [P,L,M]       dKL/dq_mu
+    double *gkl_Q;           // [P,L,M,M]     dKL/dq_sqrt (lower)
+    double *gkl_ell, *gkl_var;   // [P,L]     dKL/d lengthscale, d variance (constrained space)
     // float32 operands of the sample path
-    float *A, *C, *m;        // [P,L,N,Mz], [P,L,Mz,Mz], [P,L,Mz]
+    float *A4;               // [P,L,N,Mz,4]  {A, dA/dell, dA/dvar, 0},  A = Kfu (Kuu + jI)^-1
+    float *AT;               // [P,L,Mz,N]    A transposed
+    float *C;                // [P,L,Mz,Mz]   q_sqrt (full)
+    float *CT_ell, *CT_var;  // [P,L,Mz,Mz]   (dC/d theta)^T
+    float *Lk32;             // [P,L,Mz,Mz]   chol(Kuu + jitter I)
+    float *m;                // [P,L,Mz]
     float *Phi, *dPhi;       // [P,L,J,B]
     float *F0, *H;           // [SK][P,S,L,J]
     float *R;                // [P,S,L,Mz]
@@ -32,7 +33,7 @@ inline int vg_j(const vgpmp_dims* d) { return d->N + d->M + 2; }
 inline int vg_chunks(const vgpmp_dims* d) { return (d->S + VG_SC - 1) / VG_SC; }
 inline size_t vg_part_len(const vgpmp_dims* d) {
     size_t mz = (size_t)vg_mz(d);
-    return mz + mz * mz + (size_t)d->N * mz + 4;
+    return mz + mz * mz + 4;
 }
 
 int vg_check_dims(const vgpmp_dims* d);
@@ -47,4 +48,4 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
                  const vgpmp_params* params, const vgpmp_params* am, const vgpmp_params* av, const vgpmp_noise* noise,
                  const vgpmp_outputs* out, const vg_workspace* ws, int what, int trainable, double lr, int adam_t,
                  uint32_t seed, uint32_t problem_base, uint32_t step, hipStream_t st, hipEvent_t* ev);
-constexpr int VG_NUM_STAGES = 8;   // rng, cov_fwd, features, prior_gemm, paths_fwd, loglik, paths_bwd, cov_bwd
+constexpr int VG_NUM_STAGES = 8;   // cov_fwd, rng, features, prior_gemm, paths_fwd, loglik, paths_bwd, final

@@ -12,6 +12,14 @@
 #include "gp_path.h"
 #include <string.h>
 
+#ifdef VGPMP_BISECT
+#include <stdlib.h>
+#define VG_STOP(args, k) do { if ((args).stop == (k)) return; } while (0)
+static int vg_bisect_stop(const char* name) { const char* e = getenv(name); return e ? atoi(e) : -1; }
+#else
+#define VG_STOP(args, k) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -28,6 +36,20 @@ __device__ __forceinline__ double matern52(double t1, double t2, double ell, dou
 __device__ __forceinline__ double matern52_dell(double t1, double t2, double ell, double var) {
     double r = fabs(t1 - t2) / ell;
     return var * exp(-kSqrt5 * r) * (5.0 * r * r / (3.0 * ell)) * (1.0 + kSqrt5 * r);
+}
+
+// strided dot product with four independent accumulators (a dependent f64 FMA costs ~40 cycles)
+__device__ __attribute__((noinline)) double dot4(const double* a, int sa, const double* b, int sb, int n) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = 0;
+    for (; k + 3 < n; k += 4) {
+        s0 = fma(a[k * sa], b[k * sb], s0);
+        s1 = fma(a[(k + 1) * sa], b[(k + 1) * sb], s1);
+        s2 = fma(a[(k + 2) * sa], b[(k + 2) * sb], s2);
+        s3 = fma(a[(k + 3) * sa], b[(k + 3) * sb], s3);
+    }
+    for (; k < n; ++k) s0 = fma(a[k * sa], b[k * sb], s0);
+    return (s0 + s1) + (s2 + s3);
 }
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
@@ -53,17 +75,25 @@ __global__ __launch_bounds__(kBlock) void rng_basis_kernel(int L, int B, int D, 
     const uint32_t lb = blockIdx.x * kBlock + threadIdx.x;
     if (lb >= (uint32_t)(L * B)) return;
     const uint2 key = vg_key(seed, problem_base + p, step);
-    float4 c0 = vg_normal4(2u * lb, VG_STREAM_CHI, key);
-    float4 c1 = vg_normal4(2u * lb + 1u, VG_STREAM_CHI, key);
-    float gam = (c0.x * c0.x + c0.y * c0.y + c0.z * c0.z + c0.w * c0.w + c1.x * c1.x) * 0.2f;
-    float sc = 1.0f / sqrtf(gam);
-    const uint32_t e0 = lb * (uint32_t)D;
-    uint32_t cur = 0xFFFFFFFFu;
-    float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int d = 0; d < D; ++d) {
-        uint32_t e = e0 + d;
-        if ((e >> 2) != cur) { cur = e >> 2; nv = vg_normal4(cur, VG_STREAM_OMEGA, key); }
-        omega[((size_t)p * L * B + lb) * D + d] = vg_lane(nv, (int)(e & 3u)) * sc;
+    const uint32_t e0 = lb * (uint32_t)D, c_first = e0 >> 2, c_last = (e0 + D - 1) >> 2;
+    float* om = omega + ((size_t)p * L * B + lb) * D;
+    float gam = 0.f, sc = 0.f;
+    // pass q = 0,1: chi-square counters (5 of 8 normals); then the omega counters of this row
+#pragma nounroll
+    for (uint32_t q = 0; q < 2u + (c_last - c_first + 1u); ++q) {
+        const bool chi = q < 2u;
+        const uint32_t c = chi ? 2u * lb + q : c_first + (q - 2u);
+        const float4 v = vg_normal4(c, chi ? VG_STREAM_CHI : VG_STREAM_OMEGA, key);
+        if (chi) {
+            gam += q == 0u ? v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w : v.x * v.x;
+            if (q == 1u) sc = __builtin_amdgcn_rsqf(gam * 0.2f);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t e = 4u * c + k;
+                if (e >= e0 && e < e0 + (uint32_t)D) om[e - e0] = vg_lane(v, k) * sc;
+            }
+        }
     }
     uint4 r = vg_philox(make_uint4(lb >> 2, VG_STREAM_BETA, 0u, 0u), key);
     uint32_t rb = (lb & 3u) == 0 ? r.x : (lb & 3u) == 1 ? r.y : (lb & 3u) == 2 ? r.z : r.w;
@@ -98,146 +128,317 @@ __global__ __launch_bounds__(kBlock) void rng_normals_kernel(uint32_t nW, uint32
 }
 
 // =================================================================================================
-// Covariance path, forward (float64).  One workgroup per (latent, problem).
+// Covariance path (float64).
+//
+// cov_fwd_kernel -- one workgroup per (latent, problem): Kuu, chol, inverse, q_sqrt, KL and its
+//   gradient, plus the FORWARD-MODE tangents of chol/q_sqrt/KL wrt the latent's two kernel
+//   hyper-parameters (lengthscale, variance).
+// cov_rows_kernel -- row tiles of A = Kfu (Kuu + jI)^-1 and of its two tangents, spread over
+//   N/8 workgroups per latent.
+// With the tangents available the sample-dependent reverse pass needs only dot products of its
+// upstream gradients with them -- no Cholesky adjoint, no N-sized float64 reductions -- and both
+// kernels sit off the critical path (side stream) next to the noise/feature/GEMM branch.
 // =================================================================================================
 struct CovArgs {
     int N, M, L, D;
     const double *X, *Zy, *y_u;
-    double jitter, kl_scale;
+    double jitter;
     const double *q_mu, *q_sqrt, *raw_ell, *raw_var;
+    int want_dell;
+    int stop;
     vg_workspace ws;
 };
 
-__global__ __launch_bounds__(kBlock) void cov_fwd_kernel(CovArgs a) {
-    extern __shared__ double sm[];
-    const int l = blockIdx.x, p = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
-    const int M = a.M, Mz = M + 2, N = a.N, L = a.L, D = a.D, ld = Mz + 1;
-    const size_t pl = (size_t)p * L + l;
-    double* La = sm;                 // Cholesky factor (in place)
-    double* Li = La + Mz * ld;       // Lk^-1
-    double* Ki = Li + Mz * ld;       // (K + jitter I)^-1
-    double* zs = Ki + Mz * ld;       // Zy[:, l]
-    double* dl = zs + Mz;            // q_mu - p_mu
-    __shared__ double red[kBlock / VG_WAVE];
+constexpr int kCovThreads = 256;
+constexpr int kRowTile = 8;
 
-    const double ell = softplus_d(a.raw_ell[pl]);
-    const double var = kVarFloor + softplus_d(a.raw_var[pl]);
-    if (tid == 0) { a.ws.ell[pl] = ell; a.ws.var[pl] = var; }
-    for (int i = tid; i < Mz; i += nt) zs[i] = a.Zy[(size_t)i * D + l];
-    __syncthreads();
-    double* Kg = a.ws.K + pl * Mz * Mz;
-    for (int e = tid; e < Mz * Mz; e += nt) {
-        int i = e / Mz, j = e - i * Mz;
-        double k = matern52(zs[i], zs[j], ell, var);
-        Kg[e] = k;
-        La[i * ld + j] = k + (i == j ? a.jitter : 0.0);
-        Li[i * ld + j] = 0.0;
+// ---- float64 matrix-core tiles ---------------------------------------------------------------------
+// v_mfma_f64_16x16x4_f64: lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15] (one
+// double each); it receives D[row = (l >> 4) + 4 q][col = l & 15] in accumulator element q = 0..3.
+// All matrices live in LDS with dimension Mp = roundup(Mz, 16) (zero padded), so no edge handling.
+typedef double vg_f64x4 __attribute__((ext_vector_type(4)));
+
+struct MatView {            // element (r, c) at p[r * sr + c * sc]
+    const double* p;
+    int sr, sc;
+};
+
+__device__ __forceinline__ vg_f64x4 mfma_tile_f64(MatView A, MatView B, int K, int lane, int i0, int j0) {
+    vg_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    const int r = lane & 15, g = lane >> 4;
+    const double* ap = A.p + (i0 + r) * A.sr + g * A.sc;
+    const double* bp = B.p + g * B.sr + (j0 + r) * B.sc;
+#pragma nounroll
+    for (int k = 0; k < K; k += 4) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[k * A.sc], bp[k * B.sr], acc, 0, 0, 0);
     }
-    double* Kufg = a.ws.Kuf + pl * Mz * N;
-    for (int e = tid; e < Mz * N; e += nt) {
-        int i = e / N, n = e - i * N;
-        Kufg[e] = matern52(zs[i], a.X[(size_t)n * D + l], ell, var);
+    return acc;
+}
+
+// D = A B over all 16x16 tiles of an Mp x Mp result, tiles dealt round-robin to the waves; `emit(r, c, v)`
+// receives every element.
+template <typename Emit>
+__device__ __forceinline__ void matmul_f64(MatView A, MatView B, int Mp, int tid, int nt, Emit emit) {
+    const int lane = tid & 63, nT = Mp >> 4;
+    for (int t = tid >> 6; t < nT * nT; t += nt >> 6) {
+        const int i0 = (t / nT) << 4, j0 = (t % nT) << 4;
+        const vg_f64x4 acc = mfma_tile_f64(A, B, Mp, lane, i0, j0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) emit(i0 + (lane >> 4) + 4 * q, j0 + (lane & 15), acc[q]);
+    }
+}
+
+// Cholesky factor and its inverse of the SPD matrix held in La (LDS), by forward elimination of the
+// augmented matrix [K | I] without pivoting (K = L~ D L~^T): after Mz pivots the left half holds
+// U = D L~^T and the right half L~^-1, so  Lk = L~ D^1/2  and  Lk^-1 = D^-1/2 L~^-1.  Every pivot is
+// one rank-1 update spread over the whole workgroup and ONE barrier; the code stays rolled and small
+// (these launches are instruction-fetch bound, a fully unrolled register Cholesky was slower).
+__device__ __forceinline__ void chol_inverse_block(double* La, double* Li, double* Aug, double* rsd, int Mz, int ld,
+                                                   int tid, int nt) {
+    const int la = 2 * Mz + 1;
+    for (int e = tid; e < Mz * 2 * Mz; e += nt) {
+        const int i = e / (2 * Mz), j = e - i * 2 * Mz;
+        Aug[i * la + j] = j < Mz ? La[i * ld + j] : (j - Mz == i ? 1.0 : 0.0);
     }
     __syncthreads();
-    // ---- Cholesky of Kuu + jitter I, right-looking (models/vgpmp.py:214-215)
     for (int k = 0; k < Mz; ++k) {
-        if (tid == 0) La[k * ld + k] = sqrt(La[k * ld + k]);
-        __syncthreads();
-        const double piv = La[k * ld + k];
-        for (int i = k + 1 + tid; i < Mz; i += nt) La[i * ld + k] /= piv;
-        __syncthreads();
-        const int w = Mz - k - 1;
-        for (int e = tid; e < w * w; e += nt) {
-            int i = k + 1 + e / w, j = k + 1 + e % w;
-            if (j <= i) La[i * ld + j] -= La[i * ld + k] * La[j * ld + k];
+        const double r = 1.0 / Aug[k * la + k];
+        const int h = Mz - k - 1;                   // rows k+1 .. Mz-1, columns k+1 .. Mz+k
+        for (int e = tid; e < h * Mz; e += nt) {
+            const int i = k + 1 + e / Mz, j = k + 1 + e % Mz;
+            Aug[i * la + j] = fma(-(Aug[i * la + k] * r), Aug[k * la + j], Aug[i * la + j]);
         }
         __syncthreads();
     }
+    for (int k = tid; k < Mz; k += nt) rsd[k] = rsqrt(Aug[k * la + k]);
+    __syncthreads();
+    for (int e = tid; e < Mz * Mz; e += nt) {
+        const int i = e / Mz, j = e - i * Mz;
+        La[i * ld + j] = j <= i ? Aug[j * la + i] * rsd[j] : 0.0;
+        Li[i * ld + j] = j <= i ? Aug[i * la + Mz + j] * rsd[i] : 0.0;
+    }
+    __syncthreads();
+}
+
+template <bool TANGENTS>
+__global__ __launch_bounds__(kCovThreads) void cov_fwd_kernel(CovArgs a) {
+    extern __shared__ double sm[];
+    __shared__ double red[kCovThreads / VG_WAVE];
+    __shared__ double scal[8];
+    const int l = blockIdx.x, p = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+    const int M = a.M, Mz = M + 2, L = a.L, D = a.D;
+    const int Mp = (Mz + 15) & ~15, ld = Mp + 1;
+    const size_t pl = (size_t)p * L + l;
+    double* La = sm;                 // Cholesky factor Lk              (all Mp x ld, zero padded)
+    double* Li = La + Mp * ld;       // Lk^-1
+    double* Ks = Li + Mp * ld;       // Kuu (no jitter)
+    double* Qp = Ks + Mp * ld;       // pad(q_sqrt): Q at [2:, 2:]
+    double* Kd = Qp + Mp * ld;       // dK/dtheta, later scratch
+    double* T = Kd + Mp * ld;        // scratch
+    double* W = T + Mp * ld;         // scratch
+    double* zs = W + Mp * ld;        // [Mp] Zy[:, l]
+    double* dl = zs + Mp;            // [Mp] q_mu - p_mu
+    double* af = dl + Mp;            // [Mp] Lk^-1 (q_mu - p_mu)
+    double* v1 = af + Mp;            // [Mp] scratch
+
+    if (tid == 0) {
+        const double re = a.raw_ell[pl], rv = a.raw_var[pl];
+        scal[0] = softplus_d(re);
+        scal[1] = kVarFloor + softplus_d(rv);
+        a.ws.sig_ell[pl] = sigmoid_d(re);
+        a.ws.sig_var[pl] = sigmoid_d(rv);
+    }
+    for (int e = tid; e < 7 * Mp * ld + 4 * Mp; e += nt) sm[e] = 0.0;
+    __syncthreads();
+    for (int i = tid; i < Mz; i += nt) zs[i] = a.Zy[(size_t)i * D + l];
+    {
+        const double* Qg = a.q_sqrt + pl * M * M;
+        for (int e = tid; e < M * M; e += nt) {
+            const int r = e / M, c = e - r * M;
+            if (c <= r) Qp[(r + 2) * ld + (c + 2)] = Qg[e];
+        }
+    }
+    __syncthreads();
+    const double ell = scal[0], var = scal[1], jit = a.jitter;
+    if (tid == 0) { a.ws.ell[pl] = ell; a.ws.var[pl] = var; }
+    // Kuu and dKuu/dell share the exponential; symmetric: evaluate the lower triangle only
+    double* Kdg = a.ws.Kd_ell + pl * Mz * Mz;
     for (int e = tid; e < Mz * Mz; e += nt) {
         int i = e / Mz, j = e - i * Mz;
-        if (j > i) La[i * ld + j] = 0.0;
+        if (j > i) continue;
+        double r = fabs(zs[i] - zs[j]) / ell;
+        double ex = exp(-kSqrt5 * r);
+        double k = var * (1.0 + kSqrt5 * r + (5.0 / 3.0) * r * r) * ex;
+        double dk = var * ex * (5.0 * r * r / (3.0 * ell)) * (1.0 + kSqrt5 * r);
+        Ks[i * ld + j] = k;
+        La[i * ld + j] = k + (i == j ? jit : 0.0);
+        Kdg[(size_t)i * Mz + j] = dk;
+        if (i != j) { Ks[j * ld + i] = k; La[j * ld + i] = k; Kdg[(size_t)j * Mz + i] = dk; }
     }
     __syncthreads();
-    // ---- Lk^-1: one lane per column, forward substitution
-    if (tid < Mz) {
-        const int j = tid;
-        Li[j * ld + j] = 1.0 / La[j * ld + j];
-        for (int i = j + 1; i < Mz; ++i) {
-            double s = 0.0;
-            for (int k = j; k < i; ++k) s += La[i * ld + k] * Li[k * ld + j];
-            Li[i * ld + j] = -s / La[i * ld + i];
-        }
-    }
+    VG_STOP(a, 1);
+    chol_inverse_block(La, Li, Kd, v1, Mz, ld, tid, nt);      // Aug aliases the Kd/T/W scratch region
+    for (int e = tid; e < 3 * Mp * ld; e += nt) Kd[e] = 0.0;  // restore the zero padding of the scratch
     __syncthreads();
-    double* Lkg = a.ws.Lk + pl * Mz * Mz;
-    double* Lig = a.ws.Linv + pl * Mz * Mz;
+    VG_STOP(a, 3);
+    // ---- Kinv = Lk^-T Lk^-1 ; q_sqrt = Lk pad(Q) + jitter diag(1,1,0..)  (models/vgpmp.py:208-218)
     double* Kig = a.ws.Kinv + pl * Mz * Mz;
-    for (int e = tid; e < Mz * Mz; e += nt) {
-        int i = e / Mz, j = e - i * Mz;
-        double s = 0.0;
-        for (int k = (i > j ? i : j); k < Mz; ++k) s += Li[k * ld + i] * Li[k * ld + j];
-        Ki[i * ld + j] = s;
-        Kig[e] = s;
-        Lkg[e] = La[i * ld + j];
-        Lig[e] = Li[i * ld + j];
-    }
-    __syncthreads();
-    // ---- A = Kfu (Kuu + jitter I)^-1   [N, Mz]
-    double* A64 = a.ws.A64 + pl * N * Mz;
-    float* A32 = a.ws.A + pl * N * Mz;
-    for (int e = tid; e < N * Mz; e += nt) {
-        int n = e / Mz, m = e - n * Mz;
-        double s = 0.0;
-        for (int k = 0; k < Mz; ++k) s += Kufg[(size_t)k * N + n] * Ki[k * ld + m];
-        A64[e] = s;
-        A32[e] = (float)s;
-    }
-    // ---- q_sqrt = Lk pad(Q) + jitter diag(1,1,0..)      (models/vgpmp.py:208-218)
-    const double* Q = a.q_sqrt + pl * M * M;
+    float* Lk32 = a.ws.Lk32 + pl * Mz * Mz;
     float* C32 = a.ws.C + pl * Mz * Mz;
-    for (int e = tid; e < Mz * Mz; e += nt) {
-        int i = e / Mz, j = e - i * Mz;
-        double s = 0.0;
-        if (j >= 2) {
-            for (int k = j; k <= i; ++k) s += La[i * ld + k] * Q[(size_t)(k - 2) * M + (j - 2)];
-        }
-        if (i == j && i < 2) s += a.jitter;
-        C32[e] = (float)s;
-    }
-    // ---- q_mu (full) and the KL term  (models/vgpmp.py:200-202, prior_kl.py:16-35)
+    matmul_f64(MatView{Li, 1, ld}, MatView{Li, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
+        if (r < Mz && c < Mz) Kig[(size_t)r * Mz + c] = v;
+    });
+    matmul_f64(MatView{La, ld, 1}, MatView{Qp, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
+        if (r < Mz && c < Mz) C32[(size_t)r * Mz + c] = (float)(v + (r == c && r < 2 ? jit : 0.0));
+    });
+    for (int e = tid; e < Mz * Mz; e += nt) Lk32[e] = (float)La[(e / Mz) * ld + e % Mz];
+    VG_STOP(a, 4);
+    // ---- q_mu (full), KL and its gradient wrt q_mu / q_sqrt  (vgpmp.py:200-202, prior_kl.py:16-35)
     const double y0 = a.y_u[((size_t)p * 2 + 0) * L + l], y1 = a.y_u[((size_t)p * 2 + 1) * L + l];
-    const double k00 = Kg[0] + a.jitter, k01 = Kg[1], k11 = Kg[Mz + 1] + a.jitter;
+    const double k00 = Ks[0] + jit, k01 = Ks[1], k11 = Ks[ld + 1] + jit;
     const double det = k00 * k11 - k01 * k01;
     const double c0 = (k11 * y0 - k01 * y1) / det, c1 = (k00 * y1 - k01 * y0) / det;
-    __syncthreads();   // Kg written by other threads above
     for (int i = tid; i < Mz; i += nt) {
         double mi = i == 0 ? y0 : (i == 1 ? y1 : a.q_mu[pl * M + (i - 2)]);
         a.ws.m[pl * Mz + i] = (float)mi;
-        double ki0 = Kg[(size_t)i * Mz + 0] + (i == 0 ? a.jitter : 0.0);
-        double ki1 = Kg[(size_t)i * Mz + 1] + (i == 1 ? a.jitter : 0.0);
+        double ki0 = Ks[i * ld + 0] + (i == 0 ? jit : 0.0);
+        double ki1 = Ks[i * ld + 1] + (i == 1 ? jit : 0.0);
         dl[i] = mi - (ki0 * c0 + ki1 * c1);
     }
     __syncthreads();
     double klacc = 0.0;
     for (int i = tid; i < Mz; i += nt) {
-        double s = 0.0;
-        for (int k = 0; k <= i; ++k) s += Li[i * ld + k] * dl[k];
-        a.ws.afull[pl * Mz + i] = s;
+        const double s = dot4(Li + i * ld, 1, dl, 1, i + 1);
+        af[i] = s;
         if (i >= 2) klacc += s * s;
     }
+    double* gklQ = a.ws.gkl_Q + pl * M * M;
     for (int e = tid; e < M * M; e += nt) {
         int r = e / M, c = e - r * M;
+        double gq = 0.0;
         if (c <= r) {
-            double q = Q[e];
+            double q = Qp[(r + 2) * ld + (c + 2)];
             klacc += q * q;
-            if (c == r) klacc -= log(q * q);
+            gq = q;
+            if (c == r) { klacc -= log(q * q); gq -= 1.0 / q; }
         }
+        gklQ[e] = gq;
     }
-    double kl = block_sum(klacc, red);
-    if (tid == 0) {
-        a.ws.kl_l[pl] = 0.5 * (kl - (double)M);
-        a.ws.cvec[pl * 2] = c0;
-        a.ws.cvec[pl * 2 + 1] = c1;
+    double kl = block_sum(klacc, red);       // (contains __syncthreads: af is complete afterwards)
+    if (tid == 0) a.ws.kl_l[pl] = 0.5 * (kl - (double)M);
+    // d KL / d q_mu = (Lk^-T [0, 0, a])[2:]
+    for (int k = tid + 2; k < Mz; k += nt)
+        a.ws.gkl_qmu[pl * M + (k - 2)] = dot4(Li + k * ld + k, ld, af + k, 1, Mz - k);
+    if (!TANGENTS) return;
+    VG_STOP(a, 6);
+
+    // =================== forward-mode tangents wrt theta in {lengthscale, variance} ==============
+    //   W = Phi(Lk^-1 dK Lk^-T),  dLk = Lk W,  dC = dLk pad(Q)       (four 64-bit MFMA products each)
+    for (int th = (a.want_dell ? 0 : 1); th < 2; ++th) {
+        __syncthreads();
+        for (int e = tid; e < Mz * Mz; e += nt) {
+            int i = e / Mz, j = e - i * Mz;
+            Kd[i * ld + j] = th == 0 ? Kdg[e] : Ks[i * ld + j] / var;
+        }
+        __syncthreads();
+        matmul_f64(MatView{Li, ld, 1}, MatView{Kd, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) { T[r * ld + c] = v; });
+        __syncthreads();
+        matmul_f64(MatView{T, ld, 1}, MatView{Li, 1, ld}, Mp, tid, nt, [&](int r, int c, double v) {
+            W[r * ld + c] = c < r ? v : (c == r ? 0.5 * v : 0.0);
+        });
+        __syncthreads();
+        matmul_f64(MatView{La, ld, 1}, MatView{W, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) { T[r * ld + c] = v; });
+        __syncthreads();
+        float* CT = (th == 0 ? a.ws.CT_ell : a.ws.CT_var) + pl * Mz * Mz;
+        matmul_f64(MatView{T, ld, 1}, MatView{Qp, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
+            if (r < Mz && c < Mz) CT[(size_t)c * Mz + r] = (float)v;       // stored transposed
+        });
+        VG_STOP(a, 7 + 3 * th);
+        // KL tangent: a_dot = Lk^-1 (delta_dot - dLk a),  delta_dot = -d p_mu
+        const double d00 = Kd[0], d01 = Kd[1], d11 = Kd[ld + 1];
+        const double e0 = d00 * c0 + d01 * c1, e1 = d01 * c0 + d11 * c1;        // dKyy c
+        const double cd0 = -(k11 * e0 - k01 * e1) / det, cd1 = -(k00 * e1 - k01 * e0) / det;
+        for (int i = tid; i < Mz; i += nt) {
+            const double s = dot4(T + i * ld, 1, af, 1, i + 1);
+            double ki0 = Ks[i * ld + 0] + (i == 0 ? jit : 0.0);
+            double ki1 = Ks[i * ld + 1] + (i == 1 ? jit : 0.0);
+            double pd = Kd[i * ld + 0] * c0 + Kd[i * ld + 1] * c1 + ki0 * cd0 + ki1 * cd1;
+            v1[i] = -pd - s;
+        }
+        __syncthreads();
+        double acc = 0.0;
+        for (int i = tid; i < Mz; i += nt) {
+            if (i >= 2) acc += af[i] * dot4(Li + i * ld, 1, v1, 1, i + 1);
+        }
+        acc = block_sum(acc, red);
+        if (tid == 0) (th == 0 ? a.ws.gkl_ell : a.ws.gkl_var)[pl] = acc;
+    }
+}
+
+// A = Kfu (Kuu + jI)^-1 and its tangents for a tile of kRowTile time points:
+//   A_ell = (dKfu/dell - A dKuu/dell) Kinv,   A_var = (jitter / var) A Kinv
+// Output float32: A4[n][m] = {A, A_ell, A_var, 0} (one 16-byte load per use in the reverse pass)
+// and AT[m][n] for the forward path assembly.
+__global__ __launch_bounds__(kCovThreads) void cov_rows_kernel(CovArgs a) {
+    extern __shared__ double sm[];
+    const int tile = blockIdx.x, l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
+    const int M = a.M, Mz = M + 2, N = a.N, L = a.L, D = a.D, ld = Mz + 1;
+    const size_t pl = (size_t)p * L + l;
+    double* Ki = sm;                       // [Mz][ld]
+    double* Kd = Ki + Mz * ld;             // [Mz][ld]
+    double* kf = Kd + Mz * ld;             // [RT][Mz]  Kfu rows
+    double* df = kf + kRowTile * Mz;       // [RT][Mz]  dKfu/dell rows
+    double* ar = df + kRowTile * Mz;       // [RT][Mz]  A rows
+    double* yr = ar + kRowTile * Mz;       // [RT][Mz]
+    double* zs = yr + kRowTile * Mz;       // [Mz]
+    const double ell = a.ws.ell[pl], var = a.ws.var[pl];
+    const double* Kig = a.ws.Kinv + pl * Mz * Mz;
+    const double* Kdg = a.ws.Kd_ell + pl * Mz * Mz;
+    for (int e = tid; e < Mz * Mz; e += nt) {
+        int i = e / Mz, j = e - i * Mz;
+        Ki[i * ld + j] = Kig[e];
+        Kd[i * ld + j] = a.want_dell ? Kdg[e] : 0.0;
+    }
+    for (int i = tid; i < Mz; i += nt) zs[i] = a.Zy[(size_t)i * D + l];
+    __syncthreads();
+    const int n0 = tile * kRowTile;
+    for (int e = tid; e < kRowTile * Mz; e += nt) {
+        int r = e / Mz, m = e - r * Mz, n = n0 + r;
+        double k = 0.0, dk = 0.0;
+        if (n < N) {
+            double rr = fabs(a.X[(size_t)n * D + l] - zs[m]) / ell;
+            double ex = exp(-kSqrt5 * rr);
+            k = var * (1.0 + kSqrt5 * rr + (5.0 / 3.0) * rr * rr) * ex;
+            dk = var * ex * (5.0 * rr * rr / (3.0 * ell)) * (1.0 + kSqrt5 * rr);
+        }
+        kf[e] = k; df[e] = dk;
+    }
+    __syncthreads();
+    for (int e = tid; e < kRowTile * Mz; e += nt) {
+        int r = e / Mz, m = e - r * Mz;
+        ar[e] = dot4(kf + r * Mz, 1, Ki + m, ld, Mz);
+    }
+    __syncthreads();
+    float4* A4 = reinterpret_cast<float4*>(a.ws.A4) + pl * N * Mz;
+    float* AT = a.ws.AT + pl * N * Mz;
+    float av_keep[2] = {0.f, 0.f};
+    int cnt = 0;
+    for (int e = tid; e < kRowTile * Mz; e += nt, ++cnt) {
+        int r = e / Mz, m = e - r * Mz;
+        const double y = df[e] - dot4(ar + r * Mz, 1, Kd + m, ld, Mz);
+        const double v = dot4(ar + r * Mz, 1, Ki + m, ld, Mz);
+        yr[e] = y;
+        if (cnt < 2) av_keep[cnt] = (float)(a.jitter / var * v);
+    }
+    __syncthreads();
+    cnt = 0;
+    for (int e = tid; e < kRowTile * Mz; e += nt, ++cnt) {
+        int r = e / Mz, m = e - r * Mz, n = n0 + r;
+        if (n >= N) continue;
+        const double s = a.want_dell ? dot4(yr + r * Mz, 1, Ki + m, ld, Mz) : 0.0;
+        const float av = av_keep[cnt < 2 ? cnt : 1];
+        A4[(size_t)n * Mz + m] = make_float4((float)ar[e], (float)s, av, 0.f);
+        AT[(size_t)m * N + n] = (float)ar[e];
     }
 }
 
@@ -245,6 +446,8 @@ __global__ __launch_bounds__(kBlock) void cov_fwd_kernel(CovArgs a) {
 // Random Fourier features  Phi[l, j, b] = sqrt(2 var / B) cos(x_j . omega_lb / ell + beta_lb)
 // and dPhi/dell.  Points j < N are rows of X, the rest rows of Zy.
 // =================================================================================================
+__device__ __forceinline__ float softplus_f(float x) { return x > 15.f ? x : __logf(1.f + __expf(x)); }
+
 __global__ __launch_bounds__(kBlock) void features_kernel(int N, int Mz, int L, int D, int B,
                                                            const double* __restrict__ X,
                                                            const double* __restrict__ Zy,
@@ -257,18 +460,20 @@ __global__ __launch_bounds__(kBlock) void features_kernel(int N, int Mz, int L, 
     const int b = blockIdx.x * kBlock + threadIdx.x;
     const int j = blockIdx.y;
     const int l = blockIdx.z % L, p = blockIdx.z / L;
-    if (b >= B) return;
     const int J = N + Mz;
     const size_t pl = (size_t)p * L + l;
-    const float ell = (float)softplus_d(raw_ell[pl]);
-    const float var = (float)(kVarFloor + softplus_d(raw_var[pl]));
+    if (b >= B) return;
+    // float32 softplus of the unconstrained hyper-parameters (uniform per workgroup -> scalar loads)
+    const float ell = softplus_f((float)raw_ell[pl]);
+    const float var = (float)kVarFloor + softplus_f((float)raw_var[pl]);
     const double* pt = j < N ? X + (size_t)j * D : Zy + (size_t)(j - N) * D;
     const float* om = omega + (pl * B + b) * D;
     float proj = 0.f;
     for (int d = 0; d < D; ++d) proj = fmaf((float)pt[d], om[d], proj);
-    float sn, cs;
-    sincosf(proj / ell + beta[pl * B + b], &sn, &cs);
-    const float c = sqrtf(2.0f * var / (float)B);
+    // v_sin/v_cos take revolutions: reduce with fract (argument is a few tens of radians at most)
+    const float rev = __builtin_amdgcn_fractf((proj / ell + beta[pl * B + b]) * 0.15915494309189535f);
+    const float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
+    const float c = __builtin_amdgcn_sqrtf(2.0f * var / (float)B);
     const size_t o = (pl * J + j) * B + b;
     Phi[o] = c * cs;
     if (dPhi) dPhi[o] = c * sn * proj / (ell * ell);
@@ -347,157 +552,201 @@ __global__ __launch_bounds__(kBlock) void prior_gemm_kernel(int S, int L, int J,
 // =================================================================================================
 // Path assembly  (decoupled / Matheron update, vgpmp.py:281-282):
 //   u = m + C eps;  r = u - F0(Z) - sqrt(jitter) eps2;  f = F0(X) + A r
-// One workgroup per (sample chunk, latent, problem).
+// One workgroup per (chunk of VG_SC samples, latent, problem).
 // =================================================================================================
 struct PathArgs {
-    int S, N, Mz, L, SK;
-    size_t slab;
+    int S, N, Mz, L, SK, NC;
+    size_t slab, part_len;
     float sqrt_jitter;
-    const float *A, *C, *m, *F0, *H, *eps, *eps2;
+    const float4* A4;
+    const float *AT, *C, *CT_ell, *CT_var, *m, *F0, *H, *eps, *eps2;
     float *R, *f;
     const float* G;
     float* part;
-    size_t part_len;
-    int NC;
+    int want_dell;
+    int stop;
 };
 
-__device__ __forceinline__ float read_slabs(const float* base, size_t off, int SK, size_t slab) {
-    float v = base[off];
-    for (int k = 1; k < SK; ++k) v += base[off + (size_t)k * slab];
-    return v;
+// sum of the SK split-K slabs: SK unconditional loads issued together, then a fixed-order tree sum
+template <int SK>
+__device__ __forceinline__ float read_slabs(const float* base, size_t off, size_t slab) {
+    float v[SK];
+#pragma unroll
+    for (int k = 0; k < SK; ++k) v[k] = base[off + (size_t)k * slab];
+#pragma unroll
+    for (int w = SK / 2; w > 0; w >>= 1)
+#pragma unroll
+        for (int k = 0; k < w; ++k) v[k] += v[k + w];
+    return v[0];
 }
 
+// All operands of a workgroup are staged into LDS by ONE wave of independent coalesced loads (these
+// launches are latency bound: every dependent global access costs ~0.3-0.7 us), then the loops run
+// out of LDS.  Code is kept rolled: cold instruction fetch is the other fixed cost of tiny launches.
+template <int SK>
 __global__ __launch_bounds__(kBlock) void paths_fwd_kernel(PathArgs a) {
     extern __shared__ float smf[];
     const int ch = blockIdx.x, l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
     const int S = a.S, N = a.N, Mz = a.Mz, L = a.L, J = N + Mz, ld = Mz + 1;
     const size_t pl = (size_t)p * L + l;
     float* Cs = smf;                   // [Mz][ld]
-    float* As = Cs + Mz * ld;          // [N][ld]
-    float* rs = As + N * ld;           // [SC][ld]
-    for (int e = tid; e < Mz * Mz; e += nt) Cs[(e / Mz) * ld + e % Mz] = a.C[pl * Mz * Mz + e];
-    for (int e = tid; e < N * Mz; e += nt) As[(e / Mz) * ld + e % Mz] = a.A[pl * N * Mz + e];
-    __syncthreads();
+    float* ATs = Cs + Mz * ld;         // [Mz][N]
+    float* es = ATs + Mz * N;          // [SC][Mz]
+    float* e2s = es + VG_SC * Mz;      // [SC][Mz]
+    float* f0s = e2s + VG_SC * Mz;     // [SC][J]   prior draws (split-K slabs summed)
+    float* rs = f0s + VG_SC * J;       // [SC][Mz]
     const int s_base = ch * VG_SC;
+    for (int e = tid; e < Mz * Mz; e += nt) Cs[(e / Mz) * ld + e % Mz] = a.C[pl * Mz * Mz + e];
+    for (int e = tid; e < Mz * N; e += nt) ATs[e] = a.AT[pl * N * Mz + e];
+    for (int e = tid; e < VG_SC * Mz; e += nt) {
+        const int sl = e / Mz, k = e - sl * Mz, s = min(s_base + sl, S - 1);
+        const size_t o = (((size_t)p * S + s) * Mz + k) * L + l;
+        es[e] = a.eps[o];
+        e2s[e] = a.eps2[o];
+    }
+    for (int e = tid; e < VG_SC * J; e += nt) {
+        const int sl = e / J, j = e - sl * J, s = min(s_base + sl, S - 1);
+        f0s[e] = read_slabs<SK>(a.F0, (((size_t)p * S + s) * L + l) * J + j, a.slab);
+    }
+    __syncthreads();
     for (int e = tid; e < VG_SC * Mz; e += nt) {
         const int sl = e / Mz, mi = e - sl * Mz, s = s_base + sl;
-        float r = 0.f;
-        if (s < S) {
-            const float* ep = a.eps + ((size_t)p * S + s) * Mz * L + l;
-            float u = a.m[pl * Mz + mi];
-            for (int k = 0; k <= mi; ++k) u = fmaf(Cs[mi * ld + k], ep[(size_t)k * L], u);
-            const size_t fo = (((size_t)p * S + s) * L + l) * J + N + mi;
-            r = u - read_slabs(a.F0, fo, a.SK, a.slab) - a.sqrt_jitter * a.eps2[(((size_t)p * S + s) * Mz + mi) * L + l];
-            a.R[(((size_t)p * S + s) * L + l) * Mz + mi] = r;
-        }
-        rs[sl * ld + mi] = r;
+        float u = a.m[pl * Mz + mi];
+        for (int k = 0; k <= mi; ++k) u = fmaf(Cs[mi * ld + k], es[sl * Mz + k], u);
+        const float r = u - f0s[sl * J + N + mi] - a.sqrt_jitter * e2s[e];
+        rs[e] = r;
+        if (s < S) a.R[(((size_t)p * S + s) * L + l) * Mz + mi] = r;
     }
     __syncthreads();
     for (int e = tid; e < VG_SC * N; e += nt) {
         const int sl = e / N, n = e - sl * N, s = s_base + sl;
-        if (s >= S) continue;
-        float v = read_slabs(a.F0, (((size_t)p * S + s) * L + l) * J + n, a.SK, a.slab);
-        for (int k = 0; k < Mz; ++k) v = fmaf(As[n * ld + k], rs[sl * ld + k], v);
-        a.f[(((size_t)p * S + s) * L + l) * N + n] = v;
+        float v = f0s[sl * J + n];
+        for (int k = 0; k < Mz; ++k) v = fmaf(ATs[k * N + n], rs[sl * Mz + k], v);
+        if (s < S) a.f[(((size_t)p * S + s) * L + l) * N + n] = v;
     }
 }
 
-// Reverse of the path assembly, reduced over one chunk of samples:
-//   dR = G A;  dm = sum_s dR;  dC = dR^T eps;  dA = G^T R;
-//   s_var = <G, F0X> - <dR, F0Z>;  s_ell = <G, H_X> - <dR, H_Z>
+// Reverse of the path assembly over one chunk of samples.  With G = dloss/df:
+//   dR = G A,  dm = sum_s dR,  dC = dR^T eps                     (-> q_mu, q_sqrt)
+//   hyper-parameters by dot products with the forward-mode tangents of the covariance kernels:
+//   s_ell = <R, G A_ell> + <dR, C_ell eps> + <G, H_X> - <dR, H_Z>
+//   s_var = <R, G A_var> + <dR, C_var eps> ;  s_rff = <G, F0_X> - <dR, F0_Z>   (x 1/(2 var) later)
+template <int SK>
 __global__ __launch_bounds__(kBlock) void paths_bwd_kernel(PathArgs a) {
     extern __shared__ float smf[];
-    __shared__ float red[2][kBlock / VG_WAVE];
+    __shared__ float red[3][kBlock / VG_WAVE];
     const int ch = blockIdx.x, l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
-    const int S = a.S, N = a.N, Mz = a.Mz, L = a.L, J = N + Mz, ld = Mz + 1, ldn = N + 1;
+    const int S = a.S, N = a.N, Mz = a.Mz, L = a.L, J = N + Mz;
     const size_t pl = (size_t)p * L + l;
-    float* As = smf;                     // [N][ld]
-    float* Gs = As + N * ld;             // [SC][ldn]
-    float* Rs = Gs + VG_SC * ldn;        // [SC][ld]
-    float* Es = Rs + VG_SC * ld;         // [SC][ld]
-    float* dRs = Es + VG_SC * ld;        // [SC][ld]
+    float4* A4s = reinterpret_cast<float4*>(smf);      // [N][Mz] {A, A_ell, A_var, -}
+    float* Ces = smf + (size_t)4 * N * Mz;             // [Mz][Mz] (dC/dell)^T
+    float* Cvs = Ces + Mz * Mz;                         // [Mz][Mz] (dC/dvar)^T
+    float* Gs = Cvs + Mz * Mz;                          // [SC][N]
+    float* f0s = Gs + VG_SC * N;                        // [SC][J]
+    float* hs = f0s + VG_SC * J;                        // [SC][J]
+    float* Rs = hs + VG_SC * J;                         // [SC][Mz]
+    float* Es = Rs + VG_SC * Mz;                        // [SC][Mz]
+    float* dRs = Es + VG_SC * Mz;                       // [SC][Mz]
     const int s_base = ch * VG_SC;
-    for (int e = tid; e < N * Mz; e += nt) As[(e / Mz) * ld + e % Mz] = a.A[pl * N * Mz + e];
-    for (int e = tid; e < VG_SC * N; e += nt) {
-        const int sl = e / N, n = e - sl * N, s = s_base + sl;
-        Gs[sl * ldn + n] = s < S ? a.G[(((size_t)p * S + s) * L + l) * N + n] : 0.f;
-    }
-    for (int e = tid; e < VG_SC * Mz; e += nt) {
-        const int sl = e / Mz, mi = e - sl * Mz, s = s_base + sl;
-        Rs[sl * ld + mi] = s < S ? a.R[(((size_t)p * S + s) * L + l) * Mz + mi] : 0.f;
-        Es[sl * ld + mi] = s < S ? a.eps[(((size_t)p * S + s) * Mz + mi) * L + l] : 0.f;
-    }
-    __syncthreads();
-    float sv = 0.f, se = 0.f;
-    for (int e = tid; e < VG_SC * Mz; e += nt) {
-        const int sl = e / Mz, mi = e - sl * Mz, s = s_base + sl;
-        float d = 0.f;
-        for (int n = 0; n < N; ++n) d = fmaf(Gs[sl * ldn + n], As[n * ld + mi], d);
-        dRs[sl * ld + mi] = d;
-        if (s < S) {
-            const size_t fo = (((size_t)p * S + s) * L + l) * J + N + mi;
-            sv -= d * read_slabs(a.F0, fo, a.SK, a.slab);
-            if (a.H) se -= d * read_slabs(a.H, fo, a.SK, a.slab);
+    {
+        const float4* A4 = a.A4 + pl * N * Mz;
+        for (int e = tid; e < N * Mz; e += nt) A4s[e] = A4[e];
+        for (int e = tid; e < Mz * Mz; e += nt) {
+            Ces[e] = a.want_dell ? a.CT_ell[pl * Mz * Mz + e] : 0.f;
+            Cvs[e] = a.CT_var[pl * Mz * Mz + e];
+        }
+        for (int e = tid; e < VG_SC * N; e += nt) {
+            const int sl = e / N, n = e - sl * N, s = s_base + sl;
+            Gs[e] = s < S ? a.G[(((size_t)p * S + s) * L + l) * N + n] : 0.f;
+        }
+        for (int e = tid; e < VG_SC * J; e += nt) {
+            const int sl = e / J, j = e - sl * J, s = min(s_base + sl, S - 1);
+            const size_t fo = (((size_t)p * S + s) * L + l) * J + j;
+            f0s[e] = read_slabs<SK>(a.F0, fo, a.slab);
+            hs[e] = a.want_dell ? read_slabs<SK>(a.H, fo, a.slab) : 0.f;
+        }
+        for (int e = tid; e < VG_SC * Mz; e += nt) {
+            const int sl = e / Mz, mi = e - sl * Mz, s = s_base + sl;
+            Rs[e] = s < S ? a.R[(((size_t)p * S + s) * L + l) * Mz + mi] : 0.f;
+            Es[e] = s < S ? a.eps[(((size_t)p * S + s) * Mz + mi) * L + l] : 0.f;
         }
     }
+    __syncthreads();
+    VG_STOP(a, 1);
+    float se = 0.f, sv = 0.f, sr = 0.f;
+    for (int e = tid; e < VG_SC * Mz; e += nt) {
+        const int sl = e / Mz, mi = e - sl * Mz;
+        const float* g = Gs + sl * N;
+        float d = 0.f, de = 0.f, dv = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float4 av = A4s[n * Mz + mi];
+            const float gv = g[n];
+            d = fmaf(gv, av.x, d);
+            de = fmaf(gv, av.y, de);
+            dv = fmaf(gv, av.z, dv);
+        }
+        dRs[e] = d;
+        float ue = 0.f, uv = 0.f;
+        for (int k = 0; k <= mi; ++k) {
+            const float ev = Es[sl * Mz + k];
+            uv = fmaf(Cvs[k * Mz + mi], ev, uv);
+            ue = fmaf(Ces[k * Mz + mi], ev, ue);
+        }
+        const float rv = Rs[e];
+        sv += rv * dv + d * uv;
+        se += rv * de + d * ue - d * hs[sl * J + N + mi];
+        sr -= d * f0s[sl * J + N + mi];
+    }
     for (int e = tid; e < VG_SC * N; e += nt) {
-        const int sl = e / N, n = e - sl * N, s = s_base + sl;
-        if (s >= S) continue;
-        const size_t fo = (((size_t)p * S + s) * L + l) * J + n;
-        const float gv = Gs[sl * ldn + n];
-        sv = fmaf(gv, read_slabs(a.F0, fo, a.SK, a.slab), sv);
-        if (a.H) se = fmaf(gv, read_slabs(a.H, fo, a.SK, a.slab), se);
+        const int sl = e / N, n = e - sl * N;
+        const float gv = Gs[e];             // zero for samples beyond S
+        sr = fmaf(gv, f0s[sl * J + n], sr);
+        se = fmaf(gv, hs[sl * J + n], se);
     }
     __syncthreads();
+    VG_STOP(a, 3);
     float* out = a.part + (pl * a.NC + ch) * a.part_len;
     for (int mi = tid; mi < Mz; mi += nt) {
         float t = 0.f;
-        for (int sl = 0; sl < VG_SC; ++sl) t += dRs[sl * ld + mi];
+        for (int sl = 0; sl < VG_SC; ++sl) t += dRs[sl * Mz + mi];
         out[mi] = t;
     }
     float* oC = out + Mz;
     for (int e = tid; e < Mz * Mz; e += nt) {
         const int mi = e / Mz, k = e - mi * Mz;
         float t = 0.f;
-        for (int sl = 0; sl < VG_SC; ++sl) t = fmaf(dRs[sl * ld + mi], Es[sl * ld + k], t);
+        for (int sl = 0; sl < VG_SC; ++sl) t = fmaf(dRs[sl * Mz + mi], Es[sl * Mz + k], t);
         oC[e] = t;
     }
-    float* oA = oC + Mz * Mz;
-    for (int e = tid; e < N * Mz; e += nt) {
-        const int n = e / Mz, mi = e - n * Mz;
-        float t = 0.f;
-        for (int sl = 0; sl < VG_SC; ++sl) t = fmaf(Gs[sl * ldn + n], Rs[sl * ld + mi], t);
-        oA[e] = t;
-    }
-    sv = vg_wave_sum(sv); se = vg_wave_sum(se);
-    if ((tid & 63) == 0) { red[0][tid >> 6] = sv; red[1][tid >> 6] = se; }
+    se = vg_wave_sum(se); sv = vg_wave_sum(sv); sr = vg_wave_sum(sr);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = se; red[1][tid >> 6] = sv; red[2][tid >> 6] = sr; }
     __syncthreads();
     if (tid == 0) {
-        float t0 = 0.f, t1 = 0.f;
-        for (int k = 0; k < (int)(nt >> 6); ++k) { t0 += red[0][k]; t1 += red[1][k]; }
-        float* os = oA + (size_t)N * Mz;
-        os[0] = t0; os[1] = t1; os[2] = 0.f; os[3] = 0.f;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+        for (int k = 0; k < (int)(nt >> 6); ++k) { t0 += red[0][k]; t1 += red[1][k]; t2 += red[2][k]; }
+        float* os = oC + (size_t)Mz * Mz;
+        os[0] = t0; os[1] = t1; os[2] = t2; os[3] = 0.f;
     }
 }
 
 // =================================================================================================
-// Covariance path, reverse (float64) + Adam.  One workgroup per (latent, problem).
+// Gradient assembly + Adam.  One workgroup per (latent, problem).
 // =================================================================================================
-struct CovBwdArgs {
-    CovArgs c;
-    int NC;
+struct FinalArgs {
+    int M, L, NC, nblk;
     size_t part_len;
-    int nblk;                 // likelihood partial sums per problem
-    double lik_scale;         // alpha / S_total
+    const float *part, *Lk32, *lik_partial;
+    const double *gkl_qmu, *gkl_Q, *gkl_ell, *gkl_var, *kl_l, *var, *sig_ell, *sig_var;
+    double kl_scale, lik_scale;
     double *out_lik, *out_kl;
     double *g_qmu, *g_qsqrt, *g_ell, *g_var;
     int do_adam, trainable, want_dell;
-    double lr_t;              // lr * sqrt(1 - b2^t) / (1 - b1^t)
-    double lr;
+    double lr_t, lr;
     const uint32_t* ctr;      // device step counter (1-based Adam step after the tick) or null
-    double *mq_mu, *mq_sqrt, *m_ell, *m_var;      // Adam first moments (alias of params layout)
+    double *mq_mu, *mq_sqrt, *m_ell, *m_var;      // Adam moments
     double *vq_mu, *vq_sqrt, *v_ell, *v_var;
     double *pq_mu, *pq_sqrt, *p_ell, *p_var;      // parameters (updated in place)
+    int stop;
 };
 
 __device__ __forceinline__ void adam_update(double* x, double* m, double* v, double g, double lr_t) {
@@ -508,200 +757,102 @@ __device__ __forceinline__ void adam_update(double* x, double* m, double* v, dou
     *x -= lr_t * mm / (sqrt(vv) + 1e-7);
 }
 
-__global__ __launch_bounds__(kBlock) void cov_bwd_kernel(CovBwdArgs b) {
+__global__ __launch_bounds__(kBlock) void final_kernel(FinalArgs b) {
     extern __shared__ double sm[];
-    __shared__ double red[kBlock / VG_WAVE];
-    const CovArgs a = b.c;
+    __shared__ double lrs;
+    VG_STOP(b, 7);
     const int l = blockIdx.x, p = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
-    const int M = a.M, Mz = M + 2, N = a.N, L = a.L, D = a.D, ld = Mz + 1;
+    const int M = b.M, Mz = M + 2, L = b.L;
     const size_t pl = (size_t)p * L + l;
-    double* M0 = sm;                 // dC, later U
-    double* M1 = M0 + Mz * ld;       // T1, later P
-    double* M2 = M1 + Mz * ld;       // dKj
-    double* M3 = M2 + Mz * ld;       // dLk, later S
-    double* dmv = M3 + Mz * ld;      // [Mz]
-    double* ddv = dmv + Mz;          // [Mz]
-    double* zs = ddv + Mz;           // [Mz]
-    double* sc = zs + Mz;            // [8] scalars
-    const double ell = a.ws.ell[pl], var = a.ws.var[pl];
-    const double kls = a.kl_scale;
-    const double* Kg = a.ws.K + pl * Mz * Mz;
-    const double* Lkg = a.ws.Lk + pl * Mz * Mz;
-    const double* Lig = a.ws.Linv + pl * Mz * Mz;
-    const double* Kig = a.ws.Kinv + pl * Mz * Mz;
-    const double* Kufg = a.ws.Kuf + pl * Mz * N;
-    const double* A64 = a.ws.A64 + pl * N * Mz;
-    const double* af = a.ws.afull + pl * Mz;
-    double* dA = a.ws.dA64 + pl * N * Mz;
-    const double* Q = a.q_sqrt + pl * M * M;
-    const float* part = a.ws.part + pl * b.NC * b.part_len;
-
-    // ---- 1. sum the per-chunk partial reductions (float32 -> float64)
-    for (int i = tid; i < Mz; i += nt) {
+    double* dC = sm;                 // [Mz][Mz]
+    double* dmv = dC + Mz * Mz;      // [Mz]
+    double* sc = dmv + Mz;           // [4]
+    float* Lks = reinterpret_cast<float*>(sc + 4);   // [Mz][Mz] chol factor
+    const float* part = b.part + pl * b.NC * b.part_len;
+    const float* Lkg = b.Lk32 + pl * Mz * Mz;
+    for (int e = tid; e < Mz * Mz; e += nt) Lks[e] = Lkg[e];
+    VG_STOP(b, 5);
+    // sum the per-chunk partials; 8 independent loads in flight per pass
+    for (int e = tid; e < Mz + Mz * Mz + 3; e += nt) {
         double s = 0.0;
-        for (int c = 0; c < b.NC; ++c) s += (double)part[c * b.part_len + i];
-        dmv[i] = s;
-        zs[i] = a.Zy[(size_t)i * D + l];
-    }
-    for (int e = tid; e < Mz * Mz; e += nt) {
-        double s = 0.0;
-        for (int c = 0; c < b.NC; ++c) s += (double)part[c * b.part_len + Mz + e];
-        M0[(e / Mz) * ld + e % Mz] = s;
-    }
-    for (int e = tid; e < N * Mz; e += nt) {
-        double s = 0.0;
-        for (int c = 0; c < b.NC; ++c) s += (double)part[c * b.part_len + Mz + Mz * Mz + e];
-        dA[e] = s;
-    }
-    if (tid < 2) {
-        double s = 0.0;
-        for (int c = 0; c < b.NC; ++c) s += (double)part[c * b.part_len + Mz + Mz * Mz + (size_t)N * Mz + tid];
-        sc[tid] = s;      // sc[0] = s_var, sc[1] = s_ell
-    }
-    __syncthreads();
-    // ---- 2. T1 = A^T dA
-    for (int e = tid; e < Mz * Mz; e += nt) {
-        int i = e / Mz, j = e - i * Mz;
-        double s = 0.0;
-        for (int n = 0; n < N; ++n) s += A64[(size_t)n * Mz + i] * dA[(size_t)n * Mz + j];
-        M1[i * ld + j] = s;
-    }
-    __syncthreads();
-    // ---- 3. dKj = -T1 Kinv ; dLk = dC Qp^T (lower) ; dQ = tril(Lk^T dC)[2:,2:] ; dKfu contraction
-    double acc_var = 0.0, acc_ell = 0.0;
-    for (int e = tid; e < Mz * Mz; e += nt) {
-        int i = e / Mz, j = e - i * Mz;
-        double s = 0.0;
-        for (int k = 0; k < Mz; ++k) s += M1[i * ld + k] * Kig[(size_t)k * Mz + j];
-        M2[i * ld + j] = -s;
-        double t = 0.0;
-        if (j <= i && j >= 2) {
-            // dLk[i][j] = sum_c dC[i][c] Qp[j][c],  Qp[j][c] = Q[j-2][c-2] for 2 <= c <= j
-            for (int c = 2; c <= j; ++c) t += M0[i * ld + c] * Q[(size_t)(j - 2) * M + (c - 2)];
+        for (int c0 = 0; c0 < b.NC; c0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {          // unconditional loads (clamped), masked afterwards
+                const int c = c0 + k < b.NC ? c0 + k : b.NC - 1;
+                v[k] = part[(size_t)c * b.part_len + e];
+            }
+            double d[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] = c0 + k < b.NC ? (double)v[k] : 0.0;
+            s += ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
         }
-        M3[i * ld + j] = t;
+        if (e < Mz) dmv[e] = s;
+        else if (e < Mz + Mz * Mz) dC[e - Mz] = s;
+        else sc[e - Mz - Mz * Mz] = s;
     }
+    VG_STOP(b, 6);
+    if (tid == 0) {
+        double lr_t = b.lr_t;
+        if (b.do_adam && b.ctr) {
+            const double t = (double)*b.ctr;
+            lr_t = b.lr * sqrt(1.0 - exp(t * -0.05129329438755058)) / (1.0 - exp(t * -0.2231435513142098));
+        }
+        lrs = lr_t;
+    }
+    __syncthreads();
+    VG_STOP(b, 1);
+    const double kls = b.kl_scale;
     double* gQ = b.g_qsqrt + pl * M * M;
+    const double* kQ = b.gkl_Q + pl * M * M;
+    const bool adam_q = b.do_adam && (b.trainable & VGPMP_TRAIN_Q_SQRT);
+    const double lr_t = lrs;
     for (int e = tid; e < M * M; e += nt) {
         int r = e / M, c = e - r * M;
         double s = 0.0;
         if (c <= r) {
-            for (int i = r + 2; i < Mz; ++i) s += Lkg[(size_t)i * Mz + (r + 2)] * M0[i * ld + (c + 2)];
-            double q = Q[e];
-            s += kls * (q - (c == r ? 1.0 / q : 0.0));
+            // tril(Lk^T dC)[2:, 2:]
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int i = r + 2;
+            for (; i + 3 < Mz; i += 4) {
+                s0 = fma((double)Lks[i * Mz + (r + 2)], dC[i * Mz + (c + 2)], s0);
+                s1 = fma((double)Lks[(i + 1) * Mz + (r + 2)], dC[(i + 1) * Mz + (c + 2)], s1);
+                s2 = fma((double)Lks[(i + 2) * Mz + (r + 2)], dC[(i + 2) * Mz + (c + 2)], s2);
+                s3 = fma((double)Lks[(i + 3) * Mz + (r + 2)], dC[(i + 3) * Mz + (c + 2)], s3);
+            }
+            for (; i < Mz; ++i) s0 = fma((double)Lks[i * Mz + (r + 2)], dC[i * Mz + (c + 2)], s0);
+            s = (s0 + s1) + (s2 + s3) + kls * kQ[e];
+            if (adam_q)
+                adam_update(b.pq_sqrt + pl * M * M + e, b.mq_sqrt + pl * M * M + e, b.vq_sqrt + pl * M * M + e, s, lr_t);
         }
         gQ[e] = s;
     }
-    for (int e = tid; e < N * Mz; e += nt) {
-        int n = e / Mz, mi = e - n * Mz;
-        double s = 0.0;
-        for (int k = 0; k < Mz; ++k) s += dA[(size_t)n * Mz + k] * Kig[(size_t)k * Mz + mi];
-        const double xn = a.X[(size_t)n * D + l];
-        acc_var += s * Kufg[(size_t)mi * N + n];
-        acc_ell += s * matern52_dell(xn, zs[mi], ell, var);
-    }
-    // ---- 4. KL reverse: ddelta = Lk^-T [0,0,a]
-    for (int k = tid; k < Mz; k += nt) {
-        double s = 0.0;
-        for (int i = (k > 2 ? k : 2); i < Mz; ++i) s += Lig[(size_t)i * Mz + k] * af[i];
-        ddv[k] = s;
-    }
-    __syncthreads();
-    const double c0 = a.ws.cvec[pl * 2], c1 = a.ws.cvec[pl * 2 + 1];
-    for (int e = tid; e < Mz * Mz; e += nt) {
-        int i = e / Mz, j = e - i * Mz;
-        if (j <= i) M3[i * ld + j] -= kls * ddv[i] * af[j];
-        if (j < 2) M2[i * ld + j] += kls * (-ddv[i]) * (j == 0 ? c0 : c1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double d0 = 0.0, d1 = 0.0;
-        for (int i = 0; i < Mz; ++i) {
-            d0 += (Kg[(size_t)i * Mz + 0] + (i == 0 ? a.jitter : 0.0)) * (-ddv[i]);
-            d1 += (Kg[(size_t)i * Mz + 1] + (i == 1 ? a.jitter : 0.0)) * (-ddv[i]);
-        }
-        const double k00 = Kg[0] + a.jitter, k01 = Kg[1], k11 = Kg[Mz + 1] + a.jitter;
-        const double det = k00 * k11 - k01 * k01;
-        const double w0 = (k11 * d0 - k01 * d1) / det, w1 = (k00 * d1 - k01 * d0) / det;
-        M2[0 * ld + 0] -= kls * w0 * c0; M2[0 * ld + 1] -= kls * w0 * c1;
-        M2[1 * ld + 0] -= kls * w1 * c0; M2[1 * ld + 1] -= kls * w1 * c1;
-    }
-    __syncthreads();
-    // ---- 5. P = Phi(Lk^T tril(dLk))
-    for (int e = tid; e < Mz * Mz; e += nt) {
-        int i = e / Mz, j = e - i * Mz;
-        double s = 0.0;
-        if (j <= i) {
-            for (int k = i; k < Mz; ++k) s += Lkg[(size_t)k * Mz + i] * M3[k * ld + j];
-            if (i == j) s *= 0.5;
-        }
-        M1[i * ld + j] = s;
-    }
-    __syncthreads();
-    // ---- 6. U = P Lk^-1 (lower)
-    for (int e = tid; e < Mz * Mz; e += nt) {
-        int i = e / Mz, j = e - i * Mz;
-        double s = 0.0;
-        if (j <= i)
-            for (int k = j; k <= i; ++k) s += M1[i * ld + k] * Lig[(size_t)k * Mz + j];
-        M0[i * ld + j] = s;
-    }
-    __syncthreads();
-    // ---- 7. Sm = Lk^-T U
-    for (int e = tid; e < Mz * Mz; e += nt) {
-        int i = e / Mz, j = e - i * Mz;
-        double s = 0.0;
-        for (int k = (i > j ? i : j); k < Mz; ++k) s += Lig[(size_t)k * Mz + i] * M0[k * ld + j];
-        M3[i * ld + j] = s;
-    }
-    __syncthreads();
-    // ---- 8. dKj += sym(Sm); contract with K and dK/dell
-    for (int e = tid; e < Mz * Mz; e += nt) {
-        int i = e / Mz, j = e - i * Mz;
-        double dk = M2[i * ld + j] + 0.5 * (M3[i * ld + j] + M3[j * ld + i]);
-        acc_var += dk * Kg[e];
-        acc_ell += dk * matern52_dell(zs[i], zs[j], ell, var);
-    }
-    acc_var = block_sum(acc_var, red);
-    acc_ell = block_sum(acc_ell, red);
-    // ---- 9. outputs
-    const double g_var = (acc_var / var + sc[0] / (2.0 * var)) * sigmoid_d(a.raw_var[pl]);
-    const double g_ell = (acc_ell + (b.want_dell ? sc[1] : 0.0)) * sigmoid_d(a.raw_ell[pl]);
+    VG_STOP(b, 2);
     double* gm = b.g_qmu + pl * M;
-    for (int i = tid; i < M; i += nt) gm[i] = dmv[i + 2] + kls * ddv[i + 2];
-    if (tid == 0) {
-        b.g_ell[pl] = g_ell;
-        b.g_var[pl] = g_var;
+    for (int i = tid; i < M; i += nt) {
+        const double g = dmv[i + 2] + kls * b.gkl_qmu[pl * M + i];
+        gm[i] = g;
+        if (b.do_adam && (b.trainable & VGPMP_TRAIN_Q_MU))
+            adam_update(b.pq_mu + pl * M + i, b.mq_mu + pl * M + i, b.vq_mu + pl * M + i, g, lr_t);
+    }
+    if (tid == 64) {
+        const double var = b.var[pl];
+        const double g_ell = ((b.want_dell ? sc[0] : 0.0) + kls * b.gkl_ell[pl]) * b.sig_ell[pl];
+        const double g_var = (sc[1] + sc[2] / (2.0 * var) + kls * b.gkl_var[pl]) * b.sig_var[pl];
+        b.g_ell[pl] = g_ell; b.g_var[pl] = g_var;
+        if (b.do_adam) {
+            if (b.trainable & VGPMP_TRAIN_LENGTHSCALES) adam_update(b.p_ell + pl, b.m_ell + pl, b.v_ell + pl, g_ell, lr_t);
+            if (b.trainable & VGPMP_TRAIN_KERNEL_VARIANCE) adam_update(b.p_var + pl, b.m_var + pl, b.v_var + pl, g_var, lr_t);
+        }
     }
     if (l == 0 && tid < 64) {
-        // ELBO pieces of this problem: alpha/S * sum logp, and KL summed over the latents
         double s = 0.0;
-        for (int k = tid; k < b.nblk; k += 64) s += (double)a.ws.lik_partial[(size_t)p * b.nblk + k];
+        for (int k = tid; k < b.nblk; k += 64) s += (double)b.lik_partial[(size_t)p * b.nblk + k];
         s = vg_wave_sum(s);
         double kk = 0.0;
-        for (int k = tid; k < L; k += 64) kk += a.ws.kl_l[(size_t)p * L + k];
+        for (int k = tid; k < L; k += 64) kk += b.kl_l[(size_t)p * L + k];
         kk = vg_wave_sum(kk);
         if (tid == 0) { b.out_lik[p] = b.lik_scale * s; b.out_kl[p] = kls * kk; }
-    }
-    if (!b.do_adam) return;
-    __syncthreads();
-    if (b.ctr) {
-        const double t = (double)*b.ctr;
-        b.lr_t = b.lr * sqrt(1.0 - pow(0.95, t)) / (1.0 - pow(0.8, t));
-    }
-    if (b.trainable & VGPMP_TRAIN_Q_MU)
-        for (int i = tid; i < M; i += nt)
-            adam_update(b.pq_mu + pl * M + i, b.mq_mu + pl * M + i, b.vq_mu + pl * M + i, gm[i], b.lr_t);
-    if (b.trainable & VGPMP_TRAIN_Q_SQRT)
-        for (int e = tid; e < M * M; e += nt) {
-            int r = e / M, c = e - r * M;
-            if (c <= r)
-                adam_update(b.pq_sqrt + pl * M * M + e, b.mq_sqrt + pl * M * M + e, b.vq_sqrt + pl * M * M + e, gQ[e],
-                            b.lr_t);
-        }
-    if (tid == 0) {
-        if (b.trainable & VGPMP_TRAIN_LENGTHSCALES) adam_update(b.p_ell + pl, b.m_ell + pl, b.v_ell + pl, g_ell, b.lr_t);
-        if (b.trainable & VGPMP_TRAIN_KERNEL_VARIANCE) adam_update(b.p_var + pl, b.m_var + pl, b.v_var + pl, g_var, b.lr_t);
     }
 }
 
@@ -749,7 +900,7 @@ int vg_check_dims(const vgpmp_dims* d) {
     if (d->M + 2 > VGPMP_MAX_MZ || d->L > VGPMP_MAX_DOF || (d->B % 16) != 0) return VGPMP_E_SHAPE;
     if (d->split_k != 1 && d->split_k != 2 && d->split_k != 4 && d->split_k != 8) return VGPMP_E_SHAPE;
     if ((d->B / d->split_k) % 16 != 0) return VGPMP_E_SHAPE;
-    if (d->N > 1024) return VGPMP_E_SHAPE;
+    if (d->N > 4096) return VGPMP_E_SHAPE;
     return 0;
 }
 
@@ -757,22 +908,25 @@ size_t vg_layout_workspace(const vgpmp_dims* d, void* base, vg_workspace* ws) {
     const bool real = base != nullptr;
     char* cur = real ? (char*)base : (char*)(uintptr_t)256;
     char* start = cur;
-    const size_t P = d->num_problems, L = d->L, N = d->N, Mz = vg_mz(d), J = vg_j(d), S = d->S, B = d->B;
+    const size_t P = d->num_problems, L = d->L, N = d->N, Mz = vg_mz(d), J = vg_j(d), S = d->S, B = d->B, M = d->M;
     const size_t PL = P * L;
     ws->ell = carve<double>(cur, PL, real);
     ws->var = carve<double>(cur, PL, real);
-    ws->K = carve<double>(cur, PL * Mz * Mz, real);
-    ws->Lk = carve<double>(cur, PL * Mz * Mz, real);
-    ws->Linv = carve<double>(cur, PL * Mz * Mz, real);
+    ws->sig_ell = carve<double>(cur, PL, real);
+    ws->sig_var = carve<double>(cur, PL, real);
     ws->Kinv = carve<double>(cur, PL * Mz * Mz, real);
-    ws->Kuf = carve<double>(cur, PL * Mz * N, real);
-    ws->A64 = carve<double>(cur, PL * N * Mz, real);
-    ws->afull = carve<double>(cur, PL * Mz, real);
-    ws->cvec = carve<double>(cur, PL * 2, real);
+    ws->Kd_ell = carve<double>(cur, PL * Mz * Mz, real);
     ws->kl_l = carve<double>(cur, PL, real);
-    ws->dA64 = carve<double>(cur, PL * N * Mz, real);
-    ws->A = carve<float>(cur, PL * N * Mz, real);
+    ws->gkl_qmu = carve<double>(cur, PL * M, real);
+    ws->gkl_Q = carve<double>(cur, PL * M * M, real);
+    ws->gkl_ell = carve<double>(cur, PL, real);
+    ws->gkl_var = carve<double>(cur, PL, real);
+    ws->A4 = carve<float>(cur, PL * N * Mz * 4, real);
+    ws->AT = carve<float>(cur, PL * N * Mz, real);
     ws->C = carve<float>(cur, PL * Mz * Mz, real);
+    ws->CT_ell = carve<float>(cur, PL * Mz * Mz, real);
+    ws->CT_var = carve<float>(cur, PL * Mz * Mz, real);
+    ws->Lk32 = carve<float>(cur, PL * Mz * Mz, real);
     ws->m = carve<float>(cur, PL * Mz, real);
     ws->Phi = carve<float>(cur, PL * J * B, real);
     ws->dPhi = carve<float>(cur, PL * J * B, real);
@@ -789,7 +943,7 @@ int vg_workspace_lookup(const vgpmp_dims* d, const vg_workspace* ws, const char*
                         int32_t* is_double) {
     const size_t P = d->num_problems, L = d->L, N = d->N, Mz = vg_mz(d), J = vg_j(d), S = d->S, B = d->B;
     *is_double = 0;
-    if (!strcmp(name, "A")) { *ptr = ws->A; *count = P * L * N * Mz; }
+    if (!strcmp(name, "A4")) { *ptr = ws->A4; *count = P * L * N * Mz * 4; }
     else if (!strcmp(name, "C")) { *ptr = ws->C; *count = P * L * Mz * Mz; }
     else if (!strcmp(name, "m")) { *ptr = ws->m; *count = P * L * Mz; }
     else if (!strcmp(name, "Phi")) { *ptr = ws->Phi; *count = P * L * J * B; }
@@ -799,7 +953,6 @@ int vg_workspace_lookup(const vgpmp_dims* d, const vg_workspace* ws, const char*
     else if (!strcmp(name, "G")) { *ptr = ws->G; *count = P * S * L * N; }
     else if (!strcmp(name, "kl_l")) { *ptr = ws->kl_l; *count = P * L; *is_double = 1; }
     else if (!strcmp(name, "Kinv")) { *ptr = ws->Kinv; *count = P * L * Mz * Mz; *is_double = 1; }
-    else if (!strcmp(name, "Lk")) { *ptr = ws->Lk; *count = P * L * Mz * Mz; *is_double = 1; }
     else return VGPMP_E_ARG;
     return 0;
 }
@@ -833,42 +986,75 @@ int vg_launch_adam(const vgpmp_dims* d, const vgpmp_params* x, const vgpmp_param
     return (int)hipGetLastError();
 }
 
+// Raises a kernel's dynamic-LDS limit when needed.  The attribute call is a slow host operation, so
+// the largest size already granted per kernel is remembered (benign race: worst case a repeat call).
 static int set_dyn_lds(const void* fn, size_t bytes) {
     if (bytes > 160 * 1024) return VGPMP_E_SHAPE;
-    if (bytes > 48 * 1024) VG_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (bytes <= 48 * 1024) return 0;
+    constexpr int kSlots = 16;
+    static const void* fns[kSlots];
+    static size_t granted[kSlots];
+    int slot = -1;
+    for (int i = 0; i < kSlots; ++i) {
+        if (fns[i] == fn) { slot = i; break; }
+        if (fns[i] == nullptr) { fns[i] = fn; slot = i; break; }
+    }
+    if (slot >= 0 && granted[slot] >= bytes) return 0;
+    VG_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (slot >= 0) granted[slot] = bytes;
     return 0;
 }
-
 
 int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sdf, const vgpmp_problem* pb,
                  const vgpmp_params* params, const vgpmp_params* am, const vgpmp_params* av, const vgpmp_noise* nz,
                  const vgpmp_outputs* out, const vg_workspace* ws, int what, int trainable, double lr, int adam_t,
                  uint32_t seed, uint32_t problem_base, uint32_t step, hipStream_t st, hipEvent_t* ev) {
     const int P = d->num_problems, S = d->S, N = d->N, M = d->M, L = d->L, B = d->B, Mz = M + 2, J = N + Mz;
-    int evi = 0;
-    auto mark = [&]() { if (ev) (void)hipEventRecord(ev[evi++], st); };
-    uint32_t* ctr = pb->step_counter;
-    mark();
     const int SK = d->split_k, NC = vg_chunks(d);
     const bool backward = (what & VGPMP_DO_BACKWARD) != 0;
     const bool want_dell = backward && (trainable & VGPMP_TRAIN_LENGTHSCALES);
+    int evi = 0;
+    auto mark = [&]() { if (ev) (void)hipEventRecord(ev[evi++], st); };
+    uint32_t* ctr = pb->step_counter;
     int rc;
+    // ---- covariance path (float64): on the side stream when the caller provides one, so that it
+    //      overlaps the noise / feature / GEMM branch; joined before the path assembly.
+    CovArgs ca;
+    ca.N = N; ca.M = M; ca.L = L; ca.D = L;
+    ca.X = pb->X; ca.Zy = pb->Zy; ca.y_u = pb->y_u; ca.jitter = pb->jitter;
+    ca.q_mu = params->q_mu; ca.q_sqrt = params->q_sqrt; ca.raw_ell = params->raw_ell; ca.raw_var = params->raw_var;
+    ca.want_dell = want_dell ? 1 : 0;
+    ca.stop = -1;
+#ifdef VGPMP_BISECT
+    ca.stop = vg_bisect_stop("VGPMP_STOP_COV");
+#endif
+    ca.ws = *ws;
+    const int Mp = (Mz + 15) & ~15;
+    const size_t lds_cov = ((size_t)7 * Mp * (Mp + 1) + 4 * Mp) * sizeof(double);
+    const size_t lds_rows = ((size_t)2 * Mz * (Mz + 1) + (size_t)4 * kRowTile * Mz + Mz) * sizeof(double);
+    const bool fork = !ev && pb->side_stream && pb->fork_event && pb->join_event;
+    hipStream_t cst = fork ? (hipStream_t)pb->side_stream : st;
+    mark();
+    if (fork) {
+        VG_CHECK_HIP(hipEventRecord((hipEvent_t)pb->fork_event, st));
+        VG_CHECK_HIP(hipStreamWaitEvent(cst, (hipEvent_t)pb->fork_event, 0));
+    }
+    {
+        const void* fn = backward ? (const void*)cov_fwd_kernel<true> : (const void*)cov_fwd_kernel<false>;
+        rc = set_dyn_lds(fn, lds_cov);
+        if (rc) return rc;
+        void* kargs[] = {(void*)&ca};
+        VG_CHECK_HIP(hipLaunchKernel(fn, dim3(L, P), dim3(kCovThreads), kargs, lds_cov, cst));
+        rc = set_dyn_lds((const void*)cov_rows_kernel, lds_rows);
+        if (rc) return rc;
+        hipLaunchKernelGGL(cov_rows_kernel, dim3((N + kRowTile - 1) / kRowTile, L, P), dim3(kCovThreads), lds_rows, cst, ca);
+    }
+    if (fork) VG_CHECK_HIP(hipEventRecord((hipEvent_t)pb->join_event, cst));
+    mark();
     if (what & VGPMP_GEN_NOISE) {
         rc = vg_launch_rng(d, nz, seed, problem_base, step, ctr, st);
         if (rc) return rc;
     }
-    mark();
-    // ---- covariance path (float64)
-    CovArgs ca;
-    ca.N = N; ca.M = M; ca.L = L; ca.D = L;
-    ca.X = pb->X; ca.Zy = pb->Zy; ca.y_u = pb->y_u;
-    ca.jitter = pb->jitter; ca.kl_scale = pb->kl_scale;
-    ca.q_mu = params->q_mu; ca.q_sqrt = params->q_sqrt; ca.raw_ell = params->raw_ell; ca.raw_var = params->raw_var;
-    ca.ws = *ws;
-    const size_t lds_cov = ((size_t)3 * Mz * (Mz + 1) + 2 * Mz) * sizeof(double);
-    rc = set_dyn_lds((const void*)cov_fwd_kernel, lds_cov);
-    if (rc) return rc;
-    hipLaunchKernelGGL(cov_fwd_kernel, dim3(L, P), dim3(kBlock), lds_cov, st, ca);
     mark();
     // ---- features and prior GEMM
     hipLaunchKernelGGL(features_kernel, dim3((B + kBlock - 1) / kBlock, J, P * L), dim3(kBlock), 0, st, N, Mz, L, L, B,
@@ -880,17 +1066,28 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
     hipLaunchKernelGGL(prior_gemm_kernel, dim3((J + 16 * kNT - 1) / (16 * kNT), (S + 63) / 64, P * L * SK * nsel),
                        dim3(kBlock), 0, st, S, L, J, B, SK, nsel, nz->w, ws->Phi, ws->dPhi, ws->F0, ws->H, slab);
     mark();
+    if (fork) VG_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)pb->join_event, 0));
     // ---- path assembly
     PathArgs pa;
-    pa.S = S; pa.N = N; pa.Mz = Mz; pa.L = L; pa.SK = SK; pa.slab = slab;
+    pa.S = S; pa.N = N; pa.Mz = Mz; pa.L = L; pa.SK = SK; pa.NC = NC; pa.slab = slab; pa.part_len = vg_part_len(d);
     pa.sqrt_jitter = (float)sqrt(pb->jitter);
-    pa.A = ws->A; pa.C = ws->C; pa.m = ws->m; pa.F0 = ws->F0; pa.H = want_dell ? ws->H : nullptr;
+    pa.A4 = reinterpret_cast<const float4*>(ws->A4); pa.AT = ws->AT;
+    pa.C = ws->C; pa.CT_ell = ws->CT_ell; pa.CT_var = ws->CT_var; pa.m = ws->m;
+    pa.F0 = ws->F0; pa.H = ws->H; pa.want_dell = want_dell ? 1 : 0;
     pa.eps = nz->eps; pa.eps2 = nz->eps2; pa.R = ws->R; pa.f = out->f; pa.G = ws->G; pa.part = ws->part;
-    pa.part_len = vg_part_len(d); pa.NC = NC;
-    const size_t lds_pf = ((size_t)Mz * (Mz + 1) + (size_t)N * (Mz + 1) + (size_t)VG_SC * (Mz + 1)) * sizeof(float);
-    rc = set_dyn_lds((const void*)paths_fwd_kernel, lds_pf);
-    if (rc) return rc;
-    hipLaunchKernelGGL(paths_fwd_kernel, dim3(NC, L, P), dim3(kBlock), lds_pf, st, pa);
+    pa.stop = -1;
+#ifdef VGPMP_BISECT
+    pa.stop = vg_bisect_stop("VGPMP_STOP_PATHS");
+#endif
+    const size_t lds_pf = ((size_t)Mz * (Mz + 1) + (size_t)Mz * N + (size_t)3 * VG_SC * Mz + (size_t)VG_SC * J) * sizeof(float);
+    {
+        const void* fn = SK == 1 ? (const void*)paths_fwd_kernel<1> : SK == 2 ? (const void*)paths_fwd_kernel<2>
+                       : SK == 4 ? (const void*)paths_fwd_kernel<4> : (const void*)paths_fwd_kernel<8>;
+        rc = set_dyn_lds(fn, lds_pf);
+        if (rc) return rc;
+        void* kargs[] = {(void*)&pa};
+        VG_CHECK_HIP(hipLaunchKernel(fn, dim3(NC, L, P), dim3(kBlock), kargs, lds_pf, st));
+    }
     mark();
     // ---- likelihood forward + reverse (fk_sdf.hip)
     const double lik_scale = pb->alpha / (double)d->S_total;
@@ -904,28 +1101,41 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
                            pb->kl_scale, out->lik, out->kl);
         return (int)hipGetLastError();
     }
-    // ---- reverse of the path assembly, then of the covariance path (+ Adam)
-    const size_t lds_pb = ((size_t)N * (Mz + 1) + (size_t)VG_SC * (N + 1) + (size_t)3 * VG_SC * (Mz + 1)) * sizeof(float);
-    rc = set_dyn_lds((const void*)paths_bwd_kernel, lds_pb);
-    if (rc) return rc;
-    hipLaunchKernelGGL(paths_bwd_kernel, dim3(NC, L, P), dim3(kBlock), lds_pb, st, pa);
+    // ---- reverse of the path assembly, then gradient assembly (+ Adam)
+    const size_t lds_pb = ((size_t)4 * N * Mz + (size_t)2 * Mz * Mz + (size_t)VG_SC * N + (size_t)2 * VG_SC * J +
+                           (size_t)3 * VG_SC * Mz) * sizeof(float);
+    {
+        const void* fn = SK == 1 ? (const void*)paths_bwd_kernel<1> : SK == 2 ? (const void*)paths_bwd_kernel<2>
+                       : SK == 4 ? (const void*)paths_bwd_kernel<4> : (const void*)paths_bwd_kernel<8>;
+        rc = set_dyn_lds(fn, lds_pb);
+        if (rc) return rc;
+        void* kargs[] = {(void*)&pa};
+        VG_CHECK_HIP(hipLaunchKernel(fn, dim3(NC, L, P), dim3(kBlock), kargs, lds_pb, st));
+    }
     mark();
-    CovBwdArgs cb;
-    cb.c = ca; cb.NC = NC; cb.part_len = vg_part_len(d); cb.nblk = nblk; cb.lik_scale = lik_scale;
-    cb.out_lik = out->lik; cb.out_kl = out->kl;
-    cb.g_qmu = out->grad.q_mu; cb.g_qsqrt = out->grad.q_sqrt; cb.g_ell = out->grad.raw_ell; cb.g_var = out->grad.raw_var;
-    cb.do_adam = (what & VGPMP_DO_ADAM) ? 1 : 0; cb.trainable = trainable; cb.want_dell = want_dell ? 1 : 0;
-    cb.lr_t = cb.do_adam ? adam_lr_t(lr, adam_t) : 0.0;
-    cb.lr = lr; cb.ctr = ctr;
-    cb.mq_mu = am ? am->q_mu : nullptr; cb.mq_sqrt = am ? am->q_sqrt : nullptr;
-    cb.m_ell = am ? am->raw_ell : nullptr; cb.m_var = am ? am->raw_var : nullptr;
-    cb.vq_mu = av ? av->q_mu : nullptr; cb.vq_sqrt = av ? av->q_sqrt : nullptr;
-    cb.v_ell = av ? av->raw_ell : nullptr; cb.v_var = av ? av->raw_var : nullptr;
-    cb.pq_mu = params->q_mu; cb.pq_sqrt = params->q_sqrt; cb.p_ell = params->raw_ell; cb.p_var = params->raw_var;
-    const size_t lds_cb = ((size_t)4 * Mz * (Mz + 1) + 3 * Mz + 8) * sizeof(double);
-    rc = set_dyn_lds((const void*)cov_bwd_kernel, lds_cb);
+    FinalArgs fa;
+    fa.M = M; fa.L = L; fa.NC = NC; fa.nblk = nblk; fa.part_len = vg_part_len(d);
+    fa.part = ws->part; fa.Lk32 = ws->Lk32; fa.lik_partial = ws->lik_partial;
+    fa.gkl_qmu = ws->gkl_qmu; fa.gkl_Q = ws->gkl_Q; fa.gkl_ell = ws->gkl_ell; fa.gkl_var = ws->gkl_var;
+    fa.kl_l = ws->kl_l; fa.var = ws->var; fa.sig_ell = ws->sig_ell; fa.sig_var = ws->sig_var;
+    fa.kl_scale = pb->kl_scale; fa.lik_scale = lik_scale; fa.out_lik = out->lik; fa.out_kl = out->kl;
+    fa.g_qmu = out->grad.q_mu; fa.g_qsqrt = out->grad.q_sqrt; fa.g_ell = out->grad.raw_ell; fa.g_var = out->grad.raw_var;
+    fa.do_adam = (what & VGPMP_DO_ADAM) ? 1 : 0; fa.trainable = trainable; fa.want_dell = want_dell ? 1 : 0;
+    fa.lr_t = fa.do_adam ? adam_lr_t(lr, adam_t > 0 ? adam_t : 1) : 0.0;
+    fa.lr = lr; fa.ctr = ctr;
+    fa.mq_mu = am ? am->q_mu : nullptr; fa.mq_sqrt = am ? am->q_sqrt : nullptr;
+    fa.m_ell = am ? am->raw_ell : nullptr; fa.m_var = am ? am->raw_var : nullptr;
+    fa.vq_mu = av ? av->q_mu : nullptr; fa.vq_sqrt = av ? av->q_sqrt : nullptr;
+    fa.v_ell = av ? av->raw_ell : nullptr; fa.v_var = av ? av->raw_var : nullptr;
+    fa.pq_mu = params->q_mu; fa.pq_sqrt = params->q_sqrt; fa.p_ell = params->raw_ell; fa.p_var = params->raw_var;
+    fa.stop = -1;
+#ifdef VGPMP_BISECT
+    fa.stop = vg_bisect_stop("VGPMP_STOP_FINAL");
+#endif
+    const size_t lds_fin = ((size_t)Mz * Mz + Mz + 4) * sizeof(double) + (size_t)Mz * Mz * sizeof(float);
+    rc = set_dyn_lds((const void*)final_kernel, lds_fin);
     if (rc) return rc;
-    hipLaunchKernelGGL(cov_bwd_kernel, dim3(L, P), dim3(kBlock), lds_cb, st, cb);
+    hipLaunchKernelGGL(final_kernel, dim3(L, P), dim3(kBlock), lds_fin, st, fa);
     mark();
     return (int)hipGetLastError();
 }

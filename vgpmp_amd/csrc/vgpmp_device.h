@@ -71,13 +71,15 @@ __device__ __forceinline__ uint4 vg_philox(uint4 c, uint2 k) {
 __device__ __forceinline__ float vg_u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * 5.9604644775390625e-08f; }
 
 // four standard normals of counter (i, stream, 0, 0): Box-Muller on lanes (0,1) and (2,3)
+// Hardware transcendentals: v_log_f32 (log2) and v_sin/v_cos_f32, whose argument is in REVOLUTIONS --
+// exactly the uniform of Box-Muller, so no range reduction and very little code.
 __device__ __forceinline__ float4 vg_normal4(uint32_t i, uint32_t stream, uint2 key) {
     uint4 r = vg_philox(make_uint4(i, stream, 0u, 0u), key);
-    float r0 = sqrtf(-2.0f * logf(vg_u01(r.x))), r1 = sqrtf(-2.0f * logf(vg_u01(r.z)));
-    float s0, c0, s1, c1;
-    sincosf(6.283185307179586f * vg_u01(r.y), &s0, &c0);
-    sincosf(6.283185307179586f * vg_u01(r.w), &s1, &c1);
-    return make_float4(r0 * c0, r0 * s0, r1 * c1, r1 * s1);
+    const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(vg_u01(r.x)));
+    const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(vg_u01(r.z)));
+    const float u1 = vg_u01(r.y), u3 = vg_u01(r.w);
+    return make_float4(r0 * __builtin_amdgcn_cosf(u1), r0 * __builtin_amdgcn_sinf(u1),
+                       r1 * __builtin_amdgcn_cosf(u3), r1 * __builtin_amdgcn_sinf(u3));
 }
 __device__ __forceinline__ float vg_lane(const float4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
 __device__ __forceinline__ float vg_normal1(uint32_t e, uint32_t stream, uint2 key) {

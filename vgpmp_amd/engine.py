@@ -183,6 +183,11 @@ class PlannerBatch:
         self.kl_scale = float(kl_scale)
         # device-resident step counter: lets a captured hipGraph of the step be replayed
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        # side stream + fork/join events: the float64 covariance kernel overlaps the noise/GEMM branch
+        self._side = torch.cuda.Stream(device=dev)
+        self._fork_ev, self._join_ev = torch.cuda.Event(), torch.cuda.Event()
+        self._fork_ev.record(); self._join_ev.record()
+        self.overlap = True
         self._graph = None
         self._graph_unroll = 0
         self._pack()
@@ -196,10 +201,12 @@ class PlannerBatch:
         self._av = self._params_struct(self.adam_v)
         self._noise = capi.Noise(capi.ptr(self.omega), capi.ptr(self.beta), capi.ptr(self.w), capi.ptr(self.eps),
                                  capi.ptr(self.eps2))
+        side = (int(self._side.cuda_stream), int(self._fork_ev.cuda_event), int(self._join_ev.cuda_event)) \
+            if self.overlap else (None, None, None)
         self._problem = capi.Problem(capi.ptr(self.X), capi.ptr(self.Zy), capi.ptr(self.y_u), self.alpha, JITTER,
-                                     self.kl_scale, None)
+                                     self.kl_scale, None, *side)
         self._problem_ctr = capi.Problem(capi.ptr(self.X), capi.ptr(self.Zy), capi.ptr(self.y_u), self.alpha, JITTER,
-                                         self.kl_scale, capi.ptr(self.step_counter))
+                                         self.kl_scale, capi.ptr(self.step_counter), *side)
         self._out = capi.Outputs(capi.ptr(self.f), capi.ptr(self.logp), capi.ptr(self.lik), capi.ptr(self.kl),
                                  self._params_struct(self.grad))
 
