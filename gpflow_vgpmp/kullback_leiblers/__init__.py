@@ -1,0 +1,1 @@
+"""See gpflow_vgpmp/__init__.py."""

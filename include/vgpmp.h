@@ -79,6 +79,10 @@ typedef struct vgpmp_dims {
     int32_t L;             /* latent GPs == dof */
     int32_t B;             /* Fourier bases, multiple of 16 */
     int32_t split_k;       /* K-slices of the prior GEMM (1, 2, 4 or 8) */
+    int32_t sample_offset; /* index of this rank's first sample in the global sample stream: the prior
+                            * weights / eps / eps2 of local sample s are the draws of global sample
+                            * sample_offset + s (the Fourier basis omega, beta is the same on every rank) */
+    int32_t reserved;
 } vgpmp_dims;
 
 /* Variational + kernel parameters in UNCONSTRAINED space, float64, with their Adam moments

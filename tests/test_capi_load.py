@@ -27,7 +27,7 @@ def test_struct_sizes_match_header_layout():
     # sizes implied by include/vgpmp.h (natural alignment, 8-byte tail for the doubles)
     assert ctypes.sizeof(capi.Robot) == 4 * 4 + 7 * 16 * 4 + 12 * 4 + 64 * 4 + 64 * 12 + 64 * 4 + 64 * 4 + 8 + 24
     assert ctypes.sizeof(capi.Sdf) == 8 + 16 + 24 + 8
-    assert ctypes.sizeof(capi.Dims) == 32
+    assert ctypes.sizeof(capi.Dims) == 40
     assert ctypes.sizeof(capi.Params) == 32 and ctypes.sizeof(capi.Noise) == 40
     assert ctypes.sizeof(capi.Problem) == 80 and ctypes.sizeof(capi.Outputs) == 64
 
@@ -35,11 +35,11 @@ def test_struct_sizes_match_header_layout():
 def test_argument_errors_without_gpu():
     handle = capi.load(require=True)
     n = ctypes.c_size_t(0)
-    bad = capi.Dims(1, 8, 8, 10, 47, 7, 64, 1)          # M + 2 > VGPMP_MAX_MZ
+    bad = capi.Dims(1, 8, 8, 10, 47, 7, 64, 1, 0, 0)          # M + 2 > VGPMP_MAX_MZ
     assert handle.vgpmp_workspace_bytes(ctypes.byref(bad), ctypes.byref(n)) == -2
-    bad = capi.Dims(1, 8, 8, 10, 5, 7, 60, 1)           # B not a multiple of 16
+    bad = capi.Dims(1, 8, 8, 10, 5, 7, 60, 1, 0, 0)           # B not a multiple of 16
     assert handle.vgpmp_workspace_bytes(ctypes.byref(bad), ctypes.byref(n)) == -2
-    ok = capi.Dims(1, 128, 128, 100, 30, 7, 1024, 4)
+    ok = capi.Dims(1, 128, 128, 100, 30, 7, 1024, 4, 0, 0)
     assert handle.vgpmp_workspace_bytes(ctypes.byref(ok), ctypes.byref(n)) == 0 and n.value > 0
     assert handle.vgpmp_workspace_bytes(None, ctypes.byref(n)) == -1
 

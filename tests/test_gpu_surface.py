@@ -1,0 +1,180 @@
+"""GPU tests of the reference-shaped surface (gpflow_vgpmp.*), the driver flow of benchmarking.py,
+sample-axis sharding, plan extraction and edge shapes.  All compute goes through the C ABI."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vgpmp_oracle as orc
+from helpers import oracle_robot, oracle_scene, small_problem
+from vgpmp_amd import robots as rb
+from vgpmp_amd import scenes
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _env():
+    from gpflow_vgpmp.utils.simulation_manager import SimulationManager
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return SimulationManager(file_path=ROOT / "parameters.yaml")
+
+
+def test_driver_flow_like_benchmarking_py():
+    """The call sequence of the reference's benchmarking.py:14-93 on two queries."""
+    ns = {}
+    exec("from gpflow_vgpmp.utils.miscellaneous import *", ns)
+    gpflow, np_, p, solve = ns["gpflow"], ns["np"], ns["p"], ns["solve_planning_problem"]
+    gpflow.config.set_default_float(np_.float64)
+    env = _env()
+    assert env.config["robot_params"]["robot_name"] == "franka"
+    env.config["planner_params"].update(num_steps=60, num_samples=16, num_inducing=12, time_spacing_X=40, time_spacing_Xnew=60)
+    queries = env.config["scene_params"]["queries"][:2]
+    solved_total = 0
+    for start, end in queries:
+        start = np_.array(start, dtype=np_.float64).reshape(1, env.robot.dof)
+        end = np_.array(end, dtype=np_.float64).reshape(1, env.robot.dof)
+        env.robot.set_current_joint_config(np_.squeeze(start))
+        env.robot.set_joint_motor_control(np_.squeeze(start), 300, 0.5)
+        p.stepSimulation()
+        solved, traj = solve(env=env, start_joints=start, end_joints=end)
+        assert env.simulation.check_simulation_thread_health() is False      # as in the reference
+        assert traj.shape == (60, 7) and np_.isfinite(traj).all()
+        # pinned end points (1e-6 conditioning): path starts/ends at the query states
+        assert np_.abs(traj[0] - start[0]).max() < 5e-2 and np_.abs(traj[-1] - end[0]).max() < 5e-2
+        solved_total += bool(solved)
+        p.removeAllUserDebugItems()
+    env.simulation.stop_simulation_thread()
+    assert 0 <= solved_total <= 2
+
+
+def test_model_surface_against_oracle():
+    from gpflow_vgpmp.models.vgpmp import VGPMP
+    env = _env()
+    ps = rb.load_problemset("franka", "industrial")
+    y = np.array([ps.states[0], ps.states[1]])
+    pp = dict(ps.planner_params, num_samples=8, num_inducing=6, num_bases=64)
+    model = VGPMP.initialize(sdf=env.sdf, robot=env.robot, sampler=env.sampler, query_states=y,
+                             scene_offset=env.scene.position, **pp)
+    X = orc.init_trainset(12, 7)
+    e = model.elbo(X)
+    assert np.isfinite(e)
+    # q_mu / q_sqrt properties (models/vgpmp.py:200-218) against the oracle
+    osc = oracle_scene(env.robot.spec, env.sdf.grid, env.scene.position, sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"])
+    params = orc.init_params(osc.robot, y, 6, pp["lengthscales"], pp["variance"])
+    cv = orc.cov_forward(params, X, orc.inducing_Zy(6, 7), orc.joint_sigmoid_inverse(osc.robot, y))
+    np.testing.assert_allclose(model.q_sqrt, cv["C"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(model.q_mu, np.concatenate([orc.joint_sigmoid_inverse(osc.robot, y), params.q_mu]), rtol=1e-12)
+    assert model._q_sqrt.shape == (7, 6, 6) and len(model.trainable_variables) == 4
+    # likelihood.log_prob [S, N, D] -> [S, N]; sampler FK; SDF lookups (likelihood.py:57, sampler.py:103,216, sdf_utils.py:73)
+    rng = np.random.default_rng(0)
+    g = rng.uniform(osc.robot.low, osc.robot.high, (5, 9, 7)).astype(np.float32)
+    lp = model.likelihood.log_prob(g).cpu().numpy()
+    want = orc.log_prob(osc, g.astype(np.float64))
+    assert lp.shape == (5, 9) and np.isclose(lp, want, rtol=2e-4, atol=1e-5).mean() > 0.95
+    q = g[0, 0].astype(np.float64)
+    np.testing.assert_allclose(env.sampler.forward_kinematics(q.reshape(7, 1)), orc.forward_kinematics(osc.robot, q), atol=5e-6)
+    np.testing.assert_allclose(env.sampler.forward_kinematics_cost(q.reshape(7, 1)).cpu().numpy(),
+                               orc.sphere_positions(osc.robot, q), atol=5e-6)
+    pos = rng.uniform(-0.5, 0.5, (33, 3))
+    assert np.array_equal(env.sdf.get_distance_tf(pos).cpu().numpy(), orc.sdf_distance(osc.sdf, pos).astype(np.float32))
+    assert np.array_equal(env.sdf.get_distance_grad_tf(pos).cpu().numpy(), orc.sdf_gradient(osc.sdf, pos).astype(np.float32))
+    # training and plan extraction run and keep the paths inside the joint limits
+    from gpflow_vgpmp.utils.miscellaneous import training_loop, disable_param_opt
+    disable_param_opt(model, env.config["trainable_params"])
+    training_loop(model, X, 25)
+    mu, best, samples, unc = model.sample_from_posterior(orc.init_trainset(20, 7), env.robot)
+    assert mu.shape == (20, 7) and best.shape == (20, 7) and samples.shape == (7, 20, 7) and unc == 2.0
+    assert (best >= osc.robot.low - 1e-6).all() and (best <= osc.robot.high + 1e-6).all()
+    assert model.get_best_sample(samples) in range(7)
+    with pytest.raises(NotImplementedError):
+        disable_param_opt(model, dict(env.config["trainable_params"], alpha=True))
+
+
+def test_sample_sharding_two_ranks_equal_full_batch():
+    """Two emulated ranks (sample_offset 0 / 8, KL on rank 0) sum to the 16-sample gradient: the device
+    generator hands each rank its slice of the same global Philox sample stream."""
+    from vgpmp_amd import engine
+    S, N, M, B = 16, 11, 6, 64
+    pb = small_problem(robot="franka", S=S, N=N, M=M, B=B, seed=4, n_grid=48)
+    sc = engine.DeviceScene(pb["spec"], pb["grid"], pb["offset"])
+    kw = dict(num_inducing=M, num_data=N, num_bases=B, lengthscales=[2.0] * 7, variance=0.2, alpha=pb["alpha"], seed=77,
+              split_k=1)
+    full = engine.PlannerBatch(sc, pb["y"][None], num_samples=S, **kw)
+    r0 = engine.PlannerBatch(sc, pb["y"][None], num_samples=8, samples_total=S, sample_offset=0, kl_scale=1.0, **kw)
+    r1 = engine.PlannerBatch(sc, pb["y"][None], num_samples=8, samples_total=S, sample_offset=8, kl_scale=0.0, **kw)
+    lf, gf = full.loss_and_grad(step=3)
+    l0, g0 = r0.loss_and_grad(step=3)
+    l1, g1 = r1.loss_and_grad(step=3)
+    assert torch.equal(full.w[0, :8], r0.w[0]) and torch.equal(full.w[0, 8:], r1.w[0])      # same global stream
+    assert torch.equal(full.eps[0, 8:], r1.eps[0]) and torch.equal(full.omega, r1.omega)
+    np.testing.assert_allclose(float(l0[0] + l1[0]), float(lf[0]), rtol=1e-5)
+    for a, b, c in zip(gf, g0, g1):
+        want, got = a[0].cpu().numpy(), (b[0] + c[0]).cpu().numpy()
+        assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max() + 1e-9
+    assert float(r1.kl[0]) == 0.0 and float(r0.kl[0]) == float(full.kl[0])
+
+
+@pytest.mark.parametrize("S,N,M,B", [(1, 1, 1, 16), (13, 37, 3, 48), (9, 150, 46, 32), (150, 100, 30, 64)])
+def test_edge_shapes_against_oracle(S, N, M, B):
+    """Ragged / extreme shapes: one sample, one time point, one inducing point, S and N that are not
+    multiples of any tile, the largest supported inducing set (Mz = 48), the 150-path posterior draw."""
+    from vgpmp_amd import engine
+    pb = small_problem(robot="franka", S=S, N=N, M=M, B=B, seed=21, n_grid=32)
+    sc = engine.DeviceScene(pb["spec"], pb["grid"], pb["offset"])
+    pl = engine.PlannerBatch(sc, pb["y"][None], num_samples=S, num_inducing=M, num_data=N, num_bases=B,
+                             lengthscales=[2.0] * 7, variance=0.2, alpha=pb["alpha"], split_k=1)
+    p = pb["params"]
+    pl.q_mu.copy_(torch.tensor(p.q_mu.T[None])); pl.q_sqrt.copy_(torch.tensor(p.q_sqrt[None]))
+    pl.raw_ell.copy_(torch.tensor(p.raw_ell[None])); pl.raw_var.copy_(torch.tensor(p.raw_var[None]))
+    r32 = lambda a: a.astype(np.float32).astype(np.float64)
+    nz = pb["noise"]
+    nz = orc.Noise(r32(nz.omega), r32(nz.beta), r32(nz.w), r32(nz.eps), r32(nz.eps2))
+    pl.set_noise(nz.omega[None], nz.beta[None], nz.w[None], nz.eps[None], nz.eps2[None])
+    loss, grads = pl.loss_and_grad(generate=False)
+    fw = orc.elbo_forward(p, pb["scene"], pb["X"], pb["Zy"], pb["y"], nz, pb["alpha"])
+    og, _ = orc.elbo_backward(p, pb["scene"], pb["X"], pb["Zy"], nz, pb["alpha"], fw)
+    np.testing.assert_allclose(pl.f[0].cpu().numpy(), fw["f"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(float(pl.kl[0]), fw["cv"]["kl"], rtol=1e-8)
+    ok = np.isclose(pl.logp[0].cpu().numpy(), fw["logp"], rtol=2e-3, atol=1e-4)
+    assert ok.mean() >= 0.97
+    if ok.all():
+        np.testing.assert_allclose(float(loss[0]), -fw["elbo"], rtol=5e-4)
+        for got, name in zip(grads, ("q_mu", "q_sqrt", "raw_ell", "raw_var")):
+            want = getattr(og, name)
+            got = got[0].cpu().numpy().T if name == "q_mu" else got[0].cpu().numpy()
+            assert np.abs(got - want).max() <= 5e-3 * np.abs(want).max() + 1e-9, name
+    # forward-only entry reproduces the same ELBO pieces
+    e = pl.elbo(generate=False)
+    assert float(e[0]) == float(-loss[0])
+
+
+def test_trainable_flags_freeze_parameters():
+    from vgpmp_amd import engine
+    pb = small_problem(robot="franka", S=8, N=10, M=5, B=32, seed=2, n_grid=32)
+    sc = engine.DeviceScene(pb["spec"], pb["grid"], pb["offset"])
+    pl = engine.PlannerBatch(sc, pb["y"][None], num_samples=8, num_inducing=5, num_data=10, num_bases=32,
+                             lengthscales=[2.0] * 7, variance=0.2, trainable=dict(q_mu=True, q_sqrt=False,
+                             lengthscales=False, kernel_variance=True))
+    q0, s0, e0, v0 = pl.q_mu.clone(), pl.q_sqrt.clone(), pl.raw_ell.clone(), pl.raw_var.clone()
+    for _ in range(3):
+        pl.step()
+    assert not torch.equal(pl.q_mu, q0) and not torch.equal(pl.raw_var, v0)
+    assert torch.equal(pl.q_sqrt, s0) and torch.equal(pl.raw_ell, e0)
+
+
+def test_graph_replay_matches_eager_steps():
+    from vgpmp_amd import engine
+    pb = small_problem(robot="franka", S=8, N=10, M=5, B=32, seed=2, n_grid=32)
+    sc = engine.DeviceScene(pb["spec"], pb["grid"], pb["offset"])
+    kw = dict(num_samples=8, num_inducing=5, num_data=10, num_bases=32, lengthscales=[2.0] * 7, variance=0.2, seed=5)
+    a, b = engine.PlannerBatch(sc, pb["y"][None], **kw), engine.PlannerBatch(sc, pb["y"][None], **kw)
+    a.capture(unroll=3)                    # one eager step + capture
+    a.run_steps(7)                         # two graph replays + one eager step
+    b.run_steps(8)
+    torch.cuda.synchronize()
+    assert a.t == b.t == 8
+    assert torch.allclose(a.q_mu, b.q_mu, rtol=0, atol=1e-12) and torch.allclose(a.raw_ell, b.raw_ell, rtol=0, atol=1e-12)

@@ -1,0 +1,102 @@
+"""CPU tests of the host-side mirror of the reference's boundary (no GPU, no compute calls)."""
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_driver_star_import_surface():
+    """Names the reference's benchmarking.py takes from `from gpflow_vgpmp.utils.miscellaneous import *`
+    (benchmarking.py:3,9,11,14,17,60-65,81,83,91,95)."""
+    ns = {}
+    exec("from gpflow_vgpmp.utils.miscellaneous import *", ns)
+    for name in ("gpflow", "np", "p", "time", "os", "get_root_package_path", "solve_planning_problem"):
+        assert name in ns, name
+    ns["gpflow"].config.set_default_float(np.float64)
+    ns["gpflow"].config.Config(jitter=1e-6)
+    pb = ns["p"]
+    body = pb.register_body((0, 0, 0.346), (0, 0, 0, 1))
+    pos, orn = pb.getBasePositionAndOrientation(body)
+    pb.resetBasePositionAndOrientation(body, (pos[0], pos[1], pos[2] - 0.346), orn)
+    assert pb.getBasePositionAndOrientation(body)[0] == (0.0, 0.0, 0.0)
+    pb.resetDebugVisualizerCamera(cameraDistance=2, cameraYaw=-75, cameraPitch=-45, cameraTargetPosition=[0, 0, 0])
+    pb.stepSimulation(); pb.removeAllUserDebugItems()
+    assert Path(ns["get_root_package_path"]()) == ROOT
+
+
+def test_parameter_loader_schema_and_queries():
+    from gpflow_vgpmp.utils.parameter_loader import ParameterLoader
+    pl = ParameterLoader()
+    with pytest.warns(UserWarning):                      # the .sdf blob is absent -> synthetic scene
+        pl.initialize(file_path=ROOT / "parameters.yaml")
+    cfg = pl.params
+    assert set(cfg) == {"robot_params", "scene_params", "planner_params", "trainable_params", "graphics_params"}
+    assert cfg["robot_params"]["robot_name"] == "franka" and cfg["robot_params"]["dof"] == 7
+    assert len(cfg["scene_params"]["queries"]) == 36      # C(9, 2), utils/parameter_loader.py:138
+    assert cfg["planner_params"]["num_steps"] == 200 and cfg["trainable_params"]["lengthscales"] is True
+    assert "benchmark_attributes" not in cfg["scene_params"]
+
+
+def test_parameter_loader_non_benchmark_and_errors(tmp_path):
+    import yaml
+    from gpflow_vgpmp.utils.parameter_loader import ParameterLoader
+    params = yaml.safe_load(open(ROOT / "parameters.yaml"))
+    params[1]["scene"]["benchmark"] = False
+    pl = ParameterLoader()
+    with pytest.warns(UserWarning):
+        pl.initialize(params=params)
+    assert len(pl.params["scene_params"]["queries"]) == 1 and pl.params["planner_params"]["num_inducing"] == 10
+    params[0]["robot"]["robot_name"] = "pr2"
+    with pytest.raises(SystemExit):
+        ParameterLoader().initialize(params=params)
+    with pytest.raises(SystemExit):
+        ParameterLoader().initialize(file_path=tmp_path / "nope.yaml")
+
+
+def test_init_trainset_matches_reference_grid():
+    from gpflow_vgpmp.utils.miscellaneous import init_trainset
+    X, y, Xnew = init_trainset(50, 100, 7, 7, np.arange(7.0), -np.arange(7.0), scale=1)
+    assert X.shape == (50, 7) and Xnew.shape == (100, 7) and y.shape == (2, 7)
+    np.testing.assert_allclose(X[:, 3], np.linspace(0, 1, 50))
+    assert (X == X[:, :1]).all() and np.array_equal(y[1], -np.arange(7.0))
+
+
+def test_fill_order_independent_variables_and_problemsets():
+    from vgpmp_amd import robots
+    ps = robots.load_problemset("wam", "industrial")
+    assert len(ps.queries) == 36 and ps.planner_params["num_inducing"] == 24
+    assert ps.robot_pos_and_orn[0] == [0.0, 0.0, 0.346]
+    with pytest.raises(ValueError):
+        robots.load_problemset("franka", "kitchen")
+    arm = robots.synthetic_arm(14)
+    assert arm.dof == 14 and arm.num_spheres == 45 and list(arm.sphere_frame) == sorted(arm.sphere_frame)
+
+
+def test_dispatcher_lookalikes_match_oracle():
+    from gpflow_vgpmp.covariances import Kuu, Kuf, Kfu
+    from gpflow_vgpmp.kullback_leiblers.prior_kl import prior_kl
+    from gpflow_vgpmp.inducing_variables.inducing_variables import (ConditionedVariableInducingPoints,
+                                                                    SharedIndependentInducingVariables)
+    from gpflow_vgpmp.kernels.kernels import Matern52, VanillaConditioningSeparateIndependent
+    from oracle import vgpmp_oracle as orc
+    L, M, N = 3, 5, 6
+    Z = np.tile(np.linspace(0.1, 0.9, M)[:, None], (1, L))
+    iv = SharedIndependentInducingVariables(ConditionedVariableInducingPoints(Z, np.stack([np.zeros(L), np.ones(L)])))
+    ell, var = [2.0, 3.0, 0.7], 0.3
+    kern = VanillaConditioningSeparateIndependent([Matern52(e, var) for e in ell])
+    X = orc.init_trainset(N, L)
+    Zy = orc.inducing_Zy(M, L)
+    K = Kuu(iv, kern, jitter=1e-6).numpy()
+    for l in range(L):
+        np.testing.assert_allclose(K[l], orc.matern52(Zy[:, l], Zy[:, l], ell[l], var) + 1e-6 * np.eye(M + 2), rtol=1e-12)
+        np.testing.assert_allclose(Kuf(iv, kern, X)[l].numpy(), orc.matern52(Zy[:, l], X[:, l], ell[l], var), rtol=1e-12)
+    assert Kfu(iv, kern, X).shape == (L, N, M + 2)
+    rng = np.random.default_rng(0)
+    p = orc.Params(q_mu=rng.standard_normal((M, L)), q_sqrt=np.tril(rng.standard_normal((L, M, M))) + 2 * np.eye(M),
+                   raw_ell=orc.softplus_inverse(np.array(ell)), raw_var=np.full(L, orc.softplus_inverse(var - 0.1)))
+    y_u = rng.standard_normal((2, L))
+    cv = orc.cov_forward(p, X, Zy, y_u)
+    np.testing.assert_allclose(float(prior_kl(iv, kern, p.q_mu, p.q_sqrt, y_u)), cv["kl"], rtol=1e-9)

@@ -48,7 +48,8 @@ class Sdf(C.Structure):
 
 class Dims(C.Structure):
     _fields_ = [("num_problems", C.c_int32), ("S", C.c_int32), ("S_total", C.c_int32), ("N", C.c_int32),
-                ("M", C.c_int32), ("L", C.c_int32), ("B", C.c_int32), ("split_k", C.c_int32)]
+                ("M", C.c_int32), ("L", C.c_int32), ("B", C.c_int32), ("split_k", C.c_int32),
+                ("sample_offset", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Params(C.Structure):

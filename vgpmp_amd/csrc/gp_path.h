@@ -9,6 +9,7 @@ struct vg_workspace {
     double *ell, *var, *sig_ell, *sig_var;   // [P,L] constrained values and d(constrained)/d(raw)
     double *Kinv;            // [P,L,Mz,Mz]   (Kuu + jitter I)^-1
     double *Kd_ell;          // [P,L,Mz,Mz]   dKuu / d lengthscale
+    double *Ks64, *Lk64, *Li64;  // [P,L,Mz,Mz] Kuu, chol(Kuu + jI) and its inverse (stage A -> stage B)
     double *kl_l;            // [P,L]
     double *gkl_qmu;         // [P,L,M]       dKL/dq_mu
     double *gkl_Q;           // [P,L,M,M]     dKL/dq_sqrt (lower)

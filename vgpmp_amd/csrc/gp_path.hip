@@ -100,31 +100,28 @@ __global__ __launch_bounds__(kBlock) void rng_basis_kernel(int L, int B, int D, 
     beta[(size_t)p * L * B + lb] = 6.283185307179586f * vg_u01(rb);
 }
 
-// w [P, nW], eps [P, nE], eps2 [P, nE]: counter i of a stream yields elements 4i..4i+3
-__global__ __launch_bounds__(kBlock) void rng_normals_kernel(uint32_t nW, uint32_t nE, float* __restrict__ w,
-                                                              float* __restrict__ eps, float* __restrict__ eps2,
-                                                              uint32_t seed, uint32_t problem_base, uint32_t step,
+// w [P, nW]: counter i of the stream yields global elements 4i..4i+3 (wOff is a multiple of 4);
+// eps, eps2 [P, nE]: one thread per element (their global offset need not be aligned).
+__global__ __launch_bounds__(kBlock) void rng_normals_kernel(uint32_t nW, uint32_t nE, uint32_t wOff, uint32_t eOff,
+                                                              float* __restrict__ w, float* __restrict__ eps,
+                                                              float* __restrict__ eps2, uint32_t seed,
+                                                              uint32_t problem_base, uint32_t step,
                                                               const uint32_t* __restrict__ ctr) {
     const int p = blockIdx.y;
     if (ctr) step = *ctr;
-    const uint32_t cW = (nW + 3u) >> 2, cE = (nE + 3u) >> 2;
+    const uint32_t cW = nW >> 2;
     uint32_t c = blockIdx.x * kBlock + threadIdx.x;
-    if (c >= cW + 2u * cE) return;
+    if (c >= cW + 2u * nE) return;
     const uint2 key = vg_key(seed, problem_base + p, step);
-    float* dst; uint32_t n, stream;
-    if (c < cW) { dst = w + (size_t)p * nW; n = nW; stream = VG_STREAM_W; }
-    else if (c < cW + cE) { c -= cW; dst = eps + (size_t)p * nE; n = nE; stream = VG_STREAM_EPS; }
-    else { c -= cW + cE; dst = eps2 + (size_t)p * nE; n = nE; stream = VG_STREAM_EPS2; }
-    float4 v = vg_normal4(c, stream, key);
-    const uint32_t e = 4u * c;
-    if (e + 3u < n && ((((size_t)p * n) & 3u) == 0)) {
-        *reinterpret_cast<float4*>(dst + e) = v;
-    } else {
-        if (e < n) dst[e] = v.x;
-        if (e + 1u < n) dst[e + 1] = v.y;
-        if (e + 2u < n) dst[e + 2] = v.z;
-        if (e + 3u < n) dst[e + 3] = v.w;
+    if (c < cW) {
+        const float4 v = vg_normal4((wOff >> 2) + c, VG_STREAM_W, key);
+        *reinterpret_cast<float4*>(w + (size_t)p * nW + 4u * c) = v;
+        return;
     }
+    c -= cW;
+    const bool second = c >= nE;
+    if (second) c -= nE;
+    (second ? eps2 : eps)[(size_t)p * nE + c] = vg_normal1(eOff + c, second ? VG_STREAM_EPS2 : VG_STREAM_EPS, key);
 }
 
 // =================================================================================================
@@ -220,27 +217,19 @@ __device__ __forceinline__ void chol_inverse_block(double* La, double* Li, doubl
     __syncthreads();
 }
 
-template <bool TANGENTS>
-__global__ __launch_bounds__(kCovThreads) void cov_fwd_kernel(CovArgs a) {
+// ---- stage A: Kuu, factorisation, inverse --------------------------------------------------------
+__global__ __launch_bounds__(kCovThreads) void cov_a_kernel(CovArgs a) {
     extern __shared__ double sm[];
-    __shared__ double red[kCovThreads / VG_WAVE];
-    __shared__ double scal[8];
+    __shared__ double scal[2];
     const int l = blockIdx.x, p = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
     const int M = a.M, Mz = M + 2, L = a.L, D = a.D;
     const int Mp = (Mz + 15) & ~15, ld = Mp + 1;
     const size_t pl = (size_t)p * L + l;
-    double* La = sm;                 // Cholesky factor Lk              (all Mp x ld, zero padded)
+    double* La = sm;                 // Kuu + jI -> Cholesky factor Lk      (Mp x ld, zero padded)
     double* Li = La + Mp * ld;       // Lk^-1
-    double* Ks = Li + Mp * ld;       // Kuu (no jitter)
-    double* Qp = Ks + Mp * ld;       // pad(q_sqrt): Q at [2:, 2:]
-    double* Kd = Qp + Mp * ld;       // dK/dtheta, later scratch
-    double* T = Kd + Mp * ld;        // scratch
-    double* W = T + Mp * ld;         // scratch
-    double* zs = W + Mp * ld;        // [Mp] Zy[:, l]
-    double* dl = zs + Mp;            // [Mp] q_mu - p_mu
-    double* af = dl + Mp;            // [Mp] Lk^-1 (q_mu - p_mu)
-    double* v1 = af + Mp;            // [Mp] scratch
-
+    double* Sc = Li + Mp * ld;       // 2 x (Mp x ld) scratch: augmented matrix of the elimination
+    double* zs = Sc + 2 * Mp * ld;   // [Mp]
+    double* rsd = zs + Mp;           // [Mp]
     if (tid == 0) {
         const double re = a.raw_ell[pl], rv = a.raw_var[pl];
         scal[0] = softplus_d(re);
@@ -248,20 +237,13 @@ __global__ __launch_bounds__(kCovThreads) void cov_fwd_kernel(CovArgs a) {
         a.ws.sig_ell[pl] = sigmoid_d(re);
         a.ws.sig_var[pl] = sigmoid_d(rv);
     }
-    for (int e = tid; e < 7 * Mp * ld + 4 * Mp; e += nt) sm[e] = 0.0;
-    __syncthreads();
+    for (int e = tid; e < 2 * Mp * ld; e += nt) sm[e] = 0.0;
     for (int i = tid; i < Mz; i += nt) zs[i] = a.Zy[(size_t)i * D + l];
-    {
-        const double* Qg = a.q_sqrt + pl * M * M;
-        for (int e = tid; e < M * M; e += nt) {
-            const int r = e / M, c = e - r * M;
-            if (c <= r) Qp[(r + 2) * ld + (c + 2)] = Qg[e];
-        }
-    }
     __syncthreads();
     const double ell = scal[0], var = scal[1], jit = a.jitter;
     if (tid == 0) { a.ws.ell[pl] = ell; a.ws.var[pl] = var; }
     // Kuu and dKuu/dell share the exponential; symmetric: evaluate the lower triangle only
+    double* Kg = a.ws.Ks64 + pl * Mz * Mz;
     double* Kdg = a.ws.Kd_ell + pl * Mz * Mz;
     for (int e = tid; e < Mz * Mz; e += nt) {
         int i = e / Mz, j = e - i * Mz;
@@ -270,40 +252,93 @@ __global__ __launch_bounds__(kCovThreads) void cov_fwd_kernel(CovArgs a) {
         double ex = exp(-kSqrt5 * r);
         double k = var * (1.0 + kSqrt5 * r + (5.0 / 3.0) * r * r) * ex;
         double dk = var * ex * (5.0 * r * r / (3.0 * ell)) * (1.0 + kSqrt5 * r);
-        Ks[i * ld + j] = k;
         La[i * ld + j] = k + (i == j ? jit : 0.0);
+        Kg[(size_t)i * Mz + j] = k;
         Kdg[(size_t)i * Mz + j] = dk;
-        if (i != j) { Ks[j * ld + i] = k; La[j * ld + i] = k; Kdg[(size_t)j * Mz + i] = dk; }
+        if (i != j) { La[j * ld + i] = k; Kg[(size_t)j * Mz + i] = k; Kdg[(size_t)j * Mz + i] = dk; }
     }
     __syncthreads();
-    VG_STOP(a, 1);
-    chol_inverse_block(La, Li, Kd, v1, Mz, ld, tid, nt);      // Aug aliases the Kd/T/W scratch region
-    for (int e = tid; e < 3 * Mp * ld; e += nt) Kd[e] = 0.0;  // restore the zero padding of the scratch
-    __syncthreads();
-    VG_STOP(a, 3);
-    // ---- Kinv = Lk^-T Lk^-1 ; q_sqrt = Lk pad(Q) + jitter diag(1,1,0..)  (models/vgpmp.py:208-218)
+    chol_inverse_block(La, Li, Sc, rsd, Mz, ld, tid, nt);
     double* Kig = a.ws.Kinv + pl * Mz * Mz;
-    float* Lk32 = a.ws.Lk32 + pl * Mz * Mz;
-    float* C32 = a.ws.C + pl * Mz * Mz;
     matmul_f64(MatView{Li, 1, ld}, MatView{Li, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
         if (r < Mz && c < Mz) Kig[(size_t)r * Mz + c] = v;
     });
-    matmul_f64(MatView{La, ld, 1}, MatView{Qp, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
-        if (r < Mz && c < Mz) C32[(size_t)r * Mz + c] = (float)(v + (r == c && r < 2 ? jit : 0.0));
-    });
-    for (int e = tid; e < Mz * Mz; e += nt) Lk32[e] = (float)La[(e / Mz) * ld + e % Mz];
-    VG_STOP(a, 4);
-    // ---- q_mu (full), KL and its gradient wrt q_mu / q_sqrt  (vgpmp.py:200-202, prior_kl.py:16-35)
+    double* Lkg = a.ws.Lk64 + pl * Mz * Mz;
+    double* Lig = a.ws.Li64 + pl * Mz * Mz;
+    float* Lk32 = a.ws.Lk32 + pl * Mz * Mz;
+    for (int e = tid; e < Mz * Mz; e += nt) {
+        const int i = e / Mz, j = e - i * Mz;
+        Lkg[e] = La[i * ld + j];
+        Lig[e] = Li[i * ld + j];
+        Lk32[e] = (float)La[i * ld + j];
+    }
+}
+
+// ---- stage B: heterogeneous launch, role = blockIdx.x ---------------------------------------------
+//   0            q_sqrt = Lk pad(Q) + jitter, q_mu, KL and its gradient wrt q_mu / q_sqrt
+//   1, 2         forward-mode tangent wrt lengthscale / variance:  dC = (Lk Phi(Lk^-1 dK Lk^-T)) pad(Q), dKL
+//   3 + t        row tile t of A = Kfu (Kuu + jI)^-1 and its tangents (cov_rows_body)
+__device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int p, int tid, int nt);
+
+template <bool TANGENTS>
+__global__ __launch_bounds__(kCovThreads) void cov_b_kernel(CovArgs a) {
+    extern __shared__ double sm[];
+    __shared__ double red[kCovThreads / VG_WAVE];
+    const int role = blockIdx.x, l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
+    if (role >= 3) {
+        cov_rows_body(a, sm, role - 3, l, p, tid, nt);
+        return;
+    }
+    if (role > 0 && (!TANGENTS || (role == 1 && !a.want_dell))) return;
+    const int M = a.M, Mz = M + 2, L = a.L;
+    const int Mp = (Mz + 15) & ~15, ld = Mp + 1;
+    const size_t pl = (size_t)p * L + l;
+    double* La = sm;                 // Lk                               (all Mp x ld, zero padded)
+    double* Li = La + Mp * ld;       // Lk^-1
+    double* Qp = Li + Mp * ld;       // pad(q_sqrt): Q at [2:, 2:]
+    double* Kd = Qp + Mp * ld;       // dK/dtheta
+    double* T = Kd + Mp * ld;        // scratch
+    double* W = T + Mp * ld;         // scratch
+    double* dl = W + Mp * ld;        // [Mp] q_mu - p_mu
+    double* af = dl + Mp;            // [Mp] Lk^-1 (q_mu - p_mu)
+    double* v1 = af + Mp;            // [Mp]
+    double* k0 = v1 + Mp;            // [Mp] first two columns of Kuu + jI
+    double* k1 = k0 + Mp;
+    for (int e = tid; e < 6 * Mp * ld + 5 * Mp; e += nt) sm[e] = 0.0;
+    __syncthreads();
+    const double jit = a.jitter, var = a.ws.var[pl];
+    const double* Kg = a.ws.Ks64 + pl * Mz * Mz;
+    {
+        const double* Lkg = a.ws.Lk64 + pl * Mz * Mz;
+        const double* Lig = a.ws.Li64 + pl * Mz * Mz;
+        const double* Kdg = a.ws.Kd_ell + pl * Mz * Mz;
+        const double* Qg = a.q_sqrt + pl * M * M;
+        for (int e = tid; e < Mz * Mz; e += nt) {
+            const int i = e / Mz, j = e - i * Mz;
+            La[i * ld + j] = Lkg[e];
+            Li[i * ld + j] = Lig[e];
+            if (role == 1) Kd[i * ld + j] = Kdg[e];
+            if (role == 2) Kd[i * ld + j] = Kg[e] / var;
+        }
+        for (int e = tid; e < M * M; e += nt) {
+            const int r = e / M, c = e - r * M;
+            if (c <= r) Qp[(r + 2) * ld + (c + 2)] = Qg[e];
+        }
+        for (int i = tid; i < Mz; i += nt) {
+            k0[i] = Kg[(size_t)i * Mz + 0] + (i == 0 ? jit : 0.0);
+            k1[i] = Kg[(size_t)i * Mz + 1] + (i == 1 ? jit : 0.0);
+        }
+    }
+    __syncthreads();
+    // prior mean through the two conditioned points and a = Lk^-1 (q_mu - p_mu)  (prior_kl.py:16-35)
     const double y0 = a.y_u[((size_t)p * 2 + 0) * L + l], y1 = a.y_u[((size_t)p * 2 + 1) * L + l];
-    const double k00 = Ks[0] + jit, k01 = Ks[1], k11 = Ks[ld + 1] + jit;
+    const double k00 = k0[0], k01 = k1[0], k11 = k1[1];
     const double det = k00 * k11 - k01 * k01;
     const double c0 = (k11 * y0 - k01 * y1) / det, c1 = (k00 * y1 - k01 * y0) / det;
     for (int i = tid; i < Mz; i += nt) {
-        double mi = i == 0 ? y0 : (i == 1 ? y1 : a.q_mu[pl * M + (i - 2)]);
-        a.ws.m[pl * Mz + i] = (float)mi;
-        double ki0 = Ks[i * ld + 0] + (i == 0 ? jit : 0.0);
-        double ki1 = Ks[i * ld + 1] + (i == 1 ? jit : 0.0);
-        dl[i] = mi - (ki0 * c0 + ki1 * c1);
+        const double mi = i == 0 ? y0 : (i == 1 ? y1 : a.q_mu[pl * M + (i - 2)]);
+        if (role == 0) a.ws.m[pl * Mz + i] = (float)mi;
+        dl[i] = mi - (k0[i] * c0 + k1[i] * c1);
     }
     __syncthreads();
     double klacc = 0.0;
@@ -312,76 +347,65 @@ __global__ __launch_bounds__(kCovThreads) void cov_fwd_kernel(CovArgs a) {
         af[i] = s;
         if (i >= 2) klacc += s * s;
     }
-    double* gklQ = a.ws.gkl_Q + pl * M * M;
-    for (int e = tid; e < M * M; e += nt) {
-        int r = e / M, c = e - r * M;
-        double gq = 0.0;
-        if (c <= r) {
-            double q = Qp[(r + 2) * ld + (c + 2)];
-            klacc += q * q;
-            gq = q;
-            if (c == r) { klacc -= log(q * q); gq -= 1.0 / q; }
-        }
-        gklQ[e] = gq;
-    }
-    double kl = block_sum(klacc, red);       // (contains __syncthreads: af is complete afterwards)
-    if (tid == 0) a.ws.kl_l[pl] = 0.5 * (kl - (double)M);
-    // d KL / d q_mu = (Lk^-T [0, 0, a])[2:]
-    for (int k = tid + 2; k < Mz; k += nt)
-        a.ws.gkl_qmu[pl * M + (k - 2)] = dot4(Li + k * ld + k, ld, af + k, 1, Mz - k);
-    if (!TANGENTS) return;
-    VG_STOP(a, 6);
-
-    // =================== forward-mode tangents wrt theta in {lengthscale, variance} ==============
-    //   W = Phi(Lk^-1 dK Lk^-T),  dLk = Lk W,  dC = dLk pad(Q)       (four 64-bit MFMA products each)
-    for (int th = (a.want_dell ? 0 : 1); th < 2; ++th) {
-        __syncthreads();
-        for (int e = tid; e < Mz * Mz; e += nt) {
-            int i = e / Mz, j = e - i * Mz;
-            Kd[i * ld + j] = th == 0 ? Kdg[e] : Ks[i * ld + j] / var;
-        }
-        __syncthreads();
-        matmul_f64(MatView{Li, ld, 1}, MatView{Kd, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) { T[r * ld + c] = v; });
-        __syncthreads();
-        matmul_f64(MatView{T, ld, 1}, MatView{Li, 1, ld}, Mp, tid, nt, [&](int r, int c, double v) {
-            W[r * ld + c] = c < r ? v : (c == r ? 0.5 * v : 0.0);
+    __syncthreads();
+    if (role == 0) {
+        float* C32 = a.ws.C + pl * Mz * Mz;
+        matmul_f64(MatView{La, ld, 1}, MatView{Qp, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
+            if (r < Mz && c < Mz) C32[(size_t)r * Mz + c] = (float)(v + (r == c && r < 2 ? jit : 0.0));
         });
-        __syncthreads();
-        matmul_f64(MatView{La, ld, 1}, MatView{W, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) { T[r * ld + c] = v; });
-        __syncthreads();
-        float* CT = (th == 0 ? a.ws.CT_ell : a.ws.CT_var) + pl * Mz * Mz;
-        matmul_f64(MatView{T, ld, 1}, MatView{Qp, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
-            if (r < Mz && c < Mz) CT[(size_t)c * Mz + r] = (float)v;       // stored transposed
-        });
-        VG_STOP(a, 7 + 3 * th);
-        // KL tangent: a_dot = Lk^-1 (delta_dot - dLk a),  delta_dot = -d p_mu
-        const double d00 = Kd[0], d01 = Kd[1], d11 = Kd[ld + 1];
-        const double e0 = d00 * c0 + d01 * c1, e1 = d01 * c0 + d11 * c1;        // dKyy c
-        const double cd0 = -(k11 * e0 - k01 * e1) / det, cd1 = -(k00 * e1 - k01 * e0) / det;
-        for (int i = tid; i < Mz; i += nt) {
-            const double s = dot4(T + i * ld, 1, af, 1, i + 1);
-            double ki0 = Ks[i * ld + 0] + (i == 0 ? jit : 0.0);
-            double ki1 = Ks[i * ld + 1] + (i == 1 ? jit : 0.0);
-            double pd = Kd[i * ld + 0] * c0 + Kd[i * ld + 1] * c1 + ki0 * cd0 + ki1 * cd1;
-            v1[i] = -pd - s;
+        double* gklQ = a.ws.gkl_Q + pl * M * M;
+        for (int e = tid; e < M * M; e += nt) {
+            int r = e / M, c = e - r * M;
+            double gq = 0.0;
+            if (c <= r) {
+                double q = Qp[(r + 2) * ld + (c + 2)];
+                klacc += q * q;
+                gq = q;
+                if (c == r) { klacc -= log(q * q); gq -= 1.0 / q; }
+            }
+            gklQ[e] = gq;
         }
-        __syncthreads();
-        double acc = 0.0;
-        for (int i = tid; i < Mz; i += nt) {
-            if (i >= 2) acc += af[i] * dot4(Li + i * ld, 1, v1, 1, i + 1);
-        }
-        acc = block_sum(acc, red);
-        if (tid == 0) (th == 0 ? a.ws.gkl_ell : a.ws.gkl_var)[pl] = acc;
+        const double kl = block_sum(klacc, red);
+        if (tid == 0) a.ws.kl_l[pl] = 0.5 * (kl - (double)M);
+        // d KL / d q_mu = (Lk^-T [0, 0, a])[2:]
+        for (int k = tid + 2; k < Mz; k += nt)
+            a.ws.gkl_qmu[pl * M + (k - 2)] = dot4(Li + k * ld + k, ld, af + k, 1, Mz - k);
+        return;
     }
+    // ---- tangent wrt theta: W = Phi(Lk^-1 dK Lk^-T), dLk = Lk W, dC = dLk pad(Q)   (64-bit MFMA products)
+    matmul_f64(MatView{Li, ld, 1}, MatView{Kd, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) { T[r * ld + c] = v; });
+    __syncthreads();
+    matmul_f64(MatView{T, ld, 1}, MatView{Li, 1, ld}, Mp, tid, nt, [&](int r, int c, double v) {
+        W[r * ld + c] = c < r ? v : (c == r ? 0.5 * v : 0.0);
+    });
+    __syncthreads();
+    matmul_f64(MatView{La, ld, 1}, MatView{W, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) { T[r * ld + c] = v; });
+    __syncthreads();
+    float* CT = (role == 1 ? a.ws.CT_ell : a.ws.CT_var) + pl * Mz * Mz;
+    matmul_f64(MatView{T, ld, 1}, MatView{Qp, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
+        if (r < Mz && c < Mz) CT[(size_t)c * Mz + r] = (float)v;       // stored transposed
+    });
+    // KL tangent: a_dot = Lk^-1 (delta_dot - dLk a),  delta_dot = -d p_mu
+    const double d00 = Kd[0], d01 = Kd[1], d11 = Kd[ld + 1];
+    const double e0 = d00 * c0 + d01 * c1, e1 = d01 * c0 + d11 * c1;        // dKyy c
+    const double cd0 = -(k11 * e0 - k01 * e1) / det, cd1 = -(k00 * e1 - k01 * e0) / det;
+    for (int i = tid; i < Mz; i += nt) {
+        const double s = dot4(T + i * ld, 1, af, 1, i + 1);
+        const double pd = Kd[i * ld + 0] * c0 + Kd[i * ld + 1] * c1 + k0[i] * cd0 + k1[i] * cd1;
+        v1[i] = -pd - s;
+    }
+    __syncthreads();
+    double acc = 0.0;
+    for (int i = tid + 2; i < Mz; i += nt) acc += af[i] * dot4(Li + i * ld, 1, v1, 1, i + 1);
+    acc = block_sum(acc, red);
+    if (tid == 0) (role == 1 ? a.ws.gkl_ell : a.ws.gkl_var)[pl] = acc;
 }
 
 // A = Kfu (Kuu + jI)^-1 and its tangents for a tile of kRowTile time points:
 //   A_ell = (dKfu/dell - A dKuu/dell) Kinv,   A_var = (jitter / var) A Kinv
 // Output float32: A4[n][m] = {A, A_ell, A_var, 0} (one 16-byte load per use in the reverse pass)
 // and AT[m][n] for the forward path assembly.
-__global__ __launch_bounds__(kCovThreads) void cov_rows_kernel(CovArgs a) {
-    extern __shared__ double sm[];
-    const int tile = blockIdx.x, l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
+__device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int p, int tid, int nt) {
     const int M = a.M, Mz = M + 2, N = a.N, L = a.L, D = a.D, ld = Mz + 1;
     const size_t pl = (size_t)p * L + l;
     double* Ki = sm;                       // [Mz][ld]
@@ -897,6 +921,7 @@ T* carve(char*& cur, size_t count, bool real) {
 int vg_check_dims(const vgpmp_dims* d) {
     if (d->num_problems < 1 || d->S < 1 || d->S_total < d->S || d->N < 1 || d->M < 1 || d->L < 1 || d->B < 16)
         return VGPMP_E_SHAPE;
+    if (d->sample_offset < 0 || d->sample_offset + d->S > d->S_total) return VGPMP_E_SHAPE;
     if (d->M + 2 > VGPMP_MAX_MZ || d->L > VGPMP_MAX_DOF || (d->B % 16) != 0) return VGPMP_E_SHAPE;
     if (d->split_k != 1 && d->split_k != 2 && d->split_k != 4 && d->split_k != 8) return VGPMP_E_SHAPE;
     if ((d->B / d->split_k) % 16 != 0) return VGPMP_E_SHAPE;
@@ -916,6 +941,9 @@ size_t vg_layout_workspace(const vgpmp_dims* d, void* base, vg_workspace* ws) {
     ws->sig_var = carve<double>(cur, PL, real);
     ws->Kinv = carve<double>(cur, PL * Mz * Mz, real);
     ws->Kd_ell = carve<double>(cur, PL * Mz * Mz, real);
+    ws->Ks64 = carve<double>(cur, PL * Mz * Mz, real);
+    ws->Lk64 = carve<double>(cur, PL * Mz * Mz, real);
+    ws->Li64 = carve<double>(cur, PL * Mz * Mz, real);
     ws->kl_l = carve<double>(cur, PL, real);
     ws->gkl_qmu = carve<double>(cur, PL * M, real);
     ws->gkl_Q = carve<double>(cur, PL * M * M, real);
@@ -962,10 +990,11 @@ int vg_launch_rng(const vgpmp_dims* d, const vgpmp_noise* nz, uint32_t seed, uin
     const int P = d->num_problems, L = d->L, B = d->B, D = d->L, Mz = vg_mz(d);
     hipLaunchKernelGGL(rng_basis_kernel, dim3((L * B + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, L, B, D, nz->omega,
                        nz->beta, seed, problem_base, step, ctr);
-    const uint32_t nW = (uint32_t)d->S * L * B, nE = (uint32_t)d->S * Mz * L;
-    const uint32_t nctr = ((nW + 3) >> 2) + 2 * ((nE + 3) >> 2);
-    hipLaunchKernelGGL(rng_normals_kernel, dim3((nctr + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, nW, nE, nz->w,
-                       nz->eps, nz->eps2, seed, problem_base, step, ctr);
+    const uint32_t nW = (uint32_t)d->S * L * B, nE = (uint32_t)d->S * Mz * L;      // nW % 4 == 0 since B % 16 == 0
+    const uint32_t wOff = (uint32_t)d->sample_offset * L * B, eOff = (uint32_t)d->sample_offset * Mz * L;
+    const uint32_t nthr = (nW >> 2) + 2 * nE;
+    hipLaunchKernelGGL(rng_normals_kernel, dim3((nthr + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, nW, nE, wOff, eOff,
+                       nz->w, nz->eps, nz->eps2, seed, problem_base, step, ctr);
     return (int)hipGetLastError();
 }
 
@@ -1030,7 +1059,8 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
 #endif
     ca.ws = *ws;
     const int Mp = (Mz + 15) & ~15;
-    const size_t lds_cov = ((size_t)7 * Mp * (Mp + 1) + 4 * Mp) * sizeof(double);
+    const size_t lds_cov = ((size_t)6 * Mp * (Mp + 1) + 5 * Mp) * sizeof(double);
+    const size_t lds_cov_a = ((size_t)4 * Mp * (Mp + 1) + 2 * Mp) * sizeof(double);
     const size_t lds_rows = ((size_t)2 * Mz * (Mz + 1) + (size_t)4 * kRowTile * Mz + Mz) * sizeof(double);
     const bool fork = !ev && pb->side_stream && pb->fork_event && pb->join_event;
     hipStream_t cst = fork ? (hipStream_t)pb->side_stream : st;
@@ -1040,14 +1070,15 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
         VG_CHECK_HIP(hipStreamWaitEvent(cst, (hipEvent_t)pb->fork_event, 0));
     }
     {
-        const void* fn = backward ? (const void*)cov_fwd_kernel<true> : (const void*)cov_fwd_kernel<false>;
-        rc = set_dyn_lds(fn, lds_cov);
+        rc = set_dyn_lds((const void*)cov_a_kernel, lds_cov_a);
+        if (rc) return rc;
+        hipLaunchKernelGGL(cov_a_kernel, dim3(L, P), dim3(kCovThreads), lds_cov_a, cst, ca);
+        const void* fn = backward ? (const void*)cov_b_kernel<true> : (const void*)cov_b_kernel<false>;
+        const size_t lds_b = lds_cov > lds_rows ? lds_cov : lds_rows;
+        rc = set_dyn_lds(fn, lds_b);
         if (rc) return rc;
         void* kargs[] = {(void*)&ca};
-        VG_CHECK_HIP(hipLaunchKernel(fn, dim3(L, P), dim3(kCovThreads), kargs, lds_cov, cst));
-        rc = set_dyn_lds((const void*)cov_rows_kernel, lds_rows);
-        if (rc) return rc;
-        hipLaunchKernelGGL(cov_rows_kernel, dim3((N + kRowTile - 1) / kRowTile, L, P), dim3(kCovThreads), lds_rows, cst, ca);
+        VG_CHECK_HIP(hipLaunchKernel(fn, dim3(3 + (N + kRowTile - 1) / kRowTile, L, P), dim3(kCovThreads), kargs, lds_b, cst));
     }
     if (fork) VG_CHECK_HIP(hipEventRecord((hipEvent_t)pb->join_event, cst));
     mark();

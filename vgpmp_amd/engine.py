@@ -134,7 +134,8 @@ class PlannerBatch:
                  num_data: int, lengthscales: Sequence[float], variance: float, alpha: float = 100.0,
                  learning_rate: float = 0.02, num_bases: int = 1024, trainable: Optional[Dict[str, bool]] = None,
                  seed: int = 0, problem_base: int = 0, split_k: Optional[int] = None,
-                 samples_total: Optional[int] = None, kl_scale: float = 1.0, X: Optional[np.ndarray] = None):
+                 samples_total: Optional[int] = None, sample_offset: int = 0, kl_scale: float = 1.0,
+                 X: Optional[np.ndarray] = None):
         self.scene, self.lib, self.device = scene, scene.lib, scene.device
         spec = scene.spec
         q = np.asarray(queries, dtype=np.float64).reshape(-1, 2, spec.dof)
@@ -147,7 +148,7 @@ class PlannerBatch:
             split_k = 8 if P * L <= 16 else (4 if P * L <= 64 else (2 if P * L <= 256 else 1))
             while (B // split_k) % 16:
                 split_k //= 2
-        self.dims = capi.Dims(P, S, int(samples_total or S), N, M, L, B, int(split_k))
+        self.dims = capi.Dims(P, S, int(samples_total or S), N, M, L, B, int(split_k), int(sample_offset), 0)
         dev, f64, f32 = self.device, torch.float64, torch.float32
         # ---- unconstrained variables (models/vgpmp.py:166-171, 255-263)
         y_u = scene.joint_sigmoid_inverse(q)                                       # [P, 2, L]
@@ -309,6 +310,51 @@ class PlannerBatch:
         nbytes = n.value * (8 if dbl.value else 4)
         raw = self.workspace[off:off + nbytes]
         return raw.view(torch.float64 if dbl.value else torch.float32).clone()
+
+    # ---- plan extraction (models/vgpmp.py:312-339) -------------------------------------------------
+    def posterior_sampler(self, num_samples: int = 150, Xnew: Optional[np.ndarray] = None) -> "PlannerBatch":
+        """A forward-only view of the same models at other (S, N): shares the parameter tensors."""
+        n_new = self.N if Xnew is None else int(np.asarray(Xnew).shape[0])
+        key = (int(num_samples), n_new)
+        cache = self.__dict__.setdefault("_samplers", {})
+        if key not in cache:
+            mid = np.tile(0.5 * (self.scene.spec.low + self.scene.spec.high), (self.P, 2, 1))   # placeholder queries
+            child = PlannerBatch(self.scene, mid, num_samples=num_samples, num_inducing=self.M, num_data=n_new,
+                                 lengthscales=[1.0] * self.L, variance=1.0, alpha=self.alpha, learning_rate=self.lr,
+                                 num_bases=self.B, trainable=self.trainable, seed=self.seed + 7919,
+                                 problem_base=self.problem_base, X=Xnew)
+            child.q_mu, child.q_sqrt, child.raw_ell, child.raw_var = self.q_mu, self.q_sqrt, self.raw_ell, self.raw_var
+            child.y_u = self.y_u
+            child._pack()
+            cache[key] = child
+        return cache[key]
+
+    def posterior_mean(self) -> torch.Tensor:
+        """Mean of q(f) at this batch's X after a forward pass: joint_sigmoid(Kfu (Kuu + jI)^-1 q_mu), [P, N, L]."""
+        A = self.view("A4").reshape(self.P, self.L, self.N, self.Mz, 4)[..., 0]
+        m = self.view("m").reshape(self.P, self.L, self.Mz)
+        return self.scene.joint_sigmoid(torch.einsum("plnm,plm->pnl", A, m))
+
+    def sample_from_posterior(self, num_samples: int = 150, Xnew: Optional[np.ndarray] = None, step: int = 0):
+        """(mean, best sample, samples, best index) per problem; best = argmax_s sum_n log p (vgpmp.py:336-339)."""
+        sp = self.posterior_sampler(num_samples, Xnew)
+        sp.elbo(generate=True, step=step)
+        samples = sp.samples()                                       # [P, S, N, L]
+        best = sp.logp.sum(-1).argmax(dim=1)                         # [P]
+        idx = best.view(-1, 1, 1, 1).expand(-1, 1, samples.shape[2], samples.shape[3])
+        return sp.posterior_mean(), samples.gather(1, idx)[:, 0], samples, best
+
+    def path_clearance(self, path: torch.Tensor) -> torch.Tensor:
+        """Signed clearance (SDF distance minus sphere radius) of every sphere along joint paths
+        [..., N, L] -> [..., N, P].  Used by the headless success check that replaces the reference's
+        simulated trajectory execution (utils/robot.py:416-480)."""
+        sc = self.scene
+        q = path.reshape(-1, self.L).to(torch.float32)
+        pos = sc.fk_spheres(q).to(torch.float64)
+        rel = pos - torch.as_tensor(sc.scene_offset, dtype=torch.float64, device=pos.device)
+        _, dist, _ = sc.sdf_query(rel.reshape(-1, 3))
+        radii = torch.as_tensor(sc.spec.sphere_radii, dtype=torch.float32, device=pos.device)
+        return (dist.reshape(-1, sc.spec.num_spheres) - radii).reshape(path.shape[:-1] + (sc.spec.num_spheres,))
 
     # ---- results --------------------------------------------------------------------------------
     def samples(self) -> torch.Tensor:

@@ -1,0 +1,86 @@
+"""Orchestration of one planning problem behind the reference's names (utils/miscellaneous.py).
+
+The module is star-imported by the reference's driver, which then uses `gpflow`, `np`, `p`, `time`,
+`get_root_package_path` and `solve_planning_problem` (benchmarking.py:3-97), so those names are bound
+here on purpose.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+
+from .environment import get_root_package_path
+from .shims import gpflow, p, set_trainable
+
+
+def init_trainset(grid_spacing_X, grid_spacing_Xnew, input_dimension, degree_of_freedom, start_joints, end_joints,
+                  scale=100, end_time=1):
+    """utils/miscellaneous.py:115-127: time grids X / Xnew (rows t * 1_D) and y = [start; end]."""
+    X = np.array([np.full(input_dimension, t) for t in np.linspace(0, end_time * scale, grid_spacing_X)])
+    Xnew = np.array([np.full(input_dimension, t) for t in np.linspace(0, end_time * scale, grid_spacing_Xnew)])
+    y = np.concatenate([np.asarray(start_joints, dtype=np.float64).reshape(1, degree_of_freedom),
+                        np.asarray(end_joints, dtype=np.float64).reshape(1, degree_of_freedom)], axis=0)
+    return X, y, Xnew
+
+
+def disable_param_opt(planner, trainable_params):
+    """utils/miscellaneous.py:324-343: apply the `trainable_params` flags of parameters.yaml.
+    sigma_obs / alpha / inducing_variable can only be held fixed on the HIP path (the reference's
+    default); asking to train them raises."""
+    for key in ("sigma_obs", "alpha", "inducing_variable"):
+        if trainable_params.get(key, False):
+            raise NotImplementedError(f"training `{key}` is not supported by the HIP path (reference default: False)")
+    for kern in planner.kernel.kernels:
+        set_trainable(kern.variance, trainable_params["kernel_variance"])
+        set_trainable(kern.lengthscales, trainable_params["lengthscales"])
+    planner.trainable = {"q_mu": bool(trainable_params["q_mu"]), "q_sqrt": bool(trainable_params["q_sqrt"]),
+                         "lengthscales": bool(trainable_params["lengthscales"]),
+                         "kernel_variance": bool(trainable_params["kernel_variance"])}
+    if planner._planner is not None:
+        planner._planner.trainable = dict(planner.trainable)
+
+
+def optimization_step(model, closure=None, optimizer=None, data=None):
+    """utils/miscellaneous.py:68-84: one Adam step on -ELBO; returns the loss of that step's paths."""
+    pl = model._ensure(model._n_train if data is None else model._check_data(data))
+    pl.step()
+    model.optimizer.iterations = pl.t
+    return float(-(pl.lik - pl.kl)[0])
+
+
+def training_loop(model, data, num_steps, print_summary=False, randomize=False):
+    """utils/miscellaneous.py:87-112."""
+    print("Starting training....")
+    model.optimization_steps(data, int(num_steps))
+    if print_summary:
+        for kern in model.kernel.kernels:
+            print(f"model lengthscale: {kern.lengthscales.numpy()} \\nmodel variance: {kern.variance.numpy()}")
+
+
+def solve_planning_problem(env, start_joints, end_joints, run=0, k=0):
+    """utils/miscellaneous.py:141-321 without the GUI branches: build the model for this start-goal
+    pair, optimise, draw 150 posterior paths, keep the most likely one and check it.
+    Returns (solved, best_sample[Nnew, D])."""
+    from .model import VGPMP
+    planner_params = env.config["planner_params"]
+    trainable_params = env.config["trainable_params"]
+    dof = env.robot.dof
+    X, y, Xnew = init_trainset(planner_params["time_spacing_X"], planner_params["time_spacing_Xnew"], dof, dof,
+                               start_joints, end_joints, scale=1)
+    planner = VGPMP.initialize(sdf=env.sdf, robot=env.robot, sampler=env.sampler, query_states=y,
+                               scene_offset=env.scene.position, q_mu=None, interpolation_method="linear",
+                               **planner_params)
+    disable_param_opt(planner, trainable_params)
+    env.robot.set_current_joint_config(np.squeeze(start_joints))
+    training_loop(model=planner, num_steps=planner_params["num_steps"], data=X)
+    sample_mean, best_sample, samples, uncertainties = planner.sample_from_posterior(Xnew, env.robot)
+    env.robot.set_current_joint_config(np.squeeze(start_joints))
+    env.robot.enable_collision_active_links(-1)
+    pl = planner._planner
+    import torch
+    env.robot.clearance_fn = lambda path: float(pl.path_clearance(torch.as_tensor(path, device=pl.device)).min())
+    res = env.robot.move_to_ee_config(best_sample)
+    return res, best_sample
