@@ -32,9 +32,23 @@ F32_MFMA_PEAK_TFLOPS = 157.3    # v_mfma_f32_16x16x4_f32 dense peak
 
 def build_problem(rank: int, args):
     ps = robots.load_problemset("franka", "industrial")
+    pp = ps.planner_params
+    if args.workload == "stress":
+        # BASELINE config 5, one GPU's share: synthetic 14-DoF arm, 512^3 float4 table (2 GiB > Infinity Cache),
+        # random start-goal pairs in +-2 rad (seed 0)
+        spec = robots.synthetic_arm(14)
+        grid = scenes.synthetic_boxes_sdf(n=args.grid, delta=2.0 / args.grid, origin=(-1.0, -1.0, -1.0), seed=0,
+                                          n_boxes=24, n_spheres=16, dtype=np.float32)
+        rng = np.random.default_rng(rank)
+        qs = rng.uniform(-2.0, 2.0, (args.problems, 2, 14))
+        scene = engine.DeviceScene(spec, grid, (0.0, 0.0, 0.0), sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"])
+        planner = engine.PlannerBatch(scene, qs, num_samples=args.samples, num_inducing=args.inducing,
+                                      num_data=args.timesteps, num_bases=1024, lengthscales=[2.0] * 14, variance=0.2,
+                                      alpha=pp["alpha"], learning_rate=pp["learning_rate"], seed=1234,
+                                      problem_base=rank * args.problems)
+        return ps, spec, grid, scene, planner
     spec = robots.load_robot("franka", *ps.robot_pos_and_orn)
     grid = scenes.synthetic_boxes_sdf(n=args.grid, delta=1.6 / args.grid, origin=(-0.8, -0.8, -0.2), seed=0)
-    pp = ps.planner_params
     scene = engine.DeviceScene(spec, grid, ps.object_positions[0], sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"])
     queries = ps.queries
     qs = np.array([queries[(rank * args.problems + i) % len(queries)] for i in range(args.problems)])
@@ -91,6 +105,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=40)
     ap.add_argument("--allow-nan", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--workload", choices=("config2", "stress"), default="config2",
+                    help="config2 = the benchmark line; stress = BASELINE config 5 per-GPU share (use --problems 64 --grid 512)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,6 +144,17 @@ def main():
         elapsed = float(t[0])
     assert args.allow_nan or torch.isfinite(planner.q_mu).all(), "optimisation diverged"
 
+    # ---- one plan = num_steps optimisation steps + 150 posterior paths + best-sample pick (models/vgpmp.py:312-339)
+    t_sample = None
+    if args.workload == "config2":
+        n_new = int(ps.planner_params["time_spacing_Xnew"])
+        Xnew = np.tile(np.linspace(0.0, 1.0, n_new)[:, None], (1, spec.dof))
+        planner.sample_from_posterior(150, Xnew)            # warm (allocations)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        planner.sample_from_posterior(150, Xnew)[1].cpu()
+        t_sample = time.perf_counter() - t1
+
     # ---- per-kernel durations with HIP events (separate pass so the timed region stays clean)
     stage_ms = planner.profile_steps(max(1, args.profile_steps))
     S, N, M, D, P, B = args.samples, args.timesteps, args.inducing, spec.dof, spec.num_spheres, 1024
@@ -142,6 +169,15 @@ def main():
                  "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_flops / t_gemm / 1e12 / F32_MFMA_PEAK_TFLOPS,
                  "traffic": None, "algorithmic_flops_per_launch": gemm_flops, "avg_launch_ms": stage_ms["prior_gemm"]}
     dominant = max(stage_ms, key=stage_ms.get)
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tfile) and args.workload == "config2" and npb == 1:
+        try:
+            t = json.load(open(tfile))
+            roof_sdf["traffic"] = t.get("loglik_paths_kernel", {}).get("hbm_bytes_per_launch")
+            roof_sdf["traffic_source"] = t.get("source")
+            roof_gemm["traffic"] = t.get("prior_gemm_kernel", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
 
     if rank == 0:
         line = {
@@ -150,12 +186,17 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: Franka 7-DoF, industrial offset, synthetic "
+            "config": {"workload": ("BASELINE config 2: Franka 7-DoF, industrial offset" if args.workload == "config2"
+                                    else "BASELINE config 5 per-GPU share: synthetic 14-DoF arm") + ", synthetic "
                                    f"{args.grid}^3 SDF, {npb} start-goal problem(s) per GPU, S={S} M={M} T={N} B={B}, "
                                    "q_mu/q_sqrt/lengthscales/kernel_variance trainable",
                        "parallelism": f"problems sharded x{world}, no collective",
                        "launch": f"hipGraph x{args.unroll} steps" if args.unroll else "eager"},
-            "plans_per_sec": world * npb * args.steps / elapsed / float(ps.planner_params["num_steps"]),
+            "plans_per_sec": (world * npb / (float(ps.planner_params["num_steps"]) * elapsed / args.steps + t_sample)
+                              if t_sample is not None else None),
+            "plan_definition": f"{ps.planner_params['num_steps']} optimisation steps + 150 posterior paths at "
+                               f"{ps.planner_params['time_spacing_Xnew']} time points + best-sample pick "
+                               f"(sampling measured: {1e3 * t_sample:.2f} ms)" if t_sample is not None else None,
             "roofline": roof_sdf, "roofline_secondary": roof_gemm,
             "dominant_stage": dominant, "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
         }
