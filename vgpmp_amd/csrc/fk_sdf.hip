@@ -8,6 +8,11 @@
 // utils/sdf_utils.py:62-136.
 #include "vgpmp_device.h"
 
+#ifdef VGPMP_BISECT
+#include <stdlib.h>
+static int lik_bisect_mode() { const char* e = getenv("VGPMP_STOP_LIK"); return e ? atoi(e) : 0; }
+#endif
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -100,8 +105,9 @@ __device__ __forceinline__ int voxel_axis(float pos, float ch, float cl, float i
     return idx;
 }
 
-// Per-thread scratch in LDS ([slot][thread], conflict free): the frame loop stays ROLLED (small code:
-// these launches are instruction-fetch bound), so per-frame data cannot live in indexed registers.
+// Per-configuration scratch in LDS ([slot][configuration], conflict free): the frame loop stays ROLLED
+// (small code: these launches are instruction-fetch bound), so per-frame data cannot live in indexed
+// registers.  LPC lanes (1 or 4, adjacent lanes of one wave) share one configuration and its scratch.
 struct LikScratch {
     float* base;
     int stride;
@@ -110,49 +116,71 @@ struct LikScratch {
 // slots: [0, D) sin, [D, 2D) cos, then 6 per frame (F, M)
 __device__ __forceinline__ int lik_scratch_slots(int D) { return 2 * D + 6 * (D + 1); }
 
-// log p(e | g) of one configuration; with GRAD, d logp / d g_j is handed to `emit(j, value)`.
-template <bool GRAD, typename GetG, typename Emit>
+template <int LPC>
+__device__ __forceinline__ float quad_sum(float v) {
+    if (LPC >= 2) v += __shfl_xor(v, 1, VG_WAVE);
+    if (LPC >= 4) v += __shfl_xor(v, 2, VG_WAVE);
+    return v;
+}
+
+__device__ __forceinline__ void lik_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// log p(e | g) of one configuration, evaluated by LPC cooperating lanes (`sub` = lane within the group):
+// every lane walks the DH chain, lane `sub` places and looks up spheres sub, sub + LPC, ... of each frame;
+// per-frame force / moment sums are combined with quad shuffles.  The instruction stream per wave --
+// not memory -- bounds this kernel when few problems are in flight, hence the split.
+// With GRAD, d logp / d g_j is handed to `emit(j, value)` on lane j % LPC.  get_g(j) is called on lane
+// j % LPC only.  Returns the group's total on every lane.
+template <bool GRAD, int LPC, typename GetG, typename Emit>
 __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ rb, const vg_sdf_dev& sdf,
-                                               const LikScratch sc, GetG get_g, Emit emit) {
+                                               const LikScratch sc, int sub, GetG get_g, Emit emit, int dbg = 0) {
     const int D = rb->dof, P = rb->num_spheres;
     const float eps = rb->epsilon;
     const double offx = rb->scene_offset[0], offy = rb->scene_offset[1], offz = rb->scene_offset[2];
     const SdfFast fs = make_fast(sdf, offx, offy, offz);
+    // joint sines / cosines, split over the group
+#pragma nounroll
+    for (int j = sub; j < D; j += LPC) {
+        float st, ct;
+        sincosf(get_g(j) + rb->twist[j], &st, &ct);
+        sc.at(j) = st; sc.at(D + j) = ct;
+    }
+    if (LPC > 1) lik_wave_sync();
     Frame T = base_frame(rb);
     vg_float3 Ft = vg_make3(0.f, 0.f, 0.f), Mt = vg_make3(0.f, 0.f, 0.f);
     float acc = 0.f;
     int p = 0;
 #pragma nounroll
     for (int i = 0; i <= D; ++i) {
-        if (i > 0) {
-            float st, ct;
-            sincosf(get_g(i - 1) + rb->twist[i - 1], &st, &ct);
-            if (GRAD) { sc.at(i - 1) = st; sc.at(D + i - 1) = ct; }
-            dh_apply(rb, i - 1, st, ct, T);
-        }
+        if (i > 0) dh_apply(rb, i - 1, sc.at(i - 1), sc.at(D + i - 1), T);
         vg_float3 F = vg_make3(0.f, 0.f, 0.f), Mo = vg_make3(0.f, 0.f, 0.f);
         int pe = p;
         while (pe < P && rb->sphere_frame[pe] == i) ++pe;        // spheres [p, pe) ride on frame i
-        // four spheres per pass: positions, voxel indices and the four 16-byte gathers are issued
-        // unconditionally (tail entries repeat the last sphere with weight 0), then consumed
+        constexpr int U = LPC == 1 ? 4 : 1;                      // spheres per lane per pass
 #pragma nounroll
-        for (; p < pe; p += 4) {
-            float4 v[4];
-            vg_float3 pos[4];
+        for (int q0 = p + sub * U; q0 < pe; q0 += LPC * U) {
+            float4 v[U];
+            vg_float3 pos[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int q = min(p + u, pe - 1);
+            for (int u = 0; u < U; ++u) {        // loads issued unconditionally (tail repeats the last sphere)
+                const int q = min(q0 + u, pe - 1);
                 pos[u] = axpy(rb->sphere_off[q][0], T.cx, axpy(rb->sphere_off[q][1], T.cy,
                               axpy(rb->sphere_off[q][2], T.cz, T.t)));
                 const int ix = voxel_axis(pos[u].x, fs.chx, fs.clx, fs.inv_delta, sdf.nx, offx, sdf.ox, sdf.delta);
                 const int iy = voxel_axis(pos[u].y, fs.chy, fs.cly, fs.inv_delta, sdf.ny, offy, sdf.oy, sdf.delta);
                 const int iz = voxel_axis(pos[u].z, fs.chz, fs.clz, fs.inv_delta, sdf.nz, offz, sdf.oz, sdf.delta);
+#ifdef VGPMP_BISECT
+                if (dbg == 2) { v[u] = make_float4(0.01f * ix, 0.1f, 0.2f * iy, 0.3f * iz); continue; }
+#endif
                 v[u] = sdf.table[((size_t)ix * sdf.ny + iy) * sdf.nz + iz];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int q = min(p + u, pe - 1);
-                const float wgt = (p + u < pe) ? 1.f : 0.f;
+            for (int u = 0; u < U; ++u) {
+                const int q = min(q0 + u, pe - 1);
+                const float wgt = (q0 + u < pe) ? 1.f : 0.f;
                 float c = fmaxf(eps - (v[u].x - rb->radius[q]), 0.f) * wgt;     // likelihood.py:131-143
                 float cs = c / rb->sigma_obs[q];
                 acc = fmaf(cs, c, acc);                                          // likelihood.py:99
@@ -166,16 +194,25 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
         }
         p = pe;
         if (GRAD) {
-            const int o = 2 * D + 6 * i;
-            sc.at(o) = F.x; sc.at(o + 1) = F.y; sc.at(o + 2) = F.z;
-            sc.at(o + 3) = Mo.x; sc.at(o + 4) = Mo.y; sc.at(o + 5) = Mo.z;
+            F = vg_make3(quad_sum<LPC>(F.x), quad_sum<LPC>(F.y), quad_sum<LPC>(F.z));
+            Mo = vg_make3(quad_sum<LPC>(Mo.x), quad_sum<LPC>(Mo.y), quad_sum<LPC>(Mo.z));
+            if (sub == 0) {
+                const int o = 2 * D + 6 * i;
+                sc.at(o) = F.x; sc.at(o + 1) = F.y; sc.at(o + 2) = F.z;
+                sc.at(o + 3) = Mo.x; sc.at(o + 4) = Mo.y; sc.at(o + 5) = Mo.z;
+            }
             Ft = vg_make3(Ft.x + F.x, Ft.y + F.y, Ft.z + F.z);
             Mt = vg_make3(Mt.x + Mo.x, Mt.y + Mo.y, Mt.z + Mo.z);
         }
     }
+    acc = quad_sum<LPC>(acc);
+#ifdef VGPMP_BISECT
+    if (dbg == 3) return -0.5f * acc;
+#endif
     if (GRAD) {
         // second sweep over the chain (sin/cos kept): joint i turns about z of frame i (Craig) or frame
         // i-1 (classic) and moves every sphere on frames >= i, i.e. the totals minus the prefix < i
+        if (LPC > 1) lik_wave_sync();
         const bool craig = rb->craig != 0;
         T = base_frame(rb);
         vg_float3 Fs = Ft, Ms = Mt;
@@ -188,7 +225,7 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
             dh_apply(rb, i - 1, sc.at(i - 1), sc.at(D + i - 1), T);
             if (craig) { z = T.cz; org = T.t; }
             const vg_float3 oxF = vg_cross(org, Fs);
-            emit(i - 1, vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)));
+            if ((i - 1) % LPC == sub) emit(i - 1, vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)));
         }
     }
     return -0.5f * acc;
@@ -209,39 +246,47 @@ __global__ __launch_bounds__(kLikBlock) void log_prob_kernel(const vgpmp_robot* 
     const LikScratch sc{lik_lds + threadIdx.x, kLikBlock};
     const float* g = gq + i * D;
     float* dg = dlogp + i * D;
-    logp[i] = loglik_config<GRAD>(rb, sdf, sc, [&](int j) { return g[j]; }, [&](int j, float v) { dg[j] = v; });
+    logp[i] = loglik_config<GRAD, 1>(rb, sdf, sc, 0, [&](int j) { return g[j]; }, [&](int j, float v) { dg[j] = v; });
 }
 
 // ---- ELBO path: f [P,S,L,N] -> logp [P,S,N], G = dloss/df [P,S,L,N], block partial sums ----------
+// LPC lanes per (sample, time) configuration; kLikBlock / LPC configurations per workgroup.
+template <int LPC>
 __global__ __launch_bounds__(kLikBlock) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
                                                                   const float* __restrict__ f, int S, int L, int N,
                                                                   float scale, float* __restrict__ G,
                                                                   float* __restrict__ logp,
-                                                                  float* __restrict__ lik_partial) {
+                                                                  float* __restrict__ lik_partial, int dbg) {
     extern __shared__ float lik_lds[];
     __shared__ float red[kLikBlock / VG_WAVE];
+#ifdef VGPMP_BISECT
+    if (dbg == 1) return;
+#endif
+    constexpr int CPB = kLikBlock / LPC;                 // configurations per workgroup
     const int pb = blockIdx.y;
-    const int idx = blockIdx.x * kLikBlock + threadIdx.x;
+    const int cl = threadIdx.x / LPC, sub = threadIdx.x % LPC;
+    const int idx = blockIdx.x * CPB + cl;
     const bool live = idx < S * N;
     float lp = 0.f;
-    if (live) {
+    {
         const vg_sdf_dev sdf = load_sdf(sdfh);
-        const int s = idx / N, n = idx - s * N;
+        const int ci = live ? idx : S * N - 1;           // dead groups recompute the last configuration, write nothing
+        const int s = ci / N, n = ci - s * N;
         const size_t base = ((size_t)pb * S + s) * L * N + n;
-        const LikScratch sc{lik_lds + threadIdx.x, kLikBlock};
-        float* dgdf = lik_lds + (size_t)lik_scratch_slots(L) * kLikBlock + threadIdx.x;   // [L][block]
-        lp = loglik_config<true>(
-            rb, sdf, sc,
+        const LikScratch sc{lik_lds + cl, CPB};
+        float* dgdf = lik_lds + (size_t)lik_scratch_slots(L) * CPB + cl;   // [L][CPB]
+        lp = loglik_config<true, LPC>(
+            rb, sdf, sc, sub,
             [&](int j) {
                 const float sg = 1.0f / (1.0f + __expf(-f[base + (size_t)j * N]));       // likelihood.py:49-52
                 const float span = rb->high[j] - rb->low[j];
-                dgdf[j * kLikBlock] = span * sg * (1.0f - sg);
+                dgdf[j * CPB] = span * sg * (1.0f - sg);
                 return fmaf(span, sg, rb->low[j]);
             },
-            [&](int j, float v) { G[base + (size_t)j * N] = scale * v * dgdf[j * kLikBlock]; });
-        logp[((size_t)pb * S + s) * N + n] = lp;
+            [&](int j, float v) { if (live) G[base + (size_t)j * N] = scale * v * dgdf[j * CPB]; }, dbg);
+        if (live && sub == 0) logp[((size_t)pb * S + s) * N + n] = lp;
     }
-    float w = vg_wave_sum(lp);
+    float w = vg_wave_sum(live && sub == 0 ? lp : 0.f);
     if ((threadIdx.x & (VG_WAVE - 1)) == 0) red[threadIdx.x / VG_WAVE] = w;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -320,7 +365,9 @@ __global__ __launch_bounds__(kBlock) void sdf_pack_kernel(const double* __restri
 
 }  // namespace
 
-int vg_loglik_blocks_per_problem(int S, int N) { return (S * N + kLikBlock - 1) / kLikBlock; }
+// lanes per configuration: 4 while the launch is too small to fill the chip (instruction bound), else 1
+static int lik_lpc(int P, int S, int N) { return (long long)P * S * N <= 65536 ? 4 : 1; }
+int vg_loglik_blocks_per_problem(int S, int N) { return (S * N * 4 + kLikBlock - 1) / kLikBlock; }   // upper bound (LPC = 4)
 
 static size_t lik_lds_bytes(int dof, bool with_dgdf) {
     return (size_t)(2 * dof + 6 * (dof + 1) + (with_dgdf ? dof : 0)) * kLikBlock * sizeof(float);
@@ -374,13 +421,24 @@ int vg_launch_log_prob_impl(const vgpmp_robot* rb, int dof, const vgpmp_sdf* sdf
 
 int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const float* f, int P, int S, int L, int N,
                            float scale, float* G, float* logp, float* lik_partial, int* nblk_out, hipStream_t st) {
-    const int nblk = vg_loglik_blocks_per_problem(S, N);
+    const int lpc = lik_lpc(P, S, N);
+    const int nblk = (S * N * lpc + kLikBlock - 1) / kLikBlock;
     if (nblk_out) *nblk_out = nblk;
     if (P == 0 || nblk == 0) return 0;
-    static size_t granted = 0;
-    int rc = lik_grant_lds((const void*)loglik_paths_kernel, lik_lds_bytes(L, true), &granted);
+    static size_t granted1 = 0, granted4 = 0;
+    const size_t lds = lik_lds_bytes(L, true) / lpc;
+    int rc = lpc == 4 ? lik_grant_lds((const void*)loglik_paths_kernel<4>, lds, &granted4)
+                      : lik_grant_lds((const void*)loglik_paths_kernel<1>, lds, &granted1);
     if (rc) return rc;
-    hipLaunchKernelGGL(loglik_paths_kernel, dim3(nblk, P), dim3(kLikBlock), lik_lds_bytes(L, true), st, rb, *sdf, f, S,
-                       L, N, scale, G, logp, lik_partial);
+    int dbg = 0;
+#ifdef VGPMP_BISECT
+    dbg = lik_bisect_mode();
+#endif
+    if (lpc == 4)
+        hipLaunchKernelGGL(loglik_paths_kernel<4>, dim3(nblk, P), dim3(kLikBlock), lds, st, rb, *sdf, f, S, L, N, scale,
+                           G, logp, lik_partial, dbg);
+    else
+        hipLaunchKernelGGL(loglik_paths_kernel<1>, dim3(nblk, P), dim3(kLikBlock), lds, st, rb, *sdf, f, S, L, N, scale,
+                           G, logp, lik_partial, dbg);
     return (int)hipGetLastError();
 }

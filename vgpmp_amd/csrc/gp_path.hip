@@ -472,7 +472,7 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
 // =================================================================================================
 __device__ __forceinline__ float softplus_f(float x) { return x > 15.f ? x : __logf(1.f + __expf(x)); }
 
-__global__ __launch_bounds__(kBlock) void features_kernel(int N, int Mz, int L, int D, int B,
+__global__ __launch_bounds__(kBlock) void features_kernel(int N, int Mz, int L, int D, int B, int jchunk,
                                                            const double* __restrict__ X,
                                                            const double* __restrict__ Zy,
                                                            const double* __restrict__ raw_ell,
@@ -481,26 +481,33 @@ __global__ __launch_bounds__(kBlock) void features_kernel(int N, int Mz, int L, 
                                                            const float* __restrict__ beta, float* __restrict__ Phi,
                                                            float* __restrict__ dPhi, uint32_t* __restrict__ tick) {
     if (tick && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *tick += 1u;
+    // one lane per (latent, basis): its frequency row stays in registers while it sweeps `jchunk` points;
+    // the points are uniform across the workgroup (scalar loads), the stores are coalesced along b
     const int b = blockIdx.x * kBlock + threadIdx.x;
-    const int j = blockIdx.y;
     const int l = blockIdx.z % L, p = blockIdx.z / L;
     const int J = N + Mz;
     const size_t pl = (size_t)p * L + l;
     if (b >= B) return;
-    // float32 softplus of the unconstrained hyper-parameters (uniform per workgroup -> scalar loads)
     const float ell = softplus_f((float)raw_ell[pl]);
     const float var = (float)kVarFloor + softplus_f((float)raw_var[pl]);
-    const double* pt = j < N ? X + (size_t)j * D : Zy + (size_t)(j - N) * D;
-    const float* om = omega + (pl * B + b) * D;
-    float proj = 0.f;
-    for (int d = 0; d < D; ++d) proj = fmaf((float)pt[d], om[d], proj);
-    // v_sin/v_cos take revolutions: reduce with fract (argument is a few tens of radians at most)
-    const float rev = __builtin_amdgcn_fractf((proj / ell + beta[pl * B + b]) * 0.15915494309189535f);
-    const float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
-    const float c = __builtin_amdgcn_sqrtf(2.0f * var / (float)B);
-    const size_t o = (pl * J + j) * B + b;
-    Phi[o] = c * cs;
-    if (dPhi) dPhi[o] = c * sn * proj / (ell * ell);
+    const float inv_ell = 1.0f / ell, c = __builtin_amdgcn_sqrtf(2.0f * var / (float)B);
+    float om[VGPMP_MAX_DOF];
+#pragma unroll
+    for (int d = 0; d < VGPMP_MAX_DOF; ++d) om[d] = d < D ? omega[(pl * B + b) * D + d] : 0.f;
+    const float bt = beta[pl * B + b];
+    const int j0 = blockIdx.y * jchunk, j1 = min(J, j0 + jchunk);
+    for (int j = j0; j < j1; ++j) {
+        const double* pt = j < N ? X + (size_t)j * D : Zy + (size_t)(j - N) * D;
+        float proj = 0.f;
+#pragma unroll
+        for (int d = 0; d < VGPMP_MAX_DOF; ++d)
+            if (d < D) proj = fmaf((float)pt[d], om[d], proj);
+        // v_sin/v_cos take revolutions: reduce with fract (argument is a few tens of radians at most)
+        const float rev = __builtin_amdgcn_fractf((proj * inv_ell + bt) * 0.15915494309189535f);
+        const size_t o = (pl * J + j) * B + b;
+        Phi[o] = c * __builtin_amdgcn_cosf(rev);
+        if (dPhi) dPhi[o] = c * __builtin_amdgcn_sinf(rev) * proj * inv_ell * inv_ell;
+    }
 }
 
 // =================================================================================================
@@ -1088,8 +1095,10 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
     }
     mark();
     // ---- features and prior GEMM
-    hipLaunchKernelGGL(features_kernel, dim3((B + kBlock - 1) / kBlock, J, P * L), dim3(kBlock), 0, st, N, Mz, L, L, B,
-                       pb->X, pb->Zy, params->raw_ell, params->raw_var, nz->omega, nz->beta, ws->Phi,
+    // few problems: one point per workgroup (more parallelism); many: sweep 16 points per lane (omega reuse)
+    const int jchunk = P * L >= 64 ? 16 : 1;
+    hipLaunchKernelGGL(features_kernel, dim3((B + kBlock - 1) / kBlock, (J + jchunk - 1) / jchunk, P * L), dim3(kBlock), 0,
+                       st, N, Mz, L, L, B, jchunk, pb->X, pb->Zy, params->raw_ell, params->raw_var, nz->omega, nz->beta, ws->Phi,
                        want_dell ? ws->dPhi : (float*)nullptr, (what & VGPMP_DO_ADAM) ? ctr : (uint32_t*)nullptr);
     mark();
     const size_t slab = (size_t)P * S * L * J;
