@@ -38,6 +38,10 @@ __device__ __forceinline__ double matern52_dell(double t1, double t2, double ell
     return var * exp(-kSqrt5 * r) * (5.0 * r * r / (3.0 * ell)) * (1.0 + kSqrt5 * r);
 }
 
+// e / n for 0 <= e < 2^21 via a float reciprocal (exact for n <= 4096, checked exhaustively): a 32-bit
+// integer division expands to ~30 instructions, and these kernels are instruction-fetch bound
+__device__ __forceinline__ int vg_div(int e, float inv_n) { return (int)(((float)e + 0.5f) * inv_n); }
+
 // strided dot product with four independent accumulators (a dependent f64 FMA costs ~40 cycles)
 __device__ __attribute__((noinline)) double dot4(const double* a, int sa, const double* b, int sb, int n) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -193,8 +197,9 @@ __device__ __forceinline__ void matmul_f64(MatView A, MatView B, int Mp, int tid
 __device__ __forceinline__ void chol_inverse_block(double* La, double* Li, double* Aug, double* rsd, int Mz, int ld,
                                                    int tid, int nt) {
     const int la = 2 * Mz + 1;
+    const float iMz = 1.0f / (float)Mz, i2Mz = 0.5f / (float)Mz;
     for (int e = tid; e < Mz * 2 * Mz; e += nt) {
-        const int i = e / (2 * Mz), j = e - i * 2 * Mz;
+        const int i = vg_div(e, i2Mz), j = e - i * 2 * Mz;
         Aug[i * la + j] = j < Mz ? La[i * ld + j] : (j - Mz == i ? 1.0 : 0.0);
     }
     __syncthreads();
@@ -202,7 +207,8 @@ __device__ __forceinline__ void chol_inverse_block(double* La, double* Li, doubl
         const double r = 1.0 / Aug[k * la + k];
         const int h = Mz - k - 1;                   // rows k+1 .. Mz-1, columns k+1 .. Mz+k
         for (int e = tid; e < h * Mz; e += nt) {
-            const int i = k + 1 + e / Mz, j = k + 1 + e % Mz;
+            const int qi = vg_div(e, iMz);
+            const int i = k + 1 + qi, j = k + 1 + (e - qi * Mz);
             Aug[i * la + j] = fma(-(Aug[i * la + k] * r), Aug[k * la + j], Aug[i * la + j]);
         }
         __syncthreads();
@@ -210,7 +216,7 @@ __device__ __forceinline__ void chol_inverse_block(double* La, double* Li, doubl
     for (int k = tid; k < Mz; k += nt) rsd[k] = rsqrt(Aug[k * la + k]);
     __syncthreads();
     for (int e = tid; e < Mz * Mz; e += nt) {
-        const int i = e / Mz, j = e - i * Mz;
+        const int i = vg_div(e, iMz), j = e - i * Mz;
         La[i * ld + j] = j <= i ? Aug[j * la + i] * rsd[j] : 0.0;
         Li[i * ld + j] = j <= i ? Aug[i * la + Mz + j] * rsd[i] : 0.0;
     }
@@ -224,6 +230,7 @@ __global__ __launch_bounds__(kCovThreads) void cov_a_kernel(CovArgs a) {
     const int l = blockIdx.x, p = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
     const int M = a.M, Mz = M + 2, L = a.L, D = a.D;
     const int Mp = (Mz + 15) & ~15, ld = Mp + 1;
+    const float iMz = 1.0f / (float)Mz;
     const size_t pl = (size_t)p * L + l;
     double* La = sm;                 // Kuu + jI -> Cholesky factor Lk      (Mp x ld, zero padded)
     double* Li = La + Mp * ld;       // Lk^-1
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(kCovThreads) void cov_a_kernel(CovArgs a) {
     double* Kg = a.ws.Ks64 + pl * Mz * Mz;
     double* Kdg = a.ws.Kd_ell + pl * Mz * Mz;
     for (int e = tid; e < Mz * Mz; e += nt) {
-        int i = e / Mz, j = e - i * Mz;
+        int i = vg_div(e, iMz), j = e - i * Mz;
         if (j > i) continue;
         double r = fabs(zs[i] - zs[j]) / ell;
         double ex = exp(-kSqrt5 * r);
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(kCovThreads) void cov_a_kernel(CovArgs a) {
     double* Lig = a.ws.Li64 + pl * Mz * Mz;
     float* Lk32 = a.ws.Lk32 + pl * Mz * Mz;
     for (int e = tid; e < Mz * Mz; e += nt) {
-        const int i = e / Mz, j = e - i * Mz;
+        const int i = vg_div(e, iMz), j = e - i * Mz;
         Lkg[e] = La[i * ld + j];
         Lig[e] = Li[i * ld + j];
         Lk32[e] = (float)La[i * ld + j];
@@ -292,6 +299,7 @@ __global__ __launch_bounds__(kCovThreads) void cov_b_kernel(CovArgs a) {
     if (role > 0 && (!TANGENTS || (role == 1 && !a.want_dell))) return;
     const int M = a.M, Mz = M + 2, L = a.L;
     const int Mp = (Mz + 15) & ~15, ld = Mp + 1;
+    const float iMz = 1.0f / (float)Mz, iM = 1.0f / (float)M;
     const size_t pl = (size_t)p * L + l;
     double* La = sm;                 // Lk                               (all Mp x ld, zero padded)
     double* Li = La + Mp * ld;       // Lk^-1
@@ -314,14 +322,14 @@ __global__ __launch_bounds__(kCovThreads) void cov_b_kernel(CovArgs a) {
         const double* Kdg = a.ws.Kd_ell + pl * Mz * Mz;
         const double* Qg = a.q_sqrt + pl * M * M;
         for (int e = tid; e < Mz * Mz; e += nt) {
-            const int i = e / Mz, j = e - i * Mz;
+            const int i = vg_div(e, iMz), j = e - i * Mz;
             La[i * ld + j] = Lkg[e];
             Li[i * ld + j] = Lig[e];
             if (role == 1) Kd[i * ld + j] = Kdg[e];
             if (role == 2) Kd[i * ld + j] = Kg[e] / var;
         }
         for (int e = tid; e < M * M; e += nt) {
-            const int r = e / M, c = e - r * M;
+            const int r = vg_div(e, iM), c = e - r * M;
             if (c <= r) Qp[(r + 2) * ld + (c + 2)] = Qg[e];
         }
         for (int i = tid; i < Mz; i += nt) {
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(kCovThreads) void cov_b_kernel(CovArgs a) {
         });
         double* gklQ = a.ws.gkl_Q + pl * M * M;
         for (int e = tid; e < M * M; e += nt) {
-            int r = e / M, c = e - r * M;
+            int r = vg_div(e, iM), c = e - r * M;
             double gq = 0.0;
             if (c <= r) {
                 double q = Qp[(r + 2) * ld + (c + 2)];
@@ -407,6 +415,7 @@ __global__ __launch_bounds__(kCovThreads) void cov_b_kernel(CovArgs a) {
 // and AT[m][n] for the forward path assembly.
 __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int p, int tid, int nt) {
     const int M = a.M, Mz = M + 2, N = a.N, L = a.L, D = a.D, ld = Mz + 1;
+    const float iMz = 1.0f / (float)Mz;
     const size_t pl = (size_t)p * L + l;
     double* Ki = sm;                       // [Mz][ld]
     double* Kd = Ki + Mz * ld;             // [Mz][ld]
@@ -419,7 +428,7 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
     const double* Kig = a.ws.Kinv + pl * Mz * Mz;
     const double* Kdg = a.ws.Kd_ell + pl * Mz * Mz;
     for (int e = tid; e < Mz * Mz; e += nt) {
-        int i = e / Mz, j = e - i * Mz;
+        int i = vg_div(e, iMz), j = e - i * Mz;
         Ki[i * ld + j] = Kig[e];
         Kd[i * ld + j] = a.want_dell ? Kdg[e] : 0.0;
     }
@@ -427,7 +436,7 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
     __syncthreads();
     const int n0 = tile * kRowTile;
     for (int e = tid; e < kRowTile * Mz; e += nt) {
-        int r = e / Mz, m = e - r * Mz, n = n0 + r;
+        int r = vg_div(e, iMz), m = e - r * Mz, n = n0 + r;
         double k = 0.0, dk = 0.0;
         if (n < N) {
             double rr = fabs(a.X[(size_t)n * D + l] - zs[m]) / ell;
@@ -439,7 +448,7 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
     }
     __syncthreads();
     for (int e = tid; e < kRowTile * Mz; e += nt) {
-        int r = e / Mz, m = e - r * Mz;
+        int r = vg_div(e, iMz), m = e - r * Mz;
         ar[e] = dot4(kf + r * Mz, 1, Ki + m, ld, Mz);
     }
     __syncthreads();
@@ -448,7 +457,7 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
     float av_keep[2] = {0.f, 0.f};
     int cnt = 0;
     for (int e = tid; e < kRowTile * Mz; e += nt, ++cnt) {
-        int r = e / Mz, m = e - r * Mz;
+        int r = vg_div(e, iMz), m = e - r * Mz;
         const double y = df[e] - dot4(ar + r * Mz, 1, Kd + m, ld, Mz);
         const double v = dot4(ar + r * Mz, 1, Ki + m, ld, Mz);
         yr[e] = y;
@@ -457,7 +466,7 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
     __syncthreads();
     cnt = 0;
     for (int e = tid; e < kRowTile * Mz; e += nt, ++cnt) {
-        int r = e / Mz, m = e - r * Mz, n = n0 + r;
+        int r = vg_div(e, iMz), m = e - r * Mz, n = n0 + r;
         if (n >= N) continue;
         const double s = a.want_dell ? dot4(yr + r * Mz, 1, Ki + m, ld, Mz) : 0.0;
         const float av = av_keep[cnt < 2 ? cnt : 1];
@@ -619,6 +628,7 @@ __global__ __launch_bounds__(kBlock) void paths_fwd_kernel(PathArgs a) {
     extern __shared__ float smf[];
     const int ch = blockIdx.x, l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
     const int S = a.S, N = a.N, Mz = a.Mz, L = a.L, J = N + Mz, ld = Mz + 1;
+    const float iMz = 1.0f / (float)Mz, iN = 1.0f / (float)N, iJ = 1.0f / (float)J;
     const size_t pl = (size_t)p * L + l;
     float* Cs = smf;                   // [Mz][ld]
     float* ATs = Cs + Mz * ld;         // [Mz][N]
@@ -627,21 +637,21 @@ __global__ __launch_bounds__(kBlock) void paths_fwd_kernel(PathArgs a) {
     float* f0s = e2s + VG_SC * Mz;     // [SC][J]   prior draws (split-K slabs summed)
     float* rs = f0s + VG_SC * J;       // [SC][Mz]
     const int s_base = ch * VG_SC;
-    for (int e = tid; e < Mz * Mz; e += nt) Cs[(e / Mz) * ld + e % Mz] = a.C[pl * Mz * Mz + e];
+    for (int e = tid; e < Mz * Mz; e += nt) Cs[(vg_div(e, iMz)) * ld + (e - vg_div(e, iMz) * Mz)] = a.C[pl * Mz * Mz + e];
     for (int e = tid; e < Mz * N; e += nt) ATs[e] = a.AT[pl * N * Mz + e];
     for (int e = tid; e < VG_SC * Mz; e += nt) {
-        const int sl = e / Mz, k = e - sl * Mz, s = min(s_base + sl, S - 1);
+        const int sl = vg_div(e, iMz), k = e - sl * Mz, s = min(s_base + sl, S - 1);
         const size_t o = (((size_t)p * S + s) * Mz + k) * L + l;
         es[e] = a.eps[o];
         e2s[e] = a.eps2[o];
     }
     for (int e = tid; e < VG_SC * J; e += nt) {
-        const int sl = e / J, j = e - sl * J, s = min(s_base + sl, S - 1);
+        const int sl = vg_div(e, iJ), j = e - sl * J, s = min(s_base + sl, S - 1);
         f0s[e] = read_slabs<SK>(a.F0, (((size_t)p * S + s) * L + l) * J + j, a.slab);
     }
     __syncthreads();
     for (int e = tid; e < VG_SC * Mz; e += nt) {
-        const int sl = e / Mz, mi = e - sl * Mz, s = s_base + sl;
+        const int sl = vg_div(e, iMz), mi = e - sl * Mz, s = s_base + sl;
         float u = a.m[pl * Mz + mi];
         for (int k = 0; k <= mi; ++k) u = fmaf(Cs[mi * ld + k], es[sl * Mz + k], u);
         const float r = u - f0s[sl * J + N + mi] - a.sqrt_jitter * e2s[e];
@@ -650,7 +660,7 @@ __global__ __launch_bounds__(kBlock) void paths_fwd_kernel(PathArgs a) {
     }
     __syncthreads();
     for (int e = tid; e < VG_SC * N; e += nt) {
-        const int sl = e / N, n = e - sl * N, s = s_base + sl;
+        const int sl = vg_div(e, iN), n = e - sl * N, s = s_base + sl;
         float v = f0s[sl * J + n];
         for (int k = 0; k < Mz; ++k) v = fmaf(ATs[k * N + n], rs[sl * Mz + k], v);
         if (s < S) a.f[(((size_t)p * S + s) * L + l) * N + n] = v;
@@ -668,6 +678,7 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_kernel(PathArgs a) {
     __shared__ float red[3][kBlock / VG_WAVE];
     const int ch = blockIdx.x, l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
     const int S = a.S, N = a.N, Mz = a.Mz, L = a.L, J = N + Mz;
+    const float iMz = 1.0f / (float)Mz, iN = 1.0f / (float)N, iJ = 1.0f / (float)J;
     const size_t pl = (size_t)p * L + l;
     float4* A4s = reinterpret_cast<float4*>(smf);      // [N][Mz] {A, A_ell, A_var, -}
     float* Ces = smf + (size_t)4 * N * Mz;             // [Mz][Mz] (dC/dell)^T
@@ -687,17 +698,17 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_kernel(PathArgs a) {
             Cvs[e] = a.CT_var[pl * Mz * Mz + e];
         }
         for (int e = tid; e < VG_SC * N; e += nt) {
-            const int sl = e / N, n = e - sl * N, s = s_base + sl;
+            const int sl = vg_div(e, iN), n = e - sl * N, s = s_base + sl;
             Gs[e] = s < S ? a.G[(((size_t)p * S + s) * L + l) * N + n] : 0.f;
         }
         for (int e = tid; e < VG_SC * J; e += nt) {
-            const int sl = e / J, j = e - sl * J, s = min(s_base + sl, S - 1);
+            const int sl = vg_div(e, iJ), j = e - sl * J, s = min(s_base + sl, S - 1);
             const size_t fo = (((size_t)p * S + s) * L + l) * J + j;
             f0s[e] = read_slabs<SK>(a.F0, fo, a.slab);
             hs[e] = a.want_dell ? read_slabs<SK>(a.H, fo, a.slab) : 0.f;
         }
         for (int e = tid; e < VG_SC * Mz; e += nt) {
-            const int sl = e / Mz, mi = e - sl * Mz, s = s_base + sl;
+            const int sl = vg_div(e, iMz), mi = e - sl * Mz, s = s_base + sl;
             Rs[e] = s < S ? a.R[(((size_t)p * S + s) * L + l) * Mz + mi] : 0.f;
             Es[e] = s < S ? a.eps[(((size_t)p * S + s) * Mz + mi) * L + l] : 0.f;
         }
@@ -706,7 +717,7 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_kernel(PathArgs a) {
     VG_STOP(a, 1);
     float se = 0.f, sv = 0.f, sr = 0.f;
     for (int e = tid; e < VG_SC * Mz; e += nt) {
-        const int sl = e / Mz, mi = e - sl * Mz;
+        const int sl = vg_div(e, iMz), mi = e - sl * Mz;
         const float* g = Gs + sl * N;
         float d = 0.f, de = 0.f, dv = 0.f;
         for (int n = 0; n < N; ++n) {
@@ -729,7 +740,7 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_kernel(PathArgs a) {
         sr -= d * f0s[sl * J + N + mi];
     }
     for (int e = tid; e < VG_SC * N; e += nt) {
-        const int sl = e / N, n = e - sl * N;
+        const int sl = vg_div(e, iN), n = e - sl * N;
         const float gv = Gs[e];             // zero for samples beyond S
         sr = fmaf(gv, f0s[sl * J + n], sr);
         se = fmaf(gv, hs[sl * J + n], se);
@@ -744,7 +755,7 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_kernel(PathArgs a) {
     }
     float* oC = out + Mz;
     for (int e = tid; e < Mz * Mz; e += nt) {
-        const int mi = e / Mz, k = e - mi * Mz;
+        const int mi = vg_div(e, iMz), k = e - mi * Mz;
         float t = 0.f;
         for (int sl = 0; sl < VG_SC; ++sl) t = fmaf(dRs[sl * Mz + mi], Es[sl * Mz + k], t);
         oC[e] = t;
@@ -794,6 +805,7 @@ __global__ __launch_bounds__(kBlock) void final_kernel(FinalArgs b) {
     VG_STOP(b, 7);
     const int l = blockIdx.x, p = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
     const int M = b.M, Mz = M + 2, L = b.L;
+    const float iM = 1.0f / (float)M;
     const size_t pl = (size_t)p * L + l;
     double* dC = sm;                 // [Mz][Mz]
     double* dmv = dC + Mz * Mz;      // [Mz]
@@ -836,44 +848,46 @@ __global__ __launch_bounds__(kBlock) void final_kernel(FinalArgs b) {
     const double kls = b.kl_scale;
     double* gQ = b.g_qsqrt + pl * M * M;
     const double* kQ = b.gkl_Q + pl * M * M;
-    const bool adam_q = b.do_adam && (b.trainable & VGPMP_TRAIN_Q_SQRT);
     const double lr_t = lrs;
     for (int e = tid; e < M * M; e += nt) {
-        int r = e / M, c = e - r * M;
+        int r = vg_div(e, iM), c = e - r * M;
         double s = 0.0;
         if (c <= r) {
             // tril(Lk^T dC)[2:, 2:]
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            double s0 = 0.0, s1 = 0.0;
             int i = r + 2;
-            for (; i + 3 < Mz; i += 4) {
+            for (; i + 1 < Mz; i += 2) {
                 s0 = fma((double)Lks[i * Mz + (r + 2)], dC[i * Mz + (c + 2)], s0);
                 s1 = fma((double)Lks[(i + 1) * Mz + (r + 2)], dC[(i + 1) * Mz + (c + 2)], s1);
-                s2 = fma((double)Lks[(i + 2) * Mz + (r + 2)], dC[(i + 2) * Mz + (c + 2)], s2);
-                s3 = fma((double)Lks[(i + 3) * Mz + (r + 2)], dC[(i + 3) * Mz + (c + 2)], s3);
             }
-            for (; i < Mz; ++i) s0 = fma((double)Lks[i * Mz + (r + 2)], dC[i * Mz + (c + 2)], s0);
-            s = (s0 + s1) + (s2 + s3) + kls * kQ[e];
-            if (adam_q)
-                adam_update(b.pq_sqrt + pl * M * M + e, b.mq_sqrt + pl * M * M + e, b.vq_sqrt + pl * M * M + e, s, lr_t);
+            if (i < Mz) s0 = fma((double)Lks[i * Mz + (r + 2)], dC[i * Mz + (c + 2)], s0);
+            s = s0 + s1 + kls * kQ[e];
         }
         gQ[e] = s;
     }
     VG_STOP(b, 2);
     double* gm = b.g_qmu + pl * M;
-    for (int i = tid; i < M; i += nt) {
-        const double g = dmv[i + 2] + kls * b.gkl_qmu[pl * M + i];
-        gm[i] = g;
-        if (b.do_adam && (b.trainable & VGPMP_TRAIN_Q_MU))
-            adam_update(b.pq_mu + pl * M + i, b.mq_mu + pl * M + i, b.vq_mu + pl * M + i, g, lr_t);
-    }
-    if (tid == 64) {
+    for (int i = tid; i < M; i += nt) gm[i] = dmv[i + 2] + kls * b.gkl_qmu[pl * M + i];
+    if (tid == 0) {
         const double var = b.var[pl];
-        const double g_ell = ((b.want_dell ? sc[0] : 0.0) + kls * b.gkl_ell[pl]) * b.sig_ell[pl];
-        const double g_var = (sc[1] + sc[2] / (2.0 * var) + kls * b.gkl_var[pl]) * b.sig_var[pl];
-        b.g_ell[pl] = g_ell; b.g_var[pl] = g_var;
-        if (b.do_adam) {
-            if (b.trainable & VGPMP_TRAIN_LENGTHSCALES) adam_update(b.p_ell + pl, b.m_ell + pl, b.v_ell + pl, g_ell, lr_t);
-            if (b.trainable & VGPMP_TRAIN_KERNEL_VARIANCE) adam_update(b.p_var + pl, b.m_var + pl, b.v_var + pl, g_var, lr_t);
+        b.g_ell[pl] = ((b.want_dell ? sc[0] : 0.0) + kls * b.gkl_ell[pl]) * b.sig_ell[pl];
+        b.g_var[pl] = (sc[1] + sc[2] / (2.0 * var) + kls * b.gkl_var[pl]) * b.sig_var[pl];
+    }
+    if (b.do_adam) {
+        __syncthreads();           // gradients above are read back below (same workgroup, global memory)
+        // ONE update loop over every variable of this latent: q_mu | q_sqrt (lower) | lengthscale | variance
+        const int nq = M + M * M;
+        for (int k = tid; k < nq + 2; k += nt) {
+            double *x, *m, *v; double g; int flag;
+            if (k < M) { x = b.pq_mu + pl * M + k; m = b.mq_mu + pl * M + k; v = b.vq_mu + pl * M + k; g = gm[k]; flag = VGPMP_TRAIN_Q_MU; }
+            else if (k < nq) {
+                const int e = k - M, r = vg_div(e, iM);
+                if (e - r * M > r) continue;
+                x = b.pq_sqrt + pl * M * M + e; m = b.mq_sqrt + pl * M * M + e; v = b.vq_sqrt + pl * M * M + e; g = gQ[e];
+                flag = VGPMP_TRAIN_Q_SQRT;
+            } else if (k == nq) { x = b.p_ell + pl; m = b.m_ell + pl; v = b.v_ell + pl; g = b.g_ell[pl]; flag = VGPMP_TRAIN_LENGTHSCALES; }
+            else { x = b.p_var + pl; m = b.m_var + pl; v = b.v_var + pl; g = b.g_var[pl]; flag = VGPMP_TRAIN_KERNEL_VARIANCE; }
+            if (b.trainable & flag) adam_update(x, m, v, g, lr_t);
         }
     }
     if (l == 0 && tid < 64) {
