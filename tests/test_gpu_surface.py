@@ -178,3 +178,28 @@ def test_graph_replay_matches_eager_steps():
     torch.cuda.synchronize()
     assert a.t == b.t == 8
     assert torch.allclose(a.q_mu, b.q_mu, rtol=0, atol=1e-12) and torch.allclose(a.raw_ell, b.raw_ell, rtol=0, atol=1e-12)
+
+
+def test_large_batch_kernels_match_small_launch_kernels():
+    """Large batches use the LDS-tiled prior GEMM (split_k = 1) and one lane per configuration in the
+    likelihood; each problem must still equal the same problem evaluated alone (split-K GEMM, 4 lanes per
+    configuration) up to float32 summation order."""
+    from vgpmp_amd import engine
+    S, N, M, B = 128, 60, 7, 64
+    ps = rb.load_problemset("franka", "industrial")
+    spec = rb.load_robot("franka")
+    grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
+    sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
+    qs = np.array([ps.queries[i] for i in range(10)])
+    kw = dict(num_samples=S, num_inducing=M, num_data=N, num_bases=B, lengthscales=[2.0] * 7, variance=0.2, seed=11)
+    batch = engine.PlannerBatch(sc, qs, split_k=1, **kw)          # 10 * 128 * 60 configurations -> 1 lane each
+    lb, gb = batch.loss_and_grad(step=5)
+    for p in (0, 4, 9):
+        solo = engine.PlannerBatch(sc, qs[p:p + 1], problem_base=p, **kw)
+        assert solo.dims.split_k > 1
+        ls, gs = solo.loss_and_grad(step=5)
+        assert torch.equal(solo.w[0], batch.w[p])
+        np.testing.assert_allclose(float(ls[0]), float(lb[p]), rtol=2e-5)
+        for a, b in zip(gs, gb):
+            a, b = a[0].cpu().numpy(), b[p].cpu().numpy()
+            assert np.abs(a - b).max() <= 2e-4 * np.abs(a).max() + 1e-9

@@ -2,7 +2,9 @@
 #pragma once
 #include "vgpmp_device.h"
 
-constexpr int VG_SC = 8;    // samples per chunk of the path kernels
+// samples per workgroup of the path kernels.  A 32-sample variant exists (template parameter) but measured
+// 10 % SLOWER at 64 problems/GPU (fewer workgroups in flight per CU), so 8 is used everywhere.
+inline int vg_sc(const vgpmp_dims*) { return 8; }
 
 struct vg_workspace {
     // float64 covariance path, per (problem, latent)
@@ -31,7 +33,7 @@ struct vg_workspace {
 
 inline int vg_mz(const vgpmp_dims* d) { return d->M + 2; }
 inline int vg_j(const vgpmp_dims* d) { return d->N + d->M + 2; }
-inline int vg_chunks(const vgpmp_dims* d) { return (d->S + VG_SC - 1) / VG_SC; }
+inline int vg_chunks(const vgpmp_dims* d) { return (d->S + vg_sc(d) - 1) / vg_sc(d); }
 inline size_t vg_part_len(const vgpmp_dims* d) {
     size_t mz = (size_t)vg_mz(d);
     return mz + mz * mz + 4;

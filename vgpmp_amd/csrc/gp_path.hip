@@ -589,6 +589,99 @@ __global__ __launch_bounds__(kBlock) void prior_gemm_kernel(int S, int L, int J,
     }
 }
 
+// LDS-tiled variant for large batches (no split-K): a workgroup owns 64 samples x 144 columns, stages
+// 32-deep K slices of W and Phi through double-buffered LDS (global -> registers -> LDS, next slice in
+// flight while the MFMAs run) and every wave reads its fragments with ds_read_b128.  Row stride 36 floats
+// keeps the 16-byte fragment reads of a 16-row group on distinct bank slots.  Raises flop per byte
+// fetched from L2 from ~10 to ~22 compared with the direct kernel above.
+constexpr int kTS = 64, kTJ = 144, kTK = 32, kTLd = 36;
+
+__global__ __launch_bounds__(kBlock) void prior_gemm_tiled_kernel(int S, int L, int J, int B, int nsel,
+                                                                   const float* __restrict__ W,
+                                                                   const float* __restrict__ Phi,
+                                                                   const float* __restrict__ dPhi,
+                                                                   float* __restrict__ F0, float* __restrict__ H) {
+    __shared__ float As[2][kTS * kTLd];
+    __shared__ float Bs[2][kTJ * kTLd];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int z = blockIdx.z;
+    const int sel = z % nsel; z /= nsel;
+    const int l = z % L, p = z / L;
+    const int s0 = blockIdx.y * kTS, j0 = blockIdx.x * kTJ;
+    const float* Bm = sel == 0 ? Phi : dPhi;
+    float* Out = sel == 0 ? F0 : H;
+    // staging map: thread -> (row, 16-byte k-chunk); A: 64 rows x 8 chunks = 512 (2 per thread),
+    // B: 144 rows x 8 chunks = 1152 (4.5 per thread -> 5 passes, last partial)
+    float4 ra[2], rbv[5];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = tid + q * kBlock, row = c >> 3, ch = c & 7;
+            const int srow = min(s0 + row, S - 1);
+            ra[q] = *reinterpret_cast<const float4*>(W + (((size_t)p * S + srow) * L + l) * B + k0 + 4 * ch);
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int c = min(tid + q * kBlock, kTJ * 8 - 1), row = c >> 3, ch = c & 7;
+            const int jrow = min(j0 + row, J - 1);
+            rbv[q] = *reinterpret_cast<const float4*>(Bm + (((size_t)p * L + l) * J + jrow) * B + k0 + 4 * ch);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = tid + q * kBlock, row = c >> 3, ch = c & 7;
+            *reinterpret_cast<float4*>(&As[buf][row * kTLd + 4 * ch]) = ra[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int c = tid + q * kBlock;
+            if (c < kTJ * 8) {
+                const int row = c >> 3, ch = c & 7;
+                *reinterpret_cast<float4*>(&Bs[buf][row * kTLd + 4 * ch]) = rbv[q];
+            }
+        }
+    };
+    vg_f32x4 acc[kTJ / 16];
+#pragma unroll
+    for (int t = 0; t < kTJ / 16; ++t) acc[t] = (vg_f32x4){0.f, 0.f, 0.f, 0.f};
+    const int r = lane & 15, g = lane >> 4;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < B; k0 += kTK) {
+        const bool more = k0 + kTK < B;
+        if (more) load_tiles(k0 + kTK);
+        const float* a_base = &As[buf][(wave * 16 + r) * kTLd + 4 * g];
+#pragma unroll
+        for (int kk = 0; kk < kTK; kk += 16) {
+            const float4 a4 = *reinterpret_cast<const float4*>(a_base + kk);
+#pragma unroll
+            for (int t = 0; t < kTJ / 16; ++t) {
+                const float4 b4 = *reinterpret_cast<const float4*>(&Bs[buf][(t * 16 + r) * kTLd + kk + 4 * g]);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc[t], 0, 0, 0);
+            }
+        }
+        if (more) store_tiles(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int t = 0; t < kTJ / 16; ++t) {
+        const int jc = j0 + 16 * t + r;
+        if (jc >= J) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int srow = s0 + wave * 16 + g * 4 + q;
+            if (srow < S) Out[(((size_t)p * S + srow) * L + l) * J + jc] = acc[t][q];
+        }
+    }
+}
+
 // =================================================================================================
 // Path assembly  (decoupled / Matheron update, vgpmp.py:281-282):
 //   u = m + C eps;  r = u - F0(Z) - sqrt(jitter) eps2;  f = F0(X) + A r
@@ -623,7 +716,7 @@ __device__ __forceinline__ float read_slabs(const float* base, size_t off, size_
 // All operands of a workgroup are staged into LDS by ONE wave of independent coalesced loads (these
 // launches are latency bound: every dependent global access costs ~0.3-0.7 us), then the loops run
 // out of LDS.  Code is kept rolled: cold instruction fetch is the other fixed cost of tiny launches.
-template <int SK>
+template <int SK, int SC>
 __global__ __launch_bounds__(kBlock) void paths_fwd_kernel(PathArgs a) {
     extern __shared__ float smf[];
     const int ch = blockIdx.x, l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
@@ -633,24 +726,24 @@ __global__ __launch_bounds__(kBlock) void paths_fwd_kernel(PathArgs a) {
     float* Cs = smf;                   // [Mz][ld]
     float* ATs = Cs + Mz * ld;         // [Mz][N]
     float* es = ATs + Mz * N;          // [SC][Mz]
-    float* e2s = es + VG_SC * Mz;      // [SC][Mz]
-    float* f0s = e2s + VG_SC * Mz;     // [SC][J]   prior draws (split-K slabs summed)
-    float* rs = f0s + VG_SC * J;       // [SC][Mz]
-    const int s_base = ch * VG_SC;
+    float* e2s = es + SC * Mz;      // [SC][Mz]
+    float* f0s = e2s + SC * Mz;     // [SC][J]   prior draws (split-K slabs summed)
+    float* rs = f0s + SC * J;       // [SC][Mz]
+    const int s_base = ch * SC;
     for (int e = tid; e < Mz * Mz; e += nt) Cs[(vg_div(e, iMz)) * ld + (e - vg_div(e, iMz) * Mz)] = a.C[pl * Mz * Mz + e];
     for (int e = tid; e < Mz * N; e += nt) ATs[e] = a.AT[pl * N * Mz + e];
-    for (int e = tid; e < VG_SC * Mz; e += nt) {
+    for (int e = tid; e < SC * Mz; e += nt) {
         const int sl = vg_div(e, iMz), k = e - sl * Mz, s = min(s_base + sl, S - 1);
         const size_t o = (((size_t)p * S + s) * Mz + k) * L + l;
         es[e] = a.eps[o];
         e2s[e] = a.eps2[o];
     }
-    for (int e = tid; e < VG_SC * J; e += nt) {
+    for (int e = tid; e < SC * J; e += nt) {
         const int sl = vg_div(e, iJ), j = e - sl * J, s = min(s_base + sl, S - 1);
         f0s[e] = read_slabs<SK>(a.F0, (((size_t)p * S + s) * L + l) * J + j, a.slab);
     }
     __syncthreads();
-    for (int e = tid; e < VG_SC * Mz; e += nt) {
+    for (int e = tid; e < SC * Mz; e += nt) {
         const int sl = vg_div(e, iMz), mi = e - sl * Mz, s = s_base + sl;
         float u = a.m[pl * Mz + mi];
         for (int k = 0; k <= mi; ++k) u = fmaf(Cs[mi * ld + k], es[sl * Mz + k], u);
@@ -659,7 +752,7 @@ __global__ __launch_bounds__(kBlock) void paths_fwd_kernel(PathArgs a) {
         if (s < S) a.R[(((size_t)p * S + s) * L + l) * Mz + mi] = r;
     }
     __syncthreads();
-    for (int e = tid; e < VG_SC * N; e += nt) {
+    for (int e = tid; e < SC * N; e += nt) {
         const int sl = vg_div(e, iN), n = e - sl * N, s = s_base + sl;
         float v = f0s[sl * J + n];
         for (int k = 0; k < Mz; ++k) v = fmaf(ATs[k * N + n], rs[sl * Mz + k], v);
@@ -672,7 +765,7 @@ __global__ __launch_bounds__(kBlock) void paths_fwd_kernel(PathArgs a) {
 //   hyper-parameters by dot products with the forward-mode tangents of the covariance kernels:
 //   s_ell = <R, G A_ell> + <dR, C_ell eps> + <G, H_X> - <dR, H_Z>
 //   s_var = <R, G A_var> + <dR, C_var eps> ;  s_rff = <G, F0_X> - <dR, F0_Z>   (x 1/(2 var) later)
-template <int SK>
+template <int SK, int SC>
 __global__ __launch_bounds__(kBlock) void paths_bwd_kernel(PathArgs a) {
     extern __shared__ float smf[];
     __shared__ float red[3][kBlock / VG_WAVE];
@@ -684,12 +777,12 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_kernel(PathArgs a) {
     float* Ces = smf + (size_t)4 * N * Mz;             // [Mz][Mz] (dC/dell)^T
     float* Cvs = Ces + Mz * Mz;                         // [Mz][Mz] (dC/dvar)^T
     float* Gs = Cvs + Mz * Mz;                          // [SC][N]
-    float* f0s = Gs + VG_SC * N;                        // [SC][J]
-    float* hs = f0s + VG_SC * J;                        // [SC][J]
-    float* Rs = hs + VG_SC * J;                         // [SC][Mz]
-    float* Es = Rs + VG_SC * Mz;                        // [SC][Mz]
-    float* dRs = Es + VG_SC * Mz;                       // [SC][Mz]
-    const int s_base = ch * VG_SC;
+    float* f0s = Gs + SC * N;                        // [SC][J]
+    float* hs = f0s + SC * J;                        // [SC][J]
+    float* Rs = hs + SC * J;                         // [SC][Mz]
+    float* Es = Rs + SC * Mz;                        // [SC][Mz]
+    float* dRs = Es + SC * Mz;                       // [SC][Mz]
+    const int s_base = ch * SC;
     {
         const float4* A4 = a.A4 + pl * N * Mz;
         for (int e = tid; e < N * Mz; e += nt) A4s[e] = A4[e];
@@ -697,17 +790,17 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_kernel(PathArgs a) {
             Ces[e] = a.want_dell ? a.CT_ell[pl * Mz * Mz + e] : 0.f;
             Cvs[e] = a.CT_var[pl * Mz * Mz + e];
         }
-        for (int e = tid; e < VG_SC * N; e += nt) {
+        for (int e = tid; e < SC * N; e += nt) {
             const int sl = vg_div(e, iN), n = e - sl * N, s = s_base + sl;
             Gs[e] = s < S ? a.G[(((size_t)p * S + s) * L + l) * N + n] : 0.f;
         }
-        for (int e = tid; e < VG_SC * J; e += nt) {
+        for (int e = tid; e < SC * J; e += nt) {
             const int sl = vg_div(e, iJ), j = e - sl * J, s = min(s_base + sl, S - 1);
             const size_t fo = (((size_t)p * S + s) * L + l) * J + j;
             f0s[e] = read_slabs<SK>(a.F0, fo, a.slab);
             hs[e] = a.want_dell ? read_slabs<SK>(a.H, fo, a.slab) : 0.f;
         }
-        for (int e = tid; e < VG_SC * Mz; e += nt) {
+        for (int e = tid; e < SC * Mz; e += nt) {
             const int sl = vg_div(e, iMz), mi = e - sl * Mz, s = s_base + sl;
             Rs[e] = s < S ? a.R[(((size_t)p * S + s) * L + l) * Mz + mi] : 0.f;
             Es[e] = s < S ? a.eps[(((size_t)p * S + s) * Mz + mi) * L + l] : 0.f;
@@ -716,7 +809,7 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_kernel(PathArgs a) {
     __syncthreads();
     VG_STOP(a, 1);
     float se = 0.f, sv = 0.f, sr = 0.f;
-    for (int e = tid; e < VG_SC * Mz; e += nt) {
+    for (int e = tid; e < SC * Mz; e += nt) {
         const int sl = vg_div(e, iMz), mi = e - sl * Mz;
         const float* g = Gs + sl * N;
         float d = 0.f, de = 0.f, dv = 0.f;
@@ -739,7 +832,7 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_kernel(PathArgs a) {
         se += rv * de + d * ue - d * hs[sl * J + N + mi];
         sr -= d * f0s[sl * J + N + mi];
     }
-    for (int e = tid; e < VG_SC * N; e += nt) {
+    for (int e = tid; e < SC * N; e += nt) {
         const int sl = vg_div(e, iN), n = e - sl * N;
         const float gv = Gs[e];             // zero for samples beyond S
         sr = fmaf(gv, f0s[sl * J + n], sr);
@@ -750,14 +843,14 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_kernel(PathArgs a) {
     float* out = a.part + (pl * a.NC + ch) * a.part_len;
     for (int mi = tid; mi < Mz; mi += nt) {
         float t = 0.f;
-        for (int sl = 0; sl < VG_SC; ++sl) t += dRs[sl * Mz + mi];
+        for (int sl = 0; sl < SC; ++sl) t += dRs[sl * Mz + mi];
         out[mi] = t;
     }
     float* oC = out + Mz;
     for (int e = tid; e < Mz * Mz; e += nt) {
         const int mi = vg_div(e, iMz), k = e - mi * Mz;
         float t = 0.f;
-        for (int sl = 0; sl < VG_SC; ++sl) t = fmaf(dRs[sl * Mz + mi], Es[sl * Mz + k], t);
+        for (int sl = 0; sl < SC; ++sl) t = fmaf(dRs[sl * Mz + mi], Es[sl * Mz + k], t);
         oC[e] = t;
     }
     se = vg_wave_sum(se); sv = vg_wave_sum(sv); sr = vg_wave_sum(sr);
@@ -1060,7 +1153,7 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
                  const vgpmp_outputs* out, const vg_workspace* ws, int what, int trainable, double lr, int adam_t,
                  uint32_t seed, uint32_t problem_base, uint32_t step, hipStream_t st, hipEvent_t* ev) {
     const int P = d->num_problems, S = d->S, N = d->N, M = d->M, L = d->L, B = d->B, Mz = M + 2, J = N + Mz;
-    const int SK = d->split_k, NC = vg_chunks(d);
+    const int SK = d->split_k, NC = vg_chunks(d), SC = vg_sc(d);
     const bool backward = (what & VGPMP_DO_BACKWARD) != 0;
     const bool want_dell = backward && (trainable & VGPMP_TRAIN_LENGTHSCALES);
     int evi = 0;
@@ -1117,8 +1210,12 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
     mark();
     const size_t slab = (size_t)P * S * L * J;
     const int nsel = want_dell ? 2 : 1;
-    hipLaunchKernelGGL(prior_gemm_kernel, dim3((J + 16 * kNT - 1) / (16 * kNT), (S + 63) / 64, P * L * SK * nsel),
-                       dim3(kBlock), 0, st, S, L, J, B, SK, nsel, nz->w, ws->Phi, ws->dPhi, ws->F0, ws->H, slab);
+    if (SK == 1 && (B % kTK) == 0)      // large batch: LDS-tiled kernel (split_k == 1 is chosen by the host for P*L > 256)
+        hipLaunchKernelGGL(prior_gemm_tiled_kernel, dim3((J + kTJ - 1) / kTJ, (S + kTS - 1) / kTS, P * L * nsel), dim3(kBlock),
+                           0, st, S, L, J, B, nsel, nz->w, ws->Phi, ws->dPhi, ws->F0, ws->H);
+    else
+        hipLaunchKernelGGL(prior_gemm_kernel, dim3((J + 16 * kNT - 1) / (16 * kNT), (S + 63) / 64, P * L * SK * nsel),
+                           dim3(kBlock), 0, st, S, L, J, B, SK, nsel, nz->w, ws->Phi, ws->dPhi, ws->F0, ws->H, slab);
     mark();
     if (fork) VG_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)pb->join_event, 0));
     // ---- path assembly
@@ -1133,10 +1230,11 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
 #ifdef VGPMP_BISECT
     pa.stop = vg_bisect_stop("VGPMP_STOP_PATHS");
 #endif
-    const size_t lds_pf = ((size_t)Mz * (Mz + 1) + (size_t)Mz * N + (size_t)3 * VG_SC * Mz + (size_t)VG_SC * J) * sizeof(float);
+    const size_t lds_pf = ((size_t)Mz * (Mz + 1) + (size_t)Mz * N + (size_t)3 * SC * Mz + (size_t)SC * J) * sizeof(float);
     {
-        const void* fn = SK == 1 ? (const void*)paths_fwd_kernel<1> : SK == 2 ? (const void*)paths_fwd_kernel<2>
-                       : SK == 4 ? (const void*)paths_fwd_kernel<4> : (const void*)paths_fwd_kernel<8>;
+        const void* fn = SC == 32 ? (const void*)paths_fwd_kernel<1, 32>
+                       : SK == 1 ? (const void*)paths_fwd_kernel<1, 8> : SK == 2 ? (const void*)paths_fwd_kernel<2, 8>
+                       : SK == 4 ? (const void*)paths_fwd_kernel<4, 8> : (const void*)paths_fwd_kernel<8, 8>;
         rc = set_dyn_lds(fn, lds_pf);
         if (rc) return rc;
         void* kargs[] = {(void*)&pa};
@@ -1156,11 +1254,12 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
         return (int)hipGetLastError();
     }
     // ---- reverse of the path assembly, then gradient assembly (+ Adam)
-    const size_t lds_pb = ((size_t)4 * N * Mz + (size_t)2 * Mz * Mz + (size_t)VG_SC * N + (size_t)2 * VG_SC * J +
-                           (size_t)3 * VG_SC * Mz) * sizeof(float);
+    const size_t lds_pb = ((size_t)4 * N * Mz + (size_t)2 * Mz * Mz + (size_t)SC * N + (size_t)2 * SC * J +
+                           (size_t)3 * SC * Mz) * sizeof(float);
     {
-        const void* fn = SK == 1 ? (const void*)paths_bwd_kernel<1> : SK == 2 ? (const void*)paths_bwd_kernel<2>
-                       : SK == 4 ? (const void*)paths_bwd_kernel<4> : (const void*)paths_bwd_kernel<8>;
+        const void* fn = SC == 32 ? (const void*)paths_bwd_kernel<1, 32>
+                       : SK == 1 ? (const void*)paths_bwd_kernel<1, 8> : SK == 2 ? (const void*)paths_bwd_kernel<2, 8>
+                       : SK == 4 ? (const void*)paths_bwd_kernel<4, 8> : (const void*)paths_bwd_kernel<8, 8>;
         rc = set_dyn_lds(fn, lds_pb);
         if (rc) return rc;
         void* kargs[] = {(void*)&pa};
