@@ -203,3 +203,53 @@ def test_large_batch_kernels_match_small_launch_kernels():
         for a, b in zip(gs, gb):
             a, b = a[0].cpu().numpy(), b[p].cpu().numpy()
             assert np.abs(a - b).max() <= 2e-4 * np.abs(a).max() + 1e-9
+
+
+def test_batched_solve_of_a_problem_set():
+    """All C(9,2) = 36 Franka/industrial queries as one device batch; every path is pinned to its query."""
+    from gpflow_vgpmp.utils.miscellaneous import solve_planning_problems_batched
+    env = _env()
+    env.config["planner_params"].update(num_steps=40, num_samples=8, num_inducing=10, time_spacing_X=30, time_spacing_Xnew=40)
+    queries = env.config["scene_params"]["queries"]
+    out = solve_planning_problems_batched(env, queries)
+    assert len(out) == 36
+    for (solved, traj), (a, b) in zip(out, queries):
+        assert traj.shape == (40, 7) and np.isfinite(traj).all()
+        assert np.abs(traj[0] - np.array(a)).max() < 5e-2 and np.abs(traj[-1] - np.array(b)).max() < 5e-2
+        assert solved in (True, False)
+
+
+@pytest.mark.parametrize("robot,problem,S,M,N,P", [("wam", "industrial", 50, 10, 70, 1),        # BASELINE config 1 shape
+                                                    ("franka", "bookshelves", 7, 24, 70, 55),     # config 3: full C(11,2) batch
+                                                    ("ur10", "industrial", 128, 18, 70, 1)])      # config 4: one rank's sample shard
+def test_baseline_config_shapes_properties(robot, problem, S, M, N, P):
+    """BASELINE configs at full size: size-independent properties (bitwise replay, finite, KL >= 0,
+    paths inside the joint limits and pinned to start/goal, loss decreases)."""
+    from vgpmp_amd import engine
+    ps = rb.load_problemset(robot, problem)
+    spec = rb.load_robot(robot, *ps.robot_pos_and_orn)
+    grid = scenes.synthetic_boxes_sdf(n=96, delta=2.4 / 96, origin=(-1.2, -1.2, -0.6), seed=1)
+    pp = ps.planner_params
+    sc = engine.DeviceScene(spec, grid, ps.object_positions[0], sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"])
+    qs = np.array(ps.queries[:P])
+    kw = dict(num_samples=S, num_inducing=M, num_data=N, num_bases=1024, lengthscales=pp["lengthscales"],
+              variance=pp["variance"], alpha=pp["alpha"], learning_rate=pp["learning_rate"], seed=3)
+    if robot == "ur10":
+        kw.update(samples_total=1024, sample_offset=256, kl_scale=0.0)
+    a, b = engine.PlannerBatch(sc, qs, **kw), engine.PlannerBatch(sc, qs, **kw)
+    l0 = -a.elbo(step=10**6).clone()
+    for _ in range(25):
+        a.step(); b.step()
+    assert torch.equal(a.q_mu, b.q_mu) and torch.equal(a.q_sqrt, b.q_sqrt) and torch.equal(a.raw_var, b.raw_var)
+    l1 = -a.elbo(step=10**6)
+    assert torch.isfinite(l0).all() and torch.isfinite(l1).all() and bool((a.kl >= 0).all())
+    assert float(l1.mean()) < float(l0.mean())
+    g = a.samples()
+    lo, hi = torch.tensor(spec.low, device=g.device), torch.tensor(spec.high, device=g.device)
+    assert bool(((g >= lo) & (g <= hi)).all())
+    if max(pp["lengthscales"]) <= 4.0:
+        # the 1e-6 "conditioning" pins the end points only while Kuu >> jitter I; with UR10's lengthscale 6 the
+        # reference's own formula gives k(0, Z)(Kuu + jI)^-1 = (0.59, 0.02, 0.30, ...) rather than e_0
+        y = torch.tensor(qs, device=g.device, dtype=g.dtype)
+        assert float((g[:, :, 0, :] - y[:, None, 0, :]).abs().max()) < 1e-1
+        assert float((g[:, :, -1, :] - y[:, None, 1, :]).abs().max()) < 1e-1

@@ -84,3 +84,39 @@ def solve_planning_problem(env, start_joints, end_joints, run=0, k=0):
     env.robot.clearance_fn = lambda path: float(pl.path_clearance(torch.as_tensor(path, device=pl.device)).min())
     res = env.robot.move_to_ee_config(best_sample)
     return res, best_sample
+
+
+def solve_planning_problems_batched(env, queries, seed: int = 0):
+    """All start-goal queries of a problem set optimised in lock step as ONE device batch (the reference
+    loops over them one by one, benchmarking.py:70-85).  Returns [(solved, best_sample[Nnew, D]), ...]."""
+    import torch
+    from .. import engine
+    from .model import VariationalMonteCarloLikelihood
+    pp = env.config["planner_params"]
+    tp = env.config["trainable_params"]
+    for key in ("sigma_obs", "alpha", "inducing_variable"):
+        if tp.get(key, False):
+            raise NotImplementedError(f"training `{key}` is not supported by the HIP path (reference default: False)")
+    dof = env.robot.dof
+    lik = VariationalMonteCarloLikelihood(sigma_obs=pp["sigma_obs"], robot=env.robot, sampler=env.sampler, sdf=env.sdf,
+                                          offset=env.scene.position, epsilon=pp["epsilon"])
+    qs = np.array([[np.asarray(a, dtype=np.float64).reshape(dof), np.asarray(b, dtype=np.float64).reshape(dof)]
+                   for a, b in queries])
+    pl = engine.PlannerBatch(lik.device_scene, qs, num_samples=pp["num_samples"], num_inducing=pp["num_inducing"],
+                             num_data=pp["time_spacing_X"], lengthscales=pp["lengthscales"], variance=pp["variance"],
+                             alpha=pp["alpha"], learning_rate=pp["learning_rate"], seed=seed,
+                             trainable={"q_mu": bool(tp["q_mu"]), "q_sqrt": bool(tp["q_sqrt"]),
+                                        "lengthscales": bool(tp["lengthscales"]),
+                                        "kernel_variance": bool(tp["kernel_variance"])})
+    steps = int(pp["num_steps"])
+    if steps >= 20:
+        pl.capture(10)
+        steps -= 1
+    pl.run_steps(steps)
+    Xnew = np.tile(np.linspace(0.0, 1.0, int(pp["time_spacing_Xnew"]))[:, None], (1, dof))
+    _, best, _, _ = pl.sample_from_posterior(150, Xnew, step=pl.t)
+    clear = pl.path_clearance(best).amin(dim=(1, 2)).cpu().numpy()
+    best = best.cpu().numpy().astype(np.float64)
+    low, high = env.robot.spec.low, env.robot.spec.high
+    inside = ((best >= low - 1e-9) & (best <= high + 1e-9)).all(axis=(1, 2))
+    return [(bool(clear[i] > 0.0 and inside[i]), best[i]) for i in range(len(queries))]

@@ -128,9 +128,14 @@ class VariationalMonteCarloLikelihood:
         self.joint_sigmoid = _JointSigmoid(low=self.joint_constraints[:, 1], high=self.joint_constraints[:, 0])
         self.epsilon = float(epsilon)
         self.p = robot.num_spheres
-        # device-resident scene: robot tables + packed voxel table
-        self.device_scene = engine.DeviceScene(robot.spec, sdf.grid, self.offset.reshape(3),
-                                               sigma_obs=self.variance.numpy().reshape(-1), epsilon=self.epsilon)
+        # device-resident scene: robot tables + packed voxel table.  The reference builds a new model per
+        # start-goal query (utils/miscellaneous.py:162-169); the upload is cached per (sdf, robot, constants)
+        key = (id(sdf), id(robot.spec), tuple(self.offset.reshape(3)), float(sigma_obs), self.epsilon)
+        cache = sdf.__dict__.setdefault("_device_scenes", {})
+        if key not in cache:
+            cache[key] = engine.DeviceScene(robot.spec, sdf.grid, self.offset.reshape(3),
+                                            sigma_obs=self.variance.numpy().reshape(-1), epsilon=self.epsilon)
+        self.device_scene = cache[key]
         sdf.bind(self.device_scene)
         sampler.bind(self.device_scene)
 
