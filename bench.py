@@ -113,10 +113,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    backend = os.environ.get("VGPMP_DIST_BACKEND", "nccl")      # "gloo": rehearsal of the N > 1 path on a 1-GPU box
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dev = local % torch.cuda.device_count()
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -139,7 +144,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
     assert args.allow_nan or torch.isfinite(planner.q_mu).all(), "optimisation diverged"
