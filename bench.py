@@ -48,7 +48,12 @@ def build_problem(rank: int, args):
                                       problem_base=rank * args.problems)
         return ps, spec, grid, scene, planner
     spec = robots.load_robot("franka", *ps.robot_pos_and_orn)
-    grid = scenes.synthetic_boxes_sdf(n=args.grid, delta=1.6 / args.grid, origin=(-0.8, -0.8, -0.2), seed=0)
+    if args.scene == "industrial":
+        # the reference's industrial scene: grid generated on the device from its collision mesh (vgpmp_mesh_sdf),
+        # SDFGen-style extent (bounding box + 20 cells) at 1.25 cm -> 129 x 154 x 80 voxels
+        grid = scenes.scene_sdf("industrial", delta=0.0125, padding=20)
+    else:
+        grid = scenes.synthetic_boxes_sdf(n=args.grid, delta=1.6 / args.grid, origin=(-0.8, -0.8, -0.2), seed=0)
     scene = engine.DeviceScene(spec, grid, ps.object_positions[0], sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"])
     queries = ps.queries
     qs = np.array([queries[(rank * args.problems + i) % len(queries)] for i in range(args.problems)])
@@ -100,7 +105,9 @@ def main():
     ap.add_argument("--inducing", type=int, default=30)
     ap.add_argument("--timesteps", type=int, default=100)
     ap.add_argument("--problems", type=int, default=1, help="problems per GPU (config 2: 1)")
-    ap.add_argument("--grid", type=int, default=128, help="SDF voxels per axis")
+    ap.add_argument("--grid", type=int, default=128, help="SDF voxels per axis (synthetic scenes)")
+    ap.add_argument("--scene", choices=("industrial", "synthetic"), default="industrial",
+                    help="industrial = SDF generated from the reference's industrial collision mesh; synthetic = boxes/spheres")
     ap.add_argument("--unroll", type=int, default=10, help="steps per captured hipGraph (0 = eager launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=40)
@@ -191,9 +198,11 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": ("BASELINE config 2: Franka 7-DoF, industrial offset" if args.workload == "config2"
-                                    else "BASELINE config 5 per-GPU share: synthetic 14-DoF arm") + ", synthetic "
-                                   f"{args.grid}^3 SDF, {npb} start-goal problem(s) per GPU, S={S} M={M} T={N} B={B}, "
+            "config": {"workload": ("BASELINE config 2: Franka 7-DoF, industrial scene" if args.workload == "config2"
+                                    else "BASELINE config 5 per-GPU share: synthetic 14-DoF arm") + ", SDF "
+                                   + "x".join(str(v) for v in grid[0].shape) + (" from the industrial collision mesh"
+                                   if args.workload == "config2" and args.scene == "industrial" else " synthetic boxes/spheres")
+                                   + f", {npb} start-goal problem(s) per GPU, S={S} M={M} T={N} B={B}, "
                                    "q_mu/q_sqrt/lengthscales/kernel_variance trainable",
                        "parallelism": f"problems sharded x{world}, no collective",
                        "launch": f"hipGraph x{args.unroll} steps" if args.unroll else "eager"},

@@ -148,6 +148,14 @@ int vgpmp_robot_upload(const vgpmp_robot* host_robot, void* dev_robot, vgpmp_str
 int vgpmp_sdf_pack(const double* dev_grid, int32_t nx, int32_t ny, int32_t nz, double delta,
                    void* dev_table, vgpmp_stream stream);
 
+/* Signed distance grid of a triangle mesh (replaces the external SDFGen binary of utils/gen_sdf.py:16-43):
+ * dev_triangles [T, 9] = vertices a, b, c of each triangle; dev_part [T] = index of the closed part each
+ * triangle belongs to, non-decreasing; host `origin[3]`; grid[x,y,z] = signed distance (negative inside)
+ * at origin + delta * (x, y, z).  Exact point-triangle distance, sign from the winding number per part. */
+int vgpmp_mesh_sdf(const double* dev_triangles, const int32_t* dev_part, int32_t num_triangles,
+                   int32_t nx, int32_t ny, int32_t nz, const double* origin, double delta,
+                   double* dev_grid, vgpmp_stream stream);
+
 /* ---- stand-alone pieces (parity tests, debugging) ------------------------------------------ */
 
 /* Sampler.forward_kinematics_cost (utils/sampler.py:216-235): q [n, dof] -> sphere centres

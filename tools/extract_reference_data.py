@@ -5,7 +5,8 @@ Run once in the build container (needs a reference checkout, default /root/refer
 
     python tools/extract_reference_data.py [/path/to/vgpmp]
 
-Writes vgpmp_amd/data/robots.json and vgpmp_amd/data/problemsets.json.  Nothing of the
+Writes vgpmp_amd/data/robots.json, problemsets.json and scene_meshes.json (vertices / triangles of the
+scene collision meshes data/scenes/*/*.obj, input of the mesh -> SDF generator).  Nothing of the
 reference's code is copied: only the numbers of data/robots/*/config.yaml, the sphere
 visuals of the URDFs and the state lists / planner parameters of data/problemsets/*.py.
 
@@ -96,6 +97,29 @@ def corrected_offset(robot, index, off):
     return [x, y, z]
 
 
+SCENE_MESH = {"industrial": "industrial/industrial-acd.obj", "bookshelves": "bookshelves/bookshelves_center.obj",
+              "boxes": "boxes/boxes-acd.obj", "lab": "lab/lab.obj"}
+
+
+def read_obj(path):
+    """Vertices, triangles (0-based) and the index of the `o` part each triangle belongs to."""
+    verts, faces, part, cur = [], [], [], -1
+    for line in open(path):
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == "o":
+            cur += 1
+        elif t[0] == "v":
+            verts.append([float(v) for v in t[1:4]])
+        elif t[0] == "f":
+            idx = [int(v.split("/")[0]) - 1 for v in t[1:]]
+            for k in range(1, len(idx) - 1):                      # fan-triangulate polygons
+                faces.append([idx[0], idx[k], idx[k + 1]])
+                part.append(max(cur, 0))
+    return verts, faces, part
+
+
 def load_problemset(ref, robot):
     stub = types.ModuleType("problemset")
     stub.AbstractProblemset = type("AbstractProblemset", (), {})
@@ -146,6 +170,11 @@ def main():
                 except ValueError:
                     pass
             psets[robot][name] = entry
+    meshes = {}
+    for name, rel in SCENE_MESH.items():
+        v, f, part = read_obj(ref / "data/scenes" / rel)
+        meshes[name] = dict(source=rel, vertices=v, faces=f, part=part)
+    json.dump(meshes, open(out_dir / "scene_meshes.json", "w"))
     json.dump(robots, open(out_dir / "robots.json", "w"), indent=1)
     json.dump(psets, open(out_dir / "problemsets.json", "w"), indent=1)
     print("wrote", out_dir / "robots.json", out_dir / "problemsets.json")

@@ -19,7 +19,7 @@ DO_FORWARD, DO_BACKWARD, DO_ADAM, GEN_NOISE = 1, 2, 4, 8
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvgpmp_hip.so"
 
-EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_pack", "vgpmp_fk_spheres", "vgpmp_sdf_query",
+EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_pack", "vgpmp_mesh_sdf", "vgpmp_fk_spheres", "vgpmp_sdf_query",
            "vgpmp_log_prob", "vgpmp_workspace_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
            "vgpmp_elbo_step_profiled", "vgpmp_adam_step", "vgpmp_workspace_view")
 NUM_STAGES = 8
@@ -100,6 +100,7 @@ def load(require: bool = True) -> Optional[C.CDLL]:
     sigs = {
         "vgpmp_robot_upload": [P(Robot), vp, vp],
         "vgpmp_sdf_pack": [vp, i32, i32, i32, dbl, vp, vp],
+        "vgpmp_mesh_sdf": [vp, vp, i32, i32, i32, i32, P(C.c_double), dbl, vp, vp],
         "vgpmp_fk_spheres": [vp, vp, i64, vp, vp, vp],
         "vgpmp_sdf_query": [P(Sdf), vp, i64, vp, vp, vp, vp],
         "vgpmp_log_prob": [vp, i32, P(Sdf), vp, i64, vp, vp, vp],

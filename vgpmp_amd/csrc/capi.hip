@@ -28,6 +28,14 @@ int vgpmp_sdf_pack(const double* dev_grid, int32_t nx, int32_t ny, int32_t nz, d
     return vg_launch_sdf_pack(dev_grid, nx, ny, nz, delta, (float4*)dev_table, (hipStream_t)stream);
 }
 
+int vgpmp_mesh_sdf(const double* dev_triangles, const int32_t* dev_part, int32_t num_triangles, int32_t nx, int32_t ny,
+                   int32_t nz, const double* origin, double delta, double* dev_grid, vgpmp_stream stream) {
+    if (!dev_triangles || !dev_part || !origin || !dev_grid) return VGPMP_E_ARG;
+    if (num_triangles < 1 || nx < 1 || ny < 1 || nz < 1 || !(delta > 0.0)) return VGPMP_E_SHAPE;
+    return vg_launch_mesh_sdf(dev_triangles, dev_part, num_triangles, nx, ny, nz, origin, delta, dev_grid,
+                              (hipStream_t)stream);
+}
+
 int vgpmp_fk_spheres(const vgpmp_robot* dev_robot, const float* dev_q, int64_t n, float* dev_pos, float* dev_frames,
                      vgpmp_stream stream) {
     if (!dev_robot || (!dev_q && n > 0) || n < 0) return VGPMP_E_ARG;

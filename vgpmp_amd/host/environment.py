@@ -132,8 +132,8 @@ class ParameterLoader:
         d = self.data_dir_path / "scenes" / environment_name
         sdf = d / (sdf_file_name + ".sdf")
         if not sdf.exists():
-            warnings.warn(f"{sdf} is missing (the reference ships its .sdf grids as large blobs); "
-                          "a synthetic box/sphere scene is used instead")
+            warnings.warn(f"{sdf} is missing (the reference ships its .sdf grids as large blobs); the grid is "
+                          "generated from the scene's collision mesh on the device (or a synthetic scene if unknown)")
             sdf = None
         return d / (environment_file_name + ".urdf"), sdf
 
@@ -351,7 +351,10 @@ class SimulationManager:
         elif self.config["scene_params"]["sdf_path"] is not None:
             self.sdf = SignedDistanceField.from_sdf(self.config["scene_params"]["sdf_path"])
         else:
-            self.sdf = SignedDistanceField.synthetic()
+            try:                   # mesh -> SDF on the device (replaces utils/gen_sdf.py + external SDFGen)
+                self.sdf = SignedDistanceField(*scenes.scene_sdf(self.config["scene_params"]["environment_name"]))
+            except KeyError:
+                self.sdf = SignedDistanceField.synthetic()
 
     @property
     def config(self) -> dict:

@@ -71,3 +71,58 @@ def synthetic_boxes_sdf(n: int = 128, delta: float = 0.0125, origin=(-0.8, -0.8,
             d = np.minimum(d, np.linalg.norm(p - c, axis=-1) - r)
         out[x0:x1] = d.astype(dtype)
     return out, origin, float(delta)
+
+
+# ---- mesh -> SDF (device) -------------------------------------------------------------------------------
+def load_scene_mesh(name: str):
+    """Triangles [T, 9] (float64) and part ids [T] (int32) of a scene collision mesh
+    (vgpmp_amd/data/scene_meshes.json: vertices/faces of the reference's data/scenes/*/*.obj)."""
+    import json
+    from pathlib import Path
+    tables = json.load(open(Path(__file__).resolve().parent / "data" / "scene_meshes.json"))
+    if name not in tables:
+        raise KeyError(f"no collision mesh for scene {name!r} (have {sorted(tables)})")
+    t = tables[name]
+    V = np.asarray(t["vertices"], dtype=np.float64)
+    F = np.asarray(t["faces"], dtype=np.int64)
+    part = np.asarray(t["part"], dtype=np.int32)
+    order = np.argsort(part, kind="stable")
+    return V[F[order]].reshape(-1, 9), part[order]
+
+
+def mesh_grid_extent(triangles: np.ndarray, delta: float, padding: int):
+    """Grid of spacing `delta` covering the mesh bounding box plus `padding` cells on every side
+    (the layout SDFGen produces for gen_sdf.py: origin = bbox_min - padding * delta)."""
+    pts = np.asarray(triangles, dtype=np.float64).reshape(-1, 3)
+    lo, hi = pts.min(0), pts.max(0)
+    origin = lo - padding * delta
+    shape = tuple(int(v) for v in np.ceil((hi - lo) / delta).astype(int) + 2 * padding + 1)
+    return origin, shape
+
+
+def mesh_sdf(triangles: np.ndarray, part: np.ndarray, delta: float, padding: int = 20, origin=None, shape=None) -> Grid:
+    """Signed distance grid of a triangle mesh, computed on the GPU (vgpmp_mesh_sdf)."""
+    import ctypes as C
+
+    import torch
+
+    from . import capi
+    lib = capi.load(require=True)
+    if not torch.cuda.is_available():
+        raise capi.VgpmpError("mesh_sdf needs a HIP device (no CPU fallback)")
+    if origin is None or shape is None:
+        origin, shape = mesh_grid_extent(triangles, delta, padding)
+    origin = np.asarray(origin, dtype=np.float64)
+    tri = torch.as_tensor(np.ascontiguousarray(triangles, dtype=np.float64)).cuda()
+    prt = torch.as_tensor(np.ascontiguousarray(part, dtype=np.int32)).cuda()
+    grid = torch.empty(shape, dtype=torch.float64, device="cuda")
+    org = (C.c_double * 3)(*origin)
+    capi.check(lib.vgpmp_mesh_sdf(capi.ptr(tri), capi.ptr(prt), int(tri.shape[0]), *shape, org, float(delta),
+                                  capi.ptr(grid), capi.stream_ptr()), "vgpmp_mesh_sdf")
+    return grid.cpu().numpy(), origin, float(delta)
+
+
+def scene_sdf(name: str, delta: float = 0.0125, padding: int = 20) -> Grid:
+    """SDF of one of the reference's scenes (industrial, bookshelves, boxes, lab) from its collision mesh."""
+    tri, part = load_scene_mesh(name)
+    return mesh_sdf(tri, part, delta, padding)
