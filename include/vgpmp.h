@@ -114,9 +114,15 @@ typedef struct vgpmp_problem {
     uint32_t* step_counter; /* dev, optional: when set, the noise key uses *step_counter and the Adam
                              * step count is *step_counter + 1; a VGPMP_DO_ADAM step increments it on
                              * the device, so a captured hipGraph of the step can be replayed */
-    vgpmp_stream side_stream; /* optional second stream + two events (hipEvent_t) owned by the caller: */
-    void* fork_event;         /* the float64 covariance kernel then runs on side_stream, concurrently  */
-    void* join_event;         /* with the noise / feature / GEMM kernels of `stream`                    */
+    /* Optional extra streams and events (hipEvent_t), all owned by the caller.  Any group may be NULL;
+     * the kernels then run in sequence on `stream` with identical results. */
+    vgpmp_stream side_stream; /* the float64 covariance kernels run here, concurrently with the            */
+    void* fork_event;         /* noise / feature / GEMM kernels; fork_event and join_event order the two   */
+    void* join_event;
+    vgpmp_stream side_stream2; /* the noise / feature / GEMM kernels get their own stream as well           */
+    void* join_event2;
+    void* hyper_event;        /* vgpmp_elbo_steps: hand-over points of step t to step t+1 (kernel hyper-   */
+    void* rest_event;         /* parameters updated / variational parameters updated)                      */
 } vgpmp_problem;
 
 /* Outputs of an ELBO evaluation. */
@@ -191,6 +197,19 @@ int vgpmp_elbo_step(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const 
                     void* dev_workspace, size_t workspace_bytes,
                     int32_t what, int32_t trainable, double learning_rate, int32_t adam_t,
                     uint32_t seed, uint32_t problem_base, uint32_t step, vgpmp_stream stream);
+
+/* `num_steps` consecutive training steps (the body of training_loop, utils/miscellaneous.py:87-112) in one
+ * call: step i uses noise key `step + i` and Adam count `adam_t + i` (or the device counter).  Results are
+ * identical to `num_steps` calls of vgpmp_elbo_step; when `problem` carries both side streams and all
+ * events, step i+1 starts as soon as step i has updated what it depends on (its covariance / feature /
+ * GEMM kernels overlap the gradient assembly of step i).  Requires VGPMP_DO_ADAM | VGPMP_GEN_NOISE. */
+int vgpmp_elbo_steps(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,
+                     const vgpmp_problem* problem, const vgpmp_params* params,
+                     const vgpmp_params* adam_m, const vgpmp_params* adam_v,
+                     const vgpmp_noise* noise, const vgpmp_outputs* out,
+                     void* dev_workspace, size_t workspace_bytes,
+                     int32_t what, int32_t trainable, double learning_rate, int32_t adam_t,
+                     uint32_t seed, uint32_t problem_base, uint32_t step, int32_t num_steps, vgpmp_stream stream);
 
 /* Same launch sequence with a HIP event recorded on `stream` around every kernel; synchronises the
  * stream and ADDS the elapsed milliseconds of the 8 stages {cov_fwd, noise, features, prior_gemm,

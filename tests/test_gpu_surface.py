@@ -180,6 +180,32 @@ def test_graph_replay_matches_eager_steps():
     assert torch.allclose(a.q_mu, b.q_mu, rtol=0, atol=1e-12) and torch.allclose(a.raw_ell, b.raw_ell, rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("P", [1, 3])
+def test_pipelined_steps_equal_single_step_calls(P):
+    """vgpmp_elbo_steps overlaps step t+1 with the gradient assembly of step t over three streams; the
+    result must equal the same steps issued one call at a time on a single stream (no overlap at all)."""
+    from vgpmp_amd import engine
+    ps = rb.load_problemset("franka", "industrial")
+    spec = rb.load_robot("franka")
+    grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
+    sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
+    qs = np.array([ps.queries[i] for i in range(P)])
+    kw = dict(num_samples=32, num_inducing=12, num_data=40, num_bases=128, lengthscales=[2.0] * 7, variance=0.2, seed=3)
+    a, b = engine.PlannerBatch(sc, qs, **kw), engine.PlannerBatch(sc, qs, **kw)
+    b.overlap = False
+    b._pack()
+    a.run_steps(25)
+    for _ in range(25):
+        b.step()
+    torch.cuda.synchronize()
+    assert a.t == b.t == 25
+    for x, y in ((a.q_mu, b.q_mu), (a.q_sqrt, b.q_sqrt), (a.raw_ell, b.raw_ell), (a.raw_var, b.raw_var),
+                 (a.adam_v[1], b.adam_v[1])):
+        assert torch.allclose(x, y, rtol=0, atol=1e-11), float((x - y).abs().max())
+    assert torch.equal(a.eps, b.eps) and torch.equal(a.w, b.w)
+    assert torch.allclose(a.lik, b.lik, rtol=1e-12) and torch.allclose(a.kl, b.kl, rtol=1e-12)
+
+
 def test_large_batch_kernels_match_small_launch_kernels():
     """Large batches use the LDS-tiled prior GEMM (split_k = 1) and one lane per configuration in the
     likelihood; each problem must still equal the same problem evaluated alone (split-K GEMM, 4 lanes per

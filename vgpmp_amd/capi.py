@@ -21,7 +21,7 @@ LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvgpmp_hip.so"
 
 EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_pack", "vgpmp_mesh_sdf", "vgpmp_fk_spheres", "vgpmp_sdf_query",
            "vgpmp_log_prob", "vgpmp_workspace_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
-           "vgpmp_elbo_step_profiled", "vgpmp_adam_step", "vgpmp_workspace_view")
+           "vgpmp_elbo_steps", "vgpmp_elbo_step_profiled", "vgpmp_adam_step", "vgpmp_workspace_view")
 NUM_STAGES = 8
 STAGE_NAMES = ("cov_fwd", "noise", "features", "prior_gemm", "paths_fwd", "loglik_fk_sdf", "paths_bwd", "final_adam")
 
@@ -64,7 +64,9 @@ class Noise(C.Structure):
 class Problem(C.Structure):
     _fields_ = [("X", C.c_void_p), ("Zy", C.c_void_p), ("y_u", C.c_void_p), ("alpha", C.c_double),
                 ("jitter", C.c_double), ("kl_scale", C.c_double), ("step_counter", C.c_void_p),
-                ("side_stream", C.c_void_p), ("fork_event", C.c_void_p), ("join_event", C.c_void_p)]
+                ("side_stream", C.c_void_p), ("fork_event", C.c_void_p), ("join_event", C.c_void_p),
+                ("side_stream2", C.c_void_p), ("join_event2", C.c_void_p), ("hyper_event", C.c_void_p),
+                ("rest_event", C.c_void_p)]
 
 
 class Outputs(C.Structure):
@@ -108,6 +110,8 @@ def load(require: bool = True) -> Optional[C.CDLL]:
         "vgpmp_generate_noise": [P(Dims), P(Noise), u32, u32, u32, vp],
         "vgpmp_elbo_step": [P(Dims), vp, P(Sdf), P(Problem), P(Params), P(Params), P(Params), P(Noise), P(Outputs),
                             vp, C.c_size_t, i32, i32, dbl, i32, u32, u32, u32, vp],
+        "vgpmp_elbo_steps": [P(Dims), vp, P(Sdf), P(Problem), P(Params), P(Params), P(Params), P(Noise), P(Outputs),
+                             vp, C.c_size_t, i32, i32, dbl, i32, u32, u32, u32, i32, vp],
         "vgpmp_elbo_step_profiled": [P(Dims), vp, P(Sdf), P(Problem), P(Params), P(Params), P(Params), P(Noise),
                                      P(Outputs), vp, C.c_size_t, i32, i32, dbl, i32, u32, u32, u32, vp,
                                      P(C.c_float)],

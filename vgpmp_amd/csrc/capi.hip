@@ -87,7 +87,7 @@ static int elbo_step_impl(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, 
                           const vgpmp_params* adam_v, const vgpmp_noise* noise, const vgpmp_outputs* out,
                           void* dev_workspace, size_t workspace_bytes, int32_t what, int32_t trainable,
                           double learning_rate, int32_t adam_t, uint32_t seed, uint32_t problem_base, uint32_t step,
-                          vgpmp_stream stream, hipEvent_t* ev) {
+                          vgpmp_stream stream, hipEvent_t* ev, int num_steps = 1) {
     if (!dims || !dev_robot || !problem || !params || !noise || !out || !dev_workspace) return VGPMP_E_ARG;
     int rc = vg_check_dims(dims);
     if (rc) return rc;
@@ -105,8 +105,13 @@ static int elbo_step_impl(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, 
     vg_workspace ws;
     size_t need = vg_layout_workspace(dims, dev_workspace, &ws);
     if (workspace_bytes < need) return VGPMP_E_WORKSPACE;
-    return vg_elbo_step(dims, dev_robot, sdf, problem, params, adam_m, adam_v, noise, out, &ws, what, trainable,
-                        learning_rate, adam_t, seed, problem_base, step, (hipStream_t)stream, ev);
+    for (int i = 0; i < num_steps; ++i) {
+        const int chain = (i > 0 ? VG_CHAIN_PREV : 0) | (i + 1 < num_steps ? VG_CHAIN_NEXT : 0);
+        rc = vg_elbo_step(dims, dev_robot, sdf, problem, params, adam_m, adam_v, noise, out, &ws, what, trainable,
+                          learning_rate, adam_t + i, seed, problem_base, step + (uint32_t)i, (hipStream_t)stream, ev, chain);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int vgpmp_elbo_step(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,
@@ -118,6 +123,19 @@ int vgpmp_elbo_step(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const 
     return elbo_step_impl(dims, dev_robot, sdf, problem, params, adam_m, adam_v, noise, out, dev_workspace,
                           workspace_bytes, what, trainable, learning_rate, adam_t, seed, problem_base, step, stream,
                           nullptr);
+}
+
+int vgpmp_elbo_steps(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,
+                     const vgpmp_problem* problem, const vgpmp_params* params, const vgpmp_params* adam_m,
+                     const vgpmp_params* adam_v, const vgpmp_noise* noise, const vgpmp_outputs* out,
+                     void* dev_workspace, size_t workspace_bytes, int32_t what, int32_t trainable,
+                     double learning_rate, int32_t adam_t, uint32_t seed, uint32_t problem_base, uint32_t step,
+                     int32_t num_steps, vgpmp_stream stream) {
+    const int32_t need = VGPMP_DO_FORWARD | VGPMP_DO_BACKWARD | VGPMP_DO_ADAM | VGPMP_GEN_NOISE;
+    if (num_steps < 1 || (what & need) != need) return VGPMP_E_ARG;
+    return elbo_step_impl(dims, dev_robot, sdf, problem, params, adam_m, adam_v, noise, out, dev_workspace,
+                          workspace_bytes, what, trainable, learning_rate, adam_t, seed, problem_base, step, stream,
+                          nullptr, num_steps);
 }
 
 int vgpmp_elbo_step_profiled(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,

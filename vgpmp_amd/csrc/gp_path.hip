@@ -272,12 +272,10 @@ __global__ __launch_bounds__(kCovThreads) void cov_a_kernel(CovArgs a) {
     });
     double* Lkg = a.ws.Lk64 + pl * Mz * Mz;
     double* Lig = a.ws.Li64 + pl * Mz * Mz;
-    float* Lk32 = a.ws.Lk32 + pl * Mz * Mz;
     for (int e = tid; e < Mz * Mz; e += nt) {
         const int i = vg_div(e, iMz), j = e - i * Mz;
         Lkg[e] = La[i * ld + j];
         Lig[e] = Li[i * ld + j];
-        Lk32[e] = (float)La[i * ld + j];
     }
 }
 
@@ -321,10 +319,13 @@ __global__ __launch_bounds__(kCovThreads) void cov_b_kernel(CovArgs a) {
         const double* Lig = a.ws.Li64 + pl * Mz * Mz;
         const double* Kdg = a.ws.Kd_ell + pl * Mz * Mz;
         const double* Qg = a.q_sqrt + pl * M * M;
-        for (int e = tid; e < Mz * Mz; e += nt) {
+        float* Lk32 = a.ws.Lk32 + pl * Mz * Mz;      // float32 copy for the gradient assembly (written here, not
+        for (int e = tid; e < Mz * Mz; e += nt) {     // in stage A: stage A of the next step may overlap it)
             const int i = vg_div(e, iMz), j = e - i * Mz;
-            La[i * ld + j] = Lkg[e];
+            const double lk = Lkg[e];
+            La[i * ld + j] = lk;
             Li[i * ld + j] = Lig[e];
+            if (role == 0) Lk32[e] = (float)lk;
             if (role == 1) Kd[i * ld + j] = Kdg[e];
             if (role == 2) Kd[i * ld + j] = Kg[e] / var;
         }
@@ -865,7 +866,10 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_kernel(PathArgs a) {
 }
 
 // =================================================================================================
-// Gradient assembly + Adam.  One workgroup per (latent, problem).
+// Gradient assembly + Adam, in two launches so that the next step can start early:
+//   hyper_kernel  -- lengthscale / variance of every latent (a handful of scalars): the covariance and
+//                    feature kernels of the NEXT step depend only on these, so they are released first;
+//   final_kernel  -- q_mu / q_sqrt of one (latent, problem) per workgroup, and the ELBO pieces.
 // =================================================================================================
 struct FinalArgs {
     int M, L, NC, nblk;
@@ -878,6 +882,7 @@ struct FinalArgs {
     int do_adam, trainable, want_dell;
     double lr_t, lr;
     const uint32_t* ctr;      // device step counter (1-based Adam step after the tick) or null
+    double* lr_dev;           // [P] step size handed from hyper_kernel to final_kernel
     double *mq_mu, *mq_sqrt, *m_ell, *m_var;      // Adam moments
     double *vq_mu, *vq_sqrt, *v_ell, *v_var;
     double *pq_mu, *pq_sqrt, *p_ell, *p_var;      // parameters (updated in place)
@@ -892,9 +897,55 @@ __device__ __forceinline__ void adam_update(double* x, double* m, double* v, dou
     *x -= lr_t * mm / (sqrt(vv) + 1e-7);
 }
 
+// sum over the NC sample chunks of one reverse-pass partial, 8 independent loads in flight per pass
+// (unconditional clamped loads, masked afterwards); fixed order: deterministic
+__device__ __forceinline__ double sum_chunks(const float* part, size_t part_len, int NC, int e) {
+    double s = 0.0;
+    for (int c0 = 0; c0 < NC; c0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = c0 + k < NC ? c0 + k : NC - 1;
+            v[k] = part[(size_t)c * part_len + e];
+        }
+        double d[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = c0 + k < NC ? (double)v[k] : 0.0;
+        s += ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+    }
+    return s;
+}
+
+// one wave per problem, one lane per latent
+__global__ __launch_bounds__(64) void hyper_kernel(FinalArgs b) {
+    const int p = blockIdx.x, l = threadIdx.x;
+    const int Mz = b.M + 2, L = b.L;
+    double lr_t = b.lr_t;
+    if (b.do_adam && b.ctr) {
+        const double t = (double)*b.ctr;
+        lr_t = b.lr * sqrt(1.0 - exp(t * -0.05129329438755058)) / (1.0 - exp(t * -0.2231435513142098));
+    }
+    if (l == 0) b.lr_dev[p] = lr_t;
+    if (l >= L) return;
+    const size_t pl = (size_t)p * L + l;
+    const float* part = b.part + pl * b.NC * b.part_len;
+    const int e0 = Mz + Mz * Mz;
+    const double s_ell = b.want_dell ? sum_chunks(part, b.part_len, b.NC, e0) : 0.0;
+    const double s_var = sum_chunks(part, b.part_len, b.NC, e0 + 1);
+    const double s_rff = sum_chunks(part, b.part_len, b.NC, e0 + 2);
+    const double kls = b.kl_scale, var = b.var[pl];
+    const double g_ell = (s_ell + kls * b.gkl_ell[pl]) * b.sig_ell[pl];
+    const double g_var = (s_var + s_rff / (2.0 * var) + kls * b.gkl_var[pl]) * b.sig_var[pl];
+    b.g_ell[pl] = g_ell;
+    b.g_var[pl] = g_var;
+    if (b.do_adam) {
+        if (b.trainable & VGPMP_TRAIN_LENGTHSCALES) adam_update(b.p_ell + pl, b.m_ell + pl, b.v_ell + pl, g_ell, lr_t);
+        if (b.trainable & VGPMP_TRAIN_KERNEL_VARIANCE) adam_update(b.p_var + pl, b.m_var + pl, b.v_var + pl, g_var, lr_t);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void final_kernel(FinalArgs b) {
     extern __shared__ double sm[];
-    __shared__ double lrs;
     VG_STOP(b, 7);
     const int l = blockIdx.x, p = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
     const int M = b.M, Mz = M + 2, L = b.L;
@@ -902,46 +953,23 @@ __global__ __launch_bounds__(kBlock) void final_kernel(FinalArgs b) {
     const size_t pl = (size_t)p * L + l;
     double* dC = sm;                 // [Mz][Mz]
     double* dmv = dC + Mz * Mz;      // [Mz]
-    double* sc = dmv + Mz;           // [4]
-    float* Lks = reinterpret_cast<float*>(sc + 4);   // [Mz][Mz] chol factor
+    float* Lks = reinterpret_cast<float*>(dmv + Mz);   // [Mz][Mz] chol factor
     const float* part = b.part + pl * b.NC * b.part_len;
     const float* Lkg = b.Lk32 + pl * Mz * Mz;
+    const double lr_t = b.do_adam ? b.lr_dev[p] : 0.0;
     for (int e = tid; e < Mz * Mz; e += nt) Lks[e] = Lkg[e];
     VG_STOP(b, 5);
-    // sum the per-chunk partials; 8 independent loads in flight per pass
-    for (int e = tid; e < Mz + Mz * Mz + 3; e += nt) {
-        double s = 0.0;
-        for (int c0 = 0; c0 < b.NC; c0 += 8) {
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {          // unconditional loads (clamped), masked afterwards
-                const int c = c0 + k < b.NC ? c0 + k : b.NC - 1;
-                v[k] = part[(size_t)c * b.part_len + e];
-            }
-            double d[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) d[k] = c0 + k < b.NC ? (double)v[k] : 0.0;
-            s += ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
-        }
+    for (int e = tid; e < Mz + Mz * Mz; e += nt) {
+        const double s = sum_chunks(part, b.part_len, b.NC, e);
         if (e < Mz) dmv[e] = s;
-        else if (e < Mz + Mz * Mz) dC[e - Mz] = s;
-        else sc[e - Mz - Mz * Mz] = s;
+        else dC[e - Mz] = s;
     }
     VG_STOP(b, 6);
-    if (tid == 0) {
-        double lr_t = b.lr_t;
-        if (b.do_adam && b.ctr) {
-            const double t = (double)*b.ctr;
-            lr_t = b.lr * sqrt(1.0 - exp(t * -0.05129329438755058)) / (1.0 - exp(t * -0.2231435513142098));
-        }
-        lrs = lr_t;
-    }
     __syncthreads();
     VG_STOP(b, 1);
     const double kls = b.kl_scale;
     double* gQ = b.g_qsqrt + pl * M * M;
     const double* kQ = b.gkl_Q + pl * M * M;
-    const double lr_t = lrs;
     for (int e = tid; e < M * M; e += nt) {
         int r = vg_div(e, iM), c = e - r * M;
         double s = 0.0;
@@ -961,25 +989,19 @@ __global__ __launch_bounds__(kBlock) void final_kernel(FinalArgs b) {
     VG_STOP(b, 2);
     double* gm = b.g_qmu + pl * M;
     for (int i = tid; i < M; i += nt) gm[i] = dmv[i + 2] + kls * b.gkl_qmu[pl * M + i];
-    if (tid == 0) {
-        const double var = b.var[pl];
-        b.g_ell[pl] = ((b.want_dell ? sc[0] : 0.0) + kls * b.gkl_ell[pl]) * b.sig_ell[pl];
-        b.g_var[pl] = (sc[1] + sc[2] / (2.0 * var) + kls * b.gkl_var[pl]) * b.sig_var[pl];
-    }
     if (b.do_adam) {
         __syncthreads();           // gradients above are read back below (same workgroup, global memory)
-        // ONE update loop over every variable of this latent: q_mu | q_sqrt (lower) | lengthscale | variance
+        // ONE update loop over the variational variables of this latent: q_mu | q_sqrt (lower)
         const int nq = M + M * M;
-        for (int k = tid; k < nq + 2; k += nt) {
+        for (int k = tid; k < nq; k += nt) {
             double *x, *m, *v; double g; int flag;
             if (k < M) { x = b.pq_mu + pl * M + k; m = b.mq_mu + pl * M + k; v = b.vq_mu + pl * M + k; g = gm[k]; flag = VGPMP_TRAIN_Q_MU; }
-            else if (k < nq) {
+            else {
                 const int e = k - M, r = vg_div(e, iM);
                 if (e - r * M > r) continue;
                 x = b.pq_sqrt + pl * M * M + e; m = b.mq_sqrt + pl * M * M + e; v = b.vq_sqrt + pl * M * M + e; g = gQ[e];
                 flag = VGPMP_TRAIN_Q_SQRT;
-            } else if (k == nq) { x = b.p_ell + pl; m = b.m_ell + pl; v = b.v_ell + pl; g = b.g_ell[pl]; flag = VGPMP_TRAIN_LENGTHSCALES; }
-            else { x = b.p_var + pl; m = b.m_var + pl; v = b.v_var + pl; g = b.g_var[pl]; flag = VGPMP_TRAIN_KERNEL_VARIANCE; }
+            }
             if (b.trainable & flag) adam_update(x, m, v, g, lr_t);
         }
     }
@@ -1078,6 +1100,7 @@ size_t vg_layout_workspace(const vgpmp_dims* d, void* base, vg_workspace* ws) {
     ws->G = carve<float>(cur, P * S * L * N, real);
     ws->lik_partial = carve<float>(cur, P * (size_t)vg_loglik_blocks_per_problem(d->S, d->N), real);
     ws->part = carve<float>(cur, PL * vg_chunks(d) * vg_part_len(d), real);
+    ws->lr_t = carve<double>(cur, P, real);
     return (size_t)(cur - start) + 256;
 }
 
@@ -1100,13 +1123,17 @@ int vg_workspace_lookup(const vgpmp_dims* d, const vg_workspace* ws, const char*
 }
 
 int vg_launch_rng(const vgpmp_dims* d, const vgpmp_noise* nz, uint32_t seed, uint32_t problem_base, uint32_t step,
-                  const uint32_t* ctr, hipStream_t st) {
+                  const uint32_t* ctr, hipStream_t st, int parts) {
     const int P = d->num_problems, L = d->L, B = d->B, D = d->L, Mz = vg_mz(d);
-    hipLaunchKernelGGL(rng_basis_kernel, dim3((L * B + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, L, B, D, nz->omega,
-                       nz->beta, seed, problem_base, step, ctr);
-    const uint32_t nW = (uint32_t)d->S * L * B, nE = (uint32_t)d->S * Mz * L;      // nW % 4 == 0 since B % 16 == 0
+    if (parts & VG_RNG_PRIOR)
+        hipLaunchKernelGGL(rng_basis_kernel, dim3((L * B + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, L, B, D,
+                           nz->omega, nz->beta, seed, problem_base, step, ctr);
+    // nW % 4 == 0 since B % 16 == 0
+    const uint32_t nW = (parts & VG_RNG_PRIOR) ? (uint32_t)d->S * L * B : 0u;
+    const uint32_t nE = (parts & VG_RNG_EPS) ? (uint32_t)d->S * Mz * L : 0u;
     const uint32_t wOff = (uint32_t)d->sample_offset * L * B, eOff = (uint32_t)d->sample_offset * Mz * L;
     const uint32_t nthr = (nW >> 2) + 2 * nE;
+    if (nthr == 0) return (int)hipGetLastError();
     hipLaunchKernelGGL(rng_normals_kernel, dim3((nthr + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, nW, nE, wOff, eOff,
                        nz->w, nz->eps, nz->eps2, seed, problem_base, step, ctr);
     return (int)hipGetLastError();
@@ -1148,10 +1175,25 @@ static int set_dyn_lds(const void* fn, size_t bytes) {
     return 0;
 }
 
+// One step of the training loop as a dependency graph over up to three streams:
+//
+//   stream A (side_stream)    cov_a(theta) ................ cov_b(theta, q_mu, q_sqrt) --+
+//   stream C (side_stream2)   [eps] features(theta) -> prior GEMM ---------------------+-+-> [next: omega, beta, w]
+//   main                                                                               v v
+//                                            paths_fwd -> loglik -> paths_bwd -> hyper -> final
+//                                                                                  |        |
+//                       theta(t+1) ready: A and C of step t+1 start here ----------+        +---- q(t+1) ready: cov_b of t+1
+//
+// Within one call of several steps (VG_CHAIN_*) the hand-over to the next step happens at those two
+// events instead of at the end of the step, so cov_a / features / GEMM of step t+1 overlap `final`
+// of step t; the prior noise of step t+1 is drawn right after the GEMM of step t has consumed the old
+// one.  Every counter access (noise key, Adam step) is ordered: the feature kernel ticks the counter on
+// stream C, the noise kernels read it on stream C, hyper_kernel reads it between the join and the
+// hand-over event.  With one stream (or under the per-stage profiler) the same kernels run in sequence.
 int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sdf, const vgpmp_problem* pb,
                  const vgpmp_params* params, const vgpmp_params* am, const vgpmp_params* av, const vgpmp_noise* nz,
                  const vgpmp_outputs* out, const vg_workspace* ws, int what, int trainable, double lr, int adam_t,
-                 uint32_t seed, uint32_t problem_base, uint32_t step, hipStream_t st, hipEvent_t* ev) {
+                 uint32_t seed, uint32_t problem_base, uint32_t step, hipStream_t st, hipEvent_t* ev, int chain) {
     const int P = d->num_problems, S = d->S, N = d->N, M = d->M, L = d->L, B = d->B, Mz = M + 2, J = N + Mz;
     const int SK = d->split_k, NC = vg_chunks(d), SC = vg_sc(d);
     const bool backward = (what & VGPMP_DO_BACKWARD) != 0;
@@ -1160,8 +1202,15 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
     auto mark = [&]() { if (ev) (void)hipEventRecord(ev[evi++], st); };
     uint32_t* ctr = pb->step_counter;
     int rc;
-    // ---- covariance path (float64): on the side stream when the caller provides one, so that it
-    //      overlaps the noise / feature / GEMM branch; joined before the path assembly.
+    const bool fork = !ev && pb->side_stream && pb->fork_event && pb->join_event;
+    const bool fork2 = fork && pb->side_stream2 && pb->join_event2;
+    const bool pipelined = fork2 && pb->hyper_event && pb->rest_event && backward && (what & VGPMP_DO_ADAM) &&
+                           (what & VGPMP_GEN_NOISE);
+    const bool chained = pipelined && (chain & VG_CHAIN_PREV);
+    const bool feeds_next = pipelined && (chain & VG_CHAIN_NEXT);
+    hipStream_t cst = fork ? (hipStream_t)pb->side_stream : st;         // stream A
+    hipStream_t pst = fork2 ? (hipStream_t)pb->side_stream2 : st;       // stream C
+    // ---- covariance path (float64)
     CovArgs ca;
     ca.N = N; ca.M = M; ca.L = L; ca.D = L;
     ca.X = pb->X; ca.Zy = pb->Zy; ca.y_u = pb->y_u; ca.jitter = pb->jitter;
@@ -1176,17 +1225,22 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
     const size_t lds_cov = ((size_t)6 * Mp * (Mp + 1) + 5 * Mp) * sizeof(double);
     const size_t lds_cov_a = ((size_t)4 * Mp * (Mp + 1) + 2 * Mp) * sizeof(double);
     const size_t lds_rows = ((size_t)2 * Mz * (Mz + 1) + (size_t)4 * kRowTile * Mz + Mz) * sizeof(double);
-    const bool fork = !ev && pb->side_stream && pb->fork_event && pb->join_event;
-    hipStream_t cst = fork ? (hipStream_t)pb->side_stream : st;
     mark();
     if (fork) {
-        VG_CHECK_HIP(hipEventRecord((hipEvent_t)pb->fork_event, st));
-        VG_CHECK_HIP(hipStreamWaitEvent(cst, (hipEvent_t)pb->fork_event, 0));
+        if (chained) {
+            VG_CHECK_HIP(hipStreamWaitEvent(cst, (hipEvent_t)pb->hyper_event, 0));
+            VG_CHECK_HIP(hipStreamWaitEvent(pst, (hipEvent_t)pb->hyper_event, 0));
+        } else {
+            VG_CHECK_HIP(hipEventRecord((hipEvent_t)pb->fork_event, st));
+            VG_CHECK_HIP(hipStreamWaitEvent(cst, (hipEvent_t)pb->fork_event, 0));
+            if (fork2) VG_CHECK_HIP(hipStreamWaitEvent(pst, (hipEvent_t)pb->fork_event, 0));
+        }
     }
     {
         rc = set_dyn_lds((const void*)cov_a_kernel, lds_cov_a);
         if (rc) return rc;
         hipLaunchKernelGGL(cov_a_kernel, dim3(L, P), dim3(kCovThreads), lds_cov_a, cst, ca);
+        if (chained) VG_CHECK_HIP(hipStreamWaitEvent(cst, (hipEvent_t)pb->rest_event, 0));
         const void* fn = backward ? (const void*)cov_b_kernel<true> : (const void*)cov_b_kernel<false>;
         const size_t lds_b = lds_cov > lds_rows ? lds_cov : lds_rows;
         rc = set_dyn_lds(fn, lds_b);
@@ -1196,8 +1250,8 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
     }
     if (fork) VG_CHECK_HIP(hipEventRecord((hipEvent_t)pb->join_event, cst));
     mark();
-    if (what & VGPMP_GEN_NOISE) {
-        rc = vg_launch_rng(d, nz, seed, problem_base, step, ctr, st);
+    if (what & VGPMP_GEN_NOISE) {       // a chained step finds omega / beta / w drawn by its predecessor
+        rc = vg_launch_rng(d, nz, seed, problem_base, step, ctr, pst, chained ? VG_RNG_EPS : (VG_RNG_PRIOR | VG_RNG_EPS));
         if (rc) return rc;
     }
     mark();
@@ -1205,19 +1259,25 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
     // few problems: one point per workgroup (more parallelism); many: sweep 16 points per lane (omega reuse)
     const int jchunk = P * L >= 64 ? 16 : 1;
     hipLaunchKernelGGL(features_kernel, dim3((B + kBlock - 1) / kBlock, (J + jchunk - 1) / jchunk, P * L), dim3(kBlock), 0,
-                       st, N, Mz, L, L, B, jchunk, pb->X, pb->Zy, params->raw_ell, params->raw_var, nz->omega, nz->beta, ws->Phi,
+                       pst, N, Mz, L, L, B, jchunk, pb->X, pb->Zy, params->raw_ell, params->raw_var, nz->omega, nz->beta, ws->Phi,
                        want_dell ? ws->dPhi : (float*)nullptr, (what & VGPMP_DO_ADAM) ? ctr : (uint32_t*)nullptr);
     mark();
     const size_t slab = (size_t)P * S * L * J;
     const int nsel = want_dell ? 2 : 1;
     if (SK == 1 && (B % kTK) == 0)      // large batch: LDS-tiled kernel (split_k == 1 is chosen by the host for P*L > 256)
         hipLaunchKernelGGL(prior_gemm_tiled_kernel, dim3((J + kTJ - 1) / kTJ, (S + kTS - 1) / kTS, P * L * nsel), dim3(kBlock),
-                           0, st, S, L, J, B, nsel, nz->w, ws->Phi, ws->dPhi, ws->F0, ws->H);
+                           0, pst, S, L, J, B, nsel, nz->w, ws->Phi, ws->dPhi, ws->F0, ws->H);
     else
         hipLaunchKernelGGL(prior_gemm_kernel, dim3((J + 16 * kNT - 1) / (16 * kNT), (S + 63) / 64, P * L * SK * nsel),
-                           dim3(kBlock), 0, st, S, L, J, B, SK, nsel, nz->w, ws->Phi, ws->dPhi, ws->F0, ws->H, slab);
+                           dim3(kBlock), 0, pst, S, L, J, B, SK, nsel, nz->w, ws->Phi, ws->dPhi, ws->F0, ws->H, slab);
     mark();
+    if (fork2) VG_CHECK_HIP(hipEventRecord((hipEvent_t)pb->join_event2, pst));
+    if (feeds_next) {                   // prior noise of the next step (the counter has ticked: key = step + 1)
+        rc = vg_launch_rng(d, nz, seed, problem_base, step + 1u, ctr, pst, VG_RNG_PRIOR);
+        if (rc) return rc;
+    }
     if (fork) VG_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)pb->join_event, 0));
+    if (fork2) VG_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)pb->join_event2, 0));
     // ---- path assembly
     PathArgs pa;
     pa.S = S; pa.N = N; pa.Mz = Mz; pa.L = L; pa.SK = SK; pa.NC = NC; pa.slab = slab; pa.part_len = vg_part_len(d);
@@ -1275,7 +1335,7 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
     fa.g_qmu = out->grad.q_mu; fa.g_qsqrt = out->grad.q_sqrt; fa.g_ell = out->grad.raw_ell; fa.g_var = out->grad.raw_var;
     fa.do_adam = (what & VGPMP_DO_ADAM) ? 1 : 0; fa.trainable = trainable; fa.want_dell = want_dell ? 1 : 0;
     fa.lr_t = fa.do_adam ? adam_lr_t(lr, adam_t > 0 ? adam_t : 1) : 0.0;
-    fa.lr = lr; fa.ctr = ctr;
+    fa.lr = lr; fa.ctr = ctr; fa.lr_dev = ws->lr_t;
     fa.mq_mu = am ? am->q_mu : nullptr; fa.mq_sqrt = am ? am->q_sqrt : nullptr;
     fa.m_ell = am ? am->raw_ell : nullptr; fa.m_var = am ? am->raw_var : nullptr;
     fa.vq_mu = av ? av->q_mu : nullptr; fa.vq_sqrt = av ? av->q_sqrt : nullptr;
@@ -1285,10 +1345,13 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
 #ifdef VGPMP_BISECT
     fa.stop = vg_bisect_stop("VGPMP_STOP_FINAL");
 #endif
-    const size_t lds_fin = ((size_t)Mz * Mz + Mz + 4) * sizeof(double) + (size_t)Mz * Mz * sizeof(float);
+    const size_t lds_fin = ((size_t)Mz * Mz + Mz) * sizeof(double) + (size_t)Mz * Mz * sizeof(float);
     rc = set_dyn_lds((const void*)final_kernel, lds_fin);
     if (rc) return rc;
+    hipLaunchKernelGGL(hyper_kernel, dim3(P), dim3(64), 0, st, fa);
+    if (feeds_next) VG_CHECK_HIP(hipEventRecord((hipEvent_t)pb->hyper_event, st));
     hipLaunchKernelGGL(final_kernel, dim3(L, P), dim3(kBlock), lds_fin, st, fa);
+    if (feeds_next) VG_CHECK_HIP(hipEventRecord((hipEvent_t)pb->rest_event, st));
     mark();
     return (int)hipGetLastError();
 }

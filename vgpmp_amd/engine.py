@@ -184,10 +184,12 @@ class PlannerBatch:
         self.kl_scale = float(kl_scale)
         # device-resident step counter: lets a captured hipGraph of the step be replayed
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
-        # side stream + fork/join events: the float64 covariance kernel overlaps the noise/GEMM branch
-        self._side = torch.cuda.Stream(device=dev)
-        self._fork_ev, self._join_ev = torch.cuda.Event(), torch.cuda.Event()
-        self._fork_ev.record(); self._join_ev.record()
+        # side streams + events: the float64 covariance kernels and the noise/feature/GEMM kernels run next to
+        # each other, and inside run_steps the next step starts while this one assembles its gradients
+        self._side, self._side2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self._events = [torch.cuda.Event() for _ in range(5)]     # fork, join, join2, hyper, rest
+        for e in self._events:
+            e.record()
         self.overlap = True
         self._graph = None
         self._graph_unroll = 0
@@ -202,8 +204,9 @@ class PlannerBatch:
         self._av = self._params_struct(self.adam_v)
         self._noise = capi.Noise(capi.ptr(self.omega), capi.ptr(self.beta), capi.ptr(self.w), capi.ptr(self.eps),
                                  capi.ptr(self.eps2))
-        side = (int(self._side.cuda_stream), int(self._fork_ev.cuda_event), int(self._join_ev.cuda_event)) \
-            if self.overlap else (None, None, None)
+        fork, join, join2, hyper, rest = (int(e.cuda_event) for e in self._events)
+        side = (int(self._side.cuda_stream), fork, join, int(self._side2.cuda_stream), join2, hyper, rest) \
+            if self.overlap else (None,) * 7
         self._problem = capi.Problem(capi.ptr(self.X), capi.ptr(self.Zy), capi.ptr(self.y_u), self.alpha, JITTER,
                                      self.kl_scale, None, *side)
         self._problem_ctr = capi.Problem(capi.ptr(self.X), capi.ptr(self.Zy), capi.ptr(self.y_u), self.alpha, JITTER,
@@ -247,17 +250,17 @@ class PlannerBatch:
         self._run(capi.DO_FORWARD | capi.DO_BACKWARD | capi.DO_ADAM | (capi.GEN_NOISE if generate else 0), step)
 
     # ---- hipGraph replay of the training step ----------------------------------------------------
-    def _run_counter(self, fn=None, stage_ms=None) -> None:
-        """One training step whose noise key / Adam step count come from the device counter."""
+    def _run_counter(self, num_steps: int = 1, stage_ms=None) -> None:
+        """`num_steps` training steps whose noise key / Adam step count come from the device counter."""
         what = capi.DO_FORWARD | capi.DO_BACKWARD | capi.DO_ADAM | capi.GEN_NOISE
         args = (C.byref(self.dims), capi.ptr(self.scene.dev_robot), C.byref(self.scene.sdf),
                 C.byref(self._problem_ctr), C.byref(self._params), C.byref(self._am), C.byref(self._av),
                 C.byref(self._noise), C.byref(self._out), capi.ptr(self.workspace), self.workspace.numel(), what,
-                trainable_mask(self.trainable), self.lr, 0, self.seed, self.problem_base, 0, capi.stream_ptr())
+                trainable_mask(self.trainable), self.lr, 0, self.seed, self.problem_base, 0)
         if stage_ms is None:
-            capi.check(self.lib.vgpmp_elbo_step(*args), "vgpmp_elbo_step")
+            capi.check(self.lib.vgpmp_elbo_steps(*args, int(num_steps), capi.stream_ptr()), "vgpmp_elbo_steps")
         else:
-            capi.check(self.lib.vgpmp_elbo_step_profiled(*args, stage_ms), "vgpmp_elbo_step_profiled")
+            capi.check(self.lib.vgpmp_elbo_step_profiled(*args, capi.stream_ptr(), stage_ms), "vgpmp_elbo_step_profiled")
 
     def capture(self, unroll: int = 10) -> None:
         """Capture `unroll` consecutive training steps into one hipGraph (torch.cuda.CUDAGraph is the
@@ -268,8 +271,7 @@ class PlannerBatch:
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            for _ in range(unroll):
-                self._run_counter()
+            self._run_counter(unroll)
         self._graph, self._graph_unroll = g, int(unroll)
 
     def run_steps(self, steps: int) -> None:
@@ -281,9 +283,8 @@ class PlannerBatch:
                 steps -= self._graph_unroll
         if steps > 0:
             self.step_counter.fill_(self.t)
-            for _ in range(steps):
-                self._run_counter()
-                self.t += 1
+            self._run_counter(steps)
+            self.t += steps
 
     def profile_steps(self, steps: int):
         """`steps` training steps with a HIP event around every kernel: mean milliseconds per stage."""
