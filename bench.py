@@ -61,6 +61,7 @@ def build_problem(rank: int, args):
                                   num_data=args.timesteps, num_bases=1024, lengthscales=pp["lengthscales"],
                                   variance=pp["variance"], alpha=pp["alpha"], learning_rate=pp["learning_rate"],
                                   seed=1234, problem_base=rank * args.problems, split_k=args.split_k or None)
+    planner.fuse = not args.no_fuse
     return ps, spec, grid, scene, planner
 
 
@@ -107,6 +108,7 @@ def main():
     ap.add_argument("--problems", type=int, default=1, help="problems per GPU (config 2: 1)")
     ap.add_argument("--grid", type=int, default=128, help="SDF voxels per axis (synthetic scenes)")
     ap.add_argument("--split-k", type=int, default=0, help="K-slices of the prior GEMM (0 = engine default)")
+    ap.add_argument("--no-fuse", action="store_true", help="one launch per kernel even for small batches (measurement)")
     ap.add_argument("--scene", choices=("industrial", "synthetic"), default="industrial",
                     help="industrial = SDF generated from the reference's industrial collision mesh; synthetic = boxes/spheres")
     ap.add_argument("--unroll", type=int, default=10, help="steps per captured hipGraph (0 = eager launches)")

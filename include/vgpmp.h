@@ -111,18 +111,10 @@ typedef struct vgpmp_problem {
     double alpha;          /* likelihood temperature (vgpmp.py:82) */
     double jitter;         /* 1e-6 */
     double kl_scale;       /* 1 on the rank that owns the KL term, 0 elsewhere */
-    uint32_t* step_counter; /* dev, optional: when set, the noise key uses *step_counter and the Adam
-                             * step count is *step_counter + 1; a VGPMP_DO_ADAM step increments it on
-                             * the device, so a captured hipGraph of the step can be replayed */
-    /* Optional extra streams and events (hipEvent_t), all owned by the caller.  Any group may be NULL;
-     * the kernels then run in sequence on `stream` with identical results. */
-    vgpmp_stream side_stream; /* the float64 covariance kernels run here, concurrently with the            */
-    void* fork_event;         /* noise / feature / GEMM kernels; fork_event and join_event order the two   */
-    void* join_event;
-    vgpmp_stream side_stream2; /* the noise / feature / GEMM kernels get their own stream as well           */
-    void* join_event2;
-    void* hyper_event;        /* vgpmp_elbo_steps: hand-over points of step t to step t+1 (kernel hyper-   */
-    void* rest_event;         /* parameters updated / variational parameters updated)                      */
+    uint32_t* step_counter; /* dev, optional: number of completed training steps.  When set, the noise key
+                             * uses *step_counter and the Adam step count is *step_counter + 1; a
+                             * VGPMP_DO_ADAM step increments it on the device, so a captured hipGraph of
+                             * the steps can be replayed */
 } vgpmp_problem;
 
 /* Outputs of an ELBO evaluation. */
@@ -143,6 +135,7 @@ typedef struct vgpmp_outputs {
 #define VGPMP_DO_BACKWARD 2     /* + gradient of -ELBO (utils/miscellaneous.py:77-80)        */
 #define VGPMP_DO_ADAM 4         /* + Adam.apply_gradients (utils/miscellaneous.py:82)        */
 #define VGPMP_GEN_NOISE 8       /* draw the noise with the device Philox generator first     */
+#define VGPMP_NO_FUSE 16        /* measurement: one launch per kernel even for small batches  */
 
 /* ---- set-up -------------------------------------------------------------------------------- */
 
@@ -200,9 +193,9 @@ int vgpmp_elbo_step(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const 
 
 /* `num_steps` consecutive training steps (the body of training_loop, utils/miscellaneous.py:87-112) in one
  * call: step i uses noise key `step + i` and Adam count `adam_t + i` (or the device counter).  Results are
- * identical to `num_steps` calls of vgpmp_elbo_step; when `problem` carries both side streams and all
- * events, step i+1 starts as soon as step i has updated what it depends on (its covariance / feature /
- * GEMM kernels overlap the gradient assembly of step i).  Requires VGPMP_DO_ADAM | VGPMP_GEN_NOISE. */
+ * identical to `num_steps` calls of vgpmp_elbo_step.  For small batches independent kernels of a step share
+ * launches, and the q_mu / q_sqrt update of step i runs next to the covariance and feature kernels of step
+ * i+1 (which only need the kernel hyper-parameters).  Requires VGPMP_DO_ADAM | VGPMP_GEN_NOISE. */
 int vgpmp_elbo_steps(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,
                      const vgpmp_problem* problem, const vgpmp_params* params,
                      const vgpmp_params* adam_m, const vgpmp_params* adam_v,

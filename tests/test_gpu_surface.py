@@ -182,8 +182,9 @@ def test_graph_replay_matches_eager_steps():
 
 @pytest.mark.parametrize("P", [1, 3])
 def test_pipelined_steps_equal_single_step_calls(P):
-    """vgpmp_elbo_steps overlaps step t+1 with the gradient assembly of step t over three streams; the
-    result must equal the same steps issued one call at a time on a single stream (no overlap at all)."""
+    """vgpmp_elbo_steps shares launches between independent kernels and runs the q_mu / q_sqrt update of step t
+    next to the covariance / feature kernels of step t+1; the result must equal the same steps issued one call
+    at a time with one launch per kernel."""
     from vgpmp_amd import engine
     ps = rb.load_problemset("franka", "industrial")
     spec = rb.load_robot("franka")
@@ -192,11 +193,10 @@ def test_pipelined_steps_equal_single_step_calls(P):
     qs = np.array([ps.queries[i] for i in range(P)])
     kw = dict(num_samples=32, num_inducing=12, num_data=40, num_bases=128, lengthscales=[2.0] * 7, variance=0.2, seed=3)
     a, b = engine.PlannerBatch(sc, qs, **kw), engine.PlannerBatch(sc, qs, **kw)
-    b.overlap = False
-    b._pack()
+    b.fuse = False
     a.run_steps(25)
     for _ in range(25):
-        b.step()
+        b.run_steps(1)
     torch.cuda.synchronize()
     assert a.t == b.t == 25
     for x, y in ((a.q_mu, b.q_mu), (a.q_sqrt, b.q_sqrt), (a.raw_ell, b.raw_ell), (a.raw_var, b.raw_var),

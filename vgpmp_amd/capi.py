@@ -15,7 +15,7 @@ import numpy as np
 
 MAX_DOF, MAX_SPHERES, MAX_MZ = 16, 64, 48
 TRAIN_Q_MU, TRAIN_Q_SQRT, TRAIN_LENGTHSCALES, TRAIN_KERNEL_VARIANCE = 1, 2, 4, 8
-DO_FORWARD, DO_BACKWARD, DO_ADAM, GEN_NOISE = 1, 2, 4, 8
+DO_FORWARD, DO_BACKWARD, DO_ADAM, GEN_NOISE, NO_FUSE = 1, 2, 4, 8, 16
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvgpmp_hip.so"
 
@@ -63,10 +63,7 @@ class Noise(C.Structure):
 
 class Problem(C.Structure):
     _fields_ = [("X", C.c_void_p), ("Zy", C.c_void_p), ("y_u", C.c_void_p), ("alpha", C.c_double),
-                ("jitter", C.c_double), ("kl_scale", C.c_double), ("step_counter", C.c_void_p),
-                ("side_stream", C.c_void_p), ("fork_event", C.c_void_p), ("join_event", C.c_void_p),
-                ("side_stream2", C.c_void_p), ("join_event2", C.c_void_p), ("hyper_event", C.c_void_p),
-                ("rest_event", C.c_void_p)]
+                ("jitter", C.c_double), ("kl_scale", C.c_double), ("step_counter", C.c_void_p)]
 
 
 class Outputs(C.Structure):

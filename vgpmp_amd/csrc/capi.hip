@@ -105,13 +105,8 @@ static int elbo_step_impl(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, 
     vg_workspace ws;
     size_t need = vg_layout_workspace(dims, dev_workspace, &ws);
     if (workspace_bytes < need) return VGPMP_E_WORKSPACE;
-    for (int i = 0; i < num_steps; ++i) {
-        const int chain = (i > 0 ? VG_CHAIN_PREV : 0) | (i + 1 < num_steps ? VG_CHAIN_NEXT : 0);
-        rc = vg_elbo_step(dims, dev_robot, sdf, problem, params, adam_m, adam_v, noise, out, &ws, what, trainable,
-                          learning_rate, adam_t + i, seed, problem_base, step + (uint32_t)i, (hipStream_t)stream, ev, chain);
-        if (rc) return rc;
-    }
-    return 0;
+    return vg_elbo_steps(dims, dev_robot, sdf, problem, params, adam_m, adam_v, noise, out, &ws, what, trainable,
+                         learning_rate, adam_t, seed, problem_base, step, num_steps, (hipStream_t)stream, ev);
 }
 
 int vgpmp_elbo_step(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,

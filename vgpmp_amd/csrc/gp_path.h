@@ -44,16 +44,12 @@ int vg_check_dims(const vgpmp_dims* d);
 size_t vg_layout_workspace(const vgpmp_dims* d, void* base, vg_workspace* ws);
 int vg_workspace_lookup(const vgpmp_dims* d, const vg_workspace* ws, const char* name, void** ptr, size_t* count,
                         int32_t* is_double);
-constexpr int VG_RNG_PRIOR = 1;   // omega, beta, w   (consumed by the feature / GEMM kernels)
-constexpr int VG_RNG_EPS = 2;     // eps, eps2       (consumed by the path kernels)
 int vg_launch_rng(const vgpmp_dims* d, const vgpmp_noise* noise, uint32_t seed, uint32_t problem_base, uint32_t step,
-                  const uint32_t* ctr, hipStream_t st, int parts = VG_RNG_PRIOR | VG_RNG_EPS);
+                  const uint32_t* ctr, hipStream_t st);
 int vg_launch_adam(const vgpmp_dims* d, const vgpmp_params* params, const vgpmp_params* grad, const vgpmp_params* am,
                    const vgpmp_params* av, int trainable, double lr, int t, hipStream_t st);
-int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sdf, const vgpmp_problem* pb,
-                 const vgpmp_params* params, const vgpmp_params* am, const vgpmp_params* av, const vgpmp_noise* noise,
-                 const vgpmp_outputs* out, const vg_workspace* ws, int what, int trainable, double lr, int adam_t,
-                 uint32_t seed, uint32_t problem_base, uint32_t step, hipStream_t st, hipEvent_t* ev, int chain = 0);
-constexpr int VG_CHAIN_PREV = 1;   // the previous step was enqueued by the same call (pipelined hand-over)
-constexpr int VG_CHAIN_NEXT = 2;   // another step follows in the same call
+int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sdf, const vgpmp_problem* pb,
+                  const vgpmp_params* params, const vgpmp_params* am, const vgpmp_params* av, const vgpmp_noise* noise,
+                  const vgpmp_outputs* out, const vg_workspace* ws, int what, int trainable, double lr, int adam_t,
+                  uint32_t seed, uint32_t problem_base, uint32_t step, int num_steps, hipStream_t st, hipEvent_t* ev);
 constexpr int VG_NUM_STAGES = 8;   // cov_fwd, rng, features, prior_gemm, paths_fwd, loglik, paths_bwd, final

@@ -23,6 +23,7 @@ static int vg_bisect_stop(const char* name) { const char* e = getenv(name); retu
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kFuseMaxPL = 64;                  // role-dispatched stage launches up to this many (problem, latent) pairs
 constexpr double kVarFloor = 0.1;               // models/vgpmp.py:139 positive(lower=1e-1)
 constexpr double kSqrt5 = 2.2360679774997896964;
 
@@ -69,18 +70,24 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 // =================================================================================================
 // RNG
 // =================================================================================================
+struct RngArgs {
+    int L, B, D;
+    uint32_t nW, nE, wOff, eOff;
+    float *omega, *beta, *w, *eps, *eps2;
+    uint32_t seed, problem_base, step, bias;
+    const uint32_t* ctr;      // device step counter: the key uses *ctr + bias instead of `step`
+};
+
+__device__ __forceinline__ uint32_t rng_step(const RngArgs& a) { return a.ctr ? *a.ctr + a.bias : a.step; }
+
 // omega [P,L,B,D] (Student-t, nu = 5: N(0,1) * rsqrt(chi2_5 / 5)) and beta [P,L,B]
-__global__ __launch_bounds__(kBlock) void rng_basis_kernel(int L, int B, int D, float* __restrict__ omega,
-                                                            float* __restrict__ beta, uint32_t seed,
-                                                            uint32_t problem_base, uint32_t step,
-                                                            const uint32_t* __restrict__ ctr) {
-    const int p = blockIdx.y;
-    if (ctr) step = *ctr;
-    const uint32_t lb = blockIdx.x * kBlock + threadIdx.x;
+__device__ __forceinline__ void rng_basis_body(const RngArgs& a, int bx, int p) {
+    const int L = a.L, B = a.B, D = a.D;
+    const uint32_t lb = bx * kBlock + threadIdx.x;
     if (lb >= (uint32_t)(L * B)) return;
-    const uint2 key = vg_key(seed, problem_base + p, step);
+    const uint2 key = vg_key(a.seed, a.problem_base + p, rng_step(a));
     const uint32_t e0 = lb * (uint32_t)D, c_first = e0 >> 2, c_last = (e0 + D - 1) >> 2;
-    float* om = omega + ((size_t)p * L * B + lb) * D;
+    float* om = a.omega + ((size_t)p * L * B + lb) * D;
     float gam = 0.f, sc = 0.f;
     // pass q = 0,1: chi-square counters (5 of 8 normals); then the omega counters of this row
 #pragma nounroll
@@ -101,31 +108,30 @@ __global__ __launch_bounds__(kBlock) void rng_basis_kernel(int L, int B, int D, 
     }
     uint4 r = vg_philox(make_uint4(lb >> 2, VG_STREAM_BETA, 0u, 0u), key);
     uint32_t rb = (lb & 3u) == 0 ? r.x : (lb & 3u) == 1 ? r.y : (lb & 3u) == 2 ? r.z : r.w;
-    beta[(size_t)p * L * B + lb] = 6.283185307179586f * vg_u01(rb);
+    a.beta[(size_t)p * L * B + lb] = 6.283185307179586f * vg_u01(rb);
 }
 
 // w [P, nW]: counter i of the stream yields global elements 4i..4i+3 (wOff is a multiple of 4);
 // eps, eps2 [P, nE]: one thread per element (their global offset need not be aligned).
-__global__ __launch_bounds__(kBlock) void rng_normals_kernel(uint32_t nW, uint32_t nE, uint32_t wOff, uint32_t eOff,
-                                                              float* __restrict__ w, float* __restrict__ eps,
-                                                              float* __restrict__ eps2, uint32_t seed,
-                                                              uint32_t problem_base, uint32_t step,
-                                                              const uint32_t* __restrict__ ctr) {
-    const int p = blockIdx.y;
-    if (ctr) step = *ctr;
+__device__ __forceinline__ void rng_normals_body(const RngArgs& a, int bx, int p, uint32_t nW, uint32_t nE) {
     const uint32_t cW = nW >> 2;
-    uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t c = bx * kBlock + threadIdx.x;
     if (c >= cW + 2u * nE) return;
-    const uint2 key = vg_key(seed, problem_base + p, step);
+    const uint2 key = vg_key(a.seed, a.problem_base + p, rng_step(a));
     if (c < cW) {
-        const float4 v = vg_normal4((wOff >> 2) + c, VG_STREAM_W, key);
-        *reinterpret_cast<float4*>(w + (size_t)p * nW + 4u * c) = v;
+        const float4 v = vg_normal4((a.wOff >> 2) + c, VG_STREAM_W, key);
+        *reinterpret_cast<float4*>(a.w + (size_t)p * nW + 4u * c) = v;
         return;
     }
     c -= cW;
     const bool second = c >= nE;
     if (second) c -= nE;
-    (second ? eps2 : eps)[(size_t)p * nE + c] = vg_normal1(eOff + c, second ? VG_STREAM_EPS2 : VG_STREAM_EPS, key);
+    (second ? a.eps2 : a.eps)[(size_t)p * nE + c] = vg_normal1(a.eOff + c, second ? VG_STREAM_EPS2 : VG_STREAM_EPS, key);
+}
+
+__global__ __launch_bounds__(kBlock) void rng_basis_kernel(RngArgs a) { rng_basis_body(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(kBlock) void rng_normals_kernel(RngArgs a) {
+    rng_normals_body(a, blockIdx.x, blockIdx.y, a.nW, a.nE);
 }
 
 // =================================================================================================
@@ -150,7 +156,7 @@ struct CovArgs {
     vg_workspace ws;
 };
 
-constexpr int kCovThreads = 256;
+constexpr int kCovThreads = 256;      // == kBlock: the covariance roles share launches with other kernels
 constexpr int kRowTile = 8;
 
 // ---- float64 matrix-core tiles ---------------------------------------------------------------------
@@ -224,10 +230,9 @@ __device__ __forceinline__ void chol_inverse_block(double* La, double* Li, doubl
 }
 
 // ---- stage A: Kuu, factorisation, inverse --------------------------------------------------------
-__global__ __launch_bounds__(kCovThreads) void cov_a_kernel(CovArgs a) {
-    extern __shared__ double sm[];
+__device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, int p) {
     __shared__ double scal[2];
-    const int l = blockIdx.x, p = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int M = a.M, Mz = M + 2, L = a.L, D = a.D;
     const int Mp = (Mz + 15) & ~15, ld = Mp + 1;
     const float iMz = 1.0f / (float)Mz;
@@ -279,6 +284,11 @@ __global__ __launch_bounds__(kCovThreads) void cov_a_kernel(CovArgs a) {
     }
 }
 
+__global__ __launch_bounds__(kCovThreads) void cov_a_kernel(CovArgs a) {
+    extern __shared__ double sm[];
+    cov_a_body(a, sm, blockIdx.x, blockIdx.y);
+}
+
 // ---- stage B: heterogeneous launch, role = blockIdx.x ---------------------------------------------
 //   0            q_sqrt = Lk pad(Q) + jitter, q_mu, KL and its gradient wrt q_mu / q_sqrt
 //   1, 2         forward-mode tangent wrt lengthscale / variance:  dC = (Lk Phi(Lk^-1 dK Lk^-T)) pad(Q), dKL
@@ -286,10 +296,9 @@ __global__ __launch_bounds__(kCovThreads) void cov_a_kernel(CovArgs a) {
 __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int p, int tid, int nt);
 
 template <bool TANGENTS>
-__global__ __launch_bounds__(kCovThreads) void cov_b_kernel(CovArgs a) {
-    extern __shared__ double sm[];
+__device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int role, int l, int p) {
     __shared__ double red[kCovThreads / VG_WAVE];
-    const int role = blockIdx.x, l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
     if (role >= 3) {
         cov_rows_body(a, sm, role - 3, l, p, tid, nt);
         return;
@@ -410,6 +419,12 @@ __global__ __launch_bounds__(kCovThreads) void cov_b_kernel(CovArgs a) {
     if (tid == 0) (role == 1 ? a.ws.gkl_ell : a.ws.gkl_var)[pl] = acc;
 }
 
+template <bool TANGENTS>
+__global__ __launch_bounds__(kCovThreads) void cov_b_kernel(CovArgs a) {
+    extern __shared__ double sm[];
+    cov_b_body<TANGENTS>(a, sm, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
 // A = Kfu (Kuu + jI)^-1 and its tangents for a tile of kRowTile time points:
 //   A_ell = (dKfu/dell - A dKuu/dell) Kinv,   A_var = (jitter / var) A Kinv
 // Output float32: A4[n][m] = {A, A_ell, A_var, 0} (one 16-byte load per use in the reverse pass)
@@ -482,30 +497,33 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
 // =================================================================================================
 __device__ __forceinline__ float softplus_f(float x) { return x > 15.f ? x : __logf(1.f + __expf(x)); }
 
-__global__ __launch_bounds__(kBlock) void features_kernel(int N, int Mz, int L, int D, int B, int jchunk,
-                                                           const double* __restrict__ X,
-                                                           const double* __restrict__ Zy,
-                                                           const double* __restrict__ raw_ell,
-                                                           const double* __restrict__ raw_var,
-                                                           const float* __restrict__ omega,
-                                                           const float* __restrict__ beta, float* __restrict__ Phi,
-                                                           float* __restrict__ dPhi, uint32_t* __restrict__ tick) {
-    if (tick && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *tick += 1u;
+struct FeatArgs {
+    int N, Mz, L, D, B, jchunk;
+    const double *X, *Zy, *raw_ell, *raw_var;
+    const float *omega, *beta;
+    float *Phi, *dPhi;
+};
+
+__device__ __forceinline__ void features_body(const FeatArgs& a, int bx, int by, int bz) {
     // one lane per (latent, basis): its frequency row stays in registers while it sweeps `jchunk` points;
     // the points are uniform across the workgroup (scalar loads), the stores are coalesced along b
-    const int b = blockIdx.x * kBlock + threadIdx.x;
-    const int l = blockIdx.z % L, p = blockIdx.z / L;
+    const int N = a.N, Mz = a.Mz, L = a.L, D = a.D, B = a.B;
+    const double *X = a.X, *Zy = a.Zy;
+    const float *omega = a.omega, *beta = a.beta;
+    float *Phi = a.Phi, *dPhi = a.dPhi;
+    const int b = bx * kBlock + threadIdx.x;
+    const int l = bz % L, p = bz / L;
     const int J = N + Mz;
     const size_t pl = (size_t)p * L + l;
     if (b >= B) return;
-    const float ell = softplus_f((float)raw_ell[pl]);
-    const float var = (float)kVarFloor + softplus_f((float)raw_var[pl]);
+    const float ell = softplus_f((float)a.raw_ell[pl]);
+    const float var = (float)kVarFloor + softplus_f((float)a.raw_var[pl]);
     const float inv_ell = 1.0f / ell, c = __builtin_amdgcn_sqrtf(2.0f * var / (float)B);
     float om[VGPMP_MAX_DOF];
 #pragma unroll
     for (int d = 0; d < VGPMP_MAX_DOF; ++d) om[d] = d < D ? omega[(pl * B + b) * D + d] : 0.f;
     const float bt = beta[pl * B + b];
-    const int j0 = blockIdx.y * jchunk, j1 = min(J, j0 + jchunk);
+    const int j0 = by * a.jchunk, j1 = min(J, j0 + a.jchunk);
     for (int j = j0; j < j1; ++j) {
         const double* pt = j < N ? X + (size_t)j * D : Zy + (size_t)(j - N) * D;
         float proj = 0.f;
@@ -520,6 +538,8 @@ __global__ __launch_bounds__(kBlock) void features_kernel(int N, int Mz, int L, 
     }
 }
 
+__global__ __launch_bounds__(kBlock) void features_kernel(FeatArgs a) { features_body(a, blockIdx.x, blockIdx.y, blockIdx.z); }
+
 // =================================================================================================
 // Prior draws  F0[s, l, j] = sum_b w[s, l, b] Phi[l, j, b]   (and H with dPhi) on the f32 MFMA pipe.
 // v_mfma_f32_16x16x4_f32: lane -> A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15];
@@ -528,18 +548,25 @@ __global__ __launch_bounds__(kBlock) void features_kernel(int N, int Mz, int L, 
 typedef float vg_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kNT = 3;     // 16-column tiles per wave
 
-__global__ __launch_bounds__(kBlock) void prior_gemm_kernel(int S, int L, int J, int B, int SK, int nsel,
-                                                             const float* __restrict__ W,
-                                                             const float* __restrict__ Phi,
-                                                             const float* __restrict__ dPhi, float* __restrict__ F0,
-                                                             float* __restrict__ H, size_t slab) {
+struct GemmArgs {
+    int S, L, J, B, SK, nsel;
+    const float *W, *Phi, *dPhi;
+    float *F0, *H;
+    size_t slab;
+};
+
+__device__ __forceinline__ void prior_gemm_body(const GemmArgs& a, int bx, int by, int bz) {
+    const int S = a.S, L = a.L, J = a.J, B = a.B, SK = a.SK, nsel = a.nsel;
+    const float *W = a.W, *Phi = a.Phi, *dPhi = a.dPhi;
+    float *F0 = a.F0, *H = a.H;
+    const size_t slab = a.slab;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int z = blockIdx.z;
+    int z = bz;
     const int sel = z % nsel; z /= nsel;
     const int sk = z % SK; z /= SK;
     const int l = z % L, p = z / L;
-    const int s0 = (blockIdx.y * 4 + wave) * 16;
-    const int j0 = blockIdx.x * (16 * kNT);
+    const int s0 = (by * 4 + wave) * 16;
+    const int j0 = bx * (16 * kNT);
     if (s0 >= S) return;
     const float* Bm = sel == 0 ? Phi : dPhi;
     float* Out = (sel == 0 ? F0 : H) + (size_t)sk * slab;
@@ -589,6 +616,8 @@ __global__ __launch_bounds__(kBlock) void prior_gemm_kernel(int S, int L, int J,
         }
     }
 }
+
+__global__ __launch_bounds__(kBlock) void prior_gemm_kernel(GemmArgs a) { prior_gemm_body(a, blockIdx.x, blockIdx.y, blockIdx.z); }
 
 // LDS-tiled variant for large batches (no split-K): a workgroup owns 64 samples x 144 columns, stages
 // 32-deep K slices of W and Phi through double-buffered LDS (global -> registers -> LDS, next slice in
@@ -697,6 +726,7 @@ struct PathArgs {
     float *R, *f;
     const float* G;
     float* part;
+    uint32_t* tick;          // device step counter, incremented by the reverse pass of a training step (or null)
     int want_dell;
     int stop;
 };
@@ -718,9 +748,8 @@ __device__ __forceinline__ float read_slabs(const float* base, size_t off, size_
 // launches are latency bound: every dependent global access costs ~0.3-0.7 us), then the loops run
 // out of LDS.  Code is kept rolled: cold instruction fetch is the other fixed cost of tiny launches.
 template <int SK, int SC>
-__global__ __launch_bounds__(kBlock) void paths_fwd_kernel(PathArgs a) {
-    extern __shared__ float smf[];
-    const int ch = blockIdx.x, l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
+__device__ __forceinline__ void paths_fwd_body(const PathArgs& a, float* smf, int ch, int l, int p) {
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int S = a.S, N = a.N, Mz = a.Mz, L = a.L, J = N + Mz, ld = Mz + 1;
     const float iMz = 1.0f / (float)Mz, iN = 1.0f / (float)N, iJ = 1.0f / (float)J;
     const size_t pl = (size_t)p * L + l;
@@ -761,6 +790,12 @@ __global__ __launch_bounds__(kBlock) void paths_fwd_kernel(PathArgs a) {
     }
 }
 
+template <int SK, int SC>
+__global__ __launch_bounds__(kBlock) void paths_fwd_kernel(PathArgs a) {
+    extern __shared__ float smf[];
+    paths_fwd_body<SK, SC>(a, smf, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
 // Reverse of the path assembly over one chunk of samples.  With G = dloss/df:
 //   dR = G A,  dm = sum_s dR,  dC = dR^T eps                     (-> q_mu, q_sqrt)
 //   hyper-parameters by dot products with the forward-mode tangents of the covariance kernels:
@@ -771,6 +806,9 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_kernel(PathArgs a) {
     extern __shared__ float smf[];
     __shared__ float red[3][kBlock / VG_WAVE];
     const int ch = blockIdx.x, l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
+    // no kernel that reads the counter runs next to this one: the noise kernels before it see the old value,
+    // hyper_kernel and the noise kernels after it the new one
+    if (a.tick && ch == 0 && l == 0 && p == 0 && tid == 0) *a.tick += 1u;
     const int S = a.S, N = a.N, Mz = a.Mz, L = a.L, J = N + Mz;
     const float iMz = 1.0f / (float)Mz, iN = 1.0f / (float)N, iJ = 1.0f / (float)J;
     const size_t pl = (size_t)p * L + l;
@@ -881,7 +919,7 @@ struct FinalArgs {
     double *g_qmu, *g_qsqrt, *g_ell, *g_var;
     int do_adam, trainable, want_dell;
     double lr_t, lr;
-    const uint32_t* ctr;      // device step counter (1-based Adam step after the tick) or null
+    const uint32_t* ctr;      // device step counter (already ticked: 1-based Adam step) or null
     double* lr_dev;           // [P] step size handed from hyper_kernel to final_kernel
     double *mq_mu, *mq_sqrt, *m_ell, *m_var;      // Adam moments
     double *vq_mu, *vq_sqrt, *v_ell, *v_var;
@@ -922,7 +960,7 @@ __global__ __launch_bounds__(64) void hyper_kernel(FinalArgs b) {
     const int Mz = b.M + 2, L = b.L;
     double lr_t = b.lr_t;
     if (b.do_adam && b.ctr) {
-        const double t = (double)*b.ctr;
+        const double t = (double)*b.ctr;               // ticked by paths_bwd_kernel: 1-based count of this update
         lr_t = b.lr * sqrt(1.0 - exp(t * -0.05129329438755058)) / (1.0 - exp(t * -0.2231435513142098));
     }
     if (l == 0) b.lr_dev[p] = lr_t;
@@ -944,10 +982,9 @@ __global__ __launch_bounds__(64) void hyper_kernel(FinalArgs b) {
     }
 }
 
-__global__ __launch_bounds__(kBlock) void final_kernel(FinalArgs b) {
-    extern __shared__ double sm[];
+__device__ __forceinline__ void final_body(const FinalArgs& b, double* sm, int l, int p) {
     VG_STOP(b, 7);
-    const int l = blockIdx.x, p = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int M = b.M, Mz = M + 2, L = b.L;
     const float iM = 1.0f / (float)M;
     const size_t pl = (size_t)p * L + l;
@@ -1016,6 +1053,11 @@ __global__ __launch_bounds__(kBlock) void final_kernel(FinalArgs b) {
     }
 }
 
+__global__ __launch_bounds__(kBlock) void final_kernel(FinalArgs b) {
+    extern __shared__ double sm[];
+    final_body(b, sm, blockIdx.x, blockIdx.y);
+}
+
 // forward-only epilogue: ELBO pieces without the reverse pass
 __global__ void elbo_pieces_kernel(int L, int nblk, const float* __restrict__ lik_partial,
                                    const double* __restrict__ kl_l, double lik_scale, double kls,
@@ -1041,6 +1083,75 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(size_t n, double* __restri
         if (e % tril_M > e / tril_M) return;
     }
     adam_update(x + i, m + i, v + i, g[i], lr_t);
+}
+
+// =================================================================================================
+// Role-dispatched launches for the few-problem regime.  One problem offers ~100 workgroups per kernel
+// on a 256-CU part and every launch pays ~3 us of dispatch plus a cold instruction fetch, while
+// overlapping kernels across HIP streams costs ~11 us per cross-stream edge on this platform (measured,
+// tools/anyorder_probe.hip; hipExtAnyOrderLaunch is not honoured on gfx9).  So independent kernels of one
+// dependency level are issued as ONE launch whose workgroup index selects the role:
+//   stage 1   cov_a(t) | final(t-1) | eps(t) | features(t)     <- after hyper(t-1)
+//   stage 2   cov_b(t) | prior GEMM(t)
+//   stage 3   paths_fwd(t) | omega, beta, w of step t+1
+// then loglik, paths_bwd and hyper as before.  Long roles come first in the grid so that they start first.
+// =================================================================================================
+struct Stage1Args {
+    CovArgs cov; FinalArgs fin; RngArgs rng; FeatArgs feat;
+    int n_cov, n_fin, n_eps, eps_gx, feat_gx, feat_gy;
+};
+__global__ __launch_bounds__(kBlock) void stage1_kernel(Stage1Args a) {
+    extern __shared__ double sm[];
+    int b = blockIdx.x;
+    if (b < a.n_cov) { cov_a_body(a.cov, sm, b % a.cov.L, b / a.cov.L); return; }
+    b -= a.n_cov;
+    if (b < a.n_fin) { final_body(a.fin, sm, b % a.fin.L, b / a.fin.L); return; }
+    b -= a.n_fin;
+    if (b < a.n_eps) { rng_normals_body(a.rng, b % a.eps_gx, b / a.eps_gx, 0u, a.rng.nE); return; }
+    b -= a.n_eps;
+    const int bx = b % a.feat_gx;
+    b /= a.feat_gx;
+    features_body(a.feat, bx, b % a.feat_gy, b / a.feat_gy);
+}
+
+struct Stage2Args {
+    CovArgs cov; GemmArgs gemm;
+    int n_cov, cov_roles, gemm_gx, gemm_gy;
+};
+template <bool TANGENTS>
+__global__ __launch_bounds__(kBlock) void stage2_kernel(Stage2Args a) {
+    extern __shared__ double sm[];
+    int b = blockIdx.x;
+    if (b < a.n_cov) {
+        const int role = b % a.cov_roles;
+        b /= a.cov_roles;
+        cov_b_body<TANGENTS>(a.cov, sm, role, b % a.cov.L, b / a.cov.L);
+        return;
+    }
+    b -= a.n_cov;
+    const int bx = b % a.gemm_gx;
+    b /= a.gemm_gx;
+    prior_gemm_body(a.gemm, bx, b % a.gemm_gy, b / a.gemm_gy);
+}
+
+struct Stage3Args {
+    PathArgs path; RngArgs rng;
+    int n_path, n_basis, basis_gx, w_gx;
+};
+template <int SK>
+__global__ __launch_bounds__(kBlock) void stage3_kernel(Stage3Args a) {
+    extern __shared__ float smf[];
+    int b = blockIdx.x;
+    if (b < a.n_path) {
+        const int ch = b % a.path.NC;
+        b /= a.path.NC;
+        paths_fwd_body<SK, 8>(a.path, smf, ch, b % a.path.L, b / a.path.L);
+        return;
+    }
+    b -= a.n_path;
+    if (b < a.n_basis) { rng_basis_body(a.rng, b % a.basis_gx, b / a.basis_gx); return; }
+    b -= a.n_basis;
+    rng_normals_body(a.rng, b % a.w_gx, b / a.w_gx, a.rng.nW, 0u);
 }
 
 template <typename T>
@@ -1122,20 +1233,26 @@ int vg_workspace_lookup(const vgpmp_dims* d, const vg_workspace* ws, const char*
     return 0;
 }
 
+static RngArgs make_rng_args(const vgpmp_dims* d, const vgpmp_noise* nz, uint32_t seed, uint32_t problem_base,
+                             uint32_t step, const uint32_t* ctr, uint32_t bias) {
+    RngArgs r;
+    r.L = d->L; r.B = d->B; r.D = d->L;
+    r.nW = (uint32_t)d->S * d->L * d->B;                 // nW % 4 == 0 since B % 16 == 0
+    r.nE = (uint32_t)d->S * vg_mz(d) * d->L;
+    r.wOff = (uint32_t)d->sample_offset * d->L * d->B;
+    r.eOff = (uint32_t)d->sample_offset * vg_mz(d) * d->L;
+    r.omega = nz->omega; r.beta = nz->beta; r.w = nz->w; r.eps = nz->eps; r.eps2 = nz->eps2;
+    r.seed = seed; r.problem_base = problem_base; r.step = step; r.bias = bias; r.ctr = ctr;
+    return r;
+}
+
 int vg_launch_rng(const vgpmp_dims* d, const vgpmp_noise* nz, uint32_t seed, uint32_t problem_base, uint32_t step,
-                  const uint32_t* ctr, hipStream_t st, int parts) {
-    const int P = d->num_problems, L = d->L, B = d->B, D = d->L, Mz = vg_mz(d);
-    if (parts & VG_RNG_PRIOR)
-        hipLaunchKernelGGL(rng_basis_kernel, dim3((L * B + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, L, B, D,
-                           nz->omega, nz->beta, seed, problem_base, step, ctr);
-    // nW % 4 == 0 since B % 16 == 0
-    const uint32_t nW = (parts & VG_RNG_PRIOR) ? (uint32_t)d->S * L * B : 0u;
-    const uint32_t nE = (parts & VG_RNG_EPS) ? (uint32_t)d->S * Mz * L : 0u;
-    const uint32_t wOff = (uint32_t)d->sample_offset * L * B, eOff = (uint32_t)d->sample_offset * Mz * L;
-    const uint32_t nthr = (nW >> 2) + 2 * nE;
-    if (nthr == 0) return (int)hipGetLastError();
-    hipLaunchKernelGGL(rng_normals_kernel, dim3((nthr + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, nW, nE, wOff, eOff,
-                       nz->w, nz->eps, nz->eps2, seed, problem_base, step, ctr);
+                  const uint32_t* ctr, hipStream_t st) {
+    const int P = d->num_problems;
+    RngArgs r = make_rng_args(d, nz, seed, problem_base, step, ctr, 0u);
+    hipLaunchKernelGGL(rng_basis_kernel, dim3((r.L * r.B + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
+    const uint32_t nthr = (r.nW >> 2) + 2 * r.nE;
+    hipLaunchKernelGGL(rng_normals_kernel, dim3((nthr + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
     return (int)hipGetLastError();
 }
 
@@ -1175,110 +1292,45 @@ static int set_dyn_lds(const void* fn, size_t bytes) {
     return 0;
 }
 
-// One step of the training loop as a dependency graph over up to three streams:
-//
-//   stream A (side_stream)    cov_a(theta) ................ cov_b(theta, q_mu, q_sqrt) --+
-//   stream C (side_stream2)   [eps] features(theta) -> prior GEMM ---------------------+-+-> [next: omega, beta, w]
-//   main                                                                               v v
-//                                            paths_fwd -> loglik -> paths_bwd -> hyper -> final
-//                                                                                  |        |
-//                       theta(t+1) ready: A and C of step t+1 start here ----------+        +---- q(t+1) ready: cov_b of t+1
-//
-// Within one call of several steps (VG_CHAIN_*) the hand-over to the next step happens at those two
-// events instead of at the end of the step, so cov_a / features / GEMM of step t+1 overlap `final`
-// of step t; the prior noise of step t+1 is drawn right after the GEMM of step t has consumed the old
-// one.  Every counter access (noise key, Adam step) is ordered: the feature kernel ticks the counter on
-// stream C, the noise kernels read it on stream C, hyper_kernel reads it between the join and the
-// hand-over event.  With one stream (or under the per-stage profiler) the same kernels run in sequence.
-int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sdf, const vgpmp_problem* pb,
-                 const vgpmp_params* params, const vgpmp_params* am, const vgpmp_params* av, const vgpmp_noise* nz,
-                 const vgpmp_outputs* out, const vg_workspace* ws, int what, int trainable, double lr, int adam_t,
-                 uint32_t seed, uint32_t problem_base, uint32_t step, hipStream_t st, hipEvent_t* ev, int chain) {
+// `num_steps` consecutive steps.  Few problems (and not under the per-stage profiler): the role-dispatched
+// stage launches above, with the variational-parameter update of step t riding in stage 1 of step t+1.
+// Many problems: every kernel fills the chip by itself, plain launches in sequence.
+int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sdf, const vgpmp_problem* pb,
+                  const vgpmp_params* params, const vgpmp_params* am, const vgpmp_params* av, const vgpmp_noise* nz,
+                  const vgpmp_outputs* out, const vg_workspace* ws, int what, int trainable, double lr, int adam_t,
+                  uint32_t seed, uint32_t problem_base, uint32_t step, int num_steps, hipStream_t st, hipEvent_t* ev) {
     const int P = d->num_problems, S = d->S, N = d->N, M = d->M, L = d->L, B = d->B, Mz = M + 2, J = N + Mz;
     const int SK = d->split_k, NC = vg_chunks(d), SC = vg_sc(d);
-    const bool backward = (what & VGPMP_DO_BACKWARD) != 0;
+    const bool backward = (what & VGPMP_DO_BACKWARD) != 0, do_adam = (what & VGPMP_DO_ADAM) != 0;
+    const bool gen = (what & VGPMP_GEN_NOISE) != 0;
     const bool want_dell = backward && (trainable & VGPMP_TRAIN_LENGTHSCALES);
+    const bool tiled_gemm = SK == 1 && (B % kTK) == 0;      // split_k == 1 is chosen by the host for large batches
+    const bool fused = !ev && !(what & VGPMP_NO_FUSE) && !tiled_gemm && SC == 8 && P * L <= kFuseMaxPL;
+    if (num_steps > 1 && !(backward && do_adam && gen)) return VGPMP_E_ARG;
     int evi = 0;
     auto mark = [&]() { if (ev) (void)hipEventRecord(ev[evi++], st); };
     uint32_t* ctr = pb->step_counter;
     int rc;
-    const bool fork = !ev && pb->side_stream && pb->fork_event && pb->join_event;
-    const bool fork2 = fork && pb->side_stream2 && pb->join_event2;
-    const bool pipelined = fork2 && pb->hyper_event && pb->rest_event && backward && (what & VGPMP_DO_ADAM) &&
-                           (what & VGPMP_GEN_NOISE);
-    const bool chained = pipelined && (chain & VG_CHAIN_PREV);
-    const bool feeds_next = pipelined && (chain & VG_CHAIN_NEXT);
-    hipStream_t cst = fork ? (hipStream_t)pb->side_stream : st;         // stream A
-    hipStream_t pst = fork2 ? (hipStream_t)pb->side_stream2 : st;       // stream C
-    // ---- covariance path (float64)
+    // ---- argument blocks ----------------------------------------------------------------------
     CovArgs ca;
     ca.N = N; ca.M = M; ca.L = L; ca.D = L;
     ca.X = pb->X; ca.Zy = pb->Zy; ca.y_u = pb->y_u; ca.jitter = pb->jitter;
     ca.q_mu = params->q_mu; ca.q_sqrt = params->q_sqrt; ca.raw_ell = params->raw_ell; ca.raw_var = params->raw_var;
     ca.want_dell = want_dell ? 1 : 0;
     ca.stop = -1;
-#ifdef VGPMP_BISECT
-    ca.stop = vg_bisect_stop("VGPMP_STOP_COV");
-#endif
     ca.ws = *ws;
-    const int Mp = (Mz + 15) & ~15;
-    const size_t lds_cov = ((size_t)6 * Mp * (Mp + 1) + 5 * Mp) * sizeof(double);
-    const size_t lds_cov_a = ((size_t)4 * Mp * (Mp + 1) + 2 * Mp) * sizeof(double);
-    const size_t lds_rows = ((size_t)2 * Mz * (Mz + 1) + (size_t)4 * kRowTile * Mz + Mz) * sizeof(double);
-    mark();
-    if (fork) {
-        if (chained) {
-            VG_CHECK_HIP(hipStreamWaitEvent(cst, (hipEvent_t)pb->hyper_event, 0));
-            VG_CHECK_HIP(hipStreamWaitEvent(pst, (hipEvent_t)pb->hyper_event, 0));
-        } else {
-            VG_CHECK_HIP(hipEventRecord((hipEvent_t)pb->fork_event, st));
-            VG_CHECK_HIP(hipStreamWaitEvent(cst, (hipEvent_t)pb->fork_event, 0));
-            if (fork2) VG_CHECK_HIP(hipStreamWaitEvent(pst, (hipEvent_t)pb->fork_event, 0));
-        }
-    }
-    {
-        rc = set_dyn_lds((const void*)cov_a_kernel, lds_cov_a);
-        if (rc) return rc;
-        hipLaunchKernelGGL(cov_a_kernel, dim3(L, P), dim3(kCovThreads), lds_cov_a, cst, ca);
-        if (chained) VG_CHECK_HIP(hipStreamWaitEvent(cst, (hipEvent_t)pb->rest_event, 0));
-        const void* fn = backward ? (const void*)cov_b_kernel<true> : (const void*)cov_b_kernel<false>;
-        const size_t lds_b = lds_cov > lds_rows ? lds_cov : lds_rows;
-        rc = set_dyn_lds(fn, lds_b);
-        if (rc) return rc;
-        void* kargs[] = {(void*)&ca};
-        VG_CHECK_HIP(hipLaunchKernel(fn, dim3(3 + (N + kRowTile - 1) / kRowTile, L, P), dim3(kCovThreads), kargs, lds_b, cst));
-    }
-    if (fork) VG_CHECK_HIP(hipEventRecord((hipEvent_t)pb->join_event, cst));
-    mark();
-    if (what & VGPMP_GEN_NOISE) {       // a chained step finds omega / beta / w drawn by its predecessor
-        rc = vg_launch_rng(d, nz, seed, problem_base, step, ctr, pst, chained ? VG_RNG_EPS : (VG_RNG_PRIOR | VG_RNG_EPS));
-        if (rc) return rc;
-    }
-    mark();
-    // ---- features and prior GEMM
-    // few problems: one point per workgroup (more parallelism); many: sweep 16 points per lane (omega reuse)
-    const int jchunk = P * L >= 64 ? 16 : 1;
-    hipLaunchKernelGGL(features_kernel, dim3((B + kBlock - 1) / kBlock, (J + jchunk - 1) / jchunk, P * L), dim3(kBlock), 0,
-                       pst, N, Mz, L, L, B, jchunk, pb->X, pb->Zy, params->raw_ell, params->raw_var, nz->omega, nz->beta, ws->Phi,
-                       want_dell ? ws->dPhi : (float*)nullptr, (what & VGPMP_DO_ADAM) ? ctr : (uint32_t*)nullptr);
-    mark();
+    FeatArgs fe;
+    fe.N = N; fe.Mz = Mz; fe.L = L; fe.D = L; fe.B = B;
+    // few problems: few points per workgroup (more parallelism); many: sweep 16 points per lane (omega reuse)
+    fe.jchunk = fused ? 4 : (P * L >= 64 ? 16 : 1);
+    fe.X = pb->X; fe.Zy = pb->Zy; fe.raw_ell = params->raw_ell; fe.raw_var = params->raw_var;
+    fe.omega = nz->omega; fe.beta = nz->beta; fe.Phi = ws->Phi; fe.dPhi = want_dell ? ws->dPhi : nullptr;
+    const dim3 feat_grid((B + kBlock - 1) / kBlock, (J + fe.jchunk - 1) / fe.jchunk, P * L);
     const size_t slab = (size_t)P * S * L * J;
-    const int nsel = want_dell ? 2 : 1;
-    if (SK == 1 && (B % kTK) == 0)      // large batch: LDS-tiled kernel (split_k == 1 is chosen by the host for P*L > 256)
-        hipLaunchKernelGGL(prior_gemm_tiled_kernel, dim3((J + kTJ - 1) / kTJ, (S + kTS - 1) / kTS, P * L * nsel), dim3(kBlock),
-                           0, pst, S, L, J, B, nsel, nz->w, ws->Phi, ws->dPhi, ws->F0, ws->H);
-    else
-        hipLaunchKernelGGL(prior_gemm_kernel, dim3((J + 16 * kNT - 1) / (16 * kNT), (S + 63) / 64, P * L * SK * nsel),
-                           dim3(kBlock), 0, pst, S, L, J, B, SK, nsel, nz->w, ws->Phi, ws->dPhi, ws->F0, ws->H, slab);
-    mark();
-    if (fork2) VG_CHECK_HIP(hipEventRecord((hipEvent_t)pb->join_event2, pst));
-    if (feeds_next) {                   // prior noise of the next step (the counter has ticked: key = step + 1)
-        rc = vg_launch_rng(d, nz, seed, problem_base, step + 1u, ctr, pst, VG_RNG_PRIOR);
-        if (rc) return rc;
-    }
-    if (fork) VG_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)pb->join_event, 0));
-    if (fork2) VG_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)pb->join_event2, 0));
-    // ---- path assembly
+    GemmArgs ga;
+    ga.S = S; ga.L = L; ga.J = J; ga.B = B; ga.SK = SK; ga.nsel = want_dell ? 2 : 1;
+    ga.W = nz->w; ga.Phi = ws->Phi; ga.dPhi = ws->dPhi; ga.F0 = ws->F0; ga.H = ws->H; ga.slab = slab;
+    const dim3 gemm_grid((J + 16 * kNT - 1) / (16 * kNT), (S + 63) / 64, P * L * SK * ga.nsel);
     PathArgs pa;
     pa.S = S; pa.N = N; pa.Mz = Mz; pa.L = L; pa.SK = SK; pa.NC = NC; pa.slab = slab; pa.part_len = vg_part_len(d);
     pa.sqrt_jitter = (float)sqrt(pb->jitter);
@@ -1286,56 +1338,18 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
     pa.C = ws->C; pa.CT_ell = ws->CT_ell; pa.CT_var = ws->CT_var; pa.m = ws->m;
     pa.F0 = ws->F0; pa.H = ws->H; pa.want_dell = want_dell ? 1 : 0;
     pa.eps = nz->eps; pa.eps2 = nz->eps2; pa.R = ws->R; pa.f = out->f; pa.G = ws->G; pa.part = ws->part;
+    pa.tick = do_adam ? ctr : nullptr;
     pa.stop = -1;
-#ifdef VGPMP_BISECT
-    pa.stop = vg_bisect_stop("VGPMP_STOP_PATHS");
-#endif
-    const size_t lds_pf = ((size_t)Mz * (Mz + 1) + (size_t)Mz * N + (size_t)3 * SC * Mz + (size_t)SC * J) * sizeof(float);
-    {
-        const void* fn = SC == 32 ? (const void*)paths_fwd_kernel<1, 32>
-                       : SK == 1 ? (const void*)paths_fwd_kernel<1, 8> : SK == 2 ? (const void*)paths_fwd_kernel<2, 8>
-                       : SK == 4 ? (const void*)paths_fwd_kernel<4, 8> : (const void*)paths_fwd_kernel<8, 8>;
-        rc = set_dyn_lds(fn, lds_pf);
-        if (rc) return rc;
-        void* kargs[] = {(void*)&pa};
-        VG_CHECK_HIP(hipLaunchKernel(fn, dim3(NC, L, P), dim3(kBlock), kargs, lds_pf, st));
-    }
-    mark();
-    // ---- likelihood forward + reverse (fk_sdf.hip)
     const double lik_scale = pb->alpha / (double)d->S_total;
-    int nblk = 0;
-    rc = vg_launch_loglik_paths(rb, sdf, out->f, P, S, L, N, (float)(-lik_scale), ws->G, out->logp, ws->lik_partial,
-                                &nblk, st);
-    if (rc) return rc;
-    mark();
-    if (!backward) {
-        hipLaunchKernelGGL(elbo_pieces_kernel, dim3(P), dim3(64), 0, st, L, nblk, ws->lik_partial, ws->kl_l, lik_scale,
-                           pb->kl_scale, out->lik, out->kl);
-        return (int)hipGetLastError();
-    }
-    // ---- reverse of the path assembly, then gradient assembly (+ Adam)
-    const size_t lds_pb = ((size_t)4 * N * Mz + (size_t)2 * Mz * Mz + (size_t)SC * N + (size_t)2 * SC * J +
-                           (size_t)3 * SC * Mz) * sizeof(float);
-    {
-        const void* fn = SC == 32 ? (const void*)paths_bwd_kernel<1, 32>
-                       : SK == 1 ? (const void*)paths_bwd_kernel<1, 8> : SK == 2 ? (const void*)paths_bwd_kernel<2, 8>
-                       : SK == 4 ? (const void*)paths_bwd_kernel<4, 8> : (const void*)paths_bwd_kernel<8, 8>;
-        rc = set_dyn_lds(fn, lds_pb);
-        if (rc) return rc;
-        void* kargs[] = {(void*)&pa};
-        VG_CHECK_HIP(hipLaunchKernel(fn, dim3(NC, L, P), dim3(kBlock), kargs, lds_pb, st));
-    }
-    mark();
     FinalArgs fa;
-    fa.M = M; fa.L = L; fa.NC = NC; fa.nblk = nblk; fa.part_len = vg_part_len(d);
+    fa.M = M; fa.L = L; fa.NC = NC; fa.nblk = P ? vg_loglik_blocks_per_problem(S, N) : 0; fa.part_len = vg_part_len(d);
     fa.part = ws->part; fa.Lk32 = ws->Lk32; fa.lik_partial = ws->lik_partial;
     fa.gkl_qmu = ws->gkl_qmu; fa.gkl_Q = ws->gkl_Q; fa.gkl_ell = ws->gkl_ell; fa.gkl_var = ws->gkl_var;
     fa.kl_l = ws->kl_l; fa.var = ws->var; fa.sig_ell = ws->sig_ell; fa.sig_var = ws->sig_var;
     fa.kl_scale = pb->kl_scale; fa.lik_scale = lik_scale; fa.out_lik = out->lik; fa.out_kl = out->kl;
     fa.g_qmu = out->grad.q_mu; fa.g_qsqrt = out->grad.q_sqrt; fa.g_ell = out->grad.raw_ell; fa.g_var = out->grad.raw_var;
-    fa.do_adam = (what & VGPMP_DO_ADAM) ? 1 : 0; fa.trainable = trainable; fa.want_dell = want_dell ? 1 : 0;
-    fa.lr_t = fa.do_adam ? adam_lr_t(lr, adam_t > 0 ? adam_t : 1) : 0.0;
-    fa.lr = lr; fa.ctr = ctr; fa.lr_dev = ws->lr_t;
+    fa.do_adam = do_adam ? 1 : 0; fa.trainable = trainable; fa.want_dell = want_dell ? 1 : 0;
+    fa.lr_t = 0.0; fa.lr = lr; fa.ctr = ctr; fa.lr_dev = ws->lr_t;
     fa.mq_mu = am ? am->q_mu : nullptr; fa.mq_sqrt = am ? am->q_sqrt : nullptr;
     fa.m_ell = am ? am->raw_ell : nullptr; fa.m_var = am ? am->raw_var : nullptr;
     fa.vq_mu = av ? av->q_mu : nullptr; fa.vq_sqrt = av ? av->q_sqrt : nullptr;
@@ -1343,15 +1357,120 @@ int vg_elbo_step(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sd
     fa.pq_mu = params->q_mu; fa.pq_sqrt = params->q_sqrt; fa.p_ell = params->raw_ell; fa.p_var = params->raw_var;
     fa.stop = -1;
 #ifdef VGPMP_BISECT
+    ca.stop = vg_bisect_stop("VGPMP_STOP_COV");
+    pa.stop = vg_bisect_stop("VGPMP_STOP_PATHS");
     fa.stop = vg_bisect_stop("VGPMP_STOP_FINAL");
 #endif
+    // ---- dynamic LDS sizes and kernel variants --------------------------------------------------
+    const int Mp = (Mz + 15) & ~15;
+    const size_t lds_cov = ((size_t)6 * Mp * (Mp + 1) + 5 * Mp) * sizeof(double);
+    const size_t lds_cov_a = ((size_t)4 * Mp * (Mp + 1) + 2 * Mp) * sizeof(double);
+    const size_t lds_rows = ((size_t)2 * Mz * (Mz + 1) + (size_t)4 * kRowTile * Mz + Mz) * sizeof(double);
+    const size_t lds_cov_b = lds_cov > lds_rows ? lds_cov : lds_rows;
+    const size_t lds_pf = ((size_t)Mz * (Mz + 1) + (size_t)Mz * N + (size_t)3 * SC * Mz + (size_t)SC * J) * sizeof(float);
+    const size_t lds_pb = ((size_t)4 * N * Mz + (size_t)2 * Mz * Mz + (size_t)SC * N + (size_t)2 * SC * J +
+                           (size_t)3 * SC * Mz) * sizeof(float);
     const size_t lds_fin = ((size_t)Mz * Mz + Mz) * sizeof(double) + (size_t)Mz * Mz * sizeof(float);
-    rc = set_dyn_lds((const void*)final_kernel, lds_fin);
-    if (rc) return rc;
-    hipLaunchKernelGGL(hyper_kernel, dim3(P), dim3(64), 0, st, fa);
-    if (feeds_next) VG_CHECK_HIP(hipEventRecord((hipEvent_t)pb->hyper_event, st));
-    hipLaunchKernelGGL(final_kernel, dim3(L, P), dim3(kBlock), lds_fin, st, fa);
-    if (feeds_next) VG_CHECK_HIP(hipEventRecord((hipEvent_t)pb->rest_event, st));
-    mark();
+    const size_t lds_s1 = lds_cov_a > lds_fin ? lds_cov_a : lds_fin;
+    const void* fn_cov_b = backward ? (const void*)cov_b_kernel<true> : (const void*)cov_b_kernel<false>;
+    const void* fn_s2 = backward ? (const void*)stage2_kernel<true> : (const void*)stage2_kernel<false>;
+    const void* fn_pf = SC == 32 ? (const void*)paths_fwd_kernel<1, 32>
+                      : SK == 1 ? (const void*)paths_fwd_kernel<1, 8> : SK == 2 ? (const void*)paths_fwd_kernel<2, 8>
+                      : SK == 4 ? (const void*)paths_fwd_kernel<4, 8> : (const void*)paths_fwd_kernel<8, 8>;
+    const void* fn_s3 = SK == 1 ? (const void*)stage3_kernel<1> : SK == 2 ? (const void*)stage3_kernel<2>
+                      : SK == 4 ? (const void*)stage3_kernel<4> : (const void*)stage3_kernel<8>;
+    const void* fn_pb = SC == 32 ? (const void*)paths_bwd_kernel<1, 32>
+                      : SK == 1 ? (const void*)paths_bwd_kernel<1, 8> : SK == 2 ? (const void*)paths_bwd_kernel<2, 8>
+                      : SK == 4 ? (const void*)paths_bwd_kernel<4, 8> : (const void*)paths_bwd_kernel<8, 8>;
+    if ((rc = set_dyn_lds(fn_pb, lds_pb))) return rc;
+    if (fused) {
+        if ((rc = set_dyn_lds((const void*)stage1_kernel, lds_s1))) return rc;
+        if ((rc = set_dyn_lds(fn_s2, lds_cov_b))) return rc;
+        if ((rc = set_dyn_lds(fn_s3, lds_pf))) return rc;
+    } else {
+        if ((rc = set_dyn_lds((const void*)cov_a_kernel, lds_cov_a))) return rc;
+        if ((rc = set_dyn_lds(fn_cov_b, lds_cov_b))) return rc;
+        if ((rc = set_dyn_lds(fn_pf, lds_pf))) return rc;
+    }
+    if ((rc = set_dyn_lds((const void*)final_kernel, lds_fin))) return rc;
+    const dim3 cov_b_grid(3 + (N + kRowTile - 1) / kRowTile, L, P);
+    const uint32_t eps_gx = (2u * (uint32_t)S * Mz * L + kBlock - 1) / kBlock;
+    const uint32_t basis_gx = ((uint32_t)L * B + kBlock - 1) / kBlock;
+    const uint32_t w_gx = (((uint32_t)S * L * B >> 2) + kBlock - 1) / kBlock;
+    auto launch = [&](const void* fn, dim3 grid, void* arg, size_t lds) -> int {
+        void* kargs[] = {arg};
+        return (int)hipLaunchKernel(fn, grid, dim3(kBlock), kargs, lds, st);
+    };
+    auto launch_final = [&]() -> int { return launch((const void*)final_kernel, dim3(L, P), &fa, lds_fin); };
+
+    for (int i = 0; i < num_steps; ++i) {
+        const bool first = i == 0, more = i + 1 < num_steps;
+        const uint32_t step_i = step + (uint32_t)i;
+        if (fused) {
+            // noise of the first step of a call: everything up front; afterwards eps rides in stage 1 and the
+            // prior noise of step i was drawn by stage 3 of step i-1
+            if (gen && first && (rc = vg_launch_rng(d, nz, seed, problem_base, step_i, ctr, st))) return rc;
+            Stage1Args s1;
+            s1.cov = ca; s1.fin = fa; s1.feat = fe;
+            s1.rng = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
+            s1.n_cov = L * P;
+            s1.n_fin = first ? 0 : L * P;
+            s1.eps_gx = (int)eps_gx;
+            s1.n_eps = (gen && !first) ? (int)eps_gx * P : 0;
+            s1.feat_gx = (int)feat_grid.x; s1.feat_gy = (int)feat_grid.y;
+            const unsigned n1 = s1.n_cov + s1.n_fin + s1.n_eps + feat_grid.x * feat_grid.y * feat_grid.z;
+            if ((rc = launch((const void*)stage1_kernel, dim3(n1), &s1, lds_s1))) return rc;
+            Stage2Args s2;
+            s2.cov = ca; s2.gemm = ga;
+            s2.cov_roles = (int)cov_b_grid.x; s2.n_cov = (int)(cov_b_grid.x * cov_b_grid.y * cov_b_grid.z);
+            s2.gemm_gx = (int)gemm_grid.x; s2.gemm_gy = (int)gemm_grid.y;
+            if ((rc = launch(fn_s2, dim3(s2.n_cov + gemm_grid.x * gemm_grid.y * gemm_grid.z), &s2, lds_cov_b))) return rc;
+            Stage3Args s3;
+            s3.path = pa;
+            // the counter ticks in paths_bwd of this step: the next step's key is counter + 1 here
+            s3.rng = make_rng_args(d, nz, seed, problem_base, step_i + 1u, ctr, 1u);
+            s3.n_path = NC * L * P;
+            s3.basis_gx = (int)basis_gx; s3.w_gx = (int)w_gx;
+            s3.n_basis = (gen && more) ? (int)basis_gx * P : 0;
+            const unsigned n3 = s3.n_path + s3.n_basis + ((gen && more) ? w_gx * P : 0u);
+            if ((rc = launch(fn_s3, dim3(n3), &s3, lds_pf))) return rc;
+        } else {
+            mark();
+            hipLaunchKernelGGL(cov_a_kernel, dim3(L, P), dim3(kCovThreads), lds_cov_a, st, ca);
+            if ((rc = launch(fn_cov_b, cov_b_grid, &ca, lds_cov_b))) return rc;
+            mark();
+            if (gen && (rc = vg_launch_rng(d, nz, seed, problem_base, step_i, ctr, st))) return rc;
+            mark();
+            hipLaunchKernelGGL(features_kernel, feat_grid, dim3(kBlock), 0, st, fe);
+            mark();
+            if (tiled_gemm)
+                hipLaunchKernelGGL(prior_gemm_tiled_kernel, dim3((J + kTJ - 1) / kTJ, (S + kTS - 1) / kTS, P * L * ga.nsel),
+                                   dim3(kBlock), 0, st, S, L, J, B, ga.nsel, nz->w, ws->Phi, ws->dPhi, ws->F0, ws->H);
+            else
+                hipLaunchKernelGGL(prior_gemm_kernel, gemm_grid, dim3(kBlock), 0, st, ga);
+            mark();
+            if ((rc = launch(fn_pf, dim3(NC, L, P), &pa, lds_pf))) return rc;
+            mark();
+        }
+        // ---- likelihood forward + reverse (fk_sdf.hip)
+        int nblk = 0;
+        rc = vg_launch_loglik_paths(rb, sdf, out->f, P, S, L, N, (float)(-lik_scale), ws->G, out->logp, ws->lik_partial,
+                                    &nblk, st);
+        if (rc) return rc;
+        fa.nblk = nblk;
+        mark();
+        if (!backward) {
+            hipLaunchKernelGGL(elbo_pieces_kernel, dim3(P), dim3(64), 0, st, L, nblk, ws->lik_partial, ws->kl_l, lik_scale,
+                               pb->kl_scale, out->lik, out->kl);
+            return (int)hipGetLastError();
+        }
+        // ---- reverse of the path assembly, hyper-parameter update, then (here or in the next stage 1) the rest
+        if ((rc = launch(fn_pb, dim3(NC, L, P), &pa, lds_pb))) return rc;
+        mark();
+        fa.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
+        hipLaunchKernelGGL(hyper_kernel, dim3(P), dim3(64), 0, st, fa);
+        if (!(fused && more) && (rc = launch_final())) return rc;
+        mark();
+    }
     return (int)hipGetLastError();
 }

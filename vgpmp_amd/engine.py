@@ -184,13 +184,7 @@ class PlannerBatch:
         self.kl_scale = float(kl_scale)
         # device-resident step counter: lets a captured hipGraph of the step be replayed
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
-        # side streams + events: the float64 covariance kernels and the noise/feature/GEMM kernels run next to
-        # each other, and inside run_steps the next step starts while this one assembles its gradients
-        self._side, self._side2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-        self._events = [torch.cuda.Event() for _ in range(5)]     # fork, join, join2, hyper, rest
-        for e in self._events:
-            e.record()
-        self.overlap = True
+        self.fuse = True          # False: one launch per kernel even for small batches (measurement)
         self._graph = None
         self._graph_unroll = 0
         self._pack()
@@ -204,13 +198,10 @@ class PlannerBatch:
         self._av = self._params_struct(self.adam_v)
         self._noise = capi.Noise(capi.ptr(self.omega), capi.ptr(self.beta), capi.ptr(self.w), capi.ptr(self.eps),
                                  capi.ptr(self.eps2))
-        fork, join, join2, hyper, rest = (int(e.cuda_event) for e in self._events)
-        side = (int(self._side.cuda_stream), fork, join, int(self._side2.cuda_stream), join2, hyper, rest) \
-            if self.overlap else (None,) * 7
         self._problem = capi.Problem(capi.ptr(self.X), capi.ptr(self.Zy), capi.ptr(self.y_u), self.alpha, JITTER,
-                                     self.kl_scale, None, *side)
+                                     self.kl_scale, None)
         self._problem_ctr = capi.Problem(capi.ptr(self.X), capi.ptr(self.Zy), capi.ptr(self.y_u), self.alpha, JITTER,
-                                         self.kl_scale, capi.ptr(self.step_counter), *side)
+                                         self.kl_scale, capi.ptr(self.step_counter))
         self._out = capi.Outputs(capi.ptr(self.f), capi.ptr(self.logp), capi.ptr(self.lik), capi.ptr(self.kl),
                                  self._params_struct(self.grad))
 
@@ -226,6 +217,7 @@ class PlannerBatch:
 
     # ---- the ELBO step --------------------------------------------------------------------------
     def _run(self, what: int, step: int) -> None:
+        what |= 0 if self.fuse else capi.NO_FUSE
         capi.check(self.lib.vgpmp_elbo_step(
             C.byref(self.dims), capi.ptr(self.scene.dev_robot), C.byref(self.scene.sdf), C.byref(self._problem),
             C.byref(self._params), C.byref(self._am), C.byref(self._av), C.byref(self._noise), C.byref(self._out),
@@ -252,7 +244,7 @@ class PlannerBatch:
     # ---- hipGraph replay of the training step ----------------------------------------------------
     def _run_counter(self, num_steps: int = 1, stage_ms=None) -> None:
         """`num_steps` training steps whose noise key / Adam step count come from the device counter."""
-        what = capi.DO_FORWARD | capi.DO_BACKWARD | capi.DO_ADAM | capi.GEN_NOISE
+        what = capi.DO_FORWARD | capi.DO_BACKWARD | capi.DO_ADAM | capi.GEN_NOISE | (0 if self.fuse else capi.NO_FUSE)
         args = (C.byref(self.dims), capi.ptr(self.scene.dev_robot), C.byref(self.scene.sdf),
                 C.byref(self._problem_ctr), C.byref(self._params), C.byref(self._am), C.byref(self._av),
                 C.byref(self._noise), C.byref(self._out), capi.ptr(self.workspace), self.workspace.numel(), what,
