@@ -153,6 +153,7 @@ struct CovArgs {
     const double *q_mu, *q_sqrt, *raw_ell, *raw_var;
     int want_dell;
     int stop;
+    uint32_t* tick;          // device step counter, ticked by one row-tile workgroup of stage 2 (or null)
     vg_workspace ws;
 };
 
@@ -300,6 +301,9 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     __shared__ double red[kCovThreads / VG_WAVE];
     const int tid = threadIdx.x, nt = blockDim.x;
     if (role >= 3) {
+        // The step counter ticks where no kernel that reads it runs alongside: noise drawn before this launch
+        // saw the old value, the noise of the next step and the Adam count see the new one.
+        if (a.tick && role == 3 && l == 0 && p == 0 && tid == 0) *a.tick += 1u;
         cov_rows_body(a, sm, role - 3, l, p, tid, nt);
         return;
     }
@@ -308,21 +312,26 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     const int Mp = (Mz + 15) & ~15, ld = Mp + 1;
     const float iMz = 1.0f / (float)Mz, iM = 1.0f / (float)M;
     const size_t pl = (size_t)p * L + l;
-    double* La = sm;                 // Lk                               (all Mp x ld, zero padded)
+    double* La = sm;                 // Lk, later pad(q_sqrt) for the tangents   (all Mp x ld, zero padded)
     double* Li = La + Mp * ld;       // Lk^-1
-    double* Qp = Li + Mp * ld;       // pad(q_sqrt): Q at [2:, 2:]
-    double* Kd = Qp + Mp * ld;       // dK/dtheta
-    double* T = Kd + Mp * ld;        // scratch
-    double* W = T + Mp * ld;         // scratch
-    double* dl = W + Mp * ld;        // [Mp] q_mu - p_mu
+    double* X1 = Li + Mp * ld;       // role 0: pad(q_sqrt), Q at [2:, 2:];  tangents: dK/dtheta, then W
+    double* X2 = X1 + Mp * ld;       // tangents: scratch T
+    double* dl = X2 + Mp * ld;       // [Mp] q_mu - p_mu
     double* af = dl + Mp;            // [Mp] Lk^-1 (q_mu - p_mu)
     double* v1 = af + Mp;            // [Mp]
     double* k0 = v1 + Mp;            // [Mp] first two columns of Kuu + jI
     double* k1 = k0 + Mp;
-    for (int e = tid; e < 6 * Mp * ld + 5 * Mp; e += nt) sm[e] = 0.0;
+    double* kd0 = k1 + Mp;           // [Mp] first two columns of dK/dtheta
+    double* kd1 = kd0 + Mp;
+    double* Qp = X1;
+    double* Kd = X1;
+    double* T = X2;
+    for (int e = tid; e < 4 * Mp * ld + 7 * Mp; e += nt) sm[e] = 0.0;
     __syncthreads();
     const double jit = a.jitter, var = a.ws.var[pl];
     const double* Kg = a.ws.Ks64 + pl * Mz * Mz;
+    constexpr int kQRegs = (VGPMP_MAX_MZ - 2) * (VGPMP_MAX_MZ - 2) / kCovThreads + 1;
+    double qreg[kQRegs];
     {
         const double* Lkg = a.ws.Lk64 + pl * Mz * Mz;
         const double* Lig = a.ws.Li64 + pl * Mz * Mz;
@@ -338,9 +347,14 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
             if (role == 1) Kd[i * ld + j] = Kdg[e];
             if (role == 2) Kd[i * ld + j] = Kg[e] / var;
         }
-        for (int e = tid; e < M * M; e += nt) {
-            const int r = vg_div(e, iM), c = e - r * M;
-            if (c <= r) Qp[(r + 2) * ld + (c + 2)] = Qg[e];
+        if (role == 0) {
+            for (int e = tid; e < M * M; e += nt) {
+                const int r = vg_div(e, iM), c = e - r * M;
+                if (c <= r) Qp[(r + 2) * ld + (c + 2)] = Qg[e];
+            }
+        } else {      // tangents: this thread's share of Q waits in registers until Lk's LDS space is free
+#pragma unroll
+            for (int k = 0; k < kQRegs; ++k) qreg[k] = Qg[min(tid + k * nt, M * M - 1)];
         }
         for (int i = tid; i < Mz; i += nt) {
             k0[i] = Kg[(size_t)i * Mz + 0] + (i == 0 ? jit : 0.0);
@@ -391,25 +405,41 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
         return;
     }
     // ---- tangent wrt theta: W = Phi(Lk^-1 dK Lk^-T), dLk = Lk W, dC = dLk pad(Q)   (64-bit MFMA products)
+    // Four LDS matrices (35 KB at Mz = 32, so that these workgroups pack 4 per CU next to the prior GEMM):
+    // W overwrites dK (its first two columns are kept), dLk overwrites T, and pad(Q) -- prefetched into
+    // registers -- takes the place of Lk once Lk has been used.
+    for (int i = tid; i < Mz; i += nt) { kd0[i] = Kd[i * ld + 0]; kd1[i] = Kd[i * ld + 1]; }
     matmul_f64(MatView{Li, ld, 1}, MatView{Kd, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) { T[r * ld + c] = v; });
     __syncthreads();
+    double* W = X1;
     matmul_f64(MatView{T, ld, 1}, MatView{Li, 1, ld}, Mp, tid, nt, [&](int r, int c, double v) {
         W[r * ld + c] = c < r ? v : (c == r ? 0.5 * v : 0.0);
     });
     __syncthreads();
     matmul_f64(MatView{La, ld, 1}, MatView{W, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) { T[r * ld + c] = v; });
     __syncthreads();
+    for (int e = tid; e < Mp * ld; e += nt) La[e] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kQRegs; ++k) {
+        const int e = tid + k * nt;
+        if (e < M * M) {
+            const int r = vg_div(e, iM), c = e - r * M;
+            if (c <= r) La[(r + 2) * ld + (c + 2)] = qreg[k];
+        }
+    }
+    __syncthreads();
     float* CT = (role == 1 ? a.ws.CT_ell : a.ws.CT_var) + pl * Mz * Mz;
-    matmul_f64(MatView{T, ld, 1}, MatView{Qp, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
+    matmul_f64(MatView{T, ld, 1}, MatView{La, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
         if (r < Mz && c < Mz) CT[(size_t)c * Mz + r] = (float)v;       // stored transposed
     });
     // KL tangent: a_dot = Lk^-1 (delta_dot - dLk a),  delta_dot = -d p_mu
-    const double d00 = Kd[0], d01 = Kd[1], d11 = Kd[ld + 1];
+    const double d00 = kd0[0], d01 = kd1[0], d11 = kd1[1];
     const double e0 = d00 * c0 + d01 * c1, e1 = d01 * c0 + d11 * c1;        // dKyy c
     const double cd0 = -(k11 * e0 - k01 * e1) / det, cd1 = -(k00 * e1 - k01 * e0) / det;
     for (int i = tid; i < Mz; i += nt) {
         const double s = dot4(T + i * ld, 1, af, 1, i + 1);
-        const double pd = Kd[i * ld + 0] * c0 + Kd[i * ld + 1] * c1 + k0[i] * cd0 + k1[i] * cd1;
+        const double pd = kd0[i] * c0 + kd1[i] * c1 + k0[i] * cd0 + k1[i] * cd1;
         v1[i] = -pd - s;
     }
     __syncthreads();
@@ -502,6 +532,7 @@ struct FeatArgs {
     const double *X, *Zy, *raw_ell, *raw_var;
     const float *omega, *beta;
     float *Phi, *dPhi;
+    uint32_t* tick;          // device step counter, ticked by the stand-alone launch of a training step (or null)
 };
 
 __device__ __forceinline__ void features_body(const FeatArgs& a, int bx, int by, int bz) {
@@ -538,7 +569,10 @@ __device__ __forceinline__ void features_body(const FeatArgs& a, int bx, int by,
     }
 }
 
-__global__ __launch_bounds__(kBlock) void features_kernel(FeatArgs a) { features_body(a, blockIdx.x, blockIdx.y, blockIdx.z); }
+__global__ __launch_bounds__(kBlock) void features_kernel(FeatArgs a) {
+    if (a.tick && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *a.tick += 1u;
+    features_body(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
 
 // =================================================================================================
 // Prior draws  F0[s, l, j] = sum_b w[s, l, b] Phi[l, j, b]   (and H with dPhi) on the f32 MFMA pipe.
@@ -553,13 +587,15 @@ struct GemmArgs {
     const float *W, *Phi, *dPhi;
     float *F0, *H;
     size_t slab;
+    int dbg;                 // measurement builds: 1 no stores, 2 no loads, 3 no MFMA
 };
 
+// KS > 0: the K-slice of a workgroup is KS steps of 16 and ALL its operands are requested before the first
+// MFMA (one L2 round trip instead of KS dependent ones -- at one problem these launches are latency bound,
+// not bandwidth bound).  KS == 0: any slice length, next step prefetched while the MFMAs of this one run.
+template <int KS>
 __device__ __forceinline__ void prior_gemm_body(const GemmArgs& a, int bx, int by, int bz) {
     const int S = a.S, L = a.L, J = a.J, B = a.B, SK = a.SK, nsel = a.nsel;
-    const float *W = a.W, *Phi = a.Phi, *dPhi = a.dPhi;
-    float *F0 = a.F0, *H = a.H;
-    const size_t slab = a.slab;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int z = bz;
     const int sel = z % nsel; z /= nsel;
@@ -568,12 +604,12 @@ __device__ __forceinline__ void prior_gemm_body(const GemmArgs& a, int bx, int b
     const int s0 = (by * 4 + wave) * 16;
     const int j0 = bx * (16 * kNT);
     if (s0 >= S) return;
-    const float* Bm = sel == 0 ? Phi : dPhi;
-    float* Out = (sel == 0 ? F0 : H) + (size_t)sk * slab;
+    const float* Bm = sel == 0 ? a.Phi : a.dPhi;
+    float* Out = (sel == 0 ? a.F0 : a.H) + (size_t)sk * a.slab;
     const int kchunk = B / SK, kbeg = sk * kchunk, kend = kbeg + kchunk;
     const int r = lane & 15, g = lane >> 4;
     const int srow = min(s0 + r, S - 1);
-    const float* ap = W + (((size_t)p * S + srow) * L + l) * B + 4 * g;
+    const float* ap = a.W + (((size_t)p * S + srow) * L + l) * B + 4 * g;
     const float* bp[kNT];
 #pragma unroll
     for (int t = 0; t < kNT; ++t) {
@@ -583,27 +619,67 @@ __device__ __forceinline__ void prior_gemm_body(const GemmArgs& a, int bx, int b
     vg_f32x4 acc[kNT];
 #pragma unroll
     for (int t = 0; t < kNT; ++t) acc[t] = (vg_f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 a_cur = *reinterpret_cast<const float4*>(ap + kbeg);
-    float4 b_cur[kNT];
+    if constexpr (KS > 0) {
+        float4 av[KS], bv[kNT][KS];
+#ifdef VGPMP_BISECT
+        if (a.dbg == 2) {
 #pragma unroll
-    for (int t = 0; t < kNT; ++t) b_cur[t] = *reinterpret_cast<const float4*>(bp[t] + kbeg);
-    for (int k = kbeg; k < kend; k += 16) {
-        const int kn = (k + 16 < kend) ? k + 16 : k;      // prefetch next k-step while the MFMAs run
-        float4 a_nxt = *reinterpret_cast<const float4*>(ap + kn);
-        float4 b_nxt[kNT];
+            for (int ks = 0; ks < KS; ++ks) {
+                av[ks] = make_float4(1.f, 2.f, 3.f, (float)lane);
 #pragma unroll
-        for (int t = 0; t < kNT; ++t) b_nxt[t] = *reinterpret_cast<const float4*>(bp[t] + kn);
+                for (int t = 0; t < kNT; ++t) bv[t][ks] = make_float4(1.f, 2.f, (float)t, (float)lane);
+            }
+        } else
+#endif
 #pragma unroll
-        for (int t = 0; t < kNT; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.x, b_cur[t].x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.y, b_cur[t].y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.z, b_cur[t].z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.w, b_cur[t].w, acc[t], 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) {
+            av[ks] = *reinterpret_cast<const float4*>(ap + kbeg + 16 * ks);
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) bv[t][ks] = *reinterpret_cast<const float4*>(bp[t] + kbeg + 16 * ks);
         }
-        a_cur = a_nxt;
+#ifdef VGPMP_BISECT
+        if (a.dbg == 3) {
 #pragma unroll
-        for (int t = 0; t < kNT; ++t) b_cur[t] = b_nxt[t];
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) acc[t][ks & 3] += av[ks].x * bv[t][ks].y + av[ks].z * bv[t][ks].w;
+        } else
+#endif
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].x, bv[t][ks].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].y, bv[t][ks].y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].z, bv[t][ks].z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].w, bv[t][ks].w, acc[t], 0, 0, 0);
+            }
+    } else {
+        float4 a_cur = *reinterpret_cast<const float4*>(ap + kbeg);
+        float4 b_cur[kNT];
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) b_cur[t] = *reinterpret_cast<const float4*>(bp[t] + kbeg);
+        for (int k = kbeg; k < kend; k += 16) {
+            const int kn = (k + 16 < kend) ? k + 16 : k;      // prefetch next k-step while the MFMAs run
+            float4 a_nxt = *reinterpret_cast<const float4*>(ap + kn);
+            float4 b_nxt[kNT];
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) b_nxt[t] = *reinterpret_cast<const float4*>(bp[t] + kn);
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.x, b_cur[t].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.y, b_cur[t].y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.z, b_cur[t].z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.w, b_cur[t].w, acc[t], 0, 0, 0);
+            }
+            a_cur = a_nxt;
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) b_cur[t] = b_nxt[t];
+        }
     }
+#ifdef VGPMP_BISECT
+    if (a.dbg == 1) { if (acc[0][0] + acc[1][1] + acc[2][2] == 123.456f) Out[0] = 1.f; return; }
+#endif
     // D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
     for (int t = 0; t < kNT; ++t) {
@@ -617,7 +693,8 @@ __device__ __forceinline__ void prior_gemm_body(const GemmArgs& a, int bx, int b
     }
 }
 
-__global__ __launch_bounds__(kBlock) void prior_gemm_kernel(GemmArgs a) { prior_gemm_body(a, blockIdx.x, blockIdx.y, blockIdx.z); }
+template <int KS>
+__global__ __launch_bounds__(kBlock) void prior_gemm_kernel(GemmArgs a) { prior_gemm_body<KS>(a, blockIdx.x, blockIdx.y, blockIdx.z); }
 
 // LDS-tiled variant for large batches (no split-K): a workgroup owns 64 samples x 144 columns, stages
 // 32-deep K slices of W and Phi through double-buffered LDS (global -> registers -> LDS, next slice in
@@ -717,6 +794,28 @@ __global__ __launch_bounds__(kBlock) void prior_gemm_tiled_kernel(int S, int L, 
 //   u = m + C eps;  r = u - F0(Z) - sqrt(jitter) eps2;  f = F0(X) + A r
 // One workgroup per (chunk of VG_SC samples, latent, problem).
 // =================================================================================================
+__device__ __forceinline__ void adam_update(double* x, double* m, double* v, double g, double lr_t) {
+    // Keras Adam (TF 2.12): beta1 = 0.8, beta2 = 0.95 (models/vgpmp.py:77), epsilon 1e-7
+    double mm = *m + (g - *m) * (1.0 - 0.8);
+    double vv = *v + (g * g - *v) * (1.0 - 0.95);
+    *m = mm; *v = vv;
+    *x -= lr_t * mm / (sqrt(vv) + 1e-7);
+}
+
+// Hyper-parameter update (hyper_kernel).  A ticket scheme that let the last workgroup of the reverse
+// pass do it was measured and rejected: the agent-scope fences it needs cost ~16 us on this 8-XCD part.
+struct HyperArgs {
+    int L, Mz, NC, want_dell;
+    size_t part_len;
+    const float* part;
+    const double *gkl_ell, *gkl_var, *var, *sig_ell, *sig_var;
+    double kl_scale, lr, lr_t;
+    double *g_ell, *g_var, *lr_dev;
+    double *m_ell, *m_var, *v_ell, *v_var, *p_ell, *p_var;
+    const uint32_t* ctr;     // device step counter (already ticked: 1-based Adam count) or null
+    int do_adam, trainable;
+};
+
 struct PathArgs {
     int S, N, Mz, L, SK, NC;
     size_t slab, part_len;
@@ -726,7 +825,6 @@ struct PathArgs {
     float *R, *f;
     const float* G;
     float* part;
-    uint32_t* tick;          // device step counter, incremented by the reverse pass of a training step (or null)
     int want_dell;
     int stop;
 };
@@ -806,9 +904,6 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_kernel(PathArgs a) {
     extern __shared__ float smf[];
     __shared__ float red[3][kBlock / VG_WAVE];
     const int ch = blockIdx.x, l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
-    // no kernel that reads the counter runs next to this one: the noise kernels before it see the old value,
-    // hyper_kernel and the noise kernels after it the new one
-    if (a.tick && ch == 0 && l == 0 && p == 0 && tid == 0) *a.tick += 1u;
     const int S = a.S, N = a.N, Mz = a.Mz, L = a.L, J = N + Mz;
     const float iMz = 1.0f / (float)Mz, iN = 1.0f / (float)N, iJ = 1.0f / (float)J;
     const size_t pl = (size_t)p * L + l;
@@ -905,35 +1000,25 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_kernel(PathArgs a) {
 
 // =================================================================================================
 // Gradient assembly + Adam, in two launches so that the next step can start early:
-//   hyper_kernel  -- lengthscale / variance of every latent (a handful of scalars): the covariance and
-//                    feature kernels of the NEXT step depend only on these, so they are released first;
+//   lengthscale / variance of every latent (a handful of scalars): the covariance and feature kernels of
+//                    the NEXT step depend only on these, so the reverse pass itself updates them (HyperArgs);
 //   final_kernel  -- q_mu / q_sqrt of one (latent, problem) per workgroup, and the ELBO pieces.
 // =================================================================================================
 struct FinalArgs {
     int M, L, NC, nblk;
     size_t part_len;
     const float *part, *Lk32, *lik_partial;
-    const double *gkl_qmu, *gkl_Q, *gkl_ell, *gkl_var, *kl_l, *var, *sig_ell, *sig_var;
+    const double *gkl_qmu, *gkl_Q, *kl_l;
     double kl_scale, lik_scale;
     double *out_lik, *out_kl;
-    double *g_qmu, *g_qsqrt, *g_ell, *g_var;
-    int do_adam, trainable, want_dell;
-    double lr_t, lr;
-    const uint32_t* ctr;      // device step counter (already ticked: 1-based Adam step) or null
-    double* lr_dev;           // [P] step size handed from hyper_kernel to final_kernel
-    double *mq_mu, *mq_sqrt, *m_ell, *m_var;      // Adam moments
-    double *vq_mu, *vq_sqrt, *v_ell, *v_var;
-    double *pq_mu, *pq_sqrt, *p_ell, *p_var;      // parameters (updated in place)
+    double *g_qmu, *g_qsqrt;
+    int do_adam, trainable;
+    const double* lr_dev;     // [P] step size handed from the reverse pass to final_kernel
+    double *mq_mu, *mq_sqrt;  // Adam moments
+    double *vq_mu, *vq_sqrt;
+    double *pq_mu, *pq_sqrt;  // parameters (updated in place)
     int stop;
 };
-
-__device__ __forceinline__ void adam_update(double* x, double* m, double* v, double g, double lr_t) {
-    // Keras Adam (TF 2.12): beta1 = 0.8, beta2 = 0.95 (models/vgpmp.py:77), epsilon 1e-7
-    double mm = *m + (g - *m) * (1.0 - 0.8);
-    double vv = *v + (g * g - *v) * (1.0 - 0.95);
-    *m = mm; *v = vv;
-    *x -= lr_t * mm / (sqrt(vv) + 1e-7);
-}
 
 // sum over the NC sample chunks of one reverse-pass partial, 8 independent loads in flight per pass
 // (unconditional clamped loads, masked afterwards); fixed order: deterministic
@@ -955,30 +1040,28 @@ __device__ __forceinline__ double sum_chunks(const float* part, size_t part_len,
 }
 
 // one wave per problem, one lane per latent
-__global__ __launch_bounds__(64) void hyper_kernel(FinalArgs b) {
+__global__ __launch_bounds__(64) void hyper_kernel(HyperArgs h) {
     const int p = blockIdx.x, l = threadIdx.x;
-    const int Mz = b.M + 2, L = b.L;
-    double lr_t = b.lr_t;
-    if (b.do_adam && b.ctr) {
-        const double t = (double)*b.ctr;               // ticked by paths_bwd_kernel: 1-based count of this update
-        lr_t = b.lr * sqrt(1.0 - exp(t * -0.05129329438755058)) / (1.0 - exp(t * -0.2231435513142098));
+    double lr_t = h.lr_t;
+    if (h.do_adam && h.ctr) {
+        const double t = (double)*h.ctr;
+        lr_t = h.lr * sqrt(1.0 - exp(t * -0.05129329438755058)) / (1.0 - exp(t * -0.2231435513142098));
     }
-    if (l == 0) b.lr_dev[p] = lr_t;
-    if (l >= L) return;
-    const size_t pl = (size_t)p * L + l;
-    const float* part = b.part + pl * b.NC * b.part_len;
-    const int e0 = Mz + Mz * Mz;
-    const double s_ell = b.want_dell ? sum_chunks(part, b.part_len, b.NC, e0) : 0.0;
-    const double s_var = sum_chunks(part, b.part_len, b.NC, e0 + 1);
-    const double s_rff = sum_chunks(part, b.part_len, b.NC, e0 + 2);
-    const double kls = b.kl_scale, var = b.var[pl];
-    const double g_ell = (s_ell + kls * b.gkl_ell[pl]) * b.sig_ell[pl];
-    const double g_var = (s_var + s_rff / (2.0 * var) + kls * b.gkl_var[pl]) * b.sig_var[pl];
-    b.g_ell[pl] = g_ell;
-    b.g_var[pl] = g_var;
-    if (b.do_adam) {
-        if (b.trainable & VGPMP_TRAIN_LENGTHSCALES) adam_update(b.p_ell + pl, b.m_ell + pl, b.v_ell + pl, g_ell, lr_t);
-        if (b.trainable & VGPMP_TRAIN_KERNEL_VARIANCE) adam_update(b.p_var + pl, b.m_var + pl, b.v_var + pl, g_var, lr_t);
+    if (l == 0) h.lr_dev[p] = lr_t;
+    if (l >= h.L) return;
+    const size_t pl = (size_t)p * h.L + l;
+    const float* part = h.part + pl * h.NC * h.part_len;
+    const int e0 = h.Mz + h.Mz * h.Mz;
+    const double s_ell = h.want_dell ? sum_chunks(part, h.part_len, h.NC, e0) : 0.0;
+    const double s_var = sum_chunks(part, h.part_len, h.NC, e0 + 1);
+    const double s_rff = sum_chunks(part, h.part_len, h.NC, e0 + 2);
+    const double g_ell = (s_ell + h.kl_scale * h.gkl_ell[pl]) * h.sig_ell[pl];
+    const double g_var = (s_var + s_rff / (2.0 * h.var[pl]) + h.kl_scale * h.gkl_var[pl]) * h.sig_var[pl];
+    h.g_ell[pl] = g_ell;
+    h.g_var[pl] = g_var;
+    if (h.do_adam) {
+        if (h.trainable & VGPMP_TRAIN_LENGTHSCALES) adam_update(h.p_ell + pl, h.m_ell + pl, h.v_ell + pl, g_ell, lr_t);
+        if (h.trainable & VGPMP_TRAIN_KERNEL_VARIANCE) adam_update(h.p_var + pl, h.m_var + pl, h.v_var + pl, g_var, lr_t);
     }
 }
 
@@ -1099,16 +1182,18 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(size_t n, double* __restri
 struct Stage1Args {
     CovArgs cov; FinalArgs fin; RngArgs rng; FeatArgs feat;
     int n_cov, n_fin, n_eps, eps_gx, feat_gx, feat_gy;
+    int skip;                 // measurement builds: bit mask of roles that return at once
 };
 __global__ __launch_bounds__(kBlock) void stage1_kernel(Stage1Args a) {
     extern __shared__ double sm[];
     int b = blockIdx.x;
-    if (b < a.n_cov) { cov_a_body(a.cov, sm, b % a.cov.L, b / a.cov.L); return; }
+    if (b < a.n_cov) { if (!(a.skip & 1)) cov_a_body(a.cov, sm, b % a.cov.L, b / a.cov.L); return; }
     b -= a.n_cov;
-    if (b < a.n_fin) { final_body(a.fin, sm, b % a.fin.L, b / a.fin.L); return; }
+    if (b < a.n_fin) { if (!(a.skip & 2)) final_body(a.fin, sm, b % a.fin.L, b / a.fin.L); return; }
     b -= a.n_fin;
-    if (b < a.n_eps) { rng_normals_body(a.rng, b % a.eps_gx, b / a.eps_gx, 0u, a.rng.nE); return; }
+    if (b < a.n_eps) { if (!(a.skip & 4)) rng_normals_body(a.rng, b % a.eps_gx, b / a.eps_gx, 0u, a.rng.nE); return; }
     b -= a.n_eps;
+    if (a.skip & 8) return;
     const int bx = b % a.feat_gx;
     b /= a.feat_gx;
     features_body(a.feat, bx, b % a.feat_gy, b / a.feat_gy);
@@ -1116,39 +1201,48 @@ __global__ __launch_bounds__(kBlock) void stage1_kernel(Stage1Args a) {
 
 struct Stage2Args {
     CovArgs cov; GemmArgs gemm;
-    int n_cov, cov_roles, gemm_gx, gemm_gy;
+    int n_cov, cov_roles, gemm_gx, gemm_gy, gemm_per_xcd;
+    int skip;
 };
-template <bool TANGENTS>
+template <bool TANGENTS, int KS>
 __global__ __launch_bounds__(kBlock) void stage2_kernel(Stage2Args a) {
     extern __shared__ double sm[];
     int b = blockIdx.x;
     if (b < a.n_cov) {
+        if (a.skip & 1) return;
         const int role = b % a.cov_roles;
         b /= a.cov_roles;
         cov_b_body<TANGENTS>(a.cov, sm, role, b % a.cov.L, b / a.cov.L);
         return;
     }
     b -= a.n_cov;
+    if (a.skip & 2) return;
+    // Workgroups go to the 8 XCDs round robin (n_cov is a multiple of 8 or the remap is off): give each XCD a
+    // CONTIGUOUS range of GEMM tiles, so the column / row tiles that share operands share an L2 as well.
+    if (a.gemm_per_xcd > 0) b = (b & 7) * a.gemm_per_xcd + (b >> 3);
     const int bx = b % a.gemm_gx;
     b /= a.gemm_gx;
-    prior_gemm_body(a.gemm, bx, b % a.gemm_gy, b / a.gemm_gy);
+    prior_gemm_body<KS>(a.gemm, bx, b % a.gemm_gy, b / a.gemm_gy);
 }
 
 struct Stage3Args {
     PathArgs path; RngArgs rng;
     int n_path, n_basis, basis_gx, w_gx;
+    int skip;
 };
 template <int SK>
 __global__ __launch_bounds__(kBlock) void stage3_kernel(Stage3Args a) {
     extern __shared__ float smf[];
     int b = blockIdx.x;
     if (b < a.n_path) {
+        if (a.skip & 1) return;
         const int ch = b % a.path.NC;
         b /= a.path.NC;
         paths_fwd_body<SK, 8>(a.path, smf, ch, b % a.path.L, b / a.path.L);
         return;
     }
     b -= a.n_path;
+    if (a.skip & 2) return;
     if (b < a.n_basis) { rng_basis_body(a.rng, b % a.basis_gx, b / a.basis_gx); return; }
     b -= a.n_basis;
     rng_normals_body(a.rng, b % a.w_gx, b / a.w_gx, a.rng.nW, 0u);
@@ -1318,6 +1412,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     ca.q_mu = params->q_mu; ca.q_sqrt = params->q_sqrt; ca.raw_ell = params->raw_ell; ca.raw_var = params->raw_var;
     ca.want_dell = want_dell ? 1 : 0;
     ca.stop = -1;
+    ca.tick = (fused && do_adam) ? ctr : nullptr;
     ca.ws = *ws;
     FeatArgs fe;
     fe.N = N; fe.Mz = Mz; fe.L = L; fe.D = L; fe.B = B;
@@ -1325,11 +1420,13 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     fe.jchunk = fused ? 4 : (P * L >= 64 ? 16 : 1);
     fe.X = pb->X; fe.Zy = pb->Zy; fe.raw_ell = params->raw_ell; fe.raw_var = params->raw_var;
     fe.omega = nz->omega; fe.beta = nz->beta; fe.Phi = ws->Phi; fe.dPhi = want_dell ? ws->dPhi : nullptr;
+    fe.tick = (!fused && do_adam) ? ctr : nullptr;
     const dim3 feat_grid((B + kBlock - 1) / kBlock, (J + fe.jchunk - 1) / fe.jchunk, P * L);
     const size_t slab = (size_t)P * S * L * J;
     GemmArgs ga;
     ga.S = S; ga.L = L; ga.J = J; ga.B = B; ga.SK = SK; ga.nsel = want_dell ? 2 : 1;
     ga.W = nz->w; ga.Phi = ws->Phi; ga.dPhi = ws->dPhi; ga.F0 = ws->F0; ga.H = ws->H; ga.slab = slab;
+    ga.dbg = 0;
     const dim3 gemm_grid((J + 16 * kNT - 1) / (16 * kNT), (S + 63) / 64, P * L * SK * ga.nsel);
     PathArgs pa;
     pa.S = S; pa.N = N; pa.Mz = Mz; pa.L = L; pa.SK = SK; pa.NC = NC; pa.slab = slab; pa.part_len = vg_part_len(d);
@@ -1338,32 +1435,41 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     pa.C = ws->C; pa.CT_ell = ws->CT_ell; pa.CT_var = ws->CT_var; pa.m = ws->m;
     pa.F0 = ws->F0; pa.H = ws->H; pa.want_dell = want_dell ? 1 : 0;
     pa.eps = nz->eps; pa.eps2 = nz->eps2; pa.R = ws->R; pa.f = out->f; pa.G = ws->G; pa.part = ws->part;
-    pa.tick = do_adam ? ctr : nullptr;
+    HyperArgs hy;
+    hy.L = L; hy.Mz = Mz; hy.NC = NC; hy.want_dell = want_dell ? 1 : 0; hy.part_len = vg_part_len(d); hy.part = ws->part;
+    hy.gkl_ell = ws->gkl_ell; hy.gkl_var = ws->gkl_var; hy.var = ws->var; hy.sig_ell = ws->sig_ell; hy.sig_var = ws->sig_var;
+    hy.kl_scale = pb->kl_scale; hy.lr = lr; hy.lr_t = 0.0;
+    hy.g_ell = out->grad.raw_ell; hy.g_var = out->grad.raw_var; hy.lr_dev = ws->lr_t;
+    hy.m_ell = am ? am->raw_ell : nullptr; hy.m_var = am ? am->raw_var : nullptr;
+    hy.v_ell = av ? av->raw_ell : nullptr; hy.v_var = av ? av->raw_var : nullptr;
+    hy.p_ell = params->raw_ell; hy.p_var = params->raw_var;
+    hy.ctr = ctr; hy.do_adam = do_adam ? 1 : 0; hy.trainable = trainable;
     pa.stop = -1;
     const double lik_scale = pb->alpha / (double)d->S_total;
     FinalArgs fa;
     fa.M = M; fa.L = L; fa.NC = NC; fa.nblk = P ? vg_loglik_blocks_per_problem(S, N) : 0; fa.part_len = vg_part_len(d);
     fa.part = ws->part; fa.Lk32 = ws->Lk32; fa.lik_partial = ws->lik_partial;
-    fa.gkl_qmu = ws->gkl_qmu; fa.gkl_Q = ws->gkl_Q; fa.gkl_ell = ws->gkl_ell; fa.gkl_var = ws->gkl_var;
-    fa.kl_l = ws->kl_l; fa.var = ws->var; fa.sig_ell = ws->sig_ell; fa.sig_var = ws->sig_var;
+    fa.gkl_qmu = ws->gkl_qmu; fa.gkl_Q = ws->gkl_Q; fa.kl_l = ws->kl_l;
     fa.kl_scale = pb->kl_scale; fa.lik_scale = lik_scale; fa.out_lik = out->lik; fa.out_kl = out->kl;
-    fa.g_qmu = out->grad.q_mu; fa.g_qsqrt = out->grad.q_sqrt; fa.g_ell = out->grad.raw_ell; fa.g_var = out->grad.raw_var;
-    fa.do_adam = do_adam ? 1 : 0; fa.trainable = trainable; fa.want_dell = want_dell ? 1 : 0;
-    fa.lr_t = 0.0; fa.lr = lr; fa.ctr = ctr; fa.lr_dev = ws->lr_t;
+    fa.g_qmu = out->grad.q_mu; fa.g_qsqrt = out->grad.q_sqrt;
+    fa.do_adam = do_adam ? 1 : 0; fa.trainable = trainable; fa.lr_dev = ws->lr_t;
     fa.mq_mu = am ? am->q_mu : nullptr; fa.mq_sqrt = am ? am->q_sqrt : nullptr;
-    fa.m_ell = am ? am->raw_ell : nullptr; fa.m_var = am ? am->raw_var : nullptr;
     fa.vq_mu = av ? av->q_mu : nullptr; fa.vq_sqrt = av ? av->q_sqrt : nullptr;
-    fa.v_ell = av ? av->raw_ell : nullptr; fa.v_var = av ? av->raw_var : nullptr;
-    fa.pq_mu = params->q_mu; fa.pq_sqrt = params->q_sqrt; fa.p_ell = params->raw_ell; fa.p_var = params->raw_var;
+    fa.pq_mu = params->q_mu; fa.pq_sqrt = params->q_sqrt;
     fa.stop = -1;
+    int skip1 = 0, skip2 = 0, skip3 = 0;
 #ifdef VGPMP_BISECT
+    ga.dbg = vg_bisect_stop("VGPMP_GEMM_DBG") > 0 ? vg_bisect_stop("VGPMP_GEMM_DBG") : 0;
+    skip1 = vg_bisect_stop("VGPMP_S1_SKIP") > 0 ? vg_bisect_stop("VGPMP_S1_SKIP") : 0;
+    skip2 = vg_bisect_stop("VGPMP_S2_SKIP") > 0 ? vg_bisect_stop("VGPMP_S2_SKIP") : 0;
+    skip3 = vg_bisect_stop("VGPMP_S3_SKIP") > 0 ? vg_bisect_stop("VGPMP_S3_SKIP") : 0;
     ca.stop = vg_bisect_stop("VGPMP_STOP_COV");
     pa.stop = vg_bisect_stop("VGPMP_STOP_PATHS");
     fa.stop = vg_bisect_stop("VGPMP_STOP_FINAL");
 #endif
     // ---- dynamic LDS sizes and kernel variants --------------------------------------------------
     const int Mp = (Mz + 15) & ~15;
-    const size_t lds_cov = ((size_t)6 * Mp * (Mp + 1) + 5 * Mp) * sizeof(double);
+    const size_t lds_cov = ((size_t)4 * Mp * (Mp + 1) + 7 * Mp) * sizeof(double);
     const size_t lds_cov_a = ((size_t)4 * Mp * (Mp + 1) + 2 * Mp) * sizeof(double);
     const size_t lds_rows = ((size_t)2 * Mz * (Mz + 1) + (size_t)4 * kRowTile * Mz + Mz) * sizeof(double);
     const size_t lds_cov_b = lds_cov > lds_rows ? lds_cov : lds_rows;
@@ -1373,7 +1479,9 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const size_t lds_fin = ((size_t)Mz * Mz + Mz) * sizeof(double) + (size_t)Mz * Mz * sizeof(float);
     const size_t lds_s1 = lds_cov_a > lds_fin ? lds_cov_a : lds_fin;
     const void* fn_cov_b = backward ? (const void*)cov_b_kernel<true> : (const void*)cov_b_kernel<false>;
-    const void* fn_s2 = backward ? (const void*)stage2_kernel<true> : (const void*)stage2_kernel<false>;
+    const bool k8 = B / SK == 128;      // B = 1024 with 8 K-slices: all operands of a workgroup in one request
+    const void* fn_s2 = backward ? (k8 ? (const void*)stage2_kernel<true, 8> : (const void*)stage2_kernel<true, 0>)
+                                 : (k8 ? (const void*)stage2_kernel<false, 8> : (const void*)stage2_kernel<false, 0>);
     const void* fn_pf = SC == 32 ? (const void*)paths_fwd_kernel<1, 32>
                       : SK == 1 ? (const void*)paths_fwd_kernel<1, 8> : SK == 2 ? (const void*)paths_fwd_kernel<2, 8>
                       : SK == 4 ? (const void*)paths_fwd_kernel<4, 8> : (const void*)paths_fwd_kernel<8, 8>;
@@ -1411,6 +1519,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             // prior noise of step i was drawn by stage 3 of step i-1
             if (gen && first && (rc = vg_launch_rng(d, nz, seed, problem_base, step_i, ctr, st))) return rc;
             Stage1Args s1;
+            s1.skip = skip1;
             s1.cov = ca; s1.fin = fa; s1.feat = fe;
             s1.rng = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
             s1.n_cov = L * P;
@@ -1421,14 +1530,18 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             const unsigned n1 = s1.n_cov + s1.n_fin + s1.n_eps + feat_grid.x * feat_grid.y * feat_grid.z;
             if ((rc = launch((const void*)stage1_kernel, dim3(n1), &s1, lds_s1))) return rc;
             Stage2Args s2;
+            s2.skip = skip2;
             s2.cov = ca; s2.gemm = ga;
             s2.cov_roles = (int)cov_b_grid.x; s2.n_cov = (int)(cov_b_grid.x * cov_b_grid.y * cov_b_grid.z);
             s2.gemm_gx = (int)gemm_grid.x; s2.gemm_gy = (int)gemm_grid.y;
+            const int n_gemm = (int)(gemm_grid.x * gemm_grid.y * gemm_grid.z);
+            s2.gemm_per_xcd = (s2.n_cov % 8 == 0 && n_gemm % 8 == 0) ? n_gemm / 8 : 0;
             if ((rc = launch(fn_s2, dim3(s2.n_cov + gemm_grid.x * gemm_grid.y * gemm_grid.z), &s2, lds_cov_b))) return rc;
             Stage3Args s3;
+            s3.skip = skip3;
             s3.path = pa;
-            // the counter ticks in paths_bwd of this step: the next step's key is counter + 1 here
-            s3.rng = make_rng_args(d, nz, seed, problem_base, step_i + 1u, ctr, 1u);
+            // the counter has ticked in stage 2: it already names the next step
+            s3.rng = make_rng_args(d, nz, seed, problem_base, step_i + 1u, ctr, 0u);
             s3.n_path = NC * L * P;
             s3.basis_gx = (int)basis_gx; s3.w_gx = (int)w_gx;
             s3.n_basis = (gen && more) ? (int)basis_gx * P : 0;
@@ -1447,7 +1560,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 hipLaunchKernelGGL(prior_gemm_tiled_kernel, dim3((J + kTJ - 1) / kTJ, (S + kTS - 1) / kTS, P * L * ga.nsel),
                                    dim3(kBlock), 0, st, S, L, J, B, ga.nsel, nz->w, ws->Phi, ws->dPhi, ws->F0, ws->H);
             else
-                hipLaunchKernelGGL(prior_gemm_kernel, gemm_grid, dim3(kBlock), 0, st, ga);
+                hipLaunchKernelGGL(prior_gemm_kernel<0>, gemm_grid, dim3(kBlock), 0, st, ga);
             mark();
             if ((rc = launch(fn_pf, dim3(NC, L, P), &pa, lds_pf))) return rc;
             mark();
@@ -1464,11 +1577,11 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                                pb->kl_scale, out->lik, out->kl);
             return (int)hipGetLastError();
         }
-        // ---- reverse of the path assembly, hyper-parameter update, then (here or in the next stage 1) the rest
+        // ---- reverse of the path assembly (+ hyper-parameter update), then (here or in the next stage 1) the rest
         if ((rc = launch(fn_pb, dim3(NC, L, P), &pa, lds_pb))) return rc;
         mark();
-        fa.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
-        hipLaunchKernelGGL(hyper_kernel, dim3(P), dim3(64), 0, st, fa);
+        hy.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
+        hipLaunchKernelGGL(hyper_kernel, dim3(P), dim3(64), 0, st, hy);
         if (!(fused && more) && (rc = launch_final())) return rc;
         mark();
     }
