@@ -1,0 +1,68 @@
+"""Measurement aid: timeline of one training step from in-kernel time stamps (measurement build).
+
+    VGPMP_HIP_LIB=tools/libvgpmp_bisect.so python tools/step_trace.py [problems]
+
+Prints, for the last full step of a short run, every stamp (kernel*100 + role*10 + phase) with its time in
+microseconds relative to the first stamp of the step."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vgpmp_amd import capi, engine, robots as rb, scenes  # noqa: E402
+
+NAMES = {100: "cov_a start", 101: "cov_a Kuu built", 102: "cov_a factorised", 103: "cov_a end",
+         110: "final start", 111: "final partials summed", 112: "final grads", 113: "final end",
+         120: "eps start", 130: "features first wg start", 131: "features first wg end", 135: "features last wg end",
+         200: "cov_b q start", 201: "cov_b q staged", 202: "cov_b q end",
+         210: "cov_b d/dell start", 211: "cov_b d/dell staged", 212: "cov_b d/dell matmuls", 213: "cov_b d/dell end",
+         220: "cov_b d/dvar start", 221: "cov_b d/dvar staged", 222: "cov_b d/dvar matmuls", 223: "cov_b d/dvar end",
+         214: "d/dell af done", 215: "d/dell matmul 1", 216: "d/dell matmul 2", 217: "d/dell matmul 3",
+         224: "d/dvar af done", 225: "d/dvar matmul 1", 226: "d/dvar matmul 2", 227: "d/dvar matmul 3",
+         233: "rows Kfu built", 234: "rows A", 235: "rows tangent 1",
+         230: "rows start", 232: "rows staged", 231: "rows end",
+         240: "gemm first wg start", 241: "gemm first wg mfma done", 242: "gemm first wg end", 245: "gemm last wg end",
+         300: "paths_fwd start", 301: "paths_fwd staged", 302: "paths_fwd end", 305: "paths_fwd last wg end",
+         310: "rng basis start", 320: "rng w start", 321: "rng w first wg end", 325: "rng w last wg end",
+         400: "loglik first wg start", 401: "loglik first wg end", 405: "loglik last wg end",
+         500: "paths_bwd start", 501: "paths_bwd staged", 502: "paths_bwd loops", 503: "paths_bwd end",
+         505: "paths_bwd last wg end", 600: "hyper start", 601: "hyper end"}
+
+
+def main():
+    P = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    lib = capi.load()
+    lib.vgpmp_debug_trace.argtypes = [C.c_void_p, C.c_int32]
+    lib.vgpmp_debug_trace.restype = C.c_int
+    ps = rb.load_problemset("franka", "industrial")
+    spec = rb.load_robot("franka")
+    grid = scenes.synthetic_boxes_sdf(n=128, delta=1.6 / 128, origin=(-0.8, -0.8, -0.2), seed=0)
+    pp = ps.planner_params
+    sc = engine.DeviceScene(spec, grid, ps.object_positions[0], sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"])
+    qs = np.array([ps.queries[i % len(ps.queries)] for i in range(P)])
+    pl = engine.PlannerBatch(sc, qs, num_samples=128, num_inducing=30, num_data=100, num_bases=1024,
+                             lengthscales=pp["lengthscales"], variance=pp["variance"], alpha=pp["alpha"],
+                             learning_rate=pp["learning_rate"], seed=1)
+    pl.fuse = os.environ.get("NO_FUSE") is None
+    buf = np.zeros(2 * 8192, dtype=np.uint64)
+    pl.run_steps(30)
+    torch.cuda.synchronize()
+    lib.vgpmp_debug_trace(buf.ctypes.data, 8192)          # discard
+    pl.run_steps(6)
+    torch.cuda.synchronize()
+    n = lib.vgpmp_debug_trace(buf.ctypes.data, 8192)
+    ev = sorted((int(buf[2 * i + 1]), int(buf[2 * i])) for i in range(n))
+    # one step = from a cov_a start to the next one; take the fourth
+    starts = [i for i, (_, k) in enumerate(ev) if k == 100]
+    lo, hi = starts[3], starts[4]
+    t0 = ev[lo][0]
+    print(f"step of {(ev[hi][0] - t0) / 100:.2f} us, {P} problem(s), fuse={pl.fuse}")
+    for t, k in ev[lo:hi + 1]:
+        print(f"{(t - t0) / 100:8.2f} us  {k:4d}  {NAMES.get(k, '')}")
+
+
+if __name__ == "__main__":
+    main()

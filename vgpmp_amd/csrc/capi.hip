@@ -175,4 +175,14 @@ int vgpmp_workspace_view(const vgpmp_dims* dims, void* dev_workspace, const char
     return vg_workspace_lookup(dims, &ws, name, dev_ptr, count, is_double);
 }
 
+#ifdef VGPMP_BISECT
+// measurement builds only: (id, 100 MHz time stamp) pairs recorded by the kernels since the last call
+int vgpmp_debug_trace(unsigned long long* host_pairs, int32_t capacity) {
+    int n = vg_trace_take_gp(host_pairs, capacity);
+    if (n < 0) return n;
+    int m = vg_trace_take_lik(host_pairs + 2 * (size_t)n, capacity - n);
+    return m < 0 ? m : n + m;
+}
+#endif
+
 }  // extern "C"

@@ -11,6 +11,7 @@
 #ifdef VGPMP_BISECT
 #include <stdlib.h>
 static int lik_bisect_mode() { const char* e = getenv("VGPMP_STOP_LIK"); return e ? atoi(e) : 0; }
+int vg_trace_take_lik(unsigned long long* host, int cap) { return vg_trace_take(host, cap); }
 #endif
 
 namespace {
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_kernel(const vgpmp_rob
 #endif
     constexpr int CPB = kLikBlock / LPC;                 // configurations per workgroup
     const int pb = blockIdx.y;
+    VG_T(blockIdx.x == 0 && pb == 0, 400);
     const int cl = threadIdx.x / LPC, sub = threadIdx.x % LPC;
     const int idx = blockIdx.x * CPB + cl;
     const bool live = idx < S * N;
@@ -295,6 +297,8 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_kernel(const vgpmp_rob
         for (int k = 0; k < kLikBlock / VG_WAVE; ++k) t += red[k];
         lik_partial[(size_t)pb * gridDim.x + blockIdx.x] = t;
     }
+    VG_T(blockIdx.x == 0 && pb == 0, 401);
+    VG_T(blockIdx.x == gridDim.x - 1 && pb == 0, 405);
 }
 
 // ---- stand-alone FK: q [n, dof] -> pos [n, P, 3], frames [n, dof+1, 12] ---------------------------

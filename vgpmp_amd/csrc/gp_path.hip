@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #define VG_STOP(args, k) do { if ((args).stop == (k)) return; } while (0)
 static int vg_bisect_stop(const char* name) { const char* e = getenv(name); return e ? atoi(e) : -1; }
+int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(host, cap); }
 #else
 #define VG_STOP(args, k) do { } while (0)
 #endif
@@ -44,7 +45,7 @@ __device__ __forceinline__ double matern52_dell(double t1, double t2, double ell
 __device__ __forceinline__ int vg_div(int e, float inv_n) { return (int)(((float)e + 0.5f) * inv_n); }
 
 // strided dot product with four independent accumulators (a dependent f64 FMA costs ~40 cycles)
-__device__ __attribute__((noinline)) double dot4(const double* a, int sa, const double* b, int sb, int n) {
+__device__ __forceinline__ double dot4(const double* a, int sa, const double* b, int sb, int n) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int k = 0;
     for (; k + 3 < n; k += 4) {
@@ -83,6 +84,7 @@ __device__ __forceinline__ uint32_t rng_step(const RngArgs& a) { return a.ctr ? 
 // omega [P,L,B,D] (Student-t, nu = 5: N(0,1) * rsqrt(chi2_5 / 5)) and beta [P,L,B]
 __device__ __forceinline__ void rng_basis_body(const RngArgs& a, int bx, int p) {
     const int L = a.L, B = a.B, D = a.D;
+    VG_T(bx == 0 && p == 0, 310);
     const uint32_t lb = bx * kBlock + threadIdx.x;
     if (lb >= (uint32_t)(L * B)) return;
     const uint2 key = vg_key(a.seed, a.problem_base + p, rng_step(a));
@@ -116,11 +118,14 @@ __device__ __forceinline__ void rng_basis_body(const RngArgs& a, int bx, int p) 
 __device__ __forceinline__ void rng_normals_body(const RngArgs& a, int bx, int p, uint32_t nW, uint32_t nE) {
     const uint32_t cW = nW >> 2;
     uint32_t c = bx * kBlock + threadIdx.x;
+    VG_T(bx == 0 && p == 0, nW ? 320 : 120);
     if (c >= cW + 2u * nE) return;
     const uint2 key = vg_key(a.seed, a.problem_base + p, rng_step(a));
     if (c < cW) {
         const float4 v = vg_normal4((a.wOff >> 2) + c, VG_STREAM_W, key);
         *reinterpret_cast<float4*>(a.w + (size_t)p * nW + 4u * c) = v;
+        VG_T(bx == 0 && p == 0, 321);
+        VG_T(c + kBlock >= cW && p == 0, 325);
         return;
     }
     c -= cW;
@@ -176,7 +181,7 @@ __device__ __forceinline__ vg_f64x4 mfma_tile_f64(MatView A, MatView B, int K, i
     const int r = lane & 15, g = lane >> 4;
     const double* ap = A.p + (i0 + r) * A.sr + g * A.sc;
     const double* bp = B.p + g * B.sr + (j0 + r) * B.sc;
-#pragma nounroll
+#pragma unroll 8
     for (int k = 0; k < K; k += 4) {
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[k * A.sc], bp[k * B.sr], acc, 0, 0, 0);
     }
@@ -234,6 +239,7 @@ __device__ __forceinline__ void chol_inverse_block(double* La, double* Li, doubl
 __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, int p) {
     __shared__ double scal[2];
     const int tid = threadIdx.x, nt = blockDim.x;
+    VG_T(l == 0 && p == 0, 100);
     const int M = a.M, Mz = M + 2, L = a.L, D = a.D;
     const int Mp = (Mz + 15) & ~15, ld = Mp + 1;
     const float iMz = 1.0f / (float)Mz;
@@ -271,7 +277,9 @@ __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, 
         if (i != j) { La[j * ld + i] = k; Kg[(size_t)j * Mz + i] = k; Kdg[(size_t)j * Mz + i] = dk; }
     }
     __syncthreads();
+    VG_T(l == 0 && p == 0, 101);
     chol_inverse_block(La, Li, Sc, rsd, Mz, ld, tid, nt);
+    VG_T(l == 0 && p == 0, 102);
     double* Kig = a.ws.Kinv + pl * Mz * Mz;
     matmul_f64(MatView{Li, 1, ld}, MatView{Li, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
         if (r < Mz && c < Mz) Kig[(size_t)r * Mz + c] = v;
@@ -283,6 +291,7 @@ __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, 
         Lkg[e] = La[i * ld + j];
         Lig[e] = Li[i * ld + j];
     }
+    VG_T(l == 0 && p == 0, 103);
 }
 
 __global__ __launch_bounds__(kCovThreads) void cov_a_kernel(CovArgs a) {
@@ -308,8 +317,9 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
         return;
     }
     if (role > 0 && (!TANGENTS || (role == 1 && !a.want_dell))) return;
+    VG_T(l == 0 && p == 0, 200 + 10 * role);
     const int M = a.M, Mz = M + 2, L = a.L;
-    const int Mp = (Mz + 15) & ~15, ld = Mp + 1;
+    const int Mp = (Mz + 15) & ~15, ld = Mp + 2;      // even: LDS rows start on 16 bytes
     const float iMz = 1.0f / (float)Mz, iM = 1.0f / (float)M;
     const size_t pl = (size_t)p * L + l;
     double* La = sm;                 // Lk, later pad(q_sqrt) for the tangents   (all Mp x ld, zero padded)
@@ -326,49 +336,67 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     double* Qp = X1;
     double* Kd = X1;
     double* T = X2;
-    for (int e = tid; e < 4 * Mp * ld + 7 * Mp; e += nt) sm[e] = 0.0;
-    __syncthreads();
+    double* qm = kd1 + Mp;           // [Mp] q_mu behind the two conditioned points
     const double jit = a.jitter, var = a.ws.var[pl];
+    const double y0 = a.y_u[((size_t)p * 2 + 0) * L + l], y1 = a.y_u[((size_t)p * 2 + 1) * L + l];
     const double* Kg = a.ws.Ks64 + pl * Mz * Mz;
     constexpr int kQRegs = (VGPMP_MAX_MZ - 2) * (VGPMP_MAX_MZ - 2) / kCovThreads + 1;
     double qreg[kQRegs];
     {
-        const double* Lkg = a.ws.Lk64 + pl * Mz * Mz;
-        const double* Lig = a.ws.Li64 + pl * Mz * Mz;
-        const double* Kdg = a.ws.Kd_ell + pl * Mz * Mz;
+        // every operand by DMA, all requests in flight together (zero padding written directly)
         const double* Qg = a.q_sqrt + pl * M * M;
-        float* Lk32 = a.ws.Lk32 + pl * Mz * Mz;      // float32 copy for the gradient assembly (written here, not
-        for (int e = tid; e < Mz * Mz; e += nt) {     // in stage A: stage A of the next step may overlap it)
-            const int i = vg_div(e, iMz), j = e - i * Mz;
-            const double lk = Lkg[e];
-            La[i * ld + j] = lk;
-            Li[i * ld + j] = Lig[e];
-            if (role == 0) Lk32[e] = (float)lk;
-            if (role == 1) Kd[i * ld + j] = Kdg[e];
-            if (role == 2) Kd[i * ld + j] = Kg[e] / var;
+        auto all = [](int, int) { return true; };
+        const bool square = Mz == Mp;      // no zero padding needed: whole rows in 16-byte units
+        if (square) {
+            vg_stage_f64_square(La, ld, a.ws.Lk64 + pl * Mz * Mz, Mz, tid, nt);
+            vg_stage_f64_square(Li, ld, a.ws.Li64 + pl * Mz * Mz, Mz, tid, nt);
+        } else {
+            vg_stage_f64(La, Mp, ld, a.ws.Lk64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
+            vg_stage_f64(Li, Mp, ld, a.ws.Li64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
         }
         if (role == 0) {
-            for (int e = tid; e < M * M; e += nt) {
-                const int r = vg_div(e, iM), c = e - r * M;
-                if (c <= r) Qp[(r + 2) * ld + (c + 2)] = Qg[e];
-            }
+            vg_stage_f64(Qp, Mp, ld, Qg, M, M, 2, 2, tid, nt, [](int r, int c) { return c <= r; });
         } else {      // tangents: this thread's share of Q waits in registers until Lk's LDS space is free
+            const double* Kdg = role == 1 ? a.ws.Kd_ell + pl * Mz * Mz : Kg;
+            if (square) vg_stage_f64_square(Kd, ld, Kdg, Mz, tid, nt);
+            else vg_stage_f64(Kd, Mp, ld, Kdg, Mz, Mz, 0, 0, tid, nt, all);
 #pragma unroll
             for (int k = 0; k < kQRegs; ++k) qreg[k] = Qg[min(tid + k * nt, M * M - 1)];
         }
-        for (int i = tid; i < Mz; i += nt) {
-            k0[i] = Kg[(size_t)i * Mz + 0] + (i == 0 ? jit : 0.0);
-            k1[i] = Kg[(size_t)i * Mz + 1] + (i == 1 ? jit : 0.0);
+        // k0 | k1: the first two columns of Kuu;  qm: q_mu at [2:]
+        vg_stage_words(k0, 4 * Mp, tid, nt, [&](int w) -> const void* {
+            const int d = w >> 1, col = d >= Mp, i = d - col * Mp;
+            return i < Mz ? reinterpret_cast<const uint32_t*>(Kg + (size_t)i * Mz + col) + (w & 1) : nullptr;
+        });
+        vg_stage_words(qm, 2 * Mp, tid, nt, [&](int w) -> const void* {
+            const int i = w >> 1;
+            return (i >= 2 && i < Mz) ? reinterpret_cast<const uint32_t*>(a.q_mu + pl * M + (i - 2)) + (w & 1) : nullptr;
+        });
+    }
+    vg_dma_wait();
+    __syncthreads();
+    if (tid == 0) { k0[0] += jit; k1[1] += jit; qm[0] = y0; qm[1] = y1; }
+    if (role == 2) {
+        for (int e = tid; e < Mz * Mz; e += nt) {       // dK/dvar = K / var
+            const int i = vg_div(e, iMz), j = e - i * Mz;
+            Kd[i * ld + j] /= var;
+        }
+    }
+    if (role == 0) {                         // float32 copy for the gradient assembly (written here, not in stage A:
+        float* Lk32 = a.ws.Lk32 + pl * Mz * Mz;      // stage A of the next step may overlap that kernel)
+        for (int e = tid; e < Mz * Mz; e += nt) {
+            const int i = vg_div(e, iMz), j = e - i * Mz;
+            Lk32[e] = (float)La[i * ld + j];
         }
     }
     __syncthreads();
+    VG_T(l == 0 && p == 0, 201 + 10 * role);
     // prior mean through the two conditioned points and a = Lk^-1 (q_mu - p_mu)  (prior_kl.py:16-35)
-    const double y0 = a.y_u[((size_t)p * 2 + 0) * L + l], y1 = a.y_u[((size_t)p * 2 + 1) * L + l];
     const double k00 = k0[0], k01 = k1[0], k11 = k1[1];
     const double det = k00 * k11 - k01 * k01;
     const double c0 = (k11 * y0 - k01 * y1) / det, c1 = (k00 * y1 - k01 * y0) / det;
     for (int i = tid; i < Mz; i += nt) {
-        const double mi = i == 0 ? y0 : (i == 1 ? y1 : a.q_mu[pl * M + (i - 2)]);
+        const double mi = qm[i];
         if (role == 0) a.ws.m[pl * Mz + i] = (float)mi;
         dl[i] = mi - (k0[i] * c0 + k1[i] * c1);
     }
@@ -402,6 +430,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
         // d KL / d q_mu = (Lk^-T [0, 0, a])[2:]
         for (int k = tid + 2; k < Mz; k += nt)
             a.ws.gkl_qmu[pl * M + (k - 2)] = dot4(Li + k * ld + k, ld, af + k, 1, Mz - k);
+        VG_T(l == 0 && p == 0, 202);
         return;
     }
     // ---- tangent wrt theta: W = Phi(Lk^-1 dK Lk^-T), dLk = Lk W, dC = dLk pad(Q)   (64-bit MFMA products)
@@ -409,15 +438,19 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     // W overwrites dK (its first two columns are kept), dLk overwrites T, and pad(Q) -- prefetched into
     // registers -- takes the place of Lk once Lk has been used.
     for (int i = tid; i < Mz; i += nt) { kd0[i] = Kd[i * ld + 0]; kd1[i] = Kd[i * ld + 1]; }
+    VG_T(l == 0 && p == 0, 204 + 10 * role);
     matmul_f64(MatView{Li, ld, 1}, MatView{Kd, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) { T[r * ld + c] = v; });
     __syncthreads();
+    VG_T(l == 0 && p == 0, 205 + 10 * role);
     double* W = X1;
     matmul_f64(MatView{T, ld, 1}, MatView{Li, 1, ld}, Mp, tid, nt, [&](int r, int c, double v) {
         W[r * ld + c] = c < r ? v : (c == r ? 0.5 * v : 0.0);
     });
     __syncthreads();
+    VG_T(l == 0 && p == 0, 206 + 10 * role);
     matmul_f64(MatView{La, ld, 1}, MatView{W, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) { T[r * ld + c] = v; });
     __syncthreads();
+    VG_T(l == 0 && p == 0, 207 + 10 * role);
     for (int e = tid; e < Mp * ld; e += nt) La[e] = 0.0;
     __syncthreads();
 #pragma unroll
@@ -433,6 +466,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     matmul_f64(MatView{T, ld, 1}, MatView{La, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
         if (r < Mz && c < Mz) CT[(size_t)c * Mz + r] = (float)v;       // stored transposed
     });
+    VG_T(l == 0 && p == 0, 202 + 10 * role);
     // KL tangent: a_dot = Lk^-1 (delta_dot - dLk a),  delta_dot = -d p_mu
     const double d00 = kd0[0], d01 = kd1[0], d11 = kd1[1];
     const double e0 = d00 * c0 + d01 * c1, e1 = d01 * c0 + d11 * c1;        // dKyy c
@@ -447,6 +481,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     for (int i = tid + 2; i < Mz; i += nt) acc += af[i] * dot4(Li + i * ld, 1, v1, 1, i + 1);
     acc = block_sum(acc, red);
     if (tid == 0) (role == 1 ? a.ws.gkl_ell : a.ws.gkl_var)[pl] = acc;
+    VG_T(l == 0 && p == 0, 203 + 10 * role);
 }
 
 template <bool TANGENTS>
@@ -460,7 +495,8 @@ __global__ __launch_bounds__(kCovThreads) void cov_b_kernel(CovArgs a) {
 // Output float32: A4[n][m] = {A, A_ell, A_var, 0} (one 16-byte load per use in the reverse pass)
 // and AT[m][n] for the forward path assembly.
 __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int p, int tid, int nt) {
-    const int M = a.M, Mz = M + 2, N = a.N, L = a.L, D = a.D, ld = Mz + 1;
+    const int M = a.M, Mz = M + 2, N = a.N, L = a.L, D = a.D, ld = (Mz + 2) & ~1;
+    VG_T(tile == 0 && l == 0 && p == 0, 230);
     const float iMz = 1.0f / (float)Mz;
     const size_t pl = (size_t)p * L + l;
     double* Ki = sm;                       // [Mz][ld]
@@ -470,22 +506,33 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
     double* ar = df + kRowTile * Mz;       // [RT][Mz]  A rows
     double* yr = ar + kRowTile * Mz;       // [RT][Mz]
     double* zs = yr + kRowTile * Mz;       // [Mz]
+    double* xs = zs + Mz;                  // [RT] times of this tile
     const double ell = a.ws.ell[pl], var = a.ws.var[pl];
-    const double* Kig = a.ws.Kinv + pl * Mz * Mz;
-    const double* Kdg = a.ws.Kd_ell + pl * Mz * Mz;
-    for (int e = tid; e < Mz * Mz; e += nt) {
-        int i = vg_div(e, iMz), j = e - i * Mz;
-        Ki[i * ld + j] = Kig[e];
-        Kd[i * ld + j] = a.want_dell ? Kdg[e] : 0.0;
-    }
-    for (int i = tid; i < Mz; i += nt) zs[i] = a.Zy[(size_t)i * D + l];
-    __syncthreads();
     const int n0 = tile * kRowTile;
+    {
+        auto all = [](int, int) { return true; };
+        if ((Mz & 1) == 0) {
+            vg_stage_f64_square(Ki, ld, a.ws.Kinv + pl * Mz * Mz, Mz, tid, nt);
+            if (a.want_dell) vg_stage_f64_square(Kd, ld, a.ws.Kd_ell + pl * Mz * Mz, Mz, tid, nt);
+            else for (int e = tid; e < Mz * ld; e += nt) Kd[e] = 0.0;
+        } else {
+            vg_stage_f64(Ki, Mz, ld, a.ws.Kinv + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
+            vg_stage_f64(Kd, Mz, ld, a.ws.Kd_ell + pl * Mz * Mz, a.want_dell ? Mz : 0, Mz, 0, 0, tid, nt, all);
+        }
+        vg_stage_words(zs, 2 * (Mz + kRowTile), tid, nt, [&](int w) -> const void* {
+            const int i = w >> 1;
+            const double* src = i < Mz ? a.Zy + (size_t)i * D + l : a.X + (size_t)min(n0 + i - Mz, N - 1) * D + l;
+            return reinterpret_cast<const uint32_t*>(src) + (w & 1);
+        });
+    }
+    vg_dma_wait();
+    __syncthreads();
+    VG_T(tile == 0 && l == 0 && p == 0, 232);
     for (int e = tid; e < kRowTile * Mz; e += nt) {
         int r = vg_div(e, iMz), m = e - r * Mz, n = n0 + r;
         double k = 0.0, dk = 0.0;
         if (n < N) {
-            double rr = fabs(a.X[(size_t)n * D + l] - zs[m]) / ell;
+            double rr = fabs(xs[r] - zs[m]) / ell;
             double ex = exp(-kSqrt5 * rr);
             k = var * (1.0 + kSqrt5 * rr + (5.0 / 3.0) * rr * rr) * ex;
             dk = var * ex * (5.0 * rr * rr / (3.0 * ell)) * (1.0 + kSqrt5 * rr);
@@ -493,11 +540,13 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
         kf[e] = k; df[e] = dk;
     }
     __syncthreads();
+    VG_T(tile == 0 && l == 0 && p == 0, 233);
     for (int e = tid; e < kRowTile * Mz; e += nt) {
         int r = vg_div(e, iMz), m = e - r * Mz;
         ar[e] = dot4(kf + r * Mz, 1, Ki + m, ld, Mz);
     }
     __syncthreads();
+    VG_T(tile == 0 && l == 0 && p == 0, 234);
     float4* A4 = reinterpret_cast<float4*>(a.ws.A4) + pl * N * Mz;
     float* AT = a.ws.AT + pl * N * Mz;
     float av_keep[2] = {0.f, 0.f};
@@ -510,6 +559,7 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
         if (cnt < 2) av_keep[cnt] = (float)(a.jitter / var * v);
     }
     __syncthreads();
+    VG_T(tile == 0 && l == 0 && p == 0, 235);
     cnt = 0;
     for (int e = tid; e < kRowTile * Mz; e += nt, ++cnt) {
         int r = vg_div(e, iMz), m = e - r * Mz, n = n0 + r;
@@ -519,6 +569,7 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
         A4[(size_t)n * Mz + m] = make_float4((float)ar[e], (float)s, av, 0.f);
         AT[(size_t)m * N + n] = (float)ar[e];
     }
+    VG_T(tile == 0 && l == 0 && p == 0, 231);
 }
 
 // =================================================================================================
@@ -542,6 +593,7 @@ __device__ __forceinline__ void features_body(const FeatArgs& a, int bx, int by,
     const double *X = a.X, *Zy = a.Zy;
     const float *omega = a.omega, *beta = a.beta;
     float *Phi = a.Phi, *dPhi = a.dPhi;
+    VG_T(bx == 0 && by == 0 && bz == 0, 130);
     const int b = bx * kBlock + threadIdx.x;
     const int l = bz % L, p = bz / L;
     const int J = N + Mz;
@@ -567,6 +619,8 @@ __device__ __forceinline__ void features_body(const FeatArgs& a, int bx, int by,
         Phi[o] = c * __builtin_amdgcn_cosf(rev);
         if (dPhi) dPhi[o] = c * __builtin_amdgcn_sinf(rev) * proj * inv_ell * inv_ell;
     }
+    VG_T(bx == 0 && by == 0 && bz == 0, 131);
+    VG_T(bx == 0 && j1 == J && bz == L - 1, 135);
 }
 
 __global__ __launch_bounds__(kBlock) void features_kernel(FeatArgs a) {
@@ -603,6 +657,7 @@ __device__ __forceinline__ void prior_gemm_body(const GemmArgs& a, int bx, int b
     const int l = z % L, p = z / L;
     const int s0 = (by * 4 + wave) * 16;
     const int j0 = bx * (16 * kNT);
+    VG_T(bx == 0 && by == 0 && bz == 0, 240);
     if (s0 >= S) return;
     const float* Bm = sel == 0 ? a.Phi : a.dPhi;
     float* Out = (sel == 0 ? a.F0 : a.H) + (size_t)sk * a.slab;
@@ -677,6 +732,7 @@ __device__ __forceinline__ void prior_gemm_body(const GemmArgs& a, int bx, int b
             for (int t = 0; t < kNT; ++t) b_cur[t] = b_nxt[t];
         }
     }
+    VG_T(bx == 0 && by == 0 && bz == 0, 241);
 #ifdef VGPMP_BISECT
     if (a.dbg == 1) { if (acc[0][0] + acc[1][1] + acc[2][2] == 123.456f) Out[0] = 1.f; return; }
 #endif
@@ -691,6 +747,8 @@ __device__ __forceinline__ void prior_gemm_body(const GemmArgs& a, int bx, int b
             if (s < S) Out[(((size_t)p * S + s) * L + l) * J + jc] = acc[t][q];
         }
     }
+    VG_T(bx == 0 && by == 0 && bz == 0, 242);
+    VG_T(bx == 2 && by == 1 && l == L - 1 && sk == SK - 1 && sel == nsel - 1, 245);
 }
 
 template <int KS>
@@ -845,35 +903,77 @@ __device__ __forceinline__ float read_slabs(const float* base, size_t off, size_
 // All operands of a workgroup are staged into LDS by ONE wave of independent coalesced loads (these
 // launches are latency bound: every dependent global access costs ~0.3-0.7 us), then the loops run
 // out of LDS.  Code is kept rolled: cold instruction fetch is the other fixed cost of tiny launches.
-template <int SK, int SC>
+// sum of the SK split-K slabs of an LDS image [SK][n]: fixed-order tree
+template <int SK>
+__device__ __forceinline__ float sum_slabs_lds(const float* raw, int e, int n) {
+    float v[SK];
+#pragma unroll
+    for (int k = 0; k < SK; ++k) v[k] = raw[k * n + e];
+#pragma unroll
+    for (int w = SK / 2; w > 0; w >>= 1)
+#pragma unroll
+        for (int k = 0; k < w; ++k) v[k] += v[k + w];
+    return v[0];
+}
+
+// Every operand of a workgroup goes global -> LDS by DMA (vg_stage_*), all requests in flight together,
+// then the loops run out of LDS.  Launches of this size are latency bound: what counts is the number of
+// dependent memory round trips, here one.
+// RAW: the split-K slabs are staged as they are ([SK][SC][J] of LDS) and summed from LDS; otherwise (LDS
+// too small for that) they are summed from registers while the other operands arrive.
+template <int SK, int SC, bool RAW>
 __device__ __forceinline__ void paths_fwd_body(const PathArgs& a, float* smf, int ch, int l, int p) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int S = a.S, N = a.N, Mz = a.Mz, L = a.L, J = N + Mz, ld = Mz + 1;
-    const float iMz = 1.0f / (float)Mz, iN = 1.0f / (float)N, iJ = 1.0f / (float)J;
+    const float iMz = 1.0f / (float)Mz, iN = 1.0f / (float)N, iJ = 1.0f / (float)J, ild = 1.0f / (float)ld;
     const size_t pl = (size_t)p * L + l;
-    float* Cs = smf;                   // [Mz][ld]
-    float* ATs = Cs + Mz * ld;         // [Mz][N]
-    float* es = ATs + Mz * N;          // [SC][Mz]
-    float* e2s = es + SC * Mz;      // [SC][Mz]
-    float* f0s = e2s + SC * Mz;     // [SC][J]   prior draws (split-K slabs summed)
-    float* rs = f0s + SC * J;       // [SC][Mz]
+    float* cur = smf;
+    auto take = [&](int n) { float* q = cur; cur += (n + 3) & ~3; return q; };      // 16-byte aligned regions
+    float* Cs = take(Mz * ld);         // [Mz][ld]
+    float* ATs = take(Mz * N);         // [Mz][N]
+    float* es = take(2 * SC * Mz);     // [SC][Mz] eps, then eps2
+    float* e2s = es + SC * Mz;
+    float* ms = take(Mz);              // [Mz]
+    float* rs = take(SC * Mz);         // [SC][Mz]
+    float* f0s = take(SC * J);         // [SC][J]   prior draws (split-K slabs summed)
+    float* raw = take(0);              // [SK][SC][J] the slabs as they arrive
     const int s_base = ch * SC;
-    for (int e = tid; e < Mz * Mz; e += nt) Cs[(vg_div(e, iMz)) * ld + (e - vg_div(e, iMz) * Mz)] = a.C[pl * Mz * Mz + e];
-    for (int e = tid; e < Mz * N; e += nt) ATs[e] = a.AT[pl * N * Mz + e];
-    for (int e = tid; e < SC * Mz; e += nt) {
-        const int sl = vg_div(e, iMz), k = e - sl * Mz, s = min(s_base + sl, S - 1);
-        const size_t o = (((size_t)p * S + s) * Mz + k) * L + l;
-        es[e] = a.eps[o];
-        e2s[e] = a.eps2[o];
+    VG_T(ch == 0 && l == 0 && p == 0, 300);
+    {
+        const float* Cg = a.C + pl * Mz * Mz;
+        vg_stage_words(Cs, Mz * ld, tid, nt, [&](int i) -> const void* {
+            const int r = vg_div(i, ild), c = i - r * ld;
+            return Cg + r * Mz + min(c, Mz - 1);                       // the pad column repeats the last one
+        });
+        const float* ATg = a.AT + pl * N * Mz;
+        vg_stage_rows(ATs, Mz, N, tid, nt, [&](int r) -> const float* { return ATg + (size_t)r * N; });
+        vg_stage_words(es, 2 * SC * Mz, tid, nt, [&](int i) -> const void* {
+            const int second = i >= SC * Mz, e = second ? i - SC * Mz : i;
+            const int sl = vg_div(e, iMz), k = e - sl * Mz, s = min(s_base + sl, S - 1);
+            return (second ? a.eps2 : a.eps) + (((size_t)p * S + s) * Mz + k) * L + l;
+        });
+        vg_stage_words(ms, Mz, tid, nt, [&](int i) -> const void* { return a.m + pl * Mz + i; });
+        if (RAW)
+            vg_stage_rows(raw, SK * SC, J, tid, nt, [&](int r) -> const float* {
+                const int k = r / SC, s = min(s_base + (r - k * SC), S - 1);
+                return a.F0 + (size_t)k * a.slab + (((size_t)p * S + s) * L + l) * J;
+            });
+        else
+            for (int e = tid; e < SC * J; e += nt) {
+                const int sl = vg_div(e, iJ), j = e - sl * J, s = min(s_base + sl, S - 1);
+                f0s[e] = read_slabs<SK>(a.F0, (((size_t)p * S + s) * L + l) * J + j, a.slab);
+            }
     }
-    for (int e = tid; e < SC * J; e += nt) {
-        const int sl = vg_div(e, iJ), j = e - sl * J, s = min(s_base + sl, S - 1);
-        f0s[e] = read_slabs<SK>(a.F0, (((size_t)p * S + s) * L + l) * J + j, a.slab);
-    }
+    vg_dma_wait();
     __syncthreads();
+    VG_T(ch == 0 && l == 0 && p == 0, 301);
+    if (RAW) {
+        for (int e = tid; e < SC * J; e += nt) f0s[e] = sum_slabs_lds<SK>(raw, e, SC * J);
+        __syncthreads();
+    }
     for (int e = tid; e < SC * Mz; e += nt) {
         const int sl = vg_div(e, iMz), mi = e - sl * Mz, s = s_base + sl;
-        float u = a.m[pl * Mz + mi];
+        float u = ms[mi];
         for (int k = 0; k <= mi; ++k) u = fmaf(Cs[mi * ld + k], es[sl * Mz + k], u);
         const float r = u - f0s[sl * J + N + mi] - a.sqrt_jitter * e2s[e];
         rs[e] = r;
@@ -886,12 +986,8 @@ __device__ __forceinline__ void paths_fwd_body(const PathArgs& a, float* smf, in
         for (int k = 0; k < Mz; ++k) v = fmaf(ATs[k * N + n], rs[sl * Mz + k], v);
         if (s < S) a.f[(((size_t)p * S + s) * L + l) * N + n] = v;
     }
-}
-
-template <int SK, int SC>
-__global__ __launch_bounds__(kBlock) void paths_fwd_kernel(PathArgs a) {
-    extern __shared__ float smf[];
-    paths_fwd_body<SK, SC>(a, smf, blockIdx.x, blockIdx.y, blockIdx.z);
+    VG_T(ch == 0 && l == 0 && p == 0, 302);
+    VG_T(ch == a.NC - 1 && l == L - 1 && p == 0, 305);
 }
 
 // Reverse of the path assembly over one chunk of samples.  With G = dloss/df:
@@ -899,48 +995,75 @@ __global__ __launch_bounds__(kBlock) void paths_fwd_kernel(PathArgs a) {
 //   hyper-parameters by dot products with the forward-mode tangents of the covariance kernels:
 //   s_ell = <R, G A_ell> + <dR, C_ell eps> + <G, H_X> - <dR, H_Z>
 //   s_var = <R, G A_var> + <dR, C_var eps> ;  s_rff = <G, F0_X> - <dR, F0_Z>   (x 1/(2 var) later)
-template <int SK, int SC>
-__global__ __launch_bounds__(kBlock) void paths_bwd_kernel(PathArgs a) {
+template <int SK, bool RAW>
+__global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
+    constexpr int SC = 8;
     extern __shared__ float smf[];
     __shared__ float red[3][kBlock / VG_WAVE];
     const int ch = blockIdx.x, l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
     const int S = a.S, N = a.N, Mz = a.Mz, L = a.L, J = N + Mz;
     const float iMz = 1.0f / (float)Mz, iN = 1.0f / (float)N, iJ = 1.0f / (float)J;
     const size_t pl = (size_t)p * L + l;
-    float4* A4s = reinterpret_cast<float4*>(smf);      // [N][Mz] {A, A_ell, A_var, -}
-    float* Ces = smf + (size_t)4 * N * Mz;             // [Mz][Mz] (dC/dell)^T
-    float* Cvs = Ces + Mz * Mz;                         // [Mz][Mz] (dC/dvar)^T
-    float* Gs = Cvs + Mz * Mz;                          // [SC][N]
-    float* f0s = Gs + SC * N;                        // [SC][J]
-    float* hs = f0s + SC * J;                        // [SC][J]
-    float* Rs = hs + SC * J;                         // [SC][Mz]
-    float* Es = Rs + SC * Mz;                        // [SC][Mz]
-    float* dRs = Es + SC * Mz;                       // [SC][Mz]
+    float* cur = smf;
+    auto take = [&](int n) { float* q = cur; cur += (n + 3) & ~3; return q; };      // 16-byte aligned regions
+    float4* A4s = reinterpret_cast<float4*>(take(4 * N * Mz));      // [N][Mz] {A, A_ell, A_var, -}
+    float* Ces = take(2 * Mz * Mz);                  // [Mz][Mz] (dC/dell)^T, then (dC/dvar)^T
+    float* Cvs = Ces + Mz * Mz;
+    float* Gs = take(SC * N);                        // [SC][N]
+    float* f0s = take(SC * J);                       // [SC][J]
+    float* hs = take(SC * J);                        // [SC][J]
+    float* Rs = take(SC * Mz);                       // [SC][Mz]
+    float* Es = take(SC * Mz);                       // [SC][Mz]
+    float* dRs = take(SC * Mz);                      // [SC][Mz]
+    float* raw = take(0);                            // [2][SK][SC][J] slabs of F0 and H as they arrive (RAW)
     const int s_base = ch * SC;
+    VG_T(ch == 0 && l == 0 && p == 0, 500);
     {
-        const float4* A4 = a.A4 + pl * N * Mz;
-        for (int e = tid; e < N * Mz; e += nt) A4s[e] = A4[e];
-        for (int e = tid; e < Mz * Mz; e += nt) {
-            Ces[e] = a.want_dell ? a.CT_ell[pl * Mz * Mz + e] : 0.f;
-            Cvs[e] = a.CT_var[pl * Mz * Mz + e];
-        }
-        for (int e = tid; e < SC * N; e += nt) {
-            const int sl = vg_div(e, iN), n = e - sl * N, s = s_base + sl;
-            Gs[e] = s < S ? a.G[(((size_t)p * S + s) * L + l) * N + n] : 0.f;
-        }
-        for (int e = tid; e < SC * J; e += nt) {
-            const int sl = vg_div(e, iJ), j = e - sl * J, s = min(s_base + sl, S - 1);
-            const size_t fo = (((size_t)p * S + s) * L + l) * J + j;
-            f0s[e] = read_slabs<SK>(a.F0, fo, a.slab);
-            hs[e] = a.want_dell ? read_slabs<SK>(a.H, fo, a.slab) : 0.f;
-        }
-        for (int e = tid; e < SC * Mz; e += nt) {
-            const int sl = vg_div(e, iMz), mi = e - sl * Mz, s = s_base + sl;
-            Rs[e] = s < S ? a.R[(((size_t)p * S + s) * L + l) * Mz + mi] : 0.f;
-            Es[e] = s < S ? a.eps[(((size_t)p * S + s) * Mz + mi) * L + l] : 0.f;
+        vg_stage_16(A4s, a.A4 + pl * N * Mz, N * Mz, tid, nt);
+        const float* Ce = a.CT_ell + pl * Mz * Mz;
+        const float* Cv = a.CT_var + pl * Mz * Mz;
+        const bool dell = a.want_dell != 0;
+        vg_stage_rows(Ces, 2 * Mz, Mz, tid, nt, [&](int r) -> const float* {
+            return r < Mz ? (dell ? Ce + (size_t)r * Mz : nullptr) : Cv + (size_t)(r - Mz) * Mz;
+        });
+        vg_stage_rows(Gs, SC, N, tid, nt, [&](int r) -> const float* {
+            const int s = s_base + r;
+            return s < S ? a.G + (((size_t)p * S + s) * L + l) * N : nullptr;              // zero beyond S
+        });
+        vg_stage_rows(Rs, SC, Mz, tid, nt, [&](int r) -> const float* {
+            const int s = s_base + r;
+            return s < S ? a.R + (((size_t)p * S + s) * L + l) * Mz : nullptr;
+        });
+        vg_stage_words(Es, SC * Mz, tid, nt, [&](int i) -> const void* {
+            const int sl = vg_div(i, iMz), mi = i - sl * Mz, s = s_base + sl;
+            return s < S ? a.eps + (((size_t)p * S + s) * Mz + mi) * L + l : nullptr;
+        });
+        if (RAW) {
+            vg_stage_rows(raw, (dell ? 2 : 1) * SK * SC, J, tid, nt, [&](int r) -> const float* {
+                const int second = r >= SK * SC, rr = second ? r - SK * SC : r;
+                const int k = rr / SC, s = min(s_base + (rr - k * SC), S - 1);
+                return (second ? a.H : a.F0) + (size_t)k * a.slab + (((size_t)p * S + s) * L + l) * J;
+            });
+        } else {
+            for (int e = tid; e < SC * J; e += nt) {
+                const int sl = vg_div(e, iJ), j = e - sl * J, s = min(s_base + sl, S - 1);
+                const size_t fo = (((size_t)p * S + s) * L + l) * J + j;
+                f0s[e] = read_slabs<SK>(a.F0, fo, a.slab);
+                hs[e] = dell ? read_slabs<SK>(a.H, fo, a.slab) : 0.f;
+            }
         }
     }
+    vg_dma_wait();
     __syncthreads();
+    if (RAW) {
+        const int nsl = SK * SC * J;
+        for (int e = tid; e < SC * J; e += nt) {
+            f0s[e] = sum_slabs_lds<SK>(raw, e, SC * J);
+            hs[e] = a.want_dell ? sum_slabs_lds<SK>(raw + nsl, e, SC * J) : 0.f;
+        }
+        __syncthreads();
+    }
+    VG_T(ch == 0 && l == 0 && p == 0, 501);
     VG_STOP(a, 1);
     float se = 0.f, sv = 0.f, sr = 0.f;
     for (int e = tid; e < SC * Mz; e += nt) {
@@ -973,6 +1096,7 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_kernel(PathArgs a) {
         se = fmaf(gv, hs[sl * J + n], se);
     }
     __syncthreads();
+    VG_T(ch == 0 && l == 0 && p == 0, 502);
     VG_STOP(a, 3);
     float* out = a.part + (pl * a.NC + ch) * a.part_len;
     for (int mi = tid; mi < Mz; mi += nt) {
@@ -996,6 +1120,8 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_kernel(PathArgs a) {
         float* os = oC + (size_t)Mz * Mz;
         os[0] = t0; os[1] = t1; os[2] = t2; os[3] = 0.f;
     }
+    VG_T(ch == 0 && l == 0 && p == 0, 503);
+    VG_T(ch == a.NC - 1 && l == L - 1 && p == 0, 505);
 }
 
 // =================================================================================================
@@ -1042,6 +1168,7 @@ __device__ __forceinline__ double sum_chunks(const float* part, size_t part_len,
 // one wave per problem, one lane per latent
 __global__ __launch_bounds__(64) void hyper_kernel(HyperArgs h) {
     const int p = blockIdx.x, l = threadIdx.x;
+    VG_T(p == 0, 600);
     double lr_t = h.lr_t;
     if (h.do_adam && h.ctr) {
         const double t = (double)*h.ctr;
@@ -1063,11 +1190,13 @@ __global__ __launch_bounds__(64) void hyper_kernel(HyperArgs h) {
         if (h.trainable & VGPMP_TRAIN_LENGTHSCALES) adam_update(h.p_ell + pl, h.m_ell + pl, h.v_ell + pl, g_ell, lr_t);
         if (h.trainable & VGPMP_TRAIN_KERNEL_VARIANCE) adam_update(h.p_var + pl, h.m_var + pl, h.v_var + pl, g_var, lr_t);
     }
+    VG_T(p == 0, 601);
 }
 
 __device__ __forceinline__ void final_body(const FinalArgs& b, double* sm, int l, int p) {
     VG_STOP(b, 7);
     const int tid = threadIdx.x, nt = blockDim.x;
+    VG_T(l == 0 && p == 0, 110);
     const int M = b.M, Mz = M + 2, L = b.L;
     const float iM = 1.0f / (float)M;
     const size_t pl = (size_t)p * L + l;
@@ -1086,6 +1215,7 @@ __device__ __forceinline__ void final_body(const FinalArgs& b, double* sm, int l
     }
     VG_STOP(b, 6);
     __syncthreads();
+    VG_T(l == 0 && p == 0, 111);
     VG_STOP(b, 1);
     const double kls = b.kl_scale;
     double* gQ = b.g_qsqrt + pl * M * M;
@@ -1109,6 +1239,7 @@ __device__ __forceinline__ void final_body(const FinalArgs& b, double* sm, int l
     VG_STOP(b, 2);
     double* gm = b.g_qmu + pl * M;
     for (int i = tid; i < M; i += nt) gm[i] = dmv[i + 2] + kls * b.gkl_qmu[pl * M + i];
+    VG_T(l == 0 && p == 0, 112);
     if (b.do_adam) {
         __syncthreads();           // gradients above are read back below (same workgroup, global memory)
         // ONE update loop over the variational variables of this latent: q_mu | q_sqrt (lower)
@@ -1134,6 +1265,7 @@ __device__ __forceinline__ void final_body(const FinalArgs& b, double* sm, int l
         kk = vg_wave_sum(kk);
         if (tid == 0) { b.out_lik[p] = b.lik_scale * s; b.out_kl[p] = kls * kk; }
     }
+    VG_T(l == 0 && p == 0, 113);
 }
 
 __global__ __launch_bounds__(kBlock) void final_kernel(FinalArgs b) {
@@ -1166,6 +1298,12 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(size_t n, double* __restri
         if (e % tril_M > e / tril_M) return;
     }
     adam_update(x + i, m + i, v + i, g[i], lr_t);
+}
+
+template <int SK, bool RAW>
+__global__ __launch_bounds__(kBlock) void paths_fwd_sc8(PathArgs a) {
+    extern __shared__ float smf[];
+    paths_fwd_body<SK, 8, RAW>(a, smf, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // =================================================================================================
@@ -1230,7 +1368,7 @@ struct Stage3Args {
     int n_path, n_basis, basis_gx, w_gx;
     int skip;
 };
-template <int SK>
+template <int SK, bool RAW>
 __global__ __launch_bounds__(kBlock) void stage3_kernel(Stage3Args a) {
     extern __shared__ float smf[];
     int b = blockIdx.x;
@@ -1238,7 +1376,7 @@ __global__ __launch_bounds__(kBlock) void stage3_kernel(Stage3Args a) {
         if (a.skip & 1) return;
         const int ch = b % a.path.NC;
         b /= a.path.NC;
-        paths_fwd_body<SK, 8>(a.path, smf, ch, b % a.path.L, b / a.path.L);
+        paths_fwd_body<SK, 8, RAW>(a.path, smf, ch, b % a.path.L, b / a.path.L);
         return;
     }
     b -= a.n_path;
@@ -1469,27 +1607,34 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
 #endif
     // ---- dynamic LDS sizes and kernel variants --------------------------------------------------
     const int Mp = (Mz + 15) & ~15;
-    const size_t lds_cov = ((size_t)4 * Mp * (Mp + 1) + 7 * Mp) * sizeof(double);
+    const size_t lds_cov = ((size_t)4 * Mp * (Mp + 2) + 8 * Mp) * sizeof(double);
     const size_t lds_cov_a = ((size_t)4 * Mp * (Mp + 1) + 2 * Mp) * sizeof(double);
-    const size_t lds_rows = ((size_t)2 * Mz * (Mz + 1) + (size_t)4 * kRowTile * Mz + Mz) * sizeof(double);
+    const size_t lds_rows = ((size_t)2 * Mz * ((Mz + 2) & ~1) + (size_t)4 * kRowTile * Mz + Mz + kRowTile) * sizeof(double);
     const size_t lds_cov_b = lds_cov > lds_rows ? lds_cov : lds_rows;
-    const size_t lds_pf = ((size_t)Mz * (Mz + 1) + (size_t)Mz * N + (size_t)3 * SC * Mz + (size_t)SC * J) * sizeof(float);
-    const size_t lds_pb = ((size_t)4 * N * Mz + (size_t)2 * Mz * Mz + (size_t)SC * N + (size_t)2 * SC * J +
-                           (size_t)3 * SC * Mz) * sizeof(float);
+    // path kernels: operands + (when it fits) the raw split-K slabs of the prior draws
+    const size_t raw_f = (size_t)SK * SC * J * sizeof(float);
+    size_t lds_pf = ((size_t)Mz * (Mz + 1) + (size_t)Mz * N + (size_t)3 * SC * Mz + Mz + (size_t)SC * J + 6 * 4) * sizeof(float);
+    size_t lds_pb = ((size_t)4 * N * Mz + (size_t)2 * Mz * Mz + (size_t)SC * N + (size_t)2 * SC * J +
+                     (size_t)3 * SC * Mz + 9 * 4) * sizeof(float);
+    const bool raw_fwd = lds_pf + raw_f <= 64 * 1024, raw_bwd = lds_pb + 2 * raw_f <= 160 * 1024;
+    if (raw_fwd) lds_pf += raw_f;
+    if (raw_bwd) lds_pb += 2 * raw_f;
     const size_t lds_fin = ((size_t)Mz * Mz + Mz) * sizeof(double) + (size_t)Mz * Mz * sizeof(float);
     const size_t lds_s1 = lds_cov_a > lds_fin ? lds_cov_a : lds_fin;
     const void* fn_cov_b = backward ? (const void*)cov_b_kernel<true> : (const void*)cov_b_kernel<false>;
     const bool k8 = B / SK == 128;      // B = 1024 with 8 K-slices: all operands of a workgroup in one request
     const void* fn_s2 = backward ? (k8 ? (const void*)stage2_kernel<true, 8> : (const void*)stage2_kernel<true, 0>)
                                  : (k8 ? (const void*)stage2_kernel<false, 8> : (const void*)stage2_kernel<false, 0>);
-    const void* fn_pf = SC == 32 ? (const void*)paths_fwd_kernel<1, 32>
-                      : SK == 1 ? (const void*)paths_fwd_kernel<1, 8> : SK == 2 ? (const void*)paths_fwd_kernel<2, 8>
-                      : SK == 4 ? (const void*)paths_fwd_kernel<4, 8> : (const void*)paths_fwd_kernel<8, 8>;
-    const void* fn_s3 = SK == 1 ? (const void*)stage3_kernel<1> : SK == 2 ? (const void*)stage3_kernel<2>
-                      : SK == 4 ? (const void*)stage3_kernel<4> : (const void*)stage3_kernel<8>;
-    const void* fn_pb = SC == 32 ? (const void*)paths_bwd_kernel<1, 32>
-                      : SK == 1 ? (const void*)paths_bwd_kernel<1, 8> : SK == 2 ? (const void*)paths_bwd_kernel<2, 8>
-                      : SK == 4 ? (const void*)paths_bwd_kernel<4, 8> : (const void*)paths_bwd_kernel<8, 8>;
+    if (SC != 8) return VGPMP_E_SHAPE;
+#define VG_PICK(kernel, raw)                                                                                        \
+    (SK == 1 ? (raw ? (const void*)kernel<1, true> : (const void*)kernel<1, false>)                                 \
+     : SK == 2 ? (raw ? (const void*)kernel<2, true> : (const void*)kernel<2, false>)                               \
+     : SK == 4 ? (raw ? (const void*)kernel<4, true> : (const void*)kernel<4, false>)                               \
+               : (raw ? (const void*)kernel<8, true> : (const void*)kernel<8, false>))
+    const void* fn_pf = VG_PICK(paths_fwd_sc8, raw_fwd);
+    const void* fn_s3 = VG_PICK(stage3_kernel, raw_fwd);
+    const void* fn_pb = VG_PICK(paths_bwd_sc8, raw_bwd);
+#undef VG_PICK
     if ((rc = set_dyn_lds(fn_pb, lds_pb))) return rc;
     if (fused) {
         if ((rc = set_dyn_lds((const void*)stage1_kernel, lds_s1))) return rc;

@@ -33,6 +33,94 @@ __device__ __forceinline__ double vg_wave_sum(double v) {
     return v;
 }
 
+// ---- global -> LDS staging without registers (global_load_lds, gfx950) ----------------------------
+// A rolled `lds[e] = g[e]` loop compiles to load / wait / store per iteration: one memory round trip per
+// 256 elements (measured 10 us for the 74 KB of the reverse pass; 3 us with the form below).  Here every
+// request of the workgroup is issued back to back and lands in LDS by itself; ONE vg_dma_wait() + barrier
+// before the first read.  Hardware rule: a wave instruction writes lane k at wave_base + k * size, so the
+// LDS image is linear in the lane index; the GLOBAL address is per lane (gathers, padding and transposes
+// go on the source side).
+typedef __attribute__((address_space(1))) const void vg_gmem;
+typedef __attribute__((address_space(3))) void vg_lmem;
+__device__ __forceinline__ void vg_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0)
+
+// LDS words [0, nwords): word i comes from the 4-byte global address map(i); map(i) == nullptr stores 0.
+template <typename Map>
+__device__ __forceinline__ void vg_stage_words(void* lds, int nwords, int tid, int nt, Map map) {
+    uint32_t* w = reinterpret_cast<uint32_t*>(lds);
+    const int lane = tid & (VG_WAVE - 1);
+    for (int c = (tid & ~(VG_WAVE - 1)); c < nwords; c += nt) {
+        const int i = c + lane;
+        if (i < nwords) {
+            const void* g = map(i);
+            if (g) __builtin_amdgcn_global_load_lds((vg_gmem*)g, (vg_lmem*)(w + c), 4, 0, 0);
+            else w[i] = 0u;
+        }
+    }
+}
+// LDS image [nrows][row_floats] (linear); row r comes from the global row row_src(r), nullptr = a row of zeros.
+// Rows whose length is a multiple of 4 floats move in 16-byte units (sources and `lds` must then be 16-byte
+// aligned -- true for every tensor here whose inner extents are multiples of 4); other lengths fall back to words.
+template <typename Map>
+__device__ __forceinline__ void vg_stage_rows(void* lds, int nrows, int row_floats, int tid, int nt, Map row_src) {
+    const int lane = tid & (VG_WAVE - 1);
+    if ((row_floats & 3) == 0) {
+        const int upr = row_floats >> 2, total = nrows * upr;
+        const float iupr = 1.0f / (float)upr;
+        for (int c = (tid & ~(VG_WAVE - 1)); c < total; c += nt) {
+            const int i = c + lane;
+            if (i < total) {
+                const int r = (int)(((float)i + 0.5f) * iupr), u = i - r * upr;
+                const float* g = row_src(r);
+                if (g) __builtin_amdgcn_global_load_lds((vg_gmem*)(g + 4 * u), (vg_lmem*)((char*)lds + 16 * (size_t)c), 16, 0, 0);
+                else reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    } else {
+        const float irf = 1.0f / (float)row_floats;
+        vg_stage_words(lds, nrows * row_floats, tid, nt, [&](int i) -> const void* {
+            const int r = (int)(((float)i + 0.5f) * irf);
+            const float* g = row_src(r);
+            return g ? g + (i - r * row_floats) : nullptr;
+        });
+    }
+}
+// Float64 matrix [rows x cols] (row-major, dense) -> LDS image with row stride `ld` doubles, zero outside
+// [0, rows) x [0, cols) up to `prows` rows; `row0`/`col0` shift the matrix inside the image (padding in front).
+// keep(r, c) == false leaves a zero (triangular masks).  Two 4-byte requests per double.
+template <typename Keep>
+__device__ __forceinline__ void vg_stage_f64(double* lds, int prows, int ld, const double* g, int rows, int cols,
+                                             int row0, int col0, int tid, int nt, Keep keep) {
+    const float ild = 1.0f / (float)ld;
+    vg_stage_words(lds, 2 * prows * ld, tid, nt, [&](int w) -> const void* {
+        const int d = w >> 1, r = (int)(((float)d + 0.5f) * ild), c = d - r * ld;
+        const int gr = r - row0, gc = c - col0;
+        if (gr < 0 || gc < 0 || gr >= rows || gc >= cols || !keep(gr, gc)) return nullptr;
+        return reinterpret_cast<const uint32_t*>(g + (size_t)gr * cols + gc) + (w & 1);
+    });
+}
+// Dense float64 n x n matrix (n even, 16-byte aligned) -> LDS rows of `ld` doubles (ld even, >= n), in 16-byte
+// units; the pad units of a row repeat its last valid unit (never read by the consumers, no out-of-range access).
+__device__ __forceinline__ void vg_stage_f64_square(double* lds, int ld, const double* g, int n, int tid, int nt) {
+    const int lane = tid & (VG_WAVE - 1), upr = ld >> 1, total = n * upr, last = (n >> 1) - 1;
+    const float iupr = 1.0f / (float)upr;
+    for (int c = (tid & ~(VG_WAVE - 1)); c < total; c += nt) {
+        const int i = c + lane;
+        if (i < total) {
+            const int r = (int)(((float)i + 0.5f) * iupr), u = min(i - r * upr, last);
+            __builtin_amdgcn_global_load_lds((vg_gmem*)(g + (size_t)r * n + 2 * u), (vg_lmem*)((char*)lds + 16 * (size_t)c), 16, 0, 0);
+        }
+    }
+}
+// contiguous copy of n16 16-byte units (both sides 16-byte aligned)
+__device__ __forceinline__ void vg_stage_16(void* lds, const void* g, int n16, int tid, int nt) {
+    const int lane = tid & (VG_WAVE - 1);
+    for (int c = (tid & ~(VG_WAVE - 1)); c < n16; c += nt)
+        if (c + lane < n16)
+            __builtin_amdgcn_global_load_lds((vg_gmem*)((const char*)g + 16 * (size_t)(c + lane)),
+                                             (vg_lmem*)((char*)lds + 16 * (size_t)c), 16, 0, 0);
+}
+
 // ---- nearest-voxel signed distance lookup (utils/sdf_utils.py:62-66,73-76) ------------------
 // Index arithmetic in float64 in the reference's operation order ((p - offset) - origin) / delta,
 // truncate, clamp, so that indices are bit-identical to the float64 reference on equal inputs.
@@ -99,6 +187,33 @@ int vg_launch_sdf_query(const vgpmp_sdf* sdf, const double* rel, int64_t n, int3
 int vg_launch_log_prob_impl(const vgpmp_robot* rb, int dof, const vgpmp_sdf* sdf, const float* g, int64_t n,
                             float* logp, float* dlogp, hipStream_t st);
 // ELBO-path likelihood: f [P,S,L,N] -> G [P,S,L,N] (dloss/df), logp [P,S,N], lik_partial [P, nblk]
+// ---- measurement builds (-DVGPMP_BISECT): in-kernel time stamps -----------------------------------
+// VG_T(cond, id) records (id, 100 MHz wall clock) from thread 0 of the workgroups that satisfy `cond`,
+// giving a timeline of one step across launches (tools/step_trace.py).  Compiled out of the product.
+#ifdef VGPMP_BISECT
+static __device__ unsigned long long vg_tr_buf[2 * 4096];
+static __device__ unsigned int vg_tr_cnt;
+__device__ __forceinline__ void vg_trace_stamp(int id) {
+    const unsigned k = atomicAdd(&vg_tr_cnt, 1u);
+    if (k < 4096u) { vg_tr_buf[2 * k] = (unsigned long long)id; vg_tr_buf[2 * k + 1] = wall_clock64(); }
+}
+#define VG_T(cond, id) do { if (threadIdx.x == 0 && (cond)) vg_trace_stamp(id); } while (0)
+static int vg_trace_take(unsigned long long* host, int cap) {      // copies and clears this translation unit's buffer
+    unsigned n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(vg_tr_cnt), sizeof(n)) != hipSuccess) return -1;
+    if (n > 4096u) n = 4096u;
+    if ((int)n > cap) n = (unsigned)cap;
+    if (n && hipMemcpyFromSymbol(host, HIP_SYMBOL(vg_tr_buf), (size_t)n * 16) != hipSuccess) return -1;
+    const unsigned zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(vg_tr_cnt), &zero, sizeof(zero));
+    return (int)n;
+}
+int vg_trace_take_gp(unsigned long long* host, int cap);
+int vg_trace_take_lik(unsigned long long* host, int cap);
+#else
+#define VG_T(cond, id) do { } while (0)
+#endif
+
 int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const float* f, int P, int S, int L, int N,
                            float scale, float* G, float* logp, float* lik_partial, int* nblk_out, hipStream_t st);
 int vg_loglik_blocks_per_problem(int S, int N);
