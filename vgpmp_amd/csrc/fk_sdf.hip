@@ -301,6 +301,169 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_kernel(const vgpmp_rob
     VG_T(blockIdx.x == gridDim.x - 1 && pb == 0, 405);
 }
 
+// ---- ELBO path, few-problem form ---------------------------------------------------------------------
+// Four adjacent lanes share one (sample, time) configuration.  What bounds this launch when few problems
+// are in flight is the LENGTH of the dependent chain of one configuration, not throughput, so the chain is
+// cut to: joint angles -> frames (all of them, kept in LDS) -> ONE round of voxel gathers (every sphere
+// of a lane in flight together, kWideU per lane) -> hinge -> per-frame force / moment sums -> one sweep
+// back over the joints.  The robot table is copied to LDS first (its per-sphere rows are read per lane).
+// Sums over a lane's spheres are kept per frame in lane-private LDS slots, written once each (spheres are
+// sorted by frame) and combined across the four lanes by shuffles in a fixed order: deterministic.
+constexpr int kWideLanes = 4;
+constexpr int kWideU = 12;         // spheres per lane per round: one round up to 48 spheres
+
+__device__ __forceinline__ int wide_group_slots(int D) { return 2 * D + 12 * (D + 1); }     // sin, cos, frames
+__device__ __forceinline__ int wide_lane_slots(int D) { return 6 * (D + 1); }               // F, M per frame
+static size_t wide_lds_bytes(int D) {
+    const int cpb = kLikBlock / kWideLanes;
+    return sizeof(vgpmp_robot) + ((size_t)(2 * D + 12 * (D + 1) + D) * cpb + (size_t)6 * (D + 1) * kLikBlock) * sizeof(float);
+}
+
+__global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpmp_robot* __restrict__ rb_g, vgpmp_sdf sdfh,
+                                                                       const float* __restrict__ f, int S, int L, int N,
+                                                                       float scale, float* __restrict__ G,
+                                                                       float* __restrict__ logp,
+                                                                       float* __restrict__ lik_partial) {
+    extern __shared__ float lik_lds[];
+    __shared__ float red[kLikBlock / VG_WAVE];
+    constexpr int LPC = kWideLanes, CPB = kLikBlock / LPC;
+    const int pb = blockIdx.y, tid = threadIdx.x;
+    VG_T(blockIdx.x == 0 && pb == 0, 400);
+    const vgpmp_robot* rb = reinterpret_cast<const vgpmp_robot*>(lik_lds);          // LDS copy
+    vg_stage_16(lik_lds, rb_g, (int)(sizeof(vgpmp_robot) / 16), tid, kLikBlock);
+    const int cl = tid / LPC, sub = tid % LPC;
+    const int idx = blockIdx.x * CPB + cl;
+    const bool live = idx < S * N;
+    const int ci = live ? idx : S * N - 1;               // dead groups recompute the last configuration, write nothing
+    const int s = ci / N, n = ci - s * N;
+    const size_t base = ((size_t)pb * S + s) * L * N + n;
+    // this lane's joints: sub, sub + 4, ... (at most 4 of them)
+    float fv[VGPMP_MAX_DOF / LPC];
+#pragma unroll
+    for (int k = 0; k < VGPMP_MAX_DOF / LPC; ++k) fv[k] = f[base + (size_t)min(sub + LPC * k, L - 1) * N];
+    vg_dma_wait();
+    __syncthreads();
+    VG_T(blockIdx.x == 0 && pb == 0, 402);
+    const int D = rb->dof, P = rb->num_spheres;
+    float* grp = lik_lds + sizeof(vgpmp_robot) / sizeof(float) + cl;                 // [slot][CPB]
+    float* dgdf = lik_lds + sizeof(vgpmp_robot) / sizeof(float) + (size_t)wide_group_slots(D) * CPB + cl;   // [D][CPB]
+    float* mine = lik_lds + sizeof(vgpmp_robot) / sizeof(float) + (size_t)(wide_group_slots(D) + D) * CPB + tid;   // [slot][block]
+    auto gs = [&](int slot) -> float& { return grp[slot * CPB]; };
+    auto ms = [&](int slot) -> float& { return mine[slot * kLikBlock]; };
+    // ---- joint angles: sigmoid to the limits (likelihood.py:49-52), sin / cos
+#pragma unroll
+    for (int k = 0; k < VGPMP_MAX_DOF / LPC; ++k) {
+        const int j = sub + LPC * k;
+        if (j < D) {
+            const float sg = 1.0f / (1.0f + __expf(-fv[k]));
+            const float span = rb->high[j] - rb->low[j];
+            dgdf[j * CPB] = span * sg * (1.0f - sg);
+            float st, ct;
+            sincosf(fmaf(span, sg, rb->low[j]) + rb->twist[j], &st, &ct);
+            gs(j) = st; gs(D + j) = ct;
+        }
+    }
+    for (int k = 0; k < wide_lane_slots(D); ++k) ms(k) = 0.f;
+    lik_wave_sync();
+    // ---- every frame of the chain, frame i stored by lane i % 4
+    {
+        Frame T = base_frame(rb);
+        for (int i = 0; i <= D; ++i) {
+            if (i > 0) dh_apply(rb, i - 1, gs(i - 1), gs(D + i - 1), T);
+            if (i % LPC == sub) {
+                const int o = 2 * D + 12 * i;
+                gs(o) = T.cx.x; gs(o + 1) = T.cx.y; gs(o + 2) = T.cx.z;
+                gs(o + 3) = T.cy.x; gs(o + 4) = T.cy.y; gs(o + 5) = T.cy.z;
+                gs(o + 6) = T.cz.x; gs(o + 7) = T.cz.y; gs(o + 8) = T.cz.z;
+                gs(o + 9) = T.t.x; gs(o + 10) = T.t.y; gs(o + 11) = T.t.z;
+            }
+        }
+    }
+    lik_wave_sync();
+    VG_T(blockIdx.x == 0 && pb == 0, 403);
+    // ---- spheres sub, sub + 4, ...: positions, voxel gathers (all in flight), hinge, per-frame sums
+    const vg_sdf_dev sdf = load_sdf(sdfh);
+    const float eps = rb->epsilon;
+    const double offx = rb->scene_offset[0], offy = rb->scene_offset[1], offz = rb->scene_offset[2];
+    const SdfFast fs = make_fast(sdf, offx, offy, offz);
+    float acc = 0.f;
+    int cur = 0;                                         // frame of the running sums
+    vg_float3 F = vg_make3(0.f, 0.f, 0.f), Mo = vg_make3(0.f, 0.f, 0.f);
+    auto flush = [&]() {
+        const int o = 6 * cur;
+        ms(o) = F.x; ms(o + 1) = F.y; ms(o + 2) = F.z; ms(o + 3) = Mo.x; ms(o + 4) = Mo.y; ms(o + 5) = Mo.z;
+    };
+    const int nk = (P + LPC - 1) / LPC;
+    for (int k0 = 0; k0 < nk; k0 += kWideU) {
+        float4 v[kWideU];
+        vg_float3 pos[kWideU];
+        int fr[kWideU];
+#pragma unroll
+        for (int u = 0; u < kWideU; ++u) {               // tail lanes repeat the last sphere (weight 0)
+            const int q = min(sub + LPC * (k0 + u), P - 1);
+            fr[u] = rb->sphere_frame[q];
+            const int o = 2 * D + 12 * fr[u];
+            const vg_float3 cx = vg_make3(gs(o), gs(o + 1), gs(o + 2)), cy = vg_make3(gs(o + 3), gs(o + 4), gs(o + 5));
+            const vg_float3 cz = vg_make3(gs(o + 6), gs(o + 7), gs(o + 8)), t = vg_make3(gs(o + 9), gs(o + 10), gs(o + 11));
+            pos[u] = axpy(rb->sphere_off[q][0], cx, axpy(rb->sphere_off[q][1], cy, axpy(rb->sphere_off[q][2], cz, t)));
+            const int ix = voxel_axis(pos[u].x, fs.chx, fs.clx, fs.inv_delta, sdf.nx, offx, sdf.ox, sdf.delta);
+            const int iy = voxel_axis(pos[u].y, fs.chy, fs.cly, fs.inv_delta, sdf.ny, offy, sdf.oy, sdf.delta);
+            const int iz = voxel_axis(pos[u].z, fs.chz, fs.clz, fs.inv_delta, sdf.nz, offz, sdf.oz, sdf.delta);
+            v[u] = sdf.table[((size_t)ix * sdf.ny + iy) * sdf.nz + iz];
+        }
+#pragma unroll
+        for (int u = 0; u < kWideU; ++u) {
+            const int qq = sub + LPC * (k0 + u);
+            const int q = min(qq, P - 1);
+            const float wgt = qq < P ? 1.f : 0.f;
+            const float c = fmaxf(eps - (v[u].x - rb->radius[q]), 0.f) * wgt;       // likelihood.py:131-143
+            const float cs = c / rb->sigma_obs[q];
+            acc = fmaf(cs, c, acc);                                                  // likelihood.py:99
+            const vg_float3 gp = vg_make3(cs * v[u].y, cs * v[u].z, cs * v[u].w);   // d logp / d pos
+            if (fr[u] != cur) {                          // spheres are sorted by frame: each slot is written once
+                flush();
+                cur = fr[u];
+                F = vg_make3(0.f, 0.f, 0.f); Mo = vg_make3(0.f, 0.f, 0.f);
+            }
+            F = vg_make3(F.x + gp.x, F.y + gp.y, F.z + gp.z);
+            const vg_float3 m = vg_cross(pos[u], gp);
+            Mo = vg_make3(Mo.x + m.x, Mo.y + m.y, Mo.z + m.z);
+        }
+    }
+    flush();
+    VG_T(blockIdx.x == 0 && pb == 0, 404);
+    acc = quad_sum<LPC>(acc);
+    const float lp = -0.5f * acc;
+    // ---- joints, last to first: joint i moves every sphere on frames >= i; it turns about z of frame i
+    //      (Craig) or of frame i-1 (classic)
+    {
+        const bool craig = rb->craig != 0;
+        vg_float3 Fs = vg_make3(0.f, 0.f, 0.f), Ms = vg_make3(0.f, 0.f, 0.f);
+        for (int i = D; i >= 1; --i) {
+            const int o = 6 * i;
+            Fs = vg_make3(Fs.x + quad_sum<LPC>(ms(o)), Fs.y + quad_sum<LPC>(ms(o + 1)), Fs.z + quad_sum<LPC>(ms(o + 2)));
+            Ms = vg_make3(Ms.x + quad_sum<LPC>(ms(o + 3)), Ms.y + quad_sum<LPC>(ms(o + 4)), Ms.z + quad_sum<LPC>(ms(o + 5)));
+            const int fo = 2 * D + 12 * (craig ? i : i - 1);
+            const vg_float3 z = vg_make3(gs(fo + 6), gs(fo + 7), gs(fo + 8)), org = vg_make3(gs(fo + 9), gs(fo + 10), gs(fo + 11));
+            const vg_float3 oxF = vg_cross(org, Fs);
+            const float val = vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z));
+            if ((i - 1) % LPC == sub && live) G[base + (size_t)(i - 1) * N] = scale * val * dgdf[(i - 1) * CPB];
+        }
+    }
+    if (live && sub == 0) logp[((size_t)pb * S + s) * N + n] = lp;
+    float w = vg_wave_sum(live && sub == 0 ? lp : 0.f);
+    if ((tid & (VG_WAVE - 1)) == 0) red[tid / VG_WAVE] = w;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < kLikBlock / VG_WAVE; ++k) t += red[k];
+        lik_partial[(size_t)pb * gridDim.x + blockIdx.x] = t;
+    }
+    VG_T(blockIdx.x == 0 && pb == 0, 401);
+    VG_T(blockIdx.x == gridDim.x - 1 && pb == 0, 405);
+}
+
 // ---- stand-alone FK: q [n, dof] -> pos [n, P, 3], frames [n, dof+1, 12] ---------------------------
 __global__ __launch_bounds__(kBlock) void fk_spheres_kernel(const vgpmp_robot* __restrict__ rb,
                                                              const float* __restrict__ q, int64_t n,
@@ -430,8 +593,8 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
     if (nblk_out) *nblk_out = nblk;
     if (P == 0 || nblk == 0) return 0;
     static size_t granted1 = 0, granted4 = 0;
-    const size_t lds = lik_lds_bytes(L, true) / lpc;
-    int rc = lpc == 4 ? lik_grant_lds((const void*)loglik_paths_kernel<4>, lds, &granted4)
+    const size_t lds = lpc == 4 ? wide_lds_bytes(L) : lik_lds_bytes(L, true);
+    int rc = lpc == 4 ? lik_grant_lds((const void*)loglik_paths_wide_kernel, lds, &granted4)
                       : lik_grant_lds((const void*)loglik_paths_kernel<1>, lds, &granted1);
     if (rc) return rc;
     int dbg = 0;
@@ -439,8 +602,8 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
     dbg = lik_bisect_mode();
 #endif
     if (lpc == 4)
-        hipLaunchKernelGGL(loglik_paths_kernel<4>, dim3(nblk, P), dim3(kLikBlock), lds, st, rb, *sdf, f, S, L, N, scale,
-                           G, logp, lik_partial, dbg);
+        hipLaunchKernelGGL(loglik_paths_wide_kernel, dim3(nblk, P), dim3(kLikBlock), lds, st, rb, *sdf, f, S, L, N, scale,
+                           G, logp, lik_partial);
     else
         hipLaunchKernelGGL(loglik_paths_kernel<1>, dim3(nblk, P), dim3(kLikBlock), lds, st, rb, *sdf, f, S, L, N, scale,
                            G, logp, lik_partial, dbg);
