@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vgpmp_amd import capi, engine, robots as rb, scenes  # noqa: E402
 
 NAMES = {100: "cov_a start", 101: "cov_a Kuu built", 102: "cov_a factorised", 103: "cov_a end",
-         110: "final start", 111: "final partials summed", 112: "final grads", 113: "final end",
+         110: "final start", 115: "final requests issued", 114: "final operands landed", 111: "final partials summed", 112: "final grads", 113: "final end",
          120: "eps start", 130: "features first wg start", 131: "features first wg end", 135: "features last wg end",
          200: "cov_b q start", 201: "cov_b q staged", 202: "cov_b q end",
          210: "cov_b d/dell start", 211: "cov_b d/dell staged", 212: "cov_b d/dell matmuls", 213: "cov_b d/dell end",

@@ -1139,12 +1139,22 @@ struct FinalArgs {
     double *out_lik, *out_kl;
     double *g_qmu, *g_qsqrt;
     int do_adam, trainable;
+    int dma;                  // the chunk partials fit in LDS: stage them by DMA
     const double* lr_dev;     // [P] step size handed from the reverse pass to final_kernel
     double *mq_mu, *mq_sqrt;  // Adam moments
     double *vq_mu, *vq_sqrt;
     double *pq_mu, *pq_sqrt;  // parameters (updated in place)
     int stop;
 };
+
+// the same update with the state already in registers
+__device__ __forceinline__ void adam_apply(double* x, double* m, double* v, double x0, double m0, double v0, double g,
+                                           double lr_t) {
+    const double mm = m0 + (g - m0) * (1.0 - 0.8);
+    const double vv = v0 + (g * g - v0) * (1.0 - 0.95);
+    *m = mm; *v = vv;
+    *x = x0 - lr_t * mm / (sqrt(vv) + 1e-7);
+}
 
 // sum over the NC sample chunks of one reverse-pass partial, 8 independent loads in flight per pass
 // (unconditional clamped loads, masked afterwards); fixed order: deterministic
@@ -1165,7 +1175,8 @@ __device__ __forceinline__ double sum_chunks(const float* part, size_t part_len,
     return s;
 }
 
-// one wave per problem, one lane per latent
+// one wave per problem, one lane per latent.  The three sums over the sample chunks are loaded in ONE round
+// (16 chunks x 3 values per pass, clamped + masked), then added in the order of sum_chunks().
 __global__ __launch_bounds__(64) void hyper_kernel(HyperArgs h) {
     const int p = blockIdx.x, l = threadIdx.x;
     VG_T(p == 0, 600);
@@ -1177,13 +1188,29 @@ __global__ __launch_bounds__(64) void hyper_kernel(HyperArgs h) {
     if (l == 0) h.lr_dev[p] = lr_t;
     if (l >= h.L) return;
     const size_t pl = (size_t)p * h.L + l;
-    const float* part = h.part + pl * h.NC * h.part_len;
-    const int e0 = h.Mz + h.Mz * h.Mz;
-    const double s_ell = h.want_dell ? sum_chunks(part, h.part_len, h.NC, e0) : 0.0;
-    const double s_var = sum_chunks(part, h.part_len, h.NC, e0 + 1);
-    const double s_rff = sum_chunks(part, h.part_len, h.NC, e0 + 2);
-    const double g_ell = (s_ell + h.kl_scale * h.gkl_ell[pl]) * h.sig_ell[pl];
-    const double g_var = (s_var + s_rff / (2.0 * h.var[pl]) + h.kl_scale * h.gkl_var[pl]) * h.sig_var[pl];
+    const float* part = h.part + pl * h.NC * h.part_len + (h.Mz + h.Mz * h.Mz);
+    const double gkl_ell = h.gkl_ell[pl], gkl_var = h.gkl_var[pl], var = h.var[pl];
+    const double sig_ell = h.sig_ell[pl], sig_var = h.sig_var[pl];
+    double s3[3] = {0.0, 0.0, 0.0};
+    for (int c0 = 0; c0 < h.NC; c0 += 16) {
+        float v[16][3];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float* q = part + (size_t)min(c0 + k, h.NC - 1) * h.part_len;
+            v[k][0] = q[0]; v[k][1] = q[1]; v[k][2] = q[2];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double d[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) d[k] = c0 + k < h.NC ? (double)v[k][j] : 0.0;
+            s3[j] += ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+            s3[j] += ((d[8] + d[9]) + (d[10] + d[11])) + ((d[12] + d[13]) + (d[14] + d[15]));
+        }
+    }
+    const double s_ell = h.want_dell ? s3[0] : 0.0;
+    const double g_ell = (s_ell + h.kl_scale * gkl_ell) * sig_ell;
+    const double g_var = (s3[1] + s3[2] / (2.0 * var) + h.kl_scale * gkl_var) * sig_var;
     h.g_ell[pl] = g_ell;
     h.g_var[pl] = g_var;
     if (h.do_adam) {
@@ -1193,78 +1220,130 @@ __global__ __launch_bounds__(64) void hyper_kernel(HyperArgs h) {
     VG_T(p == 0, 601);
 }
 
+// alpha / S * sum of the per-workgroup log-likelihood sums and the KL total of one problem: whole workgroup,
+// fixed order (thread-strided partial sums, wave sums, then the waves in order) -- shared by the forward-only
+// epilogue so that both entry points return identical numbers
+__device__ __forceinline__ void elbo_pieces(const float* lik_partial, int nblk, const double* kl_l, int L, int p,
+                                            double lik_scale, double kls, double* out_lik, double* out_kl) {
+    __shared__ double red2[2][kBlock / VG_WAVE];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = lik_partial[(size_t)p * nblk + min(tid + k * nt, nblk - 1)];
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += tid + k * nt < nblk ? (double)v[k] : 0.0;
+    for (int k = tid + 4 * nt; k < nblk; k += nt) s += (double)lik_partial[(size_t)p * nblk + k];
+    double kk = tid < L ? kl_l[(size_t)p * L + tid] : 0.0;
+    s = vg_wave_sum(s);
+    kk = vg_wave_sum(kk);
+    if ((tid & (VG_WAVE - 1)) == 0) { red2[0][tid / VG_WAVE] = s; red2[1][tid / VG_WAVE] = kk; }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0, c = 0.0;
+        for (int k = 0; k < (int)(nt / VG_WAVE); ++k) { a += red2[0][k]; c += red2[1][k]; }
+        out_lik[p] = lik_scale * a;
+        out_kl[p] = kls * c;
+    }
+}
+
+// Gradient assembly of one (latent, problem).  Everything it reads is requested up front -- the chunk partials
+// and the Cholesky factor by DMA into LDS (when `dma`), the KL gradients and the Adam state of this thread's
+// elements into registers -- so the kernel waits for memory once, not once per loop iteration.
+constexpr int kFinRegs = ((VGPMP_MAX_MZ - 2) * (VGPMP_MAX_MZ - 1) + kBlock - 1) / kBlock;      // elements per thread
 __device__ __forceinline__ void final_body(const FinalArgs& b, double* sm, int l, int p) {
     VG_STOP(b, 7);
     const int tid = threadIdx.x, nt = blockDim.x;
     VG_T(l == 0 && p == 0, 110);
-    const int M = b.M, Mz = M + 2, L = b.L;
+    const int M = b.M, Mz = M + 2, L = b.L, nq = M + M * M, np = Mz + Mz * Mz;
     const float iM = 1.0f / (float)M;
     const size_t pl = (size_t)p * L + l;
     double* dC = sm;                 // [Mz][Mz]
     double* dmv = dC + Mz * Mz;      // [Mz]
-    float* Lks = reinterpret_cast<float*>(dmv + Mz);   // [Mz][Mz] chol factor
+    float* Lks = reinterpret_cast<float*>(dmv + Mz + (Mz & 1));   // [Mz][Mz] chol factor (16-byte aligned)
+    float* raw = Lks + ((Mz * Mz + 3) & ~3);                      // [NC][np] chunk partials as they arrive (dma)
     const float* part = b.part + pl * b.NC * b.part_len;
-    const float* Lkg = b.Lk32 + pl * Mz * Mz;
     const double lr_t = b.do_adam ? b.lr_dev[p] : 0.0;
-    for (int e = tid; e < Mz * Mz; e += nt) Lks[e] = Lkg[e];
+    vg_stage_rows(Lks, 1, Mz * Mz, tid, nt, [&](int) -> const float* { return b.Lk32 + pl * Mz * Mz; });
+    if (b.dma) vg_stage_rows(raw, b.NC, np, tid, nt, [&](int c) -> const float* { return part + (size_t)c * b.part_len; });
+    // this thread's elements k = tid + j * nt of  q_mu | q_sqrt:  KL gradient and Adam state
+    double kg[kFinRegs], xs[kFinRegs], mo[kFinRegs], vo[kFinRegs];
+#pragma unroll
+    for (int j = 0; j < kFinRegs; ++j) {
+        const int k = min(tid + j * nt, nq - 1);
+        const bool mu = k < M;
+        const size_t o = mu ? pl * M + k : pl * M * M + (k - M);
+        kg[j] = (mu ? b.gkl_qmu : b.gkl_Q)[o];
+        if (b.do_adam) {
+            xs[j] = (mu ? b.pq_mu : b.pq_sqrt)[o];
+            mo[j] = (mu ? b.mq_mu : b.mq_sqrt)[o];
+            vo[j] = (mu ? b.vq_mu : b.vq_sqrt)[o];
+        }
+    }
     VG_STOP(b, 5);
-    for (int e = tid; e < Mz + Mz * Mz; e += nt) {
-        const double s = sum_chunks(part, b.part_len, b.NC, e);
-        if (e < Mz) dmv[e] = s;
-        else dC[e - Mz] = s;
+    if (!b.dma)
+        for (int e = tid; e < np; e += nt) {
+            const double s = sum_chunks(part, b.part_len, b.NC, e);
+            if (e < Mz) dmv[e] = s;
+            else dC[e - Mz] = s;
+        }
+    VG_T(l == 0 && p == 0, 115);
+    vg_dma_wait();
+    __syncthreads();
+    VG_T(l == 0 && p == 0, 114);
+    if (b.dma) {
+        for (int e = tid; e < np; e += nt) {
+            double s = 0.0;
+            for (int c0 = 0; c0 < b.NC; c0 += 8) {       // the order of sum_chunks()
+                double d[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) d[k] = c0 + k < b.NC ? (double)raw[(size_t)min(c0 + k, b.NC - 1) * np + e] : 0.0;
+                s += ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+            }
+            if (e < Mz) dmv[e] = s;
+            else dC[e - Mz] = s;
+        }
+        __syncthreads();
     }
     VG_STOP(b, 6);
-    __syncthreads();
     VG_T(l == 0 && p == 0, 111);
     VG_STOP(b, 1);
     const double kls = b.kl_scale;
     double* gQ = b.g_qsqrt + pl * M * M;
-    const double* kQ = b.gkl_Q + pl * M * M;
-    for (int e = tid; e < M * M; e += nt) {
-        int r = vg_div(e, iM), c = e - r * M;
-        double s = 0.0;
-        if (c <= r) {
-            // tril(Lk^T dC)[2:, 2:]
-            double s0 = 0.0, s1 = 0.0;
-            int i = r + 2;
-            for (; i + 1 < Mz; i += 2) {
-                s0 = fma((double)Lks[i * Mz + (r + 2)], dC[i * Mz + (c + 2)], s0);
-                s1 = fma((double)Lks[(i + 1) * Mz + (r + 2)], dC[(i + 1) * Mz + (c + 2)], s1);
+    double* gm = b.g_qmu + pl * M;
+#pragma unroll
+    for (int j = 0; j < kFinRegs; ++j) {
+        const int k = tid + j * nt;
+        if (k >= nq) continue;
+        double g;
+        if (k < M) {
+            g = dmv[k + 2] + kls * kg[j];
+            gm[k] = g;
+            if (b.do_adam && (b.trainable & VGPMP_TRAIN_Q_MU))
+                adam_apply(b.pq_mu + pl * M + k, b.mq_mu + pl * M + k, b.vq_mu + pl * M + k, xs[j], mo[j], vo[j], g, lr_t);
+        } else {
+            const int e = k - M, r = vg_div(e, iM), c = e - r * M;
+            g = 0.0;
+            if (c <= r) {
+                // tril(Lk^T dC)[2:, 2:]
+                double s0 = 0.0, s1 = 0.0;
+                int i = r + 2;
+                for (; i + 1 < Mz; i += 2) {
+                    s0 = fma((double)Lks[i * Mz + (r + 2)], dC[i * Mz + (c + 2)], s0);
+                    s1 = fma((double)Lks[(i + 1) * Mz + (r + 2)], dC[(i + 1) * Mz + (c + 2)], s1);
+                }
+                if (i < Mz) s0 = fma((double)Lks[i * Mz + (r + 2)], dC[i * Mz + (c + 2)], s0);
+                g = s0 + s1 + kls * kg[j];
             }
-            if (i < Mz) s0 = fma((double)Lks[i * Mz + (r + 2)], dC[i * Mz + (c + 2)], s0);
-            s = s0 + s1 + kls * kQ[e];
+            gQ[e] = g;
+            if (c <= r && b.do_adam && (b.trainable & VGPMP_TRAIN_Q_SQRT))
+                adam_apply(b.pq_sqrt + pl * M * M + e, b.mq_sqrt + pl * M * M + e, b.vq_sqrt + pl * M * M + e, xs[j], mo[j],
+                           vo[j], g, lr_t);
         }
-        gQ[e] = s;
     }
     VG_STOP(b, 2);
-    double* gm = b.g_qmu + pl * M;
-    for (int i = tid; i < M; i += nt) gm[i] = dmv[i + 2] + kls * b.gkl_qmu[pl * M + i];
     VG_T(l == 0 && p == 0, 112);
-    if (b.do_adam) {
-        __syncthreads();           // gradients above are read back below (same workgroup, global memory)
-        // ONE update loop over the variational variables of this latent: q_mu | q_sqrt (lower)
-        const int nq = M + M * M;
-        for (int k = tid; k < nq; k += nt) {
-            double *x, *m, *v; double g; int flag;
-            if (k < M) { x = b.pq_mu + pl * M + k; m = b.mq_mu + pl * M + k; v = b.vq_mu + pl * M + k; g = gm[k]; flag = VGPMP_TRAIN_Q_MU; }
-            else {
-                const int e = k - M, r = vg_div(e, iM);
-                if (e - r * M > r) continue;
-                x = b.pq_sqrt + pl * M * M + e; m = b.mq_sqrt + pl * M * M + e; v = b.vq_sqrt + pl * M * M + e; g = gQ[e];
-                flag = VGPMP_TRAIN_Q_SQRT;
-            }
-            if (b.trainable & flag) adam_update(x, m, v, g, lr_t);
-        }
-    }
-    if (l == 0 && tid < 64) {
-        double s = 0.0;
-        for (int k = tid; k < b.nblk; k += 64) s += (double)b.lik_partial[(size_t)p * b.nblk + k];
-        s = vg_wave_sum(s);
-        double kk = 0.0;
-        for (int k = tid; k < L; k += 64) kk += b.kl_l[(size_t)p * L + k];
-        kk = vg_wave_sum(kk);
-        if (tid == 0) { b.out_lik[p] = b.lik_scale * s; b.out_kl[p] = kls * kk; }
-    }
+    if (l == 0) elbo_pieces(b.lik_partial, b.nblk, b.kl_l, L, p, b.lik_scale, kls, b.out_lik, b.out_kl);
     VG_T(l == 0 && p == 0, 113);
 }
 
@@ -1274,17 +1353,10 @@ __global__ __launch_bounds__(kBlock) void final_kernel(FinalArgs b) {
 }
 
 // forward-only epilogue: ELBO pieces without the reverse pass
-__global__ void elbo_pieces_kernel(int L, int nblk, const float* __restrict__ lik_partial,
-                                   const double* __restrict__ kl_l, double lik_scale, double kls,
-                                   double* __restrict__ out_lik, double* __restrict__ out_kl) {
-    const int p = blockIdx.x, tid = threadIdx.x;
-    double s = 0.0;
-    for (int k = tid; k < nblk; k += 64) s += (double)lik_partial[(size_t)p * nblk + k];
-    s = vg_wave_sum(s);
-    double kk = 0.0;
-    for (int k = tid; k < L; k += 64) kk += kl_l[(size_t)p * L + k];
-    kk = vg_wave_sum(kk);
-    if (tid == 0) { out_lik[p] = lik_scale * s; out_kl[p] = kls * kk; }
+__global__ __launch_bounds__(kBlock) void elbo_pieces_kernel(int L, int nblk, const float* __restrict__ lik_partial,
+                                                              const double* __restrict__ kl_l, double lik_scale, double kls,
+                                                              double* __restrict__ out_lik, double* __restrict__ out_kl) {
+    elbo_pieces(lik_partial, nblk, kl_l, L, blockIdx.x, lik_scale, kls, out_lik, out_kl);
 }
 
 // stand-alone Adam over the packed variables (sample-sharded mode, after the gradient all-reduce)
@@ -1536,8 +1608,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const bool backward = (what & VGPMP_DO_BACKWARD) != 0, do_adam = (what & VGPMP_DO_ADAM) != 0;
     const bool gen = (what & VGPMP_GEN_NOISE) != 0;
     const bool want_dell = backward && (trainable & VGPMP_TRAIN_LENGTHSCALES);
-    const bool tiled_gemm = SK == 1 && (B % kTK) == 0;      // split_k == 1 is chosen by the host for large batches
-    const bool fused = !ev && !(what & VGPMP_NO_FUSE) && !tiled_gemm && SC == 8 && P * L <= kFuseMaxPL;
+    const bool fused = !ev && !(what & VGPMP_NO_FUSE) && SC == 8 && P * L <= kFuseMaxPL;
+    const bool tiled_gemm = !fused && SK == 1 && (B % kTK) == 0;      // large batches: LDS-tiled kernel, no K-slices
     if (num_steps > 1 && !(backward && do_adam && gen)) return VGPMP_E_ARG;
     int evi = 0;
     auto mark = [&]() { if (ev) (void)hipEventRecord(ev[evi++], st); };
@@ -1590,7 +1662,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     fa.gkl_qmu = ws->gkl_qmu; fa.gkl_Q = ws->gkl_Q; fa.kl_l = ws->kl_l;
     fa.kl_scale = pb->kl_scale; fa.lik_scale = lik_scale; fa.out_lik = out->lik; fa.out_kl = out->kl;
     fa.g_qmu = out->grad.q_mu; fa.g_qsqrt = out->grad.q_sqrt;
-    fa.do_adam = do_adam ? 1 : 0; fa.trainable = trainable; fa.lr_dev = ws->lr_t;
+    fa.do_adam = do_adam ? 1 : 0; fa.trainable = trainable; fa.lr_dev = ws->lr_t; fa.dma = 0;
     fa.mq_mu = am ? am->q_mu : nullptr; fa.mq_sqrt = am ? am->q_sqrt : nullptr;
     fa.vq_mu = av ? av->q_mu : nullptr; fa.vq_sqrt = av ? av->q_sqrt : nullptr;
     fa.pq_mu = params->q_mu; fa.pq_sqrt = params->q_sqrt;
@@ -1619,7 +1691,11 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const bool raw_fwd = lds_pf + raw_f <= 64 * 1024, raw_bwd = lds_pb + 2 * raw_f <= 160 * 1024;
     if (raw_fwd) lds_pf += raw_f;
     if (raw_bwd) lds_pb += 2 * raw_f;
-    const size_t lds_fin = ((size_t)Mz * Mz + Mz) * sizeof(double) + (size_t)Mz * Mz * sizeof(float);
+    size_t lds_fin = ((size_t)Mz * Mz + Mz + 1) * sizeof(double) + ((size_t)Mz * Mz + 4) * sizeof(float);
+    const size_t raw_fin = (size_t)NC * (Mz + Mz * Mz) * sizeof(float);
+    const bool fin_dma = lds_fin + raw_fin <= 96 * 1024;
+    if (fin_dma) lds_fin += raw_fin;
+    fa.dma = fin_dma ? 1 : 0;
     const size_t lds_s1 = lds_cov_a > lds_fin ? lds_cov_a : lds_fin;
     const void* fn_cov_b = backward ? (const void*)cov_b_kernel<true> : (const void*)cov_b_kernel<false>;
     const bool k8 = B / SK == 128;      // B = 1024 with 8 K-slices: all operands of a workgroup in one request
@@ -1718,7 +1794,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         fa.nblk = nblk;
         mark();
         if (!backward) {
-            hipLaunchKernelGGL(elbo_pieces_kernel, dim3(P), dim3(64), 0, st, L, nblk, ws->lik_partial, ws->kl_l, lik_scale,
+            hipLaunchKernelGGL(elbo_pieces_kernel, dim3(P), dim3(kBlock), 0, st, L, nblk, ws->lik_partial, ws->kl_l, lik_scale,
                                pb->kl_scale, out->lik, out->kl);
             return (int)hipGetLastError();
         }
