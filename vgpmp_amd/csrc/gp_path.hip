@@ -235,6 +235,75 @@ __device__ __forceinline__ void chol_inverse_block(double* La, double* Li, doubl
     __syncthreads();
 }
 
+// The same elimination with the augmented matrix in REGISTERS (Mz <= 32, 256 threads): thread (row i = tid & 31,
+// column block jb = tid >> 5) keeps columns [8 jb, 8 jb + 8) of [K | I] laid out as 32 + 32 columns.  Per pivot
+// the owners publish the pivot row and the pivot column through LDS (double buffered: one barrier per pivot),
+// everyone reads its 8 + 2 values in one LDS round and does 8 FMAs out of registers; measured 340 ns per pivot
+// against 420 ns for the LDS-resident loop above (three LDS reads and a write per element).
+__device__ __forceinline__ void chol_inverse_regs(double* La, double* Li, double* Aug, double* rsd, int Mz, int ld,
+                                                  int tid, int nt) {
+    const int i = tid & 31, jb = tid >> 5, la = 2 * Mz + 1;
+    const float iMz = 1.0f / (float)Mz;
+    double* prow = Aug;                  // [2][64] pivot row, both halves
+    double* pcol = Aug + 128;            // [2][32] pivot column
+    double a[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int col = 8 * jb + c;      // < 32: column of K;  >= 32: column col - 32 of I
+        a[c] = i < Mz ? (col < 32 ? (col < Mz ? La[i * ld + col] : 0.0) : (col - 32 == i ? 1.0 : 0.0)) : 0.0;
+    }
+    __syncthreads();
+#pragma nounroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int k = 8 * kb + c;
+            if (k >= Mz) break;
+            const int buf = k & 1;
+            if (i == k) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) prow[buf * 64 + 8 * jb + q] = a[q];
+            }
+            if (jb == kb) pcol[buf * 32 + i] = a[c];
+            __syncthreads();
+            // one LDS round for everything this thread needs of pivot k (read unconditionally, used conditionally)
+            const double piv = pcol[buf * 32 + k], aik = pcol[buf * 32 + i];
+            double pr[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pr[q] = prow[buf * 64 + 8 * jb + q];
+            if (tid == 0) rsd[k] = piv;          // rsqrt after the loop, off the chain
+            // 1 / piv sits on the dependency chain of every pivot: hardware estimate + two Newton steps (to the
+            // last bit or two) instead of the ~10-instruction IEEE division sequence
+            double r = __builtin_amdgcn_rcp(piv);
+            r = fma(fma(-piv, r, 1.0), r, r);
+            r = fma(fma(-piv, r, 1.0), r, r);
+            const double m = (i > k && i < Mz) ? aik * r : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = fma(-m, pr[q], a[q]);
+        }
+    }
+    __syncthreads();
+    if (tid < Mz) rsd[tid] = rsqrt(rsd[tid]);
+    __syncthreads();
+    // registers -> the [Mz][2 Mz + 1] image the tail expects: left half U = D L~^T, right half L~^-1
+    double* Img = Aug;                   // the exchange buffers are dead now
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int col = 8 * jb + c;
+        if (i < Mz) {
+            if (col < Mz) Img[i * la + col] = a[c];
+            else if (col >= 32 && col - 32 < Mz) Img[i * la + Mz + (col - 32)] = a[c];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < Mz * Mz; e += nt) {
+        const int r = vg_div(e, iMz), j = e - r * Mz;
+        La[r * ld + j] = j <= r ? Img[j * la + r] * rsd[j] : 0.0;
+        Li[r * ld + j] = j <= r ? Img[r * la + Mz + j] * rsd[r] : 0.0;
+    }
+    __syncthreads();
+}
+
 // ---- stage A: Kuu, factorisation, inverse --------------------------------------------------------
 __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, int p) {
     __shared__ double scal[2];
@@ -278,7 +347,8 @@ __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, 
     }
     __syncthreads();
     VG_T(l == 0 && p == 0, 101);
-    chol_inverse_block(La, Li, Sc, rsd, Mz, ld, tid, nt);
+    if (Mz <= 32 && nt == 256) chol_inverse_regs(La, Li, Sc, rsd, Mz, ld, tid, nt);
+    else chol_inverse_block(La, Li, Sc, rsd, Mz, ld, tid, nt);
     VG_T(l == 0 && p == 0, 102);
     double* Kig = a.ws.Kinv + pl * Mz * Mz;
     matmul_f64(MatView{Li, 1, ld}, MatView{Li, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
@@ -953,8 +1023,8 @@ __device__ __forceinline__ void paths_fwd_body(const PathArgs& a, float* smf, in
             return (second ? a.eps2 : a.eps) + (((size_t)p * S + s) * Mz + k) * L + l;
         });
         vg_stage_words(ms, Mz, tid, nt, [&](int i) -> const void* { return a.m + pl * Mz + i; });
-        if (RAW)
-            vg_stage_rows(raw, SK * SC, J, tid, nt, [&](int r) -> const float* {
+        if (RAW)      // one slab: straight into its final place
+            vg_stage_rows(SK == 1 ? f0s : raw, SK * SC, J, tid, nt, [&](int r) -> const float* {
                 const int k = r / SC, s = min(s_base + (r - k * SC), S - 1);
                 return a.F0 + (size_t)k * a.slab + (((size_t)p * S + s) * L + l) * J;
             });
@@ -967,7 +1037,7 @@ __device__ __forceinline__ void paths_fwd_body(const PathArgs& a, float* smf, in
     vg_dma_wait();
     __syncthreads();
     VG_T(ch == 0 && l == 0 && p == 0, 301);
-    if (RAW) {
+    if (RAW && SK > 1) {
         for (int e = tid; e < SC * J; e += nt) f0s[e] = sum_slabs_lds<SK>(raw, e, SC * J);
         __syncthreads();
     }
@@ -1010,8 +1080,8 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
     float* Ces = take(2 * Mz * Mz);                  // [Mz][Mz] (dC/dell)^T, then (dC/dvar)^T
     float* Cvs = Ces + Mz * Mz;
     float* Gs = take(SC * N);                        // [SC][N]
-    float* f0s = take(SC * J);                       // [SC][J]
-    float* hs = take(SC * J);                        // [SC][J]
+    float* f0s = take(2 * SC * J);                   // [SC][J] prior draws, then [SC][J] their d/dell
+    float* hs = f0s + SC * J;
     float* Rs = take(SC * Mz);                       // [SC][Mz]
     float* Es = take(SC * Mz);                       // [SC][Mz]
     float* dRs = take(SC * Mz);                      // [SC][Mz]
@@ -1038,7 +1108,13 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
             const int sl = vg_div(i, iMz), mi = i - sl * Mz, s = s_base + sl;
             return s < S ? a.eps + (((size_t)p * S + s) * Mz + mi) * L + l : nullptr;
         });
-        if (RAW) {
+        if (RAW && SK == 1) {      // one slab: straight into its final place (f0s and hs are adjacent)
+            vg_stage_rows(f0s, 2 * SC, J, tid, nt, [&](int r) -> const float* {
+                const int second = r >= SC, s = min(s_base + (second ? r - SC : r), S - 1);
+                if (second && !dell) return nullptr;
+                return (second ? a.H : a.F0) + (((size_t)p * S + s) * L + l) * J;
+            });
+        } else if (RAW) {
             vg_stage_rows(raw, (dell ? 2 : 1) * SK * SC, J, tid, nt, [&](int r) -> const float* {
                 const int second = r >= SK * SC, rr = second ? r - SK * SC : r;
                 const int k = rr / SC, s = min(s_base + (rr - k * SC), S - 1);
@@ -1055,7 +1131,7 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
     }
     vg_dma_wait();
     __syncthreads();
-    if (RAW) {
+    if (RAW && SK > 1) {
         const int nsl = SK * SC * J;
         for (int e = tid; e < SC * J; e += nt) {
             f0s[e] = sum_slabs_lds<SK>(raw, e, SC * J);
@@ -1684,7 +1760,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const size_t lds_rows = ((size_t)2 * Mz * ((Mz + 2) & ~1) + (size_t)4 * kRowTile * Mz + Mz + kRowTile) * sizeof(double);
     const size_t lds_cov_b = lds_cov > lds_rows ? lds_cov : lds_rows;
     // path kernels: operands + (when it fits) the raw split-K slabs of the prior draws
-    const size_t raw_f = (size_t)SK * SC * J * sizeof(float);
+    const size_t raw_f = SK == 1 ? 0 : (size_t)SK * SC * J * sizeof(float);      // one slab lands in place
     size_t lds_pf = ((size_t)Mz * (Mz + 1) + (size_t)Mz * N + (size_t)3 * SC * Mz + Mz + (size_t)SC * J + 6 * 4) * sizeof(float);
     size_t lds_pb = ((size_t)4 * N * Mz + (size_t)2 * Mz * Mz + (size_t)SC * N + (size_t)2 * SC * J +
                      (size_t)3 * SC * Mz + 9 * 4) * sizeof(float);

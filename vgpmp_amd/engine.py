@@ -144,8 +144,8 @@ class PlannerBatch:
         self.alpha, self.lr = float(alpha), float(learning_rate)
         self.trainable = dict(DEFAULT_TRAINABLE if trainable is None else trainable)
         self.seed, self.problem_base, self.t = int(seed), int(problem_base), 0
-        if split_k is None:   # K-slices of the prior GEMM: few problems -> more slices to fill the chip
-            split_k = 4 if P * L <= 64 else (2 if P * L <= 256 else 1)
+        if split_k is None:   # K-slices of the prior GEMM: few problems -> slices to fill the chip (fused stage launches)
+            split_k = 4 if P * L <= 64 else 1
             while (B // split_k) % 16:
                 split_k //= 2
         self.dims = capi.Dims(P, S, int(samples_total or S), N, M, L, B, int(split_k), int(sample_offset), 0)
