@@ -111,7 +111,8 @@ def main():
     ap.add_argument("--no-fuse", action="store_true", help="one launch per kernel even for small batches (measurement)")
     ap.add_argument("--scene", choices=("industrial", "synthetic"), default="industrial",
                     help="industrial = SDF generated from the reference's industrial collision mesh; synthetic = boxes/spheres")
-    ap.add_argument("--unroll", type=int, default=10, help="steps per captured hipGraph (0 = eager launches)")
+    ap.add_argument("--unroll", type=int, default=0,
+                    help="steps per captured hipGraph; 0 = plain launches (measured 2-3 %% faster than graph replay here)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=40)
     ap.add_argument("--allow-nan", action="store_true", help=argparse.SUPPRESS)
@@ -171,26 +172,32 @@ def main():
         t_sample = time.perf_counter() - t1
 
     # ---- per-kernel durations with HIP events (separate pass so the timed region stays clean)
-    stage_ms = planner.profile_steps(max(1, args.profile_steps))
+    times = planner.profile_steps(max(1, args.profile_steps))
+    kernel_ms = {k: times.pop(k) for k in ("loglik_kernel", "prior_gemm_kernel")}      # device start-to-end
+    stage_ms = times
     S, N, M, D, P, B = args.samples, args.timesteps, args.inducing, spec.dof, spec.num_spheres, 1024
     npb = args.problems
     sdf_bytes = npb * S * N * (28 * P + 8 * D + 4)                 # 7 fp32 voxels per sphere query
     gemm_flops = npb * 2 * (2.0 * S * (N + M + 2) * D * B)         # F0 and H (lengthscales trainable)
-    t_sdf, t_gemm = stage_ms["loglik_fk_sdf"] * 1e-3, stage_ms["prior_gemm"] * 1e-3
-    roof_sdf = {"kernel": "loglik_paths_kernel", "bound": "hbm", "achieved": sdf_bytes / t_sdf / 1e9,
+    t_sdf, t_gemm = kernel_ms["loglik_kernel"] * 1e-3, kernel_ms["prior_gemm_kernel"] * 1e-3
+    lik_kernel = "loglik_paths_wide_kernel" if npb * S * N <= 65536 else "loglik_paths_kernel<1>"
+    roof_sdf = {"kernel": lik_kernel, "bound": "hbm", "achieved": sdf_bytes / t_sdf / 1e9,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sdf_bytes / t_sdf / 1e9 / HBM_PEAK_GBPS,
-                "traffic": None, "algorithmic_bytes_per_launch": sdf_bytes, "avg_launch_ms": stage_ms["loglik_fk_sdf"]}
-    roof_gemm = {"kernel": "prior_gemm_kernel", "bound": "mfma", "achieved": gemm_flops / t_gemm / 1e12,
+                "traffic": None, "algorithmic_bytes_per_launch": sdf_bytes, "avg_launch_ms": kernel_ms["loglik_kernel"],
+                "timing": "HIP events stamped with the kernel's start and end on its stream (hipExtLaunchKernel), "
+                          f"mean of {max(1, args.profile_steps)} launches"}
+    gemm_kernel = "prior_gemm_tiled_kernel" if planner.dims.split_k == 1 else "prior_gemm_kernel<0>"
+    roof_gemm = {"kernel": gemm_kernel, "bound": "mfma", "achieved": gemm_flops / t_gemm / 1e12,
                  "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_flops / t_gemm / 1e12 / F32_MFMA_PEAK_TFLOPS,
-                 "traffic": None, "algorithmic_flops_per_launch": gemm_flops, "avg_launch_ms": stage_ms["prior_gemm"]}
+                 "traffic": None, "algorithmic_flops_per_launch": gemm_flops, "avg_launch_ms": kernel_ms["prior_gemm_kernel"]}
     dominant = max(stage_ms, key=stage_ms.get)
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tfile) and args.workload == "config2" and npb == 1:
         try:
             t = json.load(open(tfile))
-            roof_sdf["traffic"] = t.get("loglik_paths_kernel", {}).get("hbm_bytes_per_launch")
+            roof_sdf["traffic"] = t.get(lik_kernel, {}).get("hbm_bytes_per_launch")
             roof_sdf["traffic_source"] = t.get("source")
-            roof_gemm["traffic"] = t.get("prior_gemm_kernel", {}).get("hbm_bytes_per_launch")
+            roof_gemm["traffic"] = t.get(gemm_kernel, {}).get("hbm_bytes_per_launch")
         except Exception:
             pass
 
@@ -208,7 +215,10 @@ def main():
                                    + f", {npb} start-goal problem(s) per GPU, S={S} M={M} T={N} B={B}, "
                                    "q_mu/q_sqrt/lengthscales/kernel_variance trainable",
                        "parallelism": f"problems sharded x{world}, no collective",
-                       "launch": f"hipGraph x{args.unroll} steps" if args.unroll else "eager"},
+                       "launch": (f"hipGraph x{args.unroll} steps" if args.unroll else "plain launches")
+                                 + ("; independent kernels of a step share launches (stage1/2/3_kernel), the prior GEMM is a"
+                                    " role of stage2_kernel there and is timed alone for roofline_secondary"
+                                    if planner.fuse and npb * D <= 64 else "")},
             "plans_per_sec": (world * npb / (float(ps.planner_params["num_steps"]) * elapsed / args.steps + t_sample)
                               if t_sample is not None else None),
             "plan_definition": f"{ps.planner_params['num_steps']} optimisation steps + 150 posterior paths at "

@@ -204,10 +204,13 @@ int vgpmp_elbo_steps(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const
                      int32_t what, int32_t trainable, double learning_rate, int32_t adam_t,
                      uint32_t seed, uint32_t problem_base, uint32_t step, int32_t num_steps, vgpmp_stream stream);
 
-/* Same launch sequence with a HIP event recorded on `stream` around every kernel; synchronises the
+/* Same kernels, one launch each, with a HIP event recorded on `stream` around every stage; synchronises the
  * stream and ADDS the elapsed milliseconds of the 8 stages {cov_fwd, noise, features, prior_gemm,
- * paths_fwd, loglik(FK+SDF), paths_bwd, final+adam} to host_stage_ms[8].  Measurement only. */
+ * paths_fwd, loglik(FK+SDF), paths_bwd, final+adam} to host_stage_ms[0..7], and the device-side duration
+ * (kernel start to kernel end, what a profiler reports) of the likelihood kernel and of the prior GEMM
+ * kernel to host_stage_ms[8] and [9].  host_stage_ms has VGPMP_NUM_TIMES entries.  Measurement only. */
 #define VGPMP_NUM_STAGES 8
+#define VGPMP_NUM_TIMES 10
 int vgpmp_elbo_step_profiled(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,
                              const vgpmp_problem* problem, const vgpmp_params* params,
                              const vgpmp_params* adam_m, const vgpmp_params* adam_v,

@@ -23,7 +23,9 @@ EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_pack", "vgpmp_mesh_
            "vgpmp_log_prob", "vgpmp_workspace_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
            "vgpmp_elbo_steps", "vgpmp_elbo_step_profiled", "vgpmp_adam_step", "vgpmp_workspace_view")
 NUM_STAGES = 8
+NUM_TIMES = 10
 STAGE_NAMES = ("cov_fwd", "noise", "features", "prior_gemm", "paths_fwd", "loglik_fk_sdf", "paths_bwd", "final_adam")
+KERNEL_TIME_NAMES = ("loglik_kernel", "prior_gemm_kernel")      # device start-to-end of those two kernels
 
 
 class VgpmpError(RuntimeError):

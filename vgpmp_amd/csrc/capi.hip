@@ -140,8 +140,10 @@ int vgpmp_elbo_step_profiled(const vgpmp_dims* dims, const vgpmp_robot* dev_robo
                              double learning_rate, int32_t adam_t, uint32_t seed, uint32_t problem_base,
                              uint32_t step, vgpmp_stream stream, float* host_stage_ms) {
     if (!host_stage_ms) return VGPMP_E_ARG;
-    hipEvent_t ev[VGPMP_NUM_STAGES + 1];
-    for (int i = 0; i <= VGPMP_NUM_STAGES; ++i) VG_CHECK_HIP(hipEventCreate(&ev[i]));
+    // [0, 8]: stage boundaries on the stream;  [9, 10] / [11, 12]: device start / end of the likelihood / GEMM kernel
+    constexpr int kEv = VGPMP_NUM_STAGES + 5;
+    hipEvent_t ev[kEv];
+    for (int i = 0; i < kEv; ++i) VG_CHECK_HIP(hipEventCreate(&ev[i]));
     int rc = elbo_step_impl(dims, dev_robot, sdf, problem, params, adam_m, adam_v, noise, out, dev_workspace,
                             workspace_bytes, what, trainable, learning_rate, adam_t, seed, problem_base, step, stream,
                             ev);
@@ -151,8 +153,13 @@ int vgpmp_elbo_step_profiled(const vgpmp_dims* dims, const vgpmp_robot* dev_robo
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) host_stage_ms[i] += ms;
         }
+        for (int k = 0; k < 2; ++k) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev[VGPMP_NUM_STAGES + 1 + 2 * k], ev[VGPMP_NUM_STAGES + 2 + 2 * k]) == hipSuccess)
+                host_stage_ms[VGPMP_NUM_STAGES + k] += ms;
+        }
     }
-    for (int i = 0; i <= VGPMP_NUM_STAGES; ++i) (void)hipEventDestroy(ev[i]);
+    for (int i = 0; i < kEv; ++i) (void)hipEventDestroy(ev[i]);
     return rc;
 }
 

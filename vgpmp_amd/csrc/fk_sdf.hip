@@ -7,6 +7,7 @@
 // Reference path: likelihoods/likelihood.py:57-176, utils/sampler.py:103-120,142-244,
 // utils/sdf_utils.py:62-136.
 #include "vgpmp_device.h"
+#include <hip/hip_ext.h>
 
 #ifdef VGPMP_BISECT
 #include <stdlib.h>
@@ -587,7 +588,8 @@ int vg_launch_log_prob_impl(const vgpmp_robot* rb, int dof, const vgpmp_sdf* sdf
 }
 
 int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const float* f, int P, int S, int L, int N,
-                           float scale, float* G, float* logp, float* lik_partial, int* nblk_out, hipStream_t st) {
+                           float scale, float* G, float* logp, float* lik_partial, int* nblk_out, hipStream_t st,
+                           hipEvent_t k0, hipEvent_t k1) {
     const int lpc = lik_lpc(P, S, N);
     const int nblk = (S * N * lpc + kLikBlock - 1) / kLikBlock;
     if (nblk_out) *nblk_out = nblk;
@@ -601,11 +603,12 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
 #ifdef VGPMP_BISECT
     dbg = lik_bisect_mode();
 #endif
+    // k0 / k1 (profiler): events stamped with the kernel's own start and end on the device
     if (lpc == 4)
-        hipLaunchKernelGGL(loglik_paths_wide_kernel, dim3(nblk, P), dim3(kLikBlock), lds, st, rb, *sdf, f, S, L, N, scale,
-                           G, logp, lik_partial);
+        hipExtLaunchKernelGGL(loglik_paths_wide_kernel, dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf, f, S, L, N,
+                              scale, G, logp, lik_partial);
     else
-        hipLaunchKernelGGL(loglik_paths_kernel<1>, dim3(nblk, P), dim3(kLikBlock), lds, st, rb, *sdf, f, S, L, N, scale,
-                           G, logp, lik_partial, dbg);
+        hipExtLaunchKernelGGL(loglik_paths_kernel<1>, dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf, f, S, L, N,
+                              scale, G, logp, lik_partial, dbg);
     return (int)hipGetLastError();
 }

@@ -10,6 +10,7 @@
 // the vector pipe; A = Kfu (Kuu + jitter I)^-1 is formed once per latent in float64 and only then
 // rounded, so the per-sample work (prior GEMM, path assembly) is well conditioned float32.
 #include "gp_path.h"
+#include <hip/hip_ext.h>
 #include <string.h>
 
 #ifdef VGPMP_BISECT
@@ -1853,11 +1854,13 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             mark();
             hipLaunchKernelGGL(features_kernel, feat_grid, dim3(kBlock), 0, st, fe);
             mark();
+            hipEvent_t g0 = ev ? ev[VG_NUM_STAGES + 3] : nullptr, g1 = ev ? ev[VG_NUM_STAGES + 4] : nullptr;
             if (tiled_gemm)
-                hipLaunchKernelGGL(prior_gemm_tiled_kernel, dim3((J + kTJ - 1) / kTJ, (S + kTS - 1) / kTS, P * L * ga.nsel),
-                                   dim3(kBlock), 0, st, S, L, J, B, ga.nsel, nz->w, ws->Phi, ws->dPhi, ws->F0, ws->H);
+                hipExtLaunchKernelGGL(prior_gemm_tiled_kernel, dim3((J + kTJ - 1) / kTJ, (S + kTS - 1) / kTS, P * L * ga.nsel),
+                                      dim3(kBlock), 0, st, g0, g1, 0, S, L, J, B, ga.nsel, nz->w, ws->Phi, ws->dPhi, ws->F0,
+                                      ws->H);
             else
-                hipLaunchKernelGGL(prior_gemm_kernel<0>, gemm_grid, dim3(kBlock), 0, st, ga);
+                hipExtLaunchKernelGGL(prior_gemm_kernel<0>, gemm_grid, dim3(kBlock), 0, st, g0, g1, 0, ga);
             mark();
             if ((rc = launch(fn_pf, dim3(NC, L, P), &pa, lds_pf))) return rc;
             mark();
@@ -1865,7 +1868,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         // ---- likelihood forward + reverse (fk_sdf.hip)
         int nblk = 0;
         rc = vg_launch_loglik_paths(rb, sdf, out->f, P, S, L, N, (float)(-lik_scale), ws->G, out->logp, ws->lik_partial,
-                                    &nblk, st);
+                                    &nblk, st, ev ? ev[VG_NUM_STAGES + 1] : nullptr, ev ? ev[VG_NUM_STAGES + 2] : nullptr);
         if (rc) return rc;
         fa.nblk = nblk;
         mark();

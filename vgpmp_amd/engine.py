@@ -280,12 +280,12 @@ class PlannerBatch:
 
     def profile_steps(self, steps: int):
         """`steps` training steps with a HIP event around every kernel: mean milliseconds per stage."""
-        ms = (C.c_float * capi.NUM_STAGES)()
+        ms = (C.c_float * capi.NUM_TIMES)()
         self.step_counter.fill_(self.t)
         for _ in range(steps):
             self._run_counter(stage_ms=ms)
             self.t += 1
-        return {name: ms[i] / steps for i, name in enumerate(capi.STAGE_NAMES)}
+        return {name: ms[i] / steps for i, name in enumerate(capi.STAGE_NAMES + capi.KERNEL_TIME_NAMES)}
 
     def adam_only(self) -> None:
         """Adam.apply_gradients on self.grad (after an external all-reduce)."""
