@@ -122,6 +122,7 @@ template <int LPC>
 __device__ __forceinline__ float quad_sum(float v) {
     if (LPC >= 2) v += __shfl_xor(v, 1, VG_WAVE);
     if (LPC >= 4) v += __shfl_xor(v, 2, VG_WAVE);
+    if (LPC >= 8) v += __shfl_xor(v, 4, VG_WAVE);
     return v;
 }
 
@@ -303,23 +304,23 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_kernel(const vgpmp_rob
 }
 
 // ---- ELBO path, few-problem form ---------------------------------------------------------------------
-// Four adjacent lanes share one (sample, time) configuration.  What bounds this launch when few problems
+// LPC (4 or 8) adjacent lanes share one (sample, time) configuration.  What bounds this launch when few problems
 // are in flight is the LENGTH of the dependent chain of one configuration, not throughput, so the chain is
 // cut to: joint angles -> frames (all of them, kept in LDS) -> ONE round of voxel gathers (every sphere
-// of a lane in flight together, kWideU per lane) -> hinge -> per-frame force / moment sums -> one sweep
+// of a lane in flight together, 48 / LPC per lane) -> hinge -> per-frame force / moment sums -> one sweep
 // back over the joints.  The robot table is copied to LDS first (its per-sphere rows are read per lane).
 // Sums over a lane's spheres are kept per frame in lane-private LDS slots, written once each (spheres are
 // sorted by frame) and combined across the four lanes by shuffles in a fixed order: deterministic.
-constexpr int kWideLanes = 4;
-constexpr int kWideU = 12;         // spheres per lane per round: one round up to 48 spheres
+constexpr int kWideSpheres = 48;   // spheres covered by ONE round of gathers (kWideSpheres / LPC per lane)
 
 __device__ __forceinline__ int wide_group_slots(int D) { return 2 * D + 12 * (D + 1); }     // sin, cos, frames
 __device__ __forceinline__ int wide_lane_slots(int D) { return 6 * (D + 1); }               // F, M per frame
-static size_t wide_lds_bytes(int D) {
-    const int cpb = kLikBlock / kWideLanes;
+static size_t wide_lds_bytes(int D, int lanes) {
+    const int cpb = kLikBlock / lanes;
     return sizeof(vgpmp_robot) + ((size_t)(2 * D + 12 * (D + 1) + D) * cpb + (size_t)6 * (D + 1) * kLikBlock) * sizeof(float);
 }
 
+template <int LPC>
 __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpmp_robot* __restrict__ rb_g, vgpmp_sdf sdfh,
                                                                        const float* __restrict__ f, int S, int L, int N,
                                                                        float scale, float* __restrict__ G,
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
                                                                        float* __restrict__ lik_partial) {
     extern __shared__ float lik_lds[];
     __shared__ float red[kLikBlock / VG_WAVE];
-    constexpr int LPC = kWideLanes, CPB = kLikBlock / LPC;
+    constexpr int CPB = kLikBlock / LPC, kWideU = kWideSpheres / LPC;
     const int pb = blockIdx.y, tid = threadIdx.x;
     VG_T(blockIdx.x == 0 && pb == 0, 400);
     const vgpmp_robot* rb = reinterpret_cast<const vgpmp_robot*>(lik_lds);          // LDS copy
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
     float fv[VGPMP_MAX_DOF / LPC];
 #pragma unroll
     for (int k = 0; k < VGPMP_MAX_DOF / LPC; ++k) fv[k] = f[base + (size_t)min(sub + LPC * k, L - 1) * N];
+    static_assert(VGPMP_MAX_DOF % LPC == 0, "joints are dealt to the lanes of a group");
     vg_dma_wait();
     __syncthreads();
     VG_T(blockIdx.x == 0 && pb == 0, 402);
@@ -533,9 +535,13 @@ __global__ __launch_bounds__(kBlock) void sdf_pack_kernel(const double* __restri
 
 }  // namespace
 
-// lanes per configuration: 4 while the launch is too small to fill the chip (instruction bound), else 1
-static int lik_lpc(int P, int S, int N) { return (long long)P * S * N <= 65536 ? 4 : 1; }
-int vg_loglik_blocks_per_problem(int S, int N) { return (S * N * 4 + kLikBlock - 1) / kLikBlock; }   // upper bound (LPC = 4)
+// lanes per configuration: 8 or 4 while the launch is too small to fill the chip (bound by the length of one
+// configuration's dependent chain), else 1
+static int lik_lpc(int P, int S, int N) {
+    const long long n = (long long)P * S * N;
+    return n <= 16384 ? 8 : (n <= 65536 ? 4 : 1);
+}
+int vg_loglik_blocks_per_problem(int S, int N) { return (S * N * 8 + kLikBlock - 1) / kLikBlock; }   // upper bound
 
 static size_t lik_lds_bytes(int dof, bool with_dgdf) {
     return (size_t)(2 * dof + 6 * (dof + 1) + (with_dgdf ? dof : 0)) * kLikBlock * sizeof(float);
@@ -594,9 +600,10 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
     const int nblk = (S * N * lpc + kLikBlock - 1) / kLikBlock;
     if (nblk_out) *nblk_out = nblk;
     if (P == 0 || nblk == 0) return 0;
-    static size_t granted1 = 0, granted4 = 0;
-    const size_t lds = lpc == 4 ? wide_lds_bytes(L) : lik_lds_bytes(L, true);
-    int rc = lpc == 4 ? lik_grant_lds((const void*)loglik_paths_wide_kernel, lds, &granted4)
+    static size_t granted1 = 0, granted4 = 0, granted8 = 0;
+    const size_t lds = lpc > 1 ? wide_lds_bytes(L, lpc) : lik_lds_bytes(L, true);
+    int rc = lpc == 8 ? lik_grant_lds((const void*)loglik_paths_wide_kernel<8>, lds, &granted8)
+           : lpc == 4 ? lik_grant_lds((const void*)loglik_paths_wide_kernel<4>, lds, &granted4)
                       : lik_grant_lds((const void*)loglik_paths_kernel<1>, lds, &granted1);
     if (rc) return rc;
     int dbg = 0;
@@ -604,9 +611,12 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
     dbg = lik_bisect_mode();
 #endif
     // k0 / k1 (profiler): events stamped with the kernel's own start and end on the device
-    if (lpc == 4)
-        hipExtLaunchKernelGGL(loglik_paths_wide_kernel, dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf, f, S, L, N,
-                              scale, G, logp, lik_partial);
+    if (lpc == 8)
+        hipExtLaunchKernelGGL(loglik_paths_wide_kernel<8>, dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf, f, S, L,
+                              N, scale, G, logp, lik_partial);
+    else if (lpc == 4)
+        hipExtLaunchKernelGGL(loglik_paths_wide_kernel<4>, dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf, f, S, L,
+                              N, scale, G, logp, lik_partial);
     else
         hipExtLaunchKernelGGL(loglik_paths_kernel<1>, dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf, f, S, L, N,
                               scale, G, logp, lik_partial, dbg);
