@@ -715,9 +715,10 @@ struct GemmArgs {
     int dbg;                 // measurement builds: 1 no stores, 2 no loads, 3 no MFMA
 };
 
-// KS > 0: the K-slice of a workgroup is KS steps of 16 and ALL its operands are requested before the first
-// MFMA (one L2 round trip instead of KS dependent ones -- at one problem these launches are latency bound,
-// not bandwidth bound).  KS == 0: any slice length, next step prefetched while the MFMAs of this one run.
+// KS > 0: the K-slice of a workgroup is a multiple of KS steps of 16 and goes in passes of KS steps whose operands
+// are ALL requested before the pass's first MFMA (one L2 round trip per pass instead of one per step -- at one
+// problem these launches are latency bound, not bandwidth bound).  KS == 0: any slice length, next step
+// prefetched while the MFMAs of this one run.
 template <int KS>
 __device__ __forceinline__ void prior_gemm_body(const GemmArgs& a, int bx, int by, int bz) {
     const int S = a.S, L = a.L, J = a.J, B = a.B, SK = a.SK, nsel = a.nsel;
@@ -746,40 +747,25 @@ __device__ __forceinline__ void prior_gemm_body(const GemmArgs& a, int bx, int b
 #pragma unroll
     for (int t = 0; t < kNT; ++t) acc[t] = (vg_f32x4){0.f, 0.f, 0.f, 0.f};
     if constexpr (KS > 0) {
-        float4 av[KS], bv[kNT][KS];
-#ifdef VGPMP_BISECT
-        if (a.dbg == 2) {
+        // the K-slice in passes of KS steps: every operand of a pass is requested before its first MFMA
+        for (int k0 = kbeg; k0 < kend; k0 += 16 * KS) {
+            float4 av[KS], bv[kNT][KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                av[ks] = make_float4(1.f, 2.f, 3.f, (float)lane);
+                av[ks] = *reinterpret_cast<const float4*>(ap + k0 + 16 * ks);
 #pragma unroll
-                for (int t = 0; t < kNT; ++t) bv[t][ks] = make_float4(1.f, 2.f, (float)t, (float)lane);
+                for (int t = 0; t < kNT; ++t) bv[t][ks] = *reinterpret_cast<const float4*>(bp[t] + k0 + 16 * ks);
             }
-        } else
-#endif
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            av[ks] = *reinterpret_cast<const float4*>(ap + kbeg + 16 * ks);
-#pragma unroll
-            for (int t = 0; t < kNT; ++t) bv[t][ks] = *reinterpret_cast<const float4*>(bp[t] + kbeg + 16 * ks);
-        }
-#ifdef VGPMP_BISECT
-        if (a.dbg == 3) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int t = 0; t < kNT; ++t) acc[t][ks & 3] += av[ks].x * bv[t][ks].y + av[ks].z * bv[t][ks].w;
-        } else
-#endif
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int t = 0; t < kNT; ++t) {
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].x, bv[t][ks].x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].y, bv[t][ks].y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].z, bv[t][ks].z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].w, bv[t][ks].w, acc[t], 0, 0, 0);
-            }
+                for (int t = 0; t < kNT; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].x, bv[t][ks].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].y, bv[t][ks].y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].z, bv[t][ks].z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].w, bv[t][ks].w, acc[t], 0, 0, 0);
+                }
+        }
     } else {
         float4 a_cur = *reinterpret_cast<const float4*>(ap + kbeg);
         float4 b_cur[kNT];
@@ -1775,7 +1761,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     fa.dma = fin_dma ? 1 : 0;
     const size_t lds_s1 = lds_cov_a > lds_fin ? lds_cov_a : lds_fin;
     const void* fn_cov_b = backward ? (const void*)cov_b_kernel<true> : (const void*)cov_b_kernel<false>;
-    const bool k8 = B / SK == 128;      // B = 1024 with 8 K-slices: all operands of a workgroup in one request
+    const bool k8 = (B / SK) % 128 == 0;      // K-slice in passes of 8 steps of 16: a pass's operands in one request
     const void* fn_s2 = backward ? (k8 ? (const void*)stage2_kernel<true, 8> : (const void*)stage2_kernel<true, 0>)
                                  : (k8 ? (const void*)stage2_kernel<false, 8> : (const void*)stage2_kernel<false, 0>);
     if (SC != 8) return VGPMP_E_SHAPE;
