@@ -311,6 +311,7 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_kernel(const vgpmp_rob
 // back over the joints.  The robot table is copied to LDS first (its per-sphere rows are read per lane).
 // Sums over a lane's spheres are kept per frame in lane-private LDS slots, written once each (spheres are
 // sorted by frame) and combined across the four lanes by shuffles in a fixed order: deterministic.
+static_assert(sizeof(vgpmp_robot) % 16 == 0, "the robot table is copied to LDS in 16-byte units");
 constexpr int kWideSpheres = 48;   // spheres covered by ONE round of gathers (kWideSpheres / LPC per lane)
 
 __device__ __forceinline__ int wide_group_slots(int D) { return 2 * D + 12 * (D + 1); }     // sin, cos, frames
