@@ -107,8 +107,8 @@ __device__ __forceinline__ int voxel_axis(float pos, float ch, float cl, float i
     return idx;
 }
 
-// Per-configuration scratch in LDS ([slot][configuration], conflict free): the frame loop stays ROLLED
-// (small code: these launches are instruction-fetch bound), so per-frame data cannot live in indexed
+// Per-configuration scratch in LDS ([slot][configuration], conflict free): the frame loop is a run-time
+// loop (dof is a run-time value), so per-frame data cannot live in indexed
 // registers.  LPC lanes (1 or 4, adjacent lanes of one wave) share one configuration and its scratch.
 struct LikScratch {
     float* base;

@@ -42,7 +42,7 @@ __device__ __forceinline__ double matern52_dell(double t1, double t2, double ell
 }
 
 // e / n for 0 <= e < 2^21 via a float reciprocal (exact for n <= 4096, checked exhaustively): a 32-bit
-// integer division expands to ~30 instructions, and these kernels are instruction-fetch bound
+// integer division expands to ~30 instructions on the critical path of every indexing loop
 __device__ __forceinline__ int vg_div(int e, float inv_n) { return (int)(((float)e + 0.5f) * inv_n); }
 
 // strided dot product with four independent accumulators (a dependent f64 FMA costs ~40 cycles)
@@ -205,8 +205,8 @@ __device__ __forceinline__ void matmul_f64(MatView A, MatView B, int Mp, int tid
 // Cholesky factor and its inverse of the SPD matrix held in La (LDS), by forward elimination of the
 // augmented matrix [K | I] without pivoting (K = L~ D L~^T): after Mz pivots the left half holds
 // U = D L~^T and the right half L~^-1, so  Lk = L~ D^1/2  and  Lk^-1 = D^-1/2 L~^-1.  Every pivot is
-// one rank-1 update spread over the whole workgroup and ONE barrier; the code stays rolled and small
-// (these launches are instruction-fetch bound, a fully unrolled register Cholesky was slower).
+// one rank-1 update spread over the whole workgroup and ONE barrier (any Mz; chol_inverse_regs below is the
+// faster form for Mz <= 32).
 __device__ __forceinline__ void chol_inverse_block(double* La, double* Li, double* Aug, double* rsd, int Mz, int ld,
                                                    int tid, int nt) {
     const int la = 2 * Mz + 1;
@@ -959,7 +959,7 @@ __device__ __forceinline__ float read_slabs(const float* base, size_t off, size_
 
 // All operands of a workgroup are staged into LDS by ONE wave of independent coalesced loads (these
 // launches are latency bound: every dependent global access costs ~0.3-0.7 us), then the loops run
-// out of LDS.  Code is kept rolled: cold instruction fetch is the other fixed cost of tiny launches.
+// out of LDS.
 // sum of the SK split-K slabs of an LDS image [SK][n]: fixed-order tree
 template <int SK>
 __device__ __forceinline__ float sum_slabs_lds(const float* raw, int e, int n) {
@@ -1443,7 +1443,7 @@ __global__ __launch_bounds__(kBlock) void paths_fwd_sc8(PathArgs a) {
 
 // =================================================================================================
 // Role-dispatched launches for the few-problem regime.  One problem offers ~100 workgroups per kernel
-// on a 256-CU part and every launch pays ~3 us of dispatch plus a cold instruction fetch, while
+// on a 256-CU part and every launch pays ~2.5 us of dispatch plus a first touch of data another XCD wrote, while
 // overlapping kernels across HIP streams costs ~11 us per cross-stream edge on this platform (measured,
 // tools/anyorder_probe.hip; hipExtAnyOrderLaunch is not honoured on gfx9).  So independent kernels of one
 // dependency level are issued as ONE launch whose workgroup index selects the role:
