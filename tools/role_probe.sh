@@ -3,5 +3,5 @@
 export VGPMP_HIP_LIB=$PWD/tools/libvgpmp_bisect.so
 for cfg in "$@"; do
   echo "== $cfg"
-  env $cfg tools/prof_fused.sh --allow-nan | grep -E "stage[123]_kernel<?(true|8|\()|stage1"
+  env $cfg tools/prof_fused.sh --allow-nan | grep -E "stage[123]_kernel"
 done
