@@ -108,11 +108,7 @@ def solve_planning_problems_batched(env, queries, seed: int = 0):
                              trainable={"q_mu": bool(tp["q_mu"]), "q_sqrt": bool(tp["q_sqrt"]),
                                         "lengthscales": bool(tp["lengthscales"]),
                                         "kernel_variance": bool(tp["kernel_variance"])})
-    steps = int(pp["num_steps"])
-    if steps >= 20:
-        pl.capture(10)
-        steps -= 1
-    pl.run_steps(steps)
+    pl.run_steps(int(pp["num_steps"]))
     Xnew = np.tile(np.linspace(0.0, 1.0, int(pp["time_spacing_Xnew"]))[:, None], (1, dof))
     _, best, _, _ = pl.sample_from_posterior(150, Xnew, step=pl.t)
     clear = pl.path_clearance(best).amin(dim=(1, 2)).cpu().numpy()

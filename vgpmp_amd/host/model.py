@@ -296,8 +296,9 @@ class VGPMP:
         self._check_data(data)
         return lambda: float(-pl.elbo(generate=True)[0])
 
-    def optimization_steps(self, data, num_steps: int, graph_unroll: int = 10) -> None:
-        """num_steps x (ELBO, reverse pass, Adam) on the device; replayed as hipGraphs of `graph_unroll` steps."""
+    def optimization_steps(self, data, num_steps: int, graph_unroll: int = 0) -> None:
+        """num_steps x (ELBO, reverse pass, Adam) on the device in one vgpmp_elbo_steps call (plain launches measure
+        2-3 % faster than hipGraph replay; graph_unroll > 0 captures and replays graphs of that many steps)."""
         pl = self._ensure(self._check_data(data))
         self._check_data(data)
         if graph_unroll and num_steps >= 2 * graph_unroll and pl._graph is None:
