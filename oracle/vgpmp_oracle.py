@@ -22,7 +22,10 @@ PINNING STATUS
   * Pathwise sampling, KL, ELBO, Adam (A2-A7, A11-A13): PARITY UNPINNED -- the
     reference holds no test or golden vector for them and GPflow/GPflowSampling/
     TF cannot run here.  Their gradients are pinned only against torch.autograd
-    (float64) applied to an independent restatement in tests/.
+    (float64) applied to an independent restatement in tests/, and the first two
+    moments of the pathwise samples against the closed forms of the published
+    algorithms (tests/test_pathwise_statistics.py): a statistical check, not a
+    vector from the reference.
 
 Notation: S samples, N time points, D = L dof/latents, M inducing, Mz = M + 2,
 P spheres, B Fourier bases.
