@@ -29,7 +29,9 @@ struct vg_workspace {
     float *G;                // [P,S,L,N]     dloss/df
     float *lik_partial;      // [P,nblk]
     float *part;             // [P,L,NC,PART] per-chunk reductions of the reverse pass
-    double *lr_t;            // [P]           bias-corrected Adam step size of the running step
+    double *lr_t;            // [P]           [0]: bias-corrected Adam step size of the running step (set at the counter tick)
+    double *theta_next;      // [P,L,6]       updated hyper-parameters + moments between stage 1 and stage 2
+    double *prev_var, *prev_sig_ell, *prev_sig_var;   // [P,L] var / softplus slopes of the previous step
 };
 
 inline int vg_mz(const vgpmp_dims* d) { return d->M + 2; }

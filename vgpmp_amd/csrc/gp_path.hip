@@ -140,775 +140,6 @@ __global__ __launch_bounds__(kBlock) void rng_normals_kernel(RngArgs a) {
     rng_normals_body(a, blockIdx.x, blockIdx.y, a.nW, a.nE);
 }
 
-// =================================================================================================
-// Covariance path (float64).
-//
-// cov_fwd_kernel -- one workgroup per (latent, problem): Kuu, chol, inverse, q_sqrt, KL and its
-//   gradient, plus the FORWARD-MODE tangents of chol/q_sqrt/KL wrt the latent's two kernel
-//   hyper-parameters (lengthscale, variance).
-// cov_rows_kernel -- row tiles of A = Kfu (Kuu + jI)^-1 and of its two tangents, spread over
-//   N/8 workgroups per latent.
-// With the tangents available the sample-dependent reverse pass needs only dot products of its
-// upstream gradients with them -- no Cholesky adjoint, no N-sized float64 reductions -- and both
-// kernels sit off the critical path (side stream) next to the noise/feature/GEMM branch.
-// =================================================================================================
-struct CovArgs {
-    int N, M, L, D;
-    const double *X, *Zy, *y_u;
-    double jitter;
-    const double *q_mu, *q_sqrt, *raw_ell, *raw_var;
-    int want_dell;
-    int stop;
-    uint32_t* tick;          // device step counter, ticked by one row-tile workgroup of stage 2 (or null)
-    vg_workspace ws;
-};
-
-constexpr int kCovThreads = 256;      // == kBlock: the covariance roles share launches with other kernels
-constexpr int kRowTile = 8;
-
-// ---- float64 matrix-core tiles ---------------------------------------------------------------------
-// v_mfma_f64_16x16x4_f64: lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15] (one
-// double each); it receives D[row = (l >> 4) + 4 q][col = l & 15] in accumulator element q = 0..3.
-// All matrices live in LDS with dimension Mp = roundup(Mz, 16) (zero padded), so no edge handling.
-typedef double vg_f64x4 __attribute__((ext_vector_type(4)));
-
-struct MatView {            // element (r, c) at p[r * sr + c * sc]
-    const double* p;
-    int sr, sc;
-};
-
-__device__ __forceinline__ vg_f64x4 mfma_tile_f64(MatView A, MatView B, int K, int lane, int i0, int j0) {
-    vg_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-    const int r = lane & 15, g = lane >> 4;
-    const double* ap = A.p + (i0 + r) * A.sr + g * A.sc;
-    const double* bp = B.p + g * B.sr + (j0 + r) * B.sc;
-#pragma unroll 8
-    for (int k = 0; k < K; k += 4) {
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[k * A.sc], bp[k * B.sr], acc, 0, 0, 0);
-    }
-    return acc;
-}
-
-// D = A B over all 16x16 tiles of an Mp x Mp result, tiles dealt round-robin to the waves; `emit(r, c, v)`
-// receives every element.
-template <typename Emit>
-__device__ __forceinline__ void matmul_f64(MatView A, MatView B, int Mp, int tid, int nt, Emit emit) {
-    const int lane = tid & 63, nT = Mp >> 4;
-    for (int t = tid >> 6; t < nT * nT; t += nt >> 6) {
-        const int i0 = (t / nT) << 4, j0 = (t % nT) << 4;
-        const vg_f64x4 acc = mfma_tile_f64(A, B, Mp, lane, i0, j0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) emit(i0 + (lane >> 4) + 4 * q, j0 + (lane & 15), acc[q]);
-    }
-}
-
-// Cholesky factor and its inverse of the SPD matrix held in La (LDS), by forward elimination of the
-// augmented matrix [K | I] without pivoting (K = L~ D L~^T): after Mz pivots the left half holds
-// U = D L~^T and the right half L~^-1, so  Lk = L~ D^1/2  and  Lk^-1 = D^-1/2 L~^-1.  Every pivot is
-// one rank-1 update spread over the whole workgroup and ONE barrier (any Mz; chol_inverse_regs below is the
-// faster form for Mz <= 32).
-__device__ __forceinline__ void chol_inverse_block(double* La, double* Li, double* Aug, double* rsd, int Mz, int ld,
-                                                   int tid, int nt) {
-    const int la = 2 * Mz + 1;
-    const float iMz = 1.0f / (float)Mz, i2Mz = 0.5f / (float)Mz;
-    for (int e = tid; e < Mz * 2 * Mz; e += nt) {
-        const int i = vg_div(e, i2Mz), j = e - i * 2 * Mz;
-        Aug[i * la + j] = j < Mz ? La[i * ld + j] : (j - Mz == i ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    for (int k = 0; k < Mz; ++k) {
-        const double r = 1.0 / Aug[k * la + k];
-        const int h = Mz - k - 1;                   // rows k+1 .. Mz-1, columns k+1 .. Mz+k
-        for (int e = tid; e < h * Mz; e += nt) {
-            const int qi = vg_div(e, iMz);
-            const int i = k + 1 + qi, j = k + 1 + (e - qi * Mz);
-            Aug[i * la + j] = fma(-(Aug[i * la + k] * r), Aug[k * la + j], Aug[i * la + j]);
-        }
-        __syncthreads();
-    }
-    for (int k = tid; k < Mz; k += nt) rsd[k] = rsqrt(Aug[k * la + k]);
-    __syncthreads();
-    for (int e = tid; e < Mz * Mz; e += nt) {
-        const int i = vg_div(e, iMz), j = e - i * Mz;
-        La[i * ld + j] = j <= i ? Aug[j * la + i] * rsd[j] : 0.0;
-        Li[i * ld + j] = j <= i ? Aug[i * la + Mz + j] * rsd[i] : 0.0;
-    }
-    __syncthreads();
-}
-
-// The same elimination with the augmented matrix in REGISTERS (Mz <= 32, 256 threads): thread (row i = tid & 31,
-// column block jb = tid >> 5) keeps columns [8 jb, 8 jb + 8) of [K | I] laid out as 32 + 32 columns.  Per pivot
-// the owners publish the pivot row and the pivot column through LDS (double buffered: one barrier per pivot),
-// everyone reads its 8 + 2 values in one LDS round and does 8 FMAs out of registers; measured 340 ns per pivot
-// against 420 ns for the LDS-resident loop above (three LDS reads and a write per element).
-__device__ __forceinline__ void chol_inverse_regs(double* La, double* Li, double* Aug, double* rsd, int Mz, int ld,
-                                                  int tid, int nt) {
-    const int i = tid & 31, jb = tid >> 5, la = 2 * Mz + 1;
-    const float iMz = 1.0f / (float)Mz;
-    double* prow = Aug;                  // [2][64] pivot row, both halves
-    double* pcol = Aug + 128;            // [2][32] pivot column
-    double a[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const int col = 8 * jb + c;      // < 32: column of K;  >= 32: column col - 32 of I
-        a[c] = i < Mz ? (col < 32 ? (col < Mz ? La[i * ld + col] : 0.0) : (col - 32 == i ? 1.0 : 0.0)) : 0.0;
-    }
-    __syncthreads();
-#pragma nounroll
-    for (int kb = 0; kb < 4; ++kb) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int k = 8 * kb + c;
-            if (k >= Mz) break;
-            const int buf = k & 1;
-            if (i == k) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) prow[buf * 64 + 8 * jb + q] = a[q];
-            }
-            if (jb == kb) pcol[buf * 32 + i] = a[c];
-            __syncthreads();
-            // one LDS round for everything this thread needs of pivot k (read unconditionally, used conditionally)
-            const double piv = pcol[buf * 32 + k], aik = pcol[buf * 32 + i];
-            double pr[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) pr[q] = prow[buf * 64 + 8 * jb + q];
-            if (tid == 0) rsd[k] = piv;          // rsqrt after the loop, off the chain
-            // 1 / piv sits on the dependency chain of every pivot: hardware estimate + two Newton steps (to the
-            // last bit or two) instead of the ~10-instruction IEEE division sequence
-            double r = __builtin_amdgcn_rcp(piv);
-            r = fma(fma(-piv, r, 1.0), r, r);
-            r = fma(fma(-piv, r, 1.0), r, r);
-            const double m = (i > k && i < Mz) ? aik * r : 0.0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) a[q] = fma(-m, pr[q], a[q]);
-        }
-    }
-    __syncthreads();
-    if (tid < Mz) rsd[tid] = rsqrt(rsd[tid]);
-    __syncthreads();
-    // registers -> the [Mz][2 Mz + 1] image the tail expects: left half U = D L~^T, right half L~^-1
-    double* Img = Aug;                   // the exchange buffers are dead now
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const int col = 8 * jb + c;
-        if (i < Mz) {
-            if (col < Mz) Img[i * la + col] = a[c];
-            else if (col >= 32 && col - 32 < Mz) Img[i * la + Mz + (col - 32)] = a[c];
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < Mz * Mz; e += nt) {
-        const int r = vg_div(e, iMz), j = e - r * Mz;
-        La[r * ld + j] = j <= r ? Img[j * la + r] * rsd[j] : 0.0;
-        Li[r * ld + j] = j <= r ? Img[r * la + Mz + j] * rsd[r] : 0.0;
-    }
-    __syncthreads();
-}
-
-// ---- stage A: Kuu, factorisation, inverse --------------------------------------------------------
-__device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, int p) {
-    __shared__ double scal[2];
-    const int tid = threadIdx.x, nt = blockDim.x;
-    VG_T(l == 0 && p == 0, 100);
-    const int M = a.M, Mz = M + 2, L = a.L, D = a.D;
-    const int Mp = (Mz + 15) & ~15, ld = Mp + 1;
-    const float iMz = 1.0f / (float)Mz;
-    const size_t pl = (size_t)p * L + l;
-    double* La = sm;                 // Kuu + jI -> Cholesky factor Lk      (Mp x ld, zero padded)
-    double* Li = La + Mp * ld;       // Lk^-1
-    double* Sc = Li + Mp * ld;       // 2 x (Mp x ld) scratch: augmented matrix of the elimination
-    double* zs = Sc + 2 * Mp * ld;   // [Mp]
-    double* rsd = zs + Mp;           // [Mp]
-    if (tid == 0) {
-        const double re = a.raw_ell[pl], rv = a.raw_var[pl];
-        scal[0] = softplus_d(re);
-        scal[1] = kVarFloor + softplus_d(rv);
-        a.ws.sig_ell[pl] = sigmoid_d(re);
-        a.ws.sig_var[pl] = sigmoid_d(rv);
-    }
-    for (int e = tid; e < 2 * Mp * ld; e += nt) sm[e] = 0.0;
-    for (int i = tid; i < Mz; i += nt) zs[i] = a.Zy[(size_t)i * D + l];
-    __syncthreads();
-    const double ell = scal[0], var = scal[1], jit = a.jitter;
-    if (tid == 0) { a.ws.ell[pl] = ell; a.ws.var[pl] = var; }
-    // Kuu and dKuu/dell share the exponential; symmetric: evaluate the lower triangle only
-    double* Kg = a.ws.Ks64 + pl * Mz * Mz;
-    double* Kdg = a.ws.Kd_ell + pl * Mz * Mz;
-    for (int e = tid; e < Mz * Mz; e += nt) {
-        int i = vg_div(e, iMz), j = e - i * Mz;
-        if (j > i) continue;
-        double r = fabs(zs[i] - zs[j]) / ell;
-        double ex = exp(-kSqrt5 * r);
-        double k = var * (1.0 + kSqrt5 * r + (5.0 / 3.0) * r * r) * ex;
-        double dk = var * ex * (5.0 * r * r / (3.0 * ell)) * (1.0 + kSqrt5 * r);
-        La[i * ld + j] = k + (i == j ? jit : 0.0);
-        Kg[(size_t)i * Mz + j] = k;
-        Kdg[(size_t)i * Mz + j] = dk;
-        if (i != j) { La[j * ld + i] = k; Kg[(size_t)j * Mz + i] = k; Kdg[(size_t)j * Mz + i] = dk; }
-    }
-    __syncthreads();
-    VG_T(l == 0 && p == 0, 101);
-    if (Mz <= 32 && nt == 256) chol_inverse_regs(La, Li, Sc, rsd, Mz, ld, tid, nt);
-    else chol_inverse_block(La, Li, Sc, rsd, Mz, ld, tid, nt);
-    VG_T(l == 0 && p == 0, 102);
-    double* Kig = a.ws.Kinv + pl * Mz * Mz;
-    matmul_f64(MatView{Li, 1, ld}, MatView{Li, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
-        if (r < Mz && c < Mz) Kig[(size_t)r * Mz + c] = v;
-    });
-    double* Lkg = a.ws.Lk64 + pl * Mz * Mz;
-    double* Lig = a.ws.Li64 + pl * Mz * Mz;
-    for (int e = tid; e < Mz * Mz; e += nt) {
-        const int i = vg_div(e, iMz), j = e - i * Mz;
-        Lkg[e] = La[i * ld + j];
-        Lig[e] = Li[i * ld + j];
-    }
-    VG_T(l == 0 && p == 0, 103);
-}
-
-__global__ __launch_bounds__(kCovThreads) void cov_a_kernel(CovArgs a) {
-    extern __shared__ double sm[];
-    cov_a_body(a, sm, blockIdx.x, blockIdx.y);
-}
-
-// ---- stage B: heterogeneous launch, role = blockIdx.x ---------------------------------------------
-//   0            q_sqrt = Lk pad(Q) + jitter, q_mu, KL and its gradient wrt q_mu / q_sqrt
-//   1, 2         forward-mode tangent wrt lengthscale / variance:  dC = (Lk Phi(Lk^-1 dK Lk^-T)) pad(Q), dKL
-//   3 + t        row tile t of A = Kfu (Kuu + jI)^-1 and its tangents (cov_rows_body)
-__device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int p, int tid, int nt);
-
-template <bool TANGENTS>
-__device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int role, int l, int p) {
-    __shared__ double red[kCovThreads / VG_WAVE];
-    const int tid = threadIdx.x, nt = blockDim.x;
-    if (role >= 3) {
-        // The step counter ticks where no kernel that reads it runs alongside: noise drawn before this launch
-        // saw the old value, the noise of the next step and the Adam count see the new one.
-        if (a.tick && role == 3 && l == 0 && p == 0 && tid == 0) *a.tick += 1u;
-        cov_rows_body(a, sm, role - 3, l, p, tid, nt);
-        return;
-    }
-    if (role > 0 && (!TANGENTS || (role == 1 && !a.want_dell))) return;
-    VG_T(l == 0 && p == 0, 200 + 10 * role);
-    const int M = a.M, Mz = M + 2, L = a.L;
-    const int Mp = (Mz + 15) & ~15, ld = Mp + 2;      // even: LDS rows start on 16 bytes
-    const float iMz = 1.0f / (float)Mz, iM = 1.0f / (float)M;
-    const size_t pl = (size_t)p * L + l;
-    double* La = sm;                 // Lk, later pad(q_sqrt) for the tangents   (all Mp x ld, zero padded)
-    double* Li = La + Mp * ld;       // Lk^-1
-    double* X1 = Li + Mp * ld;       // role 0: pad(q_sqrt), Q at [2:, 2:];  tangents: dK/dtheta, then W
-    double* X2 = X1 + Mp * ld;       // tangents: scratch T
-    double* dl = X2 + Mp * ld;       // [Mp] q_mu - p_mu
-    double* af = dl + Mp;            // [Mp] Lk^-1 (q_mu - p_mu)
-    double* v1 = af + Mp;            // [Mp]
-    double* k0 = v1 + Mp;            // [Mp] first two columns of Kuu + jI
-    double* k1 = k0 + Mp;
-    double* kd0 = k1 + Mp;           // [Mp] first two columns of dK/dtheta
-    double* kd1 = kd0 + Mp;
-    double* Qp = X1;
-    double* Kd = X1;
-    double* T = X2;
-    double* qm = kd1 + Mp;           // [Mp] q_mu behind the two conditioned points
-    const double jit = a.jitter, var = a.ws.var[pl];
-    const double y0 = a.y_u[((size_t)p * 2 + 0) * L + l], y1 = a.y_u[((size_t)p * 2 + 1) * L + l];
-    const double* Kg = a.ws.Ks64 + pl * Mz * Mz;
-    constexpr int kQRegs = (VGPMP_MAX_MZ - 2) * (VGPMP_MAX_MZ - 2) / kCovThreads + 1;
-    double qreg[kQRegs];
-    {
-        // every operand by DMA, all requests in flight together (zero padding written directly)
-        const double* Qg = a.q_sqrt + pl * M * M;
-        auto all = [](int, int) { return true; };
-        const bool square = Mz == Mp;      // no zero padding needed: whole rows in 16-byte units
-        if (square) {
-            vg_stage_f64_square(La, ld, a.ws.Lk64 + pl * Mz * Mz, Mz, tid, nt);
-            vg_stage_f64_square(Li, ld, a.ws.Li64 + pl * Mz * Mz, Mz, tid, nt);
-        } else {
-            vg_stage_f64(La, Mp, ld, a.ws.Lk64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
-            vg_stage_f64(Li, Mp, ld, a.ws.Li64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
-        }
-        if (role == 0) {
-            vg_stage_f64(Qp, Mp, ld, Qg, M, M, 2, 2, tid, nt, [](int r, int c) { return c <= r; });
-        } else {      // tangents: this thread's share of Q waits in registers until Lk's LDS space is free
-            const double* Kdg = role == 1 ? a.ws.Kd_ell + pl * Mz * Mz : Kg;
-            if (square) vg_stage_f64_square(Kd, ld, Kdg, Mz, tid, nt);
-            else vg_stage_f64(Kd, Mp, ld, Kdg, Mz, Mz, 0, 0, tid, nt, all);
-#pragma unroll
-            for (int k = 0; k < kQRegs; ++k) qreg[k] = Qg[min(tid + k * nt, M * M - 1)];
-        }
-        // k0 | k1: the first two columns of Kuu;  qm: q_mu at [2:]
-        vg_stage_words(k0, 4 * Mp, tid, nt, [&](int w) -> const void* {
-            const int d = w >> 1, col = d >= Mp, i = d - col * Mp;
-            return i < Mz ? reinterpret_cast<const uint32_t*>(Kg + (size_t)i * Mz + col) + (w & 1) : nullptr;
-        });
-        vg_stage_words(qm, 2 * Mp, tid, nt, [&](int w) -> const void* {
-            const int i = w >> 1;
-            return (i >= 2 && i < Mz) ? reinterpret_cast<const uint32_t*>(a.q_mu + pl * M + (i - 2)) + (w & 1) : nullptr;
-        });
-    }
-    vg_dma_wait();
-    __syncthreads();
-    if (tid == 0) { k0[0] += jit; k1[1] += jit; qm[0] = y0; qm[1] = y1; }
-    if (role == 2) {
-        for (int e = tid; e < Mz * Mz; e += nt) {       // dK/dvar = K / var
-            const int i = vg_div(e, iMz), j = e - i * Mz;
-            Kd[i * ld + j] /= var;
-        }
-    }
-    if (role == 0) {                         // float32 copy for the gradient assembly (written here, not in stage A:
-        float* Lk32 = a.ws.Lk32 + pl * Mz * Mz;      // stage A of the next step may overlap that kernel)
-        for (int e = tid; e < Mz * Mz; e += nt) {
-            const int i = vg_div(e, iMz), j = e - i * Mz;
-            Lk32[e] = (float)La[i * ld + j];
-        }
-    }
-    __syncthreads();
-    VG_T(l == 0 && p == 0, 201 + 10 * role);
-    // prior mean through the two conditioned points and a = Lk^-1 (q_mu - p_mu)  (prior_kl.py:16-35)
-    const double k00 = k0[0], k01 = k1[0], k11 = k1[1];
-    const double det = k00 * k11 - k01 * k01;
-    const double c0 = (k11 * y0 - k01 * y1) / det, c1 = (k00 * y1 - k01 * y0) / det;
-    for (int i = tid; i < Mz; i += nt) {
-        const double mi = qm[i];
-        if (role == 0) a.ws.m[pl * Mz + i] = (float)mi;
-        dl[i] = mi - (k0[i] * c0 + k1[i] * c1);
-    }
-    __syncthreads();
-    double klacc = 0.0;
-    for (int i = tid; i < Mz; i += nt) {
-        const double s = dot4(Li + i * ld, 1, dl, 1, i + 1);
-        af[i] = s;
-        if (i >= 2) klacc += s * s;
-    }
-    __syncthreads();
-    if (role == 0) {
-        float* C32 = a.ws.C + pl * Mz * Mz;
-        matmul_f64(MatView{La, ld, 1}, MatView{Qp, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
-            if (r < Mz && c < Mz) C32[(size_t)r * Mz + c] = (float)(v + (r == c && r < 2 ? jit : 0.0));
-        });
-        double* gklQ = a.ws.gkl_Q + pl * M * M;
-        for (int e = tid; e < M * M; e += nt) {
-            int r = vg_div(e, iM), c = e - r * M;
-            double gq = 0.0;
-            if (c <= r) {
-                double q = Qp[(r + 2) * ld + (c + 2)];
-                klacc += q * q;
-                gq = q;
-                if (c == r) { klacc -= log(q * q); gq -= 1.0 / q; }
-            }
-            gklQ[e] = gq;
-        }
-        const double kl = block_sum(klacc, red);
-        if (tid == 0) a.ws.kl_l[pl] = 0.5 * (kl - (double)M);
-        // d KL / d q_mu = (Lk^-T [0, 0, a])[2:]
-        for (int k = tid + 2; k < Mz; k += nt)
-            a.ws.gkl_qmu[pl * M + (k - 2)] = dot4(Li + k * ld + k, ld, af + k, 1, Mz - k);
-        VG_T(l == 0 && p == 0, 202);
-        return;
-    }
-    // ---- tangent wrt theta: W = Phi(Lk^-1 dK Lk^-T), dLk = Lk W, dC = dLk pad(Q)   (64-bit MFMA products)
-    // Four LDS matrices (35 KB at Mz = 32, so that these workgroups pack 4 per CU next to the prior GEMM):
-    // W overwrites dK (its first two columns are kept), dLk overwrites T, and pad(Q) -- prefetched into
-    // registers -- takes the place of Lk once Lk has been used.
-    for (int i = tid; i < Mz; i += nt) { kd0[i] = Kd[i * ld + 0]; kd1[i] = Kd[i * ld + 1]; }
-    VG_T(l == 0 && p == 0, 204 + 10 * role);
-    matmul_f64(MatView{Li, ld, 1}, MatView{Kd, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) { T[r * ld + c] = v; });
-    __syncthreads();
-    VG_T(l == 0 && p == 0, 205 + 10 * role);
-    double* W = X1;
-    matmul_f64(MatView{T, ld, 1}, MatView{Li, 1, ld}, Mp, tid, nt, [&](int r, int c, double v) {
-        W[r * ld + c] = c < r ? v : (c == r ? 0.5 * v : 0.0);
-    });
-    __syncthreads();
-    VG_T(l == 0 && p == 0, 206 + 10 * role);
-    matmul_f64(MatView{La, ld, 1}, MatView{W, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) { T[r * ld + c] = v; });
-    __syncthreads();
-    VG_T(l == 0 && p == 0, 207 + 10 * role);
-    for (int e = tid; e < Mp * ld; e += nt) La[e] = 0.0;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kQRegs; ++k) {
-        const int e = tid + k * nt;
-        if (e < M * M) {
-            const int r = vg_div(e, iM), c = e - r * M;
-            if (c <= r) La[(r + 2) * ld + (c + 2)] = qreg[k];
-        }
-    }
-    __syncthreads();
-    float* CT = (role == 1 ? a.ws.CT_ell : a.ws.CT_var) + pl * Mz * Mz;
-    matmul_f64(MatView{T, ld, 1}, MatView{La, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
-        if (r < Mz && c < Mz) CT[(size_t)c * Mz + r] = (float)v;       // stored transposed
-    });
-    VG_T(l == 0 && p == 0, 202 + 10 * role);
-    // KL tangent: a_dot = Lk^-1 (delta_dot - dLk a),  delta_dot = -d p_mu
-    const double d00 = kd0[0], d01 = kd1[0], d11 = kd1[1];
-    const double e0 = d00 * c0 + d01 * c1, e1 = d01 * c0 + d11 * c1;        // dKyy c
-    const double cd0 = -(k11 * e0 - k01 * e1) / det, cd1 = -(k00 * e1 - k01 * e0) / det;
-    for (int i = tid; i < Mz; i += nt) {
-        const double s = dot4(T + i * ld, 1, af, 1, i + 1);
-        const double pd = kd0[i] * c0 + kd1[i] * c1 + k0[i] * cd0 + k1[i] * cd1;
-        v1[i] = -pd - s;
-    }
-    __syncthreads();
-    double acc = 0.0;
-    for (int i = tid + 2; i < Mz; i += nt) acc += af[i] * dot4(Li + i * ld, 1, v1, 1, i + 1);
-    acc = block_sum(acc, red);
-    if (tid == 0) (role == 1 ? a.ws.gkl_ell : a.ws.gkl_var)[pl] = acc;
-    VG_T(l == 0 && p == 0, 203 + 10 * role);
-}
-
-template <bool TANGENTS>
-__global__ __launch_bounds__(kCovThreads) void cov_b_kernel(CovArgs a) {
-    extern __shared__ double sm[];
-    cov_b_body<TANGENTS>(a, sm, blockIdx.x, blockIdx.y, blockIdx.z);
-}
-
-// A = Kfu (Kuu + jI)^-1 and its tangents for a tile of kRowTile time points:
-//   A_ell = (dKfu/dell - A dKuu/dell) Kinv,   A_var = (jitter / var) A Kinv
-// Output float32: A4[n][m] = {A, A_ell, A_var, 0} (one 16-byte load per use in the reverse pass)
-// and AT[m][n] for the forward path assembly.
-__device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int p, int tid, int nt) {
-    const int M = a.M, Mz = M + 2, N = a.N, L = a.L, D = a.D, ld = (Mz + 2) & ~1;
-    VG_T(tile == 0 && l == 0 && p == 0, 230);
-    const float iMz = 1.0f / (float)Mz;
-    const size_t pl = (size_t)p * L + l;
-    double* Ki = sm;                       // [Mz][ld]
-    double* Kd = Ki + Mz * ld;             // [Mz][ld]
-    double* kf = Kd + Mz * ld;             // [RT][Mz]  Kfu rows
-    double* df = kf + kRowTile * Mz;       // [RT][Mz]  dKfu/dell rows
-    double* ar = df + kRowTile * Mz;       // [RT][Mz]  A rows
-    double* yr = ar + kRowTile * Mz;       // [RT][Mz]
-    double* zs = yr + kRowTile * Mz;       // [Mz]
-    double* xs = zs + Mz;                  // [RT] times of this tile
-    const double ell = a.ws.ell[pl], var = a.ws.var[pl];
-    const int n0 = tile * kRowTile;
-    {
-        auto all = [](int, int) { return true; };
-        if ((Mz & 1) == 0) {
-            vg_stage_f64_square(Ki, ld, a.ws.Kinv + pl * Mz * Mz, Mz, tid, nt);
-            if (a.want_dell) vg_stage_f64_square(Kd, ld, a.ws.Kd_ell + pl * Mz * Mz, Mz, tid, nt);
-            else for (int e = tid; e < Mz * ld; e += nt) Kd[e] = 0.0;
-        } else {
-            vg_stage_f64(Ki, Mz, ld, a.ws.Kinv + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
-            vg_stage_f64(Kd, Mz, ld, a.ws.Kd_ell + pl * Mz * Mz, a.want_dell ? Mz : 0, Mz, 0, 0, tid, nt, all);
-        }
-        vg_stage_words(zs, 2 * (Mz + kRowTile), tid, nt, [&](int w) -> const void* {
-            const int i = w >> 1;
-            const double* src = i < Mz ? a.Zy + (size_t)i * D + l : a.X + (size_t)min(n0 + i - Mz, N - 1) * D + l;
-            return reinterpret_cast<const uint32_t*>(src) + (w & 1);
-        });
-    }
-    vg_dma_wait();
-    __syncthreads();
-    VG_T(tile == 0 && l == 0 && p == 0, 232);
-    for (int e = tid; e < kRowTile * Mz; e += nt) {
-        int r = vg_div(e, iMz), m = e - r * Mz, n = n0 + r;
-        double k = 0.0, dk = 0.0;
-        if (n < N) {
-            double rr = fabs(xs[r] - zs[m]) / ell;
-            double ex = exp(-kSqrt5 * rr);
-            k = var * (1.0 + kSqrt5 * rr + (5.0 / 3.0) * rr * rr) * ex;
-            dk = var * ex * (5.0 * rr * rr / (3.0 * ell)) * (1.0 + kSqrt5 * rr);
-        }
-        kf[e] = k; df[e] = dk;
-    }
-    __syncthreads();
-    VG_T(tile == 0 && l == 0 && p == 0, 233);
-    for (int e = tid; e < kRowTile * Mz; e += nt) {
-        int r = vg_div(e, iMz), m = e - r * Mz;
-        ar[e] = dot4(kf + r * Mz, 1, Ki + m, ld, Mz);
-    }
-    __syncthreads();
-    VG_T(tile == 0 && l == 0 && p == 0, 234);
-    float4* A4 = reinterpret_cast<float4*>(a.ws.A4) + pl * N * Mz;
-    float* AT = a.ws.AT + pl * N * Mz;
-    float av_keep[2] = {0.f, 0.f};
-    int cnt = 0;
-    for (int e = tid; e < kRowTile * Mz; e += nt, ++cnt) {
-        int r = vg_div(e, iMz), m = e - r * Mz;
-        const double y = df[e] - dot4(ar + r * Mz, 1, Kd + m, ld, Mz);
-        const double v = dot4(ar + r * Mz, 1, Ki + m, ld, Mz);
-        yr[e] = y;
-        if (cnt < 2) av_keep[cnt] = (float)(a.jitter / var * v);
-    }
-    __syncthreads();
-    VG_T(tile == 0 && l == 0 && p == 0, 235);
-    cnt = 0;
-    for (int e = tid; e < kRowTile * Mz; e += nt, ++cnt) {
-        int r = vg_div(e, iMz), m = e - r * Mz, n = n0 + r;
-        if (n >= N) continue;
-        const double s = a.want_dell ? dot4(yr + r * Mz, 1, Ki + m, ld, Mz) : 0.0;
-        const float av = av_keep[cnt < 2 ? cnt : 1];
-        A4[(size_t)n * Mz + m] = make_float4((float)ar[e], (float)s, av, 0.f);
-        AT[(size_t)m * N + n] = (float)ar[e];
-    }
-    VG_T(tile == 0 && l == 0 && p == 0, 231);
-}
-
-// =================================================================================================
-// Random Fourier features  Phi[l, j, b] = sqrt(2 var / B) cos(x_j . omega_lb / ell + beta_lb)
-// and dPhi/dell.  Points j < N are rows of X, the rest rows of Zy.
-// =================================================================================================
-__device__ __forceinline__ float softplus_f(float x) { return x > 15.f ? x : __logf(1.f + __expf(x)); }
-
-struct FeatArgs {
-    int N, Mz, L, D, B, jchunk;
-    const double *X, *Zy, *raw_ell, *raw_var;
-    const float *omega, *beta;
-    float *Phi, *dPhi;
-    uint32_t* tick;          // device step counter, ticked by the stand-alone launch of a training step (or null)
-};
-
-__device__ __forceinline__ void features_body(const FeatArgs& a, int bx, int by, int bz) {
-    // one lane per (latent, basis): its frequency row stays in registers while it sweeps `jchunk` points;
-    // the points are uniform across the workgroup (scalar loads), the stores are coalesced along b
-    const int N = a.N, Mz = a.Mz, L = a.L, D = a.D, B = a.B;
-    const double *X = a.X, *Zy = a.Zy;
-    const float *omega = a.omega, *beta = a.beta;
-    float *Phi = a.Phi, *dPhi = a.dPhi;
-    VG_T(bx == 0 && by == 0 && bz == 0, 130);
-    const int b = bx * kBlock + threadIdx.x;
-    const int l = bz % L, p = bz / L;
-    const int J = N + Mz;
-    const size_t pl = (size_t)p * L + l;
-    if (b >= B) return;
-    const float ell = softplus_f((float)a.raw_ell[pl]);
-    const float var = (float)kVarFloor + softplus_f((float)a.raw_var[pl]);
-    const float inv_ell = 1.0f / ell, c = __builtin_amdgcn_sqrtf(2.0f * var / (float)B);
-    float om[VGPMP_MAX_DOF];
-#pragma unroll
-    for (int d = 0; d < VGPMP_MAX_DOF; ++d) om[d] = d < D ? omega[(pl * B + b) * D + d] : 0.f;
-    const float bt = beta[pl * B + b];
-    const int j0 = by * a.jchunk, j1 = min(J, j0 + a.jchunk);
-    for (int j = j0; j < j1; ++j) {
-        const double* pt = j < N ? X + (size_t)j * D : Zy + (size_t)(j - N) * D;
-        float proj = 0.f;
-#pragma unroll
-        for (int d = 0; d < VGPMP_MAX_DOF; ++d)
-            if (d < D) proj = fmaf((float)pt[d], om[d], proj);
-        // v_sin/v_cos take revolutions: reduce with fract (argument is a few tens of radians at most)
-        const float rev = __builtin_amdgcn_fractf((proj * inv_ell + bt) * 0.15915494309189535f);
-        const size_t o = (pl * J + j) * B + b;
-        Phi[o] = c * __builtin_amdgcn_cosf(rev);
-        if (dPhi) dPhi[o] = c * __builtin_amdgcn_sinf(rev) * proj * inv_ell * inv_ell;
-    }
-    VG_T(bx == 0 && by == 0 && bz == 0, 131);
-    VG_T(bx == 0 && j1 == J && bz == L - 1, 135);
-}
-
-__global__ __launch_bounds__(kBlock) void features_kernel(FeatArgs a) {
-    if (a.tick && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *a.tick += 1u;
-    features_body(a, blockIdx.x, blockIdx.y, blockIdx.z);
-}
-
-// =================================================================================================
-// Prior draws  F0[s, l, j] = sum_b w[s, l, b] Phi[l, j, b]   (and H with dPhi) on the f32 MFMA pipe.
-// v_mfma_f32_16x16x4_f32: lane -> A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15];
-// each lane loads 4 consecutive k (16 B) per operand, so one load pair feeds 4 MFMAs (k = 4g + c).
-// =================================================================================================
-typedef float vg_f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kNT = 3;     // 16-column tiles per wave
-
-struct GemmArgs {
-    int S, L, J, B, SK, nsel;
-    const float *W, *Phi, *dPhi;
-    float *F0, *H;
-    size_t slab;
-    int dbg;                 // measurement builds: 1 no stores, 2 no loads, 3 no MFMA
-};
-
-// KS > 0: the K-slice of a workgroup is a multiple of KS steps of 16 and goes in passes of KS steps whose operands
-// are ALL requested before the pass's first MFMA (one L2 round trip per pass instead of one per step -- at one
-// problem these launches are latency bound, not bandwidth bound).  KS == 0: any slice length, next step
-// prefetched while the MFMAs of this one run.
-template <int KS>
-__device__ __forceinline__ void prior_gemm_body(const GemmArgs& a, int bx, int by, int bz) {
-    const int S = a.S, L = a.L, J = a.J, B = a.B, SK = a.SK, nsel = a.nsel;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int z = bz;
-    const int sel = z % nsel; z /= nsel;
-    const int sk = z % SK; z /= SK;
-    const int l = z % L, p = z / L;
-    const int s0 = (by * 4 + wave) * 16;
-    const int j0 = bx * (16 * kNT);
-    VG_T(bx == 0 && by == 0 && bz == 0, 240);
-    if (s0 >= S) return;
-    const float* Bm = sel == 0 ? a.Phi : a.dPhi;
-    float* Out = (sel == 0 ? a.F0 : a.H) + (size_t)sk * a.slab;
-    const int kchunk = B / SK, kbeg = sk * kchunk, kend = kbeg + kchunk;
-    const int r = lane & 15, g = lane >> 4;
-    const int srow = min(s0 + r, S - 1);
-    const float* ap = a.W + (((size_t)p * S + srow) * L + l) * B + 4 * g;
-    const float* bp[kNT];
-#pragma unroll
-    for (int t = 0; t < kNT; ++t) {
-        int jc = min(j0 + 16 * t + r, J - 1);
-        bp[t] = Bm + (((size_t)p * L + l) * J + jc) * B + 4 * g;
-    }
-    vg_f32x4 acc[kNT];
-#pragma unroll
-    for (int t = 0; t < kNT; ++t) acc[t] = (vg_f32x4){0.f, 0.f, 0.f, 0.f};
-    if constexpr (KS > 0) {
-        // the K-slice in passes of KS steps: every operand of a pass is requested before its first MFMA
-        for (int k0 = kbeg; k0 < kend; k0 += 16 * KS) {
-            float4 av[KS], bv[kNT][KS];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                av[ks] = *reinterpret_cast<const float4*>(ap + k0 + 16 * ks);
-#pragma unroll
-                for (int t = 0; t < kNT; ++t) bv[t][ks] = *reinterpret_cast<const float4*>(bp[t] + k0 + 16 * ks);
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int t = 0; t < kNT; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].x, bv[t][ks].x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].y, bv[t][ks].y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].z, bv[t][ks].z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].w, bv[t][ks].w, acc[t], 0, 0, 0);
-                }
-        }
-    } else {
-        float4 a_cur = *reinterpret_cast<const float4*>(ap + kbeg);
-        float4 b_cur[kNT];
-#pragma unroll
-        for (int t = 0; t < kNT; ++t) b_cur[t] = *reinterpret_cast<const float4*>(bp[t] + kbeg);
-        for (int k = kbeg; k < kend; k += 16) {
-            const int kn = (k + 16 < kend) ? k + 16 : k;      // prefetch next k-step while the MFMAs run
-            float4 a_nxt = *reinterpret_cast<const float4*>(ap + kn);
-            float4 b_nxt[kNT];
-#pragma unroll
-            for (int t = 0; t < kNT; ++t) b_nxt[t] = *reinterpret_cast<const float4*>(bp[t] + kn);
-#pragma unroll
-            for (int t = 0; t < kNT; ++t) {
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.x, b_cur[t].x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.y, b_cur[t].y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.z, b_cur[t].z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.w, b_cur[t].w, acc[t], 0, 0, 0);
-            }
-            a_cur = a_nxt;
-#pragma unroll
-            for (int t = 0; t < kNT; ++t) b_cur[t] = b_nxt[t];
-        }
-    }
-    VG_T(bx == 0 && by == 0 && bz == 0, 241);
-#ifdef VGPMP_BISECT
-    if (a.dbg == 1) { if (acc[0][0] + acc[1][1] + acc[2][2] == 123.456f) Out[0] = 1.f; return; }
-#endif
-    // D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
-#pragma unroll
-    for (int t = 0; t < kNT; ++t) {
-        const int jc = j0 + 16 * t + r;
-        if (jc >= J) continue;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int s = s0 + g * 4 + q;
-            if (s < S) Out[(((size_t)p * S + s) * L + l) * J + jc] = acc[t][q];
-        }
-    }
-    VG_T(bx == 0 && by == 0 && bz == 0, 242);
-    VG_T(bx == 2 && by == 1 && l == L - 1 && sk == SK - 1 && sel == nsel - 1, 245);
-}
-
-template <int KS>
-__global__ __launch_bounds__(kBlock) void prior_gemm_kernel(GemmArgs a) { prior_gemm_body<KS>(a, blockIdx.x, blockIdx.y, blockIdx.z); }
-
-// LDS-tiled variant for large batches (no split-K): a workgroup owns 64 samples x 144 columns, stages
-// 32-deep K slices of W and Phi through double-buffered LDS (global -> registers -> LDS, next slice in
-// flight while the MFMAs run) and every wave reads its fragments with ds_read_b128.  Row stride 36 floats
-// keeps the 16-byte fragment reads of a 16-row group on distinct bank slots.  Raises flop per byte
-// fetched from L2 from ~10 to ~22 compared with the direct kernel above.
-constexpr int kTS = 64, kTJ = 144, kTK = 32, kTLd = 36;
-
-__global__ __launch_bounds__(kBlock) void prior_gemm_tiled_kernel(int S, int L, int J, int B, int nsel,
-                                                                   const float* __restrict__ W,
-                                                                   const float* __restrict__ Phi,
-                                                                   const float* __restrict__ dPhi,
-                                                                   float* __restrict__ F0, float* __restrict__ H) {
-    __shared__ float As[2][kTS * kTLd];
-    __shared__ float Bs[2][kTJ * kTLd];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int z = blockIdx.z;
-    const int sel = z % nsel; z /= nsel;
-    const int l = z % L, p = z / L;
-    const int s0 = blockIdx.y * kTS, j0 = blockIdx.x * kTJ;
-    const float* Bm = sel == 0 ? Phi : dPhi;
-    float* Out = sel == 0 ? F0 : H;
-    // staging map: thread -> (row, 16-byte k-chunk); A: 64 rows x 8 chunks = 512 (2 per thread),
-    // B: 144 rows x 8 chunks = 1152 (4.5 per thread -> 5 passes, last partial)
-    float4 ra[2], rbv[5];
-    auto load_tiles = [&](int k0) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int c = tid + q * kBlock, row = c >> 3, ch = c & 7;
-            const int srow = min(s0 + row, S - 1);
-            ra[q] = *reinterpret_cast<const float4*>(W + (((size_t)p * S + srow) * L + l) * B + k0 + 4 * ch);
-        }
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const int c = min(tid + q * kBlock, kTJ * 8 - 1), row = c >> 3, ch = c & 7;
-            const int jrow = min(j0 + row, J - 1);
-            rbv[q] = *reinterpret_cast<const float4*>(Bm + (((size_t)p * L + l) * J + jrow) * B + k0 + 4 * ch);
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int c = tid + q * kBlock, row = c >> 3, ch = c & 7;
-            *reinterpret_cast<float4*>(&As[buf][row * kTLd + 4 * ch]) = ra[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const int c = tid + q * kBlock;
-            if (c < kTJ * 8) {
-                const int row = c >> 3, ch = c & 7;
-                *reinterpret_cast<float4*>(&Bs[buf][row * kTLd + 4 * ch]) = rbv[q];
-            }
-        }
-    };
-    vg_f32x4 acc[kTJ / 16];
-#pragma unroll
-    for (int t = 0; t < kTJ / 16; ++t) acc[t] = (vg_f32x4){0.f, 0.f, 0.f, 0.f};
-    const int r = lane & 15, g = lane >> 4;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    int buf = 0;
-    for (int k0 = 0; k0 < B; k0 += kTK) {
-        const bool more = k0 + kTK < B;
-        if (more) load_tiles(k0 + kTK);
-        const float* a_base = &As[buf][(wave * 16 + r) * kTLd + 4 * g];
-#pragma unroll
-        for (int kk = 0; kk < kTK; kk += 16) {
-            const float4 a4 = *reinterpret_cast<const float4*>(a_base + kk);
-#pragma unroll
-            for (int t = 0; t < kTJ / 16; ++t) {
-                const float4 b4 = *reinterpret_cast<const float4*>(&Bs[buf][(t * 16 + r) * kTLd + kk + 4 * g]);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc[t], 0, 0, 0);
-            }
-        }
-        if (more) store_tiles(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-    }
-#pragma unroll
-    for (int t = 0; t < kTJ / 16; ++t) {
-        const int jc = j0 + 16 * t + r;
-        if (jc >= J) continue;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int srow = s0 + wave * 16 + g * 4 + q;
-            if (srow < S) Out[(((size_t)p * S + srow) * L + l) * J + jc] = acc[t][q];
-        }
-    }
-}
-
-// =================================================================================================
-// Path assembly  (decoupled / Matheron update, vgpmp.py:281-282):
-//   u = m + C eps;  r = u - F0(Z) - sqrt(jitter) eps2;  f = F0(X) + A r
-// One workgroup per (chunk of VG_SC samples, latent, problem).
-// =================================================================================================
 __device__ __forceinline__ void adam_update(double* x, double* m, double* v, double g, double lr_t) {
     // Keras Adam (TF 2.12): beta1 = 0.8, beta2 = 0.95 (models/vgpmp.py:77), epsilon 1e-7
     double mm = *m + (g - *m) * (1.0 - 0.8);
@@ -916,20 +147,6 @@ __device__ __forceinline__ void adam_update(double* x, double* m, double* v, dou
     *m = mm; *v = vv;
     *x -= lr_t * mm / (sqrt(vv) + 1e-7);
 }
-
-// Hyper-parameter update (hyper_kernel).  A ticket scheme that let the last workgroup of the reverse
-// pass do it was measured and rejected: the agent-scope fences it needs cost ~16 us on this 8-XCD part.
-struct HyperArgs {
-    int L, Mz, NC, want_dell;
-    size_t part_len;
-    const float* part;
-    const double *gkl_ell, *gkl_var, *var, *sig_ell, *sig_var;
-    double kl_scale, lr, lr_t;
-    double *g_ell, *g_var, *lr_dev;
-    double *m_ell, *m_var, *v_ell, *v_var, *p_ell, *p_var;
-    const uint32_t* ctr;     // device step counter (already ticked: 1-based Adam count) or null
-    int do_adam, trainable;
-};
 
 struct PathArgs {
     int S, N, Mz, L, SK, NC;
@@ -1203,13 +420,896 @@ struct FinalArgs {
     double *g_qmu, *g_qsqrt;
     int do_adam, trainable;
     int dma;                  // the chunk partials fit in LDS: stage them by DMA
-    const double* lr_dev;     // [P] step size handed from the reverse pass to final_kernel
+    const double* lr_dev;     // [1] step size stored at the counter tick (device counter form)
+    double lr_t;              // host form
+    int use_lr_dev;
     double *mq_mu, *mq_sqrt;  // Adam moments
     double *vq_mu, *vq_sqrt;
     double *pq_mu, *pq_sqrt;  // parameters (updated in place)
     int stop;
 };
 
+// Bias-corrected Adam step size of the update with 1-based count t (Keras: lr sqrt(1 - b2^t) / (1 - b1^t))
+__device__ __forceinline__ double adam_step_size(double lr, double t) {
+    return lr * sqrt(1.0 - exp(t * -0.05129329438755058)) / (1.0 - exp(t * -0.2231435513142098));
+}
+
+// Hyper-parameter update of one (problem, latent): gradient of the loss wrt (raw lengthscale, raw variance) from the
+// reverse-pass sums and the KL tangents, chain rule through the softplus, Adam.  Two forms with identical arithmetic:
+// hyper_kernel (its own launch) and a PROLOGUE of the stage-1 roles that need the new values (small batches, steps
+// after the first of a call): every workgroup of the latent repeats the ~100 operations, only the cov_a role stores
+// (to a staging row that role 0 of stage 2 copies to the parameter / Adam tensors, which nobody reads in between).
+// Everything slow is prepared earlier: the step size at the counter tick, var and the softplus slopes by cov_a.
+// (A ticket scheme that let the last workgroup of the reverse pass do the update was measured and rejected: with
+// __threadfence() the agent-scope fences cost ~16 us on this 8-XCD part, with atomics only it is a wash.)
+struct HyperArgs {
+    int L, Mz, NC, want_dell;
+    size_t part_len;
+    const float* part;
+    const double *gkl_ell, *gkl_var, *var, *sig_ell, *sig_var;      // var / slopes of the step being finished
+    double kl_scale, lr_t;
+    const double* lr_dev;    // [1] step size stored at the counter tick (device counter form), else lr_t
+    double *g_ell, *g_var;
+    double *m_ell, *m_var, *v_ell, *v_var, *p_ell, *p_var;
+    double* next;            // [P,L,6] staging of {raw_ell, raw_var, m_ell, v_ell, m_var, v_var} (prologue form)
+    int do_adam, trainable, use_lr_dev;
+};
+
+struct HyperState { double raw_ell, raw_var, m_ell, v_ell, m_var, v_var, g_ell, g_var; };
+
+// The three sums over the sample chunks are loaded in ONE round (16 chunks x 3 values per pass, clamped + masked)
+// and added in the order of sum_chunks().
+__device__ __forceinline__ HyperState hyper_update(const HyperArgs& h, size_t pl) {
+    const float* part = h.part + pl * h.NC * h.part_len + (h.Mz + h.Mz * h.Mz);
+    HyperState o;
+    o.raw_ell = h.p_ell[pl]; o.raw_var = h.p_var[pl];
+    if (h.do_adam) { o.m_ell = h.m_ell[pl]; o.v_ell = h.v_ell[pl]; o.m_var = h.m_var[pl]; o.v_var = h.v_var[pl]; }
+    else { o.m_ell = o.v_ell = o.m_var = o.v_var = 0.0; }
+    const double gkl_ell = h.gkl_ell[pl], gkl_var = h.gkl_var[pl], var = h.var[pl];
+    const double sig_ell = h.sig_ell[pl], sig_var = h.sig_var[pl];
+    const double lr_t = (h.do_adam && h.use_lr_dev) ? h.lr_dev[0] : h.lr_t;
+    double s3[3] = {0.0, 0.0, 0.0};
+    for (int c0 = 0; c0 < h.NC; c0 += 16) {
+        float v[16][3];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float* q = part + (size_t)min(c0 + k, h.NC - 1) * h.part_len;
+            v[k][0] = q[0]; v[k][1] = q[1]; v[k][2] = q[2];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double d[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) d[k] = c0 + k < h.NC ? (double)v[k][j] : 0.0;
+            s3[j] += ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+            s3[j] += ((d[8] + d[9]) + (d[10] + d[11])) + ((d[12] + d[13]) + (d[14] + d[15]));
+        }
+    }
+    const double s_ell = h.want_dell ? s3[0] : 0.0;
+    o.g_ell = (s_ell + h.kl_scale * gkl_ell) * sig_ell;
+    o.g_var = (s3[1] + s3[2] / (2.0 * var) + h.kl_scale * gkl_var) * sig_var;
+    if (h.do_adam) {
+        if (h.trainable & VGPMP_TRAIN_LENGTHSCALES) adam_update(&o.raw_ell, &o.m_ell, &o.v_ell, o.g_ell, lr_t);
+        if (h.trainable & VGPMP_TRAIN_KERNEL_VARIANCE) adam_update(&o.raw_var, &o.m_var, &o.v_var, o.g_var, lr_t);
+    }
+    return o;
+}
+
+// =================================================================================================
+// Covariance path (float64).
+//
+// cov_fwd_kernel -- one workgroup per (latent, problem): Kuu, chol, inverse, q_sqrt, KL and its
+//   gradient, plus the FORWARD-MODE tangents of chol/q_sqrt/KL wrt the latent's two kernel
+//   hyper-parameters (lengthscale, variance).
+// cov_rows_kernel -- row tiles of A = Kfu (Kuu + jI)^-1 and of its two tangents, spread over
+//   N/8 workgroups per latent.
+// With the tangents available the sample-dependent reverse pass needs only dot products of its
+// upstream gradients with them -- no Cholesky adjoint, no N-sized float64 reductions -- and both
+// kernels sit off the critical path (side stream) next to the noise/feature/GEMM branch.
+// =================================================================================================
+struct CovArgs {
+    int N, M, L, D;
+    const double *X, *Zy, *y_u;
+    double jitter;
+    const double *q_mu, *q_sqrt, *raw_ell, *raw_var;
+    int want_dell;
+    int stop;
+    uint32_t* tick;          // device step counter, ticked by one row-tile workgroup of stage 2 (or null)
+    double lr;               // with the tick: the step size of this step's update goes to lr_dev[0]
+    double* lr_dev;
+    // hyper-parameter update of the previous step as a prologue (stage 1) / its commit (stage 2, role 0)
+    int prologue, commit, keep_prev;
+    HyperArgs hy;
+    vg_workspace ws;
+};
+
+constexpr int kCovThreads = 256;      // == kBlock: the covariance roles share launches with other kernels
+constexpr int kRowTile = 8;
+
+// ---- float64 matrix-core tiles ---------------------------------------------------------------------
+// v_mfma_f64_16x16x4_f64: lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15] (one
+// double each); it receives D[row = (l >> 4) + 4 q][col = l & 15] in accumulator element q = 0..3.
+// All matrices live in LDS with dimension Mp = roundup(Mz, 16) (zero padded), so no edge handling.
+typedef double vg_f64x4 __attribute__((ext_vector_type(4)));
+
+struct MatView {            // element (r, c) at p[r * sr + c * sc]
+    const double* p;
+    int sr, sc;
+};
+
+__device__ __forceinline__ vg_f64x4 mfma_tile_f64(MatView A, MatView B, int K, int lane, int i0, int j0) {
+    vg_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    const int r = lane & 15, g = lane >> 4;
+    const double* ap = A.p + (i0 + r) * A.sr + g * A.sc;
+    const double* bp = B.p + g * B.sr + (j0 + r) * B.sc;
+#pragma unroll 8
+    for (int k = 0; k < K; k += 4) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[k * A.sc], bp[k * B.sr], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// D = A B over all 16x16 tiles of an Mp x Mp result, tiles dealt round-robin to the waves; `emit(r, c, v)`
+// receives every element.
+template <typename Emit>
+__device__ __forceinline__ void matmul_f64(MatView A, MatView B, int Mp, int tid, int nt, Emit emit) {
+    const int lane = tid & 63, nT = Mp >> 4;
+    for (int t = tid >> 6; t < nT * nT; t += nt >> 6) {
+        const int i0 = (t / nT) << 4, j0 = (t % nT) << 4;
+        const vg_f64x4 acc = mfma_tile_f64(A, B, Mp, lane, i0, j0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) emit(i0 + (lane >> 4) + 4 * q, j0 + (lane & 15), acc[q]);
+    }
+}
+
+// Cholesky factor and its inverse of the SPD matrix held in La (LDS), by forward elimination of the
+// augmented matrix [K | I] without pivoting (K = L~ D L~^T): after Mz pivots the left half holds
+// U = D L~^T and the right half L~^-1, so  Lk = L~ D^1/2  and  Lk^-1 = D^-1/2 L~^-1.  Every pivot is
+// one rank-1 update spread over the whole workgroup and ONE barrier (any Mz; chol_inverse_regs below is the
+// faster form for Mz <= 32).
+__device__ __forceinline__ void chol_inverse_block(double* La, double* Li, double* Aug, double* rsd, int Mz, int ld,
+                                                   int tid, int nt) {
+    const int la = 2 * Mz + 1;
+    const float iMz = 1.0f / (float)Mz, i2Mz = 0.5f / (float)Mz;
+    for (int e = tid; e < Mz * 2 * Mz; e += nt) {
+        const int i = vg_div(e, i2Mz), j = e - i * 2 * Mz;
+        Aug[i * la + j] = j < Mz ? La[i * ld + j] : (j - Mz == i ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    for (int k = 0; k < Mz; ++k) {
+        const double r = 1.0 / Aug[k * la + k];
+        const int h = Mz - k - 1;                   // rows k+1 .. Mz-1, columns k+1 .. Mz+k
+        for (int e = tid; e < h * Mz; e += nt) {
+            const int qi = vg_div(e, iMz);
+            const int i = k + 1 + qi, j = k + 1 + (e - qi * Mz);
+            Aug[i * la + j] = fma(-(Aug[i * la + k] * r), Aug[k * la + j], Aug[i * la + j]);
+        }
+        __syncthreads();
+    }
+    for (int k = tid; k < Mz; k += nt) rsd[k] = rsqrt(Aug[k * la + k]);
+    __syncthreads();
+    for (int e = tid; e < Mz * Mz; e += nt) {
+        const int i = vg_div(e, iMz), j = e - i * Mz;
+        La[i * ld + j] = j <= i ? Aug[j * la + i] * rsd[j] : 0.0;
+        Li[i * ld + j] = j <= i ? Aug[i * la + Mz + j] * rsd[i] : 0.0;
+    }
+    __syncthreads();
+}
+
+// The same elimination with the augmented matrix in REGISTERS (Mz <= 32, 256 threads): thread (row i = tid & 31,
+// column block jb = tid >> 5) keeps columns [8 jb, 8 jb + 8) of [K | I] laid out as 32 + 32 columns.  Per pivot
+// the owners publish the pivot row and the pivot column through LDS (double buffered: one barrier per pivot),
+// everyone reads its 8 + 2 values in one LDS round and does 8 FMAs out of registers; measured 340 ns per pivot
+// against 420 ns for the LDS-resident loop above (three LDS reads and a write per element).
+__device__ __forceinline__ void chol_inverse_regs(double* La, double* Li, double* Aug, double* rsd, int Mz, int ld,
+                                                  int tid, int nt) {
+    const int i = tid & 31, jb = tid >> 5, la = 2 * Mz + 1;
+    const float iMz = 1.0f / (float)Mz;
+    double* prow = Aug;                  // [2][64] pivot row, both halves
+    double* pcol = Aug + 128;            // [2][32] pivot column
+    double a[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int col = 8 * jb + c;      // < 32: column of K;  >= 32: column col - 32 of I
+        a[c] = i < Mz ? (col < 32 ? (col < Mz ? La[i * ld + col] : 0.0) : (col - 32 == i ? 1.0 : 0.0)) : 0.0;
+    }
+    __syncthreads();
+#pragma nounroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int k = 8 * kb + c;
+            if (k >= Mz) break;
+            const int buf = k & 1;
+            if (i == k) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) prow[buf * 64 + 8 * jb + q] = a[q];
+            }
+            if (jb == kb) pcol[buf * 32 + i] = a[c];
+            __syncthreads();
+            // one LDS round for everything this thread needs of pivot k (read unconditionally, used conditionally)
+            const double piv = pcol[buf * 32 + k], aik = pcol[buf * 32 + i];
+            double pr[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pr[q] = prow[buf * 64 + 8 * jb + q];
+            if (tid == 0) rsd[k] = piv;          // rsqrt after the loop, off the chain
+            // 1 / piv sits on the dependency chain of every pivot: hardware estimate + two Newton steps (to the
+            // last bit or two) instead of the ~10-instruction IEEE division sequence
+            double r = __builtin_amdgcn_rcp(piv);
+            r = fma(fma(-piv, r, 1.0), r, r);
+            r = fma(fma(-piv, r, 1.0), r, r);
+            const double m = (i > k && i < Mz) ? aik * r : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = fma(-m, pr[q], a[q]);
+        }
+    }
+    __syncthreads();
+    if (tid < Mz) rsd[tid] = rsqrt(rsd[tid]);
+    __syncthreads();
+    // registers -> the [Mz][2 Mz + 1] image the tail expects: left half U = D L~^T, right half L~^-1
+    double* Img = Aug;                   // the exchange buffers are dead now
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int col = 8 * jb + c;
+        if (i < Mz) {
+            if (col < Mz) Img[i * la + col] = a[c];
+            else if (col >= 32 && col - 32 < Mz) Img[i * la + Mz + (col - 32)] = a[c];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < Mz * Mz; e += nt) {
+        const int r = vg_div(e, iMz), j = e - r * Mz;
+        La[r * ld + j] = j <= r ? Img[j * la + r] * rsd[j] : 0.0;
+        Li[r * ld + j] = j <= r ? Img[r * la + Mz + j] * rsd[r] : 0.0;
+    }
+    __syncthreads();
+}
+
+// ---- stage A: Kuu, factorisation, inverse --------------------------------------------------------
+__device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, int p) {
+    __shared__ double scal[2];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    VG_T(l == 0 && p == 0, 100);
+    const int M = a.M, Mz = M + 2, L = a.L, D = a.D;
+    const int Mp = (Mz + 15) & ~15, ld = Mp + 1;
+    const float iMz = 1.0f / (float)Mz;
+    const size_t pl = (size_t)p * L + l;
+    double* La = sm;                 // Kuu + jI -> Cholesky factor Lk      (Mp x ld, zero padded)
+    double* Li = La + Mp * ld;       // Lk^-1
+    double* Sc = Li + Mp * ld;       // 2 x (Mp x ld) scratch: augmented matrix of the elimination
+    double* zs = Sc + 2 * Mp * ld;   // [Mp]
+    double* rsd = zs + Mp;           // [Mp]
+    if (tid == 0) {
+        double re, rv;
+        if (a.prologue) {
+            const HyperState o = hyper_update(a.hy, pl);
+            a.hy.g_ell[pl] = o.g_ell; a.hy.g_var[pl] = o.g_var;
+            double* nx = a.hy.next + 6 * pl;
+            nx[0] = o.raw_ell; nx[1] = o.raw_var; nx[2] = o.m_ell; nx[3] = o.v_ell; nx[4] = o.m_var; nx[5] = o.v_var;
+            re = o.raw_ell; rv = o.raw_var;
+        } else {
+            re = a.raw_ell[pl]; rv = a.raw_var[pl];
+        }
+        scal[0] = softplus_d(re);
+        scal[1] = kVarFloor + softplus_d(rv);
+        a.ws.sig_ell[pl] = sigmoid_d(re);
+        a.ws.sig_var[pl] = sigmoid_d(rv);
+    }
+    for (int e = tid; e < 2 * Mp * ld; e += nt) sm[e] = 0.0;
+    for (int i = tid; i < Mz; i += nt) zs[i] = a.Zy[(size_t)i * D + l];
+    __syncthreads();
+    const double ell = scal[0], var = scal[1], jit = a.jitter;
+    if (tid == 0) { a.ws.ell[pl] = ell; a.ws.var[pl] = var; }
+    // Kuu and dKuu/dell share the exponential; symmetric: evaluate the lower triangle only
+    double* Kg = a.ws.Ks64 + pl * Mz * Mz;
+    double* Kdg = a.ws.Kd_ell + pl * Mz * Mz;
+    for (int e = tid; e < Mz * Mz; e += nt) {
+        int i = vg_div(e, iMz), j = e - i * Mz;
+        if (j > i) continue;
+        double r = fabs(zs[i] - zs[j]) / ell;
+        double ex = exp(-kSqrt5 * r);
+        double k = var * (1.0 + kSqrt5 * r + (5.0 / 3.0) * r * r) * ex;
+        double dk = var * ex * (5.0 * r * r / (3.0 * ell)) * (1.0 + kSqrt5 * r);
+        La[i * ld + j] = k + (i == j ? jit : 0.0);
+        Kg[(size_t)i * Mz + j] = k;
+        Kdg[(size_t)i * Mz + j] = dk;
+        if (i != j) { La[j * ld + i] = k; Kg[(size_t)j * Mz + i] = k; Kdg[(size_t)j * Mz + i] = dk; }
+    }
+    __syncthreads();
+    VG_T(l == 0 && p == 0, 101);
+    if (Mz <= 32 && nt == 256) chol_inverse_regs(La, Li, Sc, rsd, Mz, ld, tid, nt);
+    else chol_inverse_block(La, Li, Sc, rsd, Mz, ld, tid, nt);
+    VG_T(l == 0 && p == 0, 102);
+    double* Kig = a.ws.Kinv + pl * Mz * Mz;
+    matmul_f64(MatView{Li, 1, ld}, MatView{Li, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
+        if (r < Mz && c < Mz) Kig[(size_t)r * Mz + c] = v;
+    });
+    double* Lkg = a.ws.Lk64 + pl * Mz * Mz;
+    double* Lig = a.ws.Li64 + pl * Mz * Mz;
+    for (int e = tid; e < Mz * Mz; e += nt) {
+        const int i = vg_div(e, iMz), j = e - i * Mz;
+        Lkg[e] = La[i * ld + j];
+        Lig[e] = Li[i * ld + j];
+    }
+    VG_T(l == 0 && p == 0, 103);
+}
+
+__global__ __launch_bounds__(kCovThreads) void cov_a_kernel(CovArgs a) {
+    extern __shared__ double sm[];
+    cov_a_body(a, sm, blockIdx.x, blockIdx.y);
+}
+
+// ---- stage B: heterogeneous launch, role = blockIdx.x ---------------------------------------------
+//   0            q_sqrt = Lk pad(Q) + jitter, q_mu, KL and its gradient wrt q_mu / q_sqrt
+//   1, 2         forward-mode tangent wrt lengthscale / variance:  dC = (Lk Phi(Lk^-1 dK Lk^-T)) pad(Q), dKL
+//   3 + t        row tile t of A = Kfu (Kuu + jI)^-1 and its tangents (cov_rows_body)
+__device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int p, int tid, int nt);
+
+template <bool TANGENTS>
+__device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int role, int l, int p) {
+    __shared__ double red[kCovThreads / VG_WAVE];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (role >= 3) {
+        // The step counter ticks where no kernel that reads it runs alongside: noise drawn before this launch
+        // saw the old value, the noise of the next step and the Adam count see the new one.
+        if (a.tick && role == 3 && l == 0 && p == 0 && tid == 0) {
+            const uint32_t t = *a.tick + 1u;          // = 1-based Adam count of this step's update
+            *a.tick = t;
+            a.lr_dev[0] = adam_step_size(a.lr, (double)t);
+        }
+        cov_rows_body(a, sm, role - 3, l, p, tid, nt);
+        return;
+    }
+    if (role > 0 && (!TANGENTS || (role == 1 && !a.want_dell))) return;
+    VG_T(l == 0 && p == 0, 200 + 10 * role);
+    const int M = a.M, Mz = M + 2, L = a.L;
+    const int Mp = (Mz + 15) & ~15, ld = Mp + 2;      // even: LDS rows start on 16 bytes
+    const float iMz = 1.0f / (float)Mz, iM = 1.0f / (float)M;
+    const size_t pl = (size_t)p * L + l;
+    double* La = sm;                 // Lk, later pad(q_sqrt) for the tangents   (all Mp x ld, zero padded)
+    double* Li = La + Mp * ld;       // Lk^-1
+    double* X1 = Li + Mp * ld;       // role 0: pad(q_sqrt), Q at [2:, 2:];  tangents: dK/dtheta, then W
+    double* X2 = X1 + Mp * ld;       // tangents: scratch T
+    double* dl = X2 + Mp * ld;       // [Mp] q_mu - p_mu
+    double* af = dl + Mp;            // [Mp] Lk^-1 (q_mu - p_mu)
+    double* v1 = af + Mp;            // [Mp]
+    double* k0 = v1 + Mp;            // [Mp] first two columns of Kuu + jI
+    double* k1 = k0 + Mp;
+    double* kd0 = k1 + Mp;           // [Mp] first two columns of dK/dtheta
+    double* kd1 = kd0 + Mp;
+    double* Qp = X1;
+    double* Kd = X1;
+    double* T = X2;
+    double* qm = kd1 + Mp;           // [Mp] q_mu behind the two conditioned points
+    if (role == 0 && tid == 0) {
+        if (a.commit && a.hy.do_adam) {      // staged hyper-parameters of the prologue -> their tensors
+            const HyperArgs& h = a.hy;
+            const double* nx = h.next + 6 * pl;
+            h.p_ell[pl] = nx[0]; h.p_var[pl] = nx[1]; h.m_ell[pl] = nx[2]; h.v_ell[pl] = nx[3]; h.m_var[pl] = nx[4];
+            h.v_var[pl] = nx[5];
+        }
+        if (a.keep_prev) {                   // this step's var / slopes for the prologue of the next step
+            a.ws.prev_var[pl] = a.ws.var[pl];
+            a.ws.prev_sig_ell[pl] = a.ws.sig_ell[pl];
+            a.ws.prev_sig_var[pl] = a.ws.sig_var[pl];
+        }
+    }
+    const double jit = a.jitter, var = a.ws.var[pl];
+    const double y0 = a.y_u[((size_t)p * 2 + 0) * L + l], y1 = a.y_u[((size_t)p * 2 + 1) * L + l];
+    const double* Kg = a.ws.Ks64 + pl * Mz * Mz;
+    constexpr int kQRegs = (VGPMP_MAX_MZ - 2) * (VGPMP_MAX_MZ - 2) / kCovThreads + 1;
+    double qreg[kQRegs];
+    {
+        // every operand by DMA, all requests in flight together (zero padding written directly)
+        const double* Qg = a.q_sqrt + pl * M * M;
+        auto all = [](int, int) { return true; };
+        const bool square = Mz == Mp;      // no zero padding needed: whole rows in 16-byte units
+        if (square) {
+            vg_stage_f64_square(La, ld, a.ws.Lk64 + pl * Mz * Mz, Mz, tid, nt);
+            vg_stage_f64_square(Li, ld, a.ws.Li64 + pl * Mz * Mz, Mz, tid, nt);
+        } else {
+            vg_stage_f64(La, Mp, ld, a.ws.Lk64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
+            vg_stage_f64(Li, Mp, ld, a.ws.Li64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
+        }
+        if (role == 0) {
+            vg_stage_f64(Qp, Mp, ld, Qg, M, M, 2, 2, tid, nt, [](int r, int c) { return c <= r; });
+        } else {      // tangents: this thread's share of Q waits in registers until Lk's LDS space is free
+            const double* Kdg = role == 1 ? a.ws.Kd_ell + pl * Mz * Mz : Kg;
+            if (square) vg_stage_f64_square(Kd, ld, Kdg, Mz, tid, nt);
+            else vg_stage_f64(Kd, Mp, ld, Kdg, Mz, Mz, 0, 0, tid, nt, all);
+#pragma unroll
+            for (int k = 0; k < kQRegs; ++k) qreg[k] = Qg[min(tid + k * nt, M * M - 1)];
+        }
+        // k0 | k1: the first two columns of Kuu;  qm: q_mu at [2:]
+        vg_stage_words(k0, 4 * Mp, tid, nt, [&](int w) -> const void* {
+            const int d = w >> 1, col = d >= Mp, i = d - col * Mp;
+            return i < Mz ? reinterpret_cast<const uint32_t*>(Kg + (size_t)i * Mz + col) + (w & 1) : nullptr;
+        });
+        vg_stage_words(qm, 2 * Mp, tid, nt, [&](int w) -> const void* {
+            const int i = w >> 1;
+            return (i >= 2 && i < Mz) ? reinterpret_cast<const uint32_t*>(a.q_mu + pl * M + (i - 2)) + (w & 1) : nullptr;
+        });
+    }
+    vg_dma_wait();
+    __syncthreads();
+    if (tid == 0) { k0[0] += jit; k1[1] += jit; qm[0] = y0; qm[1] = y1; }
+    if (role == 2) {
+        for (int e = tid; e < Mz * Mz; e += nt) {       // dK/dvar = K / var
+            const int i = vg_div(e, iMz), j = e - i * Mz;
+            Kd[i * ld + j] /= var;
+        }
+    }
+    if (role == 0) {                         // float32 copy for the gradient assembly (written here, not in stage A:
+        float* Lk32 = a.ws.Lk32 + pl * Mz * Mz;      // stage A of the next step may overlap that kernel)
+        for (int e = tid; e < Mz * Mz; e += nt) {
+            const int i = vg_div(e, iMz), j = e - i * Mz;
+            Lk32[e] = (float)La[i * ld + j];
+        }
+    }
+    __syncthreads();
+    VG_T(l == 0 && p == 0, 201 + 10 * role);
+    // prior mean through the two conditioned points and a = Lk^-1 (q_mu - p_mu)  (prior_kl.py:16-35)
+    const double k00 = k0[0], k01 = k1[0], k11 = k1[1];
+    const double det = k00 * k11 - k01 * k01;
+    const double c0 = (k11 * y0 - k01 * y1) / det, c1 = (k00 * y1 - k01 * y0) / det;
+    for (int i = tid; i < Mz; i += nt) {
+        const double mi = qm[i];
+        if (role == 0) a.ws.m[pl * Mz + i] = (float)mi;
+        dl[i] = mi - (k0[i] * c0 + k1[i] * c1);
+    }
+    __syncthreads();
+    double klacc = 0.0;
+    for (int i = tid; i < Mz; i += nt) {
+        const double s = dot4(Li + i * ld, 1, dl, 1, i + 1);
+        af[i] = s;
+        if (i >= 2) klacc += s * s;
+    }
+    __syncthreads();
+    if (role == 0) {
+        float* C32 = a.ws.C + pl * Mz * Mz;
+        matmul_f64(MatView{La, ld, 1}, MatView{Qp, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
+            if (r < Mz && c < Mz) C32[(size_t)r * Mz + c] = (float)(v + (r == c && r < 2 ? jit : 0.0));
+        });
+        double* gklQ = a.ws.gkl_Q + pl * M * M;
+        for (int e = tid; e < M * M; e += nt) {
+            int r = vg_div(e, iM), c = e - r * M;
+            double gq = 0.0;
+            if (c <= r) {
+                double q = Qp[(r + 2) * ld + (c + 2)];
+                klacc += q * q;
+                gq = q;
+                if (c == r) { klacc -= log(q * q); gq -= 1.0 / q; }
+            }
+            gklQ[e] = gq;
+        }
+        const double kl = block_sum(klacc, red);
+        if (tid == 0) a.ws.kl_l[pl] = 0.5 * (kl - (double)M);
+        // d KL / d q_mu = (Lk^-T [0, 0, a])[2:]
+        for (int k = tid + 2; k < Mz; k += nt)
+            a.ws.gkl_qmu[pl * M + (k - 2)] = dot4(Li + k * ld + k, ld, af + k, 1, Mz - k);
+        VG_T(l == 0 && p == 0, 202);
+        return;
+    }
+    // ---- tangent wrt theta: W = Phi(Lk^-1 dK Lk^-T), dLk = Lk W, dC = dLk pad(Q)   (64-bit MFMA products)
+    // Four LDS matrices (35 KB at Mz = 32, so that these workgroups pack 4 per CU next to the prior GEMM):
+    // W overwrites dK (its first two columns are kept), dLk overwrites T, and pad(Q) -- prefetched into
+    // registers -- takes the place of Lk once Lk has been used.
+    for (int i = tid; i < Mz; i += nt) { kd0[i] = Kd[i * ld + 0]; kd1[i] = Kd[i * ld + 1]; }
+    VG_T(l == 0 && p == 0, 204 + 10 * role);
+    matmul_f64(MatView{Li, ld, 1}, MatView{Kd, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) { T[r * ld + c] = v; });
+    __syncthreads();
+    VG_T(l == 0 && p == 0, 205 + 10 * role);
+    double* W = X1;
+    matmul_f64(MatView{T, ld, 1}, MatView{Li, 1, ld}, Mp, tid, nt, [&](int r, int c, double v) {
+        W[r * ld + c] = c < r ? v : (c == r ? 0.5 * v : 0.0);
+    });
+    __syncthreads();
+    VG_T(l == 0 && p == 0, 206 + 10 * role);
+    matmul_f64(MatView{La, ld, 1}, MatView{W, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) { T[r * ld + c] = v; });
+    __syncthreads();
+    VG_T(l == 0 && p == 0, 207 + 10 * role);
+    for (int e = tid; e < Mp * ld; e += nt) La[e] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kQRegs; ++k) {
+        const int e = tid + k * nt;
+        if (e < M * M) {
+            const int r = vg_div(e, iM), c = e - r * M;
+            if (c <= r) La[(r + 2) * ld + (c + 2)] = qreg[k];
+        }
+    }
+    __syncthreads();
+    float* CT = (role == 1 ? a.ws.CT_ell : a.ws.CT_var) + pl * Mz * Mz;
+    matmul_f64(MatView{T, ld, 1}, MatView{La, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
+        if (r < Mz && c < Mz) CT[(size_t)c * Mz + r] = (float)v;       // stored transposed
+    });
+    VG_T(l == 0 && p == 0, 202 + 10 * role);
+    // KL tangent: a_dot = Lk^-1 (delta_dot - dLk a),  delta_dot = -d p_mu
+    const double d00 = kd0[0], d01 = kd1[0], d11 = kd1[1];
+    const double e0 = d00 * c0 + d01 * c1, e1 = d01 * c0 + d11 * c1;        // dKyy c
+    const double cd0 = -(k11 * e0 - k01 * e1) / det, cd1 = -(k00 * e1 - k01 * e0) / det;
+    for (int i = tid; i < Mz; i += nt) {
+        const double s = dot4(T + i * ld, 1, af, 1, i + 1);
+        const double pd = kd0[i] * c0 + kd1[i] * c1 + k0[i] * cd0 + k1[i] * cd1;
+        v1[i] = -pd - s;
+    }
+    __syncthreads();
+    double acc = 0.0;
+    for (int i = tid + 2; i < Mz; i += nt) acc += af[i] * dot4(Li + i * ld, 1, v1, 1, i + 1);
+    acc = block_sum(acc, red);
+    if (tid == 0) (role == 1 ? a.ws.gkl_ell : a.ws.gkl_var)[pl] = acc;
+    VG_T(l == 0 && p == 0, 203 + 10 * role);
+}
+
+template <bool TANGENTS>
+__global__ __launch_bounds__(kCovThreads) void cov_b_kernel(CovArgs a) {
+    extern __shared__ double sm[];
+    cov_b_body<TANGENTS>(a, sm, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// A = Kfu (Kuu + jI)^-1 and its tangents for a tile of kRowTile time points:
+//   A_ell = (dKfu/dell - A dKuu/dell) Kinv,   A_var = (jitter / var) A Kinv
+// Output float32: A4[n][m] = {A, A_ell, A_var, 0} (one 16-byte load per use in the reverse pass)
+// and AT[m][n] for the forward path assembly.
+__device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int p, int tid, int nt) {
+    const int M = a.M, Mz = M + 2, N = a.N, L = a.L, D = a.D, ld = (Mz + 2) & ~1;
+    VG_T(tile == 0 && l == 0 && p == 0, 230);
+    const float iMz = 1.0f / (float)Mz;
+    const size_t pl = (size_t)p * L + l;
+    double* Ki = sm;                       // [Mz][ld]
+    double* Kd = Ki + Mz * ld;             // [Mz][ld]
+    double* kf = Kd + Mz * ld;             // [RT][Mz]  Kfu rows
+    double* df = kf + kRowTile * Mz;       // [RT][Mz]  dKfu/dell rows
+    double* ar = df + kRowTile * Mz;       // [RT][Mz]  A rows
+    double* yr = ar + kRowTile * Mz;       // [RT][Mz]
+    double* zs = yr + kRowTile * Mz;       // [Mz]
+    double* xs = zs + Mz;                  // [RT] times of this tile
+    const double ell = a.ws.ell[pl], var = a.ws.var[pl];
+    const int n0 = tile * kRowTile;
+    {
+        auto all = [](int, int) { return true; };
+        if ((Mz & 1) == 0) {
+            vg_stage_f64_square(Ki, ld, a.ws.Kinv + pl * Mz * Mz, Mz, tid, nt);
+            if (a.want_dell) vg_stage_f64_square(Kd, ld, a.ws.Kd_ell + pl * Mz * Mz, Mz, tid, nt);
+            else for (int e = tid; e < Mz * ld; e += nt) Kd[e] = 0.0;
+        } else {
+            vg_stage_f64(Ki, Mz, ld, a.ws.Kinv + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
+            vg_stage_f64(Kd, Mz, ld, a.ws.Kd_ell + pl * Mz * Mz, a.want_dell ? Mz : 0, Mz, 0, 0, tid, nt, all);
+        }
+        vg_stage_words(zs, 2 * (Mz + kRowTile), tid, nt, [&](int w) -> const void* {
+            const int i = w >> 1;
+            const double* src = i < Mz ? a.Zy + (size_t)i * D + l : a.X + (size_t)min(n0 + i - Mz, N - 1) * D + l;
+            return reinterpret_cast<const uint32_t*>(src) + (w & 1);
+        });
+    }
+    vg_dma_wait();
+    __syncthreads();
+    VG_T(tile == 0 && l == 0 && p == 0, 232);
+    for (int e = tid; e < kRowTile * Mz; e += nt) {
+        int r = vg_div(e, iMz), m = e - r * Mz, n = n0 + r;
+        double k = 0.0, dk = 0.0;
+        if (n < N) {
+            double rr = fabs(xs[r] - zs[m]) / ell;
+            double ex = exp(-kSqrt5 * rr);
+            k = var * (1.0 + kSqrt5 * rr + (5.0 / 3.0) * rr * rr) * ex;
+            dk = var * ex * (5.0 * rr * rr / (3.0 * ell)) * (1.0 + kSqrt5 * rr);
+        }
+        kf[e] = k; df[e] = dk;
+    }
+    __syncthreads();
+    VG_T(tile == 0 && l == 0 && p == 0, 233);
+    for (int e = tid; e < kRowTile * Mz; e += nt) {
+        int r = vg_div(e, iMz), m = e - r * Mz;
+        ar[e] = dot4(kf + r * Mz, 1, Ki + m, ld, Mz);
+    }
+    __syncthreads();
+    VG_T(tile == 0 && l == 0 && p == 0, 234);
+    float4* A4 = reinterpret_cast<float4*>(a.ws.A4) + pl * N * Mz;
+    float* AT = a.ws.AT + pl * N * Mz;
+    float av_keep[2] = {0.f, 0.f};
+    int cnt = 0;
+    for (int e = tid; e < kRowTile * Mz; e += nt, ++cnt) {
+        int r = vg_div(e, iMz), m = e - r * Mz;
+        const double y = df[e] - dot4(ar + r * Mz, 1, Kd + m, ld, Mz);
+        const double v = dot4(ar + r * Mz, 1, Ki + m, ld, Mz);
+        yr[e] = y;
+        if (cnt < 2) av_keep[cnt] = (float)(a.jitter / var * v);
+    }
+    __syncthreads();
+    VG_T(tile == 0 && l == 0 && p == 0, 235);
+    cnt = 0;
+    for (int e = tid; e < kRowTile * Mz; e += nt, ++cnt) {
+        int r = vg_div(e, iMz), m = e - r * Mz, n = n0 + r;
+        if (n >= N) continue;
+        const double s = a.want_dell ? dot4(yr + r * Mz, 1, Ki + m, ld, Mz) : 0.0;
+        const float av = av_keep[cnt < 2 ? cnt : 1];
+        A4[(size_t)n * Mz + m] = make_float4((float)ar[e], (float)s, av, 0.f);
+        AT[(size_t)m * N + n] = (float)ar[e];
+    }
+    VG_T(tile == 0 && l == 0 && p == 0, 231);
+}
+
+// =================================================================================================
+// Random Fourier features  Phi[l, j, b] = sqrt(2 var / B) cos(x_j . omega_lb / ell + beta_lb)
+// and dPhi/dell.  Points j < N are rows of X, the rest rows of Zy.
+// =================================================================================================
+__device__ __forceinline__ float softplus_f(float x) { return x > 15.f ? x : __logf(1.f + __expf(x)); }
+
+struct FeatArgs {
+    int N, Mz, L, D, B, jchunk;
+    const double *X, *Zy, *raw_ell, *raw_var;
+    const float *omega, *beta;
+    float *Phi, *dPhi;
+    uint32_t* tick;          // device step counter, ticked by the stand-alone launch of a training step (or null)
+    double lr;               // with the tick: the step size of this step's update goes to lr_dev[0]
+    double* lr_dev;
+    int prologue;            // stage 1: derive this step's hyper-parameters from the previous reverse pass (hy)
+    HyperArgs hy;
+};
+
+__device__ __forceinline__ void features_body(const FeatArgs& a, int bx, int by, int bz) {
+    // one lane per (latent, basis): its frequency row stays in registers while it sweeps `jchunk` points;
+    // the points are uniform across the workgroup (scalar loads), the stores are coalesced along b
+    const int N = a.N, Mz = a.Mz, L = a.L, D = a.D, B = a.B;
+    const double *X = a.X, *Zy = a.Zy;
+    const float *omega = a.omega, *beta = a.beta;
+    float *Phi = a.Phi, *dPhi = a.dPhi;
+    VG_T(bx == 0 && by == 0 && bz == 0, 130);
+    const int b = bx * kBlock + threadIdx.x;
+    const int l = bz % L, p = bz / L;
+    const int J = N + Mz;
+    const size_t pl = (size_t)p * L + l;
+    if (b >= B) return;
+    double re, rv;
+    if (a.prologue) {
+        const HyperState o = hyper_update(a.hy, pl);
+        re = o.raw_ell; rv = o.raw_var;
+    } else {
+        re = a.raw_ell[pl]; rv = a.raw_var[pl];
+    }
+    const float ell = softplus_f((float)re);
+    const float var = (float)kVarFloor + softplus_f((float)rv);
+    const float inv_ell = 1.0f / ell, c = __builtin_amdgcn_sqrtf(2.0f * var / (float)B);
+    float om[VGPMP_MAX_DOF];
+#pragma unroll
+    for (int d = 0; d < VGPMP_MAX_DOF; ++d) om[d] = d < D ? omega[(pl * B + b) * D + d] : 0.f;
+    const float bt = beta[pl * B + b];
+    const int j0 = by * a.jchunk, j1 = min(J, j0 + a.jchunk);
+    for (int j = j0; j < j1; ++j) {
+        const double* pt = j < N ? X + (size_t)j * D : Zy + (size_t)(j - N) * D;
+        float proj = 0.f;
+#pragma unroll
+        for (int d = 0; d < VGPMP_MAX_DOF; ++d)
+            if (d < D) proj = fmaf((float)pt[d], om[d], proj);
+        // v_sin/v_cos take revolutions: reduce with fract (argument is a few tens of radians at most)
+        const float rev = __builtin_amdgcn_fractf((proj * inv_ell + bt) * 0.15915494309189535f);
+        const size_t o = (pl * J + j) * B + b;
+        Phi[o] = c * __builtin_amdgcn_cosf(rev);
+        if (dPhi) dPhi[o] = c * __builtin_amdgcn_sinf(rev) * proj * inv_ell * inv_ell;
+    }
+    VG_T(bx == 0 && by == 0 && bz == 0, 131);
+    VG_T(bx == 0 && j1 == J && bz == L - 1, 135);
+}
+
+__global__ __launch_bounds__(kBlock) void features_kernel(FeatArgs a) {
+    if (a.tick && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+        const uint32_t t = *a.tick + 1u;              // = 1-based Adam count of this step's update
+        *a.tick = t;
+        a.lr_dev[0] = adam_step_size(a.lr, (double)t);
+    }
+    features_body(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// =================================================================================================
+// Prior draws  F0[s, l, j] = sum_b w[s, l, b] Phi[l, j, b]   (and H with dPhi) on the f32 MFMA pipe.
+// v_mfma_f32_16x16x4_f32: lane -> A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15];
+// each lane loads 4 consecutive k (16 B) per operand, so one load pair feeds 4 MFMAs (k = 4g + c).
+// =================================================================================================
+typedef float vg_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kNT = 3;     // 16-column tiles per wave
+
+struct GemmArgs {
+    int S, L, J, B, SK, nsel;
+    const float *W, *Phi, *dPhi;
+    float *F0, *H;
+    size_t slab;
+    int dbg;                 // measurement builds: 1 no stores, 2 no loads, 3 no MFMA
+};
+
+// KS > 0: the K-slice of a workgroup is a multiple of KS steps of 16 and goes in passes of KS steps whose operands
+// are ALL requested before the pass's first MFMA (one L2 round trip per pass instead of one per step -- at one
+// problem these launches are latency bound, not bandwidth bound).  KS == 0: any slice length, next step
+// prefetched while the MFMAs of this one run.
+template <int KS>
+__device__ __forceinline__ void prior_gemm_body(const GemmArgs& a, int bx, int by, int bz) {
+    const int S = a.S, L = a.L, J = a.J, B = a.B, SK = a.SK, nsel = a.nsel;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int z = bz;
+    const int sel = z % nsel; z /= nsel;
+    const int sk = z % SK; z /= SK;
+    const int l = z % L, p = z / L;
+    const int s0 = (by * 4 + wave) * 16;
+    const int j0 = bx * (16 * kNT);
+    VG_T(bx == 0 && by == 0 && bz == 0, 240);
+    if (s0 >= S) return;
+    const float* Bm = sel == 0 ? a.Phi : a.dPhi;
+    float* Out = (sel == 0 ? a.F0 : a.H) + (size_t)sk * a.slab;
+    const int kchunk = B / SK, kbeg = sk * kchunk, kend = kbeg + kchunk;
+    const int r = lane & 15, g = lane >> 4;
+    const int srow = min(s0 + r, S - 1);
+    const float* ap = a.W + (((size_t)p * S + srow) * L + l) * B + 4 * g;
+    const float* bp[kNT];
+#pragma unroll
+    for (int t = 0; t < kNT; ++t) {
+        int jc = min(j0 + 16 * t + r, J - 1);
+        bp[t] = Bm + (((size_t)p * L + l) * J + jc) * B + 4 * g;
+    }
+    vg_f32x4 acc[kNT];
+#pragma unroll
+    for (int t = 0; t < kNT; ++t) acc[t] = (vg_f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (KS > 0) {
+        // the K-slice in passes of KS steps: every operand of a pass is requested before its first MFMA
+        for (int k0 = kbeg; k0 < kend; k0 += 16 * KS) {
+            float4 av[KS], bv[kNT][KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                av[ks] = *reinterpret_cast<const float4*>(ap + k0 + 16 * ks);
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) bv[t][ks] = *reinterpret_cast<const float4*>(bp[t] + k0 + 16 * ks);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].x, bv[t][ks].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].y, bv[t][ks].y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].z, bv[t][ks].z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].w, bv[t][ks].w, acc[t], 0, 0, 0);
+                }
+        }
+    } else {
+        float4 a_cur = *reinterpret_cast<const float4*>(ap + kbeg);
+        float4 b_cur[kNT];
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) b_cur[t] = *reinterpret_cast<const float4*>(bp[t] + kbeg);
+        for (int k = kbeg; k < kend; k += 16) {
+            const int kn = (k + 16 < kend) ? k + 16 : k;      // prefetch next k-step while the MFMAs run
+            float4 a_nxt = *reinterpret_cast<const float4*>(ap + kn);
+            float4 b_nxt[kNT];
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) b_nxt[t] = *reinterpret_cast<const float4*>(bp[t] + kn);
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.x, b_cur[t].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.y, b_cur[t].y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.z, b_cur[t].z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.w, b_cur[t].w, acc[t], 0, 0, 0);
+            }
+            a_cur = a_nxt;
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) b_cur[t] = b_nxt[t];
+        }
+    }
+    VG_T(bx == 0 && by == 0 && bz == 0, 241);
+#ifdef VGPMP_BISECT
+    if (a.dbg == 1) { if (acc[0][0] + acc[1][1] + acc[2][2] == 123.456f) Out[0] = 1.f; return; }
+#endif
+    // D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int t = 0; t < kNT; ++t) {
+        const int jc = j0 + 16 * t + r;
+        if (jc >= J) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s = s0 + g * 4 + q;
+            if (s < S) Out[(((size_t)p * S + s) * L + l) * J + jc] = acc[t][q];
+        }
+    }
+    VG_T(bx == 0 && by == 0 && bz == 0, 242);
+    VG_T(bx == 2 && by == 1 && l == L - 1 && sk == SK - 1 && sel == nsel - 1, 245);
+}
+
+template <int KS>
+__global__ __launch_bounds__(kBlock) void prior_gemm_kernel(GemmArgs a) { prior_gemm_body<KS>(a, blockIdx.x, blockIdx.y, blockIdx.z); }
+
+// LDS-tiled variant for large batches (no split-K): a workgroup owns 64 samples x 144 columns, stages
+// 32-deep K slices of W and Phi through double-buffered LDS (global -> registers -> LDS, next slice in
+// flight while the MFMAs run) and every wave reads its fragments with ds_read_b128.  Row stride 36 floats
+// keeps the 16-byte fragment reads of a 16-row group on distinct bank slots.  Raises flop per byte
+// fetched from L2 from ~10 to ~22 compared with the direct kernel above.
+constexpr int kTS = 64, kTJ = 144, kTK = 32, kTLd = 36;
+
+__global__ __launch_bounds__(kBlock) void prior_gemm_tiled_kernel(int S, int L, int J, int B, int nsel,
+                                                                   const float* __restrict__ W,
+                                                                   const float* __restrict__ Phi,
+                                                                   const float* __restrict__ dPhi,
+                                                                   float* __restrict__ F0, float* __restrict__ H) {
+    __shared__ float As[2][kTS * kTLd];
+    __shared__ float Bs[2][kTJ * kTLd];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int z = blockIdx.z;
+    const int sel = z % nsel; z /= nsel;
+    const int l = z % L, p = z / L;
+    const int s0 = blockIdx.y * kTS, j0 = blockIdx.x * kTJ;
+    const float* Bm = sel == 0 ? Phi : dPhi;
+    float* Out = sel == 0 ? F0 : H;
+    // staging map: thread -> (row, 16-byte k-chunk); A: 64 rows x 8 chunks = 512 (2 per thread),
+    // B: 144 rows x 8 chunks = 1152 (4.5 per thread -> 5 passes, last partial)
+    float4 ra[2], rbv[5];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = tid + q * kBlock, row = c >> 3, ch = c & 7;
+            const int srow = min(s0 + row, S - 1);
+            ra[q] = *reinterpret_cast<const float4*>(W + (((size_t)p * S + srow) * L + l) * B + k0 + 4 * ch);
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int c = min(tid + q * kBlock, kTJ * 8 - 1), row = c >> 3, ch = c & 7;
+            const int jrow = min(j0 + row, J - 1);
+            rbv[q] = *reinterpret_cast<const float4*>(Bm + (((size_t)p * L + l) * J + jrow) * B + k0 + 4 * ch);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = tid + q * kBlock, row = c >> 3, ch = c & 7;
+            *reinterpret_cast<float4*>(&As[buf][row * kTLd + 4 * ch]) = ra[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int c = tid + q * kBlock;
+            if (c < kTJ * 8) {
+                const int row = c >> 3, ch = c & 7;
+                *reinterpret_cast<float4*>(&Bs[buf][row * kTLd + 4 * ch]) = rbv[q];
+            }
+        }
+    };
+    vg_f32x4 acc[kTJ / 16];
+#pragma unroll
+    for (int t = 0; t < kTJ / 16; ++t) acc[t] = (vg_f32x4){0.f, 0.f, 0.f, 0.f};
+    const int r = lane & 15, g = lane >> 4;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < B; k0 += kTK) {
+        const bool more = k0 + kTK < B;
+        if (more) load_tiles(k0 + kTK);
+        const float* a_base = &As[buf][(wave * 16 + r) * kTLd + 4 * g];
+#pragma unroll
+        for (int kk = 0; kk < kTK; kk += 16) {
+            const float4 a4 = *reinterpret_cast<const float4*>(a_base + kk);
+#pragma unroll
+            for (int t = 0; t < kTJ / 16; ++t) {
+                const float4 b4 = *reinterpret_cast<const float4*>(&Bs[buf][(t * 16 + r) * kTLd + kk + 4 * g]);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc[t], 0, 0, 0);
+            }
+        }
+        if (more) store_tiles(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int t = 0; t < kTJ / 16; ++t) {
+        const int jc = j0 + 16 * t + r;
+        if (jc >= J) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int srow = s0 + wave * 16 + g * 4 + q;
+            if (srow < S) Out[(((size_t)p * S + srow) * L + l) * J + jc] = acc[t][q];
+        }
+    }
+}
+
+// =================================================================================================
+// Path assembly  (decoupled / Matheron update, vgpmp.py:281-282):
+//   u = m + C eps;  r = u - F0(Z) - sqrt(jitter) eps2;  f = F0(X) + A r
+// One workgroup per (chunk of VG_SC samples, latent, problem).
+// =================================================================================================
 // the same update with the state already in registers
 __device__ __forceinline__ void adam_apply(double* x, double* m, double* v, double x0, double m0, double v0, double g,
                                            double lr_t) {
@@ -1238,47 +1338,18 @@ __device__ __forceinline__ double sum_chunks(const float* part, size_t part_len,
     return s;
 }
 
-// one wave per problem, one lane per latent.  The three sums over the sample chunks are loaded in ONE round
-// (16 chunks x 3 values per pass, clamped + masked), then added in the order of sum_chunks().
+// one wave per problem, one lane per latent
 __global__ __launch_bounds__(64) void hyper_kernel(HyperArgs h) {
     const int p = blockIdx.x, l = threadIdx.x;
     VG_T(p == 0, 600);
-    double lr_t = h.lr_t;
-    if (h.do_adam && h.ctr) {
-        const double t = (double)*h.ctr;
-        lr_t = h.lr * sqrt(1.0 - exp(t * -0.05129329438755058)) / (1.0 - exp(t * -0.2231435513142098));
-    }
-    if (l == 0) h.lr_dev[p] = lr_t;
     if (l >= h.L) return;
     const size_t pl = (size_t)p * h.L + l;
-    const float* part = h.part + pl * h.NC * h.part_len + (h.Mz + h.Mz * h.Mz);
-    const double gkl_ell = h.gkl_ell[pl], gkl_var = h.gkl_var[pl], var = h.var[pl];
-    const double sig_ell = h.sig_ell[pl], sig_var = h.sig_var[pl];
-    double s3[3] = {0.0, 0.0, 0.0};
-    for (int c0 = 0; c0 < h.NC; c0 += 16) {
-        float v[16][3];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const float* q = part + (size_t)min(c0 + k, h.NC - 1) * h.part_len;
-            v[k][0] = q[0]; v[k][1] = q[1]; v[k][2] = q[2];
-        }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            double d[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) d[k] = c0 + k < h.NC ? (double)v[k][j] : 0.0;
-            s3[j] += ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
-            s3[j] += ((d[8] + d[9]) + (d[10] + d[11])) + ((d[12] + d[13]) + (d[14] + d[15]));
-        }
-    }
-    const double s_ell = h.want_dell ? s3[0] : 0.0;
-    const double g_ell = (s_ell + h.kl_scale * gkl_ell) * sig_ell;
-    const double g_var = (s3[1] + s3[2] / (2.0 * var) + h.kl_scale * gkl_var) * sig_var;
-    h.g_ell[pl] = g_ell;
-    h.g_var[pl] = g_var;
+    const HyperState o = hyper_update(h, pl);
+    h.g_ell[pl] = o.g_ell;
+    h.g_var[pl] = o.g_var;
     if (h.do_adam) {
-        if (h.trainable & VGPMP_TRAIN_LENGTHSCALES) adam_update(h.p_ell + pl, h.m_ell + pl, h.v_ell + pl, g_ell, lr_t);
-        if (h.trainable & VGPMP_TRAIN_KERNEL_VARIANCE) adam_update(h.p_var + pl, h.m_var + pl, h.v_var + pl, g_var, lr_t);
+        h.p_ell[pl] = o.raw_ell; h.m_ell[pl] = o.m_ell; h.v_ell[pl] = o.v_ell;
+        h.p_var[pl] = o.raw_var; h.m_var[pl] = o.m_var; h.v_var[pl] = o.v_var;
     }
     VG_T(p == 0, 601);
 }
@@ -1326,7 +1397,7 @@ __device__ __forceinline__ void final_body(const FinalArgs& b, double* sm, int l
     float* Lks = reinterpret_cast<float*>(dmv + Mz + (Mz & 1));   // [Mz][Mz] chol factor (16-byte aligned)
     float* raw = Lks + ((Mz * Mz + 3) & ~3);                      // [NC][np] chunk partials as they arrive (dma)
     const float* part = b.part + pl * b.NC * b.part_len;
-    const double lr_t = b.do_adam ? b.lr_dev[p] : 0.0;
+    const double lr_t = b.do_adam ? (b.use_lr_dev ? b.lr_dev[0] : b.lr_t) : 0.0;
     vg_stage_rows(Lks, 1, Mz * Mz, tid, nt, [&](int) -> const float* { return b.Lk32 + pl * Mz * Mz; });
     if (b.dma) vg_stage_rows(raw, b.NC, np, tid, nt, [&](int c) -> const float* { return part + (size_t)c * b.part_len; });
     // this thread's elements k = tid + j * nt of  q_mu | q_sqrt:  KL gradient and Adam state
@@ -1579,6 +1650,10 @@ size_t vg_layout_workspace(const vgpmp_dims* d, void* base, vg_workspace* ws) {
     ws->lik_partial = carve<float>(cur, P * (size_t)vg_loglik_blocks_per_problem(d->S, d->N), real);
     ws->part = carve<float>(cur, PL * vg_chunks(d) * vg_part_len(d), real);
     ws->lr_t = carve<double>(cur, P, real);
+    ws->theta_next = carve<double>(cur, PL * 6, real);
+    ws->prev_var = carve<double>(cur, PL, real);
+    ws->prev_sig_ell = carve<double>(cur, PL, real);
+    ws->prev_sig_var = carve<double>(cur, PL, real);
     return (size_t)(cur - start) + 256;
 }
 
@@ -1686,6 +1761,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     ca.want_dell = want_dell ? 1 : 0;
     ca.stop = -1;
     ca.tick = (fused && do_adam) ? ctr : nullptr;
+    ca.lr = lr; ca.lr_dev = ws->lr_t;
+    ca.prologue = 0; ca.commit = 0; ca.keep_prev = (fused && backward) ? 1 : 0;
     ca.ws = *ws;
     FeatArgs fe;
     fe.N = N; fe.Mz = Mz; fe.L = L; fe.D = L; fe.B = B;
@@ -1694,6 +1771,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     fe.X = pb->X; fe.Zy = pb->Zy; fe.raw_ell = params->raw_ell; fe.raw_var = params->raw_var;
     fe.omega = nz->omega; fe.beta = nz->beta; fe.Phi = ws->Phi; fe.dPhi = want_dell ? ws->dPhi : nullptr;
     fe.tick = (!fused && do_adam) ? ctr : nullptr;
+    fe.lr = lr; fe.lr_dev = ws->lr_t;
+    fe.prologue = 0;
     const dim3 feat_grid((B + kBlock - 1) / kBlock, (J + fe.jchunk - 1) / fe.jchunk, P * L);
     const size_t slab = (size_t)P * S * L * J;
     GemmArgs ga;
@@ -1711,12 +1790,15 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     HyperArgs hy;
     hy.L = L; hy.Mz = Mz; hy.NC = NC; hy.want_dell = want_dell ? 1 : 0; hy.part_len = vg_part_len(d); hy.part = ws->part;
     hy.gkl_ell = ws->gkl_ell; hy.gkl_var = ws->gkl_var; hy.var = ws->var; hy.sig_ell = ws->sig_ell; hy.sig_var = ws->sig_var;
-    hy.kl_scale = pb->kl_scale; hy.lr = lr; hy.lr_t = 0.0;
-    hy.g_ell = out->grad.raw_ell; hy.g_var = out->grad.raw_var; hy.lr_dev = ws->lr_t;
+    hy.kl_scale = pb->kl_scale; hy.lr_t = 0.0;
+    hy.g_ell = out->grad.raw_ell; hy.g_var = out->grad.raw_var; hy.lr_dev = ws->lr_t; hy.next = ws->theta_next;
     hy.m_ell = am ? am->raw_ell : nullptr; hy.m_var = am ? am->raw_var : nullptr;
     hy.v_ell = av ? av->raw_ell : nullptr; hy.v_var = av ? av->raw_var : nullptr;
     hy.p_ell = params->raw_ell; hy.p_var = params->raw_var;
-    hy.ctr = ctr; hy.do_adam = do_adam ? 1 : 0; hy.trainable = trainable;
+    hy.do_adam = do_adam ? 1 : 0; hy.trainable = trainable; hy.use_lr_dev = (ctr && do_adam) ? 1 : 0;
+    HyperArgs hyp = hy;                  // prologue form: var / slopes of the PREVIOUS step (kept by stage 2)
+    hyp.var = ws->prev_var; hyp.sig_ell = ws->prev_sig_ell; hyp.sig_var = ws->prev_sig_var;
+    ca.hy = hyp; fe.hy = hyp;
     pa.stop = -1;
     const double lik_scale = pb->alpha / (double)d->S_total;
     FinalArgs fa;
@@ -1726,6 +1808,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     fa.kl_scale = pb->kl_scale; fa.lik_scale = lik_scale; fa.out_lik = out->lik; fa.out_kl = out->kl;
     fa.g_qmu = out->grad.q_mu; fa.g_qsqrt = out->grad.q_sqrt;
     fa.do_adam = do_adam ? 1 : 0; fa.trainable = trainable; fa.lr_dev = ws->lr_t; fa.dma = 0;
+    fa.lr_t = 0.0; fa.use_lr_dev = (ctr && do_adam) ? 1 : 0;
     fa.mq_mu = am ? am->q_mu : nullptr; fa.mq_sqrt = am ? am->q_sqrt : nullptr;
     fa.vq_mu = av ? av->q_mu : nullptr; fa.vq_sqrt = av ? av->q_sqrt : nullptr;
     fa.pq_mu = params->q_mu; fa.pq_sqrt = params->q_sqrt;
@@ -1802,9 +1885,17 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             // noise of the first step of a call: everything up front; afterwards eps rides in stage 1 and the
             // prior noise of step i was drawn by stage 3 of step i-1
             if (gen && first && (rc = vg_launch_rng(d, nz, seed, problem_base, step_i, ctr, st))) return rc;
+            // steps after the first of a call: the hyper-parameter update of the previous step is a prologue of the
+            // cov_a and feature roles, its q_mu / q_sqrt update (final) another role of the same launch
+            const bool prologue = !first && backward;
+            const double lr_prev = do_adam ? adam_lr_t(lr, adam_t + i - 1 > 0 ? adam_t + i - 1 : 1) : 0.0;
+            hyp.lr_t = lr_prev;
             Stage1Args s1;
             s1.skip = skip1;
             s1.cov = ca; s1.fin = fa; s1.feat = fe;
+            s1.fin.lr_t = lr_prev;
+            s1.cov.hy = hyp; s1.feat.hy = hyp;
+            s1.cov.prologue = prologue ? 1 : 0; s1.feat.prologue = prologue ? 1 : 0;
             s1.rng = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
             s1.n_cov = L * P;
             s1.n_fin = first ? 0 : L * P;
@@ -1816,6 +1907,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             Stage2Args s2;
             s2.skip = skip2;
             s2.cov = ca; s2.gemm = ga;
+            s2.cov.hy = hyp; s2.cov.commit = prologue ? 1 : 0;
             s2.cov_roles = (int)cov_b_grid.x; s2.n_cov = (int)(cov_b_grid.x * cov_b_grid.y * cov_b_grid.z);
             s2.gemm_gx = (int)gemm_grid.x; s2.gemm_gy = (int)gemm_grid.y;
             const int n_gemm = (int)(gemm_grid.x * gemm_grid.y * gemm_grid.z);
@@ -1866,9 +1958,12 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         // ---- reverse of the path assembly (+ hyper-parameter update), then (here or in the next stage 1) the rest
         if ((rc = launch(fn_pb, dim3(NC, L, P), &pa, lds_pb))) return rc;
         mark();
-        hy.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
-        hipLaunchKernelGGL(hyper_kernel, dim3(P), dim3(64), 0, st, hy);
-        if (!(fused && more) && (rc = launch_final())) return rc;
+        if (!(fused && more)) {      // otherwise both ride in stage 1 of the next step
+            hy.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
+            fa.lr_t = hy.lr_t;
+            hipLaunchKernelGGL(hyper_kernel, dim3(P), dim3(64), 0, st, hy);
+            if ((rc = launch_final())) return rc;
+        }
         mark();
     }
     return (int)hipGetLastError();
