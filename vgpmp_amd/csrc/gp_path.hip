@@ -461,18 +461,32 @@ struct HyperState { double raw_ell, raw_var, m_ell, v_ell, m_var, v_var, g_ell, 
 // and added in the order of sum_chunks().
 __device__ __forceinline__ HyperState hyper_update(const HyperArgs& h, size_t pl) {
     const float* part = h.part + pl * h.NC * h.part_len + (h.Mz + h.Mz * h.Mz);
+    // every operand requested in one go, unconditionally (null Adam pointers fall back to a valid address): the
+    // prologue form sits on the critical chain and a second dependent round trip costs ~2 us
+    const double* mell = h.do_adam ? h.m_ell : h.p_ell;
+    const double* vell = h.do_adam ? h.v_ell : h.p_ell;
+    const double* mvar = h.do_adam ? h.m_var : h.p_var;
+    const double* vvar = h.do_adam ? h.v_var : h.p_var;
+    float v0[16][3];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float* q = part + (size_t)min(k, h.NC - 1) * h.part_len;
+        v0[k][0] = q[0]; v0[k][1] = q[1]; v0[k][2] = q[2];
+    }
     HyperState o;
     o.raw_ell = h.p_ell[pl]; o.raw_var = h.p_var[pl];
-    if (h.do_adam) { o.m_ell = h.m_ell[pl]; o.v_ell = h.v_ell[pl]; o.m_var = h.m_var[pl]; o.v_var = h.v_var[pl]; }
-    else { o.m_ell = o.v_ell = o.m_var = o.v_var = 0.0; }
+    o.m_ell = mell[pl]; o.v_ell = vell[pl]; o.m_var = mvar[pl]; o.v_var = vvar[pl];
     const double gkl_ell = h.gkl_ell[pl], gkl_var = h.gkl_var[pl], var = h.var[pl];
     const double sig_ell = h.sig_ell[pl], sig_var = h.sig_var[pl];
-    const double lr_t = (h.do_adam && h.use_lr_dev) ? h.lr_dev[0] : h.lr_t;
+    const double lr_dev = h.lr_dev[0];
+    const double lr_t = (h.do_adam && h.use_lr_dev) ? lr_dev : h.lr_t;
+    if (!h.do_adam) o.m_ell = o.v_ell = o.m_var = o.v_var = 0.0;
     double s3[3] = {0.0, 0.0, 0.0};
     for (int c0 = 0; c0 < h.NC; c0 += 16) {
         float v[16][3];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
+            if (c0 == 0) { v[k][0] = v0[k][0]; v[k][1] = v0[k][1]; v[k][2] = v0[k][2]; continue; }
             const float* q = part + (size_t)min(c0 + k, h.NC - 1) * h.part_len;
             v[k][0] = q[0]; v[k][1] = q[1]; v[k][2] = q[2];
         }
