@@ -122,7 +122,8 @@ def _noise32(noise):
 
 
 @pytest.mark.parametrize("robot,S,N,M,B,split_k", [("franka", 6, 9, 5, 64, 1), ("franka", 37, 50, 10, 256, 4),
-                                                    ("wam", 20, 33, 12, 128, 2), ("ur10", 16, 20, 6, 64, 1)])
+                                                    ("wam", 20, 33, 12, 128, 2), ("ur10", 16, 20, 6, 64, 1),
+                                                    ("franka", 128, 100, 30, 1024, 4)])     # BASELINE config 2, full size
 def test_elbo_forward_backward_against_oracle(robot, S, N, M, B, split_k):
     pb = small_problem(robot=robot, S=S, N=N, M=M, B=B, seed=11, n_grid=48)
     sc = _scene(pb["spec"], pb["grid"], pb["offset"])
@@ -150,6 +151,19 @@ def test_elbo_forward_backward_against_oracle(robot, S, N, M, B, split_k):
     assert (fw["logp"] < 0).any()
     ok = np.isclose(logp, fw["logp"], rtol=2e-3, atol=1e-4)
     assert ok.mean() >= 0.97, f"logp agreement {ok.mean():.3f}"
+    if not ok.all():
+        # a few float32 sphere centres fell into the neighbouring voxel: the sums still agree to the share of
+        # configurations affected
+        flips = 1.0 - ok.mean()
+        np.testing.assert_allclose(float(pl.kl[0]), cv["kl"], rtol=1e-9)
+        np.testing.assert_allclose(float(pl.lik[0]), fw["lik"], rtol=50 * flips + 2e-4)
+        for got, name in zip(grads, ("q_mu", "q_sqrt", "raw_ell", "raw_var")):
+            want = getattr(og, name)
+            got = got[0].cpu().numpy()
+            if name == "q_mu":
+                got = got.T
+            scale = np.abs(want).max() + 1e-12
+            assert np.abs(got - want).max() / scale < 50 * flips + 3e-3, (name, np.abs(got - want).max(), scale, flips)
     if ok.all():
         # no voxel flips: the end-to-end numbers must agree to float32 accuracy
         np.testing.assert_allclose(float(pl.kl[0]), cv["kl"], rtol=1e-9)
