@@ -1226,6 +1226,77 @@ __device__ __forceinline__ void prior_gemm_body(const GemmArgs& a, int bx, int b
 template <int KS>
 __global__ __launch_bounds__(kBlock) void prior_gemm_kernel(GemmArgs a) { prior_gemm_body<KS>(a, blockIdx.x, blockIdx.y, blockIdx.z); }
 
+// The same tile with its operands staged through LDS by DMA in passes of 128 K (the form stage 2 uses): whole
+// 512-byte rows per request instead of the 16 rows x 64 bytes a fragment-shaped load touches, all requests of a
+// pass in flight together, fragments by ds_read_b128.  LDS rows are padded to 132 floats (33 units of 16 bytes;
+// the pad unit repeats the row's last one): the 16-byte fragment reads of a 16-row group then fall on distinct
+// bank slots.  LDS: (64 + 48) x 132 x 4 = 59 KB per workgroup.
+constexpr int kGK = 128, kGLd = kGK + 4, kGRows = 64 + 16 * kNT;
+constexpr size_t kGemmLds = (size_t)kGRows * kGLd * sizeof(float);
+
+__device__ __forceinline__ void prior_gemm_lds_body(const GemmArgs& a, float* lds, int bx, int by, int bz) {
+    const int S = a.S, L = a.L, J = a.J, B = a.B, SK = a.SK, nsel = a.nsel;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int z = bz;
+    const int sel = z % nsel; z /= nsel;
+    const int sk = z % SK; z /= SK;
+    const int l = z % L, p = z / L;
+    const int s0 = by * 64, j0 = bx * (16 * kNT);
+    VG_T(bx == 0 && by == 0 && bz == 0, 240);
+    const float* Bm = sel == 0 ? a.Phi : a.dPhi;
+    float* Out = (sel == 0 ? a.F0 : a.H) + (size_t)sk * a.slab;
+    const int kchunk = B / SK, kbeg = sk * kchunk, kend = kbeg + kchunk;
+    const int r = lane & 15, g = lane >> 4;
+    constexpr int kUnits = kGLd / 4;                         // 33 units per padded row
+    float* As = lds;                                         // [64][kGLd]
+    float* Bs = lds + 64 * kGLd;                             // [16 kNT][kGLd]
+    vg_f32x4 acc[kNT];
+#pragma unroll
+    for (int t = 0; t < kNT; ++t) acc[t] = (vg_f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = kbeg; k0 < kend; k0 += kGK) {
+        if (k0 != kbeg) __syncthreads();                     // the previous pass has been read
+        for (int c = (tid & ~63); c < kGRows * kUnits; c += kBlock) {
+            const int i = c + lane;
+            if (i < kGRows * kUnits) {
+                const int row = i / kUnits, u = min(i - row * kUnits, kGK / 4 - 1);
+                const float* src = row < 64
+                    ? a.W + (((size_t)p * S + min(s0 + row, S - 1)) * L + l) * B + k0 + 4 * u
+                    : Bm + (((size_t)p * L + l) * J + min(j0 + row - 64, J - 1)) * B + k0 + 4 * u;
+                __builtin_amdgcn_global_load_lds((vg_gmem*)src, (vg_lmem*)(lds + 4 * (size_t)c), 16, 0, 0);
+            }
+        }
+        vg_dma_wait();
+        __syncthreads();
+        const float* ap = As + (wave * 16 + r) * kGLd + 4 * g;
+#pragma unroll
+        for (int ks = 0; ks < kGK / 16; ++ks) {
+            const float4 a4 = *reinterpret_cast<const float4*>(ap + 16 * ks);
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) {
+                const float4 b4 = *reinterpret_cast<const float4*>(Bs + (16 * t + r) * kGLd + 16 * ks + 4 * g);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    VG_T(bx == 0 && by == 0 && bz == 0, 241);
+    const int sw = s0 + wave * 16;
+#pragma unroll
+    for (int t = 0; t < kNT; ++t) {
+        const int jc = j0 + 16 * t + r;
+        if (jc >= J) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s = sw + g * 4 + q;
+            if (s < S) Out[(((size_t)p * S + s) * L + l) * J + jc] = acc[t][q];
+        }
+    }
+    VG_T(bx == 0 && by == 0 && bz == 0, 242);
+    VG_T(bx == 2 && by == 1 && l == L - 1 && sk == SK - 1 && sel == nsel - 1, 245);
+}
+
 // LDS-tiled variant for large batches (no split-K): a workgroup owns 64 samples x 144 columns, stages
 // 32-deep K slices of W and Phi through double-buffered LDS (global -> registers -> LDS, next slice in
 // flight while the MFMAs run) and every wave reads its fragments with ds_read_b128.  Row stride 36 floats
@@ -1580,7 +1651,8 @@ __global__ __launch_bounds__(kBlock) void stage2_kernel(Stage2Args a) {
     if (a.gemm_per_xcd > 0) b = (b & 7) * a.gemm_per_xcd + (b >> 3);
     const int bx = b % a.gemm_gx;
     b /= a.gemm_gx;
-    prior_gemm_body<KS>(a.gemm, bx, b % a.gemm_gy, b / a.gemm_gy);
+    if constexpr (KS < 0) prior_gemm_lds_body(a.gemm, reinterpret_cast<float*>(sm), bx, b % a.gemm_gy, b / a.gemm_gy);
+    else prior_gemm_body<KS>(a.gemm, bx, b % a.gemm_gy, b / a.gemm_gy);
 }
 
 struct Stage3Args {
@@ -1859,8 +1931,12 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const size_t lds_s1 = lds_cov_a > lds_fin ? lds_cov_a : lds_fin;
     const void* fn_cov_b = backward ? (const void*)cov_b_kernel<true> : (const void*)cov_b_kernel<false>;
     const bool k8 = (B / SK) % 128 == 0;      // K-slice in passes of 8 steps of 16: a pass's operands in one request
-    const void* fn_s2 = backward ? (k8 ? (const void*)stage2_kernel<true, 8> : (const void*)stage2_kernel<true, 0>)
+    // K-slices of a multiple of 128: operands through LDS by DMA (needs 59 KB per workgroup)
+    const bool glds = (B / SK) % kGK == 0 && !(what & VGPMP_GEMM_DIRECT);
+    const void* fn_s2 = glds ? (backward ? (const void*)stage2_kernel<true, -1> : (const void*)stage2_kernel<false, -1>)
+                      : backward ? (k8 ? (const void*)stage2_kernel<true, 8> : (const void*)stage2_kernel<true, 0>)
                                  : (k8 ? (const void*)stage2_kernel<false, 8> : (const void*)stage2_kernel<false, 0>);
+    const size_t lds_s2 = glds && kGemmLds > lds_cov_b ? kGemmLds : lds_cov_b;
     if (SC != 8) return VGPMP_E_SHAPE;
 #define VG_PICK(kernel, raw)                                                                                        \
     (SK == 1 ? (raw ? (const void*)kernel<1, true> : (const void*)kernel<1, false>)                                 \
@@ -1874,7 +1950,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     if ((rc = set_dyn_lds(fn_pb, lds_pb))) return rc;
     if (fused) {
         if ((rc = set_dyn_lds((const void*)stage1_kernel, lds_s1))) return rc;
-        if ((rc = set_dyn_lds(fn_s2, lds_cov_b))) return rc;
+        if ((rc = set_dyn_lds(fn_s2, lds_s2))) return rc;
         if ((rc = set_dyn_lds(fn_s3, lds_pf))) return rc;
     } else {
         if ((rc = set_dyn_lds((const void*)cov_a_kernel, lds_cov_a))) return rc;
@@ -1926,7 +2002,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             s2.gemm_gx = (int)gemm_grid.x; s2.gemm_gy = (int)gemm_grid.y;
             const int n_gemm = (int)(gemm_grid.x * gemm_grid.y * gemm_grid.z);
             s2.gemm_per_xcd = (s2.n_cov % 8 == 0 && n_gemm % 8 == 0) ? n_gemm / 8 : 0;
-            if ((rc = launch(fn_s2, dim3(s2.n_cov + gemm_grid.x * gemm_grid.y * gemm_grid.z), &s2, lds_cov_b))) return rc;
+            if ((rc = launch(fn_s2, dim3(s2.n_cov + gemm_grid.x * gemm_grid.y * gemm_grid.z), &s2, lds_s2))) return rc;
             Stage3Args s3;
             s3.skip = skip3;
             s3.path = pa;
