@@ -449,6 +449,9 @@ struct HyperArgs {
     const double *gkl_ell, *gkl_var, *var, *sig_ell, *sig_var;      // var / slopes of the step being finished
     double kl_scale, lr_t;
     const double* lr_dev;    // [1] step size stored at the counter tick (device counter form), else lr_t
+    const uint32_t* ctr;     // hyper_kernel only: derive the step size from the (ticked) counter and store it
+    double lr;
+    double* lr_store;
     double *g_ell, *g_var;
     double *m_ell, *m_var, *v_ell, *v_var, *p_ell, *p_var;
     double* next;            // [P,L,6] staging of {raw_ell, raw_var, m_ell, v_ell, m_var, v_var} (prologue form)
@@ -459,7 +462,7 @@ struct HyperState { double raw_ell, raw_var, m_ell, v_ell, m_var, v_var, g_ell, 
 
 // The three sums over the sample chunks are loaded in ONE round (16 chunks x 3 values per pass, clamped + masked)
 // and added in the order of sum_chunks().
-__device__ __forceinline__ HyperState hyper_update(const HyperArgs& h, size_t pl) {
+__device__ __forceinline__ HyperState hyper_update(const HyperArgs& h, size_t pl, bool own_lr = false, double lr_own = 0.0) {
     const float* part = h.part + pl * h.NC * h.part_len + (h.Mz + h.Mz * h.Mz);
     // every operand requested in one go, unconditionally (null Adam pointers fall back to a valid address): the
     // prologue form sits on the critical chain and a second dependent round trip costs ~2 us
@@ -479,7 +482,7 @@ __device__ __forceinline__ HyperState hyper_update(const HyperArgs& h, size_t pl
     const double gkl_ell = h.gkl_ell[pl], gkl_var = h.gkl_var[pl], var = h.var[pl];
     const double sig_ell = h.sig_ell[pl], sig_var = h.sig_var[pl];
     const double lr_dev = h.lr_dev[0];
-    const double lr_t = (h.do_adam && h.use_lr_dev) ? lr_dev : h.lr_t;
+    const double lr_t = own_lr ? lr_own : ((h.do_adam && h.use_lr_dev) ? lr_dev : h.lr_t);
     if (!h.do_adam) o.m_ell = o.v_ell = o.m_var = o.v_var = 0.0;
     double s3[3] = {0.0, 0.0, 0.0};
     for (int c0 = 0; c0 < h.NC; c0 += 16) {
@@ -1055,12 +1058,12 @@ struct FeatArgs {
     const float *omega, *beta;
     float *Phi, *dPhi;
     uint32_t* tick;          // device step counter, ticked by the stand-alone launch of a training step (or null)
-    double lr;               // with the tick: the step size of this step's update goes to lr_dev[0]
-    double* lr_dev;
-    int prologue;            // stage 1: derive this step's hyper-parameters from the previous reverse pass (hy)
-    HyperArgs hy;
+    HyperArgs hy;            // stage 1 of a chained step: the hyper-parameter update to repeat first (features_body<true>)
 };
 
+// PRO: derive this step's hyper-parameters from the previous reverse pass first (stage 1 of a chained step).  A
+// compile-time switch: the update's registers would otherwise halve the occupancy of the stand-alone kernel.
+template <bool PRO>
 __device__ __forceinline__ void features_body(const FeatArgs& a, int bx, int by, int bz) {
     // one lane per (latent, basis): its frequency row stays in registers while it sweeps `jchunk` points;
     // the points are uniform across the workgroup (scalar loads), the stores are coalesced along b
@@ -1075,7 +1078,7 @@ __device__ __forceinline__ void features_body(const FeatArgs& a, int bx, int by,
     const size_t pl = (size_t)p * L + l;
     if (b >= B) return;
     double re, rv;
-    if (a.prologue) {
+    if constexpr (PRO) {
         const HyperState o = hyper_update(a.hy, pl);
         re = o.raw_ell; rv = o.raw_var;
     } else {
@@ -1106,12 +1109,10 @@ __device__ __forceinline__ void features_body(const FeatArgs& a, int bx, int by,
 }
 
 __global__ __launch_bounds__(kBlock) void features_kernel(FeatArgs a) {
-    if (a.tick && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
-        const uint32_t t = *a.tick + 1u;              // = 1-based Adam count of this step's update
-        *a.tick = t;
-        a.lr_dev[0] = adam_step_size(a.lr, (double)t);
-    }
-    features_body(a, blockIdx.x, blockIdx.y, blockIdx.z);
+    // (the step size of this update is derived from the counter by hyper_kernel in this schedule: float64 exp /
+    // sqrt code here would cost this bandwidth-bound kernel half its occupancy)
+    if (a.tick && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *a.tick += 1u;
+    features_body<false>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // =================================================================================================
@@ -1427,9 +1428,15 @@ __device__ __forceinline__ double sum_chunks(const float* part, size_t part_len,
 __global__ __launch_bounds__(64) void hyper_kernel(HyperArgs h) {
     const int p = blockIdx.x, l = threadIdx.x;
     VG_T(p == 0, 600);
+    const bool own = h.ctr && h.do_adam;
+    double lr_own = 0.0;
+    if (own) {
+        lr_own = adam_step_size(h.lr, (double)*h.ctr);
+        if (p == 0 && l == 0) h.lr_store[0] = lr_own;         // final_kernel reads it
+    }
     if (l >= h.L) return;
     const size_t pl = (size_t)p * h.L + l;
-    const HyperState o = hyper_update(h, pl);
+    const HyperState o = hyper_update(h, pl, own, lr_own);
     h.g_ell[pl] = o.g_ell;
     h.g_var[pl] = o.g_var;
     if (h.do_adam) {
@@ -1613,6 +1620,7 @@ struct Stage1Args {
     int n_cov, n_fin, n_eps, eps_gx, feat_gx, feat_gy;
     int skip;                 // measurement builds: bit mask of roles that return at once
 };
+template <bool PRO>
 __global__ __launch_bounds__(kBlock) void stage1_kernel(Stage1Args a) {
     extern __shared__ double sm[];
     int b = blockIdx.x;
@@ -1625,7 +1633,7 @@ __global__ __launch_bounds__(kBlock) void stage1_kernel(Stage1Args a) {
     if (a.skip & 8) return;
     const int bx = b % a.feat_gx;
     b /= a.feat_gx;
-    features_body(a.feat, bx, b % a.feat_gy, b / a.feat_gy);
+    features_body<PRO>(a.feat, bx, b % a.feat_gy, b / a.feat_gy);
 }
 
 struct Stage2Args {
@@ -1857,8 +1865,6 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     fe.X = pb->X; fe.Zy = pb->Zy; fe.raw_ell = params->raw_ell; fe.raw_var = params->raw_var;
     fe.omega = nz->omega; fe.beta = nz->beta; fe.Phi = ws->Phi; fe.dPhi = want_dell ? ws->dPhi : nullptr;
     fe.tick = (!fused && do_adam) ? ctr : nullptr;
-    fe.lr = lr; fe.lr_dev = ws->lr_t;
-    fe.prologue = 0;
     const dim3 feat_grid((B + kBlock - 1) / kBlock, (J + fe.jchunk - 1) / fe.jchunk, P * L);
     const size_t slab = (size_t)P * S * L * J;
     GemmArgs ga;
@@ -1882,6 +1888,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     hy.v_ell = av ? av->raw_ell : nullptr; hy.v_var = av ? av->raw_var : nullptr;
     hy.p_ell = params->raw_ell; hy.p_var = params->raw_var;
     hy.do_adam = do_adam ? 1 : 0; hy.trainable = trainable; hy.use_lr_dev = (ctr && do_adam) ? 1 : 0;
+    hy.ctr = fused ? nullptr : ctr; hy.lr = lr; hy.lr_store = ws->lr_t;      // one launch per kernel: hyper_kernel derives it
     HyperArgs hyp = hy;                  // prologue form: var / slopes of the PREVIOUS step (kept by stage 2)
     hyp.var = ws->prev_var; hyp.sig_ell = ws->prev_sig_ell; hyp.sig_var = ws->prev_sig_var;
     ca.hy = hyp; fe.hy = hyp;
@@ -1949,7 +1956,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
 #undef VG_PICK
     if ((rc = set_dyn_lds(fn_pb, lds_pb))) return rc;
     if (fused) {
-        if ((rc = set_dyn_lds((const void*)stage1_kernel, lds_s1))) return rc;
+        if ((rc = set_dyn_lds((const void*)stage1_kernel<false>, lds_s1))) return rc;
+        if ((rc = set_dyn_lds((const void*)stage1_kernel<true>, lds_s1))) return rc;
         if ((rc = set_dyn_lds(fn_s2, lds_s2))) return rc;
         if ((rc = set_dyn_lds(fn_s3, lds_pf))) return rc;
     } else {
@@ -1985,7 +1993,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             s1.cov = ca; s1.fin = fa; s1.feat = fe;
             s1.fin.lr_t = lr_prev;
             s1.cov.hy = hyp; s1.feat.hy = hyp;
-            s1.cov.prologue = prologue ? 1 : 0; s1.feat.prologue = prologue ? 1 : 0;
+            s1.cov.prologue = prologue ? 1 : 0;
             s1.rng = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
             s1.n_cov = L * P;
             s1.n_fin = first ? 0 : L * P;
@@ -1993,7 +2001,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             s1.n_eps = (gen && !first) ? (int)eps_gx * P : 0;
             s1.feat_gx = (int)feat_grid.x; s1.feat_gy = (int)feat_grid.y;
             const unsigned n1 = s1.n_cov + s1.n_fin + s1.n_eps + feat_grid.x * feat_grid.y * feat_grid.z;
-            if ((rc = launch((const void*)stage1_kernel, dim3(n1), &s1, lds_s1))) return rc;
+            if ((rc = launch(prologue ? (const void*)stage1_kernel<true> : (const void*)stage1_kernel<false>, dim3(n1), &s1, lds_s1)))
+                return rc;
             Stage2Args s2;
             s2.skip = skip2;
             s2.cov = ca; s2.gemm = ga;
