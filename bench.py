@@ -187,7 +187,8 @@ def main():
                 "traffic": None, "algorithmic_bytes_per_launch": sdf_bytes, "avg_launch_ms": kernel_ms["loglik_kernel"],
                 "timing": "HIP events stamped with the kernel's start and end on its stream (hipExtLaunchKernel), "
                           f"mean of {max(1, args.profile_steps)} launches"}
-    gemm_kernel = "prior_gemm_tiled_kernel" if planner.dims.split_k == 1 else "prior_gemm_kernel<0>"
+    gemm_kernel = ("prior_gemm_tiled_kernel" if planner.dims.split_k == 1 else
+                   "prior_gemm_lds_kernel" if (1024 // planner.dims.split_k) % 128 == 0 and S >= 48 else "prior_gemm_kernel<0>")
     roof_gemm = {"kernel": gemm_kernel, "bound": "mfma", "achieved": gemm_flops / t_gemm / 1e12,
                  "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_flops / t_gemm / 1e12 / F32_MFMA_PEAK_TFLOPS,
                  "traffic": None, "algorithmic_flops_per_launch": gemm_flops, "avg_launch_ms": kernel_ms["prior_gemm_kernel"]}

@@ -1298,6 +1298,11 @@ __device__ __forceinline__ void prior_gemm_lds_body(const GemmArgs& a, float* ld
     VG_T(bx == 2 && by == 1 && l == L - 1 && sk == SK - 1 && sel == nsel - 1, 245);
 }
 
+__global__ __launch_bounds__(kBlock) void prior_gemm_lds_kernel(GemmArgs a) {
+    extern __shared__ float gemm_lds[];
+    prior_gemm_lds_body(a, gemm_lds, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
 // LDS-tiled variant for large batches (no split-K): a workgroup owns 64 samples x 144 columns, stages
 // 32-deep K slices of W and Phi through double-buffered LDS (global -> registers -> LDS, next slice in
 // flight while the MFMAs run) and every wave reads its fragments with ds_read_b128.  Row stride 36 floats
@@ -1938,8 +1943,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const size_t lds_s1 = lds_cov_a > lds_fin ? lds_cov_a : lds_fin;
     const void* fn_cov_b = backward ? (const void*)cov_b_kernel<true> : (const void*)cov_b_kernel<false>;
     const bool k8 = (B / SK) % 128 == 0;      // K-slice in passes of 8 steps of 16: a pass's operands in one request
-    // K-slices of a multiple of 128: operands through LDS by DMA (needs 59 KB per workgroup)
-    const bool glds = (B / SK) % kGK == 0 && !(what & VGPMP_GEMM_DIRECT);
+    // K-slices of a multiple of 128 and enough samples: operands through LDS by DMA (needs 59 KB per workgroup)
+    const bool glds = (B / SK) % kGK == 0 && S >= 48 && !(what & VGPMP_GEMM_DIRECT);      // 64-row tiles: few samples waste them
     const void* fn_s2 = glds ? (backward ? (const void*)stage2_kernel<true, -1> : (const void*)stage2_kernel<false, -1>)
                       : backward ? (k8 ? (const void*)stage2_kernel<true, 8> : (const void*)stage2_kernel<true, 0>)
                                  : (k8 ? (const void*)stage2_kernel<false, 8> : (const void*)stage2_kernel<false, 0>);
@@ -1962,6 +1967,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         if ((rc = set_dyn_lds(fn_s3, lds_pf))) return rc;
     } else {
         if ((rc = set_dyn_lds((const void*)cov_a_kernel, lds_cov_a))) return rc;
+        if (glds && (rc = set_dyn_lds((const void*)prior_gemm_lds_kernel, kGemmLds))) return rc;
         if ((rc = set_dyn_lds(fn_cov_b, lds_cov_b))) return rc;
         if ((rc = set_dyn_lds(fn_pf, lds_pf))) return rc;
     }
@@ -2036,6 +2042,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 hipExtLaunchKernelGGL(prior_gemm_tiled_kernel, dim3((J + kTJ - 1) / kTJ, (S + kTS - 1) / kTS, P * L * ga.nsel),
                                       dim3(kBlock), 0, st, g0, g1, 0, S, L, J, B, ga.nsel, nz->w, ws->Phi, ws->dPhi, ws->F0,
                                       ws->H);
+            else if (glds)
+                hipExtLaunchKernelGGL(prior_gemm_lds_kernel, gemm_grid, dim3(kBlock), kGemmLds, st, g0, g1, 0, ga);
             else
                 hipExtLaunchKernelGGL(prior_gemm_kernel<0>, gemm_grid, dim3(kBlock), 0, st, g0, g1, 0, ga);
             mark();
