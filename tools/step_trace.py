@@ -54,14 +54,14 @@ def main():
     pl.run_steps(6)
     torch.cuda.synchronize()
     n = lib.vgpmp_debug_trace(buf.ctypes.data, 8192)
+    # every stamp id keeps its LAST value: the stamps of the final steps of the run.  The last step of a call ends with
+    # the stand-alone hyper / final launches; shift times so that the latest cov_a start is zero and show one period
     ev = sorted((int(buf[2 * i + 1]), int(buf[2 * i])) for i in range(n))
-    # one step = from a cov_a start to the next one; take the fourth
-    starts = [i for i, (_, k) in enumerate(ev) if k == 100]
-    lo, hi = starts[3], starts[4]
-    t0 = ev[lo][0]
-    print(f"step of {(ev[hi][0] - t0) / 100:.2f} us, {P} problem(s), fuse={pl.fuse}")
-    for t, k in ev[lo:hi + 1]:
-        print(f"{(t - t0) / 100:8.2f} us  {k:4d}  {NAMES.get(k, '')}")
+    t_cov = max(t for t, k in ev if k == 100)
+    period = None
+    print(f"{P} problem(s), fuse={pl.fuse}; times relative to the last cov_a start (negative = previous step)")
+    for t, k in ev:
+        print(f"{(t - t_cov) / 100:8.2f} us  {k:4d}  {NAMES.get(k, '')}")
 
 
 if __name__ == "__main__":

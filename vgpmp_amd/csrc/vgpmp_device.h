@@ -191,22 +191,19 @@ int vg_launch_log_prob_impl(const vgpmp_robot* rb, int dof, const vgpmp_sdf* sdf
 // VG_T(cond, id) records (id, 100 MHz wall clock) from thread 0 of the workgroups that satisfy `cond`,
 // giving a timeline of one step across launches (tools/step_trace.py).  Compiled out of the product.
 #ifdef VGPMP_BISECT
-static __device__ unsigned long long vg_tr_buf[2 * 4096];
-static __device__ unsigned int vg_tr_cnt;
-__device__ __forceinline__ void vg_trace_stamp(int id) {
-    const unsigned k = atomicAdd(&vg_tr_cnt, 1u);
-    if (k < 4096u) { vg_tr_buf[2 * k] = (unsigned long long)id; vg_tr_buf[2 * k + 1] = wall_clock64(); }
-}
-#define VG_T(cond, id) do { if (threadIdx.x == 0 && (cond)) vg_trace_stamp(id); } while (0)
-static int vg_trace_take(unsigned long long* host, int cap) {      // copies and clears this translation unit's buffer
-    unsigned n = 0;
-    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(vg_tr_cnt), sizeof(n)) != hipSuccess) return -1;
-    if (n > 4096u) n = 4096u;
-    if ((int)n > cap) n = (unsigned)cap;
-    if (n && hipMemcpyFromSymbol(host, HIP_SYMBOL(vg_tr_buf), (size_t)n * 16) != hipSuccess) return -1;
-    const unsigned zero = 0;
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(vg_tr_cnt), &zero, sizeof(zero));
-    return (int)n;
+// one fixed slot per stamp id: a plain store, nothing to wait for (an atomic slot counter costs the stamping
+// thread a memory round trip per stamp and stretches the phases it is meant to measure)
+static __device__ unsigned long long vg_tr_buf[1024];
+#define VG_T(cond, id) do { if (threadIdx.x == 0 && (cond)) vg_tr_buf[(id) & 1023] = wall_clock64(); } while (0)
+static int vg_trace_take(unsigned long long* host, int cap) {      // (id, stamp) pairs of this translation unit; clears them
+    static unsigned long long tmp[1024];
+    if (hipMemcpyFromSymbol(tmp, HIP_SYMBOL(vg_tr_buf), sizeof(tmp)) != hipSuccess) return -1;
+    int n = 0;
+    for (int i = 0; i < 1024 && n < cap; ++i)
+        if (tmp[i]) { host[2 * n] = (unsigned long long)i; host[2 * n + 1] = tmp[i]; ++n; }
+    for (int i = 0; i < 1024; ++i) tmp[i] = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(vg_tr_buf), tmp, sizeof(tmp));
+    return n;
 }
 int vg_trace_take_gp(unsigned long long* host, int cap);
 int vg_trace_take_lik(unsigned long long* host, int cap);
