@@ -451,7 +451,7 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
             const vg_float3 z = vg_make3(gs(fo + 6), gs(fo + 7), gs(fo + 8)), org = vg_make3(gs(fo + 9), gs(fo + 10), gs(fo + 11));
             const vg_float3 oxF = vg_cross(org, Fs);
             const float val = vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z));
-            if ((i - 1) % LPC == sub && live) G[base + (size_t)(i - 1) * N] = scale * val * dgdf[(i - 1) * CPB];
+            if ((i - 1) % LPC == sub && live) vg_stream(G + base + (size_t)(i - 1) * N, scale * val * dgdf[(i - 1) * CPB]);
         }
     }
     if (live && sub == 0) logp[((size_t)pb * S + s) * N + n] = lp;

@@ -105,13 +105,13 @@ __device__ __forceinline__ void rng_basis_body(const RngArgs& a, int bx, int p) 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t e = 4u * c + k;
-                if (e >= e0 && e < e0 + (uint32_t)D) om[e - e0] = vg_lane(v, k) * sc;
+                if (e >= e0 && e < e0 + (uint32_t)D) vg_stream(om + (e - e0), vg_lane(v, k) * sc);
             }
         }
     }
     uint4 r = vg_philox(make_uint4(lb >> 2, VG_STREAM_BETA, 0u, 0u), key);
     uint32_t rb = (lb & 3u) == 0 ? r.x : (lb & 3u) == 1 ? r.y : (lb & 3u) == 2 ? r.z : r.w;
-    a.beta[(size_t)p * L * B + lb] = 6.283185307179586f * vg_u01(rb);
+    vg_stream(a.beta + (size_t)p * L * B + lb, 6.283185307179586f * vg_u01(rb));
 }
 
 // w [P, nW]: counter i of the stream yields global elements 4i..4i+3 (wOff is a multiple of 4);
@@ -124,7 +124,7 @@ __device__ __forceinline__ void rng_normals_body(const RngArgs& a, int bx, int p
     const uint2 key = vg_key(a.seed, a.problem_base + p, rng_step(a));
     if (c < cW) {
         const float4 v = vg_normal4((a.wOff >> 2) + c, VG_STREAM_W, key);
-        *reinterpret_cast<float4*>(a.w + (size_t)p * nW + 4u * c) = v;
+        vg_stream(reinterpret_cast<float4*>(a.w + (size_t)p * nW + 4u * c), v);
         VG_T(bx == 0 && p == 0, 321);
         VG_T(c + kBlock >= cW && p == 0, 325);
         return;
@@ -132,7 +132,7 @@ __device__ __forceinline__ void rng_normals_body(const RngArgs& a, int bx, int p
     c -= cW;
     const bool second = c >= nE;
     if (second) c -= nE;
-    (second ? a.eps2 : a.eps)[(size_t)p * nE + c] = vg_normal1(a.eOff + c, second ? VG_STREAM_EPS2 : VG_STREAM_EPS, key);
+    vg_stream((second ? a.eps2 : a.eps) + (size_t)p * nE + c, vg_normal1(a.eOff + c, second ? VG_STREAM_EPS2 : VG_STREAM_EPS, key));
 }
 
 __global__ __launch_bounds__(kBlock) void rng_basis_kernel(RngArgs a) { rng_basis_body(a, blockIdx.x, blockIdx.y); }
@@ -251,14 +251,14 @@ __device__ __forceinline__ void paths_fwd_body(const PathArgs& a, float* smf, in
         for (int k = 0; k <= mi; ++k) u = fmaf(Cs[mi * ld + k], es[sl * Mz + k], u);
         const float r = u - f0s[sl * J + N + mi] - a.sqrt_jitter * e2s[e];
         rs[e] = r;
-        if (s < S) a.R[(((size_t)p * S + s) * L + l) * Mz + mi] = r;
+        if (s < S) vg_stream(a.R + (((size_t)p * S + s) * L + l) * Mz + mi, r);
     }
     __syncthreads();
     for (int e = tid; e < SC * N; e += nt) {
         const int sl = vg_div(e, iN), n = e - sl * N, s = s_base + sl;
         float v = f0s[sl * J + n];
         for (int k = 0; k < Mz; ++k) v = fmaf(ATs[k * N + n], rs[sl * Mz + k], v);
-        if (s < S) a.f[(((size_t)p * S + s) * L + l) * N + n] = v;
+        if (s < S) vg_stream(a.f + (((size_t)p * S + s) * L + l) * N + n, v);
     }
     VG_T(ch == 0 && l == 0 && p == 0, 302);
     VG_T(ch == a.NC - 1 && l == L - 1 && p == 0, 305);
@@ -382,14 +382,14 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
     for (int mi = tid; mi < Mz; mi += nt) {
         float t = 0.f;
         for (int sl = 0; sl < SC; ++sl) t += dRs[sl * Mz + mi];
-        out[mi] = t;
+        vg_stream(out + mi, t);
     }
     float* oC = out + Mz;
     for (int e = tid; e < Mz * Mz; e += nt) {
         const int mi = vg_div(e, iMz), k = e - mi * Mz;
         float t = 0.f;
         for (int sl = 0; sl < SC; ++sl) t = fmaf(dRs[sl * Mz + mi], Es[sl * Mz + k], t);
-        oC[e] = t;
+        vg_stream(oC + e, t);
     }
     se = vg_wave_sum(se); sv = vg_wave_sum(sv); sr = vg_wave_sum(sr);
     if ((tid & 63) == 0) { red[0][tid >> 6] = se; red[1][tid >> 6] = sv; red[2][tid >> 6] = sr; }
@@ -1040,8 +1040,8 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
         if (n >= N) continue;
         const double s = a.want_dell ? dot4(yr + r * Mz, 1, Ki + m, ld, Mz) : 0.0;
         const float av = av_keep[cnt < 2 ? cnt : 1];
-        A4[(size_t)n * Mz + m] = make_float4((float)ar[e], (float)s, av, 0.f);
-        AT[(size_t)m * N + n] = (float)ar[e];
+        vg_stream(A4 + (size_t)n * Mz + m, make_float4((float)ar[e], (float)s, av, 0.f));
+        vg_stream(AT + (size_t)m * N + n, (float)ar[e]);
     }
     VG_T(tile == 0 && l == 0 && p == 0, 231);
 }
@@ -1101,8 +1101,10 @@ __device__ __forceinline__ void features_body(const FeatArgs& a, int bx, int by,
         // v_sin/v_cos take revolutions: reduce with fract (argument is a few tens of radians at most)
         const float rev = __builtin_amdgcn_fractf((proj * inv_ell + bt) * 0.15915494309189535f);
         const size_t o = (pl * J + j) * B + b;
-        Phi[o] = c * __builtin_amdgcn_cosf(rev);
-        if (dPhi) dPhi[o] = c * __builtin_amdgcn_sinf(rev) * proj * inv_ell * inv_ell;
+        // streamed past the caches: 7.6 MB per problem that the next launch reads from another XCD anyway, and
+        // dirty lines left in L2 lengthen the hand-over to that launch
+        vg_stream(Phi + o, c * __builtin_amdgcn_cosf(rev));
+        if (dPhi) vg_stream(dPhi + o, c * __builtin_amdgcn_sinf(rev) * proj * inv_ell * inv_ell);
     }
     VG_T(bx == 0 && by == 0 && bz == 0, 131);
     VG_T(bx == 0 && j1 == J && bz == L - 1, 135);
@@ -1217,7 +1219,7 @@ __device__ __forceinline__ void prior_gemm_body(const GemmArgs& a, int bx, int b
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int s = s0 + g * 4 + q;
-            if (s < S) Out[(((size_t)p * S + s) * L + l) * J + jc] = acc[t][q];
+            if (s < S) vg_stream(Out + (((size_t)p * S + s) * L + l) * J + jc, acc[t][q]);
         }
     }
     VG_T(bx == 0 && by == 0 && bz == 0, 242);
@@ -1291,7 +1293,7 @@ __device__ __forceinline__ void prior_gemm_lds_body(const GemmArgs& a, float* ld
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int s = sw + g * 4 + q;
-            if (s < S) Out[(((size_t)p * S + s) * L + l) * J + jc] = acc[t][q];
+            if (s < S) vg_stream(Out + (((size_t)p * S + s) * L + l) * J + jc, acc[t][q]);
         }
     }
     VG_T(bx == 0 && by == 0 && bz == 0, 242);
@@ -1391,7 +1393,7 @@ __global__ __launch_bounds__(kBlock) void prior_gemm_tiled_kernel(int S, int L, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int srow = s0 + wave * 16 + g * 4 + q;
-            if (srow < S) Out[(((size_t)p * S + srow) * L + l) * J + jc] = acc[t][q];
+            if (srow < S) vg_stream(Out + (((size_t)p * S + srow) * L + l) * J + jc, acc[t][q]);
         }
     }
 }

@@ -33,6 +33,16 @@ __device__ __forceinline__ double vg_wave_sum(double v) {
     return v;
 }
 
+// Streaming store (nontemporal): bulk outputs that the NEXT launch reads -- from another XCD, so not through this L2
+// anyway -- leave no dirty lines behind; the write-back of dirty L2 lines at the end of a kernel was measured to add
+// ~1 us to the hand-over after a launch that wrote 7.6 MB.
+template <typename T>
+__device__ __forceinline__ void vg_stream(T* p, T v) { __builtin_nontemporal_store(v, p); }
+typedef float vg_f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void vg_stream(float4* p, float4 v) {
+    __builtin_nontemporal_store((vg_f32x4_t){v.x, v.y, v.z, v.w}, reinterpret_cast<vg_f32x4_t*>(p));
+}
+
 // ---- global -> LDS staging without registers (global_load_lds, gfx950) ----------------------------
 // A rolled `lds[e] = g[e]` loop compiles to load / wait / store per iteration: one memory round trip per
 // 256 elements (measured 10 us for the 74 KB of the reverse pass; 3 us with the form below).  Here every
