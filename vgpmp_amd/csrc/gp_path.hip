@@ -462,7 +462,9 @@ struct HyperState { double raw_ell, raw_var, m_ell, v_ell, m_var, v_var, g_ell, 
 
 // The three sums over the sample chunks are loaded in ONE round (16 chunks x 3 values per pass, clamped + masked)
 // and added in the order of sum_chunks().
-__device__ __forceinline__ HyperState hyper_update(const HyperArgs& h, size_t pl, bool own_lr = false, double lr_own = 0.0) {
+// `which`: 1 = lengthscale, 2 = variance, 3 = both (the two halves are independent: cov_a runs them on two waves)
+__device__ __forceinline__ HyperState hyper_update(const HyperArgs& h, size_t pl, bool own_lr = false, double lr_own = 0.0,
+                                                   int which = 3) {
     const float* part = h.part + pl * h.NC * h.part_len + (h.Mz + h.Mz * h.Mz);
     // every operand requested in one go, unconditionally (null Adam pointers fall back to a valid address): the
     // prologue form sits on the critical chain and a second dependent round trip costs ~2 us
@@ -495,6 +497,7 @@ __device__ __forceinline__ HyperState hyper_update(const HyperArgs& h, size_t pl
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
+            if (!(which & (j == 0 ? 1 : 2))) continue;
             double d[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) d[k] = c0 + k < h.NC ? (double)v[k][j] : 0.0;
@@ -502,12 +505,15 @@ __device__ __forceinline__ HyperState hyper_update(const HyperArgs& h, size_t pl
             s3[j] += ((d[8] + d[9]) + (d[10] + d[11])) + ((d[12] + d[13]) + (d[14] + d[15]));
         }
     }
-    const double s_ell = h.want_dell ? s3[0] : 0.0;
-    o.g_ell = (s_ell + h.kl_scale * gkl_ell) * sig_ell;
-    o.g_var = (s3[1] + s3[2] / (2.0 * var) + h.kl_scale * gkl_var) * sig_var;
-    if (h.do_adam) {
-        if (h.trainable & VGPMP_TRAIN_LENGTHSCALES) adam_update(&o.raw_ell, &o.m_ell, &o.v_ell, o.g_ell, lr_t);
-        if (h.trainable & VGPMP_TRAIN_KERNEL_VARIANCE) adam_update(&o.raw_var, &o.m_var, &o.v_var, o.g_var, lr_t);
+    o.g_ell = o.g_var = 0.0;
+    if (which & 1) {
+        const double s_ell = h.want_dell ? s3[0] : 0.0;
+        o.g_ell = (s_ell + h.kl_scale * gkl_ell) * sig_ell;
+        if (h.do_adam && (h.trainable & VGPMP_TRAIN_LENGTHSCALES)) adam_update(&o.raw_ell, &o.m_ell, &o.v_ell, o.g_ell, lr_t);
+    }
+    if (which & 2) {
+        o.g_var = (s3[1] + s3[2] / (2.0 * var) + h.kl_scale * gkl_var) * sig_var;
+        if (h.do_adam && (h.trainable & VGPMP_TRAIN_KERNEL_VARIANCE)) adam_update(&o.raw_var, &o.m_var, &o.v_var, o.g_var, lr_t);
     }
     return o;
 }
@@ -696,21 +702,21 @@ __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, 
     double* Sc = Li + Mp * ld;       // 2 x (Mp x ld) scratch: augmented matrix of the elimination
     double* zs = Sc + 2 * Mp * ld;   // [Mp]
     double* rsd = zs + Mp;           // [Mp]
-    if (tid == 0) {
-        double re, rv;
+    // the latent's two scalars, each a chain of float64 exp / log / sqrt / division (~1 us): lengthscale on the first
+    // lane of wave 0, variance on the first lane of wave 1 (different waves run side by side, lanes of one do not)
+    if (tid == 0 || tid == VG_WAVE) {
+        const bool is_ell = tid == 0;
+        double raw;
         if (a.prologue) {
-            const HyperState o = hyper_update(a.hy, pl);
-            a.hy.g_ell[pl] = o.g_ell; a.hy.g_var[pl] = o.g_var;
+            const HyperState o = hyper_update(a.hy, pl, false, 0.0, is_ell ? 1 : 2);
             double* nx = a.hy.next + 6 * pl;
-            nx[0] = o.raw_ell; nx[1] = o.raw_var; nx[2] = o.m_ell; nx[3] = o.v_ell; nx[4] = o.m_var; nx[5] = o.v_var;
-            re = o.raw_ell; rv = o.raw_var;
+            if (is_ell) { a.hy.g_ell[pl] = o.g_ell; nx[0] = o.raw_ell; nx[2] = o.m_ell; nx[3] = o.v_ell; raw = o.raw_ell; }
+            else { a.hy.g_var[pl] = o.g_var; nx[1] = o.raw_var; nx[4] = o.m_var; nx[5] = o.v_var; raw = o.raw_var; }
         } else {
-            re = a.raw_ell[pl]; rv = a.raw_var[pl];
+            raw = is_ell ? a.raw_ell[pl] : a.raw_var[pl];
         }
-        scal[0] = softplus_d(re);
-        scal[1] = kVarFloor + softplus_d(rv);
-        a.ws.sig_ell[pl] = sigmoid_d(re);
-        a.ws.sig_var[pl] = sigmoid_d(rv);
+        if (is_ell) { scal[0] = softplus_d(raw); a.ws.sig_ell[pl] = sigmoid_d(raw); }
+        else { scal[1] = kVarFloor + softplus_d(raw); a.ws.sig_var[pl] = sigmoid_d(raw); }
     }
     for (int e = tid; e < 2 * Mp * ld; e += nt) sm[e] = 0.0;
     for (int i = tid; i < Mz; i += nt) zs[i] = a.Zy[(size_t)i * D + l];
