@@ -726,13 +726,18 @@ __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, 
     // Kuu and dKuu/dell share the exponential; symmetric: evaluate the lower triangle only
     double* Kg = a.ws.Ks64 + pl * Mz * Mz;
     double* Kdg = a.ws.Kd_ell + pl * Mz * Mz;
-    for (int e = tid; e < Mz * Mz; e += nt) {
-        int i = vg_div(e, iMz), j = e - i * Mz;
-        if (j > i) continue;
-        double r = fabs(zs[i] - zs[j]) / ell;
+    // lower triangle only, in triangular order (e -> row i, column j <= i): Mz (Mz + 1) / 2 evaluations of the exponential
+    // spread evenly over the workgroup; one division per thread instead of two per element
+    const double inv_ell = 1.0 / ell, c3 = 5.0 / (3.0 * ell);
+    for (int e = tid; e < Mz * (Mz + 1) / 2; e += nt) {
+        int i = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        if (i * (i + 1) / 2 > e) --i;                    // float rounding at the row boundaries
+        if ((i + 1) * (i + 2) / 2 <= e) ++i;
+        const int j = e - i * (i + 1) / 2;
+        double r = fabs(zs[i] - zs[j]) * inv_ell;
         double ex = exp(-kSqrt5 * r);
         double k = var * (1.0 + kSqrt5 * r + (5.0 / 3.0) * r * r) * ex;
-        double dk = var * ex * (5.0 * r * r / (3.0 * ell)) * (1.0 + kSqrt5 * r);
+        double dk = var * ex * (r * r * c3) * (1.0 + kSqrt5 * r);
         La[i * ld + j] = k + (i == j ? jit : 0.0);
         Kg[(size_t)i * Mz + j] = k;
         Kdg[(size_t)i * Mz + j] = dk;
