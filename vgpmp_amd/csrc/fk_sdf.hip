@@ -444,13 +444,15 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
         const bool craig = rb->craig != 0;
         vg_float3 Fs = vg_make3(0.f, 0.f, 0.f), Ms = vg_make3(0.f, 0.f, 0.f);
         for (int i = D; i >= 1; --i) {
+            // the torque is linear in (F, M): every lane forms it from the sums over ITS spheres, and only that one
+            // number is added across the lanes (3 shuffles per joint instead of 18)
             const int o = 6 * i;
-            Fs = vg_make3(Fs.x + quad_sum<LPC>(ms(o)), Fs.y + quad_sum<LPC>(ms(o + 1)), Fs.z + quad_sum<LPC>(ms(o + 2)));
-            Ms = vg_make3(Ms.x + quad_sum<LPC>(ms(o + 3)), Ms.y + quad_sum<LPC>(ms(o + 4)), Ms.z + quad_sum<LPC>(ms(o + 5)));
+            Fs = vg_make3(Fs.x + ms(o), Fs.y + ms(o + 1), Fs.z + ms(o + 2));
+            Ms = vg_make3(Ms.x + ms(o + 3), Ms.y + ms(o + 4), Ms.z + ms(o + 5));
             const int fo = 2 * D + 12 * (craig ? i : i - 1);
             const vg_float3 z = vg_make3(gs(fo + 6), gs(fo + 7), gs(fo + 8)), org = vg_make3(gs(fo + 9), gs(fo + 10), gs(fo + 11));
             const vg_float3 oxF = vg_cross(org, Fs);
-            const float val = vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z));
+            const float val = quad_sum<LPC>(vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)));
             if ((i - 1) % LPC == sub && live) vg_stream(G + base + (size_t)(i - 1) * N, scale * val * dgdf[(i - 1) * CPB]);
         }
     }
