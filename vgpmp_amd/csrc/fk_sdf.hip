@@ -126,6 +126,47 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v;
 }
 
+// DPP row shift: lane i reads lane i - R of its row of 16 (lanes without a source read 0)
+template <int R>
+__device__ __forceinline__ float row_shr(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + R, 0xF, 0xF, false));
+}
+template <int R>
+__device__ __forceinline__ Frame frame_shr(const Frame& a) {
+    Frame o;
+    o.cx = vg_make3(row_shr<R>(a.cx.x), row_shr<R>(a.cx.y), row_shr<R>(a.cx.z));
+    o.cy = vg_make3(row_shr<R>(a.cy.x), row_shr<R>(a.cy.y), row_shr<R>(a.cy.z));
+    o.cz = vg_make3(row_shr<R>(a.cz.x), row_shr<R>(a.cz.y), row_shr<R>(a.cz.z));
+    o.t = vg_make3(row_shr<R>(a.t.x), row_shr<R>(a.t.y), row_shr<R>(a.t.z));
+    return o;
+}
+// rigid transforms: (A B)(p) = A(B(p))
+__device__ __forceinline__ Frame frame_mul(const Frame& a, const Frame& b) {
+    Frame o;
+    o.cx = axpy(b.cx.x, a.cx, lin2(b.cx.y, a.cy, b.cx.z, a.cz));
+    o.cy = axpy(b.cy.x, a.cx, lin2(b.cy.y, a.cy, b.cy.z, a.cz));
+    o.cz = axpy(b.cz.x, a.cx, lin2(b.cz.y, a.cy, b.cz.z, a.cz));
+    o.t = axpy(b.t.x, a.cx, axpy(b.t.y, a.cy, axpy(b.t.z, a.cz, a.t)));
+    return o;
+}
+// the DH link transform of joint j by itself (dh_apply on the identity, products with 0 / 1 folded)
+__device__ __forceinline__ Frame dh_link(const vgpmp_robot* __restrict__ rb, int j, float st, float ct) {
+    const float ca = rb->cos_alpha[j], sa = rb->sin_alpha[j], d = rb->dh_d[j], a = rb->dh_a[j];
+    Frame o;
+    if (rb->craig) {
+        o.cx = vg_make3(ct, st * ca, st * sa);
+        o.cy = vg_make3(-st, ct * ca, ct * sa);
+        o.cz = vg_make3(0.f, -sa, ca);
+        o.t = vg_make3(a, -d * sa, d * ca);
+    } else {
+        o.cx = vg_make3(ct, st, 0.f);
+        o.cy = vg_make3(-st * ca, ct * ca, sa);
+        o.cz = vg_make3(st * sa, -ct * sa, ca);
+        o.t = vg_make3(a * ct, a * st, d);
+    }
+    return o;
+}
+
 __device__ __forceinline__ void lik_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -342,6 +383,7 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
     const size_t base = ((size_t)pb * S + s) * L * N + n;
     // this lane's joints: sub, sub + 4, ... (at most 4 of them)
     float fv[VGPMP_MAX_DOF / LPC];
+    float st0 = 0.f, ct0 = 1.f, dg0 = 0.f;               // joint `sub`: sin, cos, d g / d f
 #pragma unroll
     for (int k = 0; k < VGPMP_MAX_DOF / LPC; ++k) fv[k] = f[base + (size_t)min(sub + LPC * k, L - 1) * N];
     static_assert(VGPMP_MAX_DOF % LPC == 0, "joints are dealt to the lanes of a group");
@@ -365,12 +407,47 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
             float st, ct;
             sincosf(fmaf(span, sg, rb->low[j]) + rb->twist[j], &st, &ct);
             gs(j) = st; gs(D + j) = ct;
+            if (k == 0) { st0 = st; ct0 = ct; dg0 = span * sg * (1.0f - sg); }
         }
     }
     for (int k = 0; k < wide_lane_slots(D); ++k) ms(k) = 0.f;
+    auto put_frame = [&](int i, const Frame& T) {
+        const int o = 2 * D + 12 * i;
+        gs(o) = T.cx.x; gs(o + 1) = T.cx.y; gs(o + 2) = T.cx.z;
+        gs(o + 3) = T.cy.x; gs(o + 4) = T.cy.y; gs(o + 5) = T.cy.z;
+        gs(o + 6) = T.cz.x; gs(o + 7) = T.cz.y; gs(o + 8) = T.cz.z;
+        gs(o + 9) = T.t.x; gs(o + 10) = T.t.y; gs(o + 11) = T.t.z;
+    };
+    // the chain as a prefix product over the lanes of the group: lane j owns joint j, three rounds of
+    // (row shift, 3x4 product) instead of dof dependent products on every lane
+    const bool scan = LPC == 8 && L <= LPC;
+    if (scan) {
+        Frame Pm;
+        if (sub < L) {
+            Pm = dh_link(rb, sub, st0, ct0);
+        } else {
+            Pm.cx = vg_make3(1.f, 0.f, 0.f); Pm.cy = vg_make3(0.f, 1.f, 0.f); Pm.cz = vg_make3(0.f, 0.f, 1.f);
+            Pm.t = vg_make3(0.f, 0.f, 0.f);
+        }
+        {
+            const Frame Lf = frame_shr<1>(Pm);
+            if (sub >= 1) Pm = frame_mul(Lf, Pm);
+        }
+        {
+            const Frame Lf = frame_shr<2>(Pm);
+            if (sub >= 2) Pm = frame_mul(Lf, Pm);
+        }
+        {
+            const Frame Lf = frame_shr<4>(Pm);
+            if (sub >= 4) Pm = frame_mul(Lf, Pm);
+        }
+        const Frame B = base_frame(rb);
+        if (sub < L) put_frame(sub + 1, frame_mul(B, Pm));
+        if (sub == (L < LPC ? L : 0)) put_frame(0, B);
+    }
     lik_wave_sync();
-    // ---- every frame of the chain, frame i stored by lane i % 4
-    {
+    // ---- every frame of the chain, frame i stored by lane i % LPC
+    if (!scan) {
         Frame T = base_frame(rb);
         for (int i = 0; i <= D; ++i) {
             if (i > 0) dh_apply(rb, i - 1, gs(i - 1), gs(D + i - 1), T);
@@ -440,7 +517,34 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
     const float lp = -0.5f * acc;
     // ---- joints, last to first: joint i moves every sphere on frames >= i; it turns about z of frame i
     //      (Craig) or of frame i-1 (classic)
-    {
+    if (scan) {
+        // every lane forms all torques of ITS spheres (no lane crossing in the suffix sums), then one
+        // transposing reduction leaves the total of joint j on lane j: 7 shuffles in 3 rounds
+        const bool craig = rb->craig != 0;
+        vg_float3 Fs = vg_make3(0.f, 0.f, 0.f), Ms = vg_make3(0.f, 0.f, 0.f);
+        float tq[8];
+#pragma unroll
+        for (int i = 8; i >= 1; --i) {
+            const bool on = i <= L;
+            const int ii = on ? i : L;
+            const int o = 6 * ii;
+            const float w = on ? 1.f : 0.f;
+            Fs = vg_make3(fmaf(w, ms(o), Fs.x), fmaf(w, ms(o + 1), Fs.y), fmaf(w, ms(o + 2), Fs.z));
+            Ms = vg_make3(fmaf(w, ms(o + 3), Ms.x), fmaf(w, ms(o + 4), Ms.y), fmaf(w, ms(o + 5), Ms.z));
+            const int fo = 2 * D + 12 * (craig ? ii : ii - 1);
+            const vg_float3 z = vg_make3(gs(fo + 6), gs(fo + 7), gs(fo + 8)), org = vg_make3(gs(fo + 9), gs(fo + 10), gs(fo + 11));
+            const vg_float3 oxF = vg_cross(org, Fs);
+            tq[i - 1] = w * vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z));
+        }
+        float t4[4], t2[2];
+        const bool h4 = (sub & 4) != 0, h2 = (sub & 2) != 0, h1 = (sub & 1) != 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t4[k] = (h4 ? tq[k + 4] : tq[k]) + __shfl_xor(h4 ? tq[k] : tq[k + 4], 4, VG_WAVE);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) t2[k] = (h2 ? t4[k + 2] : t4[k]) + __shfl_xor(h2 ? t4[k] : t4[k + 2], 2, VG_WAVE);
+        const float val = (h1 ? t2[1] : t2[0]) + __shfl_xor(h1 ? t2[0] : t2[1], 1, VG_WAVE);
+        if (sub < L && live) vg_stream(G + base + (size_t)sub * N, scale * val * dg0);
+    } else {
         const bool craig = rb->craig != 0;
         vg_float3 Fs = vg_make3(0.f, 0.f, 0.f), Ms = vg_make3(0.f, 0.f, 0.f);
         for (int i = D; i >= 1; --i) {
