@@ -137,6 +137,7 @@ typedef struct vgpmp_outputs {
 #define VGPMP_GEN_NOISE 8       /* draw the noise with the device Philox generator first     */
 #define VGPMP_NO_FUSE 16        /* measurement: one launch per kernel even for small batches  */
 #define VGPMP_GEMM_DIRECT 32    /* measurement: stage-2 GEMM role with operands straight from L2 */
+#define VGPMP_NO_SPLIT 64       /* measurement: reverse path pass on one workgroup per (chunk, latent) */
 
 /* ---- set-up -------------------------------------------------------------------------------- */
 

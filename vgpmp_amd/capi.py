@@ -16,6 +16,7 @@ import numpy as np
 MAX_DOF, MAX_SPHERES, MAX_MZ = 16, 64, 48
 TRAIN_Q_MU, TRAIN_Q_SQRT, TRAIN_LENGTHSCALES, TRAIN_KERNEL_VARIANCE = 1, 2, 4, 8
 DO_FORWARD, DO_BACKWARD, DO_ADAM, GEN_NOISE, NO_FUSE = 1, 2, 4, 8, 16
+GEMM_DIRECT, NO_SPLIT = 32, 64
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvgpmp_hip.so"
 

@@ -39,7 +39,7 @@ inline int vg_j(const vgpmp_dims* d) { return d->N + d->M + 2; }
 inline int vg_chunks(const vgpmp_dims* d) { return (d->S + vg_sc(d) - 1) / vg_sc(d); }
 inline size_t vg_part_len(const vgpmp_dims* d) {
     size_t mz = (size_t)vg_mz(d);
-    return mz + mz * mz + 4;
+    return mz + mz * mz + 8;      // dm, dC, two sets of {s_ell, s_var, s_rff, -}
 }
 
 int vg_check_dims(const vgpmp_dims* d);

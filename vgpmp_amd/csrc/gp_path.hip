@@ -399,9 +399,160 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
         for (int k = 0; k < (int)(nt >> 6); ++k) { t0 += red[0][k]; t1 += red[1][k]; t2 += red[2][k]; }
         float* os = oC + (size_t)Mz * Mz;
         os[0] = t0; os[1] = t1; os[2] = t2; os[3] = 0.f;
+        os[4] = 0.f; os[5] = 0.f; os[6] = 0.f; os[7] = 0.f;      // second set: paths_bwd_split only
     }
     VG_T(ch == 0 && l == 0 && p == 0, 503);
     VG_T(ch == a.NC - 1 && l == L - 1 && p == 0, 505);
+}
+
+// The same reverse pass on TWO workgroups per (sample chunk, latent) for launches that leave half the chip idle:
+// a workgroup's time here is the ~100 KB it stages at the ~25 KB/us one CU can pull, and everything downstream is
+// linear in G, so the work splits by COLUMNS of the inducing axis: half h owns columns [h Mz/2, (h+1) Mz/2) of
+// A / dR / dm / dC (disjoint outputs, no extra partials) and the time points [n0, n0 + nx) of the two prior-draw dot
+// products (a second set of the three scalars, added by hyper_update).  Two threads per (sample, column) halve the
+// N-long chains.  Needs Mz % 8 == 0, N % 4 == 0 (16-byte rows), SK > 1.
+template <int SK>
+__global__ __launch_bounds__(kBlock) void paths_bwd_split(PathArgs a) {
+    constexpr int SC = 8;
+    extern __shared__ float smf[];
+    __shared__ float red[3][kBlock / VG_WAVE];
+    const int ch = blockIdx.x >> 1, half = blockIdx.x & 1, l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
+    const int S = a.S, N = a.N, Mz = a.Mz, L = a.L, J = N + Mz;
+    const int Mh = Mz >> 1, m0 = half * Mh;
+    const int Nh = (N >> 1) & ~3, n0 = half ? Nh : 0, nx = half ? N - Nh : Nh;
+    const float iMh = 1.0f / (float)Mh, iMz = 1.0f / (float)Mz;
+    const size_t pl = (size_t)p * L + l;
+    float* cur = smf;
+    auto take = [&](int n) { float* q = cur; cur += (n + 3) & ~3; return q; };
+    float4* A4s = reinterpret_cast<float4*>(take(4 * N * Mh));      // [N][Mh] {A, A_ell, A_var, -}
+    float* Ces = take(2 * Mz * Mh);                  // [Mz][Mh] columns of (dC/dell)^T, then of (dC/dvar)^T
+    float* Cvs = Ces + Mz * Mh;
+    float* Gs = take(SC * N);                        // [SC][N]
+    float* Rs = take(SC * Mh);                       // [SC][Mh]
+    float* Es = take(SC * Mz);                       // [SC][Mz]
+    float* dRs = take(SC * Mh);                      // [SC][Mh]
+    float* fx = take(2 * SC * nx);                   // [SC][nx] prior draws at the time points, then their d/dell
+    float* hx = fx + SC * nx;
+    float* fz = take(2 * SC * Mh);                   // [SC][Mh] ... at the inducing points
+    float* hz = fz + SC * Mh;
+    float* rawx = take(2 * SK * SC * nx);            // the split-K slabs as they arrive
+    float* rawz = take(2 * SK * SC * Mh);
+    const int s_base = ch * SC;
+    const bool dell = a.want_dell != 0;
+    VG_T(ch == 0 && half == 0 && l == 0 && p == 0, 500);
+    {
+        const float* A4g = reinterpret_cast<const float*>(a.A4 + pl * N * Mz);
+        vg_stage_rows(A4s, N, 4 * Mh, tid, nt, [&](int r) -> const float* { return A4g + ((size_t)r * Mz + m0) * 4; });
+        const float* Ce = a.CT_ell + pl * Mz * Mz + m0;
+        const float* Cv = a.CT_var + pl * Mz * Mz + m0;
+        vg_stage_rows(Ces, 2 * Mz, Mh, tid, nt, [&](int r) -> const float* {
+            return r < Mz ? (dell ? Ce + (size_t)r * Mz : nullptr) : Cv + (size_t)(r - Mz) * Mz;
+        });
+        vg_stage_rows(Gs, SC, N, tid, nt, [&](int r) -> const float* {
+            const int s = s_base + r;
+            return s < S ? a.G + (((size_t)p * S + s) * L + l) * N : nullptr;              // zero beyond S
+        });
+        vg_stage_rows(Rs, SC, Mh, tid, nt, [&](int r) -> const float* {
+            const int s = s_base + r;
+            return s < S ? a.R + (((size_t)p * S + s) * L + l) * Mz + m0 : nullptr;
+        });
+        vg_stage_words(Es, SC * Mz, tid, nt, [&](int i) -> const void* {
+            const int sl = vg_div(i, iMz), mi = i - sl * Mz, s = s_base + sl;
+            return s < S ? a.eps + (((size_t)p * S + s) * Mz + mi) * L + l : nullptr;
+        });
+        const int nrow = (dell ? 2 : 1) * SK * SC;
+        auto slab_row = [&](int r) -> const float* {
+            const int second = r >= SK * SC, rr = second ? r - SK * SC : r;
+            const int k = rr / SC, s = min(s_base + (rr - k * SC), S - 1);
+            return (second ? a.H : a.F0) + (size_t)k * a.slab + (((size_t)p * S + s) * L + l) * J;
+        };
+        vg_stage_rows(rawx, nrow, nx, tid, nt, [&](int r) -> const float* { return slab_row(r) + n0; });
+        vg_stage_rows(rawz, nrow, Mh, tid, nt, [&](int r) -> const float* { return slab_row(r) + N + m0; });
+    }
+    VG_T(ch == 0 && half == 0 && l == 0 && p == 0, 506);
+    vg_dma_wait();
+    __syncthreads();
+    VG_T(ch == 0 && half == 0 && l == 0 && p == 0, 507);
+    {
+        const int nsx = SK * SC * nx, nsz = SK * SC * Mh;
+        for (int e = tid; e < SC * nx; e += nt) {
+            fx[e] = sum_slabs_lds<SK>(rawx, e, SC * nx);
+            hx[e] = dell ? sum_slabs_lds<SK>(rawx + nsx, e, SC * nx) : 0.f;
+        }
+        for (int e = tid; e < SC * Mh; e += nt) {
+            fz[e] = sum_slabs_lds<SK>(rawz, e, SC * Mh);
+            hz[e] = dell ? sum_slabs_lds<SK>(rawz + nsz, e, SC * Mh) : 0.f;
+        }
+        __syncthreads();
+    }
+    VG_T(ch == 0 && half == 0 && l == 0 && p == 0, 501);
+    VG_STOP(a, 1);
+    float se = 0.f, sv = 0.f, sr = 0.f;
+    const int par = tid & 1;
+    for (int it = tid >> 1; it < SC * Mh; it += nt >> 1) {      // uniform trip count for the two lanes of a pair
+        const int sl = vg_div(it, iMh), ml = it - sl * Mh, mi = m0 + ml;
+        const float* g = Gs + sl * N;
+        float d = 0.f, de = 0.f, dv = 0.f;
+#pragma unroll 5
+        for (int n = par; n < N; n += 2) {
+            const float4 av = A4s[n * Mh + ml];
+            const float gv = g[n];
+            d = fmaf(gv, av.x, d);
+            de = fmaf(gv, av.y, de);
+            dv = fmaf(gv, av.z, dv);
+        }
+        float ue = 0.f, uv = 0.f;
+        for (int k = par; k <= mi; k += 2) {
+            const float ev = Es[sl * Mz + k];
+            uv = fmaf(Cvs[k * Mh + ml], ev, uv);
+            ue = fmaf(Ces[k * Mh + ml], ev, ue);
+        }
+        d += __shfl_xor(d, 1, VG_WAVE); de += __shfl_xor(de, 1, VG_WAVE); dv += __shfl_xor(dv, 1, VG_WAVE);
+        ue += __shfl_xor(ue, 1, VG_WAVE); uv += __shfl_xor(uv, 1, VG_WAVE);
+        if (par == 0) {
+            dRs[it] = d;
+            const float rv = Rs[it];
+            sv += rv * dv + d * uv;
+            se += rv * de + d * ue - d * hz[it];
+            sr -= d * fz[it];
+        }
+    }
+    {
+        const float inx = 1.0f / (float)nx;
+        for (int e = tid; e < SC * nx; e += nt) {
+            const int sl = vg_div(e, inx), j = e - sl * nx;
+            const float gv = Gs[sl * N + n0 + j];             // zero for samples beyond S
+            sr = fmaf(gv, fx[e], sr);
+            se = fmaf(gv, hx[e], se);
+        }
+    }
+    __syncthreads();
+    VG_T(ch == 0 && half == 0 && l == 0 && p == 0, 502);
+    VG_STOP(a, 3);
+    float* out = a.part + (pl * a.NC + ch) * a.part_len;
+    for (int ml = tid; ml < Mh; ml += nt) {
+        float t = 0.f;
+        for (int sl = 0; sl < SC; ++sl) t += dRs[sl * Mh + ml];
+        vg_stream(out + m0 + ml, t);
+    }
+    float* oC = out + Mz;
+    for (int e = tid; e < Mh * Mz; e += nt) {
+        const int ml = vg_div(e, iMz), k = e - ml * Mz;
+        float t = 0.f;
+        for (int sl = 0; sl < SC; ++sl) t = fmaf(dRs[sl * Mh + ml], Es[sl * Mz + k], t);
+        vg_stream(oC + (size_t)m0 * Mz + e, t);
+    }
+    se = vg_wave_sum(se); sv = vg_wave_sum(sv); sr = vg_wave_sum(sr);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = se; red[1][tid >> 6] = sv; red[2][tid >> 6] = sr; }
+    __syncthreads();
+    if (tid == 0) {
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+        for (int k = 0; k < (int)(nt >> 6); ++k) { t0 += red[0][k]; t1 += red[1][k]; t2 += red[2][k]; }
+        float* os = oC + (size_t)Mz * Mz + 4 * half;
+        os[0] = t0; os[1] = t1; os[2] = t2; os[3] = 0.f;
+    }
+    VG_T(ch == 0 && half == 0 && l == 0 && p == 0, 503);
+    VG_T(ch == a.NC - 1 && half == 1 && l == L - 1 && p == 0, 505);
 }
 
 // =================================================================================================
@@ -476,7 +627,7 @@ __device__ __forceinline__ HyperState hyper_update(const HyperArgs& h, size_t pl
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const float* q = part + (size_t)min(k, h.NC - 1) * h.part_len;
-        v0[k][0] = q[0]; v0[k][1] = q[1]; v0[k][2] = q[2];
+        v0[k][0] = q[0] + q[4]; v0[k][1] = q[1] + q[5]; v0[k][2] = q[2] + q[6];      // the two halves of paths_bwd_split
     }
     HyperState o;
     o.raw_ell = h.p_ell[pl]; o.raw_var = h.p_var[pl];
@@ -493,7 +644,7 @@ __device__ __forceinline__ HyperState hyper_update(const HyperArgs& h, size_t pl
         for (int k = 0; k < 16; ++k) {
             if (c0 == 0) { v[k][0] = v0[k][0]; v[k][1] = v0[k][1]; v[k][2] = v0[k][2]; continue; }
             const float* q = part + (size_t)min(c0 + k, h.NC - 1) * h.part_len;
-            v[k][0] = q[0]; v[k][1] = q[1]; v[k][2] = q[2];
+            v[k][0] = q[0] + q[4]; v[k][1] = q[1] + q[5]; v[k][2] = q[2] + q[6];
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -1276,7 +1427,7 @@ __device__ __forceinline__ void prior_gemm_lds_body(const GemmArgs& a, float* ld
                 const float* src = row < 64
                     ? a.W + (((size_t)p * S + min(s0 + row, S - 1)) * L + l) * B + k0 + 4 * u
                     : Bm + (((size_t)p * L + l) * J + min(j0 + row - 64, J - 1)) * B + k0 + 4 * u;
-                __builtin_amdgcn_global_load_lds((vg_gmem*)src, (vg_lmem*)(lds + 4 * (size_t)c), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((vg_gmem*)src, (vg_lmem*)(lds + 4 * (size_t)c), 16, 0, VG_DMA_AUX);
             }
         }
         vg_dma_wait();
@@ -1972,6 +2123,17 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const void* fn_s3 = VG_PICK(stage3_kernel, raw_fwd);
     const void* fn_pb = VG_PICK(paths_bwd_sc8, raw_bwd);
 #undef VG_PICK
+    // two workgroups per (chunk, latent) while the launch leaves half the chip idle
+    const int Mh = Mz / 2, nxw = N - ((N / 2) & ~3);
+    const size_t lds_pbs = ((size_t)4 * N * Mh + (size_t)2 * Mz * Mh + (size_t)SC * N + (size_t)2 * SC * Mh + (size_t)SC * Mz +
+                            (size_t)2 * SC * nxw + (size_t)2 * SC * Mh + (size_t)2 * SK * SC * nxw + (size_t)2 * SK * SC * Mh +
+                            11 * 4) * sizeof(float);
+    const bool split_bwd = backward && SK > 1 && Mz % 8 == 0 && N % 4 == 0 && N >= 8 && lds_pbs <= 80 * 1024 &&
+                           (size_t)P * L * NC * 2 <= 512 && !(what & VGPMP_NO_SPLIT);
+    if (split_bwd) {
+        fn_pb = SK == 2 ? (const void*)paths_bwd_split<2> : SK == 4 ? (const void*)paths_bwd_split<4> : (const void*)paths_bwd_split<8>;
+        lds_pb = lds_pbs;
+    }
     if ((rc = set_dyn_lds(fn_pb, lds_pb))) return rc;
     if (fused) {
         if ((rc = set_dyn_lds((const void*)stage1_kernel<false>, lds_s1))) return rc;
@@ -2076,7 +2238,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             return (int)hipGetLastError();
         }
         // ---- reverse of the path assembly (+ hyper-parameter update), then (here or in the next stage 1) the rest
-        if ((rc = launch(fn_pb, dim3(NC, L, P), &pa, lds_pb))) return rc;
+        if ((rc = launch(fn_pb, dim3(split_bwd ? 2 * NC : NC, L, P), &pa, lds_pb))) return rc;
         mark();
         if (!(fused && more)) {      // otherwise both ride in stage 1 of the next step
             hy.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;

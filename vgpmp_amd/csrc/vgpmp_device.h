@@ -44,6 +44,9 @@ __device__ __forceinline__ void vg_stream(float4* p, float4 v) {
 }
 
 // ---- global -> LDS staging without registers (global_load_lds, gfx950) ----------------------------
+#ifndef VG_DMA_AUX
+#define VG_DMA_AUX 0      // cache policy bits of the staging loads (2 = nt)
+#endif
 // A rolled `lds[e] = g[e]` loop compiles to load / wait / store per iteration: one memory round trip per
 // 256 elements (measured 10 us for the 74 KB of the reverse pass; 3 us with the form below).  Here every
 // request of the workgroup is issued back to back and lands in LDS by itself; ONE vg_dma_wait() + barrier
@@ -63,7 +66,7 @@ __device__ __forceinline__ void vg_stage_words(void* lds, int nwords, int tid, i
         const int i = c + lane;
         if (i < nwords) {
             const void* g = map(i);
-            if (g) __builtin_amdgcn_global_load_lds((vg_gmem*)g, (vg_lmem*)(w + c), 4, 0, 0);
+            if (g) __builtin_amdgcn_global_load_lds((vg_gmem*)g, (vg_lmem*)(w + c), 4, 0, VG_DMA_AUX);
             else w[i] = 0u;
         }
     }
@@ -82,7 +85,7 @@ __device__ __forceinline__ void vg_stage_rows(void* lds, int nrows, int row_floa
             if (i < total) {
                 const int r = (int)(((float)i + 0.5f) * iupr), u = i - r * upr;
                 const float* g = row_src(r);
-                if (g) __builtin_amdgcn_global_load_lds((vg_gmem*)(g + 4 * u), (vg_lmem*)((char*)lds + 16 * (size_t)c), 16, 0, 0);
+                if (g) __builtin_amdgcn_global_load_lds((vg_gmem*)(g + 4 * u), (vg_lmem*)((char*)lds + 16 * (size_t)c), 16, 0, VG_DMA_AUX);
                 else reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -118,7 +121,7 @@ __device__ __forceinline__ void vg_stage_f64_square(double* lds, int ld, const d
         const int i = c + lane;
         if (i < total) {
             const int r = (int)(((float)i + 0.5f) * iupr), u = min(i - r * upr, last);
-            __builtin_amdgcn_global_load_lds((vg_gmem*)(g + (size_t)r * n + 2 * u), (vg_lmem*)((char*)lds + 16 * (size_t)c), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((vg_gmem*)(g + (size_t)r * n + 2 * u), (vg_lmem*)((char*)lds + 16 * (size_t)c), 16, 0, VG_DMA_AUX);
         }
     }
 }
@@ -128,7 +131,7 @@ __device__ __forceinline__ void vg_stage_16(void* lds, const void* g, int n16, i
     for (int c = (tid & ~(VG_WAVE - 1)); c < n16; c += nt)
         if (c + lane < n16)
             __builtin_amdgcn_global_load_lds((vg_gmem*)((const char*)g + 16 * (size_t)(c + lane)),
-                                             (vg_lmem*)((char*)lds + 16 * (size_t)c), 16, 0, 0);
+                                             (vg_lmem*)((char*)lds + 16 * (size_t)c), 16, 0, VG_DMA_AUX);
 }
 
 // ---- nearest-voxel signed distance lookup (utils/sdf_utils.py:62-66,73-76) ------------------

@@ -186,6 +186,7 @@ class PlannerBatch:
         # device-resident step counter: lets a captured hipGraph of the step be replayed
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.fuse = True          # False: one launch per kernel even for small batches (measurement)
+        self.extra_flags = 0      # e.g. capi.NO_SPLIT (measurement)
         self._graph = None
         self._graph_unroll = 0
         self._pack()
@@ -218,7 +219,7 @@ class PlannerBatch:
 
     # ---- the ELBO step --------------------------------------------------------------------------
     def _run(self, what: int, step: int) -> None:
-        what |= 0 if self.fuse else capi.NO_FUSE
+        what |= (0 if self.fuse else capi.NO_FUSE) | self.extra_flags
         capi.check(self.lib.vgpmp_elbo_step(
             C.byref(self.dims), capi.ptr(self.scene.dev_robot), C.byref(self.scene.sdf), C.byref(self._problem),
             C.byref(self._params), C.byref(self._am), C.byref(self._av), C.byref(self._noise), C.byref(self._out),
@@ -245,7 +246,7 @@ class PlannerBatch:
     # ---- hipGraph replay of the training step ----------------------------------------------------
     def _run_counter(self, num_steps: int = 1, stage_ms=None) -> None:
         """`num_steps` training steps whose noise key / Adam step count come from the device counter."""
-        what = capi.DO_FORWARD | capi.DO_BACKWARD | capi.DO_ADAM | capi.GEN_NOISE | (0 if self.fuse else capi.NO_FUSE)
+        what = capi.DO_FORWARD | capi.DO_BACKWARD | capi.DO_ADAM | capi.GEN_NOISE | (0 if self.fuse else capi.NO_FUSE) | self.extra_flags
         args = (C.byref(self.dims), capi.ptr(self.scene.dev_robot), C.byref(self.scene.sdf),
                 C.byref(self._problem_ctr), C.byref(self._params), C.byref(self._am), C.byref(self._av),
                 C.byref(self._noise), C.byref(self._out), capi.ptr(self.workspace), self.workspace.numel(), what,
