@@ -20,6 +20,7 @@ struct vg_workspace {
     float *A4;               // [P,L,N,Mz,4]  {A, dA/dell, dA/dvar, 0},  A = Kfu (Kuu + jI)^-1
     float *AT;               // [P,L,Mz,N]    A transposed
     float *C;                // [P,L,Mz,Mz]   q_sqrt (full)
+    float *CT;               // [P,L,Mz,Mz]   q_sqrt^T
     float *CT_ell, *CT_var;  // [P,L,Mz,Mz]   (dC/d theta)^T
     float *Lk32;             // [P,L,Mz,Mz]   chol(Kuu + jitter I)
     float *m;                // [P,L,Mz]

@@ -153,7 +153,8 @@ struct PathArgs {
     size_t slab, part_len;
     float sqrt_jitter;
     const float4* A4;
-    const float *AT, *C, *CT_ell, *CT_var, *m, *F0, *H, *eps, *eps2;
+    const float *AT, *C, *CT, *CT_ell, *CT_var, *m, *F0, *H, *eps, *eps2;
+    int nsplit;               // 2: paths_fwd on two workgroups per (chunk, latent), halves of the time axis
     float *R, *f;
     const float* G;
     float* part;
@@ -262,6 +263,76 @@ __device__ __forceinline__ void paths_fwd_body(const PathArgs& a, float* smf, in
     }
     VG_T(ch == 0 && l == 0 && p == 0, 302);
     VG_T(ch == a.NC - 1 && l == L - 1 && p == 0, 305);
+}
+
+// The same on TWO workgroups per (sample chunk, latent) for launches that leave half the chip idle (see
+// paths_bwd_split): both halves form R (half 0 stores it), each assembles f on its half of the time points, so a
+// workgroup stages ~25 instead of ~36 KB.  q_sqrt comes transposed (16-byte rows, conflict-free reads).  The
+// arithmetic and its order are those of paths_fwd_body: identical bits.  Needs SK > 1, N % 4 == 0, Mz % 4 == 0.
+template <int SK>
+__device__ __forceinline__ void paths_fwd_split_body(const PathArgs& a, float* smf, int ch2, int l, int p) {
+    constexpr int SC = 8;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int S = a.S, N = a.N, Mz = a.Mz, L = a.L, J = N + Mz;
+    const int ch = ch2 >> 1, half = ch2 & 1;
+    const int Nh = (N >> 1) & ~3, n0 = half ? Nh : 0, nx = half ? N - Nh : Nh;
+    const float iMz = 1.0f / (float)Mz, inx = 1.0f / (float)nx;
+    const size_t pl = (size_t)p * L + l;
+    float* cur = smf;
+    auto take = [&](int n) { float* q = cur; cur += (n + 3) & ~3; return q; };
+    float* CTs = take(Mz * Mz);        // [Mz][Mz] q_sqrt^T
+    float* ATs = take(Mz * nx);        // [Mz][nx]
+    float* es = take(2 * SC * Mz);     // [SC][Mz] eps, then eps2
+    float* e2s = es + SC * Mz;
+    float* ms = take(Mz);              // [Mz]
+    float* rs = take(SC * Mz);         // [SC][Mz]
+    float* f0x = take(SC * nx);        // [SC][nx] prior draws at the time points
+    float* f0z = take(SC * Mz);        // [SC][Mz] ... at the inducing points
+    float* rawx = take(SK * SC * nx);  // the split-K slabs as they arrive
+    float* rawz = take(SK * SC * Mz);
+    const int s_base = ch * SC;
+    VG_T(ch2 == 0 && l == 0 && p == 0, 300);
+    {
+        const float* CTg = a.CT + pl * Mz * Mz;
+        vg_stage_rows(CTs, Mz, Mz, tid, nt, [&](int r) -> const float* { return CTg + (size_t)r * Mz; });
+        const float* ATg = a.AT + pl * N * Mz + n0;
+        vg_stage_rows(ATs, Mz, nx, tid, nt, [&](int r) -> const float* { return ATg + (size_t)r * N; });
+        vg_stage_words(es, 2 * SC * Mz, tid, nt, [&](int i) -> const void* {
+            const int second = i >= SC * Mz, e = second ? i - SC * Mz : i;
+            const int sl = vg_div(e, iMz), k = e - sl * Mz, s = min(s_base + sl, S - 1);
+            return (second ? a.eps2 : a.eps) + (((size_t)p * S + s) * Mz + k) * L + l;
+        });
+        vg_stage_words(ms, Mz, tid, nt, [&](int i) -> const void* { return a.m + pl * Mz + i; });
+        auto slab_row = [&](int r) -> const float* {
+            const int k = r / SC, s = min(s_base + (r - k * SC), S - 1);
+            return a.F0 + (size_t)k * a.slab + (((size_t)p * S + s) * L + l) * J;
+        };
+        vg_stage_rows(rawx, SK * SC, nx, tid, nt, [&](int r) -> const float* { return slab_row(r) + n0; });
+        vg_stage_rows(rawz, SK * SC, Mz, tid, nt, [&](int r) -> const float* { return slab_row(r) + N; });
+    }
+    vg_dma_wait();
+    __syncthreads();
+    VG_T(ch2 == 0 && l == 0 && p == 0, 301);
+    for (int e = tid; e < SC * nx; e += nt) f0x[e] = sum_slabs_lds<SK>(rawx, e, SC * nx);
+    for (int e = tid; e < SC * Mz; e += nt) f0z[e] = sum_slabs_lds<SK>(rawz, e, SC * Mz);
+    __syncthreads();
+    for (int e = tid; e < SC * Mz; e += nt) {
+        const int sl = vg_div(e, iMz), mi = e - sl * Mz, s = s_base + sl;
+        float u = ms[mi];
+        for (int k = 0; k <= mi; ++k) u = fmaf(CTs[k * Mz + mi], es[sl * Mz + k], u);
+        const float r = u - f0z[e] - a.sqrt_jitter * e2s[e];
+        rs[e] = r;
+        if (half == 0 && s < S) vg_stream(a.R + (((size_t)p * S + s) * L + l) * Mz + mi, r);
+    }
+    __syncthreads();
+    for (int e = tid; e < SC * nx; e += nt) {
+        const int sl = vg_div(e, inx), j = e - sl * nx, s = s_base + sl;
+        float v = f0x[e];
+        for (int k = 0; k < Mz; ++k) v = fmaf(ATs[k * nx + j], rs[sl * Mz + k], v);
+        if (s < S) vg_stream(a.f + (((size_t)p * S + s) * L + l) * N + n0 + j, v);
+    }
+    VG_T(ch2 == 0 && l == 0 && p == 0, 302);
+    VG_T(ch2 == 2 * a.NC - 1 && l == L - 1 && p == 0, 305);
 }
 
 // Reverse of the path assembly over one chunk of samples.  With G = dloss/df:
@@ -1046,8 +1117,13 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     __syncthreads();
     if (role == 0) {
         float* C32 = a.ws.C + pl * Mz * Mz;
+        float* C32T = a.ws.CT + pl * Mz * Mz;
         matmul_f64(MatView{La, ld, 1}, MatView{Qp, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
-            if (r < Mz && c < Mz) C32[(size_t)r * Mz + c] = (float)(v + (r == c && r < 2 ? jit : 0.0));
+            if (r < Mz && c < Mz) {
+                const float cv = (float)(v + (r == c && r < 2 ? jit : 0.0));
+                C32[(size_t)r * Mz + c] = cv;
+                C32T[(size_t)c * Mz + r] = cv;
+            }
         });
         double* gklQ = a.ws.gkl_Q + pl * M * M;
         for (int e = tid; e < M * M; e += nt) {
@@ -1770,6 +1846,10 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(size_t n, double* __restri
 template <int SK, bool RAW>
 __global__ __launch_bounds__(kBlock) void paths_fwd_sc8(PathArgs a) {
     extern __shared__ float smf[];
+    if (SK > 1 && a.nsplit == 2) {
+        if constexpr (SK > 1) paths_fwd_split_body<SK>(a, smf, blockIdx.x, blockIdx.y, blockIdx.z);
+        return;
+    }
     paths_fwd_body<SK, 8, RAW>(a, smf, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
@@ -1843,8 +1923,13 @@ __global__ __launch_bounds__(kBlock) void stage3_kernel(Stage3Args a) {
     int b = blockIdx.x;
     if (b < a.n_path) {
         if (a.skip & 1) return;
-        const int ch = b % a.path.NC;
-        b /= a.path.NC;
+        const int nch = a.path.NC * a.path.nsplit;
+        const int ch = b % nch;
+        b /= nch;
+        if (SK > 1 && a.path.nsplit == 2) {
+            if constexpr (SK > 1) paths_fwd_split_body<SK>(a.path, smf, ch, b % a.path.L, b / a.path.L);
+            return;
+        }
         paths_fwd_body<SK, 8, RAW>(a.path, smf, ch, b % a.path.L, b / a.path.L);
         return;
     }
@@ -1900,6 +1985,7 @@ size_t vg_layout_workspace(const vgpmp_dims* d, void* base, vg_workspace* ws) {
     ws->A4 = carve<float>(cur, PL * N * Mz * 4, real);
     ws->AT = carve<float>(cur, PL * N * Mz, real);
     ws->C = carve<float>(cur, PL * Mz * Mz, real);
+    ws->CT = carve<float>(cur, PL * Mz * Mz, real);
     ws->CT_ell = carve<float>(cur, PL * Mz * Mz, real);
     ws->CT_var = carve<float>(cur, PL * Mz * Mz, real);
     ws->Lk32 = carve<float>(cur, PL * Mz * Mz, real);
@@ -2045,7 +2131,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     pa.S = S; pa.N = N; pa.Mz = Mz; pa.L = L; pa.SK = SK; pa.NC = NC; pa.slab = slab; pa.part_len = vg_part_len(d);
     pa.sqrt_jitter = (float)sqrt(pb->jitter);
     pa.A4 = reinterpret_cast<const float4*>(ws->A4); pa.AT = ws->AT;
-    pa.C = ws->C; pa.CT_ell = ws->CT_ell; pa.CT_var = ws->CT_var; pa.m = ws->m;
+    pa.C = ws->C; pa.CT = ws->CT; pa.nsplit = 1; pa.CT_ell = ws->CT_ell; pa.CT_var = ws->CT_var; pa.m = ws->m;
     pa.F0 = ws->F0; pa.H = ws->H; pa.want_dell = want_dell ? 1 : 0;
     pa.eps = nz->eps; pa.eps2 = nz->eps2; pa.R = ws->R; pa.f = out->f; pa.G = ws->G; pa.part = ws->part;
     HyperArgs hy;
@@ -2130,6 +2216,11 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                             11 * 4) * sizeof(float);
     const bool split_bwd = backward && SK > 1 && Mz % 8 == 0 && N % 4 == 0 && N >= 8 && lds_pbs <= 80 * 1024 &&
                            (size_t)P * L * NC * 2 <= 512 && !(what & VGPMP_NO_SPLIT);
+    const size_t lds_pfs = ((size_t)Mz * Mz + (size_t)Mz * nxw + (size_t)4 * SC * Mz + Mz + (size_t)SC * nxw +
+                            (size_t)SK * SC * nxw + (size_t)SK * SC * Mz + 10 * 4) * sizeof(float);
+    const bool split_fwd = SK > 1 && Mz % 4 == 0 && N % 4 == 0 && N >= 8 && lds_pfs <= 64 * 1024 &&
+                           (size_t)P * L * NC * 2 <= 512 && !(what & VGPMP_NO_SPLIT);
+    if (split_fwd) { pa.nsplit = 2; lds_pf = lds_pfs; }
     if (split_bwd) {
         fn_pb = SK == 2 ? (const void*)paths_bwd_split<2> : SK == 4 ? (const void*)paths_bwd_split<4> : (const void*)paths_bwd_split<8>;
         lds_pb = lds_pbs;
@@ -2198,7 +2289,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             s3.path = pa;
             // the counter has ticked in stage 2: it already names the next step
             s3.rng = make_rng_args(d, nz, seed, problem_base, step_i + 1u, ctr, 0u);
-            s3.n_path = NC * L * P;
+            s3.n_path = NC * pa.nsplit * L * P;
             s3.basis_gx = (int)basis_gx; s3.w_gx = (int)w_gx;
             s3.n_basis = (gen && more) ? (int)basis_gx * P : 0;
             const unsigned n3 = s3.n_path + s3.n_basis + ((gen && more) ? w_gx * P : 0u);
@@ -2222,7 +2313,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             else
                 hipExtLaunchKernelGGL(prior_gemm_kernel<0>, gemm_grid, dim3(kBlock), 0, st, g0, g1, 0, ga);
             mark();
-            if ((rc = launch(fn_pf, dim3(NC, L, P), &pa, lds_pf))) return rc;
+            if ((rc = launch(fn_pf, dim3(NC * pa.nsplit, L, P), &pa, lds_pf))) return rc;
             mark();
         }
         // ---- likelihood forward + reverse (fk_sdf.hip)
