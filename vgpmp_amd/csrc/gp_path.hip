@@ -59,6 +59,29 @@ __device__ __forceinline__ double dot4(const double* a, int sa, const double* b,
     return (s0 + s1) + (s2 + s3);
 }
 
+// the same dot product on EIGHT adjacent lanes (sub = lane & 7): each takes every eighth term -- four loads per
+// operand in flight per 32 terms, issued unconditionally on clamped indices and masked afterwards -- then three
+// butterfly steps; every lane of the group returns the sum.  A 32-term row costs ~0.25 us instead of ~0.9.
+__device__ __forceinline__ double dot8(const double* a, int sa, const double* b, int sb, int n, int sub) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int k0 = 0; k0 < n; k0 += 32) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = min(k0 + sub + 8 * j, n - 1);
+            av[j] = a[k * sa]; bv[j] = b[k * sb];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double t = k0 + sub + 8 * j < n ? av[j] : 0.0;
+            if (j & 1) s1 = fma(t, bv[j], s1); else s0 = fma(t, bv[j], s0);
+        }
+    }
+    double s = s0 + s1;
+    s += __shfl_xor(s, 1, VG_WAVE); s += __shfl_xor(s, 2, VG_WAVE); s += __shfl_xor(s, 4, VG_WAVE);
+    return s;
+}
+
 __device__ __forceinline__ double block_sum(double v, double* red) {
     v = vg_wave_sum(v);
     __syncthreads();
@@ -787,10 +810,18 @@ __device__ __forceinline__ vg_f64x4 mfma_tile_f64(MatView A, MatView B, int K, i
     const int r = lane & 15, g = lane >> 4;
     const double* ap = A.p + (i0 + r) * A.sr + g * A.sc;
     const double* bp = B.p + g * B.sr + (j0 + r) * B.sc;
-#pragma unroll 8
-    for (int k = 0; k < K; k += 4) {
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[k * A.sc], bp[k * B.sr], acc, 0, 0, 0);
-    }
+    // K is a multiple of 16: passes of four k-steps with constant bounds, so that a pass's eight operands are
+    // requested together and its products chain in the accumulator registers (a loop with a run-time trip count is
+    // left rolled by the compiler: load, wait, move the accumulator in, multiply, move it out -- 3x slower)
+    auto pass = [&](int k0) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { av[u] = ap[(k0 + 4 * u) * A.sc]; bv[u] = bp[(k0 + 4 * u) * B.sr]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    };
+    if (K == 32) { pass(0); pass(16); }
+    else for (int k0 = 0; k0 < K; k0 += 16) pass(k0);
     return acc;
 }
 
@@ -1031,19 +1062,6 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     double* Kd = X1;
     double* T = X2;
     double* qm = kd1 + Mp;           // [Mp] q_mu behind the two conditioned points
-    if (role == 0 && tid == 0) {
-        if (a.commit && a.hy.do_adam) {      // staged hyper-parameters of the prologue -> their tensors
-            const HyperArgs& h = a.hy;
-            const double* nx = h.next + 6 * pl;
-            h.p_ell[pl] = nx[0]; h.p_var[pl] = nx[1]; h.m_ell[pl] = nx[2]; h.v_ell[pl] = nx[3]; h.m_var[pl] = nx[4];
-            h.v_var[pl] = nx[5];
-        }
-        if (a.keep_prev) {                   // this step's var / slopes for the prologue of the next step
-            a.ws.prev_var[pl] = a.ws.var[pl];
-            a.ws.prev_sig_ell[pl] = a.ws.sig_ell[pl];
-            a.ws.prev_sig_var[pl] = a.ws.sig_var[pl];
-        }
-    }
     const double jit = a.jitter, var = a.ws.var[pl];
     const double y0 = a.y_u[((size_t)p * 2 + 0) * L + l], y1 = a.y_u[((size_t)p * 2 + 1) * L + l];
     const double* Kg = a.ws.Ks64 + pl * Mz * Mz;
@@ -1080,15 +1098,36 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
             return (i >= 2 && i < Mz) ? reinterpret_cast<const uint32_t*>(a.q_mu + pl * M + (i - 2)) + (w & 1) : nullptr;
         });
     }
-    vg_dma_wait();
-    __syncthreads();
-    if (tid == 0) { k0[0] += jit; k1[1] += jit; qm[0] = y0; qm[1] = y1; }
-    if (role == 2) {
-        for (int e = tid; e < Mz * Mz; e += nt) {       // dK/dvar = K / var
-            const int i = vg_div(e, iMz), j = e - i * Mz;
-            Kd[i * ld + j] /= var;
+    if (role == 0 && tid == 0) {      // behind the staging requests: these round trips overlap them
+        if (a.commit && a.hy.do_adam) {      // staged hyper-parameters of the prologue -> their tensors
+            const HyperArgs& h = a.hy;
+            const double* nx = h.next + 6 * pl;
+            h.p_ell[pl] = nx[0]; h.p_var[pl] = nx[1]; h.m_ell[pl] = nx[2]; h.v_ell[pl] = nx[3]; h.m_var[pl] = nx[4];
+            h.v_var[pl] = nx[5];
+        }
+        if (a.keep_prev) {                   // this step's var / slopes for the prologue of the next step
+            a.ws.prev_var[pl] = a.ws.var[pl];
+            a.ws.prev_sig_ell[pl] = a.ws.sig_ell[pl];
+            a.ws.prev_sig_var[pl] = a.ws.sig_var[pl];
         }
     }
+    vg_dma_wait();
+    __syncthreads();
+    // prior mean through the two conditioned points and a = Lk^-1 (q_mu - p_mu)  (prior_kl.py:16-35); the jitter on
+    // the two leading diagonal entries and the conditioned values are applied on the fly (no fix-up pass, no barrier)
+    const double k00 = k0[0] + jit, k01 = k1[0], k11 = k1[1] + jit;
+    const double det = k00 * k11 - k01 * k01;
+    const double c0 = (k11 * y0 - k01 * y1) / det, c1 = (k00 * y1 - k01 * y0) / det;
+    // (loads first, selects afterwards: a conditional load is a branch)
+    auto K0 = [&](int i) { const double v = k0[i]; return i == 0 ? k00 : v; };
+    auto K1 = [&](int i) { const double v = k1[i]; return i == 1 ? k11 : v; };
+    for (int i = tid; i < Mz; i += nt) {
+        const double qi = qm[i];
+        const double mi = i == 0 ? y0 : (i == 1 ? y1 : qi);
+        if (role == 0) a.ws.m[pl * Mz + i] = (float)mi;
+        dl[i] = mi - (K0(i) * c0 + K1(i) * c1);
+    }
+    const double kd_scale = role == 2 ? 1.0 / var : 1.0;      // dK/dvar = K / var, applied to the products
     if (role == 0) {                         // float32 copy for the gradient assembly (written here, not in stage A:
         float* Lk32 = a.ws.Lk32 + pl * Mz * Mz;      // stage A of the next step may overlap that kernel)
         for (int e = tid; e < Mz * Mz; e += nt) {
@@ -1098,23 +1137,15 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     }
     __syncthreads();
     VG_T(l == 0 && p == 0, 201 + 10 * role);
-    // prior mean through the two conditioned points and a = Lk^-1 (q_mu - p_mu)  (prior_kl.py:16-35)
-    const double k00 = k0[0], k01 = k1[0], k11 = k1[1];
-    const double det = k00 * k11 - k01 * k01;
-    const double c0 = (k11 * y0 - k01 * y1) / det, c1 = (k00 * y1 - k01 * y0) / det;
-    for (int i = tid; i < Mz; i += nt) {
-        const double mi = qm[i];
-        if (role == 0) a.ws.m[pl * Mz + i] = (float)mi;
-        dl[i] = mi - (k0[i] * c0 + k1[i] * c1);
-    }
-    __syncthreads();
     double klacc = 0.0;
-    for (int i = tid; i < Mz; i += nt) {
-        const double s = dot4(Li + i * ld, 1, dl, 1, i + 1);
-        af[i] = s;
-        if (i >= 2) klacc += s * s;
+    const int sub = tid & 7;
+    for (int i = tid >> 3; i < Mz; i += nt >> 3) {      // af is read again only behind later barriers
+        const double s = dot8(Li + i * ld, 1, dl, 1, i + 1, sub);
+        if (sub == 0) {
+            af[i] = s;
+            if (i >= 2) klacc += s * s;
+        }
     }
-    __syncthreads();
     if (role == 0) {
         float* C32 = a.ws.C + pl * Mz * Mz;
         float* C32T = a.ws.CT + pl * Mz * Mz;
@@ -1140,8 +1171,10 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
         const double kl = block_sum(klacc, red);
         if (tid == 0) a.ws.kl_l[pl] = 0.5 * (kl - (double)M);
         // d KL / d q_mu = (Lk^-T [0, 0, a])[2:]
-        for (int k = tid + 2; k < Mz; k += nt)
-            a.ws.gkl_qmu[pl * M + (k - 2)] = dot4(Li + k * ld + k, ld, af + k, 1, Mz - k);
+        for (int k = (tid >> 3) + 2; k < Mz; k += nt >> 3) {
+            const double g = dot8(Li + k * ld + k, ld, af + k, 1, Mz - k, sub);
+            if (sub == 0) a.ws.gkl_qmu[pl * M + (k - 2)] = g;
+        }
         VG_T(l == 0 && p == 0, 202);
         return;
     }
@@ -1149,9 +1182,9 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     // Four LDS matrices (35 KB at Mz = 32, so that these workgroups pack 4 per CU next to the prior GEMM):
     // W overwrites dK (its first two columns are kept), dLk overwrites T, and pad(Q) -- prefetched into
     // registers -- takes the place of Lk once Lk has been used.
-    for (int i = tid; i < Mz; i += nt) { kd0[i] = Kd[i * ld + 0]; kd1[i] = Kd[i * ld + 1]; }
+    for (int i = tid; i < Mz; i += nt) { kd0[i] = Kd[i * ld + 0] * kd_scale; kd1[i] = Kd[i * ld + 1] * kd_scale; }
     VG_T(l == 0 && p == 0, 204 + 10 * role);
-    matmul_f64(MatView{Li, ld, 1}, MatView{Kd, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) { T[r * ld + c] = v; });
+    matmul_f64(MatView{Li, ld, 1}, MatView{Kd, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) { T[r * ld + c] = v * kd_scale; });
     __syncthreads();
     VG_T(l == 0 && p == 0, 205 + 10 * role);
     double* W = X1;
@@ -1183,14 +1216,17 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     const double d00 = kd0[0], d01 = kd1[0], d11 = kd1[1];
     const double e0 = d00 * c0 + d01 * c1, e1 = d01 * c0 + d11 * c1;        // dKyy c
     const double cd0 = -(k11 * e0 - k01 * e1) / det, cd1 = -(k00 * e1 - k01 * e0) / det;
-    for (int i = tid; i < Mz; i += nt) {
-        const double s = dot4(T + i * ld, 1, af, 1, i + 1);
-        const double pd = kd0[i] * c0 + kd1[i] * c1 + k0[i] * cd0 + k1[i] * cd1;
-        v1[i] = -pd - s;
+    for (int i = tid >> 3; i < Mz; i += nt >> 3) {
+        const double s = dot8(T + i * ld, 1, af, 1, i + 1, sub);
+        const double pd = kd0[i] * c0 + kd1[i] * c1 + K0(i) * cd0 + K1(i) * cd1;
+        if (sub == 0) v1[i] = -pd - s;
     }
     __syncthreads();
     double acc = 0.0;
-    for (int i = tid + 2; i < Mz; i += nt) acc += af[i] * dot4(Li + i * ld, 1, v1, 1, i + 1);
+    for (int i = (tid >> 3) + 2; i < Mz; i += nt >> 3) {
+        const double s = dot8(Li + i * ld, 1, v1, 1, i + 1, sub);
+        if (sub == 0) acc += af[i] * s;
+    }
     acc = block_sum(acc, red);
     if (tid == 0) (role == 1 ? a.ws.gkl_ell : a.ws.gkl_var)[pl] = acc;
     VG_T(l == 0 && p == 0, 203 + 10 * role);
