@@ -276,6 +276,7 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
 }
 
 constexpr int kLikBlock = 128;
+constexpr int kLikBatchBlock = 64;
 
 // ---- stand-alone log_prob: g [n, dof] row major ------------------------------------------------
 template <bool GRAD>
@@ -294,19 +295,20 @@ __global__ __launch_bounds__(kLikBlock) void log_prob_kernel(const vgpmp_robot* 
 }
 
 // ---- ELBO path: f [P,S,L,N] -> logp [P,S,N], G = dloss/df [P,S,L,N], block partial sums ----------
-// LPC lanes per (sample, time) configuration; kLikBlock / LPC configurations per workgroup.
-template <int LPC>
-__global__ __launch_bounds__(kLikBlock) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
+// LPC lanes per (sample, time) configuration; BLK / LPC configurations per workgroup.  Large batches run one-wave
+// workgroups (kLikBatchBlock): 188 instead of 204 us per launch at 64 problems (finer tail).
+template <int LPC, int BLK>
+__global__ __launch_bounds__(BLK) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
                                                                   const float* __restrict__ f, int S, int L, int N,
                                                                   float scale, float* __restrict__ G,
                                                                   float* __restrict__ logp,
                                                                   float* __restrict__ lik_partial, int dbg) {
     extern __shared__ float lik_lds[];
-    __shared__ float red[kLikBlock / VG_WAVE];
+    __shared__ float red[BLK / VG_WAVE];
 #ifdef VGPMP_BISECT
     if (dbg == 1) return;
 #endif
-    constexpr int CPB = kLikBlock / LPC;                 // configurations per workgroup
+    constexpr int CPB = BLK / LPC;                 // configurations per workgroup
     const int pb = blockIdx.y;
     VG_T(blockIdx.x == 0 && pb == 0, 400);
     const int cl = threadIdx.x / LPC, sub = threadIdx.x % LPC;
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_kernel(const vgpmp_rob
     if (threadIdx.x == 0) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < kLikBlock / VG_WAVE; ++k) t += red[k];
+        for (int k = 0; k < BLK / VG_WAVE; ++k) t += red[k];
         lik_partial[(size_t)pb * gridDim.x + blockIdx.x] = t;
     }
     VG_T(blockIdx.x == 0 && pb == 0, 401);
@@ -704,14 +706,15 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
                            float scale, float* G, float* logp, float* lik_partial, int* nblk_out, hipStream_t st,
                            hipEvent_t k0, hipEvent_t k1) {
     const int lpc = lik_lpc(P, S, N);
-    const int nblk = (S * N * lpc + kLikBlock - 1) / kLikBlock;
+    const int blk = lpc > 1 ? kLikBlock : kLikBatchBlock;
+    const int nblk = (S * N * lpc + blk - 1) / blk;
     if (nblk_out) *nblk_out = nblk;
     if (P == 0 || nblk == 0) return 0;
     static size_t granted1 = 0, granted4 = 0, granted8 = 0;
-    const size_t lds = lpc > 1 ? wide_lds_bytes(L, lpc) : lik_lds_bytes(L, true);
+    const size_t lds = lpc > 1 ? wide_lds_bytes(L, lpc) : lik_lds_bytes(L, true) * kLikBatchBlock / kLikBlock;
     int rc = lpc == 8 ? lik_grant_lds((const void*)loglik_paths_wide_kernel<8>, lds, &granted8)
            : lpc == 4 ? lik_grant_lds((const void*)loglik_paths_wide_kernel<4>, lds, &granted4)
-                      : lik_grant_lds((const void*)loglik_paths_kernel<1>, lds, &granted1);
+                      : lik_grant_lds((const void*)loglik_paths_kernel<1, kLikBatchBlock>, lds, &granted1);
     if (rc) return rc;
     int dbg = 0;
 #ifdef VGPMP_BISECT
@@ -725,7 +728,7 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
         hipExtLaunchKernelGGL(loglik_paths_wide_kernel<4>, dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf, f, S, L,
                               N, scale, G, logp, lik_partial);
     else
-        hipExtLaunchKernelGGL(loglik_paths_kernel<1>, dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf, f, S, L, N,
+        hipExtLaunchKernelGGL((loglik_paths_kernel<1, kLikBatchBlock>), dim3(nblk, P), dim3(kLikBatchBlock), lds, st, k0, k1, 0, rb, *sdf, f, S, L, N,
                               scale, G, logp, lik_partial, dbg);
     return (int)hipGetLastError();
 }
