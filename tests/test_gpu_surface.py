@@ -206,6 +206,39 @@ def test_pipelined_steps_equal_single_step_calls(P):
     assert torch.allclose(a.lik, b.lik, rtol=1e-12) and torch.allclose(a.kl, b.kl, rtol=1e-12)
 
 
+def test_split_path_kernels_equal_one_workgroup_form():
+    """Small launches run the path assembly and its reverse on two workgroups per (sample chunk, latent)
+    (paths_fwd_split_body: halves of the time axis; paths_bwd_split: halves of the inducing axis).  The forward
+    form keeps the arithmetic order, so f is bit-identical; the reverse form changes only float32 summation order."""
+    from vgpmp_amd import capi, engine
+    ps = rb.load_problemset("franka", "industrial")
+    spec = rb.load_robot("franka")
+    grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
+    sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
+    qs = np.array([ps.queries[0]])
+    # Mz = 16 (multiple of 8), N = 40 (multiple of 4), split-K 4: both split kernels are eligible
+    kw = dict(num_samples=32, num_inducing=14, num_data=40, num_bases=128, lengthscales=[2.0] * 7, variance=0.2, seed=5)
+    a, b = engine.PlannerBatch(sc, qs, **kw), engine.PlannerBatch(sc, qs, **kw)
+    assert a.dims.split_k == 4
+    b.extra_flags = capi.NO_SPLIT
+    la, ga = a.loss_and_grad(step=2)
+    lb, gb = b.loss_and_grad(step=2)
+    torch.cuda.synchronize()
+    assert torch.equal(a.f, b.f)
+    np.testing.assert_allclose(float(la[0]), float(lb[0]), rtol=1e-12)
+    for x, y in zip(ga, gb):
+        scale = float(y.abs().max()) + 1e-30
+        assert float((x - y).abs().max()) <= 2e-5 * scale, (float((x - y).abs().max()), scale)
+    a.run_steps(10)
+    b.run_steps(10)
+    torch.cuda.synchronize()
+    # Adam normalises every gradient entry by its own running magnitude: entries whose gradient is ~0 amplify the
+    # float32 summation-order differences, hence the loose bound on the largest entry and the tight one on the mean
+    for x, y in ((a.q_mu, b.q_mu), (a.q_sqrt, b.q_sqrt), (a.raw_ell, b.raw_ell), (a.raw_var, b.raw_var)):
+        d = (x - y).abs()
+        assert float(d.max()) < 2e-3 and float(d.mean()) < 2e-5, (float(d.max()), float(d.mean()))
+
+
 def test_large_batch_kernels_match_small_launch_kernels():
     """Large batches use the LDS-tiled prior GEMM (split_k = 1) and one lane per configuration in the
     likelihood; each problem must still equal the same problem evaluated alone (split-K GEMM, 4 lanes per
