@@ -982,19 +982,26 @@ __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, 
     // lower triangle only, in triangular order (e -> row i, column j <= i): Mz (Mz + 1) / 2 evaluations of the exponential
     // spread evenly over the workgroup; one division per thread instead of two per element
     const double inv_ell = 1.0 / ell, c3 = 5.0 / (3.0 * ell);
-    for (int e = tid; e < Mz * (Mz + 1) / 2; e += nt) {
+    // (the diagonal needs no exponential: Mz (Mz - 1) / 2 = 496 evaluations at Mz = 32 are two rounds of the
+    // workgroup, with the diagonal among them it was three)
+    for (int e = tid; e < Mz * (Mz - 1) / 2; e += nt) {
         int i = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
         if (i * (i + 1) / 2 > e) --i;                    // float rounding at the row boundaries
         if ((i + 1) * (i + 2) / 2 <= e) ++i;
-        const int j = e - i * (i + 1) / 2;
+        const int j = e - i * (i + 1) / 2;               // strictly lower entry (i + 1, j)
+        ++i;
         double r = fabs(zs[i] - zs[j]) * inv_ell;
         double ex = exp(-kSqrt5 * r);
         double k = var * (1.0 + kSqrt5 * r + (5.0 / 3.0) * r * r) * ex;
         double dk = var * ex * (r * r * c3) * (1.0 + kSqrt5 * r);
-        La[i * ld + j] = k + (i == j ? jit : 0.0);
-        Kg[(size_t)i * Mz + j] = k;
-        Kdg[(size_t)i * Mz + j] = dk;
-        if (i != j) { La[j * ld + i] = k; Kg[(size_t)j * Mz + i] = k; Kdg[(size_t)j * Mz + i] = dk; }
+        La[i * ld + j] = k; La[j * ld + i] = k;
+        Kg[(size_t)i * Mz + j] = k; Kg[(size_t)j * Mz + i] = k;
+        Kdg[(size_t)i * Mz + j] = dk; Kdg[(size_t)j * Mz + i] = dk;
+    }
+    for (int i = tid; i < Mz; i += nt) {                 // r = 0: k = var exp(-0) = var, dk = 0
+        La[i * ld + i] = var + jit;
+        Kg[(size_t)i * Mz + i] = var;
+        Kdg[(size_t)i * Mz + i] = 0.0;
     }
     __syncthreads();
     VG_T(l == 0 && p == 0, 101);
