@@ -123,6 +123,8 @@ def _noise32(noise):
 
 @pytest.mark.parametrize("robot,S,N,M,B,split_k", [("franka", 6, 9, 5, 64, 1), ("franka", 37, 50, 10, 256, 4),
                                                     ("wam", 20, 33, 12, 128, 2), ("ur10", 16, 20, 6, 64, 1),
+                                                    ("franka", 24, 40, 14, 128, 4),        # Mz = 16, N % 4 == 0: two-workgroup path kernels
+                                                    ("franka", 8, 12, 46, 64, 2),          # Mz = 48: the largest inducing set
                                                     ("franka", 128, 100, 30, 1024, 4)])     # BASELINE config 2, full size
 def test_elbo_forward_backward_against_oracle(robot, S, N, M, B, split_k):
     pb = small_problem(robot=robot, S=S, N=N, M=M, B=B, seed=11, n_grid=48)
