@@ -25,7 +25,10 @@ PINNING STATUS
     (float64) applied to an independent restatement in tests/, and the first two
     moments of the pathwise samples against the closed forms of the published
     algorithms (tests/test_pathwise_statistics.py): a statistical check, not a
-    vector from the reference.
+    vector from the reference.  The formulas shared with third-party code that
+    IS importable here are checked against it (tests/test_oracle_independent.py):
+    Matern-5/2 and the conditional mean against scikit-learn, the KL against
+    torch.distributions, the exact update against its interpolation identity.
 
 Notation: S samples, N time points, D = L dof/latents, M inducing, Mz = M + 2,
 P spheres, B Fourier bases.
