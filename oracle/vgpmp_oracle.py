@@ -540,6 +540,80 @@ def optimization_step(p, st, scene, X, Zy, y, noise, alpha, lr, trainable=DEFAUL
 
 
 # ----------------------------------------------------------------------------
+# Likelihood constants as trainable variables (A14: trainable_params.sigma_obs / alpha)
+# ----------------------------------------------------------------------------
+ALPHA_FLOOR = 1e-4     # models/vgpmp.py:82          Parameter(alpha, transform=positive(1e-4))
+SIGMA_FLOOR = 1e-5     # likelihoods/likelihood.py:31,41  positive(DEFAULT_VARIANCE_LOWER_BOUND)
+
+
+@dataclasses.dataclass
+class LikParams:
+    """Unconstrained likelihood variables: alpha = 1e-4 + softplus(raw_alpha), sigma_obs = 1e-5 + softplus(raw_sigma)
+    (one entry per sphere, likelihood.py:37-41)."""
+    raw_alpha: np.ndarray   # [] (0-d array)
+    raw_sigma: np.ndarray   # [P]
+
+    def copy(self):
+        return LikParams(np.array(self.raw_alpha, dtype=np.float64, copy=True),
+                         np.array(self.raw_sigma, dtype=np.float64, copy=True))
+
+
+def init_lik_params(alpha: float, sigma_obs: np.ndarray) -> LikParams:
+    return LikParams(np.asarray(softplus_inverse(alpha - ALPHA_FLOOR), dtype=np.float64),
+                     softplus_inverse(np.asarray(sigma_obs, dtype=np.float64) - SIGMA_FLOOR))
+
+
+def lik_constrained(lp: LikParams) -> Tuple[float, np.ndarray]:
+    return float(ALPHA_FLOOR + softplus(lp.raw_alpha)), SIGMA_FLOOR + softplus(lp.raw_sigma)
+
+
+def hinge_cost(scene: Scene, g: np.ndarray) -> np.ndarray:
+    """likelihood.py:131-143: max(epsilon - d, 0) per sphere, [..., P]."""
+    rb = scene.robot
+    pos = sphere_positions(rb, g, forward_kinematics(rb, g))
+    dist = sdf_distance(scene.sdf, pos - scene.offset) - rb.radii
+    return np.maximum(scene.epsilon - dist, 0.0)
+
+
+def lik_backward(lp: LikParams, scene: Scene, fw) -> LikParams:
+    """Gradient of the training loss wrt (raw_alpha, raw_sigma).  utils/miscellaneous.py:324-343 attaches the priors
+    Normal(loc=<the parameter itself>, scale) to both: their density is constant in the parameter (loc moves with it),
+    so of GPflow's log_prior_density only the bijectors' log|d constrained / d raw| = log sigmoid(raw) remains:
+        loss = -(ELBO + log sigmoid(raw_alpha) + sum_p log sigmoid(raw_sigma_p)).
+    `scene.sigma_obs` and the alpha passed to elbo_forward must be lik_constrained(lp)."""
+    alpha, sigma = lik_constrained(lp)
+    S = fw['S']
+    cost = hinge_cost(scene, fw['g'])                                   # [S, N, P]
+    c2 = (cost * cost).reshape(-1, cost.shape[-1]).sum(0)
+    dE_dalpha = fw['logp'].mean(0).sum()                                # ELBO = alpha * sum_n mean_s logp - KL
+    dE_dsigma = (alpha / S) * 0.5 * c2 / (sigma * sigma)                # logp = -1/2 sum_p c^2 / sigma_p
+    return LikParams(np.asarray(-(dE_dalpha * sigmoid(lp.raw_alpha) + sigmoid(-lp.raw_alpha))),
+                     -(dE_dsigma * sigmoid(lp.raw_sigma) + sigmoid(-lp.raw_sigma)))
+
+
+def optimization_step_lik(p, lp: LikParams, st, st_lik, scene: Scene, X, Zy, y, noise, lr,
+                          trainable=DEFAULT_TRAINABLE, beta1=0.8, beta2=0.95, eps=1e-7):
+    """optimization_step with sigma_obs / alpha among the variables.  st_lik = dict(m=LikParams, v=LikParams);
+    the Adam step count is shared with `st` (one optimizer, models/vgpmp.py:77).  Returns the loss."""
+    alpha, sigma = lik_constrained(lp)
+    sc = dataclasses.replace(scene, sigma_obs=sigma)
+    fw = elbo_forward(p, sc, X, Zy, y, noise, alpha, want_dell=trainable.get("lengthscales", True))
+    g, _ = elbo_backward(p, sc, X, Zy, noise, alpha, fw)
+    gl = lik_backward(lp, sc, fw)
+    adam_step(p, g, st, lr, trainable)
+    lr_t = lr * math.sqrt(1.0 - beta2 ** st.t) / (1.0 - beta1 ** st.t)
+    for name, flag in (("raw_alpha", "alpha"), ("raw_sigma", "sigma_obs")):
+        if not trainable.get(flag, False):
+            continue
+        x, gr = getattr(lp, name), getattr(gl, name)
+        m, v = getattr(st_lik["m"], name), getattr(st_lik["v"], name)
+        m += (gr - m) * (1.0 - beta1)
+        v += (gr * gr - v) * (1.0 - beta2)
+        x -= lr_t * m / (np.sqrt(v) + eps)
+    return -(fw['elbo'] + np.log(sigmoid(lp.raw_alpha)) + np.sum(np.log(sigmoid(lp.raw_sigma))))
+
+
+# ----------------------------------------------------------------------------
 # Plan extraction (A15)
 # ----------------------------------------------------------------------------
 def posterior_mean(p: Params, robot: RobotTable, Xnew, Zy, y, jitter=JITTER) -> np.ndarray:

@@ -30,6 +30,29 @@ def test_elbo_and_gradient_match_autograd(robot, problem):
         assert np.abs(got - want).max() / scale < 2e-6, (name, np.abs(got - want).max(), scale)
 
 
+def test_likelihood_constants_gradient_matches_autograd():
+    """trainable_params.sigma_obs / alpha: loss = -(ELBO + log-det-Jacobians of the two positive() bijectors); the
+    Normal priors the reference attaches are centred on the parameters themselves and drop out."""
+    import dataclasses
+    pb = small_problem(robot="franka", S=5, N=8, M=4, B=32, seed=3)
+    rng = np.random.default_rng(0)
+    P = pb["scene"].robot.num_spheres
+    lp = orc.init_lik_params(7.5, 0.004 + 0.01 * rng.uniform(size=P))
+    alpha, sigma = orc.lik_constrained(lp)
+    np.testing.assert_allclose(alpha, 7.5, rtol=1e-12)
+    sc = dataclasses.replace(pb["scene"], sigma_obs=sigma)
+    fw = orc.elbo_forward(pb["params"], sc, pb["X"], pb["Zy"], pb["y"], pb["noise"], alpha)
+    assert (fw["logp"] < 0).any()
+    gl = orc.lik_backward(lp, sc, fw)
+    e, leaves, _ = torch_ref.elbo(pb["params"], pb["scene"], pb["X"], pb["Zy"], pb["y"], pb["noise"], None, lik=lp)
+    np.testing.assert_allclose(fw["elbo"], float(e.detach()), rtol=1e-9)
+    loss = -(e + torch.nn.functional.logsigmoid(leaves["raw_alpha"]) + torch.nn.functional.logsigmoid(leaves["raw_sigma"]).sum())
+    loss.backward()
+    np.testing.assert_allclose(gl.raw_alpha, leaves["raw_alpha"].grad.numpy(), rtol=1e-9)
+    np.testing.assert_allclose(gl.raw_sigma, leaves["raw_sigma"].grad.numpy(), rtol=1e-8, atol=1e-12)
+    assert np.abs(gl.raw_sigma).max() > 1e-3
+
+
 def test_fk_backward_is_the_chain_derivative():
     pb = small_problem(robot="wam", S=3, N=4, M=3, B=8, seed=5)
     rb = pb["scene"].robot

@@ -41,7 +41,7 @@ def dh(theta, d, a, alpha, craig):
     return torch.stack(rows, -1).reshape(theta.shape + (4, 4))
 
 
-def log_prob(scene: orc.Scene, g):
+def log_prob(scene: orc.Scene, g, sigma=None):
     rb = scene.robot
     A = dh(g + T(rb.twist), T(rb.dh[:, 0]), T(rb.dh[:, 1]), T(rb.dh[:, 2]), rb.craig)
     frames = [T(rb.base_pose).expand(g.shape[:-1] + (4, 4))]
@@ -54,7 +54,7 @@ def log_prob(scene: orc.Scene, g):
     table = T(orc.sdf_gradient_table(scene.sdf))
     d = SDFLookup.apply(pos - T(scene.offset), table, T(scene.sdf.origin), scene.sdf.delta) - T(rb.radii)
     cost = torch.clamp(scene.epsilon - d, min=0.0)
-    return -0.5 * (cost * cost / T(scene.sigma_obs)).sum(-1)
+    return -0.5 * (cost * cost / (T(scene.sigma_obs) if sigma is None else sigma)).sum(-1)
 
 
 def matern52(t1, t2, ell, var):
@@ -63,11 +63,18 @@ def matern52(t1, t2, ell, var):
     return var * (1 + math.sqrt(5) * r + 5.0 / 3.0 * r2) * torch.exp(-math.sqrt(5) * r)
 
 
-def elbo(params: orc.Params, scene: orc.Scene, X, Zy, y, noise: orc.Noise, alpha, jitter=orc.JITTER):
-    """Returns (elbo tensor, leaf tensors dict)."""
+def elbo(params: orc.Params, scene: orc.Scene, X, Zy, y, noise: orc.Noise, alpha, jitter=orc.JITTER, lik=None):
+    """Returns (elbo tensor, leaf tensors dict).  With `lik` (orc.LikParams) alpha and sigma_obs are functions of
+    the extra leaves raw_alpha / raw_sigma (positive(lower) bijectors of GPflow: lower + softplus)."""
     rb = scene.robot
     leaves = dict(q_mu=T(params.q_mu).clone().requires_grad_(), q_sqrt=T(params.q_sqrt).clone().requires_grad_(),
                   raw_ell=T(params.raw_ell).clone().requires_grad_(), raw_var=T(params.raw_var).clone().requires_grad_())
+    sigma = None
+    if lik is not None:
+        leaves["raw_alpha"] = T(lik.raw_alpha).clone().requires_grad_()
+        leaves["raw_sigma"] = T(lik.raw_sigma).clone().requires_grad_()
+        alpha = orc.ALPHA_FLOOR + torch.nn.functional.softplus(leaves["raw_alpha"])
+        sigma = orc.SIGMA_FLOOR + torch.nn.functional.softplus(leaves["raw_sigma"])
     ell = torch.nn.functional.softplus(leaves["raw_ell"])
     var = orc.VARIANCE_FLOOR + torch.nn.functional.softplus(leaves["raw_var"])
     X, Zy = T(X), T(Zy)
@@ -104,5 +111,5 @@ def elbo(params: orc.Params, scene: orc.Scene, X, Zy, y, noise: orc.Noise, alpha
         kl = kl + 0.5 * ((wd ** 2).sum() - M - torch.log(torch.diagonal(Q) ** 2).sum() + (Q ** 2).sum())
     f = torch.stack(fs, -1)                                                          # [S, N, L]
     g = low + (high - low) * torch.sigmoid(f)
-    logp = log_prob(scene, g)
+    logp = log_prob(scene, g, sigma)
     return alpha * logp.mean(0).sum() - kl, leaves, dict(f=f, g=g, logp=logp, kl=kl)
