@@ -104,6 +104,27 @@ typedef struct vgpmp_noise {
     float* eps2;           /* dev [P, S, Mz, L] N(0,1) jitter perturbation      */
 } vgpmp_noise;
 
+/* The likelihood's constants as TRAINABLE variables (trainable_params.sigma_obs / alpha of
+ * utils/miscellaneous.py:324-343; reference default: both fixed).  Optional: with problem->lik == NULL,
+ * robot.sigma_obs and problem->alpha are the constants of every problem.  Otherwise, per problem,
+ *   alpha = 1e-4 + softplus(raw_alpha)                 (models/vgpmp.py:82, positive(1e-4))
+ *   sigma_obs[q] = 1e-5 + softplus(raw_sigma[q])       (likelihoods/likelihood.py:31-41, positive(1e-5))
+ * whatever the VGPMP_TRAIN_* bits say (the bits only gate the Adam update).  The training loss is
+ * -(ELBO + log sigmoid(raw_alpha) + sum_q log sigmoid(raw_sigma[q])): the Normal priors that
+ * disable_param_opt attaches are centred on the parameters themselves, so only the bijectors' log-det-Jacobians of
+ * GPflow's log_prior_density depend on the variables.  Not available with a sharded sample axis. */
+typedef struct vgpmp_lik_params {
+    double* raw_alpha;     /* dev [P]                       */
+    double* raw_sigma;     /* dev [P, VGPMP_MAX_SPHERES]    (entries >= num_spheres unused) */
+    double* m_alpha;       /* dev, Adam moments, same shapes (may be NULL without VGPMP_DO_ADAM) */
+    double* v_alpha;
+    double* m_sigma;
+    double* v_sigma;
+    double* g_alpha;       /* dev [P]                       out: d loss / d raw_alpha */
+    double* g_sigma;       /* dev [P, VGPMP_MAX_SPHERES]    out: d loss / d raw_sigma */
+    void* scratch;         /* dev, vgpmp_lik_scratch_bytes(dims) bytes: effective constants, per-workgroup sums */
+} vgpmp_lik_params;
+
 typedef struct vgpmp_problem {
     const double* X;       /* dev [N, D]   time grid (utils/miscellaneous.py:115-127)        */
     const double* Zy;      /* dev [Mz, D]  conditioned + inducing times (inducing_variables.py:73-82) */
@@ -115,6 +136,7 @@ typedef struct vgpmp_problem {
                              * uses *step_counter and the Adam step count is *step_counter + 1; a
                              * VGPMP_DO_ADAM step increments it on the device, so a captured hipGraph of
                              * the steps can be replayed */
+    const vgpmp_lik_params* lik; /* host pointer, optional (see vgpmp_lik_params) */
 } vgpmp_problem;
 
 /* Outputs of an ELBO evaluation. */
@@ -130,6 +152,8 @@ typedef struct vgpmp_outputs {
 #define VGPMP_TRAIN_Q_SQRT 2
 #define VGPMP_TRAIN_LENGTHSCALES 4
 #define VGPMP_TRAIN_KERNEL_VARIANCE 8
+#define VGPMP_TRAIN_SIGMA_OBS 16      /* needs problem->lik */
+#define VGPMP_TRAIN_ALPHA 32          /* needs problem->lik */
 
 #define VGPMP_DO_FORWARD 1      /* ELBO forward only (models/vgpmp.py:265-289)               */
 #define VGPMP_DO_BACKWARD 2     /* + gradient of -ELBO (utils/miscellaneous.py:77-80)        */
@@ -177,6 +201,9 @@ int vgpmp_log_prob(const vgpmp_robot* dev_robot, int32_t dof, const vgpmp_sdf* s
 /* ---- the ELBO step ------------------------------------------------------------------------- */
 
 int vgpmp_workspace_bytes(const vgpmp_dims* dims, size_t* bytes);
+
+/* Size of vgpmp_lik_params.scratch for these dimensions. */
+int vgpmp_lik_scratch_bytes(const vgpmp_dims* dims, size_t* bytes);
 
 /* Fills `noise` with the Philox-4x32-10 draws of (seed, problem index, step). */
 int vgpmp_generate_noise(const vgpmp_dims* dims, const vgpmp_noise* noise, uint32_t seed,

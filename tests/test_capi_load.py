@@ -29,7 +29,7 @@ def test_struct_sizes_match_header_layout():
     assert ctypes.sizeof(capi.Sdf) == 8 + 16 + 24 + 8
     assert ctypes.sizeof(capi.Dims) == 40
     assert ctypes.sizeof(capi.Params) == 32 and ctypes.sizeof(capi.Noise) == 40
-    assert ctypes.sizeof(capi.Problem) == 56 and ctypes.sizeof(capi.Outputs) == 64
+    assert ctypes.sizeof(capi.Problem) == 64 and ctypes.sizeof(capi.Outputs) == 64 and ctypes.sizeof(capi.LikParams) == 72
 
 
 def test_argument_errors_without_gpu():

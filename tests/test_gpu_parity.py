@@ -221,6 +221,93 @@ def test_adam_trajectory_matches_oracle():
     assert np.abs(pl.raw_var[0].cpu().numpy() - p.raw_var).max() < tol
 
 
+@pytest.mark.parametrize("S,N,P", [(8, 12, 1), (40, 50, 1), (40, 50, 9)])   # 8 / 4 / 1 lanes per configuration
+def test_likelihood_constants_gradient_against_oracle(S, N, P):
+    """trainable_params.sigma_obs / alpha (vgpmp_lik_params): gradient of the training loss wrt the two raw variables,
+    every problem of the batch with its own values."""
+    import dataclasses
+    M, B = 6, 64
+    pb = small_problem(robot="franka", S=S, N=N, M=M, B=B, seed=9, n_grid=48)
+    sc = _scene(pb["spec"], pb["grid"], pb["offset"])
+    eng = _engine()
+    ps = rb.load_problemset("franka", "industrial")
+    tr = dict(q_mu=True, q_sqrt=True, lengthscales=True, kernel_variance=True, sigma_obs=True, alpha=True)
+    pl = eng.PlannerBatch(sc, np.repeat(pb["y"][None], P, 0), lengthscales=ps.planner_params["lengthscales"],
+                          variance=ps.planner_params["variance"], trainable=tr, num_samples=S, num_inducing=M,
+                          num_data=N, num_bases=B, alpha=pb["alpha"], learning_rate=pb["lr"])
+    assert pl.lik_variables
+    p = pb["params"]
+    nsph = pb["spec"].num_spheres
+    rng = np.random.default_rng(4)
+    lps = []
+    for k in range(P):
+        pl.q_mu[k].copy_(torch.tensor(p.q_mu.T)); pl.q_sqrt[k].copy_(torch.tensor(p.q_sqrt))
+        pl.raw_ell[k].copy_(torch.tensor(p.raw_ell)); pl.raw_var[k].copy_(torch.tensor(p.raw_var))
+        lp = orc.init_lik_params(pb["alpha"] * (1.0 + 0.3 * k), pb["scene"].sigma_obs * (1.0 + rng.uniform(0, 1, nsph)))
+        pl.raw_alpha[k] = float(lp.raw_alpha)
+        pl.raw_sigma[k, :nsph] = torch.tensor(lp.raw_sigma)
+        lps.append(lp)
+    noise = _noise32(pb["noise"])
+    rep = lambda a: np.repeat(a[None], P, 0)
+    pl.set_noise(rep(noise.omega), rep(noise.beta), rep(noise.w), rep(noise.eps), rep(noise.eps2))
+    loss, grads = pl.loss_and_grad(generate=False)
+    torch.cuda.synchronize()
+    for k in range(P):
+        alpha, sigma = orc.lik_constrained(lps[k])
+        osc = dataclasses.replace(pb["scene"], sigma_obs=sigma)
+        fw = orc.elbo_forward(p, osc, pb["X"], pb["Zy"], pb["y"], noise, alpha)
+        assert (fw["logp"] < 0).any()
+        gl = orc.lik_backward(lps[k], osc, fw)
+        np.testing.assert_allclose(float(loss[k]), -fw["elbo"], rtol=3e-4)
+        # float32 FK flips a few voxels: tolerance on the scale of the gradient, as for the other variables
+        np.testing.assert_allclose(float(pl.lik_grad[0][k]), float(gl.raw_alpha), rtol=2e-3)
+        got = pl.lik_grad[1][k, :nsph].cpu().numpy()
+        assert np.abs(got - gl.raw_sigma).max() <= 2e-3 * np.abs(gl.raw_sigma).max() + 1e-6, (got, gl.raw_sigma)
+        assert np.all(pl.lik_grad[1][k, nsph:].cpu().numpy() == 0.0)
+        og, _ = orc.elbo_backward(p, osc, pb["X"], pb["Zy"], noise, alpha, fw)
+        gq = grads[0][k].cpu().numpy().T
+        assert np.abs(gq - og.q_mu).max() <= 5e-3 * np.abs(og.q_mu).max() + 1e-6
+
+
+def test_likelihood_constants_adam_trajectory_matches_oracle():
+    """Five optimisation steps with sigma_obs and alpha among the variables (one optimizer, shared step count)."""
+    import dataclasses
+    S, N, M, B = 8, 12, 6, 64
+    pb = small_problem(robot="franka", S=S, N=N, M=M, B=B, seed=9, n_grid=48)
+    sc = _scene(pb["spec"], pb["grid"], pb["offset"])
+    tr = dict(orc.DEFAULT_TRAINABLE, sigma_obs=True, alpha=True)
+    pl = _planner(pb, sc, S, N, M, B, split_k=1, trainable=tr)
+    nsph = pb["spec"].num_spheres
+    p = pb["params"].copy(); st = orc.adam_init(p)
+    lp = orc.init_lik_params(pb["alpha"], pb["scene"].sigma_obs)
+    np.testing.assert_allclose(pl.raw_alpha[0].item(), float(lp.raw_alpha), rtol=1e-12)
+    np.testing.assert_allclose(pl.raw_sigma[0, :nsph].cpu().numpy(), lp.raw_sigma, rtol=1e-12)
+    lp = orc.init_lik_params(3.0, pb["scene"].sigma_obs)          # small alpha: the bijector's slope matters
+    pl.raw_alpha[0] = float(lp.raw_alpha)
+    lp0 = lp.copy()
+    zl = lambda: orc.LikParams(np.zeros(()), np.zeros(nsph))
+    st_lik = dict(m=zl(), v=zl())
+    rng = np.random.default_rng(3)
+    active = False
+    for step in range(5):
+        noise = _noise32(orc.draw_noise(rng, S, 7, 7, B, M + 2))
+        _inject(pl, noise)
+        pl.step(generate=False)
+        alpha, sigma = orc.lik_constrained(lp)
+        fw = orc.elbo_forward(p, dataclasses.replace(pb["scene"], sigma_obs=sigma), pb["X"], pb["Zy"], pb["y"], noise, alpha)
+        active = active or bool((fw["logp"] < 0).any())
+        orc.optimization_step_lik(p, lp, st, st_lik, pb["scene"], pb["X"], pb["Zy"], pb["y"], noise, pb["lr"], tr)
+    assert active, "fixture must have active hinge terms"
+    tol = 5 * pb["lr"] * 2e-2
+    assert abs(pl.raw_alpha[0].item() - float(lp.raw_alpha)) < tol
+    assert np.abs(pl.raw_sigma[0, :nsph].cpu().numpy() - lp.raw_sigma).max() < tol
+    assert np.abs(pl.q_mu[0].cpu().numpy().T - p.q_mu).max() < tol
+    assert np.abs(pl.raw_ell[0].cpu().numpy() - p.raw_ell).max() < tol
+    # the variables did move
+    assert abs(float(lp.raw_alpha) - float(lp0.raw_alpha)) > pb["lr"]
+    assert np.abs(lp.raw_sigma - lp0.raw_sigma).min() > pb["lr"]
+
+
 def test_device_philox_matches_oracle_stream():
     S, N, M, B = 5, 6, 4, 32
     pb = small_problem(robot="franka", S=S, N=N, M=M, B=B, seed=1, n_grid=16)

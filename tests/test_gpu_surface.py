@@ -91,7 +91,17 @@ def test_model_surface_against_oracle():
     assert (best >= osc.robot.low - 1e-6).all() and (best <= osc.robot.high + 1e-6).all()
     assert model.get_best_sample(samples) in range(7)
     with pytest.raises(NotImplementedError):
-        disable_param_opt(model, dict(env.config["trainable_params"], alpha=True))
+        disable_param_opt(model, dict(env.config["trainable_params"], inducing_variable=True))
+    # sigma_obs / alpha as variables (reference default False): the device batch is rebuilt with them and the host
+    # parameters follow the trained values
+    disable_param_opt(model, dict(env.config["trainable_params"], alpha=True, sigma_obs=True))
+    assert model.alpha.trainable and model.likelihood.variance.trainable
+    a0, s0 = float(model.alpha), np.array(model.likelihood.variance.numpy(), copy=True)
+    training_loop(model, X, 10)
+    assert model._planner.lik_variables and float(model.alpha) != a0
+    assert model.likelihood.variance.numpy().shape == s0.shape and not np.allclose(model.likelihood.variance.numpy(), s0)
+    mu, best, samples, unc = model.sample_from_posterior(orc.init_trainset(20, 7), env.robot)
+    assert np.isfinite(best).all()
 
 
 def test_sample_sharding_two_ranks_equal_full_batch():
@@ -164,6 +174,17 @@ def test_trainable_flags_freeze_parameters():
         pl.step()
     assert not torch.equal(pl.q_mu, q0) and not torch.equal(pl.raw_var, v0)
     assert torch.equal(pl.q_sqrt, s0) and torch.equal(pl.raw_ell, e0)
+    # likelihood constants as variables: sigma_obs trained, alpha present but frozen
+    pl = engine.PlannerBatch(sc, pb["y"][None], num_samples=8, num_inducing=5, num_data=10, num_bases=32,
+                             lengthscales=[2.0] * 7, variance=0.2, trainable=dict(q_mu=True, q_sqrt=True, lengthscales=True,
+                             kernel_variance=True, sigma_obs=True, alpha=False))
+    a0, g0 = pl.raw_alpha.clone(), pl.raw_sigma.clone()
+    for _ in range(3):
+        pl.step()
+    n = pb["spec"].num_spheres
+    assert torch.equal(pl.raw_alpha, a0) and not torch.equal(pl.raw_sigma[:, :n], g0[:, :n])
+    assert torch.equal(pl.raw_sigma[:, n:], g0[:, n:])
+    assert float((pl.sigma_obs() - 0.005).abs().max()) > 1e-5 and float(pl.alphas()[0]) == pytest.approx(100.0)
 
 
 def test_graph_replay_matches_eager_steps():
@@ -204,6 +225,35 @@ def test_pipelined_steps_equal_single_step_calls(P):
         assert torch.allclose(x, y, rtol=0, atol=1e-11), float((x - y).abs().max())
     assert torch.equal(a.eps, b.eps) and torch.equal(a.w, b.w)
     assert torch.allclose(a.lik, b.lik, rtol=1e-12) and torch.allclose(a.kl, b.kl, rtol=1e-12)
+
+
+def test_pipelined_steps_with_trainable_likelihood_constants():
+    """sigma_obs / alpha among the variables: the chained schedule (their update rides between the reverse pass of
+    step t and stage 1 of step t+1) equals one call per step with one launch per kernel."""
+    from vgpmp_amd import engine
+    ps = rb.load_problemset("franka", "industrial")
+    spec = rb.load_robot("franka")
+    grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
+    sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
+    qs = np.array([ps.queries[i] for i in range(2)])
+    tr = dict(q_mu=True, q_sqrt=True, lengthscales=True, kernel_variance=True, sigma_obs=True, alpha=True)
+    kw = dict(num_samples=32, num_inducing=12, num_data=40, num_bases=128, lengthscales=[2.0] * 7, variance=0.2, seed=3,
+              alpha=4.0, trainable=tr)
+    a, b = engine.PlannerBatch(sc, qs, **kw), engine.PlannerBatch(sc, qs, **kw)
+    b.fuse = False
+    a.run_steps(12)
+    for _ in range(12):
+        b.run_steps(1)
+    torch.cuda.synchronize()
+    n = spec.num_spheres
+    for x, y in ((a.q_mu, b.q_mu), (a.raw_ell, b.raw_ell), (a.raw_alpha, b.raw_alpha), (a.raw_sigma[:, :n], b.raw_sigma[:, :n]),
+                 (a.lik_adam_v[1][:, :n], b.lik_adam_v[1][:, :n])):
+        assert torch.allclose(x, y, rtol=0, atol=1e-11), float((x - y).abs().max())
+    assert torch.allclose(a.lik, b.lik, rtol=1e-12)
+    assert float((a.raw_alpha - a.raw_alpha[0]).abs().max()) > 0 or float(a.lik.abs().max()) == 0      # problems differ
+    moved = (a.raw_sigma[:, :n] - engine.torch.tensor(engine.softplus_inverse(np.full(n, 0.005) - engine.SIGMA_FLOOR),
+                                                      device=a.raw_sigma.device)).abs()
+    assert float(moved.min()) > 0.05
 
 
 def test_split_path_kernels_equal_one_workgroup_form():

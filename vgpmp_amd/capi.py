@@ -15,13 +15,14 @@ import numpy as np
 
 MAX_DOF, MAX_SPHERES, MAX_MZ = 16, 64, 48
 TRAIN_Q_MU, TRAIN_Q_SQRT, TRAIN_LENGTHSCALES, TRAIN_KERNEL_VARIANCE = 1, 2, 4, 8
+TRAIN_SIGMA_OBS, TRAIN_ALPHA = 16, 32      # need Problem.lik
 DO_FORWARD, DO_BACKWARD, DO_ADAM, GEN_NOISE, NO_FUSE = 1, 2, 4, 8, 16
 GEMM_DIRECT, NO_SPLIT = 32, 64
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvgpmp_hip.so"
 
 EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_pack", "vgpmp_mesh_sdf", "vgpmp_fk_spheres", "vgpmp_sdf_query",
-           "vgpmp_log_prob", "vgpmp_workspace_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
+           "vgpmp_log_prob", "vgpmp_workspace_bytes", "vgpmp_lik_scratch_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
            "vgpmp_elbo_steps", "vgpmp_elbo_step_profiled", "vgpmp_adam_step", "vgpmp_workspace_view")
 NUM_STAGES = 8
 NUM_TIMES = 10
@@ -64,9 +65,17 @@ class Noise(C.Structure):
                 ("eps2", C.c_void_p)]
 
 
+class LikParams(C.Structure):
+    """vgpmp_lik_params: sigma_obs / alpha as trainable variables (device pointers)."""
+    _fields_ = [("raw_alpha", C.c_void_p), ("raw_sigma", C.c_void_p), ("m_alpha", C.c_void_p), ("v_alpha", C.c_void_p),
+                ("m_sigma", C.c_void_p), ("v_sigma", C.c_void_p), ("g_alpha", C.c_void_p), ("g_sigma", C.c_void_p),
+                ("scratch", C.c_void_p)]
+
+
 class Problem(C.Structure):
     _fields_ = [("X", C.c_void_p), ("Zy", C.c_void_p), ("y_u", C.c_void_p), ("alpha", C.c_double),
-                ("jitter", C.c_double), ("kl_scale", C.c_double), ("step_counter", C.c_void_p)]
+                ("jitter", C.c_double), ("kl_scale", C.c_double), ("step_counter", C.c_void_p),
+                ("lik", C.POINTER(LikParams))]
 
 
 class Outputs(C.Structure):

@@ -74,6 +74,15 @@ int vgpmp_workspace_bytes(const vgpmp_dims* dims, size_t* bytes) {
     return 0;
 }
 
+int vgpmp_lik_scratch_bytes(const vgpmp_dims* dims, size_t* bytes) {
+    if (!dims || !bytes) return VGPMP_E_ARG;
+    int rc = vg_check_dims(dims);
+    if (rc) return rc;
+    vg_lik_scratch sc;
+    *bytes = vg_layout_lik_scratch(dims, nullptr, &sc);
+    return 0;
+}
+
 int vgpmp_generate_noise(const vgpmp_dims* dims, const vgpmp_noise* noise, uint32_t seed, uint32_t problem_base,
                          uint32_t step, vgpmp_stream stream) {
     if (!dims || !noise || !noise->omega || !noise->beta || !noise->w || !noise->eps || !noise->eps2) return VGPMP_E_ARG;
@@ -102,6 +111,13 @@ static int elbo_step_impl(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, 
     if ((what & VGPMP_DO_ADAM) &&
         (!(what & VGPMP_DO_BACKWARD) || !adam_m || !adam_v || (adam_t < 1 && !problem->step_counter)))
         return VGPMP_E_ARG;
+    if ((trainable & (VGPMP_TRAIN_SIGMA_OBS | VGPMP_TRAIN_ALPHA)) && !problem->lik) return VGPMP_E_ARG;
+    if (const vgpmp_lik_params* lk = problem->lik) {
+        if (!lk->raw_alpha || !lk->raw_sigma || !lk->scratch || dims->S_total != dims->S) return VGPMP_E_ARG;
+        if ((what & VGPMP_DO_BACKWARD) && (!lk->g_alpha || !lk->g_sigma)) return VGPMP_E_ARG;
+        if ((what & VGPMP_DO_ADAM) && (trainable & VGPMP_TRAIN_ALPHA) && (!lk->m_alpha || !lk->v_alpha)) return VGPMP_E_ARG;
+        if ((what & VGPMP_DO_ADAM) && (trainable & VGPMP_TRAIN_SIGMA_OBS) && (!lk->m_sigma || !lk->v_sigma)) return VGPMP_E_ARG;
+    }
     vg_workspace ws;
     size_t need = vg_layout_workspace(dims, dev_workspace, &ws);
     if (workspace_bytes < need) return VGPMP_E_WORKSPACE;

@@ -178,9 +178,16 @@ __device__ __forceinline__ void lik_wave_sync() {
 // not memory -- bounds this kernel when few problems are in flight, hence the split.
 // With GRAD, d logp / d g_j is handed to `emit(j, value)` on lane j % LPC.  get_g(j) is called on lane
 // j % LPC only.  Returns the group's total on every lane.
-template <bool GRAD, int LPC, typename GetG, typename Emit>
+// With SIG (trainable sigma_obs, LPC == 1 only) the per-sphere variances come from `sig` and every sphere's
+// c^2 / sigma, weighted by sig_w (0 on dead lanes), is summed over the wave and handed to emit_sig(q, total).
+struct NoSig { __device__ __forceinline__ void operator()(int, float) const {} };
+template <bool GRAD, int LPC, bool SIG = false, typename GetG, typename Emit, typename EmitSig = NoSig>
 __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ rb, const vg_sdf_dev& sdf,
-                                               const LikScratch sc, int sub, GetG get_g, Emit emit, int dbg = 0) {
+                                               const LikScratch sc, int sub, GetG get_g, Emit emit, int dbg = 0,
+                                               const float* __restrict__ sig = nullptr, float sig_w = 0.f,
+                                               EmitSig emit_sig = NoSig()) {
+    static_assert(!SIG || LPC == 1, "per-sphere sums are wave sums of one-lane configurations");
+    const float* __restrict__ sigma = SIG ? sig : rb->sigma_obs;
     const int D = rb->dof, P = rb->num_spheres;
     const float eps = rb->epsilon;
     const double offx = rb->scene_offset[0], offy = rb->scene_offset[1], offz = rb->scene_offset[2];
@@ -226,8 +233,12 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
                 const int q = min(q0 + u, pe - 1);
                 const float wgt = (q0 + u < pe) ? 1.f : 0.f;
                 float c = fmaxf(eps - (v[u].x - rb->radius[q]), 0.f) * wgt;     // likelihood.py:131-143
-                float cs = c / rb->sigma_obs[q];
+                float cs = c / sigma[q];
                 acc = fmaf(cs, c, acc);                                          // likelihood.py:99
+                if (SIG) {      // q is uniform over the wave here (LPC == 1): one total per sphere
+                    const float t = vg_wave_sum(cs * c * sig_w);
+                    if (q0 + u < pe) emit_sig(q, t);
+                }
                 if (GRAD) {
                     vg_float3 gp = vg_make3(cs * v[u].y, cs * v[u].z, cs * v[u].w);   // d logp / d pos
                     F = vg_make3(F.x + gp.x, F.y + gp.y, F.z + gp.z);
@@ -297,12 +308,16 @@ __global__ __launch_bounds__(kLikBlock) void log_prob_kernel(const vgpmp_robot* 
 // ---- ELBO path: f [P,S,L,N] -> logp [P,S,N], G = dloss/df [P,S,L,N], block partial sums ----------
 // LPC lanes per (sample, time) configuration; BLK / LPC configurations per workgroup.  Large batches run one-wave
 // workgroups (kLikBatchBlock): 188 instead of 204 us per launch at 64 problems (finer tail).
-template <int LPC, int BLK>
+template <int LPC, int BLK, bool SIG = false>
 __global__ __launch_bounds__(BLK) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
                                                                   const float* __restrict__ f, int S, int L, int N,
                                                                   float scale, float* __restrict__ G,
                                                                   float* __restrict__ logp,
-                                                                  float* __restrict__ lik_partial, int dbg) {
+                                                                  float* __restrict__ lik_partial, int dbg,
+                                                                  const float* __restrict__ alpha_eff = nullptr,
+                                                                  const float* __restrict__ sigma_eff = nullptr,
+                                                                  float* __restrict__ sig_partial = nullptr) {
+    static_assert(!SIG || BLK == VG_WAVE, "per-sphere sums of a workgroup are one wave's sums");
     extern __shared__ float lik_lds[];
     __shared__ float red[BLK / VG_WAVE];
 #ifdef VGPMP_BISECT
@@ -322,7 +337,9 @@ __global__ __launch_bounds__(BLK) void loglik_paths_kernel(const vgpmp_robot* __
         const size_t base = ((size_t)pb * S + s) * L * N + n;
         const LikScratch sc{lik_lds + cl, CPB};
         float* dgdf = lik_lds + (size_t)lik_scratch_slots(L) * CPB + cl;   // [L][CPB]
-        lp = loglik_config<true, LPC>(
+        const float scl = SIG ? -alpha_eff[pb] : scale;
+        float* sp = SIG ? sig_partial + ((size_t)pb * gridDim.x + blockIdx.x) * VGPMP_MAX_SPHERES : nullptr;
+        lp = loglik_config<true, LPC, SIG>(
             rb, sdf, sc, sub,
             [&](int j) {
                 const float sg = 1.0f / (1.0f + __expf(-f[base + (size_t)j * N]));       // likelihood.py:49-52
@@ -330,7 +347,9 @@ __global__ __launch_bounds__(BLK) void loglik_paths_kernel(const vgpmp_robot* __
                 dgdf[j * CPB] = span * sg * (1.0f - sg);
                 return fmaf(span, sg, rb->low[j]);
             },
-            [&](int j, float v) { if (live) G[base + (size_t)j * N] = scale * v * dgdf[j * CPB]; }, dbg);
+            [&](int j, float v) { if (live) G[base + (size_t)j * N] = scl * v * dgdf[j * CPB]; }, dbg,
+            SIG ? sigma_eff + (size_t)pb * VGPMP_MAX_SPHERES : nullptr, live ? 1.f : 0.f,
+            [&](int q, float t) { if (threadIdx.x == 0) sp[q] = t; });
         if (live && sub == 0) logp[((size_t)pb * S + s) * N + n] = lp;
     }
     float w = vg_wave_sum(live && sub == 0 ? lp : 0.f);
@@ -364,12 +383,15 @@ static size_t wide_lds_bytes(int D, int lanes) {
     return sizeof(vgpmp_robot) + ((size_t)(2 * D + 12 * (D + 1) + D) * cpb + (size_t)6 * (D + 1) * kLikBlock) * sizeof(float);
 }
 
-template <int LPC>
+template <int LPC, bool SIG = false>
 __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpmp_robot* __restrict__ rb_g, vgpmp_sdf sdfh,
                                                                        const float* __restrict__ f, int S, int L, int N,
                                                                        float scale, float* __restrict__ G,
                                                                        float* __restrict__ logp,
-                                                                       float* __restrict__ lik_partial) {
+                                                                       float* __restrict__ lik_partial,
+                                                                       const float* __restrict__ alpha_eff = nullptr,
+                                                                       const float* __restrict__ sigma_eff = nullptr,
+                                                                       float* __restrict__ sig_partial = nullptr) {
     extern __shared__ float lik_lds[];
     __shared__ float red[kLikBlock / VG_WAVE];
     constexpr int CPB = kLikBlock / LPC, kWideU = kWideSpheres / LPC;
@@ -389,13 +411,24 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
 #pragma unroll
     for (int k = 0; k < VGPMP_MAX_DOF / LPC; ++k) fv[k] = f[base + (size_t)min(sub + LPC * k, L - 1) * N];
     static_assert(VGPMP_MAX_DOF % LPC == 0, "joints are dealt to the lanes of a group");
+    // trainable sigma_obs: this problem's variances replace the table's (requested before the wait, stored after it)
+    float sig_own = 0.f;
+    if (SIG && tid < VGPMP_MAX_SPHERES) sig_own = sigma_eff[(size_t)pb * VGPMP_MAX_SPHERES + tid];
+    const float scl = SIG ? -alpha_eff[pb] : scale;
     vg_dma_wait();
     __syncthreads();
+    if (SIG) {
+        if (tid < VGPMP_MAX_SPHERES) const_cast<vgpmp_robot*>(rb)->sigma_obs[tid] = sig_own;
+        __syncthreads();
+    }
     VG_T(blockIdx.x == 0 && pb == 0, 402);
     const int D = rb->dof, P = rb->num_spheres;
     float* grp = lik_lds + sizeof(vgpmp_robot) / sizeof(float) + cl;                 // [slot][CPB]
     float* dgdf = lik_lds + sizeof(vgpmp_robot) / sizeof(float) + (size_t)wide_group_slots(D) * CPB + cl;   // [D][CPB]
     float* mine = lik_lds + sizeof(vgpmp_robot) / sizeof(float) + (size_t)(wide_group_slots(D) + D) * CPB + tid;   // [slot][block]
+    // SIG: c^2 / sigma of every (configuration, sphere) of the workgroup, [CPB][MAX_SPHERES], summed in fixed order below
+    float* sgl = lik_lds + sizeof(vgpmp_robot) / sizeof(float) + (size_t)(wide_group_slots(D) + D) * CPB +
+                 (size_t)wide_lane_slots(D) * kLikBlock;
     auto gs = [&](int slot) -> float& { return grp[slot * CPB]; };
     auto ms = [&](int slot) -> float& { return mine[slot * kLikBlock]; };
     // ---- joint angles: sigmoid to the limits (likelihood.py:49-52), sin / cos
@@ -502,6 +535,7 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
             const float c = fmaxf(eps - (v[u].x - rb->radius[q]), 0.f) * wgt;       // likelihood.py:131-143
             const float cs = c / rb->sigma_obs[q];
             acc = fmaf(cs, c, acc);                                                  // likelihood.py:99
+            if (SIG && qq < P) sgl[cl * VGPMP_MAX_SPHERES + q] = live ? cs * c : 0.f;
             const vg_float3 gp = vg_make3(cs * v[u].y, cs * v[u].z, cs * v[u].w);   // d logp / d pos
             if (fr[u] != cur) {                          // spheres are sorted by frame: each slot is written once
                 flush();
@@ -545,7 +579,7 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
 #pragma unroll
         for (int k = 0; k < 2; ++k) t2[k] = (h2 ? t4[k + 2] : t4[k]) + __shfl_xor(h2 ? t4[k] : t4[k + 2], 2, VG_WAVE);
         const float val = (h1 ? t2[1] : t2[0]) + __shfl_xor(h1 ? t2[0] : t2[1], 1, VG_WAVE);
-        if (sub < L && live) vg_stream(G + base + (size_t)sub * N, scale * val * dg0);
+        if (sub < L && live) vg_stream(G + base + (size_t)sub * N, scl * val * dg0);
     } else {
         const bool craig = rb->craig != 0;
         vg_float3 Fs = vg_make3(0.f, 0.f, 0.f), Ms = vg_make3(0.f, 0.f, 0.f);
@@ -559,7 +593,7 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
             const vg_float3 z = vg_make3(gs(fo + 6), gs(fo + 7), gs(fo + 8)), org = vg_make3(gs(fo + 9), gs(fo + 10), gs(fo + 11));
             const vg_float3 oxF = vg_cross(org, Fs);
             const float val = quad_sum<LPC>(vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)));
-            if ((i - 1) % LPC == sub && live) vg_stream(G + base + (size_t)(i - 1) * N, scale * val * dgdf[(i - 1) * CPB]);
+            if ((i - 1) % LPC == sub && live) vg_stream(G + base + (size_t)(i - 1) * N, scl * val * dgdf[(i - 1) * CPB]);
         }
     }
     if (live && sub == 0) logp[((size_t)pb * S + s) * N + n] = lp;
@@ -571,6 +605,12 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
 #pragma unroll
         for (int k = 0; k < kLikBlock / VG_WAVE; ++k) t += red[k];
         lik_partial[(size_t)pb * gridDim.x + blockIdx.x] = t;
+    }
+    if (SIG && tid < VGPMP_MAX_SPHERES) {      // per-sphere sum over the workgroup's configurations, fixed order
+        float t = 0.f;
+        if (tid < P)
+            for (int c = 0; c < CPB; ++c) t += sgl[c * VGPMP_MAX_SPHERES + tid];
+        sig_partial[((size_t)pb * gridDim.x + blockIdx.x) * VGPMP_MAX_SPHERES + tid] = t;
     }
     VG_T(blockIdx.x == 0 && pb == 0, 401);
     VG_T(blockIdx.x == gridDim.x - 1 && pb == 0, 405);
@@ -704,31 +744,50 @@ int vg_launch_log_prob_impl(const vgpmp_robot* rb, int dof, const vgpmp_sdf* sdf
 
 int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const float* f, int P, int S, int L, int N,
                            float scale, float* G, float* logp, float* lik_partial, int* nblk_out, hipStream_t st,
-                           hipEvent_t k0, hipEvent_t k1) {
+                           hipEvent_t k0, hipEvent_t k1, const float* alpha_eff, const float* sigma_eff,
+                           float* sig_partial) {
     const int lpc = lik_lpc(P, S, N);
     const int blk = lpc > 1 ? kLikBlock : kLikBatchBlock;
     const int nblk = (S * N * lpc + blk - 1) / blk;
     if (nblk_out) *nblk_out = nblk;
     if (P == 0 || nblk == 0) return 0;
-    static size_t granted1 = 0, granted4 = 0, granted8 = 0;
-    const size_t lds = lpc > 1 ? wide_lds_bytes(L, lpc) : lik_lds_bytes(L, true) * kLikBatchBlock / kLikBlock;
-    int rc = lpc == 8 ? lik_grant_lds((const void*)loglik_paths_wide_kernel<8>, lds, &granted8)
-           : lpc == 4 ? lik_grant_lds((const void*)loglik_paths_wide_kernel<4>, lds, &granted4)
-                      : lik_grant_lds((const void*)loglik_paths_kernel<1, kLikBatchBlock>, lds, &granted1);
+    const bool sig = alpha_eff != nullptr;      // trainable likelihood constants: per-problem alpha / sigma_obs, per-sphere sums
+    if (sig && (!sigma_eff || !sig_partial)) return VGPMP_E_ARG;
+    static size_t granted[6] = {0, 0, 0, 0, 0, 0};
+    const size_t lds = lpc > 1 ? wide_lds_bytes(L, lpc) + (sig ? (size_t)(kLikBlock / lpc) * VGPMP_MAX_SPHERES * sizeof(float) : 0)
+                               : lik_lds_bytes(L, true) * kLikBatchBlock / kLikBlock;
+    const void* fn = lpc == 8 ? (sig ? (const void*)loglik_paths_wide_kernel<8, true> : (const void*)loglik_paths_wide_kernel<8, false>)
+                   : lpc == 4 ? (sig ? (const void*)loglik_paths_wide_kernel<4, true> : (const void*)loglik_paths_wide_kernel<4, false>)
+                              : (sig ? (const void*)loglik_paths_kernel<1, kLikBatchBlock, true>
+                                     : (const void*)loglik_paths_kernel<1, kLikBatchBlock, false>);
+    int rc = lik_grant_lds(fn, lds, &granted[(lpc == 8 ? 0 : lpc == 4 ? 2 : 4) + (sig ? 1 : 0)]);
     if (rc) return rc;
     int dbg = 0;
 #ifdef VGPMP_BISECT
     dbg = lik_bisect_mode();
 #endif
     // k0 / k1 (profiler): events stamped with the kernel's own start and end on the device
-    if (lpc == 8)
-        hipExtLaunchKernelGGL(loglik_paths_wide_kernel<8>, dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf, f, S, L,
-                              N, scale, G, logp, lik_partial);
-    else if (lpc == 4)
-        hipExtLaunchKernelGGL(loglik_paths_wide_kernel<4>, dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf, f, S, L,
-                              N, scale, G, logp, lik_partial);
-    else
-        hipExtLaunchKernelGGL((loglik_paths_kernel<1, kLikBatchBlock>), dim3(nblk, P), dim3(kLikBatchBlock), lds, st, k0, k1, 0, rb, *sdf, f, S, L, N,
-                              scale, G, logp, lik_partial, dbg);
+    if (lpc == 8) {
+        if (sig)
+            hipExtLaunchKernelGGL((loglik_paths_wide_kernel<8, true>), dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf,
+                                  f, S, L, N, scale, G, logp, lik_partial, alpha_eff, sigma_eff, sig_partial);
+        else
+            hipExtLaunchKernelGGL((loglik_paths_wide_kernel<8, false>), dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf,
+                                  f, S, L, N, scale, G, logp, lik_partial, nullptr, nullptr, nullptr);
+    } else if (lpc == 4) {
+        if (sig)
+            hipExtLaunchKernelGGL((loglik_paths_wide_kernel<4, true>), dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf,
+                                  f, S, L, N, scale, G, logp, lik_partial, alpha_eff, sigma_eff, sig_partial);
+        else
+            hipExtLaunchKernelGGL((loglik_paths_wide_kernel<4, false>), dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf,
+                                  f, S, L, N, scale, G, logp, lik_partial, nullptr, nullptr, nullptr);
+    } else {
+        if (sig)
+            hipExtLaunchKernelGGL((loglik_paths_kernel<1, kLikBatchBlock, true>), dim3(nblk, P), dim3(kLikBatchBlock), lds, st, k0, k1,
+                                  0, rb, *sdf, f, S, L, N, scale, G, logp, lik_partial, dbg, alpha_eff, sigma_eff, sig_partial);
+        else
+            hipExtLaunchKernelGGL((loglik_paths_kernel<1, kLikBatchBlock, false>), dim3(nblk, P), dim3(kLikBatchBlock), lds, st, k0,
+                                  k1, 0, rb, *sdf, f, S, L, N, scale, G, logp, lik_partial, dbg, nullptr, nullptr, nullptr);
+    }
     return (int)hipGetLastError();
 }

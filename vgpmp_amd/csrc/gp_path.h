@@ -43,6 +43,15 @@ inline size_t vg_part_len(const vgpmp_dims* d) {
     return mz + mz * mz + 8;      // dm, dC, two sets of {s_ell, s_var, s_rff, -}
 }
 
+// vgpmp_lik_params.scratch: effective likelihood constants and the per-workgroup per-sphere sums of the likelihood
+struct vg_lik_scratch {
+    double* alpha_fin;     // [P]  alpha / S of the step whose ELBO pieces `final` reports
+    float* alpha_eff;      // [P]  alpha / S the next likelihood launch uses
+    float* sigma_eff;      // [P, MAX_SPHERES]
+    float* sig_partial;    // [P, blocks per problem, MAX_SPHERES]  sum over a workgroup's configurations of c^2 / sigma
+};
+size_t vg_layout_lik_scratch(const vgpmp_dims* d, void* base, vg_lik_scratch* out);
+
 int vg_check_dims(const vgpmp_dims* d);
 size_t vg_layout_workspace(const vgpmp_dims* d, void* base, vg_workspace* ws);
 int vg_workspace_lookup(const vgpmp_dims* d, const vg_workspace* ws, const char* name, void** ptr, size_t* count,

@@ -661,6 +661,7 @@ struct FinalArgs {
     const float *part, *Lk32, *lik_partial;
     const double *gkl_qmu, *gkl_Q, *kl_l;
     double kl_scale, lik_scale;
+    const double* alpha_fin;  // [P] per-problem alpha / S (trainable likelihood constants), else lik_scale
     double *out_lik, *out_kl;
     double *g_qmu, *g_qsqrt;
     int do_adam, trainable;
@@ -1857,7 +1858,7 @@ __device__ __forceinline__ void final_body(const FinalArgs& b, double* sm, int l
     }
     VG_STOP(b, 2);
     VG_T(l == 0 && p == 0, 112);
-    if (l == 0) elbo_pieces(b.lik_partial, b.nblk, b.kl_l, L, p, b.lik_scale, kls, b.out_lik, b.out_kl);
+    if (l == 0) elbo_pieces(b.lik_partial, b.nblk, b.kl_l, L, p, b.alpha_fin ? b.alpha_fin[p] : b.lik_scale, kls, b.out_lik, b.out_kl);
     VG_T(l == 0 && p == 0, 113);
 }
 
@@ -1869,8 +1870,9 @@ __global__ __launch_bounds__(kBlock) void final_kernel(FinalArgs b) {
 // forward-only epilogue: ELBO pieces without the reverse pass
 __global__ __launch_bounds__(kBlock) void elbo_pieces_kernel(int L, int nblk, const float* __restrict__ lik_partial,
                                                               const double* __restrict__ kl_l, double lik_scale, double kls,
-                                                              double* __restrict__ out_lik, double* __restrict__ out_kl) {
-    elbo_pieces(lik_partial, nblk, kl_l, L, blockIdx.x, lik_scale, kls, out_lik, out_kl);
+                                                              double* __restrict__ out_lik, double* __restrict__ out_kl,
+                                                              const double* __restrict__ alpha_fin) {
+    elbo_pieces(lik_partial, nblk, kl_l, L, blockIdx.x, alpha_fin ? alpha_fin[blockIdx.x] : lik_scale, kls, out_lik, out_kl);
 }
 
 // stand-alone Adam over the packed variables (sample-sharded mode, after the gradient all-reduce)
@@ -1983,6 +1985,77 @@ __global__ __launch_bounds__(kBlock) void stage3_kernel(Stage3Args a) {
     rng_normals_body(a.rng, b % a.w_gx, b / a.w_gx, a.rng.nW, 0u);
 }
 
+// ---- likelihood constants as trainable variables (vgpmp_lik_params) -----------------------------------------
+constexpr double kAlphaFloor = 1e-4, kSigmaFloor = 1e-5;      // models/vgpmp.py:82, likelihoods/likelihood.py:31,41
+
+struct LikConstArgs {
+    const double *raw_alpha, *raw_sigma;
+    vg_lik_scratch sc;
+    double inv_s;          // 1 / S_total
+};
+// effective constants from the raw variables (start of every call): one wave per problem, one lane per sphere
+__global__ __launch_bounds__(VGPMP_MAX_SPHERES) void lik_consts_kernel(LikConstArgs a) {
+    const int p = blockIdx.x, q = threadIdx.x;
+    if (q == 0) {
+        const double al = (kAlphaFloor + softplus_d(a.raw_alpha[p])) * a.inv_s;
+        a.sc.alpha_fin[p] = al;
+        a.sc.alpha_eff[p] = (float)al;
+    }
+    a.sc.sigma_eff[(size_t)p * VGPMP_MAX_SPHERES + q] = (float)(kSigmaFloor + softplus_d(a.raw_sigma[(size_t)p * VGPMP_MAX_SPHERES + q]));
+}
+
+struct LikUpdArgs {
+    const vgpmp_robot* rb;
+    const float *lik_partial, *sig_partial;
+    int nblk;
+    double inv_s;          // 1 / S_total
+    double *raw_alpha, *raw_sigma, *m_alpha, *v_alpha, *m_sigma, *v_sigma, *g_alpha, *g_sigma;
+    vg_lik_scratch sc;
+    int do_adam, trainable;
+    const uint32_t* ctr;   // ticked device counter (then the step size comes from it), else lr_t
+    double lr, lr_t;
+};
+// gradient of the training loss wrt (raw_alpha, raw_sigma) of one problem, Adam, and the constants of the next step.
+//   loss = -(ELBO + log sigmoid(raw_alpha) + sum_q log sigmoid(raw_sigma_q))      (vgpmp.h: vgpmp_lik_params)
+//   d ELBO / d alpha = (1/S) sum_{s,n} logp,   d ELBO / d sigma_q = (alpha/S) 1/2 sum_{s,n} c_q^2 / sigma_q^2
+// One wave per problem, lane q = sphere q; sums over the likelihood's workgroups in fixed order.
+__global__ __launch_bounds__(VGPMP_MAX_SPHERES) void lik_update_kernel(LikUpdArgs a) {
+    const int p = blockIdx.x, q = threadIdx.x, nsph = a.rb->num_spheres;
+    double ls = 0.0;
+    for (int b = q; b < a.nblk; b += VGPMP_MAX_SPHERES) ls += (double)a.lik_partial[(size_t)p * a.nblk + b];
+    ls = vg_wave_sum(ls);                                        // sum_{s,n} logp
+    double c2 = 0.0;
+    const float* sp = a.sig_partial + (size_t)p * a.nblk * VGPMP_MAX_SPHERES + q;
+    int b = 0;
+    for (; b + 7 < a.nblk; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = sp[(size_t)(b + k) * VGPMP_MAX_SPHERES];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c2 += (double)v[k];
+    }
+    for (; b < a.nblk; ++b) c2 += (double)sp[(size_t)b * VGPMP_MAX_SPHERES];      // sum_{s,n} c_q^2 / sigma_q
+    const size_t pq = (size_t)p * VGPMP_MAX_SPHERES + q;
+    const double lr_t = a.ctr ? adam_step_size(a.lr, (double)*a.ctr) : a.lr_t;
+    double ra = a.raw_alpha[p], rs = a.raw_sigma[pq];
+    const double alpha = kAlphaFloor + softplus_d(ra), sigma = kSigmaFloor + softplus_d(rs);
+    const double gs = q < nsph ? -(alpha * a.inv_s * 0.5 * c2 / sigma * sigmoid_d(rs) + sigmoid_d(-rs)) : 0.0;
+    a.g_sigma[pq] = gs;
+    if (a.do_adam && (a.trainable & VGPMP_TRAIN_SIGMA_OBS) && q < nsph) adam_update(&rs, a.m_sigma + pq, a.v_sigma + pq, gs, lr_t);
+    if (a.do_adam && (a.trainable & VGPMP_TRAIN_SIGMA_OBS)) a.raw_sigma[pq] = rs;
+    a.sc.sigma_eff[pq] = (float)(kSigmaFloor + softplus_d(rs));
+    if (q == 0) {
+        const double ga = -(ls * a.inv_s * sigmoid_d(ra) + sigmoid_d(-ra));
+        a.g_alpha[p] = ga;
+        a.sc.alpha_fin[p] = alpha * a.inv_s;
+        if (a.do_adam && (a.trainable & VGPMP_TRAIN_ALPHA)) {
+            adam_update(&ra, a.m_alpha + p, a.v_alpha + p, ga, lr_t);
+            a.raw_alpha[p] = ra;
+        }
+        a.sc.alpha_eff[p] = (float)((kAlphaFloor + softplus_d(ra)) * a.inv_s);
+    }
+}
+
 template <typename T>
 T* carve(char*& cur, size_t count, bool real) {
     uintptr_t v = (uintptr_t)cur;
@@ -1993,6 +2066,17 @@ T* carve(char*& cur, size_t count, bool real) {
 }
 
 }  // namespace
+
+size_t vg_layout_lik_scratch(const vgpmp_dims* d, void* base, vg_lik_scratch* out) {
+    char* cur = (char*)base;
+    const bool real = base != nullptr;
+    const size_t P = (size_t)d->num_problems, nb = (size_t)vg_loglik_blocks_per_problem(d->S, d->N);
+    out->alpha_fin = carve<double>(cur, P, real);
+    out->alpha_eff = carve<float>(cur, P, real);
+    out->sigma_eff = carve<float>(cur, P * VGPMP_MAX_SPHERES, real);
+    out->sig_partial = carve<float>(cur, P * nb * VGPMP_MAX_SPHERES, real);
+    return (size_t)(cur - (char*)base) + 256;
+}
 
 int vg_check_dims(const vgpmp_dims* d) {
     if (d->num_problems < 1 || d->S < 1 || d->S_total < d->S || d->N < 1 || d->M < 1 || d->L < 1 || d->B < 16)
@@ -2197,6 +2281,10 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     fa.part = ws->part; fa.Lk32 = ws->Lk32; fa.lik_partial = ws->lik_partial;
     fa.gkl_qmu = ws->gkl_qmu; fa.gkl_Q = ws->gkl_Q; fa.kl_l = ws->kl_l;
     fa.kl_scale = pb->kl_scale; fa.lik_scale = lik_scale; fa.out_lik = out->lik; fa.out_kl = out->kl;
+    const vgpmp_lik_params* lk = pb->lik;
+    vg_lik_scratch lsc = {nullptr, nullptr, nullptr, nullptr};
+    if (lk) vg_layout_lik_scratch(d, lk->scratch, &lsc);
+    fa.alpha_fin = lk ? lsc.alpha_fin : nullptr;
     fa.g_qmu = out->grad.q_mu; fa.g_qsqrt = out->grad.q_sqrt;
     fa.do_adam = do_adam ? 1 : 0; fa.trainable = trainable; fa.lr_dev = ws->lr_t; fa.dma = 0;
     fa.lr_t = 0.0; fa.use_lr_dev = (ctr && do_adam) ? 1 : 0;
@@ -2290,6 +2378,19 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         return (int)hipLaunchKernel(fn, grid, dim3(kBlock), kargs, lds, st);
     };
     auto launch_final = [&]() -> int { return launch((const void*)final_kernel, dim3(L, P), &fa, lds_fin); };
+    // likelihood constants as variables (vgpmp_lik_params): effective values from the raw ones at the start of the call
+    LikUpdArgs lu;
+    if (lk) {
+        LikConstArgs lc;
+        lc.raw_alpha = lk->raw_alpha; lc.raw_sigma = lk->raw_sigma; lc.sc = lsc; lc.inv_s = 1.0 / (double)d->S_total;
+        hipLaunchKernelGGL(lik_consts_kernel, dim3(P), dim3(VGPMP_MAX_SPHERES), 0, st, lc);
+        lu.rb = rb; lu.lik_partial = ws->lik_partial; lu.sig_partial = lsc.sig_partial; lu.nblk = 0;
+        lu.inv_s = lc.inv_s;
+        lu.raw_alpha = lk->raw_alpha; lu.raw_sigma = lk->raw_sigma; lu.m_alpha = lk->m_alpha; lu.v_alpha = lk->v_alpha;
+        lu.m_sigma = lk->m_sigma; lu.v_sigma = lk->v_sigma; lu.g_alpha = lk->g_alpha; lu.g_sigma = lk->g_sigma;
+        lu.sc = lsc; lu.do_adam = do_adam ? 1 : 0; lu.trainable = trainable;
+        lu.ctr = do_adam ? ctr : nullptr; lu.lr = lr; lu.lr_t = 0.0;
+    }
 
     for (int i = 0; i < num_steps; ++i) {
         const bool first = i == 0, more = i + 1 < num_steps;
@@ -2362,17 +2463,24 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         // ---- likelihood forward + reverse (fk_sdf.hip)
         int nblk = 0;
         rc = vg_launch_loglik_paths(rb, sdf, out->f, P, S, L, N, (float)(-lik_scale), ws->G, out->logp, ws->lik_partial,
-                                    &nblk, st, ev ? ev[VG_NUM_STAGES + 1] : nullptr, ev ? ev[VG_NUM_STAGES + 2] : nullptr);
+                                    &nblk, st, ev ? ev[VG_NUM_STAGES + 1] : nullptr, ev ? ev[VG_NUM_STAGES + 2] : nullptr,
+                                    lk ? lsc.alpha_eff : nullptr, lk ? lsc.sigma_eff : nullptr,
+                                    lk ? lsc.sig_partial : nullptr);
         if (rc) return rc;
         fa.nblk = nblk;
         mark();
         if (!backward) {
             hipLaunchKernelGGL(elbo_pieces_kernel, dim3(P), dim3(kBlock), 0, st, L, nblk, ws->lik_partial, ws->kl_l, lik_scale,
-                               pb->kl_scale, out->lik, out->kl);
+                               pb->kl_scale, out->lik, out->kl, fa.alpha_fin);
             return (int)hipGetLastError();
         }
         // ---- reverse of the path assembly (+ hyper-parameter update), then (here or in the next stage 1) the rest
         if ((rc = launch(fn_pb, dim3(split_bwd ? 2 * NC : NC, L, P), &pa, lds_pb))) return rc;
+        if (lk) {      // trainable likelihood constants: their gradient / update, and the constants of the next step
+            lu.nblk = nblk;
+            lu.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
+            hipLaunchKernelGGL(lik_update_kernel, dim3(P), dim3(VGPMP_MAX_SPHERES), 0, st, lu);
+        }
         mark();
         if (!(fused && more)) {      // otherwise both ride in stage 1 of the next step
             hy.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;

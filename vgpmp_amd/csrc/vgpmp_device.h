@@ -226,7 +226,8 @@ int vg_trace_take_lik(unsigned long long* host, int cap);
 
 int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const float* f, int P, int S, int L, int N,
                            float scale, float* G, float* logp, float* lik_partial, int* nblk_out, hipStream_t st,
-                           hipEvent_t kernel_start = nullptr, hipEvent_t kernel_end = nullptr);
+                           hipEvent_t kernel_start = nullptr, hipEvent_t kernel_end = nullptr,
+                           const float* alpha_eff = nullptr, const float* sigma_eff = nullptr, float* sig_partial = nullptr);
 int vg_loglik_blocks_per_problem(int S, int N);
 int vg_launch_mesh_sdf(const double* tri, const int* part, int T, int nx, int ny, int nz, const double* origin,
                        double delta, double* grid, hipStream_t st);

@@ -21,6 +21,7 @@ from .robots import RobotSpec
 
 JITTER = 1e-6
 VARIANCE_FLOOR = 0.1
+ALPHA_FLOOR, SIGMA_FLOOR = 1e-4, 1e-5      # models/vgpmp.py:82, likelihoods/likelihood.py:31,41
 DEFAULT_TRAINABLE = dict(q_mu=True, q_sqrt=True, lengthscales=True, kernel_variance=True)
 
 
@@ -40,6 +41,10 @@ def trainable_mask(flags: Dict[str, bool]) -> int:
         m |= capi.TRAIN_LENGTHSCALES
     if flags.get("kernel_variance", True):
         m |= capi.TRAIN_KERNEL_VARIANCE
+    if flags.get("sigma_obs", False):
+        m |= capi.TRAIN_SIGMA_OBS
+    if flags.get("alpha", False):
+        m |= capi.TRAIN_ALPHA
     return m
 
 
@@ -183,6 +188,21 @@ class PlannerBatch:
         capi.check(self.lib.vgpmp_workspace_bytes(C.byref(self.dims), C.byref(nbytes)), "vgpmp_workspace_bytes")
         self.workspace = torch.empty(int(nbytes.value), dtype=torch.uint8, device=dev)
         self.kl_scale = float(kl_scale)
+        # ---- sigma_obs / alpha as variables (trainable_params.sigma_obs / alpha; reference default: constants)
+        self.lik_variables = bool(self.trainable.get("sigma_obs", False) or self.trainable.get("alpha", False))
+        if self.lik_variables:
+            if int(samples_total or S) != S:
+                raise NotImplementedError("trainable sigma_obs / alpha with a sharded sample axis")
+            sig = np.full(capi.MAX_SPHERES, 1.0)
+            sig[:spec.num_spheres] = scene.sigma_obs
+            self.raw_alpha = torch.full((P,), float(softplus_inverse(self.alpha - ALPHA_FLOOR)), dtype=f64, device=dev)
+            self.raw_sigma = torch.tensor(np.tile(softplus_inverse(sig - SIGMA_FLOOR), (P, 1)), dtype=f64, device=dev)
+            self.lik_adam_m = [z(self.raw_alpha), z(self.raw_sigma)]
+            self.lik_adam_v = [z(self.raw_alpha), z(self.raw_sigma)]
+            self.lik_grad = [z(self.raw_alpha), z(self.raw_sigma)]
+            nb = C.c_size_t(0)
+            capi.check(self.lib.vgpmp_lik_scratch_bytes(C.byref(self.dims), C.byref(nb)), "vgpmp_lik_scratch_bytes")
+            self.lik_scratch = torch.zeros(int(nb.value), dtype=torch.uint8, device=dev)
         # device-resident step counter: lets a captured hipGraph of the step be replayed
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.fuse = True          # False: one launch per kernel even for small batches (measurement)
@@ -200,10 +220,16 @@ class PlannerBatch:
         self._av = self._params_struct(self.adam_v)
         self._noise = capi.Noise(capi.ptr(self.omega), capi.ptr(self.beta), capi.ptr(self.w), capi.ptr(self.eps),
                                  capi.ptr(self.eps2))
+        lik = None
+        if self.lik_variables:
+            self._lik = capi.LikParams(capi.ptr(self.raw_alpha), capi.ptr(self.raw_sigma), capi.ptr(self.lik_adam_m[0]),
+                                       capi.ptr(self.lik_adam_v[0]), capi.ptr(self.lik_adam_m[1]), capi.ptr(self.lik_adam_v[1]),
+                                       capi.ptr(self.lik_grad[0]), capi.ptr(self.lik_grad[1]), capi.ptr(self.lik_scratch))
+            lik = C.pointer(self._lik)
         self._problem = capi.Problem(capi.ptr(self.X), capi.ptr(self.Zy), capi.ptr(self.y_u), self.alpha, JITTER,
-                                     self.kl_scale, None)
+                                     self.kl_scale, None, lik)
         self._problem_ctr = capi.Problem(capi.ptr(self.X), capi.ptr(self.Zy), capi.ptr(self.y_u), self.alpha, JITTER,
-                                         self.kl_scale, capi.ptr(self.step_counter))
+                                         self.kl_scale, capi.ptr(self.step_counter), lik)
         self._out = capi.Outputs(capi.ptr(self.f), capi.ptr(self.logp), capi.ptr(self.lik), capi.ptr(self.kl),
                                  self._params_struct(self.grad))
 
@@ -320,6 +346,8 @@ class PlannerBatch:
                                  problem_base=self.problem_base, X=Xnew)
             child.q_mu, child.q_sqrt, child.raw_ell, child.raw_var = self.q_mu, self.q_sqrt, self.raw_ell, self.raw_var
             child.y_u = self.y_u
+            if self.lik_variables:      # the trained sigma_obs / alpha weigh the samples of get_best_sample
+                child.raw_alpha, child.raw_sigma = self.raw_alpha, self.raw_sigma
             child._pack()
             cache[key] = child
         return cache[key]
@@ -361,3 +389,16 @@ class PlannerBatch:
 
     def variances(self) -> torch.Tensor:
         return VARIANCE_FLOOR + torch.nn.functional.softplus(self.raw_var)
+
+    def alphas(self) -> torch.Tensor:
+        """alpha of every problem [P] (the constant unless trainable_params.alpha / sigma_obs made it a variable)."""
+        if not self.lik_variables:
+            return torch.full((self.P,), self.alpha, dtype=torch.float64, device=self.device)
+        return ALPHA_FLOOR + torch.nn.functional.softplus(self.raw_alpha)
+
+    def sigma_obs(self) -> torch.Tensor:
+        """likelihood.variance of every problem [P, num_spheres]."""
+        n = self.scene.spec.num_spheres
+        if not self.lik_variables:
+            return torch.as_tensor(self.scene.sigma_obs, dtype=torch.float64, device=self.device).repeat(self.P, 1)
+        return SIGMA_FLOOR + torch.nn.functional.softplus(self.raw_sigma[:, :n])

@@ -28,19 +28,28 @@ def init_trainset(grid_spacing_X, grid_spacing_Xnew, input_dimension, degree_of_
 
 def disable_param_opt(planner, trainable_params):
     """utils/miscellaneous.py:324-343: apply the `trainable_params` flags of parameters.yaml.
-    sigma_obs / alpha / inducing_variable can only be held fixed on the HIP path (the reference's
-    default); asking to train them raises."""
-    for key in ("sigma_obs", "alpha", "inducing_variable"):
-        if trainable_params.get(key, False):
-            raise NotImplementedError(f"training `{key}` is not supported by the HIP path (reference default: False)")
+    The inducing locations can only be held fixed on the HIP path (the reference's default); asking to train
+    them raises.  sigma_obs / alpha become per-problem variables of the device batch (vgpmp.h: vgpmp_lik_params);
+    the Normal priors the reference attaches here are centred on the parameters themselves, so they contribute only
+    the bijectors' log-det-Jacobians to the loss -- that term is part of the device update."""
+    if trainable_params.get("inducing_variable", False):
+        raise NotImplementedError("training `inducing_variable` is not supported by the HIP path (reference default: False)")
     for kern in planner.kernel.kernels:
         set_trainable(kern.variance, trainable_params["kernel_variance"])
         set_trainable(kern.lengthscales, trainable_params["lengthscales"])
+    set_trainable(planner.alpha, bool(trainable_params.get("alpha", False)))
+    set_trainable(planner.likelihood.variance, bool(trainable_params.get("sigma_obs", False)))
     planner.trainable = {"q_mu": bool(trainable_params["q_mu"]), "q_sqrt": bool(trainable_params["q_sqrt"]),
                          "lengthscales": bool(trainable_params["lengthscales"]),
-                         "kernel_variance": bool(trainable_params["kernel_variance"])}
+                         "kernel_variance": bool(trainable_params["kernel_variance"]),
+                         "sigma_obs": bool(trainable_params.get("sigma_obs", False)),
+                         "alpha": bool(trainable_params.get("alpha", False))}
     if planner._planner is not None:
-        planner._planner.trainable = dict(planner.trainable)
+        want_lik = planner.trainable["sigma_obs"] or planner.trainable["alpha"]
+        if want_lik != planner._planner.lik_variables:
+            planner._planner = None          # the device batch is rebuilt with / without the likelihood variables
+        else:
+            planner._planner.trainable = dict(planner.trainable)
 
 
 def optimization_step(model, closure=None, optimizer=None, data=None):
@@ -94,9 +103,8 @@ def solve_planning_problems_batched(env, queries, seed: int = 0):
     from .model import VariationalMonteCarloLikelihood
     pp = env.config["planner_params"]
     tp = env.config["trainable_params"]
-    for key in ("sigma_obs", "alpha", "inducing_variable"):
-        if tp.get(key, False):
-            raise NotImplementedError(f"training `{key}` is not supported by the HIP path (reference default: False)")
+    if tp.get("inducing_variable", False):
+        raise NotImplementedError("training `inducing_variable` is not supported by the HIP path (reference default: False)")
     dof = env.robot.dof
     lik = VariationalMonteCarloLikelihood(sigma_obs=pp["sigma_obs"], robot=env.robot, sampler=env.sampler, sdf=env.sdf,
                                           offset=env.scene.position, epsilon=pp["epsilon"])
@@ -107,7 +115,8 @@ def solve_planning_problems_batched(env, queries, seed: int = 0):
                              alpha=pp["alpha"], learning_rate=pp["learning_rate"], seed=seed,
                              trainable={"q_mu": bool(tp["q_mu"]), "q_sqrt": bool(tp["q_sqrt"]),
                                         "lengthscales": bool(tp["lengthscales"]),
-                                        "kernel_variance": bool(tp["kernel_variance"])})
+                                        "kernel_variance": bool(tp["kernel_variance"]),
+                                        "sigma_obs": bool(tp.get("sigma_obs", False)), "alpha": bool(tp.get("alpha", False))})
     pl.run_steps(int(pp["num_steps"]))
     Xnew = np.tile(np.linspace(0.0, 1.0, int(pp["time_spacing_Xnew"]))[:, None], (1, dof))
     _, best, _, _ = pl.sample_from_posterior(150, Xnew, step=pl.t)

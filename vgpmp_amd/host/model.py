@@ -314,6 +314,9 @@ class VGPMP:
         for i, k in enumerate(self.kernel.kernels):
             k.lengthscales.assign(ell[i])
             k.variance.assign(var[i])
+        if pl.lik_variables:
+            self.alpha.assign(float(pl.alphas()[0]))
+            self.likelihood.variance.assign(pl.sigma_obs()[0].cpu().numpy()[None])
 
     def sample_from_posterior(self, X, robot=None, compute_uncertainty=False):
         """models/vgpmp.py:312-331: (mean, best sample, first 7 samples, 2 sqrt(uncertainty))."""
