@@ -1594,91 +1594,106 @@ __global__ __launch_bounds__(kBlock) void prior_gemm_lds_kernel(GemmArgs a) {
 // fetched from L2 from ~10 to ~22 compared with the direct kernel above.
 constexpr int kTS = 64, kTJ = 144, kTK = 32, kTLd = 36;
 
+// MT = 16-row tiles per wave: a workgroup owns 64 MT samples.  MT = 2 (128 samples x 144 columns) moves 35 % fewer
+// operand bytes per flop than MT = 1 and keeps a slice's products long enough (144 per wave) to cover the next
+// slice's loads; dynamic LDS 2 (64 MT + 144) 36 4 B = 60 / 78 KB, two workgroups per CU either way.
+template <int MT>
 __global__ __launch_bounds__(kBlock) void prior_gemm_tiled_kernel(int S, int L, int J, int B, int nsel,
                                                                    const float* __restrict__ W,
                                                                    const float* __restrict__ Phi,
                                                                    const float* __restrict__ dPhi,
                                                                    float* __restrict__ F0, float* __restrict__ H) {
-    __shared__ float As[2][kTS * kTLd];
-    __shared__ float Bs[2][kTJ * kTLd];
+    constexpr int TS = kTS * MT, NA = TS * 8 / kBlock;      // A: TS rows x 8 chunks of 16 bytes, NA per thread
+    extern __shared__ __attribute__((aligned(16))) float tg_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int z = blockIdx.z;
     const int sel = z % nsel; z /= nsel;
     const int l = z % L, p = z / L;
-    const int s0 = blockIdx.y * kTS, j0 = blockIdx.x * kTJ;
+    const int s0 = blockIdx.y * TS, j0 = blockIdx.x * kTJ;
     const float* Bm = sel == 0 ? Phi : dPhi;
     float* Out = sel == 0 ? F0 : H;
-    // staging map: thread -> (row, 16-byte k-chunk); A: 64 rows x 8 chunks = 512 (2 per thread),
-    // B: 144 rows x 8 chunks = 1152 (4.5 per thread -> 5 passes, last partial)
-    float4 ra[2], rbv[5];
-    auto load_tiles = [&](int k0) {
+    // staging map: thread -> (row, 16-byte k-chunk); B: 144 rows x 8 chunks = 1152 (4.5 per thread -> 5 passes, last partial)
+    // (macros, not lambdas: staging registers captured by a lambda end up in scratch memory)
+    vg_f32x4 ra[NA], rbv[5];      // (ext_vector registers: HIP's float4 struct arrays are not always promoted out of scratch)
+#define VG_TG_LOAD(k0)                                                                                              \
+    {                                                                                                               \
+        _Pragma("unroll") for (int q = 0; q < NA; ++q) {                                                            \
+            const int c = tid + q * kBlock, row = c >> 3, ch = c & 7;                                               \
+            const int srow = min(s0 + row, S - 1);                                                                  \
+            ra[q] = *reinterpret_cast<const vg_f32x4*>(W + (((size_t)p * S + srow) * L + l) * B + (k0) + 4 * ch);     \
+        }                                                                                                           \
+        _Pragma("unroll") for (int q = 0; q < 5; ++q) {                                                             \
+            const int c = min(tid + q * kBlock, kTJ * 8 - 1), row = c >> 3, ch = c & 7;                             \
+            const int jrow = min(j0 + row, J - 1);                                                                  \
+            rbv[q] = *reinterpret_cast<const vg_f32x4*>(Bm + (((size_t)p * L + l) * J + jrow) * B + (k0) + 4 * ch);   \
+        }                                                                                                           \
+    }
+#define VG_TG_STORE(buf)                                                                                            \
+    {                                                                                                               \
+        float* as_ = tg_lds + (buf) * (TS * kTLd);                                                                  \
+        float* bs_ = tg_lds + 2 * TS * kTLd + (buf) * (kTJ * kTLd);                                                 \
+        _Pragma("unroll") for (int q = 0; q < NA; ++q) {                                                            \
+            const int c = tid + q * kBlock, row = c >> 3, ch = c & 7;                                               \
+            *reinterpret_cast<vg_f32x4*>(as_ + row * kTLd + 4 * ch) = ra[q];                                          \
+        }                                                                                                           \
+        _Pragma("unroll") for (int q = 0; q < 5; ++q) {                                                             \
+            const int c = tid + q * kBlock;                                                                         \
+            if (c < kTJ * 8) {                                                                                      \
+                const int row = c >> 3, ch = c & 7;                                                                 \
+                *reinterpret_cast<vg_f32x4*>(bs_ + row * kTLd + 4 * ch) = rbv[q];                                     \
+            }                                                                                                       \
+        }                                                                                                           \
+    }
+    vg_f32x4 acc[MT][kTJ / 16];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int c = tid + q * kBlock, row = c >> 3, ch = c & 7;
-            const int srow = min(s0 + row, S - 1);
-            ra[q] = *reinterpret_cast<const float4*>(W + (((size_t)p * S + srow) * L + l) * B + k0 + 4 * ch);
-        }
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const int c = min(tid + q * kBlock, kTJ * 8 - 1), row = c >> 3, ch = c & 7;
-            const int jrow = min(j0 + row, J - 1);
-            rbv[q] = *reinterpret_cast<const float4*>(Bm + (((size_t)p * L + l) * J + jrow) * B + k0 + 4 * ch);
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int c = tid + q * kBlock, row = c >> 3, ch = c & 7;
-            *reinterpret_cast<float4*>(&As[buf][row * kTLd + 4 * ch]) = ra[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const int c = tid + q * kBlock;
-            if (c < kTJ * 8) {
-                const int row = c >> 3, ch = c & 7;
-                *reinterpret_cast<float4*>(&Bs[buf][row * kTLd + 4 * ch]) = rbv[q];
-            }
-        }
-    };
-    vg_f32x4 acc[kTJ / 16];
-#pragma unroll
-    for (int t = 0; t < kTJ / 16; ++t) acc[t] = (vg_f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < kTJ / 16; ++t) acc[m][t] = (vg_f32x4){0.f, 0.f, 0.f, 0.f};
     const int r = lane & 15, g = lane >> 4;
-    load_tiles(0);
-    store_tiles(0);
+    VG_TG_LOAD(0)
+    VG_TG_STORE(0)
     __syncthreads();
     int buf = 0;
     for (int k0 = 0; k0 < B; k0 += kTK) {
         const bool more = k0 + kTK < B;
-        if (more) load_tiles(k0 + kTK);
-        const float* a_base = &As[buf][(wave * 16 + r) * kTLd + 4 * g];
+        if (more) VG_TG_LOAD(k0 + kTK)
+        const float* a_base = &(tg_lds + buf * (TS * kTLd))[(wave * 16 + r) * kTLd + 4 * g];
 #pragma unroll
         for (int kk = 0; kk < kTK; kk += 16) {
-            const float4 a4 = *reinterpret_cast<const float4*>(a_base + kk);
+            float4 a4[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a4[m] = *reinterpret_cast<const float4*>(a_base + m * 64 * kTLd + kk);
 #pragma unroll
             for (int t = 0; t < kTJ / 16; ++t) {
-                const float4 b4 = *reinterpret_cast<const float4*>(&Bs[buf][(t * 16 + r) * kTLd + kk + 4 * g]);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc[t], 0, 0, 0);
+                const float4 b4 = *reinterpret_cast<const float4*>(&(tg_lds + 2 * TS * kTLd + buf * (kTJ * kTLd))[(t * 16 + r) * kTLd + kk + 4 * g]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m].x, b4.x, acc[m][t], 0, 0, 0);
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m].y, b4.y, acc[m][t], 0, 0, 0);
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m].z, b4.z, acc[m][t], 0, 0, 0);
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m].w, b4.w, acc[m][t], 0, 0, 0);
+                }
             }
         }
-        if (more) store_tiles(buf ^ 1);
+        if (more) VG_TG_STORE(buf ^ 1)
         __syncthreads();
         buf ^= 1;
     }
 #pragma unroll
-    for (int t = 0; t < kTJ / 16; ++t) {
-        const int jc = j0 + 16 * t + r;
-        if (jc >= J) continue;
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int srow = s0 + wave * 16 + g * 4 + q;
-            if (srow < S) vg_stream(Out + (((size_t)p * S + srow) * L + l) * J + jc, acc[t][q]);
+        for (int t = 0; t < kTJ / 16; ++t) {
+            const int jc = j0 + 16 * t + r;
+            if (jc >= J) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int srow = s0 + m * 64 + wave * 16 + g * 4 + q;
+                if (srow < S) vg_stream(Out + (((size_t)p * S + srow) * L + l) * J + jc, acc[m][t][q]);
+            }
         }
-    }
 }
+#undef VG_TG_LOAD
+#undef VG_TG_STORE
 
 // =================================================================================================
 // Path assembly  (decoupled / Matheron update, vgpmp.py:281-282):
@@ -2448,11 +2463,19 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             hipLaunchKernelGGL(features_kernel, feat_grid, dim3(kBlock), 0, st, fe);
             mark();
             hipEvent_t g0 = ev ? ev[VG_NUM_STAGES + 3] : nullptr, g1 = ev ? ev[VG_NUM_STAGES + 4] : nullptr;
-            if (tiled_gemm)
-                hipExtLaunchKernelGGL(prior_gemm_tiled_kernel, dim3((J + kTJ - 1) / kTJ, (S + kTS - 1) / kTS, P * L * ga.nsel),
-                                      dim3(kBlock), 0, st, g0, g1, 0, S, L, J, B, ga.nsel, nz->w, ws->Phi, ws->dPhi, ws->F0,
-                                      ws->H);
-            else if (glds)
+            if (tiled_gemm) {
+                const int mt = 1;      // 128-sample tiles (mt = 2) measured slower: 90 vs 98 TF/s at 64 problems
+                const size_t lds_tg = (size_t)2 * (kTS * mt + kTJ) * kTLd * sizeof(float);
+                const void* fn_tg = mt == 2 ? (const void*)prior_gemm_tiled_kernel<2> : (const void*)prior_gemm_tiled_kernel<1>;
+                if ((rc = set_dyn_lds(fn_tg, lds_tg))) return rc;
+                const dim3 tg_grid((J + kTJ - 1) / kTJ, (S + kTS * mt - 1) / (kTS * mt), P * L * ga.nsel);
+                if (mt == 2)
+                    hipExtLaunchKernelGGL(prior_gemm_tiled_kernel<2>, tg_grid, dim3(kBlock), lds_tg, st, g0, g1, 0, S, L, J, B,
+                                          ga.nsel, nz->w, ws->Phi, ws->dPhi, ws->F0, ws->H);
+                else
+                    hipExtLaunchKernelGGL(prior_gemm_tiled_kernel<1>, tg_grid, dim3(kBlock), lds_tg, st, g0, g1, 0, S, L, J, B,
+                                          ga.nsel, nz->w, ws->Phi, ws->dPhi, ws->F0, ws->H);
+            } else if (glds)
                 hipExtLaunchKernelGGL(prior_gemm_lds_kernel, gemm_grid, dim3(kBlock), kGemmLds, st, g0, g1, 0, ga);
             else
                 hipExtLaunchKernelGGL(prior_gemm_kernel<0>, gemm_grid, dim3(kBlock), 0, st, g0, g1, 0, ga);
