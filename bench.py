@@ -180,14 +180,14 @@ def main():
     sdf_bytes = npb * S * N * (28 * P + 8 * D + 4)                 # 7 fp32 voxels per sphere query
     gemm_flops = npb * 2 * (2.0 * S * (N + M + 2) * D * B)         # F0 and H (lengthscales trainable)
     t_sdf, t_gemm = kernel_ms["loglik_kernel"] * 1e-3, kernel_ms["prior_gemm_kernel"] * 1e-3
-    lik_kernel = ("loglik_paths_wide_kernel<8>" if npb * S * N <= 16384 else
-                  "loglik_paths_wide_kernel<4>" if npb * S * N <= 65536 else "loglik_paths_kernel<1, 64>")
+    lik_kernel = ("loglik_paths_wide_kernel<8, false>" if npb * S * N <= 16384 else
+                  "loglik_paths_wide_kernel<4, false>" if npb * S * N <= 65536 else "loglik_paths_kernel<1, 64, false>")
     roof_sdf = {"kernel": lik_kernel, "bound": "hbm", "achieved": sdf_bytes / t_sdf / 1e9,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sdf_bytes / t_sdf / 1e9 / HBM_PEAK_GBPS,
                 "traffic": None, "algorithmic_bytes_per_launch": sdf_bytes, "avg_launch_ms": kernel_ms["loglik_kernel"],
                 "timing": "HIP events stamped with the kernel's start and end on its stream (hipExtLaunchKernel), "
                           f"mean of {max(1, args.profile_steps)} launches"}
-    gemm_kernel = ("prior_gemm_tiled_kernel" if planner.dims.split_k == 1 else
+    gemm_kernel = ("prior_gemm_tiled_kernel<1>" if planner.dims.split_k == 1 else
                    "prior_gemm_lds_kernel" if (1024 // planner.dims.split_k) % 128 == 0 and S >= 48 else "prior_gemm_kernel<0>")
     roof_gemm = {"kernel": gemm_kernel, "bound": "mfma", "achieved": gemm_flops / t_gemm / 1e12,
                  "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_flops / t_gemm / 1e12 / F32_MFMA_PEAK_TFLOPS,

@@ -37,7 +37,7 @@ def main():
                    "profiles/r01/r01_pmc_fetch_write_kb.json; bytes = FETCH_SIZE*1024 (x2 for kernels whose reads are "
                    "16 B per lane: the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE*1024; unit calibrated on "
                    "sdf_pack_kernel in the same run (8 B per lane reads, 16 B per lane writes of a known volume)"}
-    wide16 = ("loglik_paths_wide_kernel<8>", "loglik_paths_wide_kernel<4>", "loglik_paths_kernel<1, 64>", "prior_gemm_kernel<0>", "prior_gemm_lds_kernel",
+    wide16 = ("loglik_paths_wide_kernel<8, false>", "loglik_paths_wide_kernel<4, false>", "loglik_paths_kernel<1, 64, false>", "prior_gemm_kernel<0>", "prior_gemm_lds_kernel",
               "prior_gemm_tiled_kernel",
               "stage2_kernel<true, 0>", "stage2_kernel<true, 8>", "paths_bwd_sc8", "stage3_kernel")
     for k, v in table.items():
