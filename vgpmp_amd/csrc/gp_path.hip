@@ -783,6 +783,7 @@ struct CovArgs {
     const double *q_mu, *q_sqrt, *raw_ell, *raw_var;
     int want_dell;
     int stop;
+    int elim_wave;           // Mz <= 32: the elimination on one wave (chol_inverse_wave)
     uint32_t* tick;          // device step counter, ticked by one row-tile workgroup of stage 2 (or null)
     double lr;               // with the tick: the step size of this step's update goes to lr_dev[0]
     double* lr_dev;
@@ -942,6 +943,79 @@ __device__ __forceinline__ void chol_inverse_regs(double* La, double* Li, double
     __syncthreads();
 }
 
+// The same elimination on ONE wave without LDS or barriers in the loop (Mz <= 32): lane c keeps column c of
+// [K | I] (32 + 32 columns, 32 rows = 64 registers); the pivot and the pivot column reach the other lanes as
+// scalar broadcasts (v_readlane), the loops are fully unrolled so that every row index is a register name.  What
+// is left of a pivot's cost is its dependency chain (reciprocal + two Newton steps + the update of the next pivot),
+// the trailing updates of the previous pivot fill its gaps.  (The multiplier is applied as a_ik (row_k / d_k) instead
+// of (a_ik / d_k) row_k: one independent FMA per row; results differ from the forms above in the last bit.)
+__device__ __forceinline__ double vg_bcast_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void chol_inverse_wave(double* La, double* Li, double* Aug, double* rsd, int Mz, int ld,
+                                                  int tid, int nt) {
+    const int la = 2 * Mz + 1;
+    const float iMz = 1.0f / (float)Mz;
+    double* Img = Aug;
+    if (tid < VG_WAVE) {
+        const int c = tid;
+        double a[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const double kv = La[min(i, Mz - 1) * ld + min(c & 31, Mz - 1)];      // loads first, selects afterwards
+            const double id = (i == (c & 31)) ? 1.0 : 0.0;
+            a[i] = c < 32 ? ((i < Mz && c < Mz) ? kv : id) : id;
+        }
+        // software pipelined: pivot k first finishes row k + 1 -- the next pivot row -- so that the next reciprocal
+        // (the long dependent chain) is in flight while the remaining rows of pivot k are updated
+        double piv = vg_bcast_f64(a[0], 0);
+        double r = __builtin_amdgcn_rcp(piv);
+        r = fma(fma(-piv, r, 1.0), r, r);
+        r = fma(fma(-piv, r, 1.0), r, r);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            double rn = 0.0;
+            // row_i -= (a_ik / d_k) row_k as ONE product per row: the scalar a_ik times w = row_k / d_k (per lane)
+            const double w = -a[k] * r;
+            if (k + 1 < 32) {
+                a[k + 1] = fma(vg_bcast_f64(a[k + 1], k), w, a[k + 1]);
+                const double pn = vg_bcast_f64(a[k + 1], k + 1);
+                rn = __builtin_amdgcn_rcp(pn);
+                rn = fma(fma(-pn, rn, 1.0), rn, rn);
+                rn = fma(fma(-pn, rn, 1.0), rn, rn);
+            }
+#pragma unroll
+            for (int i = k + 2; i < 32; ++i) a[i] = fma(vg_bcast_f64(a[i], k), w, a[i]);
+            r = rn;
+        }
+        // pivot k is the diagonal entry lane k ends with (row k is final once pivot k - 1 is done): rsqrt after the
+        // loop, off the chain
+        double mine = 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) mine = c == i ? a[i] : mine;
+        if (c < Mz) rsd[c] = mine;
+        // registers -> the [Mz][2 Mz + 1] image the tail expects: left half U = D L~^T, right half L~^-1
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if (i < Mz) {
+                if (c < Mz) Img[i * la + c] = a[i];
+                else if (c >= 32 && c - 32 < Mz) Img[i * la + Mz + (c - 32)] = a[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < Mz) rsd[tid] = rsqrt(rsd[tid]);
+    __syncthreads();
+    for (int e = tid; e < Mz * Mz; e += nt) {
+        const int r = vg_div(e, iMz), j = e - r * Mz;
+        La[r * ld + j] = j <= r ? Img[j * la + r] * rsd[j] : 0.0;
+        Li[r * ld + j] = j <= r ? Img[r * la + Mz + j] * rsd[r] : 0.0;
+    }
+    __syncthreads();
+}
+
 // ---- stage A: Kuu, factorisation, inverse --------------------------------------------------------
 __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, int p) {
     __shared__ double scal[2];
@@ -1006,7 +1080,8 @@ __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, 
     }
     __syncthreads();
     VG_T(l == 0 && p == 0, 101);
-    if (Mz <= 32 && nt == 256) chol_inverse_regs(La, Li, Sc, rsd, Mz, ld, tid, nt);
+    if (Mz <= 32 && a.elim_wave) chol_inverse_wave(La, Li, Sc, rsd, Mz, ld, tid, nt);
+    else if (Mz <= 32 && nt == 256) chol_inverse_regs(La, Li, Sc, rsd, Mz, ld, tid, nt);
     else chol_inverse_block(La, Li, Sc, rsd, Mz, ld, tid, nt);
     VG_T(l == 0 && p == 0, 102);
     double* Kig = a.ws.Kinv + pl * Mz * Mz;
@@ -2251,6 +2326,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     ca.q_mu = params->q_mu; ca.q_sqrt = params->q_sqrt; ca.raw_ell = params->raw_ell; ca.raw_var = params->raw_var;
     ca.want_dell = want_dell ? 1 : 0;
     ca.stop = -1;
+    ca.elim_wave = getenv("VG_ELIM_BLOCK") ? 0 : 1;      // (switch: measurement)
     ca.tick = (fused && do_adam) ? ctr : nullptr;
     ca.lr = lr; ca.lr_dev = ws->lr_t;
     ca.prologue = 0; ca.commit = 0; ca.keep_prev = (fused && backward) ? 1 : 0;
