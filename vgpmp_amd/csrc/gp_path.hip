@@ -292,11 +292,13 @@ __device__ __forceinline__ void paths_fwd_body(const PathArgs& a, float* smf, in
 // paths_bwd_split): both halves form R (half 0 stores it), each assembles f on its half of the time points, so a
 // workgroup stages ~25 instead of ~36 KB.  q_sqrt comes transposed (16-byte rows, conflict-free reads).  The
 // arithmetic and its order are those of paths_fwd_body: identical bits.  Needs SK > 1, N % 4 == 0, Mz % 4 == 0.
-template <int SK>
+// MZ = 32 fixes the inducing extent at compile time: loops with a run-time trip count stay rolled (load, wait, one
+// FMA per iteration), with a constant one their operands are requested together.
+template <int SK, int MZ = 0>
 __device__ __forceinline__ void paths_fwd_split_body(const PathArgs& a, float* smf, int ch2, int l, int p) {
     constexpr int SC = 8;
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int S = a.S, N = a.N, Mz = a.Mz, L = a.L, J = N + Mz;
+    const int S = a.S, N = a.N, Mz = MZ ? MZ : a.Mz, L = a.L, J = N + Mz;
     const int ch = ch2 >> 1, half = ch2 & 1;
     const int Nh = (N >> 1) & ~3, n0 = half ? Nh : 0, nx = half ? N - Nh : Nh;
     const float iMz = 1.0f / (float)Mz, inx = 1.0f / (float)nx;
@@ -342,7 +344,12 @@ __device__ __forceinline__ void paths_fwd_split_body(const PathArgs& a, float* s
     for (int e = tid; e < SC * Mz; e += nt) {
         const int sl = vg_div(e, iMz), mi = e - sl * Mz, s = s_base + sl;
         float u = ms[mi];
-        for (int k = 0; k <= mi; ++k) u = fmaf(CTs[k * Mz + mi], es[sl * Mz + k], u);
+        if (MZ) {      // q_sqrt is lower triangular: the terms beyond the diagonal add exact zeros
+#pragma unroll
+            for (int k = 0; k < (MZ ? MZ : 1); ++k) u = fmaf(k <= mi ? CTs[k * Mz + mi] : 0.f, es[sl * Mz + k], u);
+        } else {
+            for (int k = 0; k <= mi; ++k) u = fmaf(CTs[k * Mz + mi], es[sl * Mz + k], u);
+        }
         const float r = u - f0z[e] - a.sqrt_jitter * e2s[e];
         rs[e] = r;
         if (half == 0 && s < S) vg_stream(a.R + (((size_t)p * S + s) * L + l) * Mz + mi, r);
@@ -351,7 +358,12 @@ __device__ __forceinline__ void paths_fwd_split_body(const PathArgs& a, float* s
     for (int e = tid; e < SC * nx; e += nt) {
         const int sl = vg_div(e, inx), j = e - sl * nx, s = s_base + sl;
         float v = f0x[e];
-        for (int k = 0; k < Mz; ++k) v = fmaf(ATs[k * nx + j], rs[sl * Mz + k], v);
+        if (MZ) {
+#pragma unroll
+            for (int k = 0; k < (MZ ? MZ : 1); ++k) v = fmaf(ATs[k * nx + j], rs[sl * Mz + k], v);
+        } else {
+            for (int k = 0; k < Mz; ++k) v = fmaf(ATs[k * nx + j], rs[sl * Mz + k], v);
+        }
         if (s < S) vg_stream(a.f + (((size_t)p * S + s) * L + l) * N + n0 + j, v);
     }
     VG_T(ch2 == 0 && l == 0 && p == 0, 302);
@@ -1982,7 +1994,10 @@ template <int SK, bool RAW>
 __global__ __launch_bounds__(kBlock) void paths_fwd_sc8(PathArgs a) {
     extern __shared__ float smf[];
     if (SK > 1 && a.nsplit == 2) {
-        if constexpr (SK > 1) paths_fwd_split_body<SK>(a, smf, blockIdx.x, blockIdx.y, blockIdx.z);
+        if constexpr (SK > 1) {
+            if (a.Mz == 32) paths_fwd_split_body<SK, 32>(a, smf, blockIdx.x, blockIdx.y, blockIdx.z);
+            else paths_fwd_split_body<SK>(a, smf, blockIdx.x, blockIdx.y, blockIdx.z);
+        }
         return;
     }
     paths_fwd_body<SK, 8, RAW>(a, smf, blockIdx.x, blockIdx.y, blockIdx.z);
@@ -2062,7 +2077,10 @@ __global__ __launch_bounds__(kBlock) void stage3_kernel(Stage3Args a) {
         const int ch = b % nch;
         b /= nch;
         if (SK > 1 && a.path.nsplit == 2) {
-            if constexpr (SK > 1) paths_fwd_split_body<SK>(a.path, smf, ch, b % a.path.L, b / a.path.L);
+            if constexpr (SK > 1) {
+                if (a.path.Mz == 32) paths_fwd_split_body<SK, 32>(a.path, smf, ch, b % a.path.L, b / a.path.L);
+                else paths_fwd_split_body<SK>(a.path, smf, ch, b % a.path.L, b / a.path.L);
+            }
             return;
         }
         paths_fwd_body<SK, 8, RAW>(a.path, smf, ch, b % a.path.L, b / a.path.L);
