@@ -517,13 +517,13 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
 // A / dR / dm / dC (disjoint outputs, no extra partials) and the time points [n0, n0 + nx) of the two prior-draw dot
 // products (a second set of the three scalars, added by hyper_update).  Two threads per (sample, column) halve the
 // N-long chains.  Needs Mz % 8 == 0, N % 4 == 0 (16-byte rows), SK > 1.
-template <int SK>
+template <int SK, int MZ = 0>      // MZ = 32: inducing extent fixed at compile time (see paths_fwd_split_body)
 __global__ __launch_bounds__(kBlock) void paths_bwd_split(PathArgs a) {
     constexpr int SC = 8;
     extern __shared__ float smf[];
     __shared__ float red[3][kBlock / VG_WAVE];
     const int ch = blockIdx.x >> 1, half = blockIdx.x & 1, l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
-    const int S = a.S, N = a.N, Mz = a.Mz, L = a.L, J = N + Mz;
+    const int S = a.S, N = a.N, Mz = MZ ? MZ : a.Mz, L = a.L, J = N + Mz;
     const int Mh = Mz >> 1, m0 = half * Mh;
     const int Nh = (N >> 1) & ~3, n0 = half ? Nh : 0, nx = half ? N - Nh : Nh;
     const float iMh = 1.0f / (float)Mh, iMz = 1.0f / (float)Mz;
@@ -608,10 +608,20 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_split(PathArgs a) {
             dv = fmaf(gv, av.z, dv);
         }
         float ue = 0.f, uv = 0.f;
-        for (int k = par; k <= mi; k += 2) {
-            const float ev = Es[sl * Mz + k];
-            uv = fmaf(Cvs[k * Mh + ml], ev, uv);
-            ue = fmaf(Ces[k * Mh + ml], ev, ue);
+        if (MZ) {      // (dC/dtheta)^T is upper triangular: the terms beyond the diagonal add exact zeros
+#pragma unroll
+            for (int k2 = 0; k2 < (MZ ? MZ / 2 : 1); ++k2) {
+                const int k = par + 2 * k2;
+                const float ev = k <= mi ? Es[sl * Mz + k] : 0.f;
+                uv = fmaf(Cvs[k * Mh + ml], ev, uv);
+                ue = fmaf(Ces[k * Mh + ml], ev, ue);
+            }
+        } else {
+            for (int k = par; k <= mi; k += 2) {
+                const float ev = Es[sl * Mz + k];
+                uv = fmaf(Cvs[k * Mh + ml], ev, uv);
+                ue = fmaf(Ces[k * Mh + ml], ev, ue);
+            }
         }
         d += __shfl_xor(d, 1, VG_WAVE); de += __shfl_xor(de, 1, VG_WAVE); dv += __shfl_xor(dv, 1, VG_WAVE);
         ue += __shfl_xor(ue, 1, VG_WAVE); uv += __shfl_xor(uv, 1, VG_WAVE);
@@ -2462,7 +2472,10 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                            (size_t)P * L * NC * 2 <= 512 && !(what & VGPMP_NO_SPLIT);
     if (split_fwd) { pa.nsplit = 2; lds_pf = lds_pfs; }
     if (split_bwd) {
-        fn_pb = SK == 2 ? (const void*)paths_bwd_split<2> : SK == 4 ? (const void*)paths_bwd_split<4> : (const void*)paths_bwd_split<8>;
+        fn_pb = Mz == 32 ? (SK == 2 ? (const void*)paths_bwd_split<2, 32> : SK == 4 ? (const void*)paths_bwd_split<4, 32>
+                                                                                        : (const void*)paths_bwd_split<8, 32>)
+                         : (SK == 2 ? (const void*)paths_bwd_split<2> : SK == 4 ? (const void*)paths_bwd_split<4>
+                                                                                  : (const void*)paths_bwd_split<8>);
         lds_pb = lds_pbs;
     }
     if ((rc = set_dyn_lds(fn_pb, lds_pb))) return rc;
