@@ -599,13 +599,24 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_split(PathArgs a) {
         const int sl = vg_div(it, iMh), ml = it - sl * Mh, mi = m0 + ml;
         const float* g = Gs + sl * N;
         float d = 0.f, de = 0.f, dv = 0.f;
-#pragma unroll 5
-        for (int n = par; n < N; n += 2) {
-            const float4 av = A4s[n * Mh + ml];
-            const float gv = g[n];
-            d = fmaf(gv, av.x, d);
-            de = fmaf(gv, av.y, de);
-            dv = fmaf(gv, av.z, dv);
+        // passes of 8 time points per lane with constant bounds (operands of a pass requested together; the tail is
+        // read on clamped indices and masked)
+        for (int nb = 0; nb < N; nb += 16) {
+            float4 av[8];
+            float gv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int n = min(nb + par + 2 * u, N - 1);
+                av[u] = A4s[n * Mh + ml];
+                gv[u] = g[n];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float gm = nb + par + 2 * u < N ? gv[u] : 0.f;
+                d = fmaf(gm, av[u].x, d);
+                de = fmaf(gm, av[u].y, de);
+                dv = fmaf(gm, av[u].z, dv);
+            }
         }
         float ue = 0.f, uv = 0.f;
         if (MZ) {      // (dC/dtheta)^T is upper triangular: the terms beyond the diagonal add exact zeros
