@@ -162,6 +162,7 @@ typedef struct vgpmp_outputs {
 #define VGPMP_NO_FUSE 16        /* measurement: one launch per kernel even for small batches  */
 #define VGPMP_GEMM_DIRECT 32    /* measurement: stage-2 GEMM role with operands straight from L2 */
 #define VGPMP_NO_SPLIT 64       /* measurement: reverse path pass on one workgroup per (chunk, latent) */
+#define VGPMP_ELIM_BLOCK 128    /* measurement: Kuu elimination by the whole workgroup through LDS instead of one wave in registers */
 
 /* ---- set-up -------------------------------------------------------------------------------- */
 

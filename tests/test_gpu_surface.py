@@ -256,6 +256,27 @@ def test_pipelined_steps_with_trainable_likelihood_constants():
     assert float(moved.min()) > 0.05
 
 
+def test_elimination_forms_agree():
+    """The factorisation of Kuu + jI runs on one wave with the augmented matrix in registers (Mz <= 32); the
+    workgroup-wide form through LDS applies the same multipliers with the operands associated differently."""
+    from vgpmp_amd import capi, engine
+    pb = small_problem(robot="franka", S=8, N=12, M=30, B=64, seed=2, n_grid=32)
+    sc = engine.DeviceScene(pb["spec"], pb["grid"], pb["offset"])
+    kw = dict(num_samples=8, num_inducing=30, num_data=12, num_bases=64, lengthscales=[2.0] * 7, variance=0.2, seed=5)
+    a, b = engine.PlannerBatch(sc, pb["y"][None], **kw), engine.PlannerBatch(sc, pb["y"][None], **kw)
+    b.extra_flags = capi.ELIM_BLOCK
+    la, ga = a.loss_and_grad(step=1)
+    lb, gb = b.loss_and_grad(step=1)
+    torch.cuda.synchronize()
+    # Kuu + 1e-6 I has condition number ~1e7: the two forms agree to ~1e-9 of the factor's scale
+    for name in ("Kinv", "A4"):
+        x, y = a.view(name).double(), b.view(name).double()
+        assert float((x - y).abs().max()) <= 1e-6 * float(y.abs().max()), name
+    np.testing.assert_allclose(float(la[0]), float(lb[0]), rtol=1e-6)
+    for x, y in zip(ga, gb):
+        assert float((x - y).abs().max()) <= 1e-4 * (float(y.abs().max()) + 1e-30)
+
+
 def test_split_path_kernels_equal_one_workgroup_form():
     """Small launches run the path assembly and its reverse on two workgroups per (sample chunk, latent)
     (paths_fwd_split_body: halves of the time axis; paths_bwd_split: halves of the inducing axis).  The forward

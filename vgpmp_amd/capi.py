@@ -17,7 +17,7 @@ MAX_DOF, MAX_SPHERES, MAX_MZ = 16, 64, 48
 TRAIN_Q_MU, TRAIN_Q_SQRT, TRAIN_LENGTHSCALES, TRAIN_KERNEL_VARIANCE = 1, 2, 4, 8
 TRAIN_SIGMA_OBS, TRAIN_ALPHA = 16, 32      # need Problem.lik
 DO_FORWARD, DO_BACKWARD, DO_ADAM, GEN_NOISE, NO_FUSE = 1, 2, 4, 8, 16
-GEMM_DIRECT, NO_SPLIT = 32, 64
+GEMM_DIRECT, NO_SPLIT, ELIM_BLOCK = 32, 64, 128
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvgpmp_hip.so"
 

@@ -2365,7 +2365,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     ca.q_mu = params->q_mu; ca.q_sqrt = params->q_sqrt; ca.raw_ell = params->raw_ell; ca.raw_var = params->raw_var;
     ca.want_dell = want_dell ? 1 : 0;
     ca.stop = -1;
-    ca.elim_wave = getenv("VG_ELIM_BLOCK") ? 0 : 1;      // (switch: measurement)
+    ca.elim_wave = (what & VGPMP_ELIM_BLOCK) ? 0 : 1;
     ca.tick = (fused && do_adam) ? ctr : nullptr;
     ca.lr = lr; ca.lr_dev = ws->lr_t;
     ca.prologue = 0; ca.commit = 0; ca.keep_prev = (fused && backward) ? 1 : 0;
