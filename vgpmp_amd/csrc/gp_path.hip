@@ -25,7 +25,7 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kFuseMaxPL = 64;                  // role-dispatched stage launches up to this many (problem, latent) pairs
+constexpr int kFuseMaxPL = 32;      // measured on config 2: shared launches win up to 4 problems (x 7 latents), one launch per kernel from 5
 constexpr double kVarFloor = 0.1;               // models/vgpmp.py:139 positive(lower=1e-1)
 constexpr double kSqrt5 = 2.2360679774997896964;
 
