@@ -180,8 +180,7 @@ def main():
     sdf_bytes = npb * S * N * (28 * P + 8 * D + 4)                 # 7 fp32 voxels per sphere query
     gemm_flops = npb * 2 * (2.0 * S * (N + M + 2) * D * B)         # F0 and H (lengthscales trainable)
     t_sdf, t_gemm = kernel_ms["loglik_kernel"] * 1e-3, kernel_ms["prior_gemm_kernel"] * 1e-3
-    lik_kernel = ("loglik_paths_wide_kernel<8, false>" if npb * S * N <= 16384 else
-                  "loglik_paths_wide_kernel<4, false>" if npb * S * N <= 65536 else "loglik_paths_kernel<1, 64, false>")
+    lik_kernel = "loglik_paths_wide_kernel<8, false>" if npb * S * N <= 65536 else "loglik_paths_kernel<1, 64, false>"
     roof_sdf = {"kernel": lik_kernel, "bound": "hbm", "achieved": sdf_bytes / t_sdf / 1e9,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sdf_bytes / t_sdf / 1e9 / HBM_PEAK_GBPS,
                 "traffic": None, "algorithmic_bytes_per_launch": sdf_bytes, "avg_launch_ms": kernel_ms["loglik_kernel"],

@@ -221,7 +221,7 @@ def test_adam_trajectory_matches_oracle():
     assert np.abs(pl.raw_var[0].cpu().numpy() - p.raw_var).max() < tol
 
 
-@pytest.mark.parametrize("S,N,P", [(8, 12, 1), (40, 50, 1), (40, 50, 9)])   # 8 / 4 / 1 lanes per configuration
+@pytest.mark.parametrize("S,N,P", [(8, 12, 1), (40, 50, 1), (128, 100, 6)])   # 8 / 8 / 1 lanes per configuration
 def test_likelihood_constants_gradient_against_oracle(S, N, P):
     """trainable_params.sigma_obs / alpha (vgpmp_lik_params): gradient of the training loss wrt the two raw variables,
     every problem of the batch with its own values."""

@@ -312,7 +312,7 @@ def test_split_path_kernels_equal_one_workgroup_form():
 
 def test_large_batch_kernels_match_small_launch_kernels():
     """Large batches use the LDS-tiled prior GEMM (split_k = 1) and one lane per configuration in the
-    likelihood; each problem must still equal the same problem evaluated alone (split-K GEMM, 4 lanes per
+    likelihood; each problem must still equal the same problem evaluated alone (split-K GEMM, 8 lanes per
     configuration) up to float32 summation order."""
     from vgpmp_amd import engine
     S, N, M, B = 128, 60, 7, 64

@@ -684,11 +684,13 @@ __global__ __launch_bounds__(kBlock) void sdf_pack_kernel(const double* __restri
 
 }  // namespace
 
-// lanes per configuration: 8 or 4 while the launch is too small to fill the chip (bound by the length of one
+// lanes per configuration: 8 while the launch is too small to fill the chip (bound by the length of one
 // configuration's dependent chain), else 1
 static int lik_lpc(int P, int S, int N) {
     const long long n = (long long)P * S * N;
-    return n <= 16384 ? 8 : (n <= 65536 ? 4 : 1);
+    // measured on config 2 shapes (12 800 configurations per problem): 8 lanes win up to 5 problems, one lane per
+    // configuration from 6; 4 lanes (loglik_paths_wide_kernel<4>) never did once the 8-lane form had its scan
+    return n <= 65536 ? 8 : 1;
 }
 int vg_loglik_blocks_per_problem(int S, int N) { return (S * N * 8 + kLikBlock - 1) / kLikBlock; }   // upper bound
 
@@ -757,10 +759,9 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
     const size_t lds = lpc > 1 ? wide_lds_bytes(L, lpc) + (sig ? (size_t)(kLikBlock / lpc) * VGPMP_MAX_SPHERES * sizeof(float) : 0)
                                : lik_lds_bytes(L, true) * kLikBatchBlock / kLikBlock;
     const void* fn = lpc == 8 ? (sig ? (const void*)loglik_paths_wide_kernel<8, true> : (const void*)loglik_paths_wide_kernel<8, false>)
-                   : lpc == 4 ? (sig ? (const void*)loglik_paths_wide_kernel<4, true> : (const void*)loglik_paths_wide_kernel<4, false>)
                               : (sig ? (const void*)loglik_paths_kernel<1, kLikBatchBlock, true>
                                      : (const void*)loglik_paths_kernel<1, kLikBatchBlock, false>);
-    int rc = lik_grant_lds(fn, lds, &granted[(lpc == 8 ? 0 : lpc == 4 ? 2 : 4) + (sig ? 1 : 0)]);
+    int rc = lik_grant_lds(fn, lds, &granted[(lpc == 8 ? 0 : 4) + (sig ? 1 : 0)]);
     if (rc) return rc;
     int dbg = 0;
 #ifdef VGPMP_BISECT
@@ -773,13 +774,6 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
                                   f, S, L, N, scale, G, logp, lik_partial, alpha_eff, sigma_eff, sig_partial);
         else
             hipExtLaunchKernelGGL((loglik_paths_wide_kernel<8, false>), dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf,
-                                  f, S, L, N, scale, G, logp, lik_partial, nullptr, nullptr, nullptr);
-    } else if (lpc == 4) {
-        if (sig)
-            hipExtLaunchKernelGGL((loglik_paths_wide_kernel<4, true>), dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf,
-                                  f, S, L, N, scale, G, logp, lik_partial, alpha_eff, sigma_eff, sig_partial);
-        else
-            hipExtLaunchKernelGGL((loglik_paths_wide_kernel<4, false>), dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf,
                                   f, S, L, N, scale, G, logp, lik_partial, nullptr, nullptr, nullptr);
     } else {
         if (sig)
