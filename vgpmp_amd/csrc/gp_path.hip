@@ -2374,7 +2374,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     fe.N = N; fe.Mz = Mz; fe.L = L; fe.D = L; fe.B = B;
     // few problems: few points per workgroup (more parallelism); many: sweep 16 points per lane (omega reuse)
     // (shared launches: 8 for one problem -- the role is off the pole either way --, 16 from two: 105 -> 95 us per step)
-    fe.jchunk = fused ? (P > 1 ? 16 : 8) : (P * L >= 64 ? 16 : 1);
+    fe.jchunk = fused ? (P > 1 ? 16 : 8) : (P * L >= 16 ? 16 : 4);
     fe.X = pb->X; fe.Zy = pb->Zy; fe.raw_ell = params->raw_ell; fe.raw_var = params->raw_var;
     fe.omega = nz->omega; fe.beta = nz->beta; fe.Phi = ws->Phi; fe.dPhi = want_dell ? ws->dPhi : nullptr;
     fe.tick = (!fused && do_adam) ? ctr : nullptr;
