@@ -25,6 +25,7 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kMidMaxPL = 96;       // merged launches of the one-launch-per-kernel schedule up to this many pairs
 constexpr int kFuseMaxPL = 32;      // measured on config 2: shared launches win up to 4 problems (x 7 latents), one launch per kernel from 5
 constexpr double kVarFloor = 0.1;               // models/vgpmp.py:139 positive(lower=1e-1)
 constexpr double kSqrt5 = 2.2360679774997896964;
@@ -1705,19 +1706,25 @@ constexpr int kTS = 64, kTJ = 144, kTK = 32, kTLd = 36;
 // MT = 16-row tiles per wave: a workgroup owns 64 MT samples.  MT = 2 (128 samples x 144 columns) moves 35 % fewer
 // operand bytes per flop than MT = 1 and keeps a slice's products long enough (144 per wave) to cover the next
 // slice's loads; dynamic LDS 2 (64 MT + 144) 36 4 B = 60 / 78 KB, two workgroups per CU either way.
+struct TiledGemmArgs {
+    int S, L, J, B, nsel;
+    const float *W, *Phi, *dPhi;
+    float *F0, *H;
+};
 template <int MT>
-__global__ __launch_bounds__(kBlock) void prior_gemm_tiled_kernel(int S, int L, int J, int B, int nsel,
-                                                                   const float* __restrict__ W,
-                                                                   const float* __restrict__ Phi,
-                                                                   const float* __restrict__ dPhi,
-                                                                   float* __restrict__ F0, float* __restrict__ H) {
+__device__ __forceinline__ void prior_gemm_tiled_body(const TiledGemmArgs& ta, float* tg_lds, int bx, int by, int bz) {
+    const int S = ta.S, L = ta.L, J = ta.J, B = ta.B, nsel = ta.nsel;
+    const float* __restrict__ W = ta.W;
+    const float* __restrict__ Phi = ta.Phi;
+    const float* __restrict__ dPhi = ta.dPhi;
+    float* __restrict__ F0 = ta.F0;
+    float* __restrict__ H = ta.H;
     constexpr int TS = kTS * MT, NA = TS * 8 / kBlock;      // A: TS rows x 8 chunks of 16 bytes, NA per thread
-    extern __shared__ __attribute__((aligned(16))) float tg_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int z = blockIdx.z;
+    int z = bz;
     const int sel = z % nsel; z /= nsel;
     const int l = z % L, p = z / L;
-    const int s0 = blockIdx.y * TS, j0 = blockIdx.x * kTJ;
+    const int s0 = by * TS, j0 = bx * kTJ;
     const float* Bm = sel == 0 ? Phi : dPhi;
     float* Out = sel == 0 ? F0 : H;
     // staging map: thread -> (row, 16-byte k-chunk); B: 144 rows x 8 chunks = 1152 (4.5 per thread -> 5 passes, last partial)
@@ -1802,6 +1809,12 @@ __global__ __launch_bounds__(kBlock) void prior_gemm_tiled_kernel(int S, int L, 
 }
 #undef VG_TG_LOAD
 #undef VG_TG_STORE
+
+template <int MT>
+__global__ __launch_bounds__(kBlock) void prior_gemm_tiled_kernel(TiledGemmArgs ta) {
+    extern __shared__ __attribute__((aligned(16))) float tg_lds[];
+    prior_gemm_tiled_body<MT>(ta, tg_lds, blockIdx.x, blockIdx.y, blockIdx.z);
+}
 
 // =================================================================================================
 // Path assembly  (decoupled / Matheron update, vgpmp.py:281-282):
@@ -2114,6 +2127,73 @@ __global__ __launch_bounds__(kBlock) void stage3_kernel(Stage3Args a) {
     rng_normals_body(a.rng, b % a.w_gx, b / a.w_gx, a.rng.nW, 0u);
 }
 
+// ---- medium batches (5 problems up, one launch per kernel): independent kernels of a dependency level share a
+// launch here too.  The latency-bound ones (cov_a, cov_b, hyper-parameter update, final) then run beside the
+// throughput-bound ones (noise draws, tiled GEMM) instead of in front of them: 7 launches per step instead of 11.
+struct MidAArgs {            // cov_a | omega, beta | w, eps, eps'
+    CovArgs cov; RngArgs rng;
+    int n_cov, n_basis, basis_gx, n_gx;
+};
+__global__ __launch_bounds__(kCovThreads) void mid_cov_a_rng_kernel(MidAArgs a) {
+    extern __shared__ double sm[];
+    int b = blockIdx.x;
+    if (b < a.n_cov) { cov_a_body(a.cov, sm, b % a.cov.L, b / a.cov.L); return; }
+    b -= a.n_cov;
+    if (b < a.n_basis) { rng_basis_body(a.rng, b % a.basis_gx, b / a.basis_gx); return; }
+    b -= a.n_basis;
+    rng_normals_body(a.rng, b % a.n_gx, b / a.n_gx, a.rng.nW, a.rng.nE);
+}
+
+struct MidCArgs {            // cov_b | tiled prior GEMM
+    CovArgs cov; TiledGemmArgs gemm;
+    int cov_roles, n_cov, gemm_gx, gemm_gy;
+};
+template <bool TANGENTS>
+__global__ __launch_bounds__(kBlock) void mid_cov_b_gemm_kernel(MidCArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    int b = blockIdx.x;
+    if (b < a.n_cov) {
+        const int role = b % a.cov_roles;
+        b /= a.cov_roles;
+        cov_b_body<TANGENTS>(a.cov, sm, role, b % a.cov.L, b / a.cov.L);
+        return;
+    }
+    b -= a.n_cov;
+    const int bx = b % a.gemm_gx;
+    b /= a.gemm_gx;
+    prior_gemm_tiled_body<1>(a.gemm, reinterpret_cast<float*>(sm), bx, b % a.gemm_gy, b / a.gemm_gy);
+}
+
+struct MidGArgs {            // hyper-parameter update | q_mu, q_sqrt update + ELBO pieces
+    HyperArgs hy; FinalArgs fin;
+    int n_hyper;             // = problems
+};
+__global__ __launch_bounds__(kBlock) void mid_hyper_final_kernel(MidGArgs a) {
+    extern __shared__ double sm[];
+    int b = blockIdx.x;
+    const HyperArgs& h = a.hy;
+    const bool own = h.ctr && h.do_adam;
+    const double lr_own = own ? adam_step_size(h.lr, (double)*h.ctr) : 0.0;
+    if (b < a.n_hyper) {
+        const int p = b, l = threadIdx.x;
+        if (own && p == 0 && l == 0) h.lr_store[0] = lr_own;
+        if (l >= h.L) return;
+        const size_t pl = (size_t)p * h.L + l;
+        const HyperState o = hyper_update(h, pl, own, lr_own);
+        h.g_ell[pl] = o.g_ell;
+        h.g_var[pl] = o.g_var;
+        if (h.do_adam) {
+            h.p_ell[pl] = o.raw_ell; h.m_ell[pl] = o.m_ell; h.v_ell[pl] = o.v_ell;
+            h.p_var[pl] = o.raw_var; h.m_var[pl] = o.m_var; h.v_var[pl] = o.v_var;
+        }
+        return;
+    }
+    b -= a.n_hyper;
+    FinalArgs fb = a.fin;      // the step size comes from the counter here: the update role that stores it runs alongside
+    if (own) { fb.use_lr_dev = 0; fb.lr_t = lr_own; }
+    final_body(fb, sm, b % fb.L, b / fb.L);
+}
+
 // ---- likelihood constants as trainable variables (vgpmp_lik_params) -----------------------------------------
 constexpr double kAlphaFloor = 1e-4, kSigmaFloor = 1e-5;      // models/vgpmp.py:82, likelihoods/likelihood.py:31,41
 
@@ -2384,6 +2464,9 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     ga.S = S; ga.L = L; ga.J = J; ga.B = B; ga.SK = SK; ga.nsel = want_dell ? 2 : 1;
     ga.W = nz->w; ga.Phi = ws->Phi; ga.dPhi = ws->dPhi; ga.F0 = ws->F0; ga.H = ws->H; ga.slab = slab;
     ga.dbg = 0;
+    TiledGemmArgs tga;
+    tga.S = S; tga.L = L; tga.J = J; tga.B = B; tga.nsel = ga.nsel;
+    tga.W = nz->w; tga.Phi = ws->Phi; tga.dPhi = ws->dPhi; tga.F0 = ws->F0; tga.H = ws->H;
     const dim3 gemm_grid((J + 16 * kNT - 1) / (16 * kNT), (S + 63) / 64, P * L * SK * ga.nsel);
     PathArgs pa;
     pa.S = S; pa.N = N; pa.Mz = Mz; pa.L = L; pa.SK = SK; pa.NC = NC; pa.slab = slab; pa.part_len = vg_part_len(d);
@@ -2503,6 +2586,18 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         if ((rc = set_dyn_lds(fn_pf, lds_pf))) return rc;
     }
     if ((rc = set_dyn_lds((const void*)final_kernel, lds_fin))) return rc;
+    // medium batches: merged launches (not while profiling stage by stage, not with the shared stage launches)
+    // measured on config 2 shapes: 5 problems 197 -> 182 us per step, 9: 218 -> 205, 16: equal, 24 and 64: 2-6 % slower
+    // (the chip is full by then, the merged kernels only cost registers) -- hence the bound
+    const bool mid = !fused && !ev && tiled_gemm && backward && !(what & VGPMP_NO_FUSE) && P * L <= kMidMaxPL;
+    const size_t lds_tg1 = (size_t)2 * (kTS + kTJ) * kTLd * sizeof(float);
+    const size_t lds_midC = lds_cov_b > lds_tg1 ? lds_cov_b : lds_tg1;
+    const void* fn_midC = backward ? (const void*)mid_cov_b_gemm_kernel<true> : (const void*)mid_cov_b_gemm_kernel<false>;
+    if (mid) {
+        if ((rc = set_dyn_lds((const void*)mid_cov_a_rng_kernel, lds_cov_a))) return rc;
+        if ((rc = set_dyn_lds(fn_midC, lds_midC))) return rc;
+        if ((rc = set_dyn_lds((const void*)mid_hyper_final_kernel, lds_fin))) return rc;
+    }
     const dim3 cov_b_grid(3 + (N + kRowTile - 1) / kRowTile, L, P);
     const uint32_t eps_gx = (2u * (uint32_t)S * Mz * L + kBlock - 1) / kBlock;
     const uint32_t basis_gx = ((uint32_t)L * B + kBlock - 1) / kBlock;
@@ -2572,6 +2667,24 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             s3.n_basis = (gen && more) ? (int)basis_gx * P : 0;
             const unsigned n3 = s3.n_path + s3.n_basis + ((gen && more) ? w_gx * P : 0u);
             if ((rc = launch(fn_s3, dim3(n3), &s3, lds_pf))) return rc;
+        } else if (mid) {
+            // cov_a | noise draws;  features;  cov_b | tiled GEMM
+            MidAArgs ma;
+            ma.cov = ca;
+            ma.rng = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
+            ma.n_cov = L * P; ma.basis_gx = (int)basis_gx; ma.n_basis = gen ? (int)basis_gx * P : 0;
+            const uint32_t n_thr = (ma.rng.nW >> 2) + 2 * ma.rng.nE;
+            ma.n_gx = (int)((n_thr + kBlock - 1) / kBlock);
+            const unsigned nA = ma.n_cov + ma.n_basis + (gen ? (unsigned)ma.n_gx * P : 0u);
+            if ((rc = launch((const void*)mid_cov_a_rng_kernel, dim3(nA), &ma, lds_cov_a))) return rc;
+            hipLaunchKernelGGL(features_kernel, feat_grid, dim3(kBlock), 0, st, fe);
+            MidCArgs mc;
+            mc.cov = ca; mc.gemm = tga;
+            mc.cov_roles = (int)cov_b_grid.x; mc.n_cov = (int)(cov_b_grid.x * cov_b_grid.y * cov_b_grid.z);
+            mc.gemm_gx = (J + kTJ - 1) / kTJ; mc.gemm_gy = (S + kTS - 1) / kTS;
+            const unsigned nC = mc.n_cov + (unsigned)mc.gemm_gx * mc.gemm_gy * P * L * ga.nsel;
+            if ((rc = launch(fn_midC, dim3(nC), &mc, lds_midC))) return rc;
+            if ((rc = launch(fn_pf, dim3(NC * pa.nsplit, L, P), &pa, lds_pf))) return rc;
         } else {
             mark();
             hipLaunchKernelGGL(cov_a_kernel, dim3(L, P), dim3(kCovThreads), lds_cov_a, st, ca);
@@ -2588,12 +2701,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 const void* fn_tg = mt == 2 ? (const void*)prior_gemm_tiled_kernel<2> : (const void*)prior_gemm_tiled_kernel<1>;
                 if ((rc = set_dyn_lds(fn_tg, lds_tg))) return rc;
                 const dim3 tg_grid((J + kTJ - 1) / kTJ, (S + kTS * mt - 1) / (kTS * mt), P * L * ga.nsel);
-                if (mt == 2)
-                    hipExtLaunchKernelGGL(prior_gemm_tiled_kernel<2>, tg_grid, dim3(kBlock), lds_tg, st, g0, g1, 0, S, L, J, B,
-                                          ga.nsel, nz->w, ws->Phi, ws->dPhi, ws->F0, ws->H);
-                else
-                    hipExtLaunchKernelGGL(prior_gemm_tiled_kernel<1>, tg_grid, dim3(kBlock), lds_tg, st, g0, g1, 0, S, L, J, B,
-                                          ga.nsel, nz->w, ws->Phi, ws->dPhi, ws->F0, ws->H);
+                if (mt == 2) hipExtLaunchKernelGGL(prior_gemm_tiled_kernel<2>, tg_grid, dim3(kBlock), lds_tg, st, g0, g1, 0, tga);
+                else hipExtLaunchKernelGGL(prior_gemm_tiled_kernel<1>, tg_grid, dim3(kBlock), lds_tg, st, g0, g1, 0, tga);
             } else if (glds)
                 hipExtLaunchKernelGGL(prior_gemm_lds_kernel, gemm_grid, dim3(kBlock), kGemmLds, st, g0, g1, 0, ga);
             else
@@ -2624,7 +2733,13 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             hipLaunchKernelGGL(lik_update_kernel, dim3(P), dim3(VGPMP_MAX_SPHERES), 0, st, lu);
         }
         mark();
-        if (!(fused && more)) {      // otherwise both ride in stage 1 of the next step
+        if (mid) {
+            MidGArgs mg;
+            hy.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
+            fa.lr_t = hy.lr_t;
+            mg.hy = hy; mg.fin = fa; mg.n_hyper = P;
+            if ((rc = launch((const void*)mid_hyper_final_kernel, dim3(P + L * P), &mg, lds_fin))) return rc;
+        } else if (!(fused && more)) {      // otherwise both ride in stage 1 of the next step
             hy.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
             fa.lr_t = hy.lr_t;
             hipLaunchKernelGGL(hyper_kernel, dim3(P), dim3(64), 0, st, hy);
