@@ -1,2 +1,2 @@
-from vgpmp_amd.host.model import (FirstOrderKernelDerivativeSeparateIndependent, Matern52,  # noqa: F401
+from vgpmp_amd.host.model import (FirstOrderKernelDerivativeSeparateIndependent, Matern52, SquaredExponential,  # noqa: F401
                                   VanillaConditioningSeparateIndependent, VanillaConditioningSharedIndependent)

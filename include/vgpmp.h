@@ -199,6 +199,22 @@ int vgpmp_sdf_query(const vgpmp_sdf* sdf, const double* dev_rel_pos, int64_t n,
 int vgpmp_log_prob(const vgpmp_robot* dev_robot, int32_t dof, const vgpmp_sdf* sdf, const float* dev_g,
                    int64_t n, float* dev_logp, float* dev_dlogp_dg, vgpmp_stream stream);
 
+/* Velocity-constrained kernel variant (kernels.py:4-6 FirstOrderKernelDerivativeSeparateIndependent; unreachable from
+ * VGPMP.initialize in the reference): per latent l, with ny = the two conditioned times Zy[:2, l],
+ *   Kuu = [[d2k(ny, ny) + 1e-6 I, dk(ny, Zy)], [dk(Zy, ny), k(Zy, Zy)]] + jitter I   [L, Mz + 2, Mz + 2]
+ *   Kuf = [dk(ny, X); k(Zy, X)]                                                    [L, Mz + 2, N]
+ * (covariances/multioutput/Kuus.py:17-39, Kufs.py:14-23) with dk = d k(x, y) / dy (derivatives/first_order.py:14-29)
+ * and d2k = d^2 k / dx dy (second_order.py:27-58, exact zeros replaced by 5/3 / ell^2 as there).  kind: 0 Matern-5/2,
+ * 1 squared exponential.  Zy [Mz, L], X [N, L], ell / var [L], all float64 on the device. */
+int vgpmp_kernel_derivative(int32_t kind, int32_t order, const double* dev_x, int32_t n, const double* dev_y, int32_t m,
+                            double lengthscale, double variance, double* dev_out, vgpmp_stream stream);
+/* ^ the K_grad / K_grad_grad dispatchers on plain arrays (derivatives/dispatch.py): out [n, m] = k (order 0),
+ * dk/dy (order 1: K_grad) or d2k/dxdy (order 2: K_grad_grad) of every pair (x_i, y_j). */
+
+int vgpmp_velocity_kuu_kuf(int32_t kind, const double* dev_Zy, const double* dev_X, int32_t Mz, int32_t N, int32_t L,
+                           const double* dev_ell, const double* dev_var, double jitter, double* dev_Kuu, double* dev_Kuf,
+                           vgpmp_stream stream);
+
 /* ---- the ELBO step ------------------------------------------------------------------------- */
 
 int vgpmp_workspace_bytes(const vgpmp_dims* dims, size_t* bytes);

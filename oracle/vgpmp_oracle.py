@@ -614,6 +614,69 @@ def optimization_step_lik(p, lp: LikParams, st, st_lik, scene: Scene, X, Zy, y, 
 
 
 # ----------------------------------------------------------------------------
+# Velocity-constrained kernel variant (SURVEY f-4; unreachable from VGPMP.initialize)
+# ----------------------------------------------------------------------------
+KIND_MATERN52, KIND_SE = 0, 1
+
+
+def squared_exponential(t1, t2, ell, var):
+    d = (np.asarray(t1, dtype=np.float64)[:, None] - np.asarray(t2, dtype=np.float64)[None, :]) / ell
+    return var * np.exp(-0.5 * d * d)
+
+
+def k_grad(x, y, ell: float, var: float, kind: int = KIND_MATERN52) -> np.ndarray:
+    """derivatives/first_order.py:14-29: d k(x, y) / d y  ([len(x), len(y)]).
+    Matern-5/2: var 5/3 (1 + sqrt5 r) exp(-sqrt5 r) (x - y) / ell^2;  SE: (x - y) / ell^2 k(x, y)."""
+    x = np.asarray(x, dtype=np.float64); y = np.asarray(y, dtype=np.float64)
+    diff = x[:, None] - y[None, :]
+    if kind == KIND_SE:
+        return diff / ell ** 2 * squared_exponential(x, y, ell, var)
+    s5r = SQRT5 * np.abs(diff) / ell
+    return (5.0 / 3.0) * (1.0 + s5r) * np.exp(-s5r) * diff / ell ** 2 * var
+
+
+def k_grad_grad(x, y, ell: float, var: float, kind: int = KIND_MATERN52) -> np.ndarray:
+    """derivatives/second_order.py:27-58: d^2 k(x, y) / dx dy.
+    Matern-5/2: -var 5/3 (5 r^2 - sqrt5 r - 1) exp(-sqrt5 r) / ell^2 for r != 0; entries that come out exactly 0
+    (r == 0, where the reference's dr/dx is divide_no_nan -> 0) are REPLACED by 5/3 / ell^2 -- without the variance,
+    as the reference does (second_order.py:45).  SE: (ell^2 - (x - y)^2) / ell^4 k(x, y)."""
+    x = np.asarray(x, dtype=np.float64); y = np.asarray(y, dtype=np.float64)
+    diff = x[:, None] - y[None, :]
+    if kind == KIND_SE:
+        return (ell ** 2 - diff * diff) / ell ** 4 * squared_exponential(x, y, ell, var)
+    r = np.abs(diff) / ell
+    s5r = SQRT5 * r
+    with np.errstate(divide='ignore', invalid='ignore'):
+        dr_dx = np.where(r != 0.0, diff / (r * ell ** 2), 0.0)
+    res = var * (5.0 / 3.0) * (5.0 * r * r - s5r - 1.0) * np.exp(-s5r) * dr_dx * (-dr_dx)
+    return np.where(res == 0.0, (5.0 / 3.0) / ell ** 2, res)
+
+
+def velocity_kuu_kuf(Zy, X, ell, var, jitter=JITTER, kind: int = KIND_MATERN52):
+    """covariances/multioutput/Kuus.py:17-39 and Kufs.py:14-23 for FirstOrderKernelDerivativeSeparateIndependent:
+    per latent l, with ny = the two conditioned times Zy[:2, l],
+        Kuu = [[d2k(ny, ny) + 1e-6 I, dk(ny, Zy)], [dk(Zy, ny), k(Zy, Zy)]] + jitter I     [Mz + 2, Mz + 2]
+        Kuf = [dk(ny, X); k(Zy, X)]                                                      [Mz + 2, N]
+    (the 1e-6 on the 2 x 2 block is gpflow.default_jitter() added by the multi-output K_grad_grad,
+    derivatives/multioutput/second_order.py:11-19)."""
+    Zy = np.asarray(Zy, dtype=np.float64); X = np.asarray(X, dtype=np.float64)
+    Mz, L = Zy.shape
+    N = X.shape[0]
+    kfun = squared_exponential if kind == KIND_SE else matern52
+    Kuu = np.empty((L, Mz + 2, Mz + 2)); Kuf = np.empty((L, Mz + 2, N))
+    for l in range(L):
+        z, ny, x = Zy[:, l], Zy[:2, l], X[:, l]
+        Kuu[l, :2, :2] = k_grad_grad(ny, ny, ell[l], var[l], kind) + JITTER * np.eye(2)
+        Kuu[l, :2, 2:] = k_grad(ny, z, ell[l], var[l], kind)
+        Kuu[l, 2:, :2] = k_grad(z, ny, ell[l], var[l], kind)
+        Kuu[l, 2:, 2:] = kfun(z, z, ell[l], var[l])
+        Kuu[l] += jitter * np.eye(Mz + 2)
+        Kuf[l, :2] = k_grad(ny, x, ell[l], var[l], kind)
+        Kuf[l, 2:] = kfun(z, x, ell[l], var[l])
+    return Kuu, Kuf
+
+
+# ----------------------------------------------------------------------------
 # Plan extraction (A15)
 # ----------------------------------------------------------------------------
 def posterior_mean(p: Params, robot: RobotTable, Xnew, Zy, y, jitter=JITTER) -> np.ndarray:

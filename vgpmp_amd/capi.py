@@ -22,7 +22,7 @@ GEMM_DIRECT, NO_SPLIT, ELIM_BLOCK = 32, 64, 128
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvgpmp_hip.so"
 
 EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_pack", "vgpmp_mesh_sdf", "vgpmp_fk_spheres", "vgpmp_sdf_query",
-           "vgpmp_log_prob", "vgpmp_workspace_bytes", "vgpmp_lik_scratch_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
+           "vgpmp_log_prob", "vgpmp_kernel_derivative", "vgpmp_velocity_kuu_kuf", "vgpmp_workspace_bytes", "vgpmp_lik_scratch_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
            "vgpmp_elbo_steps", "vgpmp_elbo_step_profiled", "vgpmp_adam_step", "vgpmp_workspace_view")
 NUM_STAGES = 8
 NUM_TIMES = 10
@@ -115,7 +115,10 @@ def load(require: bool = True) -> Optional[C.CDLL]:
         "vgpmp_fk_spheres": [vp, vp, i64, vp, vp, vp],
         "vgpmp_sdf_query": [P(Sdf), vp, i64, vp, vp, vp, vp],
         "vgpmp_log_prob": [vp, i32, P(Sdf), vp, i64, vp, vp, vp],
+        "vgpmp_kernel_derivative": [i32, i32, vp, i32, vp, i32, dbl, dbl, vp, vp],
+        "vgpmp_velocity_kuu_kuf": [i32, vp, vp, i32, i32, i32, vp, vp, dbl, vp, vp, vp],
         "vgpmp_workspace_bytes": [P(Dims), P(C.c_size_t)],
+        "vgpmp_lik_scratch_bytes": [P(Dims), P(C.c_size_t)],
         "vgpmp_generate_noise": [P(Dims), P(Noise), u32, u32, u32, vp],
         "vgpmp_elbo_step": [P(Dims), vp, P(Sdf), P(Problem), P(Params), P(Params), P(Params), P(Noise), P(Outputs),
                             vp, C.c_size_t, i32, i32, dbl, i32, u32, u32, u32, vp],

@@ -74,6 +74,22 @@ int vgpmp_workspace_bytes(const vgpmp_dims* dims, size_t* bytes) {
     return 0;
 }
 
+int vgpmp_kernel_derivative(int32_t kind, int32_t order, const double* dev_x, int32_t n, const double* dev_y, int32_t m,
+                            double lengthscale, double variance, double* dev_out, vgpmp_stream stream) {
+    if (!dev_x || !dev_y || !dev_out) return VGPMP_E_ARG;
+    if ((kind != 0 && kind != 1) || order < 0 || order > 2 || n < 0 || m < 0 || !(lengthscale > 0.0)) return VGPMP_E_SHAPE;
+    return vg_launch_kernel_derivative(kind, order, dev_x, n, dev_y, m, lengthscale, variance, dev_out, (hipStream_t)stream);
+}
+
+int vgpmp_velocity_kuu_kuf(int32_t kind, const double* dev_Zy, const double* dev_X, int32_t Mz, int32_t N, int32_t L,
+                           const double* dev_ell, const double* dev_var, double jitter, double* dev_Kuu, double* dev_Kuf,
+                           vgpmp_stream stream) {
+    if (!dev_Zy || !dev_X || !dev_ell || !dev_var || !dev_Kuu || !dev_Kuf) return VGPMP_E_ARG;
+    if ((kind != 0 && kind != 1) || Mz < 2 || N < 1 || L < 1) return VGPMP_E_SHAPE;
+    return vg_launch_velocity_kuu_kuf(kind, dev_Zy, dev_X, Mz, N, L, L, dev_ell, dev_var, jitter, dev_Kuu, dev_Kuf,
+                                      (hipStream_t)stream);
+}
+
 int vgpmp_lik_scratch_bytes(const vgpmp_dims* dims, size_t* bytes) {
     if (!dims || !bytes) return VGPMP_E_ARG;
     int rc = vg_check_dims(dims);

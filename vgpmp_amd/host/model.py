@@ -36,6 +36,18 @@ class Matern52:
         return float(self.variance) * (1 + 5 ** 0.5 * r + 5.0 / 3.0 * r * r) * torch.exp(-5 ** 0.5 * r)
 
 
+class SquaredExponential:
+    def __init__(self, lengthscales=1.0, variance=1.0):
+        self.lengthscales = lengthscales if isinstance(lengthscales, Parameter) else Parameter(lengthscales, name="lengthscales")
+        self.variance = variance if isinstance(variance, Parameter) else Parameter(variance, name="variance")
+
+    def __call__(self, X, X2=None):
+        X = torch.as_tensor(np.asarray(X, dtype=np.float64))
+        X2 = X if X2 is None else torch.as_tensor(np.asarray(X2, dtype=np.float64))
+        d = (X.reshape(-1, 1) - X2.reshape(1, -1)) / float(self.lengthscales)
+        return float(self.variance) * torch.exp(-0.5 * d * d)
+
+
 class SeparateIndependent:
     def __init__(self, kernels, name=None):
         self.kernels = list(kernels)
@@ -47,10 +59,8 @@ class VanillaConditioningSeparateIndependent(SeparateIndependent):
 
 
 class FirstOrderKernelDerivativeSeparateIndependent(SeparateIndependent):
-    """Present in the reference but unreachable from VGPMP.initialize; not implemented (SURVEY f-4)."""
-
-    def __init__(self, *a, **k):
-        raise NotImplementedError("velocity-constrained kernel variant is out of scope (reference: unused)")
+    """Marker class of the velocity-constrained variant (kernels/kernels.py:4-6; unreachable from VGPMP.initialize in
+    the reference).  Kuu / Kuf dispatch on it to the derivative blocks computed on the device (host/derivatives.py)."""
 
 
 class VanillaConditioningSharedIndependent:
@@ -345,15 +355,21 @@ def K_conditioned(Z, X, kernel):
 
 
 def Kuu(inducing_variable, kernel, *, jitter: float = 0.0):
-    """covariances/multioutput/Kuus.py:42-53."""
+    """covariances/multioutput/Kuus.py:42-53 (vanilla) and :17-39 (velocity-constrained variant, on the device)."""
     iv = getattr(inducing_variable, "inducing_variable", inducing_variable)
+    if isinstance(kernel, FirstOrderKernelDerivativeSeparateIndependent):
+        from . import derivatives
+        return derivatives.velocity_kuu_kuf(iv, kernel, iv.Zy, jitter)[0]
     K = K_conditioned(iv, iv, kernel)
     return K + jitter * torch.eye(K.shape[-1], dtype=K.dtype)
 
 
 def Kuf(inducing_variable, kernel, Xnew):
-    """covariances/multioutput/Kufs.py:26-34."""
+    """covariances/multioutput/Kufs.py:26-34 (vanilla) and :14-23 (velocity-constrained variant, on the device)."""
     iv = getattr(inducing_variable, "inducing_variable", inducing_variable)
+    if isinstance(kernel, FirstOrderKernelDerivativeSeparateIndependent):
+        from . import derivatives
+        return derivatives.velocity_kuu_kuf(iv, kernel, Xnew, 0.0)[1]
     return K_conditioned(iv, Xnew, kernel)
 
 
