@@ -25,7 +25,8 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kMidMaxPL = 96;       // merged launches of the one-launch-per-kernel schedule up to this many pairs
+constexpr int kMidMaxPL = 96;       // merged launches of the one-launch-per-kernel schedule up to this many pairs ...
+constexpr int kMid2MaxPL = 192;     // ... and only cov_a | noise and hyper | final up to this many (16 problems: 333 -> 323 us)
 constexpr int kFuseMaxPL = 32;      // measured on config 2: shared launches win up to 4 problems (x 7 latents), one launch per kernel from 5
 constexpr double kVarFloor = 0.1;               // models/vgpmp.py:139 positive(lower=1e-1)
 constexpr double kSqrt5 = 2.2360679774997896964;
@@ -2589,7 +2590,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     // medium batches: merged launches (not while profiling stage by stage, not with the shared stage launches)
     // measured on config 2 shapes: 5 problems 197 -> 182 us per step, 9: 218 -> 205, 16: equal, 24 and 64: 2-6 % slower
     // (the chip is full by then, the merged kernels only cost registers) -- hence the bound
-    const bool mid = !fused && !ev && tiled_gemm && backward && !(what & VGPMP_NO_FUSE) && P * L <= kMidMaxPL;
+    const bool mid = !fused && !ev && tiled_gemm && backward && !(what & VGPMP_NO_FUSE) && P * L <= kMid2MaxPL;
+    const bool mid_gemm = P * L <= kMidMaxPL;      // cov_b beside the GEMM only while the chip is not full
     const size_t lds_tg1 = (size_t)2 * (kTS + kTJ) * kTLd * sizeof(float);
     const size_t lds_midC = lds_cov_b > lds_tg1 ? lds_cov_b : lds_tg1;
     const void* fn_midC = backward ? (const void*)mid_cov_b_gemm_kernel<true> : (const void*)mid_cov_b_gemm_kernel<false>;
@@ -2683,7 +2685,15 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             mc.cov_roles = (int)cov_b_grid.x; mc.n_cov = (int)(cov_b_grid.x * cov_b_grid.y * cov_b_grid.z);
             mc.gemm_gx = (J + kTJ - 1) / kTJ; mc.gemm_gy = (S + kTS - 1) / kTS;
             const unsigned nC = mc.n_cov + (unsigned)mc.gemm_gx * mc.gemm_gy * P * L * ga.nsel;
-            if ((rc = launch(fn_midC, dim3(nC), &mc, lds_midC))) return rc;
+            if (mid_gemm) {
+                if ((rc = launch(fn_midC, dim3(nC), &mc, lds_midC))) return rc;
+            } else {
+                if ((rc = launch(fn_cov_b, cov_b_grid, &ca, lds_cov_b))) return rc;
+                const size_t lds_tg = (size_t)2 * (kTS + kTJ) * kTLd * sizeof(float);
+                if ((rc = set_dyn_lds((const void*)prior_gemm_tiled_kernel<1>, lds_tg))) return rc;
+                hipLaunchKernelGGL(prior_gemm_tiled_kernel<1>, dim3((J + kTJ - 1) / kTJ, (S + kTS - 1) / kTS, P * L * ga.nsel),
+                                   dim3(kBlock), lds_tg, st, tga);
+            }
             if ((rc = launch(fn_pf, dim3(NC * pa.nsplit, L, P), &pa, lds_pf))) return rc;
         } else {
             mark();
