@@ -187,7 +187,8 @@ def main():
                 "timing": "HIP events stamped with the kernel's start and end on its stream (hipExtLaunchKernel), "
                           f"mean of {max(1, args.profile_steps)} launches"}
     gemm_kernel = ("prior_gemm_tiled_kernel<1>" if planner.dims.split_k == 1 else
-                   "prior_gemm_lds_kernel" if (1024 // planner.dims.split_k) % 128 == 0 and S >= 48 else "prior_gemm_kernel<0>")
+                   "prior_gemm_lds_kernel" if (1024 // planner.dims.split_k) % 128 == 0 and S >= 48 else
+                   "prior_fused_small_kernel" if planner.dims.split_k == 4 and S <= 32 else "prior_gemm_kernel<0>")
     roof_gemm = {"kernel": gemm_kernel, "bound": "mfma", "achieved": gemm_flops / t_gemm / 1e12,
                  "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_flops / t_gemm / 1e12 / F32_MFMA_PEAK_TFLOPS,
                  "traffic": None, "algorithmic_flops_per_launch": gemm_flops, "avg_launch_ms": kernel_ms["prior_gemm_kernel"]}

@@ -1817,6 +1817,134 @@ __global__ __launch_bounds__(kBlock) void prior_gemm_tiled_kernel(TiledGemmArgs 
     prior_gemm_tiled_body<MT>(ta, tg_lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// Few samples (S <= 32): the prior draws are bound by Phi / dPhi themselves -- every feature is used by only S
+// products, so writing the two matrices (features_kernel) and reading them back (GEMM) is the cost: 157 MB each way
+// for 36 problems of the reference's default shape.  Here a wave forms its feature fragments in registers and feeds
+// them straight to the MFMAs; Phi / dPhi are never stored.  One workgroup per (problem, latent, group of 5 column
+// tiles), wave w = K-slice w of the SK = 4 slabs the path kernels sum anyway.
+struct FusedPriorArgs {
+    int S, L, J, N, D, B, want_dell;
+    const double *X, *Zy, *raw_ell, *raw_var;
+    const float *omega, *beta, *W;
+    float *F0, *H;
+    size_t slab;
+    uint32_t* tick;
+};
+constexpr int kFNT = 5;      // column tiles per workgroup
+template <int MT, int DM, bool DELL>    // 16-row sample tiles; joint-space extent padded to DM (8 or 16); d/d ell wanted
+__global__ __launch_bounds__(kBlock) void prior_fused_small_kernel(FusedPriorArgs a) {
+    __shared__ float pts[kFNT * 16][DM];
+    const int S = a.S, L = a.L, J = a.J, N = a.N, D = a.D, B = a.B;
+    const int tid = threadIdx.x, lane = tid & 63, sk = tid >> 6;      // 4 waves = 4 K-slices
+    const int pl = blockIdx.x, l = pl % L, p = pl / L, j0 = blockIdx.y * (kFNT * 16);
+    if (a.tick && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.tick += 1u;
+    for (int e = tid; e < kFNT * 16 * DM; e += kBlock) {
+        const int jj = e / DM, d = e - jj * DM, j = min(j0 + jj, J - 1);
+        const double* pt = j < N ? a.X + (size_t)j * D : a.Zy + (size_t)(j - N) * D;
+        pts[jj][d] = d < D ? (float)pt[d] : 0.f;
+    }
+    __syncthreads();
+    const float ell = softplus_f((float)a.raw_ell[pl]);
+    const float var = (float)kVarFloor + softplus_f((float)a.raw_var[pl]);
+    const float inv_ell = 1.0f / ell, c = __builtin_amdgcn_sqrtf(2.0f * var / (float)B);
+    const int r = lane & 15, g = lane >> 4;
+    const int kchunk = B / 4, kbeg = sk * kchunk;
+    vg_f32x4 accF[MT][kFNT], accH[MT][kFNT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < kFNT; ++t) { accF[m][t] = (vg_f32x4){0.f, 0.f, 0.f, 0.f}; accH[m][t] = accF[m][t]; }
+    const float* wrow[MT];
+    bool wlive[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int s = 16 * m + r;
+        wrow[m] = a.W + (((size_t)p * S + min(s, S - 1)) * L + l) * B;
+        wlive[m] = s < S;
+    }
+    // operands of a pass (4 bases per lane: 28 frequencies, 4 phases, the W fragments) are requested one pass ahead
+    float om[4][DM], bt[4], om_n[4][DM], bt_n[4];
+    vg_f32x4 a4[MT], a4_n[MT];
+    auto fetch = [&](int k0, float (&o)[4][DM], float (&bb)[4], vg_f32x4 (&aa)[MT]) {
+        const int b0 = min(k0, B - 16) + 4 * g;          // (the look-ahead of the last pass re-reads it)
+        // every load unconditional on a clamped index, masked afterwards (a conditional load is a branch)
+        const float* op = a.omega + ((size_t)pl * B + b0) * D;
+        const float* bp = a.beta + (size_t)pl * B + b0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bb[q] = bp[q];
+#pragma unroll
+            for (int d = 0; d < DM; ++d) {
+                const float v = op[q * D + min(d, D - 1)];
+                o[q][d] = d < D ? v : 0.f;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const vg_f32x4 v = *reinterpret_cast<const vg_f32x4*>(wrow[m] + b0);
+            aa[m] = wlive[m] ? v : (vg_f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    fetch(kbeg, om_n, bt_n, a4_n);
+    for (int k0 = kbeg; k0 < kbeg + kchunk; k0 += 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bt[q] = bt_n[q];
+#pragma unroll
+            for (int d = 0; d < DM; ++d) om[q][d] = om_n[q][d];
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a4[m] = a4_n[m];
+        fetch(k0 + 16, om_n, bt_n, a4_n);
+        // one wave per SIMD issues in order: the features of column tile t + 1 are formed between the products of
+        // tile t (independent work next to each other in the instruction stream), not after them
+        float ph[2][4], dh[2][4];
+        auto feats = [&](int t, float (&pc)[4], float (&dc)[4]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float proj = 0.f;
+#pragma unroll
+                for (int d = 0; d < DM; ++d) proj = fmaf(pts[16 * t + r][d], om[q][d], proj);
+                const float rev = __builtin_amdgcn_fractf((proj * inv_ell + bt[q]) * 0.15915494309189535f);
+                pc[q] = c * __builtin_amdgcn_cosf(rev);
+                dc[q] = c * __builtin_amdgcn_sinf(rev) * proj * inv_ell * inv_ell;
+            }
+        };
+        feats(0, ph[0], dh[0]);
+#pragma unroll
+        for (int t = 0; t < kFNT; ++t) {
+            const int cb = t & 1;
+            if (t + 1 < kFNT) feats(t + 1, ph[cb ^ 1], dh[cb ^ 1]);
+            // (k outermost: consecutive products go to different accumulators; the order per accumulator is unchanged)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    accF[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m][q], ph[cb][q], accF[m][t], 0, 0, 0);
+                    if (DELL) accH[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m][q], dh[cb][q], accH[m][t], 0, 0, 0);
+                }
+        }
+    }
+    // D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+    float* F0 = a.F0 + (size_t)sk * a.slab;
+    float* H = a.H + (size_t)sk * a.slab;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < kFNT; ++t) {
+            const int jc = j0 + 16 * t + r;
+            if (jc >= J) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int s = 16 * m + g * 4 + q;
+                if (s >= S) continue;
+                const size_t o = (((size_t)p * S + s) * L + l) * J + jc;
+                vg_stream(F0 + o, accF[m][t][q]);
+                if (DELL) vg_stream(H + o, accH[m][t][q]);
+            }
+        }
+}
+
 // =================================================================================================
 // Path assembly  (decoupled / Matheron update, vgpmp.py:281-282):
 //   u = m + C eps;  r = u - F0(Z) - sqrt(jitter) eps2;  f = F0(X) + A r
@@ -2592,6 +2720,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     // (the chip is full by then, the merged kernels only cost registers) -- hence the bound
     const bool mid = !fused && !ev && tiled_gemm && backward && !(what & VGPMP_NO_FUSE) && P * L <= kMid2MaxPL;
     const bool mid_gemm = P * L <= kMidMaxPL;      // cov_b beside the GEMM only while the chip is not full
+    // few samples, four K-slices: features inside the GEMM (prior_fused_small_kernel)
+    const bool fused_small = !fused && SK == 4 && S <= 32 && (B % 64) == 0 && !(what & VGPMP_GEMM_DIRECT);
     const size_t lds_tg1 = (size_t)2 * (kTS + kTJ) * kTLd * sizeof(float);
     const size_t lds_midC = lds_cov_b > lds_tg1 ? lds_cov_b : lds_tg1;
     const void* fn_midC = backward ? (const void*)mid_cov_b_gemm_kernel<true> : (const void*)mid_cov_b_gemm_kernel<false>;
@@ -2702,10 +2832,25 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             mark();
             if (gen && (rc = vg_launch_rng(d, nz, seed, problem_base, step_i, ctr, st))) return rc;
             mark();
-            hipLaunchKernelGGL(features_kernel, feat_grid, dim3(kBlock), 0, st, fe);
+            if (!fused_small) hipLaunchKernelGGL(features_kernel, feat_grid, dim3(kBlock), 0, st, fe);
             mark();
             hipEvent_t g0 = ev ? ev[VG_NUM_STAGES + 3] : nullptr, g1 = ev ? ev[VG_NUM_STAGES + 4] : nullptr;
-            if (tiled_gemm) {
+            if (fused_small) {      // features formed inside the GEMM (few samples: Phi / dPhi traffic is the cost)
+                FusedPriorArgs fp;
+                fp.S = S; fp.L = L; fp.J = J; fp.N = N; fp.D = L; fp.B = B; fp.want_dell = want_dell ? 1 : 0;
+                fp.X = pb->X; fp.Zy = pb->Zy; fp.raw_ell = params->raw_ell; fp.raw_var = params->raw_var;
+                fp.omega = nz->omega; fp.beta = nz->beta; fp.W = nz->w; fp.F0 = ws->F0; fp.H = ws->H; fp.slab = slab;
+                fp.tick = fe.tick;
+                const dim3 fgrid(P * L, (J + kFNT * 16 - 1) / (kFNT * 16));
+#define VG_FUSED_SMALL(MT_, DM_)                                                                                    \
+    (want_dell ? (void)hipExtLaunchKernelGGL((prior_fused_small_kernel<MT_, DM_, true>), fgrid, dim3(kBlock), 0, st, g0, g1, \
+                                             0, fp)                                                                  \
+               : (void)hipExtLaunchKernelGGL((prior_fused_small_kernel<MT_, DM_, false>), fgrid, dim3(kBlock), 0, st, g0, g1, \
+                                             0, fp))
+                if (L <= 8) { if (S <= 16) VG_FUSED_SMALL(1, 8); else VG_FUSED_SMALL(2, 8); }
+                else { if (S <= 16) VG_FUSED_SMALL(1, 16); else VG_FUSED_SMALL(2, 16); }
+#undef VG_FUSED_SMALL
+            } else if (tiled_gemm) {
                 const int mt = 1;      // 128-sample tiles (mt = 2) measured slower: 90 vs 98 TF/s at 64 problems
                 const size_t lds_tg = (size_t)2 * (kTS * mt + kTJ) * kTLd * sizeof(float);
                 const void* fn_tg = mt == 2 ? (const void*)prior_gemm_tiled_kernel<2> : (const void*)prior_gemm_tiled_kernel<1>;
