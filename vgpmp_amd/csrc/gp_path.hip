@@ -2718,10 +2718,13 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     // medium batches: merged launches (not while profiling stage by stage, not with the shared stage launches)
     // measured on config 2 shapes: 5 problems 197 -> 182 us per step, 9: 218 -> 205, 16: equal, 24 and 64: 2-6 % slower
     // (the chip is full by then, the merged kernels only cost registers) -- hence the bound
-    const bool mid = !fused && !ev && tiled_gemm && backward && !(what & VGPMP_NO_FUSE) && P * L <= kMid2MaxPL;
-    const bool mid_gemm = P * L <= kMidMaxPL;      // cov_b beside the GEMM only while the chip is not full
     // few samples, four K-slices: features inside the GEMM (prior_fused_small_kernel)
     const bool fused_small = !fused && SK == 4 && S <= 32 && (B % 64) == 0 && !(what & VGPMP_GEMM_DIRECT);
+    // (bounds measured at S = 128; the work per problem scales with the samples)
+    const long long pls = (long long)P * L * S;
+    const bool mid = !fused && !ev && (tiled_gemm || fused_small) && backward && !(what & VGPMP_NO_FUSE) &&
+                     pls <= (long long)kMid2MaxPL * 128;
+    const bool mid_gemm = tiled_gemm && pls <= (long long)kMidMaxPL * 128;      // cov_b beside the GEMM only while the chip is not full
     const size_t lds_tg1 = (size_t)2 * (kTS + kTJ) * kTLd * sizeof(float);
     const size_t lds_midC = lds_cov_b > lds_tg1 ? lds_cov_b : lds_tg1;
     const void* fn_midC = backward ? (const void*)mid_cov_b_gemm_kernel<true> : (const void*)mid_cov_b_gemm_kernel<false>;
@@ -2737,6 +2740,22 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     auto launch = [&](const void* fn, dim3 grid, void* arg, size_t lds) -> int {
         void* kargs[] = {arg};
         return (int)hipLaunchKernel(fn, grid, dim3(kBlock), kargs, lds, st);
+    };
+    auto launch_fused_small = [&](hipEvent_t g0, hipEvent_t g1) {
+        FusedPriorArgs fp;
+        fp.S = S; fp.L = L; fp.J = J; fp.N = N; fp.D = L; fp.B = B; fp.want_dell = want_dell ? 1 : 0;
+        fp.X = pb->X; fp.Zy = pb->Zy; fp.raw_ell = params->raw_ell; fp.raw_var = params->raw_var;
+        fp.omega = nz->omega; fp.beta = nz->beta; fp.W = nz->w; fp.F0 = ws->F0; fp.H = ws->H; fp.slab = slab;
+        fp.tick = fe.tick;
+        const dim3 fgrid(P * L, (J + kFNT * 16 - 1) / (kFNT * 16));
+#define VG_FUSED_SMALL(MT_, DM_)                                            \
+    (want_dell ? (void)hipExtLaunchKernelGGL((prior_fused_small_kernel<MT_, DM_, true>), fgrid, dim3(kBlock), 0, st, g0, g1, \
+                             0, fp)                                  \
+               : (void)hipExtLaunchKernelGGL((prior_fused_small_kernel<MT_, DM_, false>), fgrid, dim3(kBlock), 0, st, g0, g1, \
+                             0, fp))
+        if (L <= 8) { if (S <= 16) VG_FUSED_SMALL(1, 8); else VG_FUSED_SMALL(2, 8); }
+        else { if (S <= 16) VG_FUSED_SMALL(1, 16); else VG_FUSED_SMALL(2, 16); }
+#undef VG_FUSED_SMALL
     };
     auto launch_final = [&]() -> int { return launch((const void*)final_kernel, dim3(L, P), &fa, lds_fin); };
     // likelihood constants as variables (vgpmp_lik_params): effective values from the raw ones at the start of the call
@@ -2809,7 +2828,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             ma.n_gx = (int)((n_thr + kBlock - 1) / kBlock);
             const unsigned nA = ma.n_cov + ma.n_basis + (gen ? (unsigned)ma.n_gx * P : 0u);
             if ((rc = launch((const void*)mid_cov_a_rng_kernel, dim3(nA), &ma, lds_cov_a))) return rc;
-            hipLaunchKernelGGL(features_kernel, feat_grid, dim3(kBlock), 0, st, fe);
+            if (!fused_small) hipLaunchKernelGGL(features_kernel, feat_grid, dim3(kBlock), 0, st, fe);
             MidCArgs mc;
             mc.cov = ca; mc.gemm = tga;
             mc.cov_roles = (int)cov_b_grid.x; mc.n_cov = (int)(cov_b_grid.x * cov_b_grid.y * cov_b_grid.z);
@@ -2817,6 +2836,9 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             const unsigned nC = mc.n_cov + (unsigned)mc.gemm_gx * mc.gemm_gy * P * L * ga.nsel;
             if (mid_gemm) {
                 if ((rc = launch(fn_midC, dim3(nC), &mc, lds_midC))) return rc;
+            } else if (fused_small) {
+                if ((rc = launch(fn_cov_b, cov_b_grid, &ca, lds_cov_b))) return rc;
+                launch_fused_small(nullptr, nullptr);
             } else {
                 if ((rc = launch(fn_cov_b, cov_b_grid, &ca, lds_cov_b))) return rc;
                 const size_t lds_tg = (size_t)2 * (kTS + kTJ) * kTLd * sizeof(float);
@@ -2836,20 +2858,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             mark();
             hipEvent_t g0 = ev ? ev[VG_NUM_STAGES + 3] : nullptr, g1 = ev ? ev[VG_NUM_STAGES + 4] : nullptr;
             if (fused_small) {      // features formed inside the GEMM (few samples: Phi / dPhi traffic is the cost)
-                FusedPriorArgs fp;
-                fp.S = S; fp.L = L; fp.J = J; fp.N = N; fp.D = L; fp.B = B; fp.want_dell = want_dell ? 1 : 0;
-                fp.X = pb->X; fp.Zy = pb->Zy; fp.raw_ell = params->raw_ell; fp.raw_var = params->raw_var;
-                fp.omega = nz->omega; fp.beta = nz->beta; fp.W = nz->w; fp.F0 = ws->F0; fp.H = ws->H; fp.slab = slab;
-                fp.tick = fe.tick;
-                const dim3 fgrid(P * L, (J + kFNT * 16 - 1) / (kFNT * 16));
-#define VG_FUSED_SMALL(MT_, DM_)                                                                                    \
-    (want_dell ? (void)hipExtLaunchKernelGGL((prior_fused_small_kernel<MT_, DM_, true>), fgrid, dim3(kBlock), 0, st, g0, g1, \
-                                             0, fp)                                                                  \
-               : (void)hipExtLaunchKernelGGL((prior_fused_small_kernel<MT_, DM_, false>), fgrid, dim3(kBlock), 0, st, g0, g1, \
-                                             0, fp))
-                if (L <= 8) { if (S <= 16) VG_FUSED_SMALL(1, 8); else VG_FUSED_SMALL(2, 8); }
-                else { if (S <= 16) VG_FUSED_SMALL(1, 16); else VG_FUSED_SMALL(2, 16); }
-#undef VG_FUSED_SMALL
+                launch_fused_small(g0, g1);
             } else if (tiled_gemm) {
                 const int mt = 1;      // 128-sample tiles (mt = 2) measured slower: 90 vs 98 TF/s at 64 problems
                 const size_t lds_tg = (size_t)2 * (kTS * mt + kTJ) * kTLd * sizeof(float);
