@@ -201,6 +201,27 @@ def test_graph_replay_matches_eager_steps():
     assert torch.allclose(a.q_mu, b.q_mu, rtol=0, atol=1e-12) and torch.allclose(a.raw_ell, b.raw_ell, rtol=0, atol=1e-12)
 
 
+def test_graph_replay_of_the_merged_launch_schedule():
+    """Six problems run the medium-batch schedule (cov_a | noise, cov_b | tiled GEMM, update | final): a captured
+    hipGraph of its steps replays to the same parameters as plain launches."""
+    from vgpmp_amd import engine
+    ps = rb.load_problemset("franka", "industrial")
+    spec = rb.load_robot("franka")
+    grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
+    sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
+    qs = np.array([ps.queries[i] for i in range(6)])
+    kw = dict(num_samples=64, num_inducing=12, num_data=40, num_bases=128, lengthscales=[2.0] * 7, variance=0.2, seed=9)
+    a, b = engine.PlannerBatch(sc, qs, **kw), engine.PlannerBatch(sc, qs, **kw)
+    assert a.dims.split_k == 1
+    a.capture(unroll=3)
+    a.run_steps(7)
+    b.run_steps(8)
+    torch.cuda.synchronize()
+    assert a.t == b.t == 8
+    for x, y in ((a.q_mu, b.q_mu), (a.q_sqrt, b.q_sqrt), (a.raw_ell, b.raw_ell), (a.raw_var, b.raw_var)):
+        assert torch.allclose(x, y, rtol=0, atol=1e-12), float((x - y).abs().max())
+
+
 @pytest.mark.parametrize("P", [1, 3])
 def test_pipelined_steps_equal_single_step_calls(P):
     """vgpmp_elbo_steps shares launches between independent kernels and runs the q_mu / q_sqrt update of step t
