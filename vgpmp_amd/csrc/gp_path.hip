@@ -545,6 +545,7 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_split(PathArgs a) {
     float* hz = fz + SC * Mh;
     float* rawx = take(2 * SK * SC * nx);            // the split-K slabs as they arrive
     float* rawz = take(2 * SK * SC * Mh);
+    float* dGA = take(3 * SC * Mh);                  // [3][SC][Mh] G A, G A_ell, G A_var (MFMA form)
     const int s_base = ch * SC;
     const bool dell = a.want_dell != 0;
     VG_T(ch == 0 && half == 0 && l == 0 && p == 0, 500);
@@ -597,13 +598,45 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_split(PathArgs a) {
     VG_STOP(a, 1);
     float se = 0.f, sv = 0.f, sr = 0.f;
     const int par = tid & 1;
+    // Mz = 32 (16 columns per half): the three products G A, G A_ell, G A_var are 16 x 16 tiles (8 sample rows used) over
+    // K = N on the f32 MFMA pipe, one component per wave, instead of N-long scalar chains: [3][SC][16] into LDS
+    if (MZ == 32) {
+        const int wv = tid >> 6, lane = tid & 63, i = lane & 15, kk = lane >> 4;
+        if (wv < 3) {
+            vg_f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+            const float* gp = Gs + min(i, SC - 1) * N;
+            const float* ap = reinterpret_cast<const float*>(A4s) + wv;      // component wv of the float4 at [n][ml]
+            int n = 0;
+            for (; n + 8 <= N; n += 8) {
+                const float a0 = i < SC ? gp[n + kk] : 0.f, a1 = i < SC ? gp[n + 4 + kk] : 0.f;
+                const float b0 = ap[((n + kk) * Mh + i) * 4], b1 = ap[((n + 4 + kk) * Mh + i) * 4];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+            }
+            for (; n < N; n += 4) {
+                const float a0 = i < SC ? gp[n + kk] : 0.f;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, ap[((n + kk) * Mh + i) * 4], acc0, 0, 0, 0);
+            }
+            // D layout: col = lane & 15 (column ml), row = (lane >> 4) * 4 + reg (sample)
+            if (kk < SC / 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dGA[(wv * SC + 4 * kk + q) * Mh + i] = acc0[q] + acc1[q];
+            }
+        }
+        __syncthreads();
+    }
     for (int it = tid >> 1; it < SC * Mh; it += nt >> 1) {      // uniform trip count for the two lanes of a pair
         const int sl = vg_div(it, iMh), ml = it - sl * Mh, mi = m0 + ml;
         const float* g = Gs + sl * N;
         float d = 0.f, de = 0.f, dv = 0.f;
+        if (MZ == 32) {      // (the pair's two lanes add their halves below: the second lane contributes zero)
+            d = par == 0 ? dGA[it] : 0.f;
+            de = par == 0 ? dGA[SC * Mh + it] : 0.f;
+            dv = par == 0 ? dGA[2 * SC * Mh + it] : 0.f;
+        }
         // passes of 8 time points per lane with constant bounds (operands of a pass requested together; the tail is
         // read on clamped indices and masked)
-        for (int nb = 0; nb < N; nb += 16) {
+        for (int nb = 0; MZ != 32 && nb < N; nb += 16) {
             float4 av[8];
             float gv[8];
 #pragma unroll
@@ -2687,7 +2720,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const int Mh = Mz / 2, nxw = N - ((N / 2) & ~3);
     const size_t lds_pbs = ((size_t)4 * N * Mh + (size_t)2 * Mz * Mh + (size_t)SC * N + (size_t)2 * SC * Mh + (size_t)SC * Mz +
                             (size_t)2 * SC * nxw + (size_t)2 * SC * Mh + (size_t)2 * SK * SC * nxw + (size_t)2 * SK * SC * Mh +
-                            11 * 4) * sizeof(float);
+                            (size_t)3 * SC * Mh + 12 * 4) * sizeof(float);
     const bool split_bwd = backward && SK > 1 && Mz % 8 == 0 && N % 4 == 0 && N >= 8 && lds_pbs <= 80 * 1024 &&
                            (size_t)P * L * NC * 2 <= 512 && !(what & VGPMP_NO_SPLIT);
     const size_t lds_pfs = ((size_t)Mz * Mz + (size_t)Mz * nxw + (size_t)4 * SC * Mz + Mz + (size_t)SC * nxw +
