@@ -545,7 +545,7 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_split(PathArgs a) {
     float* hz = fz + SC * Mh;
     float* rawx = take(2 * SK * SC * nx);            // the split-K slabs as they arrive
     float* rawz = take(2 * SK * SC * Mh);
-    float* dGA = take(3 * SC * Mh);                  // [3][SC][Mh] G A, G A_ell, G A_var (MFMA form)
+    float* dGA = take(5 * SC * Mh);                  // [5][SC][Mh] G A, G A_ell, G A_var, eps C_var^T, eps C_ell^T (MFMA form)
     const int s_base = ch * SC;
     const bool dell = a.want_dell != 0;
     VG_T(ch == 0 && half == 0 && l == 0 && p == 0, 500);
@@ -622,6 +622,24 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_split(PathArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) dGA[(wv * SC + 4 * kk + q) * Mh + i] = acc0[q] + acc1[q];
             }
+        } else {
+            // fourth wave: eps (dC/dvar)^T and eps (dC/dell)^T, [SC x Mz] [Mz x 16] each (the factors are triangular:
+            // terms beyond the diagonal are exact zeros, no mask)
+            vg_f32x4_t accv = {0.f, 0.f, 0.f, 0.f}, acce = accv;
+            const float* ep = Es + min(i, SC - 1) * Mz;
+#pragma unroll
+            for (int k = 0; k < MZ; k += 4) {
+                const float a0 = i < SC ? ep[k + kk] : 0.f;
+                accv = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, Cvs[(k + kk) * Mh + i], accv, 0, 0, 0);
+                acce = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, Ces[(k + kk) * Mh + i], acce, 0, 0, 0);
+            }
+            if (kk < SC / 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    dGA[(3 * SC + 4 * kk + q) * Mh + i] = accv[q];
+                    dGA[(4 * SC + 4 * kk + q) * Mh + i] = acce[q];
+                }
+            }
         }
         __syncthreads();
     }
@@ -654,7 +672,10 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_split(PathArgs a) {
             }
         }
         float ue = 0.f, uv = 0.f;
-        if (MZ) {      // (dC/dtheta)^T is upper triangular: the terms beyond the diagonal add exact zeros
+        if (MZ == 32) {
+            uv = par == 0 ? dGA[3 * SC * Mh + it] : 0.f;
+            ue = par == 0 ? dGA[4 * SC * Mh + it] : 0.f;
+        } else if (MZ) {      // (dC/dtheta)^T is upper triangular: the terms beyond the diagonal add exact zeros
 #pragma unroll
             for (int k2 = 0; k2 < (MZ ? MZ / 2 : 1); ++k2) {
                 const int k = par + 2 * k2;
@@ -2720,7 +2741,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const int Mh = Mz / 2, nxw = N - ((N / 2) & ~3);
     const size_t lds_pbs = ((size_t)4 * N * Mh + (size_t)2 * Mz * Mh + (size_t)SC * N + (size_t)2 * SC * Mh + (size_t)SC * Mz +
                             (size_t)2 * SC * nxw + (size_t)2 * SC * Mh + (size_t)2 * SK * SC * nxw + (size_t)2 * SK * SC * Mh +
-                            (size_t)3 * SC * Mh + 12 * 4) * sizeof(float);
+                            (size_t)5 * SC * Mh + 12 * 4) * sizeof(float);
     const bool split_bwd = backward && SK > 1 && Mz % 8 == 0 && N % 4 == 0 && N >= 8 && lds_pbs <= 80 * 1024 &&
                            (size_t)P * L * NC * 2 <= 512 && !(what & VGPMP_NO_SPLIT);
     const size_t lds_pfs = ((size_t)Mz * Mz + (size_t)Mz * nxw + (size_t)4 * SC * Mz + Mz + (size_t)SC * nxw +
