@@ -292,8 +292,9 @@ __device__ __forceinline__ void paths_fwd_body(const PathArgs& a, float* smf, in
 
 // The same on TWO workgroups per (sample chunk, latent) for launches that leave half the chip idle (see
 // paths_bwd_split): both halves form R (half 0 stores it), each assembles f on its half of the time points, so a
-// workgroup stages ~25 instead of ~36 KB.  q_sqrt comes transposed (16-byte rows, conflict-free reads).  The
-// arithmetic and its order are those of paths_fwd_body: identical bits.  Needs SK > 1, N % 4 == 0, Mz % 4 == 0.
+// workgroup stages ~25 instead of ~36 KB.  q_sqrt comes transposed (16-byte rows, conflict-free reads).  With a
+// run-time Mz the arithmetic and its order are those of paths_fwd_body (identical bits); the Mz = 32 instance runs
+// the two products on the MFMA pipe.  Needs SK > 1, N % 4 == 0, Mz % 4 == 0.
 // MZ = 32 fixes the inducing extent at compile time: loops with a run-time trip count stay rolled (load, wait, one
 // FMA per iteration), with a constant one their operands are requested together.
 template <int SK, int MZ = 0>
@@ -343,30 +344,65 @@ __device__ __forceinline__ void paths_fwd_split_body(const PathArgs& a, float* s
     for (int e = tid; e < SC * nx; e += nt) f0x[e] = sum_slabs_lds<SK>(rawx, e, SC * nx);
     for (int e = tid; e < SC * Mz; e += nt) f0z[e] = sum_slabs_lds<SK>(rawz, e, SC * Mz);
     __syncthreads();
-    for (int e = tid; e < SC * Mz; e += nt) {
-        const int sl = vg_div(e, iMz), mi = e - sl * Mz, s = s_base + sl;
-        float u = ms[mi];
-        if (MZ) {      // q_sqrt is lower triangular: the terms beyond the diagonal add exact zeros
+    if (MZ == 32) {
+        // Mz = 32: both products as 16 x 16 tiles (8 sample rows used) on the f32 MFMA pipe -- u = m + eps C^T on two
+        // waves (16 columns each), f = F0 + R A^T on one wave per 16 time points -- instead of 32-long scalar chains.
+        // (The accumulation order inside a product differs from the scalar form: f is no longer bit-identical to
+        // paths_fwd_body, only to float32 rounding.)
+        const int wv = tid >> 6, lane = tid & 63, i = lane & 15, kk = lane >> 4;
+        if (wv < 2) {
+            const int mi = 16 * wv + i;
+            vg_f32x4_t acc;
 #pragma unroll
-            for (int k = 0; k < (MZ ? MZ : 1); ++k) u = fmaf(k <= mi ? CTs[k * Mz + mi] : 0.f, es[sl * Mz + k], u);
-        } else {
+            for (int q = 0; q < 4; ++q) acc[q] = ms[mi];                      // C operand: m broadcast over the rows
+            const float* ep = es + min(i, SC - 1) * Mz;
+#pragma unroll
+            for (int k = 0; k < 32; k += 4)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(i < SC ? ep[k + kk] : 0.f, CTs[(k + kk) * Mz + mi], acc, 0, 0, 0);
+            if (kk < SC / 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int sl = 4 * kk + q, e = sl * Mz + mi, s = s_base + sl;
+                    const float r = acc[q] - f0z[e] - a.sqrt_jitter * e2s[e];
+                    rs[e] = r;
+                    if (half == 0 && s < S) vg_stream(a.R + (((size_t)p * S + s) * L + l) * Mz + mi, r);
+                }
+            }
+        }
+        __syncthreads();
+        for (int t = wv; 16 * t < nx; t += 4) {
+            const int j = min(16 * t + i, nx - 1);
+            vg_f32x4_t acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = kk < SC / 4 ? f0x[(4 * kk + q) * nx + j] : 0.f;
+            const float* rp = rs + min(i, SC - 1) * Mz;
+#pragma unroll
+            for (int k = 0; k < 32; k += 4)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(i < SC ? rp[k + kk] : 0.f, ATs[(k + kk) * nx + j], acc, 0, 0, 0);
+            if (kk < SC / 4 && 16 * t + i < nx) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int s = s_base + 4 * kk + q;
+                    if (s < S) vg_stream(a.f + (((size_t)p * S + s) * L + l) * N + n0 + j, acc[q]);
+                }
+            }
+        }
+    } else {
+        for (int e = tid; e < SC * Mz; e += nt) {
+            const int sl = vg_div(e, iMz), mi = e - sl * Mz, s = s_base + sl;
+            float u = ms[mi];
             for (int k = 0; k <= mi; ++k) u = fmaf(CTs[k * Mz + mi], es[sl * Mz + k], u);
+            const float r = u - f0z[e] - a.sqrt_jitter * e2s[e];
+            rs[e] = r;
+            if (half == 0 && s < S) vg_stream(a.R + (((size_t)p * S + s) * L + l) * Mz + mi, r);
         }
-        const float r = u - f0z[e] - a.sqrt_jitter * e2s[e];
-        rs[e] = r;
-        if (half == 0 && s < S) vg_stream(a.R + (((size_t)p * S + s) * L + l) * Mz + mi, r);
-    }
-    __syncthreads();
-    for (int e = tid; e < SC * nx; e += nt) {
-        const int sl = vg_div(e, inx), j = e - sl * nx, s = s_base + sl;
-        float v = f0x[e];
-        if (MZ) {
-#pragma unroll
-            for (int k = 0; k < (MZ ? MZ : 1); ++k) v = fmaf(ATs[k * nx + j], rs[sl * Mz + k], v);
-        } else {
+        __syncthreads();
+        for (int e = tid; e < SC * nx; e += nt) {
+            const int sl = vg_div(e, inx), j = e - sl * nx, s = s_base + sl;
+            float v = f0x[e];
             for (int k = 0; k < Mz; ++k) v = fmaf(ATs[k * nx + j], rs[sl * Mz + k], v);
+            if (s < S) vg_stream(a.f + (((size_t)p * S + s) * L + l) * N + n0 + j, v);
         }
-        if (s < S) vg_stream(a.f + (((size_t)p * S + s) * L + l) * N + n0 + j, v);
     }
     VG_T(ch2 == 0 && l == 0 && p == 0, 302);
     VG_T(ch2 == 2 * a.NC - 1 && l == L - 1 && p == 0, 305);
