@@ -433,6 +433,7 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
     float* Rs = take(SC * Mz);                       // [SC][Mz]
     float* Es = take(SC * Mz);                       // [SC][Mz]
     float* dRs = take(SC * Mz);                      // [SC][Mz]
+    float* dGA = take(5 * SC * Mz);                  // [5][SC][Mz] G A, G A_ell, G A_var, eps C_var^T, eps C_ell^T (MFMA form)
     float* raw = take(0);                            // [2][SK][SC][J] slabs of F0 and H as they arrive (RAW)
     const int s_base = ch * SC;
     VG_T(ch == 0 && l == 0 && p == 0, 500);
@@ -490,11 +491,57 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
     VG_T(ch == 0 && l == 0 && p == 0, 501);
     VG_STOP(a, 1);
     float se = 0.f, sv = 0.f, sr = 0.f;
+    // Mz = 32: the five small products as 16 x 16 MFMA tiles (8 sample rows used) -- waves 0..2 one component of G A each
+    // (both column halves), wave 3 the two triangular products -- instead of N-long scalar chains per thread
+    const bool tiles = Mz == 32 && (N & 3) == 0 && nt == 256;
+    if (tiles) {
+        const int wv = tid >> 6, lane = tid & 63, i = lane & 15, kk = lane >> 4;
+        if (wv < 3) {
+            vg_f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            const float* gp = Gs + min(i, SC - 1) * N;
+            const float* ap = reinterpret_cast<const float*>(A4s) + wv;      // component wv of the float4 at [n][mi]
+            for (int n = 0; n < N; n += 4) {
+                const float a0 = i < SC ? gp[n + kk] : 0.f;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, ap[((n + kk) * 32 + 16 * h + i) * 4], acc[h], 0, 0, 0);
+            }
+            if (kk < SC / 4) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dGA[(wv * SC + 4 * kk + q) * 32 + 16 * h + i] = acc[h][q];
+            }
+        } else {
+            vg_f32x4_t accv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acce[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            const float* ep = Es + min(i, SC - 1) * 32;
+#pragma unroll
+            for (int k = 0; k < 32; k += 4) {
+                const float a0 = i < SC ? ep[k + kk] : 0.f;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    accv[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, Cvs[(k + kk) * 32 + 16 * h + i], accv[h], 0, 0, 0);
+                    acce[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, Ces[(k + kk) * 32 + 16 * h + i], acce[h], 0, 0, 0);
+                }
+            }
+            if (kk < SC / 4) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        dGA[(3 * SC + 4 * kk + q) * 32 + 16 * h + i] = accv[h][q];
+                        dGA[(4 * SC + 4 * kk + q) * 32 + 16 * h + i] = acce[h][q];
+                    }
+            }
+        }
+        __syncthreads();
+    }
     for (int e = tid; e < SC * Mz; e += nt) {
         const int sl = vg_div(e, iMz), mi = e - sl * Mz;
         const float* g = Gs + sl * N;
         float d = 0.f, de = 0.f, dv = 0.f;
-        for (int n = 0; n < N; ++n) {
+        if (tiles) { d = dGA[e]; de = dGA[SC * 32 + e]; dv = dGA[2 * SC * 32 + e]; }
+        for (int n = 0; !tiles && n < N; ++n) {
             const float4 av = A4s[n * Mz + mi];
             const float gv = g[n];
             d = fmaf(gv, av.x, d);
@@ -503,7 +550,8 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
         }
         dRs[e] = d;
         float ue = 0.f, uv = 0.f;
-        for (int k = 0; k <= mi; ++k) {
+        if (tiles) { uv = dGA[3 * SC * 32 + e]; ue = dGA[4 * SC * 32 + e]; }
+        for (int k = 0; !tiles && k <= mi; ++k) {
             const float ev = Es[sl * Mz + k];
             uv = fmaf(Cvs[k * Mz + mi], ev, uv);
             ue = fmaf(Ces[k * Mz + mi], ev, ue);
@@ -2745,7 +2793,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const size_t raw_f = SK == 1 ? 0 : (size_t)SK * SC * J * sizeof(float);      // one slab lands in place
     size_t lds_pf = ((size_t)Mz * (Mz + 1) + (size_t)Mz * N + (size_t)3 * SC * Mz + Mz + (size_t)SC * J + 6 * 4) * sizeof(float);
     size_t lds_pb = ((size_t)4 * N * Mz + (size_t)2 * Mz * Mz + (size_t)SC * N + (size_t)2 * SC * J +
-                     (size_t)3 * SC * Mz + 9 * 4) * sizeof(float);
+                     (size_t)8 * SC * Mz + 10 * 4) * sizeof(float);
     const bool raw_fwd = lds_pf + raw_f <= 64 * 1024, raw_bwd = lds_pb + 2 * raw_f <= 160 * 1024;
     if (raw_fwd) lds_pf += raw_f;
     if (raw_bwd) lds_pb += 2 * raw_f;
