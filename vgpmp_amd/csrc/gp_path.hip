@@ -271,20 +271,63 @@ __device__ __forceinline__ void paths_fwd_body(const PathArgs& a, float* smf, in
         for (int e = tid; e < SC * J; e += nt) f0s[e] = sum_slabs_lds<SK>(raw, e, SC * J);
         __syncthreads();
     }
-    for (int e = tid; e < SC * Mz; e += nt) {
-        const int sl = vg_div(e, iMz), mi = e - sl * Mz, s = s_base + sl;
-        float u = ms[mi];
-        for (int k = 0; k <= mi; ++k) u = fmaf(Cs[mi * ld + k], es[sl * Mz + k], u);
-        const float r = u - f0s[sl * J + N + mi] - a.sqrt_jitter * e2s[e];
-        rs[e] = r;
-        if (s < S) vg_stream(a.R + (((size_t)p * S + s) * L + l) * Mz + mi, r);
-    }
-    __syncthreads();
-    for (int e = tid; e < SC * N; e += nt) {
-        const int sl = vg_div(e, iN), n = e - sl * N, s = s_base + sl;
-        float v = f0s[sl * J + n];
-        for (int k = 0; k < Mz; ++k) v = fmaf(ATs[k * N + n], rs[sl * Mz + k], v);
-        if (s < S) vg_stream(a.f + (((size_t)p * S + s) * L + l) * N + n, v);
+    if (Mz == 32 && SC == 8 && nt == 256) {
+        // Mz = 32: u = m + eps C^T (two 16-column tiles) and f = F0 + R A^T (one 16-point tile per wave and round) on the
+        // f32 MFMA pipe, 8 of 16 rows used, instead of 32-long scalar chains per thread
+        const int wv = tid >> 6, lane = tid & 63, i = lane & 15, kk = lane >> 4;
+        if (wv < 2) {
+            const int mi = 16 * wv + i;
+            vg_f32x4_t acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = ms[mi];
+            const float* ep = es + min(i, SC - 1) * 32;
+#pragma unroll
+            for (int k = 0; k < 32; k += 4)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(i < SC ? ep[k + kk] : 0.f, Cs[mi * ld + k + kk], acc, 0, 0, 0);
+            if (kk < SC / 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int sl = 4 * kk + q, e = sl * 32 + mi, s = s_base + sl;
+                    const float r = acc[q] - f0s[sl * J + N + mi] - a.sqrt_jitter * e2s[e];
+                    rs[e] = r;
+                    if (s < S) vg_stream(a.R + (((size_t)p * S + s) * L + l) * 32 + mi, r);
+                }
+            }
+        }
+        __syncthreads();
+        for (int t = wv; 16 * t < N; t += 4) {
+            const int n = min(16 * t + i, N - 1);
+            vg_f32x4_t acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = kk < SC / 4 ? f0s[(4 * kk + q) * J + n] : 0.f;
+            const float* rp = rs + min(i, SC - 1) * 32;
+#pragma unroll
+            for (int k = 0; k < 32; k += 4)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(i < SC ? rp[k + kk] : 0.f, ATs[(k + kk) * N + n], acc, 0, 0, 0);
+            if (kk < SC / 4 && 16 * t + i < N) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int s = s_base + 4 * kk + q;
+                    if (s < S) vg_stream(a.f + (((size_t)p * S + s) * L + l) * N + n, acc[q]);
+                }
+            }
+        }
+    } else {
+        for (int e = tid; e < SC * Mz; e += nt) {
+            const int sl = vg_div(e, iMz), mi = e - sl * Mz, s = s_base + sl;
+            float u = ms[mi];
+            for (int k = 0; k <= mi; ++k) u = fmaf(Cs[mi * ld + k], es[sl * Mz + k], u);
+            const float r = u - f0s[sl * J + N + mi] - a.sqrt_jitter * e2s[e];
+            rs[e] = r;
+            if (s < S) vg_stream(a.R + (((size_t)p * S + s) * L + l) * Mz + mi, r);
+        }
+        __syncthreads();
+        for (int e = tid; e < SC * N; e += nt) {
+            const int sl = vg_div(e, iN), n = e - sl * N, s = s_base + sl;
+            float v = f0s[sl * J + n];
+            for (int k = 0; k < Mz; ++k) v = fmaf(ATs[k * N + n], rs[sl * Mz + k], v);
+            if (s < S) vg_stream(a.f + (((size_t)p * S + s) * L + l) * N + n, v);
+        }
     }
     VG_T(ch == 0 && l == 0 && p == 0, 302);
     VG_T(ch == a.NC - 1 && l == L - 1 && p == 0, 305);
