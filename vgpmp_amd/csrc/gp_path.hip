@@ -846,11 +846,23 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_split(PathArgs a) {
         vg_stream(out + m0 + ml, t);
     }
     float* oC = out + Mz;
-    for (int e = tid; e < Mh * Mz; e += nt) {
-        const int ml = vg_div(e, iMz), k = e - ml * Mz;
-        float t = 0.f;
-        for (int sl = 0; sl < SC; ++sl) t = fmaf(dRs[sl * Mh + ml], Es[sl * Mz + k], t);
-        vg_stream(oC + (size_t)m0 * Mz + e, t);
+    if (MZ == 32) {      // dC rows of this half = dR^T eps: [16 x SC] [SC x 32], two MFMA tiles (waves 0 and 1)
+        const int wv = tid >> 6, lane = tid & 63, i = lane & 15, kk = lane >> 4;
+        if (wv < 2) {
+            vg_f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < SC; k += 4)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dRs[(k + kk) * Mh + i], Es[(k + kk) * Mz + 16 * wv + i], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vg_stream(oC + (size_t)(m0 + 4 * kk + q) * Mz + 16 * wv + i, acc[q]);
+        }
+    } else {
+        for (int e = tid; e < Mh * Mz; e += nt) {
+            const int ml = vg_div(e, iMz), k = e - ml * Mz;
+            float t = 0.f;
+            for (int sl = 0; sl < SC; ++sl) t = fmaf(dRs[sl * Mh + ml], Es[sl * Mz + k], t);
+            vg_stream(oC + (size_t)m0 * Mz + e, t);
+        }
     }
     se = vg_wave_sum(se); sv = vg_wave_sum(sv); sr = vg_wave_sum(sr);
     if ((tid & 63) == 0) { red[0][tid >> 6] = se; red[1][tid >> 6] = sv; red[2][tid >> 6] = sr; }
