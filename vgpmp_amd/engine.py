@@ -151,7 +151,9 @@ class PlannerBatch:
         self.seed, self.problem_base, self.t = int(seed), int(problem_base), 0
         if split_k is None:   # K-slices of the prior GEMM: few problems -> slices to fill the chip (fused stage launches)
             # large batches: the LDS-tiled GEMM (no slices) -- its 64-sample tiles need S >= 48 to pay off
-            split_k = 4 if (P * L <= 32 or S < 48) else 1      # (5 problems up: 214 vs 227 us per step without slices)
+            # K-slices pay while the launch is small: measured on config 2 shapes, 2 problems 88 vs 99 us per step with 4
+            # slices, 3 problems 130 vs 123, 4 problems 152 vs 148, 5 up: one launch per kernel with the tiled GEMM
+            split_k = 4 if (P * L <= 16 or S < 48) else 1
             while (B // split_k) % 16:
                 split_k //= 2
         self.dims = capi.Dims(P, S, int(samples_total or S), N, M, L, B, int(split_k), int(sample_offset), 0)
