@@ -27,6 +27,8 @@ sys.path.insert(0, ROOT)
 from vgpmp_amd import engine, robots, scenes  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_ACHIEVABLE_GBPS = 6290.0    # same guide: measured float4 copy
+SUMMARY = {"auto": None, "on": True, "off": False}
 F32_MFMA_PEAK_TFLOPS = 157.3    # v_mfma_f32_16x16x4_f32 dense peak
 
 
@@ -37,11 +39,13 @@ def build_problem(rank: int, args):
         # BASELINE config 5, one GPU's share: synthetic 14-DoF arm, 512^3 float4 table (2 GiB > Infinity Cache),
         # random start-goal pairs in +-2 rad (seed 0)
         spec = robots.synthetic_arm(14)
-        grid = scenes.synthetic_boxes_sdf(n=args.grid, delta=2.0 / args.grid, origin=(-1.0, -1.0, -1.0), seed=0,
-                                          n_boxes=24, n_spheres=16, dtype=np.float32)
+        rows = scenes.AnalyticSceneRows(args.grid, 2.0 / args.grid, (-1.0, -1.0, -1.0), seed=0, n_boxes=24, n_spheres=16,
+                                        round_to=torch.float32)      # evaluated on the device, slab by slab
+        grid = (rows, rows.origin, rows.delta)
         rng = np.random.default_rng(rank)
         qs = rng.uniform(-2.0, 2.0, (args.problems, 2, 14))
-        scene = engine.DeviceScene(spec, grid, (0.0, 0.0, 0.0), sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"])
+        scene = engine.DeviceScene(spec, grid, (0.0, 0.0, 0.0), sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"],
+                                   layout=args.layout, free_space_summary=SUMMARY[args.summary])
         planner = engine.PlannerBatch(scene, qs, num_samples=args.samples, num_inducing=args.inducing,
                                       num_data=args.timesteps, num_bases=1024, lengthscales=[2.0] * 14, variance=0.2,
                                       alpha=pp["alpha"], learning_rate=pp["learning_rate"], seed=1234,
@@ -54,7 +58,8 @@ def build_problem(rank: int, args):
         grid = scenes.scene_sdf("industrial", delta=0.0125, padding=20)
     else:
         grid = scenes.synthetic_boxes_sdf(n=args.grid, delta=1.6 / args.grid, origin=(-0.8, -0.8, -0.2), seed=0)
-    scene = engine.DeviceScene(spec, grid, ps.object_positions[0], sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"])
+    scene = engine.DeviceScene(spec, grid, ps.object_positions[0], sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"],
+                               layout=args.layout, free_space_summary=SUMMARY[args.summary])
     queries = ps.queries
     qs = np.array([queries[(rank * args.problems + i) % len(queries)] for i in range(args.problems)])
     planner = engine.PlannerBatch(scene, qs, num_samples=args.samples, num_inducing=args.inducing,
@@ -116,6 +121,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=40)
     ap.add_argument("--allow-nan", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--traffic-file", default="", help="pmc traffic table (tools/pmc_aggregate.py) for roofline.traffic")
+    ap.add_argument("--layout", choices=("brick", "linear"), default="brick", help="voxel table layout (include/vgpmp.h)")
+    ap.add_argument("--summary", choices=("auto", "on", "off"), default="auto",
+                    help="free-space brick summary in the batch likelihood kernel (auto: tables beyond the Infinity Cache)")
+    ap.add_argument("--min-seconds", type=float, default=0.5,
+                    help="the timed region repeats the K steps until this much time has passed (K = --steps alone is ~1 ms)")
     ap.add_argument("--workload", choices=("config2", "stress"), default="config2",
                     help="config2 = the benchmark line; stress = BASELINE config 5 per-GPU share (use --problems 64 --grid 512)")
     args = ap.parse_args()
@@ -149,11 +160,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # K steps are ~1 ms of device time at one problem: repeat the K-step block (same call, same schedule) until
+    # --min-seconds have passed, so that the figure does not hang on one host-side hiccup.  Every rank runs the same
+    # number of blocks (rank 0 decides), ms_per_step is over all of them.
     barrier()
     t0 = time.perf_counter()
     planner.run_steps(args.steps)
     barrier()
-    elapsed = time.perf_counter() - t0
+    first = time.perf_counter() - t0
+    reps = max(1, int(np.ceil(args.min_seconds / max(first, 1e-6)))) if args.min_seconds > 0 else 1
+    if dist is not None:
+        r = torch.tensor([reps], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.broadcast(r, 0)
+        reps = int(r[0])
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        planner.run_steps(args.steps)
+    barrier()
+    elapsed = (time.perf_counter() - t0) / reps
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -178,12 +203,19 @@ def main():
     S, N, M, D, P, B = args.samples, args.timesteps, args.inducing, spec.dof, spec.num_spheres, 1024
     npb = args.problems
     sdf_bytes = npb * S * N * (28 * P + 8 * D + 4)                 # 7 fp32 voxels per sphere query
+    sdf_bytes16 = npb * S * N * (16 * P + 8 * D + 4)               # what the packed table moves: one 16-byte record per query
     gemm_flops = npb * 2 * (2.0 * S * (N + M + 2) * D * B)         # F0 and H (lengthscales trainable)
     t_sdf, t_gemm = kernel_ms["loglik_kernel"] * 1e-3, kernel_ms["prior_gemm_kernel"] * 1e-3
-    lik_kernel = "loglik_paths_wide_kernel<8, false>" if npb * S * N <= 65536 else "loglik_paths_kernel<1, 64, false>"
+    lik_kernel = ("loglik_paths_wide_kernel<8, false>" if npb * S * N <= 65536 else
+                  "loglik_paths_kernel<1, 64, false, %s>" % ("true" if scene.free_space_summary else "false"))
     roof_sdf = {"kernel": lik_kernel, "bound": "hbm", "achieved": sdf_bytes / t_sdf / 1e9,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sdf_bytes / t_sdf / 1e9 / HBM_PEAK_GBPS,
                 "traffic": None, "algorithmic_bytes_per_launch": sdf_bytes, "avg_launch_ms": kernel_ms["loglik_kernel"],
+                "frac_of_achievable_6.29TBps": sdf_bytes / t_sdf / 1e9 / HBM_ACHIEVABLE_GBPS,
+                "by_16B_per_query": {"bytes_per_launch": sdf_bytes16, "achieved": sdf_bytes16 / t_sdf / 1e9,
+                                     "frac": sdf_bytes16 / t_sdf / 1e9 / HBM_PEAK_GBPS},
+                "table": {"layout": args.layout, "bytes": int(scene.table.numel() * 4),
+                          "free_space_summary": bool(scene.free_space_summary)},
                 "timing": "HIP events stamped with the kernel's start and end on its stream (hipExtLaunchKernel), "
                           f"mean of {max(1, args.profile_steps)} launches"}
     gemm_kernel = ("prior_gemm_tiled_kernel<1>" if planner.dims.split_k == 1 else
@@ -194,7 +226,9 @@ def main():
                  "traffic": None, "algorithmic_flops_per_launch": gemm_flops, "avg_launch_ms": kernel_ms["prior_gemm_kernel"]}
     dominant = max(stage_ms, key=stage_ms.get)
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tfile) and args.workload == "config2" and npb == 1:
+    if args.traffic_file:
+        tfile = args.traffic_file
+    if os.path.exists(tfile) and (args.traffic_file or (args.workload == "config2" and npb == 1)):
         try:
             t = json.load(open(tfile))
             roof_sdf["traffic"] = t.get(lik_kernel, {}).get("hbm_bytes_per_launch")
@@ -208,11 +242,12 @@ def main():
             "metric": "ELBO iters/sec + plans/sec, Franka-7DoF industrial S=128 M=30 T=100, 1/2/4/8 GPU",
             "value": world * npb * args.steps / elapsed, "unit": "ELBO iters/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "timed_blocks": reps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": ("BASELINE config 2: Franka 7-DoF, industrial scene" if args.workload == "config2"
                                     else "BASELINE config 5 per-GPU share: synthetic 14-DoF arm") + ", SDF "
-                                   + "x".join(str(v) for v in grid[0].shape) + (" from the industrial collision mesh"
+                                   + "x".join(str(v) for v in scene.shape) + (" from the industrial collision mesh"
                                    if args.workload == "config2" and args.scene == "industrial" else " synthetic boxes/spheres")
                                    + f", {npb} start-goal problem(s) per GPU, S={S} M={M} T={N} B={B}, "
                                    "q_mu/q_sqrt/lengthscales/kernel_variance trainable",

@@ -31,6 +31,7 @@ extern "C" {
 #define VGPMP_E_ARG (-1)         /* null pointer / inconsistent argument */
 #define VGPMP_E_SHAPE (-2)       /* dimension outside the supported range */
 #define VGPMP_E_WORKSPACE (-3)   /* workspace too small */
+#define VGPMP_E_COMM (-4)        /* RCCL not loadable, or a collective call failed */
 
 typedef void* vgpmp_stream;      /* hipStream_t */
 
@@ -60,13 +61,29 @@ typedef struct vgpmp_robot {
     double scene_offset[3];                /* subtracted from sphere centres before the lookup */
 } vgpmp_robot;
 
-/* Signed distance field prepared by vgpmp_sdf_pack: one float4 {d, gx, gy, gz} per voxel,
- * index (x*ny + y)*nz + z  (the reference's data[x, y, z], utils/sdf_utils.py:25-33). */
+/* Signed distance field prepared by vgpmp_sdf_pack: one float4 {d, gx, gy, gz} per voxel of the reference's
+ * data[x, y, z] (utils/sdf_utils.py:25-33), the gradient being its clamped central difference with exact zeros
+ * replaced by 0.1 (utils/sdf_utils.py:100-136).  Voxel (x, y, z) sits at element
+ *   VGPMP_SDF_LINEAR:  (x*ny + y)*nz + z
+ *   VGPMP_SDF_BRICK4:  (((x>>2)*nby + (y>>2))*nbz + (z>>2))*64 + morton(x&3, y&3, z&3),  nb? = ceil(n?/4),
+ *                      morton = z0 | y0<<1 | x0<<2 | z1<<3 | y1<<4 | x1<<5  (bit k of each local coordinate):
+ *                      a 4x4x4 brick is 1 KiB, every 128-byte line of it a 2x2x2 cube, so that sphere queries that
+ *                      are neighbours in space share lines and DRAM pages whatever the direction they differ in.
+ * The voxel INDEX a query resolves to is the reference's (utils/sdf_utils.py:62-66) under both layouts; only the
+ * address of its record differs.
+ * brick_min (optional, BRICK4 only): the smallest distance inside every brick, [nbx*nby*nbz] floats.  A sphere
+ * whose brick satisfies eps - (brick_min - radius) <= 0 has hinge cost exactly 0 at every voxel of the brick
+ * (likelihoods/likelihood.py:131-143), so the batch likelihood kernel leaves out its table gather: results are
+ * bit-identical, the (cache-resident) summary replaces the HBM access for the free-space majority of queries. */
+#define VGPMP_SDF_LINEAR 0
+#define VGPMP_SDF_BRICK4 1
 typedef struct vgpmp_sdf {
-    const void* table;                     /* dev float4[nx*ny*nz] */
-    int32_t nx, ny, nz, reserved;
+    const void* table;                     /* dev float4[vgpmp_sdf_table_bytes / 16] */
+    int32_t nx, ny, nz;
+    int32_t layout;                        /* VGPMP_SDF_LINEAR or VGPMP_SDF_BRICK4 */
     double origin[3];
     double delta;
+    const void* brick_min;                 /* dev float[nbx*nby*nbz], or NULL */
 } vgpmp_sdf;
 
 /* Problem-batch dimensions. */
@@ -169,10 +186,17 @@ typedef struct vgpmp_outputs {
 /* Copies the host struct to device memory (`dev_robot` has sizeof(vgpmp_robot) bytes). */
 int vgpmp_robot_upload(const vgpmp_robot* host_robot, void* dev_robot, vgpmp_stream stream);
 
-/* Builds the per-voxel {d, gx, gy, gz} table from a float64 grid data[x,y,z] on the device:
- * clamped central differences with exact zeros replaced by 0.1 (utils/sdf_utils.py:100-136). */
-int vgpmp_sdf_pack(const double* dev_grid, int32_t nx, int32_t ny, int32_t nz, double delta,
-                   void* dev_table, vgpmp_stream stream);
+/* Bytes of the voxel table and of the brick summary for a grid of nx*ny*nz voxels in `layout`. */
+int vgpmp_sdf_table_bytes(int32_t nx, int32_t ny, int32_t nz, int32_t layout, size_t* table_bytes,
+                          size_t* brick_min_bytes);
+
+/* Builds the per-voxel {d, gx, gy, gz} records of the voxels x0 <= x < x1 of `sdf` (whose table / brick_min
+ * pointers name the destination) from float64 rows of the grid data[x, y, z]: clamped central differences with
+ * exact zeros replaced by 0.1 (utils/sdf_utils.py:100-136).  dev_rows holds the rows row_lo <= x < row_hi,
+ * dense [row_hi - row_lo, ny, nz]; it must contain rows max(x0-1, 0) .. min(x1, nx-1), so a grid larger than a
+ * staging buffer is packed slab by slab.  BRICK4: x0 must be a multiple of 4 and x1 a multiple of 4 or nx. */
+int vgpmp_sdf_pack(const vgpmp_sdf* sdf, const double* dev_rows, int32_t row_lo, int32_t row_hi,
+                   int32_t x0, int32_t x1, vgpmp_stream stream);
 
 /* Signed distance grid of a triangle mesh (replaces the external SDFGen binary of utils/gen_sdf.py:16-43):
  * dev_triangles [T, 9] = vertices a, b, c of each triangle; dev_part [T] = index of the closed part each
@@ -270,6 +294,23 @@ int vgpmp_elbo_step_profiled(const vgpmp_dims* dims, const vgpmp_robot* dev_robo
 int vgpmp_adam_step(const vgpmp_dims* dims, const vgpmp_params* params, const vgpmp_params* grad,
                     const vgpmp_params* adam_m, const vgpmp_params* adam_v, int32_t trainable,
                     double learning_rate, int32_t adam_t, vgpmp_stream stream);
+
+/* ---- sharded Monte-Carlo sample axis: the one collective of the path ----------------------------
+ * Each rank holds dims.S of the dims.S_total samples (dims.sample_offset = its first), the KL term belongs to the
+ * rank with problem.kl_scale = 1.  Per step: vgpmp_elbo_step(FORWARD | BACKWARD) -> ONE in-place sum over the ranks
+ * of the caller's contiguous float64 buffer [grad.q_mu | grad.q_sqrt | grad.raw_ell | grad.raw_var | lik | kl] (the
+ * caller lays out->grad / lik / kl out that way: ~3.5 k doubles at M = 30, L = 7, a latency-bound message) ->
+ * vgpmp_adam_step on every rank (identical update, replicated optimizer state).  The reference is single-process
+ * (models/vgpmp.py:287 takes the sample mean on one device); this is what a multi-GPU binding would add.
+ * RCCL over xGMI, resolved at run time; one communicator per (process, device), created on the CURRENT device. */
+typedef struct vgpmp_comm vgpmp_comm;
+#define VGPMP_COMM_ID_BYTES 128
+/* Rank 0 creates the rendezvous id and hands the bytes to every rank by any host-side channel. */
+int vgpmp_comm_unique_id(void* id_bytes);
+int vgpmp_comm_init(const void* id_bytes, int32_t world_size, int32_t rank, vgpmp_comm** comm);
+/* In-place sum over all ranks of `count` float64 values at dev_buf, ordered on `stream`. */
+int vgpmp_allreduce_grads(vgpmp_comm* comm, double* dev_buf, size_t count, vgpmp_stream stream);
+int vgpmp_comm_destroy(vgpmp_comm* comm);
 
 /* Reads back intermediates of the last vgpmp_elbo_step from the workspace (parity tests):
  * name in {"A","C","m","F0","H","R","G","Phi"}; returns pointer and element count. */

@@ -42,3 +42,25 @@ def small_problem(robot="franka", S=6, N=9, M=5, B=64, seed=0, n_grid=24, proble
     noise = orc.draw_noise(rng, S, D, D, B, M + 2)
     return dict(spec=spec, scene=scene, grid=grid, y=y, params=params, X=X, Zy=Zy, noise=noise,
                 alpha=float(pp["alpha"]), lr=float(pp["learning_rate"]), offset=np.array(ps.object_positions[0]))
+
+
+def synthetic_problem(dof=14, S=8, N=12, M=6, B=64, seed=0, n_grid=48, n_problems=1):
+    """BASELINE config 5's robot (synthetic classic-DH chain, 3 spheres per frame incl. the base: P = 45 at 14 joints) on a
+    small obstacle grid, random start-goal pairs in +-2 rad; `n_problems` instances sharing params and noise."""
+    spec = rb.synthetic_arm(dof)
+    grid = scenes.synthetic_boxes_sdf(n=n_grid, delta=2.4 / n_grid, origin=(-1.2, -1.2, -0.6), seed=seed, n_boxes=10, n_spheres=6)
+    offset = np.array([0.05, -0.03, 0.02])
+    scene = oracle_scene(spec, grid, offset)
+    rng = np.random.default_rng(seed + 1)
+    ys = rng.uniform(-2.0, 2.0, (n_problems, 2, dof))
+    params = []
+    for y in ys:
+        p = orc.init_params(scene.robot, y, M, [2.0] * dof, 0.2)
+        p.q_sqrt = np.tril(p.q_sqrt + 0.05 * rng.standard_normal(p.q_sqrt.shape))
+        p.q_mu = p.q_mu + 0.05 * rng.standard_normal(p.q_mu.shape)
+        params.append(p)
+    X = orc.init_trainset(N, dof)
+    Zy = orc.inducing_Zy(M, dof)
+    noise = [orc.draw_noise(rng, S, dof, dof, B, M + 2) for _ in range(n_problems)]
+    return dict(spec=spec, scene=scene, grid=grid, ys=ys, params=params, X=X, Zy=Zy, noise=noise, alpha=100.0, lr=0.02,
+                offset=offset)

@@ -26,7 +26,7 @@ def test_library_builds_loads_and_exports_header_symbols():
 def test_struct_sizes_match_header_layout():
     # sizes implied by include/vgpmp.h (natural alignment, 8-byte tail for the doubles)
     assert ctypes.sizeof(capi.Robot) == 4 * 4 + 7 * 16 * 4 + 12 * 4 + 64 * 4 + 64 * 12 + 64 * 4 + 64 * 4 + 8 + 24
-    assert ctypes.sizeof(capi.Sdf) == 8 + 16 + 24 + 8
+    assert ctypes.sizeof(capi.Sdf) == 8 + 16 + 24 + 8 + 8
     assert ctypes.sizeof(capi.Dims) == 40
     assert ctypes.sizeof(capi.Params) == 32 and ctypes.sizeof(capi.Noise) == 40
     assert ctypes.sizeof(capi.Problem) == 64 and ctypes.sizeof(capi.Outputs) == 64 and ctypes.sizeof(capi.LikParams) == 72
@@ -42,6 +42,16 @@ def test_argument_errors_without_gpu():
     ok = capi.Dims(1, 128, 128, 100, 30, 7, 1024, 4, 0, 0)
     assert handle.vgpmp_workspace_bytes(ctypes.byref(ok), ctypes.byref(n)) == 0 and n.value > 0
     assert handle.vgpmp_workspace_bytes(None, ctypes.byref(n)) == -1
+    # voxel-table sizes: linear = 16 B per voxel, bricked = extents rounded up to whole 4x4x4 bricks + 4 B per brick
+    tb, bb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert handle.vgpmp_sdf_table_bytes(5, 1, 9, capi.SDF_LINEAR, ctypes.byref(tb), ctypes.byref(bb)) == 0
+    assert (tb.value, bb.value) == (5 * 9 * 16, 0)
+    assert handle.vgpmp_sdf_table_bytes(5, 1, 9, capi.SDF_BRICK4, ctypes.byref(tb), ctypes.byref(bb)) == 0
+    assert (tb.value, bb.value) == (2 * 1 * 3 * 1024, 2 * 1 * 3 * 4)
+    assert handle.vgpmp_sdf_table_bytes(512, 512, 512, capi.SDF_BRICK4, ctypes.byref(tb), ctypes.byref(bb)) == 0
+    assert (tb.value, bb.value) == (2 << 30, 8 << 20)
+    assert handle.vgpmp_sdf_table_bytes(4, 4, 4, 7, ctypes.byref(tb), ctypes.byref(bb)) == -1
+    assert handle.vgpmp_sdf_table_bytes(0, 4, 4, 0, ctypes.byref(tb), ctypes.byref(bb)) == -2
 
 
 def test_product_path_fails_loudly_without_library(monkeypatch, tmp_path):

@@ -1,0 +1,198 @@
+"""BASELINE config 5 (synthetic 14-DoF arm, P = 45 spheres, large voxel table) against the float64 oracle, through the
+C ABI, and the voxel-table layouts against each other.  Run with -m gpu on MI355X.
+
+dof = 14 > 8 takes code no other robot reaches: two joints per lane and the non-scan chain of the 8-lane likelihood
+kernel, a 15-frame run-time chain in the 1-lane kernels.  Layout tests: the voxel INDEX a query resolves to is the
+reference's (utils/sdf_utils.py:62-66) under both table layouts and the records are the same floats, so everything
+downstream must be BITWISE equal between layouts and with / without the free-space summary.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vgpmp_oracle as orc
+from helpers import oracle_scene, synthetic_problem
+from vgpmp_amd import robots as rb
+from vgpmp_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine():
+    from vgpmp_amd import engine
+    return engine
+
+
+def _noise32(noise):
+    r = lambda a: a.astype(np.float32).astype(np.float64)
+    return orc.Noise(r(noise.omega), r(noise.beta), r(noise.w), r(noise.eps), r(noise.eps2))
+
+
+@pytest.mark.parametrize("shape", [(41, 38, 45), (4, 4, 4), (5, 1, 9), (64, 64, 64)])
+def test_sdf_layouts_bit_exact_against_oracle(shape):
+    """Ragged extents (not multiples of the brick), a one-voxel-thick axis, exact lattice points and far-outside queries:
+    index, value and gradient equal the oracle's under both layouts."""
+    rng = np.random.default_rng(3)
+    data = rng.normal(0.0, 0.3, shape)
+    data[rng.random(shape) < 0.2] = 0.25          # equal neighbours -> exact-zero central differences -> 0.1
+    origin, delta = np.array([-0.4, 0.1, -1.0]), 0.03
+    og = orc.SDFGrid(data, origin, delta)
+    ext = delta * np.array(shape)
+    pos = origin + rng.uniform(-0.3, 1.3, (50000, 3)) * ext
+    pos[:4000] = origin + delta * rng.integers(-2, np.array(shape) + 2, (4000, 3))       # cell boundaries hit exactly
+    spec = rb.load_robot("franka")
+    want_idx, want_d, want_g = orc.sdf_index(og, pos), orc.sdf_distance(og, pos), orc.sdf_gradient(og, pos)
+    assert (want_g == 0.1).any()
+    for layout in ("linear", "brick"):
+        sc = _engine().DeviceScene(spec, (data, origin, delta), (0, 0, 0), layout=layout)
+        idx, dist, grad = sc.sdf_query(torch.tensor(pos))
+        assert np.array_equal(idx.cpu().numpy().astype(np.int64), want_idx), layout
+        assert np.array_equal(dist.cpu().numpy(), want_d.astype(np.float32)), layout
+        assert np.array_equal(grad.cpu().numpy(), want_g.astype(np.float32)), layout
+        if layout == "brick":
+            # the summary is the minimum over each brick's existing voxels
+            nb = [(s + 3) // 4 for s in shape]
+            pad = np.full([4 * b for b in nb], np.inf)
+            pad[:shape[0], :shape[1], :shape[2]] = data
+            want_min = pad.reshape(nb[0], 4, nb[1], 4, nb[2], 4).min(axis=(1, 3, 5)).astype(np.float32)
+            assert np.array_equal(sc.brick_min.cpu().numpy().reshape(nb), want_min)
+
+
+def test_slab_upload_equals_whole_upload():
+    """A grid packed in several slabs (halo rows re-sent) gives the same table as one call."""
+    rng = np.random.default_rng(5)
+    data = rng.normal(0.0, 0.3, (37, 20, 24))
+    spec = rb.load_robot("franka")
+    for layout in ("linear", "brick"):
+        a = _engine().DeviceScene(spec, (data, np.zeros(3), 0.05), (0, 0, 0), layout=layout)
+        b = _engine().DeviceScene(spec, (data, np.zeros(3), 0.05), (0, 0, 0), layout=layout, slab_bytes=8 * 8 * 20 * 24)
+        assert torch.equal(a.table, b.table)
+        if layout == "brick":
+            assert torch.equal(a.brick_min, b.brick_min)
+
+
+def test_synthetic14_log_prob_and_gradient():
+    pb = synthetic_problem(dof=14, n_grid=48)
+    spec = pb["spec"]
+    assert spec.num_spheres == 45 and not spec.craig
+    sc = _engine().DeviceScene(spec, pb["grid"], pb["offset"])
+    rng = np.random.default_rng(2)
+    g = rng.uniform(-2.5, 2.5, (4096, 14)).astype(np.float32)
+    logp, dl = sc.log_prob(torch.tensor(g), want_grad=True)
+    want_lp, want_dl = orc.log_prob(pb["scene"], g.astype(np.float64), want_grad=True)
+    logp, dl = logp.cpu().numpy(), dl.cpu().numpy()
+    assert (want_lp < 0).mean() > 0.2, "scene must put spheres inside the hinge band"
+    ok = np.isclose(logp, want_lp, rtol=2e-4, atol=1e-5)
+    assert ok.mean() > 0.99, f"only {ok.mean():.4f} of configurations agree"       # voxel flips are rare (45 spheres each)
+    scale = np.abs(want_dl).max(axis=1, keepdims=True) + 1e-6
+    okg = (np.abs(dl - want_dl) / scale).max(axis=1) < 5e-4
+    assert (okg | ~ok).mean() > 0.99
+
+
+def _batch(pb, sc, S, N, M, B, **kw):
+    P = len(pb["ys"])
+    pl = _engine().PlannerBatch(sc, pb["ys"], num_samples=S, num_inducing=M, num_data=N, num_bases=B,
+                                lengthscales=[2.0] * pb["spec"].dof, variance=0.2, alpha=pb["alpha"],
+                                learning_rate=pb["lr"], **kw)
+    for k, p in enumerate(pb["params"]):
+        pl.q_mu[k].copy_(torch.tensor(p.q_mu.T)); pl.q_sqrt[k].copy_(torch.tensor(p.q_sqrt))
+        pl.raw_ell[k].copy_(torch.tensor(p.raw_ell)); pl.raw_var[k].copy_(torch.tensor(p.raw_var))
+    nz = [_noise32(n) for n in pb["noise"]]
+    st = lambda name: np.stack([getattr(n, name) for n in nz])
+    pl.set_noise(st("omega"), st("beta"), st("w"), st("eps"), st("eps2"))
+    return pl, nz
+
+
+# (S, N, problems): 8 lanes per configuration (few configurations) / 1 lane (> 65 536 configurations in the launch)
+@pytest.mark.parametrize("S,N,M,B,P", [(8, 12, 6, 64, 1), (40, 30, 10, 128, 2), (128, 100, 30, 256, 6)])
+def test_synthetic14_elbo_forward_backward_against_oracle(S, N, M, B, P):
+    pb = synthetic_problem(dof=14, S=S, N=N, M=M, B=B, seed=13, n_grid=48, n_problems=P)
+    sc = _engine().DeviceScene(pb["spec"], pb["grid"], pb["offset"], free_space_summary=True)
+    pl, nz = _batch(pb, sc, S, N, M, B)
+    loss, grads = pl.loss_and_grad(generate=False)
+    torch.cuda.synchronize()
+    check = range(P) if S * N <= 2000 else (0, P - 1)      # the oracle takes seconds per full-size problem
+    for k in check:
+        p, y = pb["params"][k], pb["ys"][k]
+        fw = orc.elbo_forward(p, pb["scene"], pb["X"], pb["Zy"], y, nz[k], pb["alpha"])
+        og, _ = orc.elbo_backward(p, pb["scene"], pb["X"], pb["Zy"], nz[k], pb["alpha"], fw)
+        np.testing.assert_allclose(pl.f[k].cpu().numpy(), fw["f"], rtol=0, atol=1e-4)
+        assert (fw["logp"] < 0).any()
+        ok = np.isclose(pl.logp[k].cpu().numpy(), fw["logp"], rtol=2e-3, atol=1e-4)
+        assert ok.mean() >= 0.95, f"logp agreement {ok.mean():.3f}"
+        flips = 1.0 - ok.mean()
+        np.testing.assert_allclose(float(pl.kl[k]), fw["cv"]["kl"], rtol=1e-9)
+        np.testing.assert_allclose(float(pl.lik[k]), fw["lik"], rtol=50 * flips + 2e-4)
+        for got, name in zip(grads, ("q_mu", "q_sqrt", "raw_ell", "raw_var")):
+            want = getattr(og, name)
+            got = got[k].cpu().numpy()
+            if name == "q_mu":
+                got = got.T
+            scale = np.abs(want).max() + 1e-12
+            assert np.abs(got - want).max() / scale < 50 * flips + 3e-3, (name, k, np.abs(got - want).max(), scale, flips)
+
+
+@pytest.mark.parametrize("S,N,P", [(8, 12, 1), (128, 100, 6)])
+def test_layouts_and_summary_are_bitwise_equivalent(S, N, P):
+    """Same inputs through {linear, brick, brick + free-space summary}: identical bits in f, logp, lik and every
+    gradient (the summary only skips table reads whose hinge cost is exactly zero)."""
+    M, B = 6, 64
+    pb = synthetic_problem(dof=14, S=S, N=N, M=M, B=B, seed=17, n_grid=40, n_problems=P)
+    outs = []
+    for layout, summary in (("linear", False), ("brick", False), ("brick", True)):
+        sc = _engine().DeviceScene(pb["spec"], pb["grid"], pb["offset"], layout=layout, free_space_summary=summary)
+        assert sc.free_space_summary == summary
+        pl, _ = _batch(pb, sc, S, N, M, B)
+        loss, grads = pl.loss_and_grad(generate=False)
+        torch.cuda.synchronize()
+        outs.append([pl.f.clone(), pl.logp.clone(), pl.lik.clone(), pl.view("G")] + [g.clone() for g in grads])
+    assert float((outs[0][1] < 0).float().mean()) > 0.05, "hinge must be active"
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+
+
+def test_config5_full_size_properties():
+    """BASELINE config 5, one GPU's share at full size: 14-DoF arm, 512^3 voxels (2 GiB table, beyond the Infinity Cache),
+    64 problems, S=128, M=30, N=100.  No oracle at this size: bitwise replay, layout / summary independence, finite
+    outputs, KL >= 0, decreasing loss, and spot checks of table records against the analytic scene."""
+    eng = _engine()
+    n = 512
+    spec = rb.synthetic_arm(14)
+    rows = scenes.AnalyticSceneRows(n, 2.0 / n, (-1.0, -1.0, -1.0), seed=0, n_boxes=24, n_spheres=16, round_to=torch.float32)
+    grid = (rows, rows.origin, rows.delta)
+    rng = np.random.default_rng(0)
+    qs = rng.uniform(-2.0, 2.0, (64, 2, 14))
+    kw = dict(num_samples=128, num_inducing=30, num_data=100, num_bases=1024, lengthscales=[2.0] * 14, variance=0.2,
+              learning_rate=0.02, seed=1)
+    sc = eng.DeviceScene(spec, grid, (0, 0, 0))
+    assert sc.layout == 1 and sc.free_space_summary and sc.table.numel() * 4 == 2 << 30
+    # table records against the analytic distance at random voxels (values are float32 of the float64 scene)
+    pos = rows.origin + rows.delta * rng.integers(0, n, (2000, 3))
+    idx, dist, _ = sc.sdf_query(torch.tensor(pos + 0.25 * rows.delta))
+    assert np.array_equal(idx.cpu().numpy(), np.round((pos - rows.origin) / rows.delta).astype(np.int32))
+    xs = np.round((pos[:, 0] - rows.origin[0]) / rows.delta).astype(int)
+    for k in range(0, 2000, 97):
+        r = rows.rows(int(xs[k]), int(xs[k]) + 1, sc.device)[0]
+        assert float(r[idx[k, 1], idx[k, 2]]) == float(dist[k])
+    a = eng.PlannerBatch(sc, qs, **kw)
+    b = eng.PlannerBatch(sc, qs, **kw)
+    l0 = -a.elbo(step=10**6)
+    for _ in range(6):
+        a.step(); b.step()
+    assert torch.equal(a.q_mu, b.q_mu) and torch.equal(a.q_sqrt, b.q_sqrt) and torch.equal(a.raw_ell, b.raw_ell)
+    l1 = -a.elbo(step=10**6)
+    assert bool(torch.isfinite(l0).all() and torch.isfinite(l1).all()) and bool((a.kl >= 0).all())
+    assert float(l1.sum()) < float(l0.sum())
+    assert float((a.logp < 0).float().mean()) > 0.05
+    # the other table forms give the same bits from the same state and noise key
+    ref = [a.f.clone(), a.logp.clone(), a.lik.clone()]
+    del b
+    for layout, summary in (("brick", False), ("linear", False)):
+        sc2 = eng.DeviceScene(spec, grid, (0, 0, 0), layout=layout, free_space_summary=summary)
+        c = eng.PlannerBatch(sc2, qs, **kw)
+        for name in ("q_mu", "q_sqrt", "raw_ell", "raw_var"):
+            getattr(c, name).copy_(getattr(a, name))
+        c.elbo(step=10**6)
+        assert torch.equal(c.f, ref[0]) and torch.equal(c.logp, ref[1]) and torch.equal(c.lik, ref[2])
+        del c, sc2

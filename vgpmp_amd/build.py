@@ -11,7 +11,7 @@ ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB_DIR = PKG / "lib"
 LIB = LIB_DIR / "libvgpmp_hip.so"
-SOURCES = ["fk_sdf.hip", "gp_path.hip", "mesh_sdf.hip", "deriv_kernels.hip", "capi.hip"]
+SOURCES = ["fk_sdf.hip", "gp_path.hip", "mesh_sdf.hip", "deriv_kernels.hip", "comm.hip", "capi.hip"]
 HEADERS = [CSRC / "vgpmp_device.h", CSRC / "gp_path.h", ROOT / "include" / "vgpmp.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc=0",
          "-Wall", "-Wno-unused-function"]
@@ -24,19 +24,40 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def needs_build() -> bool:
-    if not LIB.exists():
+OBJ_DIR = PKG / "build"
+
+
+def _stale(target: Path, deps) -> bool:
+    if not target.exists():
         return True
-    t = LIB.stat().st_mtime
-    return any(p.stat().st_mtime > t for p in [CSRC / s for s in SOURCES] + HEADERS)
+    t = target.stat().st_mtime
+    return any(p.stat().st_mtime > t for p in deps)
+
+
+def needs_build() -> bool:
+    return _stale(LIB, [CSRC / s for s in SOURCES] + HEADERS)
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
+    """One object per translation unit (rebuilt only when it or a header changed), then the link."""
     if not force and not needs_build():
         return LIB
     LIB_DIR.mkdir(exist_ok=True)
-    cmd = [hipcc(), *[f for f in FLAGS if f != "-fgpu-rdc=0"], f"-I{ROOT / 'include'}", f"-I{CSRC}",
-           *[str(CSRC / s) for s in SOURCES], "-o", str(LIB)]
+    OBJ_DIR.mkdir(exist_ok=True)
+    cflags = [f for f in FLAGS if f not in ("-shared", "-fgpu-rdc=0")]
+    objs, procs = [], []
+    for src in SOURCES:
+        obj = OBJ_DIR / (Path(src).stem + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [CSRC / src] + HEADERS):
+            cmd = [hipcc(), *cflags, f"-I{ROOT / 'include'}", f"-I{CSRC}", "-c", str(CSRC / src), "-o", str(obj)]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", *[str(o) for o in objs], "-ldl", "-o", str(LIB)]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -14,6 +14,7 @@ from typing import Optional
 import numpy as np
 
 MAX_DOF, MAX_SPHERES, MAX_MZ = 16, 64, 48
+COMM_ID_BYTES = 128
 TRAIN_Q_MU, TRAIN_Q_SQRT, TRAIN_LENGTHSCALES, TRAIN_KERNEL_VARIANCE = 1, 2, 4, 8
 TRAIN_SIGMA_OBS, TRAIN_ALPHA = 16, 32      # need Problem.lik
 DO_FORWARD, DO_BACKWARD, DO_ADAM, GEN_NOISE, NO_FUSE = 1, 2, 4, 8, 16
@@ -21,9 +22,10 @@ GEMM_DIRECT, NO_SPLIT, ELIM_BLOCK = 32, 64, 128
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvgpmp_hip.so"
 
-EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_pack", "vgpmp_mesh_sdf", "vgpmp_fk_spheres", "vgpmp_sdf_query",
+EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_table_bytes", "vgpmp_sdf_pack", "vgpmp_mesh_sdf", "vgpmp_fk_spheres", "vgpmp_sdf_query",
            "vgpmp_log_prob", "vgpmp_kernel_derivative", "vgpmp_velocity_kuu_kuf", "vgpmp_workspace_bytes", "vgpmp_lik_scratch_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
-           "vgpmp_elbo_steps", "vgpmp_elbo_step_profiled", "vgpmp_adam_step", "vgpmp_workspace_view")
+           "vgpmp_elbo_steps", "vgpmp_elbo_step_profiled", "vgpmp_adam_step", "vgpmp_workspace_view",
+           "vgpmp_comm_unique_id", "vgpmp_comm_init", "vgpmp_allreduce_grads", "vgpmp_comm_destroy")
 NUM_STAGES = 8
 NUM_TIMES = 10
 STAGE_NAMES = ("cov_fwd", "noise", "features", "prior_gemm", "paths_fwd", "loglik_fk_sdf", "paths_bwd", "final_adam")
@@ -45,9 +47,13 @@ class Robot(C.Structure):
                 ("scene_offset", C.c_double * 3)]
 
 
+SDF_LINEAR, SDF_BRICK4 = 0, 1
+
+
 class Sdf(C.Structure):
     _fields_ = [("table", C.c_void_p), ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
-                ("reserved", C.c_int32), ("origin", C.c_double * 3), ("delta", C.c_double)]
+                ("layout", C.c_int32), ("origin", C.c_double * 3), ("delta", C.c_double),
+                ("brick_min", C.c_void_p)]
 
 
 class Dims(C.Structure):
@@ -110,7 +116,8 @@ def load(require: bool = True) -> Optional[C.CDLL]:
     vp, i32, i64, u32, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_double
     sigs = {
         "vgpmp_robot_upload": [P(Robot), vp, vp],
-        "vgpmp_sdf_pack": [vp, i32, i32, i32, dbl, vp, vp],
+        "vgpmp_sdf_table_bytes": [i32, i32, i32, i32, P(C.c_size_t), P(C.c_size_t)],
+        "vgpmp_sdf_pack": [P(Sdf), vp, i32, i32, i32, i32, vp],
         "vgpmp_mesh_sdf": [vp, vp, i32, i32, i32, i32, P(C.c_double), dbl, vp, vp],
         "vgpmp_fk_spheres": [vp, vp, i64, vp, vp, vp],
         "vgpmp_sdf_query": [P(Sdf), vp, i64, vp, vp, vp, vp],
@@ -129,6 +136,10 @@ def load(require: bool = True) -> Optional[C.CDLL]:
                                      P(C.c_float)],
         "vgpmp_adam_step": [P(Dims), P(Params), P(Params), P(Params), P(Params), i32, dbl, i32, vp],
         "vgpmp_workspace_view": [P(Dims), vp, C.c_char_p, P(vp), P(C.c_size_t), P(i32)],
+        "vgpmp_comm_unique_id": [vp],
+        "vgpmp_comm_init": [vp, i32, i32, P(vp)],
+        "vgpmp_allreduce_grads": [vp, vp, C.c_size_t, vp],
+        "vgpmp_comm_destroy": [vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -141,7 +152,7 @@ def load(require: bool = True) -> Optional[C.CDLL]:
 def check(rc: int, what: str) -> None:
     if rc == 0:
         return
-    names = {-1: "VGPMP_E_ARG", -2: "VGPMP_E_SHAPE", -3: "VGPMP_E_WORKSPACE"}
+    names = {-1: "VGPMP_E_ARG", -2: "VGPMP_E_SHAPE", -3: "VGPMP_E_WORKSPACE", -4: "VGPMP_E_COMM"}
     if rc < 0:
         raise ValueError(f"{what}: {names.get(rc, rc)}")
     raise VgpmpError(f"{what}: hipError_t {rc}")

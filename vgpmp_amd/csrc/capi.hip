@@ -21,11 +21,39 @@ int vgpmp_robot_upload(const vgpmp_robot* host_robot, void* dev_robot, vgpmp_str
     return 0;
 }
 
-int vgpmp_sdf_pack(const double* dev_grid, int32_t nx, int32_t ny, int32_t nz, double delta, void* dev_table,
+static int check_sdf(const vgpmp_sdf* sdf) {
+    if (!sdf || !sdf->table) return VGPMP_E_ARG;
+    if (sdf->nx < 1 || sdf->ny < 1 || sdf->nz < 1 || !(sdf->delta > 0.0)) return VGPMP_E_SHAPE;
+    if (sdf->layout != VGPMP_SDF_LINEAR && sdf->layout != VGPMP_SDF_BRICK4) return VGPMP_E_ARG;
+    if (sdf->brick_min && sdf->layout != VGPMP_SDF_BRICK4) return VGPMP_E_ARG;
+    return 0;
+}
+
+int vgpmp_sdf_table_bytes(int32_t nx, int32_t ny, int32_t nz, int32_t layout, size_t* table_bytes, size_t* brick_min_bytes) {
+    if (!table_bytes) return VGPMP_E_ARG;
+    if (nx < 1 || ny < 1 || nz < 1) return VGPMP_E_SHAPE;
+    if (layout == VGPMP_SDF_LINEAR) {
+        *table_bytes = (size_t)nx * ny * nz * 16;
+        if (brick_min_bytes) *brick_min_bytes = 0;
+    } else if (layout == VGPMP_SDF_BRICK4) {
+        const size_t bricks = (size_t)((nx + 3) / 4) * ((ny + 3) / 4) * ((nz + 3) / 4);
+        *table_bytes = bricks * 64 * 16;
+        if (brick_min_bytes) *brick_min_bytes = bricks * sizeof(float);
+    } else {
+        return VGPMP_E_ARG;
+    }
+    return 0;
+}
+
+int vgpmp_sdf_pack(const vgpmp_sdf* sdf, const double* dev_rows, int32_t row_lo, int32_t row_hi, int32_t x0, int32_t x1,
                    vgpmp_stream stream) {
-    if (!dev_grid || !dev_table) return VGPMP_E_ARG;
-    if (nx < 1 || ny < 1 || nz < 1 || !(delta > 0.0)) return VGPMP_E_SHAPE;
-    return vg_launch_sdf_pack(dev_grid, nx, ny, nz, delta, (float4*)dev_table, (hipStream_t)stream);
+    int rc = check_sdf(sdf);
+    if (rc) return rc;
+    if (!dev_rows) return VGPMP_E_ARG;
+    if (x0 < 0 || x1 > sdf->nx || x0 >= x1) return VGPMP_E_SHAPE;
+    if (row_lo > (x0 > 0 ? x0 - 1 : 0) || row_hi < (x1 < sdf->nx ? x1 + 1 : sdf->nx)) return VGPMP_E_ARG;   // halo rows missing
+    if (sdf->layout == VGPMP_SDF_BRICK4 && ((x0 & 3) || ((x1 & 3) && x1 != sdf->nx))) return VGPMP_E_ARG;
+    return vg_launch_sdf_pack(sdf, dev_rows, row_lo, row_hi, x0, x1, (hipStream_t)stream);
 }
 
 int vgpmp_mesh_sdf(const double* dev_triangles, const int32_t* dev_part, int32_t num_triangles, int32_t nx, int32_t ny,
@@ -40,12 +68,6 @@ int vgpmp_fk_spheres(const vgpmp_robot* dev_robot, const float* dev_q, int64_t n
                      vgpmp_stream stream) {
     if (!dev_robot || (!dev_q && n > 0) || n < 0) return VGPMP_E_ARG;
     return vg_launch_fk_spheres(dev_robot, dev_q, n, dev_pos, dev_frames, (hipStream_t)stream);
-}
-
-static int check_sdf(const vgpmp_sdf* sdf) {
-    if (!sdf || !sdf->table) return VGPMP_E_ARG;
-    if (sdf->nx < 1 || sdf->ny < 1 || sdf->nz < 1 || !(sdf->delta > 0.0)) return VGPMP_E_SHAPE;
-    return 0;
 }
 
 int vgpmp_sdf_query(const vgpmp_sdf* sdf, const double* dev_rel_pos, int64_t n, int32_t* dev_idx, float* dev_dist,

@@ -19,14 +19,7 @@ namespace {
 
 constexpr int kBlock = 256;
 
-__device__ __forceinline__ vg_sdf_dev load_sdf(const vgpmp_sdf& s) {
-    vg_sdf_dev d;
-    d.table = reinterpret_cast<const float4*>(s.table);
-    d.nx = s.nx; d.ny = s.ny; d.nz = s.nz;
-    d.ox = s.origin[0]; d.oy = s.origin[1]; d.oz = s.origin[2];
-    d.delta = s.delta;
-    return d;
-}
+__device__ __forceinline__ vg_sdf_dev load_sdf(const vgpmp_sdf& s) { return vg_load_sdf(s); }
 
 struct Frame {
     vg_float3 cx, cy, cz, t;   // rotation columns and origin
@@ -181,7 +174,7 @@ __device__ __forceinline__ void lik_wave_sync() {
 // With SIG (trainable sigma_obs, LPC == 1 only) the per-sphere variances come from `sig` and every sphere's
 // c^2 / sigma, weighted by sig_w (0 on dead lanes), is summed over the wave and handed to emit_sig(q, total).
 struct NoSig { __device__ __forceinline__ void operator()(int, float) const {} };
-template <bool GRAD, int LPC, bool SIG = false, typename GetG, typename Emit, typename EmitSig = NoSig>
+template <bool GRAD, int LPC, bool SIG = false, bool FAR = false, typename GetG, typename Emit, typename EmitSig = NoSig>
 __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ rb, const vg_sdf_dev& sdf,
                                                const LikScratch sc, int sub, GetG get_g, Emit emit, int dbg = 0,
                                                const float* __restrict__ sig = nullptr, float sig_w = 0.f,
@@ -226,7 +219,14 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
 #ifdef VGPMP_BISECT
                 if (dbg == 2) { v[u] = make_float4(0.01f * ix, 0.1f, 0.2f * iy, 0.3f * iz); continue; }
 #endif
-                v[u] = sdf.table[((size_t)ix * sdf.ny + iy) * sdf.nz + iz];
+                if (FAR) {
+                    // free-space summary: the hinge is exactly 0 on every voxel of this brick -> no table access
+                    const float bm = sdf.brick_min[vg_brick_of(sdf, ix, iy, iz)];
+                    v[u] = make_float4(bm, 0.f, 0.f, 0.f);
+                    if (eps - (bm - rb->radius[q]) > 0.f) v[u] = sdf.table[vg_table_offset(sdf, ix, iy, iz)];
+                } else {
+                    v[u] = sdf.table[vg_table_offset(sdf, ix, iy, iz)];
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kLikBlock) void log_prob_kernel(const vgpmp_robot* 
 // ---- ELBO path: f [P,S,L,N] -> logp [P,S,N], G = dloss/df [P,S,L,N], block partial sums ----------
 // LPC lanes per (sample, time) configuration; BLK / LPC configurations per workgroup.  Large batches run one-wave
 // workgroups (kLikBatchBlock): 188 instead of 204 us per launch at 64 problems (finer tail).
-template <int LPC, int BLK, bool SIG = false>
+template <int LPC, int BLK, bool SIG = false, bool FAR = false>
 __global__ __launch_bounds__(BLK) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
                                                                   const float* __restrict__ f, int S, int L, int N,
                                                                   float scale, float* __restrict__ G,
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(BLK) void loglik_paths_kernel(const vgpmp_robot* __
         float* dgdf = lik_lds + (size_t)lik_scratch_slots(L) * CPB + cl;   // [L][CPB]
         const float scl = SIG ? -alpha_eff[pb] : scale;
         float* sp = SIG ? sig_partial + ((size_t)pb * gridDim.x + blockIdx.x) * VGPMP_MAX_SPHERES : nullptr;
-        lp = loglik_config<true, LPC, SIG>(
+        lp = loglik_config<true, LPC, SIG, FAR>(
             rb, sdf, sc, sub,
             [&](int j) {
                 const float sg = 1.0f / (1.0f + __expf(-f[base + (size_t)j * N]));       // likelihood.py:49-52
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
             const int ix = voxel_axis(pos[u].x, fs.chx, fs.clx, fs.inv_delta, sdf.nx, offx, sdf.ox, sdf.delta);
             const int iy = voxel_axis(pos[u].y, fs.chy, fs.cly, fs.inv_delta, sdf.ny, offy, sdf.oy, sdf.delta);
             const int iz = voxel_axis(pos[u].z, fs.chz, fs.clz, fs.inv_delta, sdf.nz, offz, sdf.oz, sdf.delta);
-            v[u] = sdf.table[((size_t)ix * sdf.ny + iy) * sdf.nz + iz];
+            v[u] = sdf.table[vg_table_offset(sdf, ix, iy, iz)];
         }
 #pragma unroll
         for (int u = 0; u < kWideU; ++u) {
@@ -660,25 +660,53 @@ __global__ __launch_bounds__(kBlock) void sdf_query_kernel(vgpmp_sdf sdfh, const
     if (grad) { grad[3 * i] = v.y; grad[3 * i + 1] = v.z; grad[3 * i + 2] = v.w; }
 }
 
-// ---- voxel table: {d, gx, gy, gz} from the float64 grid (utils/sdf_utils.py:100-136) --------------
-__global__ __launch_bounds__(kBlock) void sdf_pack_kernel(const double* __restrict__ grid, int nx, int ny, int nz,
-                                                           double delta, float4* __restrict__ table) {
-    const size_t total = (size_t)nx * ny * nz;
-    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < total; v += (size_t)gridDim.x * kBlock) {
-        const int iz = (int)(v % nz);
-        const int iy = (int)((v / nz) % ny);
-        const int ix = (int)(v / ((size_t)nz * ny));
-        auto at = [&](int x, int y, int z) { return grid[((size_t)x * ny + y) * nz + z]; };
+// ---- voxel table: {d, gx, gy, gz} from float64 rows of the grid (utils/sdf_utils.py:100-136) -------
+// One lane per table ELEMENT (so the 16-byte stores of a wave are 1 KiB contiguous under both layouts); under
+// BRICK4 a wave is exactly one brick and also leaves the brick's smallest distance.
+__global__ __launch_bounds__(kBlock) void sdf_pack_kernel(vgpmp_sdf sdfh, const double* __restrict__ rows, int row_lo,
+                                                           int x0, int x1) {
+    const vg_sdf_dev s = vg_load_sdf(sdfh);
+    const int nx = s.nx, ny = s.ny, nz = s.nz;
+    float4* __restrict__ table = const_cast<float4*>(s.table);
+    auto at = [&](int x, int y, int z) { return rows[((size_t)(x - row_lo) * ny + y) * nz + z]; };
+    auto record = [&](int ix, int iy, int iz) {
         const int xp = min(ix + 1, nx - 1), xm = max(ix - 1, 0);
         const int yp = min(iy + 1, ny - 1), ym = max(iy - 1, 0);
         const int zp = min(iz + 1, nz - 1), zm = max(iz - 1, 0);
-        double gx = (at(xp, iy, iz) - at(xm, iy, iz)) / (2.0 * delta);
-        double gy = (at(ix, yp, iz) - at(ix, ym, iz)) / (2.0 * delta);
-        double gz = (at(ix, iy, zp) - at(ix, iy, zm)) / (2.0 * delta);
+        double gx = (at(xp, iy, iz) - at(xm, iy, iz)) / (2.0 * s.delta);
+        double gy = (at(ix, yp, iz) - at(ix, ym, iz)) / (2.0 * s.delta);
+        double gz = (at(ix, iy, zp) - at(ix, iy, zm)) / (2.0 * s.delta);
         gx = gx == 0.0 ? 0.1 : gx;
         gy = gy == 0.0 ? 0.1 : gy;
         gz = gz == 0.0 ? 0.1 : gz;
-        table[v] = make_float4((float)grid[v], (float)gx, (float)gy, (float)gz);
+        return make_float4((float)at(ix, iy, iz), (float)gx, (float)gy, (float)gz);
+    };
+    if (s.layout == VGPMP_SDF_BRICK4) {
+        const size_t bricks_per_x = (size_t)s.nby * s.nbz;
+        const size_t b0 = (size_t)(x0 >> 2) * bricks_per_x, b1 = (size_t)((x1 + 3) >> 2) * bricks_per_x;
+        const int lane = threadIdx.x & (VG_WAVE - 1);
+        const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) / VG_WAVE, nwaves = (size_t)gridDim.x * kBlock / VG_WAVE;
+        // lane -> local coordinates: the inverse of vg_morton_in_brick
+        const int lz = (lane & 1) | ((lane >> 2) & 2), ly = ((lane >> 1) & 1) | ((lane >> 3) & 2), lx = ((lane >> 2) & 1) | ((lane >> 4) & 2);
+        for (size_t b = b0 + wave; b < b1; b += nwaves) {
+            const int bz = (int)(b % s.nbz), by = (int)((b / s.nbz) % s.nby), bx = (int)(b / bricks_per_x);
+            const int ix = 4 * bx + lx, iy = 4 * by + ly, iz = 4 * bz + lz;
+            const bool in = ix < nx && iy < ny && iz < nz;
+            const float4 r = in ? record(ix, iy, iz) : make_float4(0.f, 0.f, 0.f, 0.f);    // padding is never indexed
+            table[b * 64 + lane] = r;
+            float m = in ? r.x : __builtin_inff();
+#pragma unroll
+            for (int o = VG_WAVE / 2; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, VG_WAVE));
+            if (lane == 0 && s.brick_min) const_cast<float*>(s.brick_min)[b] = m;
+        }
+    } else {
+        const size_t v0 = (size_t)x0 * ny * nz, v1 = (size_t)x1 * ny * nz;
+        for (size_t v = v0 + (size_t)blockIdx.x * kBlock + threadIdx.x; v < v1; v += (size_t)gridDim.x * kBlock) {
+            const int iz = (int)(v % nz);
+            const int iy = (int)((v / nz) % ny);
+            const int ix = (int)(v / ((size_t)nz * ny));
+            table[v] = record(ix, iy, iz);
+        }
     }
 }
 
@@ -698,20 +726,15 @@ static size_t lik_lds_bytes(int dof, bool with_dgdf) {
     return (size_t)(2 * dof + 6 * (dof + 1) + (with_dgdf ? dof : 0)) * kLikBlock * sizeof(float);
 }
 
-// dynamic LDS above 48 KB needs the attribute once per kernel (slow host call: remember what was granted)
-static int lik_grant_lds(const void* fn, size_t bytes, size_t* granted) {
-    if (bytes <= 48 * 1024 || *granted >= bytes) return 0;
-    VG_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    *granted = bytes;
-    return 0;
-}
-
-int vg_launch_sdf_pack(const double* grid, int nx, int ny, int nz, double delta, float4* table, hipStream_t st) {
-    size_t total = (size_t)nx * ny * nz;
-    unsigned blocks = (unsigned)((total + kBlock - 1) / kBlock);
-    if (blocks > 8192u) blocks = 8192u;
+int vg_launch_sdf_pack(const vgpmp_sdf* sdf, const double* rows, int row_lo, int row_hi, int x0, int x1, hipStream_t st) {
+    (void)row_hi;
+    const size_t elems = sdf->layout == VGPMP_SDF_BRICK4
+        ? (size_t)((x1 + 3) / 4 - x0 / 4) * ((sdf->ny + 3) / 4) * ((sdf->nz + 3) / 4) * 64
+        : (size_t)(x1 - x0) * sdf->ny * sdf->nz;
+    unsigned blocks = (unsigned)((elems + kBlock - 1) / kBlock);
+    if (blocks > 16384u) blocks = 16384u;
     if (blocks == 0) return 0;
-    hipLaunchKernelGGL(sdf_pack_kernel, dim3(blocks), dim3(kBlock), 0, st, grid, nx, ny, nz, delta, table);
+    hipLaunchKernelGGL(sdf_pack_kernel, dim3(blocks), dim3(kBlock), 0, st, *sdf, rows, row_lo, x0, x1);
     return (int)hipGetLastError();
 }
 
@@ -735,9 +758,7 @@ int vg_launch_log_prob_impl(const vgpmp_robot* rb, int dof, const vgpmp_sdf* sdf
     if (n == 0) return 0;
     dim3 grid((unsigned)((n + kLikBlock - 1) / kLikBlock)), block(kLikBlock);
     const size_t lds = lik_lds_bytes(dof, false);
-    static size_t granted_g = 0, granted_n = 0;
-    int rc = dlogp ? lik_grant_lds((const void*)log_prob_kernel<true>, lds, &granted_g)
-                   : lik_grant_lds((const void*)log_prob_kernel<false>, lds, &granted_n);
+    int rc = vg_grant_dyn_lds(dlogp ? (const void*)log_prob_kernel<true> : (const void*)log_prob_kernel<false>, lds);
     if (rc) return rc;
     if (dlogp) hipLaunchKernelGGL((log_prob_kernel<true>), grid, block, lds, st, rb, *sdf, g, n, logp, dlogp);
     else hipLaunchKernelGGL((log_prob_kernel<false>), grid, block, lds, st, rb, *sdf, g, n, logp, dlogp);
@@ -755,33 +776,32 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
     if (P == 0 || nblk == 0) return 0;
     const bool sig = alpha_eff != nullptr;      // trainable likelihood constants: per-problem alpha / sigma_obs, per-sphere sums
     if (sig && (!sigma_eff || !sig_partial)) return VGPMP_E_ARG;
-    static size_t granted[6] = {0, 0, 0, 0, 0, 0};
     const size_t lds = lpc > 1 ? wide_lds_bytes(L, lpc) + (sig ? (size_t)(kLikBlock / lpc) * VGPMP_MAX_SPHERES * sizeof(float) : 0)
                                : lik_lds_bytes(L, true) * kLikBatchBlock / kLikBlock;
-    const void* fn = lpc == 8 ? (sig ? (const void*)loglik_paths_wide_kernel<8, true> : (const void*)loglik_paths_wide_kernel<8, false>)
-                              : (sig ? (const void*)loglik_paths_kernel<1, kLikBatchBlock, true>
-                                     : (const void*)loglik_paths_kernel<1, kLikBatchBlock, false>);
-    int rc = lik_grant_lds(fn, lds, &granted[(lpc == 8 ? 0 : 4) + (sig ? 1 : 0)]);
-    if (rc) return rc;
+    // the brick summary (when the caller provides one) lets the batch form leave out the table access of spheres in free space
+    const bool far = lpc == 1 && sdf->layout == VGPMP_SDF_BRICK4 && sdf->brick_min != nullptr;
     int dbg = 0;
 #ifdef VGPMP_BISECT
     dbg = lik_bisect_mode();
 #endif
     // k0 / k1 (profiler): events stamped with the kernel's own start and end on the device
     if (lpc == 8) {
-        if (sig)
-            hipExtLaunchKernelGGL((loglik_paths_wide_kernel<8, true>), dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf,
-                                  f, S, L, N, scale, G, logp, lik_partial, alpha_eff, sigma_eff, sig_partial);
-        else
-            hipExtLaunchKernelGGL((loglik_paths_wide_kernel<8, false>), dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf,
-                                  f, S, L, N, scale, G, logp, lik_partial, nullptr, nullptr, nullptr);
-    } else {
-        if (sig)
-            hipExtLaunchKernelGGL((loglik_paths_kernel<1, kLikBatchBlock, true>), dim3(nblk, P), dim3(kLikBatchBlock), lds, st, k0, k1,
-                                  0, rb, *sdf, f, S, L, N, scale, G, logp, lik_partial, dbg, alpha_eff, sigma_eff, sig_partial);
-        else
-            hipExtLaunchKernelGGL((loglik_paths_kernel<1, kLikBatchBlock, false>), dim3(nblk, P), dim3(kLikBatchBlock), lds, st, k0,
-                                  k1, 0, rb, *sdf, f, S, L, N, scale, G, logp, lik_partial, dbg, nullptr, nullptr, nullptr);
+        auto go = [&](auto kern) {
+            int rc = vg_grant_dyn_lds((const void*)kern, lds);
+            if (rc) return rc;
+            hipExtLaunchKernelGGL(kern, dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf, f, S, L, N, scale, G, logp,
+                                  lik_partial, alpha_eff, sigma_eff, sig_partial);
+            return (int)hipGetLastError();
+        };
+        return sig ? go(loglik_paths_wide_kernel<8, true>) : go(loglik_paths_wide_kernel<8, false>);
     }
-    return (int)hipGetLastError();
+    auto go = [&](auto kern) {
+        int rc = vg_grant_dyn_lds((const void*)kern, lds);
+        if (rc) return rc;
+        hipExtLaunchKernelGGL(kern, dim3(nblk, P), dim3(kLikBatchBlock), lds, st, k0, k1, 0, rb, *sdf, f, S, L, N, scale, G, logp,
+                              lik_partial, dbg, alpha_eff, sigma_eff, sig_partial);
+        return (int)hipGetLastError();
+    };
+    if (sig) return far ? go(loglik_paths_kernel<1, kLikBatchBlock, true, true>) : go(loglik_paths_kernel<1, kLikBatchBlock, true, false>);
+    return far ? go(loglik_paths_kernel<1, kLikBatchBlock, false, true>) : go(loglik_paths_kernel<1, kLikBatchBlock, false, false>);
 }

@@ -2722,24 +2722,7 @@ int vg_launch_adam(const vgpmp_dims* d, const vgpmp_params* x, const vgpmp_param
     return (int)hipGetLastError();
 }
 
-// Raises a kernel's dynamic-LDS limit when needed.  The attribute call is a slow host operation, so
-// the largest size already granted per kernel is remembered (benign race: worst case a repeat call).
-static int set_dyn_lds(const void* fn, size_t bytes) {
-    if (bytes > 160 * 1024) return VGPMP_E_SHAPE;
-    if (bytes <= 48 * 1024) return 0;
-    constexpr int kSlots = 16;
-    static const void* fns[kSlots];
-    static size_t granted[kSlots];
-    int slot = -1;
-    for (int i = 0; i < kSlots; ++i) {
-        if (fns[i] == fn) { slot = i; break; }
-        if (fns[i] == nullptr) { fns[i] = fn; slot = i; break; }
-    }
-    if (slot >= 0 && granted[slot] >= bytes) return 0;
-    VG_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    if (slot >= 0) granted[slot] = bytes;
-    return 0;
-}
+static int set_dyn_lds(const void* fn, size_t bytes) { return vg_grant_dyn_lds(fn, bytes); }
 
 // `num_steps` consecutive steps.  Few problems (and not under the per-stage profiler): the role-dispatched
 // stage launches above, with the variational-parameter update of step t riding in stage 1 of step t+1.

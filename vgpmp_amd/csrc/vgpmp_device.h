@@ -139,9 +139,22 @@ __device__ __forceinline__ void vg_stage_16(void* lds, const void* g, int n16, i
 // truncate, clamp, so that indices are bit-identical to the float64 reference on equal inputs.
 struct vg_sdf_dev {
     const float4* table;
-    int nx, ny, nz;
+    const float* brick_min;     // nullptr: no summary
+    int nx, ny, nz, layout;
+    int nby, nbz;               // bricks along y and z (BRICK4)
     double ox, oy, oz, delta;
 };
+
+__device__ __forceinline__ vg_sdf_dev vg_load_sdf(const vgpmp_sdf& s) {
+    vg_sdf_dev d;
+    d.table = reinterpret_cast<const float4*>(s.table);
+    d.brick_min = reinterpret_cast<const float*>(s.brick_min);
+    d.nx = s.nx; d.ny = s.ny; d.nz = s.nz; d.layout = s.layout;
+    d.nby = (s.ny + 3) >> 2; d.nbz = (s.nz + 3) >> 2;
+    d.ox = s.origin[0]; d.oy = s.origin[1]; d.oz = s.origin[2];
+    d.delta = s.delta;
+    return d;
+}
 
 __device__ __forceinline__ int vg_voxel_axis(double rel, double origin, double delta, int n) {
     double q = (rel - origin) / delta;
@@ -149,12 +162,25 @@ __device__ __forceinline__ int vg_voxel_axis(double rel, double origin, double d
     return q < 0.0 ? 0 : (q > (double)hi ? hi : (int)q);
 }
 
+// brick of voxel (ix, iy, iz) and the voxel's place inside it (include/vgpmp.h, VGPMP_SDF_BRICK4)
+__device__ __forceinline__ size_t vg_brick_of(const vg_sdf_dev& s, int ix, int iy, int iz) {
+    return ((size_t)(ix >> 2) * s.nby + (iy >> 2)) * s.nbz + (iz >> 2);
+}
+__device__ __forceinline__ int vg_morton_in_brick(int ix, int iy, int iz) {
+    return (iz & 1) | ((iy & 1) << 1) | ((ix & 1) << 2) | ((iz & 2) << 2) | ((iy & 2) << 3) | ((ix & 2) << 4);
+}
+// element of the table that holds voxel (ix, iy, iz)
+__device__ __forceinline__ size_t vg_table_offset(const vg_sdf_dev& s, int ix, int iy, int iz) {
+    if (s.layout == VGPMP_SDF_BRICK4) return vg_brick_of(s, ix, iy, iz) * 64 + vg_morton_in_brick(ix, iy, iz);
+    return ((size_t)ix * s.ny + iy) * s.nz + iz;
+}
+
 __device__ __forceinline__ size_t vg_voxel_index(const vg_sdf_dev& s, double rx, double ry, double rz, int& ix,
                                                  int& iy, int& iz) {
     ix = vg_voxel_axis(rx, s.ox, s.delta, s.nx);
     iy = vg_voxel_axis(ry, s.oy, s.delta, s.ny);
     iz = vg_voxel_axis(rz, s.oz, s.delta, s.nz);
-    return ((size_t)ix * s.ny + iy) * s.nz + iz;
+    return vg_table_offset(s, ix, iy, iz);
 }
 
 // ---- Philox-4x32-10 (same schedule as oracle/vgpmp_oracle.py::philox4x32) --------------------
@@ -192,8 +218,31 @@ __device__ __forceinline__ uint2 vg_key(uint32_t seed, uint32_t problem, uint32_
 
 enum { VG_STREAM_OMEGA = 0, VG_STREAM_CHI = 1, VG_STREAM_BETA = 2, VG_STREAM_W = 3, VG_STREAM_EPS = 4, VG_STREAM_EPS2 = 5 };
 
+// Raises a kernel's dynamic-LDS limit when needed.  hipFuncSetAttribute is a slow host call and applies to the
+// CURRENT device only, so the largest size granted is remembered per (device, kernel).  Benign race: worst case a
+// repeated attribute call.
+inline int vg_grant_dyn_lds(const void* fn, size_t bytes) {
+    if (bytes > 160 * 1024) return VGPMP_E_SHAPE;
+    if (bytes <= 48 * 1024) return 0;
+    constexpr int kSlots = 256;
+    static const void* fns[kSlots];
+    static int devs[kSlots];
+    static size_t granted[kSlots];
+    int dev = 0;
+    VG_CHECK_HIP(hipGetDevice(&dev));
+    int slot = -1;
+    for (int i = 0; i < kSlots; ++i) {
+        if (fns[i] == fn && devs[i] == dev) { slot = i; break; }
+        if (fns[i] == nullptr) { fns[i] = fn; devs[i] = dev; slot = i; break; }
+    }
+    if (slot >= 0 && granted[slot] >= bytes) return 0;
+    VG_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (slot >= 0) granted[slot] = bytes;
+    return 0;
+}
+
 // launchers implemented in the .hip files
-int vg_launch_sdf_pack(const double* grid, int nx, int ny, int nz, double delta, float4* table, hipStream_t st);
+int vg_launch_sdf_pack(const vgpmp_sdf* sdf, const double* rows, int row_lo, int row_hi, int x0, int x1, hipStream_t st);
 int vg_launch_fk_spheres(const vgpmp_robot* rb, const float* q, int64_t n, float* pos, float* frames, hipStream_t st);
 int vg_launch_sdf_query(const vgpmp_sdf* sdf, const double* rel, int64_t n, int32_t* idx, float* dist, float* grad,
                         hipStream_t st);

@@ -57,12 +57,20 @@ class DeviceScene:
     """Robot tables + signed distance field resident in HBM."""
 
     def __init__(self, spec: RobotSpec, grid, scene_offset: Sequence[float], sigma_obs=0.005,
-                 epsilon: float = 0.05, device: Optional[torch.device] = None):
+                 epsilon: float = 0.05, device: Optional[torch.device] = None, layout: str = "brick",
+                 free_space_summary: Optional[bool] = None, slab_bytes: int = 256 << 20):
+        """grid = (data, origin, delta): data[x, y, z] as a NumPy array / torch tensor, or an object with `.shape` and
+        `.rows(x_lo, x_hi, device) -> float64 device tensor` (rows produced on demand, e.g. scenes.AnalyticSceneRows).
+        layout: "brick" (4x4x4 Morton bricks, include/vgpmp.h VGPMP_SDF_BRICK4) or "linear".
+        free_space_summary: hand the per-brick minimum distance to the batch likelihood kernel (exact: spheres whose
+        brick lies beyond epsilon + radius of every obstacle skip the table access); None = only for tables larger than
+        the Infinity Cache, where that access is an HBM gather."""
         self.lib = capi.load(require=True)
-        self.device = device or _require_gpu()
+        self.device = _require_gpu() if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.spec = spec
         data, origin, delta = grid
-        data = np.ascontiguousarray(np.asarray(data, dtype=np.float64))
         self.shape = tuple(int(v) for v in data.shape)
         self.origin = np.asarray(origin, dtype=np.float64).copy()
         self.delta = float(delta)
@@ -71,22 +79,49 @@ class DeviceScene:
         self.epsilon = float(epsilon)
         self.host_robot = capi.make_robot(spec, self.sigma_obs, epsilon, self.scene_offset)
         self.dev_robot = torch.empty(C.sizeof(capi.Robot), dtype=torch.uint8, device=self.device)
-        capi.check(self.lib.vgpmp_robot_upload(C.byref(self.host_robot), capi.ptr(self.dev_robot), capi.stream_ptr()),
+        capi.check(self.lib.vgpmp_robot_upload(C.byref(self.host_robot), capi.ptr(self.dev_robot), self._stream()),
                    "vgpmp_robot_upload")
+        self._upload_grid(data, layout, free_space_summary, slab_bytes)
+
+    def _stream(self) -> int:
+        """torch's current stream on THIS scene's device; launches need that device current (LDS attributes and
+        kernel modules are per device), so a caller driving several GPUs from one process is switched over."""
+        if torch.cuda.current_device() != self.device.index:
+            torch.cuda.set_device(self.device)
+        return int(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _upload_grid(self, data, layout: str, free_space_summary: Optional[bool], slab_bytes: int) -> None:
         nx, ny, nz = self.shape
-        self.table = torch.empty((nx, ny, nz, 4), dtype=torch.float32, device=self.device)
-        # upload in slabs so a 512^3 float64 source never needs a second full-size device copy
-        src = torch.from_numpy(data).to(self.device)
-        capi.check(self.lib.vgpmp_sdf_pack(capi.ptr(src), nx, ny, nz, self.delta, capi.ptr(self.table),
-                                           capi.stream_ptr()), "vgpmp_sdf_pack")
-        torch.cuda.current_stream().synchronize()
-        del src
+        self.layout = {"linear": capi.SDF_LINEAR, "brick": capi.SDF_BRICK4}[layout]
+        tb, bb = C.c_size_t(0), C.c_size_t(0)
+        capi.check(self.lib.vgpmp_sdf_table_bytes(nx, ny, nz, self.layout, C.byref(tb), C.byref(bb)), "vgpmp_sdf_table_bytes")
+        self.table = torch.empty(tb.value // 4, dtype=torch.float32, device=self.device)
+        self.brick_min = torch.empty(bb.value // 4, dtype=torch.float32, device=self.device) if bb.value else None
         self.sdf = capi.Sdf()
         self.sdf.table = capi.ptr(self.table)
-        self.sdf.nx, self.sdf.ny, self.sdf.nz = nx, ny, nz
+        self.sdf.nx, self.sdf.ny, self.sdf.nz, self.sdf.layout = nx, ny, nz, self.layout
         for k in range(3):
             self.sdf.origin[k] = float(self.origin[k])
         self.sdf.delta = self.delta
+        self.sdf.brick_min = capi.ptr(self.brick_min)           # the pack kernel fills it
+        # float64 rows go up slab by slab (with one halo row each side): a 512^3 source never needs a full device copy
+        step = max(4, (slab_bytes // (8 * ny * nz)) // 4 * 4)
+        lazy = hasattr(data, "rows")
+        if not lazy and not torch.is_tensor(data):
+            data = torch.from_numpy(np.ascontiguousarray(np.asarray(data, dtype=np.float64)))
+        for x0 in range(0, nx, step):
+            x1 = min(nx, x0 + step)
+            lo, hi = max(x0 - 1, 0), min(x1 + 1, nx)
+            rows = data.rows(lo, hi, self.device) if lazy else data[lo:hi].to(self.device, torch.float64).contiguous()
+            capi.check(self.lib.vgpmp_sdf_pack(C.byref(self.sdf), capi.ptr(rows), lo, hi, x0, x1, self._stream()),
+                       "vgpmp_sdf_pack")
+            torch.cuda.current_stream(self.device).synchronize()
+            del rows
+        if free_space_summary is None:
+            free_space_summary = tb.value > (256 << 20)
+        self.free_space_summary = bool(free_space_summary and self.brick_min is not None)
+        if not self.free_space_summary:
+            self.sdf.brick_min = None
 
     # ---- stand-alone pieces -------------------------------------------------------------------
     def fk_spheres(self, q: torch.Tensor, want_frames: bool = False):
@@ -96,7 +131,7 @@ class DeviceScene:
         pos = torch.empty((n, self.spec.num_spheres, 3), dtype=torch.float32, device=self.device)
         frames = torch.empty((n, self.spec.dof + 1, 3, 4), dtype=torch.float32, device=self.device) if want_frames else None
         capi.check(self.lib.vgpmp_fk_spheres(capi.ptr(self.dev_robot), capi.ptr(q), n, capi.ptr(pos), capi.ptr(frames),
-                                             capi.stream_ptr()), "vgpmp_fk_spheres")
+                                             self._stream()), "vgpmp_fk_spheres")
         return (pos, frames) if want_frames else pos
 
     def sdf_query(self, rel_pos: torch.Tensor):
@@ -107,7 +142,7 @@ class DeviceScene:
         dist = torch.empty(n, dtype=torch.float32, device=self.device)
         grad = torch.empty((n, 3), dtype=torch.float32, device=self.device)
         capi.check(self.lib.vgpmp_sdf_query(C.byref(self.sdf), capi.ptr(rel), n, capi.ptr(idx), capi.ptr(dist),
-                                            capi.ptr(grad), capi.stream_ptr()), "vgpmp_sdf_query")
+                                            capi.ptr(grad), self._stream()), "vgpmp_sdf_query")
         return idx, dist, grad
 
     def log_prob(self, g: torch.Tensor, want_grad: bool = False):
@@ -118,7 +153,7 @@ class DeviceScene:
         logp = torch.empty(n, dtype=torch.float32, device=self.device)
         dl = torch.empty_like(g2) if want_grad else None
         capi.check(self.lib.vgpmp_log_prob(capi.ptr(self.dev_robot), self.spec.dof, C.byref(self.sdf), capi.ptr(g2), n,
-                                           capi.ptr(logp), capi.ptr(dl), capi.stream_ptr()), "vgpmp_log_prob")
+                                           capi.ptr(logp), capi.ptr(dl), self._stream()), "vgpmp_log_prob")
         logp = logp.reshape(shape)
         return (logp, dl.reshape(g.shape)) if want_grad else logp
 
@@ -175,7 +210,16 @@ class PlannerBatch:
         z = lambda t: torch.zeros_like(t)
         self.adam_m = [z(self.q_mu), z(self.q_sqrt), z(self.raw_ell), z(self.raw_var)]
         self.adam_v = [z(self.q_mu), z(self.q_sqrt), z(self.raw_ell), z(self.raw_var)]
-        self.grad = [z(self.q_mu), z(self.q_sqrt), z(self.raw_ell), z(self.raw_var)]
+        # gradient + ELBO pieces as ONE contiguous float64 buffer [q_mu | q_sqrt | raw_ell | raw_var | lik | kl]: with a
+        # sharded sample axis the per-step exchange is a single in-place all-reduce of it (vgpmp_amd/sharding.py)
+        shapes = [(P, L, M), (P, L, M, M), (P, L), (P, L), (P,), (P,)]
+        self.reduce_buf = torch.zeros(sum(int(np.prod(sh)) for sh in shapes), dtype=f64, device=dev)
+        parts, o = [], 0
+        for sh in shapes:
+            n = int(np.prod(sh))
+            parts.append(self.reduce_buf[o:o + n].view(sh))
+            o += n
+        self.grad = parts[:4]
         # ---- noise, outputs, workspace
         self.omega = torch.empty((P, L, B, L), dtype=f32, device=dev)
         self.beta = torch.empty((P, L, B), dtype=f32, device=dev)
@@ -184,8 +228,7 @@ class PlannerBatch:
         self.eps2 = torch.empty((P, S, self.Mz, L), dtype=f32, device=dev)
         self.f = torch.empty((P, S, L, N), dtype=f32, device=dev)
         self.logp = torch.empty((P, S, N), dtype=f32, device=dev)
-        self.lik = torch.zeros(P, dtype=f64, device=dev)
-        self.kl = torch.zeros(P, dtype=f64, device=dev)
+        self.lik, self.kl = parts[4], parts[5]
         nbytes = C.c_size_t(0)
         capi.check(self.lib.vgpmp_workspace_bytes(C.byref(self.dims), C.byref(nbytes)), "vgpmp_workspace_bytes")
         self.workspace = torch.empty(int(nbytes.value), dtype=torch.uint8, device=dev)
@@ -243,7 +286,7 @@ class PlannerBatch:
 
     def generate_noise(self, step: int) -> None:
         capi.check(self.lib.vgpmp_generate_noise(C.byref(self.dims), C.byref(self._noise), self.seed, self.problem_base,
-                                                 int(step), capi.stream_ptr()), "vgpmp_generate_noise")
+                                                 int(step), self.scene._stream()), "vgpmp_generate_noise")
 
     # ---- the ELBO step --------------------------------------------------------------------------
     def _run(self, what: int, step: int) -> None:
@@ -252,7 +295,7 @@ class PlannerBatch:
             C.byref(self.dims), capi.ptr(self.scene.dev_robot), C.byref(self.scene.sdf), C.byref(self._problem),
             C.byref(self._params), C.byref(self._am), C.byref(self._av), C.byref(self._noise), C.byref(self._out),
             capi.ptr(self.workspace), self.workspace.numel(), what, trainable_mask(self.trainable), self.lr,
-            max(self.t, 1), self.seed, self.problem_base, int(step), capi.stream_ptr()), "vgpmp_elbo_step")
+            max(self.t, 1), self.seed, self.problem_base, int(step), self.scene._stream()), "vgpmp_elbo_step")
 
     def elbo(self, generate: bool = True, step: Optional[int] = None) -> torch.Tensor:
         """VGPMP.elbo (models/vgpmp.py:265-289) for every problem: alpha * sum_n mean_s logp - KL."""
@@ -280,9 +323,9 @@ class PlannerBatch:
                 C.byref(self._noise), C.byref(self._out), capi.ptr(self.workspace), self.workspace.numel(), what,
                 trainable_mask(self.trainable), self.lr, 0, self.seed, self.problem_base, 0)
         if stage_ms is None:
-            capi.check(self.lib.vgpmp_elbo_steps(*args, int(num_steps), capi.stream_ptr()), "vgpmp_elbo_steps")
+            capi.check(self.lib.vgpmp_elbo_steps(*args, int(num_steps), self.scene._stream()), "vgpmp_elbo_steps")
         else:
-            capi.check(self.lib.vgpmp_elbo_step_profiled(*args, capi.stream_ptr(), stage_ms), "vgpmp_elbo_step_profiled")
+            capi.check(self.lib.vgpmp_elbo_step_profiled(*args, self.scene._stream(), stage_ms), "vgpmp_elbo_step_profiled")
 
     def capture(self, unroll: int = 10) -> None:
         """Capture `unroll` consecutive training steps into one hipGraph (torch.cuda.CUDAGraph is the
@@ -322,7 +365,7 @@ class PlannerBatch:
         self.t += 1
         capi.check(self.lib.vgpmp_adam_step(C.byref(self.dims), C.byref(self._params), C.byref(self._out.grad),
                                             C.byref(self._am), C.byref(self._av), trainable_mask(self.trainable),
-                                            self.lr, self.t, capi.stream_ptr()), "vgpmp_adam_step")
+                                            self.lr, self.t, self.scene._stream()), "vgpmp_adam_step")
 
     def view(self, name: str) -> torch.Tensor:
         """Intermediate of the last evaluation, copied out of the workspace (tests only)."""

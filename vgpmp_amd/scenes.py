@@ -48,19 +48,24 @@ def lattice(shape: Sequence[int], origin, delta: float, dtype=np.float64) -> np.
     return np.stack(np.meshgrid(*ax, indexing="ij"), axis=-1)
 
 
+def _synthetic_shapes(n: int, delta: float, origin, seed: int, n_boxes: int, n_spheres: int):
+    rng = np.random.default_rng(seed)
+    origin = np.asarray(origin, dtype=np.float64)
+    ext = delta * n
+    boxes = [(origin + rng.uniform(0.15, 0.85, 3) * ext, rng.uniform(0.04, 0.14, 3) * ext) for _ in range(n_boxes)]
+    balls = [(origin + rng.uniform(0.15, 0.85, 3) * ext, rng.uniform(0.04, 0.10) * ext) for _ in range(n_spheres)]
+    return origin, boxes, balls
+
+
 def synthetic_boxes_sdf(n: int = 128, delta: float = 0.0125, origin=(-0.8, -0.8, -0.2), seed: int = 0,
                         n_boxes: int = 6, n_spheres: int = 4, dtype=np.float64) -> Grid:
     """Union of `n_boxes` axis-aligned boxes and `n_spheres` spheres, placed by `seed` inside the
     grid extent (SURVEY 8d defaults: 128^3, delta 0.0125, origin (-0.8,-0.8,-0.2))."""
-    rng = np.random.default_rng(seed)
-    origin = np.asarray(origin, dtype=np.float64)
-    ext = delta * n
+    origin, boxes, balls = _synthetic_shapes(n, delta, origin, seed, n_boxes, n_spheres)
     shape = (n, n, n)
     out = np.full(shape, np.inf, dtype=dtype)
-    # evaluate slab by slab so 512^3 grids stay within memory
+    # evaluate slab by slab so large grids stay within memory
     step = max(1, min(n, (1 << 22) // (n * n)))
-    boxes = [(origin + rng.uniform(0.15, 0.85, 3) * ext, rng.uniform(0.04, 0.14, 3) * ext) for _ in range(n_boxes)]
-    balls = [(origin + rng.uniform(0.15, 0.85, 3) * ext, rng.uniform(0.04, 0.10) * ext) for _ in range(n_spheres)]
     for x0 in range(0, n, step):
         x1 = min(n, x0 + step)
         p = lattice((x1 - x0, n, n), origin + np.array([x0 * delta, 0.0, 0.0]), delta)
@@ -71,6 +76,40 @@ def synthetic_boxes_sdf(n: int = 128, delta: float = 0.0125, origin=(-0.8, -0.8,
             d = np.minimum(d, np.linalg.norm(p - c, axis=-1) - r)
         out[x0:x1] = d.astype(dtype)
     return out, origin, float(delta)
+
+
+class AnalyticSceneRows:
+    """The same synthetic scene as `synthetic_boxes_sdf`, evaluated lazily on a device, rows [x_lo, x_hi) at a
+    time (float64 torch tensor [x_hi - x_lo, n, n]): a 512^3 grid (1 GiB in float64) is never held whole.
+    `engine.DeviceScene` accepts it in place of the array of a Grid.  Synthetic-data plumbing, not product code."""
+
+    def __init__(self, n: int, delta: float, origin, seed: int = 0, n_boxes: int = 6, n_spheres: int = 4,
+                 round_to=None):
+        self.shape = (int(n), int(n), int(n))
+        self.delta = float(delta)
+        self.origin, self.boxes, self.balls = _synthetic_shapes(n, delta, origin, seed, n_boxes, n_spheres)
+        self.round_to = round_to        # e.g. torch.float32: values rounded as a float32 grid file would hold them
+
+    def rows(self, x_lo: int, x_hi: int, device):
+        import torch
+        f64 = torch.float64
+        n = self.shape[0]
+        ax = [torch.as_tensor(self.origin[i], dtype=f64, device=device)
+              + self.delta * torch.arange(n if i else x_hi - x_lo, dtype=f64, device=device) for i in range(3)]
+        ax[0] = ax[0] + x_lo * self.delta
+        X, Y, Z = torch.meshgrid(*ax, indexing="ij")
+        d = torch.full(X.shape, float("inf"), dtype=f64, device=device)
+        zero = torch.zeros((), dtype=f64, device=device)
+        for c, h in self.boxes:
+            qx, qy, qz = (X - c[0]).abs() - h[0], (Y - c[1]).abs() - h[1], (Z - c[2]).abs() - h[2]
+            outside = torch.sqrt(torch.maximum(qx, zero) ** 2 + torch.maximum(qy, zero) ** 2 + torch.maximum(qz, zero) ** 2)
+            inside = torch.minimum(torch.maximum(torch.maximum(qx, qy), qz), zero)
+            d = torch.minimum(d, outside + inside)
+        for c, r in self.balls:
+            d = torch.minimum(d, torch.sqrt((X - c[0]) ** 2 + (Y - c[1]) ** 2 + (Z - c[2]) ** 2) - r)
+        if self.round_to is not None:
+            d = d.to(self.round_to).to(f64)
+        return d.contiguous()
 
 
 # ---- mesh -> SDF (device) -------------------------------------------------------------------------------
