@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--layout", choices=("brick", "linear"), default="brick", help="voxel table layout (include/vgpmp.h)")
     ap.add_argument("--summary", choices=("auto", "on", "off"), default="auto",
                     help="free-space brick summary in the batch likelihood kernel (auto: tables beyond the Infinity Cache)")
+    ap.add_argument("--lik-form", choices=("auto", "lanes", "lanes-lds"), default="auto",
+                    help="likelihood kernel form (measurement): lanes = the batch form at any batch size, lanes-lds = with its per-frame sums in LDS")
     ap.add_argument("--min-seconds", type=float, default=0.5,
                     help="the timed region repeats the K steps until this much time has passed (K = --steps alone is ~1 ms)")
     ap.add_argument("--workload", choices=("config2", "stress"), default="config2",
@@ -149,6 +151,8 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     ps, spec, grid, scene, planner = build_problem(rank, args)
+    from vgpmp_amd import capi
+    planner.extra_flags |= {"auto": 0, "lanes": capi.LIK_LANES, "lanes-lds": capi.LIK_LDS_STATE}[args.lik_form]
     for _ in range(args.warmup):
         planner.step()
     if args.unroll > 0:
@@ -206,8 +210,10 @@ def main():
     sdf_bytes16 = npb * S * N * (16 * P + 8 * D + 4)               # what the packed table moves: one 16-byte record per query
     gemm_flops = npb * 2 * (2.0 * S * (N + M + 2) * D * B)         # F0 and H (lengthscales trainable)
     t_sdf, t_gemm = kernel_ms["loglik_kernel"] * 1e-3, kernel_ms["prior_gemm_kernel"] * 1e-3
-    lik_kernel = ("loglik_paths_wide_kernel<8, false>" if npb * S * N <= 65536 else
-                  "loglik_paths_kernel<1, 64, false, %s>" % ("true" if scene.free_space_summary else "false"))
+    far = "true" if scene.free_space_summary else "false"
+    batch_form = args.lik_form != "auto" or npb * S * N > 65536
+    lik_kernel = ("loglik_paths_kernel<1, 64, false, %s, %s>" % (far, "true" if D <= 15 and args.lik_form != "lanes-lds" else "false")
+                  if batch_form else "loglik_paths_wide_kernel<8, false>")
     roof_sdf = {"kernel": lik_kernel, "bound": "hbm", "achieved": sdf_bytes / t_sdf / 1e9,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sdf_bytes / t_sdf / 1e9 / HBM_PEAK_GBPS,
                 "traffic": None, "algorithmic_bytes_per_launch": sdf_bytes, "avg_launch_ms": kernel_ms["loglik_kernel"],

@@ -59,6 +59,14 @@ typedef struct vgpmp_robot {
     float epsilon;
     float reserved2;
     double scene_offset[3];                /* subtracted from sphere centres before the lookup */
+    /* The rest is DERIVED by vgpmp_robot_upload (whatever the caller left there): the same numbers regrouped so that one
+     * joint / one sphere is one aligned wide load on the device. */
+    float inv_sigma_obs[VGPMP_MAX_SPHERES];  /* 1 / sigma_obs (float32) */
+    float joint_tab[VGPMP_MAX_DOF][8];       /* {cos_alpha, sin_alpha, d, a, twist, low, high, high - low} */
+    float sphere_a[VGPMP_MAX_SPHERES][4];    /* {offset x, y, z, frame (int32 bits)}; entries >= num_spheres: frame = dof */
+    float sphere_b[VGPMP_MAX_SPHERES][2];    /* {radius, 1 / sigma_obs} */
+    int32_t frame_first[VGPMP_MAX_FRAMES + 3]; /* filled by vgpmp_robot_upload: spheres [frame_first[k], frame_first[k+1])
+                                                * ride on frame k (k = 0 .. dof); entries beyond dof + 1 repeat num_spheres */
 } vgpmp_robot;
 
 /* Signed distance field prepared by vgpmp_sdf_pack: one float4 {d, gx, gy, gz} per voxel of the reference's
@@ -179,6 +187,8 @@ typedef struct vgpmp_outputs {
 #define VGPMP_NO_FUSE 16        /* measurement: one launch per kernel even for small batches  */
 #define VGPMP_GEMM_DIRECT 32    /* measurement: stage-2 GEMM role with operands straight from L2 */
 #define VGPMP_NO_SPLIT 64       /* measurement: reverse path pass on one workgroup per (chunk, latent) */
+#define VGPMP_LIK_LANES 256     /* measurement: the batch form of the likelihood (one lane per configuration) at any batch size */
+#define VGPMP_LIK_LDS_STATE 512 /* measurement: that form with the per-frame force / moment sums in LDS instead of registers */
 #define VGPMP_ELIM_BLOCK 128    /* measurement: Kuu elimination by the whole workgroup through LDS instead of one wave in registers */
 
 /* ---- set-up -------------------------------------------------------------------------------- */

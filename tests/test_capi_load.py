@@ -25,7 +25,7 @@ def test_library_builds_loads_and_exports_header_symbols():
 
 def test_struct_sizes_match_header_layout():
     # sizes implied by include/vgpmp.h (natural alignment, 8-byte tail for the doubles)
-    assert ctypes.sizeof(capi.Robot) == 4 * 4 + 7 * 16 * 4 + 12 * 4 + 64 * 4 + 64 * 12 + 64 * 4 + 64 * 4 + 8 + 24
+    assert ctypes.sizeof(capi.Robot) == 4 * 4 + 7 * 16 * 4 + 12 * 4 + 64 * 4 + 64 * 12 + 64 * 4 + 64 * 4 + 8 + 24 + 64 * 4 + 16 * 32 + 64 * 16 + 64 * 8 + 80
     assert ctypes.sizeof(capi.Sdf) == 8 + 16 + 24 + 8 + 8
     assert ctypes.sizeof(capi.Dims) == 40
     assert ctypes.sizeof(capi.Params) == 32 and ctypes.sizeof(capi.Noise) == 40

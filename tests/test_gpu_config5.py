@@ -196,3 +196,43 @@ def test_config5_full_size_properties():
         c.elbo(step=10**6)
         assert torch.equal(c.f, ref[0]) and torch.equal(c.logp, ref[1]) and torch.equal(c.lik, ref[2])
         del c, sc2
+
+
+@pytest.mark.parametrize("robot", ["franka", "wam", "ur10", "kuka", "synthetic14", "synthetic15", "synthetic9"])
+def test_batch_form_of_the_likelihood_against_oracle_on_every_robot_shape(robot):
+    """The batch form (one lane per configuration, sphere gathers in batches of 8 across frames, per-frame sums in indexed
+    registers or -- measurement flag -- in LDS) forced on small problems of every robot shape: Craig and classic DH,
+    6 / 7 / 9 / 14 / 15 joints, ragged sphere counts per frame.  Against the oracle, and the two state placements and the
+    free-space summary against each other bit for bit."""
+    from vgpmp_amd import capi
+    from helpers import small_problem
+    S, N, M, B = 9, 21, 6, 64        # S * N = 189: not a multiple of the workgroup
+    if robot.startswith("synthetic"):
+        pb = synthetic_problem(dof=int(robot[9:]), S=S, N=N, M=M, B=B, seed=23, n_grid=40, n_problems=2)
+    else:
+        sp = small_problem(robot=robot, S=S, N=N, M=M, B=B, seed=23, n_grid=40)
+        pb = dict(sp, ys=np.stack([sp["y"], sp["y"][::-1]]), params=[sp["params"], sp["params"]], noise=[sp["noise"]] * 2)
+    sc = _engine().DeviceScene(pb["spec"], pb["grid"], pb["offset"], free_space_summary=False)
+    outs = {}
+    for name, flag, summary in (("regs", capi.LIK_LANES, False), ("regs+summary", capi.LIK_LANES, True),
+                                ("lds", capi.LIK_LDS_STATE, False), ("lds+summary", capi.LIK_LDS_STATE, True)):
+        sc.sdf.brick_min = capi.ptr(sc.brick_min) if summary else None
+        pl, nz = _batch(pb, sc, S, N, M, B)
+        pl.extra_flags = flag
+        pl.fuse = False                     # one launch per kernel: the likelihood launch is the form under test
+        loss, grads = pl.loss_and_grad(generate=False)
+        torch.cuda.synchronize()
+        outs[name] = [pl.logp.clone(), pl.view("G"), pl.lik.clone()] + [g.clone() for g in grads]
+    for k in range(2):
+        fw = orc.elbo_forward(pb["params"][k], pb["scene"], pb["X"], pb["Zy"], pb["ys"][k], nz[k], pb["alpha"])
+        og, Gw = orc.elbo_backward(pb["params"][k], pb["scene"], pb["X"], pb["Zy"], nz[k], pb["alpha"], fw)
+        assert (fw["logp"] < 0).any()
+        ok = np.isclose(outs["regs"][0][k].cpu().numpy(), fw["logp"], rtol=2e-3, atol=1e-4)
+        assert ok.mean() >= 0.95, ok.mean()
+        flips = 1.0 - ok.mean()
+        np.testing.assert_allclose(float(outs["regs"][2][k]), fw["lik"], rtol=50 * flips + 2e-4)
+        got = outs["regs"][3][k].cpu().numpy().T
+        assert np.abs(got - og.q_mu).max() <= (50 * flips + 3e-3) * np.abs(og.q_mu).max()
+    for other in ("regs+summary", "lds", "lds+summary"):
+        for a, b in zip(outs["regs"], outs[other]):
+            assert torch.equal(a, b), other

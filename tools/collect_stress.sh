@@ -3,8 +3,8 @@
 # root: bench line + rocprofv3 kernel statistics for each table form, FETCH_SIZE / WRITE_SIZE passes for the likelihood
 # kernel, and the 16-byte-gather ceiling of the memory system (tools/gather_probe).  Output: gpurun_out/r02/stress_*.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-out=gpurun_out/r02; mkdir -p $out
-B="--workload stress --problems 64 --grid 512 --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 10"
+out=${OUT:-gpurun_out/r02}; mkdir -p $out
+B="--workload stress --problems 64 --grid 512 --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 10 $EXTRA"
 forms=${FORMS:-"linear:off brick:off brick:on"}
 for f in $forms; do
   lay=${f%%:*}; sm=${f##*:}; tag=stress_${lay}_summary_${sm}

@@ -18,7 +18,7 @@ COMM_ID_BYTES = 128
 TRAIN_Q_MU, TRAIN_Q_SQRT, TRAIN_LENGTHSCALES, TRAIN_KERNEL_VARIANCE = 1, 2, 4, 8
 TRAIN_SIGMA_OBS, TRAIN_ALPHA = 16, 32      # need Problem.lik
 DO_FORWARD, DO_BACKWARD, DO_ADAM, GEN_NOISE, NO_FUSE = 1, 2, 4, 8, 16
-GEMM_DIRECT, NO_SPLIT, ELIM_BLOCK = 32, 64, 128
+GEMM_DIRECT, NO_SPLIT, ELIM_BLOCK, LIK_LANES, LIK_LDS_STATE = 32, 64, 128, 256, 512
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvgpmp_hip.so"
 
@@ -44,7 +44,10 @@ class Robot(C.Structure):
                 ("base", C.c_float * 12), ("sphere_frame", C.c_int32 * MAX_SPHERES),
                 ("sphere_off", (C.c_float * 3) * MAX_SPHERES), ("radius", C.c_float * MAX_SPHERES),
                 ("sigma_obs", C.c_float * MAX_SPHERES), ("epsilon", C.c_float), ("reserved2", C.c_float),
-                ("scene_offset", C.c_double * 3)]
+                ("scene_offset", C.c_double * 3), ("inv_sigma_obs", C.c_float * MAX_SPHERES),
+                ("joint_tab", (C.c_float * 8) * MAX_DOF), ("sphere_a", (C.c_float * 4) * MAX_SPHERES),
+                ("sphere_b", (C.c_float * 2) * MAX_SPHERES),
+                ("frame_first", C.c_int32 * 20)]
 
 
 SDF_LINEAR, SDF_BRICK4 = 0, 1

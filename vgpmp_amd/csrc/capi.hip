@@ -1,6 +1,7 @@
 // extern "C" entry points of libvgpmp_hip.so (see include/vgpmp.h for the contract).
 #include "vgpmp_device.h"
 #include "gp_path.h"
+#include <string.h>
 
 extern "C" {
 
@@ -15,7 +16,27 @@ int vgpmp_robot_upload(const vgpmp_robot* host_robot, void* dev_robot, vgpmp_str
         if (host_robot->sphere_frame[p] < host_robot->sphere_frame[p - 1]) return VGPMP_E_ARG;
     for (int p = 0; p < host_robot->num_spheres; ++p)
         if (host_robot->sphere_frame[p] < 0 || host_robot->sphere_frame[p] > host_robot->dof) return VGPMP_E_ARG;
-    VG_CHECK_HIP(hipMemcpyAsync(dev_robot, host_robot, sizeof(vgpmp_robot), hipMemcpyHostToDevice, (hipStream_t)stream));
+    vgpmp_robot up = *host_robot;          // the per-frame sphere ranges are derived here, whatever the caller left there
+    for (int p = 0; p < VGPMP_MAX_SPHERES; ++p) {
+        const bool in = p < up.num_spheres;
+        up.inv_sigma_obs[p] = in ? 1.0f / up.sigma_obs[p] : 0.f;
+        const int32_t fr = in ? up.sphere_frame[p] : up.dof;
+        for (int k = 0; k < 3; ++k) up.sphere_a[p][k] = in ? up.sphere_off[p][k] : 0.f;
+        ::memcpy(&up.sphere_a[p][3], &fr, sizeof(float));
+        up.sphere_b[p][0] = in ? up.radius[p] : 0.f;
+        up.sphere_b[p][1] = up.inv_sigma_obs[p];
+    }
+    for (int j = 0; j < VGPMP_MAX_DOF; ++j) {
+        const float row[8] = {up.cos_alpha[j], up.sin_alpha[j], up.dh_d[j], up.dh_a[j], up.twist[j], up.low[j], up.high[j],
+                              up.high[j] - up.low[j]};
+        ::memcpy(up.joint_tab[j], row, sizeof(row));
+    }
+    for (int k = 0; k < VGPMP_MAX_FRAMES + 3; ++k) {
+        int c = 0;
+        for (int p = 0; p < up.num_spheres; ++p) c += up.sphere_frame[p] < k ? 1 : 0;
+        up.frame_first[k] = c;
+    }
+    VG_CHECK_HIP(hipMemcpyAsync(dev_robot, &up, sizeof(vgpmp_robot), hipMemcpyHostToDevice, (hipStream_t)stream));
     // the host struct may be a temporary of the caller: make the copy complete before returning
     VG_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     return 0;

@@ -9,6 +9,10 @@
 #include "vgpmp_device.h"
 #include <hip/hip_ext.h>
 
+// No implicit contraction in this file: every fused multiply-add is written as fmaf, so that template instantiations
+// that differ only in WHERE a voxel record comes from (layout, free-space summary) round identically.
+#pragma clang fp contract(off)
+
 #ifdef VGPMP_BISECT
 #include <stdlib.h>
 static int lik_bisect_mode() { const char* e = getenv("VGPMP_STOP_LIK"); return e ? atoi(e) : 0; }
@@ -34,7 +38,8 @@ __device__ __forceinline__ vg_float3 lin2(float a, vg_float3 x, float b, vg_floa
 
 // T_i = T_{i-1} * A_i for joint j = i-1 (0-based table index), given sin/cos of theta_j + twist_j
 __device__ __forceinline__ void dh_apply(const vgpmp_robot* __restrict__ rb, int j, float st, float ct, Frame& T) {
-    const float ca = rb->cos_alpha[j], sa = rb->sin_alpha[j], d = rb->dh_d[j], a = rb->dh_a[j];
+    const float4 jt = *reinterpret_cast<const float4*>(rb->joint_tab[j]);
+    const float ca = jt.x, sa = jt.y, d = jt.z, a = jt.w;
     if (rb->craig) {
         // Rx(alpha) Tx(a) Rz(theta) Tz(d)      (utils/sampler.py:190-214)
         vg_float3 y1 = lin2(ca, T.cy, sa, T.cz);
@@ -144,7 +149,8 @@ __device__ __forceinline__ Frame frame_mul(const Frame& a, const Frame& b) {
 }
 // the DH link transform of joint j by itself (dh_apply on the identity, products with 0 / 1 folded)
 __device__ __forceinline__ Frame dh_link(const vgpmp_robot* __restrict__ rb, int j, float st, float ct) {
-    const float ca = rb->cos_alpha[j], sa = rb->sin_alpha[j], d = rb->dh_d[j], a = rb->dh_a[j];
+    const float4 jt = *reinterpret_cast<const float4*>(rb->joint_tab[j]);
+    const float ca = jt.x, sa = jt.y, d = jt.z, a = jt.w;
     Frame o;
     if (rb->craig) {
         o.cx = vg_make3(ct, st * ca, st * sa);
@@ -165,109 +171,165 @@ __device__ __forceinline__ void lik_wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// log p(e | g) of one configuration, evaluated by LPC cooperating lanes (`sub` = lane within the group):
-// every lane walks the DH chain, lane `sub` places and looks up spheres sub, sub + LPC, ... of each frame;
-// per-frame force / moment sums are combined with quad shuffles.  The instruction stream per wave --
-// not memory -- bounds this kernel when few problems are in flight, hence the split.
-// With GRAD, d logp / d g_j is handed to `emit(j, value)` on lane j % LPC.  get_g(j) is called on lane
-// j % LPC only.  Returns the group's total on every lane.
-// With SIG (trainable sigma_obs, LPC == 1 only) the per-sphere variances come from `sig` and every sphere's
-// c^2 / sigma, weighted by sig_w (0 on dead lanes), is summed over the wave and handed to emit_sig(q, total).
+// ---- one sphere query, lean ---------------------------------------------------------------------------
+// The three axis quotients in float32, clamp + truncate, and ONE test for "some quotient is within its error bound
+// of an integer" that sends the query through the reference's float64 expression (all three axes): a few 1e-3 of
+// the queries.  Indices stay bit-identical to utils/sdf_utils.py:62-66.
+struct Vox3 { int ix, iy, iz; };
+__device__ __forceinline__ Vox3 voxel3(vg_float3 p, const SdfFast& fs, const vg_sdf_dev& s, double offx, double offy,
+                                       double offz) {
+    const float qx = ((p.x - fs.chx) - fs.clx) * fs.inv_delta;
+    const float qy = ((p.y - fs.chy) - fs.cly) * fs.inv_delta;
+    const float qz = ((p.z - fs.chz) - fs.clz) * fs.inv_delta;
+    Vox3 o;
+    o.ix = (int)__builtin_amdgcn_fmed3f(qx, 0.f, (float)(s.nx - 1));
+    o.iy = (int)__builtin_amdgcn_fmed3f(qy, 0.f, (float)(s.ny - 1));
+    o.iz = (int)__builtin_amdgcn_fmed3f(qz, 0.f, (float)(s.nz - 1));
+    // margin over the bound 1e-6 (|q| + 1) on the float32 quotient's error (see SdfFast)
+    const float ex = fabsf(qx - rintf(qx)) - fmaf(1.1e-6f, fabsf(qx), 1.1e-6f);
+    const float ey = fabsf(qy - rintf(qy)) - fmaf(1.1e-6f, fabsf(qy), 1.1e-6f);
+    const float ez = fabsf(qz - rintf(qz)) - fmaf(1.1e-6f, fabsf(qz), 1.1e-6f);
+    if (fminf(ex, fminf(ey, ez)) < 0.f) {
+        o.ix = vg_voxel_axis((double)p.x - offx, s.ox, s.delta, s.nx);      // exact reference expression
+        o.iy = vg_voxel_axis((double)p.y - offy, s.oy, s.delta, s.ny);
+        o.iz = vg_voxel_axis((double)p.z - offz, s.oz, s.delta, s.nz);
+    }
+    return o;
+}
+
+// sin and cos of a bounded angle (|x| < ~400: joint limit + DH twist): three-term Cody-Waite reduction by pi/2 and the
+// single-precision minimax polynomials of Cephes sinf / cosf on [-pi/4, pi/4] (~1 ulp); a third of the instructions
+// of the library's sincosf, whose large-argument path is dead weight here.
+__device__ __forceinline__ void vg_sincos(float x, float* sn, float* cs) {
+    const float k = rintf(x * 0.63661977236758134f);
+    float r = fmaf(-k, 1.5703125f, x);
+    r = fmaf(-k, 4.837512969970703125e-4f, r);
+    r = fmaf(-k, 7.54978995489188216e-8f, r);
+    const float z = r * r;
+    const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+    const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z,
+                          fmaf(-0.5f, z, 1.0f));
+    const int n = (int)k;
+    const float a = (n & 1) ? pc : ps, b = (n & 1) ? ps : pc;
+    *sn = (n & 2) ? -a : a;
+    *cs = ((n + 1) & 2) ? -b : b;
+}
+
+// log p(e | g) of one configuration on one lane.  The spheres are walked in table order in batches of U: for a
+// batch the chain is advanced as far as its spheres need (the sphere index, hence the frame, is uniform over the
+// wave: scalar control flow), all U positions and voxel addresses are formed and all U gathers are in flight together
+// -- one memory round trip per U spheres instead of one per frame --, then the hinge and the per-frame force / moment
+// sums.  With GRAD, d logp / d g_j is handed to `emit(j, value)`.  Returns log p.
+// With SIG (trainable sigma_obs) the per-sphere variances come from `sig` and every sphere's c^2 / sigma, weighted by
+// sig_w (0 on dead lanes), is summed over the wave and handed to emit_sig(q, total).
+// With FAR the brick summary is read first and spheres in free space skip the table.
 struct NoSig { __device__ __forceinline__ void operator()(int, float) const {} };
-template <bool GRAD, int LPC, bool SIG = false, bool FAR = false, typename GetG, typename Emit, typename EmitSig = NoSig>
+template <bool GRAD, int U, bool SIG = false, bool FAR = false, typename LoadRaw, typename ToAngle, typename Emit,
+          typename EmitSig = NoSig>
 __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ rb, const vg_sdf_dev& sdf,
-                                               const LikScratch sc, int sub, GetG get_g, Emit emit, int dbg = 0,
+                                               const LikScratch sc, LoadRaw load_raw, ToAngle to_angle, Emit emit,
                                                const float* __restrict__ sig = nullptr, float sig_w = 0.f,
                                                EmitSig emit_sig = NoSig()) {
-    static_assert(!SIG || LPC == 1, "per-sphere sums are wave sums of one-lane configurations");
-    const float* __restrict__ sigma = SIG ? sig : rb->sigma_obs;
+    static_assert(VGPMP_MAX_SPHERES % U == 0, "a batch of sphere constants never leaves the table");
     const int D = rb->dof, P = rb->num_spheres;
+    // every joint's input requested before the first is used (one memory round trip, not one per joint)
+    float raw[VGPMP_MAX_DOF];
+#pragma unroll
+    for (int j = 0; j < VGPMP_MAX_DOF; ++j) raw[j] = load_raw(min(j, D - 1));
     const float eps = rb->epsilon;
     const double offx = rb->scene_offset[0], offy = rb->scene_offset[1], offz = rb->scene_offset[2];
     const SdfFast fs = make_fast(sdf, offx, offy, offz);
-    // joint sines / cosines, split over the group
-#pragma nounroll
-    for (int j = sub; j < D; j += LPC) {
-        float st, ct;
-        sincosf(get_g(j) + rb->twist[j], &st, &ct);
-        sc.at(j) = st; sc.at(D + j) = ct;
+#pragma unroll
+    for (int j = 0; j < VGPMP_MAX_DOF; ++j) {
+        if (j < D) {                                     // uniform
+            float st, ct;
+            vg_sincos(to_angle(j, raw[j]) + rb->joint_tab[j][4], &st, &ct);
+            sc.at(j) = st; sc.at(D + j) = ct;
+        }
     }
-    if (LPC > 1) lik_wave_sync();
     Frame T = base_frame(rb);
+    int cur = 0;                                         // frame T stands at (issue side)
+    int pcur = 0;                                        // frame of the running sums (consumer side)
+    vg_float3 F = vg_make3(0.f, 0.f, 0.f), Mo = vg_make3(0.f, 0.f, 0.f);
     vg_float3 Ft = vg_make3(0.f, 0.f, 0.f), Mt = vg_make3(0.f, 0.f, 0.f);
     float acc = 0.f;
-    int p = 0;
+    auto flush = [&]() {                                 // sums of frame pcur are complete
+        const int o = 2 * D + 6 * pcur;
+        sc.at(o) = F.x; sc.at(o + 1) = F.y; sc.at(o + 2) = F.z;
+        sc.at(o + 3) = Mo.x; sc.at(o + 4) = Mo.y; sc.at(o + 5) = Mo.z;
+        Ft = vg_make3(Ft.x + F.x, Ft.y + F.y, Ft.z + F.z);
+        Mt = vg_make3(Mt.x + Mo.x, Mt.y + Mo.y, Mt.z + Mo.z);
+        F = vg_make3(0.f, 0.f, 0.f); Mo = vg_make3(0.f, 0.f, 0.f);
+        ++pcur;
+    };
 #pragma nounroll
-    for (int i = 0; i <= D; ++i) {
-        if (i > 0) dh_apply(rb, i - 1, sc.at(i - 1), sc.at(D + i - 1), T);
-        vg_float3 F = vg_make3(0.f, 0.f, 0.f), Mo = vg_make3(0.f, 0.f, 0.f);
-        int pe = p;
-        while (pe < P && rb->sphere_frame[pe] == i) ++pe;        // spheres [p, pe) ride on frame i
-        constexpr int U = LPC == 1 ? 4 : 1;                      // spheres per lane per pass
-#pragma nounroll
-        for (int q0 = p + sub * U; q0 < pe; q0 += LPC * U) {
-            float4 v[U];
-            vg_float3 pos[U];
+    for (int q0 = 0; q0 < P; q0 += U) {
+        float4 v[U];
+        vg_float3 pos[U];
+        uint32_t at[U];
+        // the batch's constants: contiguous rows of the robot table, uniform addresses (wide scalar loads, one wait)
+        float4 ca[U];
+        float2 cb[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {        // loads issued unconditionally (tail repeats the last sphere)
-                const int q = min(q0 + u, pe - 1);
-                pos[u] = axpy(rb->sphere_off[q][0], T.cx, axpy(rb->sphere_off[q][1], T.cy,
-                              axpy(rb->sphere_off[q][2], T.cz, T.t)));
-                const int ix = voxel_axis(pos[u].x, fs.chx, fs.clx, fs.inv_delta, sdf.nx, offx, sdf.ox, sdf.delta);
-                const int iy = voxel_axis(pos[u].y, fs.chy, fs.cly, fs.inv_delta, sdf.ny, offy, sdf.oy, sdf.delta);
-                const int iz = voxel_axis(pos[u].z, fs.chz, fs.clz, fs.inv_delta, sdf.nz, offz, sdf.oz, sdf.delta);
-#ifdef VGPMP_BISECT
-                if (dbg == 2) { v[u] = make_float4(0.01f * ix, 0.1f, 0.2f * iy, 0.3f * iz); continue; }
-#endif
-                if (FAR) {
-                    // free-space summary: the hinge is exactly 0 on every voxel of this brick -> no table access
-                    const float bm = sdf.brick_min[vg_brick_of(sdf, ix, iy, iz)];
-                    v[u] = make_float4(bm, 0.f, 0.f, 0.f);
-                    if (eps - (bm - rb->radius[q]) > 0.f) v[u] = sdf.table[vg_table_offset(sdf, ix, iy, iz)];
-                } else {
-                    v[u] = sdf.table[vg_table_offset(sdf, ix, iy, iz)];
+        for (int u = 0; u < U; ++u) {
+            ca[u] = *reinterpret_cast<const float4*>(rb->sphere_a[q0 + u]);      // {offset, frame}; rows >= P: frame = D
+            cb[u] = *reinterpret_cast<const float2*>(rb->sphere_b[q0 + u]);      // {radius, 1 / sigma}
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + u;
+            if (q < P) {                                 // uniform
+                const int fr = __builtin_bit_cast(int, ca[u].w);
+                while (cur < fr) {
+                    dh_apply(rb, cur, sc.at(cur), sc.at(D + cur), T);
+                    ++cur;
                 }
+                pos[u] = axpy(ca[u].x, T.cx, axpy(ca[u].y, T.cy, axpy(ca[u].z, T.cz, T.t)));
+                const Vox3 ix = voxel3(pos[u], fs, sdf, offx, offy, offz);
+                at[u] = (uint32_t)vg_table_offset(sdf, ix.ix, ix.iy, ix.iz);
+                if (FAR) v[u].x = sdf.brick_min[vg_brick_of(sdf, ix.ix, ix.iy, ix.iz)];
+                else v[u] = sdf.table[at[u]];
+            } else {
+                v[u] = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);       // hinge exactly 0
+                pos[u] = vg_make3(0.f, 0.f, 0.f);
+                at[u] = 0u;
             }
+        }
+        if (FAR) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int q = min(q0 + u, pe - 1);
-                const float wgt = (q0 + u < pe) ? 1.f : 0.f;
-                float c = fmaxf(eps - (v[u].x - rb->radius[q]), 0.f) * wgt;     // likelihood.py:131-143
-                float cs = c / sigma[q];
-                acc = fmaf(cs, c, acc);                                          // likelihood.py:99
-                if (SIG) {      // q is uniform over the wave here (LPC == 1): one total per sphere
-                    const float t = vg_wave_sum(cs * c * sig_w);
-                    if (q0 + u < pe) emit_sig(q, t);
-                }
-                if (GRAD) {
-                    vg_float3 gp = vg_make3(cs * v[u].y, cs * v[u].z, cs * v[u].w);   // d logp / d pos
-                    F = vg_make3(F.x + gp.x, F.y + gp.y, F.z + gp.z);
-                    vg_float3 m = vg_cross(pos[u], gp);
-                    Mo = vg_make3(Mo.x + m.x, Mo.y + m.y, Mo.z + m.z);
+                if (q0 + u < P) {
+                    // free space: the hinge is exactly 0 on every voxel of the brick -> no table access
+                    const float bm = v[u].x;
+                    v[u] = make_float4(bm, 0.f, 0.f, 0.f);
+                    if (eps - (bm - cb[u].x) > 0.f) v[u] = sdf.table[at[u]];
                 }
             }
         }
-        p = pe;
-        if (GRAD) {
-            F = vg_make3(quad_sum<LPC>(F.x), quad_sum<LPC>(F.y), quad_sum<LPC>(F.z));
-            Mo = vg_make3(quad_sum<LPC>(Mo.x), quad_sum<LPC>(Mo.y), quad_sum<LPC>(Mo.z));
-            if (sub == 0) {
-                const int o = 2 * D + 6 * i;
-                sc.at(o) = F.x; sc.at(o + 1) = F.y; sc.at(o + 2) = F.z;
-                sc.at(o + 3) = Mo.x; sc.at(o + 4) = Mo.y; sc.at(o + 5) = Mo.z;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + u;
+            if (q < P) {                                 // uniform
+                if (GRAD) {
+                    const int fr = __builtin_bit_cast(int, ca[u].w);
+                    while (pcur < fr) flush();
+                }
+                const float c = fmaxf(eps - (v[u].x - cb[u].x), 0.f);           // likelihood.py:131-143
+                const float cs = SIG ? c / sig[q] : c * cb[u].y;
+                acc = fmaf(cs, c, acc);                                          // likelihood.py:99
+                if (SIG) emit_sig(q, vg_wave_sum(cs * c * sig_w));               // one total per sphere
+                if (GRAD) {
+                    const vg_float3 gp = vg_make3(cs * v[u].y, cs * v[u].z, cs * v[u].w);   // d logp / d pos
+                    F = vg_make3(F.x + gp.x, F.y + gp.y, F.z + gp.z);
+                    Mo = vg_cross_acc(Mo, pos[u], gp);
+                }
             }
-            Ft = vg_make3(Ft.x + F.x, Ft.y + F.y, Ft.z + F.z);
-            Mt = vg_make3(Mt.x + Mo.x, Mt.y + Mo.y, Mt.z + Mo.z);
         }
     }
-    acc = quad_sum<LPC>(acc);
-#ifdef VGPMP_BISECT
-    if (dbg == 3) return -0.5f * acc;
-#endif
     if (GRAD) {
+        while (pcur <= D) flush();
         // second sweep over the chain (sin/cos kept): joint i turns about z of frame i (Craig) or frame
         // i-1 (classic) and moves every sphere on frames >= i, i.e. the totals minus the prefix < i
-        if (LPC > 1) lik_wave_sync();
         const bool craig = rb->craig != 0;
         T = base_frame(rb);
         vg_float3 Fs = Ft, Ms = Mt;
@@ -280,14 +342,133 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
             dh_apply(rb, i - 1, sc.at(i - 1), sc.at(D + i - 1), T);
             if (craig) { z = T.cz; org = T.t; }
             const vg_float3 oxF = vg_cross(org, Fs);
-            if ((i - 1) % LPC == sub) emit(i - 1, vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)));
+            emit(i - 1, vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)));
         }
+    }
+    return -0.5f * acc;
+}
+
+// The same walk with the per-frame force / moment sums in REGISTERS, as six 16-wide vectors indexed by the (wave-uniform)
+// frame number -- indirect register addressing -- and only sin / cos / d g / d f of the joints in LDS: 3 D instead of
+// 9 D + 6 words per lane (132 at 14 joints, which held the one-lane form at one wave per SIMD).  Up to 15 joints.
+typedef float vg_f32x16 __attribute__((ext_vector_type(16)));
+template <int U, bool SIG, bool FAR, typename LoadRaw, typename ToAngle, typename Emit, typename EmitSig = NoSig>
+__device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restrict__ rb, const vg_sdf_dev& sdf,
+                                                    const LikScratch sc, LoadRaw load_raw, ToAngle to_angle, Emit emit,
+                                                    const float* __restrict__ sig = nullptr, float sig_w = 0.f,
+                                                    EmitSig emit_sig = NoSig()) {
+    static_assert(VGPMP_MAX_SPHERES % U == 0, "a batch of sphere constants never leaves the table");
+    const int D = rb->dof, P = rb->num_spheres;          // D <= 15: frames 0 .. 15
+    float raw[VGPMP_MAX_DOF];
+#pragma unroll
+    for (int j = 0; j < VGPMP_MAX_DOF; ++j) raw[j] = load_raw(min(j, D - 1));
+    const float eps = rb->epsilon;
+    const double offx = rb->scene_offset[0], offy = rb->scene_offset[1], offz = rb->scene_offset[2];
+    const SdfFast fs = make_fast(sdf, offx, offy, offz);
+    // sin / cos / d g / d f of every joint: LDS slots [0, D), [D, 2D), [2D, 3D) of this lane
+#pragma unroll
+    for (int j = 0; j < VGPMP_MAX_DOF; ++j) {
+        if (j < D) {                                     // uniform
+            float st, ct, d;
+            vg_sincos(to_angle(j, raw[j], d) + rb->joint_tab[j][4], &st, &ct);
+            sc.at(j) = st; sc.at(D + j) = ct; sc.at(2 * D + j) = d;
+        }
+    }
+    vg_f32x16 fx = 0.f, fy = 0.f, fz = 0.f, mx = 0.f, my = 0.f, mz = 0.f;      // per-frame sums
+    Frame T = base_frame(rb);
+    int cur = 0;                                         // frame T stands at (issue side)
+    int pcur = 0;                                        // frame of the running sums (consumer side)
+    vg_float3 F = vg_make3(0.f, 0.f, 0.f), Mo = vg_make3(0.f, 0.f, 0.f);
+    vg_float3 Ft = vg_make3(0.f, 0.f, 0.f), Mt = vg_make3(0.f, 0.f, 0.f);
+    float acc = 0.f;
+    auto flush = [&]() {                                 // sums of frame pcur are complete
+        fx[pcur] = F.x; fy[pcur] = F.y; fz[pcur] = F.z; mx[pcur] = Mo.x; my[pcur] = Mo.y; mz[pcur] = Mo.z;
+        Ft = vg_make3(Ft.x + F.x, Ft.y + F.y, Ft.z + F.z);
+        Mt = vg_make3(Mt.x + Mo.x, Mt.y + Mo.y, Mt.z + Mo.z);
+        F = vg_make3(0.f, 0.f, 0.f); Mo = vg_make3(0.f, 0.f, 0.f);
+        ++pcur;
+    };
+#pragma nounroll
+    for (int q0 = 0; q0 < P; q0 += U) {
+        float4 v[U];
+        vg_float3 pos[U];
+        uint32_t at[U];
+        float4 ca[U];
+        float2 cb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ca[u] = *reinterpret_cast<const float4*>(rb->sphere_a[q0 + u]);      // {offset, frame}; rows >= P: frame = D
+            cb[u] = *reinterpret_cast<const float2*>(rb->sphere_b[q0 + u]);      // {radius, 1 / sigma}
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + u;
+            if (q < P) {                                 // uniform
+                const int fr = __builtin_bit_cast(int, ca[u].w);
+                while (cur < fr) {
+                    dh_apply(rb, cur, sc.at(cur), sc.at(D + cur), T);
+                    ++cur;
+                }
+                pos[u] = axpy(ca[u].x, T.cx, axpy(ca[u].y, T.cy, axpy(ca[u].z, T.cz, T.t)));
+                const Vox3 ix = voxel3(pos[u], fs, sdf, offx, offy, offz);
+                at[u] = (uint32_t)vg_table_offset(sdf, ix.ix, ix.iy, ix.iz);
+                if (FAR) v[u].x = sdf.brick_min[vg_brick_of(sdf, ix.ix, ix.iy, ix.iz)];
+                else v[u] = sdf.table[at[u]];
+            } else {
+                v[u] = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);       // hinge exactly 0
+                pos[u] = vg_make3(0.f, 0.f, 0.f);
+                at[u] = 0u;
+            }
+        }
+        if (FAR) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (q0 + u < P) {
+                    // free space: the hinge is exactly 0 on every voxel of the brick -> no table access
+                    const float bm = v[u].x;
+                    v[u] = make_float4(bm, 0.f, 0.f, 0.f);
+                    if (eps - (bm - cb[u].x) > 0.f) v[u] = sdf.table[at[u]];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + u;
+            if (q < P) {                                 // uniform
+                const int fr = __builtin_bit_cast(int, ca[u].w);
+                while (pcur < fr) flush();
+                const float c = fmaxf(eps - (v[u].x - cb[u].x), 0.f);           // likelihood.py:131-143
+                const float cs = SIG ? c / sig[q] : c * cb[u].y;
+                acc = fmaf(cs, c, acc);                                          // likelihood.py:99
+                if (SIG) emit_sig(q, vg_wave_sum(cs * c * sig_w));               // one total per sphere
+                const vg_float3 gp = vg_make3(cs * v[u].y, cs * v[u].z, cs * v[u].w);   // d logp / d pos
+                F = vg_make3(F.x + gp.x, F.y + gp.y, F.z + gp.z);
+                Mo = vg_cross_acc(Mo, pos[u], gp);
+            }
+        }
+    }
+    while (pcur <= D) flush();
+    // second sweep over the chain: joint i turns about z of frame i (Craig) or frame i-1 (classic) and moves every
+    // sphere on frames >= i, i.e. the totals minus the prefix < i
+    const bool craig = rb->craig != 0;
+    T = base_frame(rb);
+    vg_float3 Fs = Ft, Ms = Mt;
+#pragma nounroll
+    for (int i = 1; i <= D; ++i) {
+        Fs = vg_make3(Fs.x - fx[i - 1], Fs.y - fy[i - 1], Fs.z - fz[i - 1]);
+        Ms = vg_make3(Ms.x - mx[i - 1], Ms.y - my[i - 1], Ms.z - mz[i - 1]);
+        vg_float3 z = T.cz, org = T.t;
+        dh_apply(rb, i - 1, sc.at(i - 1), sc.at(D + i - 1), T);
+        if (craig) { z = T.cz; org = T.t; }
+        const vg_float3 oxF = vg_cross(org, Fs);
+        emit(i - 1, vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)) * sc.at(2 * D + i - 1));
     }
     return -0.5f * acc;
 }
 
 constexpr int kLikBlock = 128;
 constexpr int kLikBatchBlock = 64;
+constexpr int kLikBatchU = 8;           // sphere gathers in flight per lane in the batch form
 
 // ---- stand-alone log_prob: g [n, dof] row major ------------------------------------------------
 template <bool GRAD>
@@ -302,14 +483,15 @@ __global__ __launch_bounds__(kLikBlock) void log_prob_kernel(const vgpmp_robot* 
     const LikScratch sc{lik_lds + threadIdx.x, kLikBlock};
     const float* g = gq + i * D;
     float* dg = dlogp + i * D;
-    logp[i] = loglik_config<GRAD, 1>(rb, sdf, sc, 0, [&](int j) { return g[j]; }, [&](int j, float v) { dg[j] = v; });
+    logp[i] = loglik_config<GRAD, 8>(rb, sdf, sc, [&](int j) { return g[j]; }, [&](int, float x) { return x; },
+                                     [&](int j, float v) { dg[j] = v; });
 }
 
 // ---- ELBO path: f [P,S,L,N] -> logp [P,S,N], G = dloss/df [P,S,L,N], block partial sums ----------
 // LPC lanes per (sample, time) configuration; BLK / LPC configurations per workgroup.  Large batches run one-wave
 // workgroups (kLikBatchBlock): 188 instead of 204 us per launch at 64 problems (finer tail).
-template <int LPC, int BLK, bool SIG = false, bool FAR = false>
-__global__ __launch_bounds__(BLK) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
+template <int LPC, int BLK, bool SIG = false, bool FAR = false, bool REGS = false>
+__global__ __launch_bounds__(BLK, REGS ? 2 : 1) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
                                                                   const float* __restrict__ f, int S, int L, int N,
                                                                   float scale, float* __restrict__ G,
                                                                   float* __restrict__ logp,
@@ -317,6 +499,7 @@ __global__ __launch_bounds__(BLK) void loglik_paths_kernel(const vgpmp_robot* __
                                                                   const float* __restrict__ alpha_eff = nullptr,
                                                                   const float* __restrict__ sigma_eff = nullptr,
                                                                   float* __restrict__ sig_partial = nullptr) {
+    static_assert(LPC == 1, "one lane per configuration");
     static_assert(!SIG || BLK == VG_WAVE, "per-sphere sums of a workgroup are one wave's sums");
     extern __shared__ float lik_lds[];
     __shared__ float red[BLK / VG_WAVE];
@@ -339,17 +522,31 @@ __global__ __launch_bounds__(BLK) void loglik_paths_kernel(const vgpmp_robot* __
         float* dgdf = lik_lds + (size_t)lik_scratch_slots(L) * CPB + cl;   // [L][CPB]
         const float scl = SIG ? -alpha_eff[pb] : scale;
         float* sp = SIG ? sig_partial + ((size_t)pb * gridDim.x + blockIdx.x) * VGPMP_MAX_SPHERES : nullptr;
-        lp = loglik_config<true, LPC, SIG, FAR>(
-            rb, sdf, sc, sub,
-            [&](int j) {
-                const float sg = 1.0f / (1.0f + __expf(-f[base + (size_t)j * N]));       // likelihood.py:49-52
-                const float span = rb->high[j] - rb->low[j];
-                dgdf[j * CPB] = span * sg * (1.0f - sg);
-                return fmaf(span, sg, rb->low[j]);
-            },
-            [&](int j, float v) { if (live) G[base + (size_t)j * N] = scl * v * dgdf[j * CPB]; }, dbg,
-            SIG ? sigma_eff + (size_t)pb * VGPMP_MAX_SPHERES : nullptr, live ? 1.f : 0.f,
-            [&](int q, float t) { if (threadIdx.x == 0) sp[q] = t; });
+        auto raw_f = [&](int j) { return f[base + (size_t)j * N]; };
+        const float* sigp = SIG ? sigma_eff + (size_t)pb * VGPMP_MAX_SPHERES : nullptr;
+        auto put_sig = [&](int q, float t) { if (threadIdx.x == 0) sp[q] = t; };
+        if (REGS) {
+            lp = loglik_config_regs<kLikBatchU, SIG, FAR>(
+                rb, sdf, sc, raw_f,
+                [&](int j, float x, float& d) {
+                    const float sg = 1.0f / (1.0f + __expf(-x));                        // likelihood.py:49-52
+                    const float span = rb->joint_tab[j][7];
+                    d = span * sg * (1.0f - sg);
+                    return fmaf(span, sg, rb->joint_tab[j][5]);
+                },
+                [&](int j, float v) { if (live) G[base + (size_t)j * N] = scl * v; }, sigp, live ? 1.f : 0.f, put_sig);
+        } else {
+            lp = loglik_config<true, kLikBatchU, SIG, FAR>(
+                rb, sdf, sc, raw_f,
+                [&](int j, float x) {
+                    const float sg = 1.0f / (1.0f + __expf(-x));                        // likelihood.py:49-52
+                    const float span = rb->joint_tab[j][7];
+                    dgdf[j * CPB] = span * sg * (1.0f - sg);
+                    return fmaf(span, sg, rb->joint_tab[j][5]);
+                },
+                [&](int j, float v) { if (live) G[base + (size_t)j * N] = scl * (v * dgdf[j * CPB]); }, sigp, live ? 1.f : 0.f,
+                put_sig);
+        }
         if (live && sub == 0) logp[((size_t)pb * S + s) * N + n] = lp;
     }
     float w = vg_wave_sum(live && sub == 0 ? lp : 0.f);
@@ -418,7 +615,10 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
     vg_dma_wait();
     __syncthreads();
     if (SIG) {
-        if (tid < VGPMP_MAX_SPHERES) const_cast<vgpmp_robot*>(rb)->sigma_obs[tid] = sig_own;
+        if (tid < VGPMP_MAX_SPHERES) {
+            const_cast<vgpmp_robot*>(rb)->sigma_obs[tid] = sig_own;
+            const_cast<vgpmp_robot*>(rb)->inv_sigma_obs[tid] = 1.0f / sig_own;
+        }
         __syncthreads();
     }
     VG_T(blockIdx.x == 0 && pb == 0, 402);
@@ -440,7 +640,7 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
             const float span = rb->high[j] - rb->low[j];
             dgdf[j * CPB] = span * sg * (1.0f - sg);
             float st, ct;
-            sincosf(fmaf(span, sg, rb->low[j]) + rb->twist[j], &st, &ct);
+            vg_sincos(fmaf(span, sg, rb->low[j]) + rb->twist[j], &st, &ct);
             gs(j) = st; gs(D + j) = ct;
             if (k == 0) { st0 = st; ct0 = ct; dg0 = span * sg * (1.0f - sg); }
         }
@@ -522,10 +722,8 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
             const vg_float3 cx = vg_make3(gs(o), gs(o + 1), gs(o + 2)), cy = vg_make3(gs(o + 3), gs(o + 4), gs(o + 5));
             const vg_float3 cz = vg_make3(gs(o + 6), gs(o + 7), gs(o + 8)), t = vg_make3(gs(o + 9), gs(o + 10), gs(o + 11));
             pos[u] = axpy(rb->sphere_off[q][0], cx, axpy(rb->sphere_off[q][1], cy, axpy(rb->sphere_off[q][2], cz, t)));
-            const int ix = voxel_axis(pos[u].x, fs.chx, fs.clx, fs.inv_delta, sdf.nx, offx, sdf.ox, sdf.delta);
-            const int iy = voxel_axis(pos[u].y, fs.chy, fs.cly, fs.inv_delta, sdf.ny, offy, sdf.oy, sdf.delta);
-            const int iz = voxel_axis(pos[u].z, fs.chz, fs.clz, fs.inv_delta, sdf.nz, offz, sdf.oz, sdf.delta);
-            v[u] = sdf.table[vg_table_offset(sdf, ix, iy, iz)];
+            const Vox3 vx = voxel3(pos[u], fs, sdf, offx, offy, offz);
+            v[u] = sdf.table[vg_table_offset(sdf, vx.ix, vx.iy, vx.iz)];
         }
 #pragma unroll
         for (int u = 0; u < kWideU; ++u) {
@@ -533,7 +731,7 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
             const int q = min(qq, P - 1);
             const float wgt = qq < P ? 1.f : 0.f;
             const float c = fmaxf(eps - (v[u].x - rb->radius[q]), 0.f) * wgt;       // likelihood.py:131-143
-            const float cs = c / rb->sigma_obs[q];
+            const float cs = c * rb->inv_sigma_obs[q];
             acc = fmaf(cs, c, acc);                                                  // likelihood.py:99
             if (SIG && qq < P) sgl[cl * VGPMP_MAX_SPHERES + q] = live ? cs * c : 0.f;
             const vg_float3 gp = vg_make3(cs * v[u].y, cs * v[u].z, cs * v[u].w);   // d logp / d pos
@@ -543,8 +741,7 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
                 F = vg_make3(0.f, 0.f, 0.f); Mo = vg_make3(0.f, 0.f, 0.f);
             }
             F = vg_make3(F.x + gp.x, F.y + gp.y, F.z + gp.z);
-            const vg_float3 m = vg_cross(pos[u], gp);
-            Mo = vg_make3(Mo.x + m.x, Mo.y + m.y, Mo.z + m.z);
+            Mo = vg_cross_acc(Mo, pos[u], gp);
         }
     }
     flush();
@@ -768,22 +965,23 @@ int vg_launch_log_prob_impl(const vgpmp_robot* rb, int dof, const vgpmp_sdf* sdf
 int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const float* f, int P, int S, int L, int N,
                            float scale, float* G, float* logp, float* lik_partial, int* nblk_out, hipStream_t st,
                            hipEvent_t k0, hipEvent_t k1, const float* alpha_eff, const float* sigma_eff,
-                           float* sig_partial) {
-    const int lpc = lik_lpc(P, S, N);
-    const int blk = lpc > 1 ? kLikBlock : kLikBatchBlock;
-    const int nblk = (S * N * lpc + blk - 1) / blk;
-    if (nblk_out) *nblk_out = nblk;
-    if (P == 0 || nblk == 0) return 0;
+                           float* sig_partial, int form) {
     const bool sig = alpha_eff != nullptr;      // trainable likelihood constants: per-problem alpha / sigma_obs, per-sphere sums
     if (sig && (!sigma_eff || !sig_partial)) return VGPMP_E_ARG;
-    const size_t lds = lpc > 1 ? wide_lds_bytes(L, lpc) + (sig ? (size_t)(kLikBlock / lpc) * VGPMP_MAX_SPHERES * sizeof(float) : 0)
-                               : lik_lds_bytes(L, true) * kLikBatchBlock / kLikBlock;
-    // the brick summary (when the caller provides one) lets the batch form leave out the table access of spheres in free space
-    const bool far = lpc == 1 && sdf->layout == VGPMP_SDF_BRICK4 && sdf->brick_min != nullptr;
+    int lpc = lik_lpc(P, S, N);
+    // the brick summary (when the caller provides one) lets the batch forms leave out the table access of spheres in free space
+    const bool far = sdf->layout == VGPMP_SDF_BRICK4 && sdf->brick_min != nullptr;
+    if (form != 0) lpc = 1;                            // measurement: the batch form whatever the batch size
     int dbg = 0;
 #ifdef VGPMP_BISECT
     dbg = lik_bisect_mode();
 #endif
+    const int blk = lpc > 1 ? kLikBlock : kLikBatchBlock;
+    const int nblk = (S * N * lpc + blk - 1) / blk;
+    if (nblk_out) *nblk_out = nblk;
+    if (P == 0 || nblk == 0) return 0;
+    size_t lds = lpc > 1 ? wide_lds_bytes(L, lpc) + (sig ? (size_t)(kLikBlock / lpc) * VGPMP_MAX_SPHERES * sizeof(float) : 0)
+                               : lik_lds_bytes(L, true) * kLikBatchBlock / kLikBlock;
     // k0 / k1 (profiler): events stamped with the kernel's own start and end on the device
     if (lpc == 8) {
         auto go = [&](auto kern) {
@@ -802,6 +1000,12 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
                               lik_partial, dbg, alpha_eff, sigma_eff, sig_partial);
         return (int)hipGetLastError();
     };
+    const bool regs = L <= 15 && form != 2;              // per-frame sums in registers (form 2, measurement: in LDS)
+    if (regs) {
+        lds = (size_t)3 * L * kLikBatchBlock * sizeof(float);
+        if (sig) return far ? go(loglik_paths_kernel<1, kLikBatchBlock, true, true, true>) : go(loglik_paths_kernel<1, kLikBatchBlock, true, false, true>);
+        return far ? go(loglik_paths_kernel<1, kLikBatchBlock, false, true, true>) : go(loglik_paths_kernel<1, kLikBatchBlock, false, false, true>);
+    }
     if (sig) return far ? go(loglik_paths_kernel<1, kLikBatchBlock, true, true>) : go(loglik_paths_kernel<1, kLikBatchBlock, true, false>);
     return far ? go(loglik_paths_kernel<1, kLikBatchBlock, false, true>) : go(loglik_paths_kernel<1, kLikBatchBlock, false, false>);
 }

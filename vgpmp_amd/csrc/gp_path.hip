@@ -3056,7 +3056,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         rc = vg_launch_loglik_paths(rb, sdf, out->f, P, S, L, N, (float)(-lik_scale), ws->G, out->logp, ws->lik_partial,
                                     &nblk, st, ev ? ev[VG_NUM_STAGES + 1] : nullptr, ev ? ev[VG_NUM_STAGES + 2] : nullptr,
                                     lk ? lsc.alpha_eff : nullptr, lk ? lsc.sigma_eff : nullptr,
-                                    lk ? lsc.sig_partial : nullptr);
+                                    lk ? lsc.sig_partial : nullptr, (what & VGPMP_LIK_LDS_STATE) ? 2 : (what & VGPMP_LIK_LANES) ? 1 : 0);
         if (rc) return rc;
         fa.nblk = nblk;
         mark();

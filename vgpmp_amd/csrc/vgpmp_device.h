@@ -17,10 +17,17 @@ struct vg_float3 {
 };
 
 __device__ __forceinline__ vg_float3 vg_make3(float x, float y, float z) { return vg_float3{x, y, z}; }
+// explicit fused forms: the rounding of these does not depend on what the optimiser decides to contract in a given
+// instantiation (results must be bit-identical between kernel variants that differ only in where a voxel is fetched from)
 __device__ __forceinline__ vg_float3 vg_cross(vg_float3 a, vg_float3 b) {
-    return vg_float3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+    return vg_float3{fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))};
 }
-__device__ __forceinline__ float vg_dot(vg_float3 a, vg_float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float vg_dot(vg_float3 a, vg_float3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+// acc + a x b
+__device__ __forceinline__ vg_float3 vg_cross_acc(vg_float3 acc, vg_float3 a, vg_float3 b) {
+    return vg_float3{fmaf(a.y, b.z, fmaf(-a.z, b.y, acc.x)), fmaf(a.z, b.x, fmaf(-a.x, b.z, acc.y)),
+                     fmaf(a.x, b.y, fmaf(-a.y, b.x, acc.z))};
+}
 
 __device__ __forceinline__ float vg_wave_sum(float v) {
 #pragma unroll
@@ -276,7 +283,8 @@ int vg_trace_take_lik(unsigned long long* host, int cap);
 int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const float* f, int P, int S, int L, int N,
                            float scale, float* G, float* logp, float* lik_partial, int* nblk_out, hipStream_t st,
                            hipEvent_t kernel_start = nullptr, hipEvent_t kernel_end = nullptr,
-                           const float* alpha_eff = nullptr, const float* sigma_eff = nullptr, float* sig_partial = nullptr);
+                           const float* alpha_eff = nullptr, const float* sigma_eff = nullptr, float* sig_partial = nullptr,
+                           int form = 0);      // 0: by batch size; 1: batch form; 2: batch form with all per-frame state in LDS
 int vg_loglik_blocks_per_problem(int S, int N);
 int vg_launch_kernel_derivative(int kind, int order, const double* x, int n, const double* y, int m, double ell, double var,
                                 double* out, hipStream_t st);
