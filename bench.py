@@ -51,6 +51,25 @@ def build_problem(rank: int, args):
                                       alpha=pp["alpha"], learning_rate=pp["learning_rate"], seed=1234,
                                       problem_base=rank * args.problems)
         return ps, spec, grid, scene, planner
+    if args.shard == "samples":
+        # BASELINE config 4: UR10 6-DoF, industrial, ONE problem whose S Monte-Carlo samples are split over the ranks;
+        # one in-place all-reduce of the contiguous [gradient | lik | kl] buffer per step (vgpmp_amd/sharding.py)
+        from vgpmp_amd import sharding
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        ps = robots.load_problemset("ur10", "industrial")
+        pp = ps.planner_params
+        spec = robots.load_robot("ur10", *ps.robot_pos_and_orn)
+        grid = scenes.scene_sdf("industrial", delta=0.0125, padding=20) if args.scene == "industrial" else \
+            scenes.synthetic_boxes_sdf(n=args.grid, delta=1.6 / args.grid, origin=(-0.8, -0.8, -0.2), seed=0)
+        scene = engine.DeviceScene(spec, grid, ps.object_positions[0], sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"],
+                                   layout=args.layout, free_space_summary=SUMMARY[args.summary])
+        s_loc, s_off = sharding.shard_samples(args.samples, world, rank)
+        planner = engine.PlannerBatch(scene, np.array([ps.queries[0]]), num_samples=s_loc, samples_total=args.samples,
+                                      sample_offset=s_off, kl_scale=1.0 if rank == 0 else 0.0,
+                                      num_inducing=int(pp["num_inducing"]), num_data=int(pp["time_spacing_X"]), num_bases=1024,
+                                      lengthscales=pp["lengthscales"], variance=pp["variance"], alpha=pp["alpha"],
+                                      learning_rate=pp["learning_rate"], seed=1234)
+        return ps, spec, grid, scene, planner
     spec = robots.load_robot("franka", *ps.robot_pos_and_orn)
     if args.scene == "industrial":
         # the reference's industrial scene: grid generated on the device from its collision mesh (vgpmp_mesh_sdf),
@@ -102,6 +121,75 @@ def cpu_baseline(ps, spec, grid, args, budget_s: float = 12.0):
                       f"by the float64 NumPy oracle in {el:.1f} s; host has {os.cpu_count()} logical cores"}
 
 
+def run_sample_sharded(args, world, rank, dist, backend, ps, spec, scene, planner):
+    """BASELINE config 4: one problem, the sample axis split over the ranks; a step = local forward + reverse, ONE in-place
+    all-reduce of the contiguous [gradient | lik | kl] buffer, the replicated Adam update.  Strong scaling in S."""
+    from vgpmp_amd import sharding
+    comm = sharding.CapiComm(world, rank) if (args.collective == "capi" and (world == 1 or backend == "nccl")) else None
+    sp = sharding.SampleShardedPlanner(planner, comm=comm)
+    if world == 1 and comm is None:
+        sp._allreduce = lambda: None                         # nothing to exchange on one rank
+    sp.run_steps(args.warmup)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    sp.run_steps(args.steps)
+    barrier()
+    first = time.perf_counter() - t0
+    reps = max(1, int(np.ceil(args.min_seconds / max(first, 1e-6)))) if args.min_seconds > 0 else 1
+    if dist is not None:
+        r = torch.tensor([reps], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.broadcast(r, 0)
+        reps = int(r[0])
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sp.run_steps(args.steps)
+    barrier()
+    elapsed = (time.perf_counter() - t0) / reps
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    assert args.allow_nan or torch.isfinite(planner.q_mu).all(), "optimisation diverged"
+    times = planner.profile_steps(max(1, args.profile_steps))
+    S_loc, N, D, P = planner.S, planner.N, spec.dof, spec.num_spheres
+    t_sdf = times["loglik_kernel"] * 1e-3
+    sdf_bytes = S_loc * N * (28 * P + 8 * D + 4)
+    if rank == 0:
+        line = {
+            "metric": "ELBO iters/sec + plans/sec, Franka-7DoF industrial S=128 M=30 T=100, 1/2/4/8 GPU",
+            "value": args.steps / elapsed, "unit": "ELBO iters/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "timed_blocks": reps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 4: UR10 6-DoF, industrial scene, SDF {'x'.join(str(v) for v in scene.shape)}, "
+                                   f"ONE start-goal problem, S={args.samples} Monte-Carlo samples in total ({S_loc} on this rank), "
+                                   f"M={planner.M} T={N} B={planner.B}",
+                       "parallelism": f"samples sharded x{world}; per step one in-place all-reduce(sum) of "
+                                      f"{planner.reduce_buf.numel()} float64 (gradient + ELBO pieces) over "
+                                      + ("nothing (one rank)" if world == 1 and comm is None else
+                                         "RCCL via the C ABI (vgpmp_allreduce_grads)" if comm is not None else
+                                         f"torch.distributed ({backend}{' = RCCL' if backend == 'nccl' else ''})")
+                                      + ", then the replicated Adam update",
+                       "launch": "one vgpmp_elbo_step (forward + reverse) + one vgpmp_adam_step per step"},
+            "roofline": {"kernel": "likelihood of the local samples", "bound": "hbm", "achieved": sdf_bytes / t_sdf / 1e9,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sdf_bytes / t_sdf / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": sdf_bytes, "avg_launch_ms": times["loglik_kernel"]},
+            "stage_ms": {k: round(v, 5) for k, v in times.items()},
+        }
+        print(json.dumps(line), flush=True)
+    if comm is not None:
+        comm.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +210,11 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=40)
     ap.add_argument("--allow-nan", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--traffic-file", default="", help="pmc traffic table (tools/pmc_aggregate.py) for roofline.traffic")
+    ap.add_argument("--shard", choices=("problems", "samples"), default="problems",
+                    help="problems: independent problems per GPU, no collective (config 2 / 5); samples: BASELINE config 4, "
+                         "UR10, one problem, --samples (1024) Monte-Carlo samples split over the ranks, one all-reduce per step")
+    ap.add_argument("--collective", choices=("torch", "capi"), default="torch",
+                    help="samples sharding: torch.distributed all_reduce (RCCL) or the C ABI's vgpmp_allreduce_grads (RCCL)")
     ap.add_argument("--layout", choices=("brick", "linear"), default="brick", help="voxel table layout (include/vgpmp.h)")
     ap.add_argument("--summary", choices=("auto", "on", "off"), default="auto",
                     help="free-space brick summary in the batch likelihood kernel (auto: tables beyond the Infinity Cache)")
@@ -150,9 +243,13 @@ def main():
         torch.cuda.set_device(0)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    if args.shard == "samples" and args.samples == 128:
+        args.samples = 1024                                  # BASELINE config 4
     ps, spec, grid, scene, planner = build_problem(rank, args)
     from vgpmp_amd import capi
     planner.extra_flags |= {"auto": 0, "lanes": capi.LIK_LANES, "lanes-lds": capi.LIK_LDS_STATE}[args.lik_form]
+    if args.shard == "samples":
+        return run_sample_sharded(args, world, rank, dist, backend, ps, spec, scene, planner)
     for _ in range(args.warmup):
         planner.step()
     if args.unroll > 0:
@@ -211,7 +308,7 @@ def main():
     gemm_flops = npb * 2 * (2.0 * S * (N + M + 2) * D * B)         # F0 and H (lengthscales trainable)
     t_sdf, t_gemm = kernel_ms["loglik_kernel"] * 1e-3, kernel_ms["prior_gemm_kernel"] * 1e-3
     far = "true" if scene.free_space_summary else "false"
-    batch_form = args.lik_form != "auto" or npb * S * N > 65536
+    batch_form = args.lik_form != "auto" or npb * S * N > 28672
     lik_kernel = ("loglik_paths_kernel<1, 64, false, %s, %s>" % (far, "true" if D <= 15 and args.lik_form != "lanes-lds" else "false")
                   if batch_form else "loglik_paths_wide_kernel<8, false>")
     roof_sdf = {"kernel": lik_kernel, "bound": "hbm", "achieved": sdf_bytes / t_sdf / 1e9,

@@ -1,5 +1,8 @@
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -10,3 +13,53 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_run(config) -> bool:
+    """A `-m gpu` run on a box with a GPU device node (checked without initialising the GPU in this process)."""
+    expr = (config.getoption("-m") or "").strip()
+    return expr == "gpu" and os.path.exists("/dev/kfd")
+
+
+def pytest_sessionstart(session):
+    """The two ranks of tests/test_gpu_sharded.py are started HERE, before any test of this process makes a GPU call:
+    fresh child interpreters, one per rank, rendezvous on 127.0.0.1 (gloo)."""
+    session.config._shard_workers = None
+    if not _gpu_run(session.config):
+        return
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = tempfile.mkdtemp(prefix="vgpmp_shard_")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"), str(r), "2", str(port), out],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    session.config._shard_workers = (procs, out)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    w = getattr(session.config, "_shard_workers", None)
+    if w:
+        for p in w[0]:
+            if p.poll() is None:
+                p.kill()
+
+
+@pytest.fixture(scope="session")
+def shard_workers(request):
+    """(directory with rank0.npz / rank1.npz, [worker outputs]) once both worker processes have exited."""
+    w = getattr(request.config, "_shard_workers", None)
+    if not w:
+        pytest.skip("sharded workers are only started by `-m gpu` runs on a GPU box")
+    procs, out = w
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        logs.append(o.decode(errors="replace"))
+        assert p.returncode == 0, logs[-1][-3000:]
+    return out, logs

@@ -1,5 +1,5 @@
-"""World-size-2 gloo tests (CPU) of the multi-GPU host logic: sample-axis sharding with one packed
-all-reduce of the gradient, and problem sharding.  The arithmetic inside each rank is the oracle here
+"""World-size-2 gloo tests (CPU) of the multi-GPU host logic: sample-axis sharding with one in-place
+all-reduce of the contiguous gradient buffer, and problem sharding.  The arithmetic inside each rank is the oracle here
 (no GPU in this container); what is under test is the partitioning / packing / reduction contract that
 vgpmp_amd.sharding applies to the HIP planner on the GPU box."""
 import os
@@ -44,9 +44,15 @@ def _worker(rank, world, port, out_dir):
     fw0 = orc.elbo_forward(pb["params"], pb["scene"], pb["X"], pb["Zy"], pb["y"], local, 0.0)
     gk, _ = orc.elbo_backward(pb["params"], pb["scene"], pb["X"], pb["Zy"], local, 0.0, fw0)   # pure KL gradient
     keep = 1.0 if rank == 0 else 0.0
-    tensors = [torch.tensor(getattr(g, n) - (1.0 - keep) * getattr(gk, n)) for n in ("q_mu", "q_sqrt", "raw_ell", "raw_var")]
-    tensors += [torch.tensor([fw["lik"]]), torch.tensor([keep * fw["cv"]["kl"]])]
-    sharding.allreduce_sum(tensors)
+    parts = [torch.tensor(getattr(g, n) - (1.0 - keep) * getattr(gk, n)) for n in ("q_mu", "q_sqrt", "raw_ell", "raw_var")]
+    parts += [torch.tensor([fw["lik"]]), torch.tensor([keep * fw["cv"]["kl"]])]
+    # the planner's layout: ONE contiguous float64 buffer [q_mu | q_sqrt | raw_ell | raw_var | lik | kl], reduced in place
+    flat = torch.cat([t.reshape(-1) for t in parts]).contiguous()
+    sharding.allreduce_sum_(flat)
+    tensors, o = [], 0
+    for t in parts:
+        tensors.append(flat[o:o + t.numel()].reshape(t.shape))
+        o += t.numel()
     # problem sharding: contiguous blocks, gathered in order
     b, e = sharding.partition(7, world, rank)
     gathered = sharding.gather_results(list(range(b, e)))
@@ -82,12 +88,3 @@ def test_partition_properties():
             sizes = [e - b for b, e in parts]
             assert max(sizes) - min(sizes) <= 1
     assert sharding.shard_samples(1024, 8, 3) == (128, 384)
-
-
-def test_pack_unpack_roundtrip():
-    from vgpmp_amd import sharding
-    ts = [torch.randn(3, 4, dtype=torch.float64), torch.randn(5, dtype=torch.float64), torch.zeros(2, 2, 2, dtype=torch.float64)]
-    flat = sharding.pack(ts)
-    out = [torch.empty_like(t) for t in ts]
-    sharding.unpack_into(flat, out)
-    assert all(torch.equal(a, b) for a, b in zip(ts, out))

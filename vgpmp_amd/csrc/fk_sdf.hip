@@ -913,9 +913,9 @@ __global__ __launch_bounds__(kBlock) void sdf_pack_kernel(vgpmp_sdf sdfh, const 
 // configuration's dependent chain), else 1
 static int lik_lpc(int P, int S, int N) {
     const long long n = (long long)P * S * N;
-    // measured on config 2 shapes (12 800 configurations per problem): 8 lanes win up to 5 problems, one lane per
-    // configuration from 6; 4 lanes (loglik_paths_wide_kernel<4>) never did once the 8-lane form had its scan
-    return n <= 65536 ? 8 : 1;
+    // measured on config 2 shapes (12 800 configurations per problem; tools/lpc_scan.sh): 8 lanes 10.8 / 20.6 / 26.5 us at
+    // 1 / 2 / 3 problems, the batch form 22.2 / 23.0 / 23.2 us
+    return n <= 28672 ? 8 : 1;
 }
 int vg_loglik_blocks_per_problem(int S, int N) { return (S * N * 8 + kLikBlock - 1) / kLikBlock; }   // upper bound
 

@@ -5,13 +5,13 @@ Two axes shard naturally:
     a host-side gather of results at the end;
   * the Monte-Carlo sample axis -- every rank draws the SAME Fourier basis and its own slice of the
     global sample stream (dims.sample_offset), evaluates loss/gradient of its samples with the KL term
-    owned by rank 0 (problem.kl_scale), then ONE all-reduce(sum) of the packed gradient (+ ELBO pieces)
-    per step; every rank applies the identical Adam update.  The payload is ~14 KB at M=30, L=7:
-    latency bound, so it is sent as a single flat float64 buffer.
+    owned by rank 0 (problem.kl_scale), then ONE in-place all-reduce(sum) of the planner's contiguous
+    [gradient | lik | kl] float64 buffer per step; every rank applies the identical Adam update.  The
+    payload is ~28 KB at M=30, L=7: latency bound, one message.
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -30,42 +30,87 @@ def shard_samples(num_samples: int, world: int, rank: int) -> Tuple[int, int]:
     return e - b, b
 
 
-def pack(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
-    return torch.cat([t.reshape(-1).to(torch.float64) for t in tensors])
-
-
-def unpack_into(flat: torch.Tensor, tensors: Sequence[torch.Tensor]) -> None:
-    o = 0
-    for t in tensors:
-        n = t.numel()
-        t.copy_(flat[o:o + n].reshape(t.shape).to(t.dtype))
-        o += n
-
-
-def allreduce_sum(tensors: Sequence[torch.Tensor], group=None) -> None:
-    """One all-reduce for a list of tensors (packed into a single flat buffer, then scattered back)."""
+def allreduce_sum_(flat: torch.Tensor, group=None) -> None:
+    """In-place sum over the ranks of one contiguous buffer: ONE collective, no packing.  Device tensors go through the
+    group's own backend (RCCL when it is "nccl"); with a gloo group (the CPU rehearsal of the N > 1 path, or two ranks on
+    one GPU in the tests) a device buffer is staged through the host."""
     import torch.distributed as dist
-    flat = pack(tensors)
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    unpack_into(flat, tensors)
+    if flat.is_cuda and dist.get_backend(group) != "nccl":
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+
+
+class CapiComm:
+    """The collective behind the C ABI (vgpmp_comm_init / vgpmp_allreduce_grads: RCCL resolved by libvgpmp_hip.so itself).
+    The rendezvous id travels over an existing torch.distributed group (any backend) or, for a single rank, nowhere."""
+
+    def __init__(self, world: int, rank: int, group=None):
+        import ctypes as C
+
+        from . import capi
+        self.lib = capi.load(require=True)
+        ident = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_ubyte * capi.COMM_ID_BYTES)()
+            capi.check(self.lib.vgpmp_comm_unique_id(buf), "vgpmp_comm_unique_id")
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        if world > 1:
+            import torch.distributed as dist
+            if dist.get_backend(group) == "nccl":
+                dev = ident.cuda()
+                dist.broadcast(dev, 0, group=group)
+                ident = dev.cpu()
+            else:
+                dist.broadcast(ident, 0, group=group)
+        raw = (C.c_ubyte * capi.COMM_ID_BYTES)(*ident.tolist())
+        self.handle = C.c_void_p()
+        capi.check(self.lib.vgpmp_comm_init(raw, int(world), int(rank), C.byref(self.handle)), "vgpmp_comm_init")
+
+    def allreduce_sum_(self, flat: torch.Tensor) -> None:
+        from . import capi
+        assert flat.is_cuda and flat.dtype == torch.float64 and flat.is_contiguous()
+        capi.check(self.lib.vgpmp_allreduce_grads(self.handle, capi.ptr(flat), flat.numel(),
+                                                  int(torch.cuda.current_stream(flat.device).cuda_stream)),
+                   "vgpmp_allreduce_grads")
+
+    def close(self) -> None:
+        if self.handle:
+            self.lib.vgpmp_comm_destroy(self.handle)
+            self.handle = None
 
 
 class SampleShardedPlanner:
-    """Drives a PlannerBatch that holds this rank's slice of the samples."""
+    """Drives a PlannerBatch that holds this rank's slice of the samples (dims.sample_offset / S_total, KL on the rank
+    with kl_scale = 1).  One step = local forward + reverse, ONE in-place all-reduce of the planner's contiguous
+    [gradient | lik | kl] buffer, the identical Adam update on every rank."""
 
-    def __init__(self, planner, group=None):
-        self.planner, self.group = planner, group
+    def __init__(self, planner, group=None, comm: Optional["CapiComm"] = None):
+        self.planner, self.group, self.comm = planner, group, comm
+
+    def _allreduce(self) -> None:
+        buf = self.planner.reduce_buf
+        if self.comm is not None:
+            self.comm.allreduce_sum_(buf)
+        else:
+            allreduce_sum_(buf, self.group)
 
     def step(self) -> None:
         pl = self.planner
         pl.loss_and_grad(generate=True, step=pl.t)            # local samples; KL only where kl_scale = 1
-        allreduce_sum(list(pl.grad) + [pl.lik, pl.kl], self.group)
+        self._allreduce()
         pl.adam_only()                                         # identical update on every rank
+
+    def run_steps(self, steps: int) -> None:
+        for _ in range(steps):
+            self.step()
 
     def elbo(self) -> torch.Tensor:
         pl = self.planner
         pl.elbo(generate=True, step=pl.t)
-        allreduce_sum([pl.lik, pl.kl], self.group)
+        self._allreduce()                                      # the gradient part of the buffer is stale here: only lik / kl are read
         return pl.lik - pl.kl
 
 
