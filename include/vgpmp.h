@@ -12,6 +12,12 @@
  *   - return value: 0 = ok, negative = argument/shape error (VGPMP_E_*), positive = hipError_t.
  *   - thread-compatible; every launch goes to the explicit `stream`; no hidden global state.
  *   - arrays are dense, C order, leading dimension = problem index for batched buffers.
+ *
+ * Limits (VGPMP_E_SHAPE beyond them): dof <= 16, spheres <= 64, Mz = M + 2 <= 48, B a multiple of 16, N <= 4096 and,
+ * because one latent's A = Kfu (Kuu + jI)^-1 ([N, Mz] float32) is LDS-resident in the path kernels,
+ *   forward  (VGPMP_DO_FORWARD):   4 * (Mz (Mz + 1) + Mz N + 33 Mz + 8 N + 24)  <= 160 KiB   (N <= 970 at M = 30)
+ *   backward (VGPMP_DO_BACKWARD):  4 * (4 N Mz + 2 Mz^2 + 24 N + 80 Mz + 40)   <= 160 KiB   (N <= 238 at M = 30, 292 at M = 24)
+ * vgpmp_workspace_bytes checks the forward bound (it does not know `what`); a step with VGPMP_DO_BACKWARD checks its own.
  */
 #ifndef VGPMP_H
 #define VGPMP_H
@@ -299,6 +305,19 @@ int vgpmp_elbo_step_profiled(const vgpmp_dims* dims, const vgpmp_robot* dev_robo
                              int32_t what, int32_t trainable, double learning_rate, int32_t adam_t,
                              uint32_t seed, uint32_t problem_base, uint32_t step, vgpmp_stream stream,
                              float* host_stage_ms);
+
+/* Plan extraction, VGPMP.sample_from_posterior + get_best_sample (models/vgpmp.py:312-339), after a forward-only
+ * vgpmp_elbo_step (VGPMP_DO_FORWARD | VGPMP_GEN_NOISE) at Xnew with dims.S = 150 pathwise samples, on the state that
+ * call left in the workspace (A = Kfu (Kuu + jI)^-1, q_mu) and in out->f / out->logp.  Per problem:
+ *   dev_mean      [P, N, L]     joint_sigmoid of the posterior mean, gpflow conditional with whiten=False (:316-317)
+ *   dev_best      [P]           get_best_sample: arg-max over the samples of sum_n logp[s, n], first maximum (:336-339)
+ *   dev_best_path [P, N, L]     samples[best] as joint angles
+ *   dev_samples   [P, S, N, L]  every sample as joint angles (:318-320), or NULL
+ *   dev_ee_var    [P, N, 3]     compute_uncertainty=True (:322-327): population variance over the samples of the last
+ *                               frame's origin; the caller returns 2 sqrt of it; or NULL */
+int vgpmp_sample_paths(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, void* dev_workspace, size_t workspace_bytes,
+                       const float* dev_f, const float* dev_logp, float* dev_mean, int32_t* dev_best,
+                       float* dev_best_path, float* dev_samples, float* dev_ee_var, vgpmp_stream stream);
 
 /* Adam.apply_gradients alone (after an external all-reduce of out->grad when samples are sharded). */
 int vgpmp_adam_step(const vgpmp_dims* dims, const vgpmp_params* params, const vgpmp_params* grad,

@@ -24,7 +24,7 @@ LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvgpmp_hip.so"
 
 EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_table_bytes", "vgpmp_sdf_pack", "vgpmp_mesh_sdf", "vgpmp_fk_spheres", "vgpmp_sdf_query",
            "vgpmp_log_prob", "vgpmp_kernel_derivative", "vgpmp_velocity_kuu_kuf", "vgpmp_workspace_bytes", "vgpmp_lik_scratch_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
-           "vgpmp_elbo_steps", "vgpmp_elbo_step_profiled", "vgpmp_adam_step", "vgpmp_workspace_view",
+           "vgpmp_elbo_steps", "vgpmp_elbo_step_profiled", "vgpmp_adam_step", "vgpmp_workspace_view", "vgpmp_sample_paths",
            "vgpmp_comm_unique_id", "vgpmp_comm_init", "vgpmp_allreduce_grads", "vgpmp_comm_destroy")
 NUM_STAGES = 8
 NUM_TIMES = 10
@@ -139,6 +139,7 @@ def load(require: bool = True) -> Optional[C.CDLL]:
                                      P(C.c_float)],
         "vgpmp_adam_step": [P(Dims), P(Params), P(Params), P(Params), P(Params), i32, dbl, i32, vp],
         "vgpmp_workspace_view": [P(Dims), vp, C.c_char_p, P(vp), P(C.c_size_t), P(i32)],
+        "vgpmp_sample_paths": [P(Dims), vp, vp, C.c_size_t, vp, vp, vp, vp, vp, vp, vp, vp],
         "vgpmp_comm_unique_id": [vp],
         "vgpmp_comm_init": [vp, i32, i32, P(vp)],
         "vgpmp_allreduce_grads": [vp, vp, C.c_size_t, vp],

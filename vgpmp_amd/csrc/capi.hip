@@ -133,6 +133,19 @@ int vgpmp_velocity_kuu_kuf(int32_t kind, const double* dev_Zy, const double* dev
                                       (hipStream_t)stream);
 }
 
+int vgpmp_sample_paths(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, void* dev_workspace, size_t workspace_bytes,
+                       const float* dev_f, const float* dev_logp, float* dev_mean, int32_t* dev_best, float* dev_best_path,
+                       float* dev_samples, float* dev_ee_var, vgpmp_stream stream) {
+    if (!dims || !dev_robot || !dev_workspace || !dev_f || !dev_logp) return VGPMP_E_ARG;
+    if ((dev_best == nullptr) != (dev_best_path == nullptr)) return VGPMP_E_ARG;
+    int rc = vg_check_dims(dims);
+    if (rc) return rc;
+    vg_workspace ws;
+    if (vg_layout_workspace(dims, dev_workspace, &ws) > workspace_bytes) return VGPMP_E_WORKSPACE;
+    return vg_launch_sample_paths(dims, dev_robot, &ws, dev_f, dev_logp, dev_mean, dev_best, dev_best_path, dev_samples,
+                                  dev_ee_var, (hipStream_t)stream);
+}
+
 int vgpmp_lik_scratch_bytes(const vgpmp_dims* dims, size_t* bytes) {
     if (!dims || !bytes) return VGPMP_E_ARG;
     int rc = vg_check_dims(dims);
@@ -180,6 +193,7 @@ static int elbo_step_impl(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, 
     vg_workspace ws;
     size_t need = vg_layout_workspace(dims, dev_workspace, &ws);
     if (workspace_bytes < need) return VGPMP_E_WORKSPACE;
+    if ((what & VGPMP_DO_BACKWARD) && !vg_backward_fits(dims)) return VGPMP_E_SHAPE;      // include/vgpmp.h, "Limits"
     return vg_elbo_steps(dims, dev_robot, sdf, problem, params, adam_m, adam_v, noise, out, &ws, what, trainable,
                          learning_rate, adam_t, seed, problem_base, step, num_steps, (hipStream_t)stream, ev);
 }

@@ -53,6 +53,7 @@ struct vg_lik_scratch {
 size_t vg_layout_lik_scratch(const vgpmp_dims* d, void* base, vg_lik_scratch* out);
 
 int vg_check_dims(const vgpmp_dims* d);
+int vg_backward_fits(const vgpmp_dims* d);
 size_t vg_layout_workspace(const vgpmp_dims* d, void* base, vg_workspace* ws);
 int vg_workspace_lookup(const vgpmp_dims* d, const vg_workspace* ws, const char* name, void** ptr, size_t* count,
                         int32_t* is_double);
@@ -64,4 +65,6 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                   const vgpmp_params* params, const vgpmp_params* am, const vgpmp_params* av, const vgpmp_noise* noise,
                   const vgpmp_outputs* out, const vg_workspace* ws, int what, int trainable, double lr, int adam_t,
                   uint32_t seed, uint32_t problem_base, uint32_t step, int num_steps, hipStream_t st, hipEvent_t* ev);
+int vg_launch_sample_paths(const vgpmp_dims* d, const vgpmp_robot* rb, const vg_workspace* ws, const float* f, const float* logp,
+                           float* mean, int32_t* best, float* best_path, float* samples, float* ee_var, hipStream_t st);
 constexpr int VG_NUM_STAGES = 8;   // cov_fwd, rng, features, prior_gemm, paths_fwd, loglik, paths_bwd, final

@@ -2617,7 +2617,17 @@ int vg_check_dims(const vgpmp_dims* d) {
     if (d->split_k != 1 && d->split_k != 2 && d->split_k != 4 && d->split_k != 8) return VGPMP_E_SHAPE;
     if ((d->B / d->split_k) % 16 != 0) return VGPMP_E_SHAPE;
     if (d->N > 4096) return VGPMP_E_SHAPE;
+    // the path assembly keeps A = Kfu (Kuu + jI)^-1 of one latent ([N, Mz] float32) in LDS: N * Mz is bounded by the 160 KB
+    // of a CU (include/vgpmp.h, "Limits"); the reverse pass holds four such images (vg_backward_fits)
+    const size_t Mz = (size_t)d->M + 2, N = (size_t)d->N, J = N + Mz, SC = 8;
+    if ((Mz * (Mz + 1) + Mz * N + 3 * SC * Mz + Mz + SC * J + 24) * sizeof(float) > 160 * 1024) return VGPMP_E_SHAPE;
     return 0;
+}
+
+// VGPMP_DO_BACKWARD: {A, dA/dell, dA/dvar} and G A of one latent live in LDS together
+int vg_backward_fits(const vgpmp_dims* d) {
+    const size_t Mz = (size_t)d->M + 2, N = (size_t)d->N, J = N + Mz, SC = 8;
+    return (4 * N * Mz + 2 * Mz * Mz + SC * N + 2 * SC * J + 8 * SC * Mz + 40) * sizeof(float) <= 160 * 1024;
 }
 
 size_t vg_layout_workspace(const vgpmp_dims* d, void* base, vg_workspace* ws) {
@@ -2878,7 +2888,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                                                                                   : (const void*)paths_bwd_split<8>);
         lds_pb = lds_pbs;
     }
-    if ((rc = set_dyn_lds(fn_pb, lds_pb))) return rc;
+    if (backward && (rc = set_dyn_lds(fn_pb, lds_pb))) return rc;      // forward-only calls never launch the reverse pass
     if (fused) {
         if ((rc = set_dyn_lds((const void*)stage1_kernel<false>, lds_s1))) return rc;
         if ((rc = set_dyn_lds((const void*)stage1_kernel<true>, lds_s1))) return rc;

@@ -342,6 +342,7 @@ class PlannerBatch:
     def run_steps(self, steps: int) -> None:
         """`steps` optimisation steps: whole graphs while they fit, eager launches for the rest."""
         if self._graph is not None:
+            self.step_counter.fill_(self.t)          # step() / adam_only() between capture and replay advance only self.t
             while steps >= self._graph_unroll:
                 self._graph.replay()
                 self.t += self._graph_unroll
@@ -379,7 +380,8 @@ class PlannerBatch:
 
     # ---- plan extraction (models/vgpmp.py:312-339) -------------------------------------------------
     def posterior_sampler(self, num_samples: int = 150, Xnew: Optional[np.ndarray] = None) -> "PlannerBatch":
-        """A forward-only view of the same models at other (S, N): shares the parameter tensors."""
+        """A forward-only view of the same models at other (S, N): shares the parameter tensors.  The view is cached per
+        (S, N); its time stamps are those of THIS call (the reference passes X through on every call, models/vgpmp.py:312-331)."""
         n_new = self.N if Xnew is None else int(np.asarray(Xnew).shape[0])
         key = (int(num_samples), n_new)
         cache = self.__dict__.setdefault("_samplers", {})
@@ -395,22 +397,38 @@ class PlannerBatch:
                 child.raw_alpha, child.raw_sigma = self.raw_alpha, self.raw_sigma
             child._pack()
             cache[key] = child
-        return cache[key]
+        child = cache[key]
+        Xn = np.tile(np.linspace(0.0, 1.0, n_new)[:, None], (1, self.L)) if Xnew is None else np.asarray(Xnew, dtype=np.float64)
+        child.X.copy_(torch.as_tensor(Xn, dtype=torch.float64).reshape(child.X.shape))
+        return child
+
+    def extract_plans(self, want_samples: bool = True, compute_uncertainty: bool = False):
+        """vgpmp_sample_paths on the state the last forward pass left: (mean [P,N,L], best path [P,N,L], samples [P,S,N,L] or
+        None, best index [P], end-effector variance [P,N,3] or None), all on the device, joint angles in float32."""
+        dev, f32 = self.device, torch.float32
+        mean = torch.empty((self.P, self.N, self.L), dtype=f32, device=dev)
+        best_path = torch.empty_like(mean)
+        best = torch.empty(self.P, dtype=torch.int32, device=dev)
+        samples = torch.empty((self.P, self.S, self.N, self.L), dtype=f32, device=dev) if want_samples else None
+        ee = torch.empty((self.P, self.N, 3), dtype=f32, device=dev) if compute_uncertainty else None
+        capi.check(self.lib.vgpmp_sample_paths(C.byref(self.dims), capi.ptr(self.scene.dev_robot), capi.ptr(self.workspace),
+                                               self.workspace.numel(), capi.ptr(self.f), capi.ptr(self.logp), capi.ptr(mean),
+                                               capi.ptr(best), capi.ptr(best_path), capi.ptr(samples), capi.ptr(ee),
+                                               self.scene._stream()), "vgpmp_sample_paths")
+        return mean, best_path, samples, best, ee
 
     def posterior_mean(self) -> torch.Tensor:
         """Mean of q(f) at this batch's X after a forward pass: joint_sigmoid(Kfu (Kuu + jI)^-1 q_mu), [P, N, L]."""
-        A = self.view("A4").reshape(self.P, self.L, self.N, self.Mz, 4)[..., 0]
-        m = self.view("m").reshape(self.P, self.L, self.Mz)
-        return self.scene.joint_sigmoid(torch.einsum("plnm,plm->pnl", A, m))
+        return self.extract_plans(want_samples=False)[0]
 
-    def sample_from_posterior(self, num_samples: int = 150, Xnew: Optional[np.ndarray] = None, step: int = 0):
-        """(mean, best sample, samples, best index) per problem; best = argmax_s sum_n log p (vgpmp.py:336-339)."""
+    def sample_from_posterior(self, num_samples: int = 150, Xnew: Optional[np.ndarray] = None, step: int = 0,
+                              compute_uncertainty: bool = False):
+        """(mean, best sample, samples, best index[, end-effector variance]) per problem; best = argmax_s sum_n log p
+        (models/vgpmp.py:312-339).  One forward-only step at Xnew, then vgpmp_sample_paths: no torch arithmetic."""
         sp = self.posterior_sampler(num_samples, Xnew)
         sp.elbo(generate=True, step=step)
-        samples = sp.samples()                                       # [P, S, N, L]
-        best = sp.logp.sum(-1).argmax(dim=1)                         # [P]
-        idx = best.view(-1, 1, 1, 1).expand(-1, 1, samples.shape[2], samples.shape[3])
-        return sp.posterior_mean(), samples.gather(1, idx)[:, 0], samples, best
+        mean, best_path, samples, best, ee = sp.extract_plans(True, compute_uncertainty)
+        return (mean, best_path, samples, best, ee) if compute_uncertainty else (mean, best_path, samples, best)
 
     def path_clearance(self, path: torch.Tensor) -> torch.Tensor:
         """Signed clearance (SDF distance minus sphere radius) of every sphere along joint paths

@@ -249,6 +249,19 @@ class VGPMP:
             pl.raw_var.copy_(torch.tensor(engine.softplus_inverse(
                 np.maximum([float(kk.variance) for kk in k], engine.VARIANCE_FLOOR + 1e-6) - engine.VARIANCE_FLOOR))[None])
             pl.q_mu.copy_(torch.tensor(self.likelihood.joint_sigmoid.inverse(self._init_q_mu).T[None]))
+            old = self._planner
+            if old is not None:
+                # a different number of time stamps: the SAME variables evaluated on another X (the reference's variables do
+                # not depend on the data) -- carry the parameters, the Adam state and the step count over
+                for name in ("q_mu", "q_sqrt", "raw_ell", "raw_var"):
+                    getattr(pl, name).copy_(getattr(old, name))
+                for dst, src in zip(pl.adam_m + pl.adam_v, old.adam_m + old.adam_v):
+                    dst.copy_(src)
+                if pl.lik_variables and old.lik_variables:
+                    pl.raw_alpha.copy_(old.raw_alpha); pl.raw_sigma.copy_(old.raw_sigma)
+                    for dst, src in zip(pl.lik_adam_m + pl.lik_adam_v, old.lik_adam_m + old.lik_adam_v):
+                        dst.copy_(src)
+                pl.t = old.t
             self._planner, self._n_train = pl, n_time
         return self._planner
 
@@ -329,12 +342,15 @@ class VGPMP:
             self.likelihood.variance.assign(pl.sigma_obs()[0].cpu().numpy()[None])
 
     def sample_from_posterior(self, X, robot=None, compute_uncertainty=False):
-        """models/vgpmp.py:312-331: (mean, best sample, first 7 samples, 2 sqrt(uncertainty))."""
+        """models/vgpmp.py:312-331: (mean, best sample, first 7 samples, 2 sqrt(uncertainty)); uncertainty = the variance
+        over the 150 samples of the end-effector position when compute_uncertainty, else 1."""
         X = np.asarray(X, dtype=np.float64)
         pl = self._ensure(self._n_train or X.shape[0])
-        mu, best, samples, _ = pl.sample_from_posterior(150, X, step=pl.t)
+        out = pl.sample_from_posterior(150, X, step=pl.t, compute_uncertainty=bool(compute_uncertainty))
+        mu, best, samples = out[0], out[1], out[2]
+        unc = 2.0 * np.sqrt(out[4][0].cpu().numpy().astype(np.float64)) if compute_uncertainty else 2.0
         return (mu[0].cpu().numpy().astype(np.float64), best[0].cpu().numpy().astype(np.float64),
-                samples[0, :7].cpu().numpy().astype(np.float64), 2.0)
+                samples[0, :7].cpu().numpy().astype(np.float64), unc)
 
     def get_best_sample(self, samples):
         cost = self.likelihood.log_prob(samples).sum(-1)
