@@ -195,6 +195,9 @@ typedef struct vgpmp_outputs {
 #define VGPMP_NO_SPLIT 64       /* measurement: reverse path pass on one workgroup per (chunk, latent) */
 #define VGPMP_LIK_LANES 256     /* measurement: the batch form of the likelihood (one lane per configuration) at any batch size */
 #define VGPMP_LIK_LDS_STATE 512 /* measurement: that form with the per-frame force / moment sums in LDS instead of registers */
+#define VGPMP_COV_ONLY 2048     /* with VGPMP_DO_FORWARD alone: only the covariance stage -- Kuu, its Cholesky, q_sqrt, A and the
+                                 * per-latent prior KL (kullback_leiblers/prior_kl.py:16-35) land in the workspace (views "kl_l", "C",
+                                 * "Kinv", "A4"); no noise, no likelihood: dev_robot and sdf may be NULL, the members of `noise` and `out` too */
 #define VGPMP_ELIM_BLOCK 128    /* measurement: Kuu elimination by the whole workgroup through LDS instead of one wave in registers */
 
 /* ---- set-up -------------------------------------------------------------------------------- */
@@ -254,6 +257,13 @@ int vgpmp_kernel_derivative(int32_t kind, int32_t order, const double* dev_x, in
 int vgpmp_velocity_kuu_kuf(int32_t kind, const double* dev_Zy, const double* dev_X, int32_t Mz, int32_t N, int32_t L,
                            const double* dev_ell, const double* dev_var, double jitter, double* dev_Kuu, double* dev_Kuf,
                            vgpmp_stream stream);
+
+/* The covariance dispatchers on plain arrays (covariances/multioutput/Kuus.py:42-53, Kufs.py:26-34, covariances/Kfus.py:36-42
+ * through kernel_conditioning/multioutput/cond_kernel.py:17-25): out [L, nz, nx], out[l, i, j] = k_l(Z[i, l], X[j, l]) with the
+ * latent's own lengthscale / variance, plus `jitter` where i == j (pass 0 unless Z and X are the same set: Kuu).  Z [nz, L],
+ * X [nx, L], ell / var [L], float64 on the device; kind 0 Matern-5/2, 1 squared exponential.  Kfu is the caller's transpose. */
+int vgpmp_cov_matrices(int32_t kind, const double* dev_Z, int32_t nz, const double* dev_X, int32_t nx, int32_t L,
+                       const double* dev_ell, const double* dev_var, double jitter, double* dev_out, vgpmp_stream stream);
 
 /* ---- the ELBO step ------------------------------------------------------------------------- */
 

@@ -448,3 +448,44 @@ def test_industrial_scene_from_mesh_plans():
     assert torch.isfinite(l1).all() and float(l1.mean()) < float(l0.mean())
     _, best, _, _ = pl.sample_from_posterior(50, None)
     assert torch.isfinite(pl.path_clearance(best)).all()
+
+
+def test_dispatchers_on_the_device_match_oracle():
+    """gpflow_vgpmp.covariances.Kuu / Kuf / Kfu, kernel_conditioning.K_conditioned, kernels' __call__ and
+    kullback_leiblers.prior_kl: every number from libvgpmp_hip.so (vgpmp_cov_matrices; the covariance stage of the ELBO step
+    for the KL), against the oracle."""
+    from gpflow_vgpmp.kernel_conditioning import K_conditioned
+    from gpflow_vgpmp.covariances import Kuu, Kuf, Kfu
+    from gpflow_vgpmp.kullback_leiblers.prior_kl import prior_kl
+    from gpflow_vgpmp.inducing_variables.inducing_variables import (ConditionedVariableInducingPoints,
+                                                                    SharedIndependentInducingVariables)
+    from gpflow_vgpmp.kernels.kernels import Matern52, VanillaConditioningSeparateIndependent
+    from oracle import vgpmp_oracle as orc
+    L, M, N = 3, 5, 6
+    Z = np.tile(np.linspace(0.1, 0.9, M)[:, None], (1, L))
+    iv = SharedIndependentInducingVariables(ConditionedVariableInducingPoints(Z, np.stack([np.zeros(L), np.ones(L)])))
+    ell, var = [2.0, 3.0, 0.7], 0.3
+    kern = VanillaConditioningSeparateIndependent([Matern52(e, var) for e in ell])
+    X = orc.init_trainset(N, L)
+    Zy = orc.inducing_Zy(M, L)
+    K = Kuu(iv, kern, jitter=1e-6).numpy()
+    for l in range(L):
+        np.testing.assert_allclose(K[l], orc.matern52(Zy[:, l], Zy[:, l], ell[l], var) + 1e-6 * np.eye(M + 2), rtol=1e-12)
+        np.testing.assert_allclose(Kuf(iv, kern, X)[l].numpy(), orc.matern52(Zy[:, l], X[:, l], ell[l], var), rtol=1e-12)
+    assert Kfu(iv, kern, X).shape == (L, N, M + 2)
+    rng = np.random.default_rng(0)
+    p = orc.Params(q_mu=rng.standard_normal((M, L)), q_sqrt=np.tril(rng.standard_normal((L, M, M))) + 2 * np.eye(M),
+                   raw_ell=orc.softplus_inverse(np.array(ell)), raw_var=np.full(L, orc.softplus_inverse(var - 0.1)))
+    y_u = rng.standard_normal((2, L))
+    cv = orc.cov_forward(p, X, Zy, y_u)
+    np.testing.assert_allclose(float(prior_kl(iv, kern, p.q_mu, p.q_sqrt, y_u)), cv["kl"], rtol=1e-9)
+    np.testing.assert_allclose(K_conditioned(iv, X, kern).numpy(), Kuf(iv, kern, X).numpy(), rtol=0, atol=0)
+    np.testing.assert_allclose(kern.kernels[1](Zy[:, 1], X[:, 1]).numpy(), orc.matern52(Zy[:, 1], X[:, 1], ell[1], var), rtol=1e-12)
+    # a second geometry through the same path: more inducing points, other hyper-parameters
+    M2 = 30
+    Z2 = np.tile(np.linspace(0.1, 0.9, M2)[:, None], (1, L))
+    iv2 = SharedIndependentInducingVariables(ConditionedVariableInducingPoints(Z2, np.stack([np.zeros(L), np.ones(L)])))
+    p2 = orc.Params(q_mu=rng.standard_normal((M2, L)), q_sqrt=np.tril(0.1 * rng.standard_normal((L, M2, M2))) + np.eye(M2),
+                    raw_ell=p.raw_ell, raw_var=p.raw_var)
+    cv2 = orc.cov_forward(p2, X, orc.inducing_Zy(M2, L), y_u)
+    np.testing.assert_allclose(float(prior_kl(iv2, kern, p2.q_mu, p2.q_sqrt, y_u)), cv2["kl"], rtol=1e-8)

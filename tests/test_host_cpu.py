@@ -73,30 +73,3 @@ def test_fill_order_independent_variables_and_problemsets():
         robots.load_problemset("franka", "kitchen")
     arm = robots.synthetic_arm(14)
     assert arm.dof == 14 and arm.num_spheres == 45 and list(arm.sphere_frame) == sorted(arm.sphere_frame)
-
-
-def test_dispatcher_lookalikes_match_oracle():
-    from gpflow_vgpmp.covariances import Kuu, Kuf, Kfu
-    from gpflow_vgpmp.kullback_leiblers.prior_kl import prior_kl
-    from gpflow_vgpmp.inducing_variables.inducing_variables import (ConditionedVariableInducingPoints,
-                                                                    SharedIndependentInducingVariables)
-    from gpflow_vgpmp.kernels.kernels import Matern52, VanillaConditioningSeparateIndependent
-    from oracle import vgpmp_oracle as orc
-    L, M, N = 3, 5, 6
-    Z = np.tile(np.linspace(0.1, 0.9, M)[:, None], (1, L))
-    iv = SharedIndependentInducingVariables(ConditionedVariableInducingPoints(Z, np.stack([np.zeros(L), np.ones(L)])))
-    ell, var = [2.0, 3.0, 0.7], 0.3
-    kern = VanillaConditioningSeparateIndependent([Matern52(e, var) for e in ell])
-    X = orc.init_trainset(N, L)
-    Zy = orc.inducing_Zy(M, L)
-    K = Kuu(iv, kern, jitter=1e-6).numpy()
-    for l in range(L):
-        np.testing.assert_allclose(K[l], orc.matern52(Zy[:, l], Zy[:, l], ell[l], var) + 1e-6 * np.eye(M + 2), rtol=1e-12)
-        np.testing.assert_allclose(Kuf(iv, kern, X)[l].numpy(), orc.matern52(Zy[:, l], X[:, l], ell[l], var), rtol=1e-12)
-    assert Kfu(iv, kern, X).shape == (L, N, M + 2)
-    rng = np.random.default_rng(0)
-    p = orc.Params(q_mu=rng.standard_normal((M, L)), q_sqrt=np.tril(rng.standard_normal((L, M, M))) + 2 * np.eye(M),
-                   raw_ell=orc.softplus_inverse(np.array(ell)), raw_var=np.full(L, orc.softplus_inverse(var - 0.1)))
-    y_u = rng.standard_normal((2, L))
-    cv = orc.cov_forward(p, X, Zy, y_u)
-    np.testing.assert_allclose(float(prior_kl(iv, kern, p.q_mu, p.q_sqrt, y_u)), cv["kl"], rtol=1e-9)

@@ -18,12 +18,12 @@ COMM_ID_BYTES = 128
 TRAIN_Q_MU, TRAIN_Q_SQRT, TRAIN_LENGTHSCALES, TRAIN_KERNEL_VARIANCE = 1, 2, 4, 8
 TRAIN_SIGMA_OBS, TRAIN_ALPHA = 16, 32      # need Problem.lik
 DO_FORWARD, DO_BACKWARD, DO_ADAM, GEN_NOISE, NO_FUSE = 1, 2, 4, 8, 16
-GEMM_DIRECT, NO_SPLIT, ELIM_BLOCK, LIK_LANES, LIK_LDS_STATE = 32, 64, 128, 256, 512
+GEMM_DIRECT, NO_SPLIT, ELIM_BLOCK, LIK_LANES, LIK_LDS_STATE, COV_ONLY = 32, 64, 128, 256, 512, 2048
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvgpmp_hip.so"
 
 EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_table_bytes", "vgpmp_sdf_pack", "vgpmp_mesh_sdf", "vgpmp_fk_spheres", "vgpmp_sdf_query",
-           "vgpmp_log_prob", "vgpmp_kernel_derivative", "vgpmp_velocity_kuu_kuf", "vgpmp_workspace_bytes", "vgpmp_lik_scratch_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
+           "vgpmp_log_prob", "vgpmp_cov_matrices", "vgpmp_kernel_derivative", "vgpmp_velocity_kuu_kuf", "vgpmp_workspace_bytes", "vgpmp_lik_scratch_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
            "vgpmp_elbo_steps", "vgpmp_elbo_step_profiled", "vgpmp_adam_step", "vgpmp_workspace_view", "vgpmp_sample_paths",
            "vgpmp_comm_unique_id", "vgpmp_comm_init", "vgpmp_allreduce_grads", "vgpmp_comm_destroy")
 NUM_STAGES = 8
@@ -125,6 +125,7 @@ def load(require: bool = True) -> Optional[C.CDLL]:
         "vgpmp_fk_spheres": [vp, vp, i64, vp, vp, vp],
         "vgpmp_sdf_query": [P(Sdf), vp, i64, vp, vp, vp, vp],
         "vgpmp_log_prob": [vp, i32, P(Sdf), vp, i64, vp, vp, vp],
+        "vgpmp_cov_matrices": [i32, vp, i32, vp, i32, i32, vp, vp, dbl, vp, vp],
         "vgpmp_kernel_derivative": [i32, i32, vp, i32, vp, i32, dbl, dbl, vp, vp],
         "vgpmp_velocity_kuu_kuf": [i32, vp, vp, i32, i32, i32, vp, vp, dbl, vp, vp, vp],
         "vgpmp_workspace_bytes": [P(Dims), P(C.c_size_t)],

@@ -124,6 +124,13 @@ int vgpmp_kernel_derivative(int32_t kind, int32_t order, const double* dev_x, in
     return vg_launch_kernel_derivative(kind, order, dev_x, n, dev_y, m, lengthscale, variance, dev_out, (hipStream_t)stream);
 }
 
+int vgpmp_cov_matrices(int32_t kind, const double* dev_Z, int32_t nz, const double* dev_X, int32_t nx, int32_t L,
+                       const double* dev_ell, const double* dev_var, double jitter, double* dev_out, vgpmp_stream stream) {
+    if (!dev_Z || !dev_X || !dev_ell || !dev_var || !dev_out) return VGPMP_E_ARG;
+    if ((kind != 0 && kind != 1) || nz < 0 || nx < 0 || L < 1) return VGPMP_E_SHAPE;
+    return vg_launch_cov_matrices(kind, dev_Z, nz, dev_X, nx, L, dev_ell, dev_var, jitter, dev_out, (hipStream_t)stream);
+}
+
 int vgpmp_velocity_kuu_kuf(int32_t kind, const double* dev_Zy, const double* dev_X, int32_t Mz, int32_t N, int32_t L,
                            const double* dev_ell, const double* dev_var, double jitter, double* dev_Kuu, double* dev_Kuf,
                            vgpmp_stream stream) {
@@ -169,14 +176,22 @@ static int elbo_step_impl(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, 
                           void* dev_workspace, size_t workspace_bytes, int32_t what, int32_t trainable,
                           double learning_rate, int32_t adam_t, uint32_t seed, uint32_t problem_base, uint32_t step,
                           vgpmp_stream stream, hipEvent_t* ev, int num_steps = 1) {
-    if (!dims || !dev_robot || !problem || !params || !noise || !out || !dev_workspace) return VGPMP_E_ARG;
+    if (!dims || !problem || !params || !noise || !out || !dev_workspace) return VGPMP_E_ARG;
     int rc = vg_check_dims(dims);
     if (rc) return rc;
-    rc = check_sdf(sdf);
-    if (rc) return rc;
+    const bool cov_only = (what & VGPMP_COV_ONLY) != 0;      // covariance stage alone: nothing below it is launched
+    if (cov_only) {
+        if (what & (VGPMP_DO_BACKWARD | VGPMP_DO_ADAM | VGPMP_GEN_NOISE)) return VGPMP_E_ARG;
+        if (num_steps != 1 || ev) return VGPMP_E_ARG;
+        what |= VGPMP_NO_FUSE;
+    } else {
+        if (!dev_robot) return VGPMP_E_ARG;
+        rc = check_sdf(sdf);
+        if (rc) return rc;
+        if (!out->f || !out->logp || !out->lik || !out->kl) return VGPMP_E_ARG;
+    }
     if (!problem->X || !problem->Zy || !problem->y_u) return VGPMP_E_ARG;
     if (!params->q_mu || !params->q_sqrt || !params->raw_ell || !params->raw_var) return VGPMP_E_ARG;
-    if (!out->f || !out->logp || !out->lik || !out->kl) return VGPMP_E_ARG;
     if ((what & VGPMP_DO_BACKWARD) &&
         (!out->grad.q_mu || !out->grad.q_sqrt || !out->grad.raw_ell || !out->grad.raw_var))
         return VGPMP_E_ARG;

@@ -74,7 +74,28 @@ __global__ __launch_bounds__(kBlock) void kernel_derivative_kernel(int kind, int
     out[e] = order == 0 ? k_val(k, x[i], y[j]) : order == 1 ? k_grad(k, x[i], y[j]) : k_grad_grad(k, x[i], y[j]);
 }
 
+// K_conditioned (kernel_conditioning/multioutput/cond_kernel.py:17-25): K[l, i, j] = k_l(Z[i, l], X[j, l]) (+ jitter on i == j:
+// Kuu of covariances/multioutput/Kuus.py:42-53), every latent in one launch
+__global__ __launch_bounds__(kBlock) void cov_matrices_kernel(int kind, const double* __restrict__ Z, int nz,
+                                                               const double* __restrict__ X, int nx, int D,
+                                                               const double* __restrict__ ell, const double* __restrict__ var,
+                                                               double jitter, double* __restrict__ out) {
+    const int e = blockIdx.x * kBlock + threadIdx.x, l = blockIdx.y;
+    if (e >= nz * nx) return;
+    const int i = e / nx, j = e - i * nx;
+    const Kern k{kind, ell[l], var[l]};
+    out[(size_t)l * nz * nx + e] = k_val(k, Z[(size_t)i * D + l], X[(size_t)j * D + l]) + (i == j ? jitter : 0.0);
+}
+
 }  // namespace
+
+int vg_launch_cov_matrices(int kind, const double* Z, int nz, const double* X, int nx, int L, const double* ell,
+                           const double* var, double jitter, double* out, hipStream_t st) {
+    if (nz * nx == 0) return 0;
+    hipLaunchKernelGGL(cov_matrices_kernel, dim3((nz * nx + kBlock - 1) / kBlock, L), dim3(kBlock), 0, st, kind, Z, nz, X, nx, L,
+                       ell, var, jitter, out);
+    return (int)hipGetLastError();
+}
 
 int vg_launch_kernel_derivative(int kind, int order, const double* x, int n, const double* y, int m, double ell, double var,
                                 double* out, hipStream_t st) {

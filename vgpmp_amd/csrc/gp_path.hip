@@ -3037,6 +3037,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             mark();
             hipLaunchKernelGGL(cov_a_kernel, dim3(L, P), dim3(kCovThreads), lds_cov_a, st, ca);
             if ((rc = launch(fn_cov_b, cov_b_grid, &ca, lds_cov_b))) return rc;
+            if (what & VGPMP_COV_ONLY) return (int)hipGetLastError();     // Kuu, Cholesky, q_sqrt, A, per-latent KL: done
             mark();
             if (gen && (rc = vg_launch_rng(d, nz, seed, problem_base, step_i, ctr, st))) return rc;
             mark();

@@ -288,6 +288,8 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
 int vg_loglik_blocks_per_problem(int S, int N);
 int vg_launch_kernel_derivative(int kind, int order, const double* x, int n, const double* y, int m, double ell, double var,
                                 double* out, hipStream_t st);
+int vg_launch_cov_matrices(int kind, const double* Z, int nz, const double* X, int nx, int L, const double* ell,
+                           const double* var, double jitter, double* out, hipStream_t st);
 int vg_launch_velocity_kuu_kuf(int kind, const double* Zy, const double* X, int Mz, int N, int L, int D, const double* ell,
                                const double* var, double jitter, double* Kuu, double* Kuf, hipStream_t st);
 int vg_launch_mesh_sdf(const double* tri, const int* part, int T, int nx, int ny, int nz, const double* origin,

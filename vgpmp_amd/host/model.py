@@ -6,9 +6,7 @@
   Kuu / Kuf / Kfu / K_conditioned / prior_kl   covariances/, kernel_conditioning/, kullback_leiblers/
 
 One `VGPMP` owns a one-problem `PlannerBatch`; every evaluation (elbo, optimisation step, posterior
-sampling, log_prob) is a C-ABI call into libvgpmp_hip.so.  The small dispatcher functions at the bottom
-exist for API completeness (inspection of Kuu/Kuf); the hot path forms those matrices inside
-cov_a_kernel / cov_b_kernel and never calls them.
+sampling, log_prob, the covariance / KL dispatchers) is a C-ABI call into libvgpmp_hip.so.
 """
 from __future__ import annotations
 
@@ -29,11 +27,8 @@ class Matern52:
         self.variance = variance if isinstance(variance, Parameter) else Parameter(variance, name="variance")
 
     def __call__(self, X, X2=None):
-        X = torch.as_tensor(np.asarray(X, dtype=np.float64))
-        X2 = X if X2 is None else torch.as_tensor(np.asarray(X2, dtype=np.float64))
-        r = (X.reshape(-1, 1) - X2.reshape(1, -1)).abs() / float(self.lengthscales)
-        r = torch.sqrt(torch.clamp(r * r, min=1e-36))
-        return float(self.variance) * (1 + 5 ** 0.5 * r + 5.0 / 3.0 * r * r) * torch.exp(-5 ** 0.5 * r)
+        from .covariances import kernel_matrix
+        return kernel_matrix(self, X, X2)               # vgpmp_cov_matrices
 
 
 class SquaredExponential:
@@ -42,10 +37,8 @@ class SquaredExponential:
         self.variance = variance if isinstance(variance, Parameter) else Parameter(variance, name="variance")
 
     def __call__(self, X, X2=None):
-        X = torch.as_tensor(np.asarray(X, dtype=np.float64))
-        X2 = X if X2 is None else torch.as_tensor(np.asarray(X2, dtype=np.float64))
-        d = (X.reshape(-1, 1) - X2.reshape(1, -1)) / float(self.lengthscales)
-        return float(self.variance) * torch.exp(-0.5 * d * d)
+        from .covariances import kernel_matrix
+        return kernel_matrix(self, X, X2)               # vgpmp_cov_matrices
 
 
 class SeparateIndependent:
@@ -360,49 +353,6 @@ class VGPMP:
         return float(self.likelihood.log_prob(data).mean(0).sum())
 
 
-# ---------------------------------------------------------------- dispatcher look-alikes -------------------
-def K_conditioned(Z, X, kernel):
-    """kernel_conditioning: stack of per-latent Matern52(Z[:, l], X[:, l])  -> [L, |Z|, |X|]."""
-    Zy = Z.Zy if hasattr(Z, "Zy") else np.asarray(Z)
-    Xv = X.Zy if hasattr(X, "Zy") else np.asarray(X)
-    if isinstance(kernel, SeparateIndependent):
-        return torch.stack([k(Zy[:, i], Xv[:, i]) for i, k in enumerate(kernel.kernels)], 0)
-    return kernel(Zy, Xv)
-
-
-def Kuu(inducing_variable, kernel, *, jitter: float = 0.0):
-    """covariances/multioutput/Kuus.py:42-53 (vanilla) and :17-39 (velocity-constrained variant, on the device)."""
-    iv = getattr(inducing_variable, "inducing_variable", inducing_variable)
-    if isinstance(kernel, FirstOrderKernelDerivativeSeparateIndependent):
-        from . import derivatives
-        return derivatives.velocity_kuu_kuf(iv, kernel, iv.Zy, jitter)[0]
-    K = K_conditioned(iv, iv, kernel)
-    return K + jitter * torch.eye(K.shape[-1], dtype=K.dtype)
-
-
-def Kuf(inducing_variable, kernel, Xnew):
-    """covariances/multioutput/Kufs.py:26-34 (vanilla) and :14-23 (velocity-constrained variant, on the device)."""
-    iv = getattr(inducing_variable, "inducing_variable", inducing_variable)
-    if isinstance(kernel, FirstOrderKernelDerivativeSeparateIndependent):
-        from . import derivatives
-        return derivatives.velocity_kuu_kuf(iv, kernel, Xnew, 0.0)[1]
-    return K_conditioned(iv, Xnew, kernel)
-
-
-def Kfu(inducing_variable, kernel, Xnew):
-    """covariances/Kfus.py:36-42."""
-    return Kuf(inducing_variable, kernel, Xnew).transpose(-1, -2)
-
-
-def prior_kl(inducing_variable, kernel, q_mu, q_sqrt, query_states):
-    """kullback_leiblers/prior_kl.py:16-35 evaluated with torch float64 (inspection only; the hot path
-    computes the same quantity in cov_b_kernel)."""
-    K = Kuu(inducing_variable, kernel, jitter=gpflow.default_jitter())
-    Lc = torch.linalg.cholesky(K)
-    y = torch.as_tensor(np.asarray(query_states, dtype=np.float64))
-    qm = torch.cat([y, torch.as_tensor(np.asarray(q_mu, dtype=np.float64))], 0)
-    Q = torch.tril(torch.as_tensor(np.asarray(q_sqrt, dtype=np.float64)))
-    p_mu = K[..., :2] @ torch.cholesky_solve(y.T[..., None], Lc[..., :2, :2])
-    wd = torch.linalg.solve_triangular(Lc, qm.T[..., None] - p_mu, upper=False)[:, 2:, 0]
-    M = Q.shape[-1]
-    return 0.5 * ((wd ** 2).sum() - wd.numel() - torch.log(torch.diagonal(Q, dim1=-2, dim2=-1) ** 2).sum() + (Q ** 2).sum())
+# ---------------------------------------------------------------- dispatchers ------------------------------
+# Kuu / Kuf / Kfu / K_conditioned / prior_kl: vgpmp_amd/host/covariances.py (every number from the device)
+from .covariances import K_conditioned, Kfu, Kuf, Kuu, prior_kl  # noqa: E402,F401
