@@ -73,3 +73,46 @@ def test_fill_order_independent_variables_and_problemsets():
         robots.load_problemset("franka", "kitchen")
     arm = robots.synthetic_arm(14)
     assert arm.dof == 14 and arm.num_spheres == 45 and list(arm.sphere_frame) == sorted(arm.sphere_frame)
+
+
+def test_robot_tables_pinned_on_the_reference_known_answers():
+    """pybullet-free robot tables.  What the reference's own tests hold for them:
+    tests/test_robot.py:62-67 -- pybullet's inertial-frame offsets of UR10's active links -- must equal the URDF inertial
+    origins the sphere offsets here are expressed against (utils/robot.py:482-499 reports a sphere visual's origin in the
+    link's INERTIAL frame); :70-73 the base pose of the benchmark orientation.  Counts against the robots' config.yaml."""
+    import json
+    from pathlib import Path
+    from vgpmp_amd import robots as rb
+    kat = json.load(open(Path(__file__).resolve().parent / "golden" / "ur10_inertial_kat.json"))
+    tab = json.load(open(Path(rb.__file__).resolve().parent / "data" / "robots.json"))
+    ur = tab["ur10"]
+    got = [ur["inertial_origins"][name] for name in ur["active_links"]]
+    assert got == kat["ur10_joint_link_offsets"]
+    np.testing.assert_allclose(rb.base_pose_matrix((0, 0, 0), (0, 0, -1, 0)), np.array(kat["base_pose_benchmark"]), atol=1e-15)
+    counts = {"franka": [2, 3, 3, 4, 4, 7, 3, 11], "wam": [9, 4, 1, 11], "ur10": [1, 6, 7, 1, 2], "kuka": [2, 3, 3, 3, 4, 2, 3, 1]}
+    for name, t in tab.items():
+        assert t["num_spheres_per_link"] == counts[name]
+        assert sum(t["num_spheres_per_link"]) == t["num_spheres_config"] == len(t["radius"]) == len(t["sphere_offsets"])
+        assert len(t["num_spheres_per_link"]) == t["num_frames_for_spheres"] == len(t["fk_slice"])
+        # a sphere's stored offset = R_inertial^T (visual origin - inertial origin), then the per-index correction of
+        # utils/sampler.py:68-101; UR10's sphere links have identity inertial rotations, so the first step is a subtraction
+        spec = rb.load_robot(name)
+        assert spec.num_spheres == t["num_spheres_config"] and list(spec.sphere_frame) == sorted(spec.sphere_frame)
+    # which branch of sampler.get_mat every sphere index takes (utils/sampler.py:68-101), robot by robot
+    branches = {
+        "franka": {"identity": list(range(37))},
+        "ur10": {"else": [0] + list(range(7, 17)), "0<index<7": list(range(1, 7))},
+        "wam": {"index<8": list(range(8)), "index==8": [8], "8<index<=12": [9, 10, 11, 12], "else(13,14)": [13, 14],
+                "index>14": list(range(15, 25))},
+        "kuka": {"else": [0, 1, 20], "2<=index<5": [2, 3, 4], "5<=index<8": [5, 6, 7], "8<=index<11": [8, 9, 10],
+                 "11<=index<15": [11, 12, 13, 14], "15<=index<17": [15, 16], "17<=index<20": [17, 18, 19]},
+    }
+    for name, want in branches.items():
+        got = {}
+        for i, b in enumerate(tab[name]["sphere_offset_branch"]):
+            got.setdefault(b, []).append(i)
+        assert got == want, name
+    # UR10 spheres 1..6 (the upper arm: link with inertial origin z = 0.306) carry the +0.163941 + 0.05 shift of :83-84
+    raw, cor = np.array(ur["sphere_offsets_urdf"]), np.array(ur["sphere_offsets"])
+    np.testing.assert_allclose(cor[1:7], np.stack([raw[1:7, 2], raw[1:7, 0], raw[1:7, 1] + 0.163941 + 0.05], 1), atol=1e-15)
+    np.testing.assert_allclose(cor[7:], np.stack([raw[7:, 2], raw[7:, 0], raw[7:, 1]], 1), atol=1e-15)

@@ -63,6 +63,32 @@ def urdf_spheres(path):
     return out
 
 
+def urdf_inertial_origins(path):
+    """{link name: xyz of <inertial><origin>} for every link (zeros when absent): what pybullet reports as the link's
+    localInertialFramePosition (utils/robot.py:366-373 joint_link_offsets; KAT tests/test_robot.py:62-67)."""
+    root = ET.parse(path).getroot()
+    out = {}
+    for link in root.findall("link"):
+        ino = link.find("inertial/origin")
+        out[link.get("name")] = floats(ino.get("xyz") if ino is not None else None, (0, 0, 0))
+    return out
+
+
+def offset_branch(robot, index):
+    """Which branch of gpflow_vgpmp/utils/sampler.py:68-101 sphere `index` takes (documentation of the table below)."""
+    if robot == "wam":
+        return ("index<8" if index < 8 else "8<index<=12" if 8 < index <= 12 else "index>14" if index > 14
+                else "index==8" if index == 8 else "else(13,14)")
+    if robot == "ur10":
+        return "0<index<7" if 0 < index < 7 else "else"
+    if robot == "kuka":
+        for lo, hi in ((2, 5), (5, 8), (8, 11), (11, 15), (15, 17), (17, 20)):
+            if lo <= index < hi:
+                return f"{lo}<=index<{hi}"
+        return "else"
+    return "identity"
+
+
 def corrected_offset(robot, index, off):
     """Numbers of gpflow_vgpmp/utils/sampler.py:68-101 (per-index sphere offset fixes)."""
     x, y, z = off
@@ -152,6 +178,9 @@ def main():
             num_spheres_per_link=[len(s) for _, s in links],
             sphere_offsets_urdf=raw,
             sphere_offsets=[corrected_offset(robot, i, o) for i, o in enumerate(raw)],
+            sphere_offset_branch=[offset_branch(robot, i) for i in range(len(raw))],
+            num_spheres_config=int(cfg["num_spheres"]),
+            inertial_origins=urdf_inertial_origins(ref / "data/robots" / robot / urdf),
             joint_names=cfg["joint_names"], default_pose=[float(v) for v in cfg["default_pose"]],
             active_joints=cfg["active_joints"], active_links=cfg["active_links"],
             link_name_base=cfg["link_name_base"], link_name_wrist=cfg["link_name_wrist"])
