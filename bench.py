@@ -220,6 +220,7 @@ def main():
                     help="free-space brick summary in the batch likelihood kernel (auto: tables beyond the Infinity Cache)")
     ap.add_argument("--lik-form", choices=("auto", "lanes", "lanes-lds"), default="auto",
                     help="likelihood kernel form (measurement): lanes = the batch form at any batch size, lanes-lds = with its per-frame sums in LDS")
+    ap.add_argument("--flags", type=int, default=0, help="extra VGPMP_* measurement flags (include/vgpmp.h) OR-ed into every step")
     ap.add_argument("--min-seconds", type=float, default=0.5,
                     help="the timed region repeats the K steps until this much time has passed (K = --steps alone is ~1 ms)")
     ap.add_argument("--workload", choices=("config2", "stress"), default="config2",
@@ -247,7 +248,7 @@ def main():
         args.samples = 1024                                  # BASELINE config 4
     ps, spec, grid, scene, planner = build_problem(rank, args)
     from vgpmp_amd import capi
-    planner.extra_flags |= {"auto": 0, "lanes": capi.LIK_LANES, "lanes-lds": capi.LIK_LDS_STATE}[args.lik_form]
+    planner.extra_flags |= {"auto": 0, "lanes": capi.LIK_LANES, "lanes-lds": capi.LIK_LDS_STATE}[args.lik_form] | args.flags
     if args.shard == "samples":
         return run_sample_sharded(args, world, rank, dist, backend, ps, spec, scene, planner)
     for _ in range(args.warmup):

@@ -438,8 +438,18 @@ def chol_backward(Lc: np.ndarray, Lbar: np.ndarray) -> np.ndarray:
     return 0.5 * (Sm + Sm.T)
 
 
-def elbo_backward(p: Params, scene: Scene, X, Zy, noise: Noise, alpha: float, fw, jitter=JITTER):
-    """Gradient of loss = -ELBO wrt the unconstrained variables (analytic reverse pass)."""
+def matern52_dz(t1, t2, ell, var):
+    """d k(t1_i, t2_j) / d t1_i for the Matern-5/2 kernel: -var (5/3) (d / ell^2) (1 + sqrt5 r) exp(-sqrt5 r), d = t1_i - t2_j."""
+    d = t1[:, None] - t2[None, :]
+    r = np.abs(d) / ell
+    return -var * (5.0 / 3.0) * d / ell ** 2 * (1.0 + math.sqrt(5.0) * r) * np.exp(-math.sqrt(5.0) * r)
+
+
+def elbo_backward(p: Params, scene: Scene, X, Zy, noise: Noise, alpha: float, fw, jitter=JITTER, want_z=False):
+    """Gradient of loss = -ELBO wrt the unconstrained variables (analytic reverse pass).  With want_z also d loss / d Zy
+    [Mz, D] (rows 0, 1 = the conditioned times, constants; rows 2.. = the inducing locations Z of models/vgpmp.py:37-42,
+    trainable with trainable_params.inducing_variable): column l through latent l's Kuu / Kuf, every column through the
+    random-feature prior of every latent at the rows of Zy."""
     rb = scene.robot
     cv = fw['cv']; N, Mz, S = fw['N'], fw['Mz'], fw['S']
     L, M = p.q_sqrt.shape[0], p.q_sqrt.shape[1]
@@ -449,6 +459,8 @@ def elbo_backward(p: Params, scene: Scene, X, Zy, noise: Noise, alpha: float, fw
     G = (-(alpha / S) * fw['dlogp_dg'] * dg_df).transpose(0, 2, 1)     # dloss/df [S, L, N]
     g_qmu = np.zeros_like(p.q_mu); g_qs = np.zeros_like(p.q_sqrt)
     g_ell = np.zeros(L); g_var = np.zeros(L)
+    g_zy = np.zeros_like(np.asarray(Zy, dtype=np.float64))
+    B = noise.omega.shape[1]
     for l in range(L):
         Gl, A, Rl = G[:, l, :], cv['A'][l], fw['R'][:, l, :]
         El = noise.eps[:, :, l]
@@ -493,6 +505,19 @@ def elbo_backward(p: Params, scene: Scene, X, Zy, noise: Noise, alpha: float, fw
             + np.sum(dKfu * matern52_dell(x, z, ell[l], var[l]))
         g_ell[l] = g_ell_l * sigmoid(p.raw_ell[l])
         g_var[l] = g_var_l * sigmoid(p.raw_var[l])
+        if want_z:
+            # Kuu[i, j] = k(z_i, z_j): z_i enters row i and column i;  Kfu[n, i] = k(x_n, z_i)
+            dk = matern52_dz(z, z, ell[l], var[l])                    # d k(z_i, z_j) / d z_i
+            g_zy[:, l] += np.sum((dKj + dKj.T) * dk, axis=1)
+            g_zy[:, l] += np.sum(dKfu * matern52_dz(z, x, ell[l], var[l]).T, axis=0)
+            # prior draw at the rows of Zy: F0Z[s, i] = sum_b w[s, b] c cos(Zy[i, :] . omega[b, :] / ell + beta[b]),
+            # R = u - F0Z - ...  =>  d loss / d F0Z = -dR
+            arg = (Zy @ noise.omega[l].T) / ell[l] + noise.beta[l][None]            # [Mz, B]
+            Tm = dR.T @ noise.w[:, l, :]                                            # [Mz, B]
+            coef = math.sqrt(2.0 * var[l] / B) / ell[l]
+            g_zy += coef * (Tm * np.sin(arg)) @ noise.omega[l]                      # [Mz, D]
+    if want_z:
+        return Params(g_qmu, g_qs, g_ell, g_var), G, g_zy
     return Params(g_qmu, g_qs, g_ell, g_var), G
 
 
@@ -536,6 +561,55 @@ def optimization_step(p, st, scene, X, Zy, y, noise, alpha, lr, trainable=DEFAUL
     fw = elbo_forward(p, scene, X, Zy, y, noise, alpha, want_dell=trainable.get("lengthscales", True))
     g, _ = elbo_backward(p, scene, X, Zy, noise, alpha, fw)
     adam_step(p, g, st, lr, trainable)
+    return -fw['elbo']
+
+
+# ----------------------------------------------------------------------------
+# Inducing locations as trainable variables (A14: trainable_params.inducing_variable)
+# ----------------------------------------------------------------------------
+Z_LOW, Z_HIGH = 0.09, 0.91     # models/vgpmp.py:41  bounded_Z(low=0.09, high=0.91): tfb.Sigmoid(low, high)
+
+
+def z_constrained(raw_Z: np.ndarray) -> np.ndarray:
+    return Z_LOW + (Z_HIGH - Z_LOW) * sigmoid(raw_Z)
+
+
+def z_unconstrained(Z: np.ndarray) -> np.ndarray:
+    x = (np.asarray(Z, dtype=np.float64) - Z_LOW) / (Z_HIGH - Z_LOW)
+    return np.log(x) - np.log1p(-x)
+
+
+def init_raw_Z(num_inducing: int, dof: int) -> np.ndarray:
+    """models/vgpmp.py:37-42: Z[m, :] = linspace(0.1, 0.9, M)[m] * 1_D, held in unconstrained space."""
+    return z_unconstrained(np.tile(np.linspace(0.1, 0.9, num_inducing)[:, None], (1, dof)))
+
+
+def zy_from_raw(raw_Z: np.ndarray) -> np.ndarray:
+    """inducing_variables.py:73-82: Zy = [conditioned times 0 and 1; Z]."""
+    D = raw_Z.shape[1]
+    return np.concatenate([np.zeros((1, D)), np.ones((1, D)), z_constrained(raw_Z)], axis=0)
+
+
+def z_backward(raw_Z: np.ndarray, g_zy: np.ndarray) -> np.ndarray:
+    """d loss / d raw_Z from d loss / d Zy (rows 0, 1 are constants)."""
+    sg = sigmoid(raw_Z)
+    return g_zy[2:] * (Z_HIGH - Z_LOW) * sg * (1.0 - sg)
+
+
+def optimization_step_z(p, raw_Z, st, st_z, scene, X, y, noise, alpha, lr, trainable,
+                        beta1=0.8, beta2=0.95, eps=1e-7):
+    """One optimisation step with the inducing locations among the variables (same optimizer, shared step count).
+    st_z = dict(m=..., v=...) like raw_Z.  Updates p, raw_Z in place; returns the loss."""
+    Zy = zy_from_raw(raw_Z)
+    fw = elbo_forward(p, scene, X, Zy, y, noise, alpha, want_dell=trainable.get("lengthscales", True))
+    g, _, g_zy = elbo_backward(p, scene, X, Zy, noise, alpha, fw, want_z=True)
+    gz = z_backward(raw_Z, g_zy)
+    adam_step(p, g, st, lr, trainable)                  # advances st.t
+    if trainable.get("inducing_variable", False):
+        lr_t = lr * math.sqrt(1.0 - beta2 ** st.t) / (1.0 - beta1 ** st.t)
+        st_z["m"] += (gz - st_z["m"]) * (1.0 - beta1)
+        st_z["v"] += (gz * gz - st_z["v"]) * (1.0 - beta2)
+        raw_Z -= lr_t * st_z["m"] / (np.sqrt(st_z["v"]) + eps)
     return -fw['elbo']
 
 

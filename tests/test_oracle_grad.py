@@ -110,3 +110,31 @@ def test_optimization_reduces_loss():
         losses.append(orc.optimization_step(p, st, pb["scene"], pb["X"], pb["Zy"], pb["y"], noise, pb["alpha"], 0.02))
     assert np.isfinite(losses).all()
     assert np.mean(losses[-3:]) < np.mean(losses[:3])
+
+
+@pytest.mark.parametrize("robot", ["franka", "ur10"])
+def test_inducing_location_gradient_matches_autograd(robot):
+    """trainable_params.inducing_variable (utils/miscellaneous.py:338): Z = 0.09 + 0.82 sigmoid(raw_Z) [M, D]
+    (models/vgpmp.py:29-42), every column with its own values.  The oracle's analytic d loss / d raw_Z -- through Kuu, Kuf,
+    the Cholesky factor (q_sqrt assembly, exact update, KL) and through the random-feature prior evaluated at the rows of
+    Zy -- against torch.autograd on the independent restatement, at perturbed (non-replicated) locations."""
+    pb = small_problem(robot=robot, S=5, N=8, M=4, B=32, seed=3)
+    D = pb["scene"].robot.dof
+    rng = np.random.default_rng(1)
+    raw_Z = orc.init_raw_Z(4, D) + 0.3 * rng.standard_normal((4, D))
+    np.testing.assert_allclose(orc.zy_from_raw(orc.init_raw_Z(4, D)), pb["Zy"], rtol=0, atol=1e-15)
+    Zy = orc.zy_from_raw(raw_Z)
+    fw = orc.elbo_forward(pb["params"], pb["scene"], pb["X"], Zy, pb["y"], pb["noise"], pb["alpha"])
+    grads, _, g_zy = orc.elbo_backward(pb["params"], pb["scene"], pb["X"], Zy, pb["noise"], pb["alpha"], fw, want_z=True)
+    gz = orc.z_backward(raw_Z, g_zy)
+    e, leaves, aux = torch_ref.elbo(pb["params"], pb["scene"], pb["X"], None, pb["y"], pb["noise"], pb["alpha"], raw_Z=raw_Z)
+    assert (fw["logp"] < 0).any(), "fixture must have active hinge terms"
+    np.testing.assert_allclose(fw["elbo"], float(e), rtol=1e-9)
+    (-e).backward()
+    want = leaves["raw_Z"].grad.numpy()
+    assert np.abs(want).max() > 1e-3
+    assert np.abs(gz - want).max() / np.abs(want).max() < 2e-6, np.abs(gz - want).max()
+    # the other variables' gradients are unaffected by how Zy was produced
+    for name in ("q_mu", "raw_ell"):
+        w2 = leaves[name].grad.numpy()
+        assert np.abs(getattr(grads, name) - w2).max() / (np.abs(w2).max() + 1e-30) < 2e-6

@@ -63,7 +63,7 @@ def matern52(t1, t2, ell, var):
     return var * (1 + math.sqrt(5) * r + 5.0 / 3.0 * r2) * torch.exp(-math.sqrt(5) * r)
 
 
-def elbo(params: orc.Params, scene: orc.Scene, X, Zy, y, noise: orc.Noise, alpha, jitter=orc.JITTER, lik=None):
+def elbo(params: orc.Params, scene: orc.Scene, X, Zy, y, noise: orc.Noise, alpha, jitter=orc.JITTER, lik=None, raw_Z=None):
     """Returns (elbo tensor, leaf tensors dict).  With `lik` (orc.LikParams) alpha and sigma_obs are functions of
     the extra leaves raw_alpha / raw_sigma (positive(lower) bijectors of GPflow: lower + softplus)."""
     rb = scene.robot
@@ -77,7 +77,14 @@ def elbo(params: orc.Params, scene: orc.Scene, X, Zy, y, noise: orc.Noise, alpha
         sigma = orc.SIGMA_FLOOR + torch.nn.functional.softplus(leaves["raw_sigma"])
     ell = torch.nn.functional.softplus(leaves["raw_ell"])
     var = orc.VARIANCE_FLOOR + torch.nn.functional.softplus(leaves["raw_var"])
-    X, Zy = T(X), T(Zy)
+    X = T(X)
+    if raw_Z is not None:       # inducing locations as a leaf: Zy = [0; 1; 0.09 + 0.82 sigmoid(raw_Z)]  (models/vgpmp.py:29-42)
+        leaves["raw_Z"] = T(raw_Z).clone().requires_grad_()
+        Zv = orc.Z_LOW + (orc.Z_HIGH - orc.Z_LOW) * torch.sigmoid(leaves["raw_Z"])
+        D = Zv.shape[1]
+        Zy = torch.cat([torch.zeros(1, D, dtype=torch.float64), torch.ones(1, D, dtype=torch.float64), Zv], 0)
+    else:
+        Zy = T(Zy)
     low, high = T(rb.low), T(rb.high)
     y01 = (T(y) - low) / (high - low)
     y_u = torch.log(y01) - torch.log1p(-y01)
