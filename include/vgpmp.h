@@ -156,6 +156,22 @@ typedef struct vgpmp_lik_params {
     void* scratch;         /* dev, vgpmp_lik_scratch_bytes(dims) bytes: effective constants, per-workgroup sums */
 } vgpmp_lik_params;
 
+/* The inducing locations as TRAINABLE variables (trainable_params.inducing_variable of utils/miscellaneous.py:338; reference
+ * default: fixed).  Optional: with problem->ind == NULL, problem->Zy is the one set of times every problem uses.  Otherwise,
+ * per problem, Z = 0.09 + 0.82 sigmoid(raw_Z) [M, L] (models/vgpmp.py:29-42, tfb.Sigmoid(0.09, 0.91); every column its own
+ * values) and Zy = [0; 1; Z]: the library writes `Zy` from raw_Z at the start of every evaluation and uses it in place of
+ * problem->Zy.  Column l feeds latent l's Kuu / Kuf (kernel_conditioning/multioutput/cond_kernel.py:17-25), whole rows feed
+ * the random-feature prior of every latent.  The gradient goes in REVERSE through A = Kfu (Kuu + jI)^-1, the Cholesky factor
+ * (q_sqrt assembly, KL) and the prior draw at Zy.  One launch per kernel; not available with a sharded sample axis. */
+typedef struct vgpmp_inducing_params {
+    double* raw_Z;         /* dev [P, M, L]                   */
+    double* m_Z;           /* dev, Adam moments, same shape (may be NULL without VGPMP_DO_ADAM) */
+    double* v_Z;
+    double* g_Z;           /* dev [P, M, L]   out: d loss / d raw_Z */
+    double* Zy;            /* dev [P, Mz, L]  out: conditioned + inducing times of every problem */
+    void* scratch;         /* dev, vgpmp_inducing_scratch_bytes(dims) bytes */
+} vgpmp_inducing_params;
+
 typedef struct vgpmp_problem {
     const double* X;       /* dev [N, D]   time grid (utils/miscellaneous.py:115-127)        */
     const double* Zy;      /* dev [Mz, D]  conditioned + inducing times (inducing_variables.py:73-82) */
@@ -168,6 +184,7 @@ typedef struct vgpmp_problem {
                              * VGPMP_DO_ADAM step increments it on the device, so a captured hipGraph of
                              * the steps can be replayed */
     const vgpmp_lik_params* lik; /* host pointer, optional (see vgpmp_lik_params) */
+    const vgpmp_inducing_params* ind; /* host pointer, optional (see vgpmp_inducing_params) */
 } vgpmp_problem;
 
 /* Outputs of an ELBO evaluation. */
@@ -185,6 +202,7 @@ typedef struct vgpmp_outputs {
 #define VGPMP_TRAIN_KERNEL_VARIANCE 8
 #define VGPMP_TRAIN_SIGMA_OBS 16      /* needs problem->lik */
 #define VGPMP_TRAIN_ALPHA 32          /* needs problem->lik */
+#define VGPMP_TRAIN_INDUCING 64       /* needs problem->ind */
 
 #define VGPMP_DO_FORWARD 1      /* ELBO forward only (models/vgpmp.py:265-289)               */
 #define VGPMP_DO_BACKWARD 2     /* + gradient of -ELBO (utils/miscellaneous.py:77-80)        */
@@ -271,6 +289,9 @@ int vgpmp_workspace_bytes(const vgpmp_dims* dims, size_t* bytes);
 
 /* Size of vgpmp_lik_params.scratch for these dimensions. */
 int vgpmp_lik_scratch_bytes(const vgpmp_dims* dims, size_t* bytes);
+
+/* Size of vgpmp_inducing_params.scratch for these dimensions. */
+int vgpmp_inducing_scratch_bytes(const vgpmp_dims* dims, size_t* bytes);
 
 /* Fills `noise` with the Philox-4x32-10 draws of (seed, problem index, step). */
 int vgpmp_generate_noise(const vgpmp_dims* dims, const vgpmp_noise* noise, uint32_t seed,

@@ -373,3 +373,107 @@ def test_full_size_properties():
     # paths are pinned to start/goal by the 1e-6 conditioning: sample spread at t=0 and t=1 is tiny
     y = torch.tensor(q[0], device=g.device, dtype=g.dtype)
     assert float((g[0, :, 0, :] - y[0]).abs().max()) < 5e-2 and float((g[0, :, -1, :] - y[1]).abs().max()) < 5e-2
+
+
+@pytest.mark.parametrize("robot,S,N,M,B,P", [("franka", 8, 12, 6, 64, 1), ("ur10", 24, 20, 10, 128, 2), ("franka", 128, 100, 30, 1024, 1)])
+def test_inducing_location_gradient_against_oracle(robot, S, N, M, B, P):
+    """trainable_params.inducing_variable (utils/miscellaneous.py:338; Z = 0.09 + 0.82 sigmoid(raw_Z), models/vgpmp.py:29-42):
+    d loss / d raw_Z of every problem from the device's reverse pass (float64 covariance / Cholesky adjoint, float32 sums over
+    the samples, the random-feature prior at the rows of Zy) against the oracle, at perturbed, column-wise different
+    locations; the other gradients are unaffected by where Zy comes from."""
+    pb = small_problem(robot=robot, S=S, N=N, M=M, B=B, seed=11, n_grid=48)
+    sc = _scene(pb["spec"], pb["grid"], pb["offset"])
+    D = pb["spec"].dof
+    tr = dict(orc.DEFAULT_TRAINABLE, inducing_variable=True)
+    eng = _engine()
+    ps = rb.load_problemset(robot, "industrial")
+    pl = eng.PlannerBatch(sc, np.repeat(pb["y"][None], P, 0), lengthscales=ps.planner_params["lengthscales"],
+                          variance=ps.planner_params["variance"], trainable=tr, num_samples=S, num_inducing=M, num_data=N,
+                          num_bases=B, alpha=pb["alpha"], learning_rate=pb["lr"])
+    assert pl.z_variables
+    np.testing.assert_allclose(pl.raw_Z[0].cpu().numpy(), orc.init_raw_Z(M, D), rtol=1e-12)
+    rng = np.random.default_rng(6)
+    raws = [orc.init_raw_Z(M, D) + 0.25 * rng.standard_normal((M, D)) for _ in range(P)]
+    p = pb["params"]
+    for k in range(P):
+        pl.q_mu[k].copy_(torch.tensor(p.q_mu.T)); pl.q_sqrt[k].copy_(torch.tensor(p.q_sqrt))
+        pl.raw_ell[k].copy_(torch.tensor(p.raw_ell)); pl.raw_var[k].copy_(torch.tensor(p.raw_var))
+        pl.raw_Z[k].copy_(torch.tensor(raws[k]))
+    noise = _noise32(pb["noise"])
+    rep = lambda a: np.repeat(a[None], P, 0)
+    pl.set_noise(rep(noise.omega), rep(noise.beta), rep(noise.w), rep(noise.eps), rep(noise.eps2))
+    loss, grads = pl.loss_and_grad(generate=False)
+    torch.cuda.synchronize()
+    for k in range(P):
+        Zy = orc.zy_from_raw(raws[k])
+        np.testing.assert_allclose(pl.Zy_all[k].cpu().numpy(), Zy, rtol=1e-13, atol=1e-15)
+        fw = orc.elbo_forward(p, pb["scene"], pb["X"], Zy, pb["y"], noise, pb["alpha"])
+        og, _, g_zy = orc.elbo_backward(p, pb["scene"], pb["X"], Zy, noise, pb["alpha"], fw, want_z=True)
+        want = orc.z_backward(raws[k], g_zy)
+        assert (fw["logp"] < 0).any()
+        ok = np.isclose(pl.logp[k].cpu().numpy(), fw["logp"], rtol=2e-3, atol=1e-4)
+        flips = 1.0 - ok.mean()
+        np.testing.assert_allclose(float(pl.kl[k]), fw["cv"]["kl"], rtol=1e-9)
+        got = pl.z_grad[k].cpu().numpy()
+        scale = np.abs(want).max()
+        assert scale > 1e-3
+        assert np.abs(got - want).max() / scale < 50 * flips + 3e-3, (np.abs(got - want).max(), scale, flips)
+        gq = grads[0][k].cpu().numpy().T
+        assert np.abs(gq - og.q_mu).max() <= (50 * flips + 3e-3) * np.abs(og.q_mu).max()
+        ge = grads[2][k].cpu().numpy()
+        assert np.abs(ge - og.raw_ell).max() <= (50 * flips + 3e-3) * np.abs(og.raw_ell).max()
+
+
+def test_inducing_location_kl_gradient_is_float64_exact():
+    """alpha = 0: only the KL depends on Z, and that path is float64 on the device: 1e-7."""
+    S, N, M, B = 4, 7, 9, 64
+    pb = small_problem(robot="franka", S=S, N=N, M=M, B=B, seed=5, n_grid=24)
+    sc = _scene(pb["spec"], pb["grid"], pb["offset"])
+    tr = dict(orc.DEFAULT_TRAINABLE, inducing_variable=True)
+    pl = _planner(dict(pb, alpha=0.0), sc, S, N, M, B, split_k=1, trainable=tr)
+    rng = np.random.default_rng(2)
+    raw = orc.init_raw_Z(M, 7) + 0.3 * rng.standard_normal((M, 7))
+    pl.raw_Z[0].copy_(torch.tensor(raw))
+    noise = _noise32(pb["noise"])
+    _inject(pl, noise)
+    pl.loss_and_grad(generate=False)
+    Zy = orc.zy_from_raw(raw)
+    fw = orc.elbo_forward(pb["params"], pb["scene"], pb["X"], Zy, pb["y"], noise, 0.0)
+    _, _, g_zy = orc.elbo_backward(pb["params"], pb["scene"], pb["X"], Zy, noise, 0.0, fw, want_z=True)
+    want = orc.z_backward(raw, g_zy)
+    np.testing.assert_allclose(pl.z_grad[0].cpu().numpy(), want, rtol=1e-7, atol=1e-9 * np.abs(want).max())
+
+
+def test_inducing_location_adam_trajectory_matches_oracle():
+    """Five optimisation steps with the inducing locations among the variables (one optimizer, shared step count); four chained
+    steps of one vgpmp_elbo_steps call reproduce four one-step calls bit for bit."""
+    S, N, M, B = 8, 12, 6, 64
+    pb = small_problem(robot="franka", S=S, N=N, M=M, B=B, seed=7, n_grid=48)
+    sc = _scene(pb["spec"], pb["grid"], pb["offset"])
+    tr = dict(orc.DEFAULT_TRAINABLE, inducing_variable=True)
+    pl = _planner(pb, sc, S, N, M, B, split_k=1, trainable=tr)
+    p = pb["params"].copy(); st = orc.adam_init(p)
+    raw = orc.init_raw_Z(M, 7)
+    st_z = dict(m=np.zeros_like(raw), v=np.zeros_like(raw))
+    rng = np.random.default_rng(3)
+    for step in range(5):
+        noise = _noise32(orc.draw_noise(rng, S, 7, 7, B, M + 2))
+        _inject(pl, noise)
+        pl.step(generate=False)
+        orc.optimization_step_z(p, raw, st, st_z, pb["scene"], pb["X"], pb["y"], noise, pb["alpha"], pb["lr"], tr)
+    tol = 5 * pb["lr"] * 2e-2
+    assert np.abs(pl.raw_Z[0].cpu().numpy() - raw).max() < tol
+    assert np.abs(pl.q_mu[0].cpu().numpy().T - p.q_mu).max() < tol
+    assert np.abs(pl.raw_ell[0].cpu().numpy() - p.raw_ell).max() < tol
+    assert np.abs(raw - orc.init_raw_Z(M, 7)).min() > 1e-3 and np.abs(raw - orc.init_raw_Z(M, 7)).max() > pb["lr"]    # the locations moved
+    Z = pl.inducing_locations()[0].cpu().numpy()
+    assert (Z > 0.09).all() and (Z < 0.91).all()
+    # generated noise: 4 chained steps == 4 single-step calls
+    a = _planner(pb, sc, S, N, M, B, split_k=1, trainable=tr)
+    b = _planner(pb, sc, S, N, M, B, split_k=1, trainable=tr)
+    for _ in range(4):
+        a.run_steps(1)
+    b.run_steps(4)
+    for x, y in ((a.raw_Z, b.raw_Z), (a.q_mu, b.q_mu), (a.raw_ell, b.raw_ell), (a.z_adam_v, b.z_adam_v)):
+        assert torch.equal(x, y)
+    assert float((a.raw_Z - torch.tensor(orc.init_raw_Z(M, 7), device=a.raw_Z.device)).abs().max()) > 0

@@ -90,8 +90,16 @@ def test_model_surface_against_oracle():
     assert mu.shape == (20, 7) and best.shape == (20, 7) and samples.shape == (7, 20, 7) and unc == 2.0
     assert (best >= osc.robot.low - 1e-6).all() and (best <= osc.robot.high + 1e-6).all()
     assert model.get_best_sample(samples) in range(7)
-    with pytest.raises(NotImplementedError):
-        disable_param_opt(model, dict(env.config["trainable_params"], inducing_variable=True))
+    # inducing locations as variables (utils/miscellaneous.py:338; reference default False): the device batch is rebuilt with
+    # them, the trained values show up in the model's inducing variable, inside the Sigmoid(0.09, 0.91) bounds
+    z0 = np.array(model.inducing_variable.inducing_variable.Zy[2:], copy=True)
+    disable_param_opt(model, dict(env.config["trainable_params"], inducing_variable=True))
+    training_loop(model, X, 10)
+    z1 = model.inducing_variable.inducing_variable.Zy[2:]
+    assert z1.shape == z0.shape and np.abs(z1 - z0).max() > 1e-3 and (z1 > 0.09).all() and (z1 < 0.91).all()
+    assert np.array_equal(model.inducing_variable.inducing_variable.Zy[:2], np.stack([np.zeros(7), np.ones(7)]))
+    mu_u, _, _, unc_u = model.sample_from_posterior(orc.init_trainset(20, 7), env.robot, compute_uncertainty=True)
+    assert unc_u.shape == (20, 3) and (unc_u >= 0).all() and mu_u.shape == (20, 7)
     # sigma_obs / alpha as variables (reference default False): the device batch is rebuilt with them and the host
     # parameters follow the trained values
     disable_param_opt(model, dict(env.config["trainable_params"], alpha=True, sigma_obs=True))

@@ -11,8 +11,8 @@ ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB_DIR = PKG / "lib"
 LIB = LIB_DIR / "libvgpmp_hip.so"
-SOURCES = ["fk_sdf.hip", "gp_path.hip", "mesh_sdf.hip", "deriv_kernels.hip", "plan.hip", "comm.hip", "capi.hip"]
-HEADERS = [CSRC / "vgpmp_device.h", CSRC / "gp_path.h", CSRC / "fk_chain.h", ROOT / "include" / "vgpmp.h"]
+SOURCES = ["fk_sdf.hip", "gp_path.hip", "mesh_sdf.hip", "deriv_kernels.hip", "plan.hip", "inducing.hip", "comm.hip", "capi.hip"]
+HEADERS = [CSRC / "vgpmp_device.h", CSRC / "gp_path.h", CSRC / "fk_chain.h", CSRC / "gp_math.h", ROOT / "include" / "vgpmp.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc=0",
          "-Wall", "-Wno-unused-function"]
 

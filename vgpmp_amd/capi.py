@@ -17,13 +17,14 @@ MAX_DOF, MAX_SPHERES, MAX_MZ = 16, 64, 48
 COMM_ID_BYTES = 128
 TRAIN_Q_MU, TRAIN_Q_SQRT, TRAIN_LENGTHSCALES, TRAIN_KERNEL_VARIANCE = 1, 2, 4, 8
 TRAIN_SIGMA_OBS, TRAIN_ALPHA = 16, 32      # need Problem.lik
+TRAIN_INDUCING = 64                       # needs Problem.ind
 DO_FORWARD, DO_BACKWARD, DO_ADAM, GEN_NOISE, NO_FUSE = 1, 2, 4, 8, 16
 GEMM_DIRECT, NO_SPLIT, ELIM_BLOCK, LIK_LANES, LIK_LDS_STATE, COV_ONLY = 32, 64, 128, 256, 512, 2048
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvgpmp_hip.so"
 
 EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_table_bytes", "vgpmp_sdf_pack", "vgpmp_mesh_sdf", "vgpmp_fk_spheres", "vgpmp_sdf_query",
-           "vgpmp_log_prob", "vgpmp_cov_matrices", "vgpmp_kernel_derivative", "vgpmp_velocity_kuu_kuf", "vgpmp_workspace_bytes", "vgpmp_lik_scratch_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
+           "vgpmp_log_prob", "vgpmp_cov_matrices", "vgpmp_kernel_derivative", "vgpmp_velocity_kuu_kuf", "vgpmp_workspace_bytes", "vgpmp_lik_scratch_bytes", "vgpmp_inducing_scratch_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
            "vgpmp_elbo_steps", "vgpmp_elbo_step_profiled", "vgpmp_adam_step", "vgpmp_workspace_view", "vgpmp_sample_paths",
            "vgpmp_comm_unique_id", "vgpmp_comm_init", "vgpmp_allreduce_grads", "vgpmp_comm_destroy")
 NUM_STAGES = 8
@@ -81,10 +82,16 @@ class LikParams(C.Structure):
                 ("scratch", C.c_void_p)]
 
 
+class InducingParams(C.Structure):
+    """vgpmp_inducing_params: the inducing locations as trainable variables (device pointers)."""
+    _fields_ = [("raw_Z", C.c_void_p), ("m_Z", C.c_void_p), ("v_Z", C.c_void_p), ("g_Z", C.c_void_p), ("Zy", C.c_void_p),
+                ("scratch", C.c_void_p)]
+
+
 class Problem(C.Structure):
     _fields_ = [("X", C.c_void_p), ("Zy", C.c_void_p), ("y_u", C.c_void_p), ("alpha", C.c_double),
                 ("jitter", C.c_double), ("kl_scale", C.c_double), ("step_counter", C.c_void_p),
-                ("lik", C.POINTER(LikParams))]
+                ("lik", C.POINTER(LikParams)), ("ind", C.POINTER(InducingParams))]
 
 
 class Outputs(C.Structure):
@@ -130,6 +137,7 @@ def load(require: bool = True) -> Optional[C.CDLL]:
         "vgpmp_velocity_kuu_kuf": [i32, vp, vp, i32, i32, i32, vp, vp, dbl, vp, vp, vp],
         "vgpmp_workspace_bytes": [P(Dims), P(C.c_size_t)],
         "vgpmp_lik_scratch_bytes": [P(Dims), P(C.c_size_t)],
+        "vgpmp_inducing_scratch_bytes": [P(Dims), P(C.c_size_t)],
         "vgpmp_generate_noise": [P(Dims), P(Noise), u32, u32, u32, vp],
         "vgpmp_elbo_step": [P(Dims), vp, P(Sdf), P(Problem), P(Params), P(Params), P(Params), P(Noise), P(Outputs),
                             vp, C.c_size_t, i32, i32, dbl, i32, u32, u32, u32, vp],

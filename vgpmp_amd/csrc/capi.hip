@@ -162,6 +162,15 @@ int vgpmp_lik_scratch_bytes(const vgpmp_dims* dims, size_t* bytes) {
     return 0;
 }
 
+int vgpmp_inducing_scratch_bytes(const vgpmp_dims* dims, size_t* bytes) {
+    if (!dims || !bytes) return VGPMP_E_ARG;
+    int rc = vg_check_dims(dims);
+    if (rc) return rc;
+    vg_ind_scratch sc;
+    *bytes = vg_layout_ind_scratch(dims, nullptr, &sc);
+    return 0;
+}
+
 int vgpmp_generate_noise(const vgpmp_dims* dims, const vgpmp_noise* noise, uint32_t seed, uint32_t problem_base,
                          uint32_t step, vgpmp_stream stream) {
     if (!dims || !noise || !noise->omega || !noise->beta || !noise->w || !noise->eps || !noise->eps2) return VGPMP_E_ARG;
@@ -190,7 +199,7 @@ static int elbo_step_impl(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, 
         if (rc) return rc;
         if (!out->f || !out->logp || !out->lik || !out->kl) return VGPMP_E_ARG;
     }
-    if (!problem->X || !problem->Zy || !problem->y_u) return VGPMP_E_ARG;
+    if (!problem->X || (!problem->Zy && !problem->ind) || !problem->y_u) return VGPMP_E_ARG;
     if (!params->q_mu || !params->q_sqrt || !params->raw_ell || !params->raw_var) return VGPMP_E_ARG;
     if ((what & VGPMP_DO_BACKWARD) &&
         (!out->grad.q_mu || !out->grad.q_sqrt || !out->grad.raw_ell || !out->grad.raw_var))
@@ -199,6 +208,13 @@ static int elbo_step_impl(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, 
         (!(what & VGPMP_DO_BACKWARD) || !adam_m || !adam_v || (adam_t < 1 && !problem->step_counter)))
         return VGPMP_E_ARG;
     if ((trainable & (VGPMP_TRAIN_SIGMA_OBS | VGPMP_TRAIN_ALPHA)) && !problem->lik) return VGPMP_E_ARG;
+    if ((trainable & VGPMP_TRAIN_INDUCING) && !problem->ind) return VGPMP_E_ARG;
+    if (const vgpmp_inducing_params* iv = problem->ind) {
+        if (!iv->raw_Z || !iv->Zy || dims->S_total != dims->S) return VGPMP_E_ARG;
+        if ((what & VGPMP_DO_BACKWARD) && (!iv->g_Z || !iv->scratch)) return VGPMP_E_ARG;
+        if ((what & VGPMP_DO_BACKWARD) && (dims->B % 64) != 0) return VGPMP_E_SHAPE;       // 64 bases per workgroup of the feature part
+        if ((what & VGPMP_DO_ADAM) && (trainable & VGPMP_TRAIN_INDUCING) && (!iv->m_Z || !iv->v_Z)) return VGPMP_E_ARG;
+    }
     if (const vgpmp_lik_params* lk = problem->lik) {
         if (!lk->raw_alpha || !lk->raw_sigma || !lk->scratch || dims->S_total != dims->S) return VGPMP_E_ARG;
         if ((what & VGPMP_DO_BACKWARD) && (!lk->g_alpha || !lk->g_sigma)) return VGPMP_E_ARG;

@@ -1,0 +1,33 @@
+// Scalar float64 helpers shared by the GP kernels: bijectors, the Matern-5/2 kernel, Keras Adam.
+#pragma once
+#include "vgpmp_device.h"
+
+constexpr double kVarFloor = 0.1;               // models/vgpmp.py:139 positive(lower=1e-1)
+constexpr double kSqrt5 = 2.2360679774997896964;
+constexpr double kZLow = 0.09, kZHigh = 0.91;   // models/vgpmp.py:41 bounded_Z: tfb.Sigmoid(0.09, 0.91)
+
+__device__ __forceinline__ double softplus_d(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
+__device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
+__device__ __forceinline__ double matern52(double t1, double t2, double ell, double var) {
+    double r = fabs(t1 - t2) / ell;
+    r = sqrt(fmax(r * r, 1e-36));
+    return var * (1.0 + kSqrt5 * r + (5.0 / 3.0) * r * r) * exp(-kSqrt5 * r);
+}
+// d k(t1, t2) / d t1
+__device__ __forceinline__ double matern52_d1(double t1, double t2, double ell, double var) {
+    const double d = t1 - t2, r = fabs(d) / ell;
+    return -var * (5.0 / 3.0) * d / (ell * ell) * (1.0 + kSqrt5 * r) * exp(-kSqrt5 * r);
+}
+
+__device__ __forceinline__ void adam_update(double* x, double* m, double* v, double g, double lr_t) {
+    // Keras Adam (TF 2.12): beta1 = 0.8, beta2 = 0.95 (models/vgpmp.py:77), epsilon 1e-7
+    double mm = *m + (g - *m) * (1.0 - 0.8);
+    double vv = *v + (g * g - *v) * (1.0 - 0.95);
+    *m = mm; *v = vv;
+    *x -= lr_t * mm / (sqrt(vv) + 1e-7);
+}
+
+// Bias-corrected Adam step size of the update with 1-based count t (Keras: lr sqrt(1 - b2^t) / (1 - b1^t))
+__device__ __forceinline__ double adam_step_size(double lr, double t) {
+    return lr * sqrt(1.0 - exp(t * -0.05129329438755058)) / (1.0 - exp(t * -0.2231435513142098));
+}

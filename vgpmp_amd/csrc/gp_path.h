@@ -52,6 +52,31 @@ struct vg_lik_scratch {
 };
 size_t vg_layout_lik_scratch(const vgpmp_dims* d, void* base, vg_lik_scratch* out);
 
+// vgpmp_inducing_params.scratch: per-chunk reductions of the reverse pass wrt the inducing locations
+constexpr int kIndBChunk = 64;      // Fourier bases per workgroup of the feature part
+struct vg_ind_scratch {
+    float* dA;             // [P, L, NC, N, Mz]   sum over a chunk's samples of G^T R
+    float* dC;             // [P, L, NC, Mz, Mz]  sum over a chunk's samples of dR^T eps
+    float* dR;             // [P, S, L, Mz]       G A
+    float* rff;            // [P, L, B / kIndBChunk, Mz, L]  feature part of d loss / d Zy, per basis chunk
+    double* cov;           // [P, L, Mz]          covariance part of d loss / d Zy[:, l]
+};
+size_t vg_layout_ind_scratch(const vgpmp_dims* d, void* base, vg_ind_scratch* out);
+struct vg_ind_launch {
+    const vgpmp_dims* d;
+    const vgpmp_inducing_params* ind;
+    const vg_workspace* ws;
+    const vgpmp_noise* nz;
+    const vgpmp_params* params;
+    const double *X, *y_u;
+    double jitter;
+    int do_adam, trainable;
+    const uint32_t* ctr;   // ticked device counter (then the step size comes from it), else lr_t
+    double lr, lr_t;
+};
+int vg_launch_inducing_build(const vgpmp_dims* d, const vgpmp_inducing_params* ind, hipStream_t st);
+int vg_launch_inducing_backward(const vg_ind_launch& a, hipStream_t st);
+
 int vg_check_dims(const vgpmp_dims* d);
 int vg_backward_fits(const vgpmp_dims* d);
 size_t vg_layout_workspace(const vgpmp_dims* d, void* base, vg_workspace* ws);

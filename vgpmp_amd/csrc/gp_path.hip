@@ -10,6 +10,7 @@
 // the vector pipe; A = Kfu (Kuu + jitter I)^-1 is formed once per latent in float64 and only then
 // rounded, so the per-sample work (prior GEMM, path assembly) is well conditioned float32.
 #include "gp_path.h"
+#include "gp_math.h"
 #include <hip/hip_ext.h>
 #include <string.h>
 
@@ -28,16 +29,6 @@ constexpr int kBlock = 256;
 constexpr int kMidMaxPL = 96;       // merged launches of the one-launch-per-kernel schedule up to this many pairs ...
 constexpr int kMid2MaxPL = 192;     // ... and only cov_a | noise and hyper | final up to this many (16 problems: 333 -> 323 us)
 constexpr int kFuseMaxPL = 32;      // measured on config 2: shared launches win up to 4 problems (x 7 latents), one launch per kernel from 5
-constexpr double kVarFloor = 0.1;               // models/vgpmp.py:139 positive(lower=1e-1)
-constexpr double kSqrt5 = 2.2360679774997896964;
-
-__device__ __forceinline__ double softplus_d(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
-__device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
-__device__ __forceinline__ double matern52(double t1, double t2, double ell, double var) {
-    double r = fabs(t1 - t2) / ell;
-    r = sqrt(fmax(r * r, 1e-36));
-    return var * (1.0 + kSqrt5 * r + (5.0 / 3.0) * r * r) * exp(-kSqrt5 * r);
-}
 __device__ __forceinline__ double matern52_dell(double t1, double t2, double ell, double var) {
     double r = fabs(t1 - t2) / ell;
     return var * exp(-kSqrt5 * r) * (5.0 * r * r / (3.0 * ell)) * (1.0 + kSqrt5 * r);
@@ -163,14 +154,6 @@ __device__ __forceinline__ void rng_normals_body(const RngArgs& a, int bx, int p
 __global__ __launch_bounds__(kBlock) void rng_basis_kernel(RngArgs a) { rng_basis_body(a, blockIdx.x, blockIdx.y); }
 __global__ __launch_bounds__(kBlock) void rng_normals_kernel(RngArgs a) {
     rng_normals_body(a, blockIdx.x, blockIdx.y, a.nW, a.nE);
-}
-
-__device__ __forceinline__ void adam_update(double* x, double* m, double* v, double g, double lr_t) {
-    // Keras Adam (TF 2.12): beta1 = 0.8, beta2 = 0.95 (models/vgpmp.py:77), epsilon 1e-7
-    double mm = *m + (g - *m) * (1.0 - 0.8);
-    double vv = *v + (g * g - *v) * (1.0 - 0.95);
-    *m = mm; *v = vv;
-    *x -= lr_t * mm / (sqrt(vv) + 1e-7);
 }
 
 struct PathArgs {
@@ -903,11 +886,6 @@ struct FinalArgs {
     int stop;
 };
 
-// Bias-corrected Adam step size of the update with 1-based count t (Keras: lr sqrt(1 - b2^t) / (1 - b1^t))
-__device__ __forceinline__ double adam_step_size(double lr, double t) {
-    return lr * sqrt(1.0 - exp(t * -0.05129329438755058)) / (1.0 - exp(t * -0.2231435513142098));
-}
-
 // Hyper-parameter update of one (problem, latent): gradient of the loss wrt (raw lengthscale, raw variance) from the
 // reverse-pass sums and the KL tangents, chain rule through the softplus, Adam.  Two forms with identical arithmetic:
 // hyper_kernel (its own launch) and a PROLOGUE of the stage-1 roles that need the new values (small batches, steps
@@ -1007,6 +985,7 @@ __device__ __forceinline__ HyperState hyper_update(const HyperArgs& h, size_t pl
 struct CovArgs {
     int N, M, L, D;
     const double *X, *Zy, *y_u;
+    size_t zy_stride;        // doubles between the Zy of consecutive problems (0: one shared set)
     double jitter;
     const double *q_mu, *q_sqrt, *raw_ell, *raw_var;
     int want_dell;
@@ -1275,7 +1254,7 @@ __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, 
         else { scal[1] = kVarFloor + softplus_d(raw); a.ws.sig_var[pl] = sigmoid_d(raw); }
     }
     for (int e = tid; e < 2 * Mp * ld; e += nt) sm[e] = 0.0;
-    for (int i = tid; i < Mz; i += nt) zs[i] = a.Zy[(size_t)i * D + l];
+    for (int i = tid; i < Mz; i += nt) zs[i] = a.Zy[(size_t)p * a.zy_stride + (size_t)i * D + l];
     __syncthreads();
     const double ell = scal[0], var = scal[1], jit = a.jitter;
     if (tid == 0) { a.ws.ell[pl] = ell; a.ws.var[pl] = var; }
@@ -1580,7 +1559,8 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
         }
         vg_stage_words(zs, 2 * (Mz + kRowTile), tid, nt, [&](int w) -> const void* {
             const int i = w >> 1;
-            const double* src = i < Mz ? a.Zy + (size_t)i * D + l : a.X + (size_t)min(n0 + i - Mz, N - 1) * D + l;
+            const double* src = i < Mz ? a.Zy + (size_t)p * a.zy_stride + (size_t)i * D + l
+                                       : a.X + (size_t)min(n0 + i - Mz, N - 1) * D + l;
             return reinterpret_cast<const uint32_t*>(src) + (w & 1);
         });
     }
@@ -1640,6 +1620,7 @@ __device__ __forceinline__ float softplus_f(float x) { return x > 15.f ? x : __l
 struct FeatArgs {
     int N, Mz, L, D, B, jchunk;
     const double *X, *Zy, *raw_ell, *raw_var;
+    size_t zy_stride;
     const float *omega, *beta;
     float *Phi, *dPhi;
     uint32_t* tick;          // device step counter, ticked by the stand-alone launch of a training step (or null)
@@ -1653,12 +1634,12 @@ __device__ __forceinline__ void features_body(const FeatArgs& a, int bx, int by,
     // one lane per (latent, basis): its frequency row stays in registers while it sweeps `jchunk` points;
     // the points are uniform across the workgroup (scalar loads), the stores are coalesced along b
     const int N = a.N, Mz = a.Mz, L = a.L, D = a.D, B = a.B;
-    const double *X = a.X, *Zy = a.Zy;
     const float *omega = a.omega, *beta = a.beta;
     float *Phi = a.Phi, *dPhi = a.dPhi;
     VG_T(bx == 0 && by == 0 && bz == 0, 130);
     const int b = bx * kBlock + threadIdx.x;
     const int l = bz % L, p = bz / L;
+    const double *X = a.X, *Zy = a.Zy + (size_t)p * a.zy_stride;
     const int J = N + Mz;
     const size_t pl = (size_t)p * L + l;
     if (b >= B) return;
@@ -2018,6 +1999,7 @@ __global__ __launch_bounds__(kBlock) void prior_gemm_tiled_kernel(TiledGemmArgs 
 struct FusedPriorArgs {
     int S, L, J, N, D, B, want_dell;
     const double *X, *Zy, *raw_ell, *raw_var;
+    size_t zy_stride;
     const float *omega, *beta, *W;
     float *F0, *H;
     size_t slab;
@@ -2033,7 +2015,7 @@ __global__ __launch_bounds__(kBlock) void prior_fused_small_kernel(FusedPriorArg
     if (a.tick && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.tick += 1u;
     for (int e = tid; e < kFNT * 16 * DM; e += kBlock) {
         const int jj = e / DM, d = e - jj * DM, j = min(j0 + jj, J - 1);
-        const double* pt = j < N ? a.X + (size_t)j * D : a.Zy + (size_t)(j - N) * D;
+        const double* pt = j < N ? a.X + (size_t)j * D : a.Zy + (size_t)p * a.zy_stride + (size_t)(j - N) * D;
         pts[jj][d] = d < D ? (float)pt[d] : 0.f;
     }
     __syncthreads();
@@ -2746,7 +2728,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const bool backward = (what & VGPMP_DO_BACKWARD) != 0, do_adam = (what & VGPMP_DO_ADAM) != 0;
     const bool gen = (what & VGPMP_GEN_NOISE) != 0;
     const bool want_dell = backward && (trainable & VGPMP_TRAIN_LENGTHSCALES);
-    const bool fused = !ev && !(what & VGPMP_NO_FUSE) && SC == 8 && P * L <= kFuseMaxPL;
+    const bool fused = !ev && !(what & VGPMP_NO_FUSE) && SC == 8 && P * L <= kFuseMaxPL && !pb->ind;
     const bool tiled_gemm = !fused && SK == 1 && (B % kTK) == 0;      // large batches: LDS-tiled kernel, no K-slices
     if (num_steps > 1 && !(backward && do_adam && gen)) return VGPMP_E_ARG;
     int evi = 0;
@@ -2756,7 +2738,10 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     // ---- argument blocks ----------------------------------------------------------------------
     CovArgs ca;
     ca.N = N; ca.M = M; ca.L = L; ca.D = L;
-    ca.X = pb->X; ca.Zy = pb->Zy; ca.y_u = pb->y_u; ca.jitter = pb->jitter;
+    const vgpmp_inducing_params* ind = pb->ind;      // inducing locations as variables: per-problem Zy, written from raw_Z
+    const double* zy = ind ? ind->Zy : pb->Zy;
+    const size_t zy_stride = ind ? (size_t)Mz * L : 0;
+    ca.X = pb->X; ca.Zy = zy; ca.zy_stride = zy_stride; ca.y_u = pb->y_u; ca.jitter = pb->jitter;
     ca.q_mu = params->q_mu; ca.q_sqrt = params->q_sqrt; ca.raw_ell = params->raw_ell; ca.raw_var = params->raw_var;
     ca.want_dell = want_dell ? 1 : 0;
     ca.stop = -1;
@@ -2770,7 +2755,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     // few problems: few points per workgroup (more parallelism); many: sweep 16 points per lane (omega reuse)
     // (shared launches: 8 for one problem -- the role is off the pole either way --, 16 from two: 105 -> 95 us per step)
     fe.jchunk = fused ? (P > 1 ? 16 : 8) : (P * L >= 16 ? 16 : 4);
-    fe.X = pb->X; fe.Zy = pb->Zy; fe.raw_ell = params->raw_ell; fe.raw_var = params->raw_var;
+    fe.X = pb->X; fe.Zy = zy; fe.zy_stride = zy_stride; fe.raw_ell = params->raw_ell; fe.raw_var = params->raw_var;
     fe.omega = nz->omega; fe.beta = nz->beta; fe.Phi = ws->Phi; fe.dPhi = want_dell ? ws->dPhi : nullptr;
     fe.tick = (!fused && do_adam) ? ctr : nullptr;
     const dim3 feat_grid((B + kBlock - 1) / kBlock, (J + fe.jchunk - 1) / fe.jchunk, P * L);
@@ -2908,7 +2893,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const bool fused_small = !fused && SK == 4 && S <= 32 && (B % 64) == 0 && !(what & VGPMP_GEMM_DIRECT);
     // (bounds measured at S = 128; the work per problem scales with the samples)
     const long long pls = (long long)P * L * S;
-    const bool mid = !fused && !ev && (tiled_gemm || fused_small) && backward && !(what & VGPMP_NO_FUSE) &&
+    const bool mid = !fused && !ev && !pb->ind && (tiled_gemm || fused_small) && backward && !(what & VGPMP_NO_FUSE) &&
                      pls <= (long long)kMid2MaxPL * 128;
     const bool mid_gemm = tiled_gemm && pls <= (long long)kMidMaxPL * 128;      // cov_b beside the GEMM only while the chip is not full
     const size_t lds_tg1 = (size_t)2 * (kTS + kTJ) * kTLd * sizeof(float);
@@ -2930,7 +2915,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     auto launch_fused_small = [&](hipEvent_t g0, hipEvent_t g1) {
         FusedPriorArgs fp;
         fp.S = S; fp.L = L; fp.J = J; fp.N = N; fp.D = L; fp.B = B; fp.want_dell = want_dell ? 1 : 0;
-        fp.X = pb->X; fp.Zy = pb->Zy; fp.raw_ell = params->raw_ell; fp.raw_var = params->raw_var;
+        fp.X = pb->X; fp.Zy = zy; fp.zy_stride = zy_stride; fp.raw_ell = params->raw_ell; fp.raw_var = params->raw_var;
         fp.omega = nz->omega; fp.beta = nz->beta; fp.W = nz->w; fp.F0 = ws->F0; fp.H = ws->H; fp.slab = slab;
         fp.tick = fe.tick;
         const dim3 fgrid(P * L, (J + kFNT * 16 - 1) / (kFNT * 16));
@@ -2961,6 +2946,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     for (int i = 0; i < num_steps; ++i) {
         const bool first = i == 0, more = i + 1 < num_steps;
         const uint32_t step_i = step + (uint32_t)i;
+        if (ind && (rc = vg_launch_inducing_build(d, ind, st))) return rc;       // Zy = [0; 1; Z(raw_Z)] of every problem
         if (fused) {
             // noise of the first step of a call: everything up front; afterwards eps rides in stage 1 and the
             // prior noise of step i was drawn by stage 3 of step i-1
@@ -3078,6 +3064,14 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         }
         // ---- reverse of the path assembly (+ hyper-parameter update), then (here or in the next stage 1) the rest
         if ((rc = launch(fn_pb, dim3(split_bwd ? 2 * NC : NC, L, P), &pa, lds_pb))) return rc;
+        if (ind) {     // inducing locations as variables: reverse through the covariance path and the prior draw at Zy
+            vg_ind_launch il;
+            il.d = d; il.ind = ind; il.ws = ws; il.nz = nz; il.params = params; il.X = pb->X; il.y_u = pb->y_u;
+            il.jitter = pb->jitter; il.do_adam = do_adam ? 1 : 0; il.trainable = trainable;
+            il.ctr = do_adam ? ctr : nullptr; il.lr = lr;
+            il.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
+            if ((rc = vg_launch_inducing_backward(il, st))) return rc;
+        }
         if (lk) {      // trainable likelihood constants: their gradient / update, and the constants of the next step
             lu.nblk = nblk;
             lu.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;

@@ -22,6 +22,7 @@ from .robots import RobotSpec
 JITTER = 1e-6
 VARIANCE_FLOOR = 0.1
 ALPHA_FLOOR, SIGMA_FLOOR = 1e-4, 1e-5      # models/vgpmp.py:82, likelihoods/likelihood.py:31,41
+Z_LOW, Z_HIGH = 0.09, 0.91                 # models/vgpmp.py:41 bounded_Z: tfb.Sigmoid(0.09, 0.91)
 DEFAULT_TRAINABLE = dict(q_mu=True, q_sqrt=True, lengthscales=True, kernel_variance=True)
 
 
@@ -45,6 +46,8 @@ def trainable_mask(flags: Dict[str, bool]) -> int:
         m |= capi.TRAIN_SIGMA_OBS
     if flags.get("alpha", False):
         m |= capi.TRAIN_ALPHA
+    if flags.get("inducing_variable", False):
+        m |= capi.TRAIN_INDUCING
     return m
 
 
@@ -248,6 +251,21 @@ class PlannerBatch:
             nb = C.c_size_t(0)
             capi.check(self.lib.vgpmp_lik_scratch_bytes(C.byref(self.dims), C.byref(nb)), "vgpmp_lik_scratch_bytes")
             self.lik_scratch = torch.zeros(int(nb.value), dtype=torch.uint8, device=dev)
+        # ---- inducing locations as variables (trainable_params.inducing_variable; reference default: constants)
+        self.z_variables = bool(self.trainable.get("inducing_variable", False))
+        if self.z_variables:
+            if int(samples_total or S) != S:
+                raise NotImplementedError("trainable inducing locations with a sharded sample axis")
+            if B % 64:
+                raise ValueError("trainable inducing locations need num_bases to be a multiple of 64")
+            z01 = (np.linspace(0.1, 0.9, M) - Z_LOW) / (Z_HIGH - Z_LOW)
+            raw = np.tile((np.log(z01) - np.log1p(-z01))[None, :, None], (P, 1, L))           # models/vgpmp.py:37-42
+            self.raw_Z = torch.tensor(raw, dtype=f64, device=dev).contiguous()
+            self.z_adam_m, self.z_adam_v, self.z_grad = z(self.raw_Z), z(self.raw_Z), z(self.raw_Z)
+            self.Zy_all = torch.zeros((P, self.Mz, L), dtype=f64, device=dev)
+            nb = C.c_size_t(0)
+            capi.check(self.lib.vgpmp_inducing_scratch_bytes(C.byref(self.dims), C.byref(nb)), "vgpmp_inducing_scratch_bytes")
+            self.z_scratch = torch.zeros(int(nb.value), dtype=torch.uint8, device=dev)
         # device-resident step counter: lets a captured hipGraph of the step be replayed
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.fuse = True          # False: one launch per kernel even for small batches (measurement)
@@ -271,10 +289,15 @@ class PlannerBatch:
                                        capi.ptr(self.lik_adam_v[0]), capi.ptr(self.lik_adam_m[1]), capi.ptr(self.lik_adam_v[1]),
                                        capi.ptr(self.lik_grad[0]), capi.ptr(self.lik_grad[1]), capi.ptr(self.lik_scratch))
             lik = C.pointer(self._lik)
+        ind = None
+        if getattr(self, "z_variables", False):
+            self._ind = capi.InducingParams(capi.ptr(self.raw_Z), capi.ptr(self.z_adam_m), capi.ptr(self.z_adam_v),
+                                            capi.ptr(self.z_grad), capi.ptr(self.Zy_all), capi.ptr(self.z_scratch))
+            ind = C.pointer(self._ind)
         self._problem = capi.Problem(capi.ptr(self.X), capi.ptr(self.Zy), capi.ptr(self.y_u), self.alpha, JITTER,
-                                     self.kl_scale, None, lik)
+                                     self.kl_scale, None, lik, ind)
         self._problem_ctr = capi.Problem(capi.ptr(self.X), capi.ptr(self.Zy), capi.ptr(self.y_u), self.alpha, JITTER,
-                                         self.kl_scale, capi.ptr(self.step_counter), lik)
+                                         self.kl_scale, capi.ptr(self.step_counter), lik, ind)
         self._out = capi.Outputs(capi.ptr(self.f), capi.ptr(self.logp), capi.ptr(self.lik), capi.ptr(self.kl),
                                  self._params_struct(self.grad))
 
@@ -395,6 +418,8 @@ class PlannerBatch:
             child.y_u = self.y_u
             if self.lik_variables:      # the trained sigma_obs / alpha weigh the samples of get_best_sample
                 child.raw_alpha, child.raw_sigma = self.raw_alpha, self.raw_sigma
+            if self.z_variables:        # the trained inducing locations
+                child.raw_Z = self.raw_Z
             child._pack()
             cache[key] = child
         child = cache[key]
@@ -452,6 +477,12 @@ class PlannerBatch:
 
     def variances(self) -> torch.Tensor:
         return VARIANCE_FLOOR + torch.nn.functional.softplus(self.raw_var)
+
+    def inducing_locations(self) -> torch.Tensor:
+        """Z of every problem [P, M, L] (the constants linspace(0.1, 0.9, M) unless trainable_params.inducing_variable)."""
+        if not self.z_variables:
+            return self.Zy[2:].unsqueeze(0).repeat(self.P, 1, 1)
+        return Z_LOW + (Z_HIGH - Z_LOW) * torch.sigmoid(self.raw_Z)
 
     def alphas(self) -> torch.Tensor:
         """alpha of every problem [P] (the constant unless trainable_params.alpha / sigma_obs made it a variable)."""

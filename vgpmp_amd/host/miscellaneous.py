@@ -28,12 +28,11 @@ def init_trainset(grid_spacing_X, grid_spacing_Xnew, input_dimension, degree_of_
 
 def disable_param_opt(planner, trainable_params):
     """utils/miscellaneous.py:324-343: apply the `trainable_params` flags of parameters.yaml.
-    The inducing locations can only be held fixed on the HIP path (the reference's default); asking to train
-    them raises.  sigma_obs / alpha become per-problem variables of the device batch (vgpmp.h: vgpmp_lik_params);
+    Trainable inducing locations (utils/miscellaneous.py:338) become per-problem variables of the device batch with the
+    Sigmoid(0.09, 0.91) bijector of models/vgpmp.py:29-42 (vgpmp.h: vgpmp_inducing_params);
+    sigma_obs / alpha become per-problem variables of the device batch (vgpmp.h: vgpmp_lik_params);
     the Normal priors the reference attaches here are centred on the parameters themselves, so they contribute only
     the bijectors' log-det-Jacobians to the loss -- that term is part of the device update."""
-    if trainable_params.get("inducing_variable", False):
-        raise NotImplementedError("training `inducing_variable` is not supported by the HIP path (reference default: False)")
     for kern in planner.kernel.kernels:
         set_trainable(kern.variance, trainable_params["kernel_variance"])
         set_trainable(kern.lengthscales, trainable_params["lengthscales"])
@@ -43,11 +42,12 @@ def disable_param_opt(planner, trainable_params):
                          "lengthscales": bool(trainable_params["lengthscales"]),
                          "kernel_variance": bool(trainable_params["kernel_variance"]),
                          "sigma_obs": bool(trainable_params.get("sigma_obs", False)),
-                         "alpha": bool(trainable_params.get("alpha", False))}
+                         "alpha": bool(trainable_params.get("alpha", False)),
+                         "inducing_variable": bool(trainable_params.get("inducing_variable", False))}
     if planner._planner is not None:
         want_lik = planner.trainable["sigma_obs"] or planner.trainable["alpha"]
-        if want_lik != planner._planner.lik_variables:
-            planner._planner = None          # the device batch is rebuilt with / without the likelihood variables
+        if want_lik != planner._planner.lik_variables or planner.trainable["inducing_variable"] != planner._planner.z_variables:
+            planner._planner = None          # the device batch is rebuilt with / without those variables
         else:
             planner._planner.trainable = dict(planner.trainable)
 
@@ -103,8 +103,6 @@ def solve_planning_problems_batched(env, queries, seed: int = 0):
     from .model import VariationalMonteCarloLikelihood
     pp = env.config["planner_params"]
     tp = env.config["trainable_params"]
-    if tp.get("inducing_variable", False):
-        raise NotImplementedError("training `inducing_variable` is not supported by the HIP path (reference default: False)")
     dof = env.robot.dof
     lik = VariationalMonteCarloLikelihood(sigma_obs=pp["sigma_obs"], robot=env.robot, sampler=env.sampler, sdf=env.sdf,
                                           offset=env.scene.position, epsilon=pp["epsilon"])
@@ -116,7 +114,8 @@ def solve_planning_problems_batched(env, queries, seed: int = 0):
                              trainable={"q_mu": bool(tp["q_mu"]), "q_sqrt": bool(tp["q_sqrt"]),
                                         "lengthscales": bool(tp["lengthscales"]),
                                         "kernel_variance": bool(tp["kernel_variance"]),
-                                        "sigma_obs": bool(tp.get("sigma_obs", False)), "alpha": bool(tp.get("alpha", False))})
+                                        "sigma_obs": bool(tp.get("sigma_obs", False)), "alpha": bool(tp.get("alpha", False)),
+                                        "inducing_variable": bool(tp.get("inducing_variable", False))})
     pl.run_steps(int(pp["num_steps"]))
     Xnew = np.tile(np.linspace(0.0, 1.0, int(pp["time_spacing_Xnew"]))[:, None], (1, dof))
     _, best, _, _ = pl.sample_from_posterior(150, Xnew, step=pl.t)

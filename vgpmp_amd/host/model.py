@@ -333,6 +333,9 @@ class VGPMP:
         if pl.lik_variables:
             self.alpha.assign(float(pl.alphas()[0]))
             self.likelihood.variance.assign(pl.sigma_obs()[0].cpu().numpy()[None])
+        if pl.z_variables:
+            iv = getattr(self.inducing_variable, "inducing_variable", self.inducing_variable)
+            iv._Z.assign(pl.inducing_locations()[0].cpu().numpy())
 
     def sample_from_posterior(self, X, robot=None, compute_uncertainty=False):
         """models/vgpmp.py:312-331: (mean, best sample, first 7 samples, 2 sqrt(uncertainty)); uncertainty = the variance
