@@ -216,6 +216,7 @@ typedef struct vgpmp_outputs {
 #define VGPMP_COV_ONLY 2048     /* with VGPMP_DO_FORWARD alone: only the covariance stage -- Kuu, its Cholesky, q_sqrt, A and the
                                  * per-latent prior KL (kullback_leiblers/prior_kl.py:16-35) land in the workspace (views "kl_l", "C",
                                  * "Kinv", "A4"); no noise, no likelihood: dev_robot and sdf may be NULL, the members of `noise` and `out` too */
+#define VGPMP_NO_FUSE_PRIOR 4096 /* measurement: large batches with the generator, the feature kernel and the tiled GEMM as three launches */
 #define VGPMP_ELIM_BLOCK 128    /* measurement: Kuu elimination by the whole workgroup through LDS instead of one wave in registers */
 
 /* ---- set-up -------------------------------------------------------------------------------- */

@@ -497,3 +497,34 @@ def test_dispatchers_on_the_device_match_oracle():
                     raw_ell=p.raw_ell, raw_var=p.raw_var)
     cv2 = orc.cov_forward(p2, X, orc.inducing_Zy(M2, L), y_u)
     np.testing.assert_allclose(float(prior_kl(iv2, kern, p2.q_mu, p2.q_sqrt, y_u)), cv2["kl"], rtol=1e-8)
+
+
+@pytest.mark.parametrize("S,N,M,B,lengthscales", [(37, 50, 10, 256, True), (128, 150, 30, 1024, True), (70, 20, 5, 64, False)])
+def test_fused_prior_kernel_equals_generator_features_and_gemm(S, N, M, B, lengthscales):
+    """Large-batch schedule with device-generated noise: W and Phi / dPhi formed inside the GEMM (prior_fused_batch_kernel)
+    against the three launches it replaces (Philox generator -> w, features_kernel -> Phi / dPhi, tiled GEMM): the same
+    expressions in the same order, so the prior draws, the paths, the likelihood and every gradient agree bit for bit.
+    Ragged sample count, one and two column tiles, with and without the lengthscale tangent."""
+    from vgpmp_amd import capi, engine
+    ps = rb.load_problemset("franka", "industrial")
+    spec = rb.load_robot("franka")
+    grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
+    sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
+    qs = np.array([ps.queries[i] for i in range(3)])
+    tr = dict(q_mu=True, q_sqrt=True, lengthscales=lengthscales, kernel_variance=True)
+    kw = dict(num_samples=S, num_inducing=M, num_data=N, num_bases=B, lengthscales=[2.0] * 7, variance=0.2, seed=9, split_k=1,
+              trainable=tr, problem_base=5)
+    outs = []
+    for flag in (0, capi.NO_FUSE_PRIOR):
+        pl = engine.PlannerBatch(sc, qs, **kw)
+        pl.fuse = False                       # one launch per kernel: the large-batch schedule
+        pl.extra_flags = flag
+        pl.step(); pl.step()
+        loss, grads = pl.loss_and_grad(generate=True, step=7)
+        torch.cuda.synchronize()
+        keep = [g.clone() for k, g in enumerate(grads) if lengthscales or k != 2]      # no lengthscale tangent: that gradient is not formed
+        outs.append([pl.view("F0"), pl.view("H") if lengthscales else pl.view("F0"), pl.f.clone(), pl.logp.clone(), loss.clone(),
+                     pl.q_mu.clone(), pl.raw_ell.clone()] + keep)
+    assert float(outs[0][0].abs().max()) > 0
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -28,3 +28,11 @@ if w:
               "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_MISC", "SQ_INST_CYCLES_VMEM", "SQ_WAIT_INST_LDS"):
         if k in avg:
             print(f"{k} per wave: {4 * avg[k] / w:.0f} cycles")
+
+if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg:
+    # MfmaUtil of rocprofv3's derived metrics: MFMA-busy cycles summed over the SIMDs / (active cycles x SIMDs); GRBM_GUI_ACTIVE is
+    # reported summed over the 8 XCDs (MI355X_MICROARCH.md), 1024 SIMDs on the chip
+    cyc = avg["GRBM_GUI_ACTIVE"] / 8.0
+    print(f"kernel active cycles (GRBM_GUI_ACTIVE / 8): {cyc:.0f};  MFMA busy / (cycles x 1024 SIMDs): {avg['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024):.3f}")
+    if "SQ_INSTS_VALU_MFMA_MOPS_F32" in avg:
+        print(f"MFMA F32 flops per launch (MOPS x 512): {avg['SQ_INSTS_VALU_MFMA_MOPS_F32'] * 512:.4g}")

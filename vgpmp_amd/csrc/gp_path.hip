@@ -121,7 +121,7 @@ __device__ __forceinline__ void rng_basis_body(const RngArgs& a, int bx, int p) 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t e = 4u * c + k;
-                if (e >= e0 && e < e0 + (uint32_t)D) vg_stream(om + (e - e0), vg_lane(v, k) * sc);
+                if (e >= e0 && e < e0 + (uint32_t)D) om[e - e0] = vg_lane(v, k) * sc;      // (plain stores: a wave's rows are contiguous and merge in L2)
             }
         }
     }
@@ -1991,6 +1991,138 @@ __global__ __launch_bounds__(kBlock) void prior_gemm_tiled_kernel(TiledGemmArgs 
     prior_gemm_tiled_body<MT>(ta, tg_lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// Large batches with device-generated noise: the prior draws as ONE kernel -- the weights W come out of the Philox
+// generator and the features Phi / dPhi/dell out of sin / cos INSIDE the GEMM's K loop, straight into the LDS tiles the
+// MFMAs read.  Neither W (S L B floats per problem: 470 MB at 64 problems of 14 joints, written by the generator and
+// read back by the GEMM) nor Phi / dPhi (2 x L J B: 15 MB per problem each way) exist in memory any more; the generator
+// and the feature kernel are gone as launches.  A workgroup owns 64 samples x 144 columns of BOTH products (F0 = W Phi^T
+// and H = W dPhi^T share the W tile); per 16-deep K step a thread draws one Philox counter (4 normals of a W row) and
+// forms 9 feature pairs, then the four waves run 72 MFMAs each.  The VALU work of one workgroup's generation phase
+// overlaps the MFMA phase of the others on the CU (33 KB of LDS: four workgroups per CU).
+// Same expressions, same accumulation order as rng_normals / features_kernel / prior_gemm_tiled_kernel: bit-identical.
+constexpr int kFBK = 16, kFBLd = 20;        // K step, LDS row stride (16-row fragment reads fall on distinct banks)
+struct FusedBatchArgs {
+    int S, L, J, N, D, B, want_dell;
+    const double *X, *Zy, *raw_ell, *raw_var;
+    size_t zy_stride;
+    const float *omega, *beta;
+    float *F0, *H;
+    uint32_t seed, problem_base, step, wOff;
+    const uint32_t* ctr;
+};
+template <bool DELL, int DM>      // d/d ell wanted; joint-space extent padded to DM (8 or 16)
+__global__ __launch_bounds__(kBlock) void prior_fused_batch_kernel(FusedBatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float fb_lds[];
+    const int S = a.S, L = a.L, J = a.J, N = a.N, D = a.D, B = a.B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l = blockIdx.z % L, p = blockIdx.z / L;
+    const int s0 = blockIdx.y * kTS, j0 = blockIdx.x * kTJ;
+    const size_t pl = (size_t)p * L + l;
+    float* As = fb_lds;                                  // [64][kFBLd]         W tile
+    float* Bs = As + kTS * kFBLd;                        // [2][144][kFBLd]     Phi, dPhi tiles
+    float* pts = Bs + 2 * kTJ * kFBLd;                   // [144][DM]           the tile's points (rows of X, then of Zy), zero padded
+    float* oms = pts + kTJ * DM;                         // [2][16][DM + 4]     the K step's frequency rows (+ phase), double buffered
+    constexpr int kOLd = DM + 4;
+    for (int e = tid; e < kTJ * DM; e += kBlock) {
+        const int jj = e / DM, d = e - jj * DM, j = min(j0 + jj, J - 1);
+        const double* pt = j < N ? a.X + (size_t)j * D : a.Zy + (size_t)p * a.zy_stride + (size_t)(j - N) * D;
+        pts[e] = d < D ? (float)pt[d] : 0.f;
+    }
+    for (int e = tid; e < 2 * kFBK * kOLd; e += kBlock) oms[e] = 0.f;
+    const float ell = softplus_f((float)a.raw_ell[pl]);
+    const float var = (float)kVarFloor + softplus_f((float)a.raw_var[pl]);
+    const float inv_ell = 1.0f / ell, c = __builtin_amdgcn_sqrtf(2.0f * var / (float)B);
+    const uint2 key = vg_key(a.seed, a.problem_base + p, a.ctr ? *a.ctr : a.step);
+    // generation roles: W -- thread (row = tid / 4, quad = tid % 4) draws the 4 normals of columns 4 quad .. 4 quad + 3;
+    // features -- thread (kcol = tid % 16, jg = tid / 16) forms rows jg, jg + 16, ... of column kcol;
+    // frequencies -- thread t < 16 D fetches element t of the step's 16 contiguous rows of omega, t < 16 + 16 D a phase
+    const int wrow = tid >> 2, wq = tid & 3;
+    const int srow = min(s0 + wrow, S - 1);
+    const uint32_t wbase = (a.wOff + ((uint32_t)srow * L + l) * (uint32_t)B) >> 2;      // counter of (row, column 0)
+    const int kcol = tid & 15, jg = tid >> 4;
+    const int nom = kFBK * D;
+    const bool is_om = tid < nom, is_bt = tid >= nom && tid < nom + kFBK;
+    const int orow = is_om ? tid / D : tid - nom, ocol = is_om ? tid - orow * D : DM;      // phase sits behind the row
+    const float* osrc = is_om ? a.omega + pl * B * D + tid : a.beta + pl * B + (tid - nom);
+    const int ostep = is_om ? kFBK * D : kFBK;
+    float onext = (is_om || is_bt) ? osrc[0] : 0.f;
+    vg_f32x4 accF[kTJ / 16], accH[kTJ / 16];
+#pragma unroll
+    for (int t = 0; t < kTJ / 16; ++t) { accF[t] = (vg_f32x4){0.f, 0.f, 0.f, 0.f}; accH[t] = accF[t]; }
+    const int r = lane & 15, g = lane >> 4;
+    __syncthreads();
+    if (is_om || is_bt) oms[orow * kOLd + ocol] = onext;
+    __syncthreads();
+    int ob = 0;
+    for (int k0 = 0; k0 < B; k0 += kFBK) {
+        // ---- generate the K step's operands (the next step's frequencies are requested first, stored last)
+        {
+            if ((is_om || is_bt) && k0 + kFBK < B) onext = osrc[(size_t)(k0 / kFBK + 1) * ostep];
+            const float4 w4 = vg_normal4(wbase + (uint32_t)((k0 >> 2) + wq), VG_STREAM_W, key);
+            *reinterpret_cast<float4*>(As + wrow * kFBLd + 4 * wq) = w4;
+            float om[DM];
+            const float* orowp = oms + (ob * kFBK + kcol) * kOLd;
+#pragma unroll
+            for (int d = 0; d < DM; d += 4) {
+                const float4 o4 = *reinterpret_cast<const float4*>(orowp + d);
+                om[d] = o4.x; om[d + 1] = o4.y; om[d + 2] = o4.z; om[d + 3] = o4.w;
+            }
+            const float bt = orowp[DM];
+#pragma unroll
+            for (int i = 0; i < kTJ / 16; ++i) {
+                const int jj = jg + 16 * i;
+                float proj = 0.f;
+#pragma unroll
+                for (int d = 0; d < DM; d += 4) {          // (zero padding: the products beyond D add exact zeros)
+                    const float4 p4 = *reinterpret_cast<const float4*>(pts + jj * DM + d);
+                    proj = fmaf(p4.x, om[d], proj); proj = fmaf(p4.y, om[d + 1], proj);
+                    proj = fmaf(p4.z, om[d + 2], proj); proj = fmaf(p4.w, om[d + 3], proj);
+                }
+                const float rev = __builtin_amdgcn_fractf((proj * inv_ell + bt) * 0.15915494309189535f);
+                Bs[jj * kFBLd + kcol] = c * __builtin_amdgcn_cosf(rev);
+                if (DELL) Bs[(kTJ + jj) * kFBLd + kcol] = c * __builtin_amdgcn_sinf(rev) * proj * inv_ell * inv_ell;
+            }
+            if ((is_om || is_bt) && k0 + kFBK < B) oms[((ob ^ 1) * kFBK + orow) * kOLd + ocol] = onext;
+        }
+        __syncthreads();
+        // ---- 2 x 9 tiles of 16 x 16, four k-interleaved MFMAs each
+        {
+            const float4 a4 = *reinterpret_cast<const float4*>(As + (wave * 16 + r) * kFBLd + 4 * g);
+#pragma unroll
+            for (int t = 0; t < kTJ / 16; ++t) {
+                const float4 b4 = *reinterpret_cast<const float4*>(Bs + (t * 16 + r) * kFBLd + 4 * g);
+                accF[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, accF[t], 0, 0, 0);
+                accF[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, accF[t], 0, 0, 0);
+                accF[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, accF[t], 0, 0, 0);
+                accF[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, accF[t], 0, 0, 0);
+                if (DELL) {
+                    const float4 d4 = *reinterpret_cast<const float4*>(Bs + (kTJ + t * 16 + r) * kFBLd + 4 * g);
+                    accH[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, d4.x, accH[t], 0, 0, 0);
+                    accH[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, d4.y, accH[t], 0, 0, 0);
+                    accH[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, d4.z, accH[t], 0, 0, 0);
+                    accH[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, d4.w, accH[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        ob ^= 1;
+    }
+#pragma unroll
+    for (int t = 0; t < kTJ / 16; ++t) {
+        const int jc = j0 + 16 * t + r;
+        if (jc >= J) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s = s0 + wave * 16 + g * 4 + q;
+            if (s < S) {
+                vg_stream(a.F0 + (((size_t)p * S + s) * L + l) * J + jc, accF[t][q]);
+                if (DELL) vg_stream(a.H + (((size_t)p * S + s) * L + l) * J + jc, accH[t][q]);
+            }
+        }
+    }
+}
+__global__ void tick_kernel(uint32_t* ctr) { *ctr += 1u; }
+
 // Few samples (S <= 32): the prior draws are bound by Phi / dPhi themselves -- every feature is used by only S
 // products, so writing the two matrices (features_kernel) and reading them back (GEMM) is the cost: 157 MB each way
 // for 36 problems of the reference's default shape.  Here a wave forms its feature fragments in registers and feeds
@@ -3025,12 +3157,36 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             if ((rc = launch(fn_cov_b, cov_b_grid, &ca, lds_cov_b))) return rc;
             if (what & VGPMP_COV_ONLY) return (int)hipGetLastError();     // Kuu, Cholesky, q_sqrt, A, per-latent KL: done
             mark();
-            if (gen && (rc = vg_launch_rng(d, nz, seed, problem_base, step_i, ctr, st))) return rc;
+            // large batches drawing their own noise: W and the features are formed inside the GEMM (prior_fused_batch_kernel);
+            // trainable inducing locations read W back (inducing.hip), so they keep it in memory
+            const bool fbatch = gen && tiled_gemm && !fused_small && !ind && !(what & VGPMP_NO_FUSE_PRIOR);
+            if (gen) {
+                RngArgs r = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
+                if (fbatch) r.nW = 0;                    // omega, beta, eps, eps2 only
+                hipLaunchKernelGGL(rng_basis_kernel, dim3((r.L * r.B + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
+                const uint32_t nthr = (r.nW >> 2) + 2 * r.nE;
+                hipLaunchKernelGGL(rng_normals_kernel, dim3((nthr + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
+            }
             mark();
-            if (!fused_small) hipLaunchKernelGGL(features_kernel, feat_grid, dim3(kBlock), 0, st, fe);
+            if (!fused_small && !fbatch) hipLaunchKernelGGL(features_kernel, feat_grid, dim3(kBlock), 0, st, fe);
             mark();
             hipEvent_t g0 = ev ? ev[VG_NUM_STAGES + 3] : nullptr, g1 = ev ? ev[VG_NUM_STAGES + 4] : nullptr;
-            if (fused_small) {      // features formed inside the GEMM (few samples: Phi / dPhi traffic is the cost)
+            if (fbatch) {
+                FusedBatchArgs fb;
+                fb.S = S; fb.L = L; fb.J = J; fb.N = N; fb.D = L; fb.B = B; fb.want_dell = want_dell ? 1 : 0;
+                fb.X = pb->X; fb.Zy = zy; fb.zy_stride = zy_stride; fb.raw_ell = params->raw_ell; fb.raw_var = params->raw_var;
+                fb.omega = nz->omega; fb.beta = nz->beta; fb.F0 = ws->F0; fb.H = ws->H;
+                fb.seed = seed; fb.problem_base = problem_base; fb.step = step_i; fb.ctr = ctr;
+                fb.wOff = (uint32_t)d->sample_offset * L * B;
+                const int dm = L <= 8 ? 8 : 16;
+                const size_t lds_fb = ((size_t)kTS * kFBLd + (size_t)2 * kTJ * kFBLd + (size_t)kTJ * dm + (size_t)2 * kFBK * (dm + 4)) * sizeof(float);
+                const dim3 fb_grid((J + kTJ - 1) / kTJ, (S + kTS - 1) / kTS, P * L);
+#define VG_FB(DELL_, DM_) hipExtLaunchKernelGGL((prior_fused_batch_kernel<DELL_, DM_>), fb_grid, dim3(kBlock), lds_fb, st, g0, g1, 0, fb)
+                if (want_dell) { if (dm == 8) VG_FB(true, 8); else VG_FB(true, 16); }
+                else { if (dm == 8) VG_FB(false, 8); else VG_FB(false, 16); }
+#undef VG_FB
+                if (fe.tick) hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(1), 0, st, fe.tick);      // the feature kernel's tick
+            } else if (fused_small) {      // features formed inside the GEMM (few samples: Phi / dPhi traffic is the cost)
                 launch_fused_small(g0, g1);
             } else if (tiled_gemm) {
                 const int mt = 1;      // 128-sample tiles (mt = 2) measured slower: 90 vs 98 TF/s at 64 problems
