@@ -337,6 +337,7 @@ def main():
             t = json.load(open(tfile))
             roof_sdf["traffic"] = t.get(lik_kernel, {}).get("hbm_bytes_per_launch")
             roof_sdf["traffic_source"] = t.get("source")
+            roof_sdf["traffic_collected_at"] = t.get("collected_at")
             roof_gemm["traffic"] = t.get(gemm_kernel, {}).get("hbm_bytes_per_launch")
         except Exception:
             pass
@@ -367,6 +368,10 @@ def main():
                                f"(sampling measured: {1e3 * t_sample:.2f} ms)" if t_sample is not None else None,
             "roofline": roof_sdf, "roofline_secondary": roof_gemm,
             "dominant_stage": dominant, "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+            "stage_ms_schedule": "separate pass after the timed region with ONE launch per kernel and a HIP event around every stage "
+                                 "(vgpmp_elbo_step_profiled); at 4 problems or fewer the timed region runs the shared stage launches "
+                                 "instead, so stage_ms / dominant_stage describe that pass, not the timed schedule; the two "
+                                 "roofline kernels are timed by their own start / end events in the same pass",
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ps, spec, grid, args)

@@ -1,16 +1,57 @@
 #!/bin/bash
-# Evidence for profiles/r01 (run on the GPU box from the repo root): bench line, rocprofv3 kernel statistics of the
-# same command, FETCH_SIZE / WRITE_SIZE passes.  Every profiler run sits under `timeout`.
+# Evidence for profiles/r02 (run on the GPU box from the repo root; tools/run_collect.sh wraps it with the commit stamp):
+# bench lines, rocprofv3 kernel statistics of the same commands, FETCH_SIZE / WRITE_SIZE passes, SQ / MFMA counter passes.
+# Every profiler run sits under `timeout`; the program stands directly behind `--`.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-out=gpurun_out/r01; rm -rf $out; mkdir -p $out
-python bench.py > $out/r01_bench.json 2> $out/bench.err; tail -c 600 $out/r01_bench.json; echo
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --no-cpu-baseline > $out/r01_bench_under_rocprof.json 2> $out/stats.err
-cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $out/r01_kernel_stats.csv
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats64 -- python3 bench.py --no-cpu-baseline --problems 64 --scene synthetic > $out/r01_bench_64problems_under_rocprof.json 2> $out/stats64.err
-cp $(ls $out/stats64/*/*kernel_stats.csv | head -1) $out/r01_kernel_stats_64problems.csv
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --profile-steps 2 > $out/pmc_$c.json 2> $out/pmc_$c.err
+out=gpurun_out/r02final; rm -rf $out; mkdir -p $out
+stats() {   # stats <tag> <bench args...>: bench line under the kernel trace + the kernel statistics table
+  local tag=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$tag.d -- python3 bench.py "$@" > $out/${tag}_bench_under_rocprof.json 2> $out/$tag.err
+  cp $(ls $out/$tag.d/*/*kernel_stats.csv | head -1) $out/${tag}_kernel_stats.csv; rm -rf $out/$tag.d
+}
+pmc() {     # pmc <tag> <bench args...>: FETCH_SIZE and WRITE_SIZE in separate passes -> per-kernel KB and bytes per launch
+  local tag=$1; shift
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_$c -- python3 bench.py "$@" --min-seconds 0 --profile-steps 2 > /dev/null 2> $out/${tag}_$c.err
+  done
+  python tools/pmc_aggregate.py $out/${tag}_FETCH_SIZE $out/${tag}_WRITE_SIZE $out/${tag}_pmc_fetch_write_kb.json $out/${tag}_pmc_traffic.json > /dev/null
+  rm -rf $out/${tag}_FETCH_SIZE $out/${tag}_WRITE_SIZE
+}
+# ---- config 2 (the benchmark line): one problem per GPU
+pmc config2 --steps 40 --warmup 5 --no-cpu-baseline
+cp $out/config2_pmc_traffic.json profiles/pmc_traffic.json
+python bench.py > $out/config2_bench.json 2> $out/config2_bench.err; tail -c 400 $out/config2_bench.json; echo
+stats config2 --no-cpu-baseline
+# ---- 64 Franka problems per GPU (batch regime, cache-resident table)
+stats franka64 --no-cpu-baseline --problems 64 --scene synthetic
+python bench.py --no-cpu-baseline --problems 64 --scene synthetic > $out/franka64_bench.json 2>> $out/franka64.err
+# ---- config 4: UR10, S = 1024 samples; one rank, and two ranks on this one GPU over gloo (rehearsal of the N > 1 path)
+python bench.py --shard samples --steps 100 --warmup 10 > $out/config4_1rank_bench.json 2> $out/config4.err
+VGPMP_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --shard samples --steps 100 --warmup 10 2>> $out/config4.err | tail -1 > $out/config4_2ranks_gloo_one_gpu_bench.json
+# ---- config 5 share: 14-DoF arm, 512^3 voxels (2 GiB table), 64 problems
+B5="--workload stress --problems 64 --grid 512 --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 10"
+for f in brick:on brick:off linear:off; do
+  lay=${f%%:*}; sm=${f##*:}; tag=config5_${lay}_summary_${sm}
+  stats $tag $B5 --layout $lay --summary $sm
+  pmc $tag $B5 --layout $lay --summary $sm
+  timeout 600 python bench.py $B5 --layout $lay --summary $sm --traffic-file $out/${tag}_pmc_traffic.json > $out/${tag}_bench.json 2>> $out/$tag.err
 done
-python tools/pmc_aggregate.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/r01_pmc_fetch_write_kb.json $out/pmc_traffic.json | head -30
-rm -rf $out/stats $out/stats64 $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
-ls -la $out
+# ---- SQ / MFMA counters: the fused prior kernel and the batch likelihood at config 5, the prior GEMM role at config 2
+tools/pmc_sq.sh prior_fused_batch $out/sq_prior_fused_config5 $B5 > /dev/null 2>&1
+tools/pmc_sq.sh "loglik_paths_kernel<" $out/sq_loglik_config5 $B5 > /dev/null 2>&1
+tools/pmc_sq.sh stage2_kernel $out/sq_stage2_config2 --steps 40 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+# ---- the memory system's ceiling for 16-byte gathers
+if [ -x tools/gather_probe ]; then
+  timeout 300 tools/gather_probe > $out/gather_probe.txt 2>&1
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/gp_fetch -- tools/gather_probe calib > $out/gather_probe_calib.txt 2>&1
+  python - <<PY >> $out/gather_probe_calib.txt
+import csv, glob
+f = glob.glob("$out/gp_fetch/*/*counter_collection.csv")[0]
+v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == "FETCH_SIZE" and "gather" in r["Kernel_Name"]]
+n = 256 * 8 * 8 * 64 * 64 * 4
+print("FETCH_SIZE per gather launch (KB):", v, "-> bytes tallied per random 16-byte gather:", [x * 1024 / n for x in v])
+PY
+  rm -rf $out/gp_fetch
+fi
+find $out -name "*.err" -size 0 -delete
+ls -la $out | head -60

@@ -33,20 +33,25 @@ def main():
     table = {k: {"launches": n[k], "fetch_size_kb": round(fetch[k], 1), "write_size_kb": round(write.get(k, 0.0), 1)}
              for k in sorted(fetch)}
     json.dump(table, open(out, "w"), indent=1)
-    t = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, plain launches, 40 steps), "
-                   "profiles/r01/r01_pmc_fetch_write_kb.json; bytes = FETCH_SIZE*1024 (x2 for kernels whose reads are "
-                   "16 B per lane: the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE*1024; unit calibrated on "
-                   "sdf_pack_kernel in the same run (8 B per lane reads, 16 B per lane writes of a known volume)"}
-    wide16 = ("loglik_paths_wide_kernel<8, false>", "loglik_paths_wide_kernel<4, false>", "loglik_paths_kernel<1, 64, false>", "prior_gemm_kernel<0>", "prior_gemm_lds_kernel",
-              "prior_gemm_tiled_kernel",
-              "stage2_kernel<true, 0>", "stage2_kernel<true, 8>", "paths_bwd_sc8", "stage3_kernel")
+    import os
+    stamp = ""
+    sp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "COLLECT_STAMP")
+    if os.path.exists(sp):
+        stamp = open(sp).read().strip()
+    t = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, plain launches) of the same bench.py command, "
+                   "aggregated per kernel by tools/pmc_aggregate.py; bytes = FETCH_SIZE*1024 x multiplier + WRITE_SIZE*1024, multiplier 2 "
+                   "for kernels whose reads are wide coalesced streams (the gfx950 correction of MI355X_MICROARCH.md), 1 for the "
+                   "likelihood's 16-byte gathers (FETCH_SIZE tallies 65 B per random 16-byte gather: profiles/r02/final/gather_probe_calib.txt)",
+         "collected_at": stamp}
+    wide16 = ("prior_gemm_kernel<0>", "prior_gemm_lds_kernel", "prior_gemm_tiled_kernel", "stage2_kernel<true, 0>", "stage2_kernel<true, 8>",
+              "paths_bwd_sc8", "stage3_kernel")
     for k, v in table.items():
         mult = 2 if any(k.startswith(w.split("<")[0]) for w in wide16) else 1
         t[k] = dict(v, hbm_bytes_per_launch=int(mult * v["fetch_size_kb"] * 1024 + v["write_size_kb"] * 1024),
                     fetch_multiplier=mult)
     json.dump(t, open(traffic, "w"), indent=1)
     for k, v in t.items():
-        if k != "source":
+        if k not in ("source", "collected_at"):
             print(k, v)
 
 
