@@ -3,7 +3,7 @@
 # taken at (the GPU box has no .git).  From the repo root, in the build container.
 set -e
 head=$(git rev-parse --short HEAD); dirty=$(git status --porcelain | grep -v '^??' | wc -l)
-stamp="commit $head$([ "$dirty" != 0 ] && echo " + $dirty uncommitted file(s)")"
+stamp="commit $head"; if [ "$dirty" != 0 ]; then stamp="$stamp + $dirty uncommitted file(s)"; fi
 echo "$stamp" > profiles/COLLECT_STAMP
 /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh > gpurun_out/collect.log 2>&1; tail -5 gpurun_out/collect.log'
 dst=profiles/r02/final; rm -rf $dst; mkdir -p $dst
