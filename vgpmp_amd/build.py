@@ -13,6 +13,8 @@ LIB_DIR = PKG / "lib"
 LIB = LIB_DIR / "libvgpmp_hip.so"
 SOURCES = ["fk_sdf.hip", "gp_path.hip", "mesh_sdf.hip", "deriv_kernels.hip", "plan.hip", "inducing.hip", "comm.hip", "capi.hip"]
 HEADERS = [CSRC / "vgpmp_device.h", CSRC / "gp_path.h", CSRC / "fk_chain.h", CSRC / "gp_math.h", ROOT / "include" / "vgpmp.h"]
+# private parts of gp_path.hip (one translation unit: its stage launches dispatch these bodies by role)
+GP_PARTS = [CSRC / n for n in ("gp_common.h", "gp_rng.h", "gp_paths.h", "gp_update.h", "gp_cov.h", "gp_prior.h", "gp_lik_consts.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc=0",
          "-Wall", "-Wno-unused-function"]
 
@@ -35,7 +37,7 @@ def _stale(target: Path, deps) -> bool:
 
 
 def needs_build() -> bool:
-    return _stale(LIB, [CSRC / s for s in SOURCES] + HEADERS)
+    return _stale(LIB, [CSRC / s for s in SOURCES] + HEADERS + GP_PARTS)
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
@@ -49,7 +51,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     for src in SOURCES:
         obj = OBJ_DIR / (Path(src).stem + ".o")
         objs.append(obj)
-        if force or _stale(obj, [CSRC / src] + HEADERS):
+        if force or _stale(obj, [CSRC / src] + HEADERS + (GP_PARTS if src == "gp_path.hip" else [])):
             cmd = [hipcc(), *cflags, f"-I{ROOT / 'include'}", f"-I{CSRC}", "-c", str(CSRC / src), "-o", str(obj)]
             if verbose:
                 print(" ".join(cmd), flush=True)

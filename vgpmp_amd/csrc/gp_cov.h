@@ -1,0 +1,648 @@
+// Float64 covariance path: Kuu, factorisation, q_sqrt, KL, A = Kfu (Kuu + jI)^-1 and tangents.
+// Private part of gp_path.hip (one translation unit: the stage launches call these bodies by role).
+#pragma once
+
+namespace {
+
+// =================================================================================================
+// Covariance path (float64).
+//
+// cov_fwd_kernel -- one workgroup per (latent, problem): Kuu, chol, inverse, q_sqrt, KL and its
+//   gradient, plus the FORWARD-MODE tangents of chol/q_sqrt/KL wrt the latent's two kernel
+//   hyper-parameters (lengthscale, variance).
+// cov_rows_kernel -- row tiles of A = Kfu (Kuu + jI)^-1 and of its two tangents, spread over
+//   N/8 workgroups per latent.
+// With the tangents available the sample-dependent reverse pass needs only dot products of its
+// upstream gradients with them -- no Cholesky adjoint, no N-sized float64 reductions -- and both
+// kernels sit off the critical path (side stream) next to the noise/feature/GEMM branch.
+// =================================================================================================
+struct CovArgs {
+    int N, M, L, D;
+    const double *X, *Zy, *y_u;
+    size_t zy_stride;        // doubles between the Zy of consecutive problems (0: one shared set)
+    double jitter;
+    const double *q_mu, *q_sqrt, *raw_ell, *raw_var;
+    int want_dell;
+    int stop;
+    int elim_wave;           // Mz <= 32: the elimination on one wave (chol_inverse_wave)
+    uint32_t* tick;          // device step counter, ticked by one row-tile workgroup of stage 2 (or null)
+    double lr;               // with the tick: the step size of this step's update goes to lr_dev[0]
+    double* lr_dev;
+    // hyper-parameter update of the previous step as a prologue (stage 1) / its commit (stage 2, role 0)
+    int prologue, commit, keep_prev;
+    HyperArgs hy;
+    vg_workspace ws;
+};
+
+constexpr int kCovThreads = 256;      // == kBlock: the covariance roles share launches with other kernels
+constexpr int kRowTile = 8;
+
+// ---- float64 matrix-core tiles ---------------------------------------------------------------------
+// v_mfma_f64_16x16x4_f64: lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15] (one
+// double each); it receives D[row = (l >> 4) + 4 q][col = l & 15] in accumulator element q = 0..3.
+// All matrices live in LDS with dimension Mp = roundup(Mz, 16) (zero padded), so no edge handling.
+typedef double vg_f64x4 __attribute__((ext_vector_type(4)));
+
+struct MatView {            // element (r, c) at p[r * sr + c * sc]
+    const double* p;
+    int sr, sc;
+};
+
+__device__ __forceinline__ vg_f64x4 mfma_tile_f64(MatView A, MatView B, int K, int lane, int i0, int j0) {
+    vg_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    const int r = lane & 15, g = lane >> 4;
+    const double* ap = A.p + (i0 + r) * A.sr + g * A.sc;
+    const double* bp = B.p + g * B.sr + (j0 + r) * B.sc;
+    // K is a multiple of 16: passes of four k-steps with constant bounds, so that a pass's eight operands are
+    // requested together and its products chain in the accumulator registers (a loop with a run-time trip count is
+    // left rolled by the compiler: load, wait, move the accumulator in, multiply, move it out -- 3x slower)
+    auto pass = [&](int k0) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { av[u] = ap[(k0 + 4 * u) * A.sc]; bv[u] = bp[(k0 + 4 * u) * B.sr]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    };
+    if (K == 32) { pass(0); pass(16); }
+    else for (int k0 = 0; k0 < K; k0 += 16) pass(k0);
+    return acc;
+}
+
+// D = A B over all 16x16 tiles of an Mp x Mp result, tiles dealt round-robin to the waves; `emit(r, c, v)`
+// receives every element.
+template <typename Emit>
+__device__ __forceinline__ void matmul_f64(MatView A, MatView B, int Mp, int tid, int nt, Emit emit) {
+    const int lane = tid & 63, nT = Mp >> 4;
+    for (int t = tid >> 6; t < nT * nT; t += nt >> 6) {
+        const int i0 = (t / nT) << 4, j0 = (t % nT) << 4;
+        const vg_f64x4 acc = mfma_tile_f64(A, B, Mp, lane, i0, j0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) emit(i0 + (lane >> 4) + 4 * q, j0 + (lane & 15), acc[q]);
+    }
+}
+
+// Cholesky factor and its inverse of the SPD matrix held in La (LDS), by forward elimination of the
+// augmented matrix [K | I] without pivoting (K = L~ D L~^T): after Mz pivots the left half holds
+// U = D L~^T and the right half L~^-1, so  Lk = L~ D^1/2  and  Lk^-1 = D^-1/2 L~^-1.  Every pivot is
+// one rank-1 update spread over the whole workgroup and ONE barrier (any Mz; chol_inverse_regs below is the
+// faster form for Mz <= 32).
+__device__ __forceinline__ void chol_inverse_block(double* La, double* Li, double* Aug, double* rsd, int Mz, int ld,
+                                                   int tid, int nt) {
+    const int la = 2 * Mz + 1;
+    const float iMz = 1.0f / (float)Mz, i2Mz = 0.5f / (float)Mz;
+    for (int e = tid; e < Mz * 2 * Mz; e += nt) {
+        const int i = vg_div(e, i2Mz), j = e - i * 2 * Mz;
+        Aug[i * la + j] = j < Mz ? La[i * ld + j] : (j - Mz == i ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    for (int k = 0; k < Mz; ++k) {
+        const double r = 1.0 / Aug[k * la + k];
+        const int h = Mz - k - 1;                   // rows k+1 .. Mz-1, columns k+1 .. Mz+k
+        for (int e = tid; e < h * Mz; e += nt) {
+            const int qi = vg_div(e, iMz);
+            const int i = k + 1 + qi, j = k + 1 + (e - qi * Mz);
+            Aug[i * la + j] = fma(-(Aug[i * la + k] * r), Aug[k * la + j], Aug[i * la + j]);
+        }
+        __syncthreads();
+    }
+    for (int k = tid; k < Mz; k += nt) rsd[k] = rsqrt(Aug[k * la + k]);
+    __syncthreads();
+    for (int e = tid; e < Mz * Mz; e += nt) {
+        const int i = vg_div(e, iMz), j = e - i * Mz;
+        La[i * ld + j] = j <= i ? Aug[j * la + i] * rsd[j] : 0.0;
+        Li[i * ld + j] = j <= i ? Aug[i * la + Mz + j] * rsd[i] : 0.0;
+    }
+    __syncthreads();
+}
+
+// The same elimination with the augmented matrix in REGISTERS (Mz <= 32, 256 threads): thread (row i = tid & 31,
+// column block jb = tid >> 5) keeps columns [8 jb, 8 jb + 8) of [K | I] laid out as 32 + 32 columns.  Per pivot
+// the owners publish the pivot row and the pivot column through LDS (double buffered: one barrier per pivot),
+// everyone reads its 8 + 2 values in one LDS round and does 8 FMAs out of registers; measured 340 ns per pivot
+// against 420 ns for the LDS-resident loop above (three LDS reads and a write per element).
+__device__ __forceinline__ void chol_inverse_regs(double* La, double* Li, double* Aug, double* rsd, int Mz, int ld,
+                                                  int tid, int nt) {
+    const int i = tid & 31, jb = tid >> 5, la = 2 * Mz + 1;
+    const float iMz = 1.0f / (float)Mz;
+    double* prow = Aug;                  // [2][64] pivot row, both halves
+    double* pcol = Aug + 128;            // [2][32] pivot column
+    double a[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int col = 8 * jb + c;      // < 32: column of K;  >= 32: column col - 32 of I
+        a[c] = i < Mz ? (col < 32 ? (col < Mz ? La[i * ld + col] : 0.0) : (col - 32 == i ? 1.0 : 0.0)) : 0.0;
+    }
+    __syncthreads();
+#pragma nounroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int k = 8 * kb + c;
+            if (k >= Mz) break;
+            const int buf = k & 1;
+            if (i == k) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) prow[buf * 64 + 8 * jb + q] = a[q];
+            }
+            if (jb == kb) pcol[buf * 32 + i] = a[c];
+            __syncthreads();
+            // one LDS round for everything this thread needs of pivot k (read unconditionally, used conditionally)
+            const double piv = pcol[buf * 32 + k], aik = pcol[buf * 32 + i];
+            double pr[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pr[q] = prow[buf * 64 + 8 * jb + q];
+            if (tid == 0) rsd[k] = piv;          // rsqrt after the loop, off the chain
+            // 1 / piv sits on the dependency chain of every pivot: hardware estimate + two Newton steps (to the
+            // last bit or two) instead of the ~10-instruction IEEE division sequence
+            double r = __builtin_amdgcn_rcp(piv);
+            r = fma(fma(-piv, r, 1.0), r, r);
+            r = fma(fma(-piv, r, 1.0), r, r);
+            const double m = (i > k && i < Mz) ? aik * r : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = fma(-m, pr[q], a[q]);
+        }
+    }
+    __syncthreads();
+    if (tid < Mz) rsd[tid] = rsqrt(rsd[tid]);
+    __syncthreads();
+    // registers -> the [Mz][2 Mz + 1] image the tail expects: left half U = D L~^T, right half L~^-1
+    double* Img = Aug;                   // the exchange buffers are dead now
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int col = 8 * jb + c;
+        if (i < Mz) {
+            if (col < Mz) Img[i * la + col] = a[c];
+            else if (col >= 32 && col - 32 < Mz) Img[i * la + Mz + (col - 32)] = a[c];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < Mz * Mz; e += nt) {
+        const int r = vg_div(e, iMz), j = e - r * Mz;
+        La[r * ld + j] = j <= r ? Img[j * la + r] * rsd[j] : 0.0;
+        Li[r * ld + j] = j <= r ? Img[r * la + Mz + j] * rsd[r] : 0.0;
+    }
+    __syncthreads();
+}
+
+// The same elimination on ONE wave without LDS or barriers in the loop (Mz <= 32): lane c keeps column c of
+// [K | I] (32 + 32 columns, 32 rows = 64 registers); the pivot and the pivot column reach the other lanes as
+// scalar broadcasts (v_readlane), the loops are fully unrolled so that every row index is a register name.  What
+// is left of a pivot's cost is its dependency chain (reciprocal + two Newton steps + the update of the next pivot),
+// the trailing updates of the previous pivot fill its gaps.  (The multiplier is applied as a_ik (row_k / d_k) instead
+// of (a_ik / d_k) row_k: one independent FMA per row; results differ from the forms above in the last bit.)
+__device__ __forceinline__ double vg_bcast_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void chol_inverse_wave(double* La, double* Li, double* Aug, double* rsd, int Mz, int ld,
+                                                  int tid, int nt) {
+    const int la = 2 * Mz + 1;
+    const float iMz = 1.0f / (float)Mz;
+    double* Img = Aug;
+    if (tid < VG_WAVE) {
+        const int c = tid;
+        double a[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const double kv = La[min(i, Mz - 1) * ld + min(c & 31, Mz - 1)];      // loads first, selects afterwards
+            const double id = (i == (c & 31)) ? 1.0 : 0.0;
+            a[i] = c < 32 ? ((i < Mz && c < Mz) ? kv : id) : id;
+        }
+        // software pipelined: pivot k first finishes row k + 1 -- the next pivot row -- so that the next reciprocal
+        // (the long dependent chain) is in flight while the remaining rows of pivot k are updated
+        double piv = vg_bcast_f64(a[0], 0);
+        double r = __builtin_amdgcn_rcp(piv);
+        r = fma(fma(-piv, r, 1.0), r, r);
+        r = fma(fma(-piv, r, 1.0), r, r);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            double rn = 0.0;
+            // row_i -= (a_ik / d_k) row_k as ONE product per row: the scalar a_ik times w = row_k / d_k (per lane)
+            const double w = -a[k] * r;
+            if (k + 1 < 32) {
+                a[k + 1] = fma(vg_bcast_f64(a[k + 1], k), w, a[k + 1]);
+                const double pn = vg_bcast_f64(a[k + 1], k + 1);
+                rn = __builtin_amdgcn_rcp(pn);
+                rn = fma(fma(-pn, rn, 1.0), rn, rn);
+                rn = fma(fma(-pn, rn, 1.0), rn, rn);
+            }
+#pragma unroll
+            for (int i = k + 2; i < 32; ++i) a[i] = fma(vg_bcast_f64(a[i], k), w, a[i]);
+            r = rn;
+        }
+        // pivot k is the diagonal entry lane k ends with (row k is final once pivot k - 1 is done): rsqrt after the
+        // loop, off the chain
+        double mine = 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) mine = c == i ? a[i] : mine;
+        if (c < Mz) rsd[c] = mine;
+        // registers -> the [Mz][2 Mz + 1] image the tail expects: left half U = D L~^T, right half L~^-1
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if (i < Mz) {
+                if (c < Mz) Img[i * la + c] = a[i];
+                else if (c >= 32 && c - 32 < Mz) Img[i * la + Mz + (c - 32)] = a[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < Mz) rsd[tid] = rsqrt(rsd[tid]);
+    __syncthreads();
+    for (int e = tid; e < Mz * Mz; e += nt) {
+        const int r = vg_div(e, iMz), j = e - r * Mz;
+        La[r * ld + j] = j <= r ? Img[j * la + r] * rsd[j] : 0.0;
+        Li[r * ld + j] = j <= r ? Img[r * la + Mz + j] * rsd[r] : 0.0;
+    }
+    __syncthreads();
+}
+
+// ---- stage A: Kuu, factorisation, inverse --------------------------------------------------------
+__device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, int p) {
+    __shared__ double scal[2];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    VG_T(l == 0 && p == 0, 100);
+    const int M = a.M, Mz = M + 2, L = a.L, D = a.D;
+    const int Mp = (Mz + 15) & ~15, ld = Mp + 1;
+    const float iMz = 1.0f / (float)Mz;
+    const size_t pl = (size_t)p * L + l;
+    double* La = sm;                 // Kuu + jI -> Cholesky factor Lk      (Mp x ld, zero padded)
+    double* Li = La + Mp * ld;       // Lk^-1
+    double* Sc = Li + Mp * ld;       // 2 x (Mp x ld) scratch: augmented matrix of the elimination
+    double* zs = Sc + 2 * Mp * ld;   // [Mp]
+    double* rsd = zs + Mp;           // [Mp]
+    // the latent's two scalars, each a chain of float64 exp / log / sqrt / division (~1 us): lengthscale on the first
+    // lane of wave 0, variance on the first lane of wave 1 (different waves run side by side, lanes of one do not)
+    if (tid == 0 || tid == VG_WAVE) {
+        const bool is_ell = tid == 0;
+        double raw;
+        if (a.prologue) {
+            const HyperState o = hyper_update(a.hy, pl, false, 0.0, is_ell ? 1 : 2);
+            double* nx = a.hy.next + 6 * pl;
+            if (is_ell) { a.hy.g_ell[pl] = o.g_ell; nx[0] = o.raw_ell; nx[2] = o.m_ell; nx[3] = o.v_ell; raw = o.raw_ell; }
+            else { a.hy.g_var[pl] = o.g_var; nx[1] = o.raw_var; nx[4] = o.m_var; nx[5] = o.v_var; raw = o.raw_var; }
+        } else {
+            raw = is_ell ? a.raw_ell[pl] : a.raw_var[pl];
+        }
+        if (is_ell) { scal[0] = softplus_d(raw); a.ws.sig_ell[pl] = sigmoid_d(raw); }
+        else { scal[1] = kVarFloor + softplus_d(raw); a.ws.sig_var[pl] = sigmoid_d(raw); }
+    }
+    for (int e = tid; e < 2 * Mp * ld; e += nt) sm[e] = 0.0;
+    for (int i = tid; i < Mz; i += nt) zs[i] = a.Zy[(size_t)p * a.zy_stride + (size_t)i * D + l];
+    __syncthreads();
+    const double ell = scal[0], var = scal[1], jit = a.jitter;
+    if (tid == 0) { a.ws.ell[pl] = ell; a.ws.var[pl] = var; }
+    // Kuu and dKuu/dell share the exponential; symmetric: evaluate the lower triangle only
+    double* Kg = a.ws.Ks64 + pl * Mz * Mz;
+    double* Kdg = a.ws.Kd_ell + pl * Mz * Mz;
+    // lower triangle only, in triangular order (e -> row i, column j <= i): Mz (Mz + 1) / 2 evaluations of the exponential
+    // spread evenly over the workgroup; one division per thread instead of two per element
+    const double inv_ell = 1.0 / ell, c3 = 5.0 / (3.0 * ell);
+    // (the diagonal needs no exponential: Mz (Mz - 1) / 2 = 496 evaluations at Mz = 32 are two rounds of the
+    // workgroup, with the diagonal among them it was three)
+    for (int e = tid; e < Mz * (Mz - 1) / 2; e += nt) {
+        int i = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        if (i * (i + 1) / 2 > e) --i;                    // float rounding at the row boundaries
+        if ((i + 1) * (i + 2) / 2 <= e) ++i;
+        const int j = e - i * (i + 1) / 2;               // strictly lower entry (i + 1, j)
+        ++i;
+        double r = fabs(zs[i] - zs[j]) * inv_ell;
+        double ex = exp(-kSqrt5 * r);
+        double k = var * (1.0 + kSqrt5 * r + (5.0 / 3.0) * r * r) * ex;
+        double dk = var * ex * (r * r * c3) * (1.0 + kSqrt5 * r);
+        La[i * ld + j] = k; La[j * ld + i] = k;
+        Kg[(size_t)i * Mz + j] = k; Kg[(size_t)j * Mz + i] = k;
+        Kdg[(size_t)i * Mz + j] = dk; Kdg[(size_t)j * Mz + i] = dk;
+    }
+    for (int i = tid; i < Mz; i += nt) {                 // r = 0: k = var exp(-0) = var, dk = 0
+        La[i * ld + i] = var + jit;
+        Kg[(size_t)i * Mz + i] = var;
+        Kdg[(size_t)i * Mz + i] = 0.0;
+    }
+    __syncthreads();
+    VG_T(l == 0 && p == 0, 101);
+    if (Mz <= 32 && a.elim_wave) chol_inverse_wave(La, Li, Sc, rsd, Mz, ld, tid, nt);
+    else if (Mz <= 32 && nt == 256) chol_inverse_regs(La, Li, Sc, rsd, Mz, ld, tid, nt);
+    else chol_inverse_block(La, Li, Sc, rsd, Mz, ld, tid, nt);
+    VG_T(l == 0 && p == 0, 102);
+    double* Kig = a.ws.Kinv + pl * Mz * Mz;
+    matmul_f64(MatView{Li, 1, ld}, MatView{Li, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
+        if (r < Mz && c < Mz) Kig[(size_t)r * Mz + c] = v;
+    });
+    double* Lkg = a.ws.Lk64 + pl * Mz * Mz;
+    double* Lig = a.ws.Li64 + pl * Mz * Mz;
+    for (int e = tid; e < Mz * Mz; e += nt) {
+        const int i = vg_div(e, iMz), j = e - i * Mz;
+        Lkg[e] = La[i * ld + j];
+        Lig[e] = Li[i * ld + j];
+    }
+    VG_T(l == 0 && p == 0, 103);
+}
+
+__global__ __launch_bounds__(kCovThreads) void cov_a_kernel(CovArgs a) {
+    extern __shared__ double sm[];
+    cov_a_body(a, sm, blockIdx.x, blockIdx.y);
+}
+
+// ---- stage B: heterogeneous launch, role = blockIdx.x ---------------------------------------------
+//   0            q_sqrt = Lk pad(Q) + jitter, q_mu, KL and its gradient wrt q_mu / q_sqrt
+//   1, 2         forward-mode tangent wrt lengthscale / variance:  dC = (Lk Phi(Lk^-1 dK Lk^-T)) pad(Q), dKL
+//   3 + t        row tile t of A = Kfu (Kuu + jI)^-1 and its tangents (cov_rows_body)
+__device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int p, int tid, int nt);
+
+template <bool TANGENTS>
+__device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int role, int l, int p) {
+    __shared__ double red[kCovThreads / VG_WAVE];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (role >= 3) {
+        // The step counter ticks where no kernel that reads it runs alongside: noise drawn before this launch
+        // saw the old value, the noise of the next step and the Adam count see the new one.
+        if (a.tick && role == 3 && l == 0 && p == 0 && tid == 0) {
+            const uint32_t t = *a.tick + 1u;          // = 1-based Adam count of this step's update
+            *a.tick = t;
+            a.lr_dev[0] = adam_step_size(a.lr, (double)t);
+        }
+        cov_rows_body(a, sm, role - 3, l, p, tid, nt);
+        return;
+    }
+    if (role > 0 && (!TANGENTS || (role == 1 && !a.want_dell))) return;
+    VG_T(l == 0 && p == 0, 200 + 10 * role);
+    const int M = a.M, Mz = M + 2, L = a.L;
+    const int Mp = (Mz + 15) & ~15, ld = Mp + 2;      // even: LDS rows start on 16 bytes
+    const float iMz = 1.0f / (float)Mz, iM = 1.0f / (float)M;
+    const size_t pl = (size_t)p * L + l;
+    double* La = sm;                 // Lk, later pad(q_sqrt) for the tangents   (all Mp x ld, zero padded)
+    double* Li = La + Mp * ld;       // Lk^-1
+    double* X1 = Li + Mp * ld;       // role 0: pad(q_sqrt), Q at [2:, 2:];  tangents: dK/dtheta, then W
+    double* X2 = X1 + Mp * ld;       // tangents: scratch T
+    double* dl = X2 + Mp * ld;       // [Mp] q_mu - p_mu
+    double* af = dl + Mp;            // [Mp] Lk^-1 (q_mu - p_mu)
+    double* v1 = af + Mp;            // [Mp]
+    double* k0 = v1 + Mp;            // [Mp] first two columns of Kuu + jI
+    double* k1 = k0 + Mp;
+    double* kd0 = k1 + Mp;           // [Mp] first two columns of dK/dtheta
+    double* kd1 = kd0 + Mp;
+    double* Qp = X1;
+    double* Kd = X1;
+    double* T = X2;
+    double* qm = kd1 + Mp;           // [Mp] q_mu behind the two conditioned points
+    const double jit = a.jitter, var = a.ws.var[pl];
+    const double y0 = a.y_u[((size_t)p * 2 + 0) * L + l], y1 = a.y_u[((size_t)p * 2 + 1) * L + l];
+    const double* Kg = a.ws.Ks64 + pl * Mz * Mz;
+    constexpr int kQRegs = (VGPMP_MAX_MZ - 2) * (VGPMP_MAX_MZ - 2) / kCovThreads + 1;
+    double qreg[kQRegs];
+    {
+        // every operand by DMA, all requests in flight together (zero padding written directly)
+        const double* Qg = a.q_sqrt + pl * M * M;
+        auto all = [](int, int) { return true; };
+        const bool square = Mz == Mp;      // no zero padding needed: whole rows in 16-byte units
+        if (square) {
+            vg_stage_f64_square(La, ld, a.ws.Lk64 + pl * Mz * Mz, Mz, tid, nt);
+            vg_stage_f64_square(Li, ld, a.ws.Li64 + pl * Mz * Mz, Mz, tid, nt);
+        } else {
+            vg_stage_f64(La, Mp, ld, a.ws.Lk64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
+            vg_stage_f64(Li, Mp, ld, a.ws.Li64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
+        }
+        if (role == 0) {
+            vg_stage_f64(Qp, Mp, ld, Qg, M, M, 2, 2, tid, nt, [](int r, int c) { return c <= r; });
+        } else {      // tangents: this thread's share of Q waits in registers until Lk's LDS space is free
+            const double* Kdg = role == 1 ? a.ws.Kd_ell + pl * Mz * Mz : Kg;
+            if (square) vg_stage_f64_square(Kd, ld, Kdg, Mz, tid, nt);
+            else vg_stage_f64(Kd, Mp, ld, Kdg, Mz, Mz, 0, 0, tid, nt, all);
+#pragma unroll
+            for (int k = 0; k < kQRegs; ++k) qreg[k] = Qg[min(tid + k * nt, M * M - 1)];
+        }
+        // k0 | k1: the first two columns of Kuu;  qm: q_mu at [2:]
+        vg_stage_words(k0, 4 * Mp, tid, nt, [&](int w) -> const void* {
+            const int d = w >> 1, col = d >= Mp, i = d - col * Mp;
+            return i < Mz ? reinterpret_cast<const uint32_t*>(Kg + (size_t)i * Mz + col) + (w & 1) : nullptr;
+        });
+        vg_stage_words(qm, 2 * Mp, tid, nt, [&](int w) -> const void* {
+            const int i = w >> 1;
+            return (i >= 2 && i < Mz) ? reinterpret_cast<const uint32_t*>(a.q_mu + pl * M + (i - 2)) + (w & 1) : nullptr;
+        });
+    }
+    if (role == 0 && tid == 0) {      // behind the staging requests: these round trips overlap them
+        if (a.commit && a.hy.do_adam) {      // staged hyper-parameters of the prologue -> their tensors
+            const HyperArgs& h = a.hy;
+            const double* nx = h.next + 6 * pl;
+            h.p_ell[pl] = nx[0]; h.p_var[pl] = nx[1]; h.m_ell[pl] = nx[2]; h.v_ell[pl] = nx[3]; h.m_var[pl] = nx[4];
+            h.v_var[pl] = nx[5];
+        }
+        if (a.keep_prev) {                   // this step's var / slopes for the prologue of the next step
+            a.ws.prev_var[pl] = a.ws.var[pl];
+            a.ws.prev_sig_ell[pl] = a.ws.sig_ell[pl];
+            a.ws.prev_sig_var[pl] = a.ws.sig_var[pl];
+        }
+    }
+    vg_dma_wait();
+    __syncthreads();
+    // prior mean through the two conditioned points and a = Lk^-1 (q_mu - p_mu)  (prior_kl.py:16-35); the jitter on
+    // the two leading diagonal entries and the conditioned values are applied on the fly (no fix-up pass, no barrier)
+    const double k00 = k0[0] + jit, k01 = k1[0], k11 = k1[1] + jit;
+    const double det = k00 * k11 - k01 * k01;
+    const double c0 = (k11 * y0 - k01 * y1) / det, c1 = (k00 * y1 - k01 * y0) / det;
+    // (loads first, selects afterwards: a conditional load is a branch)
+    auto K0 = [&](int i) { const double v = k0[i]; return i == 0 ? k00 : v; };
+    auto K1 = [&](int i) { const double v = k1[i]; return i == 1 ? k11 : v; };
+    for (int i = tid; i < Mz; i += nt) {
+        const double qi = qm[i];
+        const double mi = i == 0 ? y0 : (i == 1 ? y1 : qi);
+        if (role == 0) a.ws.m[pl * Mz + i] = (float)mi;
+        dl[i] = mi - (K0(i) * c0 + K1(i) * c1);
+    }
+    const double kd_scale = role == 2 ? 1.0 / var : 1.0;      // dK/dvar = K / var, applied to the products
+    if (role == 0) {                         // float32 copy for the gradient assembly (written here, not in stage A:
+        float* Lk32 = a.ws.Lk32 + pl * Mz * Mz;      // stage A of the next step may overlap that kernel)
+        for (int e = tid; e < Mz * Mz; e += nt) {
+            const int i = vg_div(e, iMz), j = e - i * Mz;
+            Lk32[e] = (float)La[i * ld + j];
+        }
+    }
+    __syncthreads();
+    VG_T(l == 0 && p == 0, 201 + 10 * role);
+    double klacc = 0.0;
+    const int sub = tid & 7;
+    for (int i = tid >> 3; i < Mz; i += nt >> 3) {      // af is read again only behind later barriers
+        const double s = dot8(Li + i * ld, 1, dl, 1, i + 1, sub);
+        if (sub == 0) {
+            af[i] = s;
+            if (i >= 2) klacc += s * s;
+        }
+    }
+    if (role == 0) {
+        float* C32 = a.ws.C + pl * Mz * Mz;
+        float* C32T = a.ws.CT + pl * Mz * Mz;
+        matmul_f64(MatView{La, ld, 1}, MatView{Qp, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
+            if (r < Mz && c < Mz) {
+                const float cv = (float)(v + (r == c && r < 2 ? jit : 0.0));
+                C32[(size_t)r * Mz + c] = cv;
+                C32T[(size_t)c * Mz + r] = cv;
+            }
+        });
+        double* gklQ = a.ws.gkl_Q + pl * M * M;
+        for (int e = tid; e < M * M; e += nt) {
+            int r = vg_div(e, iM), c = e - r * M;
+            double gq = 0.0;
+            if (c <= r) {
+                double q = Qp[(r + 2) * ld + (c + 2)];
+                klacc += q * q;
+                gq = q;
+                if (c == r) { klacc -= log(q * q); gq -= 1.0 / q; }
+            }
+            gklQ[e] = gq;
+        }
+        const double kl = block_sum(klacc, red);
+        if (tid == 0) a.ws.kl_l[pl] = 0.5 * (kl - (double)M);
+        // d KL / d q_mu = (Lk^-T [0, 0, a])[2:]
+        for (int k = (tid >> 3) + 2; k < Mz; k += nt >> 3) {
+            const double g = dot8(Li + k * ld + k, ld, af + k, 1, Mz - k, sub);
+            if (sub == 0) a.ws.gkl_qmu[pl * M + (k - 2)] = g;
+        }
+        VG_T(l == 0 && p == 0, 202);
+        return;
+    }
+    // ---- tangent wrt theta: W = Phi(Lk^-1 dK Lk^-T), dLk = Lk W, dC = dLk pad(Q)   (64-bit MFMA products)
+    // Four LDS matrices (35 KB at Mz = 32, so that these workgroups pack 4 per CU next to the prior GEMM):
+    // W overwrites dK (its first two columns are kept), dLk overwrites T, and pad(Q) -- prefetched into
+    // registers -- takes the place of Lk once Lk has been used.
+    for (int i = tid; i < Mz; i += nt) { kd0[i] = Kd[i * ld + 0] * kd_scale; kd1[i] = Kd[i * ld + 1] * kd_scale; }
+    VG_T(l == 0 && p == 0, 204 + 10 * role);
+    matmul_f64(MatView{Li, ld, 1}, MatView{Kd, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) { T[r * ld + c] = v * kd_scale; });
+    __syncthreads();
+    VG_T(l == 0 && p == 0, 205 + 10 * role);
+    double* W = X1;
+    matmul_f64(MatView{T, ld, 1}, MatView{Li, 1, ld}, Mp, tid, nt, [&](int r, int c, double v) {
+        W[r * ld + c] = c < r ? v : (c == r ? 0.5 * v : 0.0);
+    });
+    __syncthreads();
+    VG_T(l == 0 && p == 0, 206 + 10 * role);
+    matmul_f64(MatView{La, ld, 1}, MatView{W, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) { T[r * ld + c] = v; });
+    __syncthreads();
+    VG_T(l == 0 && p == 0, 207 + 10 * role);
+    for (int e = tid; e < Mp * ld; e += nt) La[e] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kQRegs; ++k) {
+        const int e = tid + k * nt;
+        if (e < M * M) {
+            const int r = vg_div(e, iM), c = e - r * M;
+            if (c <= r) La[(r + 2) * ld + (c + 2)] = qreg[k];
+        }
+    }
+    __syncthreads();
+    float* CT = (role == 1 ? a.ws.CT_ell : a.ws.CT_var) + pl * Mz * Mz;
+    matmul_f64(MatView{T, ld, 1}, MatView{La, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
+        if (r < Mz && c < Mz) CT[(size_t)c * Mz + r] = (float)v;       // stored transposed
+    });
+    VG_T(l == 0 && p == 0, 202 + 10 * role);
+    // KL tangent: a_dot = Lk^-1 (delta_dot - dLk a),  delta_dot = -d p_mu
+    const double d00 = kd0[0], d01 = kd1[0], d11 = kd1[1];
+    const double e0 = d00 * c0 + d01 * c1, e1 = d01 * c0 + d11 * c1;        // dKyy c
+    const double cd0 = -(k11 * e0 - k01 * e1) / det, cd1 = -(k00 * e1 - k01 * e0) / det;
+    for (int i = tid >> 3; i < Mz; i += nt >> 3) {
+        const double s = dot8(T + i * ld, 1, af, 1, i + 1, sub);
+        const double pd = kd0[i] * c0 + kd1[i] * c1 + K0(i) * cd0 + K1(i) * cd1;
+        if (sub == 0) v1[i] = -pd - s;
+    }
+    __syncthreads();
+    double acc = 0.0;
+    for (int i = (tid >> 3) + 2; i < Mz; i += nt >> 3) {
+        const double s = dot8(Li + i * ld, 1, v1, 1, i + 1, sub);
+        if (sub == 0) acc += af[i] * s;
+    }
+    acc = block_sum(acc, red);
+    if (tid == 0) (role == 1 ? a.ws.gkl_ell : a.ws.gkl_var)[pl] = acc;
+    VG_T(l == 0 && p == 0, 203 + 10 * role);
+}
+
+template <bool TANGENTS>
+__global__ __launch_bounds__(kCovThreads) void cov_b_kernel(CovArgs a) {
+    extern __shared__ double sm[];
+    cov_b_body<TANGENTS>(a, sm, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// A = Kfu (Kuu + jI)^-1 and its tangents for a tile of kRowTile time points:
+//   A_ell = (dKfu/dell - A dKuu/dell) Kinv,   A_var = (jitter / var) A Kinv
+// Output float32: A4[n][m] = {A, A_ell, A_var, 0} (one 16-byte load per use in the reverse pass)
+// and AT[m][n] for the forward path assembly.
+__device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int p, int tid, int nt) {
+    const int M = a.M, Mz = M + 2, N = a.N, L = a.L, D = a.D, ld = (Mz + 2) & ~1;
+    VG_T(tile == 0 && l == 0 && p == 0, 230);
+    const float iMz = 1.0f / (float)Mz;
+    const size_t pl = (size_t)p * L + l;
+    double* Ki = sm;                       // [Mz][ld]
+    double* Kd = Ki + Mz * ld;             // [Mz][ld]
+    double* kf = Kd + Mz * ld;             // [RT][Mz]  Kfu rows
+    double* df = kf + kRowTile * Mz;       // [RT][Mz]  dKfu/dell rows
+    double* ar = df + kRowTile * Mz;       // [RT][Mz]  A rows
+    double* yr = ar + kRowTile * Mz;       // [RT][Mz]
+    double* zs = yr + kRowTile * Mz;       // [Mz]
+    double* xs = zs + Mz;                  // [RT] times of this tile
+    const double ell = a.ws.ell[pl], var = a.ws.var[pl];
+    const int n0 = tile * kRowTile;
+    {
+        auto all = [](int, int) { return true; };
+        if ((Mz & 1) == 0) {
+            vg_stage_f64_square(Ki, ld, a.ws.Kinv + pl * Mz * Mz, Mz, tid, nt);
+            if (a.want_dell) vg_stage_f64_square(Kd, ld, a.ws.Kd_ell + pl * Mz * Mz, Mz, tid, nt);
+            else for (int e = tid; e < Mz * ld; e += nt) Kd[e] = 0.0;
+        } else {
+            vg_stage_f64(Ki, Mz, ld, a.ws.Kinv + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
+            vg_stage_f64(Kd, Mz, ld, a.ws.Kd_ell + pl * Mz * Mz, a.want_dell ? Mz : 0, Mz, 0, 0, tid, nt, all);
+        }
+        vg_stage_words(zs, 2 * (Mz + kRowTile), tid, nt, [&](int w) -> const void* {
+            const int i = w >> 1;
+            const double* src = i < Mz ? a.Zy + (size_t)p * a.zy_stride + (size_t)i * D + l
+                                       : a.X + (size_t)min(n0 + i - Mz, N - 1) * D + l;
+            return reinterpret_cast<const uint32_t*>(src) + (w & 1);
+        });
+    }
+    vg_dma_wait();
+    __syncthreads();
+    VG_T(tile == 0 && l == 0 && p == 0, 232);
+    for (int e = tid; e < kRowTile * Mz; e += nt) {
+        int r = vg_div(e, iMz), m = e - r * Mz, n = n0 + r;
+        double k = 0.0, dk = 0.0;
+        if (n < N) {
+            double rr = fabs(xs[r] - zs[m]) / ell;
+            double ex = exp(-kSqrt5 * rr);
+            k = var * (1.0 + kSqrt5 * rr + (5.0 / 3.0) * rr * rr) * ex;
+            dk = var * ex * (5.0 * rr * rr / (3.0 * ell)) * (1.0 + kSqrt5 * rr);
+        }
+        kf[e] = k; df[e] = dk;
+    }
+    __syncthreads();
+    VG_T(tile == 0 && l == 0 && p == 0, 233);
+    for (int e = tid; e < kRowTile * Mz; e += nt) {
+        int r = vg_div(e, iMz), m = e - r * Mz;
+        ar[e] = dot4(kf + r * Mz, 1, Ki + m, ld, Mz);
+    }
+    __syncthreads();
+    VG_T(tile == 0 && l == 0 && p == 0, 234);
+    float4* A4 = reinterpret_cast<float4*>(a.ws.A4) + pl * N * Mz;
+    float* AT = a.ws.AT + pl * N * Mz;
+    float av_keep[2] = {0.f, 0.f};
+    int cnt = 0;
+    for (int e = tid; e < kRowTile * Mz; e += nt, ++cnt) {
+        int r = vg_div(e, iMz), m = e - r * Mz;
+        const double y = df[e] - dot4(ar + r * Mz, 1, Kd + m, ld, Mz);
+        const double v = dot4(ar + r * Mz, 1, Ki + m, ld, Mz);
+        yr[e] = y;
+        if (cnt < 2) av_keep[cnt] = (float)(a.jitter / var * v);
+    }
+    __syncthreads();
+    VG_T(tile == 0 && l == 0 && p == 0, 235);
+    cnt = 0;
+    for (int e = tid; e < kRowTile * Mz; e += nt, ++cnt) {
+        int r = vg_div(e, iMz), m = e - r * Mz, n = n0 + r;
+        if (n >= N) continue;
+        const double s = a.want_dell ? dot4(yr + r * Mz, 1, Ki + m, ld, Mz) : 0.0;
+        const float av = av_keep[cnt < 2 ? cnt : 1];
+        vg_stream(A4 + (size_t)n * Mz + m, make_float4((float)ar[e], (float)s, av, 0.f));
+        vg_stream(AT + (size_t)m * N + n, (float)ar[e]);
+    }
+    VG_T(tile == 0 && l == 0 && p == 0, 231);
+}
+
+}  // namespace
