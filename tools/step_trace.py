@@ -16,6 +16,11 @@ from vgpmp_amd import capi, engine, robots as rb, scenes  # noqa: E402
 
 NAMES = {100: "cov_a start", 101: "cov_a Kuu built", 102: "cov_a factorised", 103: "cov_a end",
          110: "final start", 115: "final requests issued", 114: "final operands landed", 111: "final partials summed", 112: "final grads", 113: "final end",
+         150: "final (in stage 1) start", 155: "final (in stage 1) requests issued", 154: "final (in stage 1) operands landed",
+         151: "final (in stage 1) partials summed", 152: "final (in stage 1) grads", 153: "final (in stage 1) end",
+         160: "cov_a slowest wg end", 161: "final slowest wg end", 162: "eps slowest wg end", 163: "features slowest wg end",
+         104: "cov_a panel 1 loaded", 105: "cov_a panel 1 eliminated", 106: "cov_a panel 1 stored", 107: "cov_a second block row formed",
+         108: "cov_a panel 2 loaded", 109: "cov_a panel 2 eliminated", 140: "cov_a panel 2 stored", 141: "cov_a workgroup joined",
          120: "eps start", 130: "features first wg start", 131: "features first wg end", 135: "features last wg end",
          200: "cov_b q start", 201: "cov_b q staged", 202: "cov_b q end",
          210: "cov_b d/dell start", 211: "cov_b d/dell staged", 212: "cov_b d/dell matmuls", 213: "cov_b d/dell end",

@@ -15,8 +15,7 @@ SOURCES = ["fk_sdf.hip", "gp_path.hip", "mesh_sdf.hip", "deriv_kernels.hip", "pl
 HEADERS = [CSRC / "vgpmp_device.h", CSRC / "gp_path.h", CSRC / "fk_chain.h", CSRC / "gp_math.h", ROOT / "include" / "vgpmp.h"]
 # private parts of gp_path.hip (one translation unit: its stage launches dispatch these bodies by role)
 GP_PARTS = [CSRC / n for n in ("gp_common.h", "gp_rng.h", "gp_paths.h", "gp_update.h", "gp_cov.h", "gp_prior.h", "gp_lik_consts.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc=0",
-         "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
 def hipcc() -> str:
@@ -40,16 +39,21 @@ def needs_build() -> bool:
     return _stale(LIB, [CSRC / s for s in SOURCES] + HEADERS + GP_PARTS)
 
 
-def build(force: bool = False, verbose: bool = True) -> Path:
-    """One object per translation unit (rebuilt only when it or a header changed), then the link."""
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = True, measurement: bool = False) -> Path:
+    """One object per translation unit (rebuilt only when it or a header changed), then the link.
+
+    `measurement=True` builds tools/libvgpmp_bisect.so instead: the same sources with -DVGPMP_BISECT (in-kernel time
+    stamps and role switches for tools/step_trace.py, tools/role_probe.sh); never loaded unless VGPMP_HIP_LIB names it."""
+    lib = ROOT / "tools" / "libvgpmp_bisect.so" if measurement else LIB
+    obj_dir = OBJ_DIR.with_name("build_bisect") if measurement else OBJ_DIR
+    if not measurement and not force and not needs_build():
         return LIB
     LIB_DIR.mkdir(exist_ok=True)
-    OBJ_DIR.mkdir(exist_ok=True)
-    cflags = [f for f in FLAGS if f not in ("-shared", "-fgpu-rdc=0")]
+    obj_dir.mkdir(exist_ok=True)
+    cflags = FLAGS + (["-DVGPMP_BISECT"] if measurement else [])
     objs, procs = [], []
     for src in SOURCES:
-        obj = OBJ_DIR / (Path(src).stem + ".o")
+        obj = obj_dir / (Path(src).stem + ".o")
         objs.append(obj)
         if force or _stale(obj, [CSRC / src] + HEADERS + (GP_PARTS if src == "gp_path.hip" else [])):
             cmd = [hipcc(), *cflags, f"-I{ROOT / 'include'}", f"-I{CSRC}", "-c", str(CSRC / src), "-o", str(obj)]
@@ -59,13 +63,12 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", *[str(o) for o in objs], "-ldl", "-o", str(LIB)]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", *[str(o) for o in objs], "-ldl", "-o", str(lib)]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    print(build(force="--force" in sys.argv, measurement="--measurement" in sys.argv))

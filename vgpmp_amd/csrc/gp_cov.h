@@ -34,6 +34,9 @@ struct CovArgs {
     vg_workspace ws;
 };
 
+#ifndef VG_ELIM_PANELS
+#define VG_ELIM_PANELS 1      // 0: measurement builds with the 32-pivot one-wave elimination
+#endif
 constexpr int kCovThreads = 256;      // == kBlock: the covariance roles share launches with other kernels
 constexpr int kRowTile = 8;
 
@@ -237,14 +240,13 @@ __device__ __forceinline__ void chol_inverse_wave(double* La, double* Li, double
 #pragma unroll
         for (int i = 0; i < 32; ++i) mine = c == i ? a[i] : mine;
         if (c < Mz) rsd[c] = mine;
-        // registers -> the [Mz][2 Mz + 1] image the tail expects: left half U = D L~^T, right half L~^-1
+        // registers -> the [Mz][2 Mz + 1] image the tail expects: left half U = D L~^T, right half L~^-1.  One
+        // unconditional store per row: lanes without a column write the image's pad column (2 Mz, never read) --
+        // per-lane conditions here compile to a divergent branch per row
+        double* dst = Img + (c < 32 ? (c < Mz ? c : 2 * Mz) : (c - 32 < Mz ? Mz + (c - 32) : 2 * Mz));
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            if (i < Mz) {
-                if (c < Mz) Img[i * la + c] = a[i];
-                else if (c >= 32 && c - 32 < Mz) Img[i * la + Mz + (c - 32)] = a[i];
-            }
-        }
+        for (int i = 0; i < 32; ++i)
+            if (i < Mz) dst[i * la] = a[i];
     }
     __syncthreads();
     if (tid < Mz) rsd[tid] = rsqrt(rsd[tid]);
@@ -253,6 +255,146 @@ __device__ __forceinline__ void chol_inverse_wave(double* La, double* Li, double
         const int r = vg_div(e, iMz), j = e - r * Mz;
         La[r * ld + j] = j <= r ? Img[j * la + r] * rsd[j] : 0.0;
         Li[r * ld + j] = j <= r ? Img[r * la + Mz + j] * rsd[r] : 0.0;
+    }
+    __syncthreads();
+}
+
+// The elimination in two 16-pivot panels (16 < Mz <= 32), still on ONE wave and without barriers, but with half the row
+// updates: the one-wave form above spends its time issuing 32 * 31 / 2 row updates (two scalar broadcasts + one FMA
+// each) on a single SIMD; here the update of the second block row by the first panel is ONE pair of 16 x 16 x 16
+// products on the float64 matrix cores.
+//   panel 1: rows 0..15 of [K11 | K12 | I] (48 lanes)  ->  U11 = D1 L~11^T,  W = L~11^-1 K12,  L~11^-1
+//   cores:   S = K22 - (W^T D1^-1) W   and   X = -(W^T D1^-1) L~11^-1        (= -K21 K11^-1)
+//   panel 2: rows 16..31 as [S | X | I]                ->  U22 = D2 L~22^T,  L~22^-1 X,  L~22^-1
+// which are the blocks of U = D L~^T and of L~^-1 the tail expects.  (The accumulator of S starts at K22, so the
+// subtraction runs in pivot order like the elimination's; results differ from the forms above in the last bits.)
+template <typename Load>
+__device__ __forceinline__ void eliminate_panel16(double (&a)[16], double (&rinv)[16], Load) {
+    double piv = vg_bcast_f64(a[0], 0);
+    double r = __builtin_amdgcn_rcp(piv);
+    r = fma(fma(-piv, r, 1.0), r, r);
+    r = fma(fma(-piv, r, 1.0), r, r);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        double rn = 0.0;
+        rinv[k] = r;
+        const double w = -a[k] * r;
+        if (k + 1 < 16) {
+            a[k + 1] = fma(vg_bcast_f64(a[k + 1], k), w, a[k + 1]);
+            const double pn = vg_bcast_f64(a[k + 1], k + 1);
+            rn = __builtin_amdgcn_rcp(pn);
+            rn = fma(fma(-pn, rn, 1.0), rn, rn);
+            rn = fma(fma(-pn, rn, 1.0), rn, rn);
+        }
+#pragma unroll
+        for (int i = k + 2; i < 16; ++i) a[i] = fma(vg_bcast_f64(a[i], k), w, a[i]);
+        r = rn;
+    }
+}
+__device__ __forceinline__ void chol_inverse_panels(double* La, double* Li, double* Aug, double* rsd, int Mz, int ld,
+                                                    int tid, int nt) {
+    const int la = 2 * Mz + 1;
+    double* Img = Aug;
+    if (tid < VG_WAVE) {
+        const int c = tid, cc = c & 15;
+        double* Wt = Li;                 // [16][16] W            (the Li image is written by the tail only)
+        double* Ws = Li + 256;           // [16][16] D1^-1 W
+        double* Lt = Li + 512;           // [16][16] L~11^-1
+        double* Dm = Li + 768;           // [16][16] dummy tile (stores of lanes without a column)
+        double* SX = Img + 16 * la;      // [16][32] S | X        (rows 16.. of the image: written after panel 2 has read this)
+        double a[16], rinv[16];
+        // ---- panel 1
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const double kv = La[i * ld + min(c, Mz - 1)];
+            a[i] = c < 32 ? (c < Mz ? kv : 0.0) : (i == c - 32 ? 1.0 : 0.0);
+        }
+        VG_T(blockIdx.x == 0, 104);
+        eliminate_panel16(a, rinv, 0);
+        VG_T(blockIdx.x == 0, 105);
+        {
+            double mine = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mine = c == i ? a[i] : mine;
+            if (c < 16) rsd[c] = mine;
+        }
+        // one unconditional store per row and destination (per-lane conditions compile to a divergent branch per row):
+        // lanes without a column write the image's pad column (2 Mz, never read) / a dummy tile
+        {
+            double* dI = Img + (c < 32 ? (c < Mz ? c : 2 * Mz) : (c < 48 ? Mz + (c - 32) : 2 * Mz));
+            double* dT = (c >= 16 && c < 32 ? Wt : c >= 32 && c < 48 ? Lt : Dm) + cc;
+            double* dS = (c >= 16 && c < 32 ? Ws : Dm) + cc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                dI[i * la] = a[i];
+                dT[i * 16] = a[i];
+                dS[i * 16] = a[i] * rinv[i];
+            }
+        }
+        VG_T(blockIdx.x == 0, 106);
+        // ---- second block row through the matrix cores: lane -> A[i = cc][k = g], B[k = g][j = cc], D[row = g + 4 q][col = cc]
+        {
+            const int g = c >> 4;
+            vg_f64x4 accS, accX = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = 16 + g + 4 * q, col = 16 + cc;
+                const double kv = La[min(row, Mz - 1) * ld + min(col, Mz - 1)];
+                accS[q] = (row < Mz && col < Mz) ? kv : (row == col ? 1.0 : 0.0);
+            }
+            double av[4], bs[4], bx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = g + 4 * u;
+                av[u] = -Ws[k * 16 + cc]; bs[u] = Wt[k * 16 + cc]; bx[u] = Lt[k * 16 + cc];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                accS = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bs[u], accS, 0, 0, 0);
+                accX = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bx[u], accX, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                SX[(g + 4 * q) * 32 + cc] = accS[q];
+                SX[(g + 4 * q) * 32 + 16 + cc] = accX[q];
+            }
+        }
+        VG_T(blockIdx.x == 0, 107);
+        // ---- panel 2
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const double sv = SX[i * 32 + (c & 31)];
+            a[i] = c < 32 ? sv : (i == c - 32 ? 1.0 : 0.0);
+        }
+        VG_T(blockIdx.x == 0, 108);
+        eliminate_panel16(a, rinv, 0);
+        VG_T(blockIdx.x == 0, 109);
+        {
+            double mine = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mine = c == i ? a[i] : mine;
+            if (c < 16 && 16 + c < Mz) rsd[16 + c] = mine;
+        }
+        {
+            double* dI = Img + (c < 16 ? (16 + c < Mz ? 16 + c : 2 * Mz)
+                                : c < 32 ? Mz + (c - 16)
+                                : c < 48 ? (16 + (c - 32) < Mz ? Mz + 16 + (c - 32) : 2 * Mz) : 2 * Mz);
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (16 + i < Mz) dI[(16 + i) * la] = a[i];
+        }
+    }
+    VG_T(blockIdx.x == 0, 140);
+    __syncthreads();
+    VG_T(blockIdx.x == 0, 141);
+    if (tid < Mz) rsd[tid] = rsqrt(rsd[tid]);
+    __syncthreads();
+    // over the whole padded 32 x 32 image: the exchange buffers above sat in Li, whose padding the products downstream read
+    for (int e = tid; e < 32 * 32; e += nt) {
+        const int r = e >> 5, j = e & 31;
+        const bool in = j <= r && r < Mz;
+        La[r * ld + j] = in ? Img[j * la + r] * rsd[j] : 0.0;
+        Li[r * ld + j] = in ? Img[min(r, Mz - 1) * la + Mz + j] * rsd[min(r, Mz - 1)] : 0.0;
     }
     __syncthreads();
 }
@@ -321,7 +463,8 @@ __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, 
     }
     __syncthreads();
     VG_T(l == 0 && p == 0, 101);
-    if (Mz <= 32 && a.elim_wave) chol_inverse_wave(La, Li, Sc, rsd, Mz, ld, tid, nt);
+    if (VG_ELIM_PANELS && Mz > 16 && Mz <= 32 && a.elim_wave) chol_inverse_panels(La, Li, Sc, rsd, Mz, ld, tid, nt);
+    else if (Mz <= 32 && a.elim_wave) chol_inverse_wave(La, Li, Sc, rsd, Mz, ld, tid, nt);
     else if (Mz <= 32 && nt == 256) chol_inverse_regs(La, Li, Sc, rsd, Mz, ld, tid, nt);
     else chol_inverse_block(La, Li, Sc, rsd, Mz, ld, tid, nt);
     VG_T(l == 0 && p == 0, 102);

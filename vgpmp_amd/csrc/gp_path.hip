@@ -22,6 +22,12 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 #else
 #define VG_STOP(args, k) do { } while (0)
 #endif
+#ifndef VG_FIN_SPLIT
+#define VG_FIN_SPLIT 1      // 0: measurement builds with the update role of stage 1 on one workgroup per latent
+#endif
+#ifndef VG_XCD_PATHS
+#define VG_XCD_PATHS 1      // 0: measurement builds without the XCD-contiguous order of the path launches
+#endif
 
 #include "gp_common.h"
 #include "gp_rng.h"
@@ -47,22 +53,35 @@ namespace {
 struct Stage1Args {
     CovArgs cov; FinalArgs fin; RngArgs rng; FeatArgs feat;
     int n_cov, n_fin, n_eps, eps_gx, feat_gx, feat_gy;
+    int fin_split;            // the q_mu / q_sqrt update on kFinSplit workgroups per (latent, problem): final_cols_body
     int skip;                 // measurement builds: bit mask of roles that return at once
 };
 template <bool PRO>
 __global__ __launch_bounds__(kBlock) void stage1_kernel(Stage1Args a) {
     extern __shared__ double sm[];
     int b = blockIdx.x;
-    if (b < a.n_cov) { if (!(a.skip & 1)) cov_a_body(a.cov, sm, b % a.cov.L, b / a.cov.L); return; }
+    if (b < a.n_cov) { if (!(a.skip & 1)) cov_a_body(a.cov, sm, b % a.cov.L, b / a.cov.L); VG_TMAX(160); return; }
     b -= a.n_cov;
-    if (b < a.n_fin) { if (!(a.skip & 2)) final_body(a.fin, sm, b % a.fin.L, b / a.fin.L); return; }
+    if (b < a.n_fin) {
+        if (a.skip & 2) return;
+        if (a.fin_split) {
+            const int q = b % kFinSplit;
+            b /= kFinSplit;
+            final_cols_body(a.fin, sm, q, b % a.fin.L, b / a.fin.L);
+        } else {
+            final_body(a.fin, sm, b % a.fin.L, b / a.fin.L);
+        }
+        VG_TMAX(161);
+        return;
+    }
     b -= a.n_fin;
-    if (b < a.n_eps) { if (!(a.skip & 4)) rng_normals_body(a.rng, b % a.eps_gx, b / a.eps_gx, 0u, a.rng.nE); return; }
+    if (b < a.n_eps) { if (!(a.skip & 4)) rng_normals_body(a.rng, b % a.eps_gx, b / a.eps_gx, 0u, a.rng.nE); VG_TMAX(162); return; }
     b -= a.n_eps;
     if (a.skip & 8) return;
     const int bx = b % a.feat_gx;
     b /= a.feat_gx;
     features_body<PRO>(a.feat, bx, b % a.feat_gy, b / a.feat_gy);
+    VG_TMAX(163);
 }
 
 struct Stage2Args {
@@ -103,6 +122,7 @@ __global__ __launch_bounds__(kBlock) void stage3_kernel(Stage3Args a) {
     int b = blockIdx.x;
     if (b < a.n_path) {
         if (a.skip & 1) return;
+        b = xcd_contiguous(b, a.path.xcd_span);
         const int nch = a.path.NC * a.path.nsplit;
         const int ch = b % nch;
         b /= nch;
@@ -411,6 +431,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     hyp.var = ws->prev_var; hyp.sig_ell = ws->prev_sig_ell; hyp.sig_var = ws->prev_sig_var;
     ca.hy = hyp; fe.hy = hyp;
     pa.stop = -1;
+    pa.xcd_span = 0;
     const double lik_scale = pb->alpha / (double)d->S_total;
     FinalArgs fa;
     fa.M = M; fa.L = L; fa.NC = NC; fa.nblk = P ? vg_loglik_blocks_per_problem(S, N) : 0; fa.part_len = vg_part_len(d);
@@ -428,6 +449,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     fa.vq_mu = av ? av->q_mu : nullptr; fa.vq_sqrt = av ? av->q_sqrt : nullptr;
     fa.pq_mu = params->q_mu; fa.pq_sqrt = params->q_sqrt;
     fa.stop = -1;
+    fa.tshift = 0;
     int skip1 = 0, skip2 = 0, skip3 = 0;
 #ifdef VGPMP_BISECT
     ga.dbg = vg_bisect_stop("VGPMP_GEMM_DBG") > 0 ? vg_bisect_stop("VGPMP_GEMM_DBG") : 0;
@@ -457,6 +479,9 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const bool fin_dma = lds_fin + raw_fin <= 96 * 1024;
     if (fin_dma) lds_fin += raw_fin;
     fa.dma = fin_dma ? 1 : 0;
+    // few problems: the update role of stage 1 by column strips on kFinSplit workgroups (its LDS need is below lds_fin)
+    const bool fin_split = VG_FIN_SPLIT && fin_dma && Mz % (4 * kFinSplit) == 0 && (size_t)(M + M * (Mz / kFinSplit)) <= 2 * kBlock &&
+                           !(what & VGPMP_NO_SPLIT);
     const size_t lds_s1 = lds_cov_a > lds_fin ? lds_cov_a : lds_fin;
     const void* fn_cov_b = backward ? (const void*)cov_b_kernel<true> : (const void*)cov_b_kernel<false>;
     const bool k8 = (B / SK) % 128 == 0;      // K-slice in passes of 8 steps of 16: a pass's operands in one request
@@ -582,11 +607,13 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             s1.skip = skip1;
             s1.cov = ca; s1.fin = fa; s1.feat = fe;
             s1.fin.lr_t = lr_prev;
+            s1.fin.tshift = 40;
             s1.cov.hy = hyp; s1.feat.hy = hyp;
             s1.cov.prologue = prologue ? 1 : 0;
             s1.rng = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
             s1.n_cov = L * P;
-            s1.n_fin = first ? 0 : L * P;
+            s1.fin_split = fin_split ? 1 : 0;
+            s1.n_fin = first ? 0 : L * P * (fin_split ? kFinSplit : 1);
             s1.eps_gx = (int)eps_gx;
             s1.n_eps = (gen && !first) ? (int)eps_gx * P : 0;
             s1.feat_gx = (int)feat_grid.x; s1.feat_gy = (int)feat_grid.y;
@@ -608,6 +635,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             // the counter has ticked in stage 2: it already names the next step
             s3.rng = make_rng_args(d, nz, seed, problem_base, step_i + 1u, ctr, 0u);
             s3.n_path = NC * pa.nsplit * L * P;
+            s3.path.xcd_span = VG_XCD_PATHS && s3.n_path % 8 == 0 ? s3.n_path / 8 : 0;
             s3.basis_gx = (int)basis_gx; s3.w_gx = (int)w_gx;
             s3.n_basis = (gen && more) ? (int)basis_gx * P : 0;
             const unsigned n3 = s3.n_path + s3.n_basis + ((gen && more) ? w_gx * P : 0u);
@@ -709,6 +737,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             return (int)hipGetLastError();
         }
         // ---- reverse of the path assembly (+ hyper-parameter update), then (here or in the next stage 1) the rest
+        pa.xcd_span = VG_XCD_PATHS && split_bwd && (2 * NC * L * P) % 8 == 0 ? 2 * NC * L * P / 8 : 0;
         if ((rc = launch(fn_pb, dim3(split_bwd ? 2 * NC : NC, L, P), &pa, lds_pb))) return rc;
         if (ind) {     // inducing locations as variables: reverse through the covariance path and the prior draw at Zy
             vg_ind_launch il;

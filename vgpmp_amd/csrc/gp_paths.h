@@ -22,7 +22,12 @@ struct PathArgs {
     float* part;
     int want_dell;
     int stop;
+    // Workgroups go to the 8 XCDs round robin.  xcd_span > 0 (= workgroups / 8): XCD x takes the CONTIGUOUS range
+    // [x span, (x + 1) span) of the (chunk, latent, problem) order, so the 2 * NC workgroups that stage the same
+    // latent's A / C tangents sit behind one L2 (at most two latents per XCD instead of all of them)
+    int xcd_span;
 };
+__device__ __forceinline__ int xcd_contiguous(int id, int span) { return span > 0 ? (id & 7) * span + (id >> 3) : id; }
 
 // sum of the SK split-K slabs: SK unconditional loads issued together, then a fixed-order tree sum
 template <int SK>
@@ -488,8 +493,12 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_split(PathArgs a) {
     constexpr int SC = 8;
     extern __shared__ float smf[];
     __shared__ float red[3][kBlock / VG_WAVE];
-    const int ch = blockIdx.x >> 1, half = blockIdx.x & 1, l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int S = a.S, N = a.N, Mz = MZ ? MZ : a.Mz, L = a.L, J = N + Mz;
+    int wg = xcd_contiguous((int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)), a.xcd_span);
+    const int bx = wg % (int)gridDim.x;
+    wg /= (int)gridDim.x;
+    const int ch = bx >> 1, half = bx & 1, l = wg % L, p = wg / L;
     const int Mh = Mz >> 1, m0 = half * Mh;
     const int Nh = (N >> 1) & ~3, n0 = half ? Nh : 0, nx = half ? N - Nh : Nh;
     const float iMh = 1.0f / (float)Mh, iMz = 1.0f / (float)Mz;

@@ -21,6 +21,7 @@ struct FinalArgs {
     double *g_qmu, *g_qsqrt;
     int do_adam, trainable;
     int dma;                  // the chunk partials fit in LDS: stage them by DMA
+    int tshift;               // measurement builds: added to the stamp ids (the role inside stage 1 vs the stand-alone launch)
     const double* lr_dev;     // [1] step size stored at the counter tick (device counter form)
     double lr_t;              // host form
     int use_lr_dev;
@@ -198,7 +199,7 @@ constexpr int kFinRegs = ((VGPMP_MAX_MZ - 2) * (VGPMP_MAX_MZ - 1) + kBlock - 1) 
 __device__ __forceinline__ void final_body(const FinalArgs& b, double* sm, int l, int p) {
     VG_STOP(b, 7);
     const int tid = threadIdx.x, nt = blockDim.x;
-    VG_T(l == 0 && p == 0, 110);
+    VG_T(l == 0 && p == 0, 110 + b.tshift);
     const int M = b.M, Mz = M + 2, L = b.L, nq = M + M * M, np = Mz + Mz * Mz;
     const float iM = 1.0f / (float)M;
     const size_t pl = (size_t)p * L + l;
@@ -231,10 +232,10 @@ __device__ __forceinline__ void final_body(const FinalArgs& b, double* sm, int l
             if (e < Mz) dmv[e] = s;
             else dC[e - Mz] = s;
         }
-    VG_T(l == 0 && p == 0, 115);
+    VG_T(l == 0 && p == 0, 115 + b.tshift);
     vg_dma_wait();
     __syncthreads();
-    VG_T(l == 0 && p == 0, 114);
+    VG_T(l == 0 && p == 0, 114 + b.tshift);
     if (b.dma) {
         for (int e = tid; e < np; e += nt) {
             double s = 0.0;
@@ -250,7 +251,7 @@ __device__ __forceinline__ void final_body(const FinalArgs& b, double* sm, int l
         __syncthreads();
     }
     VG_STOP(b, 6);
-    VG_T(l == 0 && p == 0, 111);
+    VG_T(l == 0 && p == 0, 111 + b.tshift);
     VG_STOP(b, 1);
     const double kls = b.kl_scale;
     double* gQ = b.g_qsqrt + pl * M * M;
@@ -286,9 +287,111 @@ __device__ __forceinline__ void final_body(const FinalArgs& b, double* sm, int l
         }
     }
     VG_STOP(b, 2);
-    VG_T(l == 0 && p == 0, 112);
+    VG_T(l == 0 && p == 0, 112 + b.tshift);
     if (l == 0) elbo_pieces(b.lik_partial, b.nblk, b.kl_l, L, p, b.alpha_fin ? b.alpha_fin[p] : b.lik_scale, kls, b.out_lik, b.out_kl);
-    VG_T(l == 0 && p == 0, 113);
+    VG_T(l == 0 && p == 0, 113 + b.tshift);
+}
+
+// The same assembly on kFinSplit workgroups per (latent, problem), for the few-problem schedule where one workgroup
+// pulling all NC chunk partials of a latent (72 KB at Mz = 32) through one CU is the longest role of its launch.
+// Column c of the q_sqrt gradient tril(Lk^T dC)[2:, 2:] needs column c + 2 of dC only, so workgroup q takes the
+// W = Mz / kFinSplit columns [q W, (q + 1) W) of dC: it stages that strip of every chunk partial (NC Mz rows of W floats)
+// and the factor, sums in the order of sum_chunks() and forms its columns -- bit-identical to final_body().  q_mu
+// (which needs the Mz-vector dm) rides with q = 0, whose first two columns are the fixed end points; the ELBO pieces
+// with the last strip of latent 0.  Needs Mz % (4 kFinSplit) == 0 (16-byte strips).
+constexpr int kFinSplit = 4;
+__device__ __forceinline__ void final_cols_body(const FinalArgs& b, double* sm, int q, int l, int p) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    VG_T(q == 0 && l == 0 && p == 0, 110 + b.tshift);
+    const int M = b.M, Mz = M + 2, L = b.L, W = Mz / kFinSplit, NC = b.NC;
+    const float iW = 1.0f / (float)W, iMz = 1.0f / (float)Mz;
+    const size_t pl = (size_t)p * L + l;
+    double* dC = sm;                 // [Mz][W] columns q W ... of the summed dC
+    double* dmv = dC + Mz * W;       // [Mz]
+    float* Lks = reinterpret_cast<float*>(dmv + Mz + (Mz & 1));   // [Mz][Mz] chol factor
+    float* raw = Lks + ((Mz * Mz + 3) & ~3);                      // [NC][Mz][W] strips of the chunk partials
+    float* rawm = raw + (size_t)NC * Mz * W;                      // [NC][Mz] dm partials (q = 0)
+    const float* part = b.part + pl * NC * b.part_len;
+    const double lr_t = b.do_adam ? (b.use_lr_dev ? b.lr_dev[0] : b.lr_t) : 0.0;
+    vg_stage_rows(raw, NC * Mz, W, tid, nt, [&](int r) -> const float* {
+        const int c = vg_div(r, iMz), i = r - c * Mz;
+        return part + (size_t)c * b.part_len + Mz + (size_t)i * Mz + q * W;
+    });
+    vg_stage_rows(Lks, 1, Mz * Mz, tid, nt, [&](int) -> const float* { return b.Lk32 + pl * Mz * Mz; });
+    if (q == 0) vg_stage_rows(rawm, NC, Mz, tid, nt, [&](int c) -> const float* { return part + (size_t)c * b.part_len; });
+    // this thread's elements: q = 0 has q_mu first; then (r, w) over M rows x W columns of the strip
+    const int nmu = q == 0 ? M : 0, nel = nmu + M * W;
+    double kg[2], xs[2], mo[2], vo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = min(tid + j * nt, nel - 1);
+        const bool mu = k < nmu;
+        const int idx = k - nmu, r = vg_div(max(idx, 0), iW), c = max(q * W + (idx - r * W) - 2, 0);
+        const size_t o = mu ? pl * M + k : pl * M * M + (size_t)r * M + c;
+        kg[j] = (mu ? b.gkl_qmu : b.gkl_Q)[o];
+        if (b.do_adam) {
+            xs[j] = (mu ? b.pq_mu : b.pq_sqrt)[o];
+            mo[j] = (mu ? b.mq_mu : b.mq_sqrt)[o];
+            vo[j] = (mu ? b.vq_mu : b.vq_sqrt)[o];
+        }
+    }
+    VG_T(q == 0 && l == 0 && p == 0, 115 + b.tshift);
+    vg_dma_wait();
+    __syncthreads();
+    VG_T(q == 0 && l == 0 && p == 0, 114 + b.tshift);
+    for (int e = tid; e < Mz * W + (q == 0 ? Mz : 0); e += nt) {
+        const bool isd = e >= Mz * W;
+        const float* src = isd ? rawm + (e - Mz * W) : raw + e;
+        const int stride = isd ? Mz : Mz * W;
+        double s = 0.0;
+        for (int c0 = 0; c0 < NC; c0 += 8) {             // the order of sum_chunks()
+            double d[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[k] = c0 + k < NC ? (double)src[(size_t)min(c0 + k, NC - 1) * stride] : 0.0;
+            s += ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+        }
+        if (isd) dmv[e - Mz * W] = s;
+        else dC[e] = s;
+    }
+    __syncthreads();
+    VG_T(q == 0 && l == 0 && p == 0, 111 + b.tshift);
+    const double kls = b.kl_scale;
+    double* gQ = b.g_qsqrt + pl * M * M;
+    double* gm = b.g_qmu + pl * M;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = tid + j * nt;
+        if (k >= nel) continue;
+        if (k < nmu) {
+            const double g = dmv[k + 2] + kls * kg[j];
+            gm[k] = g;
+            if (b.do_adam && (b.trainable & VGPMP_TRAIN_Q_MU))
+                adam_apply(b.pq_mu + pl * M + k, b.mq_mu + pl * M + k, b.vq_mu + pl * M + k, xs[j], mo[j], vo[j], g, lr_t);
+            continue;
+        }
+        const int idx = k - nmu, r = vg_div(idx, iW), w = idx - r * W, c = q * W + w - 2;
+        if (c < 0) continue;                             // the two fixed end points: no variable
+        const int e = r * M + c;
+        double g = 0.0;
+        if (c <= r) {
+            double s0 = 0.0, s1 = 0.0;
+            int i = r + 2;
+            for (; i + 1 < Mz; i += 2) {
+                s0 = fma((double)Lks[i * Mz + (r + 2)], dC[i * W + w], s0);
+                s1 = fma((double)Lks[(i + 1) * Mz + (r + 2)], dC[(i + 1) * W + w], s1);
+            }
+            if (i < Mz) s0 = fma((double)Lks[i * Mz + (r + 2)], dC[i * W + w], s0);
+            g = s0 + s1 + kls * kg[j];
+        }
+        gQ[e] = g;
+        if (c <= r && b.do_adam && (b.trainable & VGPMP_TRAIN_Q_SQRT))
+            adam_apply(b.pq_sqrt + pl * M * M + e, b.mq_sqrt + pl * M * M + e, b.vq_sqrt + pl * M * M + e, xs[j], mo[j], vo[j],
+                       g, lr_t);
+    }
+    VG_T(q == 0 && l == 0 && p == 0, 112 + b.tshift);
+    if (l == 0 && q == kFinSplit - 1)
+        elbo_pieces(b.lik_partial, b.nblk, b.kl_l, L, p, b.alpha_fin ? b.alpha_fin[p] : b.lik_scale, kls, b.out_lik, b.out_kl);
+    VG_T(q == 0 && l == 0 && p == 0, 113 + b.tshift);
 }
 
 __global__ __launch_bounds__(kBlock) void final_kernel(FinalArgs b) {

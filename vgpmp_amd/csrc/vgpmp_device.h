@@ -43,12 +43,17 @@ __device__ __forceinline__ double vg_wave_sum(double v) {
 // Streaming store (nontemporal): bulk outputs that the NEXT launch reads -- from another XCD, so not through this L2
 // anyway -- leave no dirty lines behind; the write-back of dirty L2 lines at the end of a kernel was measured to add
 // ~1 us to the hand-over after a launch that wrote 7.6 MB.
+typedef float vg_f32x4_t __attribute__((ext_vector_type(4)));
+#ifdef VG_STREAM_PLAIN      // measurement builds: ordinary stores instead
+template <typename T>
+__device__ __forceinline__ void vg_stream(T* p, T v) { *p = v; }
+#else
 template <typename T>
 __device__ __forceinline__ void vg_stream(T* p, T v) { __builtin_nontemporal_store(v, p); }
-typedef float vg_f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void vg_stream(float4* p, float4 v) {
     __builtin_nontemporal_store((vg_f32x4_t){v.x, v.y, v.z, v.w}, reinterpret_cast<vg_f32x4_t*>(p));
 }
+#endif
 
 // ---- global -> LDS staging without registers (global_load_lds, gfx950) ----------------------------
 #ifndef VG_DMA_AUX
@@ -264,6 +269,8 @@ int vg_launch_log_prob_impl(const vgpmp_robot* rb, int dof, const vgpmp_sdf* sdf
 // thread a memory round trip per stamp and stretches the phases it is meant to measure)
 static __device__ unsigned long long vg_tr_buf[1024];
 #define VG_T(cond, id) do { if (threadIdx.x == 0 && (cond)) vg_tr_buf[(id) & 1023] = wall_clock64(); } while (0)
+// latest end over ALL workgroups that pass here (the slowest workgroup of a role)
+#define VG_TMAX(id) do { __syncthreads(); if (threadIdx.x == 0) atomicMax(&vg_tr_buf[(id) & 1023], (unsigned long long)wall_clock64()); } while (0)
 static int vg_trace_take(unsigned long long* host, int cap) {      // (id, stamp) pairs of this translation unit; clears them
     static unsigned long long tmp[1024];
     if (hipMemcpyFromSymbol(tmp, HIP_SYMBOL(vg_tr_buf), sizeof(tmp)) != hipSuccess) return -1;
@@ -278,6 +285,7 @@ int vg_trace_take_gp(unsigned long long* host, int cap);
 int vg_trace_take_lik(unsigned long long* host, int cap);
 #else
 #define VG_T(cond, id) do { } while (0)
+#define VG_TMAX(id) do { } while (0)
 #endif
 
 int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const float* f, int P, int S, int L, int N,
