@@ -207,10 +207,13 @@ __device__ __forceinline__ void chol_inverse_wave(double* La, double* Li, double
         const int c = tid;
         double a[32];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const double kv = La[min(i, Mz - 1) * ld + min(c & 31, Mz - 1)];      // loads first, selects afterwards
+        for (int i = 0; i < 32; ++i) a[i] = La[min(i, Mz - 1) * ld + min(c & 31, Mz - 1)];      // loads first (pinned) ...
+#pragma unroll
+        for (int i = 0; i < 32; ++i) vg_pin(a[i]);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {                                                            // ... selects afterwards
             const double id = (i == (c & 31)) ? 1.0 : 0.0;
-            a[i] = c < 32 ? ((i < Mz && c < Mz) ? kv : id) : id;
+            a[i] = c < 32 ? ((i < Mz && c < Mz) ? a[i] : id) : id;
         }
         // software pipelined: pivot k first finishes row k + 1 -- the next pivot row -- so that the next reciprocal
         // (the long dependent chain) is in flight while the remaining rows of pivot k are updated
@@ -304,11 +307,14 @@ __device__ __forceinline__ void chol_inverse_panels(double* La, double* Li, doub
         double* SX = Img + 16 * la;      // [16][32] S | X        (rows 16.. of the image: written after panel 2 has read this)
         double a[16], rinv[16];
         // ---- panel 1
+        // all loads first, pinned (the compiler otherwise sinks each load into the branch of its select: 16 dependent LDS
+        // round trips, measured 1.4 us), then the selects
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const double kv = La[i * ld + min(c, Mz - 1)];
-            a[i] = c < 32 ? (c < Mz ? kv : 0.0) : (i == c - 32 ? 1.0 : 0.0);
-        }
+        for (int i = 0; i < 16; ++i) a[i] = La[i * ld + min(c, Mz - 1)];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) vg_pin(a[i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = c < 32 ? (c < Mz ? a[i] : 0.0) : (i == c - 32 ? 1.0 : 0.0);
         VG_T(blockIdx.x == 0, 104);
         eliminate_panel16(a, rinv, 0);
         VG_T(blockIdx.x == 0, 105);
@@ -337,10 +343,13 @@ __device__ __forceinline__ void chol_inverse_panels(double* La, double* Li, doub
             const int g = c >> 4;
             vg_f64x4 accS, accX = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
+            for (int q = 0; q < 4; ++q) accS[q] = La[min(16 + g + 4 * q, Mz - 1) * ld + min(16 + cc, Mz - 1)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { double t = accS[q]; vg_pin(t); accS[q] = t; }
+#pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int row = 16 + g + 4 * q, col = 16 + cc;
-                const double kv = La[min(row, Mz - 1) * ld + min(col, Mz - 1)];
-                accS[q] = (row < Mz && col < Mz) ? kv : (row == col ? 1.0 : 0.0);
+                accS[q] = (row < Mz && col < Mz) ? accS[q] : (row == col ? 1.0 : 0.0);
             }
             double av[4], bs[4], bx[4];
 #pragma unroll
@@ -362,10 +371,11 @@ __device__ __forceinline__ void chol_inverse_panels(double* La, double* Li, doub
         VG_T(blockIdx.x == 0, 107);
         // ---- panel 2
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const double sv = SX[i * 32 + (c & 31)];
-            a[i] = c < 32 ? sv : (i == c - 32 ? 1.0 : 0.0);
-        }
+        for (int i = 0; i < 16; ++i) a[i] = SX[i * 32 + (c & 31)];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) vg_pin(a[i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = c < 32 ? a[i] : (i == c - 32 ? 1.0 : 0.0);
         VG_T(blockIdx.x == 0, 108);
         eliminate_panel16(a, rinv, 0);
         VG_T(blockIdx.x == 0, 109);
@@ -413,21 +423,24 @@ __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, 
     double* Sc = Li + Mp * ld;       // 2 x (Mp x ld) scratch: augmented matrix of the elimination
     double* zs = Sc + 2 * Mp * ld;   // [Mp]
     double* rsd = zs + Mp;           // [Mp]
-    // the latent's two scalars, each a chain of float64 exp / log / sqrt / division (~1 us): lengthscale on the first
-    // lane of wave 0, variance on the first lane of wave 1 (different waves run side by side, lanes of one do not)
-    if (tid == 0 || tid == VG_WAVE) {
-        const bool is_ell = tid == 0;
+    // the latent's two scalars, each a chain of float64 exp / log / sqrt / division: on wave 0, the lengthscale in its
+    // lower half and the variance in its upper half (the same arithmetic on different data: one instruction stream)
+    if (tid < VG_WAVE) {
+        const bool isv = tid >= 32;
         double raw;
         if (a.prologue) {
-            const HyperState o = hyper_update(a.hy, pl, false, 0.0, is_ell ? 1 : 2);
+            const HyperState o = hyper_update_wave(a.hy, pl);
             double* nx = a.hy.next + 6 * pl;
-            if (is_ell) { a.hy.g_ell[pl] = o.g_ell; nx[0] = o.raw_ell; nx[2] = o.m_ell; nx[3] = o.v_ell; raw = o.raw_ell; }
-            else { a.hy.g_var[pl] = o.g_var; nx[1] = o.raw_var; nx[4] = o.m_var; nx[5] = o.v_var; raw = o.raw_var; }
+            if (tid == 0) { a.hy.g_ell[pl] = o.g_ell; nx[0] = o.raw_ell; nx[2] = o.m_ell; nx[3] = o.v_ell; }
+            if (tid == 32) { a.hy.g_var[pl] = o.g_var; nx[1] = o.raw_var; nx[4] = o.m_var; nx[5] = o.v_var; }
+            raw = isv ? o.raw_var : o.raw_ell;
         } else {
-            raw = is_ell ? a.raw_ell[pl] : a.raw_var[pl];
+            raw = isv ? a.raw_var[pl] : a.raw_ell[pl];
         }
-        if (is_ell) { scal[0] = softplus_d(raw); a.ws.sig_ell[pl] = sigmoid_d(raw); }
-        else { scal[1] = kVarFloor + softplus_d(raw); a.ws.sig_var[pl] = sigmoid_d(raw); }
+        double sp, sg;
+        softplus_sigmoid_d(raw, &sp, &sg);
+        if (tid == 0) { scal[0] = sp; a.ws.sig_ell[pl] = sg; }
+        if (tid == 32) { scal[1] = kVarFloor + sp; a.ws.sig_var[pl] = sg; }
     }
     for (int e = tid; e < 2 * Mp * ld; e += nt) sm[e] = 0.0;
     for (int i = tid; i < Mz; i += nt) zs[i] = a.Zy[(size_t)p * a.zy_stride + (size_t)i * D + l];

@@ -6,7 +6,16 @@ constexpr double kVarFloor = 0.1;               // models/vgpmp.py:139 positive(
 constexpr double kSqrt5 = 2.2360679774997896964;
 constexpr double kZLow = 0.09, kZHigh = 0.91;   // models/vgpmp.py:41 bounded_Z: tfb.Sigmoid(0.09, 0.91)
 
-__device__ __forceinline__ double softplus_d(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
+// (one evaluation for both signs: max(x, 0) + log1p(exp(-|x|)) is x + log1p(exp(-x)) for x > 0 and log1p(exp(x)) otherwise,
+// bit for bit, without the two code paths)
+__device__ __forceinline__ double softplus_d(double x) { return fmax(x, 0.0) + log1p(exp(-fabs(x))); }
+// softplus and logistic of the same argument from ONE exponential (the logistic differs from sigmoid_d in the last bit
+// for x < 0: e / (1 + e) with e = exp(x) instead of 1 / (1 + exp(-x)))
+__device__ __forceinline__ void softplus_sigmoid_d(double x, double* sp, double* sg) {
+    const double e = exp(-fabs(x)), r = 1.0 / (1.0 + e);
+    *sp = fmax(x, 0.0) + log1p(e);
+    *sg = x >= 0.0 ? r : e * r;
+}
 __device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
 __device__ __forceinline__ double matern52(double t1, double t2, double ell, double var) {
     double r = fabs(t1 - t2) / ell;
@@ -20,6 +29,7 @@ __device__ __forceinline__ double matern52_d1(double t1, double t2, double ell, 
 }
 
 __device__ __forceinline__ void adam_update(double* x, double* m, double* v, double g, double lr_t) {
+#pragma clang fp contract(off)      // the same roundings wherever this is inlined (contraction depends on the surrounding code)
     // Keras Adam (TF 2.12): beta1 = 0.8, beta2 = 0.95 (models/vgpmp.py:77), epsilon 1e-7
     double mm = *m + (g - *m) * (1.0 - 0.8);
     double vv = *v + (g * g - *v) * (1.0 - 0.95);

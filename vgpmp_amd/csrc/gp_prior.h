@@ -35,12 +35,13 @@ __device__ __forceinline__ void features_body(const FeatArgs& a, int bx, int by,
     const double *X = a.X, *Zy = a.Zy + (size_t)p * a.zy_stride;
     const int J = N + Mz;
     const size_t pl = (size_t)p * L + l;
-    if (b >= B) return;
     double re, rv;
     if constexpr (PRO) {
-        const HyperState o = hyper_update(a.hy, pl);
+        const HyperState o = hyper_update_wave(a.hy, pl);      // whole waves: before any lane leaves
         re = o.raw_ell; rv = o.raw_var;
-    } else {
+    }
+    if (b >= B) return;
+    if constexpr (!PRO) {
         re = a.raw_ell[pl]; rv = a.raw_var[pl];
     }
     const float ell = softplus_f((float)re);

@@ -62,6 +62,7 @@ struct HyperState { double raw_ell, raw_var, m_ell, v_ell, m_var, v_var, g_ell, 
 // `which`: 1 = lengthscale, 2 = variance, 3 = both (the two halves are independent: cov_a runs them on two waves)
 __device__ __forceinline__ HyperState hyper_update(const HyperArgs& h, size_t pl, bool own_lr = false, double lr_own = 0.0,
                                                    int which = 3) {
+#pragma clang fp contract(off)      // hyper_update_wave() must round identically
     const float* part = h.part + pl * h.NC * h.part_len + (h.Mz + h.Mz * h.Mz);
     // every operand requested in one go, unconditionally (null Adam pointers fall back to a valid address): the
     // prologue form sits on the critical chain and a second dependent round trip costs ~2 us
@@ -115,9 +116,60 @@ __device__ __forceinline__ HyperState hyper_update(const HyperArgs& h, size_t pl
     return o;
 }
 
+// The same update by a WHOLE WAVE (all 64 lanes must call it, converged) for the callers that have one to spare -- the
+// prologue forms in stage 1, where this sits on the critical chain of the step.  The scalar form above is ~1500
+// instructions for one lane (48 loads, 3 x 31 additions, the Adam arithmetic twice); here lane (j, k) = (lane >> 4,
+// lane & 15) loads partial j of chunk k -- every load of the update in ONE request per lane -- the three sums are
+// butterflies over 16 lanes, which add the SAME operand pairs as the tree of sum_chunks() (IEEE addition commutes
+// exactly), and the two independent scalar tails (lengthscale, variance: same arithmetic, different data) run side by
+// side in the lower and upper half of the wave.  Bit-identical to hyper_update(); every lane returns the full state.
+__device__ __forceinline__ double vg_shfl_f64(double v, int lane) { return __shfl(v, lane, VG_WAVE); }
+__device__ __forceinline__ HyperState hyper_update_wave(const HyperArgs& h, size_t pl) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & (VG_WAVE - 1), j = min(lane >> 4, 2), k = lane & 15;
+    const bool isv = lane >= 32;                 // upper half: variance, lower half: lengthscale
+    const float* part = h.part + pl * h.NC * h.part_len + (h.Mz + h.Mz * h.Mz);
+    const double* mp = h.do_adam ? (isv ? h.m_var : h.m_ell) : (isv ? h.p_var : h.p_ell);
+    const double* vp = h.do_adam ? (isv ? h.v_var : h.v_ell) : (isv ? h.p_var : h.p_ell);
+    // every operand requested in one go
+    const float* q0 = part + (size_t)min(k, h.NC - 1) * h.part_len;
+    float va = q0[j], vb = q0[4 + j];
+    double raw = (isv ? h.p_var : h.p_ell)[pl], m = mp[pl], v = vp[pl];
+    const double gkl = (isv ? h.gkl_var : h.gkl_ell)[pl], sig = (isv ? h.sig_var : h.sig_ell)[pl], var = h.var[pl];
+    const double lr_dev = h.lr_dev[0];
+    const double lr_t = (h.do_adam && h.use_lr_dev) ? lr_dev : h.lr_t;
+    if (!h.do_adam) m = v = 0.0;
+    double s = 0.0;
+    for (int c0 = 0; c0 < h.NC; c0 += 16) {
+        if (c0 > 0) {
+            const float* q = part + (size_t)min(c0 + k, h.NC - 1) * h.part_len;
+            va = q[j]; vb = q[4 + j];
+        }
+        double d = c0 + k < h.NC ? (double)(va + vb) : 0.0;        // the two halves of paths_bwd_split, then the chunk tree
+        d += __shfl_xor(d, 1, VG_WAVE);
+        d += __shfl_xor(d, 2, VG_WAVE);
+        d += __shfl_xor(d, 4, VG_WAVE);
+        s += vg_shfl_f64(d, lane & 48);
+        s += vg_shfl_f64(d, (lane & 48) + 8);
+    }
+    const double s0 = vg_shfl_f64(s, 0), s1 = vg_shfl_f64(s, 16), s2 = vg_shfl_f64(s, 32);
+    const double g_ell = ((h.want_dell ? s0 : 0.0) + h.kl_scale * gkl) * sig;
+    const double g_var = (s1 + s2 / (2.0 * var) + h.kl_scale * gkl) * sig;
+    const double g = isv ? g_var : g_ell;
+    const bool upd = h.do_adam && (h.trainable & (isv ? VGPMP_TRAIN_KERNEL_VARIANCE : VGPMP_TRAIN_LENGTHSCALES));
+    double nraw = raw, nm = m, nv = v;
+    adam_update(&nraw, &nm, &nv, g, lr_t);
+    if (upd) { raw = nraw; m = nm; v = nv; }
+    HyperState o;
+    o.raw_ell = vg_shfl_f64(raw, 0); o.m_ell = vg_shfl_f64(m, 0); o.v_ell = vg_shfl_f64(v, 0); o.g_ell = vg_shfl_f64(g, 0);
+    o.raw_var = vg_shfl_f64(raw, 32); o.m_var = vg_shfl_f64(m, 32); o.v_var = vg_shfl_f64(v, 32); o.g_var = vg_shfl_f64(g, 32);
+    return o;
+}
+
 // the same update with the state already in registers
 __device__ __forceinline__ void adam_apply(double* x, double* m, double* v, double x0, double m0, double v0, double g,
                                            double lr_t) {
+#pragma clang fp contract(off)
     const double mm = m0 + (g - m0) * (1.0 - 0.8);
     const double vv = v0 + (g * g - v0) * (1.0 - 0.95);
     *m = mm; *v = vv;

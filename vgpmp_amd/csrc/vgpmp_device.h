@@ -40,6 +40,11 @@ __device__ __forceinline__ double vg_wave_sum(double v) {
     return v;
 }
 
+// Pin a loaded value in a register at this point: clang otherwise sinks an unconditional load into the branch of the
+// select that consumes it, turning "request everything, then choose" into one memory round trip per element.
+__device__ __forceinline__ void vg_pin(double& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void vg_pin(float& v) { asm volatile("" : "+v"(v)); }
+
 // Streaming store (nontemporal): bulk outputs that the NEXT launch reads -- from another XCD, so not through this L2
 // anyway -- leave no dirty lines behind; the write-back of dirty L2 lines at the end of a kernel was measured to add
 // ~1 us to the hand-over after a launch that wrote 7.6 MB.
