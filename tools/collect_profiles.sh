@@ -53,5 +53,10 @@ print("FETCH_SIZE per gather launch (KB):", v, "-> bytes tallied per random 16-b
 PY
   rm -rf $out/gp_fetch
 fi
+# ---- in-kernel time stamps of one config-2 step (measurement build: the stamps perturb the step by ~1-2 us; rocprof's kernel
+#      durations above are the authority for totals, this shows where inside the launches the time goes)
+if [ -f tools/libvgpmp_bisect.so ]; then
+  VGPMP_HIP_LIB=$PWD/tools/libvgpmp_bisect.so timeout 300 python tools/step_trace.py 1 > $out/step_trace_config2.txt 2>&1
+fi
 find $out -name "*.err" -size 0 -delete
 ls -la $out | head -60
