@@ -481,10 +481,8 @@ __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, 
     else if (Mz <= 32 && nt == 256) chol_inverse_regs(La, Li, Sc, rsd, Mz, ld, tid, nt);
     else chol_inverse_block(La, Li, Sc, rsd, Mz, ld, tid, nt);
     VG_T(l == 0 && p == 0, 102);
-    double* Kig = a.ws.Kinv + pl * Mz * Mz;
-    matmul_f64(MatView{Li, 1, ld}, MatView{Li, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
-        if (r < Mz && c < Mz) Kig[(size_t)r * Mz + c] = v;
-    });
+    // ((Kuu + jI)^-1 = Lk^-T Lk^-1 is formed by its consumers, the row tiles of stage B, from Lk^-1: a product less on
+    // this workgroup, which is the longest role of its launch)
     double* Lkg = a.ws.Lk64 + pl * Mz * Mz;
     double* Lig = a.ws.Li64 + pl * Mz * Mz;
     for (int e = tid; e < Mz * Mz; e += nt) {
@@ -735,16 +733,17 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
     double* yr = ar + kRowTile * Mz;       // [RT][Mz]
     double* zs = yr + kRowTile * Mz;       // [Mz]
     double* xs = zs + Mz;                  // [RT] times of this tile
+    double* Lt = xs + kRowTile;            // [Mz][ld] Lk^-1 as it arrives
     const double ell = a.ws.ell[pl], var = a.ws.var[pl];
     const int n0 = tile * kRowTile;
     {
         auto all = [](int, int) { return true; };
         if ((Mz & 1) == 0) {
-            vg_stage_f64_square(Ki, ld, a.ws.Kinv + pl * Mz * Mz, Mz, tid, nt);
+            vg_stage_f64_square(Lt, ld, a.ws.Li64 + pl * Mz * Mz, Mz, tid, nt);
             if (a.want_dell) vg_stage_f64_square(Kd, ld, a.ws.Kd_ell + pl * Mz * Mz, Mz, tid, nt);
             else for (int e = tid; e < Mz * ld; e += nt) Kd[e] = 0.0;
         } else {
-            vg_stage_f64(Ki, Mz, ld, a.ws.Kinv + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
+            vg_stage_f64(Lt, Mz, ld, a.ws.Li64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
             vg_stage_f64(Kd, Mz, ld, a.ws.Kd_ell + pl * Mz * Mz, a.want_dell ? Mz : 0, Mz, 0, 0, tid, nt, all);
         }
         vg_stage_words(zs, 2 * (Mz + kRowTile), tid, nt, [&](int w) -> const void* {
@@ -757,6 +756,25 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
     vg_dma_wait();
     __syncthreads();
     VG_T(tile == 0 && l == 0 && p == 0, 232);
+    // (Kuu + jI)^-1 = Lk^-T Lk^-1: on the float64 matrix cores when Mz is a multiple of 16 (no padding needed), else by
+    // dot products over the non-zero part of the two columns; tile 0 keeps the copy the views / the inducing-location
+    // reverse pass read
+    {
+        double* Kig = tile == 0 ? a.ws.Kinv + pl * Mz * Mz : nullptr;
+        if ((Mz & 15) == 0) {
+            matmul_f64(MatView{Lt, 1, ld}, MatView{Lt, ld, 1}, Mz, tid, nt, [&](int r, int c, double v) {
+                Ki[r * ld + c] = v;
+                if (Kig) Kig[(size_t)r * Mz + c] = v;
+            });
+        } else {
+            for (int e = tid; e < Mz * Mz; e += nt) {
+                const int r = vg_div(e, iMz), c = e - r * Mz, k0 = max(r, c);
+                const double v = dot4(Lt + k0 * ld + r, ld, Lt + k0 * ld + c, ld, Mz - k0);
+                Ki[r * ld + c] = v;
+                if (Kig) Kig[e] = v;
+            }
+        }
+    }
     for (int e = tid; e < kRowTile * Mz; e += nt) {
         int r = vg_div(e, iMz), m = e - r * Mz, n = n0 + r;
         double k = 0.0, dk = 0.0;

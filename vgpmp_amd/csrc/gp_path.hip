@@ -464,7 +464,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const int Mp = (Mz + 15) & ~15;
     const size_t lds_cov = ((size_t)4 * Mp * (Mp + 2) + 8 * Mp) * sizeof(double);
     const size_t lds_cov_a = ((size_t)4 * Mp * (Mp + 1) + 2 * Mp) * sizeof(double);
-    const size_t lds_rows = ((size_t)2 * Mz * ((Mz + 2) & ~1) + (size_t)4 * kRowTile * Mz + Mz + kRowTile) * sizeof(double);
+    const size_t lds_rows = ((size_t)3 * Mz * ((Mz + 2) & ~1) + (size_t)4 * kRowTile * Mz + Mz + kRowTile) * sizeof(double);
     const size_t lds_cov_b = lds_cov > lds_rows ? lds_cov : lds_rows;
     // path kernels: operands + (when it fits) the raw split-K slabs of the prior draws
     const size_t raw_f = SK == 1 ? 0 : (size_t)SK * SC * J * sizeof(float);      // one slab lands in place
