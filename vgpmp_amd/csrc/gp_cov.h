@@ -294,8 +294,9 @@ __device__ __forceinline__ void eliminate_panel16(double (&a)[16], double (&rinv
         r = rn;
     }
 }
+// Lkg / Lig: the global copies of both factors, written straight from the assembly (the LDS images are not formed then).
 __device__ __forceinline__ void chol_inverse_panels(double* La, double* Li, double* Aug, double* rsd, int Mz, int ld,
-                                                    int tid, int nt) {
+                                                    int tid, int nt, double* Lkg, double* Lig) {
     const int la = 2 * Mz + 1;
     double* Img = Aug;
     if (tid < VG_WAVE) {
@@ -399,14 +400,16 @@ __device__ __forceinline__ void chol_inverse_panels(double* La, double* Li, doub
     VG_T(blockIdx.x == 0, 141);
     if (tid < Mz) rsd[tid] = rsqrt(rsd[tid]);
     __syncthreads();
-    // over the whole padded 32 x 32 image: the exchange buffers above sat in Li, whose padding the products downstream read
     for (int e = tid; e < 32 * 32; e += nt) {
         const int r = e >> 5, j = e & 31;
         const bool in = j <= r && r < Mz;
-        La[r * ld + j] = in ? Img[j * la + r] * rsd[j] : 0.0;
-        Li[r * ld + j] = in ? Img[min(r, Mz - 1) * la + Mz + j] * rsd[min(r, Mz - 1)] : 0.0;
+        const double lk = Img[min(j, Mz - 1) * la + min(r, Mz - 1)] * rsd[min(j, Mz - 1)];
+        const double li = Img[min(r, Mz - 1) * la + Mz + min(j, Mz - 1)] * rsd[min(r, Mz - 1)];
+        if (r < Mz && j < Mz) {
+            Lkg[r * Mz + j] = in ? lk : 0.0;
+            Lig[r * Mz + j] = in ? li : 0.0;
+        }
     }
-    __syncthreads();
 }
 
 // ---- stage A: Kuu, factorisation, inverse --------------------------------------------------------
@@ -476,19 +479,23 @@ __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, 
     }
     __syncthreads();
     VG_T(l == 0 && p == 0, 101);
-    if (VG_ELIM_PANELS && Mz > 16 && Mz <= 32 && a.elim_wave) chol_inverse_panels(La, Li, Sc, rsd, Mz, ld, tid, nt);
-    else if (Mz <= 32 && a.elim_wave) chol_inverse_wave(La, Li, Sc, rsd, Mz, ld, tid, nt);
-    else if (Mz <= 32 && nt == 256) chol_inverse_regs(La, Li, Sc, rsd, Mz, ld, tid, nt);
-    else chol_inverse_block(La, Li, Sc, rsd, Mz, ld, tid, nt);
-    VG_T(l == 0 && p == 0, 102);
     // ((Kuu + jI)^-1 = Lk^-T Lk^-1 is formed by its consumers, the row tiles of stage B, from Lk^-1: a product less on
     // this workgroup, which is the longest role of its launch)
     double* Lkg = a.ws.Lk64 + pl * Mz * Mz;
     double* Lig = a.ws.Li64 + pl * Mz * Mz;
-    for (int e = tid; e < Mz * Mz; e += nt) {
-        const int i = vg_div(e, iMz), j = e - i * Mz;
-        Lkg[e] = La[i * ld + j];
-        Lig[e] = Li[i * ld + j];
+    if (VG_ELIM_PANELS && Mz > 16 && Mz <= 32 && a.elim_wave) {
+        chol_inverse_panels(La, Li, Sc, rsd, Mz, ld, tid, nt, Lkg, Lig);
+        VG_T(l == 0 && p == 0, 102);
+    } else {
+        if (Mz <= 32 && a.elim_wave) chol_inverse_wave(La, Li, Sc, rsd, Mz, ld, tid, nt);
+        else if (Mz <= 32 && nt == 256) chol_inverse_regs(La, Li, Sc, rsd, Mz, ld, tid, nt);
+        else chol_inverse_block(La, Li, Sc, rsd, Mz, ld, tid, nt);
+        VG_T(l == 0 && p == 0, 102);
+        for (int e = tid; e < Mz * Mz; e += nt) {
+            const int i = vg_div(e, iMz), j = e - i * Mz;
+            Lkg[e] = La[i * ld + j];
+            Lig[e] = Li[i * ld + j];
+        }
     }
     VG_T(l == 0 && p == 0, 103);
 }
