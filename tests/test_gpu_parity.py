@@ -125,6 +125,8 @@ def _noise32(noise):
                                                     ("wam", 20, 33, 12, 128, 2), ("ur10", 16, 20, 6, 64, 1),
                                                     ("franka", 24, 40, 14, 128, 4),        # Mz = 16, N % 4 == 0: two-workgroup path kernels
                                                     ("franka", 8, 12, 46, 64, 2),          # Mz = 48: the largest inducing set
+                                                    ("franka", 12, 16, 20, 64, 2),         # Mz = 22: two-panel elimination on a zero-padded 32 x 32 image
+                                                    ("wam", 10, 14, 25, 64, 1),            # Mz = 27: odd, padded; (Kuu + jI)^-1 of the row tiles by dot products
                                                     ("franka", 128, 100, 30, 1024, 4)])     # BASELINE config 2, full size
 def test_elbo_forward_backward_against_oracle(robot, S, N, M, B, split_k):
     pb = small_problem(robot=robot, S=S, N=N, M=M, B=B, seed=11, n_grid=48)
