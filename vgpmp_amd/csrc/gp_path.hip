@@ -207,7 +207,13 @@ __global__ __launch_bounds__(kBlock) void mid_hyper_final_kernel(MidGArgs a) {
     b -= a.n_hyper;
     FinalArgs fb = a.fin;      // the step size comes from the counter here: the update role that stores it runs alongside
     if (own) { fb.use_lr_dev = 0; fb.lr_t = lr_own; }
-    final_body(fb, sm, b % fb.L, b / fb.L);
+    if (fb.split) {
+        const int q = b % kFinSplit;
+        b /= kFinSplit;
+        final_cols_body(fb, sm, q, b % fb.L, b / fb.L);
+    } else {
+        final_body(fb, sm, b % fb.L, b / fb.L);
+    }
 }
 
 
@@ -575,7 +581,11 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         else { if (S <= 16) VG_FUSED_SMALL(1, 16); else VG_FUSED_SMALL(2, 16); }
 #undef VG_FUSED_SMALL
     };
-    auto launch_final = [&]() -> int { return launch((const void*)final_kernel, dim3(L, P), &fa, lds_fin); };
+    // (stand-alone / merged launches: strips while the launch leaves half the chip idle -- 8 problems: 177 -> 172 us per
+    // step; at 64 problems four times the workgroups each re-staging the factor LOSE 15 us)
+    const bool fin_split_batch = fin_split && (size_t)L * P <= 128;
+    fa.split = fin_split_batch ? 1 : 0;
+    auto launch_final = [&]() -> int { return launch((const void*)final_kernel, dim3(L * (fin_split_batch ? kFinSplit : 1), P), &fa, lds_fin); };
     // likelihood constants as variables (vgpmp_lik_params): effective values from the raw ones at the start of the call
     LikUpdArgs lu;
     if (lk) {
@@ -758,7 +768,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             hy.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
             fa.lr_t = hy.lr_t;
             mg.hy = hy; mg.fin = fa; mg.n_hyper = P;
-            if ((rc = launch((const void*)mid_hyper_final_kernel, dim3(P + L * P), &mg, lds_fin))) return rc;
+            if ((rc = launch((const void*)mid_hyper_final_kernel, dim3(P + L * P * (fin_split_batch ? kFinSplit : 1)), &mg, lds_fin))) return rc;
         } else if (!(fused && more)) {      // otherwise both ride in stage 1 of the next step
             hy.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
             fa.lr_t = hy.lr_t;

@@ -21,6 +21,7 @@ struct FinalArgs {
     double *g_qmu, *g_qsqrt;
     int do_adam, trainable;
     int dma;                  // the chunk partials fit in LDS: stage them by DMA
+    int split;                // final_kernel / the merged launches: kFinSplit workgroups per (latent, problem), by column strips
     int tshift;               // measurement builds: added to the stamp ids (the role inside stage 1 vs the stand-alone launch)
     const double* lr_dev;     // [1] step size stored at the counter tick (device counter form)
     double lr_t;              // host form
@@ -446,9 +447,10 @@ __device__ __forceinline__ void final_cols_body(const FinalArgs& b, double* sm, 
     VG_T(q == 0 && l == 0 && p == 0, 113 + b.tshift);
 }
 
-__global__ __launch_bounds__(kBlock) void final_kernel(FinalArgs b) {
+__global__ __launch_bounds__(kBlock) void final_kernel(FinalArgs b) {      // grid (L, P), or (L kFinSplit, P) with b.split
     extern __shared__ double sm[];
-    final_body(b, sm, blockIdx.x, blockIdx.y);
+    if (b.split) final_cols_body(b, sm, blockIdx.x % kFinSplit, blockIdx.x / kFinSplit, blockIdx.y);
+    else final_body(b, sm, blockIdx.x, blockIdx.y);
 }
 
 // forward-only epilogue: ELBO pieces without the reverse pass
