@@ -53,6 +53,9 @@ print("FETCH_SIZE per gather launch (KB):", v, "-> bytes tallied per random 16-b
 PY
   rm -rf $out/gp_fetch
 fi
+# ---- the alternatives to a kernel boundary, and what one workgroup's operand staging sustains
+[ -x tools/handoff_probe ] && timeout 120 tools/handoff_probe > $out/handoff_probe.txt 2>&1
+[ -x tools/glds_scale_probe ] && timeout 120 tools/glds_scale_probe > $out/glds_scale_probe.txt 2>&1
 # ---- in-kernel time stamps of one config-2 step (measurement build: the stamps perturb the step by ~1-2 us; rocprof's kernel
 #      durations above are the authority for totals, this shows where inside the launches the time goes)
 if [ -f tools/libvgpmp_bisect.so ]; then
