@@ -162,22 +162,24 @@ __global__ __launch_bounds__(kCovThreads) void mid_cov_a_rng_kernel(MidAArgs a) 
 
 struct MidCArgs {            // cov_b | tiled prior GEMM
     CovArgs cov; TiledGemmArgs gemm;
-    int cov_roles, n_cov, gemm_gx, gemm_gy;
+    int cov_roles, n_cov, n_gemm, gemm_gx, gemm_gy;
 };
 template <bool TANGENTS>
 __global__ __launch_bounds__(kBlock) void mid_cov_b_gemm_kernel(MidCArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     int b = blockIdx.x;
-    if (b < a.n_cov) {
-        const int role = b % a.cov_roles;
-        b /= a.cov_roles;
-        cov_b_body<TANGENTS>(a.cov, sm, role, b % a.cov.L, b / a.cov.L);
+    // the GEMM tiles first: each runs for the whole launch (K = all bases), the covariance roles ~10 us -- behind 600+
+    // of those the tiles started late and piled up on a few CUs (6 problems: 96.6 us for this launch, 7: 67.4)
+    if (b < a.n_gemm) {
+        const int bx = b % a.gemm_gx;
+        b /= a.gemm_gx;
+        prior_gemm_tiled_body<1>(a.gemm, reinterpret_cast<float*>(sm), bx, b % a.gemm_gy, b / a.gemm_gy);
         return;
     }
-    b -= a.n_cov;
-    const int bx = b % a.gemm_gx;
-    b /= a.gemm_gx;
-    prior_gemm_tiled_body<1>(a.gemm, reinterpret_cast<float*>(sm), bx, b % a.gemm_gy, b / a.gemm_gy);
+    b -= a.n_gemm;
+    const int role = b % a.cov_roles;
+    b /= a.cov_roles;
+    cov_b_body<TANGENTS>(a.cov, sm, role, b % a.cov.L, b / a.cov.L);
 }
 
 struct MidGArgs {            // hyper-parameter update | q_mu, q_sqrt update + ELBO pieces
@@ -665,7 +667,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             mc.cov = ca; mc.gemm = tga;
             mc.cov_roles = (int)cov_b_grid.x; mc.n_cov = (int)(cov_b_grid.x * cov_b_grid.y * cov_b_grid.z);
             mc.gemm_gx = (J + kTJ - 1) / kTJ; mc.gemm_gy = (S + kTS - 1) / kTS;
-            const unsigned nC = mc.n_cov + (unsigned)mc.gemm_gx * mc.gemm_gy * P * L * ga.nsel;
+            mc.n_gemm = mc.gemm_gx * mc.gemm_gy * P * L * ga.nsel;
+            const unsigned nC = (unsigned)mc.n_cov + (unsigned)mc.n_gemm;
             if (mid_gemm) {
                 if ((rc = launch(fn_midC, dim3(nC), &mc, lds_midC))) return rc;
             } else if (fused_small) {

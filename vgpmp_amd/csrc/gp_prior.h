@@ -83,7 +83,10 @@ __global__ __launch_bounds__(kBlock) void features_kernel(FeatArgs a) {
 // each lane loads 4 consecutive k (16 B) per operand, so one load pair feeds 4 MFMAs (k = 4g + c).
 // =================================================================================================
 typedef float vg_f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kNT = 3;     // 16-column tiles per wave
+#ifndef VG_KNT
+#define VG_KNT 3
+#endif
+constexpr int kNT = VG_KNT;     // 16-column tiles per wave
 
 struct GemmArgs {
     int S, L, J, B, SK, nsel;
