@@ -88,6 +88,7 @@ struct Stage2Args {
     CovArgs cov; GemmArgs gemm;
     int n_cov, cov_roles, gemm_gx, gemm_gy, gemm_per_xcd;
     int skip;
+    int n_gemm;               // stage2_gemm_first_kernel
 };
 template <bool TANGENTS, int KS>
 __global__ __launch_bounds__(kBlock) void stage2_kernel(Stage2Args a) {
@@ -104,6 +105,27 @@ __global__ __launch_bounds__(kBlock) void stage2_kernel(Stage2Args a) {
     if (a.skip & 2) return;
     // Workgroups go to the 8 XCDs round robin (n_cov is a multiple of 8 or the remap is off): give each XCD a
     // CONTIGUOUS range of GEMM tiles, so the column / row tiles that share operands share an L2 as well.
+    if (a.gemm_per_xcd > 0) b = (b & 7) * a.gemm_per_xcd + (b >> 3);
+    const int bx = b % a.gemm_gx;
+    b /= a.gemm_gx;
+    if constexpr (KS < 0) prior_gemm_lds_body(a.gemm, reinterpret_cast<float*>(sm), bx, b % a.gemm_gy, b / a.gemm_gy);
+    else prior_gemm_body<KS>(a.gemm, bx, b % a.gemm_gy, b / a.gemm_gy);
+}
+// The same launch with the GEMM tiles at the FRONT of the grid, for whole-K tiles (no K-slices: 3 problems up).  They are
+// the longest workgroups of the launch then and must not start behind the short covariance roles: 3 problems
+// 113 -> 107 us per step, 4: 131 -> 121.  (With K-slices -- one or two problems -- the covariance chains are the longer
+// workgroups and the order above is the better one by ~1 us.)
+template <bool TANGENTS, int KS>
+__global__ __launch_bounds__(kBlock) void stage2_gemm_first_kernel(Stage2Args a) {
+    extern __shared__ double sm[];
+    int b = blockIdx.x;
+    if (b >= a.n_gemm) {
+        b -= a.n_gemm;
+        const int role = b % a.cov_roles;
+        b /= a.cov_roles;
+        cov_b_body<TANGENTS>(a.cov, sm, role, b % a.cov.L, b / a.cov.L);
+        return;
+    }
     if (a.gemm_per_xcd > 0) b = (b & 7) * a.gemm_per_xcd + (b >> 3);
     const int bx = b % a.gemm_gx;
     b /= a.gemm_gx;
@@ -495,9 +517,11 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const bool k8 = (B / SK) % 128 == 0;      // K-slice in passes of 8 steps of 16: a pass's operands in one request
     // K-slices of a multiple of 128 and enough samples: operands through LDS by DMA (needs 59 KB per workgroup)
     const bool glds = (B / SK) % kGK == 0 && S >= 48 && !(what & VGPMP_GEMM_DIRECT);      // 64-row tiles: few samples waste them
-    const void* fn_s2 = glds ? (backward ? (const void*)stage2_kernel<true, -1> : (const void*)stage2_kernel<false, -1>)
-                      : backward ? (k8 ? (const void*)stage2_kernel<true, 8> : (const void*)stage2_kernel<true, 0>)
-                                 : (k8 ? (const void*)stage2_kernel<false, 8> : (const void*)stage2_kernel<false, 0>);
+    const bool gemm_first = SK == 1;      // whole-K tiles (3 problems up) are the longest workgroups of stage 2: at its front
+#define VG_S2(T, K) (gemm_first ? (const void*)stage2_gemm_first_kernel<T, K> : (const void*)stage2_kernel<T, K>)
+    const void* fn_s2 = glds ? (backward ? VG_S2(true, -1) : VG_S2(false, -1))
+                      : backward ? (k8 ? VG_S2(true, 8) : VG_S2(true, 0)) : (k8 ? VG_S2(false, 8) : VG_S2(false, 0));
+#undef VG_S2
     const size_t lds_s2 = glds && kGemmLds > lds_cov_b ? kGemmLds : lds_cov_b;
     if (SC != 8) return VGPMP_E_SHAPE;
 #define VG_PICK(kernel, raw)                                                                                        \
@@ -639,7 +663,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             s2.cov_roles = (int)cov_b_grid.x; s2.n_cov = (int)(cov_b_grid.x * cov_b_grid.y * cov_b_grid.z);
             s2.gemm_gx = (int)gemm_grid.x; s2.gemm_gy = (int)gemm_grid.y;
             const int n_gemm = (int)(gemm_grid.x * gemm_grid.y * gemm_grid.z);
-            s2.gemm_per_xcd = (s2.n_cov % 8 == 0 && n_gemm % 8 == 0) ? n_gemm / 8 : 0;
+            s2.n_gemm = n_gemm;
+            s2.gemm_per_xcd = ((gemm_first || s2.n_cov % 8 == 0) && n_gemm % 8 == 0) ? n_gemm / 8 : 0;
             if ((rc = launch(fn_s2, dim3(s2.n_cov + gemm_grid.x * gemm_grid.y * gemm_grid.z), &s2, lds_s2))) return rc;
             Stage3Args s3;
             s3.skip = skip3;
