@@ -55,6 +55,7 @@ struct Stage1Args {
     int n_cov, n_fin, n_eps, eps_gx, feat_gx, feat_gy;
     int fin_split;            // the q_mu / q_sqrt update on kFinSplit workgroups per (latent, problem): final_cols_body
     int skip;                 // measurement builds: bit mask of roles that return at once
+    int n_feat;
 };
 template <bool PRO>
 __global__ __launch_bounds__(kBlock) void stage1_kernel(Stage1Args a) {
@@ -75,13 +76,19 @@ __global__ __launch_bounds__(kBlock) void stage1_kernel(Stage1Args a) {
         return;
     }
     b -= a.n_fin;
-    if (b < a.n_eps) { if (!(a.skip & 4)) rng_normals_body(a.rng, b % a.eps_gx, b / a.eps_gx, 0u, a.rng.nE); VG_TMAX(162); return; }
-    b -= a.n_eps;
-    if (a.skip & 8) return;
-    const int bx = b % a.feat_gx;
-    b /= a.feat_gx;
-    features_body<PRO>(a.feat, bx, b % a.feat_gy, b / a.feat_gy);
-    VG_TMAX(163);
+    // the feature role before the (short) eps draws: long roles at the front of the grid start in the first round of
+    // workgroups, the short ones fill in behind (matters from 3 problems, where the launch exceeds what is resident at once)
+    if (b < a.n_feat) {
+        if (a.skip & 8) return;
+        const int bx = b % a.feat_gx;
+        b /= a.feat_gx;
+        features_body<PRO>(a.feat, bx, b % a.feat_gy, b / a.feat_gy);
+        VG_TMAX(163);
+        return;
+    }
+    b -= a.n_feat;
+    if (!(a.skip & 4)) rng_normals_body(a.rng, b % a.eps_gx, b / a.eps_gx, 0u, a.rng.nE);
+    VG_TMAX(162);
 }
 
 struct Stage2Args {
@@ -653,6 +660,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             s1.eps_gx = (int)eps_gx;
             s1.n_eps = (gen && !first) ? (int)eps_gx * P : 0;
             s1.feat_gx = (int)feat_grid.x; s1.feat_gy = (int)feat_grid.y;
+            s1.n_feat = (int)(feat_grid.x * feat_grid.y * feat_grid.z);
             const unsigned n1 = s1.n_cov + s1.n_fin + s1.n_eps + feat_grid.x * feat_grid.y * feat_grid.z;
             if ((rc = launch(prologue ? (const void*)stage1_kernel<true> : (const void*)stage1_kernel<false>, dim3(n1), &s1, lds_s1)))
                 return rc;
