@@ -22,6 +22,9 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 #else
 #define VG_STOP(args, k) do { } while (0)
 #endif
+#ifndef VG_COV_WITH_PRIOR
+#define VG_COV_WITH_PRIOR 1  // 0: measurement builds with cov_b and the fused prior kernel as two launches
+#endif
 #ifndef VG_FIN_SPLIT
 #define VG_FIN_SPLIT 1      // 0: measurement builds with the update role of stage 1 on one workgroup per latent
 #endif
@@ -209,6 +212,29 @@ __global__ __launch_bounds__(kBlock) void mid_cov_b_gemm_kernel(MidCArgs a) {
     const int role = b % a.cov_roles;
     b /= a.cov_roles;
     cov_b_body<TANGENTS>(a.cov, sm, role, b % a.cov.L, b / a.cov.L);
+}
+
+// ---- large batches: the covariance roles of stage B beside the fused prior kernel.  cov_b is a launch of latency-bound
+// float64 chains (90 us at 64 Franka problems, 174 us at config 5) that leaves most of the chip's issue slots idle, the
+// prior kernel is MFMA / VALU bound and independent of it: one launch, prior tiles first (they run ~115 us each).
+struct BatchCArgs {
+    CovArgs cov; FusedBatchArgs fb;
+    int cov_roles, n_prior, fb_gx, fb_gy;
+};
+template <bool DELL, int DM>
+__global__ __launch_bounds__(kBlock) void batch_cov_b_prior_kernel(BatchCArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    int b = blockIdx.x;
+    if (b < a.n_prior) {
+        const int bx = b % a.fb_gx;
+        b /= a.fb_gx;
+        prior_fused_batch_body<DELL, DM>(a.fb, reinterpret_cast<float*>(sm), bx, b % a.fb_gy, b / a.fb_gy);
+        return;
+    }
+    b -= a.n_prior;
+    const int role = b % a.cov_roles;
+    b /= a.cov_roles;
+    cov_b_body<true>(a.cov, sm, role, b % a.cov.L, b / a.cov.L);
 }
 
 struct MidGArgs {            // hyper-parameter update | q_mu, q_sqrt update + ELBO pieces
@@ -718,12 +744,19 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         } else {
             mark();
             hipLaunchKernelGGL(cov_a_kernel, dim3(L, P), dim3(kCovThreads), lds_cov_a, st, ca);
-            if ((rc = launch(fn_cov_b, cov_b_grid, &ca, lds_cov_b))) return rc;
-            if (what & VGPMP_COV_ONLY) return (int)hipGetLastError();     // Kuu, Cholesky, q_sqrt, A, per-latent KL: done
-            mark();
             // large batches drawing their own noise: W and the features are formed inside the GEMM (prior_fused_batch_kernel);
             // trainable inducing locations read W back (inducing.hip), so they keep it in memory
             const bool fbatch = gen && tiled_gemm && !fused_small && !ind && !(what & VGPMP_NO_FUSE_PRIOR);
+            // ... and stage B of the covariance path rides in the same launch while the prior tiles leave room in their
+            // (single) round of two workgroups per CU: 28 problems 477 -> 432 us per step, 32: 500 -> 480; once the tiles
+            // fill the chip the covariance roles only queue behind them at the tiles' register budget (64 problems +0.7 %,
+            // config 5 +7.5 %).  Not while profiling stage by stage.
+            const size_t n_prior_tiles = (size_t)((J + kTJ - 1) / kTJ) * ((S + kTS - 1) / kTS) * P * L;
+            const bool cov_with_prior = VG_COV_WITH_PRIOR && fbatch && backward && !ev && n_prior_tiles <= 480 &&
+                                        !(what & (VGPMP_COV_ONLY | VGPMP_NO_FUSE));
+            if (!cov_with_prior && (rc = launch(fn_cov_b, cov_b_grid, &ca, lds_cov_b))) return rc;
+            if (what & VGPMP_COV_ONLY) return (int)hipGetLastError();     // Kuu, Cholesky, q_sqrt, A, per-latent KL: done
+            mark();
             if (gen) {
                 RngArgs r = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
                 if (fbatch) r.nW = 0;                    // omega, beta, eps, eps2 only
@@ -745,10 +778,23 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 const int dm = L <= 8 ? 8 : 16;
                 const size_t lds_fb = ((size_t)kTS * kFBLd + (size_t)2 * kTJ * kFBLd + (size_t)kTJ * dm + (size_t)2 * kFBK * (dm + 4)) * sizeof(float);
                 const dim3 fb_grid((J + kTJ - 1) / kTJ, (S + kTS - 1) / kTS, P * L);
+                if (cov_with_prior) {
+                    BatchCArgs bc;
+                    bc.cov = ca; bc.fb = fb;
+                    bc.cov_roles = (int)cov_b_grid.x; bc.fb_gx = (int)fb_grid.x; bc.fb_gy = (int)fb_grid.y;
+                    bc.n_prior = (int)(fb_grid.x * fb_grid.y * fb_grid.z);
+                    const unsigned nB = (unsigned)bc.n_prior + cov_b_grid.x * cov_b_grid.y * cov_b_grid.z;
+                    const size_t lds_bc = lds_fb > lds_cov_b ? lds_fb : lds_cov_b;
+                    const void* fn_bc = want_dell ? (dm == 8 ? (const void*)batch_cov_b_prior_kernel<true, 8> : (const void*)batch_cov_b_prior_kernel<true, 16>)
+                                                  : (dm == 8 ? (const void*)batch_cov_b_prior_kernel<false, 8> : (const void*)batch_cov_b_prior_kernel<false, 16>);
+                    if ((rc = set_dyn_lds(fn_bc, lds_bc))) return rc;
+                    if ((rc = launch(fn_bc, dim3(nB), &bc, lds_bc))) return rc;
+                } else {
 #define VG_FB(DELL_, DM_) hipExtLaunchKernelGGL((prior_fused_batch_kernel<DELL_, DM_>), fb_grid, dim3(kBlock), lds_fb, st, g0, g1, 0, fb)
-                if (want_dell) { if (dm == 8) VG_FB(true, 8); else VG_FB(true, 16); }
-                else { if (dm == 8) VG_FB(false, 8); else VG_FB(false, 16); }
+                    if (want_dell) { if (dm == 8) VG_FB(true, 8); else VG_FB(true, 16); }
+                    else { if (dm == 8) VG_FB(false, 8); else VG_FB(false, 16); }
 #undef VG_FB
+                }
                 if (fe.tick) hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(1), 0, st, fe.tick);      // the feature kernel's tick
             } else if (fused_small) {      // features formed inside the GEMM (few samples: Phi / dPhi traffic is the cost)
                 launch_fused_small(g0, g1);

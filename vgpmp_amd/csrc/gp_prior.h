@@ -408,12 +408,11 @@ struct FusedBatchArgs {
     const uint32_t* ctr;
 };
 template <bool DELL, int DM>      // d/d ell wanted; joint-space extent padded to DM (8 or 16)
-__global__ __launch_bounds__(kBlock) void prior_fused_batch_kernel(FusedBatchArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float fb_lds[];
+__device__ __forceinline__ void prior_fused_batch_body(const FusedBatchArgs& a, float* fb_lds, int bx, int by, int bz) {
     const int S = a.S, L = a.L, J = a.J, N = a.N, D = a.D, B = a.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l = blockIdx.z % L, p = blockIdx.z / L;
-    const int s0 = blockIdx.y * kTS, j0 = blockIdx.x * kTJ;
+    const int l = bz % L, p = bz / L;
+    const int s0 = by * kTS, j0 = bx * kTJ;
     const size_t pl = (size_t)p * L + l;
     float* As = fb_lds;                                  // [64][kFBLd]         W tile
     float* Bs = As + kTS * kFBLd;                        // [2][144][kFBLd]     Phi, dPhi tiles
@@ -517,6 +516,11 @@ __global__ __launch_bounds__(kBlock) void prior_fused_batch_kernel(FusedBatchArg
             }
         }
     }
+}
+template <bool DELL, int DM>
+__global__ __launch_bounds__(kBlock) void prior_fused_batch_kernel(FusedBatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float fb_lds[];
+    prior_fused_batch_body<DELL, DM>(a, fb_lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 __global__ void tick_kernel(uint32_t* ctr) { *ctr += 1u; }
 
