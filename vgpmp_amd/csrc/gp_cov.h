@@ -803,14 +803,15 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
     VG_T(tile == 0 && l == 0 && p == 0, 234);
     float4* A4 = reinterpret_cast<float4*>(a.ws.A4) + pl * N * Mz;
     float* AT = a.ws.AT + pl * N * Mz;
-    float av_keep[2] = {0.f, 0.f};
+    float av0 = 0.f, av1 = 0.f;      // (two scalars, not an array: a run-time index would put it in scratch memory)
     int cnt = 0;
     for (int e = tid; e < kRowTile * Mz; e += nt, ++cnt) {
         int r = vg_div(e, iMz), m = e - r * Mz;
         const double y = df[e] - dot4(ar + r * Mz, 1, Kd + m, ld, Mz);
         const double v = dot4(ar + r * Mz, 1, Ki + m, ld, Mz);
         yr[e] = y;
-        if (cnt < 2) av_keep[cnt] = (float)(a.jitter / var * v);
+        const float avv = (float)(a.jitter / var * v);
+        if (cnt == 0) av0 = avv; else if (cnt == 1) av1 = avv;
     }
     __syncthreads();
     VG_T(tile == 0 && l == 0 && p == 0, 235);
@@ -819,7 +820,7 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
         int r = vg_div(e, iMz), m = e - r * Mz, n = n0 + r;
         if (n >= N) continue;
         const double s = a.want_dell ? dot4(yr + r * Mz, 1, Ki + m, ld, Mz) : 0.0;
-        const float av = av_keep[cnt < 2 ? cnt : 1];
+        const float av = cnt == 0 ? av0 : av1;
         vg_stream(A4 + (size_t)n * Mz + m, make_float4((float)ar[e], (float)s, av, 0.f));
         vg_stream(AT + (size_t)m * N + n, (float)ar[e]);
     }
