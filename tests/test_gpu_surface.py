@@ -501,18 +501,20 @@ def test_dispatchers_on_the_device_match_oracle():
     np.testing.assert_allclose(float(prior_kl(iv2, kern, p2.q_mu, p2.q_sqrt, y_u)), cv2["kl"], rtol=1e-8)
 
 
-@pytest.mark.parametrize("S,N,M,B,lengthscales", [(37, 50, 10, 256, True), (128, 150, 30, 1024, True), (70, 20, 5, 64, False)])
-def test_fused_prior_kernel_equals_generator_features_and_gemm(S, N, M, B, lengthscales):
+@pytest.mark.parametrize("S,N,M,B,lengthscales,P", [(37, 50, 10, 256, True, 3), (128, 150, 30, 1024, True, 3), (70, 20, 5, 64, False, 3),
+                                                      (70, 20, 5, 64, True, 63), (128, 12, 5, 128, False, 64)])   # 128-row tiles (ragged / full)
+def test_fused_prior_kernel_equals_generator_features_and_gemm(S, N, M, B, lengthscales, P):
     """Large-batch schedule with device-generated noise: W and Phi / dPhi formed inside the GEMM (prior_fused_batch_kernel)
     against the three launches it replaces (Philox generator -> w, features_kernel -> Phi / dPhi, tiled GEMM): the same
     expressions in the same order, so the prior draws, the paths, the likelihood and every gradient agree bit for bit.
-    Ragged sample count, one and two column tiles, with and without the lengthscale tangent."""
+    Ragged sample count, one and two column tiles, with and without the lengthscale tangent; 63 / 64 problems: the
+    128-row tiles of the full-chip regime."""
     from vgpmp_amd import capi, engine
     ps = rb.load_problemset("franka", "industrial")
     spec = rb.load_robot("franka")
     grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
     sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
-    qs = np.array([ps.queries[i] for i in range(3)])
+    qs = np.array([ps.queries[i % len(ps.queries)] for i in range(P)])
     tr = dict(q_mu=True, q_sqrt=True, lengthscales=lengthscales, kernel_variance=True)
     kw = dict(num_samples=S, num_inducing=M, num_data=N, num_bases=B, lengthscales=[2.0] * 7, variance=0.2, seed=9, split_k=1,
               trainable=tr, problem_base=5)

@@ -22,6 +22,9 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 #else
 #define VG_STOP(args, k) do { } while (0)
 #endif
+#ifndef VG_FB_MT2
+#define VG_FB_MT2 1          // 0: measurement builds with 64-row tiles of the fused prior kernel at every batch size
+#endif
 #ifndef VG_COV_WITH_PRIOR
 #define VG_COV_WITH_PRIOR 1  // 0: measurement builds with cov_b and the fused prior kernel as two launches
 #endif
@@ -776,8 +779,15 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 fb.seed = seed; fb.problem_base = problem_base; fb.step = step_i; fb.ctr = ctr;
                 fb.wOff = (uint32_t)d->sample_offset * L * B;
                 const int dm = L <= 8 ? 8 : 16;
-                const size_t lds_fb = ((size_t)kTS * kFBLd + (size_t)2 * kTJ * kFBLd + (size_t)kTJ * dm + (size_t)2 * kFBK * (dm + 4)) * sizeof(float);
-                const dim3 fb_grid((J + kTJ - 1) / kTJ, (S + kTS - 1) / kTS, P * L);
+                // 128-row tiles (one workgroup per CU, the features of a K step shared by twice the rows): 64 Franka problems
+                // 883 -> 862 us per step.  Their workgroups run twice as long, so a thin last round costs a whole one: only
+                // when the last round of P L workgroups over the 256 CUs is at least 70 % full (40 problems: +10 % otherwise);
+                // the 16-wide joint padding (9-16 joints) measured 1.4 % slower with them (config 5), so 8-wide only.
+                const int fb_tail = (int)(((size_t)P * L) % 256);
+                const int fmt = VG_FB_MT2 && !cov_with_prior && S > kTS && dm == 8 && (size_t)P * L >= 256 &&
+                                (fb_tail == 0 || fb_tail >= 180) ? 2 : 1;
+                const size_t lds_fb = ((size_t)kTS * fmt * kFBLd + (size_t)2 * kTJ * kFBLd + (size_t)kTJ * dm + (size_t)2 * kFBK * (dm + 4)) * sizeof(float);
+                const dim3 fb_grid((J + kTJ - 1) / kTJ, (S + kTS * fmt - 1) / (kTS * fmt), P * L);
                 if (cov_with_prior) {
                     BatchCArgs bc;
                     bc.cov = ca; bc.fb = fb;
@@ -790,7 +800,11 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                     if ((rc = set_dyn_lds(fn_bc, lds_bc))) return rc;
                     if ((rc = launch(fn_bc, dim3(nB), &bc, lds_bc))) return rc;
                 } else {
-#define VG_FB(DELL_, DM_) hipExtLaunchKernelGGL((prior_fused_batch_kernel<DELL_, DM_>), fb_grid, dim3(kBlock), lds_fb, st, g0, g1, 0, fb)
+#define VG_FB(DELL_, DM_)                                                                                                 \
+    do {                                                                                                                  \
+        if (fmt == 2) hipExtLaunchKernelGGL((prior_fused_batch_kernel<DELL_, DM_, 2>), fb_grid, dim3(kBlock), lds_fb, st, g0, g1, 0, fb); \
+        else hipExtLaunchKernelGGL((prior_fused_batch_kernel<DELL_, DM_, 1>), fb_grid, dim3(kBlock), lds_fb, st, g0, g1, 0, fb);          \
+    } while (0)
                     if (want_dell) { if (dm == 8) VG_FB(true, 8); else VG_FB(true, 16); }
                     else { if (dm == 8) VG_FB(false, 8); else VG_FB(false, 16); }
 #undef VG_FB

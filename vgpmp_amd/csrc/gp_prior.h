@@ -407,15 +407,19 @@ struct FusedBatchArgs {
     uint32_t seed, problem_base, step, wOff;
     const uint32_t* ctr;
 };
-template <bool DELL, int DM>      // d/d ell wanted; joint-space extent padded to DM (8 or 16)
+// MT = 2: 128 sample rows per workgroup (two 16-row tiles per wave) -- the features of a K step, which do not depend on the
+// sample, are formed once for 128 rows instead of once per 64, and every B fragment read from LDS feeds two MFMAs; 36
+// accumulator tiles per wave (144 registers): one workgroup per CU.
+template <bool DELL, int DM, int MT = 1>      // d/d ell wanted; joint-space extent padded to DM (8 or 16); 16-row tiles per wave
 __device__ __forceinline__ void prior_fused_batch_body(const FusedBatchArgs& a, float* fb_lds, int bx, int by, int bz) {
     const int S = a.S, L = a.L, J = a.J, N = a.N, D = a.D, B = a.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l = bz % L, p = bz / L;
-    const int s0 = by * kTS, j0 = bx * kTJ;
+    constexpr int kRows = kTS * MT;
+    const int s0 = by * kRows, j0 = bx * kTJ;
     const size_t pl = (size_t)p * L + l;
-    float* As = fb_lds;                                  // [64][kFBLd]         W tile
-    float* Bs = As + kTS * kFBLd;                        // [2][144][kFBLd]     Phi, dPhi tiles
+    float* As = fb_lds;                                  // [64 MT][kFBLd]      W tile
+    float* Bs = As + kRows * kFBLd;                        // [2][144][kFBLd]     Phi, dPhi tiles
     float* pts = Bs + 2 * kTJ * kFBLd;                   // [144][DM]           the tile's points (rows of X, then of Zy), zero padded
     float* oms = pts + kTJ * DM;                         // [2][16][DM + 4]     the K step's frequency rows (+ phase), double buffered
     constexpr int kOLd = DM + 4;
@@ -433,8 +437,9 @@ __device__ __forceinline__ void prior_fused_batch_body(const FusedBatchArgs& a, 
     // features -- thread (kcol = tid % 16, jg = tid / 16) forms rows jg, jg + 16, ... of column kcol;
     // frequencies -- thread t < 16 D fetches element t of the step's 16 contiguous rows of omega, t < 16 + 16 D a phase
     const int wrow = tid >> 2, wq = tid & 3;
-    const int srow = min(s0 + wrow, S - 1);
-    const uint32_t wbase = (a.wOff + ((uint32_t)srow * L + l) * (uint32_t)B) >> 2;      // counter of (row, column 0)
+    uint32_t wbase[MT];                                  // counter of (row, column 0); rows wrow, wrow + 64
+#pragma unroll
+    for (int m = 0; m < MT; ++m) wbase[m] = (a.wOff + ((uint32_t)min(s0 + wrow + kTS * m, S - 1) * L + l) * (uint32_t)B) >> 2;
     const int kcol = tid & 15, jg = tid >> 4;
     const int nom = kFBK * D;
     const bool is_om = tid < nom, is_bt = tid >= nom && tid < nom + kFBK;
@@ -442,9 +447,11 @@ __device__ __forceinline__ void prior_fused_batch_body(const FusedBatchArgs& a, 
     const float* osrc = is_om ? a.omega + pl * B * D + tid : a.beta + pl * B + (tid - nom);
     const int ostep = is_om ? kFBK * D : kFBK;
     float onext = (is_om || is_bt) ? osrc[0] : 0.f;
-    vg_f32x4 accF[kTJ / 16], accH[kTJ / 16];
+    vg_f32x4 accF[MT][kTJ / 16], accH[MT][kTJ / 16];
 #pragma unroll
-    for (int t = 0; t < kTJ / 16; ++t) { accF[t] = (vg_f32x4){0.f, 0.f, 0.f, 0.f}; accH[t] = accF[t]; }
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < kTJ / 16; ++t) { accF[m][t] = (vg_f32x4){0.f, 0.f, 0.f, 0.f}; accH[m][t] = accF[m][t]; }
     const int r = lane & 15, g = lane >> 4;
     __syncthreads();
     if (is_om || is_bt) oms[orow * kOLd + ocol] = onext;
@@ -454,8 +461,11 @@ __device__ __forceinline__ void prior_fused_batch_body(const FusedBatchArgs& a, 
         // ---- generate the K step's operands (the next step's frequencies are requested first, stored last)
         {
             if ((is_om || is_bt) && k0 + kFBK < B) onext = osrc[(size_t)(k0 / kFBK + 1) * ostep];
-            const float4 w4 = vg_normal4(wbase + (uint32_t)((k0 >> 2) + wq), VG_STREAM_W, key);
-            *reinterpret_cast<float4*>(As + wrow * kFBLd + 4 * wq) = w4;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float4 w4 = vg_normal4(wbase[m] + (uint32_t)((k0 >> 2) + wq), VG_STREAM_W, key);
+                *reinterpret_cast<float4*>(As + (wrow + kTS * m) * kFBLd + 4 * wq) = w4;
+            }
             float om[DM];
             const float* orowp = oms + (ob * kFBK + kcol) * kOLd;
 #pragma unroll
@@ -481,22 +491,30 @@ __device__ __forceinline__ void prior_fused_batch_body(const FusedBatchArgs& a, 
             if ((is_om || is_bt) && k0 + kFBK < B) oms[((ob ^ 1) * kFBK + orow) * kOLd + ocol] = onext;
         }
         __syncthreads();
-        // ---- 2 x 9 tiles of 16 x 16, four k-interleaved MFMAs each
+        // ---- 2 x 9 tiles of 16 x 16 per row tile, four k-interleaved MFMAs each
         {
-            const float4 a4 = *reinterpret_cast<const float4*>(As + (wave * 16 + r) * kFBLd + 4 * g);
+            float4 a4[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a4[m] = *reinterpret_cast<const float4*>(As + (kTS * m + wave * 16 + r) * kFBLd + 4 * g);
 #pragma unroll
             for (int t = 0; t < kTJ / 16; ++t) {
                 const float4 b4 = *reinterpret_cast<const float4*>(Bs + (t * 16 + r) * kFBLd + 4 * g);
-                accF[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, accF[t], 0, 0, 0);
-                accF[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, accF[t], 0, 0, 0);
-                accF[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, accF[t], 0, 0, 0);
-                accF[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, accF[t], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    accF[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m].x, b4.x, accF[m][t], 0, 0, 0);
+                    accF[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m].y, b4.y, accF[m][t], 0, 0, 0);
+                    accF[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m].z, b4.z, accF[m][t], 0, 0, 0);
+                    accF[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m].w, b4.w, accF[m][t], 0, 0, 0);
+                }
                 if (DELL) {
                     const float4 d4 = *reinterpret_cast<const float4*>(Bs + (kTJ + t * 16 + r) * kFBLd + 4 * g);
-                    accH[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, d4.x, accH[t], 0, 0, 0);
-                    accH[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, d4.y, accH[t], 0, 0, 0);
-                    accH[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, d4.z, accH[t], 0, 0, 0);
-                    accH[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, d4.w, accH[t], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        accH[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m].x, d4.x, accH[m][t], 0, 0, 0);
+                        accH[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m].y, d4.y, accH[m][t], 0, 0, 0);
+                        accH[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m].z, d4.z, accH[m][t], 0, 0, 0);
+                        accH[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m].w, d4.w, accH[m][t], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -504,23 +522,25 @@ __device__ __forceinline__ void prior_fused_batch_body(const FusedBatchArgs& a, 
         ob ^= 1;
     }
 #pragma unroll
-    for (int t = 0; t < kTJ / 16; ++t) {
-        const int jc = j0 + 16 * t + r;
-        if (jc >= J) continue;
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int s = s0 + wave * 16 + g * 4 + q;
-            if (s < S) {
-                vg_stream(a.F0 + (((size_t)p * S + s) * L + l) * J + jc, accF[t][q]);
-                if (DELL) vg_stream(a.H + (((size_t)p * S + s) * L + l) * J + jc, accH[t][q]);
+        for (int t = 0; t < kTJ / 16; ++t) {
+            const int jc = j0 + 16 * t + r;
+            if (jc >= J) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int s = s0 + kTS * m + wave * 16 + g * 4 + q;
+                if (s < S) {
+                    vg_stream(a.F0 + (((size_t)p * S + s) * L + l) * J + jc, accF[m][t][q]);
+                    if (DELL) vg_stream(a.H + (((size_t)p * S + s) * L + l) * J + jc, accH[m][t][q]);
+                }
             }
         }
-    }
 }
-template <bool DELL, int DM>
+template <bool DELL, int DM, int MT = 1>
 __global__ __launch_bounds__(kBlock) void prior_fused_batch_kernel(FusedBatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) float fb_lds[];
-    prior_fused_batch_body<DELL, DM>(a, fb_lds, blockIdx.x, blockIdx.y, blockIdx.z);
+    prior_fused_batch_body<DELL, DM, MT>(a, fb_lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 __global__ void tick_kernel(uint32_t* ctr) { *ctr += 1u; }
 
