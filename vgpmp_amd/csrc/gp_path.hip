@@ -22,6 +22,9 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 #else
 #define VG_STOP(args, k) do { } while (0)
 #endif
+#ifndef VG_BATCH_MERGE
+#define VG_BATCH_MERGE 1      // 0: measurement builds with every small launch of the large-batch schedule on its own
+#endif
 #ifndef VG_FB_MT2
 #define VG_FB_MT2 1          // 0: measurement builds with 64-row tiles of the fused prior kernel at every batch size
 #endif
@@ -498,6 +501,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     ca.hy = hyp; fe.hy = hyp;
     pa.stop = -1;
     pa.xcd_span = 0;
+    pa.tick = nullptr;
     const double lik_scale = pb->alpha / (double)d->S_total;
     FinalArgs fa;
     fa.M = M; fa.L = L; fa.NC = NC; fa.nblk = P ? vg_loglik_blocks_per_problem(S, N) : 0; fa.part_len = vg_part_len(d);
@@ -614,9 +618,9 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const size_t lds_tg1 = (size_t)2 * (kTS + kTJ) * kTLd * sizeof(float);
     const size_t lds_midC = lds_cov_b > lds_tg1 ? lds_cov_b : lds_tg1;
     const void* fn_midC = backward ? (const void*)mid_cov_b_gemm_kernel<true> : (const void*)mid_cov_b_gemm_kernel<false>;
-    if (mid) {
+    if (mid && (rc = set_dyn_lds(fn_midC, lds_midC))) return rc;
+    if (!fused) {      // (the large-batch schedule merges its small launches with these two as well)
         if ((rc = set_dyn_lds((const void*)mid_cov_a_rng_kernel, lds_cov_a))) return rc;
-        if ((rc = set_dyn_lds(fn_midC, lds_midC))) return rc;
         if ((rc = set_dyn_lds((const void*)mid_hyper_final_kernel, lds_fin))) return rc;
     }
     const dim3 cov_b_grid(3 + (N + kRowTile - 1) / kRowTile, L, P);
@@ -647,6 +651,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     // step; at 64 problems four times the workgroups each re-staging the factor LOSE 15 us)
     const bool fin_split_batch = fin_split && (size_t)L * P <= 128;
     fa.split = fin_split_batch ? 1 : 0;
+    bool batch_merged = false;      // this call's steps run the large-batch schedule with its small launches merged
     auto launch_final = [&]() -> int { return launch((const void*)final_kernel, dim3(L * (fin_split_batch ? kFinSplit : 1), P), &fa, lds_fin); };
     // likelihood constants as variables (vgpmp_lik_params): effective values from the raw ones at the start of the call
     LikUpdArgs lu;
@@ -746,10 +751,24 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             if ((rc = launch(fn_pf, dim3(NC * pa.nsplit, L, P), &pa, lds_pf))) return rc;
         } else {
             mark();
-            hipLaunchKernelGGL(cov_a_kernel, dim3(L, P), dim3(kCovThreads), lds_cov_a, st, ca);
             // large batches drawing their own noise: W and the features are formed inside the GEMM (prior_fused_batch_kernel);
             // trainable inducing locations read W back (inducing.hip), so they keep it in memory
             const bool fbatch = gen && tiled_gemm && !fused_small && !ind && !(what & VGPMP_NO_FUSE_PRIOR);
+            // the small launches of a step share launches here too (not while profiling stage by stage): stage A of the
+            // covariance path beside the noise draws, the two updates at the end in one, the counter tick inside paths_fwd
+            const bool batch_merge = VG_BATCH_MERGE && gen && backward && !ev && !ind && !lk && !(what & (VGPMP_COV_ONLY | VGPMP_NO_FUSE));
+            if (batch_merge) {
+                MidAArgs ma;
+                ma.cov = ca;
+                ma.rng = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
+                if (fbatch) ma.rng.nW = 0;               // omega, beta, eps, eps2 only
+                ma.n_cov = L * P; ma.basis_gx = (int)((ma.rng.L * ma.rng.B + kBlock - 1) / kBlock); ma.n_basis = ma.basis_gx * P;
+                const uint32_t n_thr = (ma.rng.nW >> 2) + 2 * ma.rng.nE;
+                ma.n_gx = (int)((n_thr + kBlock - 1) / kBlock);
+                if ((rc = launch((const void*)mid_cov_a_rng_kernel, dim3(ma.n_cov + ma.n_basis + (unsigned)ma.n_gx * P), &ma, lds_cov_a))) return rc;
+            } else {
+                hipLaunchKernelGGL(cov_a_kernel, dim3(L, P), dim3(kCovThreads), lds_cov_a, st, ca);
+            }
             // ... and stage B of the covariance path rides in the same launch while the prior tiles leave room in their
             // (single) round of two workgroups per CU: 28 problems 477 -> 432 us per step, 32: 500 -> 480; once the tiles
             // fill the chip the covariance roles only queue behind them at the tiles' register budget (64 problems +0.7 %,
@@ -760,7 +779,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             if (!cov_with_prior && (rc = launch(fn_cov_b, cov_b_grid, &ca, lds_cov_b))) return rc;
             if (what & VGPMP_COV_ONLY) return (int)hipGetLastError();     // Kuu, Cholesky, q_sqrt, A, per-latent KL: done
             mark();
-            if (gen) {
+            if (gen && !batch_merge) {
                 RngArgs r = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
                 if (fbatch) r.nW = 0;                    // omega, beta, eps, eps2 only
                 hipLaunchKernelGGL(rng_basis_kernel, dim3((r.L * r.B + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
@@ -809,7 +828,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                     else { if (dm == 8) VG_FB(false, 8); else VG_FB(false, 16); }
 #undef VG_FB
                 }
-                if (fe.tick) hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(1), 0, st, fe.tick);      // the feature kernel's tick
+                if (fe.tick && batch_merge) pa.tick = fe.tick;      // the feature kernel's tick: by paths_fwd (next launch), or alone
+                else if (fe.tick) hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(1), 0, st, fe.tick);
             } else if (fused_small) {      // features formed inside the GEMM (few samples: Phi / dPhi traffic is the cost)
                 launch_fused_small(g0, g1);
             } else if (tiled_gemm) {
@@ -826,7 +846,9 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 hipExtLaunchKernelGGL(prior_gemm_kernel<0>, gemm_grid, dim3(kBlock), 0, st, g0, g1, 0, ga);
             mark();
             if ((rc = launch(fn_pf, dim3(NC * pa.nsplit, L, P), &pa, lds_pf))) return rc;
+            pa.tick = nullptr;
             mark();
+            batch_merged = batch_merge;
         }
         // ---- likelihood forward + reverse (fk_sdf.hip)
         int nblk = 0;
@@ -859,7 +881,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             hipLaunchKernelGGL(lik_update_kernel, dim3(P), dim3(VGPMP_MAX_SPHERES), 0, st, lu);
         }
         mark();
-        if (mid) {
+        if (mid || batch_merged) {
             MidGArgs mg;
             hy.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
             fa.lr_t = hy.lr_t;

@@ -26,6 +26,7 @@ struct PathArgs {
     // [x span, (x + 1) span) of the (chunk, latent, problem) order, so the 2 * NC workgroups that stage the same
     // latent's A / C tangents sit behind one L2 (at most two latents per XCD instead of all of them)
     int xcd_span;
+    uint32_t* tick;           // paths_fwd_sc8: the step counter ticks here (large-batch schedule; nullptr: elsewhere)
 };
 __device__ __forceinline__ int xcd_contiguous(int id, int span) { return span > 0 ? (id & 7) * span + (id >> 3) : id; }
 
@@ -726,6 +727,7 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_split(PathArgs a) {
 template <int SK, bool RAW>
 __global__ __launch_bounds__(kBlock) void paths_fwd_sc8(PathArgs a) {
     extern __shared__ float smf[];
+    if (a.tick && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *a.tick += 1u;
     if (SK > 1 && a.nsplit == 2) {
         if constexpr (SK > 1) {
             if (a.Mz == 32) paths_fwd_split_body<SK, 32>(a, smf, blockIdx.x, blockIdx.y, blockIdx.z);
