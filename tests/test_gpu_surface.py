@@ -230,7 +230,7 @@ def test_graph_replay_of_the_merged_launch_schedule():
         assert torch.allclose(x, y, rtol=0, atol=1e-12), float((x - y).abs().max())
 
 
-@pytest.mark.parametrize("P,M", [(1, 12), (3, 12), (1, 30), (2, 30), (1, 20)])
+@pytest.mark.parametrize("P,M", [(1, 12), (3, 12), (1, 30), (2, 30), (1, 20), (6, 12), (30, 12), (40, 30)])
 def test_pipelined_steps_equal_single_step_calls(P, M):
     """vgpmp_elbo_steps shares launches between independent kernels and runs the q_mu / q_sqrt update of step t
     next to the covariance / feature kernels of step t+1; the result must equal the same steps issued one call
@@ -240,7 +240,10 @@ def test_pipelined_steps_equal_single_step_calls(P, M):
     spec = rb.load_robot("franka")
     grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
     sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
-    qs = np.array([ps.queries[i] for i in range(P)])
+    qs = np.array([ps.queries[i % len(ps.queries)] for i in range(P)])
+    # 6 problems: the merged launches of the medium batches (cov_a | noise, cov_b | tiled GEMM with the tiles first, hyper |
+    # final); 30: stage B of the covariance path inside the fused prior launch; 40: the large-batch schedule with its small
+    # launches merged and the counter tick inside paths_fwd -- each against one launch per kernel.
     # M = 30 (Mz = 32): the update role on four column strips, the two-panel elimination and the whole-wave hyper-parameter
     # update of the shared launches against final_kernel / hyper_kernel; M = 20 (Mz = 22): the zero-padded forms
     kw = dict(num_samples=32, num_inducing=M, num_data=40, num_bases=128, lengthscales=[2.0] * 7, variance=0.2, seed=3)
