@@ -124,7 +124,20 @@ __device__ __forceinline__ HyperState hyper_update(const HyperArgs& h, size_t pl
 // butterflies over 16 lanes, which add the SAME operand pairs as the tree of sum_chunks() (IEEE addition commutes
 // exactly), and the two independent scalar tails (lengthscale, variance: same arithmetic, different data) run side by
 // side in the lower and upper half of the wave.  Bit-identical to hyper_update(); every lane returns the full state.
-__device__ __forceinline__ double vg_shfl_f64(double v, int lane) { return __shfl(v, lane, VG_WAVE); }
+// value of a CONSTANT lane (v_readlane: an SGPR broadcast, no LDS round trip like ds_bpermute)
+template <int LANE>
+__device__ __forceinline__ double vg_lane_f64(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), LANE);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), LANE);
+    return __hiloint2double(hi, lo);
+}
+// DPP move of a double (both halves): quad permutes, half-row mirror, row rotate -- a few cycles each
+template <int CTRL>
+__device__ __forceinline__ double vg_dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ HyperState hyper_update_wave(const HyperArgs& h, size_t pl) {
 #pragma clang fp contract(off)
     const int lane = threadIdx.x & (VG_WAVE - 1), j = min(lane >> 4, 2), k = lane & 15;
@@ -147,13 +160,14 @@ __device__ __forceinline__ HyperState hyper_update_wave(const HyperArgs& h, size
             va = q[j]; vb = q[4 + j];
         }
         double d = c0 + k < h.NC ? (double)(va + vb) : 0.0;        // the two halves of paths_bwd_split, then the chunk tree
-        d += __shfl_xor(d, 1, VG_WAVE);
-        d += __shfl_xor(d, 2, VG_WAVE);
-        d += __shfl_xor(d, 4, VG_WAVE);
-        s += vg_shfl_f64(d, lane & 48);
-        s += vg_shfl_f64(d, (lane & 48) + 8);
+        d += vg_dpp_f64<0xB1>(d);                        // quad_perm [1, 0, 3, 2]: lane ^ 1
+        d += vg_dpp_f64<0x4E>(d);                        // quad_perm [2, 3, 0, 1]: lane ^ 2
+        d += vg_dpp_f64<0x141>(d);                       // row_half_mirror: the other quad of the eight (all four lanes of a quad agree)
+        const double other = vg_dpp_f64<0x128>(d);       // row_ror 8: the other eight of the sixteen
+        s += (lane & 8) ? other : d;                     // + chunks 0..7 of the pass, then + chunks 8..15, as sum_chunks() does
+        s += (lane & 8) ? d : other;
     }
-    const double s0 = vg_shfl_f64(s, 0), s1 = vg_shfl_f64(s, 16), s2 = vg_shfl_f64(s, 32);
+    const double s0 = vg_lane_f64<0>(s), s1 = vg_lane_f64<16>(s), s2 = vg_lane_f64<32>(s);
     const double g_ell = ((h.want_dell ? s0 : 0.0) + h.kl_scale * gkl) * sig;
     const double g_var = (s1 + s2 / (2.0 * var) + h.kl_scale * gkl) * sig;
     const double g = isv ? g_var : g_ell;
@@ -162,8 +176,8 @@ __device__ __forceinline__ HyperState hyper_update_wave(const HyperArgs& h, size
     adam_update(&nraw, &nm, &nv, g, lr_t);
     if (upd) { raw = nraw; m = nm; v = nv; }
     HyperState o;
-    o.raw_ell = vg_shfl_f64(raw, 0); o.m_ell = vg_shfl_f64(m, 0); o.v_ell = vg_shfl_f64(v, 0); o.g_ell = vg_shfl_f64(g, 0);
-    o.raw_var = vg_shfl_f64(raw, 32); o.m_var = vg_shfl_f64(m, 32); o.v_var = vg_shfl_f64(v, 32); o.g_var = vg_shfl_f64(g, 32);
+    o.raw_ell = vg_lane_f64<0>(raw); o.m_ell = vg_lane_f64<0>(m); o.v_ell = vg_lane_f64<0>(v); o.g_ell = vg_lane_f64<0>(g);
+    o.raw_var = vg_lane_f64<32>(raw); o.m_var = vg_lane_f64<32>(m); o.v_var = vg_lane_f64<32>(v); o.g_var = vg_lane_f64<32>(g);
     return o;
 }
 
