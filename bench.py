@@ -1,16 +1,23 @@
 #!/usr/bin/env python3
-"""ELBO iterations/sec of the MI355X-native vGPMP hot path (BASELINE.json metric).
+"""ELBO iterations/sec + plans/sec of the MI355X-native vGPMP hot path (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus N ...                      # starts N fresh rank processes itself (vgpmp_amd/launch.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W            # or under an external launcher
 
 A "step" is one full optimisation step of one planning problem: fresh Philox noise, ELBO forward
 (Kuu/Kuf + Cholesky, RFF prior, Matheron update, FK, SDF lookup, hinge likelihood, KL), its reverse
-pass and the Adam update (reference utils/miscellaneous.py:68-84).  Workload at every N: BASELINE
-config 2 -- Franka 7-DoF, industrial offset, ONE start-goal problem per GPU, S=128, M=30, T=100,
-B=1024 on a synthetic 128^3 SDF (the reference's .sdf blobs are missing from its checkout).  Ranks
-hold independent problems (no data-path collective): weak scaling, value = total steps / max time.
+pass and the Adam update (reference utils/miscellaneous.py:68-84).  Default workload at every N:
+BASELINE config 2 -- Franka 7-DoF, industrial scene (SDF generated on the device from the reference's
+industrial collision mesh: its .sdf blobs are missing from the checkout), ONE start-goal problem per
+GPU, S=128, M=30, T=100, B=1024.  Ranks hold independent problems (no data-path collective): weak
+scaling, value = total steps / max time over ranks.  With N > 1 the line also carries `batch_512`:
+BASELINE config 5's share of the 512-problem batch (64 problems of the 14-DoF arm per GPU, 512^3 table).
+
+Other workloads: --workload config3 (Franka / bookshelves, all 55 start-goal pairs as one batch),
+--workload stress (config 5 share), --shard samples (config 4: UR10, S=1024 split over the ranks,
+one all-reduce of the gradient buffer per step).
 """
 import argparse
 import json
@@ -18,21 +25,82 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-from vgpmp_amd import engine, robots, scenes  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 HBM_ACHIEVABLE_GBPS = 6290.0    # same guide: measured float4 copy
 SUMMARY = {"auto": None, "on": True, "off": False}
 F32_MFMA_PEAK_TFLOPS = 157.3    # v_mfma_f32_16x16x4_f32 dense peak
+METRIC = "ELBO iters/sec + plans/sec, Franka-7DoF industrial S=128 M=30 T=100, 1/2/4/8 GPU"
 
 
-def build_problem(rank: int, args):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--samples", type=int, default=0, help="Monte-Carlo samples (0 = the workload's own: 128 / 7 / 1024)")
+    ap.add_argument("--inducing", type=int, default=0, help="inducing points (0 = the workload's own)")
+    ap.add_argument("--timesteps", type=int, default=0, help="time stamps (0 = the workload's own)")
+    ap.add_argument("--problems", type=int, default=0, help="problems per GPU (0 = the workload's own: config 2: 1, config 3: 55, stress: 64)")
+    ap.add_argument("--grid", type=int, default=0, help="SDF voxels per axis of the synthetic scenes (0 = 128; stress: 512)")
+    ap.add_argument("--split-k", type=int, default=0, help="K-slices of the prior GEMM (0 = engine default)")
+    ap.add_argument("--no-fuse", action="store_true", help="one launch per kernel even for small batches (measurement)")
+    ap.add_argument("--scene", choices=("mesh", "industrial", "synthetic"), default="mesh",
+                    help="mesh = SDF generated from the reference's collision mesh of the workload's scene; synthetic = boxes/spheres")
+    ap.add_argument("--unroll", type=int, default=0,
+                    help="steps per captured hipGraph; 0 = plain launches (measured 2-3 %% faster than graph replay here)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-solve", action="store_true", help="skip the measured solve_planning_problem() calls (plans/sec)")
+    ap.add_argument("--profile-steps", type=int, default=40)
+    ap.add_argument("--allow-nan", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--traffic-file", default="", help="pmc traffic table (tools/pmc_aggregate.py) for roofline.traffic")
+    ap.add_argument("--shard", choices=("problems", "samples"), default="problems",
+                    help="problems: independent problems per GPU, no collective (config 2 / 3 / 5); samples: BASELINE config 4, "
+                         "UR10, one problem, 1024 Monte-Carlo samples split over the ranks, one all-reduce per step")
+    ap.add_argument("--collective", choices=("torch", "capi"), default="torch",
+                    help="samples sharding: torch.distributed all_reduce (RCCL) or the C ABI's vgpmp_allreduce_grads (RCCL)")
+    ap.add_argument("--layout", choices=("brick", "linear"), default="brick", help="voxel table layout (include/vgpmp.h)")
+    ap.add_argument("--summary", choices=("auto", "on", "off"), default="auto",
+                    help="free-space brick summary in the batch likelihood kernel (auto: tables beyond the Infinity Cache)")
+    ap.add_argument("--lik-form", choices=("auto", "lanes", "lanes-lds"), default="auto",
+                    help="likelihood kernel form (measurement): lanes = the batch form at any batch size, lanes-lds = with its per-frame sums in LDS")
+    ap.add_argument("--flags", type=int, default=0, help="extra VGPMP_* measurement flags (include/vgpmp.h) OR-ed into every step")
+    ap.add_argument("--min-seconds", type=float, default=2.0,
+                    help="the timed region repeats the K steps until this much time has passed (K = --steps alone is ~10 ms)")
+    ap.add_argument("--workload", choices=("config2", "config3", "stress"), default="config2",
+                    help="config2 = the benchmark line; config3 = Franka / bookshelves, 55 pairs, S=7 M=24 T=70; "
+                         "stress = BASELINE config 5 per-GPU share (64 problems, 512^3 table)")
+    ap.add_argument("--also-stress", choices=("auto", "on", "off"), default="auto",
+                    help="append the config-5 share (batch_512) to the line; auto = when N > 1 runs the default workload")
+    return ap.parse_args(argv)
+
+
+WORKLOAD_DEFAULTS = {            # samples, inducing, timesteps, problems per GPU, grid
+    "config2": (128, 30, 100, 1, 128),
+    "config3": (7, 24, 70, 55, 128),
+    "stress": (128, 30, 100, 64, 512),
+}
+
+
+def resolve(args):
+    """Fill in the workload's own sizes where the command line left them at 0."""
+    s, m, n, p, g = WORKLOAD_DEFAULTS[args.workload]
+    if args.shard == "samples":
+        s, m, n, p = 1024, 18, 70, 1                       # BASELINE config 4 (data/problemsets/ur10.py:71-84)
+    args.samples = args.samples or s
+    args.inducing = args.inducing or m
+    args.timesteps = args.timesteps or n
+    args.problems = args.problems or p
+    args.grid = args.grid or g
+    return args
+
+
+def build_problem(rank: int, args, world: int = 1):
+    import numpy as np
+    import torch
+    from vgpmp_amd import engine, robots, scenes
     ps = robots.load_problemset("franka", "industrial")
     pp = ps.planner_params
     if args.workload == "stress":
@@ -55,26 +123,32 @@ def build_problem(rank: int, args):
         # BASELINE config 4: UR10 6-DoF, industrial, ONE problem whose S Monte-Carlo samples are split over the ranks;
         # one in-place all-reduce of the contiguous [gradient | lik | kl] buffer per step (vgpmp_amd/sharding.py)
         from vgpmp_amd import sharding
-        world = int(os.environ.get("WORLD_SIZE", "1"))
         ps = robots.load_problemset("ur10", "industrial")
         pp = ps.planner_params
         spec = robots.load_robot("ur10", *ps.robot_pos_and_orn)
-        grid = scenes.scene_sdf("industrial", delta=0.0125, padding=20) if args.scene == "industrial" else \
+        grid = scenes.scene_sdf("industrial", delta=0.0125, padding=20) if args.scene != "synthetic" else \
             scenes.synthetic_boxes_sdf(n=args.grid, delta=1.6 / args.grid, origin=(-0.8, -0.8, -0.2), seed=0)
         scene = engine.DeviceScene(spec, grid, ps.object_positions[0], sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"],
                                    layout=args.layout, free_space_summary=SUMMARY[args.summary])
         s_loc, s_off = sharding.shard_samples(args.samples, world, rank)
         planner = engine.PlannerBatch(scene, np.array([ps.queries[0]]), num_samples=s_loc, samples_total=args.samples,
                                       sample_offset=s_off, kl_scale=1.0 if rank == 0 else 0.0,
-                                      num_inducing=int(pp["num_inducing"]), num_data=int(pp["time_spacing_X"]), num_bases=1024,
+                                      num_inducing=args.inducing, num_data=args.timesteps, num_bases=1024,
                                       lengthscales=pp["lengthscales"], variance=pp["variance"], alpha=pp["alpha"],
                                       learning_rate=pp["learning_rate"], seed=1234)
         return ps, spec, grid, scene, planner
+    scene_name = "industrial"
+    if args.workload == "config3":
+        # BASELINE config 3: Franka, bookshelves offset (0.62, -0.15, 0.834), all C(11,2) = 55 start-goal pairs in one
+        # problem-parallel batch, S=7 M=24 N=70, lr 0.09 (data/problemsets/franka.py:11-24,91-104)
+        ps = robots.load_problemset("franka", "bookshelves")
+        pp = ps.planner_params
+        scene_name = "bookshelves"
     spec = robots.load_robot("franka", *ps.robot_pos_and_orn)
-    if args.scene == "industrial":
-        # the reference's industrial scene: grid generated on the device from its collision mesh (vgpmp_mesh_sdf),
-        # SDFGen-style extent (bounding box + 20 cells) at 1.25 cm -> 129 x 154 x 80 voxels
-        grid = scenes.scene_sdf("industrial", delta=0.0125, padding=20)
+    if args.scene != "synthetic":
+        # the reference's scene: grid generated on the device from its collision mesh (vgpmp_mesh_sdf),
+        # SDFGen-style extent (bounding box + 20 cells) at 1.25 cm (industrial: 129 x 154 x 80 voxels)
+        grid = scenes.scene_sdf(scene_name, delta=0.0125, padding=20)
     else:
         grid = scenes.synthetic_boxes_sdf(n=args.grid, delta=1.6 / args.grid, origin=(-0.8, -0.8, -0.2), seed=0)
     scene = engine.DeviceScene(spec, grid, ps.object_positions[0], sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"],
@@ -89,8 +163,10 @@ def build_problem(rank: int, args):
     return ps, spec, grid, scene, planner
 
 
-def cpu_baseline(ps, spec, grid, args, budget_s: float = 12.0):
-    """The float64 NumPy oracle (a restatement, not the GPflow/TF stack) timed on the host cores."""
+def cpu_baseline(ps, spec, grid, args, budget_s: float = 10.0):
+    """The float64 NumPy oracle (a restatement, not the GPflow/TF stack) timed on the host cores: all threads of the
+    BLAS pool, then ONE thread (BASELINE.md section 3 asks for both and for the thread count)."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_scene
     from oracle import vgpmp_oracle as orc
@@ -104,32 +180,97 @@ def cpu_baseline(ps, spec, grid, args, budget_s: float = 12.0):
     rng = np.random.default_rng(0)
     one = lambda: orc.optimization_step(p, st, sc, X, Zy, y, orc.draw_noise(rng, S, D, D, B, M + 2),
                                         float(pp["alpha"]), float(pp["learning_rate"]))
-    one()                                   # warm caches / BLAS threads
-    n, t0 = 0, time.perf_counter()
-    while True:
-        one(); n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s and n >= 3:
-            break
+
+    def timed(budget):
+        one()                                   # warm caches / BLAS threads
+        n, t0 = 0, time.perf_counter()
+        while True:
+            one(); n += 1
+            el = time.perf_counter() - t0
+            if el > budget and n >= 3:
+                return n, el
+
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
         threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
     except Exception:
-        threads = os.cpu_count() or 1
-    return {"value": n / el, "unit": "ELBO iters/sec", "cores": int(threads), "kind": "port",
-            "sample": f"{n} full optimisation steps of the same workload (noise draw + forward + reverse + Adam) "
-                      f"by the float64 NumPy oracle in {el:.1f} s; host has {os.cpu_count()} logical cores"}
+        threadpool_limits, threads = None, os.cpu_count() or 1
+    n, el = timed(budget_s)
+    out = {"value": n / el, "unit": "ELBO iters/sec", "cores": int(threads), "kind": "port",
+           "logical_cores": os.cpu_count(),
+           "sample": f"{n} full optimisation steps of the same workload (noise draw + forward + reverse + Adam) "
+                     f"by the float64 NumPy oracle in {el:.1f} s on {threads} BLAS threads; host has {os.cpu_count()} logical cores"}
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            n1, el1 = timed(budget_s)
+        out["single_thread"] = {"value": n1 / el1, "cores": 1,
+                                "sample": f"{n1} steps in {el1:.1f} s with the BLAS pool limited to one thread"}
+    return out
 
 
-def run_sample_sharded(args, world, rank, dist, backend, ps, spec, scene, planner):
-    """BASELINE config 4: one problem, the sample axis split over the ranks; a step = local forward + reverse, ONE in-place
-    all-reduce of the contiguous [gradient | lik | kl] buffer, the replicated Adam update.  Strong scaling in S."""
-    from vgpmp_amd import sharding
-    comm = sharding.CapiComm(world, rank) if (args.collective == "capi" and (world == 1 or backend == "nccl")) else None
-    sp = sharding.SampleShardedPlanner(planner, comm=comm)
-    if world == 1 and comm is None:
-        sp._allreduce = lambda: None                         # nothing to exchange on one rank
-    sp.run_steps(args.warmup)
+def measured_solves(args, world, rank, dist, backend):
+    """plans/sec as the metric words it: complete solve_planning_problem() calls through the reference-shaped surface
+    (gpflow_vgpmp.utils.miscellaneous, utils/miscellaneous.py:141-321 minus GUI / simulated execution: model construction,
+    disable_param_opt, num_steps optimisation steps, 150 posterior paths, best-sample pick, clearance check), one after
+    another as benchmarking.py:68-85 does, and the whole problem set as ONE device batch (solve_planning_problems_batched).
+    BASELINE config 2 sizes (S=128, M=30, T=100) on the reference's industrial problem set."""
+    import warnings
+    import numpy as np
+    import torch
+    ns = {}
+    exec("from gpflow_vgpmp.utils.miscellaneous import *", ns)
+    from gpflow_vgpmp.utils.simulation_manager import SimulationManager
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        env = SimulationManager(file_path=os.path.join(ROOT, "parameters.yaml"))
+    env.config["planner_params"].update(num_samples=args.samples, num_inducing=args.inducing, time_spacing_X=args.timesteps)
+    pp = env.config["planner_params"]
+    solve, batched = ns["solve_planning_problem"], ns["solve_planning_problems_batched"]
+    queries = env.config["scene_params"]["queries"]
+    dof = env.robot.dof
+    mine = [queries[(rank * 7 + i) % len(queries)] for i in range(7)]      # one warm-up + six timed, per rank
+    per, solved = [], 0
+    devnull = open(os.devnull, "w")
+    for k, (a, b) in enumerate(mine):
+        a = np.array(a, dtype=np.float64).reshape(1, dof)
+        b = np.array(b, dtype=np.float64).reshape(1, dof)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out, sys.stdout = sys.stdout, devnull          # the reference prints "Starting training...." per call
+        try:
+            ok, traj = solve(env=env, start_joints=a, end_joints=b)
+        finally:
+            sys.stdout = out
+        torch.cuda.synchronize()
+        if k:
+            per.append(time.perf_counter() - t0)
+            solved += bool(ok)
+    batched(env, queries[:4])                                                # warm (allocations of the batch shapes)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = batched(env, queries)
+    torch.cuda.synchronize()
+    tb = time.perf_counter() - t0
+    tot = float(sum(per))
+    if dist is not None:
+        t = torch.tensor([tot, tb], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tot, tb = float(t[0]), float(t[1])
+    return {"plans_per_sec_measured": world * len(per) / tot,
+            "plans_per_sec_batched_measured": world * len(queries) / tb,
+            "plan_measurement": f"{len(per)} sequential solve_planning_problem() calls per rank after one warm-up call "
+                                f"({pp['num_steps']} steps, S={pp['num_samples']} M={pp['num_inducing']} T={pp['time_spacing_X']}, "
+                                f"150 posterior paths at {pp['time_spacing_Xnew']} time points, clearance check): "
+                                f"{1e3 * tot / len(per):.2f} ms per plan, {solved}/{len(per)} paths collision-free on rank 0; "
+                                f"solve_planning_problems_batched on all {len(queries)} industrial queries as one device batch: "
+                                f"{1e3 * tb:.1f} ms, {sum(int(r[0]) for r in res)}/{len(queries)} collision-free"}
+
+
+def timed_region(run_steps, args, dist, backend):
+    """W warm-up steps are done by the caller; here: barrier + synchronize, K steps (repeated until --min-seconds have passed,
+    every rank the same number of blocks), barrier + synchronize; MAX over ranks.  Returns (seconds per K-step block, blocks)."""
+    import numpy as np
+    import torch
 
     def barrier():
         if dist is not None:
@@ -138,32 +279,55 @@ def run_sample_sharded(args, world, rank, dist, backend, ps, spec, scene, planne
 
     barrier()
     t0 = time.perf_counter()
-    sp.run_steps(args.steps)
+    run_steps(args.steps)
     barrier()
     first = time.perf_counter() - t0
     reps = max(1, int(np.ceil(args.min_seconds / max(first, 1e-6)))) if args.min_seconds > 0 else 1
+    dev = "cuda" if backend == "nccl" else "cpu"
     if dist is not None:
-        r = torch.tensor([reps], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        r = torch.tensor([reps], dtype=torch.int64, device=dev)
         dist.broadcast(r, 0)
         reps = int(r[0])
     barrier()
     t0 = time.perf_counter()
     for _ in range(reps):
-        sp.run_steps(args.steps)
+        run_steps(args.steps)
     barrier()
     elapsed = (time.perf_counter() - t0) / reps
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
+    return elapsed, reps
+
+
+def run_sample_sharded(args, world, rank, dist, backend):
+    """BASELINE config 4: one problem, the sample axis split over the ranks; a step = local forward + reverse, ONE in-place
+    all-reduce of the contiguous [gradient | lik | kl] buffer, the replicated Adam update.  Strong scaling in S."""
+    import torch
+    from vgpmp_amd import sharding
+    ps, spec, grid, scene, planner = build_problem(rank, args, world)
+    planner.extra_flags |= args.flags
+    rccl = world > 1 and backend == "nccl"
+    comm = sharding.CapiComm(world, rank) if (args.collective == "capi" and (world == 1 or rccl)) else None
+    sp = sharding.SampleShardedPlanner(planner, comm=comm)
+    if world == 1 and comm is None:
+        sp._allreduce = lambda buf=None: None                 # nothing to exchange on one rank
+    sp.run_steps(args.warmup)
+    elapsed, reps = timed_region(sp.run_steps, args, dist, backend)
     assert args.allow_nan or torch.isfinite(planner.q_mu).all(), "optimisation diverged"
     times = planner.profile_steps(max(1, args.profile_steps))
     S_loc, N, D, P = planner.S, planner.N, spec.dof, spec.num_spheres
     t_sdf = times["loglik_kernel"] * 1e-3
     sdf_bytes = S_loc * N * (28 * P + 8 * D + 4)
+    line = None
     if rank == 0:
+        how = ("nothing (one rank)" if world == 1 and comm is None else
+               f"RCCL via the C ABI (vgpmp_allreduce_grads), {world} rank(s) in the communicator" if comm is not None else
+               f"torch.distributed ({backend}{' = RCCL' if backend == 'nccl' else ', host-staged: ranks share a device'}), "
+               f"{world} ranks in the group")
         line = {
-            "metric": "ELBO iters/sec + plans/sec, Franka-7DoF industrial S=128 M=30 T=100, 1/2/4/8 GPU",
+            "metric": "ELBO iters/sec, BASELINE config 4: UR10-6DoF industrial S=1024 M=18 T=70, samples sharded over the GPUs",
             "value": args.steps / elapsed, "unit": "ELBO iters/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "timed_blocks": reps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -171,126 +335,40 @@ def run_sample_sharded(args, world, rank, dist, backend, ps, spec, scene, planne
                                    f"ONE start-goal problem, S={args.samples} Monte-Carlo samples in total ({S_loc} on this rank), "
                                    f"M={planner.M} T={N} B={planner.B}",
                        "parallelism": f"samples sharded x{world}; per step one in-place all-reduce(sum) of "
-                                      f"{planner.reduce_buf.numel()} float64 (gradient + ELBO pieces) over "
-                                      + ("nothing (one rank)" if world == 1 and comm is None else
-                                         "RCCL via the C ABI (vgpmp_allreduce_grads)" if comm is not None else
-                                         f"torch.distributed ({backend}{' = RCCL' if backend == 'nccl' else ''})")
-                                      + ", then the replicated Adam update",
-                       "launch": "one vgpmp_elbo_step (forward + reverse) + one vgpmp_adam_step per step"},
+                                      f"{planner.reduce_buf.numel()} float64 (gradient + ELBO pieces) over {how}, "
+                                      "then the replicated Adam update",
+                       "collective_ranks": world if (comm is not None or world > 1) else 0,
+                       "launch": getattr(sp, "schedule", "one vgpmp_elbo_step (forward + reverse) + one vgpmp_adam_step per step")},
             "roofline": {"kernel": "likelihood of the local samples", "bound": "hbm", "achieved": sdf_bytes / t_sdf / 1e9,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sdf_bytes / t_sdf / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                          "algorithmic_bytes_per_launch": sdf_bytes, "avg_launch_ms": times["loglik_kernel"]},
             "stage_ms": {k: round(v, 5) for k, v in times.items()},
         }
-        print(json.dumps(line), flush=True)
     if comm is not None:
         comm.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    return line
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--samples", type=int, default=128)
-    ap.add_argument("--inducing", type=int, default=30)
-    ap.add_argument("--timesteps", type=int, default=100)
-    ap.add_argument("--problems", type=int, default=1, help="problems per GPU (config 2: 1)")
-    ap.add_argument("--grid", type=int, default=128, help="SDF voxels per axis (synthetic scenes)")
-    ap.add_argument("--split-k", type=int, default=0, help="K-slices of the prior GEMM (0 = engine default)")
-    ap.add_argument("--no-fuse", action="store_true", help="one launch per kernel even for small batches (measurement)")
-    ap.add_argument("--scene", choices=("industrial", "synthetic"), default="industrial",
-                    help="industrial = SDF generated from the reference's industrial collision mesh; synthetic = boxes/spheres")
-    ap.add_argument("--unroll", type=int, default=0,
-                    help="steps per captured hipGraph; 0 = plain launches (measured 2-3 %% faster than graph replay here)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-steps", type=int, default=40)
-    ap.add_argument("--allow-nan", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--traffic-file", default="", help="pmc traffic table (tools/pmc_aggregate.py) for roofline.traffic")
-    ap.add_argument("--shard", choices=("problems", "samples"), default="problems",
-                    help="problems: independent problems per GPU, no collective (config 2 / 5); samples: BASELINE config 4, "
-                         "UR10, one problem, --samples (1024) Monte-Carlo samples split over the ranks, one all-reduce per step")
-    ap.add_argument("--collective", choices=("torch", "capi"), default="torch",
-                    help="samples sharding: torch.distributed all_reduce (RCCL) or the C ABI's vgpmp_allreduce_grads (RCCL)")
-    ap.add_argument("--layout", choices=("brick", "linear"), default="brick", help="voxel table layout (include/vgpmp.h)")
-    ap.add_argument("--summary", choices=("auto", "on", "off"), default="auto",
-                    help="free-space brick summary in the batch likelihood kernel (auto: tables beyond the Infinity Cache)")
-    ap.add_argument("--lik-form", choices=("auto", "lanes", "lanes-lds"), default="auto",
-                    help="likelihood kernel form (measurement): lanes = the batch form at any batch size, lanes-lds = with its per-frame sums in LDS")
-    ap.add_argument("--flags", type=int, default=0, help="extra VGPMP_* measurement flags (include/vgpmp.h) OR-ed into every step")
-    ap.add_argument("--min-seconds", type=float, default=0.5,
-                    help="the timed region repeats the K steps until this much time has passed (K = --steps alone is ~1 ms)")
-    ap.add_argument("--workload", choices=("config2", "stress"), default="config2",
-                    help="config2 = the benchmark line; stress = BASELINE config 5 per-GPU share (use --problems 64 --grid 512)")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    backend = os.environ.get("VGPMP_DIST_BACKEND", "nccl")      # "gloo": rehearsal of the N > 1 path on a 1-GPU box
-    if world > 1:
-        import torch.distributed as dist
-        dev = local % torch.cuda.device_count()
-        torch.cuda.set_device(dev)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group(backend)
-    else:
-        torch.cuda.set_device(0)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-
-    if args.shard == "samples" and args.samples == 128:
-        args.samples = 1024                                  # BASELINE config 4
-    ps, spec, grid, scene, planner = build_problem(rank, args)
+def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
+    """Independent problems per GPU (configs 2, 3, 5): no data-path collective, weak scaling."""
+    import numpy as np
+    import torch
     from vgpmp_amd import capi
+    ps, spec, grid, scene, planner = build_problem(rank, args, world)
     planner.extra_flags |= {"auto": 0, "lanes": capi.LIK_LANES, "lanes-lds": capi.LIK_LDS_STATE}[args.lik_form] | args.flags
-    if args.shard == "samples":
-        return run_sample_sharded(args, world, rank, dist, backend, ps, spec, scene, planner)
     for _ in range(args.warmup):
         planner.step()
     if args.unroll > 0:
         planner.capture(args.unroll)
     torch.cuda.synchronize()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # K steps are ~1 ms of device time at one problem: repeat the K-step block (same call, same schedule) until
-    # --min-seconds have passed, so that the figure does not hang on one host-side hiccup.  Every rank runs the same
-    # number of blocks (rank 0 decides), ms_per_step is over all of them.
-    barrier()
-    t0 = time.perf_counter()
-    planner.run_steps(args.steps)
-    barrier()
-    first = time.perf_counter() - t0
-    reps = max(1, int(np.ceil(args.min_seconds / max(first, 1e-6)))) if args.min_seconds > 0 else 1
-    if dist is not None:
-        r = torch.tensor([reps], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
-        dist.broadcast(r, 0)
-        reps = int(r[0])
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        planner.run_steps(args.steps)
-    barrier()
-    elapsed = (time.perf_counter() - t0) / reps
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    elapsed, reps = timed_region(planner.run_steps, args, dist, backend)
     assert args.allow_nan or torch.isfinite(planner.q_mu).all(), "optimisation diverged"
+    pp = ps.planner_params
 
     # ---- one plan = num_steps optimisation steps + 150 posterior paths + best-sample pick (models/vgpmp.py:312-339)
     t_sample = None
-    if args.workload == "config2":
-        n_new = int(ps.planner_params["time_spacing_Xnew"])
+    if args.workload in ("config2", "config3"):
+        n_new = int(pp["time_spacing_Xnew"])
         Xnew = np.tile(np.linspace(0.0, 1.0, n_new)[:, None], (1, spec.dof))
         planner.sample_from_posterior(150, Xnew)            # warm (allocations)
         torch.cuda.synchronize()
@@ -322,10 +400,20 @@ def main():
                           "free_space_summary": bool(scene.free_space_summary)},
                 "timing": "HIP events stamped with the kernel's start and end on its stream (hipExtLaunchKernel), "
                           f"mean of {max(1, args.profile_steps)} launches"}
-    gemm_kernel = ("prior_gemm_tiled_kernel<1>" if planner.dims.split_k == 1 else
-                   "prior_gemm_lds_kernel" if (1024 // planner.dims.split_k) % 128 == 0 and S >= 48 else
-                   "prior_fused_small_kernel" if planner.dims.split_k == 4 and S <= 32 else "prior_gemm_kernel<0>")
-    roof_gemm = {"kernel": gemm_kernel, "bound": "mfma", "achieved": gemm_flops / t_gemm / 1e12,
+    # the kernel that forms the prior draws in the pass the events come from (one launch per kernel, device-drawn noise);
+    # same selection as vg_elbo_steps (csrc/gp_path.hip)
+    sk = planner.dims.split_k
+    if sk == 1:
+        gemm_kernel = "prior_fused_batch_kernel"
+        gemm_note = ("W and the features are formed inside the GEMM; the same kernel runs in the timed schedule from 28 problems "
+                     "of this shape up (below that the tiled GEMM shares a launch with the covariance stage)")
+    elif sk == 4 and S <= 32:
+        gemm_kernel, gemm_note = "prior_fused_small_kernel", "few samples: features formed inside the GEMM, four K-slices"
+    elif (1024 // sk) % 128 == 0 and S >= 48:
+        gemm_kernel, gemm_note = "prior_gemm_lds_kernel", "a role of stage2_kernel in the timed schedule; timed alone here"
+    else:
+        gemm_kernel, gemm_note = "prior_gemm_kernel<0>", "a role of stage2_kernel in the timed schedule; timed alone here"
+    roof_gemm = {"kernel": gemm_kernel, "note": gemm_note, "bound": "mfma", "achieved": gemm_flops / t_gemm / 1e12,
                  "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_flops / t_gemm / 1e12 / F32_MFMA_PEAK_TFLOPS,
                  "traffic": None, "algorithmic_flops_per_launch": gemm_flops, "avg_launch_ms": kernel_ms["prior_gemm_kernel"]}
     dominant = max(stage_ms, key=stage_ms.get)
@@ -338,44 +426,96 @@ def main():
             roof_sdf["traffic"] = t.get(lik_kernel, {}).get("hbm_bytes_per_launch")
             roof_sdf["traffic_source"] = t.get("source")
             roof_sdf["traffic_collected_at"] = t.get("collected_at")
-            roof_gemm["traffic"] = t.get(gemm_kernel, {}).get("hbm_bytes_per_launch")
+            key = next((k for k in t if k.startswith(gemm_kernel.split("<")[0])), None)
+            roof_gemm["traffic"] = t[key].get("hbm_bytes_per_launch") if key else None
         except Exception:
             pass
 
+    names = {"config2": "BASELINE config 2: Franka 7-DoF, industrial scene",
+             "config3": "BASELINE config 3: Franka 7-DoF, bookshelves scene, the full C(11,2) start-goal batch",
+             "stress": "BASELINE config 5 per-GPU share: synthetic 14-DoF arm"}
+    line = {
+        "metric": METRIC,
+        "value": world * npb * args.steps / elapsed, "unit": "ELBO iters/sec", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "timed_blocks": reps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": names[args.workload] + ", SDF " + "x".join(str(v) for v in scene.shape)
+                               + (" from the reference's collision mesh" if args.workload != "stress" and args.scene != "synthetic"
+                                  else " synthetic boxes/spheres")
+                               + f", {npb} start-goal problem(s) per GPU, S={S} M={M} T={N} B={B}, "
+                               "q_mu/q_sqrt/lengthscales/kernel_variance trainable",
+                   "parallelism": f"problems sharded x{world}, no collective",
+                   "launch": (f"hipGraph x{args.unroll} steps" if args.unroll else "plain launches")
+                             + ("; independent kernels of a step share launches (stage1/2/3_kernel), the prior GEMM is a"
+                                " role of stage2_kernel there and is timed alone for roofline_secondary"
+                                if planner.fuse and npb * D <= 32 else "")},
+        "plans_per_sec": (world * npb / (float(pp["num_steps"]) * elapsed / args.steps + t_sample)
+                          if t_sample is not None else None),
+        "plan_definition": (f"computed: {pp['num_steps']} optimisation steps at the timed rate + 150 posterior paths at "
+                            f"{pp['time_spacing_Xnew']} time points + best-sample pick (sampling measured: {1e3 * t_sample:.2f} ms "
+                            f"for the batch); plans_per_sec_measured is the timed solve_planning_problem() figure")
+                           if t_sample is not None else None,
+        "roofline": roof_sdf, "roofline_secondary": roof_gemm,
+        "dominant_stage": dominant, "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+        "stage_ms_schedule": "separate pass after the timed region with ONE launch per kernel and a HIP event around every stage "
+                             "(vgpmp_elbo_step_profiled); at 4 problems or fewer the timed region runs the shared stage launches "
+                             "instead, so stage_ms / dominant_stage describe that pass, not the timed schedule; the two "
+                             "roofline kernels are timed by their own start / end events in the same pass",
+    }
+    del planner, scene
+    torch.cuda.empty_cache()
+    if want_extras and args.workload == "config2" and not args.no_solve:
+        line.update(measured_solves(args, world, rank, dist, backend))
+    if want_extras and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(ps, spec, grid, args)
+        line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+    return line if rank == 0 else None
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no external launcher: start the ranks as fresh child interpreters BEFORE this process touches the GPU
+        # (torch.cuda.device_count() does not initialise it) and relay rank 0's line
+        import torch
+        from vgpmp_amd import launch
+        sys.exit(launch.spawn_ranks(args.gpus, sys.argv[1:], script=os.path.abspath(__file__),
+                                    devices=torch.cuda.device_count()))
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    backend = os.environ.get("VGPMP_DIST_BACKEND", "nccl")      # "gloo": rehearsal of the N > 1 path on a 1-GPU box
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world > 1:
+        import torch.distributed as dist
+        dev = local % torch.cuda.device_count()
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
+    else:
+        torch.cuda.set_device(0)
+    default_workload = args.workload == "config2" and args.shard == "problems" and not args.problems
+    resolve(args)
+    if args.shard == "samples":
+        line = run_sample_sharded(args, world, rank, dist, backend)
+    else:
+        line = run_problem_sharded(args, world, rank, dist, backend)
+        if args.also_stress == "on" or (args.also_stress == "auto" and world > 1 and default_workload):
+            # the 512-problem batch of the north star, this GPU's 64: same ranks, same barriers, appended to the line
+            a2 = resolve(parse_args(["--workload", "stress", "--gpus", str(world), "--steps", "10", "--warmup", "3",
+                                     "--profile-steps", "5", "--min-seconds", "1"]))
+            l2 = run_problem_sharded(a2, world, rank, dist, backend, want_extras=False)
+            if rank == 0:
+                line["batch_512"] = {k: l2[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "timed_blocks", "scaling",
+                                                        "config", "roofline", "roofline_secondary", "stage_ms")}
+                line["batch_512"]["problems_total"] = world * a2.problems
     if rank == 0:
-        line = {
-            "metric": "ELBO iters/sec + plans/sec, Franka-7DoF industrial S=128 M=30 T=100, 1/2/4/8 GPU",
-            "value": world * npb * args.steps / elapsed, "unit": "ELBO iters/sec", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "timed_blocks": reps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": ("BASELINE config 2: Franka 7-DoF, industrial scene" if args.workload == "config2"
-                                    else "BASELINE config 5 per-GPU share: synthetic 14-DoF arm") + ", SDF "
-                                   + "x".join(str(v) for v in scene.shape) + (" from the industrial collision mesh"
-                                   if args.workload == "config2" and args.scene == "industrial" else " synthetic boxes/spheres")
-                                   + f", {npb} start-goal problem(s) per GPU, S={S} M={M} T={N} B={B}, "
-                                   "q_mu/q_sqrt/lengthscales/kernel_variance trainable",
-                       "parallelism": f"problems sharded x{world}, no collective",
-                       "launch": (f"hipGraph x{args.unroll} steps" if args.unroll else "plain launches")
-                                 + ("; independent kernels of a step share launches (stage1/2/3_kernel), the prior GEMM is a"
-                                    " role of stage2_kernel there and is timed alone for roofline_secondary"
-                                    if planner.fuse and npb * D <= 64 else "")},
-            "plans_per_sec": (world * npb / (float(ps.planner_params["num_steps"]) * elapsed / args.steps + t_sample)
-                              if t_sample is not None else None),
-            "plan_definition": f"{ps.planner_params['num_steps']} optimisation steps + 150 posterior paths at "
-                               f"{ps.planner_params['time_spacing_Xnew']} time points + best-sample pick "
-                               f"(sampling measured: {1e3 * t_sample:.2f} ms)" if t_sample is not None else None,
-            "roofline": roof_sdf, "roofline_secondary": roof_gemm,
-            "dominant_stage": dominant, "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
-            "stage_ms_schedule": "separate pass after the timed region with ONE launch per kernel and a HIP event around every stage "
-                                 "(vgpmp_elbo_step_profiled); at 4 problems or fewer the timed region runs the shared stage launches "
-                                 "instead, so stage_ms / dominant_stage describe that pass, not the timed schedule; the two "
-                                 "roofline kernels are timed by their own start / end events in the same pass",
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(ps, spec, grid, args)
-            line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

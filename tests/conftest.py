@@ -36,6 +36,13 @@ def pytest_sessionstart(session):
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"), str(r), "2", str(port), out],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     session.config._shard_workers = (procs, out)
+    # bench.py --gpus 2 with NO external launcher: it starts its two ranks itself; also started here,
+    # before this process touches the GPU.  The two ranks share the box's one GPU and rendezvous over gloo.
+    log = open(os.path.join(out, "bench_gpus2.out"), "w")
+    err = open(os.path.join(out, "bench_gpus2.err"), "w")
+    bench = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shard", "samples", "--steps", "5",
+                              "--warmup", "2", "--min-seconds", "0", "--profile-steps", "1"], env=env, stdout=log, stderr=err)
+    session.config._bench_gpus2 = (bench, out)
 
 
 def pytest_sessionfinish(session, exitstatus):
@@ -44,6 +51,13 @@ def pytest_sessionfinish(session, exitstatus):
         for p in w[0]:
             if p.poll() is None:
                 p.kill()
+    b = getattr(session.config, "_bench_gpus2", None)
+    if b and b[0].poll() is None:
+        b[0].terminate()
+        try:
+            b[0].wait(timeout=5)
+        except subprocess.TimeoutExpired:
+            b[0].kill()
 
 
 @pytest.fixture(scope="session")
@@ -63,3 +77,21 @@ def shard_workers(request):
         logs.append(o.decode(errors="replace"))
         assert p.returncode == 0, logs[-1][-3000:]
     return out, logs
+
+
+@pytest.fixture(scope="session")
+def bench_gpus2(request):
+    """(stdout, stderr) of `python bench.py --gpus 2 --shard samples ...` started at session start without a launcher."""
+    b = getattr(request.config, "_bench_gpus2", None)
+    if not b:
+        pytest.skip("only started by `-m gpu` runs on a GPU box")
+    proc, out = b
+    try:
+        proc.wait(timeout=900)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.wait()
+    so = open(os.path.join(out, "bench_gpus2.out")).read()
+    se = open(os.path.join(out, "bench_gpus2.err")).read()
+    assert proc.returncode == 0, se[-3000:]
+    return so, se

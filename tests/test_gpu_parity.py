@@ -479,3 +479,118 @@ def test_inducing_location_adam_trajectory_matches_oracle():
     for x, y in ((a.raw_Z, b.raw_Z), (a.q_mu, b.q_mu), (a.raw_ell, b.raw_ell), (a.z_adam_v, b.z_adam_v)):
         assert torch.equal(x, y)
     assert float((a.raw_Z - torch.tensor(orc.init_raw_Z(M, 7), device=a.raw_Z.device)).abs().max()) > 0
+
+
+def _compare_with_oracle(pl, k, p, scene, X, Zy, y, noise, alpha, S, N, M, L, split_k, lik_scale=1.0, kl_scale=1.0):
+    """Problem k of the batch `pl` against the oracle, with the tolerances of test_elbo_forward_backward_against_oracle.
+    lik_scale / kl_scale: a rank's share of a sharded sample axis (S local of S_total samples, KL on rank 0 only)."""
+    Mz, J = M + 2, N + M + 2
+    fw = orc.elbo_forward(p, scene, X, Zy, y, noise, alpha * lik_scale)
+    og, _ = orc.elbo_backward(p, scene, X, Zy, noise, alpha * lik_scale, fw)
+    if kl_scale != 1.0:
+        fw0 = orc.elbo_forward(p, scene, X, Zy, y, noise, 0.0)
+        g0, _ = orc.elbo_backward(p, scene, X, Zy, noise, 0.0, fw0)            # the KL's own gradient
+        for name in ("q_mu", "q_sqrt", "raw_ell", "raw_var"):
+            setattr(og, name, getattr(og, name) - (1.0 - kl_scale) * getattr(g0, name))
+    cv = fw["cv"]
+    A4 = pl.view("A4").reshape(pl.P, L, N, Mz, 4)[k].cpu().numpy()
+    np.testing.assert_allclose(A4[..., 0], cv["A"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(pl.view("C").reshape(pl.P, L, Mz, Mz)[k].cpu().numpy(), cv["C"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(pl.view("kl_l").reshape(pl.P, -1)[k].cpu().numpy().sum(), cv["kl"], rtol=1e-9)
+    F0 = pl.view("F0").reshape(split_k, pl.P, S, L, J).sum(0)[k].cpu().numpy()
+    np.testing.assert_allclose(F0, fw["F0"], rtol=0, atol=2e-5 * np.abs(fw["F0"]).max())
+    H = pl.view("H").reshape(split_k, pl.P, S, L, J).sum(0)[k].cpu().numpy()
+    np.testing.assert_allclose(H, fw["H"], rtol=0, atol=2e-5 * (np.abs(fw["H"]).max() + 1e-9))
+    np.testing.assert_allclose(pl.view("R").reshape(pl.P, S, L, Mz)[k].cpu().numpy(), fw["R"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(pl.f[k].cpu().numpy(), fw["f"], rtol=0, atol=1e-4)
+    logp = pl.logp[k].cpu().numpy()
+    ok = np.isclose(logp, fw["logp"], rtol=2e-3, atol=1e-4)
+    assert ok.mean() >= 0.97, f"logp agreement {ok.mean():.3f}"
+    flips = 1.0 - ok.mean()
+    np.testing.assert_allclose(float(pl.kl[k]), kl_scale * cv["kl"], rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(float(pl.lik[k]), fw["lik"], rtol=50 * flips + 2e-4)
+    for got, name in zip(pl.grad, ("q_mu", "q_sqrt", "raw_ell", "raw_var")):
+        want = getattr(og, name)
+        got = got[k].cpu().numpy()
+        if name == "q_mu":
+            got = got.T
+        scale = np.abs(want).max() + 1e-12
+        assert np.abs(got - want).max() / scale < 50 * flips + 3e-3, (name, k, np.abs(got - want).max(), scale, flips)
+    return fw
+
+
+@pytest.mark.parametrize("config", ["config1", "config3", "config4"])
+def test_baseline_configs_at_full_size_against_oracle(config):
+    """BASELINE configs 1, 3 and 4 at their FULL (S, M, N, B = 1024) against the oracle, not only
+    through size-independent properties.  config1 = WAM / industrial, S=50 M=10 N=70 (data/problemsets/wam.py:93-106);
+    config3 = Franka / bookshelves, S=7 M=24 N=70 with 8 of the 55 start-goal pairs in ONE batch, so the few-sample prior
+    kernel and the batch schedule run at batch size (data/problemsets/franka.py:91-104); config4 = one rank's share of UR10 /
+    industrial: S=128 of 1024 samples at sample_offset 256, KL owned by another rank (data/problemsets/ur10.py:71-84)."""
+    robot, problem, S, M, N, P, extra = {
+        "config1": ("wam", "industrial", 50, 10, 70, 1, {}),
+        "config3": ("franka", "bookshelves", 7, 24, 70, 8, {}),
+        "config4": ("ur10", "industrial", 128, 18, 70, 1, dict(samples_total=1024, sample_offset=256, kl_scale=0.0)),
+    }[config]
+    B = 1024
+    ps = rb.load_problemset(robot, problem)
+    spec = rb.load_robot(robot, *ps.robot_pos_and_orn)
+    pp = ps.planner_params
+    grid = scenes.synthetic_boxes_sdf(n=64, delta=2.4 / 64, origin=(-1.2, -1.2, -0.6), seed=3)
+    off = ps.object_positions[0]
+    sc = _engine().DeviceScene(spec, grid, off, sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"])
+    osc = oracle_scene(spec, grid, off, sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"])
+    L = spec.dof
+    step = max(1, len(ps.queries) // P)
+    qs = np.array([ps.queries[(i * step) % len(ps.queries)] for i in range(P)], dtype=np.float64)
+    pl = _engine().PlannerBatch(sc, qs, num_samples=S, num_inducing=M, num_data=N, num_bases=B,
+                                lengthscales=pp["lengthscales"], variance=pp["variance"], alpha=pp["alpha"],
+                                learning_rate=pp["learning_rate"], **extra)
+    split_k = pl.dims.split_k
+    rng = np.random.default_rng(21)
+    X, Zy = orc.init_trainset(N, L), orc.inducing_Zy(M, L)
+    params, noises = [], []
+    for k in range(P):
+        p = orc.init_params(osc.robot, qs[k], M, pp["lengthscales"], max(pp["variance"], 0.1 + 1e-6))
+        p.q_sqrt = np.tril(p.q_sqrt + 0.05 * rng.standard_normal(p.q_sqrt.shape))
+        p.q_mu = p.q_mu + 0.05 * rng.standard_normal(p.q_mu.shape)
+        params.append(p)
+        noises.append(_noise32(orc.draw_noise(rng, S, L, L, B, M + 2)))
+        pl.q_mu[k].copy_(torch.tensor(p.q_mu.T)); pl.q_sqrt[k].copy_(torch.tensor(p.q_sqrt))
+        pl.raw_ell[k].copy_(torch.tensor(p.raw_ell)); pl.raw_var[k].copy_(torch.tensor(p.raw_var))
+    st = lambda name: np.stack([getattr(nz, name) for nz in noises])
+    pl.set_noise(st("omega"), st("beta"), st("w"), st("eps"), st("eps2"))
+    pl.loss_and_grad(generate=False)
+    torch.cuda.synchronize()
+    lik_scale = S / float(extra.get("samples_total", S))
+    active = False
+    for k in range(P):
+        fw = _compare_with_oracle(pl, k, params[k], osc, X, Zy, qs[k], noises[k], float(pp["alpha"]), S, N, M, L, split_k,
+                                  lik_scale=lik_scale, kl_scale=float(extra.get("kl_scale", 1.0)))
+        active = active or bool((fw["logp"] < 0).any())
+    assert active, "the scene must put spheres inside the hinge band for at least one problem"
+
+
+def test_adam_update_arithmetic_is_float64_exact():
+    """with alpha = 0 the whole optimisation step is float64 on the device (covariance path, KL, its
+    reverse, the update), so a five-step trajectory pins Keras' Adam(lr, 0.8, 0.95, epsilon 1e-7) of models/vgpmp.py:77
+    exactly -- moment recursion, bias correction and the place of epsilon (outside the square root): 1e-9, where the
+    float32 trajectories above can only afford steps * lr * 2e-2."""
+    S, N, M, B = 4, 9, 7, 32
+    pb = small_problem(robot="franka", S=S, N=N, M=M, B=B, seed=5, n_grid=24)
+    sc = _scene(pb["spec"], pb["grid"], pb["offset"])
+    pl = _planner(dict(pb, alpha=0.0), sc, S, N, M, B, split_k=1)
+    p = pb["params"].copy(); st = orc.adam_init(p)
+    p0 = pb["params"].copy()
+    rng = np.random.default_rng(8)
+    for step in range(5):
+        noise = _noise32(orc.draw_noise(rng, S, 7, 7, B, M + 2))
+        _inject(pl, noise)
+        pl.step(generate=False)
+        orc.optimization_step(p, st, pb["scene"], pb["X"], pb["Zy"], pb["y"], noise, 0.0, pb["lr"])
+    for got, want, start in ((pl.q_mu[0].cpu().numpy().T, p.q_mu, p0.q_mu), (pl.q_sqrt[0].cpu().numpy(), p.q_sqrt, p0.q_sqrt),
+                             (pl.raw_ell[0].cpu().numpy(), p.raw_ell, p0.raw_ell), (pl.raw_var[0].cpu().numpy(), p.raw_var, p0.raw_var)):
+        assert np.abs(want - start).max() > pb["lr"], "the variable must have moved"
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
+    # the moments themselves (float64 state)
+    np.testing.assert_allclose(pl.adam_m[0][0].cpu().numpy().T, st.m.q_mu, rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(pl.adam_v[1][0].cpu().numpy(), st.v.q_sqrt, rtol=1e-7, atol=1e-14)

@@ -50,3 +50,17 @@ def test_capi_communicator_single_rank_is_identity():
     torch.cuda.synchronize()
     assert torch.equal(buf, want)
     comm.close()
+
+
+def test_bench_starts_its_own_ranks(bench_gpus2):
+    """`python bench.py --gpus 2 --shard samples` with no external launcher: bench.py starts two fresh
+    rank processes before touching the GPU, they rendezvous on 127.0.0.1 (gloo: both ranks share this box's one GPU), run
+    the sample-sharded step with one all-reduce per step, and rank 0's ONE JSON line comes back on stdout."""
+    import json
+    so, se = bench_gpus2
+    lines = [l for l in so.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (so[-2000:], se[-2000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 5
+    assert d["config"]["collective_ranks"] == 2 and "512 on this rank" in d["config"]["workload"]
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0

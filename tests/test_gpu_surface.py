@@ -112,6 +112,33 @@ def test_model_surface_against_oracle():
     assert np.isfinite(best).all()
 
 
+def test_trained_inducing_locations_survive_a_change_of_time_stamps():
+    """VGPMP._ensure rebuilds the device batch when the number of time stamps changes; the trained inducing
+    locations (raw_Z), their Adam moments and the step count must move over with the other variables (the reference's
+    variables do not depend on the data, models/vgpmp.py:29-42), and trainable_variables lists raw_Z."""
+    from gpflow_vgpmp.models.vgpmp import VGPMP
+    from gpflow_vgpmp.utils.miscellaneous import training_loop, disable_param_opt
+    env = _env()
+    ps = rb.load_problemset("franka", "industrial")
+    y = np.array([ps.states[0], ps.states[1]])
+    pp = dict(ps.planner_params, num_samples=8, num_inducing=6, num_bases=64)
+    model = VGPMP.initialize(sdf=env.sdf, robot=env.robot, sampler=env.sampler, query_states=y,
+                             scene_offset=env.scene.position, **pp)
+    disable_param_opt(model, dict(env.config["trainable_params"], inducing_variable=True))
+    training_loop(model, orc.init_trainset(12, 7), 8)
+    old = model._planner
+    assert old.z_variables and len(model.trainable_variables) == 5 and model.trainable_variables[-1] is old.raw_Z
+    z_trained = old.inducing_locations().clone()
+    assert float((z_trained[0, :, 0].cpu() - torch.linspace(0.1, 0.9, 6, dtype=torch.float64)).abs().max()) > 1e-3
+    m, v, t = old.z_adam_m.clone(), old.z_adam_v.clone(), old.t
+    assert np.isfinite(model.elbo(orc.init_trainset(15, 7)))            # another N: the batch is rebuilt
+    new = model._planner
+    assert new is not old and new.N == 15 and new.t == t
+    assert torch.equal(new.inducing_locations(), z_trained)
+    assert torch.equal(new.z_adam_m, m) and torch.equal(new.z_adam_v, v) and float(v.abs().max()) > 0
+    assert torch.equal(new.q_mu, old.q_mu) and torch.equal(new.raw_ell, old.raw_ell)
+
+
 def test_sample_sharding_two_ranks_equal_full_batch():
     """Two emulated ranks (sample_offset 0 / 8, KL on rank 0) sum to the 16-sample gradient: the device
     generator hands each rank its slice of the same global Philox sample stream."""

@@ -1,0 +1,91 @@
+"""bench.py's own rank launcher (vgpmp_amd/launch.py) and the evidence files bench.py reads -- CPU only."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+from vgpmp_amd import launch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _script(tmp_path, body):
+    path = tmp_path / "child.py"
+    path.write_text(textwrap.dedent(body))
+    return str(path)
+
+
+def test_spawn_ranks_sets_the_rendezvous_environment_and_relays_rank0(tmp_path):
+    out = tmp_path / "out"
+    out.mkdir()
+    script = _script(tmp_path, """
+        import json, os, sys
+        keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY", "VGPMP_DIST_BACKEND")
+        rec = {k: os.environ.get(k) for k in keys}
+        rec["argv"] = sys.argv[1:]
+        open(os.path.join(sys.argv[1], "rank%s.json" % os.environ["RANK"]), "w").write(json.dumps(rec))
+        print("line from rank", os.environ["RANK"])
+    """)
+    code = ("import sys; sys.path.insert(0, %r); from vgpmp_amd import launch; "
+            "sys.exit(launch.spawn_ranks(3, [%r, '--x', '1'], script=%r, devices=1))" % (ROOT, str(out), script))
+    env = {k: v for k, v in os.environ.items() if k != "VGPMP_DIST_BACKEND"}
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert res.returncode == 0, res.stderr
+    assert res.stdout.strip() == "line from rank 0"                      # only rank 0 reaches the parent's stdout
+    assert "line from rank 1" in res.stderr and "line from rank 2" in res.stderr
+    recs = [json.load(open(out / f"rank{r}.json")) for r in range(3)]
+    assert [r["RANK"] for r in recs] == ["0", "1", "2"] and all(r["WORLD_SIZE"] == "3" for r in recs)
+    assert all(r["MASTER_ADDR"] == "127.0.0.1" and r["MASTER_PORT"] == recs[0]["MASTER_PORT"] for r in recs)
+    assert all(r["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for r in recs)
+    assert all(r["VGPMP_DIST_BACKEND"] == "gloo" for r in recs)          # fewer devices than ranks: the rehearsal backend
+    assert recs[1]["argv"] == [str(out), "--x", "1"]
+
+
+def test_spawn_ranks_reports_a_failed_rank_and_ends_the_others(tmp_path):
+    script = _script(tmp_path, """
+        import os, sys, time
+        if os.environ["RANK"] == "1":
+            sys.exit(7)
+        time.sleep(60)
+    """)
+    rc = launch.spawn_ranks(2, [], script=script, devices=8, timeout_s=50)
+    assert rc == 7
+    env = launch.rank_env(0, 2, 1234, base={}, devices=8)
+    assert "VGPMP_DIST_BACKEND" not in env                               # enough devices: RCCL ("nccl")
+
+
+def test_bench_gloo_world2_rendezvous_of_the_timed_region(tmp_path):
+    """The barrier / repeat-count broadcast / MAX-over-ranks plumbing of bench.py's timed region with two gloo ranks on
+    the CPU (the kernels replaced by a sleep): every rank runs the same number of blocks, the slowest rank sets the time."""
+    script = _script(tmp_path, """
+        import argparse, json, os, sys, time
+        sys.path.insert(0, %r)
+        import torch, torch.distributed as dist
+        import bench
+        torch.cuda.synchronize = lambda *a, **k: None
+        dist.init_process_group("gloo")
+        rank = dist.get_rank()
+        calls = []
+        def run_steps(k):
+            calls.append(k)
+            time.sleep(0.01 * (1 + 2 * rank))
+        args = argparse.Namespace(steps=5, min_seconds=0.1)
+        elapsed, reps = bench.timed_region(run_steps, args, dist, "gloo")
+        json.dump({"elapsed": elapsed, "reps": reps, "calls": len(calls)}, open(os.path.join(sys.argv[1], "r%%d.json" %% rank), "w"))
+        dist.barrier(); dist.destroy_process_group()
+    """ % ROOT)
+    assert launch.spawn_ranks(2, [str(tmp_path)], script=script, devices=0, timeout_s=120) == 0
+    r0, r1 = (json.load(open(tmp_path / f"r{r}.json")) for r in range(2))
+    assert r0["reps"] == r1["reps"] and r0["calls"] == r1["calls"] == r0["reps"] + 1
+    assert abs(r0["elapsed"] - r1["elapsed"]) < 1e-12 and r0["elapsed"] >= 0.03       # MAX over ranks: rank 1 sleeps 30 ms
+
+
+def test_committed_traffic_table_is_this_rounds():
+    """profiles/pmc_traffic.json (read by bench.py for roofline.traffic) must be a table produced by
+    tools/pmc_aggregate.py with its commit stamp, not the round-1 file (which listed rocBLAS / ATen kernels)."""
+    t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert t.get("collected_at", "").startswith("commit "), t.get("collected_at")
+    assert not any(k.startswith("Cijk_") or "at::native::sigmoid" in k for k in t)
+    lik = [k for k in t if k.startswith("loglik_paths_wide_kernel")]
+    assert lik and all(t[k]["hbm_bytes_per_launch"] > 0 for k in lik)

@@ -1,36 +1,54 @@
 #!/bin/bash
-# Evidence for profiles/r02 (run on the GPU box from the repo root; tools/run_collect.sh wraps it with the commit stamp):
+# Evidence for profiles/<round> (run on the GPU box from the repo root; tools/run_collect.sh wraps it with the commit stamp):
 # bench lines, rocprofv3 kernel statistics of the same commands, FETCH_SIZE / WRITE_SIZE passes, SQ / MFMA counter passes.
 # Every profiler run sits under `timeout`; the program stands directly behind `--`.
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-out=gpurun_out/r02final; rm -rf $out; mkdir -p $out
+set -uo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}"
+round=${ROUND:-r03}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/${round}final; rm -rf "$out"; mkdir -p "$out"
 stats() {   # stats <tag> <bench args...>: bench line under the kernel trace + the kernel statistics table
   local tag=$1; shift
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$tag.d -- python3 bench.py "$@" > $out/${tag}_bench_under_rocprof.json 2> $out/$tag.err
-  cp $(ls $out/$tag.d/*/*kernel_stats.csv | head -1) $out/${tag}_kernel_stats.csv; rm -rf $out/$tag.d
+  if timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$tag.d -- python3 bench.py "$@" > $out/${tag}_bench_under_rocprof.json 2> $out/$tag.err; then
+    local f; f=$(ls $out/$tag.d/*/*kernel_stats.csv 2>/dev/null | head -1)
+    if [ -n "$f" ]; then cp "$f" $out/${tag}_kernel_stats.csv; else echo "no kernel_stats for $tag" >&2; fi
+  else echo "rocprofv3 stats run failed for $tag" >&2; fi
+  rm -rf $out/$tag.d
 }
 pmc() {     # pmc <tag> <bench args...>: FETCH_SIZE and WRITE_SIZE in separate passes -> per-kernel KB and bytes per launch
   local tag=$1; shift
+  local ok=1
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_$c -- python3 bench.py "$@" --min-seconds 0 --profile-steps 2 > /dev/null 2> $out/${tag}_$c.err
+    timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_$c -- python3 bench.py "$@" --min-seconds 0 --profile-steps 2 > /dev/null 2> $out/${tag}_$c.err || ok=0
   done
-  python tools/pmc_aggregate.py $out/${tag}_FETCH_SIZE $out/${tag}_WRITE_SIZE $out/${tag}_pmc_fetch_write_kb.json $out/${tag}_pmc_traffic.json > /dev/null
+  if [ $ok = 1 ]; then python tools/pmc_aggregate.py $out/${tag}_FETCH_SIZE $out/${tag}_WRITE_SIZE $out/${tag}_pmc_fetch_write_kb.json $out/${tag}_pmc_traffic.json > /dev/null
+  else echo "pmc pass failed for $tag" >&2; fi
   rm -rf $out/${tag}_FETCH_SIZE $out/${tag}_WRITE_SIZE
 }
+Q="--no-cpu-baseline --no-solve"
 # ---- config 2 (the benchmark line): one problem per GPU
-pmc config2 --steps 40 --warmup 5 --no-cpu-baseline
-cp $out/config2_pmc_traffic.json profiles/pmc_traffic.json
+pmc config2 --steps 40 --warmup 5 $Q
+if [ -f $out/config2_pmc_traffic.json ]; then cp $out/config2_pmc_traffic.json profiles/pmc_traffic.json; fi
 python bench.py > $out/config2_bench.json 2> $out/config2_bench.err; tail -c 400 $out/config2_bench.json; echo
-stats config2 --no-cpu-baseline
+stats config2 $Q
+# ---- the metric's plans/sec as wall time of solve_planning_problem() calls
+timeout 600 python tools/solve_timing.py > $out/solve_timing_config2.txt 2>&1
+# ---- config 3: Franka / bookshelves, the full C(11,2) = 55 start-goal batch, S=7 M=24 T=70
+python bench.py --workload config3 --steps 130 --warmup 10 $Q > $out/config3_bench.json 2> $out/config3.err
+stats config3 --workload config3 --steps 130 --warmup 10 $Q --min-seconds 0.5
 # ---- 64 Franka problems per GPU (batch regime, cache-resident table)
-stats franka64 --no-cpu-baseline --problems 64 --scene synthetic
-python bench.py --no-cpu-baseline --problems 64 --scene synthetic > $out/franka64_bench.json 2>> $out/franka64.err
-# ---- config 4: UR10, S = 1024 samples; one rank, and two ranks on this one GPU over gloo (rehearsal of the N > 1 path)
+stats franka64 $Q --problems 64 --scene synthetic --min-seconds 0.5
+python bench.py $Q --problems 64 --scene synthetic > $out/franka64_bench.json 2>> $out/franka64.err
+# ---- config 4: UR10, S = 1024 samples; one rank, and two ranks on this one GPU over gloo (rehearsal of the N > 1 path,
+#      started by bench.py itself: no external launcher)
 python bench.py --shard samples --steps 100 --warmup 10 > $out/config4_1rank_bench.json 2> $out/config4.err
-VGPMP_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --shard samples --steps 100 --warmup 10 2>> $out/config4.err | tail -1 > $out/config4_2ranks_gloo_one_gpu_bench.json
+stats config4_1rank --shard samples --steps 100 --warmup 10 --min-seconds 0.5
+timeout 600 python bench.py --gpus 2 --shard samples --steps 100 --warmup 10 2>> $out/config4.err | tail -1 > $out/config4_2ranks_gloo_one_gpu_bench.json
+# ---- the default N > 1 line (config 2 per GPU + the config-5 share as batch_512), two ranks on this one GPU: rehearsal only
+timeout 900 python bench.py --gpus 2 --steps 100 --warmup 10 $Q 2> $out/gpus2.err | tail -1 > $out/gpus2_rehearsal_one_gpu_bench.json
 # ---- config 5 share: 14-DoF arm, 512^3 voxels (2 GiB table), 64 problems
-B5="--workload stress --problems 64 --grid 512 --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 10"
-for f in brick:on brick:off linear:off; do
+B5="--workload stress --steps 10 --warmup 3 $Q --profile-steps 10 --min-seconds 0.5"
+for f in ${FORMS:-brick:on brick:off linear:off}; do
   lay=${f%%:*}; sm=${f##*:}; tag=config5_${lay}_summary_${sm}
   stats $tag $B5 --layout $lay --summary $sm
   pmc $tag $B5 --layout $lay --summary $sm
@@ -39,7 +57,8 @@ done
 # ---- SQ / MFMA counters: the fused prior kernel and the batch likelihood at config 5, the prior GEMM role at config 2
 tools/pmc_sq.sh prior_fused_batch $out/sq_prior_fused_config5 $B5 > /dev/null 2>&1
 tools/pmc_sq.sh "loglik_paths_kernel<" $out/sq_loglik_config5 $B5 > /dev/null 2>&1
-tools/pmc_sq.sh stage2_kernel $out/sq_stage2_config2 --steps 40 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+tools/pmc_sq.sh paths_bwd $out/sq_paths_bwd_config5 $B5 > /dev/null 2>&1
+tools/pmc_sq.sh stage2_kernel $out/sq_stage2_config2 --steps 40 --warmup 5 $Q > /dev/null 2>&1
 # ---- the memory system's ceiling for 16-byte gathers
 if [ -x tools/gather_probe ]; then
   timeout 300 tools/gather_probe > $out/gather_probe.txt 2>&1
@@ -53,13 +72,10 @@ print("FETCH_SIZE per gather launch (KB):", v, "-> bytes tallied per random 16-b
 PY
   rm -rf $out/gp_fetch
 fi
-# ---- the alternatives to a kernel boundary, and what one workgroup's operand staging sustains
-[ -x tools/handoff_probe ] && timeout 120 tools/handoff_probe > $out/handoff_probe.txt 2>&1
-[ -x tools/glds_scale_probe ] && timeout 120 tools/glds_scale_probe > $out/glds_scale_probe.txt 2>&1
 # ---- in-kernel time stamps of one config-2 step (measurement build: the stamps perturb the step by ~1-2 us; rocprof's kernel
 #      durations above are the authority for totals, this shows where inside the launches the time goes)
 if [ -f tools/libvgpmp_bisect.so ]; then
   VGPMP_HIP_LIB=$PWD/tools/libvgpmp_bisect.so timeout 300 python tools/step_trace.py 1 > $out/step_trace_config2.txt 2>&1
 fi
 find $out -name "*.err" -size 0 -delete
-ls -la $out | head -60
+ls -la $out | head -80

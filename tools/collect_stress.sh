@@ -2,9 +2,10 @@
 # BASELINE config 5 (one GPU's share: 14-DoF arm, 512^3 voxels = 2 GiB table, 64 problems) on the GPU box, from the repo
 # root: bench line + rocprofv3 kernel statistics for each table form, FETCH_SIZE / WRITE_SIZE passes for the likelihood
 # kernel, and the 16-byte-gather ceiling of the memory system (tools/gather_probe).  Output: gpurun_out/r02/stress_*.
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=${OUT:-gpurun_out/r02}; mkdir -p $out
-B="--workload stress --problems 64 --grid 512 --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 10 $EXTRA"
+B="--workload stress --problems 64 --grid 512 --steps 10 --warmup 3 --no-cpu-baseline --no-solve --profile-steps 10 $EXTRA"
 forms=${FORMS:-"linear:off brick:off brick:on"}
 for f in $forms; do
   lay=${f%%:*}; sm=${f##*:}; tag=stress_${lay}_summary_${sm}

@@ -1,7 +1,8 @@
 #!/bin/bash
 # SQ counter passes over one bench.py command line (run on the GPU box from the repo root):
 #   tools/pmc_sq.sh <kernel name substring> <out dir> <bench.py arguments ...>
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 key=$1; out=$2; shift 2
 mkdir -p $out
 i=0

@@ -2,7 +2,7 @@
 # Measurement aid: per-kernel average durations of the eager single-problem bench (rocprofv3 kernel trace).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_fused; rm -rf $out
-timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --scene synthetic --no-cpu-baseline --unroll ${UNROLL:-0} --profile-steps 1 "$@" > gpurun_out/prof_fused.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --scene synthetic --no-cpu-baseline --no-solve --unroll ${UNROLL:-0} --profile-steps 1 "$@" > gpurun_out/prof_fused.log 2>&1
 echo rc=$?
 f=$(ls $out/*/*kernel_stats.csv | head -1)
 python3 - "$f" <<'PY'

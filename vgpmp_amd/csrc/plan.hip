@@ -30,6 +30,7 @@ __global__ __launch_bounds__(kPlanBlock) void plan_pick_kernel(const vgpmp_robot
         const float* row = logp + ((size_t)p * S + s) * N;
         double t = 0.0;
         for (int n = 0; n < N; ++n) t += (double)row[n];          // models/vgpmp.py:337: sum over time
+        if (t != t) t = -__builtin_huge_val();                     // a diverged sample (NaN score) never wins
         if (t > bv) { bv = t; bi = s; }
     }
     sv[tid] = bv; si[tid] = bi;
@@ -42,8 +43,9 @@ __global__ __launch_bounds__(kPlanBlock) void plan_pick_kernel(const vgpmp_robot
         }
         __syncthreads();
     }
-    const int b = si[0];
+    const int b = si[0] < S ? si[0] : 0;                            // every score NaN / -inf (or S == 0): a valid index, as tf.argmax
     if (tid == 0) best[p] = b;
+    if (S <= 0) return;
     const float* fb = f + ((size_t)p * S + b) * L * N;
     for (int e = tid; e < N * L; e += kPlanBlock) {
         const int n = e / L, l = e - n * L;

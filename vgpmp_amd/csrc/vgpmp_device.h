@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include "vgpmp.h"
 
 #define VG_WAVE 64
@@ -236,8 +237,8 @@ __device__ __forceinline__ uint2 vg_key(uint32_t seed, uint32_t problem, uint32_
 enum { VG_STREAM_OMEGA = 0, VG_STREAM_CHI = 1, VG_STREAM_BETA = 2, VG_STREAM_W = 3, VG_STREAM_EPS = 4, VG_STREAM_EPS2 = 5 };
 
 // Raises a kernel's dynamic-LDS limit when needed.  hipFuncSetAttribute is a slow host call and applies to the
-// CURRENT device only, so the largest size granted is remembered per (device, kernel).  Benign race: worst case a
-// repeated attribute call.
+// CURRENT device only, so the largest size granted is remembered per (device, kernel).  The table is guarded by a
+// mutex: one process may drive several GPUs from several threads (DeviceScene._stream switches the device).
 inline int vg_grant_dyn_lds(const void* fn, size_t bytes) {
     if (bytes > 160 * 1024) return VGPMP_E_SHAPE;
     if (bytes <= 48 * 1024) return 0;
@@ -245,8 +246,10 @@ inline int vg_grant_dyn_lds(const void* fn, size_t bytes) {
     static const void* fns[kSlots];
     static int devs[kSlots];
     static size_t granted[kSlots];
+    static std::mutex mu;
     int dev = 0;
     VG_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
     int slot = -1;
     for (int i = 0; i < kSlots; ++i) {
         if (fns[i] == fn && devs[i] == dev) { slot = i; break; }

@@ -254,6 +254,8 @@ class VGPMP:
                     pl.raw_alpha.copy_(old.raw_alpha); pl.raw_sigma.copy_(old.raw_sigma)
                     for dst, src in zip(pl.lik_adam_m + pl.lik_adam_v, old.lik_adam_m + old.lik_adam_v):
                         dst.copy_(src)
+                if pl.z_variables and old.z_variables:          # trained inducing locations and their Adam moments
+                    pl.raw_Z.copy_(old.raw_Z); pl.z_adam_m.copy_(old.z_adam_m); pl.z_adam_v.copy_(old.z_adam_v)
                 pl.t = old.t
             self._planner, self._n_train = pl, n_time
         return self._planner
@@ -298,8 +300,13 @@ class VGPMP:
     @property
     def trainable_variables(self):
         pl = self._ensure(self._n_train or self.num_data)
-        names = (("q_mu", pl.q_mu), ("q_sqrt", pl.q_sqrt), ("lengthscales", pl.raw_ell), ("kernel_variance", pl.raw_var))
-        return [t for n, t in names if self.trainable.get(n, True)]
+        names = [("q_mu", pl.q_mu), ("q_sqrt", pl.q_sqrt), ("lengthscales", pl.raw_ell), ("kernel_variance", pl.raw_var)]
+        out = [t for n, t in names if self.trainable.get(n, True)]
+        if pl.lik_variables:                                    # disable_param_opt flags sigma_obs / alpha
+            out += [t for n, t in (("sigma_obs", pl.raw_sigma), ("alpha", pl.raw_alpha)) if self.trainable.get(n, False)]
+        if pl.z_variables:                                      # inducing_variable: raw_Z behind Sigmoid(0.09, 0.91)
+            out.append(pl.raw_Z)
+        return out
 
     def elbo(self, data) -> float:
         """models/vgpmp.py:265-289: alpha * sum_n mean_s log p(e | g) - KL, with freshly drawn paths."""

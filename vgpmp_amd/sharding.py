@@ -89,9 +89,10 @@ class SampleShardedPlanner:
 
     def __init__(self, planner, group=None, comm: Optional["CapiComm"] = None):
         self.planner, self.group, self.comm = planner, group, comm
+        self.schedule = "one vgpmp_elbo_step (forward + reverse) + the all-reduce + one vgpmp_adam_step per step"
 
-    def _allreduce(self) -> None:
-        buf = self.planner.reduce_buf
+    def _allreduce(self, buf: Optional[torch.Tensor] = None) -> None:
+        buf = self.planner.reduce_buf if buf is None else buf
         if self.comm is not None:
             self.comm.allreduce_sum_(buf)
         else:
@@ -110,7 +111,9 @@ class SampleShardedPlanner:
     def elbo(self) -> torch.Tensor:
         pl = self.planner
         pl.elbo(generate=True, step=pl.t)
-        self._allreduce()                                      # the gradient part of the buffer is stale here: only lik / kl are read
+        # only the [lik | kl] tail is fresh after a forward-only pass: reduce just that (contiguous, 2 P doubles) and
+        # leave the gradient part of the buffer alone (summing it in place would scale a stale gradient by the world size)
+        self._allreduce(pl.reduce_buf[pl.reduce_buf.numel() - 2 * pl.P:])
         return pl.lik - pl.kl
 
 
