@@ -217,6 +217,8 @@ typedef struct vgpmp_outputs {
                                  * per-latent prior KL (kullback_leiblers/prior_kl.py:16-35) land in the workspace (views "kl_l", "C",
                                  * "Kinv", "A4"); no noise, no likelihood: dev_robot and sdf may be NULL, the members of `noise` and `out` too */
 #define VGPMP_NO_FUSE_PRIOR 4096 /* measurement: large batches with the generator, the feature kernel and the tiled GEMM as three launches */
+#define VGPMP_PRIOR_F32 8192   /* measurement: large batches form the prior draws with float32 MFMAs (the round-2 kernel) instead of
+                                 * the f16-split products of prior_fused_split_kernel */
 #define VGPMP_ELIM_BLOCK 128    /* measurement: Kuu elimination by the whole workgroup through LDS instead of one wave in registers */
 
 /* ---- set-up -------------------------------------------------------------------------------- */

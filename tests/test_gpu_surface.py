@@ -534,10 +534,10 @@ def test_dispatchers_on_the_device_match_oracle():
 @pytest.mark.parametrize("S,N,M,B,lengthscales,P", [(37, 50, 10, 256, True, 3), (128, 150, 30, 1024, True, 3), (70, 20, 5, 64, False, 3),
                                                       (70, 20, 5, 64, True, 63), (128, 12, 5, 128, False, 64)])   # 128-row tiles (ragged / full)
 def test_fused_prior_kernel_equals_generator_features_and_gemm(S, N, M, B, lengthscales, P):
-    """Large-batch schedule with device-generated noise: W and Phi / dPhi formed inside the GEMM (prior_fused_batch_kernel)
-    against the three launches it replaces (Philox generator -> w, features_kernel -> Phi / dPhi, tiled GEMM): the same
-    expressions in the same order, so the prior draws, the paths, the likelihood and every gradient agree bit for bit.
-    Ragged sample count, one and two column tiles, with and without the lengthscale tangent; 63 / 64 problems: the
+    """Large-batch schedule with device-generated noise: W and Phi / dPhi formed inside the GEMM (prior_fused_batch_kernel,
+    float32 MFMAs: flag PRIOR_F32) against the three launches it replaces (Philox generator -> w, features_kernel -> Phi / dPhi,
+    tiled GEMM): the same expressions in the same order, so the prior draws, the paths, the likelihood and every gradient agree
+    bit for bit.  Ragged sample count, one and two column tiles, with and without the lengthscale tangent; 63 / 64 problems: the
     128-row tiles of the full-chip regime."""
     from vgpmp_amd import capi, engine
     ps = rb.load_problemset("franka", "industrial")
@@ -549,7 +549,7 @@ def test_fused_prior_kernel_equals_generator_features_and_gemm(S, N, M, B, lengt
     kw = dict(num_samples=S, num_inducing=M, num_data=N, num_bases=B, lengthscales=[2.0] * 7, variance=0.2, seed=9, split_k=1,
               trainable=tr, problem_base=5)
     outs = []
-    for flag in (0, capi.NO_FUSE_PRIOR):
+    for flag in (capi.PRIOR_F32, capi.NO_FUSE_PRIOR):
         pl = engine.PlannerBatch(sc, qs, **kw)
         pl.fuse = False                       # one launch per kernel: the large-batch schedule
         pl.extra_flags = flag
@@ -562,3 +562,85 @@ def test_fused_prior_kernel_equals_generator_features_and_gemm(S, N, M, B, lengt
     assert float(outs[0][0].abs().max()) > 0
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("robot,S,N,M,B,lengthscales,P", [("franka", 37, 50, 10, 256, True, 3), ("franka", 128, 100, 30, 1024, True, 5),
+                                                            ("franka", 70, 20, 5, 64, False, 3), ("franka", 64, 33, 6, 128, True, 2),
+                                                            ("synthetic14", 128, 100, 30, 1024, True, 2), ("synthetic14", 50, 12, 5, 64, True, 3)])
+def test_f16_split_prior_kernel_against_float64_and_the_float32_kernels(robot, S, N, M, B, lengthscales, P):
+    """prior_fused_split_kernel (csrc/gp_prior_split.h, the default of the large-batch schedule): F0 = W Phi^T and
+    H = W (dPhi / d ell)^T with every float32 operand split into two f16 halves and three f16 MFMAs per product, float32
+    accumulators (restates the `temporary_paths` draw, models/vgpmp.py:281-282).  Gate: its distance from
+    a float64 evaluation of the SAME W, omega, beta (the generator's own values, read back from the three-launch form) must
+    not exceed that of the float32-MFMA kernels by more than rounding noise, and stays inside the 2e-5 max|.| the oracle
+    parity tests allow; paths, likelihood and gradients follow.  7 joints (8-wide padding) and 14 joints (16-wide), 64- and
+    128-row tiles, ragged S, with and without the lengthscale tangent."""
+    from vgpmp_amd import capi, engine
+    if robot == "franka":
+        ps = rb.load_problemset("franka", "industrial")
+        spec = rb.load_robot("franka")
+        qs = np.array([ps.queries[i % len(ps.queries)] for i in range(P)])
+        off = ps.object_positions[0]
+    else:
+        spec = rb.synthetic_arm(14)
+        qs = np.random.default_rng(3).uniform(-2.0, 2.0, (P, 2, 14))
+        off = (0.05, -0.03, 0.02)
+    L = spec.dof
+    grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
+    sc = engine.DeviceScene(spec, grid, off)
+    tr = dict(q_mu=True, q_sqrt=True, lengthscales=lengthscales, kernel_variance=True)
+    kw = dict(num_samples=S, num_inducing=M, num_data=N, num_bases=B, lengthscales=[2.0] * L, variance=0.2, seed=9, split_k=1,
+              trainable=tr, problem_base=5)
+    J = N + M + 2
+    res = {}
+    for name, flag in (("split", 0), ("f32", capi.PRIOR_F32), ("three", capi.NO_FUSE_PRIOR)):
+        pl = engine.PlannerBatch(sc, qs, **kw)
+        pl.fuse = False                       # one launch per kernel: the large-batch schedule
+        pl.extra_flags = flag
+        loss, grads = pl.loss_and_grad(generate=True, step=7)          # fresh variables: identical inputs in the three runs
+        torch.cuda.synchronize()
+        res[name] = dict(F0=pl.view("F0").reshape(P, S, L, J).cpu().numpy().astype(np.float64),
+                         H=pl.view("H").reshape(P, S, L, J).cpu().numpy().astype(np.float64) if lengthscales else None,
+                         f=pl.f.cpu().numpy(), logp=pl.logp.cpu().numpy(), loss=loss.cpu().numpy().copy(),
+                         grads=[g.cpu().numpy().copy() for g in grads], pl=pl)
+    three = res["three"]["pl"]
+    assert torch.equal(res["f32"]["pl"].omega, three.omega) and torch.equal(res["split"]["pl"].omega, three.omega)
+    X, Zy = orc.init_trainset(N, L), orc.inducing_Zy(M, L)
+    pts = np.concatenate([X, Zy], axis=0)
+    ell, var = three.lengthscales().cpu().numpy(), three.variances().cpu().numpy()
+    worst = {}
+    for k in range(P):
+        nz = orc.Noise(three.omega[k].cpu().numpy().astype(np.float64), three.beta[k].cpu().numpy().astype(np.float64),
+                       three.w[k].cpu().numpy().astype(np.float64), None, None)
+        Phi, dPhi = orc.rff_features(nz, pts, ell[k], var[k], True)
+        F0 = np.matmul(nz.w.transpose(1, 0, 2), Phi.transpose(0, 2, 1)).transpose(1, 0, 2)
+        H = np.matmul(nz.w.transpose(1, 0, 2), dPhi.transpose(0, 2, 1)).transpose(1, 0, 2)
+        for name in ("split", "f32", "three"):
+            e = np.abs(res[name]["F0"][k] - F0).max() / np.abs(F0).max()
+            worst[name, "F0"] = max(worst.get((name, "F0"), 0.0), e)
+            if lengthscales:
+                e = np.abs(res[name]["H"][k] - H).max() / np.abs(H).max()
+                worst[name, "H"] = max(worst.get((name, "H"), 0.0), e)
+    print("max |device - float64| / max|.|:", {f"{a} {b}": f"{v:.2e}" for (a, b), v in sorted(worst.items())})
+    for mat in ("F0", "H") if lengthscales else ("F0",):
+        assert worst["f32", mat] < 2e-5 and worst["split", mat] < 2e-5
+        assert worst["split", mat] <= 1.5 * worst["f32", mat] + 2e-7, (mat, worst["split", mat], worst["f32", mat])
+    # downstream of the draws: paths, likelihood, loss, gradients (a float32 sphere centre may change voxel: fractions)
+    a, b = res["split"], res["f32"]
+    np.testing.assert_allclose(a["f"], b["f"], rtol=0, atol=2e-5)
+    ok = np.isclose(a["logp"], b["logp"], rtol=2e-3, atol=1e-4)
+    assert ok.mean() > 0.99
+    flips = 1.0 - ok.mean()
+    np.testing.assert_allclose(a["loss"], b["loss"], rtol=50 * flips + 1e-4)
+    for k, (ga, gb) in enumerate(zip(a["grads"], b["grads"])):
+        if k == 2 and not lengthscales:
+            continue                                    # no lengthscale tangent: that gradient is not formed
+        assert np.abs(ga - gb).max() <= (50 * flips + 1e-3) * np.abs(gb).max() + 1e-12
+    # ... and three optimisation steps stay together (Adam normalises: float32-level gradient differences move a variable by
+    # far less than lr per step)
+    sp, fp = res["split"]["pl"], res["f32"]["pl"]
+    for _ in range(3):
+        sp.step(); fp.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(sp.q_mu).all()
+    assert float((sp.q_mu - fp.q_mu).abs().max()) < 3 * sp.lr * 2e-2

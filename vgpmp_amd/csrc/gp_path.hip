@@ -44,6 +44,7 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 #include "gp_update.h"
 #include "gp_cov.h"
 #include "gp_prior.h"
+#include "gp_prior_split.h"
 #include "gp_lik_consts.h"
 
 namespace {
@@ -807,7 +808,28 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                                 (fb_tail == 0 || fb_tail >= 180) ? 2 : 1;
                 const size_t lds_fb = ((size_t)kTS * fmt * kFBLd + (size_t)2 * kTJ * kFBLd + (size_t)kTJ * dm + (size_t)2 * kFBK * (dm + 4)) * sizeof(float);
                 const dim3 fb_grid((J + kTJ - 1) / kTJ, (S + kTS * fmt - 1) / (kTS * fmt), P * L);
-                if (cov_with_prior) {
+                // the f16-split form (gp_prior_split.h): 512-thread workgroups, 128-row tiles whenever there are more than 64
+                // samples, two workgroups per CU; the float32-MFMA kernel stays behind VGPMP_PRIOR_F32 and for the launch
+                // shared with stage B of the covariance path
+                const bool split16 = !cov_with_prior && !(what & VGPMP_PRIOR_F32);
+                if (split16) {
+                    const int hmt = S > kTS ? 2 : 1;
+                    const size_t lds_h = vg_fused_split_lds(hmt, dm);
+                    const dim3 hgrid((J + kTJ - 1) / kTJ, (S + kTS * hmt - 1) / (kTS * hmt), P * L);
+#define VG_FH(DELL_, DM_, MT_)                                                                                            \
+    do {                                                                                                                  \
+        if ((rc = set_dyn_lds((const void*)prior_fused_split_kernel<DELL_, DM_, MT_>, lds_h))) return rc;                 \
+        hipExtLaunchKernelGGL((prior_fused_split_kernel<DELL_, DM_, MT_>), hgrid, dim3(kHThreads), lds_h, st, g0, g1, 0, fb); \
+    } while (0)
+                    if (want_dell) {
+                        if (dm == 8) { if (hmt == 2) VG_FH(true, 8, 2); else VG_FH(true, 8, 1); }
+                        else { if (hmt == 2) VG_FH(true, 16, 2); else VG_FH(true, 16, 1); }
+                    } else {
+                        if (dm == 8) { if (hmt == 2) VG_FH(false, 8, 2); else VG_FH(false, 8, 1); }
+                        else { if (hmt == 2) VG_FH(false, 16, 2); else VG_FH(false, 16, 1); }
+                    }
+#undef VG_FH
+                } else if (cov_with_prior) {
                     BatchCArgs bc;
                     bc.cov = ca; bc.fb = fb;
                     bc.cov_roles = (int)cov_b_grid.x; bc.fb_gx = (int)fb_grid.x; bc.fb_gy = (int)fb_grid.y;
