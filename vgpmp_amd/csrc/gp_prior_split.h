@@ -34,6 +34,15 @@ typedef _Float16 vg_h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 vg_h8 __attribute__((ext_vector_type(8)));
 typedef float vg_f2 __attribute__((ext_vector_type(2)));
 
+#ifndef VG_HS_WBAR
+#define VG_HS_WBAR 1         // scheduling barrier between the Philox counters of a thread
+#endif
+#ifndef VG_HS_PROJ2
+#define VG_HS_PROJ2 0        // projection as two interleaved partial chains
+#endif
+#ifndef VG_HS_PRIO
+#define VG_HS_PRIO 0         // raised priority for the product phase
+#endif
 constexpr int kHK = 32;                  // K step = one v_mfma_f32_16x16x32_f16
 constexpr int kHThreads = 512;
 constexpr int kHRowBytes = 2 * kHK;      // 64-byte tile rows
@@ -181,7 +190,9 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
             const int off = wrow * kHRowBytes + vg_swz(wrow, kq >> 1) * 16 + (kq & 1) * 8;
             *reinterpret_cast<vg_h4*>(Ah + off) = (vg_h4){h0[0], h0[1], h1[0], h1[1]};
             *reinterpret_cast<vg_h4*>(Al + off) = (vg_h4){l0[0], l0[1], l1[0], l1[1]};
+#if VG_HS_WBAR
             __builtin_amdgcn_sched_barrier(0);      // one counter at a time: two in flight need more registers than there are
+#endif
         }
         {   // features
             vg_f2 om[DM / 2];                                     // (omega[fk][d], omega[fk][d + 1])
@@ -196,12 +207,23 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
             for (int i = 0; i < ni; ++i) {
                 const int q = jq + 16 * i;
                 vg_f2 proj = (vg_f2){0.f, 0.f};
+#if VG_HS_PROJ2
+                vg_f2 projb = (vg_f2){0.f, 0.f};
+#pragma unroll
+                for (int d = 0; d < DM; d += 2) {                 // (zero padding: the products beyond D add exact zeros)
+                    const vg_f32x4 p4 = *reinterpret_cast<const vg_f32x4*>(pts + (q * DM + d) * 2);
+                    proj = vg_pk_fma_lo(__builtin_shufflevector(p4, p4, 0, 1), om[d / 2], proj);
+                    projb = vg_pk_fma_hi(__builtin_shufflevector(p4, p4, 2, 3), om[d / 2], projb);
+                }
+                proj += projb;
+#else
 #pragma unroll
                 for (int d = 0; d < DM; d += 2) {                 // (zero padding: the products beyond D add exact zeros)
                     const vg_f32x4 p4 = *reinterpret_cast<const vg_f32x4*>(pts + (q * DM + d) * 2);
                     proj = vg_pk_fma_lo(__builtin_shufflevector(p4, p4, 0, 1), om[d / 2], proj);
                     proj = vg_pk_fma_hi(__builtin_shufflevector(p4, p4, 2, 3), om[d / 2], proj);
                 }
+#endif
                 const vg_f2 rv = __builtin_elementwise_fma(proj, rev_scale, bt);
                 const float r0 = __builtin_amdgcn_fractf(rv[0]), r1 = __builtin_amdgcn_fractf(rv[1]);
                 const vg_f2 cs = (vg_f2){__builtin_amdgcn_cosf(r0), __builtin_amdgcn_cosf(r1)};
@@ -226,6 +248,9 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
         if (more) om_store(ob ^ 1);
         __syncthreads();
         // ================= products: per 16 x 16 tile  hi hi + hi lo + lo hi, float32 accumulators
+#if VG_HS_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
         {
             const int arow = 16 * rt + r;
             const int aoff = arow * kHRowBytes + vg_swz(arow, g) * 16;
@@ -247,6 +272,9 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
                 }
             }
         }
+#if VG_HS_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __syncthreads();
         ob ^= 1;
     }
