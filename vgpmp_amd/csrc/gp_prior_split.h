@@ -43,6 +43,9 @@ typedef float vg_f2 __attribute__((ext_vector_type(2)));
 #ifndef VG_HS_PRIO
 #define VG_HS_PRIO 0         // raised priority for the product phase
 #endif
+#ifndef VG_HS_SKIP
+#define VG_HS_SKIP 0         // measurement: 1 = no products, 2 = no W draws, 4 = no features (results are garbage)
+#endif
 constexpr int kHK = 32;                  // K step = one v_mfma_f32_16x16x32_f16
 constexpr int kHThreads = 512;
 constexpr int kHRowBytes = 2 * kHK;      // 64-byte tile rows
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
         if (more) om_fetch(k0 + kHK);
         // W: counter m of the thread covers k = 4 kq .. 4 kq + 3, kq = MT wpart + m: 8 bytes of each half tile
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+        for (int m = 0; m < ((VG_HS_SKIP & 2) ? 0 : MT); ++m) {
             const int kq = wpart * MT + m;
             const float4 w4 = vg_normal4_mad(wbase + (uint32_t)(k0 >> 2) + (uint32_t)m, VG_STREAM_W, key);
             vg_h2 h0, l0, h1, l1;
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
                 om[d / 2] = (vg_f2){o4[0], o4[1]}; om[d / 2 + 1] = (vg_f2){o4[2], o4[3]};
             }
             const vg_f2 bt = (vg_f2){orow[DM], orow[DM]};
-            const int ni = wave < 4 ? 5 : 4;                      // point pairs jq + 16 i < 72 (wave-uniform)
+            const int ni = (VG_HS_SKIP & 4) ? 0 : wave < 4 ? 5 : 4;                      // point pairs jq + 16 i < 72 (wave-uniform)
             for (int i = 0; i < ni; ++i) {
                 const int q = jq + 16 * i;
                 vg_f2 proj = (vg_f2){0.f, 0.f};
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
             const vg_h8 ah = *reinterpret_cast<const vg_h8*>(Ah + aoff);
             const vg_h8 al = *reinterpret_cast<const vg_h8*>(Al + aoff);
 #pragma unroll
-            for (int t = 0; t < kTJ / 16; ++t) {
+            for (int t = 0; t < ((VG_HS_SKIP & 1) ? 0 : kTJ / 16); ++t) {
                 const int brow = 16 * t + r;
                 const int boff = brow * kHRowBytes + vg_swz(brow, g) * 16;
 #pragma unroll
