@@ -814,20 +814,15 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 const bool split16 = !cov_with_prior && !(what & VGPMP_PRIOR_F32);
                 if (split16) {
                     const int hmt = S > kTS ? 2 : 1;
-                    const size_t lds_h = vg_fused_split_lds(hmt, dm);
+                    const size_t lds_h = vg_fused_split_lds(hmt);
                     const dim3 hgrid((J + kTJ - 1) / kTJ, (S + kTS * hmt - 1) / (kTS * hmt), P * L);
-#define VG_FH(DELL_, DM_, MT_)                                                                                            \
+#define VG_FH(DELL_, MT_)                                                                                                 \
     do {                                                                                                                  \
-        if ((rc = set_dyn_lds((const void*)prior_fused_split_kernel<DELL_, DM_, MT_>, lds_h))) return rc;                 \
-        hipExtLaunchKernelGGL((prior_fused_split_kernel<DELL_, DM_, MT_>), hgrid, dim3(kHThreads), lds_h, st, g0, g1, 0, fb); \
+        if ((rc = set_dyn_lds((const void*)prior_fused_split_kernel<DELL_, MT_>, lds_h))) return rc;                      \
+        hipExtLaunchKernelGGL((prior_fused_split_kernel<DELL_, MT_>), hgrid, dim3(kHThreads), lds_h, st, g0, g1, 0, fb);   \
     } while (0)
-                    if (want_dell) {
-                        if (dm == 8) { if (hmt == 2) VG_FH(true, 8, 2); else VG_FH(true, 8, 1); }
-                        else { if (hmt == 2) VG_FH(true, 16, 2); else VG_FH(true, 16, 1); }
-                    } else {
-                        if (dm == 8) { if (hmt == 2) VG_FH(false, 8, 2); else VG_FH(false, 8, 1); }
-                        else { if (hmt == 2) VG_FH(false, 16, 2); else VG_FH(false, 16, 1); }
-                    }
+                    if (want_dell) { if (hmt == 2) VG_FH(true, 2); else VG_FH(true, 1); }
+                    else { if (hmt == 2) VG_FH(false, 2); else VG_FH(false, 1); }
 #undef VG_FH
                 } else if (cov_with_prior) {
                     BatchCArgs bc;
