@@ -644,3 +644,29 @@ def test_f16_split_prior_kernel_against_float64_and_the_float32_kernels(robot, S
     torch.cuda.synchronize()
     assert torch.isfinite(sp.q_mu).all()
     assert float((sp.q_mu - fp.q_mu).abs().max()) < 3 * sp.lr * 2e-2
+
+
+@pytest.mark.parametrize("S,N,M,P", [(128, 100, 30, 64), (70, 20, 5, 63), (37, 50, 10, 40)])
+def test_reverse_path_pass_over_several_chunks_per_workgroup_is_bitwise_the_same(S, N, M, P):
+    """paths_bwd_sc8 stages a latent's A / C tangents once and walks several 8-sample chunks (the
+    per-chunk re-staging moved 3.6x the operand bytes); the per-chunk partial sums it leaves are the same numbers in the
+    same order as with one chunk per workgroup (flag BWD_ONE_CHUNK), so losses, gradients and updates agree bit for bit."""
+    from vgpmp_amd import capi, engine
+    ps = rb.load_problemset("franka", "industrial")
+    spec = rb.load_robot("franka")
+    grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
+    sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
+    qs = np.array([ps.queries[i % len(ps.queries)] for i in range(P)])
+    kw = dict(num_samples=S, num_inducing=M, num_data=N, num_bases=128, lengthscales=[2.0] * 7, variance=0.2, seed=4, split_k=1)
+    outs = []
+    for flag in (0, capi.BWD_ONE_CHUNK):
+        pl = engine.PlannerBatch(sc, qs, **kw)
+        pl.fuse = False
+        pl.extra_flags = flag
+        pl.step(); pl.step()
+        loss, grads = pl.loss_and_grad(generate=True, step=5)
+        torch.cuda.synchronize()
+        outs.append([loss.clone(), pl.q_mu.clone(), pl.q_sqrt.clone(), pl.raw_ell.clone(), pl.raw_var.clone()] + [g.clone() for g in grads])
+    assert float(outs[0][5].abs().max()) > 0
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

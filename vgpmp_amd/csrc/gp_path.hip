@@ -503,6 +503,10 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     pa.stop = -1;
     pa.xcd_span = 0;
     pa.tick = nullptr;
+    // paths_bwd_sc8: sample chunks per workgroup -- as many as leave six workgroups per CU (the values do not depend on it)
+    pa.cpw = 1;
+    if (!(what & VGPMP_BWD_ONE_CHUNK))
+        while (pa.cpw < NC && (size_t)P * L * ((NC + 2 * pa.cpw - 1) / (2 * pa.cpw)) >= 1536) pa.cpw *= 2;
     const double lik_scale = pb->alpha / (double)d->S_total;
     FinalArgs fa;
     fa.M = M; fa.L = L; fa.NC = NC; fa.nblk = P ? vg_loglik_blocks_per_problem(S, N) : 0; fa.part_len = vg_part_len(d);
@@ -540,7 +544,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     // path kernels: operands + (when it fits) the raw split-K slabs of the prior draws
     const size_t raw_f = SK == 1 ? 0 : (size_t)SK * SC * J * sizeof(float);      // one slab lands in place
     size_t lds_pf = ((size_t)Mz * (Mz + 1) + (size_t)Mz * N + (size_t)3 * SC * Mz + Mz + (size_t)SC * J + 6 * 4) * sizeof(float);
-    size_t lds_pb = ((size_t)4 * N * Mz + (size_t)2 * Mz * Mz + (size_t)SC * N + (size_t)2 * SC * J +
+    size_t lds_pb = ((size_t)3 * N * Mz + (size_t)2 * Mz * Mz + (size_t)SC * N + (size_t)2 * SC * J +
                      (size_t)8 * SC * Mz + 10 * 4) * sizeof(float);
     const bool raw_fwd = lds_pf + raw_f <= 64 * 1024, raw_bwd = lds_pb + 2 * raw_f <= 160 * 1024;
     if (raw_fwd) lds_pf += raw_f;
@@ -883,7 +887,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         }
         // ---- reverse of the path assembly (+ hyper-parameter update), then (here or in the next stage 1) the rest
         pa.xcd_span = VG_XCD_PATHS && split_bwd && (2 * NC * L * P) % 8 == 0 ? 2 * NC * L * P / 8 : 0;
-        if ((rc = launch(fn_pb, dim3(split_bwd ? 2 * NC : NC, L, P), &pa, lds_pb))) return rc;
+        if ((rc = launch(fn_pb, dim3(split_bwd ? 2 * NC : (NC + pa.cpw - 1) / pa.cpw, L, P), &pa, lds_pb))) return rc;
         if (ind) {     // inducing locations as variables: reverse through the covariance path and the prior draw at Zy
             vg_ind_launch il;
             il.d = d; il.ind = ind; il.ws = ws; il.nz = nz; il.params = params; il.X = pb->X; il.y_u = pb->y_u;

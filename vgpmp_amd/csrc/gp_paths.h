@@ -27,6 +27,7 @@ struct PathArgs {
     // latent's A / C tangents sit behind one L2 (at most two latents per XCD instead of all of them)
     int xcd_span;
     uint32_t* tick;           // paths_fwd_sc8: the step counter ticks here (large-batch schedule; nullptr: elsewhere)
+    int cpw;                  // paths_bwd_sc8: sample chunks per workgroup (the latent's A / C tangents are staged once for all of them)
 };
 __device__ __forceinline__ int xcd_contiguous(int id, int span) { return span > 0 ? (id & 7) * span + (id >> 3) : id; }
 
@@ -299,18 +300,21 @@ __device__ __forceinline__ void paths_fwd_split_body(const PathArgs& a, float* s
 //   hyper-parameters by dot products with the forward-mode tangents of the covariance kernels:
 //   s_ell = <R, G A_ell> + <dR, C_ell eps> + <G, H_X> - <dR, H_Z>
 //   s_var = <R, G A_var> + <dR, C_var eps> ;  s_rff = <G, F0_X> - <dR, F0_Z>   (x 1/(2 var) later)
+#ifndef VG_PB_SKIP
+#define VG_PB_SKIP 0      // measurement: 1 = no MFMA tiles, 2 = no element-wise part, 4 = no dm / dC partials, 8 = chunk operands staged once
+#endif
 template <int SK, bool RAW>
 __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
     constexpr int SC = 8;
     extern __shared__ float smf[];
     __shared__ float red[3][kBlock / VG_WAVE];
-    const int ch = blockIdx.x, l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
-    const int S = a.S, N = a.N, Mz = a.Mz, L = a.L, J = N + Mz;
+    const int l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = blockDim.x;
+    const int S = a.S, N = a.N, Mz = a.Mz, L = a.L, J = N + Mz, NM = N * Mz;
     const float iMz = 1.0f / (float)Mz, iN = 1.0f / (float)N, iJ = 1.0f / (float)J;
     const size_t pl = (size_t)p * L + l;
     float* cur = smf;
     auto take = [&](int n) { float* q = cur; cur += (n + 3) & ~3; return q; };      // 16-byte aligned regions
-    float4* A4s = reinterpret_cast<float4*>(take(4 * N * Mz));      // [N][Mz] {A, A_ell, A_var, -}
+    float* Ap = take(3 * NM);                        // [3][N][Mz] A, dA/dell, dA/dvar as planes
     float* Ces = take(2 * Mz * Mz);                  // [Mz][Mz] (dC/dell)^T, then (dC/dvar)^T
     float* Cvs = Ces + Mz * Mz;
     float* Gs = take(SC * N);                        // [SC][N]
@@ -321,16 +325,34 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
     float* dRs = take(SC * Mz);                      // [SC][Mz]
     float* dGA = take(5 * SC * Mz);                  // [5][SC][Mz] G A, G A_ell, G A_var, eps C_var^T, eps C_ell^T (MFMA form)
     float* raw = take(0);                            // [2][SK][SC][J] slabs of F0 and H as they arrive (RAW)
-    const int s_base = ch * SC;
-    VG_T(ch == 0 && l == 0 && p == 0, 500);
+    const bool dell = a.want_dell != 0;
+    // ---- what every chunk of this (problem, latent) shares: staged ONCE per workgroup (a.cpw chunks each).  With one
+    //      chunk per workgroup the 16 chunks of a latent each pulled these 59 KB again: 689 MB per launch at the config-5
+    //      share against ~190 MB of operands.  The float4 records {A, A_ell, A_var, -} go through registers into
+    //      three planes: a quarter less LDS, and the MFMA operand reads below fall on consecutive banks
     {
-        vg_stage_16(A4s, a.A4 + pl * N * Mz, N * Mz, tid, nt);
+        const float4* Ag = a.A4 + pl * NM;
+        for (int e0 = 0; e0 < NM; e0 += 4 * nt) {
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = Ag[min(e0 + q * nt + tid, NM - 1)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = e0 + q * nt + tid;
+                if (e < NM) { Ap[e] = v[q].x; Ap[NM + e] = v[q].y; Ap[2 * NM + e] = v[q].z; }
+            }
+        }
         const float* Ce = a.CT_ell + pl * Mz * Mz;
         const float* Cv = a.CT_var + pl * Mz * Mz;
-        const bool dell = a.want_dell != 0;
         vg_stage_rows(Ces, 2 * Mz, Mz, tid, nt, [&](int r) -> const float* {
             return r < Mz ? (dell ? Ce + (size_t)r * Mz : nullptr) : Cv + (size_t)(r - Mz) * Mz;
         });
+    }
+    const int ch_end = min((int)(blockIdx.x + 1) * a.cpw, a.NC);
+    for (int ch = blockIdx.x * a.cpw; ch < ch_end; ++ch) {
+    const int s_base = ch * SC;
+    VG_T(ch == 0 && l == 0 && p == 0, 500);
+    if (!(VG_PB_SKIP & 8) || ch == (int)blockIdx.x * a.cpw) {
         vg_stage_rows(Gs, SC, N, tid, nt, [&](int r) -> const float* {
             const int s = s_base + r;
             return s < S ? a.G + (((size_t)p * S + s) * L + l) * N : nullptr;              // zero beyond S
@@ -380,17 +402,17 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
     // Mz = 32: the five small products as 16 x 16 MFMA tiles (8 sample rows used) -- waves 0..2 one component of G A each
     // (both column halves), wave 3 the two triangular products -- instead of N-long scalar chains per thread
     const bool tiles = Mz == 32 && (N & 3) == 0 && nt == 256;
-    if (tiles) {
+    if (tiles && !(VG_PB_SKIP & 1)) {
         const int wv = tid >> 6, lane = tid & 63, i = lane & 15, kk = lane >> 4;
         if (wv < 3) {
             vg_f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             const float* gp = Gs + min(i, SC - 1) * N;
-            const float* ap = reinterpret_cast<const float*>(A4s) + wv;      // component wv of the float4 at [n][mi]
+            const float* ap = Ap + wv * NM;                          // plane wv at [n][mi]
             for (int n = 0; n < N; n += 4) {
                 const float a0 = i < SC ? gp[n + kk] : 0.f;
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
-                    acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, ap[((n + kk) * 32 + 16 * h + i) * 4], acc[h], 0, 0, 0);
+                    acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, ap[(n + kk) * 32 + 16 * h + i], acc[h], 0, 0, 0);
             }
             if (kk < SC / 4) {
 #pragma unroll
@@ -422,17 +444,16 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
         }
         __syncthreads();
     }
-    for (int e = tid; e < SC * Mz; e += nt) {
+    for (int e = tid; e < ((VG_PB_SKIP & 2) ? 0 : SC * Mz); e += nt) {
         const int sl = vg_div(e, iMz), mi = e - sl * Mz;
         const float* g = Gs + sl * N;
         float d = 0.f, de = 0.f, dv = 0.f;
         if (tiles) { d = dGA[e]; de = dGA[SC * 32 + e]; dv = dGA[2 * SC * 32 + e]; }
         for (int n = 0; !tiles && n < N; ++n) {
-            const float4 av = A4s[n * Mz + mi];
             const float gv = g[n];
-            d = fmaf(gv, av.x, d);
-            de = fmaf(gv, av.y, de);
-            dv = fmaf(gv, av.z, dv);
+            d = fmaf(gv, Ap[n * Mz + mi], d);
+            de = fmaf(gv, Ap[NM + n * Mz + mi], de);
+            dv = fmaf(gv, Ap[2 * NM + n * Mz + mi], dv);
         }
         dRs[e] = d;
         float ue = 0.f, uv = 0.f;
@@ -447,7 +468,7 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
         se += rv * de + d * ue - d * hs[sl * J + N + mi];
         sr -= d * f0s[sl * J + N + mi];
     }
-    for (int e = tid; e < SC * N; e += nt) {
+    for (int e = tid; e < ((VG_PB_SKIP & 2) ? 0 : SC * N); e += nt) {
         const int sl = vg_div(e, iN), n = e - sl * N;
         const float gv = Gs[e];             // zero for samples beyond S
         sr = fmaf(gv, f0s[sl * J + n], sr);
@@ -457,13 +478,13 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
     VG_T(ch == 0 && l == 0 && p == 0, 502);
     VG_STOP(a, 3);
     float* out = a.part + (pl * a.NC + ch) * a.part_len;
-    for (int mi = tid; mi < Mz; mi += nt) {
+    for (int mi = tid; mi < ((VG_PB_SKIP & 4) ? 0 : Mz); mi += nt) {
         float t = 0.f;
         for (int sl = 0; sl < SC; ++sl) t += dRs[sl * Mz + mi];
         vg_stream(out + mi, t);
     }
     float* oC = out + Mz;
-    for (int e = tid; e < Mz * Mz; e += nt) {
+    for (int e = tid; e < ((VG_PB_SKIP & 4) ? 0 : Mz * Mz); e += nt) {
         const int mi = vg_div(e, iMz), k = e - mi * Mz;
         float t = 0.f;
         for (int sl = 0; sl < SC; ++sl) t = fmaf(dRs[sl * Mz + mi], Es[sl * Mz + k], t);
@@ -481,6 +502,8 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
     }
     VG_T(ch == 0 && l == 0 && p == 0, 503);
     VG_T(ch == a.NC - 1 && l == L - 1 && p == 0, 505);
+    __syncthreads();      // the chunk's operands are overwritten by the next one's
+    }
 }
 
 // The same reverse pass on TWO workgroups per (sample chunk, latent) for launches that leave half the chip idle:
