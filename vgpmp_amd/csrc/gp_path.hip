@@ -597,6 +597,12 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                                                                                   : (const void*)paths_bwd_split<8>);
         lds_pb = lds_pbs;
     }
+    // large batches: the latent's constants in registers, pairs of chunks through 40 KB of LDS (paths_bwd_regs)
+    const bool regs_bwd = backward && !split_bwd && SK == 1 && Mz == 32 && (N & 3) == 0 && N <= 100 && pa.cpw >= 2;
+    if (regs_bwd) {
+        fn_pb = (const void*)paths_bwd_regs<25>;
+        lds_pb = ((size_t)16 * N + (size_t)32 * J + (size_t)8 * 16 * Mz + 8 * 4) * sizeof(float);
+    }
     if (backward && (rc = set_dyn_lds(fn_pb, lds_pb))) return rc;      // forward-only calls never launch the reverse pass
     if (fused) {
         if ((rc = set_dyn_lds((const void*)stage1_kernel<false>, lds_s1))) return rc;

@@ -506,6 +506,182 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
     }
 }
 
+// The reverse pass of large batches (Mz = 32, N a multiple of 4 up to 4 KS, one slab of prior draws): what a latent's
+// chunks share -- the three planes of A4 and the two tangents of C, B operands of every product here -- lives in
+// REGISTERS (a lane's fragments of all K steps: 2 KS values for the waves that form G A, 32 for the wave that forms
+// eps C^T), read from global memory once per workgroup; LDS then holds only the operands of the current PAIR of 8-sample
+// chunks (40 KB: four workgroups per CU instead of two), the 16 x 16 MFMA tiles use all sixteen rows (two chunks at once;
+// paths_bwd_sc8 leaves eight of them empty) and no product waits on an LDS read of a B operand.  Per chunk the
+// element-wise part, the partial sums and their order are those of paths_bwd_sc8: the same numbers, bit for bit
+// (tests/test_gpu_surface.py::test_reverse_path_pass_...).  Measured on paths_bwd_sc8 at the config-5 share (257 us): the
+// MFMA loops 82 us, per-chunk staging latency 73 us, staging the constants through LDS and the loop skeleton 46 us.
+#ifndef VG_PBR_WAVES
+#define VG_PBR_WAVES 4
+#endif
+template <int KS>
+__global__ __launch_bounds__(kBlock, VG_PBR_WAVES) void paths_bwd_regs(PathArgs a) {
+    constexpr int SC = 8, Mz = 32, R2 = 2 * SC;
+    extern __shared__ float smf[];
+    __shared__ float red[3][kBlock / VG_WAVE];
+    const int l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = kBlock;
+    const int S = a.S, N = a.N, L = a.L, J = N + Mz;
+    const float iMz = 1.0f / (float)Mz, iN = 1.0f / (float)N;
+    const size_t pl = (size_t)p * L + l;
+    float* cur = smf;
+    auto take = [&](int n) { float* q = cur; cur += (n + 3) & ~3; return q; };      // 16-byte aligned regions
+    float* Gs2 = take(R2 * N);                       // [16][N]      the pair's rows: chunk c at rows 8 c ..
+    float* f0s2 = take(2 * R2 * J);                  // [16][J] prior draws, then [16][J] their d/dell
+    float* hs2 = f0s2 + R2 * J;
+    float* Rs2 = take(R2 * Mz);                      // [16][Mz]
+    float* Es2 = take(R2 * Mz);                      // [16][Mz]
+    float* dRs2 = take(R2 * Mz);                     // [16][Mz]
+    float* dGA = take(5 * R2 * Mz);                  // [5][16][Mz] G A, G A_ell, G A_var, eps C_var^T, eps C_ell^T
+    const bool dell = a.want_dell != 0;
+    const int wv = tid >> 6, lane = tid & 63, i = lane & 15, kk = lane >> 4;
+    // ---- B fragments of every K step, once per workgroup
+    static_assert(2 * KS >= 32, "the wave that forms eps C^T keeps 32 fragments in the same registers");
+    float bA[2 * KS];                                // waves 0-2: plane wv of A4 at rows 4 ks + kk, columns 16 h + i
+    float* bCv = bA;                                 // wave 3 (same registers): (dC/dvar)^T and (dC/dell)^T at rows 4 k8 + kk
+    float* bCe = bA + 16;
+    if (wv < 3) {
+        const float* Ag = reinterpret_cast<const float*>(a.A4 + pl * N * Mz) + wv;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int n = 4 * ks + kk;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float v = Ag[(size_t)(min(n, N - 1) * Mz + 16 * h + i) * 4];
+                bA[2 * ks + h] = n < N ? v : 0.f;
+            }
+        }
+    } else {
+        const float* Cv = a.CT_var + pl * Mz * Mz;
+        const float* Ce = a.CT_ell + pl * Mz * Mz;
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int o = (4 * k8 + kk) * Mz + 16 * h + i;
+                bCv[2 * k8 + h] = Cv[o];
+                const float e = Ce[dell ? o : 0];
+                bCe[2 * k8 + h] = dell ? e : 0.f;
+            }
+    }
+    const int cp_end = min((int)(blockIdx.x + 1) * a.cpw, a.NC);
+    for (int ch0 = blockIdx.x * a.cpw; ch0 < cp_end; ch0 += 2) {
+        const int s_base = ch0 * SC;
+        {
+            vg_stage_rows(Gs2, R2, N, tid, nt, [&](int r) -> const float* {
+                const int s = s_base + r;
+                return s < S ? a.G + (((size_t)p * S + s) * L + l) * N : nullptr;              // zero beyond S
+            });
+            vg_stage_rows(Rs2, R2, Mz, tid, nt, [&](int r) -> const float* {
+                const int s = s_base + r;
+                return s < S ? a.R + (((size_t)p * S + s) * L + l) * Mz : nullptr;
+            });
+            vg_stage_words(Es2, R2 * Mz, tid, nt, [&](int w) -> const void* {
+                const int sl = vg_div(w, iMz), mi = w - sl * Mz, s = s_base + sl;
+                return s < S ? a.eps + (((size_t)p * S + s) * Mz + mi) * L + l : nullptr;
+            });
+            vg_stage_rows(f0s2, 2 * R2, J, tid, nt, [&](int r) -> const float* {
+                const int second = r >= R2, s = min(s_base + (second ? r - R2 : r), S - 1);
+                if (second && !dell) return nullptr;
+                return (second ? a.H : a.F0) + (((size_t)p * S + s) * L + l) * J;
+            });
+        }
+        vg_dma_wait();
+        __syncthreads();
+        // ---- the five products on all sixteen rows
+        if (wv < 3) {
+            float av[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) av[ks] = Gs2[i * N + min(4 * ks + kk, N - 1)];
+            vg_f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)          // (K steps beyond N multiply by the zeros of bA: exact no-ops, no branches)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bA[2 * ks + h], acc[h], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dGA[(wv * R2 + 4 * kk + q) * Mz + 16 * h + i] = acc[h][q];
+        } else {
+            float ev[8];
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) ev[k8] = Es2[i * Mz + 4 * k8 + kk];
+            vg_f32x4_t accv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, acce[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    accv[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[k8], bCv[2 * k8 + h], accv[h], 0, 0, 0);
+                    acce[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[k8], bCe[2 * k8 + h], acce[h], 0, 0, 0);
+                }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    dGA[(3 * R2 + 4 * kk + q) * Mz + 16 * h + i] = accv[h][q];
+                    dGA[(4 * R2 + 4 * kk + q) * Mz + 16 * h + i] = acce[h][q];
+                }
+        }
+        __syncthreads();
+        // ---- per chunk: exactly the element-wise part and the partials of paths_bwd_sc8
+        for (int c = 0; c < 2 && ch0 + c < a.NC; ++c) {
+            const int ch = ch0 + c;
+            const float* Gs = Gs2 + c * SC * N;
+            const float* f0s = f0s2 + c * SC * J;
+            const float* hs = hs2 + c * SC * J;
+            const float* Rs = Rs2 + c * SC * Mz;
+            const float* Es = Es2 + c * SC * Mz;
+            float* dRs = dRs2 + c * SC * Mz;
+            float se = 0.f, sv = 0.f, sr = 0.f;
+            for (int e = tid; e < SC * Mz; e += nt) {
+                const int sl = vg_div(e, iMz), mi = e - sl * Mz;
+                const int o = c * SC * Mz + e;
+                const float d = dGA[o], de = dGA[R2 * Mz + o], dv = dGA[2 * R2 * Mz + o];
+                dRs[e] = d;
+                const float uv = dGA[3 * R2 * Mz + o], ue = dGA[4 * R2 * Mz + o];
+                const float rv = Rs[e];
+                sv += rv * dv + d * uv;
+                se += rv * de + d * ue - d * hs[sl * J + N + mi];
+                sr -= d * f0s[sl * J + N + mi];
+            }
+            for (int e = tid; e < SC * N; e += nt) {
+                const int sl = vg_div(e, iN), n = e - sl * N;
+                const float gv = Gs[e];             // zero for samples beyond S
+                sr = fmaf(gv, f0s[sl * J + n], sr);
+                se = fmaf(gv, hs[sl * J + n], se);
+            }
+            __syncthreads();
+            float* out = a.part + (pl * a.NC + ch) * a.part_len;
+            for (int mi = tid; mi < Mz; mi += nt) {
+                float t = 0.f;
+                for (int sl = 0; sl < SC; ++sl) t += dRs[sl * Mz + mi];
+                vg_stream(out + mi, t);
+            }
+            float* oC = out + Mz;
+            for (int e = tid; e < Mz * Mz; e += nt) {
+                const int mi = vg_div(e, iMz), k = e - mi * Mz;
+                float t = 0.f;
+                for (int sl = 0; sl < SC; ++sl) t = fmaf(dRs[sl * Mz + mi], Es[sl * Mz + k], t);
+                vg_stream(oC + e, t);
+            }
+            se = vg_wave_sum(se); sv = vg_wave_sum(sv); sr = vg_wave_sum(sr);
+            if ((tid & 63) == 0) { red[0][tid >> 6] = se; red[1][tid >> 6] = sv; red[2][tid >> 6] = sr; }
+            __syncthreads();
+            if (tid == 0) {
+                float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+                for (int k = 0; k < (int)(nt >> 6); ++k) { t0 += red[0][k]; t1 += red[1][k]; t2 += red[2][k]; }
+                float* os = oC + (size_t)Mz * Mz;
+                os[0] = t0; os[1] = t1; os[2] = t2; os[3] = 0.f;
+                os[4] = 0.f; os[5] = 0.f; os[6] = 0.f; os[7] = 0.f;      // second set: paths_bwd_split only
+            }
+            __syncthreads();      // `red` and the chunk's rows are reused
+        }
+    }
+}
+
 // The same reverse pass on TWO workgroups per (sample chunk, latent) for launches that leave half the chip idle:
 // a workgroup's time here is the ~100 KB it stages at the ~25 KB/us one CU can pull, and everything downstream is
 // linear in G, so the work splits by COLUMNS of the inducing axis: half h owns columns [h Mz/2, (h+1) Mz/2) of
