@@ -22,6 +22,9 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 #else
 #define VG_STOP(args, k) do { } while (0)
 #endif
+#ifndef VG_PB_MIN_WGS
+#define VG_PB_MIN_WGS 1536    // reverse path pass: chunks per workgroup double while this many workgroups remain (six per CU)
+#endif
 #ifndef VG_BATCH_MERGE
 #define VG_BATCH_MERGE 1      // 0: measurement builds with every small launch of the large-batch schedule on its own
 #endif
@@ -506,7 +509,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     // paths_bwd_sc8: sample chunks per workgroup -- as many as leave six workgroups per CU (the values do not depend on it)
     pa.cpw = 1;
     if (!(what & VGPMP_BWD_ONE_CHUNK))
-        while (pa.cpw < NC && (size_t)P * L * ((NC + 2 * pa.cpw - 1) / (2 * pa.cpw)) >= 1536) pa.cpw *= 2;
+        while (pa.cpw < NC && (size_t)P * L * ((NC + 2 * pa.cpw - 1) / (2 * pa.cpw)) >= VG_PB_MIN_WGS) pa.cpw *= 2;
     const double lik_scale = pb->alpha / (double)d->S_total;
     FinalArgs fa;
     fa.M = M; fa.L = L; fa.NC = NC; fa.nblk = P ? vg_loglik_blocks_per_problem(S, N) : 0; fa.part_len = vg_part_len(d);
