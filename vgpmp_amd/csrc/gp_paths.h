@@ -661,16 +661,13 @@ __global__ __launch_bounds__(kBlock, VG_PBR_WAVES) void paths_bwd_regs(PathArgs 
                 vg_stream(out + mi, t);
             }
             float* oC = out + Mz;
-            {   // dC = dR^T eps of the chunk: thread (mi, four adjacent k) -- the same fma chain per element, a quarter of the LDS reads
-                const int mi = tid >> 3, k0 = (tid & 7) * 4;
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int sl = 0; sl < SC; ++sl) {
-                    const float dr = dRs[sl * Mz + mi];
-                    const float4 ev = *reinterpret_cast<const float4*>(Es + sl * Mz + k0);
-                    t.x = fmaf(dr, ev.x, t.x); t.y = fmaf(dr, ev.y, t.y); t.z = fmaf(dr, ev.z, t.z); t.w = fmaf(dr, ev.w, t.w);
-                }
-                vg_stream(reinterpret_cast<float4*>(oC + mi * Mz + k0), t);
+            // (one element per thread and pass: a (mi, four adjacent k) form with float4 reads of eps and one 16-byte store per
+            //  thread measured SLOWER, 145 vs 130 us at the config-5 share)
+            for (int e = tid; e < Mz * Mz; e += nt) {
+                const int mi = vg_div(e, iMz), k = e - mi * Mz;
+                float t = 0.f;
+                for (int sl = 0; sl < SC; ++sl) t = fmaf(dRs[sl * Mz + mi], Es[sl * Mz + k], t);
+                vg_stream(oC + e, t);
             }
             se = vg_wave_sum(se); sv = vg_wave_sum(sv); sr = vg_wave_sum(sr);
             if ((tid & 63) == 0) { red[0][tid >> 6] = se; red[1][tid >> 6] = sv; red[2][tid >> 6] = sr; }
