@@ -417,9 +417,6 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
     return -0.5f * acc;
 }
 
-#ifndef VG_LIK_XCD
-#define VG_LIK_XCD 1
-#endif
 constexpr int kLikBlock = 128;
 constexpr int kLikBatchBlock = 64;
 constexpr int kLikBatchU = 8;           // sphere gathers in flight per lane in the batch form
@@ -452,8 +449,7 @@ __global__ __launch_bounds__(BLK, REGS ? 2 : 1) void loglik_paths_kernel(const v
                                                                   float* __restrict__ lik_partial, int dbg,
                                                                   const float* __restrict__ alpha_eff = nullptr,
                                                                   const float* __restrict__ sigma_eff = nullptr,
-                                                                  float* __restrict__ sig_partial = nullptr,
-                                                                  int nblk = 0, int P = 0) {
+                                                                  float* __restrict__ sig_partial = nullptr) {
     static_assert(LPC == 1, "one lane per configuration");
     static_assert(!SIG || BLK == VG_WAVE, "per-sphere sums of a workgroup are one wave's sums");
     extern __shared__ float lik_lds[];
@@ -462,19 +458,10 @@ __global__ __launch_bounds__(BLK, REGS ? 2 : 1) void loglik_paths_kernel(const v
     if (dbg == 1) return;
 #endif
     constexpr int CPB = BLK / LPC;                 // configurations per workgroup
-    // nblk > 0: a one-dimensional grid of nblk x (P rounded up to 8) workgroups dealt so that ALL workgroups of a problem run
-    // behind ONE XCD's L2 (workgroups go to the XCDs round robin: hardware index h sits on XCD h % 8): the samples and time
-    // steps of a problem visit the same bricks of the voxel table, and spread over the eight L2s every XCD fetched them again
-    int bxr = blockIdx.x, pbr = blockIdx.y, nbr = gridDim.x;
-    if (nblk > 0) {
-        const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
-        pbr = x + 8 * (k / nblk); bxr = k % nblk; nbr = nblk;
-        if (pbr >= P) return;
-    }
-    const int pb = pbr, bx = bxr;
-    VG_T(bx == 0 && pb == 0, 400);
+    const int pb = blockIdx.y;
+    VG_T(blockIdx.x == 0 && pb == 0, 400);
     const int cl = threadIdx.x / LPC, sub = threadIdx.x % LPC;
-    const int idx = bx * CPB + cl;
+    const int idx = blockIdx.x * CPB + cl;
     const bool live = idx < S * N;
     float lp = 0.f;
     {
@@ -485,7 +472,7 @@ __global__ __launch_bounds__(BLK, REGS ? 2 : 1) void loglik_paths_kernel(const v
         const LikScratch sc{lik_lds + cl, CPB};
         float* dgdf = lik_lds + (size_t)lik_scratch_slots(L) * CPB + cl;   // [L][CPB]
         const float scl = SIG ? -alpha_eff[pb] : scale;
-        float* sp = SIG ? sig_partial + ((size_t)pb * nbr + bx) * VGPMP_MAX_SPHERES : nullptr;
+        float* sp = SIG ? sig_partial + ((size_t)pb * gridDim.x + blockIdx.x) * VGPMP_MAX_SPHERES : nullptr;
         auto raw_f = [&](int j) { return f[base + (size_t)j * N]; };
         const float* sigp = SIG ? sigma_eff + (size_t)pb * VGPMP_MAX_SPHERES : nullptr;
         auto put_sig = [&](int q, float t) { if (threadIdx.x == 0) sp[q] = t; };
@@ -520,10 +507,10 @@ __global__ __launch_bounds__(BLK, REGS ? 2 : 1) void loglik_paths_kernel(const v
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < BLK / VG_WAVE; ++k) t += red[k];
-        lik_partial[(size_t)pb * nbr + bx] = t;
+        lik_partial[(size_t)pb * gridDim.x + blockIdx.x] = t;
     }
-    VG_T(bx == 0 && pb == 0, 401);
-    VG_T(bx == nbr - 1 && pb == 0, 405);
+    VG_T(blockIdx.x == 0 && pb == 0, 401);
+    VG_T(blockIdx.x == gridDim.x - 1 && pb == 0, 405);
 }
 
 // ---- ELBO path, few-problem form ---------------------------------------------------------------------
@@ -957,17 +944,11 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
         };
         return sig ? go(loglik_paths_wide_kernel<8, true>) : go(loglik_paths_wide_kernel<8, false>);
     }
-    // eight problems or more: a problem's workgroups behind one XCD's L2 (see the kernel)
-    const bool xcd = VG_LIK_XCD && P >= 8;
     auto go = [&](auto kern) {
         int rc = vg_grant_dyn_lds((const void*)kern, lds);
         if (rc) return rc;
-        if (xcd)
-            hipExtLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)((P + 7) & ~7)), dim3(kLikBatchBlock), lds, st, k0, k1, 0, rb, *sdf, f, S,
-                                  L, N, scale, G, logp, lik_partial, dbg, alpha_eff, sigma_eff, sig_partial, nblk, P);
-        else
-            hipExtLaunchKernelGGL(kern, dim3(nblk, P), dim3(kLikBatchBlock), lds, st, k0, k1, 0, rb, *sdf, f, S, L, N, scale, G, logp,
-                                  lik_partial, dbg, alpha_eff, sigma_eff, sig_partial, 0, 0);
+        hipExtLaunchKernelGGL(kern, dim3(nblk, P), dim3(kLikBatchBlock), lds, st, k0, k1, 0, rb, *sdf, f, S, L, N, scale, G, logp,
+                              lik_partial, dbg, alpha_eff, sigma_eff, sig_partial);
         return (int)hipGetLastError();
     };
     const bool regs = L <= 15 && form != 2;              // per-frame sums in registers (form 2, measurement: in LDS)
