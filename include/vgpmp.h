@@ -259,6 +259,14 @@ int vgpmp_fk_spheres(const vgpmp_robot* dev_robot, const float* dev_q, int64_t n
 int vgpmp_sdf_query(const vgpmp_sdf* sdf, const double* dev_rel_pos, int64_t n,
                     int32_t* dev_idx, float* dev_dist, float* dev_grad, vgpmp_stream stream);
 
+/* The voxel indices the ELBO kernels themselves compute (utils/sdf_utils.py:62-66 on float32 sphere centres in the robot
+ * frame, `host_scene_offset` [3] subtracted in float64 as likelihoods/likelihood.py:146-176 does): float32 quotient, and
+ * the reference's float64 index without a division wherever that quotient is within its error of a cell boundary.  For the
+ * parity tests: idx [n,3] int32 must equal clip(trunc(((double(pos) - offset) - origin) / delta), 0, n - 1) bit for bit.
+ * A first component < 0 flags a disagreement between the kernels' two index forms (-1 - index). */
+int vgpmp_sdf_index_f32(const vgpmp_sdf* sdf, const double* host_scene_offset, const float* dev_pos, int64_t n,
+                        int32_t* dev_idx, vgpmp_stream stream);
+
 /* VariationalMonteCarloLikelihood.log_prob (likelihoods/likelihood.py:57-176) on joint angles
  * g [n, dof]: logp [n] and, if dev_dlogp_dg != NULL, its gradient [n, dof]. */
 int vgpmp_log_prob(const vgpmp_robot* dev_robot, int32_t dof, const vgpmp_sdf* sdf, const float* dev_g,

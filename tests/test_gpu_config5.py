@@ -236,3 +236,39 @@ def test_batch_form_of_the_likelihood_against_oracle_on_every_robot_shape(robot)
     for other in ("regs+summary", "lds", "lds+summary"):
         for a, b in zip(outs["regs"], outs[other]):
             assert torch.equal(a, b), other
+
+
+@pytest.mark.parametrize("n,delta,origin,offset", [(512, 2.0 / 512, (-1.0, -1.0, -1.0), (0.0, 0.0, 0.0)),        # config 5: a power of two
+                                                   (130, 0.0125, (-0.9125, -0.96, -0.49), (-0.2, 0.0, -0.2)),       # the industrial grid
+                                                   (96, 0.025, (-1.2, -1.2, -0.6), (0.62, -0.15, 0.834)),           # bookshelves offset
+                                                   (40, 0.03, (-0.4, 0.1, -1.0), (0.05, -0.03, 0.02))])
+def test_kernel_index_path_is_the_reference_index_on_cell_boundaries(n, delta, origin, offset):
+    """The ELBO kernels' own voxel index (float32 quotient; near a cell boundary the reference's float64 index WITHOUT the
+    division, csrc/fk_sdf.hip::voxel_axis_near) against utils/sdf_utils.py:62-66 evaluated in float64 NumPy on the same
+    float32 sphere centres: bit-exact on random points, on lattice points, and on the float32 neighbours (+- 1..3 ulps) of
+    every kind of boundary -- where the quotient rounds up to an integer, where it stays just below one, at the clamps."""
+    rng = np.random.default_rng(7)
+    origin, offset = np.array(origin, dtype=np.float64), np.array(offset, dtype=np.float64)
+    data = np.zeros((n, 8, 8))
+    spec = rb.load_robot("franka")
+    shape3 = np.array([n, 8, 8])
+    sc = _engine().DeviceScene(spec, (data, origin, delta), offset, layout="brick")
+    ext = delta * shape3
+    rnd = (offset + origin + rng.uniform(-0.1, 1.1, (200000, 3)) * ext).astype(np.float32)
+    k = rng.integers(-2, shape3 + 3, (60000, 3))
+    lat = (offset + origin + delta * k).astype(np.float32)                         # the float32 nearest a boundary
+    near = [np.nextafter(lat, np.float32(np.inf) * s) for s in (1, -1)]
+    near2 = [np.nextafter(np.nextafter(lat, np.float32(np.inf) * s), np.float32(np.inf) * s) for s in (1, -1)]
+    tiny = (lat.astype(np.float64) * (1 + rng.uniform(-3e-7, 3e-7, lat.shape))).astype(np.float32)
+    pos = np.concatenate([rnd, lat] + near + near2 + [tiny])
+    p64 = pos.astype(np.float64)
+    q = ((p64 - offset) - origin) / delta                                          # sdf_utils.py:62-66, float64
+    want = np.clip(np.trunc(q), 0, shape3 - 1).astype(np.int64)
+    got = sc.sdf_index_f32(torch.tensor(pos)).cpu().numpy().astype(np.int64)
+    assert (got[:, 0] >= 0).all(), "the two index forms of the kernels disagree"
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, (bad[:5], pos[bad[:5]], got[bad[:5]], want[bad[:5]], q[bad[:5]])
+    # the boundary cases were really there: quotients within 1e-9 of an integer on both sides, and exact integers
+    frac = np.abs(q - np.rint(q))
+    assert (frac == 0).sum() > 100 or delta != 2.0 / 512
+    assert ((frac > 0) & (frac < 1e-6)).sum() > 1000

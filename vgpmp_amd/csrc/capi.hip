@@ -99,6 +99,14 @@ int vgpmp_sdf_query(const vgpmp_sdf* sdf, const double* dev_rel_pos, int64_t n, 
     return vg_launch_sdf_query(sdf, dev_rel_pos, n, dev_idx, dev_dist, dev_grad, (hipStream_t)stream);
 }
 
+int vgpmp_sdf_index_f32(const vgpmp_sdf* sdf, const double* host_scene_offset, const float* dev_pos, int64_t n, int32_t* dev_idx,
+                        vgpmp_stream stream) {
+    int rc = check_sdf(sdf);
+    if (rc) return rc;
+    if (!host_scene_offset || (n > 0 && (!dev_pos || !dev_idx)) || n < 0) return VGPMP_E_ARG;
+    return vg_launch_sdf_index_f32(sdf, host_scene_offset, dev_pos, n, dev_idx, (hipStream_t)stream);
+}
+
 int vgpmp_log_prob(const vgpmp_robot* dev_robot, int32_t dof, const vgpmp_sdf* sdf, const float* dev_g, int64_t n,
                    float* dev_logp, float* dev_dlogp_dg, vgpmp_stream stream) {
     int rc = check_sdf(sdf);

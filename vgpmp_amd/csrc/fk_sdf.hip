@@ -46,13 +46,33 @@ __device__ __forceinline__ SdfFast make_fast(const vg_sdf_dev& s, double offx, d
     return f;
 }
 
+// The reference index clamp(trunc(RN(num / delta)), 0, n - 1), num = (p - offset) - origin in float64, when the float32
+// quotient q is known to lie within its error bound of the integer m = rint(q) -- WITHOUT the float64 division (25
+// dependent float64 instructions; one lane of a wave near a cell boundary sends all 64 through this path, ~13 % of the
+// sphere iterations at 512 cells per axis).  RN(num / delta) >= m  <=>  num / delta >= m - u, u = half the distance from m
+// to the float64 below it (no float64 lies strictly between m - 2u and m, and a quotient exactly on m - u would need
+// num = delta (m - u), 100+ significant bits) <=>  num - m delta >= -u delta: ONE fma (exact difference, rounded once:
+// sign and size right to 2^-53 relative) against a power-of-two multiple of delta.  m <= 0 gives 0 (the quotient is below 1),
+// m >= n gives n - 1.  Pinned bit for bit on lattice points +- a few float32 ulps by tests/test_gpu_config5.py.
+__device__ __forceinline__ int voxel_axis_near(double num, double delta, float q, int n) {
+    const float mf = rintf(q);
+    const int m = (int)mf;
+    const uint32_t fb = __builtin_bit_cast(uint32_t, mf);
+    // u delta = 2^(e - 53 - [m is a power of two]) delta, e = floor(log2 m): a float64 with that exponent, mantissa 0
+    const int ue = (int)(fb >> 23) - 127 - 53 - ((fb & 0x7fffffu) == 0u ? 1 : 0);
+    const double u = __hiloint2double((ue + 1023) << 20, 0);
+    const double r = fma(-(double)mf, delta, num);
+    const int idx = m - (r >= -(u * delta) ? 0 : 1);
+    return m <= 0 ? 0 : (m >= n ? n - 1 : idx);
+}
+
 __device__ __forceinline__ int voxel_axis(float pos, float ch, float cl, float inv_delta, int n, double off,
                                           double origin, double delta) {
     const float q = ((pos - ch) - cl) * inv_delta;
     const int hi = n - 1;
     int idx = q < 0.f ? 0 : (q > (float)hi ? hi : (int)q);
     if (fabsf(q - rintf(q)) < 1e-6f * (fabsf(q) + 1.f))
-        idx = vg_voxel_axis((double)pos - off, origin, delta, n);      // exact reference expression
+        idx = voxel_axis_near(((double)pos - off) - origin, delta, q, n);      // the reference's index, exactly
     return idx;
 }
 
@@ -141,9 +161,11 @@ __device__ __forceinline__ Vox3 voxel3(vg_float3 p, const SdfFast& fs, const vg_
     const float ey = fabsf(qy - rintf(qy)) - fmaf(1.1e-6f, fabsf(qy), 1.1e-6f);
     const float ez = fabsf(qz - rintf(qz)) - fmaf(1.1e-6f, fabsf(qz), 1.1e-6f);
     if (fminf(ex, fminf(ey, ez)) < 0.f) {
-        o.ix = vg_voxel_axis((double)p.x - offx, s.ox, s.delta, s.nx);      // exact reference expression
-        o.iy = vg_voxel_axis((double)p.y - offy, s.oy, s.delta, s.ny);
-        o.iz = vg_voxel_axis((double)p.z - offz, s.oz, s.delta, s.nz);
+        // some axis sits within the float32 error of a cell boundary: the reference's float64 index, exactly, on the axes
+        // concerned (voxel_axis_near); the others keep theirs
+        if (ex < 0.f) o.ix = voxel_axis_near(((double)p.x - offx) - s.ox, s.delta, qx, s.nx);
+        if (ey < 0.f) o.iy = voxel_axis_near(((double)p.y - offy) - s.oy, s.delta, qy, s.ny);
+        if (ez < 0.f) o.iz = voxel_axis_near(((double)p.z - offz) - s.oz, s.delta, qz, s.nz);
     }
     return o;
 }
@@ -808,6 +830,22 @@ __global__ __launch_bounds__(kBlock) void sdf_query_kernel(vgpmp_sdf sdfh, const
     if (grad) { grad[3 * i] = v.y; grad[3 * i + 1] = v.z; grad[3 * i + 2] = v.w; }
 }
 
+// the ELBO kernels' own index path (voxel3) on float32 positions in the robot frame: test entry vgpmp_sdf_index_f32
+__global__ __launch_bounds__(kBlock) void sdf_index_f32_kernel(vgpmp_sdf sdfh, double offx, double offy, double offz,
+                                                                const float* __restrict__ pos, int64_t n, int32_t* __restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const vg_sdf_dev sdf = load_sdf(sdfh);
+    const SdfFast fs = make_fast(sdf, offx, offy, offz);
+    const Vox3 v = voxel3(vg_make3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]), fs, sdf, offx, offy, offz);
+    idx[3 * i] = v.ix; idx[3 * i + 1] = v.iy; idx[3 * i + 2] = v.iz;
+    // the eight-lane form's per-axis path must agree
+    const int ax = voxel_axis(pos[3 * i], fs.chx, fs.clx, fs.inv_delta, sdf.nx, offx, sdf.ox, sdf.delta);
+    const int ay = voxel_axis(pos[3 * i + 1], fs.chy, fs.cly, fs.inv_delta, sdf.ny, offy, sdf.oy, sdf.delta);
+    const int az = voxel_axis(pos[3 * i + 2], fs.chz, fs.clz, fs.inv_delta, sdf.nz, offz, sdf.oz, sdf.delta);
+    if (ax != v.ix || ay != v.iy || az != v.iz) idx[3 * i] = -1 - idx[3 * i];
+}
+
 // ---- voxel table: {d, gx, gy, gz} from float64 rows of the grid (utils/sdf_utils.py:100-136) -------
 // One lane per table ELEMENT (so the 16-byte stores of a wave are 1 KiB contiguous under both layouts); under
 // BRICK4 a wave is exactly one brick and also leaves the brick's smallest distance.
@@ -890,6 +928,13 @@ int vg_launch_fk_spheres(const vgpmp_robot* rb, const float* q, int64_t n, float
     if (n == 0) return 0;
     hipLaunchKernelGGL(fk_spheres_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, rb, q, n,
                        pos, frames);
+    return (int)hipGetLastError();
+}
+
+int vg_launch_sdf_index_f32(const vgpmp_sdf* sdf, const double* offset, const float* pos, int64_t n, int32_t* idx, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(sdf_index_f32_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, *sdf, offset[0],
+                       offset[1], offset[2], pos, n, idx);
     return (int)hipGetLastError();
 }
 

@@ -148,6 +148,15 @@ class DeviceScene:
                                             capi.ptr(grad), self._stream()), "vgpmp_sdf_query")
         return idx, dist, grad
 
+    def sdf_index_f32(self, pos: torch.Tensor) -> torch.Tensor:
+        """Voxel indices [n, 3] of float32 sphere centres in the robot frame by the ELBO kernels' own index path (tests)."""
+        pos = pos.to(self.device, torch.float32).contiguous().reshape(-1, 3)
+        idx = torch.empty((pos.shape[0], 3), dtype=torch.int32, device=self.device)
+        off = (C.c_double * 3)(*[float(v) for v in self.scene_offset])
+        capi.check(self.lib.vgpmp_sdf_index_f32(C.byref(self.sdf), off, capi.ptr(pos), pos.shape[0], capi.ptr(idx), self._stream()),
+                   "vgpmp_sdf_index_f32")
+        return idx
+
     def log_prob(self, g: torch.Tensor, want_grad: bool = False):
         """VariationalMonteCarloLikelihood.log_prob on joint angles g [..., dof]."""
         shape = g.shape[:-1]
