@@ -264,7 +264,7 @@ int vgpmp_sdf_query(const vgpmp_sdf* sdf, const double* dev_rel_pos, int64_t n,
  * the reference's float64 index without a division wherever that quotient is within its error of a cell boundary.  For the
  * parity tests: idx [n,3] int32 must equal clip(trunc(((double(pos) - offset) - origin) / delta), 0, n - 1) bit for bit.
  * A first component < 0 flags a disagreement between the kernels' two index forms (-1 - index). */
-int vgpmp_sdf_index_f32(const vgpmp_sdf* sdf, const double* host_scene_offset, const float* dev_pos, int64_t n,
+int vgpmp_sdf_index_float(const vgpmp_sdf* sdf, const double* host_scene_offset, const float* dev_pos, int64_t n,
                         int32_t* dev_idx, vgpmp_stream stream);
 
 /* VariationalMonteCarloLikelihood.log_prob (likelihoods/likelihood.py:57-176) on joint angles

@@ -23,7 +23,7 @@ GEMM_DIRECT, NO_SPLIT, ELIM_BLOCK, LIK_LANES, LIK_LDS_STATE, COV_ONLY, NO_FUSE_P
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvgpmp_hip.so"
 
-EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_table_bytes", "vgpmp_sdf_pack", "vgpmp_mesh_sdf", "vgpmp_fk_spheres", "vgpmp_sdf_query", "vgpmp_sdf_index_f32",
+EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_table_bytes", "vgpmp_sdf_pack", "vgpmp_mesh_sdf", "vgpmp_fk_spheres", "vgpmp_sdf_query", "vgpmp_sdf_index_float",
            "vgpmp_log_prob", "vgpmp_cov_matrices", "vgpmp_kernel_derivative", "vgpmp_velocity_kuu_kuf", "vgpmp_workspace_bytes", "vgpmp_lik_scratch_bytes", "vgpmp_inducing_scratch_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
            "vgpmp_elbo_steps", "vgpmp_elbo_step_profiled", "vgpmp_adam_step", "vgpmp_workspace_view", "vgpmp_sample_paths",
            "vgpmp_comm_unique_id", "vgpmp_comm_init", "vgpmp_allreduce_grads", "vgpmp_comm_destroy")
@@ -131,7 +131,7 @@ def load(require: bool = True) -> Optional[C.CDLL]:
         "vgpmp_mesh_sdf": [vp, vp, i32, i32, i32, i32, P(C.c_double), dbl, vp, vp],
         "vgpmp_fk_spheres": [vp, vp, i64, vp, vp, vp],
         "vgpmp_sdf_query": [P(Sdf), vp, i64, vp, vp, vp, vp],
-        "vgpmp_sdf_index_f32": [P(Sdf), C.POINTER(C.c_double), vp, i64, vp, vp],
+        "vgpmp_sdf_index_float": [P(Sdf), C.POINTER(C.c_double), vp, i64, vp, vp],
         "vgpmp_log_prob": [vp, i32, P(Sdf), vp, i64, vp, vp, vp],
         "vgpmp_cov_matrices": [i32, vp, i32, vp, i32, i32, vp, vp, dbl, vp, vp],
         "vgpmp_kernel_derivative": [i32, i32, vp, i32, vp, i32, dbl, dbl, vp, vp],

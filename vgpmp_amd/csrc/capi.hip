@@ -99,7 +99,7 @@ int vgpmp_sdf_query(const vgpmp_sdf* sdf, const double* dev_rel_pos, int64_t n, 
     return vg_launch_sdf_query(sdf, dev_rel_pos, n, dev_idx, dev_dist, dev_grad, (hipStream_t)stream);
 }
 
-int vgpmp_sdf_index_f32(const vgpmp_sdf* sdf, const double* host_scene_offset, const float* dev_pos, int64_t n, int32_t* dev_idx,
+int vgpmp_sdf_index_float(const vgpmp_sdf* sdf, const double* host_scene_offset, const float* dev_pos, int64_t n, int32_t* dev_idx,
                         vgpmp_stream stream) {
     int rc = check_sdf(sdf);
     if (rc) return rc;

@@ -830,7 +830,7 @@ __global__ __launch_bounds__(kBlock) void sdf_query_kernel(vgpmp_sdf sdfh, const
     if (grad) { grad[3 * i] = v.y; grad[3 * i + 1] = v.z; grad[3 * i + 2] = v.w; }
 }
 
-// the ELBO kernels' own index path (voxel3) on float32 positions in the robot frame: test entry vgpmp_sdf_index_f32
+// the ELBO kernels' own index path (voxel3) on float32 positions in the robot frame: test entry vgpmp_sdf_index_float
 __global__ __launch_bounds__(kBlock) void sdf_index_f32_kernel(vgpmp_sdf sdfh, double offx, double offy, double offz,
                                                                 const float* __restrict__ pos, int64_t n, int32_t* __restrict__ idx) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;

@@ -153,8 +153,8 @@ class DeviceScene:
         pos = pos.to(self.device, torch.float32).contiguous().reshape(-1, 3)
         idx = torch.empty((pos.shape[0], 3), dtype=torch.int32, device=self.device)
         off = (C.c_double * 3)(*[float(v) for v in self.scene_offset])
-        capi.check(self.lib.vgpmp_sdf_index_f32(C.byref(self.sdf), off, capi.ptr(pos), pos.shape[0], capi.ptr(idx), self._stream()),
-                   "vgpmp_sdf_index_f32")
+        capi.check(self.lib.vgpmp_sdf_index_float(C.byref(self.sdf), off, capi.ptr(pos), pos.shape[0], capi.ptr(idx), self._stream()),
+                   "vgpmp_sdf_index_float")
         return idx
 
     def log_prob(self, g: torch.Tensor, want_grad: bool = False):
