@@ -146,6 +146,9 @@ __device__ __forceinline__ void lik_wave_sync() {
 // The three axis quotients in float32, clamp + truncate, and ONE test for "some quotient is within its error bound
 // of an integer" that sends the query through the reference's float64 expression (all three axes): a few 1e-3 of
 // the queries.  Indices stay bit-identical to utils/sdf_utils.py:62-66.
+#ifndef VG_VOX_DIV
+#define VG_VOX_DIV 0
+#endif
 struct Vox3 { int ix, iy, iz; };
 __device__ __forceinline__ Vox3 voxel3(vg_float3 p, const SdfFast& fs, const vg_sdf_dev& s, double offx, double offy,
                                        double offz) {
@@ -163,9 +166,15 @@ __device__ __forceinline__ Vox3 voxel3(vg_float3 p, const SdfFast& fs, const vg_
     if (fminf(ex, fminf(ey, ez)) < 0.f) {
         // some axis sits within the float32 error of a cell boundary: the reference's float64 index, exactly, on the axes
         // concerned (voxel_axis_near); the others keep theirs
+#if VG_VOX_DIV      // measurement: the round-2 form, three float64 divisions
+        o.ix = vg_voxel_axis((double)p.x - offx, s.ox, s.delta, s.nx);
+        o.iy = vg_voxel_axis((double)p.y - offy, s.oy, s.delta, s.ny);
+        o.iz = vg_voxel_axis((double)p.z - offz, s.oz, s.delta, s.nz);
+#else
         if (ex < 0.f) o.ix = voxel_axis_near(((double)p.x - offx) - s.ox, s.delta, qx, s.nx);
         if (ey < 0.f) o.iy = voxel_axis_near(((double)p.y - offy) - s.oy, s.delta, qy, s.ny);
         if (ez < 0.f) o.iz = voxel_axis_near(((double)p.z - offz) - s.oz, s.delta, qz, s.nz);
+#endif
     }
     return o;
 }
