@@ -418,14 +418,18 @@ int vg_launch_adam(const vgpmp_dims* d, const vgpmp_params* x, const vgpmp_param
                    const vgpmp_params* av, int trainable, double lr, int t, hipStream_t st) {
     const size_t P = d->num_problems, L = d->L, M = d->M;
     const double lr_t = adam_lr_t(lr, t);
+    AdamAllArgs aa;
+    aa.nseg = 0; aa.lr_t = lr_t; aa.first_block[0] = 0;
     auto go = [&](size_t n, double* xx, const double* gg, double* mm, double* vv, int tril) {
-        hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, n, xx, gg, mm,
-                           vv, lr_t, tril);
+        const int k = aa.nseg++;
+        aa.n[k] = n; aa.x[k] = xx; aa.g[k] = gg; aa.m[k] = mm; aa.v[k] = vv; aa.tril_M[k] = tril;
+        aa.first_block[k + 1] = aa.first_block[k] + (unsigned)((n + kBlock - 1) / kBlock);
     };
     if (trainable & VGPMP_TRAIN_Q_MU) go(P * L * M, x->q_mu, g->q_mu, am->q_mu, av->q_mu, 0);
     if (trainable & VGPMP_TRAIN_Q_SQRT) go(P * L * M * M, x->q_sqrt, g->q_sqrt, am->q_sqrt, av->q_sqrt, (int)M);
     if (trainable & VGPMP_TRAIN_LENGTHSCALES) go(P * L, x->raw_ell, g->raw_ell, am->raw_ell, av->raw_ell, 0);
     if (trainable & VGPMP_TRAIN_KERNEL_VARIANCE) go(P * L, x->raw_var, g->raw_var, am->raw_var, av->raw_var, 0);
+    if (aa.nseg > 0 && aa.first_block[aa.nseg] > 0) hipLaunchKernelGGL(adam_all_kernel, dim3(aa.first_block[aa.nseg]), dim3(kBlock), 0, st, aa);
     return (int)hipGetLastError();
 }
 
@@ -633,10 +637,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const size_t lds_midC = lds_cov_b > lds_tg1 ? lds_cov_b : lds_tg1;
     const void* fn_midC = backward ? (const void*)mid_cov_b_gemm_kernel<true> : (const void*)mid_cov_b_gemm_kernel<false>;
     if (mid && (rc = set_dyn_lds(fn_midC, lds_midC))) return rc;
-    if (!fused) {      // (the large-batch schedule merges its small launches with these two as well)
-        if ((rc = set_dyn_lds((const void*)mid_cov_a_rng_kernel, lds_cov_a))) return rc;
-        if ((rc = set_dyn_lds((const void*)mid_hyper_final_kernel, lds_fin))) return rc;
-    }
+    if (!fused && (rc = set_dyn_lds((const void*)mid_cov_a_rng_kernel, lds_cov_a))) return rc;      // (the large-batch schedule merges its small launches with these two as well)
+    if ((rc = set_dyn_lds((const void*)mid_hyper_final_kernel, lds_fin))) return rc;
     const dim3 cov_b_grid(3 + (N + kRowTile - 1) / kRowTile, L, P);
     const uint32_t eps_gx = (2u * (uint32_t)S * Mz * L + kBlock - 1) / kBlock;
     const uint32_t basis_gx = ((uint32_t)L * B + kBlock - 1) / kBlock;
@@ -688,7 +690,12 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         if (fused) {
             // noise of the first step of a call: everything up front; afterwards eps rides in stage 1 and the
             // prior noise of step i was drawn by stage 3 of step i-1
-            if (gen && first && (rc = vg_launch_rng(d, nz, seed, problem_base, step_i, ctr, st))) return rc;
+            // (VGPMP_NOISE_READY: a previous call's stage 3 drew this step's omega, beta, w already -- only eps is missing and
+            //  rides in stage 1; VGPMP_NOISE_AHEAD: stage 3 of this call's last step draws the next call's.  The sample-sharded
+            //  step is one call per step with an all-reduce in between: without these it paid two noise launches per step.)
+            const bool ready = !first || (what & VGPMP_NOISE_READY);
+            const bool ahead = more || (what & VGPMP_NOISE_AHEAD);
+            if (gen && !ready && (rc = vg_launch_rng(d, nz, seed, problem_base, step_i, ctr, st))) return rc;
             // steps after the first of a call: the hyper-parameter update of the previous step is a prologue of the
             // cov_a and feature roles, its q_mu / q_sqrt update (final) another role of the same launch
             const bool prologue = !first && backward;
@@ -706,7 +713,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             s1.fin_split = fin_split ? 1 : 0;
             s1.n_fin = first ? 0 : L * P * (fin_split ? kFinSplit : 1);
             s1.eps_gx = (int)eps_gx;
-            s1.n_eps = (gen && !first) ? (int)eps_gx * P : 0;
+            s1.n_eps = (gen && ready) ? (int)eps_gx * P : 0;
             s1.feat_gx = (int)feat_grid.x; s1.feat_gy = (int)feat_grid.y;
             s1.n_feat = (int)(feat_grid.x * feat_grid.y * feat_grid.z);
             const unsigned n1 = s1.n_cov + s1.n_fin + s1.n_eps + feat_grid.x * feat_grid.y * feat_grid.z;
@@ -730,8 +737,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             s3.n_path = NC * pa.nsplit * L * P;
             s3.path.xcd_span = VG_XCD_PATHS && s3.n_path % 8 == 0 ? s3.n_path / 8 : 0;
             s3.basis_gx = (int)basis_gx; s3.w_gx = (int)w_gx;
-            s3.n_basis = (gen && more) ? (int)basis_gx * P : 0;
-            const unsigned n3 = s3.n_path + s3.n_basis + ((gen && more) ? w_gx * P : 0u);
+            s3.n_basis = (gen && ahead) ? (int)basis_gx * P : 0;
+            const unsigned n3 = s3.n_path + s3.n_basis + ((gen && ahead) ? w_gx * P : 0u);
             if ((rc = launch(fn_s3, dim3(n3), &s3, lds_pf))) return rc;
         } else if (mid) {
             // cov_a | noise draws;  features;  cov_b | tiled GEMM
@@ -911,13 +918,13 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             hipLaunchKernelGGL(lik_update_kernel, dim3(P), dim3(VGPMP_MAX_SPHERES), 0, st, lu);
         }
         mark();
-        if (mid || batch_merged) {
+        if (mid || batch_merged || (fused && !more)) {      // (fused, more steps to come: both ride in stage 1 of the next step)
             MidGArgs mg;
             hy.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
             fa.lr_t = hy.lr_t;
             mg.hy = hy; mg.fin = fa; mg.n_hyper = P;
             if ((rc = launch((const void*)mid_hyper_final_kernel, dim3(P + L * P * (fin_split_batch ? kFinSplit : 1)), &mg, lds_fin))) return rc;
-        } else if (!(fused && more)) {      // otherwise both ride in stage 1 of the next step
+        } else if (!fused) {
             hy.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
             fa.lr_t = hy.lr_t;
             hipLaunchKernelGGL(hyper_kernel, dim3(P), dim3(64), 0, st, hy);

@@ -475,17 +475,29 @@ __global__ __launch_bounds__(kBlock) void elbo_pieces_kernel(int L, int nblk, co
     elbo_pieces(lik_partial, nblk, kl_l, L, blockIdx.x, alpha_fin ? alpha_fin[blockIdx.x] : lik_scale, kls, out_lik, out_kl);
 }
 
-// stand-alone Adam over the packed variables (sample-sharded mode, after the gradient all-reduce)
-__global__ __launch_bounds__(kBlock) void adam_kernel(size_t n, double* __restrict__ x, const double* __restrict__ g,
-                                                       double* __restrict__ m, double* __restrict__ v, double lr_t,
-                                                       int tril_M) {
-    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    if (tril_M > 0) {
-        int e = (int)(i % ((size_t)tril_M * tril_M));
-        if (e % tril_M > e / tril_M) return;
+// stand-alone Adam over the packed variables (sample-sharded mode, after the gradient all-reduce): ONE launch for the
+// (up to) four tensors -- the blocks of segment k follow those of segment k - 1 (four launches cost ~8 us each on the
+// one-problem step of BASELINE config 4, more than the update itself)
+struct AdamAllArgs {
+    int nseg;
+    unsigned first_block[5];      // segment k owns blocks [first_block[k], first_block[k + 1])
+    size_t n[4];
+    double *x[4], *m[4], *v[4];
+    const double* g[4];
+    int tril_M[4];
+    double lr_t;
+};
+__global__ __launch_bounds__(kBlock) void adam_all_kernel(AdamAllArgs a) {
+    int k = 0;
+    while (k + 1 < a.nseg && blockIdx.x >= a.first_block[k + 1]) ++k;
+    const size_t i = (size_t)(blockIdx.x - a.first_block[k]) * kBlock + threadIdx.x;
+    if (i >= a.n[k]) return;
+    const int M = a.tril_M[k];
+    if (M > 0) {
+        const int e = (int)(i % ((size_t)M * M));
+        if (e % M > e / M) return;
     }
-    adam_update(x + i, m + i, v + i, g[i], lr_t);
+    adam_update(a.x[k] + i, a.m[k] + i, a.v[k] + i, a.g[k][i], a.lr_t);
 }
 
 }  // namespace
