@@ -20,7 +20,7 @@ struct FinalArgs {
     double *out_lik, *out_kl;
     double *g_qmu, *g_qsqrt;
     int do_adam, trainable;
-    int dma;                  // the chunk partials fit in LDS: stage them by DMA
+    int dma;                  // the chunk partials go to LDS by DMA, `dma` chunks per pass (a multiple of 8, or all NC of them; 0: summed from global memory)
     int split;                // final_kernel / the merged launches: kFinSplit workgroups per (latent, problem), by column strips
     int tshift;               // measurement builds: added to the stamp ids (the role inside stage 1 vs the stand-alone launch)
     const double* lr_dev;     // [1] step size stored at the counter tick (device counter form)
@@ -277,7 +277,8 @@ __device__ __forceinline__ void final_body(const FinalArgs& b, double* sm, int l
     const float* part = b.part + pl * b.NC * b.part_len;
     const double lr_t = b.do_adam ? (b.use_lr_dev ? b.lr_dev[0] : b.lr_t) : 0.0;
     vg_stage_rows(Lks, 1, Mz * Mz, tid, nt, [&](int) -> const float* { return b.Lk32 + pl * Mz * Mz; });
-    if (b.dma) vg_stage_rows(raw, b.NC, np, tid, nt, [&](int c) -> const float* { return part + (size_t)c * b.part_len; });
+    const int cpp = b.dma;           // chunks per DMA pass
+    if (cpp) vg_stage_rows(raw, min(cpp, b.NC), np, tid, nt, [&](int c) -> const float* { return part + (size_t)c * b.part_len; });
     // this thread's elements k = tid + j * nt of  q_mu | q_sqrt:  KL gradient and Adam state
     double kg[kFinRegs], xs[kFinRegs], mo[kFinRegs], vo[kFinRegs];
 #pragma unroll
@@ -293,7 +294,7 @@ __device__ __forceinline__ void final_body(const FinalArgs& b, double* sm, int l
         }
     }
     VG_STOP(b, 5);
-    if (!b.dma)
+    if (!cpp)
         for (int e = tid; e < np; e += nt) {
             const double s = sum_chunks(part, b.part_len, b.NC, e);
             if (e < Mz) dmv[e] = s;
@@ -303,17 +304,43 @@ __device__ __forceinline__ void final_body(const FinalArgs& b, double* sm, int l
     vg_dma_wait();
     __syncthreads();
     VG_T(l == 0 && p == 0, 114 + b.tshift);
-    if (b.dma) {
-        for (int e = tid; e < np; e += nt) {
-            double s = 0.0;
-            for (int c0 = 0; c0 < b.NC; c0 += 8) {       // the order of sum_chunks()
-                double d[8];
+    if (cpp) {
+        // running sums of this thread's elements e = tid + j nt, passes of `cpp` chunks (sample-sharded runs on few ranks have
+        // more chunks than LDS holds: 128 at S = 1024; summed from global memory that cost 16 dependent round trips)
+        constexpr int kSumRegs = (VGPMP_MAX_MZ + VGPMP_MAX_MZ * VGPMP_MAX_MZ + kBlock - 1) / kBlock;
+        double sacc[kSumRegs];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) d[k] = c0 + k < b.NC ? (double)raw[(size_t)min(c0 + k, b.NC - 1) * np + e] : 0.0;
-                s += ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+        for (int j = 0; j < kSumRegs; ++j) sacc[j] = 0.0;
+        for (int cb = 0; cb < b.NC; cb += cpp) {
+            const int nc = min(cpp, b.NC - cb);
+            if (cb > 0) {
+                __syncthreads();                     // the previous pass has been read
+                vg_stage_rows(raw, nc, np, tid, nt, [&](int c) -> const float* { return part + (size_t)(cb + c) * b.part_len; });
+                vg_dma_wait();
+                __syncthreads();
             }
-            if (e < Mz) dmv[e] = s;
-            else dC[e - Mz] = s;
+#pragma unroll
+            for (int j = 0; j < kSumRegs; ++j) {
+                const int e = tid + j * nt;
+                if (e < np) {
+                    double s = sacc[j];
+                    for (int c0 = 0; c0 < nc; c0 += 8) {       // the order of sum_chunks()
+                        double d[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) d[k] = c0 + k < nc ? (double)raw[(size_t)min(c0 + k, nc - 1) * np + e] : 0.0;
+                        s += ((d[0] + d[1]) + (d[2] + d[3])) + ((d[4] + d[5]) + (d[6] + d[7]));
+                    }
+                    sacc[j] = s;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kSumRegs; ++j) {
+            const int e = tid + j * nt;
+            if (e < np) {
+                if (e < Mz) dmv[e] = sacc[j];
+                else dC[e - Mz] = sacc[j];
+            }
         }
         __syncthreads();
     }
