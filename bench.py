@@ -361,7 +361,15 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
     if args.unroll > 0:
         planner.capture(args.unroll)
     torch.cuda.synchronize()
-    elapsed, reps = timed_region(planner.run_steps, args, dist, backend)
+
+    def plan_block(k):
+        # every timed block of K steps starts from the freshly initialised models, as the reference does per start-goal query
+        # (a new VGPMP per call of solve_planning_problem, utils/miscellaneous.py:162-169); thousands of steps on one model
+        # drive the lengthscales of config 3 (lr 0.09) to ~1e-5 and the factorisation to NaN
+        planner.reset()
+        planner.run_steps(k)
+
+    elapsed, reps = timed_region(plan_block, args, dist, backend)
     assert args.allow_nan or torch.isfinite(planner.q_mu).all(), "optimisation diverged"
     pp = ps.planner_params
 

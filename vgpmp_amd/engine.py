@@ -281,7 +281,17 @@ class PlannerBatch:
         self.extra_flags = 0      # e.g. capi.NO_SPLIT (measurement)
         self._graph = None
         self._graph_unroll = 0
+        self._initial = [t.clone() for t in (self.q_mu, self.q_sqrt, self.raw_ell, self.raw_var)]
         self._pack()
+
+    def reset(self) -> None:
+        """Back to the freshly initialised model of every problem (variables, Adam moments, step count): what the reference
+        gets by building a new VGPMP per start-goal query (utils/miscellaneous.py:162-169).  Device copies only, no sync."""
+        for dst, src in zip((self.q_mu, self.q_sqrt, self.raw_ell, self.raw_var), self._initial):
+            dst.copy_(src)
+        for t in self.adam_m + self.adam_v:
+            t.zero_()
+        self.t = 0
 
     def _params_struct(self, tensors) -> capi.Params:
         return capi.Params(*(capi.ptr(t) for t in tensors))
