@@ -32,6 +32,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 HBM_ACHIEVABLE_GBPS = 6290.0    # same guide: measured float4 copy
 SUMMARY = {"auto": None, "on": True, "off": False}
 F32_MFMA_PEAK_TFLOPS = 157.3    # v_mfma_f32_16x16x4_f32 dense peak
+F16_MFMA_PEAK_TFLOPS = 2516.6   # v_mfma_f32_16x16x32_f16: 1024 flop / cycle / SIMD x 1024 SIMDs x 2.4 GHz (the guide's ~2.5 PF dense)
 METRIC = "ELBO iters/sec + plans/sec, Franka-7DoF industrial S=128 M=30 T=100, 1/2/4/8 GPU"
 
 
@@ -411,10 +412,20 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
     # the kernel that forms the prior draws in the pass the events come from (one launch per kernel, device-drawn noise);
     # same selection as vg_elbo_steps (csrc/gp_path.hip)
     sk = planner.dims.split_k
+    peak_gemm = F32_MFMA_PEAK_TFLOPS
     if sk == 1:
-        gemm_kernel = "prior_fused_batch_kernel"
-        gemm_note = ("W and the features are formed inside the GEMM; the same kernel runs in the timed schedule from 28 problems "
-                     "of this shape up (below that the tiled GEMM shares a launch with the covariance stage)")
+        split16 = not (planner.extra_flags & capi.PRIOR_F32)
+        gemm_kernel = "prior_fused_split_kernel<true, %d>" % (2 if S > 64 else 1) if split16 else "prior_fused_batch_kernel"
+        gemm_note = ("W and the features are formed inside the GEMM; the same kernel runs in the timed schedule from 35 problems "
+                     "of this shape up (below that the tiled float32 GEMM shares a launch with the covariance stage)")
+        if split16:
+            # every float32 product = three f16 MFMAs (hi hi + hi lo + lo hi, float32 accumulators): the matrix-pipe ceiling for
+            # the ALGORITHMIC flops is a third of the f16 peak; what bounds the kernel is the vector work that generates the operands
+            peak_gemm = F16_MFMA_PEAK_TFLOPS / 3.0
+            gemm_note += ("; f16-split products: peak = f16 dense MFMA peak / 3 MFMAs per float32 product; the kernel is bound by the "
+                          "vector instructions that generate W and the features (Philox, sin / cos, f16 halves), MFMA busy ~0.3 "
+                          "(profiles/r03/final/sq_prior_fused_config5.txt); the same flops against the f32-MFMA peak of 157.3 TF/s: "
+                          "%.2f" % (gemm_flops / t_gemm / 1e12 / F32_MFMA_PEAK_TFLOPS))
     elif sk == 4 and S <= 32:
         gemm_kernel, gemm_note = "prior_fused_small_kernel", "few samples: features formed inside the GEMM, four K-slices"
     elif (1024 // sk) % 128 == 0 and S >= 48:
@@ -422,7 +433,7 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
     else:
         gemm_kernel, gemm_note = "prior_gemm_kernel<0>", "a role of stage2_kernel in the timed schedule; timed alone here"
     roof_gemm = {"kernel": gemm_kernel, "note": gemm_note, "bound": "mfma", "achieved": gemm_flops / t_gemm / 1e12,
-                 "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_flops / t_gemm / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                 "peak": peak_gemm, "unit": "TFLOP/s", "frac": gemm_flops / t_gemm / 1e12 / peak_gemm,
                  "traffic": None, "algorithmic_flops_per_launch": gemm_flops, "avg_launch_ms": kernel_ms["prior_gemm_kernel"]}
     dominant = max(stage_ms, key=stage_ms.get)
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -516,8 +527,8 @@ def main():
         line = run_problem_sharded(args, world, rank, dist, backend)
         if args.also_stress == "on" or (args.also_stress == "auto" and world > 1 and default_workload):
             # the 512-problem batch of the north star, this GPU's 64: same ranks, same barriers, appended to the line
-            a2 = resolve(parse_args(["--workload", "stress", "--gpus", str(world), "--steps", "10", "--warmup", "3",
-                                     "--profile-steps", "5", "--min-seconds", "1"]))
+            a2 = resolve(parse_args(["--workload", "stress", "--gpus", str(world), "--steps", "100", "--warmup", "3",
+                                     "--profile-steps", "5", "--min-seconds", "0.5"]))
             l2 = run_problem_sharded(a2, world, rank, dist, backend, want_extras=False)
             if rank == 0:
                 line["batch_512"] = {k: l2[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "timed_blocks", "scaling",

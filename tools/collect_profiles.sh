@@ -37,8 +37,8 @@ timeout 600 python tools/solve_timing.py > $out/solve_timing_config2.txt 2>&1
 python bench.py --workload config3 --steps 130 --warmup 10 $Q > $out/config3_bench.json 2> $out/config3.err
 stats config3 --workload config3 --steps 130 --warmup 10 $Q --min-seconds 0.5
 # ---- 64 Franka problems per GPU (batch regime, cache-resident table)
-stats franka64 $Q --problems 64 --scene synthetic --min-seconds 0.5
-python bench.py $Q --problems 64 --scene synthetic > $out/franka64_bench.json 2>> $out/franka64.err
+stats franka64 $Q --problems 64 --scene synthetic --min-seconds 0.5 --steps 200
+python bench.py $Q --problems 64 --scene synthetic --steps 200 > $out/franka64_bench.json 2>> $out/franka64.err
 # ---- config 4: UR10, S = 1024 samples; one rank, and two ranks on this one GPU over gloo (rehearsal of the N > 1 path,
 #      started by bench.py itself: no external launcher)
 python bench.py --shard samples --steps 100 --warmup 10 > $out/config4_1rank_bench.json 2> $out/config4.err
@@ -47,7 +47,7 @@ timeout 600 python bench.py --gpus 2 --shard samples --steps 100 --warmup 10 2>>
 # ---- the default N > 1 line (config 2 per GPU + the config-5 share as batch_512), two ranks on this one GPU: rehearsal only
 timeout 900 python bench.py --gpus 2 --steps 100 --warmup 10 $Q 2> $out/gpus2.err | tail -1 > $out/gpus2_rehearsal_one_gpu_bench.json
 # ---- config 5 share: 14-DoF arm, 512^3 voxels (2 GiB table), 64 problems
-B5="--workload stress --steps 10 --warmup 3 $Q --profile-steps 10 --min-seconds 0.5"
+B5="--workload stress --steps 200 --warmup 3 $Q --profile-steps 10 --min-seconds 0.5"      # a timed block = a whole plan from fresh models
 for f in ${FORMS:-brick:on brick:off linear:off}; do
   lay=${f%%:*}; sm=${f##*:}; tag=config5_${lay}_summary_${sm}
   stats $tag $B5 --layout $lay --summary $sm
@@ -55,9 +55,10 @@ for f in ${FORMS:-brick:on brick:off linear:off}; do
   timeout 600 python bench.py $B5 --layout $lay --summary $sm --traffic-file $out/${tag}_pmc_traffic.json > $out/${tag}_bench.json 2>> $out/$tag.err
 done
 # ---- SQ / MFMA counters: the fused prior kernel and the batch likelihood at config 5, the prior GEMM role at config 2
-tools/pmc_sq.sh prior_fused_batch $out/sq_prior_fused_config5 $B5 > /dev/null 2>&1
-tools/pmc_sq.sh "loglik_paths_kernel<" $out/sq_loglik_config5 $B5 > /dev/null 2>&1
-tools/pmc_sq.sh paths_bwd $out/sq_paths_bwd_config5 $B5 > /dev/null 2>&1
+B5S="--workload stress --steps 20 --warmup 3 $Q --profile-steps 2"
+tools/pmc_sq.sh prior_fused_split $out/sq_prior_fused_config5 $B5S > /dev/null 2>&1
+tools/pmc_sq.sh "loglik_paths_kernel<" $out/sq_loglik_config5 $B5S > /dev/null 2>&1
+tools/pmc_sq.sh paths_bwd_regs $out/sq_paths_bwd_config5 $B5S > /dev/null 2>&1
 tools/pmc_sq.sh stage2_kernel $out/sq_stage2_config2 --steps 40 --warmup 5 $Q > /dev/null 2>&1
 # ---- the memory system's ceiling for 16-byte gathers
 if [ -x tools/gather_probe ]; then
