@@ -562,7 +562,27 @@ static size_t wide_lds_bytes(int D, int lanes) {
     return sizeof(vgpmp_robot) + ((size_t)(2 * D + 12 * (D + 1) + D) * cpb + (size_t)6 * (D + 1) * kLikBlock) * sizeof(float);
 }
 
-template <int LPC, bool SIG = false>
+// sum of the SK split-K slabs of an LDS image [SK][n]: the fixed-order tree of gp_paths.h::sum_slabs_lds
+template <int SK>
+__device__ __forceinline__ float lik_sum_slabs(const float* raw, int e, int n) {
+    float v[SK];
+#pragma unroll
+    for (int k = 0; k < SK; ++k) v[k] = raw[k * n + e];
+#pragma unroll
+    for (int w = SK / 2; w > 0; w >>= 1)
+#pragma unroll
+        for (int k = 0; k < w; ++k) v[k] += v[k + w];
+    return v[0];
+}
+// words the path operands of the SK > 0 form need, overlaid on the per-lane force / moment slots (used only later)
+static int wide_paths_words(int L, int SK) { return L * 32 * 16 + SK * L * 16 + SK * L * 32 + 3 * L * 32 + 2 * L * 16; }
+
+// SK > 0 (eight lanes, Mz = 32, N a multiple of 4): the workgroup ASSEMBLES the paths of its sixteen configurations itself --
+// one sample, sixteen consecutive time points (blockIdx.x = sample x ceil(N / 16) + tile) -- instead of reading f that a
+// path-assembly launch wrote: r = U - f0(Z) - sqrt(jitter) eps' (U = m + C eps from stage B), f = f0(X) + r A^T by the MFMA
+// sequence of paths_fwd_split_body on row 0 of the tile (same operands, same order: the same bits); tile 0 of a sample
+// stores r for the reverse pass, every tile its f.  One launch and its hand-over fewer on the one-problem step.
+template <int LPC, bool SIG = false, int SK = 0>
 __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpmp_robot* __restrict__ rb_g, vgpmp_sdf sdfh,
                                                                        const float* __restrict__ f, int S, int L, int N,
                                                                        float scale, float* __restrict__ G,
@@ -570,7 +590,10 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
                                                                        float* __restrict__ lik_partial,
                                                                        const float* __restrict__ alpha_eff = nullptr,
                                                                        const float* __restrict__ sigma_eff = nullptr,
-                                                                       float* __restrict__ sig_partial = nullptr) {
+                                                                       float* __restrict__ sig_partial = nullptr,
+                                                                       vg_lik_paths lpa = vg_lik_paths{}) {
+    constexpr bool PATHS = SK > 0;
+    static_assert(!PATHS || LPC == 8, "the path-assembling form is the eight-lane form");
     extern __shared__ float lik_lds[];
     __shared__ float red[kLikBlock / VG_WAVE];
     constexpr int CPB = kLikBlock / LPC, kWideU = kWideSpheres / LPC;
@@ -579,16 +602,52 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
     const vgpmp_robot* rb = reinterpret_cast<const vgpmp_robot*>(lik_lds);          // LDS copy
     vg_stage_16(lik_lds, rb_g, (int)(sizeof(vgpmp_robot) / 16), tid, kLikBlock);
     const int cl = tid / LPC, sub = tid % LPC;
-    const int idx = blockIdx.x * CPB + cl;
-    const bool live = idx < S * N;
-    const int ci = live ? idx : S * N - 1;               // dead groups recompute the last configuration, write nothing
-    const int s = ci / N, n = ci - s * N;
+    int s, n, n0 = 0, tile = 0;
+    bool live;
+    if (PATHS) {
+        const int tps = (N + CPB - 1) / CPB;
+        s = blockIdx.x / tps; tile = blockIdx.x - s * tps; n0 = tile * CPB;
+        live = n0 + cl < N;
+        n = min(n0 + cl, N - 1);                         // dead groups recompute the last time point, write nothing
+    } else {
+        const int idx = blockIdx.x * CPB + cl;
+        live = idx < S * N;
+        const int ci = live ? idx : S * N - 1;           // dead groups recompute the last configuration, write nothing
+        s = ci / N; n = ci - s * N;
+    }
     const size_t base = ((size_t)pb * S + s) * L * N + n;
+    // path operands (PATHS), overlaid on the per-lane slots `mine` below
+    float* ov = lik_lds + sizeof(vgpmp_robot) / sizeof(float) + (size_t)(wide_group_slots(L) + L) * CPB;
+    float* ATs = ov;                                     // [L][32][16]  A^T at the tile's time points
+    float* rawx = ATs + L * 32 * 16;                     // [SK][L][16]  prior draws at the time points, slab by slab
+    float* rawz = rawx + SK * L * 16;                    // [SK][L][32]  ... at the inducing points
+    float* Us = rawz + SK * L * 32;                      // [L][32]
+    float* e2s = Us + L * 32;                            // [32][L]
+    float* rs = e2s + 32 * L;                            // [L][32]
+    float* f0xs = rs + L * 32;                           // [L][16]
+    float* fasm = f0xs + L * 16;                         // [L][16]   the assembled f of the tile
+    if (PATHS) {
+        const int J = N + 32;
+        const size_t sl = (size_t)pb * S + s;
+        vg_stage_rows(ATs, L * 32, 16, tid, kLikBlock, [&](int r) -> const float* { return lpa.AT + ((size_t)pb * L * 32 + r) * N + n0; });
+        vg_stage_rows(rawx, SK * L, 16, tid, kLikBlock, [&](int r) -> const float* {
+            const int k = r / L, l = r - k * L;
+            return lpa.F0 + (size_t)k * lpa.slab + (sl * L + l) * J + n0;
+        });
+        vg_stage_rows(rawz, SK * L, 32, tid, kLikBlock, [&](int r) -> const float* {
+            const int k = r / L, l = r - k * L;
+            return lpa.F0 + (size_t)k * lpa.slab + (sl * L + l) * J + N;
+        });
+        vg_stage_rows(Us, L, 32, tid, kLikBlock, [&](int l) -> const float* { return lpa.U + (sl * L + l) * 32; });
+        vg_stage_rows(e2s, 1, 32 * L, tid, kLikBlock, [&](int) -> const float* { return lpa.eps2 + sl * 32 * L; });
+    }
     // this lane's joints: sub, sub + 4, ... (at most 4 of them)
     float fv[VGPMP_MAX_DOF / LPC];
     float st0 = 0.f, ct0 = 1.f, dg0 = 0.f;               // joint `sub`: sin, cos, d g / d f
+    if (!PATHS) {
 #pragma unroll
-    for (int k = 0; k < VGPMP_MAX_DOF / LPC; ++k) fv[k] = f[base + (size_t)min(sub + LPC * k, L - 1) * N];
+        for (int k = 0; k < VGPMP_MAX_DOF / LPC; ++k) fv[k] = f[base + (size_t)min(sub + LPC * k, L - 1) * N];
+    }
     static_assert(VGPMP_MAX_DOF % LPC == 0, "joints are dealt to the lanes of a group");
     // trainable sigma_obs: this problem's variances replace the table's (requested before the wait, stored after it)
     float sig_own = 0.f;
@@ -602,6 +661,37 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
             const_cast<vgpmp_robot*>(rb)->inv_sigma_obs[tid] = 1.0f / sig_own;
         }
         __syncthreads();
+    }
+    if (PATHS) {
+        if constexpr (PATHS) {
+            const size_t sl = (size_t)pb * S + s;
+            for (int e = tid; e < L * 32; e += kLikBlock) {
+                const int l = e >> 5, m = e & 31;
+                const float r = vg_path_r(Us[e], lik_sum_slabs<SK>(rawz, e, L * 32), lpa.sqrt_jitter, e2s[m * L + l]);
+                rs[e] = r;
+                if (tile == 0) vg_stream(lpa.R + (sl * L + l) * 32 + m, r);
+            }
+            for (int e = tid; e < L * 16; e += kLikBlock) f0xs[e] = lik_sum_slabs<SK>(rawx, e, L * 16);
+            __syncthreads();
+            const int wv = tid >> 6, lane = tid & 63, i = lane & 15, kk = lane >> 4;
+            const int jc = min(i, N - 1 - n0);               // columns beyond the last time point repeat it (dead configurations)
+            for (int l = wv; l < L; l += kLikBlock / VG_WAVE) {
+                vg_f32x4_t acc = {kk == 0 ? f0xs[l * 16 + jc] : 0.f, 0.f, 0.f, 0.f};
+                const float* rp = rs + l * 32;
+                const float* ap = ATs + (size_t)l * 32 * 16 + jc;
+#pragma unroll
+                for (int k = 0; k < 32; k += 4)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(i == 0 ? rp[k + kk] : 0.f, ap[(k + kk) * 16], acc, 0, 0, 0);
+                if (kk == 0) {
+                    fasm[l * 16 + i] = acc[0];
+                    if (n0 + i < N) vg_stream(lpa.f + (sl * L + l) * N + n0 + i, acc[0]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < VGPMP_MAX_DOF / LPC; ++k) fv[k] = fasm[min(sub + LPC * k, L - 1) * 16 + cl];
+            __syncthreads();                                 // the overlay is dead from here: `mine` may be written
+        }
     }
     VG_T(blockIdx.x == 0 && pb == 0, 402);
     const int D = rb->dof, P = rb->num_spheres;
@@ -915,7 +1005,7 @@ static int lik_lpc(int P, int S, int N) {
     // 1 / 2 / 3 problems, the batch form 22.2 / 23.0 / 23.2 us
     return n <= 28672 ? 8 : 1;
 }
-int vg_loglik_blocks_per_problem(int S, int N) { return (S * N * 8 + kLikBlock - 1) / kLikBlock; }   // upper bound
+int vg_loglik_blocks_per_problem(int S, int N) { return S * ((N * 8 + kLikBlock - 1) / kLikBlock); }   // upper bound (one sample per workgroup row in the path-assembling form)
 
 static size_t lik_lds_bytes(int dof, bool with_dgdf) {
     return (size_t)(2 * dof + 6 * (dof + 1) + (with_dgdf ? dof : 0)) * kLikBlock * sizeof(float);
@@ -967,10 +1057,12 @@ int vg_launch_log_prob_impl(const vgpmp_robot* rb, int dof, const vgpmp_sdf* sdf
     return (int)hipGetLastError();
 }
 
+bool vg_lik_paths_fit(int L, int SK) { return L <= 8 && wide_paths_words(L, SK) <= 6 * (L + 1) * kLikBlock; }
+
 int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const float* f, int P, int S, int L, int N,
                            float scale, float* G, float* logp, float* lik_partial, int* nblk_out, hipStream_t st,
                            hipEvent_t k0, hipEvent_t k1, const float* alpha_eff, const float* sigma_eff,
-                           float* sig_partial, int form) {
+                           float* sig_partial, int form, const vg_lik_paths* paths) {
     const bool sig = alpha_eff != nullptr;      // trainable likelihood constants: per-problem alpha / sigma_obs, per-sphere sums
     if (sig && (!sigma_eff || !sig_partial)) return VGPMP_E_ARG;
     int lpc = lik_lpc(P, S, N);
@@ -982,20 +1074,31 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
     dbg = lik_bisect_mode();
 #endif
     const int blk = lpc > 1 ? kLikBlock : kLikBatchBlock;
-    const int nblk = (S * N * lpc + blk - 1) / blk;
+    if (paths && (lpc != 8 || !vg_lik_paths_fit(L, paths->SK) || (N & 3))) return VGPMP_E_ARG;
+    // the path-assembling form: one sample per row of ceil(N / 16) workgroups
+    const int nblk = paths ? S * ((N + kLikBlock / 8 - 1) / (kLikBlock / 8)) : (S * N * lpc + blk - 1) / blk;
     if (nblk_out) *nblk_out = nblk;
     if (P == 0 || nblk == 0) return 0;
     size_t lds = lpc > 1 ? wide_lds_bytes(L, lpc) + (sig ? (size_t)(kLikBlock / lpc) * VGPMP_MAX_SPHERES * sizeof(float) : 0)
                                : lik_lds_bytes(L, true) * kLikBatchBlock / kLikBlock;
     // k0 / k1 (profiler): events stamped with the kernel's own start and end on the device
     if (lpc == 8) {
+        const vg_lik_paths lp = paths ? *paths : vg_lik_paths{};
         auto go = [&](auto kern) {
             int rc = vg_grant_dyn_lds((const void*)kern, lds);
             if (rc) return rc;
             hipExtLaunchKernelGGL(kern, dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf, f, S, L, N, scale, G, logp,
-                                  lik_partial, alpha_eff, sigma_eff, sig_partial);
+                                  lik_partial, alpha_eff, sigma_eff, sig_partial, lp);
             return (int)hipGetLastError();
         };
+        if (paths) {
+            switch (paths->SK) {
+                case 2: return sig ? go(loglik_paths_wide_kernel<8, true, 2>) : go(loglik_paths_wide_kernel<8, false, 2>);
+                case 4: return sig ? go(loglik_paths_wide_kernel<8, true, 4>) : go(loglik_paths_wide_kernel<8, false, 4>);
+                case 8: return sig ? go(loglik_paths_wide_kernel<8, true, 8>) : go(loglik_paths_wide_kernel<8, false, 8>);
+                default: return VGPMP_E_ARG;
+            }
+        }
         return sig ? go(loglik_paths_wide_kernel<8, true>) : go(loglik_paths_wide_kernel<8, false>);
     }
     auto go = [&](auto kern) {

@@ -30,6 +30,10 @@ struct CovArgs {
     double* lr_dev;
     // hyper-parameter update of the previous step as a prologue (stage 1) / its commit (stage 2, role 0)
     int prologue, commit, keep_prev;
+    // stage B, role 0 also forms U = m + C eps of every sample (ws.U) for the likelihood that assembles its own paths
+    // (Mz = 32): the MFMA sequence of paths_fwd_split_body on the float32 C it has just built
+    int form_u, S;
+    const float* eps;        // [P,S,Mz,L]
     HyperArgs hy;
     vg_workspace ws;
 };
@@ -547,6 +551,12 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     double* Kd = X1;
     double* T = X2;
     double* qm = kd1 + Mp;           // [Mp] q_mu behind the two conditioned points
+    // role 0 with form_u (Mz == 32): float32 q_sqrt^T and m in the scratch of the tangent roles, every sample's eps behind
+    // the float64 regions (the launch's dynamic LDS is sized for it)
+    float* ctl = reinterpret_cast<float*>(X2);          // [Mz][Mz]
+    float* ml = ctl + Mz * Mz;                          // [Mz]
+    float* epl = reinterpret_cast<float*>(qm + Mp);     // [S][Mz]
+    const bool form_u = role == 0 && a.form_u != 0;
     const double jit = a.jitter, var = a.ws.var[pl];
     const double y0 = a.y_u[((size_t)p * 2 + 0) * L + l], y1 = a.y_u[((size_t)p * 2 + 1) * L + l];
     const double* Kg = a.ws.Ks64 + pl * Mz * Mz;
@@ -598,6 +608,11 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     }
     vg_dma_wait();
     __syncthreads();
+    if (form_u)      // requested now, waited for at the end: the samples' eps land while the float64 chain runs
+        vg_stage_words(epl, a.S * Mz, tid, nt, [&](int w) -> const void* {
+            const int sl = vg_div(w, iMz), k = w - sl * Mz;
+            return a.eps + (((size_t)p * a.S + sl) * Mz + k) * L + l;
+        });
     // prior mean through the two conditioned points and a = Lk^-1 (q_mu - p_mu)  (prior_kl.py:16-35); the jitter on
     // the two leading diagonal entries and the conditioned values are applied on the fly (no fix-up pass, no barrier)
     const double k00 = k0[0] + jit, k01 = k1[0], k11 = k1[1] + jit;
@@ -610,6 +625,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
         const double qi = qm[i];
         const double mi = i == 0 ? y0 : (i == 1 ? y1 : qi);
         if (role == 0) a.ws.m[pl * Mz + i] = (float)mi;
+        if (form_u) ml[i] = (float)mi;
         dl[i] = mi - (K0(i) * c0 + K1(i) * c1);
     }
     const double kd_scale = role == 2 ? 1.0 / var : 1.0;      // dK/dvar = K / var, applied to the products
@@ -639,6 +655,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
                 const float cv = (float)(v + (r == c && r < 2 ? jit : 0.0));
                 C32[(size_t)r * Mz + c] = cv;
                 C32T[(size_t)c * Mz + r] = cv;
+                if (form_u) ctl[c * Mz + r] = cv;
             }
         });
         double* gklQ = a.ws.gkl_Q + pl * M * M;
@@ -659,6 +676,31 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
         for (int k = (tid >> 3) + 2; k < Mz; k += nt >> 3) {
             const double g = dot8(Li + k * ld + k, ld, af + k, 1, Mz - k, sub);
             if (sub == 0) a.ws.gkl_qmu[pl * M + (k - 2)] = g;
+        }
+        if (form_u) {
+            // U = m + eps C^T of every sample: sixteen samples per pass (two chunks of paths_fwd_split_body at once: its rows do
+            // not mix), two 16-column tiles, eight k-interleaved MFMAs each -- the same operands in the same order, so the
+            // same bits; four waves share the (pass, tile) units
+            vg_dma_wait();
+            __syncthreads();
+            const int wv = tid >> 6, lane = tid & 63, i = lane & 15, kk = lane >> 4;
+            const int S = a.S, units = 2 * ((S + 15) >> 4);
+            for (int u = wv; u < units; u += (int)(nt >> 6)) {
+                const int s0 = (u >> 1) << 4, mi = 16 * (u & 1) + i;
+                vg_f32x4_t acc;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = ml[mi];
+                const int sr = s0 + i;
+                const float* ep = epl + min(sr, S - 1) * 32;
+#pragma unroll
+                for (int k = 0; k < 32; k += 4)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sr < S ? ep[k + kk] : 0.f, ctl[(k + kk) * 32 + mi], acc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int s = s0 + 4 * kk + q;
+                    if (s < S) a.ws.U[(((size_t)p * S + s) * L + l) * 32 + mi] = acc[q];
+                }
+            }
         }
         VG_T(l == 0 && p == 0, 202);
         return;

@@ -27,6 +27,7 @@ struct vg_workspace {
     float *Phi, *dPhi;       // [P,L,J,B]
     float *F0, *H;           // [SK][P,S,L,J]
     float *R;                // [P,S,L,Mz]
+    float *U;                // [P,S,L,Mz]   m + C eps, formed by stage B when the likelihood assembles the paths itself
     float *G;                // [P,S,L,N]     dloss/df
     float *lik_partial;      // [P,nblk]
     float *part;             // [P,L,NC,PART] per-chunk reductions of the reverse pass

@@ -25,6 +25,9 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 #ifndef VG_PB_MIN_WGS
 #define VG_PB_MIN_WGS 1536    // reverse path pass: chunks per workgroup double while this many workgroups remain (six per CU)
 #endif
+#ifndef VG_LIK_PATHS
+#define VG_LIK_PATHS 1        // 0: measurement builds with stage 3 (paths_fwd) as a launch of its own at few problems
+#endif
 #ifndef VG_BATCH_MERGE
 #define VG_BATCH_MERGE 1      // 0: measurement builds with every small launch of the large-batch schedule on its own
 #endif
@@ -180,6 +183,24 @@ __global__ __launch_bounds__(kBlock) void stage3_kernel(Stage3Args a) {
     }
     b -= a.n_path;
     if (a.skip & 2) return;
+    if (b < a.n_basis) { rng_basis_body(a.rng, b % a.basis_gx, b / a.basis_gx); return; }
+    b -= a.n_basis;
+    rng_normals_body(a.rng, b % a.w_gx, b / a.w_gx, a.rng.nW, 0u);
+}
+
+// The step without stage 3 (few problems, Mz = 32, K-slices): the likelihood assembles its own paths (fk_sdf.hip,
+// loglik_paths_wide_kernel<8, SIG, SK>) from U = m + C eps that stage B leaves, and the draws of the next step's omega, beta, w
+// -- the other role of stage 3 -- ride with the reverse path pass instead: four launches per step.
+struct Stage4Args {
+    PathArgs path; RngArgs rng;
+    int n_bwd, bwd_gx, n_basis, basis_gx, w_gx;
+};
+template <int SK, int MZ>
+__global__ __launch_bounds__(kBlock) void stage4_kernel(Stage4Args a) {
+    extern __shared__ float smf[];
+    int b = blockIdx.x;
+    if (b < a.n_bwd) { paths_bwd_split_body<SK, MZ>(a.path, smf, b, a.bwd_gx); return; }
+    b -= a.n_bwd;
     if (b < a.n_basis) { rng_basis_body(a.rng, b % a.basis_gx, b / a.basis_gx); return; }
     b -= a.n_basis;
     rng_normals_body(a.rng, b % a.w_gx, b / a.w_gx, a.rng.nW, 0u);
@@ -360,6 +381,7 @@ size_t vg_layout_workspace(const vgpmp_dims* d, void* base, vg_workspace* ws) {
     ws->F0 = carve<float>(cur, (size_t)d->split_k * P * S * L * J, real);
     ws->H = carve<float>(cur, (size_t)d->split_k * P * S * L * J, real);
     ws->R = carve<float>(cur, P * S * L * Mz, real);
+    ws->U = carve<float>(cur, P * S * L * Mz, real);
     ws->G = carve<float>(cur, P * S * L * N, real);
     ws->lik_partial = carve<float>(cur, P * (size_t)vg_loglik_blocks_per_problem(d->S, d->N), real);
     ws->part = carve<float>(cur, PL * vg_chunks(d) * vg_part_len(d), real);
@@ -577,7 +599,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const void* fn_s2 = glds ? (backward ? VG_S2(true, -1) : VG_S2(false, -1))
                       : backward ? (k8 ? VG_S2(true, 8) : VG_S2(true, 0)) : (k8 ? VG_S2(false, 8) : VG_S2(false, 0));
 #undef VG_S2
-    const size_t lds_s2 = glds && kGemmLds > lds_cov_b ? kGemmLds : lds_cov_b;
+    size_t lds_s2 = glds && kGemmLds > lds_cov_b ? kGemmLds : lds_cov_b;
     if (SC != 8) return VGPMP_E_SHAPE;
 #define VG_PICK(kernel, raw)                                                                                        \
     (SK == 1 ? (raw ? (const void*)kernel<1, true> : (const void*)kernel<1, false>)                                 \
@@ -600,6 +622,12 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const bool split_fwd = SK > 1 && Mz % 4 == 0 && N % 4 == 0 && N >= 8 && lds_pfs <= 64 * 1024 &&
                            (size_t)P * L * NC * 2 <= 512 && !(what & VGPMP_NO_SPLIT);
     if (split_fwd) { pa.nsplit = 2; lds_pf = lds_pfs; }
+    // few problems, Mz = 32: no stage 3 -- the likelihood assembles its paths, the reverse pass carries the noise roles
+    const bool lik_paths = VG_LIK_PATHS && fused && backward && split_fwd && split_bwd && Mz == 32 && !lk && !pb->ind &&
+                           !(what & (VGPMP_LIK_LANES | VGPMP_LIK_LDS_STATE | VGPMP_NO_SPLIT)) && vg_lik_paths_fit(L, SK) &&
+                           (long long)P * S * N <= 28672;
+    ca.form_u = lik_paths ? 1 : 0; ca.S = S; ca.eps = nz->eps;
+    const void* fn_s4 = SK == 2 ? (const void*)stage4_kernel<2, 32> : SK == 4 ? (const void*)stage4_kernel<4, 32> : (const void*)stage4_kernel<8, 32>;
     if (split_bwd) {
         fn_pb = Mz == 32 ? (SK == 2 ? (const void*)paths_bwd_split<2, 32> : SK == 4 ? (const void*)paths_bwd_split<4, 32>
                                                                                         : (const void*)paths_bwd_split<8, 32>)
@@ -614,9 +642,11 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         lds_pb = ((size_t)16 * N + (size_t)32 * J + (size_t)8 * 16 * Mz + 8 * 4) * sizeof(float);
     }
     if (backward && (rc = set_dyn_lds(fn_pb, lds_pb))) return rc;      // forward-only calls never launch the reverse pass
+    if (lik_paths && (rc = set_dyn_lds(fn_s4, lds_pb))) return rc;
     if (fused) {
         if ((rc = set_dyn_lds((const void*)stage1_kernel<false>, lds_s1))) return rc;
         if ((rc = set_dyn_lds((const void*)stage1_kernel<true>, lds_s1))) return rc;
+        if (lik_paths && lds_cov_b + (size_t)S * Mz * sizeof(float) > lds_s2) lds_s2 = lds_cov_b + (size_t)S * Mz * sizeof(float);
         if ((rc = set_dyn_lds(fn_s2, lds_s2))) return rc;
         if ((rc = set_dyn_lds(fn_s3, lds_pf))) return rc;
     } else {
@@ -686,8 +716,12 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         lu.ctr = do_adam ? ctr : nullptr; lu.lr = lr; lu.lr_t = 0.0;
     }
 
+    vg_lik_paths lpa;
+    lpa.SK = SK; lpa.slab = slab; lpa.sqrt_jitter = pa.sqrt_jitter; lpa.AT = ws->AT; lpa.F0 = ws->F0; lpa.U = ws->U;
+    lpa.eps2 = nz->eps2; lpa.R = ws->R; lpa.f = out->f;
     for (int i = 0; i < num_steps; ++i) {
         const bool first = i == 0, more = i + 1 < num_steps;
+        bool draw_next = false;      // (lik_paths) the reverse path launch also draws the next step's omega, beta, w
         const uint32_t step_i = step + (uint32_t)i;
         if (ind && (rc = vg_launch_inducing_build(d, ind, st))) return rc;       // Zy = [0; 1; Z(raw_Z)] of every problem
         if (fused) {
@@ -732,17 +766,20 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             s2.n_gemm = n_gemm;
             s2.gemm_per_xcd = ((gemm_first || s2.n_cov % 8 == 0) && n_gemm % 8 == 0) ? n_gemm / 8 : 0;
             if ((rc = launch(fn_s2, dim3(s2.n_cov + gemm_grid.x * gemm_grid.y * gemm_grid.z), &s2, lds_s2))) return rc;
-            Stage3Args s3;
-            s3.skip = skip3;
-            s3.path = pa;
-            // the counter has ticked in stage 2: it already names the next step
-            s3.rng = make_rng_args(d, nz, seed, problem_base, step_i + 1u, ctr, 0u);
-            s3.n_path = NC * pa.nsplit * L * P;
-            s3.path.xcd_span = VG_XCD_PATHS && s3.n_path % 8 == 0 ? s3.n_path / 8 : 0;
-            s3.basis_gx = (int)basis_gx; s3.w_gx = (int)w_gx;
-            s3.n_basis = (gen && ahead) ? (int)basis_gx * P : 0;
-            const unsigned n3 = s3.n_path + s3.n_basis + ((gen && ahead) ? w_gx * P : 0u);
-            if ((rc = launch(fn_s3, dim3(n3), &s3, lds_pf))) return rc;
+            if (!lik_paths) {
+                Stage3Args s3;
+                s3.skip = skip3;
+                s3.path = pa;
+                // the counter has ticked in stage 2: it already names the next step
+                s3.rng = make_rng_args(d, nz, seed, problem_base, step_i + 1u, ctr, 0u);
+                s3.n_path = NC * pa.nsplit * L * P;
+                s3.path.xcd_span = VG_XCD_PATHS && s3.n_path % 8 == 0 ? s3.n_path / 8 : 0;
+                s3.basis_gx = (int)basis_gx; s3.w_gx = (int)w_gx;
+                s3.n_basis = (gen && ahead) ? (int)basis_gx * P : 0;
+                const unsigned n3 = s3.n_path + s3.n_basis + ((gen && ahead) ? w_gx * P : 0u);
+                if ((rc = launch(fn_s3, dim3(n3), &s3, lds_pf))) return rc;
+            }
+            draw_next = gen && ahead;
         } else if (mid) {
             // cov_a | noise draws;  features;  cov_b | tiled GEMM
             MidAArgs ma;
@@ -895,7 +932,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         rc = vg_launch_loglik_paths(rb, sdf, out->f, P, S, L, N, (float)(-lik_scale), ws->G, out->logp, ws->lik_partial,
                                     &nblk, st, ev ? ev[VG_NUM_STAGES + 1] : nullptr, ev ? ev[VG_NUM_STAGES + 2] : nullptr,
                                     lk ? lsc.alpha_eff : nullptr, lk ? lsc.sigma_eff : nullptr,
-                                    lk ? lsc.sig_partial : nullptr, (what & VGPMP_LIK_LDS_STATE) ? 2 : (what & VGPMP_LIK_LANES) ? 1 : 0);
+                                    lk ? lsc.sig_partial : nullptr, (what & VGPMP_LIK_LDS_STATE) ? 2 : (what & VGPMP_LIK_LANES) ? 1 : 0,
+                                    lik_paths ? &lpa : nullptr);
         if (rc) return rc;
         fa.nblk = nblk;
         mark();
@@ -906,7 +944,16 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         }
         // ---- reverse of the path assembly (+ hyper-parameter update), then (here or in the next stage 1) the rest
         pa.xcd_span = VG_XCD_PATHS && split_bwd && (2 * NC * L * P) % 8 == 0 ? 2 * NC * L * P / 8 : 0;
-        if ((rc = launch(fn_pb, dim3(split_bwd ? 2 * NC : (NC + pa.cpw - 1) / pa.cpw, L, P), &pa, lds_pb))) return rc;
+        if (lik_paths) {
+            Stage4Args s4;
+            s4.path = pa;
+            s4.rng = make_rng_args(d, nz, seed, problem_base, step_i + 1u, ctr, 0u);      // (the counter has ticked in stage 2)
+            s4.n_bwd = 2 * NC * L * P; s4.bwd_gx = 2 * NC;
+            s4.basis_gx = (int)basis_gx; s4.w_gx = (int)w_gx;
+            s4.n_basis = draw_next ? (int)basis_gx * P : 0;
+            const unsigned n4 = (unsigned)s4.n_bwd + (unsigned)s4.n_basis + (draw_next ? w_gx * P : 0u);
+            if ((rc = launch(fn_s4, dim3(n4), &s4, lds_pb))) return rc;
+        } else if ((rc = launch(fn_pb, dim3(split_bwd ? 2 * NC : (NC + pa.cpw - 1) / pa.cpw, L, P), &pa, lds_pb))) return rc;
         if (ind) {     // inducing locations as variables: reverse through the covariance path and the prior draw at Zy
             vg_ind_launch il;
             il.d = d; il.ind = ind; il.ws = ws; il.nz = nz; il.params = params; il.X = pb->X; il.y_u = pb->y_u;

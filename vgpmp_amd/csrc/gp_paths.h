@@ -132,7 +132,7 @@ __device__ __forceinline__ void paths_fwd_body(const PathArgs& a, float* smf, in
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int sl = 4 * kk + q, e = sl * 32 + mi, s = s_base + sl;
-                    const float r = acc[q] - f0s[sl * J + N + mi] - a.sqrt_jitter * e2s[e];
+                    const float r = vg_path_r(acc[q], f0s[sl * J + N + mi], a.sqrt_jitter, e2s[e]);
                     rs[e] = r;
                     if (s < S) vg_stream(a.R + (((size_t)p * S + s) * L + l) * 32 + mi, r);
                 }
@@ -161,7 +161,7 @@ __device__ __forceinline__ void paths_fwd_body(const PathArgs& a, float* smf, in
             const int sl = vg_div(e, iMz), mi = e - sl * Mz, s = s_base + sl;
             float u = ms[mi];
             for (int k = 0; k <= mi; ++k) u = fmaf(Cs[mi * ld + k], es[sl * Mz + k], u);
-            const float r = u - f0s[sl * J + N + mi] - a.sqrt_jitter * e2s[e];
+            const float r = vg_path_r(u, f0s[sl * J + N + mi], a.sqrt_jitter, e2s[e]);
             rs[e] = r;
             if (s < S) vg_stream(a.R + (((size_t)p * S + s) * L + l) * Mz + mi, r);
         }
@@ -250,7 +250,7 @@ __device__ __forceinline__ void paths_fwd_split_body(const PathArgs& a, float* s
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int sl = 4 * kk + q, e = sl * Mz + mi, s = s_base + sl;
-                    const float r = acc[q] - f0z[e] - a.sqrt_jitter * e2s[e];
+                    const float r = vg_path_r(acc[q], f0z[e], a.sqrt_jitter, e2s[e]);
                     rs[e] = r;
                     if (half == 0 && s < S) vg_stream(a.R + (((size_t)p * S + s) * L + l) * Mz + mi, r);
                 }
@@ -279,7 +279,7 @@ __device__ __forceinline__ void paths_fwd_split_body(const PathArgs& a, float* s
             const int sl = vg_div(e, iMz), mi = e - sl * Mz, s = s_base + sl;
             float u = ms[mi];
             for (int k = 0; k <= mi; ++k) u = fmaf(CTs[k * Mz + mi], es[sl * Mz + k], u);
-            const float r = u - f0z[e] - a.sqrt_jitter * e2s[e];
+            const float r = vg_path_r(u, f0z[e], a.sqrt_jitter, e2s[e]);
             rs[e] = r;
             if (half == 0 && s < S) vg_stream(a.R + (((size_t)p * S + s) * L + l) * Mz + mi, r);
         }
@@ -690,16 +690,17 @@ __global__ __launch_bounds__(kBlock, VG_PBR_WAVES) void paths_bwd_regs(PathArgs 
 // A / dR / dm / dC (disjoint outputs, no extra partials) and the time points [n0, n0 + nx) of the two prior-draw dot
 // products (a second set of the three scalars, added by hyper_update).  Two threads per (sample, column) halve the
 // N-long chains.  Needs Mz % 8 == 0, N % 4 == 0 (16-byte rows), SK > 1.
+// (body: `wg_lin` = workgroup number in (chunk half, latent, problem) order, `gx` = 2 NC; the launch of its own below, and a
+//  role of stage4_kernel in gp_path.hip)
 template <int SK, int MZ = 0>      // MZ = 32: inducing extent fixed at compile time (see paths_fwd_split_body)
-__global__ __launch_bounds__(kBlock) void paths_bwd_split(PathArgs a) {
+__device__ __forceinline__ void paths_bwd_split_body(const PathArgs& a, float* smf, int wg_lin, int gx) {
     constexpr int SC = 8;
-    extern __shared__ float smf[];
     __shared__ float red[3][kBlock / VG_WAVE];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int S = a.S, N = a.N, Mz = MZ ? MZ : a.Mz, L = a.L, J = N + Mz;
-    int wg = xcd_contiguous((int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)), a.xcd_span);
-    const int bx = wg % (int)gridDim.x;
-    wg /= (int)gridDim.x;
+    int wg = xcd_contiguous(wg_lin, a.xcd_span);
+    const int bx = wg % gx;
+    wg /= gx;
     const int ch = bx >> 1, half = bx & 1, l = wg % L, p = wg / L;
     const int Mh = Mz >> 1, m0 = half * Mh;
     const int Nh = (N >> 1) & ~3, n0 = half ? Nh : 0, nx = half ? N - Nh : Nh;
@@ -923,6 +924,12 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_split(PathArgs a) {
     }
     VG_T(ch == 0 && half == 0 && l == 0 && p == 0, 503);
     VG_T(ch == a.NC - 1 && half == 1 && l == L - 1 && p == 0, 505);
+}
+
+template <int SK, int MZ = 0>
+__global__ __launch_bounds__(kBlock) void paths_bwd_split(PathArgs a) {
+    extern __shared__ float smf[];
+    paths_bwd_split_body<SK, MZ>(a, smf, (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)), (int)gridDim.x);
 }
 
 template <int SK, bool RAW>

@@ -201,6 +201,10 @@ __device__ __forceinline__ size_t vg_voxel_index(const vg_sdf_dev& s, double rx,
     return vg_table_offset(s, ix, iy, iz);
 }
 
+// r = u - f0(Z) - sqrt(jitter) eps'  of the Matheron update, in ONE written-out form: the path kernels (gp_path.hip, contraction
+// allowed) and the likelihood that assembles its own paths (fk_sdf.hip, contraction off) must round identically
+__device__ __forceinline__ float vg_path_r(float u, float f0z, float sqrt_jitter, float e2) { return fmaf(-sqrt_jitter, e2, u - f0z); }
+
 // ---- Philox-4x32-10 (same schedule as oracle/vgpmp_oracle.py::philox4x32) --------------------
 __device__ __forceinline__ uint4 vg_philox(uint4 c, uint2 k) {
 #pragma unroll
@@ -297,11 +301,24 @@ int vg_trace_take_lik(unsigned long long* host, int cap);
 #define VG_TMAX(id) do { } while (0)
 #endif
 
+// The few-problem likelihood assembling the paths it needs itself (loglik_paths_wide_kernel<8, SIG, SK>, Mz = 32): what it reads
+// besides the robot and the voxel table, and where r and f go.  U = m + C eps comes from stage B (cov_b role 0).
+struct vg_lik_paths {
+    int SK;                  // split-K slabs of the prior draws (2, 4 or 8)
+    size_t slab;
+    float sqrt_jitter;
+    const float *AT, *F0, *U, *eps2;
+    float *R, *f;
+};
+
 int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const float* f, int P, int S, int L, int N,
                            float scale, float* G, float* logp, float* lik_partial, int* nblk_out, hipStream_t st,
                            hipEvent_t kernel_start = nullptr, hipEvent_t kernel_end = nullptr,
                            const float* alpha_eff = nullptr, const float* sigma_eff = nullptr, float* sig_partial = nullptr,
-                           int form = 0);      // 0: by batch size; 1: batch form; 2: batch form with all per-frame state in LDS
+                           int form = 0,       // 0: by batch size; 1: batch form; 2: batch form with all per-frame state in LDS
+                           const vg_lik_paths* paths = nullptr);      // the eight-lane form assembles f (and r) itself: `f` is unused
+// LDS the eight-lane form has to overlay the path operands on (bytes), and what they need; paths fit iff need <= room
+bool vg_lik_paths_fit(int L, int SK);
 int vg_loglik_blocks_per_problem(int S, int N);
 int vg_launch_kernel_derivative(int kind, int order, const double* x, int n, const double* y, int m, double ell, double var,
                                 double* out, hipStream_t st);
