@@ -285,7 +285,10 @@ def test_pipelined_steps_equal_single_step_calls(P, M):
                  (a.adam_v[1], b.adam_v[1])):
         assert torch.allclose(x, y, rtol=0, atol=1e-11), float((x - y).abs().max())
     assert torch.equal(a.eps, b.eps) and torch.equal(a.w, b.w)
-    assert torch.allclose(a.lik, b.lik, rtol=1e-12) and torch.allclose(a.kl, b.kl, rtol=1e-12)
+    assert torch.equal(a.f, b.f) and torch.equal(a.logp, b.logp)
+    # (the reported likelihood is a float32 sum of logp by workgroup: the form that assembles its own paths -- one problem,
+    #  Mz = 32 -- walks a sample's time points in tiles of sixteen, the other forms sixteen consecutive configurations)
+    assert torch.allclose(a.lik, b.lik, rtol=1e-7) and torch.allclose(a.kl, b.kl, rtol=1e-12)
 
 
 def test_pipelined_steps_with_trainable_likelihood_constants():

@@ -575,7 +575,7 @@ __device__ __forceinline__ float lik_sum_slabs(const float* raw, int e, int n) {
     return v[0];
 }
 // words the path operands of the SK > 0 form need, overlaid on the per-lane force / moment slots (used only later)
-static int wide_paths_words(int L, int SK) { return L * 32 * 16 + SK * L * 16 + SK * L * 32 + 3 * L * 32 + 2 * L * 16; }
+static int wide_paths_words(int L, int SK) { return SK * L * 16 + SK * L * 32 + 3 * L * 32 + 2 * L * 16; }
 
 // SK > 0 (eight lanes, Mz = 32, N a multiple of 4): the workgroup ASSEMBLES the paths of its sixteen configurations itself --
 // one sample, sixteen consecutive time points (blockIdx.x = sample x ceil(N / 16) + tile) -- instead of reading f that a
@@ -618,18 +618,29 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
     const size_t base = ((size_t)pb * S + s) * L * N + n;
     // path operands (PATHS), overlaid on the per-lane slots `mine` below
     float* ov = lik_lds + sizeof(vgpmp_robot) / sizeof(float) + (size_t)(wide_group_slots(L) + L) * CPB;
-    float* ATs = ov;                                     // [L][32][16]  A^T at the tile's time points
-    float* rawx = ATs + L * 32 * 16;                     // [SK][L][16]  prior draws at the time points, slab by slab
+    float* rawx = ov;                                    // [SK][L][16]  prior draws at the time points, slab by slab
     float* rawz = rawx + SK * L * 16;                    // [SK][L][32]  ... at the inducing points
     float* Us = rawz + SK * L * 32;                      // [L][32]
     float* e2s = Us + L * 32;                            // [32][L]
     float* rs = e2s + 32 * L;                            // [L][32]
     float* f0xs = rs + L * 32;                           // [L][16]
     float* fasm = f0xs + L * 16;                         // [L][16]   the assembled f of the tile
+    // B operands of f = f0(X) + r A^T: A^T[l][4 k8 + kk][n0 + column] of this wave's latents (l = wave, wave + 2, ...), straight
+    // from memory into registers (A^T is 90 KB per problem, L2 resident; through LDS it was half of what a workgroup staged)
+    constexpr int kPL = (8 + kLikBlock / VG_WAVE - 1) / (kLikBlock / VG_WAVE);      // latents per wave (up to 8 latents)
+    float bat[kPL][8];
     if (PATHS) {
         const int J = N + 32;
         const size_t sl = (size_t)pb * S + s;
-        vg_stage_rows(ATs, L * 32, 16, tid, kLikBlock, [&](int r) -> const float* { return lpa.AT + ((size_t)pb * L * 32 + r) * N + n0; });
+        {
+            const int lane = tid & 63, i = lane & 15, kk = lane >> 4, jc = min(i, N - 1 - n0);
+#pragma unroll
+            for (int li = 0; li < kPL; ++li) {
+                const int l = min((tid >> 6) + li * (kLikBlock / VG_WAVE), L - 1);
+#pragma unroll
+                for (int k8 = 0; k8 < 8; ++k8) bat[li][k8] = lpa.AT[((size_t)(pb * L + l) * 32 + 4 * k8 + kk) * N + n0 + jc];
+            }
+        }
         vg_stage_rows(rawx, SK * L, 16, tid, kLikBlock, [&](int r) -> const float* {
             const int k = r / L, l = r - k * L;
             return lpa.F0 + (size_t)k * lpa.slab + (sl * L + l) * J + n0;
@@ -675,16 +686,28 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
             __syncthreads();
             const int wv = tid >> 6, lane = tid & 63, i = lane & 15, kk = lane >> 4;
             const int jc = min(i, N - 1 - n0);               // columns beyond the last time point repeat it (dead configurations)
-            for (int l = wv; l < L; l += kLikBlock / VG_WAVE) {
-                vg_f32x4_t acc = {kk == 0 ? f0xs[l * 16 + jc] : 0.f, 0.f, 0.f, 0.f};
-                const float* rp = rs + l * 32;
-                const float* ap = ATs + (size_t)l * 32 * 16 + jc;
+            // this wave's latents side by side: their A fragments requested together, then eight rounds of one MFMA per latent
+            // (independent accumulators: the rounds issue back to back); per element the order of paths_fwd_split_body
+            float ar[kPL][8];
+            vg_f32x4_t acc[kPL];
 #pragma unroll
-                for (int k = 0; k < 32; k += 4)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(i == 0 ? rp[k + kk] : 0.f, ap[(k + kk) * 16], acc, 0, 0, 0);
-                if (kk == 0) {
-                    fasm[l * 16 + i] = acc[0];
-                    if (n0 + i < N) vg_stream(lpa.f + (sl * L + l) * N + n0 + i, acc[0]);
+            for (int li = 0; li < kPL; ++li) {
+                const int l = min(wv + li * (kLikBlock / VG_WAVE), L - 1);
+#pragma unroll
+                for (int k8 = 0; k8 < 8; ++k8) ar[li][k8] = rs[l * 32 + 4 * k8 + kk];
+                acc[li] = (vg_f32x4_t){kk == 0 ? f0xs[l * 16 + jc] : 0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8)
+#pragma unroll
+                for (int li = 0; li < kPL; ++li)
+                    acc[li] = __builtin_amdgcn_mfma_f32_16x16x4f32(i == 0 ? ar[li][k8] : 0.f, bat[li][k8], acc[li], 0, 0, 0);
+#pragma unroll
+            for (int li = 0; li < kPL; ++li) {
+                const int l = wv + li * (kLikBlock / VG_WAVE);
+                if (l < L && kk == 0) {
+                    fasm[l * 16 + i] = acc[li][0];
+                    if (n0 + i < N) vg_stream(lpa.f + (sl * L + l) * N + n0 + i, acc[li][0]);
                 }
             }
             __syncthreads();

@@ -33,7 +33,7 @@ struct CovArgs {
     // stage B, role 0 also forms U = m + C eps of every sample (ws.U) for the likelihood that assembles its own paths
     // (Mz = 32): the MFMA sequence of paths_fwd_split_body on the float32 C it has just built
     int form_u, S;
-    const float* eps;        // [P,S,Mz,L]
+    const float* eps;        // [P,L,S,Mz]  (ws.epsT: the generator's second copy, a latent's rows contiguous)
     HyperArgs hy;
     vg_workspace ws;
 };
@@ -609,10 +609,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     vg_dma_wait();
     __syncthreads();
     if (form_u)      // requested now, waited for at the end: the samples' eps land while the float64 chain runs
-        vg_stage_words(epl, a.S * Mz, tid, nt, [&](int w) -> const void* {
-            const int sl = vg_div(w, iMz), k = w - sl * Mz;
-            return a.eps + (((size_t)p * a.S + sl) * Mz + k) * L + l;
-        });
+        vg_stage_16(epl, a.eps + pl * a.S * Mz, a.S * Mz / 4, tid, nt);
     // prior mean through the two conditioned points and a = Lk^-1 (q_mu - p_mu)  (prior_kl.py:16-35); the jitter on
     // the two leading diagonal entries and the conditioned values are applied on the fly (no fix-up pass, no barrier)
     const double k00 = k0[0] + jit, k01 = k1[0], k11 = k1[1] + jit;
@@ -685,16 +682,23 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
             __syncthreads();
             const int wv = tid >> 6, lane = tid & 63, i = lane & 15, kk = lane >> 4;
             const int S = a.S, units = 2 * ((S + 15) >> 4);
+            // a wave's units share their column tile (units wv, wv + 4, ...: same parity): its B fragments once, in registers;
+            // the A fragments of a unit are requested together, then the eight MFMAs run back to back
+            const int mi = 16 * (wv & 1) + i;
+            float bq[8];
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) bq[k8] = ctl[(4 * k8 + kk) * 32 + mi];
+            const float m0 = ml[mi];
             for (int u = wv; u < units; u += (int)(nt >> 6)) {
-                const int s0 = (u >> 1) << 4, mi = 16 * (u & 1) + i;
-                vg_f32x4_t acc;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = ml[mi];
-                const int sr = s0 + i;
+                const int s0 = (u >> 1) << 4, sr = s0 + i;
                 const float* ep = epl + min(sr, S - 1) * 32;
+                float aq[8];
 #pragma unroll
-                for (int k = 0; k < 32; k += 4)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sr < S ? ep[k + kk] : 0.f, ctl[(k + kk) * 32 + mi], acc, 0, 0, 0);
+                for (int k8 = 0; k8 < 8; ++k8) aq[k8] = ep[4 * k8 + kk];
+                vg_f32x4_t acc = {m0, m0, m0, m0};
+#pragma unroll
+                for (int k8 = 0; k8 < 8; ++k8)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sr < S ? aq[k8] : 0.f, bq[k8], acc, 0, 0, 0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int s = s0 + 4 * kk + q;

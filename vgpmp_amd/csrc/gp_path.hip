@@ -382,6 +382,7 @@ size_t vg_layout_workspace(const vgpmp_dims* d, void* base, vg_workspace* ws) {
     ws->H = carve<float>(cur, (size_t)d->split_k * P * S * L * J, real);
     ws->R = carve<float>(cur, P * S * L * Mz, real);
     ws->U = carve<float>(cur, P * S * L * Mz, real);
+    ws->epsT = carve<float>(cur, P * S * L * Mz, real);
     ws->G = carve<float>(cur, P * S * L * N, real);
     ws->lik_partial = carve<float>(cur, P * (size_t)vg_loglik_blocks_per_problem(d->S, d->N), real);
     ws->part = carve<float>(cur, PL * vg_chunks(d) * vg_part_len(d), real);
@@ -421,13 +422,15 @@ static RngArgs make_rng_args(const vgpmp_dims* d, const vgpmp_noise* nz, uint32_
     r.eOff = (uint32_t)d->sample_offset * vg_mz(d) * d->L;
     r.omega = nz->omega; r.beta = nz->beta; r.w = nz->w; r.eps = nz->eps; r.eps2 = nz->eps2;
     r.seed = seed; r.problem_base = problem_base; r.step = step; r.bias = bias; r.ctr = ctr;
+    r.epsT = nullptr; r.Mz = vg_mz(d); r.S = d->S;
     return r;
 }
 
 int vg_launch_rng(const vgpmp_dims* d, const vgpmp_noise* nz, uint32_t seed, uint32_t problem_base, uint32_t step,
-                  const uint32_t* ctr, hipStream_t st) {
+                  const uint32_t* ctr, hipStream_t st, float* epsT) {
     const int P = d->num_problems;
     RngArgs r = make_rng_args(d, nz, seed, problem_base, step, ctr, 0u);
+    r.epsT = epsT;
     hipLaunchKernelGGL(rng_basis_kernel, dim3((r.L * r.B + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
     const uint32_t nthr = (r.nW >> 2) + 2 * r.nE;
     hipLaunchKernelGGL(rng_normals_kernel, dim3((nthr + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
@@ -623,10 +626,10 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                            (size_t)P * L * NC * 2 <= 512 && !(what & VGPMP_NO_SPLIT);
     if (split_fwd) { pa.nsplit = 2; lds_pf = lds_pfs; }
     // few problems, Mz = 32: no stage 3 -- the likelihood assembles its paths, the reverse pass carries the noise roles
-    const bool lik_paths = VG_LIK_PATHS && fused && backward && split_fwd && split_bwd && Mz == 32 && !lk && !pb->ind &&
+    const bool lik_paths = VG_LIK_PATHS && fused && gen && backward && split_fwd && split_bwd && Mz == 32 && !lk && !pb->ind &&
                            !(what & (VGPMP_LIK_LANES | VGPMP_LIK_LDS_STATE | VGPMP_NO_SPLIT)) && vg_lik_paths_fit(L, SK) &&
                            (long long)P * S * N <= 28672;
-    ca.form_u = lik_paths ? 1 : 0; ca.S = S; ca.eps = nz->eps;
+    ca.form_u = lik_paths ? 1 : 0; ca.S = S; ca.eps = ws->epsT;
     const void* fn_s4 = SK == 2 ? (const void*)stage4_kernel<2, 32> : SK == 4 ? (const void*)stage4_kernel<4, 32> : (const void*)stage4_kernel<8, 32>;
     if (split_bwd) {
         fn_pb = Mz == 32 ? (SK == 2 ? (const void*)paths_bwd_split<2, 32> : SK == 4 ? (const void*)paths_bwd_split<4, 32>
@@ -732,7 +735,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             //  step is one call per step with an all-reduce in between: without these it paid two noise launches per step.)
             const bool ready = !first || (what & VGPMP_NOISE_READY);
             const bool ahead = more || (what & VGPMP_NOISE_AHEAD);
-            if (gen && !ready && (rc = vg_launch_rng(d, nz, seed, problem_base, step_i, ctr, st))) return rc;
+            if (gen && !ready && (rc = vg_launch_rng(d, nz, seed, problem_base, step_i, ctr, st, lik_paths ? ws->epsT : nullptr))) return rc;
             // steps after the first of a call: the hyper-parameter update of the previous step is a prologue of the
             // cov_a and feature roles, its q_mu / q_sqrt update (final) another role of the same launch
             const bool prologue = !first && backward;
@@ -746,6 +749,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             s1.cov.hy = hyp; s1.feat.hy = hyp;
             s1.cov.prologue = prologue ? 1 : 0;
             s1.rng = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
+            s1.rng.epsT = lik_paths ? ws->epsT : nullptr;
             s1.n_cov = L * P;
             s1.fin_split = fin_split ? 1 : 0;
             s1.n_fin = first ? 0 : L * P * (fin_split ? kFinSplit : 1);

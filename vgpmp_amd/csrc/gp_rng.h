@@ -13,6 +13,8 @@ struct RngArgs {
     float *omega, *beta, *w, *eps, *eps2;
     uint32_t seed, problem_base, step, bias;
     const uint32_t* ctr;      // device step counter: the key uses *ctr + bias instead of `step`
+    float* epsT;              // optional second copy of eps as [P,L,S,Mz] (the rows stage B reads when it forms U = m + C eps)
+    int Mz, S;
 };
 
 __device__ __forceinline__ uint32_t rng_step(const RngArgs& a) { return a.ctr ? *a.ctr + a.bias : a.step; }
@@ -67,7 +69,12 @@ __device__ __forceinline__ void rng_normals_body(const RngArgs& a, int bx, int p
     c -= cW;
     const bool second = c >= nE;
     if (second) c -= nE;
-    vg_stream((second ? a.eps2 : a.eps) + (size_t)p * nE + c, vg_normal1(a.eOff + c, second ? VG_STREAM_EPS2 : VG_STREAM_EPS, key));
+    const float v = vg_normal1(a.eOff + c, second ? VG_STREAM_EPS2 : VG_STREAM_EPS, key);
+    vg_stream((second ? a.eps2 : a.eps) + (size_t)p * nE + c, v);
+    if (a.epsT && !second) {                             // c = (s Mz + k) L + l
+        const uint32_t l = c % (uint32_t)a.L, sk = c / (uint32_t)a.L, k = sk % (uint32_t)a.Mz, s = sk / (uint32_t)a.Mz;
+        a.epsT[(((size_t)p * a.L + l) * a.S + s) * a.Mz + k] = v;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void rng_basis_kernel(RngArgs a) { rng_basis_body(a, blockIdx.x, blockIdx.y); }
