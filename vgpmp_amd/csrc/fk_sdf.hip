@@ -575,7 +575,7 @@ __device__ __forceinline__ float lik_sum_slabs(const float* raw, int e, int n) {
     return v[0];
 }
 // words the path operands of the SK > 0 form need, overlaid on the per-lane force / moment slots (used only later)
-static int wide_paths_words(int L, int SK) { return SK * L * 16 + SK * L * 32 + 3 * L * 32 + 2 * L * 16; }
+static int wide_paths_words(int L, int SK) { (void)SK; return L * 32 + L * 16; }
 
 // SK > 0 (eight lanes, Mz = 32, N a multiple of 4): the workgroup ASSEMBLES the paths of its sixteen configurations itself --
 // one sample, sixteen consecutive time points (blockIdx.x = sample x ceil(N / 16) + tile) -- instead of reading f that a
@@ -618,39 +618,35 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
     const size_t base = ((size_t)pb * S + s) * L * N + n;
     // path operands (PATHS), overlaid on the per-lane slots `mine` below
     float* ov = lik_lds + sizeof(vgpmp_robot) / sizeof(float) + (size_t)(wide_group_slots(L) + L) * CPB;
-    float* rawx = ov;                                    // [SK][L][16]  prior draws at the time points, slab by slab
-    float* rawz = rawx + SK * L * 16;                    // [SK][L][32]  ... at the inducing points
-    float* Us = rawz + SK * L * 32;                      // [L][32]
-    float* e2s = Us + L * 32;                            // [32][L]
-    float* rs = e2s + 32 * L;                            // [L][32]
-    float* f0xs = rs + L * 32;                           // [L][16]
-    float* fasm = f0xs + L * 16;                         // [L][16]   the assembled f of the tile
-    // B operands of f = f0(X) + r A^T: A^T[l][4 k8 + kk][n0 + column] of this wave's latents (l = wave, wave + 2, ...), straight
-    // from memory into registers (A^T is 90 KB per problem, L2 resident; through LDS it was half of what a workgroup staged)
-    constexpr int kPL = (8 + kLikBlock / VG_WAVE - 1) / (kLikBlock / VG_WAVE);      // latents per wave (up to 8 latents)
-    float bat[kPL][8];
+    float* rs = ov;                                      // [L][32]   r of the sample
+    float* fasm = rs + L * 32;                           // [L][16]   the assembled f of the tile
+    // PATHS: thread t < 16 L forms f of (latent t / 16, column t % 16) by ONE fmaf chain over the 32 inducing points -- the order
+    // in which v_mfma_f32_16x16x4_f32 accumulates (k ascending: the same bits as paths_fwd_split_body's tiles) -- and loads its
+    // column of A^T and its slab entries straight from memory (L2 resident); thread t < 32 L forms r[t] for everybody
+    constexpr int kFT = 16 * 8 <= kLikBlock ? 1 : 2;     // columns per thread if 16 L exceeded the workgroup (it does not: L <= 8)
+    static_assert(kFT == 1, "one (latent, column) per thread");
+    float atc[32], f0c[SK > 0 ? SK : 1];
+    float ru[2], re2[2], rz[2][SK > 0 ? SK : 1];
+    const int fl = tid >> 4, fj = tid & 15, fjc = min(fj, N - 1 - n0);
     if (PATHS) {
-        const int J = N + 32;
-        const size_t sl = (size_t)pb * S + s;
-        {
-            const int lane = tid & 63, i = lane & 15, kk = lane >> 4, jc = min(i, N - 1 - n0);
+        if constexpr (PATHS) {
+            const int J = N + 32;
+            const size_t sl = (size_t)pb * S + s;
+            const int l = min(fl, L - 1);
+            const float* atp = lpa.AT + ((size_t)(pb * L + l) * 32) * N + n0 + fjc;
 #pragma unroll
-            for (int li = 0; li < kPL; ++li) {
-                const int l = min((tid >> 6) + li * (kLikBlock / VG_WAVE), L - 1);
+            for (int k = 0; k < 32; ++k) atc[k] = atp[(size_t)k * N];
 #pragma unroll
-                for (int k8 = 0; k8 < 8; ++k8) bat[li][k8] = lpa.AT[((size_t)(pb * L + l) * 32 + 4 * k8 + kk) * N + n0 + jc];
+            for (int k = 0; k < SK; ++k) f0c[k] = lpa.F0[(size_t)k * lpa.slab + (sl * L + l) * J + n0 + fjc];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = min(tid + q * kLikBlock, L * 32 - 1), el = e >> 5, em = e & 31;
+                ru[q] = lpa.U[(sl * L + el) * 32 + em];
+                re2[q] = lpa.eps2[(sl * 32 + em) * L + el];
+#pragma unroll
+                for (int k = 0; k < SK; ++k) rz[q][k] = lpa.F0[(size_t)k * lpa.slab + (sl * L + el) * J + N + em];
             }
         }
-        vg_stage_rows(rawx, SK * L, 16, tid, kLikBlock, [&](int r) -> const float* {
-            const int k = r / L, l = r - k * L;
-            return lpa.F0 + (size_t)k * lpa.slab + (sl * L + l) * J + n0;
-        });
-        vg_stage_rows(rawz, SK * L, 32, tid, kLikBlock, [&](int r) -> const float* {
-            const int k = r / L, l = r - k * L;
-            return lpa.F0 + (size_t)k * lpa.slab + (sl * L + l) * J + N;
-        });
-        vg_stage_rows(Us, L, 32, tid, kLikBlock, [&](int l) -> const float* { return lpa.U + (sl * L + l) * 32; });
-        vg_stage_rows(e2s, 1, 32 * L, tid, kLikBlock, [&](int) -> const float* { return lpa.eps2 + sl * 32 * L; });
     }
     // this lane's joints: sub, sub + 4, ... (at most 4 of them)
     float fv[VGPMP_MAX_DOF / LPC];
@@ -676,39 +672,37 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
     if (PATHS) {
         if constexpr (PATHS) {
             const size_t sl = (size_t)pb * S + s;
-            for (int e = tid; e < L * 32; e += kLikBlock) {
-                const int l = e >> 5, m = e & 31;
-                const float r = vg_path_r(Us[e], lik_sum_slabs<SK>(rawz, e, L * 32), lpa.sqrt_jitter, e2s[m * L + l]);
-                rs[e] = r;
-                if (tile == 0) vg_stream(lpa.R + (sl * L + l) * 32 + m, r);
-            }
-            for (int e = tid; e < L * 16; e += kLikBlock) f0xs[e] = lik_sum_slabs<SK>(rawx, e, L * 16);
-            __syncthreads();
-            const int wv = tid >> 6, lane = tid & 63, i = lane & 15, kk = lane >> 4;
-            const int jc = min(i, N - 1 - n0);               // columns beyond the last time point repeat it (dead configurations)
-            // this wave's latents side by side: their A fragments requested together, then eight rounds of one MFMA per latent
-            // (independent accumulators: the rounds issue back to back); per element the order of paths_fwd_split_body
-            float ar[kPL][8];
-            vg_f32x4_t acc[kPL];
 #pragma unroll
-            for (int li = 0; li < kPL; ++li) {
-                const int l = min(wv + li * (kLikBlock / VG_WAVE), L - 1);
+            for (int q = 0; q < 2; ++q) {
+                const int e = tid + q * kLikBlock;
+                if (e < L * 32) {
+                    float v[SK];
 #pragma unroll
-                for (int k8 = 0; k8 < 8; ++k8) ar[li][k8] = rs[l * 32 + 4 * k8 + kk];
-                acc[li] = (vg_f32x4_t){kk == 0 ? f0xs[l * 16 + jc] : 0.f, 0.f, 0.f, 0.f};
-            }
+                    for (int k = 0; k < SK; ++k) v[k] = rz[q][k];
 #pragma unroll
-            for (int k8 = 0; k8 < 8; ++k8)
+                    for (int w = SK / 2; w > 0; w >>= 1)      // the fixed-order tree of gp_paths.h::sum_slabs_lds
 #pragma unroll
-                for (int li = 0; li < kPL; ++li)
-                    acc[li] = __builtin_amdgcn_mfma_f32_16x16x4f32(i == 0 ? ar[li][k8] : 0.f, bat[li][k8], acc[li], 0, 0, 0);
-#pragma unroll
-            for (int li = 0; li < kPL; ++li) {
-                const int l = wv + li * (kLikBlock / VG_WAVE);
-                if (l < L && kk == 0) {
-                    fasm[l * 16 + i] = acc[li][0];
-                    if (n0 + i < N) vg_stream(lpa.f + (sl * L + l) * N + n0 + i, acc[li][0]);
+                        for (int k = 0; k < w; ++k) v[k] += v[k + w];
+                    const float r = vg_path_r(ru[q], v[0], lpa.sqrt_jitter, re2[q]);
+                    rs[e] = r;
+                    if (tile == 0) vg_stream(lpa.R + sl * L * 32 + e, r);
                 }
+            }
+            __syncthreads();
+            if (fl < L) {
+                float v[SK];
+#pragma unroll
+                for (int k = 0; k < SK; ++k) v[k] = f0c[k];
+#pragma unroll
+                for (int w = SK / 2; w > 0; w >>= 1)
+#pragma unroll
+                    for (int k = 0; k < w; ++k) v[k] += v[k + w];
+                float acc = v[0];
+                const float* rp = rs + fl * 32;
+#pragma unroll
+                for (int k = 0; k < 32; ++k) acc = fmaf(rp[k], atc[k], acc);
+                fasm[fl * 16 + fj] = acc;
+                if (n0 + fj < N) vg_stream(lpa.f + (sl * L + fl) * N + n0 + fj, acc);
             }
             __syncthreads();
 #pragma unroll

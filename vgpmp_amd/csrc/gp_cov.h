@@ -574,7 +574,23 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
             vg_stage_f64(La, Mp, ld, a.ws.Lk64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
             vg_stage_f64(Li, Mp, ld, a.ws.Li64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
         }
-        if (role == 0) {
+        if (role == 0 && square && !(M & 1)) {
+            // pad(Q) with Q at [2:, 2:] as ONE linear image of 16-byte units (ld even: a unit = two columns of a row): units
+            // inside the block come from the rows of q_sqrt by DMA, the others are zeros written directly; the upper triangle
+            // of the block is cleared behind the wait.  (Two 4-byte requests per double made this the longest staging of the
+            // stage, on the role that ends it.)
+            const int upl = ld >> 1, total = Mp * upl, lane = tid & (VG_WAVE - 1);
+            for (int c0 = (tid & ~(VG_WAVE - 1)); c0 < total; c0 += nt) {
+                const int iu = c0 + lane;
+                if (iu < total) {
+                    const int row = iu / upl, r = row - 2, c = 2 * (iu - row * upl) - 2;
+                    if (r >= 0 && r < M && c >= 0 && c < M)
+                        __builtin_amdgcn_global_load_lds((vg_gmem*)(Qg + (size_t)r * M + c), (vg_lmem*)((char*)Qp + 16 * (size_t)c0), 16, 0, VG_DMA_AUX);
+                    else
+                        reinterpret_cast<double2*>(Qp)[iu] = make_double2(0.0, 0.0);
+                }
+            }
+        } else if (role == 0) {
             vg_stage_f64(Qp, Mp, ld, Qg, M, M, 2, 2, tid, nt, [](int r, int c) { return c <= r; });
         } else {      // tangents: this thread's share of Q waits in registers until Lk's LDS space is free
             const double* Kdg = role == 1 ? a.ws.Kd_ell + pl * Mz * Mz : Kg;
@@ -592,6 +608,9 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
             const int i = w >> 1;
             return (i >= 2 && i < Mz) ? reinterpret_cast<const uint32_t*>(a.q_mu + pl * M + (i - 2)) + (w & 1) : nullptr;
         });
+        // the samples' eps for U (16-byte units, behind what the float64 chain needs: every barrier waits for outstanding
+        // requests, so later would not be cheaper)
+        if (form_u) vg_stage_16(epl, a.eps + pl * a.S * Mz, a.S * Mz / 4, tid, nt);
     }
     if (role == 0 && tid == 0) {      // behind the staging requests: these round trips overlap them
         if (a.commit && a.hy.do_adam) {      // staged hyper-parameters of the prologue -> their tensors
@@ -608,8 +627,6 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     }
     vg_dma_wait();
     __syncthreads();
-    if (form_u)      // requested now, waited for at the end: the samples' eps land while the float64 chain runs
-        vg_stage_16(epl, a.eps + pl * a.S * Mz, a.S * Mz / 4, tid, nt);
     // prior mean through the two conditioned points and a = Lk^-1 (q_mu - p_mu)  (prior_kl.py:16-35); the jitter on
     // the two leading diagonal entries and the conditioned values are applied on the fly (no fix-up pass, no barrier)
     const double k00 = k0[0] + jit, k01 = k1[0], k11 = k1[1] + jit;
@@ -626,6 +643,12 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
         dl[i] = mi - (K0(i) * c0 + K1(i) * c1);
     }
     const double kd_scale = role == 2 ? 1.0 / var : 1.0;      // dK/dvar = K / var, applied to the products
+    if (role == 0 && Mz == Mp && !(M & 1)) {      // (16-byte staging of Q above: the strict upper triangle of the block is not Q's)
+        for (int e = tid; e < M * M; e += nt) {
+            const int r = vg_div(e, iM), c = e - r * M;
+            if (c > r) Qp[(r + 2) * ld + (c + 2)] = 0.0;
+        }
+    }
     if (role == 0) {                         // float32 copy for the gradient assembly (written here, not in stage A:
         float* Lk32 = a.ws.Lk32 + pl * Mz * Mz;      // stage A of the next step may overlap that kernel)
         for (int e = tid; e < Mz * Mz; e += nt) {
@@ -678,7 +701,6 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
             // U = m + eps C^T of every sample: sixteen samples per pass (two chunks of paths_fwd_split_body at once: its rows do
             // not mix), two 16-column tiles, eight k-interleaved MFMAs each -- the same operands in the same order, so the
             // same bits; four waves share the (pass, tile) units
-            vg_dma_wait();
             __syncthreads();
             const int wv = tid >> 6, lane = tid & 63, i = lane & 15, kk = lane >> 4;
             const int S = a.S, units = 2 * ((S + 15) >> 4);
