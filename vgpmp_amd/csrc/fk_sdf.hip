@@ -575,13 +575,13 @@ __device__ __forceinline__ float lik_sum_slabs(const float* raw, int e, int n) {
     return v[0];
 }
 // words the path operands of the SK > 0 form need, overlaid on the per-lane force / moment slots (used only later)
-static int wide_paths_words(int L, int SK) { (void)SK; return L * 32 + L * 16 + 2 * 32 * L; }
+static int wide_paths_words(int L, int SK) { (void)SK; return L * 32 + L * 16; }
 
 // SK > 0 (eight lanes, Mz = 32, N a multiple of 4): the workgroup ASSEMBLES the paths of its sixteen configurations itself --
 // one sample, sixteen consecutive time points (blockIdx.x = sample x ceil(N / 16) + tile) -- instead of reading f that a
-// path-assembly launch wrote: u = m + C eps, r = u - f0(Z) - sqrt(jitter) eps', f = f0(X) + r A^T, each element one fmaf chain
-// in the order paths_fwd_split_body's v_mfma_f32_16x16x4_f32 tiles accumulate (k ascending: the same bits); tile 0 of a
-// sample stores r for the reverse pass, every tile its f.  One launch and its hand-over fewer on the one-problem step.
+// path-assembly launch wrote: r = U - f0(Z) - sqrt(jitter) eps' (U = m + C eps from stage B), f = f0(X) + r A^T by the MFMA
+// sequence of paths_fwd_split_body on row 0 of the tile (same operands, same order: the same bits); tile 0 of a sample
+// stores r for the reverse pass, every tile its f.  One launch and its hand-over fewer on the one-problem step.
 template <int LPC, bool SIG = false, int SK = 0>
 __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpmp_robot* __restrict__ rb_g, vgpmp_sdf sdfh,
                                                                        const float* __restrict__ f, int S, int L, int N,
@@ -620,37 +620,32 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
     float* ov = lik_lds + sizeof(vgpmp_robot) / sizeof(float) + (size_t)(wide_group_slots(L) + L) * CPB;
     float* rs = ov;                                      // [L][32]   r of the sample
     float* fasm = rs + L * 32;                           // [L][16]   the assembled f of the tile
-    float* eps_s = fasm + L * 16;                        // [32][L]   eps of the sample, then eps'
-    float* e2_s = eps_s + 32 * L;
     // PATHS: thread t < 16 L forms f of (latent t / 16, column t % 16) by ONE fmaf chain over the 32 inducing points -- the order
     // in which v_mfma_f32_16x16x4_f32 accumulates (k ascending: the same bits as paths_fwd_split_body's tiles) -- and loads its
     // column of A^T and its slab entries straight from memory (L2 resident); thread t < 32 L forms r[t] for everybody
+    constexpr int kFT = 16 * 8 <= kLikBlock ? 1 : 2;     // columns per thread if 16 L exceeded the workgroup (it does not: L <= 8)
+    static_assert(kFT == 1, "one (latent, column) per thread");
     float atc[32], f0c[SK > 0 ? SK : 1];
-    float4 crow[2][8];                                   // row m of q_sqrt (= column m of its transpose) of this thread's two (latent, m)
-    float rm[2], rz[2][SK > 0 ? SK : 1];
+    float ru[2], re2[2], rz[2][SK > 0 ? SK : 1];
     const int fl = tid >> 4, fj = tid & 15, fjc = min(fj, N - 1 - n0);
     if (PATHS) {
         if constexpr (PATHS) {
             const int J = N + 32;
             const size_t sl = (size_t)pb * S + s;
-            vg_stage_rows(eps_s, 2, 32 * L, tid, kLikBlock, [&](int r) -> const float* { return (r ? lpa.eps2 : lpa.eps) + sl * 32 * L; });
-            // what r needs first (it is consumed first), then the column of A^T and the slab entries of f
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int e = min(tid + q * kLikBlock, L * 32 - 1), el = e >> 5, em = e & 31;
-                const float4* cp = reinterpret_cast<const float4*>(lpa.C + ((size_t)(pb * L + el) * 32 + em) * 32);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) crow[q][k] = cp[k];
-                rm[q] = lpa.m[(size_t)(pb * L + el) * 32 + em];
-#pragma unroll
-                for (int k = 0; k < SK; ++k) rz[q][k] = lpa.F0[(size_t)k * lpa.slab + (sl * L + el) * J + N + em];
-            }
             const int l = min(fl, L - 1);
             const float* atp = lpa.AT + ((size_t)(pb * L + l) * 32) * N + n0 + fjc;
 #pragma unroll
             for (int k = 0; k < 32; ++k) atc[k] = atp[(size_t)k * N];
 #pragma unroll
             for (int k = 0; k < SK; ++k) f0c[k] = lpa.F0[(size_t)k * lpa.slab + (sl * L + l) * J + n0 + fjc];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = min(tid + q * kLikBlock, L * 32 - 1), el = e >> 5, em = e & 31;
+                ru[q] = lpa.U[(sl * L + el) * 32 + em];
+                re2[q] = lpa.eps2[(sl * 32 + em) * L + el];
+#pragma unroll
+                for (int k = 0; k < SK; ++k) rz[q][k] = lpa.F0[(size_t)k * lpa.slab + (sl * L + el) * J + N + em];
+            }
         }
     }
     // this lane's joints: sub, sub + 4, ... (at most 4 of them)
@@ -688,17 +683,7 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
                     for (int w = SK / 2; w > 0; w >>= 1)      // the fixed-order tree of gp_paths.h::sum_slabs_lds
 #pragma unroll
                         for (int k = 0; k < w; ++k) v[k] += v[k + w];
-                    // u = m + sum_k eps[k] C^T[k][m]: one fmaf chain, k ascending -- the order of paths_fwd_split_body's MFMA tiles
-                    const int el = e >> 5, em = e & 31;
-                    float u = rm[q];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        u = fmaf(eps_s[(4 * k) * L + el], crow[q][k].x, u);
-                        u = fmaf(eps_s[(4 * k + 1) * L + el], crow[q][k].y, u);
-                        u = fmaf(eps_s[(4 * k + 2) * L + el], crow[q][k].z, u);
-                        u = fmaf(eps_s[(4 * k + 3) * L + el], crow[q][k].w, u);
-                    }
-                    const float r = vg_path_r(u, v[0], lpa.sqrt_jitter, e2_s[em * L + el]);
+                    const float r = vg_path_r(ru[q], v[0], lpa.sqrt_jitter, re2[q]);
                     rs[e] = r;
                     if (tile == 0) vg_stream(lpa.R + sl * L * 32 + e, r);
                 }

@@ -32,7 +32,7 @@ struct CovArgs {
     int prologue, commit, keep_prev;
     // stage B, role 0 also forms U = m + C eps of every sample (ws.U) for the likelihood that assembles its own paths
     // (Mz = 32): the MFMA sequence of paths_fwd_split_body on the float32 C it has just built
-    int form_u, S;
+    int form_u, S, u_role;
     const float* eps;        // [P,L,S,Mz]  (ws.epsT: the generator's second copy, a latent's rows contiguous)
     HyperArgs hy;
     vg_workspace ws;
@@ -519,6 +519,11 @@ template <bool TANGENTS>
 __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int role, int l, int p) {
     __shared__ double red[kCovThreads / VG_WAVE];
     const int tid = threadIdx.x, nt = blockDim.x;
+    // the extra role of the launch whose likelihood assembles its paths: q_sqrt = Lk pad(Q) + jitter once more (role 0's
+    // operands through role 0's product: the same bits) and U = m + C eps of every sample from it -- beside role 0, which
+    // ends the stage, not behind it
+    const bool form_u = a.form_u != 0 && role == a.u_role;
+    if (form_u) role = 0;
     if (role >= 3) {
         // The step counter ticks where no kernel that reads it runs alongside: noise drawn before this launch
         // saw the old value, the noise of the next step and the Adam count see the new one.
@@ -556,7 +561,6 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     float* ctl = reinterpret_cast<float*>(X2);          // [Mz][Mz]
     float* ml = ctl + Mz * Mz;                          // [Mz]
     float* epl = reinterpret_cast<float*>(qm + Mp);     // [S][Mz]
-    const bool form_u = role == 0 && a.form_u != 0;
     const double jit = a.jitter, var = a.ws.var[pl];
     const double y0 = a.y_u[((size_t)p * 2 + 0) * L + l], y1 = a.y_u[((size_t)p * 2 + 1) * L + l];
     const double* Kg = a.ws.Ks64 + pl * Mz * Mz;
@@ -569,7 +573,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
         const bool square = Mz == Mp;      // no zero padding needed: whole rows in 16-byte units
         if (square) {
             vg_stage_f64_square(La, ld, a.ws.Lk64 + pl * Mz * Mz, Mz, tid, nt);
-            vg_stage_f64_square(Li, ld, a.ws.Li64 + pl * Mz * Mz, Mz, tid, nt);
+            if (!form_u) vg_stage_f64_square(Li, ld, a.ws.Li64 + pl * Mz * Mz, Mz, tid, nt);
         } else {
             vg_stage_f64(La, Mp, ld, a.ws.Lk64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
             vg_stage_f64(Li, Mp, ld, a.ws.Li64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
@@ -612,7 +616,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
         // requests, so later would not be cheaper)
         if (form_u) vg_stage_16(epl, a.eps + pl * a.S * Mz, a.S * Mz / 4, tid, nt);
     }
-    if (role == 0 && tid == 0) {      // behind the staging requests: these round trips overlap them
+    if (role == 0 && !form_u && tid == 0) {      // behind the staging requests: these round trips overlap them
         if (a.commit && a.hy.do_adam) {      // staged hyper-parameters of the prologue -> their tensors
             const HyperArgs& h = a.hy;
             const double* nx = h.next + 6 * pl;
@@ -638,7 +642,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     for (int i = tid; i < Mz; i += nt) {
         const double qi = qm[i];
         const double mi = i == 0 ? y0 : (i == 1 ? y1 : qi);
-        if (role == 0) a.ws.m[pl * Mz + i] = (float)mi;
+        if (role == 0 && !form_u) a.ws.m[pl * Mz + i] = (float)mi;
         if (form_u) ml[i] = (float)mi;
         dl[i] = mi - (K0(i) * c0 + K1(i) * c1);
     }
@@ -649,7 +653,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
             if (c > r) Qp[(r + 2) * ld + (c + 2)] = 0.0;
         }
     }
-    if (role == 0) {                         // float32 copy for the gradient assembly (written here, not in stage A:
+    if (role == 0 && !form_u) {              // float32 copy for the gradient assembly (written here, not in stage A:
         float* Lk32 = a.ws.Lk32 + pl * Mz * Mz;      // stage A of the next step may overlap that kernel)
         for (int e = tid; e < Mz * Mz; e += nt) {
             const int i = vg_div(e, iMz), j = e - i * Mz;
@@ -660,7 +664,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     VG_T(l == 0 && p == 0, 201 + 10 * role);
     double klacc = 0.0;
     const int sub = tid & 7;
-    for (int i = tid >> 3; i < Mz; i += nt >> 3) {      // af is read again only behind later barriers
+    for (int i = tid >> 3; i < Mz && !form_u; i += nt >> 3) {      // af is read again only behind later barriers
         const double s = dot8(Li + i * ld, 1, dl, 1, i + 1, sub);
         if (sub == 0) {
             af[i] = s;
@@ -673,11 +677,14 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
         matmul_f64(MatView{La, ld, 1}, MatView{Qp, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
             if (r < Mz && c < Mz) {
                 const float cv = (float)(v + (r == c && r < 2 ? jit : 0.0));
-                C32[(size_t)r * Mz + c] = cv;
-                C32T[(size_t)c * Mz + r] = cv;
                 if (form_u) ctl[c * Mz + r] = cv;
+                else {
+                    C32[(size_t)r * Mz + c] = cv;
+                    C32T[(size_t)c * Mz + r] = cv;
+                }
             }
         });
+        if (!form_u) {
         double* gklQ = a.ws.gkl_Q + pl * M * M;
         for (int e = tid; e < M * M; e += nt) {
             int r = vg_div(e, iM), c = e - r * M;
@@ -696,6 +703,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
         for (int k = (tid >> 3) + 2; k < Mz; k += nt >> 3) {
             const double g = dot8(Li + k * ld + k, ld, af + k, 1, Mz - k, sub);
             if (sub == 0) a.ws.gkl_qmu[pl * M + (k - 2)] = g;
+        }
         }
         if (form_u) {
             // U = m + eps C^T of every sample: sixteen samples per pass (two chunks of paths_fwd_split_body at once: its rows do

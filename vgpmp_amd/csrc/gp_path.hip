@@ -629,7 +629,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const bool lik_paths = VG_LIK_PATHS && fused && gen && backward && split_fwd && split_bwd && Mz == 32 && !lk && !pb->ind &&
                            !(what & (VGPMP_LIK_LANES | VGPMP_LIK_LDS_STATE | VGPMP_NO_SPLIT)) && vg_lik_paths_fit(L, SK) &&
                            (long long)P * S * N <= 28672;
-    ca.form_u = 0; ca.S = S; ca.eps = nullptr;
+    ca.form_u = lik_paths ? 1 : 0; ca.S = S; ca.eps = ws->epsT; ca.u_role = -1;
     const void* fn_s4 = SK == 2 ? (const void*)stage4_kernel<2, 32> : SK == 4 ? (const void*)stage4_kernel<4, 32> : (const void*)stage4_kernel<8, 32>;
     if (split_bwd) {
         fn_pb = Mz == 32 ? (SK == 2 ? (const void*)paths_bwd_split<2, 32> : SK == 4 ? (const void*)paths_bwd_split<4, 32>
@@ -720,8 +720,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     }
 
     vg_lik_paths lpa;
-    lpa.SK = SK; lpa.slab = slab; lpa.sqrt_jitter = pa.sqrt_jitter; lpa.AT = ws->AT; lpa.F0 = ws->F0; lpa.C = ws->C; lpa.m = ws->m;
-    lpa.eps = nz->eps; lpa.eps2 = nz->eps2; lpa.R = ws->R; lpa.f = out->f;
+    lpa.SK = SK; lpa.slab = slab; lpa.sqrt_jitter = pa.sqrt_jitter; lpa.AT = ws->AT; lpa.F0 = ws->F0; lpa.U = ws->U;
+    lpa.eps2 = nz->eps2; lpa.R = ws->R; lpa.f = out->f;
     for (int i = 0; i < num_steps; ++i) {
         const bool first = i == 0, more = i + 1 < num_steps;
         bool draw_next = false;      // (lik_paths) the reverse path launch also draws the next step's omega, beta, w
@@ -735,7 +735,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             //  step is one call per step with an all-reduce in between: without these it paid two noise launches per step.)
             const bool ready = !first || (what & VGPMP_NOISE_READY);
             const bool ahead = more || (what & VGPMP_NOISE_AHEAD);
-            if (gen && !ready && (rc = vg_launch_rng(d, nz, seed, problem_base, step_i, ctr, st, nullptr))) return rc;
+            if (gen && !ready && (rc = vg_launch_rng(d, nz, seed, problem_base, step_i, ctr, st, lik_paths ? ws->epsT : nullptr))) return rc;
             // steps after the first of a call: the hyper-parameter update of the previous step is a prologue of the
             // cov_a and feature roles, its q_mu / q_sqrt update (final) another role of the same launch
             const bool prologue = !first && backward;
@@ -749,7 +749,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             s1.cov.hy = hyp; s1.feat.hy = hyp;
             s1.cov.prologue = prologue ? 1 : 0;
             s1.rng = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
-            s1.rng.epsT = nullptr;
+            s1.rng.epsT = lik_paths ? ws->epsT : nullptr;
             s1.n_cov = L * P;
             s1.fin_split = fin_split ? 1 : 0;
             s1.n_fin = first ? 0 : L * P * (fin_split ? kFinSplit : 1);
@@ -764,7 +764,9 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             s2.skip = skip2;
             s2.cov = ca; s2.gemm = ga;
             s2.cov.hy = hyp; s2.cov.commit = prologue ? 1 : 0;
-            s2.cov_roles = (int)cov_b_grid.x; s2.n_cov = (int)(cov_b_grid.x * cov_b_grid.y * cov_b_grid.z);
+            s2.cov_roles = (int)cov_b_grid.x + (lik_paths ? 1 : 0);      // (the extra role forms U = m + C eps)
+            s2.cov.u_role = lik_paths ? (int)cov_b_grid.x : -1;
+            s2.n_cov = (int)(s2.cov_roles * cov_b_grid.y * cov_b_grid.z);
             s2.gemm_gx = (int)gemm_grid.x; s2.gemm_gy = (int)gemm_grid.y;
             const int n_gemm = (int)(gemm_grid.x * gemm_grid.y * gemm_grid.z);
             s2.n_gemm = n_gemm;

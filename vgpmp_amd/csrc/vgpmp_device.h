@@ -302,12 +302,12 @@ int vg_trace_take_lik(unsigned long long* host, int cap);
 #endif
 
 // The few-problem likelihood assembling the paths it needs itself (loglik_paths_wide_kernel<8, SIG, SK>, Mz = 32): what it reads
-// besides the robot and the voxel table, and where r and f go.
+// besides the robot and the voxel table, and where r and f go.  U = m + C eps comes from stage B (cov_b role 0).
 struct vg_lik_paths {
     int SK;                  // split-K slabs of the prior draws (2, 4 or 8)
     size_t slab;
     float sqrt_jitter;
-    const float *AT, *F0, *C, *m, *eps, *eps2;      // A^T [P,L,Mz,N], slabs [SK][P,S,L,J], q_sqrt [P,L,Mz,Mz], m [P,L,Mz], noise [P,S,Mz,L]
+    const float *AT, *F0, *U, *eps2;
     float *R, *f;
 };
 
