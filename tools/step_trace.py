@@ -32,7 +32,7 @@ NAMES = {100: "cov_a start", 101: "cov_a Kuu built", 102: "cov_a factorised", 10
          240: "gemm first wg start", 241: "gemm first wg mfma done", 242: "gemm first wg end", 245: "gemm last wg end",
          300: "paths_fwd start", 301: "paths_fwd staged", 302: "paths_fwd end", 305: "paths_fwd last wg end",
          310: "rng basis start", 320: "rng w start", 321: "rng w first wg end", 325: "rng w last wg end",
-         400: "loglik first wg start", 402: "loglik robot + f loaded", 403: "loglik frames done", 404: "loglik spheres done", 401: "loglik first wg end", 406: "loglik path requests issued", 407: "loglik path operands landed", 408: "loglik r formed", 405: "loglik last wg end",
+         400: "loglik first wg start", 402: "loglik robot + f loaded", 403: "loglik frames done", 404: "loglik spheres done", 401: "loglik first wg end", 405: "loglik last wg end",
          500: "paths_bwd start", 501: "paths_bwd staged", 502: "paths_bwd loops", 503: "paths_bwd end",
          505: "paths_bwd last wg end", 506: "paths_bwd requests issued", 507: "paths_bwd operands landed", 600: "hyper start", 601: "hyper end"}
 

@@ -622,30 +622,30 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
     float* fasm = rs + L * 32;                           // [L][16]   the assembled f of the tile
     // PATHS: thread t < 16 L forms f of (latent t / 16, column t % 16) by ONE fmaf chain over the 32 inducing points -- the order
     // in which v_mfma_f32_16x16x4_f32 accumulates (k ascending: the same bits as paths_fwd_split_body's tiles) -- and loads its
-    // row of A and its slab entries straight from memory (L2 resident); thread t < 32 L forms r[t] for everybody
+    // column of A^T and its slab entries straight from memory (L2 resident); thread t < 32 L forms r[t] for everybody
     constexpr int kFT = 16 * 8 <= kLikBlock ? 1 : 2;     // columns per thread if 16 L exceeded the workgroup (it does not: L <= 8)
     static_assert(kFT == 1, "one (latent, column) per thread");
-    float4 arow[8];                                      // this thread's row of A
-    float f0c[SK > 0 ? SK : 1];
+    float atc[32], f0c[SK > 0 ? SK : 1];
     float ru[2], re2[2], rz[2][SK > 0 ? SK : 1];
     const int fl = tid >> 4, fj = tid & 15, fjc = min(fj, N - 1 - n0);
     if (PATHS) {
         if constexpr (PATHS) {
-            // (32-bit element offsets from uniform bases: one address register per request)
-            const unsigned J = N + 32, sl = pb * S + s, l = min(fl, L - 1);
+            const int J = N + 32;
+            const size_t sl = (size_t)pb * S + s;
+            const int l = min(fl, L - 1);
+            const float* atp = lpa.AT + ((size_t)(pb * L + l) * 32) * N + n0 + fjc;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) atc[k] = atp[(size_t)k * N];
+#pragma unroll
+            for (int k = 0; k < SK; ++k) f0c[k] = lpa.F0[(size_t)k * lpa.slab + (sl * L + l) * J + n0 + fjc];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const unsigned e = min(tid + q * kLikBlock, L * 32 - 1), el = e >> 5, em = e & 31;
+                const int e = min(tid + q * kLikBlock, L * 32 - 1), el = e >> 5, em = e & 31;
                 ru[q] = lpa.U[(sl * L + el) * 32 + em];
                 re2[q] = lpa.eps2[(sl * 32 + em) * L + el];
 #pragma unroll
-                for (int k = 0; k < SK; ++k) rz[q][k] = (lpa.F0 + (size_t)k * lpa.slab)[(sl * L + el) * J + N + em];
+                for (int k = 0; k < SK; ++k) rz[q][k] = lpa.F0[(size_t)k * lpa.slab + (sl * L + el) * J + N + em];
             }
-            const float4* ap = reinterpret_cast<const float4*>(lpa.A) + ((pb * L + l) * (unsigned)N + n0 + fjc) * 8u;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) arow[k] = ap[k];
-#pragma unroll
-            for (int k = 0; k < SK; ++k) f0c[k] = (lpa.F0 + (size_t)k * lpa.slab)[(sl * L + l) * J + n0 + fjc];
         }
     }
     // this lane's joints: sub, sub + 4, ... (at most 4 of them)
@@ -660,10 +660,8 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
     float sig_own = 0.f;
     if (SIG && tid < VGPMP_MAX_SPHERES) sig_own = sigma_eff[(size_t)pb * VGPMP_MAX_SPHERES + tid];
     const float scl = SIG ? -alpha_eff[pb] : scale;
-    VG_T(PATHS && blockIdx.x == 0 && pb == 0, 406);
     vg_dma_wait();
     __syncthreads();
-    VG_T(PATHS && blockIdx.x == 0 && pb == 0, 407);
     if (SIG) {
         if (tid < VGPMP_MAX_SPHERES) {
             const_cast<vgpmp_robot*>(rb)->sigma_obs[tid] = sig_own;
@@ -691,7 +689,6 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
                 }
             }
             __syncthreads();
-            VG_T(blockIdx.x == 0 && pb == 0, 408);
             if (fl < L) {
                 float v[SK];
 #pragma unroll
@@ -703,13 +700,7 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
                 float acc = v[0];
                 const float* rp = rs + fl * 32;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float4 r4 = reinterpret_cast<const float4*>(rp)[k];
-                    acc = fmaf(r4.x, arow[k].x, acc);
-                    acc = fmaf(r4.y, arow[k].y, acc);
-                    acc = fmaf(r4.z, arow[k].z, acc);
-                    acc = fmaf(r4.w, arow[k].w, acc);
-                }
+                for (int k = 0; k < 32; ++k) acc = fmaf(rp[k], atc[k], acc);
                 fasm[fl * 16 + fj] = acc;
                 if (n0 + fj < N) vg_stream(lpa.f + (sl * L + fl) * N + n0 + fj, acc);
             }

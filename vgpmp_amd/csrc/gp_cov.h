@@ -899,7 +899,6 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
         const float av = cnt == 0 ? av0 : av1;
         vg_stream(A4 + (size_t)n * Mz + m, make_float4((float)ar[e], (float)s, av, 0.f));
         vg_stream(AT + (size_t)m * N + n, (float)ar[e]);
-        if (a.form_u) vg_stream(a.ws.An + (pl * N + n) * Mz + m, (float)ar[e]);      // rows of A for the likelihood's own path assembly
     }
     VG_T(tile == 0 && l == 0 && p == 0, 231);
 }

@@ -19,7 +19,6 @@ struct vg_workspace {
     // float32 operands of the sample path
     float *A4;               // [P,L,N,Mz,4]  {A, dA/dell, dA/dvar, 0},  A = Kfu (Kuu + jI)^-1
     float *AT;               // [P,L,Mz,N]    A transposed
-    float *An;               // [P,L,N,Mz]    A alone (written when the likelihood assembles its paths: a thread reads a whole row)
     float *C;                // [P,L,Mz,Mz]   q_sqrt (full)
     float *CT;               // [P,L,Mz,Mz]   q_sqrt^T
     float *CT_ell, *CT_var;  // [P,L,Mz,Mz]   (dC/d theta)^T

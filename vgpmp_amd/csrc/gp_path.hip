@@ -370,7 +370,6 @@ size_t vg_layout_workspace(const vgpmp_dims* d, void* base, vg_workspace* ws) {
     ws->gkl_var = carve<double>(cur, PL, real);
     ws->A4 = carve<float>(cur, PL * N * Mz * 4, real);
     ws->AT = carve<float>(cur, PL * N * Mz, real);
-    ws->An = carve<float>(cur, PL * N * Mz, real);
     ws->C = carve<float>(cur, PL * Mz * Mz, real);
     ws->CT = carve<float>(cur, PL * Mz * Mz, real);
     ws->CT_ell = carve<float>(cur, PL * Mz * Mz, real);
@@ -721,7 +720,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     }
 
     vg_lik_paths lpa;
-    lpa.SK = SK; lpa.slab = slab; lpa.sqrt_jitter = pa.sqrt_jitter; lpa.A = ws->An; lpa.F0 = ws->F0; lpa.U = ws->U;
+    lpa.SK = SK; lpa.slab = slab; lpa.sqrt_jitter = pa.sqrt_jitter; lpa.AT = ws->AT; lpa.F0 = ws->F0; lpa.U = ws->U;
     lpa.eps2 = nz->eps2; lpa.R = ws->R; lpa.f = out->f;
     for (int i = 0; i < num_steps; ++i) {
         const bool first = i == 0, more = i + 1 < num_steps;

@@ -307,7 +307,7 @@ struct vg_lik_paths {
     int SK;                  // split-K slabs of the prior draws (2, 4 or 8)
     size_t slab;
     float sqrt_jitter;
-    const float *A, *F0, *U, *eps2;        // A [P,L,N,Mz] (ws.An), slabs [SK][P,S,L,J], U [P,S,L,Mz], eps' [P,S,Mz,L]
+    const float *AT, *F0, *U, *eps2;
     float *R, *f;
 };
 
