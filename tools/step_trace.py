@@ -22,7 +22,8 @@ NAMES = {100: "cov_a start", 101: "cov_a Kuu built", 102: "cov_a factorised", 10
          104: "cov_a panel 1 loaded", 105: "cov_a panel 1 eliminated", 106: "cov_a panel 1 stored", 107: "cov_a second block row formed",
          108: "cov_a panel 2 loaded", 109: "cov_a panel 2 eliminated", 140: "cov_a panel 2 stored", 141: "cov_a workgroup joined",
          120: "eps start", 130: "features first wg start", 131: "features first wg end", 135: "features last wg end",
-         200: "cov_b q start", 201: "cov_b q staged", 202: "cov_b q end",
+         200: "cov_b KL start", 201: "cov_b KL staged", 202: "cov_b KL end",
+         250: "cov_b q_sqrt role start", 251: "cov_b q_sqrt role staged", 252: "cov_b q_sqrt role end",
          210: "cov_b d/dell start", 211: "cov_b d/dell staged", 212: "cov_b d/dell matmuls", 213: "cov_b d/dell end",
          220: "cov_b d/dvar start", 221: "cov_b d/dvar staged", 222: "cov_b d/dvar matmuls", 223: "cov_b d/dvar end",
          214: "d/dell af done", 215: "d/dell matmul 1", 216: "d/dell matmul 2", 217: "d/dell matmul 3",

@@ -30,9 +30,9 @@ struct CovArgs {
     double* lr_dev;
     // hyper-parameter update of the previous step as a prologue (stage 1) / its commit (stage 2, role 0)
     int prologue, commit, keep_prev;
-    // stage B, role 0 also forms U = m + C eps of every sample (ws.U) for the likelihood that assembles its own paths
+    // stage B, role 3 also forms U = m + C eps of every sample (ws.U) for the likelihood that assembles its own paths
     // (Mz = 32): the MFMA sequence of paths_fwd_split_body on the float32 C it has just built
-    int form_u, S, u_role;
+    int form_u, S;
     const float* eps;        // [P,L,S,Mz]  (ws.epsT: the generator's second copy, a latent's rows contiguous)
     HyperArgs hy;
     vg_workspace ws;
@@ -510,33 +510,48 @@ __global__ __launch_bounds__(kCovThreads) void cov_a_kernel(CovArgs a) {
 }
 
 // ---- stage B: heterogeneous launch, role = blockIdx.x ---------------------------------------------
-//   0            q_sqrt = Lk pad(Q) + jitter, q_mu, KL and its gradient wrt q_mu / q_sqrt
+//   0            KL and its gradient wrt q_mu / q_sqrt
 //   1, 2         forward-mode tangent wrt lengthscale / variance:  dC = (Lk Phi(Lk^-1 dK Lk^-T)) pad(Q), dKL
-//   3 + t        row tile t of A = Kfu (Kuu + jI)^-1 and its tangents (cov_rows_body)
+//   3            q_sqrt = Lk pad(Q) + jitter, m, the float32 copy of Lk -- and, when the likelihood assembles the paths
+//                itself, U = m + C eps of every sample.  (KL and q_sqrt were one role: the longest of the stage, 14 us
+//                against the tangents' 13; apart they take 6 and 9.)
+//   4 + t        row tile t of A = Kfu (Kuu + jI)^-1 and its tangents (cov_rows_body)
+constexpr int kCovRoleC = 3, kCovFixedRoles = 4;
 __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int p, int tid, int nt);
 
 template <bool TANGENTS>
 __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int role, int l, int p) {
     __shared__ double red[kCovThreads / VG_WAVE];
     const int tid = threadIdx.x, nt = blockDim.x;
-    // the extra role of the launch whose likelihood assembles its paths: q_sqrt = Lk pad(Q) + jitter once more (role 0's
-    // operands through role 0's product: the same bits) and U = m + C eps of every sample from it -- beside role 0, which
-    // ends the stage, not behind it
-    const bool form_u = a.form_u != 0 && role == a.u_role;
-    if (form_u) role = 0;
-    if (role >= 3) {
-        // The step counter ticks where no kernel that reads it runs alongside: noise drawn before this launch
-        // saw the old value, the noise of the next step and the Adam count see the new one.
-        if (a.tick && role == 3 && l == 0 && p == 0 && tid == 0) {
-            const uint32_t t = *a.tick + 1u;          // = 1-based Adam count of this step's update
-            *a.tick = t;
-            a.lr_dev[0] = adam_step_size(a.lr, (double)t);
+    if (role >= kCovFixedRoles) {
+        if (role == kCovFixedRoles) {      // the first row tile of (l, p) carries the launch's small chores
+            // The step counter ticks where no kernel that reads it runs alongside: noise drawn before this launch
+            // saw the old value, the noise of the next step and the Adam count see the new one.
+            if (a.tick && l == 0 && p == 0 && tid == 0) {
+                const uint32_t t = *a.tick + 1u;          // = 1-based Adam count of this step's update
+                *a.tick = t;
+                a.lr_dev[0] = adam_step_size(a.lr, (double)t);
+            }
+            // one word per thread, one round trip (on thread 0 of role 0 these were two serial ones on the role that
+            // ended the stage)
+            const size_t pl = (size_t)p * a.L + l;
+            if (a.commit && a.hy.do_adam && tid < 6) {      // staged hyper-parameters of the prologue -> their tensors
+                const HyperArgs& h = a.hy;
+                double* dst = tid == 0 ? h.p_ell : tid == 1 ? h.p_var : tid == 2 ? h.m_ell : tid == 3 ? h.v_ell : tid == 4 ? h.m_var : h.v_var;
+                dst[pl] = h.next[6 * pl + tid];
+            }
+            if (a.keep_prev && tid >= 8 && tid < 11) {      // this step's var / slopes for the prologue of the next step
+                const double* src = tid == 8 ? a.ws.var : tid == 9 ? a.ws.sig_ell : a.ws.sig_var;
+                double* dst = tid == 8 ? a.ws.prev_var : tid == 9 ? a.ws.prev_sig_ell : a.ws.prev_sig_var;
+                dst[pl] = src[pl];
+            }
         }
-        cov_rows_body(a, sm, role - 3, l, p, tid, nt);
+        cov_rows_body(a, sm, role - kCovFixedRoles, l, p, tid, nt);
         return;
     }
-    if (role > 0 && (!TANGENTS || (role == 1 && !a.want_dell))) return;
-    VG_T(l == 0 && p == 0, 200 + 10 * role);
+    const bool crole = role == kCovRoleC, form_u = crole && a.form_u != 0;
+    if ((role == 1 || role == 2) && (!TANGENTS || (role == 1 && !a.want_dell))) return;
+    VG_T(l == 0 && p == 0, 200 + 10 * (crole ? 5 : role));
     const int M = a.M, Mz = M + 2, L = a.L;
     const int Mp = (Mz + 15) & ~15, ld = Mp + 2;      // even: LDS rows start on 16 bytes
     const float iMz = 1.0f / (float)Mz, iM = 1.0f / (float)M;
@@ -556,7 +571,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     double* Kd = X1;
     double* T = X2;
     double* qm = kd1 + Mp;           // [Mp] q_mu behind the two conditioned points
-    // role 0 with form_u (Mz == 32): float32 q_sqrt^T and m in the scratch of the tangent roles, every sample's eps behind
+    // role 3 with form_u (Mz == 32): float32 q_sqrt^T and m in the scratch of the tangent roles, every sample's eps behind
     // the float64 regions (the launch's dynamic LDS is sized for it)
     float* ctl = reinterpret_cast<float*>(X2);          // [Mz][Mz]
     float* ml = ctl + Mz * Mz;                          // [Mz]
@@ -566,23 +581,24 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     const double* Kg = a.ws.Ks64 + pl * Mz * Mz;
     constexpr int kQRegs = (VGPMP_MAX_MZ - 2) * (VGPMP_MAX_MZ - 2) / kCovThreads + 1;
     double qreg[kQRegs];
+    double mine_qmu = 0.0;            // (role 3) q_mu of row tid
+    static_assert(VGPMP_MAX_MZ <= kCovThreads, "one row of m per thread");
     {
         // every operand by DMA, all requests in flight together (zero padding written directly)
         const double* Qg = a.q_sqrt + pl * M * M;
         auto all = [](int, int) { return true; };
         const bool square = Mz == Mp;      // no zero padding needed: whole rows in 16-byte units
         if (square) {
-            vg_stage_f64_square(La, ld, a.ws.Lk64 + pl * Mz * Mz, Mz, tid, nt);
-            if (!form_u) vg_stage_f64_square(Li, ld, a.ws.Li64 + pl * Mz * Mz, Mz, tid, nt);
+            if (role != 0) vg_stage_f64_square(La, ld, a.ws.Lk64 + pl * Mz * Mz, Mz, tid, nt);
+            if (!crole) vg_stage_f64_square(Li, ld, a.ws.Li64 + pl * Mz * Mz, Mz, tid, nt);
         } else {
-            vg_stage_f64(La, Mp, ld, a.ws.Lk64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
-            vg_stage_f64(Li, Mp, ld, a.ws.Li64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
+            if (role != 0) vg_stage_f64(La, Mp, ld, a.ws.Lk64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
+            if (!crole) vg_stage_f64(Li, Mp, ld, a.ws.Li64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
         }
-        if (role == 0 && square && !(M & 1)) {
+        if (crole && square && !(M & 1)) {
             // pad(Q) with Q at [2:, 2:] as ONE linear image of 16-byte units (ld even: a unit = two columns of a row): units
             // inside the block come from the rows of q_sqrt by DMA, the others are zeros written directly; the upper triangle
-            // of the block is cleared behind the wait.  (Two 4-byte requests per double made this the longest staging of the
-            // stage, on the role that ends it.)
+            // of the block is cleared behind the wait.
             const int upl = ld >> 1, total = Mp * upl, lane = tid & (VG_WAVE - 1);
             for (int c0 = (tid & ~(VG_WAVE - 1)); c0 < total; c0 += nt) {
                 const int iu = c0 + lane;
@@ -594,117 +610,67 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
                         reinterpret_cast<double2*>(Qp)[iu] = make_double2(0.0, 0.0);
                 }
             }
-        } else if (role == 0) {
+        } else if (crole) {
             vg_stage_f64(Qp, Mp, ld, Qg, M, M, 2, 2, tid, nt, [](int r, int c) { return c <= r; });
-        } else {      // tangents: this thread's share of Q waits in registers until Lk's LDS space is free
-            const double* Kdg = role == 1 ? a.ws.Kd_ell + pl * Mz * Mz : Kg;
-            if (square) vg_stage_f64_square(Kd, ld, Kdg, Mz, tid, nt);
-            else vg_stage_f64(Kd, Mp, ld, Kdg, Mz, Mz, 0, 0, tid, nt, all);
+        } else {
+            if (role != 0) {
+                const double* Kdg = role == 1 ? a.ws.Kd_ell + pl * Mz * Mz : Kg;
+                if (square) vg_stage_f64_square(Kd, ld, Kdg, Mz, tid, nt);
+                else vg_stage_f64(Kd, Mp, ld, Kdg, Mz, Mz, 0, 0, tid, nt, all);
+            }
+            // this thread's share of Q in registers: the KL terms are element-wise; the tangents write theirs where Lk was
+            // once Lk has been used
 #pragma unroll
             for (int k = 0; k < kQRegs; ++k) qreg[k] = Qg[min(tid + k * nt, M * M - 1)];
         }
-        // k0 | k1: the first two columns of Kuu;  qm: q_mu at [2:]
-        vg_stage_words(k0, 4 * Mp, tid, nt, [&](int w) -> const void* {
-            const int d = w >> 1, col = d >= Mp, i = d - col * Mp;
-            return i < Mz ? reinterpret_cast<const uint32_t*>(Kg + (size_t)i * Mz + col) + (w & 1) : nullptr;
-        });
-        vg_stage_words(qm, 2 * Mp, tid, nt, [&](int w) -> const void* {
-            const int i = w >> 1;
-            return (i >= 2 && i < Mz) ? reinterpret_cast<const uint32_t*>(a.q_mu + pl * M + (i - 2)) + (w & 1) : nullptr;
-        });
-        // the samples' eps for U (16-byte units, behind what the float64 chain needs: every barrier waits for outstanding
-        // requests, so later would not be cheaper)
+        if (!crole) {
+            // k0 | k1: the first two columns of Kuu;  qm: q_mu at [2:]
+            vg_stage_words(k0, 4 * Mp, tid, nt, [&](int w) -> const void* {
+                const int d = w >> 1, col = d >= Mp, i = d - col * Mp;
+                return i < Mz ? reinterpret_cast<const uint32_t*>(Kg + (size_t)i * Mz + col) + (w & 1) : nullptr;
+            });
+            vg_stage_words(qm, 2 * Mp, tid, nt, [&](int w) -> const void* {
+                const int i = w >> 1;
+                return (i >= 2 && i < Mz) ? reinterpret_cast<const uint32_t*>(a.q_mu + pl * M + (i - 2)) + (w & 1) : nullptr;
+            });
+        } else if (tid >= 2 && tid < Mz) mine_qmu = a.q_mu[pl * M + (tid - 2)];
+        // the samples' eps for U (16-byte units)
         if (form_u) vg_stage_16(epl, a.eps + pl * a.S * Mz, a.S * Mz / 4, tid, nt);
-    }
-    if (role == 0 && !form_u && tid == 0) {      // behind the staging requests: these round trips overlap them
-        if (a.commit && a.hy.do_adam) {      // staged hyper-parameters of the prologue -> their tensors
-            const HyperArgs& h = a.hy;
-            const double* nx = h.next + 6 * pl;
-            h.p_ell[pl] = nx[0]; h.p_var[pl] = nx[1]; h.m_ell[pl] = nx[2]; h.v_ell[pl] = nx[3]; h.m_var[pl] = nx[4];
-            h.v_var[pl] = nx[5];
-        }
-        if (a.keep_prev) {                   // this step's var / slopes for the prologue of the next step
-            a.ws.prev_var[pl] = a.ws.var[pl];
-            a.ws.prev_sig_ell[pl] = a.ws.sig_ell[pl];
-            a.ws.prev_sig_var[pl] = a.ws.sig_var[pl];
-        }
     }
     vg_dma_wait();
     __syncthreads();
-    // prior mean through the two conditioned points and a = Lk^-1 (q_mu - p_mu)  (prior_kl.py:16-35); the jitter on
-    // the two leading diagonal entries and the conditioned values are applied on the fly (no fix-up pass, no barrier)
-    const double k00 = k0[0] + jit, k01 = k1[0], k11 = k1[1] + jit;
-    const double det = k00 * k11 - k01 * k01;
-    const double c0 = (k11 * y0 - k01 * y1) / det, c1 = (k00 * y1 - k01 * y0) / det;
-    // (loads first, selects afterwards: a conditional load is a branch)
-    auto K0 = [&](int i) { const double v = k0[i]; return i == 0 ? k00 : v; };
-    auto K1 = [&](int i) { const double v = k1[i]; return i == 1 ? k11 : v; };
-    for (int i = tid; i < Mz; i += nt) {
-        const double qi = qm[i];
-        const double mi = i == 0 ? y0 : (i == 1 ? y1 : qi);
-        if (role == 0 && !form_u) a.ws.m[pl * Mz + i] = (float)mi;
-        if (form_u) ml[i] = (float)mi;
-        dl[i] = mi - (K0(i) * c0 + K1(i) * c1);
-    }
-    const double kd_scale = role == 2 ? 1.0 / var : 1.0;      // dK/dvar = K / var, applied to the products
-    if (role == 0 && Mz == Mp && !(M & 1)) {      // (16-byte staging of Q above: the strict upper triangle of the block is not Q's)
-        for (int e = tid; e < M * M; e += nt) {
-            const int r = vg_div(e, iM), c = e - r * M;
-            if (c > r) Qp[(r + 2) * ld + (c + 2)] = 0.0;
+    if (crole) {
+        // ---- role 3: m, the float32 Lk, q_sqrt = Lk pad(Q) + jitter I (first two diagonal entries), U
+        if (tid < Mz) {
+            const float mi = (float)(tid == 0 ? y0 : (tid == 1 ? y1 : mine_qmu));
+            a.ws.m[pl * Mz + tid] = mi;
+            if (form_u) ml[tid] = mi;
         }
-    }
-    if (role == 0 && !form_u) {              // float32 copy for the gradient assembly (written here, not in stage A:
-        float* Lk32 = a.ws.Lk32 + pl * Mz * Mz;      // stage A of the next step may overlap that kernel)
-        for (int e = tid; e < Mz * Mz; e += nt) {
-            const int i = vg_div(e, iMz), j = e - i * Mz;
-            Lk32[e] = (float)La[i * ld + j];
+        if (Mz == Mp && !(M & 1)) {      // (16-byte staging of Q above: the strict upper triangle of the block is not Q's)
+            for (int e = tid; e < M * M; e += nt) {
+                const int r = vg_div(e, iM), c = e - r * M;
+                if (c > r) Qp[(r + 2) * ld + (c + 2)] = 0.0;
+            }
         }
-    }
-    __syncthreads();
-    VG_T(l == 0 && p == 0, 201 + 10 * role);
-    double klacc = 0.0;
-    const int sub = tid & 7;
-    for (int i = tid >> 3; i < Mz && !form_u; i += nt >> 3) {      // af is read again only behind later barriers
-        const double s = dot8(Li + i * ld, 1, dl, 1, i + 1, sub);
-        if (sub == 0) {
-            af[i] = s;
-            if (i >= 2) klacc += s * s;
+        {                                    // float32 copy for the gradient assembly (written here, not in stage A:
+            float* Lk32 = a.ws.Lk32 + pl * Mz * Mz;      // stage A of the next step may overlap that kernel)
+            for (int e = tid; e < Mz * Mz; e += nt) {
+                const int i = vg_div(e, iMz), j = e - i * Mz;
+                Lk32[e] = (float)La[i * ld + j];
+            }
         }
-    }
-    if (role == 0) {
+        __syncthreads();
+        VG_T(l == 0 && p == 0, 251);
         float* C32 = a.ws.C + pl * Mz * Mz;
         float* C32T = a.ws.CT + pl * Mz * Mz;
         matmul_f64(MatView{La, ld, 1}, MatView{Qp, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
             if (r < Mz && c < Mz) {
                 const float cv = (float)(v + (r == c && r < 2 ? jit : 0.0));
+                C32[(size_t)r * Mz + c] = cv;
+                C32T[(size_t)c * Mz + r] = cv;
                 if (form_u) ctl[c * Mz + r] = cv;
-                else {
-                    C32[(size_t)r * Mz + c] = cv;
-                    C32T[(size_t)c * Mz + r] = cv;
-                }
             }
         });
-        if (!form_u) {
-        double* gklQ = a.ws.gkl_Q + pl * M * M;
-        for (int e = tid; e < M * M; e += nt) {
-            int r = vg_div(e, iM), c = e - r * M;
-            double gq = 0.0;
-            if (c <= r) {
-                double q = Qp[(r + 2) * ld + (c + 2)];
-                klacc += q * q;
-                gq = q;
-                if (c == r) { klacc -= log(q * q); gq -= 1.0 / q; }
-            }
-            gklQ[e] = gq;
-        }
-        const double kl = block_sum(klacc, red);
-        if (tid == 0) a.ws.kl_l[pl] = 0.5 * (kl - (double)M);
-        // d KL / d q_mu = (Lk^-T [0, 0, a])[2:]
-        for (int k = (tid >> 3) + 2; k < Mz; k += nt >> 3) {
-            const double g = dot8(Li + k * ld + k, ld, af + k, 1, Mz - k, sub);
-            if (sub == 0) a.ws.gkl_qmu[pl * M + (k - 2)] = g;
-        }
-        }
         if (form_u) {
             // U = m + eps C^T of every sample: sixteen samples per pass (two chunks of paths_fwd_split_body at once: its rows do
             // not mix), two 16-column tiles, eight k-interleaved MFMAs each -- the same operands in the same order, so the
@@ -735,6 +701,59 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
                     if (s < S) a.ws.U[(((size_t)p * S + s) * L + l) * 32 + mi] = acc[q];
                 }
             }
+        }
+        VG_T(l == 0 && p == 0, 252);
+        return;
+    }
+    // prior mean through the two conditioned points and a = Lk^-1 (q_mu - p_mu)  (prior_kl.py:16-35); the jitter on
+    // the two leading diagonal entries and the conditioned values are applied on the fly (no fix-up pass, no barrier)
+    const double k00 = k0[0] + jit, k01 = k1[0], k11 = k1[1] + jit;
+    const double det = k00 * k11 - k01 * k01;
+    const double c0 = (k11 * y0 - k01 * y1) / det, c1 = (k00 * y1 - k01 * y0) / det;
+    // (loads first, selects afterwards: a conditional load is a branch)
+    auto K0 = [&](int i) { const double v = k0[i]; return i == 0 ? k00 : v; };
+    auto K1 = [&](int i) { const double v = k1[i]; return i == 1 ? k11 : v; };
+    for (int i = tid; i < Mz; i += nt) {
+        const double qi = qm[i];
+        const double mi = i == 0 ? y0 : (i == 1 ? y1 : qi);
+        dl[i] = mi - (K0(i) * c0 + K1(i) * c1);
+    }
+    const double kd_scale = role == 2 ? 1.0 / var : 1.0;      // dK/dvar = K / var, applied to the products
+    __syncthreads();
+    VG_T(l == 0 && p == 0, 201 + 10 * role);
+    double klacc = 0.0;
+    const int sub = tid & 7;
+    for (int i = tid >> 3; i < Mz; i += nt >> 3) {      // af is read again only behind later barriers
+        const double s = dot8(Li + i * ld, 1, dl, 1, i + 1, sub);
+        if (sub == 0) {
+            af[i] = s;
+            if (i >= 2) klacc += s * s;
+        }
+    }
+    if (role == 0) {
+        // ---- role 0: KL and its gradient wrt q_mu / q_sqrt (Q from this thread's registers: element-wise terms)
+        double* gklQ = a.ws.gkl_Q + pl * M * M;
+#pragma unroll
+        for (int k = 0; k < kQRegs; ++k) {
+            const int e = tid + k * nt;
+            if (e < M * M) {
+                const int r = vg_div(e, iM), c = e - r * M;
+                double gq = 0.0;
+                if (c <= r) {
+                    const double q = qreg[k];
+                    klacc += q * q;
+                    gq = q;
+                    if (c == r) { klacc -= log(q * q); gq -= 1.0 / q; }
+                }
+                gklQ[e] = gq;
+            }
+        }
+        const double kl = block_sum(klacc, red);
+        if (tid == 0) a.ws.kl_l[pl] = 0.5 * (kl - (double)M);
+        // d KL / d q_mu = (Lk^-T [0, 0, a])[2:]
+        for (int k = (tid >> 3) + 2; k < Mz; k += nt >> 3) {
+            const double g = dot8(Li + k * ld + k, ld, af + k, 1, Mz - k, sub);
+            if (sub == 0) a.ws.gkl_qmu[pl * M + (k - 2)] = g;
         }
         VG_T(l == 0 && p == 0, 202);
         return;

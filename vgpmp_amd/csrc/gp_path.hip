@@ -629,7 +629,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const bool lik_paths = VG_LIK_PATHS && fused && gen && backward && split_fwd && split_bwd && Mz == 32 && !lk && !pb->ind &&
                            !(what & (VGPMP_LIK_LANES | VGPMP_LIK_LDS_STATE | VGPMP_NO_SPLIT)) && vg_lik_paths_fit(L, SK) &&
                            (long long)P * S * N <= 28672;
-    ca.form_u = lik_paths ? 1 : 0; ca.S = S; ca.eps = ws->epsT; ca.u_role = -1;
+    ca.form_u = lik_paths ? 1 : 0; ca.S = S; ca.eps = ws->epsT;
     const void* fn_s4 = SK == 2 ? (const void*)stage4_kernel<2, 32> : SK == 4 ? (const void*)stage4_kernel<4, 32> : (const void*)stage4_kernel<8, 32>;
     if (split_bwd) {
         fn_pb = Mz == 32 ? (SK == 2 ? (const void*)paths_bwd_split<2, 32> : SK == 4 ? (const void*)paths_bwd_split<4, 32>
@@ -675,7 +675,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     if (mid && (rc = set_dyn_lds(fn_midC, lds_midC))) return rc;
     if (!fused && (rc = set_dyn_lds((const void*)mid_cov_a_rng_kernel, lds_cov_a))) return rc;      // (the large-batch schedule merges its small launches with these two as well)
     if ((rc = set_dyn_lds((const void*)mid_hyper_final_kernel, lds_fin))) return rc;
-    const dim3 cov_b_grid(3 + (N + kRowTile - 1) / kRowTile, L, P);
+    const dim3 cov_b_grid(kCovFixedRoles + (N + kRowTile - 1) / kRowTile, L, P);
     const uint32_t eps_gx = (2u * (uint32_t)S * Mz * L + kBlock - 1) / kBlock;
     const uint32_t basis_gx = ((uint32_t)L * B + kBlock - 1) / kBlock;
     const uint32_t w_gx = (((uint32_t)S * L * B >> 2) + kBlock - 1) / kBlock;
@@ -764,9 +764,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             s2.skip = skip2;
             s2.cov = ca; s2.gemm = ga;
             s2.cov.hy = hyp; s2.cov.commit = prologue ? 1 : 0;
-            s2.cov_roles = (int)cov_b_grid.x + (lik_paths ? 1 : 0);      // (the extra role forms U = m + C eps)
-            s2.cov.u_role = lik_paths ? (int)cov_b_grid.x : -1;
-            s2.n_cov = (int)(s2.cov_roles * cov_b_grid.y * cov_b_grid.z);
+            s2.cov_roles = (int)cov_b_grid.x; s2.n_cov = (int)(cov_b_grid.x * cov_b_grid.y * cov_b_grid.z);
             s2.gemm_gx = (int)gemm_grid.x; s2.gemm_gy = (int)gemm_grid.y;
             const int n_gemm = (int)(gemm_grid.x * gemm_grid.y * gemm_grid.z);
             s2.n_gemm = n_gemm;
