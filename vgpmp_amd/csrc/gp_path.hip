@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void stage2_kernel(Stage2Args a) {
     }
     b -= a.n_cov;
     if (a.skip & 2) return;
-    // Workgroups go to the 8 XCDs round robin (n_cov is a multiple of 8 or the remap is off): give each XCD a
+    // Workgroups go to the 8 XCDs round robin: give each XCD a
     // CONTIGUOUS range of GEMM tiles, so the column / row tiles that share operands share an L2 as well.
     if (a.gemm_per_xcd > 0) b = (b & 7) * a.gemm_per_xcd + (b >> 3);
     const int bx = b % a.gemm_gx;
@@ -768,7 +768,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             s2.gemm_gx = (int)gemm_grid.x; s2.gemm_gy = (int)gemm_grid.y;
             const int n_gemm = (int)(gemm_grid.x * gemm_grid.y * gemm_grid.z);
             s2.n_gemm = n_gemm;
-            s2.gemm_per_xcd = ((gemm_first || s2.n_cov % 8 == 0) && n_gemm % 8 == 0) ? n_gemm / 8 : 0;
+            // (tiles whose index agrees mod 8 share an XCD whatever the number of covariance workgroups in front of them)
+            s2.gemm_per_xcd = n_gemm % 8 == 0 ? n_gemm / 8 : 0;
             if ((rc = launch(fn_s2, dim3(s2.n_cov + gemm_grid.x * gemm_grid.y * gemm_grid.z), &s2, lds_s2))) return rc;
             if (!lik_paths) {
                 Stage3Args s3;
