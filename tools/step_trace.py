@@ -49,7 +49,8 @@ def main():
     pp = ps.planner_params
     sc = engine.DeviceScene(spec, grid, ps.object_positions[0], sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"])
     qs = np.array([ps.queries[i % len(ps.queries)] for i in range(P)])
-    pl = engine.PlannerBatch(sc, qs, num_samples=128, num_inducing=30, num_data=100, num_bases=1024,
+    env = lambda k, d: int(os.environ.get(k, d))      # SAMPLES / INDUCING / TIMESTEPS: other shapes than config 2's
+    pl = engine.PlannerBatch(sc, qs, num_samples=env("SAMPLES", 128), num_inducing=env("INDUCING", 30), num_data=env("TIMESTEPS", 100), num_bases=1024,
                              lengthscales=pp["lengthscales"], variance=pp["variance"], alpha=pp["alpha"],
                              learning_rate=pp["learning_rate"], seed=1)
     pl.fuse = os.environ.get("NO_FUSE") is None

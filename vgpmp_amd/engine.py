@@ -344,10 +344,15 @@ class PlannerBatch:
         self._run(capi.DO_FORWARD | (capi.GEN_NOISE if generate else 0), self.t if step is None else step)
         return self.lik - self.kl
 
-    def loss_and_grad(self, generate: bool = True, step: Optional[int] = None):
-        """loss = -ELBO and its gradient wrt the unconstrained variables (no update)."""
+    def accumulate_grad(self, generate: bool = True, step: Optional[int] = None) -> None:
+        """Forward and reverse pass into self.lik / self.kl / self.grad; no update and nothing else on the stream (the
+        sample-sharded step calls this every iteration: forming the loss tensor as well cost two launches per step)."""
         self._run(capi.DO_FORWARD | capi.DO_BACKWARD | (capi.GEN_NOISE if generate else 0),
                   self.t if step is None else step)
+
+    def loss_and_grad(self, generate: bool = True, step: Optional[int] = None):
+        """loss = -ELBO and its gradient wrt the unconstrained variables (no update)."""
+        self.accumulate_grad(generate, step)
         return -(self.lik - self.kl), self.grad
 
     def step(self, generate: bool = True) -> None:

@@ -107,7 +107,7 @@ class SampleShardedPlanner:
         keep = pl.extra_flags
         pl.extra_flags = keep | capi.NOISE_AHEAD | (capi.NOISE_READY if self._chained_at == pl.t else 0)
         try:
-            pl.loss_and_grad(generate=True, step=pl.t)        # local samples; KL only where kl_scale = 1
+            pl.accumulate_grad(generate=True, step=pl.t)      # local samples; KL only where kl_scale = 1
         finally:
             pl.extra_flags = keep
         self._chained_at = pl.t + 1
