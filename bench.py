@@ -136,7 +136,7 @@ def build_problem(rank: int, args, world: int = 1):
                                       sample_offset=s_off, kl_scale=1.0 if rank == 0 else 0.0,
                                       num_inducing=args.inducing, num_data=args.timesteps, num_bases=1024,
                                       lengthscales=pp["lengthscales"], variance=pp["variance"], alpha=pp["alpha"],
-                                      learning_rate=pp["learning_rate"], seed=1234)
+                                      learning_rate=pp["learning_rate"], seed=1234, split_k=args.split_k or None)
         return ps, spec, grid, scene, planner
     scene_name = "industrial"
     if args.workload == "config3":

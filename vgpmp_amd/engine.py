@@ -200,7 +200,10 @@ class PlannerBatch:
             # large batches: the LDS-tiled GEMM (no slices) -- its 64-sample tiles need S >= 48 to pay off
             # K-slices pay while the launch is small: measured on config 2 shapes, 2 problems 88 vs 99 us per step with 4
             # slices, 3 problems 130 vs 123, 4 problems 152 vs 148, 5 up: one launch per kernel with the tiled GEMM
-            split_k = 4 if (P * L <= 16 or S < 48) else 1
+            # (the measure is the number of 64-sample row tiles, not of problems: ONE problem with 1024 samples -- config 4 on
+            #  one rank, 96 row tiles -- takes 134 us per step without slices, 151 with four)
+            row_tiles = -(-S // 64) * P * L
+            split_k = 4 if (row_tiles <= 32 or S < 48) else 1
             while (B // split_k) % 16:
                 split_k //= 2
         self.dims = capi.Dims(P, S, int(samples_total or S), N, M, L, B, int(split_k), int(sample_offset), 0)
