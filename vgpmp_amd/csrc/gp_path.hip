@@ -432,7 +432,7 @@ int vg_launch_rng(const vgpmp_dims* d, const vgpmp_noise* nz, uint32_t seed, uin
     RngArgs r = make_rng_args(d, nz, seed, problem_base, step, ctr, 0u);
     r.epsT = epsT;
     hipLaunchKernelGGL(rng_basis_kernel, dim3((r.L * r.B + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
-    const uint32_t nthr = (r.nW >> 2) + 2 * r.nE;
+    const uint32_t nthr = rng_normal_threads(r.nW, r.nE, r.eOff);
     hipLaunchKernelGGL(rng_normals_kernel, dim3((nthr + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
     return (int)hipGetLastError();
 }
@@ -676,7 +676,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     if (!fused && (rc = set_dyn_lds((const void*)mid_cov_a_rng_kernel, lds_cov_a))) return rc;      // (the large-batch schedule merges its small launches with these two as well)
     if ((rc = set_dyn_lds((const void*)mid_hyper_final_kernel, lds_fin))) return rc;
     const dim3 cov_b_grid(kCovFixedRoles + (N + kRowTile - 1) / kRowTile, L, P);
-    const uint32_t eps_gx = (2u * (uint32_t)S * Mz * L + kBlock - 1) / kBlock;
+    const uint32_t eps_gx = (2u * rng_eps_quads((uint32_t)S * Mz * L, (uint32_t)d->sample_offset * Mz * L) + kBlock - 1) / kBlock;
     const uint32_t basis_gx = ((uint32_t)L * B + kBlock - 1) / kBlock;
     const uint32_t w_gx = (((uint32_t)S * L * B >> 2) + kBlock - 1) / kBlock;
     auto launch = [&](const void* fn, dim3 grid, void* arg, size_t lds) -> int {
@@ -791,7 +791,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             ma.cov = ca;
             ma.rng = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
             ma.n_cov = L * P; ma.basis_gx = (int)basis_gx; ma.n_basis = gen ? (int)basis_gx * P : 0;
-            const uint32_t n_thr = (ma.rng.nW >> 2) + 2 * ma.rng.nE;
+            const uint32_t n_thr = rng_normal_threads(ma.rng.nW, ma.rng.nE, ma.rng.eOff);
             ma.n_gx = (int)((n_thr + kBlock - 1) / kBlock);
             const unsigned nA = ma.n_cov + ma.n_basis + (gen ? (unsigned)ma.n_gx * P : 0u);
             if ((rc = launch((const void*)mid_cov_a_rng_kernel, dim3(nA), &ma, lds_cov_a))) return rc;
@@ -829,7 +829,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 ma.rng = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
                 if (fbatch) ma.rng.nW = 0;               // omega, beta, eps, eps2 only
                 ma.n_cov = L * P; ma.basis_gx = (int)((ma.rng.L * ma.rng.B + kBlock - 1) / kBlock); ma.n_basis = ma.basis_gx * P;
-                const uint32_t n_thr = (ma.rng.nW >> 2) + 2 * ma.rng.nE;
+                const uint32_t n_thr = rng_normal_threads(ma.rng.nW, ma.rng.nE, ma.rng.eOff);
                 ma.n_gx = (int)((n_thr + kBlock - 1) / kBlock);
                 if ((rc = launch((const void*)mid_cov_a_rng_kernel, dim3(ma.n_cov + ma.n_basis + (unsigned)ma.n_gx * P), &ma, lds_cov_a))) return rc;
             } else {
@@ -849,7 +849,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 RngArgs r = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
                 if (fbatch) r.nW = 0;                    // omega, beta, eps, eps2 only
                 hipLaunchKernelGGL(rng_basis_kernel, dim3((r.L * r.B + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
-                const uint32_t nthr = (r.nW >> 2) + 2 * r.nE;
+                const uint32_t nthr = rng_normal_threads(r.nW, r.nE, r.eOff);
                 hipLaunchKernelGGL(rng_normals_kernel, dim3((nthr + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
             }
             mark();

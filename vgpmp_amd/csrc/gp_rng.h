@@ -19,45 +19,60 @@ struct RngArgs {
 
 __device__ __forceinline__ uint32_t rng_step(const RngArgs& a) { return a.ctr ? *a.ctr + a.bias : a.step; }
 
-// omega [P,L,B,D] (Student-t, nu = 5: N(0,1) * rsqrt(chi2_5 / 5)) and beta [P,L,B]
+// omega [P,L,B,D] (Student-t, nu = 5: N(0,1) * rsqrt(chi2_5 / 5)) and beta [P,L,B].
+// A workgroup owns kBlock consecutive rows (l, b): each thread draws its row's chi-square scale (two counters, 5 of 8
+// normals) into LDS, then the workgroup walks the omega counters of its rows -- kBlock D / 4 of them, contiguous in memory --
+// one counter per thread and pass: four normals, their rows' scales, ONE aligned 16-byte store.  (A thread per row wrote its
+// D values by D scattered 4-byte stores and regenerated the counters that straddle two rows: 60 us at 64 x 14 latents, most
+// of it in the store path.)  beta: the thread of every fourth row draws four.
 __device__ __forceinline__ void rng_basis_body(const RngArgs& a, int bx, int p) {
-    const int L = a.L, B = a.B, D = a.D;
+    __shared__ float sc_s[kBlock];
+    const int L = a.L, B = a.B, D = a.D, tid = threadIdx.x;
     VG_T(bx == 0 && p == 0, 310);
-    const uint32_t lb = bx * kBlock + threadIdx.x;
-    if (lb >= (uint32_t)(L * B)) return;
+    const uint32_t rows = (uint32_t)(L * B), r0 = (uint32_t)bx * kBlock, lb = r0 + tid;
+    const uint32_t nrow = min((uint32_t)kBlock, rows - r0);          // rows % 16 == 0 (B % 16 == 0): nrow D % 4 == 0
     const uint2 key = vg_key(a.seed, a.problem_base + p, rng_step(a));
-    const uint32_t e0 = lb * (uint32_t)D, c_first = e0 >> 2, c_last = (e0 + D - 1) >> 2;
-    float* om = a.omega + ((size_t)p * L * B + lb) * D;
-    float gam = 0.f, sc = 0.f;
-    // pass q = 0,1: chi-square counters (5 of 8 normals); then the omega counters of this row
-#pragma nounroll
-    for (uint32_t q = 0; q < 2u + (c_last - c_first + 1u); ++q) {
-        const bool chi = q < 2u;
-        const uint32_t c = chi ? 2u * lb + q : c_first + (q - 2u);
-        const float4 v = vg_normal4(c, chi ? VG_STREAM_CHI : VG_STREAM_OMEGA, key);
-        if (chi) {
-            gam += q == 0u ? v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w : v.x * v.x;
-            if (q == 1u) sc = __builtin_amdgcn_rsqf(gam * 0.2f);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t e = 4u * c + k;
-                if (e >= e0 && e < e0 + (uint32_t)D) om[e - e0] = vg_lane(v, k) * sc;      // (plain stores: a wave's rows are contiguous and merge in L2)
-            }
+    if (lb < rows) {
+        const float4 v0 = vg_normal4(2u * lb, VG_STREAM_CHI, key), v1 = vg_normal4(2u * lb + 1u, VG_STREAM_CHI, key);
+        const float gam = v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w + v1.x * v1.x;
+        sc_s[tid] = __builtin_amdgcn_rsqf(gam * 0.2f);
+        if ((lb & 3u) == 0u) {
+            const uint4 r = vg_philox(make_uint4(lb >> 2, VG_STREAM_BETA, 0u, 0u), key);
+            vg_stream(reinterpret_cast<float4*>(a.beta + (size_t)p * rows + lb),
+                      make_float4(6.283185307179586f * vg_u01(r.x), 6.283185307179586f * vg_u01(r.y),
+                                  6.283185307179586f * vg_u01(r.z), 6.283185307179586f * vg_u01(r.w)));
         }
     }
-    uint4 r = vg_philox(make_uint4(lb >> 2, VG_STREAM_BETA, 0u, 0u), key);
-    uint32_t rb = (lb & 3u) == 0 ? r.x : (lb & 3u) == 1 ? r.y : (lb & 3u) == 2 ? r.z : r.w;
-    vg_stream(a.beta + (size_t)p * L * B + lb, 6.283185307179586f * vg_u01(rb));
+    __syncthreads();
+    const uint32_t e0 = r0 * (uint32_t)D, nq = nrow * (uint32_t)D >> 2;      // e0 % 4 == 0: kBlock % 4 == 0
+    float4* om = reinterpret_cast<float4*>(a.omega + (size_t)p * rows * D + e0);
+    for (uint32_t q = tid; q < nq; q += kBlock) {
+        const float4 v = vg_normal4((e0 >> 2) + q, VG_STREAM_OMEGA, key);
+        uint32_t row = (4u * q) / (uint32_t)D, rem = 4u * q - row * (uint32_t)D;      // local row of element 4 q, its column
+        float s[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s[k] = sc_s[row];
+            if (++rem == (uint32_t)D) { rem = 0u; ++row; }
+        }
+        om[q] = make_float4(v.x * s[0], v.y * s[1], v.z * s[2], v.w * s[3]);      // (plain stores: the features read them back through L2)
+    }
 }
 
 // w [P, nW]: counter i of the stream yields global elements 4i..4i+3 (wOff is a multiple of 4);
-// eps, eps2 [P, nE]: one thread per element (their global offset need not be aligned).
+// eps, eps2 [P, nE]: a thread per COUNTER of the stream as well -- elements eOff .. eOff + nE - 1 of the global sample axis,
+// which need not start on a counter (sample-sharded ranks): the first and last counters of a rank are partly its neighbours'.
+__host__ __device__ __forceinline__ uint32_t rng_eps_quads(uint32_t nE, uint32_t eOff) {
+    return nE ? ((eOff + nE - 1u) >> 2) - (eOff >> 2) + 1u : 0u;
+}
+__host__ __device__ __forceinline__ uint32_t rng_normal_threads(uint32_t nW, uint32_t nE, uint32_t eOff) {
+    return (nW >> 2) + 2u * rng_eps_quads(nE, eOff);
+}
 __device__ __forceinline__ void rng_normals_body(const RngArgs& a, int bx, int p, uint32_t nW, uint32_t nE) {
-    const uint32_t cW = nW >> 2;
+    const uint32_t cW = nW >> 2, nq = rng_eps_quads(nE, a.eOff);
     uint32_t c = bx * kBlock + threadIdx.x;
     VG_T(bx == 0 && p == 0, nW ? 320 : 120);
-    if (c >= cW + 2u * nE) return;
+    if (c >= cW + 2u * nq) return;
     const uint2 key = vg_key(a.seed, a.problem_base + p, rng_step(a));
     if (c < cW) {
         const float4 v = vg_normal4((a.wOff >> 2) + c, VG_STREAM_W, key);
@@ -67,13 +82,30 @@ __device__ __forceinline__ void rng_normals_body(const RngArgs& a, int bx, int p
         return;
     }
     c -= cW;
-    const bool second = c >= nE;
-    if (second) c -= nE;
-    const float v = vg_normal1(a.eOff + c, second ? VG_STREAM_EPS2 : VG_STREAM_EPS, key);
-    vg_stream((second ? a.eps2 : a.eps) + (size_t)p * nE + c, v);
-    if (a.epsT && !second) {                             // c = (s Mz + k) L + l
-        const uint32_t l = c % (uint32_t)a.L, sk = c / (uint32_t)a.L, k = sk % (uint32_t)a.Mz, s = sk / (uint32_t)a.Mz;
-        a.epsT[(((size_t)p * a.L + l) * a.S + s) * a.Mz + k] = v;
+    const bool second = c >= nq;
+    if (second) c -= nq;
+    const uint32_t q = (a.eOff >> 2) + c;                 // counter of the stream
+    const float4 v = vg_normal4(q, second ? VG_STREAM_EPS2 : VG_STREAM_EPS, key);
+    float* dst = (second ? a.eps2 : a.eps) + (size_t)p * nE;
+    const uint32_t first = 4u * q - a.eOff;               // local element of lane 0 (wraps below zero on a rank's first counter)
+    if (4u * q >= a.eOff && first + 3u < nE && ((((size_t)p * nE + first) & 3u) == 0u)) {
+        vg_stream(reinterpret_cast<float4*>(dst + first), v);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t e = first + (uint32_t)k;       // unsigned: an element below the rank's range compares >= nE
+            if (e < nE) vg_stream(dst + e, vg_lane(v, k));
+        }
+    }
+    if (a.epsT && !second) {                             // e = (s Mz + k) L + l
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t e = first + (uint32_t)k;
+            if (e < nE) {
+                const uint32_t l = e % (uint32_t)a.L, sk = e / (uint32_t)a.L, kk = sk % (uint32_t)a.Mz, s_ = sk / (uint32_t)a.Mz;
+                a.epsT[(((size_t)p * a.L + l) * a.S + s_) * a.Mz + kk] = vg_lane(v, k);
+            }
+        }
     }
 }
 
