@@ -669,7 +669,9 @@ def test_reverse_path_pass_over_several_chunks_per_workgroup_is_bitwise_the_same
         pl.step(); pl.step()
         loss, grads = pl.loss_and_grad(generate=True, step=5)
         torch.cuda.synchronize()
-        outs.append([loss.clone(), pl.q_mu.clone(), pl.q_sqrt.clone(), pl.raw_ell.clone(), pl.raw_var.clone()] + [g.clone() for g in grads])
-    assert float(outs[0][5].abs().max()) > 0
+        # (the flag also keeps the forward assembly on paths_fwd_sc8; without it paths_fwd_regs forms the paths: f and R as well)
+        outs.append([loss.clone(), pl.q_mu.clone(), pl.q_sqrt.clone(), pl.raw_ell.clone(), pl.raw_var.clone(), pl.f.clone(), pl.view("R")]
+                    + [g.clone() for g in grads])
+    assert float(outs[0][7].abs().max()) > 0
     for a, b in zip(*outs):
         assert torch.equal(a, b)

@@ -22,6 +22,9 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 #else
 #define VG_STOP(args, k) do { } while (0)
 #endif
+#ifndef VG_FWD_REGS
+#define VG_FWD_REGS 1        // 0: measurement builds with the forward path assembly of large batches on paths_fwd_sc8
+#endif
 #ifndef VG_PB_MIN_WGS
 #define VG_PB_MIN_WGS 1536    // reverse path pass: chunks per workgroup double while this many workgroups remain (six per CU)
 #endif
@@ -644,6 +647,12 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         fn_pb = (const void*)paths_bwd_regs<25>;
         lds_pb = ((size_t)16 * N + (size_t)32 * J + (size_t)8 * 16 * Mz + 8 * 4) * sizeof(float);
     }
+    // ... and the forward assembly likewise (paths_fwd_regs); both take pa.cpw chunks per workgroup
+    const bool regs_fwd = VG_FWD_REGS && !fused && !split_fwd && SK == 1 && Mz == 32 && N <= 128 && pa.cpw >= 2;
+    if (regs_fwd) {
+        fn_pf = (const void*)paths_fwd_regs<2>;
+        lds_pf = ((size_t)16 * (3 * Mz + J) + 4 * 4) * sizeof(float);
+    }
     if (backward && (rc = set_dyn_lds(fn_pb, lds_pb))) return rc;      // forward-only calls never launch the reverse pass
     if (lik_paths && (rc = set_dyn_lds(fn_s4, lds_pb))) return rc;
     if (fused) {
@@ -814,7 +823,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 hipLaunchKernelGGL(prior_gemm_tiled_kernel<1>, dim3((J + kTJ - 1) / kTJ, (S + kTS - 1) / kTS, P * L * ga.nsel),
                                    dim3(kBlock), lds_tg, st, tga);
             }
-            if ((rc = launch(fn_pf, dim3(NC * pa.nsplit, L, P), &pa, lds_pf))) return rc;
+            if ((rc = launch(fn_pf, dim3(regs_fwd ? (NC + pa.cpw - 1) / pa.cpw : NC * pa.nsplit, L, P), &pa, lds_pf))) return rc;
         } else {
             mark();
             // large batches drawing their own noise: W and the features are formed inside the GEMM (prior_fused_batch_kernel);
@@ -927,7 +936,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             else
                 hipExtLaunchKernelGGL(prior_gemm_kernel<0>, gemm_grid, dim3(kBlock), 0, st, g0, g1, 0, ga);
             mark();
-            if ((rc = launch(fn_pf, dim3(NC * pa.nsplit, L, P), &pa, lds_pf))) return rc;
+            if ((rc = launch(fn_pf, dim3(regs_fwd ? (NC + pa.cpw - 1) / pa.cpw : NC * pa.nsplit, L, P), &pa, lds_pf))) return rc;
             pa.tick = nullptr;
             mark();
             batch_merged = batch_merge;

@@ -932,6 +932,103 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_split(PathArgs a) {
     paths_bwd_split_body<SK, MZ>(a, smf, (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)), (int)gridDim.x);
 }
 
+// The forward path assembly of large batches (Mz = 32, one slab of prior draws, N <= 64 NT): what a latent's chunks share --
+// q_sqrt and A^T, the B operands of the two products -- lives in REGISTERS (a lane's fragments of all eight K steps: 8 for
+// the two waves that form u = m + eps C^T, 8 NT for every wave's time tiles), read once per workgroup; LDS holds only the
+// noise and the prior draws of the current PAIR of 8-sample chunks (15 KB instead of 36), the 16 x 16 tiles use all sixteen
+// rows (paths_fwd_sc8 leaves eight empty).  A row of a tile depends on that row's operands alone: the same numbers as
+// paths_fwd_sc8, bit for bit.  (paths_fwd_sc8 re-staged 17 KB of constants per 8 samples: 77 us at the config-5 share.)
+template <int NT>
+__global__ __launch_bounds__(kBlock, 4) void paths_fwd_regs(PathArgs a) {
+    constexpr int SC = 8, Mz = 32, R2 = 2 * SC;
+    extern __shared__ float smf[];
+    if (a.tick && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *a.tick += 1u;
+    const int l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = kBlock;
+    const int S = a.S, N = a.N, L = a.L, J = N + Mz;
+    const float iMz = 1.0f / (float)Mz;
+    const size_t pl = (size_t)p * L + l;
+    float* cur = smf;
+    auto take = [&](int n) { float* q = cur; cur += (n + 3) & ~3; return q; };      // 16-byte aligned regions
+    float* es2 = take(2 * R2 * Mz);                  // [16][Mz] eps, then [16][Mz] eps'
+    float* e2s2 = es2 + R2 * Mz;
+    float* f0s2 = take(R2 * J);                      // [16][J]  prior draws
+    float* rs2 = take(R2 * Mz);                      // [16][Mz]
+    const int wv = tid >> 6, lane = tid & 63, i = lane & 15, kk = lane >> 4;
+    // ---- B fragments of every K step, once per workgroup
+    float bAT[NT][8], bC[8];
+    int ncol[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        ncol[t] = 16 * (wv + 4 * t) + i;
+        const float* ATg = a.AT + pl * N * Mz + min(ncol[t], N - 1);
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) bAT[t][k8] = ATg[(size_t)(4 * k8 + kk) * N];
+    }
+    const int mi = 16 * (wv & 1) + i;
+    const float m0 = a.m[pl * Mz + mi];
+    {
+        const float* Cg = a.C + pl * Mz * Mz + mi * Mz;
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) bC[k8] = Cg[4 * k8 + kk];
+    }
+    const int cp_end = min((int)(blockIdx.x + 1) * a.cpw, a.NC);
+    for (int ch0 = blockIdx.x * a.cpw; ch0 < cp_end; ch0 += 2) {
+        const int s_base = ch0 * SC;
+        vg_stage_words(es2, 2 * R2 * Mz, tid, nt, [&](int w) -> const void* {
+            const int second = w >= R2 * Mz, e = second ? w - R2 * Mz : w;
+            const int sl = vg_div(e, iMz), k = e - sl * Mz, s = s_base + sl;
+            return s < S ? (second ? a.eps2 : a.eps) + (((size_t)p * S + s) * Mz + k) * L + l : nullptr;      // zero beyond S
+        });
+        vg_stage_rows(f0s2, R2, J, tid, nt, [&](int r) -> const float* {
+            return a.F0 + (((size_t)p * S + min(s_base + r, S - 1)) * L + l) * J;
+        });
+        vg_dma_wait();
+        __syncthreads();
+        if (wv < 2) {
+            // u = m + eps C^T on sixteen samples, this wave's sixteen inducing points; r = u - f0(Z) - sqrt(jitter) eps'
+            float av[8];
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) av[k8] = es2[i * Mz + 4 * k8 + kk];
+            vg_f32x4_t acc = {m0, m0, m0, m0};
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k8], bC[k8], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int sl = 4 * kk + q, e = sl * Mz + mi, s = s_base + sl;
+                const float r = vg_path_r(acc[q], f0s2[sl * J + N + mi], a.sqrt_jitter, e2s2[e]);
+                rs2[e] = r;
+                if (s < S) vg_stream(a.R + (((size_t)p * S + s) * L + l) * Mz + mi, r);
+            }
+        }
+        __syncthreads();
+        {
+            // f = f0(X) + r A^T: this wave's time tiles
+            float rv[8];
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) rv[k8] = rs2[i * Mz + 4 * k8 + kk];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (16 * (wv + 4 * t) < N) {             // (wave-uniform)
+                    const int n = min(ncol[t], N - 1);
+                    vg_f32x4_t acc;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = f0s2[(4 * kk + q) * J + n];
+#pragma unroll
+                    for (int k8 = 0; k8 < 8; ++k8) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rv[k8], bAT[t][k8], acc, 0, 0, 0);
+                    if (ncol[t] < N) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int s = s_base + 4 * kk + q;
+                            if (s < S) vg_stream(a.f + (((size_t)p * S + s) * L + l) * N + n, acc[q]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();      // the pair's operands are overwritten by the next one's
+    }
+}
+
 template <int SK, bool RAW>
 __global__ __launch_bounds__(kBlock) void paths_fwd_sc8(PathArgs a) {
     extern __shared__ float smf[];
