@@ -28,7 +28,7 @@ struct vg_workspace {
     float *F0, *H;           // [SK][P,S,L,J]
     float *R;                // [P,S,L,Mz]
     float *U;                // [P,S,L,Mz]   m + C eps, formed by stage B when the likelihood assembles the paths itself
-    float *epsT;             // [P,L,S,Mz]   eps again, rows of a latent contiguous (what stage B stages for U)
+    float *epsT, *eps2T;     // [P,L,S,Mz]   eps, eps' again, rows of a latent contiguous (stage B's U role, paths_fwd_regs, paths_bwd_regs)
     float *G;                // [P,S,L,N]     dloss/df
     float *lik_partial;      // [P,nblk]
     float *part;             // [P,L,NC,PART] per-chunk reductions of the reverse pass
@@ -85,7 +85,7 @@ size_t vg_layout_workspace(const vgpmp_dims* d, void* base, vg_workspace* ws);
 int vg_workspace_lookup(const vgpmp_dims* d, const vg_workspace* ws, const char* name, void** ptr, size_t* count,
                         int32_t* is_double);
 int vg_launch_rng(const vgpmp_dims* d, const vgpmp_noise* noise, uint32_t seed, uint32_t problem_base, uint32_t step,
-                  const uint32_t* ctr, hipStream_t st, float* epsT = nullptr);
+                  const uint32_t* ctr, hipStream_t st, float* epsT = nullptr, float* eps2T = nullptr);
 int vg_launch_adam(const vgpmp_dims* d, const vgpmp_params* params, const vgpmp_params* grad, const vgpmp_params* am,
                    const vgpmp_params* av, int trainable, double lr, int t, hipStream_t st);
 int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sdf, const vgpmp_problem* pb,

@@ -106,7 +106,10 @@ __global__ __launch_bounds__(kBlock) void stage1_kernel(Stage1Args a) {
         return;
     }
     b -= a.n_feat;
-    if (!(a.skip & 4)) rng_normals_body(a.rng, b % a.eps_gx, b / a.eps_gx, 0u, a.rng.nE);
+    if (!(a.skip & 4)) {
+        if (a.rng.epsT) rng_eps_t_body(a.rng, b % a.eps_gx, b / a.eps_gx);
+        else rng_normals_body(a.rng, b % a.eps_gx, b / a.eps_gx, 0u, a.rng.nE);
+    }
     VG_TMAX(162);
 }
 
@@ -214,7 +217,8 @@ __global__ __launch_bounds__(kBlock) void stage4_kernel(Stage4Args a) {
 // throughput-bound ones (noise draws, tiled GEMM) instead of in front of them: 7 launches per step instead of 11.
 struct MidAArgs {            // cov_a | omega, beta | w, eps, eps'
     CovArgs cov; RngArgs rng;
-    int n_cov, n_basis, basis_gx, n_gx;
+    int n_cov, n_basis, basis_gx, n_gx, n_norm;      // n_norm: workgroups of rng_normals_body (n_gx per problem); behind them rng_eps_t_body's
+    int e_gx;
 };
 __global__ __launch_bounds__(kCovThreads) void mid_cov_a_rng_kernel(MidAArgs a) {
     extern __shared__ double sm[];
@@ -223,7 +227,9 @@ __global__ __launch_bounds__(kCovThreads) void mid_cov_a_rng_kernel(MidAArgs a) 
     b -= a.n_cov;
     if (b < a.n_basis) { rng_basis_body(a.rng, b % a.basis_gx, b / a.basis_gx); return; }
     b -= a.n_basis;
-    rng_normals_body(a.rng, b % a.n_gx, b / a.n_gx, a.rng.nW, a.rng.nE);
+    if (b < a.n_norm) { rng_normals_body(a.rng, b % a.n_gx, b / a.n_gx, a.rng.nW, a.rng.nE); return; }
+    b -= a.n_norm;
+    rng_eps_t_body(a.rng, b % a.e_gx, b / a.e_gx);
 }
 
 struct MidCArgs {            // cov_b | tiled prior GEMM
@@ -386,6 +392,7 @@ size_t vg_layout_workspace(const vgpmp_dims* d, void* base, vg_workspace* ws) {
     ws->R = carve<float>(cur, P * S * L * Mz, real);
     ws->U = carve<float>(cur, P * S * L * Mz, real);
     ws->epsT = carve<float>(cur, P * S * L * Mz, real);
+    ws->eps2T = carve<float>(cur, P * S * L * Mz, real);
     ws->G = carve<float>(cur, P * S * L * N, real);
     ws->lik_partial = carve<float>(cur, P * (size_t)vg_loglik_blocks_per_problem(d->S, d->N), real);
     ws->part = carve<float>(cur, PL * vg_chunks(d) * vg_part_len(d), real);
@@ -425,18 +432,22 @@ static RngArgs make_rng_args(const vgpmp_dims* d, const vgpmp_noise* nz, uint32_
     r.eOff = (uint32_t)d->sample_offset * vg_mz(d) * d->L;
     r.omega = nz->omega; r.beta = nz->beta; r.w = nz->w; r.eps = nz->eps; r.eps2 = nz->eps2;
     r.seed = seed; r.problem_base = problem_base; r.step = step; r.bias = bias; r.ctr = ctr;
-    r.epsT = nullptr; r.Mz = vg_mz(d); r.S = d->S;
+    r.epsT = nullptr; r.eps2T = nullptr; r.Mz = vg_mz(d); r.S = d->S;
     return r;
 }
 
 int vg_launch_rng(const vgpmp_dims* d, const vgpmp_noise* nz, uint32_t seed, uint32_t problem_base, uint32_t step,
-                  const uint32_t* ctr, hipStream_t st, float* epsT) {
+                  const uint32_t* ctr, hipStream_t st, float* epsT, float* eps2T) {
     const int P = d->num_problems;
     RngArgs r = make_rng_args(d, nz, seed, problem_base, step, ctr, 0u);
-    r.epsT = epsT;
+    r.epsT = epsT; r.eps2T = eps2T;
     hipLaunchKernelGGL(rng_basis_kernel, dim3((r.L * r.B + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
+    if (epsT) {      // eps / eps' in both layouts by their own launch, w alone by the other
+        hipLaunchKernelGGL(rng_eps_t_kernel, dim3(rng_eps_t_blocks((uint32_t)r.S * r.Mz), P), dim3(kBlock), 0, st, r);
+        r.nE = 0;
+    }
     const uint32_t nthr = rng_normal_threads(r.nW, r.nE, r.eOff);
-    hipLaunchKernelGGL(rng_normals_kernel, dim3((nthr + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
+    if (nthr) hipLaunchKernelGGL(rng_normals_kernel, dim3((nthr + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
     return (int)hipGetLastError();
 }
 
@@ -521,7 +532,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     pa.A4 = reinterpret_cast<const float4*>(ws->A4); pa.AT = ws->AT;
     pa.C = ws->C; pa.CT = ws->CT; pa.nsplit = 1; pa.CT_ell = ws->CT_ell; pa.CT_var = ws->CT_var; pa.m = ws->m;
     pa.F0 = ws->F0; pa.H = ws->H; pa.want_dell = want_dell ? 1 : 0;
-    pa.eps = nz->eps; pa.eps2 = nz->eps2; pa.R = ws->R; pa.f = out->f; pa.G = ws->G; pa.part = ws->part;
+    pa.eps = nz->eps; pa.eps2 = nz->eps2; pa.epsT = nullptr; pa.eps2T = nullptr; pa.R = ws->R; pa.f = out->f; pa.G = ws->G; pa.part = ws->part;
     HyperArgs hy;
     hy.L = L; hy.Mz = Mz; hy.NC = NC; hy.want_dell = want_dell ? 1 : 0; hy.part_len = vg_part_len(d); hy.part = ws->part;
     hy.gkl_ell = ws->gkl_ell; hy.gkl_var = ws->gkl_var; hy.var = ws->var; hy.sig_ell = ws->sig_ell; hy.sig_var = ws->sig_var;
@@ -685,7 +696,23 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     if (!fused && (rc = set_dyn_lds((const void*)mid_cov_a_rng_kernel, lds_cov_a))) return rc;      // (the large-batch schedule merges its small launches with these two as well)
     if ((rc = set_dyn_lds((const void*)mid_hyper_final_kernel, lds_fin))) return rc;
     const dim3 cov_b_grid(kCovFixedRoles + (N + kRowTile - 1) / kRowTile, L, P);
-    const uint32_t eps_gx = (2u * rng_eps_quads((uint32_t)S * Mz * L, (uint32_t)d->sample_offset * Mz * L) + kBlock - 1) / kBlock;
+    // eps / eps' also as [P,L,S,Mz] wherever a consumer stages them per latent (the register-resident path kernels, stage B's U
+    // role): drawn by rng_eps_t_body then, kEpsRows rows of (s, k) per workgroup
+    // (only for noise drawn here: the caller's own eps -- generate = false -- come in the interface's layout alone)
+    const bool eps_t = gen && (lik_paths || regs_fwd || regs_bwd);
+    pa.epsT = eps_t && (regs_fwd || regs_bwd) ? ws->epsT : nullptr; pa.eps2T = eps_t && regs_fwd ? ws->eps2T : nullptr;
+    float* const eps_t1 = eps_t ? ws->epsT : nullptr;
+    float* const eps_t2 = eps_t && regs_fwd ? ws->eps2T : nullptr;
+    const uint32_t eps_gx = eps_t ? rng_eps_t_blocks((uint32_t)S * Mz)
+                                  : (2u * rng_eps_quads((uint32_t)S * Mz * L, (uint32_t)d->sample_offset * Mz * L) + kBlock - 1) / kBlock;
+    auto mid_normal_grid = [&](MidAArgs& ma) -> unsigned {      // the normal-draw roles of mid_cov_a_rng_kernel
+        if (eps_t) { ma.rng.epsT = eps_t1; ma.rng.eps2T = eps_t2; ma.rng.nE = 0; }
+        const uint32_t n_thr = rng_normal_threads(ma.rng.nW, ma.rng.nE, ma.rng.eOff);
+        ma.n_gx = (int)((n_thr + kBlock - 1) / kBlock);
+        ma.n_norm = ma.n_gx * P;
+        ma.e_gx = eps_t ? (int)rng_eps_t_blocks((uint32_t)S * Mz) : 0;
+        return (unsigned)ma.n_norm + (unsigned)ma.e_gx * P;
+    };
     const uint32_t basis_gx = ((uint32_t)L * B + kBlock - 1) / kBlock;
     const uint32_t w_gx = (((uint32_t)S * L * B >> 2) + kBlock - 1) / kBlock;
     auto launch = [&](const void* fn, dim3 grid, void* arg, size_t lds) -> int {
@@ -744,7 +771,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             //  step is one call per step with an all-reduce in between: without these it paid two noise launches per step.)
             const bool ready = !first || (what & VGPMP_NOISE_READY);
             const bool ahead = more || (what & VGPMP_NOISE_AHEAD);
-            if (gen && !ready && (rc = vg_launch_rng(d, nz, seed, problem_base, step_i, ctr, st, lik_paths ? ws->epsT : nullptr))) return rc;
+            if (gen && !ready && (rc = vg_launch_rng(d, nz, seed, problem_base, step_i, ctr, st, eps_t1, eps_t2))) return rc;
             // steps after the first of a call: the hyper-parameter update of the previous step is a prologue of the
             // cov_a and feature roles, its q_mu / q_sqrt update (final) another role of the same launch
             const bool prologue = !first && backward;
@@ -758,7 +785,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             s1.cov.hy = hyp; s1.feat.hy = hyp;
             s1.cov.prologue = prologue ? 1 : 0;
             s1.rng = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
-            s1.rng.epsT = lik_paths ? ws->epsT : nullptr;
+            s1.rng.epsT = eps_t1; s1.rng.eps2T = eps_t2;
             s1.n_cov = L * P;
             s1.fin_split = fin_split ? 1 : 0;
             s1.n_fin = first ? 0 : L * P * (fin_split ? kFinSplit : 1);
@@ -800,9 +827,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             ma.cov = ca;
             ma.rng = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
             ma.n_cov = L * P; ma.basis_gx = (int)basis_gx; ma.n_basis = gen ? (int)basis_gx * P : 0;
-            const uint32_t n_thr = rng_normal_threads(ma.rng.nW, ma.rng.nE, ma.rng.eOff);
-            ma.n_gx = (int)((n_thr + kBlock - 1) / kBlock);
-            const unsigned nA = ma.n_cov + ma.n_basis + (gen ? (unsigned)ma.n_gx * P : 0u);
+            const unsigned n_draw = gen ? mid_normal_grid(ma) : 0u;
+            const unsigned nA = ma.n_cov + ma.n_basis + n_draw;
             if ((rc = launch((const void*)mid_cov_a_rng_kernel, dim3(nA), &ma, lds_cov_a))) return rc;
             if (!fused_small) hipLaunchKernelGGL(features_kernel, feat_grid, dim3(kBlock), 0, st, fe);
             MidCArgs mc;
@@ -838,9 +864,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 ma.rng = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
                 if (fbatch) ma.rng.nW = 0;               // omega, beta, eps, eps2 only
                 ma.n_cov = L * P; ma.basis_gx = (int)((ma.rng.L * ma.rng.B + kBlock - 1) / kBlock); ma.n_basis = ma.basis_gx * P;
-                const uint32_t n_thr = rng_normal_threads(ma.rng.nW, ma.rng.nE, ma.rng.eOff);
-                ma.n_gx = (int)((n_thr + kBlock - 1) / kBlock);
-                if ((rc = launch((const void*)mid_cov_a_rng_kernel, dim3(ma.n_cov + ma.n_basis + (unsigned)ma.n_gx * P), &ma, lds_cov_a))) return rc;
+                const unsigned n_draw = mid_normal_grid(ma);
+                if ((rc = launch((const void*)mid_cov_a_rng_kernel, dim3(ma.n_cov + ma.n_basis + n_draw), &ma, lds_cov_a))) return rc;
             } else {
                 hipLaunchKernelGGL(cov_a_kernel, dim3(L, P), dim3(kCovThreads), lds_cov_a, st, ca);
             }
@@ -858,8 +883,13 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 RngArgs r = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
                 if (fbatch) r.nW = 0;                    // omega, beta, eps, eps2 only
                 hipLaunchKernelGGL(rng_basis_kernel, dim3((r.L * r.B + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
+                if (eps_t) {
+                    r.epsT = ws->epsT; r.eps2T = ws->eps2T;
+                    hipLaunchKernelGGL(rng_eps_t_kernel, dim3(rng_eps_t_blocks((uint32_t)S * Mz), P), dim3(kBlock), 0, st, r);
+                    r.nE = 0;
+                }
                 const uint32_t nthr = rng_normal_threads(r.nW, r.nE, r.eOff);
-                hipLaunchKernelGGL(rng_normals_kernel, dim3((nthr + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
+                if (nthr) hipLaunchKernelGGL(rng_normals_kernel, dim3((nthr + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
             }
             mark();
             if (!fused_small && !fbatch) hipLaunchKernelGGL(features_kernel, feat_grid, dim3(kBlock), 0, st, fe);

@@ -16,6 +16,7 @@ struct PathArgs {
     float sqrt_jitter;
     const float4* A4;
     const float *AT, *C, *CT, *CT_ell, *CT_var, *m, *F0, *H, *eps, *eps2;
+    const float *epsT, *eps2T;    // [P,L,S,Mz] copies of eps / eps' (paths_fwd_regs, paths_bwd_regs); nullptr: the [P,S,Mz,L] tensors
     int nsplit;               // 2: paths_fwd on two workgroups per (chunk, latent), halves of the time axis
     float *R, *f;
     const float* G;
@@ -579,10 +580,16 @@ __global__ __launch_bounds__(kBlock, VG_PBR_WAVES) void paths_bwd_regs(PathArgs 
                 const int s = s_base + r;
                 return s < S ? a.R + (((size_t)p * S + s) * L + l) * Mz : nullptr;
             });
-            vg_stage_words(Es2, R2 * Mz, tid, nt, [&](int w) -> const void* {
-                const int sl = vg_div(w, iMz), mi = w - sl * Mz, s = s_base + sl;
-                return s < S ? a.eps + (((size_t)p * S + s) * Mz + mi) * L + l : nullptr;
-            });
+            if (a.epsT)
+                vg_stage_rows(Es2, R2, Mz, tid, nt, [&](int r) -> const float* {
+                    const int s = s_base + r;
+                    return s < S ? a.epsT + (pl * S + s) * Mz : nullptr;
+                });
+            else
+                vg_stage_words(Es2, R2 * Mz, tid, nt, [&](int w) -> const void* {
+                    const int sl = vg_div(w, iMz), mi = w - sl * Mz, s = s_base + sl;
+                    return s < S ? a.eps + (((size_t)p * S + s) * Mz + mi) * L + l : nullptr;
+                });
             vg_stage_rows(f0s2, 2 * R2, J, tid, nt, [&](int r) -> const float* {
                 const int second = r >= R2, s = min(s_base + (second ? r - R2 : r), S - 1);
                 if (second && !dell) return nullptr;
@@ -974,11 +981,17 @@ __global__ __launch_bounds__(kBlock, 4) void paths_fwd_regs(PathArgs a) {
     const int cp_end = min((int)(blockIdx.x + 1) * a.cpw, a.NC);
     for (int ch0 = blockIdx.x * a.cpw; ch0 < cp_end; ch0 += 2) {
         const int s_base = ch0 * SC;
-        vg_stage_words(es2, 2 * R2 * Mz, tid, nt, [&](int w) -> const void* {
-            const int second = w >= R2 * Mz, e = second ? w - R2 * Mz : w;
-            const int sl = vg_div(e, iMz), k = e - sl * Mz, s = s_base + sl;
-            return s < S ? (second ? a.eps2 : a.eps) + (((size_t)p * S + s) * Mz + k) * L + l : nullptr;      // zero beyond S
-        });
+        if (a.epsT)
+            vg_stage_rows(es2, 2 * R2, Mz, tid, nt, [&](int r) -> const float* {
+                const int second = r >= R2, s = s_base + (second ? r - R2 : r);
+                return s < S ? (second ? a.eps2T : a.epsT) + (pl * S + s) * Mz : nullptr;                      // zero beyond S
+            });
+        else
+            vg_stage_words(es2, 2 * R2 * Mz, tid, nt, [&](int w) -> const void* {
+                const int second = w >= R2 * Mz, e = second ? w - R2 * Mz : w;
+                const int sl = vg_div(e, iMz), k = e - sl * Mz, s = s_base + sl;
+                return s < S ? (second ? a.eps2 : a.eps) + (((size_t)p * S + s) * Mz + k) * L + l : nullptr;
+            });
         vg_stage_rows(f0s2, R2, J, tid, nt, [&](int r) -> const float* {
             return a.F0 + (((size_t)p * S + min(s_base + r, S - 1)) * L + l) * J;
         });

@@ -13,7 +13,8 @@ struct RngArgs {
     float *omega, *beta, *w, *eps, *eps2;
     uint32_t seed, problem_base, step, bias;
     const uint32_t* ctr;      // device step counter: the key uses *ctr + bias instead of `step`
-    float* epsT;              // optional second copy of eps as [P,L,S,Mz] (the rows stage B reads when it forms U = m + C eps)
+    float *epsT, *eps2T;      // optional second copies [P,L,S,Mz] (a latent's rows contiguous: what the per-latent consumers stage;
+                              //  with epsT set, eps / eps' are drawn by rng_eps_t_body, not by rng_normals_body)
     int Mz, S;
 };
 
@@ -97,19 +98,54 @@ __device__ __forceinline__ void rng_normals_body(const RngArgs& a, int bx, int p
             if (e < nE) vg_stream(dst + e, vg_lane(v, k));
         }
     }
-    if (a.epsT && !second) {                             // e = (s Mz + k) L + l
+}
+
+// eps, eps' in BOTH layouts: [P,S,Mz,L] (the interface's) and [P,L,S,Mz] (epsT / eps2T: the consumers work per latent -- from the
+// first layout each of their 4-byte requests pulled a 64-byte sector shared by the L latents).  A workgroup owns kEpsRows
+// rows (s, k) of one of the two streams: L kEpsRows consecutive elements, their counters one per thread and pass; the normals
+// go out in the first layout as they are drawn and through an LDS tile in the second, 64 consecutive floats per wave.
+constexpr int kEpsRows = 64;
+__host__ __device__ __forceinline__ uint32_t rng_eps_t_blocks(uint32_t rows) { return 2u * ((rows + kEpsRows - 1) / kEpsRows); }
+__device__ __forceinline__ void rng_eps_t_body(const RngArgs& a, int bx, int p) {
+    __shared__ float tile[kEpsRows * VGPMP_MAX_DOF];
+    const int tid = threadIdx.x, L = a.L;
+    const uint32_t rows = (uint32_t)a.S * a.Mz, half = (rows + kEpsRows - 1) / kEpsRows, nE = rows * (uint32_t)L;
+    const bool second = (uint32_t)bx >= half;
+    const uint32_t r0 = ((uint32_t)bx - (second ? half : 0u)) * kEpsRows, nr = min((uint32_t)kEpsRows, rows - r0);
+    const uint32_t e_lo = r0 * L, e_hi = e_lo + nr * L;            // local elements of this workgroup
+    VG_T(bx == 0 && p == 0, 120);
+    const uint2 key = vg_key(a.seed, a.problem_base + p, rng_step(a));
+    float* dst = (second ? a.eps2 : a.eps) + (size_t)p * nE;
+    float* dstT = second ? a.eps2T : a.epsT;
+    const uint32_t q_lo = (a.eOff + e_lo) >> 2, q_hi = (a.eOff + e_hi - 1u) >> 2;
+    for (uint32_t q = q_lo + tid; q <= q_hi; q += kBlock) {
+        const float4 v = vg_normal4(q, second ? VG_STREAM_EPS2 : VG_STREAM_EPS, key);
+        const uint32_t first = 4u * q - a.eOff;           // local element of lane 0 (wraps below zero on a rank's first counter)
+        if (4u * q >= a.eOff + e_lo && first + 3u < e_hi && ((((size_t)p * nE + first) & 3u) == 0u)) {
+            vg_stream(reinterpret_cast<float4*>(dst + first), v);
+            if (dstT) {
+                float* t = tile + (first - e_lo);
+                t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+            }
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t e = first + (uint32_t)k;
-            if (e < nE) {
-                const uint32_t l = e % (uint32_t)a.L, sk = e / (uint32_t)a.L, kk = sk % (uint32_t)a.Mz, s_ = sk / (uint32_t)a.Mz;
-                a.epsT[(((size_t)p * a.L + l) * a.S + s_) * a.Mz + kk] = vg_lane(v, k);
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t e = first + (uint32_t)k;   // unsigned: an element below the range compares >= e_hi
+                if (e >= e_lo && e < e_hi) { vg_stream(dst + e, vg_lane(v, k)); if (dstT) tile[e - e_lo] = vg_lane(v, k); }
             }
         }
+    }
+    if (!dstT) return;                                    // (uniform)
+    __syncthreads();
+    // element (r, l) of the tile -> epsT[p][l][r0 + r]: lanes along r
+    for (uint32_t idx = tid; idx < (uint32_t)L * kEpsRows; idx += kBlock) {
+        const uint32_t l = idx / kEpsRows, r = idx % kEpsRows;
+        if (r < nr) vg_stream(dstT + ((size_t)p * L + l) * rows + r0 + r, tile[r * L + l]);
     }
 }
 
 __global__ __launch_bounds__(kBlock) void rng_basis_kernel(RngArgs a) { rng_basis_body(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(kBlock) void rng_eps_t_kernel(RngArgs a) { rng_eps_t_body(a, blockIdx.x, blockIdx.y); }
 __global__ __launch_bounds__(kBlock) void rng_normals_kernel(RngArgs a) {
     rng_normals_body(a, blockIdx.x, blockIdx.y, a.nW, a.nE);
 }
