@@ -33,6 +33,7 @@ struct CovArgs {
     // stage B, role 3 also forms U = m + C eps of every sample (ws.U) for the likelihood that assembles its own paths
     // (Mz = 32): the MFMA sequence of paths_fwd_split_body on the float32 C it has just built
     int form_u, S;
+    int rows_tpw;            // row tiles (kRowTile time points) per workgroup of the rows role
     const float* eps;        // [P,L,S,Mz]  (ws.epsT: the generator's second copy, a latent's rows contiguous)
     HyperArgs hy;
     vg_workspace ws;
@@ -822,8 +823,11 @@ __global__ __launch_bounds__(kCovThreads) void cov_b_kernel(CovArgs a) {
 //   A_ell = (dKfu/dell - A dKuu/dell) Kinv,   A_var = (jitter / var) A Kinv
 // Output float32: A4[n][m] = {A, A_ell, A_var, 0} (one 16-byte load per use in the reverse pass)
 // and AT[m][n] for the forward path assembly.
-__device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int p, int tid, int nt) {
+__device__ void cov_rows_body(const CovArgs& a, double* sm, int wg_tile, int l, int p, int tid, int nt) {
     const int M = a.M, Mz = M + 2, N = a.N, L = a.L, D = a.D, ld = (Mz + 2) & ~1;
+    // a workgroup walks `tpw` consecutive tiles (large batches: Lk^-1, dKuu/dell and (Kuu + jI)^-1 once for all of them -- one
+    // tile per workgroup re-staged 16 KB and redid the 32^3 product for every 8 time points, 13 times per latent at N = 100)
+    const int tpw = max(a.rows_tpw, 1), tile = wg_tile * tpw;
     VG_T(tile == 0 && l == 0 && p == 0, 230);
     const float iMz = 1.0f / (float)Mz;
     const size_t pl = (size_t)p * L + l;
@@ -834,10 +838,12 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
     double* ar = df + kRowTile * Mz;       // [RT][Mz]  A rows
     double* yr = ar + kRowTile * Mz;       // [RT][Mz]
     double* zs = yr + kRowTile * Mz;       // [Mz]
-    double* xs = zs + Mz;                  // [RT] times of this tile
-    double* Lt = xs + kRowTile;            // [Mz][ld] Lk^-1 as it arrives
+    double* xs = zs + Mz;                  // [tpw][RT] times of this workgroup's tiles
+    double* Lt = xs + tpw * kRowTile;      // [Mz][ld] Lk^-1 as it arrives
     const double ell = a.ws.ell[pl], var = a.ws.var[pl];
-    const int n0 = tile * kRowTile;
+    float4* A4 = reinterpret_cast<float4*>(a.ws.A4) + pl * N * Mz;
+    float* AT = a.ws.AT + pl * N * Mz;
+    const int n00 = tile * kRowTile;
     {
         auto all = [](int, int) { return true; };
         if ((Mz & 1) == 0) {
@@ -848,10 +854,10 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
             vg_stage_f64(Lt, Mz, ld, a.ws.Li64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
             vg_stage_f64(Kd, Mz, ld, a.ws.Kd_ell + pl * Mz * Mz, a.want_dell ? Mz : 0, Mz, 0, 0, tid, nt, all);
         }
-        vg_stage_words(zs, 2 * (Mz + kRowTile), tid, nt, [&](int w) -> const void* {
+        vg_stage_words(zs, 2 * (Mz + tpw * kRowTile), tid, nt, [&](int w) -> const void* {
             const int i = w >> 1;
             const double* src = i < Mz ? a.Zy + (size_t)p * a.zy_stride + (size_t)i * D + l
-                                       : a.X + (size_t)min(n0 + i - Mz, N - 1) * D + l;
+                                       : a.X + (size_t)min(n00 + i - Mz, N - 1) * D + l;
             return reinterpret_cast<const uint32_t*>(src) + (w & 1);
         });
     }
@@ -877,11 +883,15 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
             }
         }
     }
+    for (int tt = 0; tt < tpw; ++tt) {
+    const int n0 = n00 + tt * kRowTile;
+    if (n0 >= N) break;
+    const double* xt = xs + tt * kRowTile;
     for (int e = tid; e < kRowTile * Mz; e += nt) {
         int r = vg_div(e, iMz), m = e - r * Mz, n = n0 + r;
         double k = 0.0, dk = 0.0;
         if (n < N) {
-            double rr = fabs(xs[r] - zs[m]) / ell;
+            double rr = fabs(xt[r] - zs[m]) / ell;
             double ex = exp(-kSqrt5 * rr);
             k = var * (1.0 + kSqrt5 * rr + (5.0 / 3.0) * rr * rr) * ex;
             dk = var * ex * (5.0 * rr * rr / (3.0 * ell)) * (1.0 + kSqrt5 * rr);
@@ -896,8 +906,6 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
     }
     __syncthreads();
     VG_T(tile == 0 && l == 0 && p == 0, 234);
-    float4* A4 = reinterpret_cast<float4*>(a.ws.A4) + pl * N * Mz;
-    float* AT = a.ws.AT + pl * N * Mz;
     float av0 = 0.f, av1 = 0.f;      // (two scalars, not an array: a run-time index would put it in scratch memory)
     int cnt = 0;
     for (int e = tid; e < kRowTile * Mz; e += nt, ++cnt) {
@@ -918,6 +926,8 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int
         const float av = cnt == 0 ? av0 : av1;
         vg_stream(A4 + (size_t)n * Mz + m, make_float4((float)ar[e], (float)s, av, 0.f));
         vg_stream(AT + (size_t)m * N + n, (float)ar[e]);
+    }
+    if (tt + 1 < tpw) __syncthreads();      // the tile's LDS rows are the next one's
     }
     VG_T(tile == 0 && l == 0 && p == 0, 231);
 }

@@ -506,7 +506,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     ca.elim_wave = (what & VGPMP_ELIM_BLOCK) ? 0 : 1;
     ca.tick = (fused && do_adam) ? ctr : nullptr;
     ca.lr = lr; ca.lr_dev = ws->lr_t;
-    ca.prologue = 0; ca.commit = 0; ca.keep_prev = (fused && backward) ? 1 : 0;
+    ca.rows_tpw = 1; ca.prologue = 0; ca.commit = 0; ca.keep_prev = (fused && backward) ? 1 : 0;
     ca.ws = *ws;
     FeatArgs fe;
     fe.N = N; fe.Mz = Mz; fe.L = L; fe.D = L; fe.B = B;
@@ -585,7 +585,13 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const int Mp = (Mz + 15) & ~15;
     const size_t lds_cov = ((size_t)4 * Mp * (Mp + 2) + 8 * Mp) * sizeof(double);
     const size_t lds_cov_a = ((size_t)4 * Mp * (Mp + 1) + 2 * Mp) * sizeof(double);
-    const size_t lds_rows = ((size_t)3 * Mz * ((Mz + 2) & ~1) + (size_t)4 * kRowTile * Mz + Mz + kRowTile) * sizeof(double);
+    // row tiles per workgroup of stage B's rows role: one while the launch is small (latency), up to four once there are
+    // eight workgroups per CU anyway
+    const int row_tiles = (N + kRowTile - 1) / kRowTile;
+    int rows_tpw = 1;
+    while (rows_tpw < 4 && (size_t)P * L * (kCovFixedRoles + (row_tiles + 2 * rows_tpw - 1) / (2 * rows_tpw)) >= 2048) rows_tpw *= 2;
+    ca.rows_tpw = rows_tpw;
+    const size_t lds_rows = ((size_t)3 * Mz * ((Mz + 2) & ~1) + (size_t)4 * kRowTile * Mz + Mz + rows_tpw * kRowTile) * sizeof(double);
     const size_t lds_cov_b = lds_cov > lds_rows ? lds_cov : lds_rows;
     // path kernels: operands + (when it fits) the raw split-K slabs of the prior draws
     const size_t raw_f = SK == 1 ? 0 : (size_t)SK * SC * J * sizeof(float);      // one slab lands in place
@@ -695,7 +701,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     if (mid && (rc = set_dyn_lds(fn_midC, lds_midC))) return rc;
     if (!fused && (rc = set_dyn_lds((const void*)mid_cov_a_rng_kernel, lds_cov_a))) return rc;      // (the large-batch schedule merges its small launches with these two as well)
     if ((rc = set_dyn_lds((const void*)mid_hyper_final_kernel, lds_fin))) return rc;
-    const dim3 cov_b_grid(kCovFixedRoles + (N + kRowTile - 1) / kRowTile, L, P);
+    const dim3 cov_b_grid(kCovFixedRoles + (row_tiles + rows_tpw - 1) / rows_tpw, L, P);
     // eps / eps' also as [P,L,S,Mz] wherever a consumer stages them per latent (the register-resident path kernels, stage B's U
     // role): drawn by rng_eps_t_body then, kEpsRows rows of (s, k) per workgroup
     // (only for noise drawn here: the caller's own eps -- generate = false -- come in the interface's layout alone)
