@@ -22,6 +22,9 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 #else
 #define VG_STOP(args, k) do { } while (0)
 #endif
+#ifndef VG_ROWS_TPW_MAX
+#define VG_ROWS_TPW_MAX 4
+#endif
 #ifndef VG_FWD_REGS
 #define VG_FWD_REGS 1        // 0: measurement builds with the forward path assembly of large batches on paths_fwd_sc8
 #endif
@@ -589,7 +592,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     // eight workgroups per CU anyway
     const int row_tiles = (N + kRowTile - 1) / kRowTile;
     int rows_tpw = 1;
-    while (rows_tpw < 4 && (size_t)P * L * (kCovFixedRoles + (row_tiles + 2 * rows_tpw - 1) / (2 * rows_tpw)) >= 2048) rows_tpw *= 2;
+    while (rows_tpw < VG_ROWS_TPW_MAX && (size_t)P * L * (kCovFixedRoles + (row_tiles + 2 * rows_tpw - 1) / (2 * rows_tpw)) >= 2048) rows_tpw *= 2;
     ca.rows_tpw = rows_tpw;
     const size_t lds_rows = ((size_t)3 * Mz * ((Mz + 2) & ~1) + (size_t)4 * kRowTile * Mz + Mz + rows_tpw * kRowTile) * sizeof(double);
     const size_t lds_cov_b = lds_cov > lds_rows ? lds_cov : lds_rows;
