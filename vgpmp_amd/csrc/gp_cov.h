@@ -825,8 +825,8 @@ __global__ __launch_bounds__(kCovThreads) void cov_b_kernel(CovArgs a) {
 // and AT[m][n] for the forward path assembly.
 __device__ void cov_rows_body(const CovArgs& a, double* sm, int wg_tile, int l, int p, int tid, int nt) {
     const int M = a.M, Mz = M + 2, N = a.N, L = a.L, D = a.D, ld = (Mz + 2) & ~1;
-    // a workgroup walks `tpw` consecutive tiles (large batches: Lk^-1, dKuu/dell and (Kuu + jI)^-1 once for all of them -- one
-    // tile per workgroup re-staged 16 KB and redid the 32^3 product for every 8 time points, 13 times per latent at N = 100)
+    // a workgroup walks `tpw` consecutive tiles (large batches: Lk^-1, dKuu/dell and (Kuu + jI)^-1 once for both of them -- one
+    // tile per workgroup re-stages 16 KB and redoes the 32^3 product for every 8 time points, 13 times per latent at N = 100)
     const int tpw = max(a.rows_tpw, 1), tile = wg_tile * tpw;
     VG_T(tile == 0 && l == 0 && p == 0, 230);
     const float iMz = 1.0f / (float)Mz;
