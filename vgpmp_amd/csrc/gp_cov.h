@@ -883,6 +883,75 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int wg_tile, int l, 
             }
         }
     }
+    if (Mz == 32) {
+        // ---- Mz = 32: the four [rows x 32] . [32 x 32] products on the float64 matrix cores, sixteen time points per pass
+        // (two tiles; one tile leaves half the rows empty).  The scalar form below reads both operands of every output from LDS
+        // -- 256 eight-byte reads per thread and tile: at 64 x 14 latents x 13 tiles that was 6 GB through the chip's 79 TB/s
+        // of LDS bandwidth, more than half of stage B's launch.  Lk^-1 is dead once (Kuu + jI)^-1 stands: its space takes the
+        // kernel rows, the scalar form's four row blocks take A and y.
+        double* kf2 = Lt;                      // [16][32]  Kfu rows
+        double* df2 = Lt + 16 * 32;            // [16][32]  dKfu/dell rows
+        double* ar2 = kf;                      // [16][32]  A rows
+        double* yr2 = kf + 16 * 32;            // [16][32]  dKfu/dell - A dKuu/dell
+        const int rows_w = tpw * kRowTile, wv = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
+        __syncthreads();                       // every wave has read Lk^-1
+        for (int r0 = 0; r0 < rows_w; r0 += 16) {
+            const int n0 = n00 + r0;
+            if (n0 >= N) break;
+            for (int e = tid; e < 16 * 32; e += nt) {
+                const int r = e >> 5, m = e & 31, n = n0 + r;
+                double k = 0.0, dk = 0.0;
+                if (n < N && r0 + r < rows_w) {
+                    double rr = fabs(xs[r0 + r] - zs[m]) / ell;
+                    double ex = exp(-kSqrt5 * rr);
+                    k = var * (1.0 + kSqrt5 * rr + (5.0 / 3.0) * rr * rr) * ex;
+                    dk = var * ex * (5.0 * rr * rr / (3.0 * ell)) * (1.0 + kSqrt5 * rr);
+                }
+                kf2[e] = k; df2[e] = dk;
+            }
+            __syncthreads();
+            VG_T(tile == 0 && l == 0 && p == 0 && r0 == 0, 233);
+            if (wv < 2) {                      // A = Kfu (Kuu + jI)^-1, this wave's sixteen columns
+                const vg_f64x4 acc = mfma_tile_f64(MatView{kf2, 32, 1}, MatView{Ki, ld, 1}, 32, lane, 0, 16 * wv);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ar2[(g + 4 * q) * 32 + 16 * wv + i] = acc[q];
+            }
+            __syncthreads();
+            VG_T(tile == 0 && l == 0 && p == 0 && r0 == 0, 234);
+            float av[4] = {0.f, 0.f, 0.f, 0.f};
+            const int j0 = 16 * (wv & 1);
+            if (wv < 2) {                      // y = dKfu/dell - A dKuu/dell
+                const vg_f64x4 acc = mfma_tile_f64(MatView{ar2, 32, 1}, MatView{Kd, ld, 1}, 32, lane, 0, j0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = (g + 4 * q) * 32 + j0 + i;
+                    yr2[o] = df2[o] - acc[q];
+                }
+            } else {                           // A_var = (jitter / var) A (Kuu + jI)^-1: stays with the lane that stores it
+                const vg_f64x4 acc = mfma_tile_f64(MatView{ar2, 32, 1}, MatView{Ki, ld, 1}, 32, lane, 0, j0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) av[q] = (float)(a.jitter / var * acc[q]);
+            }
+            __syncthreads();
+            VG_T(tile == 0 && l == 0 && p == 0 && r0 == 0, 235);
+            if (wv >= 2) {                     // A_ell = y (Kuu + jI)^-1, and the three planes go out
+                vg_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+                if (a.want_dell) acc = mfma_tile_f64(MatView{yr2, 32, 1}, MatView{Ki, ld, 1}, 32, lane, 0, j0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = g + 4 * q, n = n0 + r, m = j0 + i;
+                    if (n < N && r0 + r < rows_w) {
+                        const float av0 = (float)ar2[r * 32 + m];
+                        vg_stream(A4 + (size_t)n * 32 + m, make_float4(av0, (float)acc[q], av[q], 0.f));
+                        vg_stream(AT + (size_t)m * N + n, av0);
+                    }
+                }
+            }
+            // (the next pass writes kf2 / df2 -- read before the last barrier -- and meets a barrier before it writes ar2)
+        }
+        VG_T(tile == 0 && l == 0 && p == 0, 231);
+        return;
+    }
     for (int tt = 0; tt < tpw; ++tt) {
     const int n0 = n00 + tt * kRowTile;
     if (n0 >= N) break;
