@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void stage1_kernel(Stage1Args a) {
     }
     b -= a.n_feat;
     if (!(a.skip & 4)) {
-        if (a.rng.epsT) rng_eps_t_body(a.rng, b % a.eps_gx, b / a.eps_gx);
+        if (a.rng.epsT) rng_eps_t_body(a.rng, b % a.eps_gx, b / a.eps_gx, reinterpret_cast<float*>(sm));
         else rng_normals_body(a.rng, b % a.eps_gx, b / a.eps_gx, 0u, a.rng.nE);
     }
     VG_TMAX(162);
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void stage3_kernel(Stage3Args a) {
     }
     b -= a.n_path;
     if (a.skip & 2) return;
-    if (b < a.n_basis) { rng_basis_body(a.rng, b % a.basis_gx, b / a.basis_gx); return; }
+    if (b < a.n_basis) { rng_basis_body(a.rng, b % a.basis_gx, b / a.basis_gx, smf); return; }
     b -= a.n_basis;
     rng_normals_body(a.rng, b % a.w_gx, b / a.w_gx, a.rng.nW, 0u);
 }
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void stage4_kernel(Stage4Args a) {
     int b = blockIdx.x;
     if (b < a.n_bwd) { paths_bwd_split_body<SK, MZ>(a.path, smf, b, a.bwd_gx); return; }
     b -= a.n_bwd;
-    if (b < a.n_basis) { rng_basis_body(a.rng, b % a.basis_gx, b / a.basis_gx); return; }
+    if (b < a.n_basis) { rng_basis_body(a.rng, b % a.basis_gx, b / a.basis_gx, smf); return; }
     b -= a.n_basis;
     rng_normals_body(a.rng, b % a.w_gx, b / a.w_gx, a.rng.nW, 0u);
 }
@@ -228,11 +228,11 @@ __global__ __launch_bounds__(kCovThreads) void mid_cov_a_rng_kernel(MidAArgs a) 
     int b = blockIdx.x;
     if (b < a.n_cov) { cov_a_body(a.cov, sm, b % a.cov.L, b / a.cov.L); return; }
     b -= a.n_cov;
-    if (b < a.n_basis) { rng_basis_body(a.rng, b % a.basis_gx, b / a.basis_gx); return; }
+    if (b < a.n_basis) { rng_basis_body(a.rng, b % a.basis_gx, b / a.basis_gx, reinterpret_cast<float*>(sm)); return; }
     b -= a.n_basis;
     if (b < a.n_norm) { rng_normals_body(a.rng, b % a.n_gx, b / a.n_gx, a.rng.nW, a.rng.nE); return; }
     b -= a.n_norm;
-    rng_eps_t_body(a.rng, b % a.e_gx, b / a.e_gx);
+    rng_eps_t_body(a.rng, b % a.e_gx, b / a.e_gx, reinterpret_cast<float*>(sm));
 }
 
 struct MidCArgs {            // cov_b | tiled prior GEMM

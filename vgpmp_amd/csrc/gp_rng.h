@@ -26,8 +26,7 @@ __device__ __forceinline__ uint32_t rng_step(const RngArgs& a) { return a.ctr ? 
 // one counter per thread and pass: four normals, their rows' scales, ONE aligned 16-byte store.  (A thread per row wrote its
 // D values by D scattered 4-byte stores and regenerated the counters that straddle two rows: 60 us at 64 x 14 latents, most
 // of it in the store path.)  beta: the thread of every fourth row draws four.
-__device__ __forceinline__ void rng_basis_body(const RngArgs& a, int bx, int p) {
-    __shared__ float sc_s[kBlock];
+__device__ __forceinline__ void rng_basis_body(const RngArgs& a, int bx, int p, float* sc_s) {      // sc_s: kBlock floats of LDS
     const int L = a.L, B = a.B, D = a.D, tid = threadIdx.x;
     VG_T(bx == 0 && p == 0, 310);
     const uint32_t rows = (uint32_t)(L * B), r0 = (uint32_t)bx * kBlock, lb = r0 + tid;
@@ -106,8 +105,8 @@ __device__ __forceinline__ void rng_normals_body(const RngArgs& a, int bx, int p
 // go out in the first layout as they are drawn and through an LDS tile in the second, 64 consecutive floats per wave.
 constexpr int kEpsRows = 64;
 __host__ __device__ __forceinline__ uint32_t rng_eps_t_blocks(uint32_t rows) { return 2u * ((rows + kEpsRows - 1) / kEpsRows); }
-__device__ __forceinline__ void rng_eps_t_body(const RngArgs& a, int bx, int p) {
-    __shared__ float tile[kEpsRows * VGPMP_MAX_DOF];
+// (`tile`: kEpsRows L floats of the launch's dynamic LDS -- static arrays here would add to every role of the merged launches)
+__device__ __forceinline__ void rng_eps_t_body(const RngArgs& a, int bx, int p, float* tile) {
     const int tid = threadIdx.x, L = a.L;
     const uint32_t rows = (uint32_t)a.S * a.Mz, half = (rows + kEpsRows - 1) / kEpsRows, nE = rows * (uint32_t)L;
     const bool second = (uint32_t)bx >= half;
@@ -144,8 +143,14 @@ __device__ __forceinline__ void rng_eps_t_body(const RngArgs& a, int bx, int p) 
     }
 }
 
-__global__ __launch_bounds__(kBlock) void rng_basis_kernel(RngArgs a) { rng_basis_body(a, blockIdx.x, blockIdx.y); }
-__global__ __launch_bounds__(kBlock) void rng_eps_t_kernel(RngArgs a) { rng_eps_t_body(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(kBlock) void rng_basis_kernel(RngArgs a) {
+    __shared__ float sc_s[kBlock];
+    rng_basis_body(a, blockIdx.x, blockIdx.y, sc_s);
+}
+__global__ __launch_bounds__(kBlock) void rng_eps_t_kernel(RngArgs a) {
+    __shared__ float tile[kEpsRows * VGPMP_MAX_DOF];
+    rng_eps_t_body(a, blockIdx.x, blockIdx.y, tile);
+}
 __global__ __launch_bounds__(kBlock) void rng_normals_kernel(RngArgs a) {
     rng_normals_body(a, blockIdx.x, blockIdx.y, a.nW, a.nE);
 }
