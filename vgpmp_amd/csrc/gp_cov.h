@@ -518,6 +518,10 @@ __global__ __launch_bounds__(kCovThreads) void cov_a_kernel(CovArgs a) {
 //                against the tangents' 13; apart they take 6 and 9.)
 //   4 + t        row tile t of A = Kfu (Kuu + jI)^-1 and its tangents (cov_rows_body)
 constexpr int kCovRoleC = 3, kCovFixedRoles = 4;
+// Role of workgroup b of a role-major grid (b = group * roles + j), rotated by the group: workgroups go to the 8 XCDs round
+// robin, so with a role count that shares a factor with 8 the plain b % roles pins every role to a fixed subset of the XCDs --
+// the tangent roles, the longest, to two of them with 8 roles (config-5 share: 946 -> 985 us per step).
+__device__ __forceinline__ int cov_role_rotated(int b, int roles) { return (b + b / roles) % roles; }
 __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int p, int tid, int nt);
 
 template <bool TANGENTS>
@@ -816,7 +820,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
 template <bool TANGENTS>
 __global__ __launch_bounds__(kCovThreads) void cov_b_kernel(CovArgs a) {
     extern __shared__ double sm[];
-    cov_b_body<TANGENTS>(a, sm, blockIdx.x, blockIdx.y, blockIdx.z);
+    cov_b_body<TANGENTS>(a, sm, (int)((blockIdx.x + blockIdx.y + gridDim.y * blockIdx.z) % gridDim.x), blockIdx.y, blockIdx.z);
 }
 
 // A = Kfu (Kuu + jI)^-1 and its tangents for a tile of kRowTile time points:

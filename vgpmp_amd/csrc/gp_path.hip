@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kBlock) void stage2_kernel(Stage2Args a) {
     int b = blockIdx.x;
     if (b < a.n_cov) {
         if (a.skip & 1) return;
-        const int role = b % a.cov_roles;
+        const int role = cov_role_rotated(b, a.cov_roles);
         b /= a.cov_roles;
         cov_b_body<TANGENTS>(a.cov, sm, role, b % a.cov.L, b / a.cov.L);
         return;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void stage2_gemm_first_kernel(Stage2Args a)
     int b = blockIdx.x;
     if (b >= a.n_gemm) {
         b -= a.n_gemm;
-        const int role = b % a.cov_roles;
+        const int role = cov_role_rotated(b, a.cov_roles);
         b /= a.cov_roles;
         cov_b_body<TANGENTS>(a.cov, sm, role, b % a.cov.L, b / a.cov.L);
         return;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void mid_cov_b_gemm_kernel(MidCArgs a) {
         return;
     }
     b -= a.n_gemm;
-    const int role = b % a.cov_roles;
+    const int role = cov_role_rotated(b, a.cov_roles);
     b /= a.cov_roles;
     cov_b_body<TANGENTS>(a.cov, sm, role, b % a.cov.L, b / a.cov.L);
 }
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void batch_cov_b_prior_kernel(BatchCArgs a)
         return;
     }
     b -= a.n_prior;
-    const int role = b % a.cov_roles;
+    const int role = cov_role_rotated(b, a.cov_roles);
     b /= a.cov_roles;
     cov_b_body<true>(a.cov, sm, role, b % a.cov.L, b / a.cov.L);
 }
