@@ -22,6 +22,9 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 #else
 #define VG_STOP(args, k) do { } while (0)
 #endif
+#ifndef VG_EPS_FIRST
+#define VG_EPS_FIRST 1
+#endif
 #ifndef VG_ROWS_TPW_MAX
 #define VG_ROWS_TPW_MAX 2      // config-5 share: 976 / 965 / 1041 us per step with 1 / 2 / 4 tiles per workgroup, config 3: 241 / 234 / 237
 #endif
@@ -98,6 +101,24 @@ __global__ __launch_bounds__(kBlock) void stage1_kernel(Stage1Args a) {
         return;
     }
     b -= a.n_fin;
+#if VG_EPS_FIRST
+    // the eps draws ahead of the feature role (one or two problems: everything is resident at once, and the workgroups at the
+    // END of the grid were the last to finish -- 1.4 us behind cov_a)
+    if (b < a.n_eps) {
+        if (!(a.skip & 4)) {
+            if (a.rng.epsT) rng_eps_t_body(a.rng, b % a.eps_gx, b / a.eps_gx, reinterpret_cast<float*>(sm));
+            else rng_normals_body(a.rng, b % a.eps_gx, b / a.eps_gx, 0u, a.rng.nE);
+        }
+        VG_TMAX(162);
+        return;
+    }
+    b -= a.n_eps;
+    if (a.skip & 8) return;
+    const int bx = b % a.feat_gx;
+    b /= a.feat_gx;
+    features_body<PRO>(a.feat, bx, b % a.feat_gy, b / a.feat_gy);
+    VG_TMAX(163);
+#else
     // the feature role before the (short) eps draws: long roles at the front of the grid start in the first round of
     // workgroups, the short ones fill in behind (matters from 3 problems, where the launch exceeds what is resident at once)
     if (b < a.n_feat) {
@@ -114,6 +135,7 @@ __global__ __launch_bounds__(kBlock) void stage1_kernel(Stage1Args a) {
         else rng_normals_body(a.rng, b % a.eps_gx, b / a.eps_gx, 0u, a.rng.nE);
     }
     VG_TMAX(162);
+#endif
 }
 
 struct Stage2Args {
