@@ -163,6 +163,58 @@ def test_sample_sharding_two_ranks_equal_full_batch():
     assert float(r1.kl[0]) == 0.0 and float(r0.kl[0]) == float(full.kl[0])
 
 
+def test_sample_slices_that_start_inside_a_philox_counter():
+    """A rank's eps / eps' range need not start on a counter of the global stream (four normals per counter): Mz = 7, L = 7 and
+    a sample offset of 3 put its first element at 147.  The rank draws whole counters and keeps its own elements."""
+    from vgpmp_amd import engine
+    S, N, M, B = 11, 9, 5, 32
+    pb = small_problem(robot="franka", S=S, N=N, M=M, B=B, seed=5, n_grid=32)
+    sc = engine.DeviceScene(pb["spec"], pb["grid"], pb["offset"])
+    kw = dict(num_inducing=M, num_data=N, num_bases=B, lengthscales=[2.0] * 7, variance=0.2, alpha=pb["alpha"], seed=91, split_k=1)
+    full = engine.PlannerBatch(sc, pb["y"][None], num_samples=S, **kw)
+    r1 = engine.PlannerBatch(sc, pb["y"][None], num_samples=S - 3, samples_total=S, sample_offset=3, kl_scale=0.0, **kw)
+    full.loss_and_grad(step=2); r1.loss_and_grad(step=2)
+    torch.cuda.synchronize()
+    assert (3 * (M + 2) * 7) % 4 != 0
+    assert torch.equal(full.eps[0, 3:], r1.eps[0]) and torch.equal(full.eps2[0, 3:], r1.eps2[0])
+    assert torch.equal(full.w[0, 3:], r1.w[0])
+
+
+def test_latent_major_noise_copies_and_register_path_kernels_on_sample_slices():
+    """Large batches draw eps / eps' in two layouts (rng_eps_t_body: [P,S,Mz,L] and, for the per-latent path kernels,
+    [P,L,S,Mz]) and assemble the paths with a latent's operands in registers (paths_fwd_regs / paths_bwd_regs).  Both on a
+    rank's slice of the samples: the copies are transposes of each other, the slices are the full stream's, and two ranks
+    sum to the full batch."""
+    from vgpmp_amd import engine
+    P, S, N, M, B = 224, 32, 20, 30, 64
+    ps = rb.load_problemset("franka", "industrial")
+    spec = rb.load_robot("franka")
+    grid = scenes.synthetic_boxes_sdf(n=32, delta=0.08, origin=(-1.2, -1.2, -0.6), seed=0)
+    sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
+    qs = np.array([ps.queries[i % len(ps.queries)] for i in range(P)])
+    kw = dict(num_inducing=M, num_data=N, num_bases=B, lengthscales=[2.0] * 7, variance=0.2, seed=13, split_k=1)
+    full = engine.PlannerBatch(sc, qs, num_samples=S, **kw)
+    r0 = engine.PlannerBatch(sc, qs, num_samples=S // 2, samples_total=S, sample_offset=0, kl_scale=1.0, **kw)
+    r1 = engine.PlannerBatch(sc, qs, num_samples=S // 2, samples_total=S, sample_offset=S // 2, kl_scale=0.0, **kw)
+    for pl in (full, r0, r1):
+        pl.fuse = False
+    lf, gf = full.loss_and_grad(step=3)
+    l0, g0 = r0.loss_and_grad(step=3)
+    l1, g1 = r1.loss_and_grad(step=3)
+    torch.cuda.synchronize()
+    Mz, L = M + 2, 7
+    for pl in (full, r0, r1):
+        for name, t in (("epsT", pl.eps), ("eps2T", pl.eps2)):
+            tt = pl.view(name).reshape(P, L, pl.S, Mz)
+            assert torch.equal(tt, t.reshape(P, pl.S, Mz, L).permute(0, 3, 1, 2))
+    assert torch.equal(full.eps[:, S // 2:], r1.eps) and torch.equal(full.eps2[:, :S // 2], r0.eps2)
+    assert torch.equal(full.f[:, S // 2:], r1.f) and torch.equal(full.f[:, :S // 2], r0.f)      # rows of a tile are independent
+    np.testing.assert_allclose((l0 + l1).cpu().numpy(), lf.cpu().numpy(), rtol=1e-5)
+    for a, b, c in zip(gf, g0, g1):
+        want, got = a.cpu().numpy(), (b + c).cpu().numpy()
+        assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max() + 1e-9
+
+
 @pytest.mark.parametrize("S,N,M,B", [(1, 1, 1, 16), (13, 37, 3, 48), (9, 150, 46, 32), (150, 100, 30, 64)])
 def test_edge_shapes_against_oracle(S, N, M, B):
     """Ragged / extreme shapes: one sample, one time point, one inducing point, S and N that are not

@@ -440,6 +440,8 @@ int vg_workspace_lookup(const vgpmp_dims* d, const vg_workspace* ws, const char*
     else if (!strcmp(name, "F0")) { *ptr = ws->F0; *count = (size_t)d->split_k * P * S * L * J; }
     else if (!strcmp(name, "H")) { *ptr = ws->H; *count = (size_t)d->split_k * P * S * L * J; }
     else if (!strcmp(name, "R")) { *ptr = ws->R; *count = P * S * L * Mz; }
+    else if (!strcmp(name, "epsT")) { *ptr = ws->epsT; *count = P * S * L * Mz; }
+    else if (!strcmp(name, "eps2T")) { *ptr = ws->eps2T; *count = P * S * L * Mz; }
     else if (!strcmp(name, "G")) { *ptr = ws->G; *count = P * S * L * N; }
     else if (!strcmp(name, "kl_l")) { *ptr = ws->kl_l; *count = P * L; *is_double = 1; }
     else if (!strcmp(name, "Kinv")) { *ptr = ws->Kinv; *count = P * L * Mz * Mz; *is_double = 1; }
