@@ -558,7 +558,10 @@ struct FusedPriorArgs {
     size_t slab;
     uint32_t* tick;
 };
-constexpr int kFNT = 5;      // column tiles per workgroup
+#ifndef VG_KFNT_SMALL
+#define VG_KFNT_SMALL 5
+#endif
+constexpr int kFNT = VG_KFNT_SMALL;      // column tiles per workgroup
 template <int MT, int DM, bool DELL>    // 16-row sample tiles; joint-space extent padded to DM (8 or 16); d/d ell wanted
 __global__ __launch_bounds__(kBlock) void prior_fused_small_kernel(FusedPriorArgs a) {
     __shared__ float pts[kFNT * 16][DM];
