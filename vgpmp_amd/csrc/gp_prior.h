@@ -559,7 +559,7 @@ struct FusedPriorArgs {
     uint32_t* tick;
 };
 #ifndef VG_KFNT_SMALL
-#define VG_KFNT_SMALL 5
+#define VG_KFNT_SMALL 2      // config 3 (55 problems, S = 7, J = 96): 234 / 198 / 194 / 210 us per step with 5 / 3 / 2 / 1 -- more, lighter waves
 #endif
 constexpr int kFNT = VG_KFNT_SMALL;      // column tiles per workgroup
 template <int MT, int DM, bool DELL>    // 16-row sample tiles; joint-space extent padded to DM (8 or 16); d/d ell wanted
