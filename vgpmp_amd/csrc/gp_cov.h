@@ -828,22 +828,20 @@ __global__ __launch_bounds__(kCovThreads) void cov_b_kernel(CovArgs a) {
 // Output float32: A4[n][m] = {A, A_ell, A_var, 0} (one 16-byte load per use in the reverse pass)
 // and AT[m][n] for the forward path assembly.
 __device__ void cov_rows_body(const CovArgs& a, double* sm, int wg_tile, int l, int p, int tid, int nt) {
-    // Mz <= 32: every matrix padded with zeros to 32 (the products run on 16 x 16 float64 MFMA tiles)
-    const int M = a.M, Mz = M + 2, N = a.N, L = a.L, D = a.D, Mq = Mz <= 32 ? 32 : Mz, ld = (Mq + 2) & ~1;
-    const bool pad32 = Mz <= 32;
+    const int M = a.M, Mz = M + 2, N = a.N, L = a.L, D = a.D, ld = (Mz + 2) & ~1;
     // a workgroup walks `tpw` consecutive tiles (large batches: Lk^-1, dKuu/dell and (Kuu + jI)^-1 once for both of them -- one
     // tile per workgroup re-stages 16 KB and redoes the 32^3 product for every 8 time points, 13 times per latent at N = 100)
     const int tpw = max(a.rows_tpw, 1), tile = wg_tile * tpw;
     VG_T(tile == 0 && l == 0 && p == 0, 230);
     const float iMz = 1.0f / (float)Mz;
     const size_t pl = (size_t)p * L + l;
-    double* Ki = sm;                       // [Mq][ld]
-    double* Kd = Ki + Mq * ld;             // [Mq][ld]
-    double* kf = Kd + Mq * ld;             // [RT][Mq]  Kfu rows
-    double* df = kf + kRowTile * Mq;       // [RT][Mq]  dKfu/dell rows
-    double* ar = df + kRowTile * Mq;       // [RT][Mq]  A rows
-    double* yr = ar + kRowTile * Mq;       // [RT][Mq]
-    double* zs = yr + kRowTile * Mq;       // [Mz]
+    double* Ki = sm;                       // [Mz][ld]
+    double* Kd = Ki + Mz * ld;             // [Mz][ld]
+    double* kf = Kd + Mz * ld;             // [RT][Mz]  Kfu rows
+    double* df = kf + kRowTile * Mz;       // [RT][Mz]  dKfu/dell rows
+    double* ar = df + kRowTile * Mz;       // [RT][Mz]  A rows
+    double* yr = ar + kRowTile * Mz;       // [RT][Mz]
+    double* zs = yr + kRowTile * Mz;       // [Mz]
     double* xs = zs + Mz;                  // [tpw][RT] times of this workgroup's tiles
     double* Lt = xs + tpw * kRowTile;      // [Mz][ld] Lk^-1 as it arrives
     const double ell = a.ws.ell[pl], var = a.ws.var[pl];
@@ -852,13 +850,13 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int wg_tile, int l, 
     const int n00 = tile * kRowTile;
     {
         auto all = [](int, int) { return true; };
-        if ((Mz & 1) == 0 && Mq == Mz) {
+        if ((Mz & 1) == 0) {
             vg_stage_f64_square(Lt, ld, a.ws.Li64 + pl * Mz * Mz, Mz, tid, nt);
             if (a.want_dell) vg_stage_f64_square(Kd, ld, a.ws.Kd_ell + pl * Mz * Mz, Mz, tid, nt);
             else for (int e = tid; e < Mz * ld; e += nt) Kd[e] = 0.0;
         } else {
-            vg_stage_f64(Lt, Mq, ld, a.ws.Li64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
-            vg_stage_f64(Kd, Mq, ld, a.ws.Kd_ell + pl * Mz * Mz, a.want_dell ? Mz : 0, Mz, 0, 0, tid, nt, all);
+            vg_stage_f64(Lt, Mz, ld, a.ws.Li64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
+            vg_stage_f64(Kd, Mz, ld, a.ws.Kd_ell + pl * Mz * Mz, a.want_dell ? Mz : 0, Mz, 0, 0, tid, nt, all);
         }
         vg_stage_words(zs, 2 * (Mz + tpw * kRowTile), tid, nt, [&](int w) -> const void* {
             const int i = w >> 1;
@@ -875,10 +873,10 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int wg_tile, int l, 
     // reverse pass read
     {
         double* Kig = tile == 0 ? a.ws.Kinv + pl * Mz * Mz : nullptr;
-        if ((Mq & 15) == 0) {
-            matmul_f64(MatView{Lt, 1, ld}, MatView{Lt, ld, 1}, Mq, tid, nt, [&](int r, int c, double v) {
+        if ((Mz & 15) == 0) {
+            matmul_f64(MatView{Lt, 1, ld}, MatView{Lt, ld, 1}, Mz, tid, nt, [&](int r, int c, double v) {
                 Ki[r * ld + c] = v;
-                if (Kig && r < Mz && c < Mz) Kig[(size_t)r * Mz + c] = v;
+                if (Kig) Kig[(size_t)r * Mz + c] = v;
             });
         } else {
             for (int e = tid; e < Mz * Mz; e += nt) {
@@ -889,8 +887,8 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int wg_tile, int l, 
             }
         }
     }
-    if (pad32) {
-        // ---- Mz <= 32: the four [rows x 32] . [32 x 32] products on the float64 matrix cores, sixteen time points per pass
+    if (Mz == 32) {
+        // ---- Mz = 32: the four [rows x 32] . [32 x 32] products on the float64 matrix cores, sixteen time points per pass
         // (two tiles; one tile leaves half the rows empty).  The scalar form below reads both operands of every output from LDS
         // -- 256 eight-byte reads per thread and tile: at 64 x 14 latents x 13 tiles that was 6 GB through the chip's 79 TB/s
         // of LDS bandwidth, more than half of stage B's launch.  Lk^-1 is dead once (Kuu + jI)^-1 stands: its space takes the
@@ -907,7 +905,7 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int wg_tile, int l, 
             for (int e = tid; e < 16 * 32; e += nt) {
                 const int r = e >> 5, m = e & 31, n = n0 + r;
                 double k = 0.0, dk = 0.0;
-                if (n < N && r0 + r < rows_w && m < Mz) {
+                if (n < N && r0 + r < rows_w) {
                     double rr = fabs(xs[r0 + r] - zs[m]) / ell;
                     double ex = exp(-kSqrt5 * rr);
                     k = var * (1.0 + kSqrt5 * rr + (5.0 / 3.0) * rr * rr) * ex;
@@ -946,9 +944,9 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int wg_tile, int l, 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int r = g + 4 * q, n = n0 + r, m = j0 + i;
-                    if (n < N && r0 + r < rows_w && m < Mz) {
+                    if (n < N && r0 + r < rows_w) {
                         const float av0 = (float)ar2[r * 32 + m];
-                        vg_stream(A4 + (size_t)n * Mz + m, make_float4(av0, (float)acc[q], av[q], 0.f));
+                        vg_stream(A4 + (size_t)n * 32 + m, make_float4(av0, (float)acc[q], av[q], 0.f));
                         vg_stream(AT + (size_t)m * N + n, av0);
                     }
                 }

@@ -618,8 +618,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     int rows_tpw = 1;
     while (rows_tpw < VG_ROWS_TPW_MAX && (size_t)P * L * (kCovFixedRoles + (row_tiles + 2 * rows_tpw - 1) / (2 * rows_tpw)) >= 2048) rows_tpw *= 2;
     ca.rows_tpw = rows_tpw;
-    const int Mr = Mz <= 32 ? 32 : Mz;      // the rows role pads to 32 (MFMA tiles)
-    const size_t lds_rows = ((size_t)3 * Mr * ((Mr + 2) & ~1) + (size_t)4 * kRowTile * Mr + Mz + rows_tpw * kRowTile) * sizeof(double);
+    const size_t lds_rows = ((size_t)3 * Mz * ((Mz + 2) & ~1) + (size_t)4 * kRowTile * Mz + Mz + rows_tpw * kRowTile) * sizeof(double);
     const size_t lds_cov_b = lds_cov > lds_rows ? lds_cov : lds_rows;
     // path kernels: operands + (when it fits) the raw split-K slabs of the prior draws
     const size_t raw_f = SK == 1 ? 0 : (size_t)SK * SC * J * sizeof(float);      // one slab lands in place
