@@ -398,7 +398,8 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
     far = "true" if scene.free_space_summary else "false"
     batch_form = args.lik_form != "auto" or npb * S * N > 28672
     lik_kernel = ("loglik_paths_kernel<1, 64, false, %s, %s>" % (far, "true" if D <= 15 and args.lik_form != "lanes-lds" else "false")
-                  if batch_form else "loglik_paths_wide_kernel<8, false>")
+                  if batch_form else "loglik_paths_wide_kernel<8, false, 0>")      # (one or two problems: the timed schedule runs the
+    # <8, false, SK> form, which assembles the paths of its sample first; the events time the likelihood alone)
     roof_sdf = {"kernel": lik_kernel, "bound": "hbm", "achieved": sdf_bytes / t_sdf / 1e9,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sdf_bytes / t_sdf / 1e9 / HBM_PEAK_GBPS,
                 "traffic": None, "algorithmic_bytes_per_launch": sdf_bytes, "avg_launch_ms": kernel_ms["loglik_kernel"],
@@ -467,7 +468,8 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
                                "q_mu/q_sqrt/lengthscales/kernel_variance trainable",
                    "parallelism": f"problems sharded x{world}, no collective",
                    "launch": (f"hipGraph x{args.unroll} steps" if args.unroll else "plain launches")
-                             + ("; independent kernels of a step share launches (stage1/2/3_kernel), the prior GEMM is a"
+                             + ("; independent kernels of a step share launches (stage1 / stage2 / likelihood + path assembly / stage4 for"
+                                " one or two problems, stage1/2/3_kernel + likelihood + reverse pass from three), the prior GEMM is a"
                                 " role of stage2_kernel there and is timed alone for roofline_secondary"
                                 if planner.fuse and npb * D <= 32 else "")},
         "plans_per_sec": (world * npb / (float(pp["num_steps"]) * elapsed / args.steps + t_sample)

@@ -31,6 +31,12 @@ pmc config2 --steps 40 --warmup 5 $Q
 if [ -f $out/config2_pmc_traffic.json ]; then cp $out/config2_pmc_traffic.json profiles/pmc_traffic.json; fi
 python bench.py > $out/config2_bench.json 2> $out/config2_bench.err; tail -c 400 $out/config2_bench.json; echo
 stats config2 $Q
+# ---- the few-problem schedules: microseconds per step by the number of problems on the GPU
+for n in 1 2 3 4 6 8 13 16 24 32 48; do
+  python bench.py --problems $n $Q --min-seconds 1 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('problems', $n, 'us_per_step', round(1e3 * d['ms_per_step'], 2), 'problem_steps_per_s', round(d['value']))" >> $out/problems_sweep.txt
+done
 # ---- the metric's plans/sec as wall time of solve_planning_problem() calls
 timeout 600 python tools/solve_timing.py > $out/solve_timing_config2.txt 2>&1
 # ---- config 3: Franka / bookshelves, the full C(11,2) = 55 start-goal batch, S=7 M=24 T=70
