@@ -219,7 +219,7 @@ typedef struct vgpmp_outputs {
 #define VGPMP_NO_FUSE_PRIOR 4096 /* measurement: large batches with the generator, the feature kernel and the tiled GEMM as three launches */
 #define VGPMP_PRIOR_F32 8192   /* measurement: large batches form the prior draws with float32 MFMAs (the round-2 kernel) instead of
                                  * the f16-split products of prior_fused_split_kernel */
-#define VGPMP_NOISE_AHEAD 32768  /* few problems: stage 3 of the call's last step also draws the NEXT step's omega, beta, w */
+#define VGPMP_NOISE_AHEAD 32768  /* few problems: the call's last step also draws the NEXT step's omega, beta, w (beside its path assembly / reverse pass) */
 #define VGPMP_NOISE_READY 65536  /* ... and this call's first step finds its own already drawn (a previous call ran with NOISE_AHEAD at step - 1) */
 #define VGPMP_BWD_ONE_CHUNK 16384 /* measurement: reverse path pass with one sample chunk per workgroup (the values do not depend on it) */
 #define VGPMP_ELIM_BLOCK 128    /* measurement: Kuu elimination by the whole workgroup through LDS instead of one wave in registers */

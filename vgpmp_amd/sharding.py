@@ -91,7 +91,7 @@ class SampleShardedPlanner:
         self.planner, self.group, self.comm = planner, group, comm
         self.schedule = ("per step: vgpmp_elbo_step (forward + reverse: stage 1-3, likelihood, reverse paths, one launch for the "
                          "gradients; the next step's prior noise drawn beside the path assembly), the all-reduce, vgpmp_adam_step (one launch)")
-        self._chained_at = None          # step whose omega / beta / w the previous call's stage 3 has drawn
+        self._chained_at = None          # step whose omega / beta / w the previous call has drawn
 
     def _allreduce(self, buf: Optional[torch.Tensor] = None) -> None:
         buf = self.planner.reduce_buf if buf is None else buf
@@ -103,7 +103,7 @@ class SampleShardedPlanner:
     def step(self) -> None:
         from . import capi
         pl = self.planner
-        # consecutive steps: stage 3 of step t draws the prior noise of step t + 1 beside the path assembly (no noise launches)
+        # consecutive steps: step t draws the prior noise of step t + 1 beside its path assembly (no noise launches)
         keep = pl.extra_flags
         pl.extra_flags = keep | capi.NOISE_AHEAD | (capi.NOISE_READY if self._chained_at == pl.t else 0)
         try:
