@@ -25,6 +25,9 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 #ifndef VG_EPS_FIRST
 #define VG_EPS_FIRST 1
 #endif
+#ifndef VG_ROWS_TPW_WGS
+#define VG_ROWS_TPW_WGS 2048
+#endif
 #ifndef VG_ROWS_TPW_MAX
 #define VG_ROWS_TPW_MAX 2      // config-5 share: 976 / 965 / 1041 us per step with 1 / 2 / 4 tiles per workgroup, config 3: 241 / 234 / 237
 #endif
@@ -616,7 +619,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     // workgroups per CU anyway (four make the rows workgroups the long ones of the launch: slower again)
     const int row_tiles = (N + kRowTile - 1) / kRowTile;
     int rows_tpw = 1;
-    while (rows_tpw < VG_ROWS_TPW_MAX && (size_t)P * L * (kCovFixedRoles + (row_tiles + 2 * rows_tpw - 1) / (2 * rows_tpw)) >= 2048) rows_tpw *= 2;
+    while (rows_tpw < VG_ROWS_TPW_MAX && (size_t)P * L * (kCovFixedRoles + (row_tiles + 2 * rows_tpw - 1) / (2 * rows_tpw)) >= VG_ROWS_TPW_WGS) rows_tpw *= 2;
     ca.rows_tpw = rows_tpw;
     const size_t lds_rows = ((size_t)3 * Mz * ((Mz + 2) & ~1) + (size_t)4 * kRowTile * Mz + Mz + rows_tpw * kRowTile) * sizeof(double);
     const size_t lds_cov_b = lds_cov > lds_rows ? lds_cov : lds_rows;
