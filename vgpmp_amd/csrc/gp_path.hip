@@ -26,7 +26,7 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 #define VG_EPS_FIRST 1
 #endif
 #ifndef VG_ROWS_TPW_WGS
-#define VG_ROWS_TPW_WGS 2048
+#define VG_ROWS_TPW_WGS 256       // 24 problems: 405.6 -> 392.7 us per step against 2048, 13: 244.4 -> 241.9, 3: unchanged
 #endif
 #ifndef VG_ROWS_TPW_MAX
 #define VG_ROWS_TPW_MAX 2      // config-5 share: 976 / 965 / 1041 us per step with 1 / 2 / 4 tiles per workgroup, config 3: 241 / 234 / 237
@@ -615,8 +615,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const int Mp = (Mz + 15) & ~15;
     const size_t lds_cov = ((size_t)4 * Mp * (Mp + 2) + 8 * Mp) * sizeof(double);
     const size_t lds_cov_a = ((size_t)4 * Mp * (Mp + 1) + 2 * Mp) * sizeof(double);
-    // row tiles per workgroup of stage B's rows role: one while the launch is small (latency), two once there are eight
-    // workgroups per CU anyway (four make the rows workgroups the long ones of the launch: slower again)
+    // row tiles per workgroup of stage B's rows role: one while the launch is small (latency), two from a few hundred
+    // workgroups (a 16-row MFMA pass is full then; four make the rows workgroups the long ones of the launch: slower again)
     const int row_tiles = (N + kRowTile - 1) / kRowTile;
     int rows_tpw = 1;
     while (rows_tpw < VG_ROWS_TPW_MAX && (size_t)P * L * (kCovFixedRoles + (row_tiles + 2 * rows_tpw - 1) / (2 * rows_tpw)) >= VG_ROWS_TPW_WGS) rows_tpw *= 2;
