@@ -25,6 +25,9 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 #ifndef VG_EPS_FIRST
 #define VG_EPS_FIRST 1
 #endif
+#ifndef VG_H_MT2_MIN_TILES
+#define VG_H_MT2_MIN_TILES 0
+#endif
 #ifndef VG_ROWS_TPW_WGS
 #define VG_ROWS_TPW_WGS 256       // 24 problems: 405.6 -> 392.7 us per step against 2048, 13: 244.4 -> 241.9, 3: unchanged
 #endif
@@ -953,7 +956,10 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 // shared with stage B of the covariance path
                 const bool split16 = !cov_with_prior && !(what & VGPMP_PRIOR_F32);
                 if (split16) {
-                    const int hmt = S > kTS ? 2 : 1;
+                    // (128-row tiles halve the feature work per sample, but below ~one tile per CU their workgroups run alone:
+                    //  64-row tiles then, twice the workgroups at ~0.6 of the duration)
+                    const size_t h_tiles2 = (size_t)((J + kTJ - 1) / kTJ) * ((S + 2 * kTS - 1) / (2 * kTS)) * P * L;
+                    const int hmt = S > kTS && h_tiles2 > VG_H_MT2_MIN_TILES ? 2 : 1;
                     const size_t lds_h = vg_fused_split_lds(hmt);
                     const dim3 hgrid((J + kTJ - 1) / kTJ, (S + kTS * hmt - 1) / (kTS * hmt), P * L);
 #define VG_FH(DELL_, MT_)                                                                                                 \
