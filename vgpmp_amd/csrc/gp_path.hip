@@ -26,7 +26,7 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 #define VG_EPS_FIRST 1
 #endif
 #ifndef VG_H_MT2_MIN_TILES
-#define VG_H_MT2_MIN_TILES 0
+#define VG_H_MT2_MIN_TILES 300      // 36 problems: 330.5 -> 325.5 us per step; from 48 problems no difference
 #endif
 #ifndef VG_ROWS_TPW_WGS
 #define VG_ROWS_TPW_WGS 256       // 24 problems: 405.6 -> 392.7 us per step against 2048, 13: 244.4 -> 241.9, 3: unchanged
