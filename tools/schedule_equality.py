@@ -5,19 +5,24 @@ import sys, os
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vgpmp_amd import engine, robots as rb, scenes
+from vgpmp_amd import capi, engine, robots as rb, scenes
 
 ps = rb.load_problemset("franka", "industrial")
 spec = rb.load_robot("franka")
 grid = scenes.synthetic_boxes_sdf(n=64, delta=0.025, origin=(-0.8, -0.8, -0.2), seed=0)
 pp = ps.planner_params
 sc = engine.DeviceScene(spec, grid, ps.object_positions[0], sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"])
-for P, steps in ((1, 3000), (4, 1500), (8, 800)):
+CASES = ((1, 3000), (4, 1500), (8, 800))
+if len(sys.argv) > 2:      # tools/schedule_equality.py <problems> <steps>
+    CASES = ((int(sys.argv[1]), int(sys.argv[2])),)
+for P, steps in CASES:
     qs = np.array([ps.queries[i] for i in range(P)])
     kw = dict(num_samples=128, num_inducing=30, num_data=100, num_bases=1024, lengthscales=pp["lengthscales"],
               variance=pp["variance"], alpha=pp["alpha"], learning_rate=pp["learning_rate"], seed=3)
     a, b = engine.PlannerBatch(sc, qs, **kw), engine.PlannerBatch(sc, qs, **kw)
     b.fuse = False
+    # (one launch per kernel forms the prior draws by the f16-split kernel at SK = 1: the bitwise comparison needs its float32 form)
+    b.extra_flags |= capi.PRIOR_F32
     worst = 0.0
     for blk in range(steps // 100):
         a.run_steps(100 if blk % 2 else 37)
