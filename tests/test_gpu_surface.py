@@ -343,6 +343,31 @@ def test_pipelined_steps_equal_single_step_calls(P, M):
     assert torch.allclose(a.lik, b.lik, rtol=1e-7) and torch.allclose(a.kl, b.kl, rtol=1e-12)
 
 
+@pytest.mark.parametrize("P", [4, 8])
+def test_shared_launches_without_k_slices_equal_one_launch_per_kernel(P):
+    """128 samples and four or eight problems: whole-K GEMM tiles at the front of stage 2 (four problems) / the merged
+    launches of the medium batches (eight), the rows role with two tiles per workgroup.  The one-launch-per-kernel schedule
+    forms its prior draws by the f16-split kernel at this size; with its float32 form (VGPMP_PRIOR_F32) the two schedules
+    agree bit for bit."""
+    from vgpmp_amd import capi, engine
+    ps = rb.load_problemset("franka", "industrial")
+    spec = rb.load_robot("franka")
+    grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
+    sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
+    qs = np.array([ps.queries[i % len(ps.queries)] for i in range(P)])
+    kw = dict(num_samples=128, num_inducing=30, num_data=40, num_bases=256, lengthscales=[2.0] * 7, variance=0.2, seed=3)
+    a, b = engine.PlannerBatch(sc, qs, **kw), engine.PlannerBatch(sc, qs, **kw)
+    assert a.dims.split_k == 1
+    b.fuse = False
+    b.extra_flags |= capi.PRIOR_F32
+    a.run_steps(7); a.run_steps(5)
+    b.run_steps(12)
+    torch.cuda.synchronize()
+    for x, y in ((a.q_mu, b.q_mu), (a.q_sqrt, b.q_sqrt), (a.raw_ell, b.raw_ell), (a.raw_var, b.raw_var), (a.adam_v[1], b.adam_v[1])):
+        assert torch.equal(x, y), float((x - y).abs().max())
+    assert torch.equal(a.f, b.f) and torch.equal(a.logp, b.logp)
+
+
 def test_pipelined_steps_with_trainable_likelihood_constants():
     """sigma_obs / alpha among the variables: the chained schedule (their update rides between the reverse pass of
     step t and stage 1 of step t+1) equals one call per step with one launch per kernel."""
