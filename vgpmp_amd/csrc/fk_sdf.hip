@@ -20,6 +20,10 @@ static int lik_bisect_mode() { const char* e = getenv("VGPMP_STOP_LIK"); return 
 int vg_trace_take_lik(unsigned long long* host, int cap) { return vg_trace_take(host, cap); }
 #endif
 
+#ifndef VG_LIK_PREFIX
+#define VG_LIK_PREFIX 1      // 0: measurement builds with the per-frame sums of the batch likelihood in registers (two waves per SIMD)
+#endif
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -356,7 +360,16 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
             sc.at(j) = st; sc.at(D + j) = ct; sc.at(2 * D + j) = d;
         }
     }
+#if VG_LIK_PREFIX
+    // Joint i moves every sphere on frames >= i: its gradient is z_i . (M - o_i x F) over the totals MINUS the same expression
+    // over the prefix of frames < i.  The prefix term is a scalar the moment frame i - 1 is complete: a second copy of the
+    // chain (T2) follows the consumer side and leaves it in LDS slot 3 D + i - 1.  (Per-frame sums in registers -- six
+    // 16-wide vectors, 96 VGPRs -- held the kernel at two waves per SIMD; it is bound by the latency of its gathers.)
+    Frame T2 = base_frame(rb);
+    const bool craig = rb->craig != 0;
+#else
     vg_f32x16 fx = 0.f, fy = 0.f, fz = 0.f, mx = 0.f, my = 0.f, mz = 0.f;      // per-frame sums
+#endif
     Frame T = base_frame(rb);
     int cur = 0;                                         // frame T stands at (issue side)
     int pcur = 0;                                        // frame of the running sums (consumer side)
@@ -364,10 +377,21 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
     vg_float3 Ft = vg_make3(0.f, 0.f, 0.f), Mt = vg_make3(0.f, 0.f, 0.f);
     float acc = 0.f;
     auto flush = [&]() {                                 // sums of frame pcur are complete
+#if !VG_LIK_PREFIX
         fx[pcur] = F.x; fy[pcur] = F.y; fz[pcur] = F.z; mx[pcur] = Mo.x; my[pcur] = Mo.y; mz[pcur] = Mo.z;
+#endif
         Ft = vg_make3(Ft.x + F.x, Ft.y + F.y, Ft.z + F.z);
         Mt = vg_make3(Mt.x + Mo.x, Mt.y + Mo.y, Mt.z + Mo.z);
         F = vg_make3(0.f, 0.f, 0.f); Mo = vg_make3(0.f, 0.f, 0.f);
+#if VG_LIK_PREFIX
+        if (pcur < D) {                                  // (uniform) joint pcur + 1: its axis and origin, the prefix of frames <= pcur
+            vg_float3 z = T2.cz, org = T2.t;
+            dh_apply(rb, pcur, sc.at(pcur), sc.at(D + pcur), T2);
+            if (craig) { z = T2.cz; org = T2.t; }
+            const vg_float3 oxF = vg_cross(org, Ft);
+            sc.at(3 * D + pcur) = vg_dot(z, vg_make3(Mt.x - oxF.x, Mt.y - oxF.y, Mt.z - oxF.z));
+        }
+#endif
         ++pcur;
     };
 #pragma nounroll
@@ -432,6 +456,18 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
     while (pcur <= D) flush();
     // second sweep over the chain: joint i turns about z of frame i (Craig) or frame i-1 (classic) and moves every
     // sphere on frames >= i, i.e. the totals minus the prefix < i
+#if VG_LIK_PREFIX
+    T = base_frame(rb);
+#pragma nounroll
+    for (int i = 1; i <= D; ++i) {
+        vg_float3 z = T.cz, org = T.t;
+        dh_apply(rb, i - 1, sc.at(i - 1), sc.at(D + i - 1), T);
+        if (craig) { z = T.cz; org = T.t; }
+        const vg_float3 oxF = vg_cross(org, Ft);
+        const float tot = vg_dot(z, vg_make3(Mt.x - oxF.x, Mt.y - oxF.y, Mt.z - oxF.z));
+        emit(i - 1, (tot - sc.at(3 * D + i - 1)) * sc.at(2 * D + i - 1));
+    }
+#else
     const bool craig = rb->craig != 0;
     T = base_frame(rb);
     vg_float3 Fs = Ft, Ms = Mt;
@@ -445,6 +481,7 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
         const vg_float3 oxF = vg_cross(org, Fs);
         emit(i - 1, vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)) * sc.at(2 * D + i - 1));
     }
+#endif
     return -0.5f * acc;
 }
 
@@ -473,7 +510,7 @@ __global__ __launch_bounds__(kLikBlock) void log_prob_kernel(const vgpmp_robot* 
 // LPC lanes per (sample, time) configuration; BLK / LPC configurations per workgroup.  Large batches run one-wave
 // workgroups (kLikBatchBlock): 188 instead of 204 us per launch at 64 problems (finer tail).
 template <int LPC, int BLK, bool SIG = false, bool FAR = false, bool REGS = false>
-__global__ __launch_bounds__(BLK, REGS ? 2 : 1) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
+__global__ __launch_bounds__(BLK, REGS ? (VG_LIK_PREFIX ? 3 : 2) : 1) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
                                                                   const float* __restrict__ f, int S, int L, int N,
                                                                   float scale, float* __restrict__ G,
                                                                   float* __restrict__ logp,
@@ -1127,7 +1164,7 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
     };
     const bool regs = L <= 15 && form != 2;              // per-frame sums in registers (form 2, measurement: in LDS)
     if (regs) {
-        lds = (size_t)3 * L * kLikBatchBlock * sizeof(float);
+        lds = (size_t)(VG_LIK_PREFIX ? 4 : 3) * L * kLikBatchBlock * sizeof(float);
         if (sig) return far ? go(loglik_paths_kernel<1, kLikBatchBlock, true, true, true>) : go(loglik_paths_kernel<1, kLikBatchBlock, true, false, true>);
         return far ? go(loglik_paths_kernel<1, kLikBatchBlock, false, true, true>) : go(loglik_paths_kernel<1, kLikBatchBlock, false, false, true>);
     }
