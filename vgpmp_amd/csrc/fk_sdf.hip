@@ -20,8 +20,9 @@ static int lik_bisect_mode() { const char* e = getenv("VGPMP_STOP_LIK"); return 
 int vg_trace_take_lik(unsigned long long* host, int cap) { return vg_trace_take(host, cap); }
 #endif
 
-#ifndef VG_LIK_PREFIX
-#define VG_LIK_PREFIX 1      // 0: measurement builds with the per-frame sums of the batch likelihood in registers (two waves per SIMD)
+#ifndef VG_LIK_PREFIX_MAX_DOF
+#define VG_LIK_PREFIX_MAX_DOF 8      // batch likelihood: up to this many joints the prefix-scalar form (three waves per SIMD), beyond it
+                                    // the per-frame sums in registers (two); 0: measurement builds without the former
 #endif
 
 namespace {
@@ -338,7 +339,7 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
 // frame number -- indirect register addressing -- and only sin / cos / d g / d f of the joints in LDS: 3 D instead of
 // 9 D + 6 words per lane (132 at 14 joints, which held the one-lane form at one wave per SIMD).  Up to 15 joints.
 typedef float vg_f32x16 __attribute__((ext_vector_type(16)));
-template <int U, bool SIG, bool FAR, typename LoadRaw, typename ToAngle, typename Emit, typename EmitSig = NoSig>
+template <int U, bool SIG, bool FAR, bool PFX, typename LoadRaw, typename ToAngle, typename Emit, typename EmitSig = NoSig>
 __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restrict__ rb, const vg_sdf_dev& sdf,
                                                     const LikScratch sc, LoadRaw load_raw, ToAngle to_angle, Emit emit,
                                                     const float* __restrict__ sig = nullptr, float sig_w = 0.f,
@@ -360,16 +361,15 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
             sc.at(j) = st; sc.at(D + j) = ct; sc.at(2 * D + j) = d;
         }
     }
-#if VG_LIK_PREFIX
-    // Joint i moves every sphere on frames >= i: its gradient is z_i . (M - o_i x F) over the totals MINUS the same expression
+    // PFX: joint i moves every sphere on frames >= i: its gradient is z_i . (M - o_i x F) over the totals MINUS the same expression
     // over the prefix of frames < i.  The prefix term is a scalar the moment frame i - 1 is complete: a second copy of the
     // chain (T2) follows the consumer side and leaves it in LDS slot 3 D + i - 1.  (Per-frame sums in registers -- six
     // 16-wide vectors, 96 VGPRs -- held the kernel at two waves per SIMD; it is bound by the latency of its gathers.)
+    // With many joints the two extra chain sweeps cost what the third wave buys (14 joints: +1.8 % on the 2 GiB table, 7: -4 %):
+    // !PFX keeps the sums per frame.
     Frame T2 = base_frame(rb);
     const bool craig = rb->craig != 0;
-#else
-    vg_f32x16 fx = 0.f, fy = 0.f, fz = 0.f, mx = 0.f, my = 0.f, mz = 0.f;      // per-frame sums
-#endif
+    vg_f32x16 fx = 0.f, fy = 0.f, fz = 0.f, mx = 0.f, my = 0.f, mz = 0.f;      // (!PFX) per-frame sums
     Frame T = base_frame(rb);
     int cur = 0;                                         // frame T stands at (issue side)
     int pcur = 0;                                        // frame of the running sums (consumer side)
@@ -377,21 +377,17 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
     vg_float3 Ft = vg_make3(0.f, 0.f, 0.f), Mt = vg_make3(0.f, 0.f, 0.f);
     float acc = 0.f;
     auto flush = [&]() {                                 // sums of frame pcur are complete
-#if !VG_LIK_PREFIX
-        fx[pcur] = F.x; fy[pcur] = F.y; fz[pcur] = F.z; mx[pcur] = Mo.x; my[pcur] = Mo.y; mz[pcur] = Mo.z;
-#endif
+        if constexpr (!PFX) { fx[pcur] = F.x; fy[pcur] = F.y; fz[pcur] = F.z; mx[pcur] = Mo.x; my[pcur] = Mo.y; mz[pcur] = Mo.z; }
         Ft = vg_make3(Ft.x + F.x, Ft.y + F.y, Ft.z + F.z);
         Mt = vg_make3(Mt.x + Mo.x, Mt.y + Mo.y, Mt.z + Mo.z);
         F = vg_make3(0.f, 0.f, 0.f); Mo = vg_make3(0.f, 0.f, 0.f);
-#if VG_LIK_PREFIX
-        if (pcur < D) {                                  // (uniform) joint pcur + 1: its axis and origin, the prefix of frames <= pcur
+        if (PFX && pcur < D) {                                  // (uniform) joint pcur + 1: its axis and origin, the prefix of frames <= pcur
             vg_float3 z = T2.cz, org = T2.t;
             dh_apply(rb, pcur, sc.at(pcur), sc.at(D + pcur), T2);
             if (craig) { z = T2.cz; org = T2.t; }
             const vg_float3 oxF = vg_cross(org, Ft);
             sc.at(3 * D + pcur) = vg_dot(z, vg_make3(Mt.x - oxF.x, Mt.y - oxF.y, Mt.z - oxF.z));
         }
-#endif
         ++pcur;
     };
 #pragma nounroll
@@ -456,8 +452,8 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
     while (pcur <= D) flush();
     // second sweep over the chain: joint i turns about z of frame i (Craig) or frame i-1 (classic) and moves every
     // sphere on frames >= i, i.e. the totals minus the prefix < i
-#if VG_LIK_PREFIX
     T = base_frame(rb);
+    if constexpr (PFX) {
 #pragma nounroll
     for (int i = 1; i <= D; ++i) {
         vg_float3 z = T.cz, org = T.t;
@@ -467,9 +463,7 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
         const float tot = vg_dot(z, vg_make3(Mt.x - oxF.x, Mt.y - oxF.y, Mt.z - oxF.z));
         emit(i - 1, (tot - sc.at(3 * D + i - 1)) * sc.at(2 * D + i - 1));
     }
-#else
-    const bool craig = rb->craig != 0;
-    T = base_frame(rb);
+    } else {
     vg_float3 Fs = Ft, Ms = Mt;
 #pragma nounroll
     for (int i = 1; i <= D; ++i) {
@@ -481,7 +475,7 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
         const vg_float3 oxF = vg_cross(org, Fs);
         emit(i - 1, vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)) * sc.at(2 * D + i - 1));
     }
-#endif
+    }
     return -0.5f * acc;
 }
 
@@ -509,8 +503,8 @@ __global__ __launch_bounds__(kLikBlock) void log_prob_kernel(const vgpmp_robot* 
 // ---- ELBO path: f [P,S,L,N] -> logp [P,S,N], G = dloss/df [P,S,L,N], block partial sums ----------
 // LPC lanes per (sample, time) configuration; BLK / LPC configurations per workgroup.  Large batches run one-wave
 // workgroups (kLikBatchBlock): 188 instead of 204 us per launch at 64 problems (finer tail).
-template <int LPC, int BLK, bool SIG = false, bool FAR = false, bool REGS = false>
-__global__ __launch_bounds__(BLK, REGS ? (VG_LIK_PREFIX ? 3 : 2) : 1) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
+template <int LPC, int BLK, bool SIG = false, bool FAR = false, bool REGS = false, bool PFX = false>
+__global__ __launch_bounds__(BLK, REGS ? (PFX ? 3 : 2) : 1) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
                                                                   const float* __restrict__ f, int S, int L, int N,
                                                                   float scale, float* __restrict__ G,
                                                                   float* __restrict__ logp,
@@ -545,7 +539,7 @@ __global__ __launch_bounds__(BLK, REGS ? (VG_LIK_PREFIX ? 3 : 2) : 1) void logli
         const float* sigp = SIG ? sigma_eff + (size_t)pb * VGPMP_MAX_SPHERES : nullptr;
         auto put_sig = [&](int q, float t) { if (threadIdx.x == 0) sp[q] = t; };
         if (REGS) {
-            lp = loglik_config_regs<kLikBatchU, SIG, FAR>(
+            lp = loglik_config_regs<kLikBatchU, SIG, FAR, PFX>(
                 rb, sdf, sc, raw_f,
                 [&](int j, float x, float& d) {
                     const float sg = 1.0f / (1.0f + __expf(-x));                        // likelihood.py:49-52
@@ -1164,7 +1158,12 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
     };
     const bool regs = L <= 15 && form != 2;              // per-frame sums in registers (form 2, measurement: in LDS)
     if (regs) {
-        lds = (size_t)(VG_LIK_PREFIX ? 4 : 3) * L * kLikBatchBlock * sizeof(float);
+        const bool pfx = L <= VG_LIK_PREFIX_MAX_DOF;      // the prefix-scalar form of the reverse sweep (a fourth LDS slot row)
+        lds = (size_t)(pfx ? 4 : 3) * L * kLikBatchBlock * sizeof(float);
+        if (pfx) {
+            if (sig) return far ? go(loglik_paths_kernel<1, kLikBatchBlock, true, true, true, true>) : go(loglik_paths_kernel<1, kLikBatchBlock, true, false, true, true>);
+            return far ? go(loglik_paths_kernel<1, kLikBatchBlock, false, true, true, true>) : go(loglik_paths_kernel<1, kLikBatchBlock, false, false, true, true>);
+        }
         if (sig) return far ? go(loglik_paths_kernel<1, kLikBatchBlock, true, true, true>) : go(loglik_paths_kernel<1, kLikBatchBlock, true, false, true>);
         return far ? go(loglik_paths_kernel<1, kLikBatchBlock, false, true, true>) : go(loglik_paths_kernel<1, kLikBatchBlock, false, false, true>);
     }
