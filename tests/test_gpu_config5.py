@@ -241,7 +241,7 @@ def test_batch_form_of_the_likelihood_against_oracle_on_every_robot_shape(robot)
     for other in ("regs+summary", "lds", "lds+summary"):
         for a, b in zip(outs["regs"], outs[other]):
             if prefix_form and other.startswith("lds"):
-                assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-12, other
+                assert float((a - b).abs().max()) <= 4e-6 * float(b.abs().max()) + 1e-12, other
             else:
                 assert torch.equal(a, b), other
 
