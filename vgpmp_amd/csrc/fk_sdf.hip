@@ -342,7 +342,7 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
 // frame number -- indirect register addressing -- and only sin / cos / d g / d f of the joints in LDS: 3 D instead of
 // 9 D + 6 words per lane (132 at 14 joints, which held the one-lane form at one wave per SIMD).  Up to 15 joints.
 typedef float vg_f32x16 __attribute__((ext_vector_type(16)));
-template <int U, bool SIG, bool FAR, bool PFX, typename LoadRaw, typename ToAngle, typename Emit, typename EmitSig = NoSig>
+template <int U, bool SIG, bool FAR, typename LoadRaw, typename ToAngle, typename Emit, typename EmitSig = NoSig>
 __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restrict__ rb, const vg_sdf_dev& sdf,
                                                     const LikScratch sc, LoadRaw load_raw, ToAngle to_angle, Emit emit,
                                                     const float* __restrict__ sig = nullptr, float sig_w = 0.f,
@@ -364,15 +364,7 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
             sc.at(j) = st; sc.at(D + j) = ct; sc.at(2 * D + j) = d;
         }
     }
-    // PFX: joint i moves every sphere on frames >= i: its gradient is z_i . (M - o_i x F) over the totals MINUS the same expression
-    // over the prefix of frames < i.  The prefix term is a scalar the moment frame i - 1 is complete: a second copy of the
-    // chain (T2) follows the consumer side and leaves it in LDS slot 3 D + i - 1.  (Per-frame sums in registers -- six
-    // 16-wide vectors, 96 VGPRs -- held the kernel at two waves per SIMD; it is bound by the latency of its gathers.)
-    // With many joints the two extra chain sweeps cost what the third wave buys (14 joints: +1.8 % on the 2 GiB table, 7: -4 %):
-    // !PFX keeps the sums per frame.
-    Frame T2 = base_frame(rb);
-    const bool craig = rb->craig != 0;
-    vg_f32x16 fx = 0.f, fy = 0.f, fz = 0.f, mx = 0.f, my = 0.f, mz = 0.f;      // (!PFX) per-frame sums
+    vg_f32x16 fx = 0.f, fy = 0.f, fz = 0.f, mx = 0.f, my = 0.f, mz = 0.f;      // per-frame sums
     Frame T = base_frame(rb);
     int cur = 0;                                         // frame T stands at (issue side)
     int pcur = 0;                                        // frame of the running sums (consumer side)
@@ -380,11 +372,135 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
     vg_float3 Ft = vg_make3(0.f, 0.f, 0.f), Mt = vg_make3(0.f, 0.f, 0.f);
     float acc = 0.f;
     auto flush = [&]() {                                 // sums of frame pcur are complete
-        if constexpr (!PFX) { fx[pcur] = F.x; fy[pcur] = F.y; fz[pcur] = F.z; mx[pcur] = Mo.x; my[pcur] = Mo.y; mz[pcur] = Mo.z; }
+        fx[pcur] = F.x; fy[pcur] = F.y; fz[pcur] = F.z; mx[pcur] = Mo.x; my[pcur] = Mo.y; mz[pcur] = Mo.z;
         Ft = vg_make3(Ft.x + F.x, Ft.y + F.y, Ft.z + F.z);
         Mt = vg_make3(Mt.x + Mo.x, Mt.y + Mo.y, Mt.z + Mo.z);
         F = vg_make3(0.f, 0.f, 0.f); Mo = vg_make3(0.f, 0.f, 0.f);
-        if (PFX && pcur < D) {                                  // (uniform) joint pcur + 1: its axis and origin, the prefix of frames <= pcur
+        ++pcur;
+    };
+#pragma nounroll
+    for (int q0 = 0; q0 < P; q0 += U) {
+        float4 v[U];
+        vg_float3 pos[U];
+        uint32_t at[U];
+        float4 ca[U];
+        float2 cb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ca[u] = *reinterpret_cast<const float4*>(rb->sphere_a[q0 + u]);      // {offset, frame}; rows >= P: frame = D
+            cb[u] = *reinterpret_cast<const float2*>(rb->sphere_b[q0 + u]);      // {radius, 1 / sigma}
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + u;
+            if (q < P) {                                 // uniform
+                const int fr = __builtin_bit_cast(int, ca[u].w);
+                while (cur < fr) {
+                    dh_apply(rb, cur, sc.at(cur), sc.at(D + cur), T);
+                    ++cur;
+                }
+                pos[u] = axpy(ca[u].x, T.cx, axpy(ca[u].y, T.cy, axpy(ca[u].z, T.cz, T.t)));
+                const Vox3 ix = voxel3(pos[u], fs, sdf, offx, offy, offz);
+                at[u] = (uint32_t)vg_table_offset(sdf, ix.ix, ix.iy, ix.iz);
+                if (FAR) v[u].x = sdf.brick_min[vg_brick_of(sdf, ix.ix, ix.iy, ix.iz)];
+                else v[u] = sdf.table[at[u]];
+            } else {
+                v[u] = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);       // hinge exactly 0
+                pos[u] = vg_make3(0.f, 0.f, 0.f);
+                at[u] = 0u;
+            }
+        }
+        if (FAR) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (q0 + u < P) {
+                    // free space: the hinge is exactly 0 on every voxel of the brick -> no table access
+                    const float bm = v[u].x;
+                    v[u] = make_float4(bm, 0.f, 0.f, 0.f);
+                    if (eps - (bm - cb[u].x) > 0.f) v[u] = sdf.table[at[u]];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + u;
+            if (q < P) {                                 // uniform
+                const int fr = __builtin_bit_cast(int, ca[u].w);
+                while (pcur < fr) flush();
+                const float c = fmaxf(eps - (v[u].x - cb[u].x), 0.f);           // likelihood.py:131-143
+                const float cs = SIG ? c / sig[q] : c * cb[u].y;
+                acc = fmaf(cs, c, acc);                                          // likelihood.py:99
+                if (SIG) emit_sig(q, vg_wave_sum(cs * c * sig_w));               // one total per sphere
+                const vg_float3 gp = vg_make3(cs * v[u].y, cs * v[u].z, cs * v[u].w);   // d logp / d pos
+                F = vg_make3(F.x + gp.x, F.y + gp.y, F.z + gp.z);
+                Mo = vg_cross_acc(Mo, pos[u], gp);
+            }
+        }
+    }
+    while (pcur <= D) flush();
+    // second sweep over the chain: joint i turns about z of frame i (Craig) or frame i-1 (classic) and moves every
+    // sphere on frames >= i, i.e. the totals minus the prefix < i
+    const bool craig = rb->craig != 0;
+    T = base_frame(rb);
+    vg_float3 Fs = Ft, Ms = Mt;
+#pragma nounroll
+    for (int i = 1; i <= D; ++i) {
+        Fs = vg_make3(Fs.x - fx[i - 1], Fs.y - fy[i - 1], Fs.z - fz[i - 1]);
+        Ms = vg_make3(Ms.x - mx[i - 1], Ms.y - my[i - 1], Ms.z - mz[i - 1]);
+        vg_float3 z = T.cz, org = T.t;
+        dh_apply(rb, i - 1, sc.at(i - 1), sc.at(D + i - 1), T);
+        if (craig) { z = T.cz; org = T.t; }
+        const vg_float3 oxF = vg_cross(org, Fs);
+        emit(i - 1, vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)) * sc.at(2 * D + i - 1));
+    }
+    return -0.5f * acc;
+}
+
+// The same with the prefix term of every joint's gradient as a scalar in LDS instead of per-frame sums in registers (up to
+// VG_LIK_PREFIX_MAX_DOF joints).  A function of its own: folded into loglik_config_regs as a template switch, the form WITHOUT
+// the prefix terms came out 22 % slower at the config-5 share -- same numbers, same register count, a different schedule of
+// its gathers.
+template <int U, bool SIG, bool FAR, typename LoadRaw, typename ToAngle, typename Emit, typename EmitSig = NoSig>
+__device__ __forceinline__ float loglik_config_prefix(const vgpmp_robot* __restrict__ rb, const vg_sdf_dev& sdf,
+                                                    const LikScratch sc, LoadRaw load_raw, ToAngle to_angle, Emit emit,
+                                                    const float* __restrict__ sig = nullptr, float sig_w = 0.f,
+                                                    EmitSig emit_sig = NoSig()) {
+    static_assert(VGPMP_MAX_SPHERES % U == 0, "a batch of sphere constants never leaves the table");
+    const int D = rb->dof, P = rb->num_spheres;          // D <= 15: frames 0 .. 15
+    float raw[VGPMP_MAX_DOF];
+#pragma unroll
+    for (int j = 0; j < VGPMP_MAX_DOF; ++j) raw[j] = load_raw(min(j, D - 1));
+    const float eps = rb->epsilon;
+    const double offx = rb->scene_offset[0], offy = rb->scene_offset[1], offz = rb->scene_offset[2];
+    const SdfFast fs = make_fast(sdf, offx, offy, offz);
+    // sin / cos / d g / d f of every joint: LDS slots [0, D), [D, 2D), [2D, 3D) of this lane
+#pragma unroll
+    for (int j = 0; j < VGPMP_MAX_DOF; ++j) {
+        if (j < D) {                                     // uniform
+            float st, ct, d;
+            vg_sincos(to_angle(j, raw[j], d) + rb->joint_tab[j][4], &st, &ct);
+            sc.at(j) = st; sc.at(D + j) = ct; sc.at(2 * D + j) = d;
+        }
+    }
+    // Joint i moves every sphere on frames >= i: its gradient is z_i . (M - o_i x F) over the totals MINUS the same expression
+    // over the prefix of frames < i.  The prefix term is a scalar the moment frame i - 1 is complete: a second copy of the
+    // chain (T2) follows the consumer side and leaves it in LDS slot 3 D + i - 1.  (Per-frame sums in registers -- six
+    // 16-wide vectors, 96 VGPRs -- held the kernel at two waves per SIMD; it is bound by the latency of its gathers.)
+    // With many joints the two extra chain sweeps cost what the third wave buys (14 joints: +1.8 % on the 2 GiB table, 7: -4 %):
+    // loglik_config_regs keeps the sums per frame.
+    Frame T2 = base_frame(rb);
+    const bool craig = rb->craig != 0;
+    Frame T = base_frame(rb);
+    int cur = 0;                                         // frame T stands at (issue side)
+    int pcur = 0;                                        // frame of the running sums (consumer side)
+    vg_float3 F = vg_make3(0.f, 0.f, 0.f), Mo = vg_make3(0.f, 0.f, 0.f);
+    vg_float3 Ft = vg_make3(0.f, 0.f, 0.f), Mt = vg_make3(0.f, 0.f, 0.f);
+    float acc = 0.f;
+    auto flush = [&]() {                                 // sums of frame pcur are complete
+                Ft = vg_make3(Ft.x + F.x, Ft.y + F.y, Ft.z + F.z);
+        Mt = vg_make3(Mt.x + Mo.x, Mt.y + Mo.y, Mt.z + Mo.z);
+        F = vg_make3(0.f, 0.f, 0.f); Mo = vg_make3(0.f, 0.f, 0.f);
+        if (pcur < D) {                                  // (uniform) joint pcur + 1: its axis and origin, the prefix of frames <= pcur
             vg_float3 z = T2.cz, org = T2.t;
             dh_apply(rb, pcur, sc.at(pcur), sc.at(D + pcur), T2);
             if (craig) { z = T2.cz; org = T2.t; }
@@ -460,7 +576,6 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
     // second sweep over the chain: joint i turns about z of frame i (Craig) or frame i-1 (classic) and moves every
     // sphere on frames >= i, i.e. the totals minus the prefix < i
     T = base_frame(rb);
-    if constexpr (PFX) {
 #pragma nounroll
     for (int i = 1; i <= D; ++i) {
         vg_float3 z = T.cz, org = T.t;
@@ -469,19 +584,6 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
         const vg_float3 oxF = vg_cross(org, Ft);
         const float tot = vg_dot(z, vg_make3(Mt.x - oxF.x, Mt.y - oxF.y, Mt.z - oxF.z));
         emit(i - 1, (tot - sc.at(3 * D + i - 1)) * sc.at(2 * D + i - 1));
-    }
-    } else {
-    vg_float3 Fs = Ft, Ms = Mt;
-#pragma nounroll
-    for (int i = 1; i <= D; ++i) {
-        Fs = vg_make3(Fs.x - fx[i - 1], Fs.y - fy[i - 1], Fs.z - fz[i - 1]);
-        Ms = vg_make3(Ms.x - mx[i - 1], Ms.y - my[i - 1], Ms.z - mz[i - 1]);
-        vg_float3 z = T.cz, org = T.t;
-        dh_apply(rb, i - 1, sc.at(i - 1), sc.at(D + i - 1), T);
-        if (craig) { z = T.cz; org = T.t; }
-        const vg_float3 oxF = vg_cross(org, Fs);
-        emit(i - 1, vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)) * sc.at(2 * D + i - 1));
-    }
     }
     return -0.5f * acc;
 }
@@ -546,7 +648,11 @@ __global__ __launch_bounds__(BLK, REGS ? (PFX ? 3 : 2) : 1) void loglik_paths_ke
         const float* sigp = SIG ? sigma_eff + (size_t)pb * VGPMP_MAX_SPHERES : nullptr;
         auto put_sig = [&](int q, float t) { if (threadIdx.x == 0) sp[q] = t; };
         if (REGS) {
-            lp = loglik_config_regs<kLikBatchU, SIG, FAR, PFX>(
+            auto regs_form = [&](auto&&... a) {
+                if constexpr (PFX) return loglik_config_prefix<kLikBatchU, SIG, FAR>(a...);
+                else return loglik_config_regs<kLikBatchU, SIG, FAR>(a...);
+            };
+            lp = regs_form(
                 rb, sdf, sc, raw_f,
                 [&](int j, float x, float& d) {
                     const float sg = 1.0f / (1.0f + __expf(-x));                        // likelihood.py:49-52
