@@ -20,6 +20,9 @@ static int lik_bisect_mode() { const char* e = getenv("VGPMP_STOP_LIK"); return 
 int vg_trace_take_lik(unsigned long long* host, int cap) { return vg_trace_take(host, cap); }
 #endif
 
+#ifndef VG_LIK_PFX_WAVES
+#define VG_LIK_PFX_WAVES 3
+#endif
 #ifndef VG_LIK_PREFIX_MAX_DOF
 #define VG_LIK_PREFIX_MAX_DOF 8      // batch likelihood: up to this many joints the prefix-scalar form (three waves per SIMD), beyond it
                                     // the per-frame sums in registers (two); 0: measurement builds without the former
@@ -613,7 +616,7 @@ __global__ __launch_bounds__(kLikBlock) void log_prob_kernel(const vgpmp_robot* 
 // LPC lanes per (sample, time) configuration; BLK / LPC configurations per workgroup.  Large batches run one-wave
 // workgroups (kLikBatchBlock): 188 instead of 204 us per launch at 64 problems (finer tail).
 template <int LPC, int BLK, bool SIG = false, bool FAR = false, bool REGS = false, bool PFX = false>
-__global__ __launch_bounds__(BLK, REGS ? (PFX ? 3 : 2) : 1) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
+__global__ __launch_bounds__(BLK, REGS ? (PFX ? VG_LIK_PFX_WAVES : 2) : 1) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
                                                                   const float* __restrict__ f, int S, int L, int N,
                                                                   float scale, float* __restrict__ G,
                                                                   float* __restrict__ logp,
