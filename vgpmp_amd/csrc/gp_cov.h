@@ -42,6 +42,13 @@ struct CovArgs {
 #ifndef VG_ELIM_PANELS
 #define VG_ELIM_PANELS 1      // 0: measurement builds with the 32-pivot one-wave elimination
 #endif
+// stores of stage B that the NEXT launch reads (never this one): past the caches -- dirty lines left in L2 lengthen the
+// hand-over to that launch (VG_HO_PLAIN: measurement builds with plain stores)
+#ifdef VG_HO_PLAIN
+#define VG_HO(p, v) (*(p) = (v))
+#else
+#define VG_HO(p, v) vg_stream((p), (v))
+#endif
 constexpr int kCovThreads = 256;      // == kBlock: the covariance roles share launches with other kernels
 constexpr int kRowTile = 8;
 
@@ -648,7 +655,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
         // ---- role 3: m, the float32 Lk, q_sqrt = Lk pad(Q) + jitter I (first two diagonal entries), U
         if (tid < Mz) {
             const float mi = (float)(tid == 0 ? y0 : (tid == 1 ? y1 : mine_qmu));
-            a.ws.m[pl * Mz + tid] = mi;
+            VG_HO(a.ws.m + pl * Mz + tid, mi);
             if (form_u) ml[tid] = mi;
         }
         if (Mz == Mp && !(M & 1)) {      // (16-byte staging of Q above: the strict upper triangle of the block is not Q's)
@@ -661,7 +668,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
             float* Lk32 = a.ws.Lk32 + pl * Mz * Mz;      // stage A of the next step may overlap that kernel)
             for (int e = tid; e < Mz * Mz; e += nt) {
                 const int i = vg_div(e, iMz), j = e - i * Mz;
-                Lk32[e] = (float)La[i * ld + j];
+                VG_HO(Lk32 + e, (float)La[i * ld + j]);
             }
         }
         __syncthreads();
@@ -671,8 +678,8 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
         matmul_f64(MatView{La, ld, 1}, MatView{Qp, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
             if (r < Mz && c < Mz) {
                 const float cv = (float)(v + (r == c && r < 2 ? jit : 0.0));
-                C32[(size_t)r * Mz + c] = cv;
-                C32T[(size_t)c * Mz + r] = cv;
+                VG_HO(C32 + (size_t)r * Mz + c, cv);
+                VG_HO(C32T + (size_t)c * Mz + r, cv);
                 if (form_u) ctl[c * Mz + r] = cv;
             }
         });
@@ -703,7 +710,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int s = s0 + 4 * kk + q;
-                    if (s < S) a.ws.U[(((size_t)p * S + s) * L + l) * 32 + mi] = acc[q];
+                    if (s < S) VG_HO(a.ws.U + (((size_t)p * S + s) * L + l) * 32 + mi, acc[q]);
                 }
             }
         }
@@ -750,7 +757,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
                     gq = q;
                     if (c == r) { klacc -= log(q * q); gq -= 1.0 / q; }
                 }
-                gklQ[e] = gq;
+                VG_HO(gklQ + e, gq);
             }
         }
         const double kl = block_sum(klacc, red);
@@ -794,7 +801,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     __syncthreads();
     float* CT = (role == 1 ? a.ws.CT_ell : a.ws.CT_var) + pl * Mz * Mz;
     matmul_f64(MatView{T, ld, 1}, MatView{La, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
-        if (r < Mz && c < Mz) CT[(size_t)c * Mz + r] = (float)v;       // stored transposed
+        if (r < Mz && c < Mz) VG_HO(CT + (size_t)c * Mz + r, (float)v);       // stored transposed
     });
     VG_T(l == 0 && p == 0, 202 + 10 * role);
     // KL tangent: a_dot = Lk^-1 (delta_dot - dLk a),  delta_dot = -d p_mu
