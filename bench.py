@@ -397,7 +397,10 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
     t_sdf, t_gemm = kernel_ms["loglik_kernel"] * 1e-3, kernel_ms["prior_gemm_kernel"] * 1e-3
     far = "true" if scene.free_space_summary else "false"
     batch_form = args.lik_form != "auto" or npb * S * N > 28672
-    lik_kernel = ("loglik_paths_kernel<1, 64, false, %s, %s>" % (far, "true" if D <= 15 and args.lik_form != "lanes-lds" else "false")
+    regs_form = D <= 15 and args.lik_form != "lanes-lds"
+    # (template arguments as rocprofv3 prints them: <LPC, BLK, SIG, FAR, REGS, PFX> -- PFX: the prefix-scalar form, up to 8 joints)
+    lik_kernel = ("loglik_paths_kernel<1, 64, false, %s, %s, %s>" % (far, "true" if regs_form else "false",
+                                                                     "true" if regs_form and D <= 8 else "false")
                   if batch_form else "loglik_paths_wide_kernel<8, false, 0>")      # (one or two problems: the timed schedule runs the
     # <8, false, SK> form, which assembles the paths of its sample first; the events time the likelihood alone)
     roof_sdf = {"kernel": lik_kernel, "bound": "hbm", "achieved": sdf_bytes / t_sdf / 1e9,
