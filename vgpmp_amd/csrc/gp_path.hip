@@ -25,6 +25,9 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 #ifndef VG_EPS_FIRST
 #define VG_EPS_FIRST 1
 #endif
+#ifndef VG_JCHUNK_ONE
+#define VG_JCHUNK_ONE 8       // points per workgroup of the feature role at one problem
+#endif
 #ifndef VG_H_MT2_MIN_TILES
 #define VG_H_MT2_MIN_TILES 300      // 36 problems: 330.5 -> 325.5 us per step; from 48 problems no difference
 #endif
@@ -545,7 +548,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     fe.N = N; fe.Mz = Mz; fe.L = L; fe.D = L; fe.B = B;
     // few problems: few points per workgroup (more parallelism); many: sweep 16 points per lane (omega reuse)
     // (shared launches: 8 for one problem -- the role is off the pole either way --, 16 from two: 105 -> 95 us per step)
-    fe.jchunk = fused ? (P > 1 ? 16 : 8) : (P * L >= 16 ? 16 : 4);
+    fe.jchunk = fused ? (P > 1 ? 16 : VG_JCHUNK_ONE) : (P * L >= 16 ? 16 : 4);
     fe.X = pb->X; fe.Zy = zy; fe.zy_stride = zy_stride; fe.raw_ell = params->raw_ell; fe.raw_var = params->raw_var;
     fe.omega = nz->omega; fe.beta = nz->beta; fe.Phi = ws->Phi; fe.dPhi = want_dell ? ws->dPhi : nullptr;
     fe.tick = (!fused && do_adam) ? ctr : nullptr;
