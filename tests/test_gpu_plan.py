@@ -78,6 +78,23 @@ def test_sampler_cache_follows_the_time_stamps_of_each_call():
     assert np.abs(wa - wb).max() > 1e-2
 
 
+def test_planners_of_one_scene_share_the_sampler_view_but_not_its_variables():
+    """solve_planning_problem builds one planner per start-goal query; their 150-path views have the same shape and hand one
+    set of buffers on.  Two planners alive at once must still each sample from their OWN variables."""
+    from vgpmp_amd import engine
+    pb, sc, a = _setup("franka", 16, 9, 6, 64)
+    b = engine.PlannerBatch(sc, np.stack([pb["y"][::-1], pb["y"]]), num_samples=4, num_inducing=6, num_data=7, num_bases=64,
+                            lengthscales=[2.0] * 7, variance=0.2, alpha=pb["alpha"])
+    b.q_mu.mul_(0.5)
+    ma = a.sample_from_posterior(16, None, step=3)[0].clone()
+    mb = b.sample_from_posterior(16, None, step=3)[0].clone()
+    assert a.posterior_sampler(16) is b.posterior_sampler(16)            # one view ...
+    ma2 = a.sample_from_posterior(16, None, step=3)[0].clone()
+    mb2 = b.sample_from_posterior(16, None, step=3)[0].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(ma, ma2) and torch.equal(mb, mb2) and not torch.equal(ma, mb)      # ... two sets of variables
+
+
 def test_path_clearance_against_oracle():
     pb, sc, pl = _setup("franka", 150, 23, 6, 64)
     rng = np.random.default_rng(8)

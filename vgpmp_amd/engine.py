@@ -436,11 +436,23 @@ class PlannerBatch:
         key = (int(num_samples), n_new)
         cache = self.__dict__.setdefault("_samplers", {})
         if key not in cache:
-            mid = np.tile(0.5 * (self.scene.spec.low + self.scene.spec.high), (self.P, 2, 1))   # placeholder queries
-            child = PlannerBatch(self.scene, mid, num_samples=num_samples, num_inducing=self.M, num_data=n_new,
-                                 lengthscales=[1.0] * self.L, variance=1.0, alpha=self.alpha, learning_rate=self.lr,
-                                 num_bases=self.B, trainable=self.trainable, seed=self.seed + 7919,
-                                 problem_base=self.problem_base, X=Xnew)
+            # the view's own buffers (noise, paths, workspace) depend on shapes and constants only: planners of the same scene
+            # and shape -- one per start-goal query in the reference's driver loop -- hand one set on (the variables it reads
+            # are re-pointed at THIS planner's below)
+            shared = self.scene.__dict__.setdefault("_sampler_views", {})
+            skey = key + (self.P, self.M, self.B, self.alpha, self.lr, self.seed, self.problem_base,
+                          tuple(sorted(self.trainable.items())))
+            child = shared.get(skey)
+            if child is None:
+                mid = np.tile(0.5 * (self.scene.spec.low + self.scene.spec.high), (self.P, 2, 1))   # placeholder queries
+                child = PlannerBatch(self.scene, mid, num_samples=num_samples, num_inducing=self.M, num_data=n_new,
+                                     lengthscales=[1.0] * self.L, variance=1.0, alpha=self.alpha, learning_rate=self.lr,
+                                     num_bases=self.B, trainable=self.trainable, seed=self.seed + 7919,
+                                     problem_base=self.problem_base, X=Xnew)
+                shared[skey] = child
+            cache[key] = child
+        child = cache[key]
+        if getattr(child, "_view_of", None) is not self:      # (another planner of this scene and shape used the view since)
             child.q_mu, child.q_sqrt, child.raw_ell, child.raw_var = self.q_mu, self.q_sqrt, self.raw_ell, self.raw_var
             child.y_u = self.y_u
             if self.lik_variables:      # the trained sigma_obs / alpha weigh the samples of get_best_sample
@@ -448,8 +460,7 @@ class PlannerBatch:
             if self.z_variables:        # the trained inducing locations
                 child.raw_Z = self.raw_Z
             child._pack()
-            cache[key] = child
-        child = cache[key]
+            child._view_of = self
         Xn = np.tile(np.linspace(0.0, 1.0, n_new)[:, None], (1, self.L)) if Xnew is None else np.asarray(Xnew, dtype=np.float64)
         child.X.copy_(torch.as_tensor(Xn, dtype=torch.float64).reshape(child.X.shape))
         return child
