@@ -48,6 +48,8 @@ def parse_args(argv=None):
     ap.add_argument("--grid", type=int, default=0, help="SDF voxels per axis of the synthetic scenes (0 = 128; stress: 512)")
     ap.add_argument("--split-k", type=int, default=0, help="K-slices of the prior GEMM (0 = engine default)")
     ap.add_argument("--no-fuse", action="store_true", help="one launch per kernel even for small batches (measurement)")
+    ap.add_argument("--also-train", default="", help="comma list of further trainable_params flags (inducing_variable, sigma_obs, "
+                    "alpha) on top of the reference's defaults: the schedules those variables run on (config 2 / 3 workloads)")
     ap.add_argument("--scene", choices=("mesh", "industrial", "synthetic"), default="mesh",
                     help="mesh = SDF generated from the reference's collision mesh of the workload's scene; synthetic = boxes/spheres")
     ap.add_argument("--unroll", type=int, default=0,
@@ -159,7 +161,9 @@ def build_problem(rank: int, args, world: int = 1):
     planner = engine.PlannerBatch(scene, qs, num_samples=args.samples, num_inducing=args.inducing,
                                   num_data=args.timesteps, num_bases=1024, lengthscales=pp["lengthscales"],
                                   variance=pp["variance"], alpha=pp["alpha"], learning_rate=pp["learning_rate"],
-                                  seed=1234, problem_base=rank * args.problems, split_k=args.split_k or None)
+                                  seed=1234, problem_base=rank * args.problems, split_k=args.split_k or None,
+                                  trainable=(dict(engine.DEFAULT_TRAINABLE, **{k: True for k in args.also_train.split(",") if k})
+                                             if args.also_train else None))
     planner.fuse = not args.no_fuse
     return ps, spec, grid, scene, planner
 
@@ -468,7 +472,8 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
                                + (" from the reference's collision mesh" if args.workload != "stress" and args.scene != "synthetic"
                                   else " synthetic boxes/spheres")
                                + f", {npb} start-goal problem(s) per GPU, S={S} M={M} T={N} B={B}, "
-                               "q_mu/q_sqrt/lengthscales/kernel_variance trainable",
+                               "q_mu/q_sqrt/lengthscales/kernel_variance trainable"
+                               + (" + " + args.also_train if args.also_train else ""),
                    "parallelism": f"problems sharded x{world}, no collective",
                    "launch": (f"hipGraph x{args.unroll} steps" if args.unroll else "plain launches")
                              + ("; independent kernels of a step share launches (stage1 / stage2 / likelihood + path assembly / stage4 for"

@@ -62,7 +62,10 @@ struct vg_ind_scratch {
     float* dR;             // [P, S, L, Mz]       G A
     float* rff;            // [P, L, B / kIndBChunk, Mz, L]  feature part of d loss / d Zy, per basis chunk
     double* cov;           // [P, L, Mz]          covariance part of d loss / d Zy[:, l]
+    double* mt_part;       // [P, L, tiles, Mz, Mz]  A^T dA of a tile of time points (z_cov_rows_kernel)
+    double* gz_part;       // [P, L, tiles, Mz]      the tile's part of d loss / d Zy through Kfu
 };
+constexpr int kIndRowTile = 16;      // time points per workgroup of z_cov_rows_kernel
 size_t vg_layout_ind_scratch(const vgpmp_dims* d, void* base, vg_ind_scratch* out);
 struct vg_ind_launch {
     const vgpmp_dims* d;
