@@ -37,6 +37,15 @@ def main():
         nz = orc.Noise(r32(nz.omega), r32(nz.beta), r32(nz.w), r32(nz.eps), r32(nz.eps2))
         rep = lambda a: np.repeat(a[None], P, 0)
         pl.set_noise(rep(nz.omega), rep(nz.beta), rep(nz.w), rep(nz.eps), rep(nz.eps2))
+        # every third case: the batch form of the likelihood (one lane per configuration) and one launch per kernel forced on the
+        # small problem -- the forms large batches run
+        form = case % 3
+        if form == 1:
+            from vgpmp_amd import capi
+            pl.extra_flags = capi.LIK_LANES
+            pl.fuse = False
+        elif form == 2:
+            pl.fuse = False
         loss, grads = pl.loss_and_grad(generate=False)
         torch.cuda.synchronize()
         fw = orc.elbo_forward(p, pb["scene"], pb["X"], pb["Zy"], pb["y"], nz, pb["alpha"])
@@ -46,7 +55,7 @@ def main():
         ee = max(np.abs(grads[2][k].cpu().numpy() - og.raw_ell).max() / (np.abs(og.raw_ell).max() + 1e-12) for k in range(P))
         ev = max(np.abs(grads[3][k].cpu().numpy() - og.raw_var).max() / (np.abs(og.raw_var).max() + 1e-12) for k in range(P))
         worst = max(worst, el, eq)
-        print(f"case {case:2d} {robot:6s} P={P} S={S:2d} N={N:2d} M={M:2d} B={B:3d} sk={pl.dims.split_k}: loss {el:.1e}  dq_mu {eq:.1e}  dell {ee:.1e}  dvar {ev:.1e}"
+        print(f"case {case:2d} form {form} {robot:6s} P={P} S={S:2d} N={N:2d} M={M:2d} B={B:3d} sk={pl.dims.split_k}: loss {el:.1e}  dq_mu {eq:.1e}  dell {ee:.1e}  dvar {ev:.1e}"
               + ("   <-- CHECK" if max(el, eq) > 2e-2 else ""))
     print("worst relative deviation (loss, dq_mu):", f"{worst:.2e}")
 
