@@ -37,23 +37,31 @@ struct LikUpdArgs {
 // gradient of the training loss wrt (raw_alpha, raw_sigma) of one problem, Adam, and the constants of the next step.
 //   loss = -(ELBO + log sigmoid(raw_alpha) + sum_q log sigmoid(raw_sigma_q))      (vgpmp.h: vgpmp_lik_params)
 //   d ELBO / d alpha = (1/S) sum_{s,n} logp,   d ELBO / d sigma_q = (alpha/S) 1/2 sum_{s,n} c_q^2 / sigma_q^2
-// One wave per problem, lane q = sphere q; sums over the likelihood's workgroups in fixed order.
-__global__ __launch_bounds__(VGPMP_MAX_SPHERES) void lik_update_kernel(LikUpdArgs a) {
-    const int p = blockIdx.x, q = threadIdx.x, nsph = a.rb->num_spheres;
+// Four waves per problem, lane q = sphere q, wave w = every fourth workgroup of the likelihood: sums in a fixed order (per wave
+// ascending, 32 partials requested together; then ((w0 + w1) + (w2 + w3))).  One wave walking all 896 partials of config 2
+// eight at a time was 112 serial round trips: 36 us per launch.
+constexpr int kLikUpdWaves = 4;
+__global__ __launch_bounds__(kLikUpdWaves * VGPMP_MAX_SPHERES) void lik_update_kernel(LikUpdArgs a) {
+    static_assert(VGPMP_MAX_SPHERES == VG_WAVE, "lane = sphere");
+    __shared__ double part[2][kLikUpdWaves][VGPMP_MAX_SPHERES];
+    const int p = blockIdx.x, q = threadIdx.x & (VG_WAVE - 1), w = threadIdx.x >> 6, nsph = a.rb->num_spheres;
     double ls = 0.0;
-    for (int b = q; b < a.nblk; b += VGPMP_MAX_SPHERES) ls += (double)a.lik_partial[(size_t)p * a.nblk + b];
-    ls = vg_wave_sum(ls);                                        // sum_{s,n} logp
+    for (int b = threadIdx.x; b < a.nblk; b += kLikUpdWaves * VGPMP_MAX_SPHERES) ls += (double)a.lik_partial[(size_t)p * a.nblk + b];
+    ls = vg_wave_sum(ls);
     double c2 = 0.0;
     const float* sp = a.sig_partial + (size_t)p * a.nblk * VGPMP_MAX_SPHERES + q;
-    int b = 0;
-    for (; b + 7 < a.nblk; b += 8) {
-        float v[8];
+    for (int b0 = w; b0 < a.nblk; b0 += 32 * kLikUpdWaves) {
+        float v[32];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = sp[(size_t)(b + k) * VGPMP_MAX_SPHERES];
+        for (int k = 0; k < 32; ++k) v[k] = sp[(size_t)min(b0 + k * kLikUpdWaves, a.nblk - 1) * VGPMP_MAX_SPHERES];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) c2 += (double)v[k];
+        for (int k = 0; k < 32; ++k) if (b0 + k * kLikUpdWaves < a.nblk) c2 += (double)v[k];
     }
-    for (; b < a.nblk; ++b) c2 += (double)sp[(size_t)b * VGPMP_MAX_SPHERES];      // sum_{s,n} c_q^2 / sigma_q
+    part[0][w][q] = c2; part[1][w][q] = ls;
+    __syncthreads();
+    if (w != 0) return;
+    c2 = (part[0][0][q] + part[0][1][q]) + (part[0][2][q] + part[0][3][q]);      // sum_{s,n} c_q^2 / sigma_q
+    ls = (part[1][0][q] + part[1][1][q]) + (part[1][2][q] + part[1][3][q]);      // sum_{s,n} logp
     const size_t pq = (size_t)p * VGPMP_MAX_SPHERES + q;
     const double lr_t = a.ctr ? adam_step_size(a.lr, (double)*a.ctr) : a.lr_t;
     double ra = a.raw_alpha[p], rs = a.raw_sigma[pq];

@@ -1054,7 +1054,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         if (lk) {      // trainable likelihood constants: their gradient / update, and the constants of the next step
             lu.nblk = nblk;
             lu.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
-            hipLaunchKernelGGL(lik_update_kernel, dim3(P), dim3(VGPMP_MAX_SPHERES), 0, st, lu);
+            hipLaunchKernelGGL(lik_update_kernel, dim3(P), dim3(kLikUpdWaves * VGPMP_MAX_SPHERES), 0, st, lu);
         }
         mark();
         if (mid || batch_merged || (fused && !more)) {      // (fused, more steps to come: both ride in stage 1 of the next step)
