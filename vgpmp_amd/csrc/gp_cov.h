@@ -964,50 +964,50 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int wg_tile, int l, 
         return;
     }
     for (int tt = 0; tt < tpw; ++tt) {
-    const int n0 = n00 + tt * kRowTile;
-    if (n0 >= N) break;
-    const double* xt = xs + tt * kRowTile;
-    for (int e = tid; e < kRowTile * Mz; e += nt) {
-        int r = vg_div(e, iMz), m = e - r * Mz, n = n0 + r;
-        double k = 0.0, dk = 0.0;
-        if (n < N) {
-            double rr = fabs(xt[r] - zs[m]) / ell;
-            double ex = exp(-kSqrt5 * rr);
-            k = var * (1.0 + kSqrt5 * rr + (5.0 / 3.0) * rr * rr) * ex;
-            dk = var * ex * (5.0 * rr * rr / (3.0 * ell)) * (1.0 + kSqrt5 * rr);
+        const int n0 = n00 + tt * kRowTile;
+        if (n0 >= N) break;
+        const double* xt = xs + tt * kRowTile;
+        for (int e = tid; e < kRowTile * Mz; e += nt) {
+            int r = vg_div(e, iMz), m = e - r * Mz, n = n0 + r;
+            double k = 0.0, dk = 0.0;
+            if (n < N) {
+                double rr = fabs(xt[r] - zs[m]) / ell;
+                double ex = exp(-kSqrt5 * rr);
+                k = var * (1.0 + kSqrt5 * rr + (5.0 / 3.0) * rr * rr) * ex;
+                dk = var * ex * (5.0 * rr * rr / (3.0 * ell)) * (1.0 + kSqrt5 * rr);
+            }
+            kf[e] = k; df[e] = dk;
         }
-        kf[e] = k; df[e] = dk;
-    }
-    __syncthreads();
-    VG_T(tile == 0 && l == 0 && p == 0, 233);
-    for (int e = tid; e < kRowTile * Mz; e += nt) {
-        int r = vg_div(e, iMz), m = e - r * Mz;
-        ar[e] = dot4(kf + r * Mz, 1, Ki + m, ld, Mz);
-    }
-    __syncthreads();
-    VG_T(tile == 0 && l == 0 && p == 0, 234);
-    float av0 = 0.f, av1 = 0.f;      // (two scalars, not an array: a run-time index would put it in scratch memory)
-    int cnt = 0;
-    for (int e = tid; e < kRowTile * Mz; e += nt, ++cnt) {
-        int r = vg_div(e, iMz), m = e - r * Mz;
-        const double y = df[e] - dot4(ar + r * Mz, 1, Kd + m, ld, Mz);
-        const double v = dot4(ar + r * Mz, 1, Ki + m, ld, Mz);
-        yr[e] = y;
-        const float avv = (float)(a.jitter / var * v);
-        if (cnt == 0) av0 = avv; else if (cnt == 1) av1 = avv;
-    }
-    __syncthreads();
-    VG_T(tile == 0 && l == 0 && p == 0, 235);
-    cnt = 0;
-    for (int e = tid; e < kRowTile * Mz; e += nt, ++cnt) {
-        int r = vg_div(e, iMz), m = e - r * Mz, n = n0 + r;
-        if (n >= N) continue;
-        const double s = a.want_dell ? dot4(yr + r * Mz, 1, Ki + m, ld, Mz) : 0.0;
-        const float av = cnt == 0 ? av0 : av1;
-        vg_stream(A4 + (size_t)n * Mz + m, make_float4((float)ar[e], (float)s, av, 0.f));
-        vg_stream(AT + (size_t)m * N + n, (float)ar[e]);
-    }
-    if (tt + 1 < tpw) __syncthreads();      // the tile's LDS rows are the next one's
+        __syncthreads();
+        VG_T(tile == 0 && l == 0 && p == 0, 233);
+        for (int e = tid; e < kRowTile * Mz; e += nt) {
+            int r = vg_div(e, iMz), m = e - r * Mz;
+            ar[e] = dot4(kf + r * Mz, 1, Ki + m, ld, Mz);
+        }
+        __syncthreads();
+        VG_T(tile == 0 && l == 0 && p == 0, 234);
+        float av0 = 0.f, av1 = 0.f;      // (two scalars, not an array: a run-time index would put it in scratch memory)
+        int cnt = 0;
+        for (int e = tid; e < kRowTile * Mz; e += nt, ++cnt) {
+            int r = vg_div(e, iMz), m = e - r * Mz;
+            const double y = df[e] - dot4(ar + r * Mz, 1, Kd + m, ld, Mz);
+            const double v = dot4(ar + r * Mz, 1, Ki + m, ld, Mz);
+            yr[e] = y;
+            const float avv = (float)(a.jitter / var * v);
+            if (cnt == 0) av0 = avv; else if (cnt == 1) av1 = avv;
+        }
+        __syncthreads();
+        VG_T(tile == 0 && l == 0 && p == 0, 235);
+        cnt = 0;
+        for (int e = tid; e < kRowTile * Mz; e += nt, ++cnt) {
+            int r = vg_div(e, iMz), m = e - r * Mz, n = n0 + r;
+            if (n >= N) continue;
+            const double s = a.want_dell ? dot4(yr + r * Mz, 1, Ki + m, ld, Mz) : 0.0;
+            const float av = cnt == 0 ? av0 : av1;
+            vg_stream(A4 + (size_t)n * Mz + m, make_float4((float)ar[e], (float)s, av, 0.f));
+            vg_stream(AT + (size_t)m * N + n, (float)ar[e]);
+        }
+        if (tt + 1 < tpw) __syncthreads();      // the tile's LDS rows are the next one's
     }
     VG_T(tile == 0 && l == 0 && p == 0, 231);
 }
