@@ -367,6 +367,7 @@ __device__ __forceinline__ void final_body(const FinalArgs& b, double* sm, int l
                 // tril(Lk^T dC)[2:, 2:]
                 double s0 = 0.0, s1 = 0.0;
                 int i = r + 2;
+#pragma unroll 4
                 for (; i + 1 < Mz; i += 2) {
                     s0 = fma((double)Lks[i * Mz + (r + 2)], dC[i * Mz + (c + 2)], s0);
                     s1 = fma((double)Lks[(i + 1) * Mz + (r + 2)], dC[(i + 1) * Mz + (c + 2)], s1);
