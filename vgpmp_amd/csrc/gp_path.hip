@@ -25,9 +25,6 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 #ifndef VG_EPS_FIRST
 #define VG_EPS_FIRST 1
 #endif
-#ifndef VG_SMALL_STG
-#define VG_SMALL_STG 1      // 0: measurement builds with the few-sample prior kernel's operands requested pass by pass
-#endif
 #ifndef VG_JCHUNK_ONE
 #define VG_JCHUNK_ONE 8       // points per workgroup of the feature role at one problem
 #endif
@@ -776,19 +773,6 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                              0, fp)                                  \
                : (void)hipExtLaunchKernelGGL((prior_fused_small_kernel<MT_, DM_, false>), fgrid, dim3(kBlock), 0, st, g0, g1, \
                              0, fp))
-        // one sample tile and the latent's omega / beta / W within 64 KB: staged once, every pass out of LDS
-        const size_t stg_bytes = ((size_t)B * L + B + (size_t)S * B) * sizeof(float);
-        if (VG_SMALL_STG && S <= 16 && stg_bytes <= 64 * 1024) {
-#define VG_FUSED_STG(DM_, DELL_)                                                                                              \
-    do {                                                                                                                      \
-        if (vg_grant_dyn_lds((const void*)prior_fused_small_kernel<1, DM_, DELL_, true>, stg_bytes) == 0)                     \
-            hipExtLaunchKernelGGL((prior_fused_small_kernel<1, DM_, DELL_, true>), fgrid, dim3(kBlock), stg_bytes, st, g0, g1, 0, fp); \
-    } while (0)
-            if (L <= 8) { if (want_dell) VG_FUSED_STG(8, true); else VG_FUSED_STG(8, false); }
-            else { if (want_dell) VG_FUSED_STG(16, true); else VG_FUSED_STG(16, false); }
-#undef VG_FUSED_STG
-            return;
-        }
         if (L <= 8) { if (S <= 16) VG_FUSED_SMALL(1, 8); else VG_FUSED_SMALL(2, 8); }
         else { if (S <= 16) VG_FUSED_SMALL(1, 16); else VG_FUSED_SMALL(2, 16); }
 #undef VG_FUSED_SMALL

@@ -562,13 +562,9 @@ struct FusedPriorArgs {
 #define VG_KFNT_SMALL 2      // config 3 (55 problems, S = 7, J = 96): 234 / 198 / 194 / 210 us per step with 5 / 3 / 2 / 1 -- more, lighter waves
 #endif
 constexpr int kFNT = VG_KFNT_SMALL;      // column tiles per workgroup
-// STG (one sample tile, 64 KB of LDS suffice): the latent's frequencies, phases and the samples' weights are staged once by DMA
-// and every pass reads its operands from LDS; without it each pass requests them from memory one pass ahead -- a pass is
-// ~600 cycles, the round trip ~2000: the waves stood still two thirds of the time (config 3: 66 us per launch).
-template <int MT, int DM, bool DELL, bool STG = false>    // 16-row sample tiles; joint-space extent padded to DM (8 or 16); d/d ell wanted
+template <int MT, int DM, bool DELL>    // 16-row sample tiles; joint-space extent padded to DM (8 or 16); d/d ell wanted
 __global__ __launch_bounds__(kBlock) void prior_fused_small_kernel(FusedPriorArgs a) {
     __shared__ float pts[kFNT * 16][DM];
-    extern __shared__ __attribute__((aligned(16))) float stg[];      // STG: omega [B][D] | beta [B] | W [S][B]
     const int S = a.S, L = a.L, J = a.J, N = a.N, D = a.D, B = a.B;
     const int tid = threadIdx.x, lane = tid & 63, sk = tid >> 6;      // 4 waves = 4 K-slices
     const int pl = blockIdx.x, l = pl % L, p = pl / L, j0 = blockIdx.y * (kFNT * 16);
@@ -577,15 +573,6 @@ __global__ __launch_bounds__(kBlock) void prior_fused_small_kernel(FusedPriorArg
         const int jj = e / DM, d = e - jj * DM, j = min(j0 + jj, J - 1);
         const double* pt = j < N ? a.X + (size_t)j * D : a.Zy + (size_t)p * a.zy_stride + (size_t)(j - N) * D;
         pts[jj][d] = d < D ? (float)pt[d] : 0.f;
-    }
-    float* oms = stg;
-    float* bts = oms + (size_t)B * D;
-    float* Ws = bts + B;
-    if constexpr (STG) {
-        vg_stage_16(oms, a.omega + (size_t)pl * B * D, B * D / 4, tid, kBlock);
-        vg_stage_16(bts, a.beta + (size_t)pl * B, B / 4, tid, kBlock);
-        vg_stage_rows(Ws, S, B, tid, kBlock, [&](int s) -> const float* { return a.W + (((size_t)p * S + s) * L + l) * B; });
-        vg_dma_wait();
     }
     __syncthreads();
     const float ell = softplus_f((float)a.raw_ell[pl]);
@@ -611,21 +598,6 @@ __global__ __launch_bounds__(kBlock) void prior_fused_small_kernel(FusedPriorArg
     vg_f32x4 a4[MT], a4_n[MT];
     auto fetch = [&](int k0, float (&o)[4][DM], float (&bb)[4], vg_f32x4 (&aa)[MT]) {
         const int b0 = min(k0, B - 16) + 4 * g;          // (the look-ahead of the last pass re-reads it)
-        if constexpr (STG) {
-            const vg_f32x4 b4 = *reinterpret_cast<const vg_f32x4*>(bts + b0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                bb[q] = b4[q];
-#pragma unroll
-                for (int d = 0; d < DM; ++d) {
-                    const float v = oms[(b0 + q) * D + min(d, D - 1)];
-                    o[q][d] = d < D ? v : 0.f;
-                }
-            }
-            const vg_f32x4 v = *reinterpret_cast<const vg_f32x4*>(Ws + (size_t)min(r, S - 1) * B + b0);
-            aa[0] = wlive[0] ? v : (vg_f32x4){0.f, 0.f, 0.f, 0.f};
-            return;
-        }
         // every load unconditional on a clamped index, masked afterwards (a conditional load is a branch)
         const float* op = a.omega + ((size_t)pl * B + b0) * D;
         const float* bp = a.beta + (size_t)pl * B + b0;
