@@ -616,19 +616,9 @@ __global__ __launch_bounds__(kBlock) void prior_fused_small_kernel(FusedPriorArg
             aa[m] = wlive[m] ? v : (vg_f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
-    fetch(kbeg, om_n, bt_n, a4_n);
-    for (int k0 = kbeg; k0 < kbeg + kchunk; k0 += 16) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bt[q] = bt_n[q];
-#pragma unroll
-            for (int d = 0; d < DM; ++d) om[q][d] = om_n[q][d];
-        }
-#pragma unroll
-        for (int m = 0; m < MT; ++m) a4[m] = a4_n[m];
-        fetch(k0 + 16, om_n, bt_n, a4_n);
-        // one wave per SIMD issues in order: the features of column tile t + 1 are formed between the products of
-        // tile t (independent work next to each other in the instruction stream), not after them
+    // one pass: 16 bases x kFNT column tiles.  One wave per SIMD issues in order: the features of column tile t + 1 are formed
+    // between the products of tile t (independent work next to each other in the instruction stream), not after them
+    auto pass = [&](const float (&om)[4][DM], const float (&bt)[4], const vg_f32x4 (&a4)[MT]) {
         float ph[2][4], dh[2][4];
         auto feats = [&](int t, float (&pc)[4], float (&dc)[4]) {
 #pragma unroll
@@ -655,7 +645,18 @@ __global__ __launch_bounds__(kBlock) void prior_fused_small_kernel(FusedPriorArg
                     if (DELL) accH[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m][q], dh[cb][q], accH[m][t], 0, 0, 0);
                 }
         }
+    };
+    // two register sets in turn (no copies of the look-ahead set into the working set: 36 moves per pass on a kernel that is
+    // bound by the FP32 pipe its VALU work and its float32 MFMAs share)
+    fetch(kbeg, om, bt, a4);
+    int k0 = kbeg;
+    for (; k0 + 32 <= kbeg + kchunk; k0 += 32) {
+        fetch(k0 + 16, om_n, bt_n, a4_n);
+        pass(om, bt, a4);
+        fetch(k0 + 32, om, bt, a4);
+        pass(om_n, bt_n, a4_n);
     }
+    if (k0 < kbeg + kchunk) pass(om, bt, a4);      // (a slice of 16 bases: B = 64)
     // D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
     float* F0 = a.F0 + (size_t)sk * a.slab;
     float* H = a.H + (size_t)sk * a.slab;
