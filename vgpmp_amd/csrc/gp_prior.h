@@ -586,13 +586,8 @@ __global__ __launch_bounds__(kBlock) void prior_fused_small_kernel(FusedPriorArg
 #pragma unroll
         for (int t = 0; t < kFNT; ++t) { accF[m][t] = (vg_f32x4){0.f, 0.f, 0.f, 0.f}; accH[m][t] = accF[m][t]; }
     const float* wrow[MT];
-    bool wlive[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int s = 16 * m + r;
-        wrow[m] = a.W + (((size_t)p * S + min(s, S - 1)) * L + l) * B;
-        wlive[m] = s < S;
-    }
+    for (int m = 0; m < MT; ++m) wrow[m] = a.W + (((size_t)p * S + min(16 * m + r, S - 1)) * L + l) * B;
     // operands of a pass (4 bases per lane: 28 frequencies, 4 phases, the W fragments) are requested one pass ahead
     float om[4][DM], bt[4], om_n[4][DM], bt_n[4];
     vg_f32x4 a4[MT], a4_n[MT];
@@ -605,16 +600,12 @@ __global__ __launch_bounds__(kBlock) void prior_fused_small_kernel(FusedPriorArg
         for (int q = 0; q < 4; ++q) {
             bb[q] = bp[q];
 #pragma unroll
-            for (int d = 0; d < DM; ++d) {
-                const float v = op[q * D + min(d, D - 1)];
-                o[q][d] = d < D ? v : 0.f;
-            }
+            // (no masks: beyond D a clamped -- finite -- frequency meets the zero padding of the points, and the tile rows beyond
+            //  S, fed a clamped row of W, are never stored: 36 selects per pass on a kernel bound by the FP32 pipe)
+            for (int d = 0; d < DM; ++d) o[q][d] = op[q * D + min(d, D - 1)];
         }
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const vg_f32x4 v = *reinterpret_cast<const vg_f32x4*>(wrow[m] + b0);
-            aa[m] = wlive[m] ? v : (vg_f32x4){0.f, 0.f, 0.f, 0.f};
-        }
+        for (int m = 0; m < MT; ++m) aa[m] = *reinterpret_cast<const vg_f32x4*>(wrow[m] + b0);
     };
     // one pass: 16 bases x kFNT column tiles.  One wave per SIMD issues in order: the features of column tile t + 1 are formed
     // between the products of tile t (independent work next to each other in the instruction stream), not after them
