@@ -1,6 +1,7 @@
 // Random Fourier features and the prior GEMMs on the f32 MFMA pipe.
 // Private part of gp_path.hip (one translation unit: the stage launches call these bodies by role).
 #pragma once
+#include <type_traits>
 
 namespace {
 
@@ -596,13 +597,33 @@ __global__ __launch_bounds__(kBlock) void prior_fused_small_kernel(FusedPriorArg
         // every load unconditional on a clamped index, masked afterwards (a conditional load is a branch)
         const float* op = a.omega + ((size_t)pl * B + b0) * D;
         const float* bp = a.beta + (size_t)pl * B + b0;
+        // a lane's four bases are 4 D consecutive floats, i.e. D aligned 16-byte vectors (b0 is a multiple of 4): with D known at
+        // compile time (the 6- and 7-joint arms) D + 1 requests replace 4 D + 4, and their address arithmetic with them
+        auto vec = [&](auto dd) {
+            constexpr int DD = decltype(dd)::value;
+            const vg_f32x4* op4 = reinterpret_cast<const vg_f32x4*>(op);
+            vg_f32x4 f[DD];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bb[q] = bp[q];
+            for (int i = 0; i < DD; ++i) f[i] = op4[i];
+            const vg_f32x4 b4 = *reinterpret_cast<const vg_f32x4*>(bp);
 #pragma unroll
-            // (no masks: beyond D a clamped -- finite -- frequency meets the zero padding of the points, and the tile rows beyond
-            //  S, fed a clamped row of W, are never stored: 36 selects per pass on a kernel bound by the FP32 pipe)
-            for (int d = 0; d < DM; ++d) o[q][d] = op[q * D + min(d, D - 1)];
+            for (int q = 0; q < 4; ++q) {
+                bb[q] = b4[q];
+#pragma unroll
+                for (int d = 0; d < DM; ++d) o[q][d] = d < DD ? f[(q * DD + d) / 4][(q * DD + d) % 4] : 0.f;
+            }
+        };
+        if (D == 7 && DM >= 7) vec(std::integral_constant<int, 7>{});
+        else if (D == 6) vec(std::integral_constant<int, 6>{});
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bb[q] = bp[q];
+                // (no masks: beyond D a clamped -- finite -- frequency meets the zero padding of the points, and the tile rows
+                //  beyond S, fed a clamped row of W, are never stored: 36 selects per pass on a kernel bound by the FP32 pipe)
+#pragma unroll
+                for (int d = 0; d < DM; ++d) o[q][d] = op[q * D + min(d, D - 1)];
+            }
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m) aa[m] = *reinterpret_cast<const vg_f32x4*>(wrow[m] + b0);
