@@ -9,7 +9,10 @@ constexpr int kBlock = 256;
 #define VG_MID_MAX_PL 192
 #endif
 constexpr int kMidMaxPL = VG_MID_MAX_PL;       // cov_b beside the tiled GEMM (tiles first) up to this many pairs: 14 problems 273 -> 255 us, 20: 365 -> 334, 27: equal
-constexpr int kMid2MaxPL = 192;     // ... and only cov_a | noise and hyper | final up to this many (16 problems: 333 -> 323 us)
+#ifndef VG_MID2_MAX_PL
+#define VG_MID2_MAX_PL 192
+#endif
+constexpr int kMid2MaxPL = VG_MID2_MAX_PL;     // ... and only cov_a | noise and hyper | final up to this many (16 problems: 333 -> 323 us)
 #ifndef VG_FUSE_MAX_PL
 #define VG_FUSE_MAX_PL 32
 #endif

@@ -53,7 +53,9 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 #define VG_FB_MT2 1          // 0: measurement builds with 64-row tiles of the fused prior kernel at every batch size
 #endif
 #ifndef VG_COV_WITH_PRIOR
-#define VG_COV_WITH_PRIOR 1  // 0: measurement builds with cov_b and the fused prior kernel as two launches
+#define VG_COV_WITH_PRIOR 0  // 1: stage B of the covariance path inside the launch of the float32 fused prior kernel (28-34 problems).  It paid
+                             // against that kernel alone (477 -> 432 us per step at 28 problems); against the f16-split kernel + cov_b as
+                             // two launches it loses 30 % (387 vs 273 us)
 #endif
 #ifndef VG_FIN_SPLIT
 #define VG_FIN_SPLIT 1      // 0: measurement builds with the update role of stage 1 on one workgroup per latent
