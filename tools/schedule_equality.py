@@ -23,6 +23,8 @@ for P, steps in CASES:
     b.fuse = False
     # (one launch per kernel forms the prior draws by the f16-split kernel at SK = 1: the bitwise comparison needs its float32 form)
     b.extra_flags |= capi.PRIOR_F32
+    if P > 4:
+        a.extra_flags |= capi.PRIOR_F32      # (the large-batch schedule forms them by the f16-split kernel as well)
     worst = 0.0
     for blk in range(steps // 100):
         a.run_steps(100 if blk % 2 else 37)
