@@ -40,6 +40,9 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 #ifndef VG_FWD_REGS
 #define VG_FWD_REGS 1        // 0: measurement builds with the forward path assembly of large batches on paths_fwd_sc8
 #endif
+#ifndef VG_PB_PAIRS
+#define VG_PB_PAIRS 1
+#endif
 #ifndef VG_PB_MIN_WGS
 #define VG_PB_MIN_WGS 1536    // reverse path pass: chunks per workgroup double while this many workgroups remain (six per CU)
 #endif
@@ -589,8 +592,15 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     pa.tick = nullptr;
     // paths_bwd_sc8: sample chunks per workgroup -- as many as leave six workgroups per CU (the values do not depend on it)
     pa.cpw = 1;
-    if (!(what & VGPMP_BWD_ONE_CHUNK))
+    if (!(what & VGPMP_BWD_ONE_CHUNK)) {
         while (pa.cpw < NC && (size_t)P * L * ((NC + 2 * pa.cpw - 1) / (2 * pa.cpw)) >= VG_PB_MIN_WGS) pa.cpw *= 2;
+        // the register-resident path kernels (Mz = 32, one slab) work on PAIRS of chunks: two per workgroup as soon as that
+        // leaves a workgroup per CU, four from ~600 workgroups (6 problems of config 2's shape: 155 -> 147 us per step, 13: 187 ->
+        // 168, 24: 290 -> 245; the rule above alone left them on the one-chunk kernels below 28 problems)
+        const bool pairs = VG_PB_PAIRS && SK == 1 && Mz == 32 && (N & 3) == 0 && N <= 100 && NC >= 2 && P * L > kFuseMaxPL;
+        if (pairs && pa.cpw < 2 && (size_t)P * L * ((NC + 1) / 2) >= 256) pa.cpw = 2;
+        if (pairs && pa.cpw == 2 && NC >= 4 && (size_t)P * L * ((NC + 3) / 4) >= 600) pa.cpw = 4;
+    }
     const double lik_scale = pb->alpha / (double)d->S_total;
     FinalArgs fa;
     fa.M = M; fa.L = L; fa.NC = NC; fa.nblk = P ? vg_loglik_blocks_per_problem(S, N) : 0; fa.part_len = vg_part_len(d);
