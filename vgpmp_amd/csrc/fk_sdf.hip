@@ -23,6 +23,12 @@ int vg_trace_take_lik(unsigned long long* host, int cap) { return vg_trace_take(
 #ifndef VG_LIK_PFX_WAVES
 #define VG_LIK_PFX_WAVES 3
 #endif
+#ifndef VG_LIK_NOSUMS
+#define VG_LIK_NOSUMS 0      // measurement only (WRONG gradients): the register form without its per-frame sums -- what a form
+#endif                       // that needs no per-frame state would gain from a third wave per SIMD
+#ifndef VG_LIK_REGS_WAVES
+#define VG_LIK_REGS_WAVES 2
+#endif
 #ifndef VG_LIK_PREFIX_MAX_DOF
 #define VG_LIK_PREFIX_MAX_DOF 8      // batch likelihood: up to this many joints the prefix-scalar form (three waves per SIMD), beyond it
                                     // the per-frame sums in registers (two); 0: measurement builds without the former
@@ -372,7 +378,9 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
     vg_float3 Ft = vg_make3(0.f, 0.f, 0.f), Mt = vg_make3(0.f, 0.f, 0.f);
     float acc = 0.f;
     auto flush = [&]() {                                 // sums of frame pcur are complete
+#if !VG_LIK_NOSUMS
         fx[pcur] = F.x; fy[pcur] = F.y; fz[pcur] = F.z; mx[pcur] = Mo.x; my[pcur] = Mo.y; mz[pcur] = Mo.z;
+#endif
         Ft = vg_make3(Ft.x + F.x, Ft.y + F.y, Ft.z + F.z);
         Mt = vg_make3(Mt.x + Mo.x, Mt.y + Mo.y, Mt.z + Mo.z);
         F = vg_make3(0.f, 0.f, 0.f); Mo = vg_make3(0.f, 0.f, 0.f);
@@ -445,8 +453,10 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
     vg_float3 Fs = Ft, Ms = Mt;
 #pragma nounroll
     for (int i = 1; i <= D; ++i) {
+#if !VG_LIK_NOSUMS
         Fs = vg_make3(Fs.x - fx[i - 1], Fs.y - fy[i - 1], Fs.z - fz[i - 1]);
         Ms = vg_make3(Ms.x - mx[i - 1], Ms.y - my[i - 1], Ms.z - mz[i - 1]);
+#endif
         vg_float3 z = T.cz, org = T.t;
         dh_apply(rb, i - 1, sc.at(i - 1), sc.at(D + i - 1), T);
         if (craig) { z = T.cz; org = T.t; }
@@ -588,7 +598,10 @@ __device__ __forceinline__ float loglik_config_prefix(const vgpmp_robot* __restr
 
 constexpr int kLikBlock = 128;
 constexpr int kLikBatchBlock = 64;
-constexpr int kLikBatchU = 8;           // sphere gathers in flight per lane in the batch form
+#ifndef VG_LIK_U
+#define VG_LIK_U 8
+#endif
+constexpr int kLikBatchU = VG_LIK_U;    // sphere gathers in flight per lane in the batch form
 
 // ---- stand-alone log_prob: g [n, dof] row major ------------------------------------------------
 template <bool GRAD>
@@ -611,7 +624,7 @@ __global__ __launch_bounds__(kLikBlock) void log_prob_kernel(const vgpmp_robot* 
 // LPC lanes per (sample, time) configuration; BLK / LPC configurations per workgroup.  Large batches run one-wave
 // workgroups (kLikBatchBlock): 188 instead of 204 us per launch at 64 problems (finer tail).
 template <int LPC, int BLK, bool SIG = false, bool FAR = false, bool REGS = false, bool PFX = false>
-__global__ __launch_bounds__(BLK, REGS ? (PFX ? VG_LIK_PFX_WAVES : 2) : 1) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
+__global__ __launch_bounds__(BLK, REGS ? (PFX ? VG_LIK_PFX_WAVES : VG_LIK_REGS_WAVES) : 1) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
                                                                   const float* __restrict__ f, int S, int L, int N,
                                                                   float scale, float* __restrict__ G,
                                                                   float* __restrict__ logp,

@@ -284,17 +284,37 @@ class PlannerBatch:
         self.extra_flags = 0      # e.g. capi.NO_SPLIT (measurement)
         self._graph = None
         self._graph_unroll = 0
-        self._initial = [t.clone() for t in (self.q_mu, self.q_sqrt, self.raw_ell, self.raw_var)]
+        self._initial = [(t, t.clone()) for t in self._variables()]
         self._pack()
 
+    def _variables(self):
+        """Every unconstrained variable this planner may train (the optional ones only when they exist)."""
+        v = [self.q_mu, self.q_sqrt, self.raw_ell, self.raw_var]
+        if self.lik_variables:
+            v += [self.raw_alpha, self.raw_sigma]
+        if self.z_variables:
+            v += [self.raw_Z]
+        return v
+
+    def _moments(self):
+        m = self.adam_m + self.adam_v
+        if self.lik_variables:
+            m += self.lik_adam_m + self.lik_adam_v + self.lik_grad
+        if self.z_variables:
+            m += [self.z_adam_m, self.z_adam_v, self.z_grad]
+        return m
+
     def reset(self) -> None:
-        """Back to the freshly initialised model of every problem (variables, Adam moments, step count): what the reference
-        gets by building a new VGPMP per start-goal query (utils/miscellaneous.py:162-169).  Device copies only, no sync."""
-        for dst, src in zip((self.q_mu, self.q_sqrt, self.raw_ell, self.raw_var), self._initial):
+        """Back to the freshly initialised model of every problem (EVERY variable incl. sigma_obs / alpha / inducing locations
+        when they are variables, their Adam moments, step count): what the reference gets by building a new VGPMP per start-goal
+        query (utils/miscellaneous.py:162-169).  The effective likelihood constants and Zy are derived from the raw variables at
+        the start of every call (lik_consts_kernel, z_build_kernel), so nothing cached survives.  Device copies only, no sync."""
+        for dst, src in self._initial:
             dst.copy_(src)
-        for t in self.adam_m + self.adam_v:
+        for t in self._moments():
             t.zero_()
         self.t = 0
+        self.noise_ahead_step = None
 
     def _params_struct(self, tensors) -> capi.Params:
         return capi.Params(*(capi.ptr(t) for t in tensors))
