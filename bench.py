@@ -67,6 +67,8 @@ def parse_args(argv=None):
     ap.add_argument("--layout", choices=("brick", "linear"), default="brick", help="voxel table layout (include/vgpmp.h)")
     ap.add_argument("--summary", choices=("auto", "on", "off"), default="auto",
                     help="free-space brick summary in the batch likelihood kernel (auto: tables beyond the Infinity Cache)")
+    ap.add_argument("--mask", choices=("auto", "on", "off"), default="auto",
+                    help="free-space bit masks held in LDS by the batch likelihood kernel (auto: as --summary)")
     ap.add_argument("--lik-form", choices=("auto", "lanes", "lanes-lds"), default="auto",
                     help="likelihood kernel form (measurement): lanes = the batch form at any batch size, lanes-lds = with its per-frame sums in LDS")
     ap.add_argument("--flags", type=int, default=0, help="extra VGPMP_* measurement flags (include/vgpmp.h) OR-ed into every step")
@@ -116,7 +118,8 @@ def build_problem(rank: int, args, world: int = 1):
         rng = np.random.default_rng(rank)
         qs = rng.uniform(-2.0, 2.0, (args.problems, 2, 14))
         scene = engine.DeviceScene(spec, grid, (0.0, 0.0, 0.0), sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"],
-                                   layout=args.layout, free_space_summary=SUMMARY[args.summary])
+                                   layout=args.layout, free_space_summary=SUMMARY[args.summary],
+                                   free_space_mask=SUMMARY[args.mask])
         planner = engine.PlannerBatch(scene, qs, num_samples=args.samples, num_inducing=args.inducing,
                                       num_data=args.timesteps, num_bases=1024, lengthscales=[2.0] * 14, variance=0.2,
                                       alpha=pp["alpha"], learning_rate=pp["learning_rate"], seed=1234,
@@ -132,7 +135,8 @@ def build_problem(rank: int, args, world: int = 1):
         grid = scenes.scene_sdf("industrial", delta=0.0125, padding=20) if args.scene != "synthetic" else \
             scenes.synthetic_boxes_sdf(n=args.grid, delta=1.6 / args.grid, origin=(-0.8, -0.8, -0.2), seed=0)
         scene = engine.DeviceScene(spec, grid, ps.object_positions[0], sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"],
-                                   layout=args.layout, free_space_summary=SUMMARY[args.summary])
+                                   layout=args.layout, free_space_summary=SUMMARY[args.summary],
+                                   free_space_mask=SUMMARY[args.mask])
         s_loc, s_off = sharding.shard_samples(args.samples, world, rank)
         planner = engine.PlannerBatch(scene, np.array([ps.queries[0]]), num_samples=s_loc, samples_total=args.samples,
                                       sample_offset=s_off, kl_scale=1.0 if rank == 0 else 0.0,
@@ -155,7 +159,8 @@ def build_problem(rank: int, args, world: int = 1):
     else:
         grid = scenes.synthetic_boxes_sdf(n=args.grid, delta=1.6 / args.grid, origin=(-0.8, -0.8, -0.2), seed=0)
     scene = engine.DeviceScene(spec, grid, ps.object_positions[0], sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"],
-                               layout=args.layout, free_space_summary=SUMMARY[args.summary])
+                               layout=args.layout, free_space_summary=SUMMARY[args.summary],
+                                   free_space_mask=SUMMARY[args.mask])
     queries = ps.queries
     qs = np.array([queries[(rank * args.problems + i) % len(queries)] for i in range(args.problems)])
     planner = engine.PlannerBatch(scene, qs, num_samples=args.samples, num_inducing=args.inducing,
@@ -510,6 +515,7 @@ def main():
         # (torch.cuda.device_count() does not initialise it) and relay rank 0's line
         import torch
         from vgpmp_amd import launch
+        assert not torch.cuda.is_initialized(), "the rank launcher must run before this process touches the GPU"
         sys.exit(launch.spawn_ranks(args.gpus, sys.argv[1:], script=os.path.abspath(__file__),
                                     devices=torch.cuda.device_count()))
     import torch
@@ -523,10 +529,13 @@ def main():
         import torch.distributed as dist
         dev = local % torch.cuda.device_count()
         torch.cuda.set_device(dev)
+        # ranks started by vgpmp_amd/launch.py meet through a file store (no port to lose to a parallel job); under an external
+        # launcher (torch.distributed.run) the usual env:// rendezvous on MASTER_ADDR:MASTER_PORT
+        rdzv = dict(init_method=os.environ["VGPMP_INIT_METHOD"], rank=rank, world_size=world) if os.environ.get("VGPMP_INIT_METHOD") else {}
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev), **rdzv)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **rdzv)
     else:
         torch.cuda.set_device(0)
     default_workload = args.workload == "config2" and args.shard == "problems" and not args.problems

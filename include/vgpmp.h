@@ -98,7 +98,21 @@ typedef struct vgpmp_sdf {
     double origin[3];
     double delta;
     const void* brick_min;                 /* dev float[nbx*nby*nbz], or NULL */
+    /* Free-space masks (optional, BRICK4 only; built by vgpmp_sdf_free_mask from brick_min): mask k holds ONE BIT per block of
+     * (1 << mask_shift)^3 voxels, blocks in [bx][by][bz] order (nb? = ceil(n? / 2^mask_shift)), bit b of 32-bit word b >> 5:
+     * set iff every voxel of the block lies at least mask_clearance[k] from the obstacles.  A sphere of radius r whose voxel falls
+     * in a set block of a mask with mask_clearance[k] >= epsilon + r has hinge cost exactly 0 (likelihoods/likelihood.py:131-143),
+     * like the brick_min test -- but a mask is a few KB (32 KB at 512^3 with 8^3-voxel blocks) and is read out of LDS by the batch
+     * likelihood kernel: the test costs no memory request.  mask_count = 0: none.  Clearances ascend; mask k starts at word
+     * k * mask_words. */
+    const void* free_mask;                 /* dev uint32[mask_count * mask_words], or NULL */
+    int32_t mask_shift;                    /* log2 of the block edge in voxels, >= 2 */
+    int32_t mask_count;                    /* 0 .. VGPMP_MAX_MASKS */
+    int32_t mask_words;                    /* 32-bit words per mask, a multiple of 4 */
+    int32_t reserved;
+    float mask_clearance[4];
 } vgpmp_sdf;
+#define VGPMP_MAX_MASKS 4
 
 /* Problem-batch dimensions. */
 typedef struct vgpmp_dims {
@@ -232,6 +246,14 @@ int vgpmp_robot_upload(const vgpmp_robot* host_robot, void* dev_robot, vgpmp_str
 /* Bytes of the voxel table and of the brick summary for a grid of nx*ny*nz voxels in `layout`. */
 int vgpmp_sdf_table_bytes(int32_t nx, int32_t ny, int32_t nz, int32_t layout, size_t* table_bytes,
                           size_t* brick_min_bytes);
+
+/* 32-bit words (rounded up to a multiple of 4) of ONE free-space mask of an nx x ny x nz grid with blocks of (1 << shift)^3 voxels. */
+int vgpmp_sdf_mask_words(int32_t nx, int32_t ny, int32_t nz, int32_t shift, size_t* words);
+
+/* Fills sdf->free_mask (mask_count masks of mask_words words, block edge 1 << mask_shift, clearances mask_clearance[]) from
+ * sdf->brick_min, which must be complete (every slab packed).  Replaces nothing in the reference: a device-side acceleration
+ * structure of the nearest-voxel lookup (utils/sdf_utils.py:62-76) whose use leaves every result bit-identical. */
+int vgpmp_sdf_free_mask(const vgpmp_sdf* sdf, vgpmp_stream stream);
 
 /* Builds the per-voxel {d, gx, gy, gz} records of the voxels x0 <= x < x1 of `sdf` (whose table / brick_min
  * pointers name the destination) from float64 rows of the grid data[x, y, z]: clamped central differences with

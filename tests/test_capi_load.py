@@ -26,7 +26,7 @@ def test_library_builds_loads_and_exports_header_symbols():
 def test_struct_sizes_match_header_layout():
     # sizes implied by include/vgpmp.h (natural alignment, 8-byte tail for the doubles)
     assert ctypes.sizeof(capi.Robot) == 4 * 4 + 7 * 16 * 4 + 12 * 4 + 64 * 4 + 64 * 12 + 64 * 4 + 64 * 4 + 8 + 24 + 64 * 4 + 16 * 32 + 64 * 16 + 64 * 8 + 80
-    assert ctypes.sizeof(capi.Sdf) == 8 + 16 + 24 + 8 + 8
+    assert ctypes.sizeof(capi.Sdf) == 8 + 16 + 24 + 8 + 8 + 8 + 16 + 16          # + free_mask, shift / count / words / reserved, clearances
     assert ctypes.sizeof(capi.Dims) == 40
     assert ctypes.sizeof(capi.Params) == 32 and ctypes.sizeof(capi.Noise) == 40
     assert ctypes.sizeof(capi.Problem) == 72 and ctypes.sizeof(capi.Outputs) == 64 and ctypes.sizeof(capi.LikParams) == 72
@@ -53,6 +53,12 @@ def test_argument_errors_without_gpu():
     assert (tb.value, bb.value) == (2 << 30, 8 << 20)
     assert handle.vgpmp_sdf_table_bytes(4, 4, 4, 7, ctypes.byref(tb), ctypes.byref(bb)) == -1
     assert handle.vgpmp_sdf_table_bytes(0, 4, 4, 0, ctypes.byref(tb), ctypes.byref(bb)) == -2
+    # free-space masks: one bit per block of 2^shift voxels per edge, words rounded up to 16 bytes
+    w = ctypes.c_size_t(0)
+    assert handle.vgpmp_sdf_mask_words(512, 512, 512, 3, ctypes.byref(w)) == 0 and w.value * 4 == 32 << 10
+    assert handle.vgpmp_sdf_mask_words(130, 154, 80, 2, ctypes.byref(w)) == 0 and w.value == ((33 * 39 * 20 + 31) // 32 + 3) // 4 * 4
+    assert handle.vgpmp_sdf_mask_words(8, 8, 8, 1, ctypes.byref(w)) == -2
+    assert handle.vgpmp_sdf_free_mask(None, None) == -1
 
 
 def test_product_path_fails_loudly_without_library(monkeypatch, tmp_path):

@@ -139,10 +139,19 @@ def test_layouts_and_summary_are_bitwise_equivalent(S, N, P):
     M, B = 6, 64
     pb = synthetic_problem(dof=14, S=S, N=N, M=M, B=B, seed=17, n_grid=40, n_problems=P)
     outs = []
-    for layout, summary in (("linear", False), ("brick", False), ("brick", True)):
-        sc = _engine().DeviceScene(pb["spec"], pb["grid"], pb["offset"], layout=layout, free_space_summary=summary)
-        assert sc.free_space_summary == summary
+    # ... and the free-space masks in LDS (batch form, 9-15 joints): alone, with the summary behind them, with coarser blocks
+    # (a budget that forces 8^3-voxel blocks on this 40^3 grid)
+    for layout, summary, mask, budget in (("linear", False, False, 0), ("brick", False, False, 0), ("brick", True, False, 0),
+                                          ("brick", False, True, 32 << 10), ("brick", True, True, 32 << 10),
+                                          ("brick", False, True, 64), ("brick", True, True, 64)):
+        sc = _engine().DeviceScene(pb["spec"], pb["grid"], pb["offset"], layout=layout, free_space_summary=summary,
+                                   free_space_mask=mask, mask_budget_bytes=budget)
+        assert sc.free_space_summary == summary and sc.free_space_mask == mask
+        if mask:
+            assert sc.mask_shift == {32 << 10: 2, 64: 3}[budget]
         pl, _ = _batch(pb, sc, S, N, M, B)
+        if P > 1:
+            pl.extra_flags |= _engine().capi.LIK_LANES      # (the batch form whatever the batch size: the one that reads the masks)
         loss, grads = pl.loss_and_grad(generate=False)
         torch.cuda.synchronize()
         outs.append([pl.f.clone(), pl.logp.clone(), pl.lik.clone(), pl.view("G")] + [g.clone() for g in grads])
@@ -150,6 +159,56 @@ def test_layouts_and_summary_are_bitwise_equivalent(S, N, P):
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert torch.equal(a, b)
+
+
+def test_free_space_masks_are_the_block_minima_against_the_clearances():
+    """vgpmp_sdf_free_mask: bit b of mask k is set iff every voxel of block b lies at least clearance k from the obstacles
+    (ragged extents; several radius classes), and the classes are epsilon + radius one float32 ulp up."""
+    rng = np.random.default_rng(11)
+    shape = (37, 22, 45)
+    data = rng.normal(0.15, 0.12, shape)
+    spec = rb.synthetic_arm(14)
+    spec.sphere_radii = np.asarray([0.03, 0.05, 0.08] * 15, dtype=np.float64)
+    for budget, shift in ((32 << 10, 2), (200, 3)):
+        sc = _engine().DeviceScene(spec, (data, np.zeros(3), 0.05), (0, 0, 0), free_space_mask=True, mask_budget_bytes=budget)
+        assert sc.mask_shift == shift and len(sc.mask_clearances) == 3
+        e = 1 << shift
+        nb = [(n + e - 1) // e for n in shape]
+        pad = np.full([e * b for b in nb], np.inf)
+        pad[:shape[0], :shape[1], :shape[2]] = data.astype(np.float32)
+        bmin = pad.reshape(nb[0], e, nb[1], e, nb[2], e).min(axis=(1, 3, 5)).reshape(-1)
+        words = sc.sdf.mask_words
+        got = sc.free_mask.cpu().numpy().view(np.uint32).reshape(3, words)
+        for k, (r, clr) in enumerate(zip((0.03, 0.05, 0.08), sc.mask_clearances)):
+            assert np.float32(clr) == np.nextafter(np.float32(np.float32(0.05) + np.float32(r)), np.float32(np.inf))
+            want = np.zeros(words * 32, dtype=bool)
+            want[:bmin.size] = bmin >= np.float32(clr)
+            bits = ((got[k][:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).astype(bool).reshape(-1)
+            assert np.array_equal(bits, want), (shift, k)
+            assert 0 < want.sum() < bmin.size
+
+
+def test_masks_with_several_radius_classes_are_bitwise_neutral():
+    """Spheres of three radii: every sphere uses the mask of the smallest clearance that covers it; outputs equal the
+    mask-free form bit for bit (batch form, 14 joints)."""
+    S, N, M, B, P = 64, 40, 6, 64, 3
+    pb = synthetic_problem(dof=14, S=S, N=N, M=M, B=B, seed=19, n_grid=40, n_problems=P)
+    pb["spec"].sphere_radii = np.asarray([0.03, 0.05, 0.08] * 15, dtype=np.float64)
+    outs, free = [], []
+    for mask in (False, True):
+        sc = _engine().DeviceScene(pb["spec"], pb["grid"], pb["offset"], free_space_summary=False, free_space_mask=mask)
+        pl, _ = _batch(pb, sc, S, N, M, B)
+        pl.extra_flags |= _engine().capi.LIK_LANES
+        loss, grads = pl.loss_and_grad(generate=False)
+        torch.cuda.synchronize()
+        outs.append([pl.f.clone(), pl.logp.clone(), pl.lik.clone(), pl.view("G")] + [g.clone() for g in grads])
+        if mask:
+            bits = sc.free_mask.cpu().numpy().view(np.uint32)
+            free.append(float(np.unpackbits(bits.view(np.uint8)).mean()))
+    assert 0.02 < free[0] < 0.98, free
+    assert float((outs[0][1] < 0).float().mean()) > 0.05, "hinge must be active"
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
 
 
 def test_config5_full_size_properties():
@@ -167,6 +226,7 @@ def test_config5_full_size_properties():
               learning_rate=0.02, seed=1)
     sc = eng.DeviceScene(spec, grid, (0, 0, 0))
     assert sc.layout == 1 and sc.free_space_summary and sc.table.numel() * 4 == 2 << 30
+    assert sc.free_space_mask and sc.mask_shift == 3 and sc.free_mask.numel() * 4 == 32 << 10      # 64^3 bits of 8^3-voxel blocks
     # table records against the analytic distance at random voxels (values are float32 of the float64 scene)
     pos = rows.origin + rows.delta * rng.integers(0, n, (2000, 3))
     idx, dist, _ = sc.sdf_query(torch.tensor(pos + 0.25 * rows.delta))
@@ -188,8 +248,8 @@ def test_config5_full_size_properties():
     # the other table forms give the same bits from the same state and noise key
     ref = [a.f.clone(), a.logp.clone(), a.lik.clone()]
     del b
-    for layout, summary in (("brick", False), ("linear", False)):
-        sc2 = eng.DeviceScene(spec, grid, (0, 0, 0), layout=layout, free_space_summary=summary)
+    for layout, summary, mask in (("brick", False, False), ("brick", True, False), ("brick", False, True), ("linear", False, False)):
+        sc2 = eng.DeviceScene(spec, grid, (0, 0, 0), layout=layout, free_space_summary=summary, free_space_mask=mask)
         c = eng.PlannerBatch(sc2, qs, **kw)
         for name in ("q_mu", "q_sqrt", "raw_ell", "raw_var"):
             getattr(c, name).copy_(getattr(a, name))

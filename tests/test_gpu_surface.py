@@ -399,6 +399,63 @@ def test_pipelined_steps_with_trainable_likelihood_constants():
     assert float(moved.min()) > 0.05
 
 
+@pytest.mark.parametrize("extra", [dict(sigma_obs=True, alpha=True), dict(inducing_variable=True), dict()])
+def test_reset_is_a_freshly_built_planner(extra):
+    """PlannerBatch.reset() (bench.py calls it before every timed block) must leave what a NEW planner holds: every variable
+    the planner trains -- likelihood constants and inducing locations included --, their Adam moments and the step count.
+    k steps after reset() == k steps of a new planner, bit for bit (raw_alpha / raw_sigma / raw_Z were kept)."""
+    from vgpmp_amd import engine
+    ps = rb.load_problemset("franka", "industrial")
+    spec = rb.load_robot("franka")
+    grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
+    sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
+    qs = np.array([ps.queries[i] for i in range(2)])
+    tr = dict(engine.DEFAULT_TRAINABLE, **extra)
+    kw = dict(num_samples=16, num_inducing=10, num_data=24, num_bases=64, lengthscales=[2.0] * 7, variance=0.2, seed=3,
+              alpha=4.0, trainable=tr)
+    a, b = engine.PlannerBatch(sc, qs, **kw), engine.PlannerBatch(sc, qs, **kw)
+    a.run_steps(7)                      # trains everything, moments non-zero
+    torch.cuda.synchronize()
+    assert not torch.equal(a.q_mu, b.q_mu)
+    a.reset()
+    assert a.t == 0
+    for x, y in zip(a._variables() + a._moments(), b._variables() + b._moments()):
+        assert torch.equal(x, y)
+    a.run_steps(5)
+    b.run_steps(5)
+    torch.cuda.synchronize()
+    for x, y in zip(a._variables() + a._moments(), b._variables() + b._moments()):
+        assert torch.equal(x, y), float((x - y).abs().max())
+    assert torch.equal(a.f, b.f) and torch.equal(a.lik, b.lik) and torch.equal(a.kl, b.kl)
+
+
+def test_noise_drawn_ahead_is_never_paired_with_another_step():
+    """The sample-sharded step lets step t draw the prior noise of step t + 1 (VGPMP_NOISE_AHEAD / _READY).  Which step's
+    draws the buffers hold is tracked by the planner: a direct call in between that redraws them (elbo at another step)
+    must make the next sharded step draw its own -- the trajectory equals the uninterrupted one."""
+    from vgpmp_amd import engine, sharding
+    ps = rb.load_problemset("ur10", "industrial")
+    spec = rb.load_robot("ur10", *ps.robot_pos_and_orn)
+    grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
+    sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
+    kw = dict(num_samples=32, num_inducing=12, num_data=40, num_bases=128, lengthscales=[2.0] * 6, variance=0.2, seed=9)
+    runs = []
+    for interrupt in (False, True):
+        pl = engine.PlannerBatch(sc, np.array([ps.queries[0]]), **kw)
+        sp = sharding.SampleShardedPlanner(pl)
+        sp._allreduce = lambda buf=None: None
+        for k in range(6):
+            if interrupt and k == 3:
+                pl.elbo(generate=True, step=40)        # leaves step 40's omega / beta / w in the shared buffers
+                assert pl.noise_ahead_step is None
+            sp.step()
+            assert pl.noise_ahead_step == pl.t
+        torch.cuda.synchronize()
+        runs.append([t.clone() for t in (pl.q_mu, pl.q_sqrt, pl.raw_ell, pl.raw_var)])
+    for x, y in zip(*runs):
+        assert torch.equal(x, y)
+
+
 def test_elimination_forms_agree():
     """The factorisation of Kuu + jI runs on one wave with the augmented matrix in registers (Mz <= 32); the
     workgroup-wide form through LDS applies the same multipliers with the operands associated differently."""

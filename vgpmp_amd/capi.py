@@ -24,7 +24,7 @@ NOISE_AHEAD, NOISE_READY = 32768, 65536
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvgpmp_hip.so"
 
-EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_table_bytes", "vgpmp_sdf_pack", "vgpmp_mesh_sdf", "vgpmp_fk_spheres", "vgpmp_sdf_query", "vgpmp_sdf_index_float",
+EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_table_bytes", "vgpmp_sdf_pack", "vgpmp_sdf_mask_words", "vgpmp_sdf_free_mask", "vgpmp_mesh_sdf", "vgpmp_fk_spheres", "vgpmp_sdf_query", "vgpmp_sdf_index_float",
            "vgpmp_log_prob", "vgpmp_cov_matrices", "vgpmp_kernel_derivative", "vgpmp_velocity_kuu_kuf", "vgpmp_workspace_bytes", "vgpmp_lik_scratch_bytes", "vgpmp_inducing_scratch_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
            "vgpmp_elbo_steps", "vgpmp_elbo_step_profiled", "vgpmp_adam_step", "vgpmp_workspace_view", "vgpmp_sample_paths",
            "vgpmp_comm_unique_id", "vgpmp_comm_init", "vgpmp_allreduce_grads", "vgpmp_comm_destroy")
@@ -58,7 +58,11 @@ SDF_LINEAR, SDF_BRICK4 = 0, 1
 class Sdf(C.Structure):
     _fields_ = [("table", C.c_void_p), ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
                 ("layout", C.c_int32), ("origin", C.c_double * 3), ("delta", C.c_double),
-                ("brick_min", C.c_void_p)]
+                ("brick_min", C.c_void_p), ("free_mask", C.c_void_p), ("mask_shift", C.c_int32), ("mask_count", C.c_int32),
+                ("mask_words", C.c_int32), ("reserved", C.c_int32), ("mask_clearance", C.c_float * 4)]
+
+
+MAX_MASKS = 4
 
 
 class Dims(C.Structure):
@@ -129,6 +133,8 @@ def load(require: bool = True) -> Optional[C.CDLL]:
         "vgpmp_robot_upload": [P(Robot), vp, vp],
         "vgpmp_sdf_table_bytes": [i32, i32, i32, i32, P(C.c_size_t), P(C.c_size_t)],
         "vgpmp_sdf_pack": [P(Sdf), vp, i32, i32, i32, i32, vp],
+        "vgpmp_sdf_mask_words": [i32, i32, i32, i32, P(C.c_size_t)],
+        "vgpmp_sdf_free_mask": [P(Sdf), vp],
         "vgpmp_mesh_sdf": [vp, vp, i32, i32, i32, i32, P(C.c_double), dbl, vp, vp],
         "vgpmp_fk_spheres": [vp, vp, i64, vp, vp, vp],
         "vgpmp_sdf_query": [P(Sdf), vp, i64, vp, vp, vp, vp],

@@ -77,6 +77,28 @@ int vgpmp_sdf_pack(const vgpmp_sdf* sdf, const double* dev_rows, int32_t row_lo,
     return vg_launch_sdf_pack(sdf, dev_rows, row_lo, row_hi, x0, x1, (hipStream_t)stream);
 }
 
+int vgpmp_sdf_mask_words(int32_t nx, int32_t ny, int32_t nz, int32_t shift, size_t* words) {
+    if (!words) return VGPMP_E_ARG;
+    if (nx < 1 || ny < 1 || nz < 1 || shift < 2 || shift > 12) return VGPMP_E_SHAPE;
+    const size_t e = (size_t)1 << shift;
+    const size_t bits = ((nx + e - 1) >> shift) * ((ny + e - 1) >> shift) * ((nz + e - 1) >> shift);
+    *words = (((bits + 31) / 32) + 3) & ~(size_t)3;
+    return 0;
+}
+
+int vgpmp_sdf_free_mask(const vgpmp_sdf* sdf, vgpmp_stream stream) {
+    int rc = check_sdf(sdf);
+    if (rc) return rc;
+    if (sdf->layout != VGPMP_SDF_BRICK4 || !sdf->brick_min || !sdf->free_mask) return VGPMP_E_ARG;
+    if (sdf->mask_count < 1 || sdf->mask_count > VGPMP_MAX_MASKS) return VGPMP_E_SHAPE;
+    size_t words = 0;
+    if ((rc = vgpmp_sdf_mask_words(sdf->nx, sdf->ny, sdf->nz, sdf->mask_shift, &words))) return rc;
+    if ((size_t)sdf->mask_words != words) return VGPMP_E_ARG;
+    for (int k = 1; k < sdf->mask_count; ++k)
+        if (!(sdf->mask_clearance[k] >= sdf->mask_clearance[k - 1])) return VGPMP_E_ARG;
+    return vg_launch_sdf_free_mask(sdf, (hipStream_t)stream);
+}
+
 int vgpmp_mesh_sdf(const double* dev_triangles, const int32_t* dev_part, int32_t num_triangles, int32_t nx, int32_t ny,
                    int32_t nz, const double* origin, double delta, double* dev_grid, vgpmp_stream stream) {
     if (!dev_triangles || !dev_part || !origin || !dev_grid) return VGPMP_E_ARG;

@@ -348,11 +348,13 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
 // frame number -- indirect register addressing -- and only sin / cos / d g / d f of the joints in LDS: 3 D instead of
 // 9 D + 6 words per lane (132 at 14 joints, which held the one-lane form at one wave per SIMD).  Up to 15 joints.
 typedef float vg_f32x16 __attribute__((ext_vector_type(16)));
-template <int U, bool SIG, bool FAR, typename LoadRaw, typename ToAngle, typename Emit, typename EmitSig = NoSig>
+// FAR: 0 every sphere reads the table; 1 the brick summary first (a second dependent global load); 2 the free-space MASK of the
+// sphere's radius class out of LDS (`lmask`: the masks as staged by the workgroup), then the table; 3 mask, then summary, then table.
+template <int U, bool SIG, int FAR, typename LoadRaw, typename ToAngle, typename Emit, typename EmitSig = NoSig>
 __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restrict__ rb, const vg_sdf_dev& sdf,
                                                     const LikScratch sc, LoadRaw load_raw, ToAngle to_angle, Emit emit,
                                                     const float* __restrict__ sig = nullptr, float sig_w = 0.f,
-                                                    EmitSig emit_sig = NoSig()) {
+                                                    EmitSig emit_sig = NoSig(), const uint32_t* lmask = nullptr) {
     static_assert(VGPMP_MAX_SPHERES % U == 0, "a batch of sphere constants never leaves the table");
     const int D = rb->dof, P = rb->num_spheres;          // D <= 15: frames 0 .. 15
     float raw[VGPMP_MAX_DOF];
@@ -391,6 +393,7 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
         float4 v[U];
         vg_float3 pos[U];
         uint32_t at[U];
+        uint32_t mb[(FAR & 2) ? U : 1], bk[FAR == 3 ? U : 1];
         float4 ca[U];
         float2 cb[U];
 #pragma unroll
@@ -410,15 +413,44 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
                 pos[u] = axpy(ca[u].x, T.cx, axpy(ca[u].y, T.cy, axpy(ca[u].z, T.cz, T.t)));
                 const Vox3 ix = voxel3(pos[u], fs, sdf, offx, offy, offz);
                 at[u] = (uint32_t)vg_table_offset(sdf, ix.ix, ix.iy, ix.iz);
-                if (FAR) v[u].x = sdf.brick_min[vg_brick_of(sdf, ix.ix, ix.iy, ix.iz)];
+                if (FAR & 2) {
+                    // the mask of the smallest clearance that covers this sphere (uniform): clearance >= eps + r in the hinge's
+                    // own float32 form, so a set bit means cost exactly 0 on every voxel of the block (monotone rounding)
+                    int mo = -1;
+#pragma unroll
+                    for (int k = VGPMP_MAX_MASKS - 1; k >= 0; --k)
+                        if (k < sdf.mcount && !(eps - (sdf.mclr[k] - cb[u].x) > 0.f)) mo = k * sdf.mwords;
+                    const uint32_t bit = (uint32_t)(((ix.ix >> sdf.mshift) * sdf.mby + (ix.iy >> sdf.mshift)) * sdf.mbz + (ix.iz >> sdf.mshift));
+                    mb[u] = mo < 0 ? 0u : lmask[mo + (bit >> 5)] >> (bit & 31u);       // bit 0: free
+                    if (FAR == 3) bk[u] = (uint32_t)vg_brick_of(sdf, ix.ix, ix.iy, ix.iz);
+                } else if (FAR == 1) v[u].x = sdf.brick_min[vg_brick_of(sdf, ix.ix, ix.iy, ix.iz)];
                 else v[u] = sdf.table[at[u]];
             } else {
                 v[u] = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);       // hinge exactly 0
                 pos[u] = vg_make3(0.f, 0.f, 0.f);
                 at[u] = 0u;
+                if (FAR & 2) { mb[u] = 1u; if (FAR == 3) bk[u] = 0u; }
             }
         }
-        if (FAR) {
+        if (FAR == 2) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (q0 + u < P) {
+                    v[u] = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);
+                    if (!(mb[u] & 1u)) v[u] = sdf.table[at[u]];
+                }
+            }
+        }
+        if (FAR == 3) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (q0 + u < P) {
+                    v[u].x = __builtin_inff();
+                    if (!(mb[u] & 1u)) v[u].x = sdf.brick_min[bk[u]];
+                }
+            }
+        }
+        if (FAR & 1) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (q0 + u < P) {
@@ -697,6 +729,76 @@ __global__ __launch_bounds__(BLK, REGS ? (PFX ? VG_LIK_PFX_WAVES : VG_LIK_REGS_W
     }
     VG_T(blockIdx.x == 0 && pb == 0, 401);
     VG_T(blockIdx.x == gridDim.x - 1 && pb == 0, 405);
+}
+
+// ---- ELBO path, batch form with the free-space masks in LDS -------------------------------------------------
+// Four waves per workgroup share ONE copy of the scene's free-space masks (include/vgpmp.h: a bit per block of voxels, a few KB
+// to 32 KB) staged into LDS by DMA while the waves load their joint values; each wave then runs the register form on its own 64
+// configurations exactly as a one-wave workgroup of loglik_paths_kernel would (same partial sums, one per wave), except that a
+// sphere whose block is marked free costs an LDS read instead of a request to the memory system.  The 8 MiB brick summary of a
+// 512^3 grid does not fit an XCD's L2 next to the table's lines: every query paid a scattered 4-byte load for it (36.9 M per launch
+// at the config-5 share) before its 16-byte gather.  Results are bit-identical (skipped spheres cost exactly 0).
+constexpr int kLikMaskBlock = 256;
+template <int FARM>
+__global__ __launch_bounds__(kLikMaskBlock, 2) void loglik_paths_mask_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
+                                                                            const float* __restrict__ f, int S, int L, int N,
+                                                                            float scale, float* __restrict__ G,
+                                                                            float* __restrict__ logp,
+                                                                            float* __restrict__ lik_partial, int nwaves) {
+    extern __shared__ float lik_lds[];
+    const vg_sdf_dev sdf = load_sdf(sdfh);
+    const int mask_words = sdf.mcount * sdf.mwords;                 // a multiple of 4
+    uint32_t* lmask = reinterpret_cast<uint32_t*>(lik_lds);
+    float* scratch = lik_lds + mask_words;
+    vg_stage_16(lmask, sdf.free_mask, mask_words >> 2, threadIdx.x, kLikMaskBlock);
+    const int pb = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (VG_WAVE - 1);
+    const int wv = blockIdx.x * (kLikMaskBlock / VG_WAVE) + wave;        // this wave's 64 configurations
+    const int idx = wv * VG_WAVE + lane;
+    const bool live = idx < S * N;
+    const int ci = live ? idx : S * N - 1;           // dead lanes recompute the last configuration, write nothing
+    const int s = ci / N, n = ci - s * N;
+    const size_t base = ((size_t)pb * S + s) * L * N + n;
+    const LikScratch sc{scratch + threadIdx.x, kLikMaskBlock};
+    vg_dma_wait();
+    __syncthreads();
+    const float lp = loglik_config_regs<kLikBatchU, false, FARM>(
+        rb, sdf, sc, [&](int j) { return f[base + (size_t)j * N]; },
+        [&](int j, float x, float& d) {
+            const float sg = 1.0f / (1.0f + __expf(-x));                        // likelihood.py:49-52
+            const float span = rb->joint_tab[j][7];
+            d = span * sg * (1.0f - sg);
+            return fmaf(span, sg, rb->joint_tab[j][5]);
+        },
+        [&](int j, float v) { if (live) G[base + (size_t)j * N] = scale * v; }, nullptr, 0.f, NoSig(), lmask);
+    if (live) logp[((size_t)pb * S + s) * N + n] = lp;
+    const float w = vg_wave_sum(live ? lp : 0.f);
+    if (lane == 0 && wv < nwaves) lik_partial[(size_t)pb * nwaves + wv] = w;
+}
+
+// free-space masks from the brick summary: thread = block of 2^shift voxels per edge, bit = every brick of the block clears
+__global__ __launch_bounds__(kBlock) void sdf_free_mask_kernel(vgpmp_sdf sdfh) {
+    const vg_sdf_dev s = vg_load_sdf(sdfh);
+    const int sh = s.mshift, e = 1 << (sh - 2);                         // bricks per block edge
+    const int nbx = (s.nx + 3) >> 2;
+    const int mbx = (s.nx + (1 << sh) - 1) >> sh;
+    const size_t nbits = (size_t)mbx * s.mby * s.mbz;
+    const size_t b = (size_t)blockIdx.x * kBlock + threadIdx.x;         // bit index; the grid covers mwords * 32 bits
+    float m = __builtin_inff();
+    if (b < nbits) {
+        const int bz = (int)(b % s.mbz), by = (int)((b / s.mbz) % s.mby), bx = (int)(b / ((size_t)s.mbz * s.mby));
+        for (int x = bx * e; x < min((bx + 1) * e, nbx); ++x)
+            for (int y = by * e; y < min((by + 1) * e, s.nby); ++y)
+                for (int z = bz * e; z < min((bz + 1) * e, s.nbz); ++z)
+                    m = fminf(m, s.brick_min[((size_t)x * s.nby + y) * s.nbz + z]);
+    }
+    uint32_t* out = const_cast<uint32_t*>(s.free_mask);
+    for (int k = 0; k < s.mcount; ++k) {
+        const unsigned long long bal = __ballot(b < nbits && m >= s.mclr[k]);
+        const int lane = threadIdx.x & (VG_WAVE - 1);
+        if (lane == 0) out[(size_t)k * s.mwords + (b >> 5)] = (uint32_t)bal;
+        if (lane == 32) out[(size_t)k * s.mwords + (b >> 5)] = (uint32_t)(bal >> 32);
+    }
 }
 
 // ---- ELBO path, few-problem form ---------------------------------------------------------------------
@@ -1195,6 +1297,12 @@ int vg_launch_sdf_pack(const vgpmp_sdf* sdf, const double* rows, int row_lo, int
     return (int)hipGetLastError();
 }
 
+int vg_launch_sdf_free_mask(const vgpmp_sdf* sdf, hipStream_t st) {
+    const size_t bits = (size_t)sdf->mask_words * 32;
+    hipLaunchKernelGGL(sdf_free_mask_kernel, dim3((unsigned)((bits + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, *sdf);
+    return (int)hipGetLastError();
+}
+
 int vg_launch_fk_spheres(const vgpmp_robot* rb, const float* q, int64_t n, float* pos, float* frames, hipStream_t st) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(fk_spheres_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, rb, q, n,
@@ -1283,6 +1391,18 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
     const bool regs = L <= 15 && form != 2;              // per-frame sums in registers (form 2, measurement: in LDS)
     if (regs) {
         const bool pfx = L <= VG_LIK_PREFIX_MAX_DOF;      // the prefix-scalar form of the reverse sweep (a fourth LDS slot row)
+        // free-space masks in LDS (four-wave workgroups; the per-wave partial sums and their count stay those of the one-wave form)
+        const size_t lds_mask = (size_t)sdf->mask_count * sdf->mask_words * 4 + (size_t)3 * L * kLikMaskBlock * sizeof(float);
+        if (!pfx && !sig && sdf->layout == VGPMP_SDF_BRICK4 && sdf->free_mask && sdf->mask_count > 0 && 2 * lds_mask <= 160 * 1024) {
+            auto gom = [&](auto kern) {
+                int rc = vg_grant_dyn_lds((const void*)kern, lds_mask);
+                if (rc) return rc;
+                hipExtLaunchKernelGGL(kern, dim3((nblk + 3) / 4, P), dim3(kLikMaskBlock), lds_mask, st, k0, k1, 0, rb, *sdf, f, S, L, N,
+                                      scale, G, logp, lik_partial, nblk);
+                return (int)hipGetLastError();
+            };
+            return far ? gom(loglik_paths_mask_kernel<3>) : gom(loglik_paths_mask_kernel<2>);
+        }
         lds = (size_t)(pfx ? 4 : 3) * L * kLikBatchBlock * sizeof(float);
         if (pfx) {
             if (sig) return far ? go(loglik_paths_kernel<1, kLikBatchBlock, true, true, true, true>) : go(loglik_paths_kernel<1, kLikBatchBlock, true, false, true, true>);

@@ -161,6 +161,10 @@ struct vg_sdf_dev {
     int nx, ny, nz, layout;
     int nby, nbz;               // bricks along y and z (BRICK4)
     double ox, oy, oz, delta;
+    // free-space masks (include/vgpmp.h): block edge 2^mshift voxels, mby x mbz blocks along y, z
+    const uint32_t* free_mask;
+    int mshift, mcount, mwords, mby, mbz;
+    float mclr[VGPMP_MAX_MASKS];
 };
 
 __device__ __forceinline__ vg_sdf_dev vg_load_sdf(const vgpmp_sdf& s) {
@@ -171,6 +175,11 @@ __device__ __forceinline__ vg_sdf_dev vg_load_sdf(const vgpmp_sdf& s) {
     d.nby = (s.ny + 3) >> 2; d.nbz = (s.nz + 3) >> 2;
     d.ox = s.origin[0]; d.oy = s.origin[1]; d.oz = s.origin[2];
     d.delta = s.delta;
+    d.free_mask = reinterpret_cast<const uint32_t*>(s.free_mask);
+    d.mshift = s.mask_shift; d.mcount = s.free_mask ? s.mask_count : 0; d.mwords = s.mask_words;
+    d.mby = (s.ny + (1 << s.mask_shift) - 1) >> s.mask_shift; d.mbz = (s.nz + (1 << s.mask_shift) - 1) >> s.mask_shift;
+#pragma unroll
+    for (int k = 0; k < VGPMP_MAX_MASKS; ++k) d.mclr[k] = s.mask_clearance[k];
     return d;
 }
 
@@ -267,6 +276,7 @@ inline int vg_grant_dyn_lds(const void* fn, size_t bytes) {
 
 // launchers implemented in the .hip files
 int vg_launch_sdf_pack(const vgpmp_sdf* sdf, const double* rows, int row_lo, int row_hi, int x0, int x1, hipStream_t st);
+int vg_launch_sdf_free_mask(const vgpmp_sdf* sdf, hipStream_t st);
 int vg_launch_fk_spheres(const vgpmp_robot* rb, const float* q, int64_t n, float* pos, float* frames, hipStream_t st);
 int vg_launch_sdf_index_f32(const vgpmp_sdf* sdf, const double* offset, const float* pos, int64_t n, int32_t* idx, hipStream_t st);
 int vg_launch_sdf_query(const vgpmp_sdf* sdf, const double* rel, int64_t n, int32_t* idx, float* dist, float* grad,

@@ -11,6 +11,8 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import threading
+import weakref
 from typing import Dict, Optional, Sequence
 
 import numpy as np
@@ -61,13 +63,17 @@ class DeviceScene:
 
     def __init__(self, spec: RobotSpec, grid, scene_offset: Sequence[float], sigma_obs=0.005,
                  epsilon: float = 0.05, device: Optional[torch.device] = None, layout: str = "brick",
-                 free_space_summary: Optional[bool] = None, slab_bytes: int = 256 << 20):
+                 free_space_summary: Optional[bool] = None, slab_bytes: int = 256 << 20,
+                 free_space_mask: Optional[bool] = None, mask_budget_bytes: int = 32 << 10):
         """grid = (data, origin, delta): data[x, y, z] as a NumPy array / torch tensor, or an object with `.shape` and
         `.rows(x_lo, x_hi, device) -> float64 device tensor` (rows produced on demand, e.g. scenes.AnalyticSceneRows).
         layout: "brick" (4x4x4 Morton bricks, include/vgpmp.h VGPMP_SDF_BRICK4) or "linear".
         free_space_summary: hand the per-brick minimum distance to the batch likelihood kernel (exact: spheres whose
         brick lies beyond epsilon + radius of every obstacle skip the table access); None = only for tables larger than
-        the Infinity Cache, where that access is an HBM gather."""
+        the Infinity Cache, where that access is an HBM gather.
+        free_space_mask: bit masks of the blocks of voxels that clear epsilon + radius (one mask per radius class, at most four,
+        `mask_budget_bytes` in all) for the batch likelihood kernel, which keeps them in LDS: the same exact test without a
+        memory request per query; None = as for the summary."""
         self.lib = capi.load(require=True)
         self.device = _require_gpu() if device is None else torch.device(device)
         if self.device.index is None:
@@ -85,6 +91,11 @@ class DeviceScene:
         capi.check(self.lib.vgpmp_robot_upload(C.byref(self.host_robot), capi.ptr(self.dev_robot), self._stream()),
                    "vgpmp_robot_upload")
         self._upload_grid(data, layout, free_space_summary, slab_bytes)
+        self._build_free_masks(free_space_mask, mask_budget_bytes)
+        # forward-only sampler views shared by the planners of this scene (PlannerBatch.posterior_sampler): re-pointing one at
+        # a planner, packing its arguments and launching on it happen under this lock (planners may be driven from threads)
+        self._sampler_lock = threading.RLock()
+        self._sampler_views: Dict = {}
 
     def _stream(self) -> int:
         """torch's current stream on THIS scene's device; launches need that device current (LDS attributes and
@@ -125,6 +136,41 @@ class DeviceScene:
         self.free_space_summary = bool(free_space_summary and self.brick_min is not None)
         if not self.free_space_summary:
             self.sdf.brick_min = None
+
+    def _build_free_masks(self, want: Optional[bool], budget_bytes: int) -> None:
+        """Free-space masks (include/vgpmp.h, vgpmp_sdf_free_mask): radius classes -> clearances epsilon + r (float32, one ulp
+        up: the kernel re-checks `eps - (clearance - r) <= 0` in the hinge's own arithmetic, a sphere a class does not cover
+        falls to the next), block edge = the smallest power of two (>= one brick) whose masks fit the LDS budget."""
+        self.free_mask = None
+        self.free_space_mask = False
+        if want is None:
+            want = self.table.numel() * 4 > (256 << 20)
+        if not want or self.brick_min is None:
+            return
+        radii = np.unique(np.asarray(self.spec.sphere_radii, dtype=np.float64))
+        if radii.size > capi.MAX_MASKS:      # the largest radius and evenly spaced quantiles below it
+            radii = np.unique(np.quantile(radii, np.linspace(0.0, 1.0, capi.MAX_MASKS), method="higher"))
+        clr = [float(np.nextafter(np.float32(np.float32(self.epsilon) + np.float32(r)), np.float32(np.inf))) for r in radii]
+        nx, ny, nz = self.shape
+        words = C.c_size_t(0)
+        shift = 2
+        while True:
+            capi.check(self.lib.vgpmp_sdf_mask_words(nx, ny, nz, shift, C.byref(words)), "vgpmp_sdf_mask_words")
+            if words.value * 4 * len(clr) <= budget_bytes or shift >= 12:
+                break
+            shift += 1
+        self.free_mask = torch.zeros(words.value * len(clr), dtype=torch.int32, device=self.device)
+        full = capi.Sdf.from_buffer_copy(self.sdf)
+        full.brick_min = capi.ptr(self.brick_min)               # the masks derive from the summary whether or not the kernels read it
+        full.free_mask, full.mask_shift, full.mask_count, full.mask_words = capi.ptr(self.free_mask), shift, len(clr), int(words.value)
+        for k, c in enumerate(clr):
+            full.mask_clearance[k] = c
+        capi.check(self.lib.vgpmp_sdf_free_mask(C.byref(full), self._stream()), "vgpmp_sdf_free_mask")
+        self.sdf.free_mask, self.sdf.mask_shift, self.sdf.mask_count, self.sdf.mask_words = full.free_mask, shift, len(clr), int(words.value)
+        for k, c in enumerate(clr):
+            self.sdf.mask_clearance[k] = c
+        self.mask_shift, self.mask_clearances = shift, clr
+        self.free_space_mask = True
 
     # ---- stand-alone pieces -------------------------------------------------------------------
     def fk_spheres(self, q: torch.Tensor, want_frames: bool = False):
@@ -282,8 +328,15 @@ class PlannerBatch:
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.fuse = True          # False: one launch per kernel even for small batches (measurement)
         self.extra_flags = 0      # e.g. capi.NO_SPLIT (measurement)
+        # the f16-split prior kernel of large batches keeps x, omega and x . omega as f16 pairs: its range argument assumes time
+        # stamps of order one (init_trainset: [0, 1]).  Stamps far outside that go to the float32-MFMA form instead.
+        if float(np.abs(Xn).max()) > 16.0:
+            self.extra_flags |= capi.PRIOR_F32
         self._graph = None
         self._graph_unroll = 0
+        # the step whose omega / beta / w a call with VGPMP_NOISE_AHEAD has left in the noise buffers (None: nobody's); every
+        # other writer of those buffers clears it, so VGPMP_NOISE_READY can never pair another step's draws with this one's eps
+        self.noise_ahead_step = None
         self._initial = [(t, t.clone()) for t in self._variables()]
         self._pack()
 
@@ -348,14 +401,20 @@ class PlannerBatch:
         """Inject the random tensors of one ELBO evaluation (parity tests)."""
         for dst, src in ((self.omega, omega), (self.beta, beta), (self.w, w), (self.eps, eps), (self.eps2, eps2)):
             dst.copy_(torch.as_tensor(np.asarray(src), dtype=torch.float32).reshape(dst.shape))
+        self.noise_ahead_step = None
 
     def generate_noise(self, step: int) -> None:
+        self.noise_ahead_step = None
         capi.check(self.lib.vgpmp_generate_noise(C.byref(self.dims), C.byref(self._noise), self.seed, self.problem_base,
                                                  int(step), self.scene._stream()), "vgpmp_generate_noise")
 
     # ---- the ELBO step --------------------------------------------------------------------------
     def _run(self, what: int, step: int) -> None:
         what |= (0 if self.fuse else capi.NO_FUSE) | self.extra_flags
+        if (what & capi.NOISE_READY) and self.noise_ahead_step != int(step):
+            what &= ~capi.NOISE_READY          # the buffers hold another step's draws (or none): this call draws its own
+        ahead = bool(what & capi.NOISE_AHEAD) and bool(what & capi.GEN_NOISE)
+        self.noise_ahead_step = int(step) + 1 if ahead else None
         capi.check(self.lib.vgpmp_elbo_step(
             C.byref(self.dims), capi.ptr(self.scene.dev_robot), C.byref(self.scene.sdf), C.byref(self._problem),
             C.byref(self._params), C.byref(self._am), C.byref(self._av), C.byref(self._noise), C.byref(self._out),
@@ -388,6 +447,8 @@ class PlannerBatch:
     def _run_counter(self, num_steps: int = 1, stage_ms=None) -> None:
         """`num_steps` training steps whose noise key / Adam step count come from the device counter."""
         what = capi.DO_FORWARD | capi.DO_BACKWARD | capi.DO_ADAM | capi.GEN_NOISE | (0 if self.fuse else capi.NO_FUSE) | self.extra_flags
+        what &= ~(capi.NOISE_READY | capi.NOISE_AHEAD)       # counter-driven calls always draw their own noise
+        self.noise_ahead_step = None
         args = (C.byref(self.dims), capi.ptr(self.scene.dev_robot), C.byref(self.scene.sdf),
                 C.byref(self._problem_ctr), C.byref(self._params), C.byref(self._am), C.byref(self._av),
                 C.byref(self._noise), C.byref(self._out), capi.ptr(self.workspace), self.workspace.numel(), what,
@@ -459,7 +520,7 @@ class PlannerBatch:
             # the view's own buffers (noise, paths, workspace) depend on shapes and constants only: planners of the same scene
             # and shape -- one per start-goal query in the reference's driver loop -- hand one set on (the variables it reads
             # are re-pointed at THIS planner's below)
-            shared = self.scene.__dict__.setdefault("_sampler_views", {})
+            shared = self.scene._sampler_views
             skey = key + (self.P, self.M, self.B, self.alpha, self.lr, self.seed, self.problem_base,
                           tuple(sorted(self.trainable.items())))
             child = shared.get(skey)
@@ -469,10 +530,13 @@ class PlannerBatch:
                                      lengthscales=[1.0] * self.L, variance=1.0, alpha=self.alpha, learning_rate=self.lr,
                                      num_bases=self.B, trainable=self.trainable, seed=self.seed + 7919,
                                      problem_base=self.problem_base, X=Xnew)
+                while len(shared) >= 8:                      # bounded: the oldest view (and its workspace) goes
+                    shared.pop(next(iter(shared)))
                 shared[skey] = child
             cache[key] = child
         child = cache[key]
-        if getattr(child, "_view_of", None) is not self:      # (another planner of this scene and shape used the view since)
+        owner = getattr(child, "_view_of", None)
+        if owner is None or owner() is not self:              # (another planner of this scene and shape used the view since)
             child.q_mu, child.q_sqrt, child.raw_ell, child.raw_var = self.q_mu, self.q_sqrt, self.raw_ell, self.raw_var
             child.y_u = self.y_u
             if self.lik_variables:      # the trained sigma_obs / alpha weigh the samples of get_best_sample
@@ -480,7 +544,7 @@ class PlannerBatch:
             if self.z_variables:        # the trained inducing locations
                 child.raw_Z = self.raw_Z
             child._pack()
-            child._view_of = self
+            child._view_of = weakref.ref(self)                # (no strong reference: the view must not keep a planner alive)
         Xn = np.tile(np.linspace(0.0, 1.0, n_new)[:, None], (1, self.L)) if Xnew is None else np.asarray(Xnew, dtype=np.float64)
         child.X.copy_(torch.as_tensor(Xn, dtype=torch.float64).reshape(child.X.shape))
         return child
@@ -508,9 +572,10 @@ class PlannerBatch:
                               compute_uncertainty: bool = False):
         """(mean, best sample, samples, best index[, end-effector variance]) per problem; best = argmax_s sum_n log p
         (models/vgpmp.py:312-339).  One forward-only step at Xnew, then vgpmp_sample_paths: no torch arithmetic."""
-        sp = self.posterior_sampler(num_samples, Xnew)
-        sp.elbo(generate=True, step=step)
-        mean, best_path, samples, best, ee = sp.extract_plans(True, compute_uncertainty)
+        with self.scene._sampler_lock:       # the view is shared by the planners of this scene: re-point, launch, extract as one
+            sp = self.posterior_sampler(num_samples, Xnew)
+            sp.elbo(generate=True, step=step)
+            mean, best_path, samples, best, ee = sp.extract_plans(True, compute_uncertainty)
         return (mean, best_path, samples, best, ee) if compute_uncertainty else (mean, best_path, samples, best)
 
     def path_clearance(self, path: torch.Tensor) -> torch.Tensor:

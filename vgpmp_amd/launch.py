@@ -17,6 +17,7 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 from typing import Dict, List, Optional, Sequence
 
@@ -29,10 +30,17 @@ def free_port() -> int:
     return port
 
 
-def rank_env(rank: int, world: int, port: int, base: Optional[Dict[str, str]] = None, devices: Optional[int] = None) -> Dict[str, str]:
+def rank_env(rank: int, world: int, port: int, base: Optional[Dict[str, str]] = None, devices: Optional[int] = None,
+             store: Optional[str] = None) -> Dict[str, str]:
+    """Environment of one rank.  `store`: path of a file-store rendezvous (VGPMP_INIT_METHOD = file://...), which scripts
+    that know about it (bench.py) prefer to MASTER_PORT: free_port() closes its socket before the ranks bind it, so a job
+    started beside this one could take the port in between; a fresh file cannot be taken."""
     env = dict(os.environ if base is None else base)
+    if store:
+        env["VGPMP_INIT_METHOD"] = "file://" + store
     env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+               MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC unless the user chose otherwise
     if devices is not None and devices < world and "VGPMP_DIST_BACKEND" not in env:
         env["VGPMP_DIST_BACKEND"] = "gloo"          # ranks share devices: RCCL cannot, gloo rehearses the path
     return env
@@ -43,9 +51,11 @@ def spawn_ranks(world: int, argv: Sequence[str], script: Optional[str] = None, d
     """Run `script argv...` as `world` ranks; rank 0 inherits stdout, the others' stdout goes to stderr."""
     script = script or os.path.abspath(sys.argv[0])
     port = free_port()
+    store_dir = tempfile.mkdtemp(prefix="vgpmp_rdzv_")
+    store = os.path.join(store_dir, "store")
     procs: List[subprocess.Popen] = []
     for r in range(world):
-        procs.append(subprocess.Popen([sys.executable, script, *argv], env=rank_env(r, world, port, devices=devices),
+        procs.append(subprocess.Popen([sys.executable, script, *argv], env=rank_env(r, world, port, devices=devices, store=store),
                                       stdout=None if r == 0 else sys.stderr))
     deadline = time.monotonic() + timeout_s
     rc = 0
@@ -68,4 +78,10 @@ def spawn_ranks(world: int, argv: Sequence[str], script: Optional[str] = None, d
         except subprocess.TimeoutExpired:
             p.kill()
             p.wait()
+    try:
+        if os.path.exists(store):
+            os.unlink(store)
+        os.rmdir(store_dir)
+    except OSError:
+        pass
     return rc

@@ -91,7 +91,6 @@ class SampleShardedPlanner:
         self.planner, self.group, self.comm = planner, group, comm
         self.schedule = ("per step: vgpmp_elbo_step (forward + reverse: stage 1-3, likelihood, reverse paths, one launch for the "
                          "gradients; the next step's prior noise drawn beside the path assembly), the all-reduce, vgpmp_adam_step (one launch)")
-        self._chained_at = None          # step whose omega / beta / w the previous call has drawn
 
     def _allreduce(self, buf: Optional[torch.Tensor] = None) -> None:
         buf = self.planner.reduce_buf if buf is None else buf
@@ -104,13 +103,14 @@ class SampleShardedPlanner:
         from . import capi
         pl = self.planner
         # consecutive steps: step t draws the prior noise of step t + 1 beside its path assembly (no noise launches)
+        # (which step's draws the buffers hold is tracked by the planner itself -- PlannerBatch.noise_ahead_step -- so a direct
+        #  call on it between two steps here, which redraws them, cannot be paired with the wrong eps)
         keep = pl.extra_flags
-        pl.extra_flags = keep | capi.NOISE_AHEAD | (capi.NOISE_READY if self._chained_at == pl.t else 0)
+        pl.extra_flags = keep | capi.NOISE_AHEAD | capi.NOISE_READY
         try:
             pl.accumulate_grad(generate=True, step=pl.t)      # local samples; KL only where kl_scale = 1
         finally:
             pl.extra_flags = keep
-        self._chained_at = pl.t + 1
         self._allreduce()
         pl.adam_only()                                         # identical update on every rank
 
@@ -120,8 +120,7 @@ class SampleShardedPlanner:
 
     def elbo(self) -> torch.Tensor:
         pl = self.planner
-        pl.elbo(generate=True, step=pl.t)
-        self._chained_at = None                                # that call drew its own noise into the shared buffers
+        pl.elbo(generate=True, step=pl.t)                      # (draws its own noise: clears pl.noise_ahead_step)
         # only the [lik | kl] tail is fresh after a forward-only pass: reduce just that (contiguous, 2 P doubles) and
         # leave the gradient part of the buffer alone (summing it in place would scale a stale gradient by the world size)
         self._allreduce(pl.reduce_buf[pl.reduce_buf.numel() - 2 * pl.P:])
