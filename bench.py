@@ -78,7 +78,9 @@ def parse_args(argv=None):
                     help="config2 = the benchmark line; config3 = Franka / bookshelves, 55 pairs, S=7 M=24 T=70; "
                          "stress = BASELINE config 5 per-GPU share (64 problems, 512^3 table)")
     ap.add_argument("--also-stress", choices=("auto", "on", "off"), default="auto",
-                    help="append the config-5 share (batch_512) to the line; auto = when N > 1 runs the default workload")
+                    help="append the config-5 share (batch_512) to the line; auto = with the default workload, at every N")
+    ap.add_argument("--also-config3", choices=("auto", "on", "off"), default="auto",
+                    help="append BASELINE config 3 (55 pairs) and 64 problems of config 2's shape (batch_64); auto = default workload at N = 1")
     return ap.parse_args(argv)
 
 
@@ -173,14 +175,18 @@ def build_problem(rank: int, args, world: int = 1):
     return ps, spec, grid, scene, planner
 
 
-def cpu_baseline(ps, spec, grid, args, budget_s: float = 10.0):
-    """The float64 NumPy oracle (a restatement, not the GPflow/TF stack) timed on the host cores: all threads of the
-    BLAS pool, then ONE thread (BASELINE.md section 3 asks for both and for the thread count)."""
+def cpu_baseline(ps, spec, grid, args, budget_s: float = 10.0, pool=None):
+    """The float64 NumPy oracle (a restatement, not the GPflow/TF stack) timed on the host cores: one process on the BLAS pool
+    (`cores` = the cores it actually kept busy: process CPU time / wall time), the same with the pool limited to ONE thread, and
+    -- `pool`, started before this process touched the GPU -- one single-threaded process per core over independent problems
+    (the axis the GPU batches): aggregate problem-steps/s (SURVEY 8(d) "CPU baseline timing")."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_scene
     from oracle import vgpmp_oracle as orc
     pp = ps.planner_params
+    if pool is not None:
+        pool.go(ps, spec, grid, args)                  # the workers build their problems while this process times its own
     sc = oracle_scene(spec, grid, ps.object_positions[0], sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"])
     y = np.array(ps.queries[0], dtype=np.float64)
     S, N, M, B, D = args.samples, args.timesteps, args.inducing, 1024, spec.dof
@@ -193,29 +199,152 @@ def cpu_baseline(ps, spec, grid, args, budget_s: float = 10.0):
 
     def timed(budget):
         one()                                   # warm caches / BLAS threads
-        n, t0 = 0, time.perf_counter()
+        n, t0, c0 = 0, time.perf_counter(), time.process_time()
         while True:
             one(); n += 1
             el = time.perf_counter() - t0
             if el > budget and n >= 3:
-                return n, el
+                return n, el, (time.process_time() - c0) / el
 
     try:
         from threadpoolctl import threadpool_info, threadpool_limits
         threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
     except Exception:
         threadpool_limits, threads = None, os.cpu_count() or 1
-    n, el = timed(budget_s)
-    out = {"value": n / el, "unit": "ELBO iters/sec", "cores": int(threads), "kind": "port",
-           "logical_cores": os.cpu_count(),
+    if pool is not None:
+        pool.wait_ready()                        # (their set-up must not share the cores with the single-process timing below)
+    n, el, busy = timed(budget_s)
+    out = {"value": n / el, "unit": "ELBO iters/sec", "cores": max(1, int(round(busy))), "kind": "port",
+           "blas_threads": int(threads), "cores_busy_measured": round(busy, 2), "logical_cores": os.cpu_count(),
            "sample": f"{n} full optimisation steps of the same workload (noise draw + forward + reverse + Adam) "
-                     f"by the float64 NumPy oracle in {el:.1f} s on {threads} BLAS threads; host has {os.cpu_count()} logical cores"}
+                     f"by the float64 NumPy oracle in {el:.1f} s, one process, BLAS pool of {threads} threads of which {busy:.1f} cores "
+                     f"were busy on average (process CPU time / wall time: the restatement is element-wise NumPy, it does not "
+                     f"thread); host has {os.cpu_count()} logical cores"}
     if threadpool_limits is not None:
         with threadpool_limits(limits=1):
-            n1, el1 = timed(budget_s)
+            n1, el1, _ = timed(budget_s)
         out["single_thread"] = {"value": n1 / el1, "cores": 1,
                                 "sample": f"{n1} steps in {el1:.1f} s with the BLAS pool limited to one thread"}
+    if pool is not None:
+        out["problem_parallel"] = pool.run(budget_s)
     return out
+
+
+class CpuPool:
+    """One single-threaded oracle process per core, over independent start-goal problems of the bench workload.  The children
+    are started BEFORE the parent touches the GPU (fresh interpreters of this script in `--cpu-worker` mode; they never import
+    torch) and sleep until `go()` hands them the scene: they cost nothing while the GPU part is timed."""
+
+    def __init__(self, n: int):
+        import subprocess
+        import tempfile
+        self.n = int(n)
+        self.dir = tempfile.mkdtemp(prefix="vgpmp_cpu_pool_")
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", NUMEXPR_NUM_THREADS="1")
+        self.err = open(os.path.join(self.dir, "workers.err"), "w")
+        self.procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", self.dir, str(i)], env=env,
+                                       stdout=subprocess.DEVNULL, stderr=self.err) for i in range(self.n)]
+
+    def go(self, ps, spec, grid, args) -> None:
+        import numpy as np
+        data, origin, delta = grid
+        np.save(os.path.join(self.dir, "grid.npy"), np.ascontiguousarray(np.asarray(data, dtype=np.float64)))
+        job = {"robot": ps.robot, "problemset": ps.name, "origin": [float(v) for v in origin], "delta": float(delta),
+               "S": args.samples, "N": args.timesteps, "M": args.inducing, "B": 1024}
+        tmp = os.path.join(self.dir, "go.tmp")
+        json.dump(job, open(tmp, "w"))
+        os.replace(tmp, os.path.join(self.dir, "go.json"))
+
+    def _wait(self, pattern: str, timeout_s: float):
+        t0 = time.time()
+        while time.time() - t0 < timeout_s:
+            have = [i for i in range(self.n) if os.path.exists(os.path.join(self.dir, pattern % i))]
+            alive = [p.poll() is None for p in self.procs]
+            if len(have) == self.n or not any(alive):
+                return have
+            time.sleep(0.05)
+        return [i for i in range(self.n) if os.path.exists(os.path.join(self.dir, pattern % i))]
+
+    def wait_ready(self, timeout_s: float = 120.0):
+        self.ready = self._wait("ready_%d", timeout_s)
+
+    def run(self, budget_s: float):
+        json.dump({"budget": budget_s}, open(os.path.join(self.dir, "start.tmp"), "w"))
+        os.replace(os.path.join(self.dir, "start.tmp"), os.path.join(self.dir, "start.json"))
+        done = self._wait("result_%d.json", budget_s * 3 + 60.0)
+        res = [json.load(open(os.path.join(self.dir, "result_%d.json" % i))) for i in done]
+        self.close()
+        if not res:
+            return {"value": None, "error": "no worker finished (see " + self.err.name + ")"}
+        steps, wall = sum(r["steps"] for r in res), max(r["elapsed"] for r in res)
+        return {"value": steps / wall, "unit": "problem-steps/sec", "cores": len(res), "processes": self.n, "kind": "port",
+                "per_process": steps / wall / len(res),
+                "sample": f"{len(res)} single-threaded processes (one per core; host has {os.cpu_count()} logical cores), each the same "
+                          f"float64 oracle step on its own start-goal problem of the workload's problem set, all timed together "
+                          f"for {wall:.1f} s: {steps} problem-steps; to be compared with the GPU BATCH figure (batch_64), not with the "
+                          f"one-problem line"}
+
+    def close(self) -> None:
+        open(os.path.join(self.dir, "cancel"), "w").close()
+        for p in self.procs:
+            try:
+                p.wait(timeout=5)
+            except Exception:
+                p.kill()
+        self.err.close()
+
+
+def cpu_worker_main(jobdir: str, index: int) -> int:
+    """`bench.py --cpu-worker <dir> <i>`: one process of CpuPool.  NumPy + the oracle only (no torch, no GPU)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_scene
+    from oracle import vgpmp_oracle as orc
+    from vgpmp_amd import robots
+    parent = os.getppid()
+
+    def wait_for(name, timeout_s):
+        t0 = time.time()
+        path = os.path.join(jobdir, name)
+        while not os.path.exists(path):
+            if os.path.exists(os.path.join(jobdir, "cancel")) or os.getppid() != parent or time.time() - t0 > timeout_s:
+                return None
+            time.sleep(0.05)
+        return json.load(open(path))
+
+    job = wait_for("go.json", 3600.0)
+    if job is None:
+        return 0
+    ps = robots.load_problemset(job["robot"], job["problemset"])
+    pp = ps.planner_params
+    spec = robots.load_robot(job["robot"], *ps.robot_pos_and_orn)
+    data = np.load(os.path.join(jobdir, "grid.npy"), mmap_mode="r")
+    sc = oracle_scene(spec, (data, np.array(job["origin"]), job["delta"]), ps.object_positions[0], sigma_obs=pp["sigma_obs"],
+                      epsilon=pp["epsilon"])
+    queries = ps.queries
+    y = np.array(queries[index % len(queries)], dtype=np.float64)
+    S, N, M, B, D = job["S"], job["N"], job["M"], job["B"], spec.dof
+    p = orc.init_params(sc.robot, y, M, pp["lengthscales"], pp["variance"])
+    st = orc.adam_init(p)
+    X, Zy = orc.init_trainset(N, D), orc.inducing_Zy(M, D)
+    rng = np.random.default_rng(index)
+    one = lambda: orc.optimization_step(p, st, sc, X, Zy, y, orc.draw_noise(rng, S, D, D, B, M + 2),
+                                        float(pp["alpha"]), float(pp["learning_rate"]))
+    one()
+    open(os.path.join(jobdir, "ready_%d" % index), "w").close()
+    start = wait_for("start.json", 600.0)
+    if start is None:
+        return 0
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one(); n += 1
+        el = time.perf_counter() - t0
+        if el > start["budget"] and n >= 3:
+            break
+    tmp = os.path.join(jobdir, "result_%d.tmp" % index)
+    json.dump({"steps": n, "elapsed": el}, open(tmp, "w"))
+    os.replace(tmp, os.path.join(jobdir, "result_%d.json" % index))
+    return 0
 
 
 def measured_solves(args, world, rank, dist, backend):
@@ -449,10 +578,12 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
                  "peak": peak_gemm, "unit": "TFLOP/s", "frac": gemm_flops / t_gemm / 1e12 / peak_gemm,
                  "traffic": None, "algorithmic_flops_per_launch": gemm_flops, "avg_launch_ms": kernel_ms["prior_gemm_kernel"]}
     dominant = max(stage_ms, key=stage_ms.get)
-    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    # counter traffic of THIS round's collection, per workload (tools/run_collect.sh copies the tables to these names)
+    own = {("config2", 1): "pmc_traffic.json", ("stress", 64): "pmc_traffic_config5.json", ("config3", 55): "pmc_traffic_config3.json"}
+    tfile = os.path.join(ROOT, "profiles", own.get((args.workload, npb), "none"))
     if args.traffic_file:
         tfile = args.traffic_file
-    if os.path.exists(tfile) and (args.traffic_file or (args.workload == "config2" and npb == 1)):
+    if os.path.exists(tfile) and (args.traffic_file or ((args.workload, npb) in own and args.scene == "mesh" and not args.also_train)):
         try:
             t = json.load(open(tfile))
             roof_sdf["traffic"] = t.get(lik_kernel, {}).get("hbm_bytes_per_launch")
@@ -471,7 +602,10 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
         "value": world * npb * args.steps / elapsed, "unit": "ELBO iters/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "timed_blocks": reps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": ("f32; prior products f16-split x3, f32 accumulate (v_mfma_f32_16x16x32_f16); covariance path and Adam f64"
+                  if (sk == 1 and not (planner.extra_flags & capi.PRIOR_F32) and not (planner.fuse and npb * D <= 32))
+                  else "f32 (f32 MFMA prior products; covariance path and Adam f64)"),
         "data": "synthetic",
         "config": {"workload": names[args.workload] + ", SDF " + "x".join(str(v) for v in scene.shape)
                                + (" from the reference's collision mesh" if args.workload != "stress" and args.scene != "synthetic"
@@ -479,7 +613,9 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
                                + f", {npb} start-goal problem(s) per GPU, S={S} M={M} T={N} B={B}, "
                                "q_mu/q_sqrt/lengthscales/kernel_variance trainable"
                                + (" + " + args.also_train if args.also_train else ""),
-                   "parallelism": f"problems sharded x{world}, no collective",
+                   "parallelism": f"problems sharded x{world}, no collective"
+                                  + ("; this line is ONE problem per GPU (weak scaling reads ~N x by construction): the figure that "
+                                     "carries the multi-GPU claim is batch_512 below (64 problems per GPU)" if world > 1 and npb == 1 else ""),
                    "launch": (f"hipGraph x{args.unroll} steps" if args.unroll else "plain launches")
                              + ("; independent kernels of a step share launches (stage1 / stage2 / likelihood + path assembly / stage4 for"
                                 " one or two problems, stage1/2/3_kernel + likelihood + reverse pass from three), the prior GEMM is a"
@@ -502,13 +638,31 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
     torch.cuda.empty_cache()
     if want_extras and args.workload == "config2" and not args.no_solve:
         line.update(measured_solves(args, world, rank, dist, backend))
-    if want_extras and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(ps, spec, grid, args)
-        line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+    if rank == 0:
+        line["_ctx"] = (ps, spec, grid, args)          # main() times the CPU baseline last, after every GPU figure
     return line if rank == 0 else None
 
 
+SUB_KEYS = ("value", "unit", "ms_per_step", "steps", "warmup", "timed_blocks", "scaling", "dtype", "config", "roofline",
+            "roofline_secondary", "dominant_stage", "stage_ms")
+
+
+def sub_record(argv, world, rank, dist, backend):
+    """A further workload timed by the same ranks behind the same barriers, after (and outside) the line's own timed region;
+    compact form of its line."""
+    a = resolve(parse_args(list(argv) + ["--gpus", str(world)]))
+    l2 = run_problem_sharded(a, world, rank, dist, backend, want_extras=False)
+    if rank != 0:
+        return None
+    l2.pop("_ctx", None)
+    rec = {k: l2[k] for k in SUB_KEYS}
+    rec["problems_total"] = world * a.problems
+    return rec
+
+
 def main():
+    if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-worker":
+        sys.exit(cpu_worker_main(sys.argv[2], int(sys.argv[3])))
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no external launcher: start the ranks as fresh child interpreters BEFORE this process touches the GPU
@@ -518,10 +672,15 @@ def main():
         assert not torch.cuda.is_initialized(), "the rank launcher must run before this process touches the GPU"
         sys.exit(launch.spawn_ranks(args.gpus, sys.argv[1:], script=os.path.abspath(__file__),
                                     devices=torch.cuda.device_count()))
-    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    default_workload = args.workload == "config2" and args.shard == "problems" and not args.problems
+    # the problem-parallel CPU baseline: its worker processes start NOW, before this process touches the GPU, and sleep
+    pool = None
+    if world == 1 and not args.no_cpu_baseline and args.shard == "problems" and args.workload == "config2" and args.scene == "mesh":
+        pool = CpuPool(max(1, min((os.cpu_count() or 2) // 2, 64)))
+    import torch
     dist = None
     backend = os.environ.get("VGPMP_DIST_BACKEND", "nccl")      # "gloo": rehearsal of the N > 1 path on a 1-GPU box
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -538,21 +697,41 @@ def main():
             dist.init_process_group(backend, **rdzv)
     else:
         torch.cuda.set_device(0)
-    default_workload = args.workload == "config2" and args.shard == "problems" and not args.problems
     resolve(args)
-    if args.shard == "samples":
-        line = run_sample_sharded(args, world, rank, dist, backend)
-    else:
-        line = run_problem_sharded(args, world, rank, dist, backend)
-        if args.also_stress == "on" or (args.also_stress == "auto" and world > 1 and default_workload):
-            # the 512-problem batch of the north star, this GPU's 64: same ranks, same barriers, appended to the line
-            a2 = resolve(parse_args(["--workload", "stress", "--gpus", str(world), "--steps", "100", "--warmup", "3",
-                                     "--profile-steps", "5", "--min-seconds", "0.5"]))
-            l2 = run_problem_sharded(a2, world, rank, dist, backend, want_extras=False)
-            if rank == 0:
-                line["batch_512"] = {k: l2[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "timed_blocks", "scaling",
-                                                        "config", "roofline", "roofline_secondary", "stage_ms")}
-                line["batch_512"]["problems_total"] = world * a2.problems
+    try:
+        if args.shard == "samples":
+            line = run_sample_sharded(args, world, rank, dist, backend)
+        else:
+            line = run_problem_sharded(args, world, rank, dist, backend)
+            ctx = line.pop("_ctx", None) if rank == 0 else None
+            quick = ["--no-cpu-baseline", "--no-solve", "--warmup", "3", "--profile-steps", "5", "--min-seconds", "0.5"]
+            if args.also_stress == "on" or (args.also_stress == "auto" and default_workload):
+                # the batch regime in front of the driver: the 512-problem batch of the north star, this GPU's 64 (BASELINE
+                # config 5 share), whole plans of 200 steps from fresh models
+                rec = sub_record(["--workload", "stress", "--steps", "200"] + quick, world, rank, dist, backend)
+                if rank == 0:
+                    line["batch_512"] = rec
+            if args.also_config3 == "on" or (args.also_config3 == "auto" and default_workload and world == 1):
+                # BASELINE config 3, the reference's literal benchmark workload: 55 Franka / bookshelves pairs, S=7, 130 steps
+                rec = sub_record(["--workload", "config3", "--steps", "130"] + quick, world, rank, dist, backend)
+                if rank == 0:
+                    line["config3"] = rec
+                # 64 problems of the line's own shape (config 2) as one batch: the GPU figure the problem-parallel CPU baseline
+                # is to be held against
+                rec = sub_record(["--problems", "64", "--steps", "200"] + quick, world, rank, dist, backend)
+                if rank == 0:
+                    line["batch_64"] = rec
+            if rank == 0 and ctx is not None and world == 1 and not args.no_cpu_baseline:
+                torch.cuda.synchronize()
+                line["cpu_baseline"] = cpu_baseline(*ctx, pool=pool)
+                pool = None
+                line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+                pp_ = line["cpu_baseline"].get("problem_parallel")
+                if pp_ and pp_.get("value") and "batch_64" in line:
+                    line["gpu_batch_over_cpu_problem_parallel"] = line["batch_64"]["value"] / pp_["value"]
+    finally:
+        if pool is not None:
+            pool.close()
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

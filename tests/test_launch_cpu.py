@@ -89,3 +89,28 @@ def test_committed_traffic_table_is_this_rounds():
     assert not any(k.startswith("Cijk_") or "at::native::sigmoid" in k for k in t)
     lik = [k for k in t if k.startswith("loglik_paths_wide_kernel")]
     assert lik and all(t[k]["hbm_bytes_per_launch"] > 0 for k in lik)
+
+
+def test_cpu_pool_of_the_problem_parallel_baseline(tmp_path):
+    """bench.py's problem-parallel CPU baseline: worker processes (no torch, no GPU) started ahead of time, woken with the
+    scene, timed together; aggregate problem-steps/s over the workers that finished."""
+    import argparse
+    import numpy as np
+    import bench
+    from vgpmp_amd import robots, scenes
+    pool = bench.CpuPool(2)
+    try:
+        ps = robots.load_problemset("franka", "industrial")
+        spec = robots.load_robot("franka", *ps.robot_pos_and_orn)
+        grid = scenes.synthetic_boxes_sdf(n=24, delta=0.1, origin=(-1.2, -1.2, -0.6), seed=0)
+        args = argparse.Namespace(samples=4, timesteps=8, inducing=4)
+        pool.go(ps, spec, grid, args)
+        pool.wait_ready(timeout_s=120)
+        assert pool.ready == [0, 1]
+        rec = pool.run(0.5)
+    finally:
+        if any(p.poll() is None for p in pool.procs):
+            pool.close()
+    assert rec["cores"] == 2 and rec["processes"] == 2 and rec["unit"] == "problem-steps/sec"
+    assert rec["value"] > 0 and abs(rec["per_process"] * 2 - rec["value"]) < 1e-9
+    assert all(p.poll() == 0 for p in pool.procs)

@@ -498,6 +498,164 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
     return -0.5f * acc;
 }
 
+// The register form as a two-stage software pipeline over batches of U spheres.  Measured on the config-5 share (r04): the
+// duration of the register form is its vector time PLUS its gather time, T = 177 us + (gathers issued) / 165 per ns, whatever
+// the number of waves per SIMD or of gathers in flight -- waves of one launch run the same program in phase, so the memory
+// system is idle while they compute and saturated while they wait.  Here a wave overlaps the two by itself: the gathers of
+// batch b are issued, THEN the chain is advanced and the positions, voxel indices, addresses and free-space tests of batch
+// b + 1 are formed (the largest share of the vector work) while they are in flight, then the hinge and the force / moment sums
+// of batch b.  Two position / address buffers, one record buffer; U = 4 keeps it at two waves per SIMD.  Same arithmetic in
+// the same order as loglik_config_regs: bit-identical results.
+// FAR: 0 every sphere reads the table; 1 brick summary (requested for batch b + 1 under the gathers of batch b: straight-line
+// loads, so the compiler's wait for the gathers leaves them in flight); 2 free-space masks in LDS.
+template <int U, int FAR, typename LoadRaw, typename ToAngle, typename Emit>
+__device__ __forceinline__ float loglik_config_pipe(const vgpmp_robot* __restrict__ rb, const vg_sdf_dev& sdf,
+                                                    const LikScratch sc, LoadRaw load_raw, ToAngle to_angle, Emit emit,
+                                                    const uint32_t* lmask = nullptr) {
+    static_assert(VGPMP_MAX_SPHERES % (2 * U) == 0, "two batches of sphere constants never leave the table");
+    static_assert(FAR >= 0 && FAR <= 2, "none, summary or masks");
+    const int D = rb->dof, P = rb->num_spheres;          // D <= 15: frames 0 .. 15
+    float raw[VGPMP_MAX_DOF];
+#pragma unroll
+    for (int j = 0; j < VGPMP_MAX_DOF; ++j) raw[j] = load_raw(min(j, D - 1));
+    const float eps = rb->epsilon;
+    const double offx = rb->scene_offset[0], offy = rb->scene_offset[1], offz = rb->scene_offset[2];
+    const SdfFast fs = make_fast(sdf, offx, offy, offz);
+#pragma unroll
+    for (int j = 0; j < VGPMP_MAX_DOF; ++j) {
+        if (j < D) {                                     // uniform
+            float st, ct, d;
+            vg_sincos(to_angle(j, raw[j], d) + rb->joint_tab[j][4], &st, &ct);
+            sc.at(j) = st; sc.at(D + j) = ct; sc.at(2 * D + j) = d;
+        }
+    }
+    vg_f32x16 fx = 0.f, fy = 0.f, fz = 0.f, mx = 0.f, my = 0.f, mz = 0.f;      // per-frame sums
+    Frame T = base_frame(rb);
+    int cur = 0;                                         // frame T stands at (issue side)
+    int pcur = 0;                                        // frame of the running sums (consumer side)
+    vg_float3 F = vg_make3(0.f, 0.f, 0.f), Mo = vg_make3(0.f, 0.f, 0.f);
+    vg_float3 Ft = vg_make3(0.f, 0.f, 0.f), Mt = vg_make3(0.f, 0.f, 0.f);
+    float acc = 0.f;
+    auto flush = [&]() {                                 // sums of frame pcur are complete
+        fx[pcur] = F.x; fy[pcur] = F.y; fz[pcur] = F.z; mx[pcur] = Mo.x; my[pcur] = Mo.y; mz[pcur] = Mo.z;
+        Ft = vg_make3(Ft.x + F.x, Ft.y + F.y, Ft.z + F.z);
+        Mt = vg_make3(Mt.x + Mo.x, Mt.y + Mo.y, Mt.z + Mo.z);
+        F = vg_make3(0.f, 0.f, 0.f); Mo = vg_make3(0.f, 0.f, 0.f);
+        ++pcur;
+    };
+    struct Batch {
+        vg_float3 pos[U];
+        uint32_t at[U];
+        float sm[FAR ? U : 1];        // FAR 1: the brick's smallest distance; FAR 2: 0 where the block is marked free, else +inf... see issue()
+    };
+    // stage 1: chain, positions, voxel addresses and the free-space test's operand of batch q0
+    auto stage1 = [&](int q0, Batch& b) {
+        float4 ca[U];
+        float2 cb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ca[u] = *reinterpret_cast<const float4*>(rb->sphere_a[q0 + u]);      // {offset, frame}; rows >= P: frame = D
+            cb[u] = *reinterpret_cast<const float2*>(rb->sphere_b[q0 + u]);      // {radius, 1 / sigma}
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (q0 + u < P) {                            // uniform
+                const int fr = __builtin_bit_cast(int, ca[u].w);
+                while (cur < fr) {
+                    dh_apply(rb, cur, sc.at(cur), sc.at(D + cur), T);
+                    ++cur;
+                }
+                b.pos[u] = axpy(ca[u].x, T.cx, axpy(ca[u].y, T.cy, axpy(ca[u].z, T.cz, T.t)));
+                const Vox3 ix = voxel3(b.pos[u], fs, sdf, offx, offy, offz);
+                b.at[u] = (uint32_t)vg_table_offset(sdf, ix.ix, ix.iy, ix.iz);
+                if (FAR == 1) b.sm[u] = sdf.brick_min[vg_brick_of(sdf, ix.ix, ix.iy, ix.iz)];
+                if (FAR == 2) {
+                    // the mask of the smallest clearance that covers this sphere (uniform): clearance >= eps + r in the hinge's
+                    // own float32 form, so a set bit means cost exactly 0 on every voxel of the block (monotone rounding)
+                    int mo = -1;
+#pragma unroll
+                    for (int k = VGPMP_MAX_MASKS - 1; k >= 0; --k)
+                        if (k < sdf.mcount && !(eps - (sdf.mclr[k] - cb[u].x) > 0.f)) mo = k * sdf.mwords;
+                    const uint32_t bit = (uint32_t)(((ix.ix >> sdf.mshift) * sdf.mby + (ix.iy >> sdf.mshift)) * sdf.mbz + (ix.iz >> sdf.mshift));
+                    const uint32_t w = mo < 0 ? 0u : lmask[mo + (bit >> 5)] >> (bit & 31u);
+                    b.sm[u] = (w & 1u) ? __builtin_inff() : -__builtin_inff();      // a distance that is / is not beyond every hinge
+                }
+            } else {
+                b.pos[u] = vg_make3(0.f, 0.f, 0.f);
+                b.at[u] = 0u;
+                if (FAR) b.sm[u] = __builtin_inff();
+            }
+        }
+    };
+    // the gathers of a batch: spheres in free space keep a record whose hinge is exactly 0
+    auto issue = [&](int q0, const Batch& b, float4 (&v)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (q0 + u < P) {                            // uniform
+                if (FAR) {
+                    const float r = rb->sphere_b[q0 + u][0];
+                    v[u] = make_float4(FAR == 1 ? b.sm[u] : __builtin_inff(), 0.f, 0.f, 0.f);
+                    if (eps - (b.sm[u] - r) > 0.f) v[u] = sdf.table[b.at[u]];
+                } else {
+                    v[u] = sdf.table[b.at[u]];
+                }
+            } else {
+                v[u] = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);       // hinge exactly 0
+            }
+        }
+    };
+    // stage 3: hinge, log-density and the per-frame force / moment sums of batch q0
+    auto stage3 = [&](int q0, const Batch& b, const float4 (&v)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + u;
+            if (q < P) {                                 // uniform
+                const float4 ca = *reinterpret_cast<const float4*>(rb->sphere_a[q]);
+                const float2 cb = *reinterpret_cast<const float2*>(rb->sphere_b[q]);
+                const int fr = __builtin_bit_cast(int, ca.w);
+                while (pcur < fr) flush();
+                const float c = fmaxf(eps - (v[u].x - cb.x), 0.f);               // likelihood.py:131-143
+                const float cs = c * cb.y;
+                acc = fmaf(cs, c, acc);                                          // likelihood.py:99
+                const vg_float3 gp = vg_make3(cs * v[u].y, cs * v[u].z, cs * v[u].w);   // d logp / d pos
+                F = vg_make3(F.x + gp.x, F.y + gp.y, F.z + gp.z);
+                Mo = vg_cross_acc(Mo, b.pos[u], gp);
+            }
+        }
+    };
+    Batch A, B;
+    float4 v[U];
+    stage1(0, A);
+#pragma nounroll
+    for (int q0 = 0; q0 < P; q0 += 2 * U) {
+        issue(q0, A, v);
+        if (q0 + U < P) stage1(q0 + U, B);               // (under the gathers of A)
+        stage3(q0, A, v);
+        if (q0 + U < P) {
+            issue(q0 + U, B, v);
+            if (q0 + 2 * U < P) stage1(q0 + 2 * U, A);   // (under the gathers of B)
+            stage3(q0 + U, B, v);
+        }
+    }
+    while (pcur <= D) flush();
+    // second sweep over the chain: joint i turns about z of frame i (Craig) or frame i-1 (classic) and moves every
+    // sphere on frames >= i, i.e. the totals minus the prefix < i
+    const bool craig = rb->craig != 0;
+    T = base_frame(rb);
+    vg_float3 Fs = Ft, Ms = Mt;
+#pragma nounroll
+    for (int i = 1; i <= D; ++i) {
+        Fs = vg_make3(Fs.x - fx[i - 1], Fs.y - fy[i - 1], Fs.z - fz[i - 1]);
+        Ms = vg_make3(Ms.x - mx[i - 1], Ms.y - my[i - 1], Ms.z - mz[i - 1]);
+        vg_float3 z = T.cz, org = T.t;
+        dh_apply(rb, i - 1, sc.at(i - 1), sc.at(D + i - 1), T);
+        if (craig) { z = T.cz; org = T.t; }
+        const vg_float3 oxF = vg_cross(org, Fs);
+        emit(i - 1, vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)) * sc.at(2 * D + i - 1));
+    }
+    return -0.5f * acc;
+}
+
 // The same with the prefix term of every joint's gradient as a scalar in LDS instead of per-frame sums in registers (up to
 // VG_LIK_PREFIX_MAX_DOF joints).  A function of its own: folded into loglik_config_regs as a template switch, the form WITHOUT
 // the prefix terms came out 22 % slower at the config-5 share -- same numbers, same register count, a different schedule of
@@ -739,6 +897,13 @@ __global__ __launch_bounds__(BLK, REGS ? (PFX ? VG_LIK_PFX_WAVES : VG_LIK_REGS_W
 // 512^3 grid does not fit an XCD's L2 next to the table's lines: every query paid a scattered 4-byte load for it (36.9 M per launch
 // at the config-5 share) before its 16-byte gather.  Results are bit-identical (skipped spheres cost exactly 0).
 constexpr int kLikMaskBlock = 256;
+#ifndef VG_LIK_PIPE_U
+#define VG_LIK_PIPE_U 4
+#endif
+constexpr int kLikPipeU = VG_LIK_PIPE_U;      // spheres per batch of the pipelined form (two batches in registers)
+#ifndef VG_LIK_PIPE
+#define VG_LIK_PIPE 1                         // 0: measurement builds with the un-pipelined register form in the four-wave kernel
+#endif
 template <int FARM>
 __global__ __launch_bounds__(kLikMaskBlock, 2) void loglik_paths_mask_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
                                                                             const float* __restrict__ f, int S, int L, int N,
@@ -762,15 +927,17 @@ __global__ __launch_bounds__(kLikMaskBlock, 2) void loglik_paths_mask_kernel(con
     const LikScratch sc{scratch + threadIdx.x, kLikMaskBlock};
     vg_dma_wait();
     __syncthreads();
-    const float lp = loglik_config_regs<kLikBatchU, false, FARM>(
-        rb, sdf, sc, [&](int j) { return f[base + (size_t)j * N]; },
-        [&](int j, float x, float& d) {
-            const float sg = 1.0f / (1.0f + __expf(-x));                        // likelihood.py:49-52
-            const float span = rb->joint_tab[j][7];
-            d = span * sg * (1.0f - sg);
-            return fmaf(span, sg, rb->joint_tab[j][5]);
-        },
-        [&](int j, float v) { if (live) G[base + (size_t)j * N] = scale * v; }, nullptr, 0.f, NoSig(), lmask);
+    auto raw_f = [&](int j) { return f[base + (size_t)j * N]; };
+    auto angle = [&](int j, float x, float& d) {
+        const float sg = 1.0f / (1.0f + __expf(-x));                        // likelihood.py:49-52
+        const float span = rb->joint_tab[j][7];
+        d = span * sg * (1.0f - sg);
+        return fmaf(span, sg, rb->joint_tab[j][5]);
+    };
+    auto put = [&](int j, float v) { if (live) G[base + (size_t)j * N] = scale * v; };
+    float lp;
+    if constexpr (FARM >= 4) lp = loglik_config_pipe<kLikPipeU, FARM == 4 ? 2 : FARM == 5 ? 1 : 0>(rb, sdf, sc, raw_f, angle, put, lmask);
+    else lp = loglik_config_regs<kLikBatchU, false, FARM>(rb, sdf, sc, raw_f, angle, put, nullptr, 0.f, NoSig(), lmask);
     if (live) logp[((size_t)pb * S + s) * N + n] = lp;
     const float w = vg_wave_sum(live ? lp : 0.f);
     if (lane == 0 && wv < nwaves) lik_partial[(size_t)pb * nwaves + wv] = w;
@@ -1392,8 +1559,9 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
     if (regs) {
         const bool pfx = L <= VG_LIK_PREFIX_MAX_DOF;      // the prefix-scalar form of the reverse sweep (a fourth LDS slot row)
         // free-space masks in LDS (four-wave workgroups; the per-wave partial sums and their count stay those of the one-wave form)
-        const size_t lds_mask = (size_t)sdf->mask_count * sdf->mask_words * 4 + (size_t)3 * L * kLikMaskBlock * sizeof(float);
-        if (!pfx && !sig && sdf->layout == VGPMP_SDF_BRICK4 && sdf->free_mask && sdf->mask_count > 0 && 2 * lds_mask <= 160 * 1024) {
+        const size_t lds_mask = (sdf->free_mask ? (size_t)sdf->mask_count * sdf->mask_words * 4 : 0) + (size_t)3 * L * kLikMaskBlock * sizeof(float);
+        const bool masks = sdf->layout == VGPMP_SDF_BRICK4 && sdf->free_mask && sdf->mask_count > 0;
+        if (!pfx && !sig && (masks || VG_LIK_PIPE) && 2 * lds_mask <= 160 * 1024) {
             auto gom = [&](auto kern) {
                 int rc = vg_grant_dyn_lds((const void*)kern, lds_mask);
                 if (rc) return rc;
@@ -1401,7 +1569,12 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
                                       scale, G, logp, lik_partial, nblk);
                 return (int)hipGetLastError();
             };
+#if VG_LIK_PIPE
+            // masks in LDS where the scene has them (one dependent global load per sphere), else the summary, else every sphere
+            return masks ? gom(loglik_paths_mask_kernel<4>) : far ? gom(loglik_paths_mask_kernel<5>) : gom(loglik_paths_mask_kernel<6>);
+#else
             return far ? gom(loglik_paths_mask_kernel<3>) : gom(loglik_paths_mask_kernel<2>);
+#endif
         }
         lds = (size_t)(pfx ? 4 : 3) * L * kLikBatchBlock * sizeof(float);
         if (pfx) {
