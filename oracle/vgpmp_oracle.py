@@ -811,6 +811,21 @@ def philox_normals(n: int, key: Tuple[int, int], stream: int) -> np.ndarray:
     return out.reshape(-1)[:n]
 
 
+def philox_normals8(n: int, key: Tuple[int, int], stream: int) -> np.ndarray:
+    """n standard normals, EIGHT per counter (the W stream; csrc/vgpmp_device.h::vg_normal8): word j of counter i // 8 gives the
+    Box-Muller pair (8 i + 2 j, 8 i + 2 j + 1) from two 16-bit uniforms u = (h + 1/2) 2^-16 -- radius from the low half of
+    the word, angle from the high half."""
+    nc = (n + 7) // 8
+    ctr = np.zeros((nc, 4), dtype=np.uint32)
+    ctr[:, 0] = np.arange(nc, dtype=np.uint32); ctr[:, 1] = np.uint32(stream)
+    r = philox4x32(ctr, key)
+    u_rad = ((r & np.uint32(0xFFFF)).astype(np.float64) + 0.5) * 2.0 ** -16
+    u_ang = ((r >> np.uint32(16)).astype(np.float64) + 0.5) * 2.0 ** -16
+    rad = np.sqrt(-2.0 * np.log(u_rad))
+    out = np.stack([rad * np.cos(2.0 * math.pi * u_ang), rad * np.sin(2.0 * math.pi * u_ang)], axis=-1)      # [nc, 4, 2]
+    return out.reshape(-1)[:n]
+
+
 def philox_uniforms(n: int, key: Tuple[int, int], stream: int) -> np.ndarray:
     nc = (n + 3) // 4
     ctr = np.zeros((nc, 4), dtype=np.uint32)
@@ -833,7 +848,7 @@ def philox_noise(seed: int, problem: int, step: int, S, L, D, B, Mz) -> Noise:
     gam = (chi * chi).sum(-1) / 5.0
     return Noise(omega=z / np.sqrt(gam)[..., None],
                  beta=2.0 * math.pi * philox_uniforms(L * B, key, STREAM_BETA).reshape(L, B),
-                 w=philox_normals(S * L * B, key, STREAM_W).reshape(S, L, B),
+                 w=philox_normals8(S * L * B, key, STREAM_W).reshape(S, L, B),
                  eps=philox_normals(S * Mz * L, key, STREAM_EPS).reshape(S, Mz, L),
                  eps2=philox_normals(S * Mz * L, key, STREAM_EPS2).reshape(S, Mz, L))
 

@@ -166,7 +166,10 @@ def test_free_space_masks_are_the_block_minima_against_the_clearances():
     (ragged extents; several radius classes), and the classes are epsilon + radius one float32 ulp up."""
     rng = np.random.default_rng(11)
     shape = (37, 22, 45)
-    data = rng.normal(0.15, 0.12, shape)
+    # a distance-like field (two balls) with a little noise: blocks far from both are free for every class, near ones for none
+    g = np.stack(np.meshgrid(*[0.05 * np.arange(n) for n in shape], indexing="ij"), axis=-1)
+    data = np.minimum(np.linalg.norm(g - [0.5, 0.4, 0.6], axis=-1) - 0.25, np.linalg.norm(g - [1.4, 0.8, 1.7], axis=-1) - 0.3)
+    data = data + rng.normal(0.0, 0.004, shape)
     spec = rb.synthetic_arm(14)
     spec.sphere_radii = np.asarray([0.03, 0.05, 0.08] * 15, dtype=np.float64)
     for budget, shift in ((32 << 10, 2), (200, 3)):

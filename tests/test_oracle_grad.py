@@ -95,7 +95,23 @@ def test_philox_known_answer_and_moments():
     assert [int(v) for v in o] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     n = orc.philox_normals(200000, orc.philox_key(7, 3, 11), orc.STREAM_W)
     assert abs(n.mean()) < 0.01 and abs(n.std() - 1.0) < 0.01
+    # the W stream: eight normals per counter (a Box-Muller pair per 32-bit word, 16-bit uniforms): moments, the bound
+    # |z| <= sqrt(-2 ln 2^-17) of the coarser radius, independence of the two members of a pair and of neighbouring pairs,
+    # and the word -> element map (element 8 i + 2 j + {0, 1} from word j of counter i)
+    key = orc.philox_key(7, 3, 11)
+    w = orc.philox_normals8(400000, key, orc.STREAM_W)
+    assert abs(w.mean()) < 0.005 and abs(w.std() - 1.0) < 0.005
+    assert abs((w ** 4).mean() - 3.0) < 0.06 and abs((w ** 3).mean()) < 0.03
+    assert np.abs(w).max() <= np.sqrt(-2.0 * np.log(2.0 ** -17)) + 1e-12
+    assert abs(np.corrcoef(w[0::2], w[1::2])[0, 1]) < 0.01 and abs(np.corrcoef(w[:-2:2], w[2::2])[0, 1]) < 0.01
+    from scipy import stats
+    assert stats.kstest(w[:100000], "norm").pvalue > 1e-3
+    r = orc.philox4x32(np.array([[5, orc.STREAM_W, 0, 0]], dtype=np.uint32), key)[0]
+    u_rad, u_ang = ((int(r[2]) & 0xFFFF) + 0.5) / 65536.0, ((int(r[2]) >> 16) + 0.5) / 65536.0
+    np.testing.assert_allclose(w[8 * 5 + 4: 8 * 5 + 6], np.sqrt(-2 * np.log(u_rad)) * np.array([np.cos(2 * np.pi * u_ang), np.sin(2 * np.pi * u_ang)]),
+                               rtol=1e-13)
     nz = orc.philox_noise(7, 0, 0, S=64, L=3, D=3, B=256, Mz=6)
+    np.testing.assert_array_equal(nz.w.reshape(-1), orc.philox_normals8(64 * 3 * 256, orc.philox_key(7, 0, 0), orc.STREAM_W))
     # Student-t(5) spectral draw: variance nu/(nu-2) = 5/3
     assert abs(nz.omega.var() - 5.0 / 3.0) < 0.25 and 0 <= nz.beta.min() and nz.beta.max() <= 2 * np.pi
 

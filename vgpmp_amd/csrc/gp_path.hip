@@ -467,7 +467,7 @@ static RngArgs make_rng_args(const vgpmp_dims* d, const vgpmp_noise* nz, uint32_
                              uint32_t step, const uint32_t* ctr, uint32_t bias) {
     RngArgs r;
     r.L = d->L; r.B = d->B; r.D = d->L;
-    r.nW = (uint32_t)d->S * d->L * d->B;                 // nW % 4 == 0 since B % 16 == 0
+    r.nW = (uint32_t)d->S * d->L * d->B;                 // nW % 16 == 0 since B % 16 == 0
     r.nE = (uint32_t)d->S * vg_mz(d) * d->L;
     r.wOff = (uint32_t)d->sample_offset * d->L * d->B;
     r.eOff = (uint32_t)d->sample_offset * vg_mz(d) * d->L;
@@ -768,7 +768,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         return (unsigned)ma.n_norm + (unsigned)ma.e_gx * P;
     };
     const uint32_t basis_gx = ((uint32_t)L * B + kBlock - 1) / kBlock;
-    const uint32_t w_gx = (((uint32_t)S * L * B >> 2) + kBlock - 1) / kBlock;
+    const uint32_t w_gx = (((uint32_t)S * L * B >> 3) + kBlock - 1) / kBlock;      // a thread per counter of the W stream: eight normals
     auto launch = [&](const void* fn, dim3 grid, void* arg, size_t lds) -> int {
         void* kargs[] = {arg};
         return (int)hipLaunchKernel(fn, grid, dim3(kBlock), kargs, lds, st);

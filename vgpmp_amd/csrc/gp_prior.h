@@ -438,9 +438,9 @@ __device__ __forceinline__ void prior_fused_batch_body(const FusedBatchArgs& a, 
     // features -- thread (kcol = tid % 16, jg = tid / 16) forms rows jg, jg + 16, ... of column kcol;
     // frequencies -- thread t < 16 D fetches element t of the step's 16 contiguous rows of omega, t < 16 + 16 D a phase
     const int wrow = tid >> 2, wq = tid & 3;
-    uint32_t wbase[MT];                                  // counter of (row, column 0); rows wrow, wrow + 64
+    uint32_t wbase[MT];                                  // W counter of (row, column 0): eight columns each; rows wrow, wrow + 64
 #pragma unroll
-    for (int m = 0; m < MT; ++m) wbase[m] = (a.wOff + ((uint32_t)min(s0 + wrow + kTS * m, S - 1) * L + l) * (uint32_t)B) >> 2;
+    for (int m = 0; m < MT; ++m) wbase[m] = (a.wOff + ((uint32_t)min(s0 + wrow + kTS * m, S - 1) * L + l) * (uint32_t)B) >> 3;
     const int kcol = tid & 15, jg = tid >> 4;
     const int nom = kFBK * D;
     const bool is_om = tid < nom, is_bt = tid >= nom && tid < nom + kFBK;
@@ -464,7 +464,11 @@ __device__ __forceinline__ void prior_fused_batch_body(const FusedBatchArgs& a, 
             if ((is_om || is_bt) && k0 + kFBK < B) onext = osrc[(size_t)(k0 / kFBK + 1) * ostep];
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const float4 w4 = vg_normal4(wbase[m] + (uint32_t)((k0 >> 2) + wq), VG_STREAM_W, key);
+                // (a W counter holds eight normals: the threads of quads 2 h and 2 h + 1 draw the same one and keep a half each --
+                //  this float32 form is the measurement / reference form of the large-batch draw, gp_prior_split.h the product)
+                float z[8];
+                vg_normal8(wbase[m] + (uint32_t)((k0 >> 3) + (wq >> 1)), VG_STREAM_W, key, z);
+                const float4 w4 = (wq & 1) ? make_float4(z[4], z[5], z[6], z[7]) : make_float4(z[0], z[1], z[2], z[3]);
                 *reinterpret_cast<float4*>(As + (wrow + kTS * m) * kFBLd + 4 * wq) = w4;
             }
             float om[DM];

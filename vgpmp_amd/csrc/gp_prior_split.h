@@ -19,8 +19,9 @@
 // workgroups per CU (<= 128 VGPRs, 76 KB of LDS) = four waves per SIMD -- the vector ALU needs that many to issue at its
 // full rate -- and the two workgroups drift apart, so one's product phase runs beside the other's generation phase.
 // Per K step:
-//   * W: a thread draws MT Philox counters (4 normals of a W row each; one v_mad_u64_u32 per 32 x 32 -> 64 product),
-//     splits them and stores 8 bytes into each half tile;
+//   * W: a thread draws ONE Philox counter = eight normals of a W row (vg_normal8: a Box-Muller pair per 32-bit word; one
+//     v_mad_u64_u32 per 32 x 32 -> 64 product, one v_bitop3_b32 per three-way xor), splits them and stores 16 bytes into each
+//     half tile -- the generator was two thirds of the kernel's vector instructions with four normals per counter;
 //   * features: the projections x . omega of the tile's 144 points on the step's 32 frequencies are themselves f16-split
 //     products: A = [omega_hi | omega_lo] (joint coordinates 0..15 twice along K = 32), B1 = [x_hi | x_hi], B2 = [x_lo | 0],
 //     so TWO MFMAs give omega_hi x_hi + omega_lo x_hi + omega_hi x_lo for a 16 x 16 block.  A lane then holds four adjacent
@@ -60,20 +61,17 @@ __device__ __forceinline__ uint4 vg_philox_mad(uint4 c, uint2 k) {
         unsigned long long p0, p1;
         asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p0) : "v"(c.x), "s"(0xD2511F53u) : "vcc");
         asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p1) : "v"(c.z), "s"(0xCD9E8D57u) : "vcc");
-        c = make_uint4((uint32_t)(p1 >> 32) ^ c.y ^ k.x, (uint32_t)p1, (uint32_t)(p0 >> 32) ^ c.w ^ k.y, (uint32_t)p0);
+        // (three-input xor in one v_bitop3_b32: the compiler emits two v_xor_b32 for the C form)
+        c = make_uint4(__builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c.y, k.x, 0x96), (uint32_t)p1,
+                       __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c.w, k.y, 0x96), (uint32_t)p0);
         k.x += 0x9E3779B9u;
         k.y += 0xBB67AE85u;
     }
     return c;
 }
-// vg_normal4 on it: the same expressions, hence the same four normals
-__device__ __forceinline__ float4 vg_normal4_mad(uint32_t i, uint32_t stream, uint2 key) {
-    uint4 r = vg_philox_mad(make_uint4(i, stream, 0u, 0u), key);
-    const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(vg_u01(r.x)));
-    const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(vg_u01(r.z)));
-    const float u1 = vg_u01(r.y), u3 = vg_u01(r.w);
-    return make_float4(r0 * __builtin_amdgcn_cosf(u1), r0 * __builtin_amdgcn_sinf(u1),
-                       r1 * __builtin_amdgcn_cosf(u3), r1 * __builtin_amdgcn_sinf(u3));
+// vg_normal8 on it: the same expressions, hence the same eight normals
+__device__ __forceinline__ void vg_normal8_mad(uint32_t i, uint32_t stream, uint2 key, float (&z)[8]) {
+    vg_normal8_from(vg_philox_mad(make_uint4(i, stream, 0u, 0u), key), z);
 }
 
 __device__ __forceinline__ float vg_uniform(float x) {
@@ -139,11 +137,11 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
     const float rs = vg_uniform(inv_ell * kInv2Pi);
     const uint2 key = vg_key(a.seed, a.problem_base + p, a.ctr ? *a.ctr : a.step);
     // ---- generation roles
-    // W: MT = 2: thread (row = tid / 4, part = tid % 4) draws the 8 normals of k = 8 part .. 8 part + 7 (two counters);
-    //    MT = 1: thread (row = tid / 8, part = tid % 8) the 4 normals of k = 4 part .. 4 part + 3 (one counter)
-    constexpr int kWShift = MT == 2 ? 2 : 3;
-    const int wrow = tid >> kWShift, wpart = tid & ((1 << kWShift) - 1);
-    const uint32_t wbase = ((a.wOff + ((uint32_t)min(s0 + wrow, S - 1) * L + l) * (uint32_t)B) >> 2) + (uint32_t)wpart * MT;
+    // W: thread (row = tid / 4, part = tid % 4) draws the 8 normals of k = 8 part .. 8 part + 7: ONE counter of the W stream
+    //    (vg_normal8).  MT = 2: all 512 threads (128 rows); MT = 1: the first four waves (64 rows), the others start on the features
+    const int wrow = (tid >> 2) & (kRows - 1), wpart = tid & 3;
+    const bool draws_w = MT == 2 || wave < 4;
+    const uint32_t wbase = ((a.wOff + ((uint32_t)min(s0 + wrow, S - 1) * L + l) * (uint32_t)B) >> 3) + (uint32_t)wpart;
     // frequencies: element e of the step's 32 contiguous rows of omega (32 D floats), then the 32 phases
     const int n_om = kHK * D, n_ob = n_om + kHK;
     constexpr int kONext = (kHK * kHD + kHK + kHThreads - 1) / kHThreads;      // loads per thread (2 up to 16 joints)
@@ -192,20 +190,25 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
         // ================= generate the K step's operands (the next step's frequencies are requested first, stored last)
         const bool more = k0 + kHK < B;
         if (more) om_fetch(k0 + kHK);
-        // ---- W: counter m of the thread covers k = 4 kq .. 4 kq + 3, kq = MT wpart + m: 8 bytes of each half tile
-#pragma unroll
-        for (int m = 0; m < ((VG_HS_SKIP & 2) ? 0 : MT); ++m) {
-            const int kq = wpart * MT + m;
-            const float4 w4 = vg_normal4_mad(wbase + (uint32_t)(k0 >> 2) + (uint32_t)m, VG_STREAM_W, key);
-            vg_h4 hi, lo;
-            vg_split4((vg_f32x4){w4.x, w4.y, w4.z, w4.w}, hi, lo);
-            const int off = wrow * kHRowBytes + vg_swz(wrow, kq >> 1) * 16 + (kq & 1) * 8;
-            *reinterpret_cast<vg_h4*>(Ah + off) = hi;
-            *reinterpret_cast<vg_h4*>(Al + off) = lo;
+        // ---- W: the thread's counter covers k = 8 wpart .. 8 wpart + 7: one 16-byte chunk of each half tile
+        if (!(VG_HS_SKIP & 2) && draws_w) {      // (uniform per wave)
+            float z[8];
+            vg_normal8_mad(wbase + (uint32_t)(k0 >> 3), VG_STREAM_W, key, z);
+            vg_h4 h0, l0, h1, l1;
+            vg_split4((vg_f32x4){z[0], z[1], z[2], z[3]}, h0, l0);
+            vg_split4((vg_f32x4){z[4], z[5], z[6], z[7]}, h1, l1);
+            const int off = wrow * kHRowBytes + vg_swz(wrow, wpart) * 16;
+            *reinterpret_cast<vg_h8*>(Ah + off) = (vg_h8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+            *reinterpret_cast<vg_h8*>(Al + off) = (vg_h8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
         }
         // ---- features: unit u = (point tile t, frequency half h) -> a 16 x 16 block of projections by two MFMAs;
         //      lane (r, g) then holds point 16 t + r against the frequencies 16 h + 4 g .. + 3
-        for (int u = (VG_HS_SKIP & 4) ? 18 : wave; u < 2 * (kTJ / 16); u += kHThreads / 64) {
+        // (MT = 1: waves 4-7, which draw no W, take the first twelve units, three each; waves 0-3 the last six)
+        constexpr int kUnits = 2 * (kTJ / 16);
+        const int u_first = MT == 2 ? wave : (wave >= 4 ? wave - 4 : 12 + wave);
+        const int u_last = MT == 2 ? kUnits : (wave >= 4 ? 12 : kUnits);
+        const int u_step = MT == 2 ? kHThreads / 64 : 4;
+        for (int u = (VG_HS_SKIP & 4) ? kUnits : u_first; u < u_last; u += u_step) {
             const int t = u >> 1, h = u & 1;
             const int frow = 16 * h + r, prow = 16 * t + r;
             const vg_h8 fa = *reinterpret_cast<const vg_h8*>(Om + (ob * kHK + frow) * kHRowBytes + vg_swz(frow, g) * 16);

@@ -59,24 +59,27 @@ __device__ __forceinline__ void rng_basis_body(const RngArgs& a, int bx, int p, 
     }
 }
 
-// w [P, nW]: counter i of the stream yields global elements 4i..4i+3 (wOff is a multiple of 4);
+// w [P, nW]: counter i of the stream yields global elements 8i..8i+7 (vg_normal8; wOff and nW are multiples of 16: B is);
 // eps, eps2 [P, nE]: a thread per COUNTER of the stream as well -- elements eOff .. eOff + nE - 1 of the global sample axis,
 // which need not start on a counter (sample-sharded ranks): the first and last counters of a rank are partly its neighbours'.
 __host__ __device__ __forceinline__ uint32_t rng_eps_quads(uint32_t nE, uint32_t eOff) {
     return nE ? ((eOff + nE - 1u) >> 2) - (eOff >> 2) + 1u : 0u;
 }
 __host__ __device__ __forceinline__ uint32_t rng_normal_threads(uint32_t nW, uint32_t nE, uint32_t eOff) {
-    return (nW >> 2) + 2u * rng_eps_quads(nE, eOff);
+    return (nW >> 3) + 2u * rng_eps_quads(nE, eOff);
 }
 __device__ __forceinline__ void rng_normals_body(const RngArgs& a, int bx, int p, uint32_t nW, uint32_t nE) {
-    const uint32_t cW = nW >> 2, nq = rng_eps_quads(nE, a.eOff);
+    const uint32_t cW = nW >> 3, nq = rng_eps_quads(nE, a.eOff);
     uint32_t c = bx * kBlock + threadIdx.x;
     VG_T(bx == 0 && p == 0, nW ? 320 : 120);
     if (c >= cW + 2u * nq) return;
     const uint2 key = vg_key(a.seed, a.problem_base + p, rng_step(a));
     if (c < cW) {
-        const float4 v = vg_normal4((a.wOff >> 2) + c, VG_STREAM_W, key);
-        vg_stream(reinterpret_cast<float4*>(a.w + (size_t)p * nW + 4u * c), v);
+        float z[8];
+        vg_normal8((a.wOff >> 3) + c, VG_STREAM_W, key, z);
+        float4* dst = reinterpret_cast<float4*>(a.w + (size_t)p * nW + 8u * c);
+        vg_stream(dst, make_float4(z[0], z[1], z[2], z[3]));
+        vg_stream(dst + 1, make_float4(z[4], z[5], z[6], z[7]));
         VG_T(bx == 0 && p == 0, 321);
         VG_T(c + kBlock >= cW && p == 0, 325);
         return;

@@ -239,6 +239,25 @@ __device__ __forceinline__ float4 vg_normal4(uint32_t i, uint32_t stream, uint2 
     return make_float4(r0 * __builtin_amdgcn_cosf(u1), r0 * __builtin_amdgcn_sinf(u1),
                        r1 * __builtin_amdgcn_cosf(u3), r1 * __builtin_amdgcn_sinf(u3));
 }
+// The W stream (prior weights: by far the largest draw of a step, S L B normals per problem) spends ONE counter per EIGHT
+// normals: every 32-bit word of the Philox block gives one Box-Muller pair from two 16-bit uniforms, radius from the low half,
+// angle from the high half, u = (h + 1/2) 2^-16.  (Element 8 i + 2 j + {0, 1} of the stream comes from word j of counter i.)
+// Sixteen bits put 65 536 radii x 65 536 directions under every pair and bound |z| by 4.71; mean 0 exactly (the directions are
+// symmetric), variance 1 - 4e-6.  Identical restatement: oracle/vgpmp_oracle.py::philox_normals8.
+__device__ __forceinline__ float vg_u01_16(uint32_t h) { return ((float)h + 0.5f) * 1.52587890625e-05f; }
+__device__ __forceinline__ void vg_normal8_from(uint4 r, float (&z)[8]) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(vg_u01_16(w[j] & 0xffffu)));
+        const float ang = vg_u01_16(w[j] >> 16);
+        z[2 * j] = rad * __builtin_amdgcn_cosf(ang);
+        z[2 * j + 1] = rad * __builtin_amdgcn_sinf(ang);
+    }
+}
+__device__ __forceinline__ void vg_normal8(uint32_t i, uint32_t stream, uint2 key, float (&z)[8]) {
+    vg_normal8_from(vg_philox(make_uint4(i, stream, 0u, 0u), key), z);
+}
 __device__ __forceinline__ float vg_lane(const float4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
 __device__ __forceinline__ float vg_normal1(uint32_t e, uint32_t stream, uint2 key) {
     return vg_lane(vg_normal4(e >> 2, stream, key), (int)(e & 3u));
