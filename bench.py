@@ -230,6 +230,24 @@ def cpu_baseline(ps, spec, grid, args, budget_s: float = 10.0, pool=None):
     return out
 
 
+def oracle_plan_check(n_queries: int = 3):
+    """The float64 oracle run as a PLANNER on the first queries of the industrial problem set at the reference's own planner
+    parameters (data/problemsets/franka.py:77-90), noise = the device's Philox stream (seed 0, problem = query, step): the
+    clearance of its posterior-mean path after num_steps, to be read beside the device's (tests/plan_report.py; the same
+    comparison is asserted by tests/test_gpu_plans.py).  Part of the CPU leg: the only place bench.py runs the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import plan_report
+    rep, (ps, spec, grid, pp, pl) = plan_report.device_report("franka", "industrial")
+    out = []
+    for k in range(n_queries):
+        o = plan_report.oracle_plan(ps, spec, grid, pp, k)
+        d = rep["queries"][k]
+        out.append({"query": k, "oracle_mean_path_clearance": round(o["mean_path"], 4), "device_mean_path_clearance": round(d["mean_path"], 4),
+                    "device_best_sample_clearance": round(d["best_sample"], 4), "oracle_loss_first_last": [round(o["loss_first"], 1), round(o["loss_last"], 1)],
+                    "device_loss_first_last": [round(d["loss_first"], 1), round(d["loss_last"], 1)]})
+    return {"planner_params": "the reference's own (S=20 M=10 T=50, 200 steps, lr 0.02)", "queries": out}
+
+
 class CpuPool:
     """One single-threaded oracle process per core, over independent start-goal problems of the bench workload.  The children
     are started BEFORE the parent touches the GPU (fresh interpreters of this script in `--cpu-worker` mode; they never import
@@ -390,12 +408,17 @@ def measured_solves(args, world, rank, dist, backend):
     res = batched(env, queries)
     torch.cuda.synchronize()
     tb = time.perf_counter() - t0
+    # are the plans plans?  per query: clearance of its own end states, of the straight line it starts from, of the best sample
+    rep = {}
+    res_rep = batched(env, queries, report=rep)
+    quality = plan_quality(rep, [bool(r[0]) for r in res_rep])
     tot = float(sum(per))
     if dist is not None:
         t = torch.tensor([tot, tb], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         tot, tb = float(t[0]), float(t[1])
-    return {"plans_per_sec_measured": world * len(per) / tot,
+    return {"plan_quality": quality,
+            "plans_per_sec_measured": world * len(per) / tot,
             "plans_per_sec_batched_measured": world * len(queries) / tb,
             "plan_measurement": f"{len(per)} sequential solve_planning_problem() calls per rank after one warm-up call "
                                 f"({pp['num_steps']} steps, S={pp['num_samples']} M={pp['num_inducing']} T={pp['time_spacing_X']}, "
@@ -403,6 +426,26 @@ def measured_solves(args, world, rank, dist, backend):
                                 f"{1e3 * tot / len(per):.2f} ms per plan, {solved}/{len(per)} paths collision-free on rank 0; "
                                 f"solve_planning_problems_batched on all {len(queries)} industrial queries as one device batch: "
                                 f"{1e3 * tb:.1f} ms, {sum(int(r[0]) for r in res)}/{len(queries)} collision-free"}
+
+
+def plan_quality(rep, solved):
+    """Summary of solve_planning_problems_batched's clearance report (metres, signed: distance to the obstacles minus the sphere
+    radius, minimum over spheres and time).  `solved` is the strict headless check (best sample clear everywhere, end states
+    included); `within_end_states` accepts what the query's own end states already violate."""
+    import numpy as np
+    st, go, ini, best = (np.asarray(rep[k]) for k in ("start", "goal", "initial_path", "best_sample"))
+    free_ends = (st > 0) & (go > 0)
+    floor = np.minimum(0.0, np.minimum(st, go))
+    r3 = lambda a: [round(float(v), 4) for v in a]
+    return {"queries": int(st.size), "end_states_collision_free": int(free_ends.sum()),
+            "initial_straight_line_clear": int((ini > 0).sum()),
+            "solved": int(np.sum(solved)), "solved_among_free_end_states": int(np.sum(np.asarray(solved) & free_ends)),
+            "within_end_states": int((best >= floor - 1e-3).sum()),
+            "not_worse_than_initial": int((best >= ini - 1e-3).sum()),
+            "clearance_start": r3(st), "clearance_goal": r3(go), "clearance_initial_path": r3(ini), "clearance_best_sample": r3(best),
+            "note": "signed clearance by the planner's own sphere model against the mesh-generated SDF; the reference counts a query "
+                    "solved when pybullet can drive the arm along the path (utils/robot.py:455-480): link meshes, not inflated spheres. "
+                    "A query whose start or goal state has negative clearance by the spheres cannot pass the strict check"}
 
 
 def timed_region(run_steps, args, dist, backend):
@@ -725,6 +768,8 @@ def main():
                 torch.cuda.synchronize()
                 line["cpu_baseline"] = cpu_baseline(*ctx, pool=pool)
                 pool = None
+                if default_workload and not args.no_solve:
+                    line["cpu_baseline"]["oracle_plan_check"] = oracle_plan_check()
                 line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
                 pp_ = line["cpu_baseline"].get("problem_parallel")
                 if pp_ and pp_.get("value") and "batch_64" in line:

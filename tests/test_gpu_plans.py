@@ -1,0 +1,156 @@
+"""Are the plans plans?    GPU tests through the C ABI:
+
+* the optimisation TRAJECTORY with the device's own generated noise against the float64 oracle driven by the identical Philox
+  stream (oracle.philox_noise), as an 8-problem batch -- at the reference's own planner parameters (few samples: the
+  few-sample fused prior kernel) and at BASELINE config 2's sizes (the large-batch schedule: f16-split prior kernel with the
+  weights drawn inside the GEMM, register-resident path kernels, batch likelihood) -- the end-to-end check that injected-noise
+  tests cannot give for kernels that never materialise W;
+* plan quality on the reference's industrial problem set: what the headless success check (clearance > 0 everywhere) can and
+  cannot say, and that optimisation improves clearance wherever the query's own end states allow it;
+* the oracle run as a planner reaches the same clearance as the device.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vgpmp_oracle as orc
+from helpers import oracle_scene
+import plan_report
+from vgpmp_amd import robots as rb
+from vgpmp_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def industrial():
+    from vgpmp_amd import engine
+    ps = rb.load_problemset("franka", "industrial")
+    spec = rb.load_robot("franka", *ps.robot_pos_and_orn)
+    grid = scenes.scene_sdf("industrial", delta=0.0125, padding=20)
+    return engine, ps, spec, grid
+
+
+# (planner parameters, steps compared, relative tolerance on the per-step loss at the first / last compared step)
+@pytest.mark.parametrize("name,over,steps", [("reference", {}, 20),
+                                             ("config2", dict(num_samples=128, num_inducing=30, time_spacing_X=100), 8)])
+def test_generated_noise_trajectory_against_oracle(industrial, name, over, steps):
+    """-ELBO of every optimisation step, device (noise drawn by the device generator, seed 77) against the oracle
+    (orc.philox_noise of the same seed / problem / step), eight problems in one batch.  The two differ by float32 arithmetic
+    and by nearest-voxel flips of float32 sphere centres; Adam (which normalises every gradient entry) lets that grow slowly
+    with the step: tolerance 2e-3 relative at the first step, 2e-2 at the last."""
+    engine, ps, spec, grid = industrial
+    pp = dict(ps.planner_params, **over)
+    S, M, N, B, D = int(pp["num_samples"]), int(pp["num_inducing"]), int(pp["time_spacing_X"]), 1024, spec.dof
+    sc = engine.DeviceScene(spec, grid, ps.object_positions[0], sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"])
+    osc = oracle_scene(spec, grid, ps.object_positions[0], sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"])
+    pick = [0, 2, 9, 10, 21, 24, 28, 35]                   # easy and hard queries of the set
+    qs = np.array([ps.queries[k] for k in pick], dtype=np.float64)
+    seed, base = 77, 5
+    pl = engine.PlannerBatch(sc, qs, num_samples=S, num_inducing=M, num_data=N, lengthscales=pp["lengthscales"],
+                             variance=pp["variance"], alpha=pp["alpha"], learning_rate=pp["learning_rate"], seed=seed,
+                             problem_base=base)
+    if name == "config2":
+        assert pl.dims.split_k == 1                         # the large-batch schedule: prior draws by the f16-split kernel
+    dev_loss = np.zeros((steps, len(pick)))
+    for t in range(steps):
+        pl.step()
+        dev_loss[t] = (-(pl.lik - pl.kl)).cpu().numpy()
+    X, Zy = orc.init_trainset(N, D), orc.inducing_Zy(M, D)
+    check = range(len(pick)) if name == "reference" else (0, 3, 7)       # (the oracle takes ~0.2 s per config-2 step)
+    worst = 0.0
+    for k in check:
+        y = qs[k]
+        p = orc.init_params(osc.robot, y, M, pp["lengthscales"], pp["variance"])
+        st = orc.adam_init(p)
+        for t in range(steps):
+            nz = orc.philox_noise(seed, base + k, t, S, D, D, B, M + 2)
+            want = orc.optimization_step(p, st, osc, X, Zy, y, nz, float(pp["alpha"]), float(pp["learning_rate"]))
+            tol = 2e-3 + (2e-2 - 2e-3) * t / max(steps - 1, 1)
+            rel = abs(dev_loss[t, k] - want) / abs(want)
+            worst = max(worst, rel / tol)
+            assert rel <= tol, (name, k, t, dev_loss[t, k], want, rel)
+        # the variables after the last step: Adam normalises every entry, float32-level gradient differences move one by
+        # ~lr * 1e-3 per step at most
+        tolp = steps * float(pp["learning_rate"]) * 2e-2
+        assert np.abs(pl.q_mu[k].cpu().numpy().T - p.q_mu).max() < tolp
+        assert np.abs(pl.raw_ell[k].cpu().numpy() - p.raw_ell).max() < tolp
+    assert dev_loss[-1].sum() < dev_loss[0].sum()
+    print(f"{name}: worst per-step loss deviation / tolerance = {worst:.3f}")
+
+
+def test_plans_on_the_industrial_problem_set(industrial):
+    """All 36 queries at the reference's own planner parameters.  By the planner's sphere model against the mesh-generated SDF
+    four of the nine states of the set touch the obstacles themselves (by up to 2.2 cm), so only C(5,2) = 10 queries CAN pass
+    the strict headless check; the others end exactly at what their end states allow.  Assertions that fail if optimisation
+    stops improving clearance:
+      * no query ends worse than the straight line it started from;
+      * at least 8 of the queries with collision-free end states are solved (9 measured), although at most 3 start on a clear line;
+      * at least 30 of 36 end within what their own end states violate (33 measured);
+      * the `solved` flag of solve_planning_problems_batched is exactly "best sample clear everywhere and inside the limits"."""
+    rep, _ = plan_report.device_report("franka", "industrial")
+    q = rep["queries"]
+    assert len(q) == 36
+    bad_states = [s["state"] for s in rep["states"] if s["clearance"] <= 0]
+    assert len(bad_states) == 4, rep["states"]
+    free = [r for r in q if r["start"] > 0 and r["goal"] > 0]
+    assert len(free) == 10
+    assert all(r["best_sample"] >= r["initial_path"] - 1e-3 for r in q), [r for r in q if r["best_sample"] < r["initial_path"] - 1e-3]
+    assert sum(r["initial_path"] > 0 for r in q) <= 3
+    assert sum(r["best_sample"] > 0 for r in free) >= 8
+    floor = lambda r: min(0.0, r["start"], r["goal"])
+    assert sum(r["best_sample"] >= floor(r) - 1e-3 for r in q) >= 30
+    assert all(r["loss_last"] < 0.2 * r["loss_first"] for r in q if r["initial_path"] < -0.02)
+    # the driver-facing flag
+    from gpflow_vgpmp.utils.miscellaneous import solve_planning_problems_batched
+    from gpflow_vgpmp.utils.simulation_manager import SimulationManager
+    import warnings
+    from pathlib import Path
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        env = SimulationManager(file_path=Path(__file__).resolve().parent.parent / "parameters.yaml")
+    info = {}
+    out = solve_planning_problems_batched(env, env.config["scene_params"]["queries"], report=info)
+    low, high = env.robot.spec.low, env.robot.spec.high
+    for (solved, traj), best in zip(out, info["best_sample"]):
+        inside = bool(((traj >= low - 1e-9) & (traj <= high + 1e-9)).all())
+        assert solved == (best > 0.0 and inside)
+    assert sum(int(s) for s, _ in out) >= 7
+
+
+def test_oracle_as_a_planner_reaches_the_device_clearance(industrial):
+    """Two queries, 200 steps at the reference's parameters, the oracle on the device's Philox stream: posterior-mean path
+    clearance within 5 mm of the device's, final loss within 15 % (mean of the oracle's last ten steps)."""
+    engine, ps, spec, grid = industrial
+    rep, (ps2, spec2, grid2, pp, pl) = plan_report.device_report("franka", "industrial")
+    for k in (2, 0):
+        o = plan_report.oracle_plan(ps, spec, grid2, pp, k)
+        d = rep["queries"][k]
+        assert abs(o["mean_path"] - d["mean_path"]) < 5e-3, (k, o, d)
+        assert abs(o["loss_last"] - d["loss_last"]) < 0.15 * abs(o["loss_last"]) + 20.0, (k, o, d)
+
+
+def test_a_blocked_straight_line_is_planned_around():
+    """A scene built to be solvable: one ball in the way of the straight line between two collision-free states.  The initial
+    path hits it by centimetres; after optimisation the best sample clears it."""
+    from vgpmp_amd import engine
+    spec = rb.load_robot("franka")
+    n, delta, origin = 96, 0.02, np.array([-0.96, -0.96, -0.3])
+    start = np.array([-0.9, 0.4, 0.0, -1.6, 0.0, 2.0, 0.8])
+    goal = np.array([0.9, 0.4, 0.0, -1.6, 0.0, 2.0, 0.8])
+    # the ball sits where the hand passes half way along the straight line
+    sc0 = engine.DeviceScene(spec, (np.full((8, 8, 8), 5.0), np.zeros(3), 1.0), (0, 0, 0))
+    mid = sc0.fk_spheres(torch.tensor(0.5 * (start + goal)[None], dtype=torch.float32))[0].cpu().numpy()
+    centre, radius = mid[-1] + np.array([0.0, 0.0, 0.0]), 0.10
+    g = np.stack(np.meshgrid(*[origin[i] + delta * np.arange(n) for i in range(3)], indexing="ij"), axis=-1)
+    data = np.linalg.norm(g - centre, axis=-1) - radius
+    sc = engine.DeviceScene(spec, (data, origin, delta), (0, 0, 0), sigma_obs=0.005, epsilon=0.05)
+    pl = engine.PlannerBatch(sc, np.array([[start, goal]]), num_samples=32, num_inducing=12, num_data=60, lengthscales=[2.0] * 7,
+                             variance=0.2, alpha=100.0, learning_rate=0.02, seed=3)
+    c0, c1, cl = pl.query_clearances(100)
+    assert float(c0) > 0.02 and float(c1) > 0.02 and float(cl) < -0.03, (float(c0), float(c1), float(cl))
+    pl.run_steps(250)
+    Xnew = np.tile(np.linspace(0.0, 1.0, 100)[:, None], (1, 7))
+    mean, best, _, _ = pl.sample_from_posterior(150, Xnew, step=pl.t)
+    cb = float(pl.path_clearance(best).min())
+    assert cb > 0.0, cb

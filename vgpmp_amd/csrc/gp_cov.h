@@ -834,7 +834,9 @@ __global__ __launch_bounds__(kCovThreads) void cov_b_kernel(CovArgs a) {
 //   A_ell = (dKfu/dell - A dKuu/dell) Kinv,   A_var = (jitter / var) A Kinv
 // Output float32: A4[n][m] = {A, A_ell, A_var, 0} (one 16-byte load per use in the reverse pass)
 // and AT[m][n] for the forward path assembly.
+__device__ void cov_rows_padded_body(const CovArgs& a, double* sm, int wg_tile, int l, int p, int tid, int nt);
 __device__ void cov_rows_body(const CovArgs& a, double* sm, int wg_tile, int l, int p, int tid, int nt) {
+    if (a.M + 2 != 32) { cov_rows_padded_body(a, sm, wg_tile, l, p, tid, nt); return; }
     const int M = a.M, Mz = M + 2, N = a.N, L = a.L, D = a.D, ld = (Mz + 2) & ~1;
     // a workgroup walks `tpw` consecutive tiles (large batches: Lk^-1, dKuu/dell and (Kuu + jI)^-1 once for both of them -- one
     // tile per workgroup re-stages 16 KB and redoes the 32^3 product for every 8 time points, 13 times per latent at N = 100)
@@ -963,51 +965,107 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int wg_tile, int l, 
         VG_T(tile == 0 && l == 0 && p == 0, 231);
         return;
     }
-    for (int tt = 0; tt < tpw; ++tt) {
-        const int n0 = n00 + tt * kRowTile;
+    VG_T(tile == 0 && l == 0 && p == 0, 231);
+}
+
+// The rows role for any other Mz: the same four products on the float64 matrix cores with every operand zero padded to
+// Mp = roundup(Mz, 16) columns (one to three column tiles).  The scalar form this replaces read both operands of every
+// output from LDS -- at config 3 (Mz = 26: 385 latents x 9 tiles) it made stage B 52 us of a 183 us step.
+__device__ void cov_rows_padded_body(const CovArgs& a, double* sm, int wg_tile, int l, int p, int tid, int nt) {
+    const int M = a.M, Mz = M + 2, N = a.N, L = a.L, D = a.D;
+    const int Mp = (Mz + 15) & ~15, ld = Mp + 2, ct = Mp >> 4;
+    const int tpw = max(a.rows_tpw, 1), tile = wg_tile * tpw;
+    VG_T(tile == 0 && l == 0 && p == 0, 230);
+    const size_t pl = (size_t)p * L + l;
+    double* Ki = sm;                       // [Mp][ld]  (Kuu + jI)^-1, zero padded
+    double* Kd = Ki + Mp * ld;             // [Mp][ld]  dKuu/dell
+    double* Lt = Kd + Mp * ld;             // [Mp][ld]  Lk^-1 as it arrives; from Mp = 32 its space takes the kernel rows afterwards
+    double* ar2 = Lt + Mp * ld;            // [16][Mp]  A rows
+    double* yr2 = ar2 + 16 * Mp;           // [16][Mp]  dKfu/dell - A dKuu/dell
+    double* zs = yr2 + 16 * Mp;            // [Mp]
+    double* xs = zs + Mp;                  // [tpw][RT]
+    double* kf2 = Mp >= 32 ? Lt : xs + tpw * kRowTile;      // [16][Mp]  Kfu rows
+    double* df2 = kf2 + 16 * Mp;                            // [16][Mp]  dKfu/dell rows
+    const double ell = a.ws.ell[pl], var = a.ws.var[pl];
+    float4* A4 = reinterpret_cast<float4*>(a.ws.A4) + pl * N * Mz;
+    float* AT = a.ws.AT + pl * N * Mz;
+    const int n00 = tile * kRowTile;
+    {
+        auto all = [](int, int) { return true; };
+        vg_stage_f64(Lt, Mp, ld, a.ws.Li64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
+        vg_stage_f64(Kd, Mp, ld, a.ws.Kd_ell + pl * Mz * Mz, a.want_dell ? Mz : 0, Mz, 0, 0, tid, nt, all);
+        vg_stage_words(zs, 2 * (Mp + tpw * kRowTile), tid, nt, [&](int w) -> const void* {
+            const int i = w >> 1;
+            if (i >= Mz && i < Mp) return nullptr;
+            const double* src = i < Mz ? a.Zy + (size_t)p * a.zy_stride + (size_t)i * D + l
+                                       : a.X + (size_t)min(n00 + i - Mp, N - 1) * D + l;
+            return reinterpret_cast<const uint32_t*>(src) + (w & 1);
+        });
+    }
+    vg_dma_wait();
+    __syncthreads();
+    VG_T(tile == 0 && l == 0 && p == 0, 232);
+    {   // (Kuu + jI)^-1 = Lk^-T Lk^-1; tile 0 keeps the copy the views / the inducing-location reverse pass read
+        double* Kig = tile == 0 ? a.ws.Kinv + pl * Mz * Mz : nullptr;
+        matmul_f64(MatView{Lt, 1, ld}, MatView{Lt, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
+            Ki[r * ld + c] = v;
+            if (Kig && r < Mz && c < Mz) Kig[(size_t)r * Mz + c] = v;
+        });
+    }
+    const int rows_w = tpw * kRowTile, wv = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const float iMp = 1.0f / (float)Mp;
+    __syncthreads();                       // every wave has read Lk^-1; Ki stands
+    for (int r0 = 0; r0 < rows_w; r0 += 16) {
+        const int n0 = n00 + r0;
         if (n0 >= N) break;
-        const double* xt = xs + tt * kRowTile;
-        for (int e = tid; e < kRowTile * Mz; e += nt) {
-            int r = vg_div(e, iMz), m = e - r * Mz, n = n0 + r;
+        for (int e = tid; e < 16 * Mp; e += nt) {
+            const int r = vg_div(e, iMp), m = e - r * Mp, n = n0 + r;
             double k = 0.0, dk = 0.0;
-            if (n < N) {
-                double rr = fabs(xt[r] - zs[m]) / ell;
+            if (m < Mz && n < N && r0 + r < rows_w) {
+                double rr = fabs(xs[r0 + r] - zs[m]) / ell;
                 double ex = exp(-kSqrt5 * rr);
                 k = var * (1.0 + kSqrt5 * rr + (5.0 / 3.0) * rr * rr) * ex;
                 dk = var * ex * (5.0 * rr * rr / (3.0 * ell)) * (1.0 + kSqrt5 * rr);
             }
-            kf[e] = k; df[e] = dk;
+            kf2[e] = k; df2[e] = dk;
         }
         __syncthreads();
-        VG_T(tile == 0 && l == 0 && p == 0, 233);
-        for (int e = tid; e < kRowTile * Mz; e += nt) {
-            int r = vg_div(e, iMz), m = e - r * Mz;
-            ar[e] = dot4(kf + r * Mz, 1, Ki + m, ld, Mz);
+        VG_T(tile == 0 && l == 0 && p == 0 && r0 == 0, 233);
+        const int j0 = 16 * wv;
+        if (wv < ct) {                     // A = Kfu (Kuu + jI)^-1, this wave's sixteen columns
+            const vg_f64x4 acc = mfma_tile_f64(MatView{kf2, Mp, 1}, MatView{Ki, ld, 1}, Mp, lane, 0, j0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ar2[(g + 4 * q) * Mp + j0 + i] = acc[q];
         }
         __syncthreads();
-        VG_T(tile == 0 && l == 0 && p == 0, 234);
-        float av0 = 0.f, av1 = 0.f;      // (two scalars, not an array: a run-time index would put it in scratch memory)
-        int cnt = 0;
-        for (int e = tid; e < kRowTile * Mz; e += nt, ++cnt) {
-            int r = vg_div(e, iMz), m = e - r * Mz;
-            const double y = df[e] - dot4(ar + r * Mz, 1, Kd + m, ld, Mz);
-            const double v = dot4(ar + r * Mz, 1, Ki + m, ld, Mz);
-            yr[e] = y;
-            const float avv = (float)(a.jitter / var * v);
-            if (cnt == 0) av0 = avv; else if (cnt == 1) av1 = avv;
+        VG_T(tile == 0 && l == 0 && p == 0 && r0 == 0, 234);
+        float av[4] = {0.f, 0.f, 0.f, 0.f};
+        if (wv < ct) {                     // y = dKfu/dell - A dKuu/dell;  A_var = (jitter / var) A (Kuu + jI)^-1 stays with its lane
+            const vg_f64x4 accy = mfma_tile_f64(MatView{ar2, Mp, 1}, MatView{Kd, ld, 1}, Mp, lane, 0, j0);
+            const vg_f64x4 accv = mfma_tile_f64(MatView{ar2, Mp, 1}, MatView{Ki, ld, 1}, Mp, lane, 0, j0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int o = (g + 4 * q) * Mp + j0 + i;
+                yr2[o] = df2[o] - accy[q];
+                av[q] = (float)(a.jitter / var * accv[q]);
+            }
         }
         __syncthreads();
-        VG_T(tile == 0 && l == 0 && p == 0, 235);
-        cnt = 0;
-        for (int e = tid; e < kRowTile * Mz; e += nt, ++cnt) {
-            int r = vg_div(e, iMz), m = e - r * Mz, n = n0 + r;
-            if (n >= N) continue;
-            const double s = a.want_dell ? dot4(yr + r * Mz, 1, Ki + m, ld, Mz) : 0.0;
-            const float av = cnt == 0 ? av0 : av1;
-            vg_stream(A4 + (size_t)n * Mz + m, make_float4((float)ar[e], (float)s, av, 0.f));
-            vg_stream(AT + (size_t)m * N + n, (float)ar[e]);
+        VG_T(tile == 0 && l == 0 && p == 0 && r0 == 0, 235);
+        if (wv < ct) {                     // A_ell = y (Kuu + jI)^-1, and the three planes go out
+            vg_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            if (a.want_dell) acc = mfma_tile_f64(MatView{yr2, Mp, 1}, MatView{Ki, ld, 1}, Mp, lane, 0, j0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = g + 4 * q, n = n0 + r, m = j0 + i;
+                if (m < Mz && n < N && r0 + r < rows_w) {
+                    const float av0 = (float)ar2[r * Mp + m];
+                    vg_stream(A4 + (size_t)n * Mz + m, make_float4(av0, (float)acc[q], av[q], 0.f));
+                    vg_stream(AT + (size_t)m * N + n, av0);
+                }
+            }
         }
-        if (tt + 1 < tpw) __syncthreads();      // the tile's LDS rows are the next one's
+        __syncthreads();                   // (the next pass writes kf2 / df2 / ar2 / yr2)
     }
     VG_T(tile == 0 && l == 0 && p == 0, 231);
 }

@@ -639,7 +639,10 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     int rows_tpw = 1;
     while (rows_tpw < VG_ROWS_TPW_MAX && (size_t)P * L * (kCovFixedRoles + (row_tiles + 2 * rows_tpw - 1) / (2 * rows_tpw)) >= VG_ROWS_TPW_WGS) rows_tpw *= 2;
     ca.rows_tpw = rows_tpw;
-    const size_t lds_rows = ((size_t)3 * Mz * ((Mz + 2) & ~1) + (size_t)4 * kRowTile * Mz + Mz + rows_tpw * kRowTile) * sizeof(double);
+    // (Mz = 32: cov_rows_body; any other Mz: cov_rows_padded_body, operands zero padded to Mp columns)
+    const size_t lds_rows = Mz == 32
+        ? ((size_t)3 * Mz * ((Mz + 2) & ~1) + (size_t)4 * kRowTile * Mz + Mz + rows_tpw * kRowTile) * sizeof(double)
+        : ((size_t)3 * Mp * (Mp + 2) + (size_t)(Mp >= 32 ? 2 : 4) * 16 * Mp + Mp + rows_tpw * kRowTile) * sizeof(double);
     const size_t lds_cov_b = lds_cov > lds_rows ? lds_cov : lds_rows;
     // path kernels: operands + (when it fits) the raw split-K slabs of the prior draws
     const size_t raw_f = SK == 1 ? 0 : (size_t)SK * SC * J * sizeof(float);      // one slab lands in place

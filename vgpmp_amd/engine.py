@@ -590,6 +590,18 @@ class PlannerBatch:
         radii = torch.as_tensor(sc.spec.sphere_radii, dtype=torch.float32, device=pos.device)
         return (dist.reshape(-1, sc.spec.num_spheres) - radii).reshape(path.shape[:-1] + (sc.spec.num_spheres,))
 
+    def query_clearances(self, num_points: int = 100):
+        """Signed clearance (minimum over spheres) of what a query starts from: its start state, its goal state and the
+        straight line between them in joint space sampled at `num_points` (the path the variational mean is initialised on,
+        models/vgpmp.py:166-171): three [P] tensors.  A query whose own end states touch the obstacles cannot pass the
+        headless success check whatever the planner does; the report next to plans/sec says so per query."""
+        dev = self.device
+        q = self.scene.joint_sigmoid(self.y_u)                                   # [P, 2, L] the pinned states
+        lam = torch.linspace(0.0, 1.0, int(num_points), device=dev, dtype=torch.float64)[None, :, None]
+        line = q[:, :1] + (q[:, 1:] - q[:, :1]) * lam                            # [P, n, L]
+        c = self.path_clearance(line.to(torch.float32)).amin(dim=2)              # [P, n]
+        return c[:, 0], c[:, -1], c.amin(dim=1)
+
     # ---- results --------------------------------------------------------------------------------
     def samples(self) -> torch.Tensor:
         """Joint-space paths of the last evaluation: joint_sigmoid(f) as [P, S, N, L]."""

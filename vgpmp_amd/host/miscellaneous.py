@@ -95,9 +95,12 @@ def solve_planning_problem(env, start_joints, end_joints, run=0, k=0):
     return res, best_sample
 
 
-def solve_planning_problems_batched(env, queries, seed: int = 0):
+def solve_planning_problems_batched(env, queries, seed: int = 0, report: dict = None):
     """All start-goal queries of a problem set optimised in lock step as ONE device batch (the reference
-    loops over them one by one, benchmarking.py:70-85).  Returns [(solved, best_sample[Nnew, D]), ...]."""
+    loops over them one by one, benchmarking.py:70-85).  Returns [(solved, best_sample[Nnew, D]), ...].
+    `report` (a dict) receives per query the signed clearances of the start state, the goal state, the initial straight line
+    and the best sample: the headless success check (clearance > 0 everywhere, utils/robot.py:455-480 without the physics)
+    cannot pass for a query whose own end states touch the obstacles by the sphere model, whatever the planner does."""
     import torch
     from .. import engine
     from .model import VariationalMonteCarloLikelihood
@@ -116,10 +119,15 @@ def solve_planning_problems_batched(env, queries, seed: int = 0):
                                         "kernel_variance": bool(tp["kernel_variance"]),
                                         "sigma_obs": bool(tp.get("sigma_obs", False)), "alpha": bool(tp.get("alpha", False)),
                                         "inducing_variable": bool(tp.get("inducing_variable", False))})
+    if report is not None:
+        c0, c1, cl = pl.query_clearances(int(pp["time_spacing_Xnew"]))
     pl.run_steps(int(pp["num_steps"]))
     Xnew = np.tile(np.linspace(0.0, 1.0, int(pp["time_spacing_Xnew"]))[:, None], (1, dof))
     _, best, _, _ = pl.sample_from_posterior(150, Xnew, step=pl.t)
     clear = pl.path_clearance(best).amin(dim=(1, 2)).cpu().numpy()
+    if report is not None:
+        report.update(start=c0.cpu().numpy().astype(float).tolist(), goal=c1.cpu().numpy().astype(float).tolist(),
+                      initial_path=cl.cpu().numpy().astype(float).tolist(), best_sample=clear.astype(float).tolist())
     best = best.cpu().numpy().astype(np.float64)
     low, high = env.robot.spec.low, env.robot.spec.high
     inside = ((best >= low - 1e-9) & (best <= high + 1e-9)).all(axis=(1, 2))
