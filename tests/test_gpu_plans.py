@@ -38,7 +38,8 @@ def test_generated_noise_trajectory_against_oracle(industrial, name, over, steps
     """-ELBO of every optimisation step, device (noise drawn by the device generator, seed 77) against the oracle
     (orc.philox_noise of the same seed / problem / step), eight problems in one batch.  The two differ by float32 arithmetic
     and by nearest-voxel flips of float32 sphere centres; Adam (which normalises every gradient entry) lets that grow slowly
-    with the step: tolerance 2e-3 relative at the first step, 2e-2 at the last."""
+    with the step: tolerance 5e-4 relative at the first step, 5e-3 at the last (measured: 2 % of that at the reference's
+    parameters, 0.2 % at config 2's sizes)."""
     engine, ps, spec, grid = industrial
     pp = dict(ps.planner_params, **over)
     S, M, N, B, D = int(pp["num_samples"]), int(pp["num_inducing"]), int(pp["time_spacing_X"]), 1024, spec.dof
@@ -66,7 +67,7 @@ def test_generated_noise_trajectory_against_oracle(industrial, name, over, steps
         for t in range(steps):
             nz = orc.philox_noise(seed, base + k, t, S, D, D, B, M + 2)
             want = orc.optimization_step(p, st, osc, X, Zy, y, nz, float(pp["alpha"]), float(pp["learning_rate"]))
-            tol = 2e-3 + (2e-2 - 2e-3) * t / max(steps - 1, 1)
+            tol = 5e-4 + (5e-3 - 5e-4) * t / max(steps - 1, 1)
             rel = abs(dev_loss[t, k] - want) / abs(want)
             worst = max(worst, rel / tol)
             assert rel <= tol, (name, k, t, dev_loss[t, k], want, rel)
