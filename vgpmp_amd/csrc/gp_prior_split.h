@@ -27,8 +27,8 @@
 //     so TWO MFMAs give omega_hi x_hi + omega_lo x_hi + omega_hi x_lo for a 16 x 16 block.  A lane then holds four adjacent
 //     frequencies of one point: phase, v_fract, v_cos / v_sin, the f16 halves (v_cvt_pk_f16_f32 + v_fma_mix_f32) and ONE
 //     8-byte LDS store per half tile.  (Formed by v_pk_fma_f32 chains this phase took half the kernel.)
-//   * products: each wave runs 54 MFMAs -- ONE of the two products on its 16 MT sample rows, so a B fragment read serves its
-//     MT row tiles -- the fragments of the next column tile requested before the MFMAs of the current one.
+//   * products: each wave runs 54 MFMAs on its 16-row tile(s), the fragments of the next column tile requested before
+//     the MFMAs of the current one.
 // LDS tiles are [row][32 k] f16 with 64-byte rows and no padding: the 16-byte chunk c of row r sits at chunk
 // c ^ h[(r >> 2) & 3], h = (0, 2, 3, 1), which makes the ds_read_b128 fragment reads of a 16-row tile conflict-free
 // for the lane groups the hardware serves together ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS).
@@ -170,13 +170,11 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
             }
         }
     };
-    // ---- product roles: wave w forms product w / 4 (F0 for waves 0-3, H for waves 4-7) on MT row tiles: MT = 2: sample rows
-    //      32 (w % 4) .. + 31, MT = 1: 16 (w % 4) .. + 15.  A wave therefore reads the B fragments of ONE product and uses each
-    //      for its MT row tiles (one row tile of both products per wave read all of B in every wave: 42 ds_read_b128 per wave
-    //      and K step, 0.45 of the LDS bandwidth of the CU; now 22)
-    constexpr int NU = MT;                                        // row tiles per wave
-    const int rt0 = MT * (wave & 3);
-    const int mat0 = wave >> 2;
+    // ---- product roles: MT = 2: wave w owns sample rows 16 w .. 16 w + 15 of both products;
+    //                     MT = 1: row tile w % 4, product w / 4 (F0 for waves 0-3, H for waves 4-7)
+    constexpr int NU = MT;                                        // (row tile, product) units per wave
+    const int rt = MT == 2 ? wave : (wave & 3);
+    const int mat0 = MT == 2 ? 0 : (wave >> 2);
     vg_f32x4 acc[NU][kTJ / 16];
 #pragma unroll
     for (int u = 0; u < NU; ++u)
@@ -242,23 +240,21 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
         if (more) om_store(ob ^ 1);
         __syncthreads();
         // ================= products: per 16 x 16 tile  hi hi + hi lo + lo hi, float32 accumulators
-        if (DELL || mat0 == 0) {
-            vg_h8 ah[NU], al[NU];
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int arow = 16 * (rt0 + u) + r;
-                const int aoff = arow * kHRowBytes + vg_swz(arow, g) * 16;
-                ah[u] = *reinterpret_cast<const vg_h8*>(Ah + aoff);
-                al[u] = *reinterpret_cast<const vg_h8*>(Al + aoff);
-            }
+        {
+            const int arow = 16 * rt + r;
+            const int aoff = arow * kHRowBytes + vg_swz(arow, g) * 16;
+            const vg_h8 ah = *reinterpret_cast<const vg_h8*>(Ah + aoff);
+            const vg_h8 al = *reinterpret_cast<const vg_h8*>(Al + aoff);
             const int boff0 = r * kHRowBytes + vg_swz(r, g) * 16;      // (16 t + r has the swizzle of r)
             constexpr int NT = (VG_HS_SKIP & 1) ? 0 : kTJ / 16;
-            vg_h8 bh[2], bl[2];
-            const unsigned char* Bh = Bt + (2 * mat0) * kTJ * kHRowBytes + boff0;
-            const unsigned char* Bl = Bt + (2 * mat0 + 1) * kTJ * kHRowBytes + boff0;
+            vg_h8 bh[2][NU], bl[2][NU];
             auto load_b = [&](int t, int slot) {
-                bh[slot] = *reinterpret_cast<const vg_h8*>(Bh + t * 16 * kHRowBytes);
-                bl[slot] = *reinterpret_cast<const vg_h8*>(Bl + t * 16 * kHRowBytes);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int mat = MT == 2 ? u : mat0;
+                    bh[slot][u] = *reinterpret_cast<const vg_h8*>(Bt + (2 * mat) * kTJ * kHRowBytes + t * 16 * kHRowBytes + boff0);
+                    bl[slot][u] = *reinterpret_cast<const vg_h8*>(Bt + (2 * mat + 1) * kTJ * kHRowBytes + t * 16 * kHRowBytes + boff0);
+                }
             };
             if (NT) load_b(0, 0);
 #pragma unroll
@@ -266,9 +262,11 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
                 if (t + 1 < NT) load_b(t + 1, (t + 1) & 1);
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
-                    acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u], bh[t & 1], acc[u][t], 0, 0, 0);
-                    acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], bl[t & 1], acc[u][t], 0, 0, 0);
-                    acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], bh[t & 1], acc[u][t], 0, 0, 0);
+                    const int mat = MT == 2 ? u : mat0;
+                    if (!DELL && mat == 1) continue;
+                    acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[t & 1][u], acc[u][t], 0, 0, 0);
+                    acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[t & 1][u], acc[u][t], 0, 0, 0);
+                    acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[t & 1][u], acc[u][t], 0, 0, 0);
                 }
             }
         }
@@ -277,20 +275,20 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
     }
     // ---- D layout: col = lane & 15, row = (lane >> 4) * 4 + reg; the constant factors left out of the tiles go in here
     const float scale_f = c, scale_h = c * inv_ell * inv_ell;
-    if (DELL || mat0 == 0) {
-        float* dst = mat0 == 0 ? a.F0 : a.H;
-        const float sc = mat0 == 0 ? scale_f : scale_h;
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
+    for (int u = 0; u < NU; ++u) {
+        const int mat = MT == 2 ? u : mat0;
+        if (!DELL && mat == 1) continue;
+        float* dst = mat == 0 ? a.F0 : a.H;
+        const float sc = mat == 0 ? scale_f : scale_h;
 #pragma unroll
-            for (int t = 0; t < kTJ / 16; ++t) {
-                const int jc = j0 + 16 * t + r;
-                if (jc >= J) continue;
+        for (int t = 0; t < kTJ / 16; ++t) {
+            const int jc = j0 + 16 * t + r;
+            if (jc >= J) continue;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int s = s0 + 16 * (rt0 + u) + g * 4 + q;
-                    if (s < S) vg_stream(dst + (((size_t)p * S + s) * L + l) * J + jc, acc[u][t][q] * sc);
-                }
+            for (int q = 0; q < 4; ++q) {
+                const int s = s0 + 16 * rt + g * 4 + q;
+                if (s < S) vg_stream(dst + (((size_t)p * S + s) * L + l) * J + jc, acc[u][t][q] * sc);
             }
         }
     }
