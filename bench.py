@@ -615,6 +615,9 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
     lik_kernel = ("loglik_paths_kernel<1, 64, false, %s, %s, %s>" % (far, "true" if regs_form else "false",
                                                                      "true" if regs_form and D <= 8 else "false")
                   if batch_form else "loglik_paths_wide_kernel<8, false, 0>")      # (one or two problems: the timed schedule runs the
+    if batch_form and regs_form and D > 8 and not args.also_train:
+        # 9 to 15 joints: the pipelined four-wave form -- <4> free-space masks in LDS, <5> brick summary, <6> every sphere gathers
+        lik_kernel = "loglik_paths_mask_kernel<%d>" % (4 if scene.free_space_mask else 5 if scene.free_space_summary else 6)
     # <8, false, SK> form, which assembles the paths of its sample first; the events time the likelihood alone)
     roof_sdf = {"kernel": lik_kernel, "bound": "hbm", "achieved": sdf_bytes / t_sdf / 1e9,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sdf_bytes / t_sdf / 1e9 / HBM_PEAK_GBPS,
@@ -623,7 +626,8 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
                 "by_16B_per_query": {"bytes_per_launch": sdf_bytes16, "achieved": sdf_bytes16 / t_sdf / 1e9,
                                      "frac": sdf_bytes16 / t_sdf / 1e9 / HBM_PEAK_GBPS},
                 "table": {"layout": args.layout, "bytes": int(scene.table.numel() * 4),
-                          "free_space_summary": bool(scene.free_space_summary)},
+                          "free_space_summary": bool(scene.free_space_summary), "free_space_masks_in_lds": bool(scene.free_space_mask),
+                          "mask_bytes": int(scene.free_mask.numel() * 4) if scene.free_space_mask else 0},
                 "timing": "HIP events stamped with the kernel's start and end on its stream (hipExtLaunchKernel), "
                           f"mean of {max(1, args.profile_steps)} launches"}
     # the kernel that forms the prior draws in the pass the events come from (one launch per kernel, device-drawn noise);
@@ -780,13 +784,14 @@ def main():
             line = run_problem_sharded(args, world, rank, dist, backend)
             ctx = line.pop("_ctx", None) if rank == 0 else None
             quick = ["--no-cpu-baseline", "--no-solve", "--warmup", "3", "--profile-steps", "5", "--min-seconds", "0.5"]
-            if args.also_stress == "on" or (args.also_stress == "auto" and default_workload):
+            auto = default_workload and not (args.no_solve and args.no_cpu_baseline)      # (measurement runs of the line alone pass both)
+            if args.also_stress == "on" or (args.also_stress == "auto" and auto):
                 # the batch regime in front of the driver: the 512-problem batch of the north star, this GPU's 64 (BASELINE
                 # config 5 share), whole plans of 200 steps from fresh models
                 rec = sub_record(["--workload", "stress", "--steps", "200"] + quick, world, rank, dist, backend)
                 if rank == 0:
                     line["batch_512"] = rec
-            if args.also_config3 == "on" or (args.also_config3 == "auto" and default_workload and world == 1):
+            if args.also_config3 == "on" or (args.also_config3 == "auto" and auto and world == 1):
                 # BASELINE config 3, the reference's literal benchmark workload: 55 Franka / bookshelves pairs, S=7, 130 steps
                 rec = sub_record(["--workload", "config3", "--steps", "130"] + quick, world, rank, dist, backend)
                 if rank == 0:

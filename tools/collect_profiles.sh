@@ -4,7 +4,7 @@
 # Every profiler run sits under `timeout`; the program stands directly behind `--`.
 set -uo pipefail
 : "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}"
-round=${ROUND:-r03}
+round=${ROUND:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/${round}final; rm -rf "$out"; mkdir -p "$out"
 stats() {   # stats <tag> <bench args...>: bench line under the kernel trace + the kernel statistics table
@@ -25,11 +25,10 @@ pmc() {     # pmc <tag> <bench args...>: FETCH_SIZE and WRITE_SIZE in separate p
   else echo "pmc pass failed for $tag" >&2; fi
   rm -rf $out/${tag}_FETCH_SIZE $out/${tag}_WRITE_SIZE
 }
-Q="--no-cpu-baseline --no-solve"
+Q="--no-cpu-baseline --no-solve --also-stress off --also-config3 off"      # the line alone (no sub-records)
 # ---- config 2 (the benchmark line): one problem per GPU
 pmc config2 --steps 40 --warmup 5 $Q
 if [ -f $out/config2_pmc_traffic.json ]; then cp $out/config2_pmc_traffic.json profiles/pmc_traffic.json; fi
-python bench.py > $out/config2_bench.json 2> $out/config2_bench.err; tail -c 400 $out/config2_bench.json; echo
 stats config2 $Q
 # ---- the few-problem schedules: microseconds per step by the number of problems on the GPU
 for n in 1 2 3 4 6 8 13 16 24 32 48; do
@@ -42,6 +41,8 @@ timeout 600 python tools/solve_timing.py > $out/solve_timing_config2.txt 2>&1
 # ---- config 3: Franka / bookshelves, the full C(11,2) = 55 start-goal batch, S=7 M=24 T=70
 python bench.py --workload config3 --steps 130 --warmup 10 $Q > $out/config3_bench.json 2> $out/config3.err
 stats config3 --workload config3 --steps 130 --warmup 10 $Q --min-seconds 0.5
+pmc config3 --workload config3 --steps 130 --warmup 10 $Q
+if [ -f $out/config3_pmc_traffic.json ]; then cp $out/config3_pmc_traffic.json profiles/pmc_traffic_config3.json; fi
 # ---- 64 Franka problems per GPU (batch regime, cache-resident table)
 stats franka64 $Q --problems 64 --scene synthetic --min-seconds 0.5 --steps 200
 python bench.py $Q --problems 64 --scene synthetic --steps 200 > $out/franka64_bench.json 2>> $out/franka64.err
@@ -52,18 +53,25 @@ stats config4_1rank --shard samples --steps 100 --warmup 10 --min-seconds 0.5
 timeout 600 python bench.py --gpus 2 --shard samples --steps 100 --warmup 10 2>> $out/config4.err | tail -1 > $out/config4_2ranks_gloo_one_gpu_bench.json
 # ---- the default N > 1 line (config 2 per GPU + the config-5 share as batch_512), two ranks on this one GPU: rehearsal only
 timeout 900 python bench.py --gpus 2 --steps 100 --warmup 10 $Q 2> $out/gpus2.err | tail -1 > $out/gpus2_rehearsal_one_gpu_bench.json
-# ---- config 5 share: 14-DoF arm, 512^3 voxels (2 GiB table), 64 problems
+# ---- config 5 share: 14-DoF arm, 512^3 voxels (2 GiB table), 64 problems; by free-space test of the SDF pass:
+#      mask = bit masks in LDS (the default), summary = the brick summary in memory, none = every sphere gathers
 B5="--workload stress --steps 200 --warmup 3 $Q --profile-steps 10 --min-seconds 0.5"      # a timed block = a whole plan from fresh models
-for f in ${FORMS:-brick:on brick:off linear:off}; do
-  lay=${f%%:*}; sm=${f##*:}; tag=config5_${lay}_summary_${sm}
-  stats $tag $B5 --layout $lay --summary $sm
-  pmc $tag $B5 --layout $lay --summary $sm
-  timeout 600 python bench.py $B5 --layout $lay --summary $sm --traffic-file $out/${tag}_pmc_traffic.json > $out/${tag}_bench.json 2>> $out/$tag.err
+for f in ${FORMS:-mask:on:off summary:off:on none:off:off}; do
+  IFS=: read name mk sm <<< "$f"; tag=config5_$name
+  stats $tag $B5 --mask $mk --summary $sm
+  pmc $tag $B5 --mask $mk --summary $sm
+  timeout 600 python bench.py $B5 --mask $mk --summary $sm --traffic-file $out/${tag}_pmc_traffic.json > $out/${tag}_bench.json 2>> $out/$tag.err
 done
+if [ -f $out/config5_mask_pmc_traffic.json ]; then cp $out/config5_mask_pmc_traffic.json profiles/pmc_traffic_config5.json; fi
+# the SDF pass over a plan: first steps / whole plan, by form (tools/ab_mask.sh), and what a coarse free-space level could skip
+timeout 1200 bash tools/ab_mask.sh "product" "on:off off:on off:off" > $out/sdf_pass_by_form.txt 2>&1
+timeout 900 python tools/sdf_frames.py > $out/sdf_frames_config5.txt 2>&1
+# ---- are the plans plans: clearance per query at the reference's own planner parameters, oracle beside the device
+timeout 900 python tests/plan_report.py franka industrial --json $out/plan_report_franka_industrial.json > $out/plan_report_franka_industrial.txt 2>&1
 # ---- SQ / MFMA counters: the fused prior kernel and the batch likelihood at config 5, the prior GEMM role at config 2
 B5S="--workload stress --steps 20 --warmup 3 $Q --profile-steps 2"
 tools/pmc_sq.sh prior_fused_split $out/sq_prior_fused_config5 $B5S > /dev/null 2>&1
-tools/pmc_sq.sh "loglik_paths_kernel<" $out/sq_loglik_config5 $B5S > /dev/null 2>&1
+tools/pmc_sq.sh "loglik_paths_mask_kernel<" $out/sq_loglik_config5 $B5S > /dev/null 2>&1
 tools/pmc_sq.sh paths_bwd_regs $out/sq_paths_bwd_config5 $B5S > /dev/null 2>&1
 tools/pmc_sq.sh stage2_kernel $out/sq_stage2_config2 --steps 40 --warmup 5 $Q > /dev/null 2>&1
 # ---- the memory system's ceiling for 16-byte gathers
@@ -84,5 +92,8 @@ fi
 if [ -f tools/libvgpmp_bisect.so ]; then
   VGPMP_HIP_LIB=$PWD/tools/libvgpmp_bisect.so timeout 300 python tools/step_trace.py 1 > $out/step_trace_config2.txt 2>&1
 fi
+# ---- the driver's line: config 2 + sub-records (batch_512, config3, batch_64) + plan quality + CPU baselines, with this
+#      collection's traffic tables in place
+python bench.py > $out/config2_bench.json 2> $out/config2_bench.err; tail -c 600 $out/config2_bench.json; echo
 find $out -name "*.err" -size 0 -delete
 ls -la $out | head -80

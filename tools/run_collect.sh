@@ -2,7 +2,7 @@
 # Run tools/collect_profiles.sh on a GPU box and file the results under profiles/<round>/final, stamped with the commit they
 # were taken at (the GPU box has no .git).  From the repo root, in the build container.  ROUND=r03 by default.
 set -euo pipefail
-round=${ROUND:-r03}
+round=${ROUND:-r04}
 head=$(git rev-parse --short HEAD); dirty=$(git status --porcelain | grep -v '^??' | wc -l || true)
 stamp="commit $head"; if [ "$dirty" != 0 ]; then stamp="$stamp + $dirty uncommitted file(s)"; fi
 echo "$stamp" > profiles/COLLECT_STAMP
@@ -16,6 +16,8 @@ for d in "$src"/sq_*; do if [ -f "$d/summary.txt" ]; then cp "$d/summary.txt" "$
 echo "$stamp" > "$dst/COLLECTED_AT"
 # the table bench.py reads for roofline.traffic is THIS collection's (round 2 left the round-1 file in place)
 cp "$dst/config2_pmc_traffic.json" profiles/pmc_traffic.json
+[ -f "$dst/config5_mask_pmc_traffic.json" ] && cp "$dst/config5_mask_pmc_traffic.json" profiles/pmc_traffic_config5.json
+[ -f "$dst/config3_pmc_traffic.json" ] && cp "$dst/config3_pmc_traffic.json" profiles/pmc_traffic_config3.json
 python - <<PY
 import json
 t = json.load(open("profiles/pmc_traffic.json"))

@@ -603,11 +603,14 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
         if (square) {
             if (role != 0) vg_stage_f64_square(La, ld, a.ws.Lk64 + pl * Mz * Mz, Mz, tid, nt);
             if (!crole) vg_stage_f64_square(Li, ld, a.ws.Li64 + pl * Mz * Mz, Mz, tid, nt);
+        } else if (!(Mz & 1)) {     // zero padded to Mp, still in 16-byte units
+            if (role != 0) vg_stage_f64_even(La, Mp, ld, a.ws.Lk64 + pl * Mz * Mz, Mz, Mz, tid, nt);
+            if (!crole) vg_stage_f64_even(Li, Mp, ld, a.ws.Li64 + pl * Mz * Mz, Mz, Mz, tid, nt);
         } else {
             if (role != 0) vg_stage_f64(La, Mp, ld, a.ws.Lk64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
             if (!crole) vg_stage_f64(Li, Mp, ld, a.ws.Li64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
         }
-        if (crole && square && !(M & 1)) {
+        if (crole && !(M & 1)) {
             // pad(Q) with Q at [2:, 2:] as ONE linear image of 16-byte units (ld even: a unit = two columns of a row): units
             // inside the block come from the rows of q_sqrt by DMA, the others are zeros written directly; the upper triangle
             // of the block is cleared behind the wait.
@@ -628,6 +631,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
             if (role != 0) {
                 const double* Kdg = role == 1 ? a.ws.Kd_ell + pl * Mz * Mz : Kg;
                 if (square) vg_stage_f64_square(Kd, ld, Kdg, Mz, tid, nt);
+                else if (!(Mz & 1)) vg_stage_f64_even(Kd, Mp, ld, Kdg, Mz, Mz, tid, nt);
                 else vg_stage_f64(Kd, Mp, ld, Kdg, Mz, Mz, 0, 0, tid, nt, all);
             }
             // this thread's share of Q in registers: the KL terms are element-wise; the tangents write theirs where Lk was
@@ -658,7 +662,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
             VG_HO(a.ws.m + pl * Mz + tid, mi);
             if (form_u) ml[tid] = mi;
         }
-        if (Mz == Mp && !(M & 1)) {      // (16-byte staging of Q above: the strict upper triangle of the block is not Q's)
+        if (!(M & 1)) {      // (16-byte staging of Q above: the strict upper triangle of the block is not Q's)
             for (int e = tid; e < M * M; e += nt) {
                 const int r = vg_div(e, iM), c = e - r * M;
                 if (c > r) Qp[(r + 2) * ld + (c + 2)] = 0.0;
@@ -992,8 +996,13 @@ __device__ void cov_rows_padded_body(const CovArgs& a, double* sm, int wg_tile, 
     const int n00 = tile * kRowTile;
     {
         auto all = [](int, int) { return true; };
-        vg_stage_f64(Lt, Mp, ld, a.ws.Li64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
-        vg_stage_f64(Kd, Mp, ld, a.ws.Kd_ell + pl * Mz * Mz, a.want_dell ? Mz : 0, Mz, 0, 0, tid, nt, all);
+        if (!(Mz & 1)) {
+            vg_stage_f64_even(Lt, Mp, ld, a.ws.Li64 + pl * Mz * Mz, Mz, Mz, tid, nt);
+            vg_stage_f64_even(Kd, Mp, ld, a.ws.Kd_ell + pl * Mz * Mz, a.want_dell ? Mz : 0, Mz, tid, nt);
+        } else {
+            vg_stage_f64(Lt, Mp, ld, a.ws.Li64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
+            vg_stage_f64(Kd, Mp, ld, a.ws.Kd_ell + pl * Mz * Mz, a.want_dell ? Mz : 0, Mz, 0, 0, tid, nt, all);
+        }
         vg_stage_words(zs, 2 * (Mp + tpw * kRowTile), tid, nt, [&](int w) -> const void* {
             const int i = w >> 1;
             if (i >= Mz && i < Mp) return nullptr;

@@ -143,6 +143,24 @@ __device__ __forceinline__ void vg_stage_f64_square(double* lds, int ld, const d
         }
     }
 }
+// Dense float64 rows x cols matrix (cols even, 16-byte aligned) -> the [prows][ld] LDS image (ld even), ZERO outside the matrix:
+// units inside come by DMA in 16-byte units, the others are zeros written directly (each lane writes only its own unit of the
+// linear image, so nothing races with the DMA).  The word-granular vg_stage_f64 moves the same bytes in four times the
+// requests -- and a CU's staging goes by the number of wave requests (lesson 41): at Mz = 26 it was most of stage B's time.
+__device__ __forceinline__ void vg_stage_f64_even(double* lds, int prows, int ld, const double* g, int rows, int cols, int tid, int nt) {
+    const int lane = tid & (VG_WAVE - 1), upr = ld >> 1, total = prows * upr, cu = cols >> 1;
+    const float iupr = 1.0f / (float)upr;
+    for (int c = (tid & ~(VG_WAVE - 1)); c < total; c += nt) {
+        const int i = c + lane;
+        if (i < total) {
+            const int r = (int)(((float)i + 0.5f) * iupr), u = i - r * upr;
+            if (r < rows && u < cu)
+                __builtin_amdgcn_global_load_lds((vg_gmem*)(g + (size_t)r * cols + 2 * u), (vg_lmem*)((char*)lds + 16 * (size_t)c), 16, 0, VG_DMA_AUX);
+            else
+                reinterpret_cast<double2*>(lds)[i] = make_double2(0.0, 0.0);
+        }
+    }
+}
 // contiguous copy of n16 16-byte units (both sides 16-byte aligned)
 __device__ __forceinline__ void vg_stage_16(void* lds, const void* g, int n16, int tid, int nt) {
     const int lane = tid & (VG_WAVE - 1);
