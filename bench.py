@@ -248,6 +248,25 @@ def oracle_plan_check(n_queries: int = 3):
     return {"planner_params": "the reference's own (S=20 M=10 T=50, 200 steps, lr 0.02)", "queries": out}
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container on a 256-thread host may
+    own far fewer: the r04 GPU box gave 64 single-threaded workers the throughput of ~9.4 cores)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+        try:
+            quota, period = parse(open(path).read())
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
 class CpuPool:
     """One single-threaded oracle process per core, over independent start-goal problems of the bench workload.  The children
     are started BEFORE the parent touches the GPU (fresh interpreters of this script in `--cpu-worker` mode; they never import
@@ -295,9 +314,11 @@ class CpuPool:
         if not res:
             return {"value": None, "error": "no worker finished (see " + self.err.name + ")"}
         steps, wall = sum(r["steps"] for r in res), max(r["elapsed"] for r in res)
-        return {"value": steps / wall, "unit": "problem-steps/sec", "cores": len(res), "processes": self.n, "kind": "port",
-                "per_process": steps / wall / len(res),
-                "sample": f"{len(res)} single-threaded processes (one per core; host has {os.cpu_count()} logical cores), each the same "
+        busy = sum(r.get("cpu_seconds", r["elapsed"]) / r["elapsed"] for r in res)
+        return {"value": steps / wall, "unit": "problem-steps/sec", "cores": max(1, int(round(busy))), "processes": self.n, "kind": "port",
+                "per_process": steps / wall / len(res), "cores_busy_measured": round(busy, 1), "usable_cores": usable_cores(),
+                "sample": f"{len(res)} single-threaded processes (one per usable core: {usable_cores()} by affinity / cgroup quota; host has "
+                          f"{os.cpu_count()} logical cores; {busy:.1f} cores busy by the workers' own CPU time), each the same "
                           f"float64 oracle step on its own start-goal problem of the workload's problem set, all timed together "
                           f"for {wall:.1f} s: {steps} problem-steps; to be compared with the GPU BATCH figure (batch_64), not with the "
                           f"one-problem line"}
@@ -353,14 +374,14 @@ def cpu_worker_main(jobdir: str, index: int) -> int:
     start = wait_for("start.json", 600.0)
     if start is None:
         return 0
-    n, t0 = 0, time.perf_counter()
+    n, t0, c0 = 0, time.perf_counter(), time.process_time()
     while True:
         one(); n += 1
         el = time.perf_counter() - t0
         if el > start["budget"] and n >= 3:
             break
     tmp = os.path.join(jobdir, "result_%d.tmp" % index)
-    json.dump({"steps": n, "elapsed": el}, open(tmp, "w"))
+    json.dump({"steps": n, "elapsed": el, "cpu_seconds": time.process_time() - c0}, open(tmp, "w"))
     os.replace(tmp, os.path.join(jobdir, "result_%d.json" % index))
     return 0
 
@@ -616,8 +637,8 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
                                                                      "true" if regs_form and D <= 8 else "false")
                   if batch_form else "loglik_paths_wide_kernel<8, false, 0>")      # (one or two problems: the timed schedule runs the
     if batch_form and regs_form and D > 8 and not args.also_train:
-        # 9 to 15 joints: the pipelined four-wave form -- <4> free-space masks in LDS, <5> brick summary, <6> every sphere gathers
-        lik_kernel = "loglik_paths_mask_kernel<%d>" % (4 if scene.free_space_mask else 5 if scene.free_space_summary else 6)
+        # 9 to 15 joints: the pipelined four-wave form -- <2> free-space masks in LDS, <1> brick summary, <0> every sphere gathers
+        lik_kernel = "loglik_paths_mask_kernel<%d>" % (2 if scene.free_space_mask else 1 if scene.free_space_summary else 0)
     # <8, false, SK> form, which assembles the paths of its sample first; the events time the likelihood alone)
     roof_sdf = {"kernel": lik_kernel, "bound": "hbm", "achieved": sdf_bytes / t_sdf / 1e9,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sdf_bytes / t_sdf / 1e9 / HBM_PEAK_GBPS,
@@ -758,7 +779,7 @@ def main():
     # the problem-parallel CPU baseline: its worker processes start NOW, before this process touches the GPU, and sleep
     pool = None
     if world == 1 and not args.no_cpu_baseline and args.shard == "problems" and args.workload == "config2" and args.scene == "mesh":
-        pool = CpuPool(max(1, min((os.cpu_count() or 2) // 2, 64)))
+        pool = CpuPool(max(1, min(usable_cores(), 64)))
     import torch
     dist = None
     backend = os.environ.get("VGPMP_DIST_BACKEND", "nccl")      # "gloo": rehearsal of the N > 1 path on a 1-GPU box

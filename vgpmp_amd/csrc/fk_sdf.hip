@@ -20,19 +20,9 @@ static int lik_bisect_mode() { const char* e = getenv("VGPMP_STOP_LIK"); return 
 int vg_trace_take_lik(unsigned long long* host, int cap) { return vg_trace_take(host, cap); }
 #endif
 
-#ifndef VG_LIK_PFX_WAVES
-#define VG_LIK_PFX_WAVES 3
-#endif
-#ifndef VG_LIK_NOSUMS
-#define VG_LIK_NOSUMS 0      // measurement only (WRONG gradients): the register form without its per-frame sums -- what a form
-#endif                       // that needs no per-frame state would gain from a third wave per SIMD
-#ifndef VG_LIK_REGS_WAVES
-#define VG_LIK_REGS_WAVES 2
-#endif
-#ifndef VG_LIK_PREFIX_MAX_DOF
-#define VG_LIK_PREFIX_MAX_DOF 8      // batch likelihood: up to this many joints the prefix-scalar form (three waves per SIMD), beyond it
-                                    // the per-frame sums in registers (two); 0: measurement builds without the former
-#endif
+constexpr int kLikPfxWaves = 3;           // waves per SIMD of the prefix-scalar form (151 registers)
+constexpr int kLikPrefixMaxDof = 8;       // batch likelihood: up to this many joints the prefix-scalar form (three waves per SIMD), beyond
+                                          // it the per-frame sums in registers (two): measured crossover, DESIGN section 3
 
 namespace {
 
@@ -160,9 +150,6 @@ __device__ __forceinline__ void lik_wave_sync() {
 // The three axis quotients in float32, clamp + truncate, and ONE test for "some quotient is within its error bound
 // of an integer" that sends the query through the reference's float64 expression (all three axes): a few 1e-3 of
 // the queries.  Indices stay bit-identical to utils/sdf_utils.py:62-66.
-#ifndef VG_VOX_DIV
-#define VG_VOX_DIV 0
-#endif
 struct Vox3 { int ix, iy, iz; };
 __device__ __forceinline__ Vox3 voxel3(vg_float3 p, const SdfFast& fs, const vg_sdf_dev& s, double offx, double offy,
                                        double offz) {
@@ -180,15 +167,9 @@ __device__ __forceinline__ Vox3 voxel3(vg_float3 p, const SdfFast& fs, const vg_
     if (fminf(ex, fminf(ey, ez)) < 0.f) {
         // some axis sits within the float32 error of a cell boundary: the reference's float64 index, exactly, on the axes
         // concerned (voxel_axis_near); the others keep theirs
-#if VG_VOX_DIV      // measurement: the round-2 form, three float64 divisions
-        o.ix = vg_voxel_axis((double)p.x - offx, s.ox, s.delta, s.nx);
-        o.iy = vg_voxel_axis((double)p.y - offy, s.oy, s.delta, s.ny);
-        o.iz = vg_voxel_axis((double)p.z - offz, s.oz, s.delta, s.nz);
-#else
         if (ex < 0.f) o.ix = voxel_axis_near(((double)p.x - offx) - s.ox, s.delta, qx, s.nx);
         if (ey < 0.f) o.iy = voxel_axis_near(((double)p.y - offy) - s.oy, s.delta, qy, s.ny);
         if (ez < 0.f) o.iz = voxel_axis_near(((double)p.z - offz) - s.oz, s.delta, qz, s.nz);
-#endif
     }
     return o;
 }
@@ -348,13 +329,11 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
 // frame number -- indirect register addressing -- and only sin / cos / d g / d f of the joints in LDS: 3 D instead of
 // 9 D + 6 words per lane (132 at 14 joints, which held the one-lane form at one wave per SIMD).  Up to 15 joints.
 typedef float vg_f32x16 __attribute__((ext_vector_type(16)));
-// FAR: 0 every sphere reads the table; 1 the brick summary first (a second dependent global load); 2 the free-space MASK of the
-// sphere's radius class out of LDS (`lmask`: the masks as staged by the workgroup), then the table; 3 mask, then summary, then table.
-template <int U, bool SIG, int FAR, typename LoadRaw, typename ToAngle, typename Emit, typename EmitSig = NoSig>
+template <int U, bool SIG, bool FAR, typename LoadRaw, typename ToAngle, typename Emit, typename EmitSig = NoSig>
 __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restrict__ rb, const vg_sdf_dev& sdf,
                                                     const LikScratch sc, LoadRaw load_raw, ToAngle to_angle, Emit emit,
                                                     const float* __restrict__ sig = nullptr, float sig_w = 0.f,
-                                                    EmitSig emit_sig = NoSig(), const uint32_t* lmask = nullptr) {
+                                                    EmitSig emit_sig = NoSig()) {
     static_assert(VGPMP_MAX_SPHERES % U == 0, "a batch of sphere constants never leaves the table");
     const int D = rb->dof, P = rb->num_spheres;          // D <= 15: frames 0 .. 15
     float raw[VGPMP_MAX_DOF];
@@ -380,9 +359,7 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
     vg_float3 Ft = vg_make3(0.f, 0.f, 0.f), Mt = vg_make3(0.f, 0.f, 0.f);
     float acc = 0.f;
     auto flush = [&]() {                                 // sums of frame pcur are complete
-#if !VG_LIK_NOSUMS
         fx[pcur] = F.x; fy[pcur] = F.y; fz[pcur] = F.z; mx[pcur] = Mo.x; my[pcur] = Mo.y; mz[pcur] = Mo.z;
-#endif
         Ft = vg_make3(Ft.x + F.x, Ft.y + F.y, Ft.z + F.z);
         Mt = vg_make3(Mt.x + Mo.x, Mt.y + Mo.y, Mt.z + Mo.z);
         F = vg_make3(0.f, 0.f, 0.f); Mo = vg_make3(0.f, 0.f, 0.f);
@@ -393,7 +370,6 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
         float4 v[U];
         vg_float3 pos[U];
         uint32_t at[U];
-        uint32_t mb[(FAR & 2) ? U : 1], bk[FAR == 3 ? U : 1];
         float4 ca[U];
         float2 cb[U];
 #pragma unroll
@@ -413,44 +389,15 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
                 pos[u] = axpy(ca[u].x, T.cx, axpy(ca[u].y, T.cy, axpy(ca[u].z, T.cz, T.t)));
                 const Vox3 ix = voxel3(pos[u], fs, sdf, offx, offy, offz);
                 at[u] = (uint32_t)vg_table_offset(sdf, ix.ix, ix.iy, ix.iz);
-                if (FAR & 2) {
-                    // the mask of the smallest clearance that covers this sphere (uniform): clearance >= eps + r in the hinge's
-                    // own float32 form, so a set bit means cost exactly 0 on every voxel of the block (monotone rounding)
-                    int mo = -1;
-#pragma unroll
-                    for (int k = VGPMP_MAX_MASKS - 1; k >= 0; --k)
-                        if (k < sdf.mcount && !(eps - (sdf.mclr[k] - cb[u].x) > 0.f)) mo = k * sdf.mwords;
-                    const uint32_t bit = (uint32_t)(((ix.ix >> sdf.mshift) * sdf.mby + (ix.iy >> sdf.mshift)) * sdf.mbz + (ix.iz >> sdf.mshift));
-                    mb[u] = mo < 0 ? 0u : lmask[mo + (bit >> 5)] >> (bit & 31u);       // bit 0: free
-                    if (FAR == 3) bk[u] = (uint32_t)vg_brick_of(sdf, ix.ix, ix.iy, ix.iz);
-                } else if (FAR == 1) v[u].x = sdf.brick_min[vg_brick_of(sdf, ix.ix, ix.iy, ix.iz)];
+                if (FAR) v[u].x = sdf.brick_min[vg_brick_of(sdf, ix.ix, ix.iy, ix.iz)];
                 else v[u] = sdf.table[at[u]];
             } else {
                 v[u] = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);       // hinge exactly 0
                 pos[u] = vg_make3(0.f, 0.f, 0.f);
                 at[u] = 0u;
-                if (FAR & 2) { mb[u] = 1u; if (FAR == 3) bk[u] = 0u; }
             }
         }
-        if (FAR == 2) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (q0 + u < P) {
-                    v[u] = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);
-                    if (!(mb[u] & 1u)) v[u] = sdf.table[at[u]];
-                }
-            }
-        }
-        if (FAR == 3) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (q0 + u < P) {
-                    v[u].x = __builtin_inff();
-                    if (!(mb[u] & 1u)) v[u].x = sdf.brick_min[bk[u]];
-                }
-            }
-        }
-        if (FAR & 1) {
+        if (FAR) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (q0 + u < P) {
@@ -485,10 +432,8 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
     vg_float3 Fs = Ft, Ms = Mt;
 #pragma nounroll
     for (int i = 1; i <= D; ++i) {
-#if !VG_LIK_NOSUMS
         Fs = vg_make3(Fs.x - fx[i - 1], Fs.y - fy[i - 1], Fs.z - fz[i - 1]);
         Ms = vg_make3(Ms.x - mx[i - 1], Ms.y - my[i - 1], Ms.z - mz[i - 1]);
-#endif
         vg_float3 z = T.cz, org = T.t;
         dh_apply(rb, i - 1, sc.at(i - 1), sc.at(D + i - 1), T);
         if (craig) { z = T.cz; org = T.t; }
@@ -657,7 +602,7 @@ __device__ __forceinline__ float loglik_config_pipe(const vgpmp_robot* __restric
 }
 
 // The same with the prefix term of every joint's gradient as a scalar in LDS instead of per-frame sums in registers (up to
-// VG_LIK_PREFIX_MAX_DOF joints).  A function of its own: folded into loglik_config_regs as a template switch, the form WITHOUT
+// kLikPrefixMaxDof joints).  A function of its own: folded into loglik_config_regs as a template switch, the form WITHOUT
 // the prefix terms came out 22 % slower at the config-5 share -- same numbers, same register count, a different schedule of
 // its gathers.
 template <int U, bool SIG, bool FAR, typename LoadRaw, typename ToAngle, typename Emit, typename EmitSig = NoSig>
@@ -788,10 +733,7 @@ __device__ __forceinline__ float loglik_config_prefix(const vgpmp_robot* __restr
 
 constexpr int kLikBlock = 128;
 constexpr int kLikBatchBlock = 64;
-#ifndef VG_LIK_U
-#define VG_LIK_U 8
-#endif
-constexpr int kLikBatchU = VG_LIK_U;    // sphere gathers in flight per lane in the batch form
+constexpr int kLikBatchU = 8;           // sphere gathers in flight per lane in the batch form
 
 // ---- stand-alone log_prob: g [n, dof] row major ------------------------------------------------
 template <bool GRAD>
@@ -814,7 +756,7 @@ __global__ __launch_bounds__(kLikBlock) void log_prob_kernel(const vgpmp_robot* 
 // LPC lanes per (sample, time) configuration; BLK / LPC configurations per workgroup.  Large batches run one-wave
 // workgroups (kLikBatchBlock): 188 instead of 204 us per launch at 64 problems (finer tail).
 template <int LPC, int BLK, bool SIG = false, bool FAR = false, bool REGS = false, bool PFX = false>
-__global__ __launch_bounds__(BLK, REGS ? (PFX ? VG_LIK_PFX_WAVES : VG_LIK_REGS_WAVES) : 1) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
+__global__ __launch_bounds__(BLK, REGS ? (PFX ? kLikPfxWaves : 2) : 1) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
                                                                   const float* __restrict__ f, int S, int L, int N,
                                                                   float scale, float* __restrict__ G,
                                                                   float* __restrict__ logp,
@@ -889,7 +831,8 @@ __global__ __launch_bounds__(BLK, REGS ? (PFX ? VG_LIK_PFX_WAVES : VG_LIK_REGS_W
     VG_T(blockIdx.x == gridDim.x - 1 && pb == 0, 405);
 }
 
-// ---- ELBO path, batch form with the free-space masks in LDS -------------------------------------------------
+// ---- ELBO path, batch form of 9 to 15 joints: pipelined, free-space masks in LDS ------------------------------
+// FARM = the pipelined form's FAR: 0 every sphere gathers, 1 brick summary, 2 free-space masks (the scene's default).
 // Four waves per workgroup share ONE copy of the scene's free-space masks (include/vgpmp.h: a bit per block of voxels, a few KB
 // to 32 KB) staged into LDS by DMA while the waves load their joint values; each wave then runs the register form on its own 64
 // configurations exactly as a one-wave workgroup of loglik_paths_kernel would (same partial sums, one per wave), except that a
@@ -897,13 +840,7 @@ __global__ __launch_bounds__(BLK, REGS ? (PFX ? VG_LIK_PFX_WAVES : VG_LIK_REGS_W
 // 512^3 grid does not fit an XCD's L2 next to the table's lines: every query paid a scattered 4-byte load for it (36.9 M per launch
 // at the config-5 share) before its 16-byte gather.  Results are bit-identical (skipped spheres cost exactly 0).
 constexpr int kLikMaskBlock = 256;
-#ifndef VG_LIK_PIPE_U
-#define VG_LIK_PIPE_U 4
-#endif
-constexpr int kLikPipeU = VG_LIK_PIPE_U;      // spheres per batch of the pipelined form (two batches in registers)
-#ifndef VG_LIK_PIPE
-#define VG_LIK_PIPE 1                         // 0: measurement builds with the un-pipelined register form in the four-wave kernel
-#endif
+constexpr int kLikPipeU = 4;      // spheres per batch of the pipelined form (two batches in registers; 8 spills 190 registers)
 template <int FARM>
 __global__ __launch_bounds__(kLikMaskBlock, 2) void loglik_paths_mask_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
                                                                             const float* __restrict__ f, int S, int L, int N,
@@ -935,9 +872,7 @@ __global__ __launch_bounds__(kLikMaskBlock, 2) void loglik_paths_mask_kernel(con
         return fmaf(span, sg, rb->joint_tab[j][5]);
     };
     auto put = [&](int j, float v) { if (live) G[base + (size_t)j * N] = scale * v; };
-    float lp;
-    if constexpr (FARM >= 4) lp = loglik_config_pipe<kLikPipeU, FARM == 4 ? 2 : FARM == 5 ? 1 : 0>(rb, sdf, sc, raw_f, angle, put, lmask);
-    else lp = loglik_config_regs<kLikBatchU, false, FARM>(rb, sdf, sc, raw_f, angle, put, nullptr, 0.f, NoSig(), lmask);
+    const float lp = loglik_config_pipe<kLikPipeU, FARM>(rb, sdf, sc, raw_f, angle, put, lmask);
     if (live) logp[((size_t)pb * S + s) * N + n] = lp;
     const float w = vg_wave_sum(live ? lp : 0.f);
     if (lane == 0 && wv < nwaves) lik_partial[(size_t)pb * nwaves + wv] = w;
@@ -1557,11 +1492,11 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
     };
     const bool regs = L <= 15 && form != 2;              // per-frame sums in registers (form 2, measurement: in LDS)
     if (regs) {
-        const bool pfx = L <= VG_LIK_PREFIX_MAX_DOF;      // the prefix-scalar form of the reverse sweep (a fourth LDS slot row)
+        const bool pfx = L <= kLikPrefixMaxDof;      // the prefix-scalar form of the reverse sweep (a fourth LDS slot row)
         // free-space masks in LDS (four-wave workgroups; the per-wave partial sums and their count stay those of the one-wave form)
         const size_t lds_mask = (sdf->free_mask ? (size_t)sdf->mask_count * sdf->mask_words * 4 : 0) + (size_t)3 * L * kLikMaskBlock * sizeof(float);
         const bool masks = sdf->layout == VGPMP_SDF_BRICK4 && sdf->free_mask && sdf->mask_count > 0;
-        if (!pfx && !sig && (masks || VG_LIK_PIPE) && 2 * lds_mask <= 160 * 1024) {
+        if (!pfx && !sig && 2 * lds_mask <= 160 * 1024) {
             auto gom = [&](auto kern) {
                 int rc = vg_grant_dyn_lds((const void*)kern, lds_mask);
                 if (rc) return rc;
@@ -1569,12 +1504,8 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
                                       scale, G, logp, lik_partial, nblk);
                 return (int)hipGetLastError();
             };
-#if VG_LIK_PIPE
             // masks in LDS where the scene has them (one dependent global load per sphere), else the summary, else every sphere
-            return masks ? gom(loglik_paths_mask_kernel<4>) : far ? gom(loglik_paths_mask_kernel<5>) : gom(loglik_paths_mask_kernel<6>);
-#else
-            return far ? gom(loglik_paths_mask_kernel<3>) : gom(loglik_paths_mask_kernel<2>);
-#endif
+            return masks ? gom(loglik_paths_mask_kernel<2>) : far ? gom(loglik_paths_mask_kernel<1>) : gom(loglik_paths_mask_kernel<0>);
         }
         lds = (size_t)(pfx ? 4 : 3) * L * kLikBatchBlock * sizeof(float);
         if (pfx) {

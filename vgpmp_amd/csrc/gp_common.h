@@ -5,20 +5,7 @@
 namespace {
 
 constexpr int kBlock = 256;
-#ifndef VG_MID_MAX_PL
-#define VG_MID_MAX_PL 0
-#endif
-constexpr int kMidMaxPL = VG_MID_MAX_PL;       // cov_b beside the tiled GEMM (tiles first) up to this many pairs: 14 problems 273 -> 255 us, 20: 365 -> 334, 27: equal
-#ifndef VG_MID2_MAX_PL
-#define VG_MID2_MAX_PL 0      // (192 until the f16-split prior kernel: the merged launches of the medium batches run the tiled float32
-                             //  GEMM and lose to the large-batch schedule from six problems -- 13: 233 vs 188 us per step, 24: 384 vs 290;
-                             //  equal with few samples.  Kept as a measurement build.)
-#endif
-constexpr int kMid2MaxPL = VG_MID2_MAX_PL;     // ... and only cov_a | noise and hyper | final up to this many (16 problems: 333 -> 323 us)
-#ifndef VG_FUSE_MAX_PL
-#define VG_FUSE_MAX_PL 32
-#endif
-constexpr int kFuseMaxPL = VG_FUSE_MAX_PL;      // measured on config 2: shared launches win up to 4 problems (x 7 latents), one launch per kernel from 5
+constexpr int kFuseMaxPL = 32;      // measured on config 2: shared launches win up to 4 problems (x 7 latents), one launch per kernel from 5
 __device__ __forceinline__ double matern52_dell(double t1, double t2, double ell, double var) {
     double r = fabs(t1 - t2) / ell;
     return var * exp(-kSqrt5 * r) * (5.0 * r * r / (3.0 * ell)) * (1.0 + kSqrt5 * r);

@@ -39,16 +39,9 @@ struct CovArgs {
     vg_workspace ws;
 };
 
-#ifndef VG_ELIM_PANELS
-#define VG_ELIM_PANELS 1      // 0: measurement builds with the 32-pivot one-wave elimination
-#endif
 // stores of stage B that the NEXT launch reads (never this one): past the caches -- dirty lines left in L2 lengthen the
-// hand-over to that launch (VG_HO_PLAIN: measurement builds with plain stores)
-#ifdef VG_HO_PLAIN
-#define VG_HO(p, v) (*(p) = (v))
-#else
+// hand-over to that launch
 #define VG_HO(p, v) vg_stream((p), (v))
-#endif
 constexpr int kCovThreads = 256;      // == kBlock: the covariance roles share launches with other kernels
 constexpr int kRowTile = 8;
 
@@ -495,7 +488,7 @@ __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, 
     // this workgroup, which is the longest role of its launch)
     double* Lkg = a.ws.Lk64 + pl * Mz * Mz;
     double* Lig = a.ws.Li64 + pl * Mz * Mz;
-    if (VG_ELIM_PANELS && Mz > 16 && Mz <= 32 && a.elim_wave) {
+    if (Mz > 16 && Mz <= 32 && a.elim_wave) {
         chol_inverse_panels(La, Li, Sc, rsd, Mz, ld, tid, nt, Lkg, Lig);
         VG_T(l == 0 && p == 0, 102);
     } else {

@@ -2,9 +2,6 @@
 #pragma once
 #include "vgpmp_device.h"
 
-#ifndef VG_LOG1P_NEWTON
-#define VG_LOG1P_NEWTON 1
-#endif
 constexpr double kVarFloor = 0.1;               // models/vgpmp.py:139 positive(lower=1e-1)
 constexpr double kSqrt5 = 2.2360679774997896964;
 constexpr double kZLow = 0.09, kZHigh = 0.91;   // models/vgpmp.py:41 bounded_Z: tfb.Sigmoid(0.09, 0.91)
@@ -18,13 +15,9 @@ __device__ __forceinline__ double softplus_d(double x) { return fmax(x, 0.0) + l
 // with t = (1 + e) exp(-y0) = 1 + d the correction log(t) = d - d^2 / 2 + O(d^3) leaves ~1e-21.  (The library log1p is a
 // long routine of its own; here the only long routine on the chain is exp, which the caller has just run.)
 __device__ __forceinline__ double vg_log1p_unit(double e) {
-#if VG_LOG1P_NEWTON
     const double y0 = (double)__logf((float)(1.0 + e));
     const double d = (1.0 + e) * exp(-y0) - 1.0;
     return y0 + (d - 0.5 * d * d);
-#else
-    return log1p(e);
-#endif
 }
 __device__ __forceinline__ void softplus_sigmoid_d(double x, double* sp, double* sg) {
     const double e = exp(-fabs(x)), r = 1.0 / (1.0 + e);

@@ -22,50 +22,12 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 #else
 #define VG_STOP(args, k) do { } while (0)
 #endif
-#ifndef VG_EPS_FIRST
-#define VG_EPS_FIRST 1
-#endif
-#ifndef VG_JCHUNK_ONE
-#define VG_JCHUNK_ONE 8       // points per workgroup of the feature role at one problem
-#endif
-#ifndef VG_H_MT2_MIN_TILES
-#define VG_H_MT2_MIN_TILES 300      // 36 problems: 330.5 -> 325.5 us per step; from 48 problems no difference
-#endif
-#ifndef VG_ROWS_TPW_WGS
-#define VG_ROWS_TPW_WGS 256       // 24 problems: 405.6 -> 392.7 us per step against 2048, 13: 244.4 -> 241.9, 3: unchanged
-#endif
-#ifndef VG_ROWS_TPW_MAX
-#define VG_ROWS_TPW_MAX 2      // config-5 share: 976 / 965 / 1041 us per step with 1 / 2 / 4 tiles per workgroup, config 3: 241 / 234 / 237
-#endif
-#ifndef VG_FWD_REGS
-#define VG_FWD_REGS 1        // 0: measurement builds with the forward path assembly of large batches on paths_fwd_sc8
-#endif
-#ifndef VG_PB_PAIRS
-#define VG_PB_PAIRS 1
-#endif
-#ifndef VG_PB_MIN_WGS
-#define VG_PB_MIN_WGS 1536    // reverse path pass: chunks per workgroup double while this many workgroups remain (six per CU)
-#endif
-#ifndef VG_LIK_PATHS
-#define VG_LIK_PATHS 1        // 0: measurement builds with stage 3 (paths_fwd) as a launch of its own at few problems
-#endif
-#ifndef VG_BATCH_MERGE
-#define VG_BATCH_MERGE 1      // 0: measurement builds with every small launch of the large-batch schedule on its own
-#endif
-#ifndef VG_FB_MT2
-#define VG_FB_MT2 1          // 0: measurement builds with 64-row tiles of the fused prior kernel at every batch size
-#endif
-#ifndef VG_COV_WITH_PRIOR
-#define VG_COV_WITH_PRIOR 0  // 1: stage B of the covariance path inside the launch of the float32 fused prior kernel (28-34 problems).  It paid
-                             // against that kernel alone (477 -> 432 us per step at 28 problems); against the f16-split kernel + cov_b as
-                             // two launches it loses 30 % (387 vs 273 us)
-#endif
-#ifndef VG_FIN_SPLIT
-#define VG_FIN_SPLIT 1      // 0: measurement builds with the update role of stage 1 on one workgroup per latent
-#endif
-#ifndef VG_XCD_PATHS
-#define VG_XCD_PATHS 1      // 0: measurement builds without the XCD-contiguous order of the path launches
-#endif
+// ---- schedule constants (each measured; the sweeps are in profiles/r03/final/problems_sweep.txt and DESIGN section 3)
+constexpr int kJChunkOne = 8;          // points per workgroup of the feature role at one problem
+constexpr int kHMt2MinTiles = 300;     // f16-split prior kernel: 128-row tiles above this many of them (36 problems: 330.5 -> 325.5 us per step)
+constexpr int kRowsTpwWgs = 256;       // stage B rows role: two tiles per workgroup once the launch has this many workgroups (24 problems: 405.6 -> 392.7 us)
+constexpr int kRowsTpwMax = 2;         // ... and never more (config-5 share: 976 / 965 / 1041 us per step with 1 / 2 / 4)
+constexpr int kPbMinWgs = 1536;        // reverse path pass: chunks per workgroup double while this many workgroups remain (six per CU)
 
 #include "gp_common.h"
 #include "gp_rng.h"
@@ -115,7 +77,6 @@ __global__ __launch_bounds__(kBlock) void stage1_kernel(Stage1Args a) {
         return;
     }
     b -= a.n_fin;
-#if VG_EPS_FIRST
     // the eps draws ahead of the feature role (one or two problems: everything is resident at once, and the workgroups at the
     // END of the grid were the last to finish -- 1.4 us behind cov_a)
     if (b < a.n_eps) {
@@ -132,24 +93,6 @@ __global__ __launch_bounds__(kBlock) void stage1_kernel(Stage1Args a) {
     b /= a.feat_gx;
     features_body<PRO>(a.feat, bx, b % a.feat_gy, b / a.feat_gy);
     VG_TMAX(163);
-#else
-    // the feature role before the (short) eps draws: long roles at the front of the grid start in the first round of
-    // workgroups, the short ones fill in behind (matters from 3 problems, where the launch exceeds what is resident at once)
-    if (b < a.n_feat) {
-        if (a.skip & 8) return;
-        const int bx = b % a.feat_gx;
-        b /= a.feat_gx;
-        features_body<PRO>(a.feat, bx, b % a.feat_gy, b / a.feat_gy);
-        VG_TMAX(163);
-        return;
-    }
-    b -= a.n_feat;
-    if (!(a.skip & 4)) {
-        if (a.rng.epsT) rng_eps_t_body(a.rng, b % a.eps_gx, b / a.eps_gx, reinterpret_cast<float*>(sm));
-        else rng_normals_body(a.rng, b % a.eps_gx, b / a.eps_gx, 0u, a.rng.nE);
-    }
-    VG_TMAX(162);
-#endif
 }
 
 struct Stage2Args {
@@ -269,51 +212,6 @@ __global__ __launch_bounds__(kCovThreads) void mid_cov_a_rng_kernel(MidAArgs a) 
     if (b < a.n_norm) { rng_normals_body(a.rng, b % a.n_gx, b / a.n_gx, a.rng.nW, a.rng.nE); return; }
     b -= a.n_norm;
     rng_eps_t_body(a.rng, b % a.e_gx, b / a.e_gx, reinterpret_cast<float*>(sm));
-}
-
-struct MidCArgs {            // cov_b | tiled prior GEMM
-    CovArgs cov; TiledGemmArgs gemm;
-    int cov_roles, n_cov, n_gemm, gemm_gx, gemm_gy;
-};
-template <bool TANGENTS>
-__global__ __launch_bounds__(kBlock) void mid_cov_b_gemm_kernel(MidCArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    int b = blockIdx.x;
-    // the GEMM tiles first: each runs for the whole launch (K = all bases), the covariance roles ~10 us -- behind 600+
-    // of those the tiles started late and piled up on a few CUs (6 problems: 96.6 us for this launch, 7: 67.4)
-    if (b < a.n_gemm) {
-        const int bx = b % a.gemm_gx;
-        b /= a.gemm_gx;
-        prior_gemm_tiled_body<1>(a.gemm, reinterpret_cast<float*>(sm), bx, b % a.gemm_gy, b / a.gemm_gy);
-        return;
-    }
-    b -= a.n_gemm;
-    const int role = cov_role_rotated(b, a.cov_roles);
-    b /= a.cov_roles;
-    cov_b_body<TANGENTS>(a.cov, sm, role, b % a.cov.L, b / a.cov.L);
-}
-
-// ---- large batches: the covariance roles of stage B beside the fused prior kernel.  cov_b is a launch of latency-bound
-// float64 chains (90 us at 64 Franka problems, 174 us at config 5) that leaves most of the chip's issue slots idle, the
-// prior kernel is MFMA / VALU bound and independent of it: one launch, prior tiles first (they run ~115 us each).
-struct BatchCArgs {
-    CovArgs cov; FusedBatchArgs fb;
-    int cov_roles, n_prior, fb_gx, fb_gy;
-};
-template <bool DELL, int DM>
-__global__ __launch_bounds__(kBlock) void batch_cov_b_prior_kernel(BatchCArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    int b = blockIdx.x;
-    if (b < a.n_prior) {
-        const int bx = b % a.fb_gx;
-        b /= a.fb_gx;
-        prior_fused_batch_body<DELL, DM>(a.fb, reinterpret_cast<float*>(sm), bx, b % a.fb_gy, b / a.fb_gy);
-        return;
-    }
-    b -= a.n_prior;
-    const int role = cov_role_rotated(b, a.cov_roles);
-    b /= a.cov_roles;
-    cov_b_body<true>(a.cov, sm, role, b % a.cov.L, b / a.cov.L);
 }
 
 struct MidGArgs {            // hyper-parameter update | q_mu, q_sqrt update + ELBO pieces
@@ -553,7 +451,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     fe.N = N; fe.Mz = Mz; fe.L = L; fe.D = L; fe.B = B;
     // few problems: few points per workgroup (more parallelism); many: sweep 16 points per lane (omega reuse)
     // (shared launches: 8 for one problem -- the role is off the pole either way --, 16 from two: 105 -> 95 us per step)
-    fe.jchunk = fused ? (P > 1 ? 16 : VG_JCHUNK_ONE) : (P * L >= 16 ? 16 : 4);
+    fe.jchunk = fused ? (P > 1 ? 16 : kJChunkOne) : (P * L >= 16 ? 16 : 4);
     fe.X = pb->X; fe.Zy = zy; fe.zy_stride = zy_stride; fe.raw_ell = params->raw_ell; fe.raw_var = params->raw_var;
     fe.omega = nz->omega; fe.beta = nz->beta; fe.Phi = ws->Phi; fe.dPhi = want_dell ? ws->dPhi : nullptr;
     fe.tick = (!fused && do_adam) ? ctr : nullptr;
@@ -593,11 +491,11 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     // paths_bwd_sc8: sample chunks per workgroup -- as many as leave six workgroups per CU (the values do not depend on it)
     pa.cpw = 1;
     if (!(what & VGPMP_BWD_ONE_CHUNK)) {
-        while (pa.cpw < NC && (size_t)P * L * ((NC + 2 * pa.cpw - 1) / (2 * pa.cpw)) >= VG_PB_MIN_WGS) pa.cpw *= 2;
+        while (pa.cpw < NC && (size_t)P * L * ((NC + 2 * pa.cpw - 1) / (2 * pa.cpw)) >= kPbMinWgs) pa.cpw *= 2;
         // the register-resident path kernels (Mz = 32, one slab) work on PAIRS of chunks: two per workgroup as soon as that
         // leaves a workgroup per CU, four from ~600 workgroups (6 problems of config 2's shape: 155 -> 147 us per step, 13: 187 ->
         // 168, 24: 290 -> 245; the rule above alone left them on the one-chunk kernels below 28 problems)
-        const bool pairs = VG_PB_PAIRS && SK == 1 && Mz == 32 && (N & 3) == 0 && N <= 100 && NC >= 2 && P * L > kFuseMaxPL;
+        const bool pairs = SK == 1 && Mz == 32 && (N & 3) == 0 && N <= 100 && NC >= 2 && P * L > kFuseMaxPL;
         if (pairs && pa.cpw < 2 && (size_t)P * L * ((NC + 1) / 2) >= 256) pa.cpw = 2;
         if (pairs && pa.cpw == 2 && NC >= 4 && (size_t)P * L * ((NC + 3) / 4) >= 600) pa.cpw = 4;
     }
@@ -637,7 +535,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     // workgroups (a 16-row MFMA pass is full then; four make the rows workgroups the long ones of the launch: slower again)
     const int row_tiles = (N + kRowTile - 1) / kRowTile;
     int rows_tpw = 1;
-    while (rows_tpw < VG_ROWS_TPW_MAX && (size_t)P * L * (kCovFixedRoles + (row_tiles + 2 * rows_tpw - 1) / (2 * rows_tpw)) >= VG_ROWS_TPW_WGS) rows_tpw *= 2;
+    while (rows_tpw < kRowsTpwMax && (size_t)P * L * (kCovFixedRoles + (row_tiles + 2 * rows_tpw - 1) / (2 * rows_tpw)) >= kRowsTpwWgs) rows_tpw *= 2;
     ca.rows_tpw = rows_tpw;
     // (Mz = 32: cov_rows_body; any other Mz: cov_rows_padded_body, operands zero padded to Mp columns)
     const size_t lds_rows = Mz == 32
@@ -661,7 +559,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     lds_fin += fin_dma ? raw_fin : (size_t)fin_pass * row_fin;
     fa.dma = fin_pass;
     // few problems: the update role of stage 1 by column strips on kFinSplit workgroups (its LDS need is below lds_fin)
-    const bool fin_split = VG_FIN_SPLIT && fin_dma && Mz % (4 * kFinSplit) == 0 && (size_t)(M + M * (Mz / kFinSplit)) <= 2 * kBlock &&
+    const bool fin_split = fin_dma && Mz % (4 * kFinSplit) == 0 && (size_t)(M + M * (Mz / kFinSplit)) <= 2 * kBlock &&
                            !(what & VGPMP_NO_SPLIT);
     const size_t lds_s1 = lds_cov_a > lds_fin ? lds_cov_a : lds_fin;
     const void* fn_cov_b = backward ? (const void*)cov_b_kernel<true> : (const void*)cov_b_kernel<false>;
@@ -697,7 +595,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                            (size_t)P * L * NC * 2 <= 512 && !(what & VGPMP_NO_SPLIT);
     if (split_fwd) { pa.nsplit = 2; lds_pf = lds_pfs; }
     // few problems, Mz = 32: no stage 3 -- the likelihood assembles its paths, the reverse pass carries the noise roles
-    const bool lik_paths = VG_LIK_PATHS && fused && gen && backward && split_fwd && split_bwd && Mz == 32 && !lk && !pb->ind &&
+    const bool lik_paths = fused && gen && backward && split_fwd && split_bwd && Mz == 32 && !lk && !pb->ind &&
                            !(what & (VGPMP_LIK_LANES | VGPMP_LIK_LDS_STATE | VGPMP_NO_SPLIT)) && vg_lik_paths_fit(L, SK) &&
                            (long long)P * S * N <= 28672;
     ca.form_u = lik_paths ? 1 : 0; ca.S = S; ca.eps = ws->epsT;
@@ -716,7 +614,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         lds_pb = ((size_t)16 * N + (size_t)32 * J + (size_t)8 * 16 * Mz + 8 * 4) * sizeof(float);
     }
     // ... and the forward assembly likewise (paths_fwd_regs); both take pa.cpw chunks per workgroup
-    const bool regs_fwd = VG_FWD_REGS && !fused && !split_fwd && SK == 1 && Mz == 32 && N <= 128 && pa.cpw >= 2;
+    const bool regs_fwd = !fused && !split_fwd && SK == 1 && Mz == 32 && N <= 128 && pa.cpw >= 2;
     if (regs_fwd) {
         fn_pf = (const void*)paths_fwd_regs<2>;
         lds_pf = ((size_t)16 * (3 * Mz + J) + 4 * 4) * sizeof(float);
@@ -741,15 +639,6 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     // (the chip is full by then, the merged kernels only cost registers) -- hence the bound
     // few samples, four K-slices: features inside the GEMM (prior_fused_small_kernel)
     const bool fused_small = !fused && SK == 4 && S <= 32 && (B % 64) == 0 && !(what & VGPMP_GEMM_DIRECT);
-    // (bounds measured at S = 128; the work per problem scales with the samples)
-    const long long pls = (long long)P * L * S;
-    const bool mid = !fused && !ev && !pb->ind && (tiled_gemm || fused_small) && backward && !(what & VGPMP_NO_FUSE) &&
-                     pls <= (long long)kMid2MaxPL * 128;
-    const bool mid_gemm = tiled_gemm && pls <= (long long)kMidMaxPL * 128;      // cov_b beside the GEMM only while the chip is not full
-    const size_t lds_tg1 = (size_t)2 * (kTS + kTJ) * kTLd * sizeof(float);
-    const size_t lds_midC = lds_cov_b > lds_tg1 ? lds_cov_b : lds_tg1;
-    const void* fn_midC = backward ? (const void*)mid_cov_b_gemm_kernel<true> : (const void*)mid_cov_b_gemm_kernel<false>;
-    if (mid && (rc = set_dyn_lds(fn_midC, lds_midC))) return rc;
     if (!fused && (rc = set_dyn_lds((const void*)mid_cov_a_rng_kernel, lds_cov_a))) return rc;      // (the large-batch schedule merges its small launches with these two as well)
     if ((rc = set_dyn_lds((const void*)mid_hyper_final_kernel, lds_fin))) return rc;
     const dim3 cov_b_grid(kCovFixedRoles + (row_tiles + rows_tpw - 1) / rows_tpw, L, P);
@@ -871,42 +760,13 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 // the counter has ticked in stage 2: it already names the next step
                 s3.rng = make_rng_args(d, nz, seed, problem_base, step_i + 1u, ctr, 0u);
                 s3.n_path = NC * pa.nsplit * L * P;
-                s3.path.xcd_span = VG_XCD_PATHS && s3.n_path % 8 == 0 ? s3.n_path / 8 : 0;
+                s3.path.xcd_span = s3.n_path % 8 == 0 ? s3.n_path / 8 : 0;
                 s3.basis_gx = (int)basis_gx; s3.w_gx = (int)w_gx;
                 s3.n_basis = (gen && ahead) ? (int)basis_gx * P : 0;
                 const unsigned n3 = s3.n_path + s3.n_basis + ((gen && ahead) ? w_gx * P : 0u);
                 if ((rc = launch(fn_s3, dim3(n3), &s3, lds_pf))) return rc;
             }
             draw_next = gen && ahead;
-        } else if (mid) {
-            // cov_a | noise draws;  features;  cov_b | tiled GEMM
-            MidAArgs ma;
-            ma.cov = ca;
-            ma.rng = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
-            ma.n_cov = L * P; ma.basis_gx = (int)basis_gx; ma.n_basis = gen ? (int)basis_gx * P : 0;
-            const unsigned n_draw = gen ? mid_normal_grid(ma) : 0u;
-            const unsigned nA = ma.n_cov + ma.n_basis + n_draw;
-            if ((rc = launch((const void*)mid_cov_a_rng_kernel, dim3(nA), &ma, lds_cov_a))) return rc;
-            if (!fused_small) hipLaunchKernelGGL(features_kernel, feat_grid, dim3(kBlock), 0, st, fe);
-            MidCArgs mc;
-            mc.cov = ca; mc.gemm = tga;
-            mc.cov_roles = (int)cov_b_grid.x; mc.n_cov = (int)(cov_b_grid.x * cov_b_grid.y * cov_b_grid.z);
-            mc.gemm_gx = (J + kTJ - 1) / kTJ; mc.gemm_gy = (S + kTS - 1) / kTS;
-            mc.n_gemm = mc.gemm_gx * mc.gemm_gy * P * L * ga.nsel;
-            const unsigned nC = (unsigned)mc.n_cov + (unsigned)mc.n_gemm;
-            if (mid_gemm) {
-                if ((rc = launch(fn_midC, dim3(nC), &mc, lds_midC))) return rc;
-            } else if (fused_small) {
-                if ((rc = launch(fn_cov_b, cov_b_grid, &ca, lds_cov_b))) return rc;
-                launch_fused_small(nullptr, nullptr);
-            } else {
-                if ((rc = launch(fn_cov_b, cov_b_grid, &ca, lds_cov_b))) return rc;
-                const size_t lds_tg = (size_t)2 * (kTS + kTJ) * kTLd * sizeof(float);
-                if ((rc = set_dyn_lds((const void*)prior_gemm_tiled_kernel<1>, lds_tg))) return rc;
-                hipLaunchKernelGGL(prior_gemm_tiled_kernel<1>, dim3((J + kTJ - 1) / kTJ, (S + kTS - 1) / kTS, P * L * ga.nsel),
-                                   dim3(kBlock), lds_tg, st, tga);
-            }
-            if ((rc = launch(fn_pf, dim3(regs_fwd ? (NC + pa.cpw - 1) / pa.cpw : NC * pa.nsplit, L, P), &pa, lds_pf))) return rc;
         } else {
             mark();
             // large batches drawing their own noise: W and the features are formed inside the GEMM (prior_fused_batch_kernel);
@@ -914,7 +774,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             const bool fbatch = gen && tiled_gemm && !fused_small && !ind && !(what & VGPMP_NO_FUSE_PRIOR);
             // the small launches of a step share launches here too (not while profiling stage by stage): stage A of the
             // covariance path beside the noise draws, the two updates at the end in one, the counter tick inside paths_fwd
-            const bool batch_merge = VG_BATCH_MERGE && gen && backward && !ev && !ind && !lk && !(what & (VGPMP_COV_ONLY | VGPMP_NO_FUSE));
+            const bool batch_merge = gen && backward && !ev && !ind && !lk && !(what & (VGPMP_COV_ONLY | VGPMP_NO_FUSE));
             if (batch_merge) {
                 MidAArgs ma;
                 ma.cov = ca;
@@ -926,14 +786,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             } else {
                 hipLaunchKernelGGL(cov_a_kernel, dim3(L, P), dim3(kCovThreads), lds_cov_a, st, ca);
             }
-            // ... and stage B of the covariance path rides in the same launch while the prior tiles leave room in their
-            // (single) round of two workgroups per CU: 28 problems 477 -> 432 us per step, 32: 500 -> 480; once the tiles
-            // fill the chip the covariance roles only queue behind them at the tiles' register budget (64 problems +0.7 %,
-            // config 5 +7.5 %).  Not while profiling stage by stage.
-            const size_t n_prior_tiles = (size_t)((J + kTJ - 1) / kTJ) * ((S + kTS - 1) / kTS) * P * L;
-            const bool cov_with_prior = VG_COV_WITH_PRIOR && fbatch && backward && !ev && n_prior_tiles <= 480 &&
-                                        !(what & (VGPMP_COV_ONLY | VGPMP_NO_FUSE));
-            if (!cov_with_prior && (rc = launch(fn_cov_b, cov_b_grid, &ca, lds_cov_b))) return rc;
+            if ((rc = launch(fn_cov_b, cov_b_grid, &ca, lds_cov_b))) return rc;
             if (what & VGPMP_COV_ONLY) return (int)hipGetLastError();     // Kuu, Cholesky, q_sqrt, A, per-latent KL: done
             mark();
             if (gen && !batch_merge) {
@@ -965,19 +818,18 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 // when the last round of P L workgroups over the 256 CUs is at least 70 % full (40 problems: +10 % otherwise);
                 // the 16-wide joint padding (9-16 joints) measured 1.4 % slower with them (config 5), so 8-wide only.
                 const int fb_tail = (int)(((size_t)P * L) % 256);
-                const int fmt = VG_FB_MT2 && !cov_with_prior && S > kTS && dm == 8 && (size_t)P * L >= 256 &&
+                const int fmt = S > kTS && dm == 8 && (size_t)P * L >= 256 &&
                                 (fb_tail == 0 || fb_tail >= 180) ? 2 : 1;
                 const size_t lds_fb = ((size_t)kTS * fmt * kFBLd + (size_t)2 * kTJ * kFBLd + (size_t)kTJ * dm + (size_t)2 * kFBK * (dm + 4)) * sizeof(float);
                 const dim3 fb_grid((J + kTJ - 1) / kTJ, (S + kTS * fmt - 1) / (kTS * fmt), P * L);
                 // the f16-split form (gp_prior_split.h): 512-thread workgroups, 128-row tiles whenever there are more than 64
-                // samples, two workgroups per CU; the float32-MFMA kernel stays behind VGPMP_PRIOR_F32 and for the launch
-                // shared with stage B of the covariance path
-                const bool split16 = !cov_with_prior && !(what & VGPMP_PRIOR_F32);
+                // samples, two workgroups per CU; the float32-MFMA kernel stays behind VGPMP_PRIOR_F32 (the tests' reference form)
+                const bool split16 = !(what & VGPMP_PRIOR_F32);
                 if (split16) {
                     // (128-row tiles halve the feature work per sample, but below ~one tile per CU their workgroups run alone:
                     //  64-row tiles then, twice the workgroups at ~0.6 of the duration)
                     const size_t h_tiles2 = (size_t)((J + kTJ - 1) / kTJ) * ((S + 2 * kTS - 1) / (2 * kTS)) * P * L;
-                    const int hmt = S > kTS && h_tiles2 > VG_H_MT2_MIN_TILES ? 2 : 1;
+                    const int hmt = S > kTS && h_tiles2 > kHMt2MinTiles ? 2 : 1;
                     const size_t lds_h = vg_fused_split_lds(hmt);
                     const dim3 hgrid((J + kTJ - 1) / kTJ, (S + kTS * hmt - 1) / (kTS * hmt), P * L);
 #define VG_FH(DELL_, MT_)                                                                                                 \
@@ -988,17 +840,6 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                     if (want_dell) { if (hmt == 2) VG_FH(true, 2); else VG_FH(true, 1); }
                     else { if (hmt == 2) VG_FH(false, 2); else VG_FH(false, 1); }
 #undef VG_FH
-                } else if (cov_with_prior) {
-                    BatchCArgs bc;
-                    bc.cov = ca; bc.fb = fb;
-                    bc.cov_roles = (int)cov_b_grid.x; bc.fb_gx = (int)fb_grid.x; bc.fb_gy = (int)fb_grid.y;
-                    bc.n_prior = (int)(fb_grid.x * fb_grid.y * fb_grid.z);
-                    const unsigned nB = (unsigned)bc.n_prior + cov_b_grid.x * cov_b_grid.y * cov_b_grid.z;
-                    const size_t lds_bc = lds_fb > lds_cov_b ? lds_fb : lds_cov_b;
-                    const void* fn_bc = want_dell ? (dm == 8 ? (const void*)batch_cov_b_prior_kernel<true, 8> : (const void*)batch_cov_b_prior_kernel<true, 16>)
-                                                  : (dm == 8 ? (const void*)batch_cov_b_prior_kernel<false, 8> : (const void*)batch_cov_b_prior_kernel<false, 16>);
-                    if ((rc = set_dyn_lds(fn_bc, lds_bc))) return rc;
-                    if ((rc = launch(fn_bc, dim3(nB), &bc, lds_bc))) return rc;
                 } else {
 #define VG_FB(DELL_, DM_)                                                                                                 \
     do {                                                                                                                  \
@@ -1047,7 +888,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             return (int)hipGetLastError();
         }
         // ---- reverse of the path assembly (+ hyper-parameter update), then (here or in the next stage 1) the rest
-        pa.xcd_span = VG_XCD_PATHS && split_bwd && (2 * NC * L * P) % 8 == 0 ? 2 * NC * L * P / 8 : 0;
+        pa.xcd_span = split_bwd && (2 * NC * L * P) % 8 == 0 ? 2 * NC * L * P / 8 : 0;
         if (lik_paths) {
             Stage4Args s4;
             s4.path = pa;
@@ -1072,7 +913,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             hipLaunchKernelGGL(lik_update_kernel, dim3(P), dim3(kLikUpdWaves * VGPMP_MAX_SPHERES), 0, st, lu);
         }
         mark();
-        if (mid || batch_merged || (fused && !more)) {      // (fused, more steps to come: both ride in stage 1 of the next step)
+        if (batch_merged || (fused && !more)) {      // (fused, more steps to come: both ride in stage 1 of the next step)
             MidGArgs mg;
             hy.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
             fa.lr_t = hy.lr_t;

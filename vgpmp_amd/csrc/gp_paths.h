@@ -301,9 +301,6 @@ __device__ __forceinline__ void paths_fwd_split_body(const PathArgs& a, float* s
 //   hyper-parameters by dot products with the forward-mode tangents of the covariance kernels:
 //   s_ell = <R, G A_ell> + <dR, C_ell eps> + <G, H_X> - <dR, H_Z>
 //   s_var = <R, G A_var> + <dR, C_var eps> ;  s_rff = <G, F0_X> - <dR, F0_Z>   (x 1/(2 var) later)
-#ifndef VG_PB_SKIP
-#define VG_PB_SKIP 0      // measurement: 1 = no MFMA tiles, 2 = no element-wise part, 4 = no dm / dC partials, 8 = chunk operands staged once
-#endif
 template <int SK, bool RAW>
 __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
     constexpr int SC = 8;
@@ -353,7 +350,7 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
     for (int ch = blockIdx.x * a.cpw; ch < ch_end; ++ch) {
     const int s_base = ch * SC;
     VG_T(ch == 0 && l == 0 && p == 0, 500);
-    if (!(VG_PB_SKIP & 8) || ch == (int)blockIdx.x * a.cpw) {
+    {
         vg_stage_rows(Gs, SC, N, tid, nt, [&](int r) -> const float* {
             const int s = s_base + r;
             return s < S ? a.G + (((size_t)p * S + s) * L + l) * N : nullptr;              // zero beyond S
@@ -403,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
     // Mz = 32: the five small products as 16 x 16 MFMA tiles (8 sample rows used) -- waves 0..2 one component of G A each
     // (both column halves), wave 3 the two triangular products -- instead of N-long scalar chains per thread
     const bool tiles = Mz == 32 && (N & 3) == 0 && nt == 256;
-    if (tiles && !(VG_PB_SKIP & 1)) {
+    if (tiles) {
         const int wv = tid >> 6, lane = tid & 63, i = lane & 15, kk = lane >> 4;
         if (wv < 3) {
             vg_f32x4_t acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -445,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
         }
         __syncthreads();
     }
-    for (int e = tid; e < ((VG_PB_SKIP & 2) ? 0 : SC * Mz); e += nt) {
+    for (int e = tid; e < SC * Mz; e += nt) {
         const int sl = vg_div(e, iMz), mi = e - sl * Mz;
         const float* g = Gs + sl * N;
         float d = 0.f, de = 0.f, dv = 0.f;
@@ -469,7 +466,7 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
         se += rv * de + d * ue - d * hs[sl * J + N + mi];
         sr -= d * f0s[sl * J + N + mi];
     }
-    for (int e = tid; e < ((VG_PB_SKIP & 2) ? 0 : SC * N); e += nt) {
+    for (int e = tid; e < SC * N; e += nt) {
         const int sl = vg_div(e, iN), n = e - sl * N;
         const float gv = Gs[e];             // zero for samples beyond S
         sr = fmaf(gv, f0s[sl * J + n], sr);
@@ -479,13 +476,13 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
     VG_T(ch == 0 && l == 0 && p == 0, 502);
     VG_STOP(a, 3);
     float* out = a.part + (pl * a.NC + ch) * a.part_len;
-    for (int mi = tid; mi < ((VG_PB_SKIP & 4) ? 0 : Mz); mi += nt) {
+    for (int mi = tid; mi < Mz; mi += nt) {
         float t = 0.f;
         for (int sl = 0; sl < SC; ++sl) t += dRs[sl * Mz + mi];
         vg_stream(out + mi, t);
     }
     float* oC = out + Mz;
-    for (int e = tid; e < ((VG_PB_SKIP & 4) ? 0 : Mz * Mz); e += nt) {
+    for (int e = tid; e < Mz * Mz; e += nt) {
         const int mi = vg_div(e, iMz), k = e - mi * Mz;
         float t = 0.f;
         for (int sl = 0; sl < SC; ++sl) t = fmaf(dRs[sl * Mz + mi], Es[sl * Mz + k], t);
@@ -516,11 +513,9 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
 // element-wise part, the partial sums and their order are those of paths_bwd_sc8: the same numbers, bit for bit
 // (tests/test_gpu_surface.py::test_reverse_path_pass_...).  Measured on paths_bwd_sc8 at the config-5 share (257 us): the
 // MFMA loops 82 us, per-chunk staging latency 73 us, staging the constants through LDS and the loop skeleton 46 us.
-#ifndef VG_PBR_WAVES
-#define VG_PBR_WAVES 3      // 168 registers: at 4 (128) the register-resident fragments spill (160 vs 132 us at the config-5 share)
-#endif
+constexpr int kPbrWaves = 3;     // 168 registers: at 4 (128) the register-resident fragments spill (160 vs 132 us at the config-5 share)
 template <int KS>
-__global__ __launch_bounds__(kBlock, VG_PBR_WAVES) void paths_bwd_regs(PathArgs a) {
+__global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) {
     constexpr int SC = 8, Mz = 32, R2 = 2 * SC;
     extern __shared__ float smf[];
     __shared__ float red[3][kBlock / VG_WAVE];

@@ -84,10 +84,7 @@ __global__ __launch_bounds__(kBlock) void features_kernel(FeatArgs a) {
 // each lane loads 4 consecutive k (16 B) per operand, so one load pair feeds 4 MFMAs (k = 4g + c).
 // =================================================================================================
 typedef float vg_f32x4 __attribute__((ext_vector_type(4)));
-#ifndef VG_KNT
-#define VG_KNT 3
-#endif
-constexpr int kNT = VG_KNT;     // 16-column tiles per wave
+constexpr int kNT = 3;     // 16-column tiles per wave
 
 struct GemmArgs {
     int S, L, J, B, SK, nsel;
@@ -563,10 +560,7 @@ struct FusedPriorArgs {
     size_t slab;
     uint32_t* tick;
 };
-#ifndef VG_KFNT_SMALL
-#define VG_KFNT_SMALL 2      // config 3 (55 problems, S = 7, J = 96): 234 / 198 / 194 / 210 us per step with 5 / 3 / 2 / 1 -- more, lighter waves
-#endif
-constexpr int kFNT = VG_KFNT_SMALL;      // column tiles per workgroup
+constexpr int kFNT = 2;     // column tiles per workgroup     // config 3 (55 problems, S = 7, J = 96): 234 / 198 / 194 / 210 us per step with 5 / 3 / 2 / 1 -- more, lighter waves
 template <int MT, int DM, bool DELL>    // 16-row sample tiles; joint-space extent padded to DM (8 or 16); d/d ell wanted
 __global__ __launch_bounds__(kBlock) void prior_fused_small_kernel(FusedPriorArgs a) {
     __shared__ float pts[kFNT * 16][DM];

@@ -41,9 +41,6 @@ typedef _Float16 vg_h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 vg_h8 __attribute__((ext_vector_type(8)));
 typedef float vg_f2 __attribute__((ext_vector_type(2)));
 
-#ifndef VG_HS_SKIP
-#define VG_HS_SKIP 0         // measurement: 1 = no products, 2 = no W draws, 4 = no features (results are garbage)
-#endif
 constexpr int kHK = 32;                  // K step = one v_mfma_f32_16x16x32_f16
 constexpr int kHThreads = 512;
 constexpr int kHRowBytes = 2 * kHK;      // 64-byte tile rows
@@ -191,7 +188,7 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
         const bool more = k0 + kHK < B;
         if (more) om_fetch(k0 + kHK);
         // ---- W: the thread's counter covers k = 8 wpart .. 8 wpart + 7: one 16-byte chunk of each half tile
-        if (!(VG_HS_SKIP & 2) && draws_w) {      // (uniform per wave)
+        if (draws_w) {      // (uniform per wave)
             float z[8];
             vg_normal8_mad(wbase + (uint32_t)(k0 >> 3), VG_STREAM_W, key, z);
             vg_h4 h0, l0, h1, l1;
@@ -208,7 +205,7 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
         const int u_first = MT == 2 ? wave : (wave >= 4 ? wave - 4 : 12 + wave);
         const int u_last = MT == 2 ? kUnits : (wave >= 4 ? 12 : kUnits);
         const int u_step = MT == 2 ? kHThreads / 64 : 4;
-        for (int u = (VG_HS_SKIP & 4) ? kUnits : u_first; u < u_last; u += u_step) {
+        for (int u = u_first; u < u_last; u += u_step) {
             const int t = u >> 1, h = u & 1;
             const int frow = 16 * h + r, prow = 16 * t + r;
             const vg_h8 fa = *reinterpret_cast<const vg_h8*>(Om + (ob * kHK + frow) * kHRowBytes + vg_swz(frow, g) * 16);
@@ -246,7 +243,7 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
             const vg_h8 ah = *reinterpret_cast<const vg_h8*>(Ah + aoff);
             const vg_h8 al = *reinterpret_cast<const vg_h8*>(Al + aoff);
             const int boff0 = r * kHRowBytes + vg_swz(r, g) * 16;      // (16 t + r has the swizzle of r)
-            constexpr int NT = (VG_HS_SKIP & 1) ? 0 : kTJ / 16;
+            constexpr int NT = kTJ / 16;
             vg_h8 bh[2][NU], bl[2][NU];
             auto load_b = [&](int t, int slot) {
 #pragma unroll

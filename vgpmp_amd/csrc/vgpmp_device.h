@@ -50,21 +50,14 @@ __device__ __forceinline__ void vg_pin(float& v) { asm volatile("" : "+v"(v)); }
 // anyway -- leave no dirty lines behind; the write-back of dirty L2 lines at the end of a kernel was measured to add
 // ~1 us to the hand-over after a launch that wrote 7.6 MB.
 typedef float vg_f32x4_t __attribute__((ext_vector_type(4)));
-#ifdef VG_STREAM_PLAIN      // measurement builds: ordinary stores instead
-template <typename T>
-__device__ __forceinline__ void vg_stream(T* p, T v) { *p = v; }
-#else
 template <typename T>
 __device__ __forceinline__ void vg_stream(T* p, T v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void vg_stream(float4* p, float4 v) {
     __builtin_nontemporal_store((vg_f32x4_t){v.x, v.y, v.z, v.w}, reinterpret_cast<vg_f32x4_t*>(p));
 }
-#endif
 
 // ---- global -> LDS staging without registers (global_load_lds, gfx950) ----------------------------
-#ifndef VG_DMA_AUX
-#define VG_DMA_AUX 0      // cache policy bits of the staging loads (2 = nt)
-#endif
+#define VG_DMA_AUX 0      // cache policy bits of the staging loads (plain)
 // A rolled `lds[e] = g[e]` loop compiles to load / wait / store per iteration: one memory round trip per
 // 256 elements (measured 10 us for the 74 KB of the reverse pass; 3 us with the form below).  Here every
 // request of the workgroup is issued back to back and lands in LDS by itself; ONE vg_dma_wait() + barrier
