@@ -199,6 +199,10 @@ typedef struct vgpmp_problem {
                              * the steps can be replayed */
     const vgpmp_lik_params* lik; /* host pointer, optional (see vgpmp_lik_params) */
     const vgpmp_inducing_params* ind; /* host pointer, optional (see vgpmp_inducing_params) */
+    vgpmp_stream aux_stream; /* optional second stream of the caller (NULL: none).  Large batches run stage B of the covariance path
+                              * on it BESIDE the prior draws of the same step (the two are independent; the float64 roles are
+                              * latency-bound and fill what the prior kernel's last round of workgroups leaves idle); forked from
+                              * and joined back into the call's stream by events, so the caller still synchronises on that alone */
 } vgpmp_problem;
 
 /* Outputs of an ELBO evaluation. */

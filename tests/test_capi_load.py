@@ -29,7 +29,7 @@ def test_struct_sizes_match_header_layout():
     assert ctypes.sizeof(capi.Sdf) == 8 + 16 + 24 + 8 + 8 + 8 + 16 + 16          # + free_mask, shift / count / words / reserved, clearances
     assert ctypes.sizeof(capi.Dims) == 40
     assert ctypes.sizeof(capi.Params) == 32 and ctypes.sizeof(capi.Noise) == 40
-    assert ctypes.sizeof(capi.Problem) == 72 and ctypes.sizeof(capi.Outputs) == 64 and ctypes.sizeof(capi.LikParams) == 72
+    assert ctypes.sizeof(capi.Problem) == 80 and ctypes.sizeof(capi.Outputs) == 64 and ctypes.sizeof(capi.LikParams) == 72
     assert ctypes.sizeof(capi.InducingParams) == 48
 
 

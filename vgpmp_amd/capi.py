@@ -96,7 +96,7 @@ class InducingParams(C.Structure):
 class Problem(C.Structure):
     _fields_ = [("X", C.c_void_p), ("Zy", C.c_void_p), ("y_u", C.c_void_p), ("alpha", C.c_double),
                 ("jitter", C.c_double), ("kl_scale", C.c_double), ("step_counter", C.c_void_p),
-                ("lik", C.POINTER(LikParams)), ("ind", C.POINTER(InducingParams))]
+                ("lik", C.POINTER(LikParams)), ("ind", C.POINTER(InducingParams)), ("aux_stream", C.c_void_p)]
 
 
 class Outputs(C.Structure):

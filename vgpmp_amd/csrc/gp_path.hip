@@ -416,6 +416,27 @@ static int set_dyn_lds(const void* fn, size_t bytes) { return vg_grant_dyn_lds(f
 // `num_steps` consecutive steps.  Few problems (and not under the per-stage profiler): the role-dispatched
 // stage launches above, with the variational-parameter update of step t riding in stage 1 of step t+1.
 // Many problems: every kernel fills the chip by itself, plain launches in sequence.
+// Fork / join events of an auxiliary stream (vgpmp_problem.aux_stream), created once per stream and kept: an event pair per call
+// would cost two host calls per step.  Guarded like the dynamic-LDS table (several host threads may drive several GPUs).
+static int vg_aux_events(hipStream_t aux, hipEvent_t* fork, hipEvent_t* join) {
+    constexpr int kSlots = 64;
+    static hipStream_t streams[kSlots];
+    static hipEvent_t evs[kSlots][2];
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < kSlots; ++i) {
+        if (streams[i] == aux && evs[i][0]) { *fork = evs[i][0]; *join = evs[i][1]; return 0; }
+        if (streams[i] == nullptr) {
+            VG_CHECK_HIP(hipEventCreateWithFlags(&evs[i][0], hipEventDisableTiming));
+            VG_CHECK_HIP(hipEventCreateWithFlags(&evs[i][1], hipEventDisableTiming));
+            streams[i] = aux;
+            *fork = evs[i][0]; *join = evs[i][1];
+            return 0;
+        }
+    }
+    return VGPMP_E_ARG;      // (more auxiliary streams than slots: the caller should reuse them)
+}
+
 int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sdf, const vgpmp_problem* pb,
                   const vgpmp_params* params, const vgpmp_params* am, const vgpmp_params* av, const vgpmp_noise* nz,
                   const vgpmp_outputs* out, const vg_workspace* ws, int what, int trainable, double lr, int adam_t,
@@ -786,7 +807,21 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             } else {
                 hipLaunchKernelGGL(cov_a_kernel, dim3(L, P), dim3(kCovThreads), lds_cov_a, st, ca);
             }
-            if ((rc = launch(fn_cov_b, cov_b_grid, &ca, lds_cov_b))) return rc;
+            // stage B of the covariance path beside the prior draws on the caller's auxiliary stream: independent of each other,
+            // both need only stage A | noise; joined before the path assembly.  (Merged into ONE launch the float64 roles queued
+            // behind the prior tiles at their register budget and lost 7 %: lesson 39; as a kernel of its own on a second queue
+            // they take the CUs the prior kernel's last, thin round of workgroups leaves idle.)
+            const bool cov_aside = pb->aux_stream && batch_merge && fbatch && (size_t)P * L >= 64;
+            hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+            if (cov_aside) {
+                hipStream_t aux = (hipStream_t)pb->aux_stream;
+                if ((rc = vg_aux_events(aux, &ev_fork, &ev_join))) return rc;
+                VG_CHECK_HIP(hipEventRecord(ev_fork, st));
+                VG_CHECK_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+                void* kargs[] = {&ca};
+                VG_CHECK_HIP(hipLaunchKernel(fn_cov_b, cov_b_grid, dim3(kBlock), kargs, lds_cov_b, aux));
+                VG_CHECK_HIP(hipEventRecord(ev_join, aux));
+            } else if ((rc = launch(fn_cov_b, cov_b_grid, &ca, lds_cov_b))) return rc;
             if (what & VGPMP_COV_ONLY) return (int)hipGetLastError();     // Kuu, Cholesky, q_sqrt, A, per-latent KL: done
             mark();
             if (gen && !batch_merge) {
@@ -867,6 +902,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             else
                 hipExtLaunchKernelGGL(prior_gemm_kernel<0>, gemm_grid, dim3(kBlock), 0, st, g0, g1, 0, ga);
             mark();
+            if (cov_aside) VG_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
             if ((rc = launch(fn_pf, dim3(regs_fwd ? (NC + pa.cpw - 1) / pa.cpw : NC * pa.nsplit, L, P), &pa, lds_pf))) return rc;
             pa.tick = nullptr;
             mark();
