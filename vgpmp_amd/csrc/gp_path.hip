@@ -811,7 +811,10 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             // both need only stage A | noise; joined before the path assembly.  (Merged into ONE launch the float64 roles queued
             // behind the prior tiles at their register budget and lost 7 %: lesson 39; as a kernel of its own on a second queue
             // they take the CUs the prior kernel's last, thin round of workgroups leaves idle.)
-            const bool cov_aside = pb->aux_stream && batch_merge && fbatch && (size_t)P * L >= 64;
+            // Measured (r04, ms per step, two streams / one): 16 Franka problems 0.192 / 0.199, 64: 0.445 / 0.449, config-5 share
+            // (896 pairs of 14-joint latents) 0.920 / 0.907 -- there the prior kernel fills every round and the second queue only
+            // takes CUs from it: hence the upper bound.
+            const bool cov_aside = pb->aux_stream && batch_merge && fbatch && (size_t)P * L >= 64 && (size_t)P * L <= 512;
             hipEvent_t ev_fork = nullptr, ev_join = nullptr;
             if (cov_aside) {
                 hipStream_t aux = (hipStream_t)pb->aux_stream;
