@@ -577,9 +577,9 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     // otherwise in passes of as many chunks (a multiple of 8: the summation order goes by eights) as 96 KB hold
     const size_t row_fin = (size_t)(Mz + Mz * Mz) * sizeof(float);
     int fin_pass = fin_dma ? NC : (int)(((96 * 1024 - lds_fin) / row_fin) & ~(size_t)7);
-#ifdef VG_FIN_PASS8      // measurement: large batches in passes of eight chunks (a third workgroup per CU; the same sums in the same order)
+    // large batches: passes of eight chunks -- 46 instead of 80 KB of LDS, a third workgroup per CU; the same sums in the same order
+    // (config-5 share: 51 -> 47 us for the launch)
     if (!fused && NC > 8 && (size_t)P * L >= 512) fin_pass = 8;
-#endif
     lds_fin += (size_t)fin_pass * row_fin;
     fa.dma = fin_pass;
     // few problems: the update role of stage 1 by column strips on kFinSplit workgroups (its LDS need is below lds_fin)
