@@ -450,7 +450,9 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
 // batch b are issued, THEN the chain is advanced and the positions, voxel indices, addresses and free-space tests of batch
 // b + 1 are formed (the largest share of the vector work) while they are in flight, then the hinge and the force / moment sums
 // of batch b.  Two position / address buffers, one record buffer; U = 4 keeps it at two waves per SIMD.  Same arithmetic in
-// the same order as loglik_config_regs: bit-identical results.
+// the same order as loglik_config_regs: bit-identical results.  (Two batches of gathers in flight -- a second record buffer, the
+// gathers of batch b + 1 issued before the hinge of batch b -- measured 276 against 266 us with the masks and 399 against 414 us
+// with every sphere gathering: the pass sits at what the memory system serves in scattered 64-byte sectors, profiles/r04.)
 // FAR: 0 every sphere reads the table; 1 brick summary (requested for batch b + 1 under the gathers of batch b: straight-line
 // loads, so the compiler's wait for the gathers leaves them in flight); 2 free-space masks in LDS.
 template <int U, int FAR, typename LoadRaw, typename ToAngle, typename Emit>
@@ -569,21 +571,6 @@ __device__ __forceinline__ float loglik_config_pipe(const vgpmp_robot* __restric
         }
     };
     Batch A, B;
-#if VG_LIK_DEEP
-    // two batches of gathers in flight: those of batch b + 1 are issued before the hinge of batch b is formed
-    float4 va[U], vb[U];
-    stage1(0, A); issue(0, A, va);
-    if (U < P) { stage1(U, B); issue(U, B, vb); }
-#pragma nounroll
-    for (int q0 = 0; q0 < P; q0 += 2 * U) {
-        stage3(q0, A, va);
-        if (q0 + 2 * U < P) { stage1(q0 + 2 * U, A); issue(q0 + 2 * U, A, va); }
-        if (q0 + U < P) {
-            stage3(q0 + U, B, vb);
-            if (q0 + 3 * U < P) { stage1(q0 + 3 * U, B); issue(q0 + 3 * U, B, vb); }
-        }
-    }
-#else
     float4 v[U];
     stage1(0, A);
 #pragma nounroll
@@ -597,7 +584,6 @@ __device__ __forceinline__ float loglik_config_pipe(const vgpmp_robot* __restric
             stage3(q0 + U, B, v);
         }
     }
-#endif
     while (pcur <= D) flush();
     // second sweep over the chain: joint i turns about z of frame i (Craig) or frame i-1 (classic) and moves every
     // sphere on frames >= i, i.e. the totals minus the prefix < i
@@ -856,9 +842,6 @@ __global__ __launch_bounds__(BLK, REGS ? (PFX ? kLikPfxWaves : 2) : 1) void logl
 // 512^3 grid does not fit an XCD's L2 next to the table's lines: every query paid a scattered 4-byte load for it (36.9 M per launch
 // at the config-5 share) before its 16-byte gather.  Results are bit-identical (skipped spheres cost exactly 0).
 constexpr int kLikMaskBlock = 256;
-#ifndef VG_LIK_DEEP
-#define VG_LIK_DEEP 0      // measurement: two batches of gathers in flight
-#endif
 constexpr int kLikPipeU = 4;      // spheres per batch of the pipelined form (two batches in registers; 8 spills 190 registers)
 template <int FARM>
 __global__ __launch_bounds__(kLikMaskBlock, 2) void loglik_paths_mask_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
