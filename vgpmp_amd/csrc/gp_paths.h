@@ -513,7 +513,11 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
 // element-wise part, the partial sums and their order are those of paths_bwd_sc8: the same numbers, bit for bit
 // (tests/test_gpu_surface.py::test_reverse_path_pass_...).  Measured on paths_bwd_sc8 at the config-5 share (257 us): the
 // MFMA loops 82 us, per-chunk staging latency 73 us, staging the constants through LDS and the loop skeleton 46 us.
-constexpr int kPbrWaves = 3;     // 168 registers: at 4 (128) the register-resident fragments spill (160 vs 132 us at the config-5 share)
+#ifndef VG_PBR_BUFS
+#define VG_PBR_BUFS 1      // measurement: 2 = the next pair of chunks staged under the current pair's work
+#endif
+constexpr int kPbrBufs = VG_PBR_BUFS;
+constexpr int kPbrWaves = kPbrBufs > 1 ? 2 : 3;     // 168 registers: at 4 (128) the register-resident fragments spill (160 vs 132 us at the config-5 share)
 template <int KS>
 __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) {
     constexpr int SC = 8, Mz = 32, R2 = 2 * SC;
@@ -525,11 +529,15 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
     const size_t pl = (size_t)p * L + l;
     float* cur = smf;
     auto take = [&](int n) { float* q = cur; cur += (n + 3) & ~3; return q; };      // 16-byte aligned regions
-    float* Gs2 = take(R2 * N);                       // [16][N]      the pair's rows: chunk c at rows 8 c ..
-    float* f0s2 = take(2 * R2 * J);                  // [16][J] prior draws, then [16][J] their d/dell
-    float* hs2 = f0s2 + R2 * J;
-    float* Rs2 = take(R2 * Mz);                      // [16][Mz]
-    float* Es2 = take(R2 * Mz);                      // [16][Mz]
+    // the rows a pair of chunks stages: kPbrBufs sets of them (two: the next pair is requested under the current pair's work)
+    float *GsB[kPbrBufs], *f0B[kPbrBufs], *RsB[kPbrBufs], *EsB[kPbrBufs];
+#pragma unroll
+    for (int b = 0; b < kPbrBufs; ++b) {
+        GsB[b] = take(R2 * N);                       // [16][N]      the pair's rows: chunk c at rows 8 c ..
+        f0B[b] = take(2 * R2 * J);                   // [16][J] prior draws, then [16][J] their d/dell
+        RsB[b] = take(R2 * Mz);                      // [16][Mz]
+        EsB[b] = take(R2 * Mz);                      // [16][Mz]
+    }
     float* dRs2 = take(R2 * Mz);                     // [16][Mz]
     float* dGA = take(5 * R2 * Mz);                  // [5][16][Mz] G A, G A_ell, G A_var, eps C_var^T, eps C_ell^T
     const bool dell = a.want_dell != 0;
@@ -564,8 +572,9 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
             }
     }
     const int cp_end = min((int)(blockIdx.x + 1) * a.cpw, a.NC);
-    for (int ch0 = blockIdx.x * a.cpw; ch0 < cp_end; ch0 += 2) {
+    auto stage_pair = [&](int ch0, int b) {
         const int s_base = ch0 * SC;
+        float *Gs2 = GsB[b], *f0s2 = f0B[b], *Rs2 = RsB[b], *Es2 = EsB[b];
         {
             vg_stage_rows(Gs2, R2, N, tid, nt, [&](int r) -> const float* {
                 const int s = s_base + r;
@@ -591,8 +600,17 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
                 return (second ? a.H : a.F0) + (((size_t)p * S + s) * L + l) * J;
             });
         }
+    };
+    if (kPbrBufs > 1) stage_pair(blockIdx.x * a.cpw, 0);
+    int cb = 0;
+    for (int ch0 = blockIdx.x * a.cpw; ch0 < cp_end; ch0 += 2) {
+        if (kPbrBufs == 1) stage_pair(ch0, 0);
         vg_dma_wait();
         __syncthreads();
+        float *Gs2 = GsB[cb], *f0s2 = f0B[cb], *Rs2 = RsB[cb], *Es2 = EsB[cb];
+        float* hs2 = f0s2 + R2 * J;
+        // the next pair's rows into the other set while this pair is worked on (everybody has left that set: the barrier above)
+        if (kPbrBufs > 1) { if (ch0 + 2 < cp_end) stage_pair(ch0 + 2, cb ^ 1); cb ^= 1; }
         // ---- the five products on all sixteen rows
         if (wv < 3) {
             float av[KS];
