@@ -623,7 +623,9 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
         planner.sample_from_posterior(150, Xnew)[1].cpu()
         t_sample = time.perf_counter() - t1
 
-    # ---- per-kernel durations with HIP events (separate pass so the timed region stays clean)
+    # ---- per-kernel durations with HIP events (separate pass so the timed region stays clean), over the steps of a plan from
+    #      fresh models like a timed block: the SDF pass of a batch is 10-15 % slower in a plan's first steps than in its last
+    planner.reset()
     times = planner.profile_steps(max(1, args.profile_steps))
     kernel_ms = {k: times.pop(k) for k in ("loglik_kernel", "prior_gemm_kernel")}      # device start-to-end
     stage_ms = times
@@ -654,7 +656,7 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
                           "free_space_summary": bool(scene.free_space_summary), "free_space_masks_in_lds": bool(scene.free_space_mask),
                           "mask_bytes": int(scene.free_mask.numel() * 4) if scene.free_space_mask else 0},
                 "timing": "HIP events stamped with the kernel's start and end on its stream (hipExtLaunchKernel), "
-                          f"mean of {max(1, args.profile_steps)} launches"}
+                          f"mean of the first {max(1, args.profile_steps)} launches of a plan from fresh models"}
     # the kernel that forms the prior draws in the pass the events come from (one launch per kernel, device-drawn noise);
     # same selection as vg_elbo_steps (csrc/gp_path.hip)
     sk = planner.dims.split_k
@@ -808,22 +810,22 @@ def main():
         else:
             line = run_problem_sharded(args, world, rank, dist, backend)
             ctx = line.pop("_ctx", None) if rank == 0 else None
-            quick = ["--no-cpu-baseline", "--no-solve", "--warmup", "3", "--profile-steps", "5", "--min-seconds", "0.5"]
+            quick = ["--no-cpu-baseline", "--no-solve", "--warmup", "3", "--min-seconds", "0.5"]      # (+ --profile-steps = a whole plan)
             auto = default_workload and not (args.no_solve and args.no_cpu_baseline)      # (measurement runs of the line alone pass both)
             if args.also_stress == "on" or (args.also_stress == "auto" and auto):
                 # the batch regime in front of the driver: the 512-problem batch of the north star, this GPU's 64 (BASELINE
                 # config 5 share), whole plans of 200 steps from fresh models
-                rec = sub_record(["--workload", "stress", "--steps", "200"] + quick, world, rank, dist, backend)
+                rec = sub_record(["--workload", "stress", "--steps", "200", "--profile-steps", "200"] + quick, world, rank, dist, backend)
                 if rank == 0:
                     line["batch_512"] = rec
             if args.also_config3 == "on" or (args.also_config3 == "auto" and auto and world == 1):
                 # BASELINE config 3, the reference's literal benchmark workload: 55 Franka / bookshelves pairs, S=7, 130 steps
-                rec = sub_record(["--workload", "config3", "--steps", "130"] + quick, world, rank, dist, backend)
+                rec = sub_record(["--workload", "config3", "--steps", "130", "--profile-steps", "130"] + quick, world, rank, dist, backend)
                 if rank == 0:
                     line["config3"] = rec
                 # 64 problems of the line's own shape (config 2) as one batch: the GPU figure the problem-parallel CPU baseline
                 # is to be held against
-                rec = sub_record(["--problems", "64", "--steps", "200"] + quick, world, rank, dist, backend)
+                rec = sub_record(["--problems", "64", "--steps", "200", "--profile-steps", "200"] + quick, world, rank, dist, backend)
                 if rank == 0:
                     line["batch_64"] = rec
             if rank == 0 and ctx is not None and world == 1 and not args.no_cpu_baseline:

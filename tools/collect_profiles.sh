@@ -55,7 +55,7 @@ timeout 600 python bench.py --gpus 2 --shard samples --steps 100 --warmup 10 2>>
 timeout 900 python bench.py --gpus 2 --steps 100 --warmup 10 $Q 2> $out/gpus2.err | tail -1 > $out/gpus2_rehearsal_one_gpu_bench.json
 # ---- config 5 share: 14-DoF arm, 512^3 voxels (2 GiB table), 64 problems; by free-space test of the SDF pass:
 #      mask = bit masks in LDS (the default), summary = the brick summary in memory, none = every sphere gathers
-B5="--workload stress --steps 200 --warmup 3 $Q --profile-steps 10 --min-seconds 0.5"      # a timed block = a whole plan from fresh models
+B5="--workload stress --steps 200 --warmup 3 $Q --profile-steps 200 --min-seconds 0.5"      # a timed block = a whole plan from fresh models
 for f in ${FORMS:-mask:on:off summary:off:on none:off:off}; do
   IFS=: read name mk sm <<< "$f"; tag=config5_$name
   stats $tag $B5 --mask $mk --summary $sm
