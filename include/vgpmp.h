@@ -412,6 +412,21 @@ int vgpmp_comm_init(const void* id_bytes, int32_t world_size, int32_t rank, vgpm
 int vgpmp_allreduce_grads(vgpmp_comm* comm, double* dev_buf, size_t count, vgpmp_stream stream);
 int vgpmp_comm_destroy(vgpmp_comm* comm);
 
+/* The sample-sharded training loop in ONE call (SampleShardedPlanner.step() `num_steps` times without a host round trip per
+ * step): local forward + reverse of this rank's samples (`what`: measurement flags only; forward, backward, noise generation and
+ * the noise-ahead chaining are implied), the in-place all-reduce(sum) of `dev_reduce_buf` -- the caller's contiguous
+ * [gradient | lik | kl] buffer that out->grad / out->lik / out->kl point into -- over `comm` (NULL: a single rank, nothing to
+ * exchange), then Adam.apply_gradients (utils/miscellaneous.py:82) on every rank, all enqueued on `stream`.  `adam_t` = updates
+ * applied before this call, `step` = noise key of its first step; problem->step_counter must be NULL.  The loop being sharded:
+ * benchmarking.py:68-85 with the mean over samples of models/vgpmp.py:287. */
+int vgpmp_elbo_steps_reduced(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,
+                             const vgpmp_problem* problem, const vgpmp_params* params, const vgpmp_params* adam_m,
+                             const vgpmp_params* adam_v, const vgpmp_noise* noise, const vgpmp_outputs* out,
+                             void* dev_workspace, size_t workspace_bytes, int32_t what, int32_t trainable,
+                             double learning_rate, int32_t adam_t, uint32_t seed, uint32_t problem_base, uint32_t step,
+                             int32_t num_steps, vgpmp_comm* comm, double* dev_reduce_buf, size_t reduce_count,
+                             vgpmp_stream stream);
+
 /* Reads back intermediates of the last vgpmp_elbo_step from the workspace (parity tests):
  * name in {"A","C","m","F0","H","R","G","Phi"}; returns pointer and element count. */
 int vgpmp_workspace_view(const vgpmp_dims* dims, void* dev_workspace, const char* name,

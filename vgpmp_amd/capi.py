@@ -27,7 +27,7 @@ LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvgpmp_hip.so"
 EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_table_bytes", "vgpmp_sdf_pack", "vgpmp_sdf_mask_words", "vgpmp_sdf_free_mask", "vgpmp_mesh_sdf", "vgpmp_fk_spheres", "vgpmp_sdf_query", "vgpmp_sdf_index_float",
            "vgpmp_log_prob", "vgpmp_cov_matrices", "vgpmp_kernel_derivative", "vgpmp_velocity_kuu_kuf", "vgpmp_workspace_bytes", "vgpmp_lik_scratch_bytes", "vgpmp_inducing_scratch_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
            "vgpmp_elbo_steps", "vgpmp_elbo_step_profiled", "vgpmp_adam_step", "vgpmp_workspace_view", "vgpmp_sample_paths",
-           "vgpmp_comm_unique_id", "vgpmp_comm_init", "vgpmp_allreduce_grads", "vgpmp_comm_destroy")
+           "vgpmp_comm_unique_id", "vgpmp_comm_init", "vgpmp_allreduce_grads", "vgpmp_comm_destroy", "vgpmp_elbo_steps_reduced")
 NUM_STAGES = 8
 NUM_TIMES = 10
 STAGE_NAMES = ("cov_fwd", "noise", "features", "prior_gemm", "paths_fwd", "loglik_fk_sdf", "paths_bwd", "final_adam")
@@ -161,6 +161,8 @@ def load(require: bool = True) -> Optional[C.CDLL]:
         "vgpmp_comm_init": [vp, i32, i32, P(vp)],
         "vgpmp_allreduce_grads": [vp, vp, C.c_size_t, vp],
         "vgpmp_comm_destroy": [vp],
+        "vgpmp_elbo_steps_reduced": [P(Dims), vp, P(Sdf), P(Problem), P(Params), P(Params), P(Params), P(Noise), P(Outputs),
+                                     vp, C.c_size_t, i32, i32, dbl, i32, u32, u32, u32, i32, vp, vp, C.c_size_t, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

@@ -283,6 +283,30 @@ int vgpmp_elbo_steps(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const
                           nullptr, num_steps);
 }
 
+int vgpmp_elbo_steps_reduced(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,
+                             const vgpmp_problem* problem, const vgpmp_params* params, const vgpmp_params* adam_m,
+                             const vgpmp_params* adam_v, const vgpmp_noise* noise, const vgpmp_outputs* out,
+                             void* dev_workspace, size_t workspace_bytes, int32_t what, int32_t trainable,
+                             double learning_rate, int32_t adam_t, uint32_t seed, uint32_t problem_base, uint32_t step,
+                             int32_t num_steps, vgpmp_comm* comm, double* dev_reduce_buf, size_t reduce_count,
+                             vgpmp_stream stream) {
+    if (num_steps < 1 || adam_t < 0 || !adam_m || !adam_v || (comm && (!dev_reduce_buf || !reduce_count))) return VGPMP_E_ARG;
+    if (what & (VGPMP_DO_ADAM | VGPMP_COV_ONLY)) return VGPMP_E_ARG;      // the update follows the exchange: this call applies it
+    if (problem && problem->step_counter) return VGPMP_E_ARG;             // (the step comes from the arguments)
+    what |= VGPMP_DO_FORWARD | VGPMP_DO_BACKWARD | VGPMP_GEN_NOISE | VGPMP_NOISE_AHEAD;
+    for (int i = 0; i < num_steps; ++i) {
+        // local samples: forward + reverse into out->grad / lik / kl; every step but the caller's first finds its prior noise drawn
+        const int32_t w = (i > 0) ? (what | VGPMP_NOISE_READY) : what;
+        int rc = elbo_step_impl(dims, dev_robot, sdf, problem, params, adam_m, adam_v, noise, out, dev_workspace, workspace_bytes,
+                                w, trainable, learning_rate, adam_t + i + 1, seed, problem_base, step + (uint32_t)i, stream, nullptr);
+        if (rc) return rc;
+        if (comm && (rc = vgpmp_allreduce_grads(comm, dev_reduce_buf, reduce_count, stream))) return rc;
+        if ((rc = vg_launch_adam(dims, params, &out->grad, adam_m, adam_v, trainable, learning_rate, adam_t + i + 1, (hipStream_t)stream)))
+            return rc;
+    }
+    return 0;
+}
+
 int vgpmp_elbo_step_profiled(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,
                              const vgpmp_problem* problem, const vgpmp_params* params, const vgpmp_params* adam_m,
                              const vgpmp_params* adam_v, const vgpmp_noise* noise, const vgpmp_outputs* out,

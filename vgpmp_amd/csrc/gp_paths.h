@@ -513,10 +513,8 @@ __global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
 // element-wise part, the partial sums and their order are those of paths_bwd_sc8: the same numbers, bit for bit
 // (tests/test_gpu_surface.py::test_reverse_path_pass_...).  Measured on paths_bwd_sc8 at the config-5 share (257 us): the
 // MFMA loops 82 us, per-chunk staging latency 73 us, staging the constants through LDS and the loop skeleton 46 us.
-#ifndef VG_PBR_BUFS
-#define VG_PBR_BUFS 1      // measurement: 2 = the next pair of chunks staged under the current pair's work
-#endif
-constexpr int kPbrBufs = VG_PBR_BUFS;
+constexpr int kPbrBufs = 1;       // sets of staged rows (2 = the next pair requested under the current pair's work: 67 KB of LDS, two workgroups
+                                 // per CU instead of three -- measured 198 against 131 us at the config-5 share: the resident workgroups ARE the overlap)
 constexpr int kPbrWaves = kPbrBufs > 1 ? 2 : 3;     // 168 registers: at 4 (128) the register-resident fragments spill (160 vs 132 us at the config-5 share)
 template <int KS>
 __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) {

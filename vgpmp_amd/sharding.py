@@ -115,6 +115,27 @@ class SampleShardedPlanner:
         pl.adam_only()                                         # identical update on every rank
 
     def run_steps(self, steps: int) -> None:
+        """`steps` sharded steps.  With the C ABI's communicator (or a single rank and no group) the whole loop is ONE call,
+        vgpmp_elbo_steps_reduced: step, all-reduce and Adam enqueued from C -- at eight ranks a step is ~75 us of device work,
+        less than three host calls through Python."""
+        pl = self.planner
+        one_rank = self.comm is None and getattr(self, "_single_rank", False)
+        if steps > 0 and (self.comm is not None or one_rank):
+            import ctypes as C
+
+            from . import capi
+            from .engine import trainable_mask
+            what = (0 if pl.fuse else capi.NO_FUSE) | pl.extra_flags
+            ready = pl.noise_ahead_step == pl.t
+            capi.check(pl.lib.vgpmp_elbo_steps_reduced(
+                C.byref(pl.dims), capi.ptr(pl.scene.dev_robot), C.byref(pl.scene.sdf), C.byref(pl._problem), C.byref(pl._params),
+                C.byref(pl._am), C.byref(pl._av), C.byref(pl._noise), C.byref(pl._out), capi.ptr(pl.workspace), pl.workspace.numel(),
+                what | (capi.NOISE_READY if ready else 0), trainable_mask(pl.trainable), pl.lr, pl.t, pl.seed, pl.problem_base, pl.t,
+                int(steps), self.comm.handle if self.comm is not None else None, capi.ptr(pl.reduce_buf), pl.reduce_buf.numel(),
+                pl.scene._stream()), "vgpmp_elbo_steps_reduced")
+            pl.t += int(steps)
+            pl.noise_ahead_step = pl.t
+            return
         for _ in range(steps):
             self.step()
 
