@@ -517,6 +517,7 @@ def run_sample_sharded(args, world, rank, dist, backend):
     sp = sharding.SampleShardedPlanner(planner, comm=comm)
     if world == 1 and comm is None:
         sp._allreduce = lambda buf=None: None                 # nothing to exchange on one rank
+        sp._single_rank = True                                # ... and the whole loop is one C call (vgpmp_elbo_steps_reduced)
     sp.run_steps(args.warmup)
     elapsed, reps = timed_region(sp.run_steps, args, dist, backend)
     assert args.allow_nan or torch.isfinite(planner.q_mu).all(), "optimisation diverged"
@@ -563,6 +564,7 @@ def run_sample_sharded(args, world, rank, dist, backend):
                                   learning_rate=pp["learning_rate"], seed=1234)
         sp8 = sharding.SampleShardedPlanner(pl8)
         sp8._allreduce = lambda buf=None: None
+        sp8._single_rank = True
         sp8.run_steps(args.warmup)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -479,6 +479,31 @@ def test_noise_drawn_ahead_is_never_paired_with_another_step():
         assert torch.equal(x, y)
 
 
+def test_sharded_loop_in_one_call_equals_the_python_loop():
+    """vgpmp_elbo_steps_reduced (step, all-reduce, Adam enqueued from C; here one rank, nothing to exchange) against
+    SampleShardedPlanner.step() called from Python: bit for bit, also when the two are mixed."""
+    from vgpmp_amd import engine, sharding
+    ps = rb.load_problemset("ur10", "industrial")
+    spec = rb.load_robot("ur10", *ps.robot_pos_and_orn)
+    grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
+    sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
+    kw = dict(num_samples=64, num_inducing=12, num_data=40, num_bases=128, lengthscales=[2.0] * 6, variance=0.2, seed=9)
+    out = []
+    for c_loop in (False, True):
+        pl = engine.PlannerBatch(sc, np.array([ps.queries[0]]), **kw)
+        sp = sharding.SampleShardedPlanner(pl)
+        sp._allreduce = lambda buf=None: None
+        sp._single_rank = c_loop
+        sp.run_steps(5)
+        sp.step()                       # (a Python step in between: the noise-ahead chain carries over)
+        sp.run_steps(4)
+        torch.cuda.synchronize()
+        assert pl.t == 10
+        out.append([t.clone() for t in (pl.q_mu, pl.q_sqrt, pl.raw_ell, pl.raw_var, pl.adam_m[0], pl.adam_v[1], pl.f)])
+    for x, y in zip(*out):
+        assert torch.equal(x, y), float((x - y).abs().max())
+
+
 def test_elimination_forms_agree():
     """The factorisation of Kuu + jI runs on one wave with the augmented matrix in registers (Mz <= 32); the
     workgroup-wide form through LDS applies the same multipliers with the operands associated differently."""
