@@ -89,6 +89,14 @@ def test_committed_traffic_table_is_this_rounds():
     assert not any(k.startswith("Cijk_") or "at::native::sigmoid" in k for k in t)
     lik = [k for k in t if k.startswith("loglik_paths_wide_kernel")]
     assert lik and all(t[k]["hbm_bytes_per_launch"] > 0 for k in lik)
+    # round 4: the sub-records of the default line read their own tables, taken by the same collection
+    t5 = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_config5.json")))
+    t3 = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_config3.json")))
+    assert t5["collected_at"] == t["collected_at"] == t3["collected_at"]
+    assert t5["loglik_paths_mask_kernel<2>"]["hbm_bytes_per_launch"] > 1e8          # 2 GiB table: hundreds of MB of sectors per launch
+    assert any(k.startswith("prior_fused_small_kernel") for k in t3)
+    stamp = open(os.path.join(ROOT, "profiles", "r04", "final", "COLLECTED_AT")).read().strip()
+    assert stamp == t["collected_at"]
 
 
 def test_cpu_pool_of_the_problem_parallel_baseline(tmp_path):
