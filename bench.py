@@ -676,11 +676,6 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
                           "vector instructions that generate W and the features (Philox, sin / cos, f16 halves), MFMA busy ~0.3 "
                           "(profiles/r03/final/sq_prior_fused_config5.txt); the same flops against the f32-MFMA peak of 157.3 TF/s: "
                           "%.2f" % (gemm_flops / t_gemm / 1e12 / F32_MFMA_PEAK_TFLOPS))
-    elif sk == 4 and S <= 16 and not (planner.extra_flags & capi.PRIOR_F32):
-        gemm_kernel = "prior_fused_split_kernel<true, 0>"
-        peak_gemm = F16_MFMA_PEAK_TFLOPS / 3.0
-        gemm_note = ("few samples: the 16-row form of the f16-split kernel, one workgroup per K-slice (four), W and the features formed "
-                     "inside it; 7 of the tile's 16 rows are samples at S = 7: the flops counted are the useful ones")
     elif sk == 4 and S <= 32:
         gemm_kernel, gemm_note = "prior_fused_small_kernel", "few samples: features formed inside the GEMM, four K-slices"
     elif (1024 // sk) % 128 == 0 and S >= 48:
@@ -717,7 +712,7 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
         "timed_blocks": reps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("f32; prior products f16-split x3, f32 accumulate (v_mfma_f32_16x16x32_f16); covariance path and Adam f64"
-                  if ((sk == 1 or (sk == 4 and S <= 16)) and not (planner.extra_flags & capi.PRIOR_F32) and not (planner.fuse and npb * D <= 32))
+                  if (sk == 1 and not (planner.extra_flags & capi.PRIOR_F32) and not (planner.fuse and npb * D <= 32))
                   else "f32 (f32 MFMA prior products; covariance path and Adam f64)"),
         "data": "synthetic",
         "config": {"workload": names[args.workload] + ", SDF " + "x".join(str(v) for v in scene.shape)

@@ -34,7 +34,7 @@ def industrial():
 # (planner parameters, steps compared, relative tolerance on the per-step loss at the first / last compared step)
 @pytest.mark.parametrize("name,over,steps", [("reference", {}, 20),
                                              ("config2", dict(num_samples=128, num_inducing=30, time_spacing_X=100), 8),
-                                             # config 3's sizes: the 16-row form of the f16-split prior kernel (S <= 16)
+                                             # config 3's sizes: the few-sample fused prior kernel, Mz = 26 (padded float64 tiles of stage B)
                                              ("config3", dict(num_samples=7, num_inducing=24, time_spacing_X=70), 12)])
 def test_generated_noise_trajectory_against_oracle(industrial, name, over, steps):
     """-ELBO of every optimisation step, device (noise drawn by the device generator, seed 77) against the oracle

@@ -796,11 +796,6 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             // large batches drawing their own noise: W and the features are formed inside the GEMM (prior_fused_batch_kernel);
             // trainable inducing locations read W back (inducing.hip), so they keep it in memory
             const bool fbatch = gen && tiled_gemm && !fused_small && !ind && !(what & VGPMP_NO_FUSE_PRIOR);
-            // few samples (S <= 16: BASELINE config 3) drawing their own noise: the 16-row form of the f16-split kernel, one
-            // workgroup per K-slice -- W never exists in memory here either; injected noise and the float32 reference form keep
-            // prior_fused_small_kernel (config 3: 55 -> 3x us for the prior draws)
-            const bool split_small = gen && fused_small && S <= 16 && !ind && (B / SK) % kHK == 0 &&
-                                     !(what & (VGPMP_NO_FUSE_PRIOR | VGPMP_PRIOR_F32));
             // the small launches of a step share launches here too (not while profiling stage by stage): stage A of the
             // covariance path beside the noise draws, the two updates at the end in one, the counter tick inside paths_fwd
             const bool batch_merge = gen && backward && !ev && !ind && !lk && !(what & (VGPMP_COV_ONLY | VGPMP_NO_FUSE));
@@ -808,7 +803,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 MidAArgs ma;
                 ma.cov = ca;
                 ma.rng = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
-                if (fbatch || split_small) ma.rng.nW = 0;               // omega, beta, eps, eps2 only
+                if (fbatch) ma.rng.nW = 0;               // omega, beta, eps, eps2 only
                 ma.n_cov = L * P; ma.basis_gx = (int)((ma.rng.L * ma.rng.B + kBlock - 1) / kBlock); ma.n_basis = ma.basis_gx * P;
                 const unsigned n_draw = mid_normal_grid(ma);
                 if ((rc = launch((const void*)mid_cov_a_rng_kernel, dim3(ma.n_cov + ma.n_basis + n_draw), &ma, lds_cov_a))) return rc;
@@ -837,7 +832,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             mark();
             if (gen && !batch_merge) {
                 RngArgs r = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
-                if (fbatch || split_small) r.nW = 0;                    // omega, beta, eps, eps2 only
+                if (fbatch) r.nW = 0;                    // omega, beta, eps, eps2 only
                 hipLaunchKernelGGL(rng_basis_kernel, dim3((r.L * r.B + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
                 if (eps_t) {
                     r.epsT = ws->epsT; r.eps2T = ws->eps2T;
@@ -858,7 +853,6 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 fb.omega = nz->omega; fb.beta = nz->beta; fb.F0 = ws->F0; fb.H = ws->H;
                 fb.seed = seed; fb.problem_base = problem_base; fb.step = step_i; fb.ctr = ctr;
                 fb.wOff = (uint32_t)d->sample_offset * L * B;
-                fb.ksl = 1; fb.slab = 0;
                 const int dm = L <= 8 ? 8 : 16;
                 // 128-row tiles (one workgroup per CU, the features of a K step shared by twice the rows): 64 Franka problems
                 // 883 -> 862 us per step.  Their workgroups run twice as long, so a thin last round costs a whole one: only
@@ -898,22 +892,6 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
 #undef VG_FB
                 }
                 if (fe.tick && batch_merge) pa.tick = fe.tick;      // the feature kernel's tick: by paths_fwd (next launch), or alone
-                else if (fe.tick) hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(1), 0, st, fe.tick);
-            } else if (split_small) {
-                FusedBatchArgs fb;
-                fb.S = S; fb.L = L; fb.J = J; fb.N = N; fb.D = L; fb.B = B; fb.want_dell = want_dell ? 1 : 0;
-                fb.X = pb->X; fb.Zy = zy; fb.zy_stride = zy_stride; fb.raw_ell = params->raw_ell; fb.raw_var = params->raw_var;
-                fb.omega = nz->omega; fb.beta = nz->beta; fb.F0 = ws->F0; fb.H = ws->H;
-                fb.seed = seed; fb.problem_base = problem_base; fb.step = step_i; fb.ctr = ctr;
-                fb.wOff = (uint32_t)d->sample_offset * L * B;
-                fb.ksl = SK; fb.slab = slab;
-                const size_t lds_h = vg_fused_split_lds(0);
-                const dim3 hgrid((J + kTJ - 1) / kTJ, (S + 15) / 16, P * L * SK);
-                const void* fn_h = want_dell ? (const void*)prior_fused_split_kernel<true, 0> : (const void*)prior_fused_split_kernel<false, 0>;
-                if ((rc = set_dyn_lds(fn_h, lds_h))) return rc;
-                if (want_dell) hipExtLaunchKernelGGL((prior_fused_split_kernel<true, 0>), hgrid, dim3(kHThreads), lds_h, st, g0, g1, 0, fb);
-                else hipExtLaunchKernelGGL((prior_fused_split_kernel<false, 0>), hgrid, dim3(kHThreads), lds_h, st, g0, g1, 0, fb);
-                if (fe.tick && batch_merge) pa.tick = fe.tick;
                 else if (fe.tick) hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(1), 0, st, fe.tick);
             } else if (fused_small) {      // features formed inside the GEMM (few samples: Phi / dPhi traffic is the cost)
                 launch_fused_small(g0, g1);

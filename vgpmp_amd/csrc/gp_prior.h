@@ -404,8 +404,6 @@ struct FusedBatchArgs {
     float *F0, *H;
     uint32_t seed, problem_base, step, wOff;
     const uint32_t* ctr;
-    int ksl;          // prior_fused_split_kernel<., 0>: K-slices (one workgroup and one slab of F0 / H each); otherwise unused
-    size_t slab;      // elements between the slabs
 };
 // MT = 2: 128 sample rows per workgroup (two 16-row tiles per wave) -- the features of a K step, which do not depend on the
 // sample, are formed once for 128 rows instead of once per 64, and every B fragment read from LDS feeds two MFMAs; 36

@@ -93,24 +93,18 @@ __device__ __forceinline__ void vg_split4(const vg_f32x4& x, vg_h4& hi, vg_h4& l
     lo = (vg_h4){l0[0], l0[1], l1[0], l1[1]};
 }
 
-inline size_t vg_fused_split_lds(int MT) {      // MT = 0: the 16-row form of few samples
-    return (size_t)2 * (MT ? kTS * MT : 16) * kHRowBytes + (size_t)4 * kTJ * kHRowBytes + (size_t)2 * kTJ * kHRowBytes +
+inline size_t vg_fused_split_lds(int MT) {
+    return (size_t)2 * kTS * MT * kHRowBytes + (size_t)4 * kTJ * kHRowBytes + (size_t)2 * kTJ * kHRowBytes +
            (size_t)2 * kHK * kHRowBytes + (size_t)2 * kHK * sizeof(float);
 }
 
-// MT = 0: few samples (S <= 16, BASELINE config 3: S = 7) -- ONE 16-row tile of samples, K in a.ksl slices over as many workgroups
-// (each writes its split-K slab of F0 / H: the path kernels sum the slabs in a fixed order); wave 0 draws W, all eight waves form
-// the features, and the 18 (product, column tile) units of the one row tile go round the waves.
-template <bool DELL, int MT>      // d/d ell wanted; 64 MT sample rows per workgroup (MT = 0: 16)
+template <bool DELL, int MT>      // d/d ell wanted; 64 MT sample rows per workgroup
 __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char hs_lds[];
     const int S = a.S, L = a.L, J = a.J, N = a.N, D = a.D, B = a.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nsl = MT == 0 && a.ksl > 1 ? a.ksl : 1, npl = (int)gridDim.z / nsl;
-    const int zpl = (int)blockIdx.z % npl, slice = (int)blockIdx.z / npl;
-    const int l = zpl % L, p = zpl / L;
-    const int k_begin = slice * (B / nsl), k_end = k_begin + B / nsl;
-    constexpr int kRows = MT ? kTS * MT : 16;
+    const int l = blockIdx.z % L, p = blockIdx.z / L;
+    constexpr int kRows = kTS * MT;
     const int s0 = blockIdx.y * kRows, j0 = blockIdx.x * kTJ;
     const size_t pl = (size_t)p * L + l;
     unsigned char* Ah = hs_lds;                                   // [kRows][64 B]   W, high halves
@@ -143,7 +137,7 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
     // W: thread (row = tid / 4, part = tid % 4) draws the 8 normals of k = 8 part .. 8 part + 7: ONE counter of the W stream
     //    (vg_normal8).  MT = 2: all 512 threads (128 rows); MT = 1: the first four waves (64 rows), the others start on the features
     const int wrow = (tid >> 2) & (kRows - 1), wpart = tid & 3;
-    const bool draws_w = MT == 2 || (MT == 1 ? wave < 4 : wave == 0);
+    const bool draws_w = MT == 2 || wave < 4;
     const uint32_t wbase = ((a.wOff + ((uint32_t)min(s0 + wrow, S - 1) * L + l) * (uint32_t)B) >> 3) + (uint32_t)wpart;
     // frequencies: element e of the step's 32 contiguous rows of omega (32 D floats), then the 32 phases
     const int n_om = kHK * D, n_ob = n_om + kHK;
@@ -175,25 +169,23 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
     };
     // ---- product roles: MT = 2: wave w owns sample rows 16 w .. 16 w + 15 of both products;
     //                     MT = 1: row tile w % 4, product w / 4 (F0 for waves 0-3, H for waves 4-7)
-    //                     MT = 0: the one row tile; (product, column tile) units wave, wave + 8, wave + 16 of the eighteen
-    constexpr int NU = MT ? MT : 1;                               // (row tile, product) units per wave
-    constexpr int NA = MT ? kTJ / 16 : 3;                         // accumulator tiles per unit
-    const int rt = MT == 2 ? wave : MT == 1 ? (wave & 3) : 0;
+    constexpr int NU = MT;                                        // (row tile, product) units per wave
+    const int rt = MT == 2 ? wave : (wave & 3);
     const int mat0 = MT == 2 ? 0 : (wave >> 2);
-    vg_f32x4 acc[NU][NA];
+    vg_f32x4 acc[NU][kTJ / 16];
 #pragma unroll
     for (int u = 0; u < NU; ++u)
 #pragma unroll
-        for (int t = 0; t < NA; ++t) acc[u][t] = (vg_f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < kTJ / 16; ++t) acc[u][t] = (vg_f32x4){0.f, 0.f, 0.f, 0.f};
     const int r = lane & 15, g = lane >> 4;
     __syncthreads();
-    om_fetch(k_begin);
+    om_fetch(0);
     om_store(0);
     __syncthreads();
     int ob = 0;
-    for (int k0 = k_begin; k0 < k_end; k0 += kHK) {
+    for (int k0 = 0; k0 < B; k0 += kHK) {
         // ================= generate the K step's operands (the next step's frequencies are requested first, stored last)
-        const bool more = k0 + kHK < k_end;
+        const bool more = k0 + kHK < B;
         if (more) om_fetch(k0 + kHK);
         // ---- W: the thread's counter covers k = 8 wpart .. 8 wpart + 7: one 16-byte chunk of each half tile
         if (draws_w) {      // (uniform per wave)
@@ -210,9 +202,9 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
         //      lane (r, g) then holds point 16 t + r against the frequencies 16 h + 4 g .. + 3
         // (MT = 1: waves 4-7, which draw no W, take the first twelve units, three each; waves 0-3 the last six)
         constexpr int kUnits = 2 * (kTJ / 16);
-        const int u_first = MT != 1 ? wave : (wave >= 4 ? wave - 4 : 12 + wave);
-        const int u_last = MT != 1 ? kUnits : (wave >= 4 ? 12 : kUnits);
-        const int u_step = MT != 1 ? kHThreads / 64 : 4;
+        const int u_first = MT == 2 ? wave : (wave >= 4 ? wave - 4 : 12 + wave);
+        const int u_last = MT == 2 ? kUnits : (wave >= 4 ? 12 : kUnits);
+        const int u_step = MT == 2 ? kHThreads / 64 : 4;
         for (int u = u_first; u < u_last; u += u_step) {
             const int t = u >> 1, h = u & 1;
             const int frow = 16 * h + r, prow = 16 * t + r;
@@ -245,26 +237,7 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
         if (more) om_store(ob ^ 1);
         __syncthreads();
         // ================= products: per 16 x 16 tile  hi hi + hi lo + lo hi, float32 accumulators
-        if constexpr (MT == 0) {
-            const int aoff = r * kHRowBytes + vg_swz(r, g) * 16;
-            const vg_h8 ah = *reinterpret_cast<const vg_h8*>(Ah + aoff);
-            const vg_h8 al = *reinterpret_cast<const vg_h8*>(Al + aoff);
-            vg_h8 bh[NA], bl[NA];
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {       // this wave's units: their fragments requested together
-                const int idx = min(wave + 8 * i, 2 * (kTJ / 16) - 1), mat = idx / (kTJ / 16), t = idx - mat * (kTJ / 16);
-                bh[i] = *reinterpret_cast<const vg_h8*>(Bt + (2 * mat) * kTJ * kHRowBytes + t * 16 * kHRowBytes + aoff);
-                bl[i] = *reinterpret_cast<const vg_h8*>(Bt + (2 * mat + 1) * kTJ * kHRowBytes + t * 16 * kHRowBytes + aoff);
-            }
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int idx = wave + 8 * i;
-                if (idx >= 2 * (kTJ / 16) || (!DELL && idx >= kTJ / 16)) continue;      // (uniform)
-                acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[i], acc[0][i], 0, 0, 0);
-                acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[i], acc[0][i], 0, 0, 0);
-                acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[i], acc[0][i], 0, 0, 0);
-            }
-        } else {
+        {
             const int arow = 16 * rt + r;
             const int aoff = arow * kHRowBytes + vg_swz(arow, g) * 16;
             const vg_h8 ah = *reinterpret_cast<const vg_h8*>(Ah + aoff);
@@ -299,25 +272,6 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
     }
     // ---- D layout: col = lane & 15, row = (lane >> 4) * 4 + reg; the constant factors left out of the tiles go in here
     const float scale_f = c, scale_h = c * inv_ell * inv_ell;
-    if constexpr (MT == 0) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int idx = wave + 8 * i;
-            if (idx >= 2 * (kTJ / 16)) continue;
-            const int mat = idx / (kTJ / 16), t = idx - mat * (kTJ / 16);
-            if (!DELL && mat == 1) continue;
-            float* dst = (mat == 0 ? a.F0 : a.H) + (size_t)slice * a.slab;
-            const float sc = mat == 0 ? scale_f : scale_h;
-            const int jc = j0 + 16 * t + r;
-            if (jc >= J) continue;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int sr = s0 + g * 4 + q;
-                if (sr < S) vg_stream(dst + (((size_t)p * S + sr) * L + l) * J + jc, acc[0][i][q] * sc);
-            }
-        }
-        return;
-    }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int mat = MT == 2 ? u : mat0;
