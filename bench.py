@@ -791,6 +791,8 @@ def main():
     import torch
     dist = None
     backend = os.environ.get("VGPMP_DIST_BACKEND", "nccl")      # "gloo": rehearsal of the N > 1 path on a 1-GPU box
+    if world > 1 and "VGPMP_DIST_BACKEND" not in os.environ and torch.cuda.device_count() < world:
+        backend = "gloo"      # (an external launcher on a box with fewer devices than ranks: RCCL refuses two ranks on one device)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if world > 1:
         import torch.distributed as dist
