@@ -36,6 +36,18 @@ for n in 1 2 3 4 6 8 13 16 24 32 48; do
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('problems', $n, 'us_per_step', round(1e3 * d['ms_per_step'], 2), 'problem_steps_per_s', round(d['value']))" >> $out/problems_sweep.txt
 done
+# ... the same for the 14-joint arm of config 5 (L = 14: twice the latent pairs per problem, a cache-resident 128^3 table so that the
+#     sweep is about the schedules, not the table) and for config 3's shape (S = 7, M = 24, T = 70)
+for n in 1 2 3 4 6 8 16 32 64; do
+  python bench.py --workload stress --grid 128 --problems $n $Q --min-seconds 0.5 --steps 100 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('14-joint arm, problems', $n, 'us_per_step', round(1e3 * d['ms_per_step'], 2), 'problem_steps_per_s', round(d['value']))" >> $out/problems_sweep_L14.txt
+done
+for n in 1 2 4 8 16 32 55; do
+  python bench.py --workload config3 --problems $n $Q --min-seconds 0.5 --steps 130 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('config 3 shape (S=7), problems', $n, 'us_per_step', round(1e3 * d['ms_per_step'], 2), 'problem_steps_per_s', round(d['value']))" >> $out/problems_sweep_S7.txt
+done
 # ---- the metric's plans/sec as wall time of solve_planning_problem() calls
 timeout 600 python tools/solve_timing.py > $out/solve_timing_config2.txt 2>&1
 # ---- config 3: Franka / bookshelves, the full C(11,2) = 55 start-goal batch, S=7 M=24 T=70

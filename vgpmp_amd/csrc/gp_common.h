@@ -5,7 +5,10 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kFuseMaxPL = 32;      // measured on config 2: shared launches win up to 4 problems (x 7 latents), one launch per kernel from 5
+#ifndef VG_FUSE_MAX_PL
+#define VG_FUSE_MAX_PL 32
+#endif
+constexpr int kFuseMaxPL = VG_FUSE_MAX_PL;      // measured on config 2: shared launches win up to 4 problems (x 7 latents), one launch per kernel from 5
 __device__ __forceinline__ double matern52_dell(double t1, double t2, double ell, double var) {
     double r = fabs(t1 - t2) / ell;
     return var * exp(-kSqrt5 * r) * (5.0 * r * r / (3.0 * ell)) * (1.0 + kSqrt5 * r);
