@@ -712,7 +712,7 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
         "timed_blocks": reps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("f32; prior products f16-split x3, f32 accumulate (v_mfma_f32_16x16x32_f16); covariance path and Adam f64"
-                  if (sk == 1 and not (planner.extra_flags & capi.PRIOR_F32) and not (planner.fuse and npb * D <= 32))
+                  if (sk == 1 and not (planner.extra_flags & capi.PRIOR_F32) and not (planner.fuse and npb * D <= (64 if S <= 32 else 32)))
                   else "f32 (f32 MFMA prior products; covariance path and Adam f64)"),
         "data": "synthetic",
         "config": {"workload": names[args.workload] + ", SDF " + "x".join(str(v) for v in scene.shape)
@@ -728,7 +728,7 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
                              + ("; independent kernels of a step share launches (stage1 / stage2 / likelihood + path assembly / stage4 for"
                                 " one or two problems, stage1/2/3_kernel + likelihood + reverse pass from three), the prior GEMM is a"
                                 " role of stage2_kernel there and is timed alone for roofline_secondary"
-                                if planner.fuse and npb * D <= 32 else "")},
+                                if planner.fuse and npb * D <= (64 if S <= 32 else 32) else "")},
         "plans_per_sec": (world * npb / (float(pp["num_steps"]) * elapsed / args.steps + t_sample)
                           if t_sample is not None else None),
         "plan_definition": (f"computed: {pp['num_steps']} optimisation steps at the timed rate + 150 posterior paths at "

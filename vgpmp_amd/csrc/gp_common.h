@@ -5,10 +5,11 @@
 namespace {
 
 constexpr int kBlock = 256;
-#ifndef VG_FUSE_MAX_PL
-#define VG_FUSE_MAX_PL 32
-#endif
-constexpr int kFuseMaxPL = VG_FUSE_MAX_PL;      // measured on config 2: shared launches win up to 4 problems (x 7 latents), one launch per kernel from 5
+// shared launches (the few-problem schedule) up to this many (problem, latent) pairs: measured on config 2's shape (S = 128): they win
+// up to 4 problems x 7 latents, one launch per kernel from 5 (5 problems 147 vs 143 us, 8: 198 vs 150); with few samples (config 3's
+// shape, S = 7) up to 64 pairs (5 problems 71 vs 86 us per step, 8: 80 vs 86; 16 problems 117 vs 101)
+constexpr int kFuseMaxPL = 32, kFuseMaxPLFewSamples = 64;
+__host__ __device__ inline int vg_fuse_max_pl(int S) { return S <= 32 ? kFuseMaxPLFewSamples : kFuseMaxPL; }
 __device__ __forceinline__ double matern52_dell(double t1, double t2, double ell, double var) {
     double r = fabs(t1 - t2) / ell;
     return var * exp(-kSqrt5 * r) * (5.0 * r * r / (3.0 * ell)) * (1.0 + kSqrt5 * r);

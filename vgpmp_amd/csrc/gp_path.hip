@@ -446,7 +446,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const bool backward = (what & VGPMP_DO_BACKWARD) != 0, do_adam = (what & VGPMP_DO_ADAM) != 0;
     const bool gen = (what & VGPMP_GEN_NOISE) != 0;
     const bool want_dell = backward && (trainable & VGPMP_TRAIN_LENGTHSCALES);
-    const bool fused = !ev && !(what & VGPMP_NO_FUSE) && SC == 8 && P * L <= kFuseMaxPL && !pb->ind;
+    const bool fused = !ev && !(what & VGPMP_NO_FUSE) && SC == 8 && P * L <= vg_fuse_max_pl(S) && !pb->ind;
     const bool tiled_gemm = !fused && SK == 1 && (B % kTK) == 0;      // large batches: LDS-tiled kernel, no K-slices
     if (num_steps > 1 && !(backward && do_adam && gen)) return VGPMP_E_ARG;
     int evi = 0;
@@ -516,7 +516,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         // the register-resident path kernels (Mz = 32, one slab) work on PAIRS of chunks: two per workgroup as soon as that
         // leaves a workgroup per CU, four from ~600 workgroups (6 problems of config 2's shape: 155 -> 147 us per step, 13: 187 ->
         // 168, 24: 290 -> 245; the rule above alone left them on the one-chunk kernels below 28 problems)
-        const bool pairs = SK == 1 && Mz == 32 && (N & 3) == 0 && N <= 100 && NC >= 2 && P * L > kFuseMaxPL;
+        const bool pairs = SK == 1 && Mz == 32 && (N & 3) == 0 && N <= 100 && NC >= 2 && P * L > vg_fuse_max_pl(S);
         if (pairs && pa.cpw < 2 && (size_t)P * L * ((NC + 1) / 2) >= 256) pa.cpw = 2;
         if (pairs && pa.cpw == 2 && NC >= 4 && (size_t)P * L * ((NC + 3) / 4) >= 600) pa.cpw = 4;
     }
