@@ -332,6 +332,8 @@ class CpuPool:
             except Exception:
                 p.kill()
         self.err.close()
+        import shutil
+        shutil.rmtree(self.dir, ignore_errors=True)
 
 
 def cpu_worker_main(jobdir: str, index: int) -> int:

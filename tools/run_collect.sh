@@ -6,6 +6,7 @@ round=${ROUND:-r04}
 head=$(git rev-parse --short HEAD); dirty=$(git status --porcelain | grep -v '^??' | wc -l || true)
 stamp="commit $head"; if [ "$dirty" != 0 ]; then stamp="$stamp + $dirty uncommitted file(s)"; fi
 echo "$stamp" > profiles/COLLECT_STAMP
+python -m vgpmp_amd.build > /dev/null && python -m vgpmp_amd.build --measurement > /dev/null      # product and measurement libraries of THIS tree
 src=gpurun_out/${round}final
 rm -rf "$src"
 /usr/local/graft/bin/gpurun --timeout ${TIMEOUT:-3000} -- "ROUND=$round bash tools/collect_profiles.sh > gpurun_out/collect.log 2>&1; tail -5 gpurun_out/collect.log" || true

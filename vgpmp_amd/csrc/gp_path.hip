@@ -422,19 +422,22 @@ static int vg_aux_events(hipStream_t aux, hipEvent_t* fork, hipEvent_t* join) {
     constexpr int kSlots = 64;
     static hipStream_t streams[kSlots];
     static hipEvent_t evs[kSlots][2];
+    static int next = 0;
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
-    for (int i = 0; i < kSlots; ++i) {
+    for (int i = 0; i < kSlots; ++i)
         if (streams[i] == aux && evs[i][0]) { *fork = evs[i][0]; *join = evs[i][1]; return 0; }
-        if (streams[i] == nullptr) {
-            VG_CHECK_HIP(hipEventCreateWithFlags(&evs[i][0], hipEventDisableTiming));
-            VG_CHECK_HIP(hipEventCreateWithFlags(&evs[i][1], hipEventDisableTiming));
-            streams[i] = aux;
-            *fork = evs[i][0]; *join = evs[i][1];
-            return 0;
-        }
+    // a new stream: the next slot round robin (a process that has gone through more than kSlots auxiliary streams reuses the
+    // events of the oldest one -- events belong to no stream, and a caller that still uses that stream gets a fresh pair)
+    const int i = next;
+    next = (next + 1) % kSlots;
+    if (!evs[i][0]) {
+        VG_CHECK_HIP(hipEventCreateWithFlags(&evs[i][0], hipEventDisableTiming));
+        VG_CHECK_HIP(hipEventCreateWithFlags(&evs[i][1], hipEventDisableTiming));
     }
-    return VGPMP_E_ARG;      // (more auxiliary streams than slots: the caller should reuse them)
+    streams[i] = aux;
+    *fork = evs[i][0]; *join = evs[i][1];
+    return 0;
 }
 
 int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sdf, const vgpmp_problem* pb,
