@@ -52,6 +52,29 @@ def test_capi_communicator_single_rank_is_identity():
     comm.close()
 
 
+def test_sharded_loop_through_rccl_on_one_rank():
+    """vgpmp_elbo_steps_reduced with a REAL communicator (one rank: the all-reduce of the gradient buffer is enqueued between
+    the reverse pass and Adam of every step, on the step's stream) equals the same loop without one, bit for bit."""
+    from vgpmp_amd import engine, sharding
+    spec, grid, off, q, kw = problem()
+    sc = engine.DeviceScene(spec, grid, off)
+    out = []
+    for with_comm in (False, True):
+        pl = engine.PlannerBatch(sc, q, num_samples=S_TOTAL, **kw)
+        comm = sharding.CapiComm(1, 0) if with_comm else None
+        sp = sharding.SampleShardedPlanner(pl, comm=comm)
+        if comm is None:
+            sp._allreduce = lambda buf=None: None
+            sp._single_rank = True
+        sp.run_steps(4)
+        torch.cuda.synchronize()
+        out.append([t.clone() for t in (pl.q_mu, pl.q_sqrt, pl.raw_ell, pl.raw_var, pl.reduce_buf)])
+        if comm is not None:
+            comm.close()
+    for x, y in zip(*out):
+        assert torch.equal(x, y)
+
+
 def test_bench_starts_its_own_ranks(bench_gpus2):
     """`python bench.py --gpus 2 --shard samples` with no external launcher: bench.py starts two fresh
     rank processes before touching the GPU, they rendezvous on 127.0.0.1 (gloo: both ranks share this box's one GPU), run
