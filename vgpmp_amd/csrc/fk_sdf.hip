@@ -493,7 +493,8 @@ __device__ __forceinline__ float loglik_config_pipe(const vgpmp_robot* __restric
     struct Batch {
         vg_float3 pos[U];
         uint32_t at[U];
-        float sm[FAR ? U : 1];        // FAR 1: the brick's smallest distance; FAR 2: 0 where the block is marked free, else +inf... see issue()
+        float sm[FAR ? U : 1];        // what the free-space test of issue() compares: FAR 1 the brick's smallest distance,
+                                      // FAR 2 +inf where the sphere's block is marked free in its radius class's mask, else -inf
     };
     // stage 1: chain, positions, voxel addresses and the free-space test's operand of batch q0
     auto stage1 = [&](int q0, Batch& b) {
