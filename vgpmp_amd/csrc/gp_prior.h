@@ -562,7 +562,9 @@ struct FusedPriorArgs {
 };
 constexpr int kFNT = 2;     // column tiles per workgroup     // config 3 (55 problems, S = 7, J = 96): 234 / 198 / 194 / 210 us per step with 5 / 3 / 2 / 1 -- more, lighter waves
 template <int MT, int DM, bool DELL>    // 16-row sample tiles; joint-space extent padded to DM (8 or 16); d/d ell wanted
-__global__ __launch_bounds__(kBlock) void prior_fused_small_kernel(FusedPriorArgs a) {
+// (one sample tile of arms up to 8 joints: held to 96 registers = 5 workgroups per CU; 100 otherwise, which is 4)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MT == 1 && DM == 8 ? 5 : 1, MT == 1 && DM == 8 ? 5 : 8)))
+void prior_fused_small_kernel(FusedPriorArgs a) {
     __shared__ float pts[kFNT * 16][DM];
     const int S = a.S, L = a.L, J = a.J, N = a.N, D = a.D, B = a.B;
     const int tid = threadIdx.x, lane = tid & 63, sk = tid >> 6;      // 4 waves = 4 K-slices
@@ -587,11 +589,11 @@ __global__ __launch_bounds__(kBlock) void prior_fused_small_kernel(FusedPriorArg
     const float* wrow[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) wrow[m] = a.W + (((size_t)p * S + min(16 * m + r, S - 1)) * L + l) * B;
-    // operands of a pass (4 bases per lane: 28 frequencies, 4 phases, the W fragments) are requested one pass ahead
-    float om[4][DM], bt[4], om_n[4][DM], bt_n[4];
-    vg_f32x4 a4[MT], a4_n[MT];
+    // operands of a pass: 4 bases per lane (28 frequencies, 4 phases) and the W fragments
+    float om[4][DM], bt[4];
+    vg_f32x4 a4[MT];
     auto fetch = [&](int k0, float (&o)[4][DM], float (&bb)[4], vg_f32x4 (&aa)[MT]) {
-        const int b0 = min(k0, B - 16) + 4 * g;          // (the look-ahead of the last pass re-reads it)
+        const int b0 = k0 + 4 * g;
         // every load unconditional on a clamped index, masked afterwards (a conditional load is a branch)
         const float* op = a.omega + ((size_t)pl * B + b0) * D;
         const float* bp = a.beta + (size_t)pl * B + b0;
@@ -656,17 +658,13 @@ __global__ __launch_bounds__(kBlock) void prior_fused_small_kernel(FusedPriorArg
                 }
         }
     };
-    // two register sets in turn (no copies of the look-ahead set into the working set: 36 moves per pass on a kernel that is
-    // bound by the FP32 pipe its VALU work and its float32 MFMAs share)
-    fetch(kbeg, om, bt, a4);
-    int k0 = kbeg;
-    for (; k0 + 32 <= kbeg + kchunk; k0 += 32) {
-        fetch(k0 + 16, om_n, bt_n, a4_n);
+    // one register set, operands requested right before their pass: the waves beside this one cover the latency.  (Two sets in
+    // turn, requested a pass ahead, cost 144 registers = 3 workgroups per CU; one set fits 5, and config 3's 1155 workgroups run
+    // in one round instead of one and a half: 55.4 -> 51 us, r04)
+    for (int k0 = kbeg; k0 < kbeg + kchunk; k0 += 16) {
+        fetch(k0, om, bt, a4);
         pass(om, bt, a4);
-        fetch(k0 + 32, om, bt, a4);
-        pass(om_n, bt_n, a4_n);
     }
-    if (k0 < kbeg + kchunk) pass(om, bt, a4);      // (a slice of 16 bases: B = 64)
     // D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
     float* F0 = a.F0 + (size_t)sk * a.slab;
     float* H = a.H + (size_t)sk * a.slab;
