@@ -523,12 +523,13 @@ def _compare_with_oracle(pl, k, p, scene, X, Zy, y, noise, alpha, S, N, M, L, sp
 def test_baseline_configs_at_full_size_against_oracle(config):
     """BASELINE configs 1, 3 and 4 at their FULL (S, M, N, B = 1024) against the oracle, not only
     through size-independent properties.  config1 = WAM / industrial, S=50 M=10 N=70 (data/problemsets/wam.py:93-106);
-    config3 = Franka / bookshelves, S=7 M=24 N=70 with 8 of the 55 start-goal pairs in ONE batch, so the few-sample prior
-    kernel and the batch schedule run at batch size (data/problemsets/franka.py:91-104); config4 = one rank's share of UR10 /
+    config3 = Franka / bookshelves, S=7 M=24 N=70 with 10 of the 55 start-goal pairs in ONE batch (70 latents: beyond the 64 the
+    few-problem schedule takes at this sample count), so the few-sample prior kernel -- its 4 x 4 x 1 MFMA form for up to 8
+    samples -- and the batch schedule run at batch size (data/problemsets/franka.py:91-104); config4 = one rank's share of UR10 /
     industrial: S=128 of 1024 samples at sample_offset 256, KL owned by another rank (data/problemsets/ur10.py:71-84)."""
     robot, problem, S, M, N, P, extra = {
         "config1": ("wam", "industrial", 50, 10, 70, 1, {}),
-        "config3": ("franka", "bookshelves", 7, 24, 70, 8, {}),
+        "config3": ("franka", "bookshelves", 7, 24, 70, 10, {}),
         "config4": ("ur10", "industrial", 128, 18, 70, 1, dict(samples_total=1024, sample_offset=256, kl_scale=0.0)),
     }[config]
     B = 1024
