@@ -562,8 +562,7 @@ struct FusedPriorArgs {
 };
 constexpr int kFNT = 2;     // column tiles per workgroup     // config 3 (55 problems, S = 7, J = 96): 234 / 198 / 194 / 210 us per step with 5 / 3 / 2 / 1 -- more, lighter waves
 template <int MT, int DM, bool DELL>    // 16-row sample tiles; joint-space extent DM = D for 6 and 7 joints, else padded to 8 or 16; d/d ell wanted
-// (one sample tile of arms up to 8 joints: held to 96 registers = 5 workgroups per CU; 100 otherwise, which is 4)
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MT == 1 && DM <= 8 ? 5 : 1, MT == 1 && DM <= 8 ? 5 : 8)))
+__global__ __launch_bounds__(kBlock)
 void prior_fused_small_kernel(FusedPriorArgs a) {
     __shared__ float pts[kFNT * 16][DM];
     const int S = a.S, L = a.L, J = a.J, N = a.N, D = a.D, B = a.B;
@@ -590,60 +589,48 @@ void prior_fused_small_kernel(FusedPriorArgs a) {
     const float* wrow[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) wrow[m] = a.W + (((size_t)p * S + min(16 * m + r, S - 1)) * L + l) * B;
-    // operands of a pass: 4 bases per lane (28 frequencies, 4 phases) and the W fragments
-    float om[4][DM], bt[4];
-    vg_f32x4 a4[MT];
-    auto fetch = [&](int k0, float (&o)[4][DM], float (&bb)[4], vg_f32x4 (&aa)[MT]) {
-        const int b0 = k0 + 4 * g;
-        // every load unconditional on a clamped index, masked afterwards (a conditional load is a branch)
-        const float* op = a.omega + ((size_t)pl * B + b0) * D;
-        const float* bp = a.beta + (size_t)pl * B + b0;
-        // a lane's four bases are 4 D consecutive floats, i.e. D aligned 16-byte vectors (b0 is a multiple of 4): with D known at
-        // compile time (the 6- and 7-joint arms) D + 1 requests replace 4 D + 4, and their address arithmetic with them
-        auto vec = [&](auto dd) {
-            constexpr int DD = decltype(dd)::value;
-            const vg_f32x4* op4 = reinterpret_cast<const vg_f32x4*>(op);
-            vg_f32x4 f[DD];
+    // The projections x . omega of a pass (16 bases x kFNT tiles of 16 points) are matrix products themselves:
+    //   proj[base 4 g + q][point r] = sum_d omega[base][d] pts[point][d]   =   accumulator element q of lane (r, g)
+    // of 16 x 16 x 4 MFMAs with A = omega[base k0 + r][4 i + g] and B = pts[16 t + r][4 i + g] -- exactly the (point, four bases)
+    // layout the feature fragments below need.  kDQ MFMAs per tile replace 4 D multiply-adds per lane, and a lane loads kDQ
+    // frequencies per pass instead of 4 D.  (Columns beyond D: the points' zero padding meets a clamped, finite frequency.)
+    constexpr int kDQ = (DM + 3) / 4;
+    float pb[kFNT][kDQ];
 #pragma unroll
-            for (int i = 0; i < DD; ++i) f[i] = op4[i];
-            const vg_f32x4 b4 = *reinterpret_cast<const vg_f32x4*>(bp);
+    for (int t = 0; t < kFNT; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                bb[q] = b4[q] * 0.15915494309189535f;
+        for (int i = 0; i < kDQ; ++i) pb[t][i] = 4 * i + g < DM ? pts[16 * t + r][min(4 * i + g, DM - 1)] : 0.f;
+    int ooff[kDQ];
 #pragma unroll
-                for (int d = 0; d < DM; ++d) o[q][d] = d < DD ? f[(q * DD + d) / 4][(q * DD + d) % 4] : 0.f;
-            }
-        };
-        if (D == 7 && DM >= 7) vec(std::integral_constant<int, 7>{});
-        else if (D == 6) vec(std::integral_constant<int, 6>{});
-        else {
+    for (int i = 0; i < kDQ; ++i) ooff[i] = min(4 * i + g, D - 1);
+    const float* orow = a.omega + ((size_t)pl * B + kbeg + r) * D;              // this lane's basis of the pass
+    const float* brow = a.beta + (size_t)pl * B + kbeg + 4 * g;                 // phases of the four bases it forms features of
+    // operands of a pass, requested one pass ahead (kDQ frequencies, 4 phases, the W fragments: a dozen registers)
+    float oa[kDQ], oa_n[kDQ];
+    vg_f32x4 bt, bt_n, a4[MT], a4_n[MT];
+    auto fetch = [&](int k, float (&o)[kDQ], vg_f32x4& bb, vg_f32x4 (&aa)[MT]) {
+        const int kk = min(k, kchunk - 16);              // (the look-ahead of the last pass re-reads it)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                bb[q] = bp[q] * 0.15915494309189535f;
-                // (no masks: beyond D a clamped -- finite -- frequency meets the zero padding of the points, and the tile rows
-                //  beyond S, fed a clamped row of W, are never stored: 36 selects per pass on a kernel bound by the FP32 pipe)
+        for (int i = 0; i < kDQ; ++i) o[i] = orow[(size_t)kk * D + ooff[i]];
+        bb = *reinterpret_cast<const vg_f32x4*>(brow + kk);
 #pragma unroll
-                for (int d = 0; d < DM; ++d) o[q][d] = op[q * D + min(d, D - 1)];
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < MT; ++m) aa[m] = *reinterpret_cast<const vg_f32x4*>(wrow[m] + b0);
+        for (int m = 0; m < MT; ++m) aa[m] = *reinterpret_cast<const vg_f32x4*>(wrow[m] + kbeg + kk + 4 * g);
     };
     // one pass: 16 bases x kFNT column tiles.  One wave per SIMD issues in order: the features of column tile t + 1 are formed
     // between the products of tile t (independent work next to each other in the instruction stream), not after them
-    auto pass = [&](const float (&om)[4][DM], const float (&bt)[4], const vg_f32x4 (&a4)[MT]) {
+    auto pass = [&](const float (&o)[kDQ], const vg_f32x4& bb, const vg_f32x4 (&aa)[MT]) {
         float ph[2][4], dh[2][4];
+        vg_f32x4 btr = bb * 0.15915494309189535f;        // phases in revolutions
         auto feats = [&](int t, float (&pc)[4], float (&dc)[4]) {
+            vg_f32x4 proj = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < kDQ; ++i) proj = __builtin_amdgcn_mfma_f32_16x16x4f32(o[i], pb[t][i], proj, 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float proj = 0.f;
-#pragma unroll
-                for (int d = 0; d < DM; ++d) proj = fmaf(pts[16 * t + r][d], om[q][d], proj);
-                // phase in revolutions by ONE fused multiply-add (1 / (2 pi ell) and the phases' 1 / (2 pi) applied per pass, not per
-                // feature); the factors c and c / ell^2 go to the accumulators at the end: 4 multiplies per feature fewer in all
-                const float rev = __builtin_amdgcn_fractf(fmaf(proj, rev_ell, bt[q]));
+                // phase in revolutions by ONE fused multiply-add; the factors c and c / ell^2 go to the accumulators at the end
+                const float rev = __builtin_amdgcn_fractf(fmaf(proj[q], rev_ell, btr[q]));
                 pc[q] = __builtin_amdgcn_cosf(rev);
-                dc[q] = __builtin_amdgcn_sinf(rev) * proj;
+                dc[q] = __builtin_amdgcn_sinf(rev) * proj[q];
             }
         };
         feats(0, ph[0], dh[0]);
@@ -656,18 +643,20 @@ void prior_fused_small_kernel(FusedPriorArgs a) {
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    accF[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m][q], ph[cb][q], accF[m][t], 0, 0, 0);
-                    if (DELL) accH[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[m][q], dh[cb][q], accH[m][t], 0, 0, 0);
+                    accF[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[m][q], ph[cb][q], accF[m][t], 0, 0, 0);
+                    if (DELL) accH[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[m][q], dh[cb][q], accH[m][t], 0, 0, 0);
                 }
         }
     };
-    // one register set, operands requested right before their pass: the waves beside this one cover the latency.  (Two sets in
-    // turn, requested a pass ahead, cost 144 registers = 3 workgroups per CU; one set fits 5, and config 3's 1155 workgroups run
-    // in one round instead of one and a half: 55.4 -> 51 us, r04)
-    for (int k0 = kbeg; k0 < kbeg + kchunk; k0 += 16) {
-        fetch(k0, om, bt, a4);
-        pass(om, bt, a4);
+    fetch(0, oa, bt, a4);
+    int k = 0;
+    for (; k + 32 <= kchunk; k += 32) {
+        fetch(k + 16, oa_n, bt_n, a4_n);
+        pass(oa, bt, a4);
+        fetch(k + 32, oa, bt, a4);
+        pass(oa_n, bt_n, a4_n);
     }
+    if (k < kchunk) pass(oa, bt, a4);      // (a slice of 16 bases: B = 64)
     // D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
     float* F0 = a.F0 + (size_t)sk * a.slab;
     float* H = a.H + (size_t)sk * a.slab;
