@@ -562,7 +562,10 @@ struct FusedPriorArgs {
 };
 constexpr int kFNT = 2;     // column tiles per workgroup     // config 3 (55 problems, S = 7, J = 96): 234 / 198 / 194 / 210 us per step with 5 / 3 / 2 / 1 -- more, lighter waves
 template <int MT, int DM, bool DELL>    // 16-row sample tiles; joint-space extent DM = D for 6 and 7 joints, else padded to 8 or 16; d/d ell wanted
-__global__ __launch_bounds__(kBlock)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2)))
+// (at least two waves per SIMD = at most 256 registers: the compiler then keeps the MFMA accumulators in ordinary VGPRs -- with 512
+//  allowed it puts them in AGPRs and pays a v_accvgpr_read per projection element plus moves per loop rotation: 134 -> 98 vector
+//  instructions per 32 bases, config 3 164.6 -> 161.7 us per step)
 void prior_fused_small_kernel(FusedPriorArgs a) {
     __shared__ float pts[kFNT * 16][DM];
     const int S = a.S, L = a.L, J = a.J, N = a.N, D = a.D, B = a.B;
