@@ -227,7 +227,9 @@ typedef struct vgpmp_outputs {
 #define VGPMP_DO_ADAM 4         /* + Adam.apply_gradients (utils/miscellaneous.py:82)        */
 #define VGPMP_GEN_NOISE 8       /* draw the noise with the device Philox generator first     */
 #define VGPMP_NO_FUSE 16        /* measurement: one launch per kernel even for small batches  */
-#define VGPMP_GEMM_DIRECT 32    /* measurement: stage-2 GEMM role with operands straight from L2 */
+#define VGPMP_GEMM_DIRECT 32    /* measurement: stage-2 GEMM role with operands straight from L2; with VGPMP_NO_FUSE also the prior
+                                 * draws of few samples as stored features + GEMM instead of the few-sample kernel (which forms
+                                 * its features inside the product, with other float32 roundings): the tests' bitwise reference */
 #define VGPMP_NO_SPLIT 64       /* measurement: reverse path pass on one workgroup per (chunk, latent) */
 #define VGPMP_LIK_LANES 256     /* measurement: the batch form of the likelihood (one lane per configuration) at any batch size */
 #define VGPMP_LIK_LDS_STATE 512 /* measurement: that form with the per-frame force / moment sums in LDS instead of registers */

@@ -328,9 +328,24 @@ def test_pipelined_steps_equal_single_step_calls(P, M):
     kw = dict(num_samples=32, num_inducing=M, num_data=40, num_bases=128, lengthscales=[2.0] * 7, variance=0.2, seed=3)
     a, b = engine.PlannerBatch(sc, qs, **kw), engine.PlannerBatch(sc, qs, **kw)
     b.fuse = False
+    few = P * spec.dof <= 64      # `a` runs the few-problem schedule: features stored, products by the stage-2 GEMM role
+    if few:
+        # one launch per kernel would form the prior draws of this many latents by the few-sample kernel (features inside the
+        # GEMM, projections on the matrix cores, constant factors applied to the accumulators: other float32 roundings than
+        # features_kernel + GEMM).  For the bitwise comparison `b` keeps the stored-feature form; the few-sample kernel (here its
+        # two-tile form, 32 samples) is held against it to float32 trajectory tolerance below, and against the oracle in
+        # test_gpu_parity / test_gpu_plans.
+        from vgpmp_amd import capi
+        b.extra_flags |= capi.GEMM_DIRECT
+        c = engine.PlannerBatch(sc, qs, **kw)
+        c.fuse = False
+        c.run_steps(1)
     a.run_steps(25)
-    for _ in range(25):
+    for i in range(25):
         b.run_steps(1)
+        if few and i == 0:      # the first step's paths: the same noise, the two forms of the prior draws
+            d = float((c.f - b.f).abs().max())
+            assert 0.0 < d < 2e-5 * float(b.f.abs().max()) + 1e-6, d
     torch.cuda.synchronize()
     assert a.t == b.t == 25
     for x, y in ((a.q_mu, b.q_mu), (a.q_sqrt, b.q_sqrt), (a.raw_ell, b.raw_ell), (a.raw_var, b.raw_var),
@@ -384,6 +399,8 @@ def test_pipelined_steps_with_trainable_likelihood_constants():
               alpha=4.0, trainable=tr)
     a, b = engine.PlannerBatch(sc, qs, **kw), engine.PlannerBatch(sc, qs, **kw)
     b.fuse = False
+    from vgpmp_amd import capi
+    b.extra_flags |= capi.GEMM_DIRECT      # (features_kernel + GEMM like `a`: see test_pipelined_steps_equal_single_step_calls)
     a.run_steps(12)
     for _ in range(12):
         b.run_steps(1)

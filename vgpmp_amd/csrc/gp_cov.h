@@ -505,7 +505,7 @@ __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, 
     VG_T(l == 0 && p == 0, 103);
 }
 
-__global__ __launch_bounds__(kCovThreads) void cov_a_kernel(CovArgs a) {
+__global__ __launch_bounds__(kCovThreads, 2) void cov_a_kernel(CovArgs a) {
     extern __shared__ double sm[];
     cov_a_body(a, sm, blockIdx.x, blockIdx.y);
 }
@@ -822,7 +822,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
 }
 
 template <bool TANGENTS>
-__global__ __launch_bounds__(kCovThreads) void cov_b_kernel(CovArgs a) {
+__global__ __launch_bounds__(kCovThreads, 2) void cov_b_kernel(CovArgs a) {
     extern __shared__ double sm[];
     cov_b_body<TANGENTS>(a, sm, (int)((blockIdx.x + blockIdx.y + gridDim.y * blockIdx.z) % gridDim.x), blockIdx.y, blockIdx.z);
 }

@@ -59,7 +59,7 @@ struct Stage1Args {
     int n_feat;
 };
 template <bool PRO>
-__global__ __launch_bounds__(kBlock) void stage1_kernel(Stage1Args a) {
+__global__ __launch_bounds__(kBlock, 2) void stage1_kernel(Stage1Args a) {
     extern __shared__ double sm[];
     int b = blockIdx.x;
     if (b < a.n_cov) { if (!(a.skip & 1)) cov_a_body(a.cov, sm, b % a.cov.L, b / a.cov.L); VG_TMAX(160); return; }
@@ -102,7 +102,7 @@ struct Stage2Args {
     int n_gemm;               // stage2_gemm_first_kernel
 };
 template <bool TANGENTS, int KS>
-__global__ __launch_bounds__(kBlock) void stage2_kernel(Stage2Args a) {
+__global__ __launch_bounds__(kBlock, 2) void stage2_kernel(Stage2Args a) {
     extern __shared__ double sm[];
     int b = blockIdx.x;
     if (b < a.n_cov) {
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kBlock) void stage2_kernel(Stage2Args a) {
 // 113 -> 107 us per step, 4: 131 -> 121.  (With K-slices -- one or two problems -- the covariance chains are the longer
 // workgroups and the order above is the better one by ~1 us.)
 template <bool TANGENTS, int KS>
-__global__ __launch_bounds__(kBlock) void stage2_gemm_first_kernel(Stage2Args a) {
+__global__ __launch_bounds__(kBlock, 2) void stage2_gemm_first_kernel(Stage2Args a) {
     extern __shared__ double sm[];
     int b = blockIdx.x;
     if (b >= a.n_gemm) {
@@ -150,7 +150,7 @@ struct Stage3Args {
     int skip;
 };
 template <int SK, bool RAW>
-__global__ __launch_bounds__(kBlock) void stage3_kernel(Stage3Args a) {
+__global__ __launch_bounds__(kBlock, 2) void stage3_kernel(Stage3Args a) {
     extern __shared__ float smf[];
     int b = blockIdx.x;
     if (b < a.n_path) {
@@ -184,7 +184,7 @@ struct Stage4Args {
     int n_bwd, bwd_gx, n_basis, basis_gx, w_gx;
 };
 template <int SK, int MZ>
-__global__ __launch_bounds__(kBlock) void stage4_kernel(Stage4Args a) {
+__global__ __launch_bounds__(kBlock, 2) void stage4_kernel(Stage4Args a) {
     extern __shared__ float smf[];
     int b = blockIdx.x;
     if (b < a.n_bwd) { paths_bwd_split_body<SK, MZ>(a.path, smf, b, a.bwd_gx); return; }
@@ -202,7 +202,7 @@ struct MidAArgs {            // cov_a | omega, beta | w, eps, eps'
     int n_cov, n_basis, basis_gx, n_gx, n_norm;      // n_norm: workgroups of rng_normals_body (n_gx per problem); behind them rng_eps_t_body's
     int e_gx;
 };
-__global__ __launch_bounds__(kCovThreads) void mid_cov_a_rng_kernel(MidAArgs a) {
+__global__ __launch_bounds__(kCovThreads, 2) void mid_cov_a_rng_kernel(MidAArgs a) {
     extern __shared__ double sm[];
     int b = blockIdx.x;
     if (b < a.n_cov) { cov_a_body(a.cov, sm, b % a.cov.L, b / a.cov.L); return; }

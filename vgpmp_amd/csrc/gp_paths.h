@@ -302,7 +302,7 @@ __device__ __forceinline__ void paths_fwd_split_body(const PathArgs& a, float* s
 //   s_ell = <R, G A_ell> + <dR, C_ell eps> + <G, H_X> - <dR, H_Z>
 //   s_var = <R, G A_var> + <dR, C_var eps> ;  s_rff = <G, F0_X> - <dR, F0_Z>   (x 1/(2 var) later)
 template <int SK, bool RAW>
-__global__ __launch_bounds__(kBlock) void paths_bwd_sc8(PathArgs a) {
+__global__ __launch_bounds__(kBlock, 2) void paths_bwd_sc8(PathArgs a) {
     constexpr int SC = 8;
     extern __shared__ float smf[];
     __shared__ float red[3][kBlock / VG_WAVE];
@@ -945,7 +945,7 @@ __device__ __forceinline__ void paths_bwd_split_body(const PathArgs& a, float* s
 }
 
 template <int SK, int MZ = 0>
-__global__ __launch_bounds__(kBlock) void paths_bwd_split(PathArgs a) {
+__global__ __launch_bounds__(kBlock, 2) void paths_bwd_split(PathArgs a) {
     extern __shared__ float smf[];
     paths_bwd_split_body<SK, MZ>(a, smf, (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)), (int)gridDim.x);
 }
@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(kBlock, 4) void paths_fwd_regs(PathArgs a) {
 }
 
 template <int SK, bool RAW>
-__global__ __launch_bounds__(kBlock) void paths_fwd_sc8(PathArgs a) {
+__global__ __launch_bounds__(kBlock, 2) void paths_fwd_sc8(PathArgs a) {
     extern __shared__ float smf[];
     if (a.tick && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *a.tick += 1u;
     if (SK > 1 && a.nsplit == 2) {

@@ -188,7 +188,7 @@ __device__ __forceinline__ void prior_gemm_body(const GemmArgs& a, int bx, int b
 }
 
 template <int KS>
-__global__ __launch_bounds__(kBlock) void prior_gemm_kernel(GemmArgs a) { prior_gemm_body<KS>(a, blockIdx.x, blockIdx.y, blockIdx.z); }
+__global__ __launch_bounds__(kBlock, 2) void prior_gemm_kernel(GemmArgs a) { prior_gemm_body<KS>(a, blockIdx.x, blockIdx.y, blockIdx.z); }
 
 // The same tile with its operands staged through LDS by DMA in passes of 128 K (the form stage 2 uses): whole
 // 512-byte rows per request instead of the 16 rows x 64 bytes a fragment-shaped load touches, all requests of a
@@ -261,7 +261,7 @@ __device__ __forceinline__ void prior_gemm_lds_body(const GemmArgs& a, float* ld
     VG_T(bx == 2 && by == 1 && l == L - 1 && sk == SK - 1 && sel == nsel - 1, 245);
 }
 
-__global__ __launch_bounds__(kBlock) void prior_gemm_lds_kernel(GemmArgs a) {
+__global__ __launch_bounds__(kBlock, 2) void prior_gemm_lds_kernel(GemmArgs a) {
     extern __shared__ float gemm_lds[];
     prior_gemm_lds_body(a, gemm_lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
@@ -381,7 +381,7 @@ __device__ __forceinline__ void prior_gemm_tiled_body(const TiledGemmArgs& ta, f
 #undef VG_TG_STORE
 
 template <int MT>
-__global__ __launch_bounds__(kBlock) void prior_gemm_tiled_kernel(TiledGemmArgs ta) {
+__global__ __launch_bounds__(kBlock, 2) void prior_gemm_tiled_kernel(TiledGemmArgs ta) {
     extern __shared__ __attribute__((aligned(16))) float tg_lds[];
     prior_gemm_tiled_body<MT>(ta, tg_lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
@@ -540,7 +540,7 @@ __device__ __forceinline__ void prior_fused_batch_body(const FusedBatchArgs& a, 
         }
 }
 template <bool DELL, int DM, int MT = 1>
-__global__ __launch_bounds__(kBlock) void prior_fused_batch_kernel(FusedBatchArgs a) {
+__global__ __launch_bounds__(kBlock, 2) void prior_fused_batch_kernel(FusedBatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) float fb_lds[];
     prior_fused_batch_body<DELL, DM, MT>(a, fb_lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
