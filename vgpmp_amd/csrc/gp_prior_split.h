@@ -50,27 +50,6 @@ __device__ __forceinline__ int vg_swz(int row, int chunk) { return chunk ^ ((0x1
 // byte offset of element k (0..31) of a tile row
 __device__ __forceinline__ int vg_tile_off(int row, int k) { return row * kHRowBytes + vg_swz(row, k >> 3) * 16 + (k & 7) * 2; }
 
-// Philox-4x32-10 with one v_mad_u64_u32 per 32 x 32 -> 64 product (both halves from one instruction; the compiler emits
-// v_mul_lo_u32 + v_mul_hi_u32 for the C form).  Same values as vg_philox.
-__device__ __forceinline__ uint4 vg_philox_mad(uint4 c, uint2 k) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        unsigned long long p0, p1;
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p0) : "v"(c.x), "s"(0xD2511F53u) : "vcc");
-        asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p1) : "v"(c.z), "s"(0xCD9E8D57u) : "vcc");
-        // (three-input xor in one v_bitop3_b32: the compiler emits two v_xor_b32 for the C form)
-        c = make_uint4(__builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c.y, k.x, 0x96), (uint32_t)p1,
-                       __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c.w, k.y, 0x96), (uint32_t)p0);
-        k.x += 0x9E3779B9u;
-        k.y += 0xBB67AE85u;
-    }
-    return c;
-}
-// vg_normal8 on it: the same expressions, hence the same eight normals
-__device__ __forceinline__ void vg_normal8_mad(uint32_t i, uint32_t stream, uint2 key, float (&z)[8]) {
-    vg_normal8_from(vg_philox_mad(make_uint4(i, stream, 0u, 0u), key), z);
-}
-
 __device__ __forceinline__ float vg_uniform(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
 }
@@ -190,7 +169,7 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
         // ---- W: the thread's counter covers k = 8 wpart .. 8 wpart + 7: one 16-byte chunk of each half tile
         if (draws_w) {      // (uniform per wave)
             float z[8];
-            vg_normal8_mad(wbase + (uint32_t)(k0 >> 3), VG_STREAM_W, key, z);
+            vg_normal8(wbase + (uint32_t)(k0 >> 3), VG_STREAM_W, key, z);
             vg_h4 h0, l0, h1, l1;
             vg_split4((vg_f32x4){z[0], z[1], z[2], z[3]}, h0, l0);
             vg_split4((vg_f32x4){z[4], z[5], z[6], z[7]}, h1, l1);
