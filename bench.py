@@ -401,7 +401,9 @@ def measured_solves(args, world, rank, dist, backend):
     ns = {}
     exec("from gpflow_vgpmp.utils.miscellaneous import *", ns)
     from gpflow_vgpmp.utils.simulation_manager import SimulationManager
-    with warnings.catch_warnings():
+    import contextlib
+    # (the reference's parameter loader prints the size of the problem set: that belongs on stderr here -- stdout carries the one JSON line)
+    with warnings.catch_warnings(), contextlib.redirect_stdout(sys.stderr):
         warnings.simplefilter("ignore")
         env = SimulationManager(file_path=os.path.join(ROOT, "parameters.yaml"))
     env.config["planner_params"].update(num_samples=args.samples, num_inducing=args.inducing, time_spacing_X=args.timesteps)

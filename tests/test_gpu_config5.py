@@ -103,8 +103,11 @@ def _batch(pb, sc, S, N, M, B, **kw):
     return pl, nz
 
 
-# (S, N, problems): 8 lanes per configuration (few configurations) / 1 lane (> 65 536 configurations in the launch)
-@pytest.mark.parametrize("S,N,M,B,P", [(8, 12, 6, 64, 1), (40, 30, 10, 128, 2), (128, 100, 30, 256, 6)])
+# (S, N, problems): 8 lanes per configuration (few configurations) / 1 lane (> 65 536 configurations in the launch);
+# 5 problems = 70 latents of few samples: the few-sample prior kernel at 14 joints (projections by four MFMAs per tile, joint extent
+# padded to 16), one and two 16-row sample tiles
+@pytest.mark.parametrize("S,N,M,B,P", [(8, 12, 6, 64, 1), (40, 30, 10, 128, 2), (128, 100, 30, 256, 6), (8, 30, 10, 128, 5),
+                                       (24, 30, 10, 128, 5)])
 def test_synthetic14_elbo_forward_backward_against_oracle(S, N, M, B, P):
     pb = synthetic_problem(dof=14, S=S, N=N, M=M, B=B, seed=13, n_grid=48, n_problems=P)
     sc = _engine().DeviceScene(pb["spec"], pb["grid"], pb["offset"], free_space_summary=True)
