@@ -34,6 +34,7 @@ struct CovArgs {
     // (Mz = 32): the MFMA sequence of paths_fwd_split_body on the float32 C it has just built
     int form_u, S;
     int rows_tpw;            // row tiles (kRowTile time points) per workgroup of the rows role
+    int ki_in_a;             // batches: (Kuu + jI)^-1 = Lk^-T Lk^-1 once per latent, by stage A (ws.Kinv), not by every row-tile workgroup of stage B
     const float* eps;        // [P,L,S,Mz]  (ws.epsT: the generator's second copy, a latent's rows contiguous)
     HyperArgs hy;
     vg_workspace ws;
@@ -300,8 +301,9 @@ __device__ __forceinline__ void eliminate_panel16(double (&a)[16], double (&rinv
     }
 }
 // Lkg / Lig: the global copies of both factors, written straight from the assembly (the LDS images are not formed then).
+// li_img: also leave Lk^-1 in LDS (the Li region, [32][ld], zeros outside the lower triangle) for a product that follows.
 __device__ __forceinline__ void chol_inverse_panels(double* La, double* Li, double* Aug, double* rsd, int Mz, int ld,
-                                                    int tid, int nt, double* Lkg, double* Lig) {
+                                                    int tid, int nt, double* Lkg, double* Lig, bool li_img = false) {
     const int la = 2 * Mz + 1;
     double* Img = Aug;
     if (tid < VG_WAVE) {
@@ -414,6 +416,7 @@ __device__ __forceinline__ void chol_inverse_panels(double* La, double* Li, doub
             Lkg[r * Mz + j] = in ? lk : 0.0;
             Lig[r * Mz + j] = in ? li : 0.0;
         }
+        if (li_img) Li[r * ld + j] = in ? li : 0.0;      // (the wave's scratch tiles in this region are dead behind the barriers above)
     }
 }
 
@@ -489,8 +492,17 @@ __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, 
     double* Lkg = a.ws.Lk64 + pl * Mz * Mz;
     double* Lig = a.ws.Li64 + pl * Mz * Mz;
     if (Mz > 16 && Mz <= 32 && a.elim_wave) {
-        chol_inverse_panels(La, Li, Sc, rsd, Mz, ld, tid, nt, Lkg, Lig);
+        chol_inverse_panels(La, Li, Sc, rsd, Mz, ld, tid, nt, Lkg, Lig, a.ki_in_a != 0);
         VG_T(l == 0 && p == 0, 102);
+        if (a.ki_in_a) {
+            // (Kuu + jI)^-1 = Lk^-T Lk^-1 here, once per latent: the routine, operands and order of the row-tile workgroups of
+            // stage B (which then stage the product instead of Lk^-1 and skip theirs) -- the same bits
+            __syncthreads();
+            double* Kig = a.ws.Kinv + pl * Mz * Mz;
+            matmul_f64(MatView{Li, 1, ld}, MatView{Li, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
+                if (r < Mz && c < Mz) Kig[(size_t)r * Mz + c] = v;
+            });
+        }
     } else {
         if (Mz <= 32 && a.elim_wave) chol_inverse_wave(La, Li, Sc, rsd, Mz, ld, tid, nt);
         else if (Mz <= 32 && nt == 256) chol_inverse_regs(La, Li, Sc, rsd, Mz, ld, tid, nt);
@@ -857,7 +869,8 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int wg_tile, int l, 
     {
         auto all = [](int, int) { return true; };
         if ((Mz & 1) == 0) {
-            vg_stage_f64_square(Lt, ld, a.ws.Li64 + pl * Mz * Mz, Mz, tid, nt);
+            if (a.ki_in_a) vg_stage_f64_square(Ki, ld, a.ws.Kinv + pl * Mz * Mz, Mz, tid, nt);      // stage A formed it
+            else vg_stage_f64_square(Lt, ld, a.ws.Li64 + pl * Mz * Mz, Mz, tid, nt);
             if (a.want_dell) vg_stage_f64_square(Kd, ld, a.ws.Kd_ell + pl * Mz * Mz, Mz, tid, nt);
             else for (int e = tid; e < Mz * ld; e += nt) Kd[e] = 0.0;
         } else {
@@ -877,7 +890,7 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int wg_tile, int l, 
     // (Kuu + jI)^-1 = Lk^-T Lk^-1: on the float64 matrix cores when Mz is a multiple of 16 (no padding needed), else by
     // dot products over the non-zero part of the two columns; tile 0 keeps the copy the views / the inducing-location
     // reverse pass read
-    {
+    if (!a.ki_in_a) {
         double* Kig = tile == 0 ? a.ws.Kinv + pl * Mz * Mz : nullptr;
         if ((Mz & 15) == 0) {
             matmul_f64(MatView{Lt, 1, ld}, MatView{Lt, ld, 1}, Mz, tid, nt, [&](int r, int c, double v) {
@@ -904,7 +917,7 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int wg_tile, int l, 
         double* ar2 = kf;                      // [16][32]  A rows
         double* yr2 = kf + 16 * 32;            // [16][32]  dKfu/dell - A dKuu/dell
         const int rows_w = tpw * kRowTile, wv = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
-        __syncthreads();                       // every wave has read Lk^-1
+        if (!a.ki_in_a) __syncthreads();       // every wave has read Lk^-1
         for (int r0 = 0; r0 < rows_w; r0 += 16) {
             const int n0 = n00 + r0;
             if (n0 >= N) break;
@@ -989,11 +1002,13 @@ __device__ void cov_rows_padded_body(const CovArgs& a, double* sm, int wg_tile, 
     const int n00 = tile * kRowTile;
     {
         auto all = [](int, int) { return true; };
+        double* first = a.ki_in_a ? Ki : Lt;      // stage A formed (Kuu + jI)^-1: it arrives instead of Lk^-1
+        const double* first_g = (a.ki_in_a ? a.ws.Kinv : a.ws.Li64) + pl * Mz * Mz;
         if (!(Mz & 1)) {
-            vg_stage_f64_even(Lt, Mp, ld, a.ws.Li64 + pl * Mz * Mz, Mz, Mz, tid, nt);
+            vg_stage_f64_even(first, Mp, ld, first_g, Mz, Mz, tid, nt);
             vg_stage_f64_even(Kd, Mp, ld, a.ws.Kd_ell + pl * Mz * Mz, a.want_dell ? Mz : 0, Mz, tid, nt);
         } else {
-            vg_stage_f64(Lt, Mp, ld, a.ws.Li64 + pl * Mz * Mz, Mz, Mz, 0, 0, tid, nt, all);
+            vg_stage_f64(first, Mp, ld, first_g, Mz, Mz, 0, 0, tid, nt, all);
             vg_stage_f64(Kd, Mp, ld, a.ws.Kd_ell + pl * Mz * Mz, a.want_dell ? Mz : 0, Mz, 0, 0, tid, nt, all);
         }
         vg_stage_words(zs, 2 * (Mp + tpw * kRowTile), tid, nt, [&](int w) -> const void* {
@@ -1007,7 +1022,7 @@ __device__ void cov_rows_padded_body(const CovArgs& a, double* sm, int wg_tile, 
     vg_dma_wait();
     __syncthreads();
     VG_T(tile == 0 && l == 0 && p == 0, 232);
-    {   // (Kuu + jI)^-1 = Lk^-T Lk^-1; tile 0 keeps the copy the views / the inducing-location reverse pass read
+    if (!a.ki_in_a) {   // (Kuu + jI)^-1 = Lk^-T Lk^-1; tile 0 keeps the copy the views / the inducing-location reverse pass read
         double* Kig = tile == 0 ? a.ws.Kinv + pl * Mz * Mz : nullptr;
         matmul_f64(MatView{Lt, 1, ld}, MatView{Lt, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
             Ki[r * ld + c] = v;
@@ -1016,7 +1031,7 @@ __device__ void cov_rows_padded_body(const CovArgs& a, double* sm, int wg_tile, 
     }
     const int rows_w = tpw * kRowTile, wv = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
     const float iMp = 1.0f / (float)Mp;
-    __syncthreads();                       // every wave has read Lk^-1; Ki stands
+    if (!a.ki_in_a) __syncthreads();       // every wave has read Lk^-1; Ki stands
     for (int r0 = 0; r0 < rows_w; r0 += 16) {
         const int n0 = n00 + r0;
         if (n0 >= N) break;

@@ -467,6 +467,9 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     ca.want_dell = want_dell ? 1 : 0;
     ca.stop = -1;
     ca.elim_wave = (what & VGPMP_ELIM_BLOCK) ? 0 : 1;
+    // batches (stage A and stage B are launches of their own, stage A off the critical path behind the generator roles): the
+    // inverse once per latent in stage A (its two-panel form) instead of in every row-tile workgroup of stage B
+    ca.ki_in_a = (!fused && ca.elim_wave && Mz > 16 && Mz <= 32) ? 1 : 0;
     ca.tick = (fused && do_adam) ? ctr : nullptr;
     ca.lr = lr; ca.lr_dev = ws->lr_t;
     ca.rows_tpw = 1; ca.prologue = 0; ca.commit = 0; ca.keep_prev = (fused && backward) ? 1 : 0;
