@@ -309,7 +309,7 @@ def test_graph_replay_of_the_merged_launch_schedule():
         assert torch.allclose(x, y, rtol=0, atol=1e-12), float((x - y).abs().max())
 
 
-@pytest.mark.parametrize("P,M", [(1, 12), (3, 12), (1, 30), (2, 30), (1, 20), (6, 12), (30, 12), (40, 30)])
+@pytest.mark.parametrize("P,M", [(1, 12), (3, 12), (1, 30), (2, 30), (1, 20), (6, 12), (30, 12), (40, 30), (112, 30), (110, 20)])
 def test_pipelined_steps_equal_single_step_calls(P, M):
     """vgpmp_elbo_steps shares launches between independent kernels and runs the q_mu / q_sqrt update of step t
     next to the covariance / feature kernels of step t+1; the result must equal the same steps issued one call
@@ -322,7 +322,8 @@ def test_pipelined_steps_equal_single_step_calls(P, M):
     qs = np.array([ps.queries[i % len(ps.queries)] for i in range(P)])
     # 6 problems: the merged launches of the medium batches (cov_a | noise, cov_b | tiled GEMM with the tiles first, hyper |
     # final); 30: stage B of the covariance path inside the fused prior launch; 40: the large-batch schedule with its small
-    # launches merged and the counter tick inside paths_fwd -- each against one launch per kernel.
+    # launches merged and the counter tick inside paths_fwd -- each against one launch per kernel; 112 / 110 problems (784 / 770
+    # latents, Mz = 32 and the zero-padded Mz = 22): more latents than workgroup slots of the covariance launches.
     # M = 30 (Mz = 32): the update role on four column strips, the two-panel elimination and the whole-wave hyper-parameter
     # update of the shared launches against final_kernel / hyper_kernel; M = 20 (Mz = 22): the zero-padded forms
     kw = dict(num_samples=32, num_inducing=M, num_data=40, num_bases=128, lengthscales=[2.0] * 7, variance=0.2, seed=3)
