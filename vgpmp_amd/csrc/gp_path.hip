@@ -707,6 +707,21 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                              0, fp)                                  \
                : (void)hipExtLaunchKernelGGL((prior_fused_small_kernel<MT_, DM_, false>), fgrid, dim3(kBlock), 0, st, g0, g1, \
                              0, fp))
+        // the f16-split form (gp_prior_split.h): K steps of 32 bases (every K-slice a multiple of that); the float32-MFMA kernel
+        // stays behind VGPMP_PRIOR_F32, as for the large batches
+        if (!(what & VGPMP_PRIOR_F32) && (B / 4) % kHK == 0) {
+#define VG_FUSED_SMALL16(MT_, DM_)                                            \
+    (want_dell ? (void)hipExtLaunchKernelGGL((prior_fused_small16_kernel<MT_, DM_, true>), fgrid, dim3(kBlock), 0, st, g0, g1, \
+                             0, fp)                                  \
+               : (void)hipExtLaunchKernelGGL((prior_fused_small16_kernel<MT_, DM_, false>), fgrid, dim3(kBlock), 0, st, g0, g1, \
+                             0, fp))
+            if (L == 7) { if (S <= 16) VG_FUSED_SMALL16(1, 7); else VG_FUSED_SMALL16(2, 7); }
+            else if (L == 6) { if (S <= 16) VG_FUSED_SMALL16(1, 6); else VG_FUSED_SMALL16(2, 6); }
+            else if (L <= 8) { if (S <= 16) VG_FUSED_SMALL16(1, 8); else VG_FUSED_SMALL16(2, 8); }
+            else { if (S <= 16) VG_FUSED_SMALL16(1, 16); else VG_FUSED_SMALL16(2, 16); }
+#undef VG_FUSED_SMALL16
+            return;
+        }
         // (6- and 7-joint arms: no padded column -- the compiler cannot drop a multiply by a zero it must assume could meet a NaN)
         if (L == 7) { if (S <= 16) VG_FUSED_SMALL(1, 7); else VG_FUSED_SMALL(2, 7); }
         else if (L == 6) { if (S <= 16) VG_FUSED_SMALL(1, 6); else VG_FUSED_SMALL(2, 6); }

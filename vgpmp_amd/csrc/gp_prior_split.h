@@ -270,4 +270,154 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
     }
 }
 
+// Few samples (S <= 32), more than 64 latents: prior_fused_small_kernel's job (gp_prior.h) with the products on the f16 matrix
+// pipe.  That kernel is three quarters float32 MFMA -- 16-row tiles that 7 samples fill to 44 % -- on the pipe its vector work
+// shares (lesson 42); here a K step of 32 bases costs twelve v_mfma_f32_16x16x32_f16 (hi lo + lo hi + hi hi for F0 and H of two
+// column tiles: 8 of their 16 cycles hold the vector issue) instead of sixty-four float32 MFMAs of 32 cycles.  Everything stays in
+// registers -- no LDS tiles, no barriers in the loop:
+//   * a lane's B fragment is 8 CONSECUTIVE bases of one point: two float32 projection MFMAs per tile with the frequencies' rows
+//     permuted (row 4 g + q of set s = base 8 g + 4 s + q) leave exactly those in lane (point, g);
+//   * features: phase by one fused multiply-add, v_cos / v_sin, split into f16 halves (vg_split4) -- the constant factors c and
+//     c / ell^2 go to the accumulators at the end, so the operands stay in f16's range as in prior_fused_split_kernel;
+//   * a lane's A fragment is 8 consecutive weights of one sample row: two 16-byte loads of W, split.
+// Four waves = the four K-slices whose slabs the path kernels sum; operands requested one K step ahead.
+template <int MT, int DM, bool DELL>    // 16-row sample tiles; joint extent DM = D for 6 / 7 joints, else padded to 8 or 16; d/d ell wanted
+__global__ __launch_bounds__(kBlock, 2) void prior_fused_small16_kernel(FusedPriorArgs a) {
+    __shared__ float pts[kFNT * 16][DM];
+    const int S = a.S, L = a.L, J = a.J, N = a.N, D = a.D, B = a.B;
+    const int tid = threadIdx.x, lane = tid & 63, sk = tid >> 6;      // 4 waves = 4 K-slices
+    const int pl = blockIdx.x, l = pl % L, p = pl / L, j0 = blockIdx.y * (kFNT * 16);
+    if (a.tick && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.tick += 1u;
+    for (int e = tid; e < kFNT * 16 * DM; e += kBlock) {
+        const int jj = e / DM, d = e - jj * DM, j = min(j0 + jj, J - 1);
+        const double* pt = j < N ? a.X + (size_t)j * D : a.Zy + (size_t)p * a.zy_stride + (size_t)(j - N) * D;
+        pts[jj][d] = d < D ? (float)pt[d] : 0.f;
+    }
+    __syncthreads();
+    const float ell = softplus_f((float)a.raw_ell[pl]);
+    const float var = (float)kVarFloor + softplus_f((float)a.raw_var[pl]);
+    const float inv_ell = 1.0f / ell, c = __builtin_amdgcn_sqrtf(2.0f * var / (float)B), c_ell2 = c * inv_ell * inv_ell;
+    const float rev_ell = inv_ell * 0.15915494309189535f;
+    const int r = lane & 15, g = lane >> 4;
+    const int kchunk = B / 4, kbeg = sk * kchunk;
+    vg_f32x4 accF[MT][kFNT], accH[MT][kFNT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < kFNT; ++t) { accF[m][t] = (vg_f32x4){0.f, 0.f, 0.f, 0.f}; accH[m][t] = accF[m][t]; }
+    // projections (float32 MFMAs, as in prior_fused_small_kernel): B operands = this lane's point coordinates, loop invariant
+    constexpr int kDQ = (DM + 3) / 4;
+    float pb[kFNT][kDQ];
+#pragma unroll
+    for (int t = 0; t < kFNT; ++t)
+#pragma unroll
+        for (int i = 0; i < kDQ; ++i) pb[t][i] = 4 * i + g < DM ? pts[16 * t + r][min(4 * i + g, DM - 1)] : 0.f;
+    int ooff[kDQ];
+#pragma unroll
+    for (int i = 0; i < kDQ; ++i) ooff[i] = min(4 * i + g, D - 1);
+    // A operand row r of projection set s holds base 8 (r >> 2) + 4 s + (r & 3) of the K step: accumulator element q of lane
+    // (point, g) is then base 8 g + 4 s + q
+    const float* orow = a.omega + ((size_t)pl * B + kbeg + 8 * (r >> 2) + (r & 3)) * D;
+    const float* brow = a.beta + (size_t)pl * B + kbeg + 8 * g;                 // phases of this lane's 8 bases
+    const float* wrow[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) wrow[m] = a.W + (((size_t)p * S + min(16 * m + r, S - 1)) * L + l) * B + kbeg + 8 * g;
+    struct Ops { float o[2][kDQ]; vg_f32x4 b0, b1, w0[MT], w1[MT]; };
+    auto fetch = [&](int k, Ops& x) {
+        const int kk = min(k, kchunk - kHK);             // (the look-ahead of the last step re-reads it)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int i = 0; i < kDQ; ++i) x.o[s2][i] = orow[(size_t)(kk + 4 * s2) * D + ooff[i]];
+        x.b0 = *reinterpret_cast<const vg_f32x4*>(brow + kk);
+        x.b1 = *reinterpret_cast<const vg_f32x4*>(brow + kk + 4);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            x.w0[m] = *reinterpret_cast<const vg_f32x4*>(wrow[m] + kk);
+            x.w1[m] = *reinterpret_cast<const vg_f32x4*>(wrow[m] + kk + 4);
+        }
+    };
+    auto step = [&](const Ops& x) {
+        // A fragments: 8 weights of the lane's sample row, split
+        vg_h8 ah[MT], al[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            vg_h4 h0, l0, h1, l1;
+            vg_split4(x.w0[m], h0, l0);
+            vg_split4(x.w1[m], h1, l1);
+            ah[m] = (vg_h8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+            al[m] = (vg_h8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+        }
+        const vg_f32x4 bt0 = x.b0 * 0.15915494309189535f, bt1 = x.b1 * 0.15915494309189535f;      // phases in revolutions
+#pragma unroll
+        for (int t = 0; t < kFNT; ++t) {
+            vg_f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
+#pragma unroll
+            for (int i = 0; i < kDQ; ++i) {
+                p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.o[0][i], pb[t][i], p0, 0, 0, 0);
+                p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.o[1][i], pb[t][i], p1, 0, 0, 0);
+            }
+            vg_f32x4 c0, c1, s0, s1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float r0 = __builtin_amdgcn_fractf(fmaf(p0[q], rev_ell, bt0[q]));
+                const float r1 = __builtin_amdgcn_fractf(fmaf(p1[q], rev_ell, bt1[q]));
+                c0[q] = __builtin_amdgcn_cosf(r0); c1[q] = __builtin_amdgcn_cosf(r1);
+                if (DELL) { s0[q] = __builtin_amdgcn_sinf(r0) * p0[q]; s1[q] = __builtin_amdgcn_sinf(r1) * p1[q]; }
+            }
+            vg_h4 h0, l0, h1, l1;
+            vg_split4(c0, h0, l0);
+            vg_split4(c1, h1, l1);
+            const vg_h8 bh = (vg_h8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+            const vg_h8 bl = (vg_h8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                accF[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh, accF[m][t], 0, 0, 0);
+                accF[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl, accF[m][t], 0, 0, 0);
+                accF[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh, accF[m][t], 0, 0, 0);
+            }
+            if (DELL) {
+                vg_split4(s0, h0, l0);
+                vg_split4(s1, h1, l1);
+                const vg_h8 dh = (vg_h8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                const vg_h8 dl = (vg_h8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    accH[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], dh, accH[m][t], 0, 0, 0);
+                    accH[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], dl, accH[m][t], 0, 0, 0);
+                    accH[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], dh, accH[m][t], 0, 0, 0);
+                }
+            }
+        }
+    };
+    Ops xa, xb;
+    fetch(0, xa);
+    int k = 0;
+    for (; k + 2 * kHK <= kchunk; k += 2 * kHK) {
+        fetch(k + kHK, xb);
+        step(xa);
+        fetch(k + 2 * kHK, xa);
+        step(xb);
+    }
+    if (k < kchunk) step(xa);      // (an odd number of K steps)
+    // D layout: col = lane & 15, row = (lane >> 4) * 4 + reg; the constant factors left out of the operands go in here
+    float* F0 = a.F0 + (size_t)sk * a.slab;
+    float* H = a.H + (size_t)sk * a.slab;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < kFNT; ++t) {
+            const int jc = j0 + 16 * t + r;
+            if (jc >= J) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int s = 16 * m + g * 4 + q;
+                if (s >= S) continue;
+                const size_t o = (((size_t)p * S + s) * L + l) * J + jc;
+                vg_stream(F0 + o, c * accF[m][t][q]);
+                if (DELL) vg_stream(H + o, c_ell2 * accH[m][t][q]);
+            }
+        }
+}
+
 }  // namespace
