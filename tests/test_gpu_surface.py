@@ -862,6 +862,44 @@ def test_f16_split_prior_kernel_against_float64_and_the_float32_kernels(robot, S
     assert float((sp.q_mu - fp.q_mu).abs().max()) < 3 * sp.lr * 2e-2
 
 
+@pytest.mark.parametrize("robot,S", [("ur10", 1024), ("franka", 512)])
+def test_many_sample_gemm_role_on_the_f16_pipe_against_its_float32_form(robot, S):
+    """A few problems of 512 samples or more (BASELINE config 4 on one rank: 1024) run stage 2's GEMM role with f16-split
+    products (csrc/gp_prior.h::prior_gemm_lds_body<true>: the float32 LDS tiles split in registers, three MFMAs per product);
+    VGPMP_PRIOR_F32 keeps the float32 MFMAs.  Same noise, same variables: paths within 2e-5, loss and gradients to float32
+    accuracy, and not the same bits (the f16 form did run)."""
+    from vgpmp_amd import capi, engine
+    ps = rb.load_problemset(robot, "industrial")
+    spec = rb.load_robot(robot, *ps.robot_pos_and_orn)
+    grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
+    sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
+    qs = np.array([ps.queries[3]])
+    kw = dict(num_samples=S, num_inducing=18, num_data=70, num_bases=1024, lengthscales=[2.0] * spec.dof, variance=0.2, seed=9)
+    res = {}
+    for name, flag in (("f16", 0), ("f32", capi.PRIOR_F32)):
+        pl = engine.PlannerBatch(sc, qs, **kw)
+        pl.extra_flags |= flag
+        loss, grads = pl.loss_and_grad(generate=True, step=7)
+        torch.cuda.synchronize()
+        res[name] = dict(f=pl.f.cpu().numpy(), logp=pl.logp.cpu().numpy(), loss=loss.cpu().numpy().copy(),
+                         grads=[g.cpu().numpy().copy() for g in grads], pl=pl)
+    a, b = res["f16"], res["f32"]
+    assert np.abs(a["f"] - b["f"]).max() > 0.0
+    np.testing.assert_allclose(a["f"], b["f"], rtol=0, atol=2e-5)
+    ok = np.isclose(a["logp"], b["logp"], rtol=2e-3, atol=1e-4)
+    assert ok.mean() > 0.99
+    flips = 1.0 - ok.mean()
+    np.testing.assert_allclose(a["loss"], b["loss"], rtol=50 * flips + 1e-4)
+    for ga, gb in zip(a["grads"], b["grads"]):
+        assert np.abs(ga - gb).max() <= (50 * flips + 1e-3) * np.abs(gb).max() + 1e-12
+    sp, fp = a["pl"], b["pl"]
+    for _ in range(3):
+        sp.step(); fp.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(sp.q_mu).all()
+    assert float((sp.q_mu - fp.q_mu).abs().max()) < 3 * sp.lr * 2e-2
+
+
 @pytest.mark.parametrize("S,N,M,P", [(128, 100, 30, 64), (70, 20, 5, 63), (37, 50, 10, 40)])
 def test_reverse_path_pass_over_several_chunks_per_workgroup_is_bitwise_the_same(S, N, M, P):
     """paths_bwd_sc8 stages a latent's A / C tangents once and walks several 8-sample chunks (the

@@ -9,6 +9,7 @@ constexpr int kBlock = 256;
 // up to 4 problems x 7 latents, one launch per kernel from 5 (5 problems 147 vs 143 us, 8: 198 vs 150); with few samples (config 3's
 // shape, S = 7) up to 64 pairs (5 problems 71 vs 86 us per step, 8: 80 vs 86; 16 problems 117 vs 101)
 constexpr int kFuseMaxPL = 32, kFuseMaxPLFewSamples = 64;
+constexpr int kGemmF16MinSamples = 512;      // few problems of this many samples: stage 2's GEMM role in its f16-split form
 __host__ __device__ inline int vg_fuse_max_pl(int S) { return S <= 32 ? kFuseMaxPLFewSamples : kFuseMaxPL; }
 __device__ __forceinline__ double matern52_dell(double t1, double t2, double ell, double var) {
     double r = fabs(t1 - t2) / ell;
@@ -65,5 +66,31 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     for (int k = 0; k < (int)(blockDim.x / VG_WAVE); ++k) t += red[k];
     return t;
 }
+
+// ---- float32 = f16 hi + f16 lo (the operands of the f16-split products: gp_prior_split.h, the stage-2 GEMM role of many samples)
+typedef float vg_f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 vg_h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 vg_h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 vg_h8 __attribute__((ext_vector_type(8)));
+typedef float vg_f2 __attribute__((ext_vector_type(2)));
+
+// (x0, x1) = hi + lo, both halves rounded to nearest: v_cvt_pk_f16_f32, the residuals x - hi by v_fma_mix_f32 (an f16
+// operand read straight from the packed pair), v_cvt_pk_f16_f32 again
+__device__ __forceinline__ void vg_split2(float x0, float x1, vg_h2& hi, vg_h2& lo) {
+    hi = __builtin_convertvector((vg_f2){x0, x1}, vg_h2);
+    const uint32_t hb = __builtin_bit_cast(uint32_t, hi);
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hb), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hb), "v"(x1));
+    lo = __builtin_convertvector((vg_f2){l0, l1}, vg_h2);
+}
+__device__ __forceinline__ void vg_split4(const vg_f32x4& x, vg_h4& hi, vg_h4& lo) {
+    vg_h2 h0, l0, h1, l1;
+    vg_split2(x[0], x[1], h0, l0);
+    vg_split2(x[2], x[3], h1, l1);
+    hi = (vg_h4){h0[0], h0[1], h1[0], h1[1]};
+    lo = (vg_h4){l0[0], l0[1], l1[0], l1[1]};
+}
+
 
 }  // namespace

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kBlock, 2) void stage2_kernel(Stage2Args a) {
     if (a.gemm_per_xcd > 0) b = (b & 7) * a.gemm_per_xcd + (b >> 3);
     const int bx = b % a.gemm_gx;
     b /= a.gemm_gx;
-    if constexpr (KS < 0) prior_gemm_lds_body(a.gemm, reinterpret_cast<float*>(sm), bx, b % a.gemm_gy, b / a.gemm_gy);
+    if constexpr (KS < 0) prior_gemm_lds_body<KS == -2>(a.gemm, reinterpret_cast<float*>(sm), bx, b % a.gemm_gy, b / a.gemm_gy);
     else prior_gemm_body<KS>(a.gemm, bx, b % a.gemm_gy, b / a.gemm_gy);
 }
 // The same launch with the GEMM tiles at the FRONT of the grid, for whole-K tiles (no K-slices: 3 problems up).  They are
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kBlock, 2) void stage2_gemm_first_kernel(Stage2Args
     if (a.gemm_per_xcd > 0) b = (b & 7) * a.gemm_per_xcd + (b >> 3);
     const int bx = b % a.gemm_gx;
     b /= a.gemm_gx;
-    if constexpr (KS < 0) prior_gemm_lds_body(a.gemm, reinterpret_cast<float*>(sm), bx, b % a.gemm_gy, b / a.gemm_gy);
+    if constexpr (KS < 0) prior_gemm_lds_body<KS == -2>(a.gemm, reinterpret_cast<float*>(sm), bx, b % a.gemm_gy, b / a.gemm_gy);
     else prior_gemm_body<KS>(a.gemm, bx, b % a.gemm_gy, b / a.gemm_gy);
 }
 
@@ -487,7 +487,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     GemmArgs ga;
     ga.S = S; ga.L = L; ga.J = J; ga.B = B; ga.SK = SK; ga.nsel = want_dell ? 2 : 1;
     ga.W = nz->w; ga.Phi = ws->Phi; ga.dPhi = ws->dPhi; ga.F0 = ws->F0; ga.H = ws->H; ga.slab = slab;
-    ga.dbg = 0;
+    ga.dbg = 0; ga.ell = ws->ell; ga.var = ws->var;
     TiledGemmArgs tga;
     tga.S = S; tga.L = L; tga.J = J; tga.B = B; tga.nsel = ga.nsel;
     tga.W = nz->w; tga.Phi = ws->Phi; tga.dPhi = ws->dPhi; tga.F0 = ws->F0; tga.H = ws->H;
@@ -598,7 +598,10 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const bool glds = (B / SK) % kGK == 0 && S >= 48 && !(what & VGPMP_GEMM_DIRECT);      // 64-row tiles: few samples waste them
     const bool gemm_first = SK == 1;      // whole-K tiles (3 problems up) are the longest workgroups of stage 2: at its front
 #define VG_S2(T, K) (gemm_first ? (const void*)stage2_gemm_first_kernel<T, K> : (const void*)stage2_kernel<T, K>)
-    const void* fn_s2 = glds ? (backward ? VG_S2(true, -1) : VG_S2(false, -1))
+    // many samples (the sample-sharded job on few ranks): the GEMM role is the step -- its products on the f16 matrix pipe
+    const bool glds16 = glds && S >= kGemmF16MinSamples && !(what & VGPMP_PRIOR_F32);
+    const void* fn_s2 = glds16 ? (backward ? VG_S2(true, -2) : VG_S2(false, -2))
+                      : glds ? (backward ? VG_S2(true, -1) : VG_S2(false, -1))
                       : backward ? (k8 ? VG_S2(true, 8) : VG_S2(true, 0)) : (k8 ? VG_S2(false, 8) : VG_S2(false, 0));
 #undef VG_S2
     size_t lds_s2 = glds && kGemmLds > lds_cov_b ? kGemmLds : lds_cov_b;

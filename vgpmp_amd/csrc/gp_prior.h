@@ -83,7 +83,6 @@ __global__ __launch_bounds__(kBlock) void features_kernel(FeatArgs a) {
 // v_mfma_f32_16x16x4_f32: lane -> A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15];
 // each lane loads 4 consecutive k (16 B) per operand, so one load pair feeds 4 MFMAs (k = 4g + c).
 // =================================================================================================
-typedef float vg_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kNT = 3;     // 16-column tiles per wave
 
 struct GemmArgs {
@@ -92,6 +91,7 @@ struct GemmArgs {
     float *F0, *H;
     size_t slab;
     int dbg;                 // measurement builds: 1 no stores, 2 no loads, 3 no MFMA
+    const double *ell, *var; // [P,L] of this step (stage A's): the f16 form takes the features' constant factors out of its operands
 };
 
 // KS > 0: the K-slice of a workgroup is a multiple of KS steps of 16 and goes in passes of KS steps whose operands
@@ -198,6 +198,12 @@ __global__ __launch_bounds__(kBlock, 2) void prior_gemm_kernel(GemmArgs a) { pri
 constexpr int kGK = 128, kGLd = kGK + 4, kGRows = 64 + 16 * kNT;
 constexpr size_t kGemmLds = (size_t)kGRows * kGLd * sizeof(float);
 
+// F16: the products on the f16 matrix pipe (operands read from the same float32 LDS tiles, split into f16 halves in registers,
+// hi lo + lo hi + hi hi in float32 accumulators: gp_prior_split.h) -- for a few problems of MANY samples (the sample-sharded
+// job on one rank: 1024), where this role is the step: 24 float32 MFMAs of 32 cycles per 32 k and three column tiles become 9 f16
+// MFMAs and 64 vector instructions.  Fewer samples keep the float32 form (the tests' bitwise reference; the role is not the
+// longest of its launch there).
+template <bool F16 = false>
 __device__ __forceinline__ void prior_gemm_lds_body(const GemmArgs& a, float* lds, int bx, int by, int bz) {
     const int S = a.S, L = a.L, J = a.J, B = a.B, SK = a.SK, nsel = a.nsel;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -217,6 +223,13 @@ __device__ __forceinline__ void prior_gemm_lds_body(const GemmArgs& a, float* ld
     vg_f32x4 acc[kNT];
 #pragma unroll
     for (int t = 0; t < kNT; ++t) acc[t] = (vg_f32x4){0.f, 0.f, 0.f, 0.f};
+    float sc_in = 1.0f, sc_out = 1.0f;                       // (F16) the features' constant factor, out of the operands / back in
+    if constexpr (F16) {
+        const size_t pl = (size_t)p * L + l;
+        const float ell = (float)a.ell[pl], cf = __builtin_amdgcn_sqrtf(2.0f * (float)a.var[pl] / (float)B);
+        sc_out = sel == 0 ? cf : cf / (ell * ell);
+        sc_in = 1.0f / sc_out;
+    }
     for (int k0 = kbeg; k0 < kend; k0 += kGK) {
         if (k0 != kbeg) __syncthreads();                     // the previous pass has been read
         for (int c = (tid & ~63); c < kGRows * kUnits; c += kBlock) {
@@ -231,6 +244,34 @@ __device__ __forceinline__ void prior_gemm_lds_body(const GemmArgs& a, float* ld
         }
         vg_dma_wait();
         __syncthreads();
+        if constexpr (F16) {
+            // a lane's fragment: 8 consecutive k of its row (two 16-byte reads), as f16 halves.  The stored features carry their
+            // constant factors (Phi = c cos, dPhi = c / ell^2 sin (x . omega): a lengthscale of 0.01 puts the latter beyond f16's
+            // 65504): `sc` takes them out -- cos and sin (x . omega) are f16-safe -- and the accumulators get them back at the end
+            auto frag = [&](const float* row, int ks2, float sc, vg_h8& hi, vg_h8& lo) {
+                const vg_f32x4 x0 = *reinterpret_cast<const vg_f32x4*>(row + 32 * ks2 + 8 * g) * sc;
+                const vg_f32x4 x1 = *reinterpret_cast<const vg_f32x4*>(row + 32 * ks2 + 8 * g + 4) * sc;
+                vg_h4 h0, l0, h1, l1;
+                vg_split4(x0, h0, l0);
+                vg_split4(x1, h1, l1);
+                hi = (vg_h8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                lo = (vg_h8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+            };
+#pragma unroll
+            for (int ks2 = 0; ks2 < kGK / 32; ++ks2) {
+                vg_h8 ah, al;
+                frag(As + (wave * 16 + r) * kGLd, ks2, 1.0f, ah, al);
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) {
+                    vg_h8 bh, bl;
+                    frag(Bs + (16 * t + r) * kGLd, ks2, sc_in, bh, bl);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[t], 0, 0, 0);
+                }
+            }
+            continue;
+        }
         const float* ap = As + (wave * 16 + r) * kGLd + 4 * g;
 #pragma unroll
         for (int ks = 0; ks < kGK / 16; ++ks) {
@@ -254,7 +295,7 @@ __device__ __forceinline__ void prior_gemm_lds_body(const GemmArgs& a, float* ld
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int s = sw + g * 4 + q;
-            if (s < S) vg_stream(Out + (((size_t)p * S + s) * L + l) * J + jc, acc[t][q]);
+            if (s < S) vg_stream(Out + (((size_t)p * S + s) * L + l) * J + jc, F16 ? acc[t][q] * sc_out : acc[t][q]);
         }
     }
     VG_T(bx == 0 && by == 0 && bz == 0, 242);
@@ -263,7 +304,7 @@ __device__ __forceinline__ void prior_gemm_lds_body(const GemmArgs& a, float* ld
 
 __global__ __launch_bounds__(kBlock, 2) void prior_gemm_lds_kernel(GemmArgs a) {
     extern __shared__ float gemm_lds[];
-    prior_gemm_lds_body(a, gemm_lds, blockIdx.x, blockIdx.y, blockIdx.z);
+    prior_gemm_lds_body<false>(a, gemm_lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // LDS-tiled variant for large batches (no split-K): a workgroup owns 64 samples x 144 columns, stages

@@ -36,11 +36,6 @@
 
 namespace {
 
-typedef _Float16 vg_h2 __attribute__((ext_vector_type(2)));
-typedef _Float16 vg_h4 __attribute__((ext_vector_type(4)));
-typedef _Float16 vg_h8 __attribute__((ext_vector_type(8)));
-typedef float vg_f2 __attribute__((ext_vector_type(2)));
-
 constexpr int kHK = 32;                  // K step = one v_mfma_f32_16x16x32_f16
 constexpr int kHThreads = 512;
 constexpr int kHRowBytes = 2 * kHK;      // 64-byte tile rows
@@ -52,24 +47,6 @@ __device__ __forceinline__ int vg_tile_off(int row, int k) { return row * kHRowB
 
 __device__ __forceinline__ float vg_uniform(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
-}
-
-// (x0, x1) = hi + lo, both halves rounded to nearest: v_cvt_pk_f16_f32, the residuals x - hi by v_fma_mix_f32 (an f16
-// operand read straight from the packed pair), v_cvt_pk_f16_f32 again
-__device__ __forceinline__ void vg_split2(float x0, float x1, vg_h2& hi, vg_h2& lo) {
-    hi = __builtin_convertvector((vg_f2){x0, x1}, vg_h2);
-    const uint32_t hb = __builtin_bit_cast(uint32_t, hi);
-    float l0, l1;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hb), "v"(x0));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hb), "v"(x1));
-    lo = __builtin_convertvector((vg_f2){l0, l1}, vg_h2);
-}
-__device__ __forceinline__ void vg_split4(const vg_f32x4& x, vg_h4& hi, vg_h4& lo) {
-    vg_h2 h0, l0, h1, l1;
-    vg_split2(x[0], x[1], h0, l0);
-    vg_split2(x[2], x[3], h1, l1);
-    hi = (vg_h4){h0[0], h0[1], h1[0], h1[1]};
-    lo = (vg_h4){l0[0], l0[1], l1[0], l1[1]};
 }
 
 inline size_t vg_fused_split_lds(int MT) {
