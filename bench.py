@@ -539,7 +539,10 @@ def run_sample_sharded(args, world, rank, dist, backend):
             "metric": "ELBO iters/sec, BASELINE config 4: UR10-6DoF industrial S=1024 M=18 T=70, samples sharded over the GPUs",
             "value": args.steps / elapsed, "unit": "ELBO iters/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "timed_blocks": reps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": ("f32; prior products f16-split x3, f32 accumulate (512 samples or more on this rank); covariance path and Adam f64"
+                      if S_loc >= 512 and not (planner.extra_flags & capi.PRIOR_F32) else "f32 (f32 MFMA prior products; covariance path and Adam f64)"),
+            "data": "synthetic",
             "config": {"workload": f"BASELINE config 4: UR10 6-DoF, industrial scene, SDF {'x'.join(str(v) for v in scene.shape)}, "
                                    f"ONE start-goal problem, S={args.samples} Monte-Carlo samples in total ({S_loc} on this rank), "
                                    f"M={planner.M} T={N} B={planner.B}",
@@ -681,7 +684,14 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
                           "(profiles/r03/final/sq_prior_fused_config5.txt); the same flops against the f32-MFMA peak of 157.3 TF/s: "
                           "%.2f" % (gemm_flops / t_gemm / 1e12 / F32_MFMA_PEAK_TFLOPS))
     elif sk == 4 and S <= 32:
-        gemm_kernel, gemm_note = "prior_fused_small_kernel", "few samples: features formed inside the GEMM, four K-slices"
+        if planner.extra_flags & capi.PRIOR_F32:
+            gemm_kernel, gemm_note = "prior_fused_small_kernel", "few samples: features formed inside the GEMM, four K-slices, float32 MFMAs"
+        else:
+            gemm_kernel = "prior_fused_small16_kernel"
+            gemm_note = ("few samples: features formed inside the GEMM from projection MFMAs, four K-slices, register-resident f16-split "
+                         "products (peak = f16 dense MFMA peak / 3 MFMAs per float32 product); 16-row tiles hold %d samples: the "
+                         "algorithmic flops are %.0f %% of what the tiles compute" % (S, 100.0 * S / (16 * ((S + 15) // 16))))
+            peak_gemm = F16_MFMA_PEAK_TFLOPS / 3.0
     elif (1024 // sk) % 128 == 0 and S >= 48:
         gemm_kernel, gemm_note = "prior_gemm_lds_kernel", "a role of stage2_kernel in the timed schedule; timed alone here"
     else:
@@ -716,7 +726,9 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
         "timed_blocks": reps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("f32; prior products f16-split x3, f32 accumulate (v_mfma_f32_16x16x32_f16); covariance path and Adam f64"
-                  if (sk == 1 and not (planner.extra_flags & capi.PRIOR_F32) and not (planner.fuse and npb * D <= (64 if S <= 32 else 32)))
+                  # (batches beyond the few-problem schedule: the f16-split kernels -- large-batch or few-sample form)
+                  if (not (planner.extra_flags & capi.PRIOR_F32) and not (planner.fuse and npb * D <= (64 if S <= 32 else 32))
+                      and (sk == 1 or S <= 32))
                   else "f32 (f32 MFMA prior products; covariance path and Adam f64)"),
         "data": "synthetic",
         "config": {"workload": names[args.workload] + ", SDF " + "x".join(str(v) for v in scene.shape)
