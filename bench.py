@@ -513,7 +513,7 @@ def run_sample_sharded(args, world, rank, dist, backend):
     """BASELINE config 4: one problem, the sample axis split over the ranks; a step = local forward + reverse, ONE in-place
     all-reduce of the contiguous [gradient | lik | kl] buffer, the replicated Adam update.  Strong scaling in S."""
     import torch
-    from vgpmp_amd import sharding
+    from vgpmp_amd import capi, sharding
     ps, spec, grid, scene, planner = build_problem(rank, args, world)
     planner.extra_flags |= args.flags
     rccl = world > 1 and backend == "nccl"
