@@ -34,6 +34,7 @@ struct CovArgs {
     // (Mz = 32): the MFMA sequence of paths_fwd_split_body on the float32 C it has just built
     int form_u, S;
     int rows_tpw;            // row tiles (kRowTile time points) per workgroup of the rows role
+    int rows_wave;           // batches (with ki_in_a): the rows role on one wave per 16 time points, in registers (cov_rows_wave_body)
     int ki_in_a;             // batches: (Kuu + jI)^-1 = Lk^-T Lk^-1 once per latent, by stage A (ws.Kinv), not by every row-tile workgroup of stage B
     const float* eps;        // [P,L,S,Mz]  (ws.epsT: the generator's second copy, a latent's rows contiguous)
     HyperArgs hy;
@@ -535,6 +536,7 @@ constexpr int kCovRoleC = 3, kCovFixedRoles = 4;
 // the tangent roles, the longest, to two of them with 8 roles (config-5 share: 946 -> 985 us per step).
 __device__ __forceinline__ int cov_role_rotated(int b, int roles) { return (b + b / roles) % roles; }
 __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int p, int tid, int nt);
+__device__ void cov_rows_wave_body(const CovArgs& a, int wg_tile, int l, int p, int tid);
 
 template <bool TANGENTS>
 __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int role, int l, int p) {
@@ -563,7 +565,8 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
                 dst[pl] = src[pl];
             }
         }
-        cov_rows_body(a, sm, role - kCovFixedRoles, l, p, tid, nt);
+        if (a.rows_wave) cov_rows_wave_body(a, role - kCovFixedRoles, l, p, tid);
+        else cov_rows_body(a, sm, role - kCovFixedRoles, l, p, tid, nt);
         return;
     }
     const bool crole = role == kCovRoleC, form_u = crole && a.form_u != 0;
@@ -834,7 +837,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
 }
 
 template <bool TANGENTS>
-__global__ __launch_bounds__(kCovThreads, 2) void cov_b_kernel(CovArgs a) {
+__global__ __launch_bounds__(kCovThreads, 4) void cov_b_kernel(CovArgs a) {
     extern __shared__ double sm[];
     cov_b_body<TANGENTS>(a, sm, (int)((blockIdx.x + blockIdx.y + gridDim.y * blockIdx.z) % gridDim.x), blockIdx.y, blockIdx.z);
 }
@@ -1085,6 +1088,107 @@ __device__ void cov_rows_padded_body(const CovArgs& a, double* sm, int wg_tile, 
         __syncthreads();                   // (the next pass writes kf2 / df2 / ar2 / yr2)
     }
     VG_T(tile == 0 && l == 0 && p == 0, 231);
+}
+
+// The rows role of the batch schedules (16 < Mz <= 32, stage A has left (Kuu + jI)^-1 in ws.Kinv): ONE wave per 16 time points,
+// everything in registers -- no LDS, no barriers; a workgroup is four independent waves (64 time points).  The products are formed
+// TRANSPOSED, A^T = Ki Kfu^T etc. (Ki and dKuu/dell are symmetric to the bit): for v_mfma_f64_16x16x4_f64 the accumulator of one
+// product -- D[row = (l >> 4) + 4 q][col = l & 15] -- IS the B operand -- B[k = l >> 4][j = l & 15], step q + 4 rt -- of the next,
+// so the chain  A^T -> y^T = dKfu^T - dKuu A^T -> A_ell^T = Ki y^T,  A_var^T = j / var Ki A^T  needs no re-layout.  Lane (j, kk)
+// evaluates the kernel at time point n0 + j against the 8 inducing points 4 s + kk: both the B operand of the first product and
+// the accumulator layout of dKfu^T.  Same products in the same k order as cov_rows_body: the same bits.
+// (The LDS form keeps four waves busy for ~5 us per 16 time points, most of it at its four barriers; this one wave for ~6.)
+__device__ void cov_rows_wave_body(const CovArgs& a, int wg_tile, int l, int p, int tid) {
+    const int M = a.M, Mz = M + 2, N = a.N, L = a.L, D = a.D;
+    const int wave = tid >> 6, lane = tid & 63, j = lane & 15, kk = lane >> 4;
+    const int n0 = (wg_tile * 4 + wave) * 16;
+    if (n0 >= N) return;
+    const size_t pl = (size_t)p * L + l;
+    const double ell = a.ws.ell[pl], var = a.ws.var[pl];
+    const double* Kig = a.ws.Kinv + pl * Mz * Mz;
+    const double* Kdg = a.ws.Kd_ell + pl * Mz * Mz;
+    // A operands of the three kinds of product: X[16 rt + j][4 s + kk], zero beyond Mz (loads first, selects afterwards)
+    double kiA[2][8], kdA[2][8];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int r = 16 * rt + j, c = 4 * s + kk;
+            const size_t o = (size_t)min(r, Mz - 1) * Mz + min(c, Mz - 1);
+            kiA[rt][s] = Kig[o];
+            kdA[rt][s] = Kdg[o];
+        }
+    const int n = n0 + j;
+    const double xn = a.X[(size_t)min(n, N - 1) * D + l];
+    double zm[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) zm[s] = a.Zy[(size_t)p * a.zy_stride + (size_t)min(4 * s + kk, Mz - 1) * D + l];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const bool in = 16 * rt + j < Mz && 4 * s + kk < Mz;
+            kiA[rt][s] = in ? kiA[rt][s] : 0.0;
+            kdA[rt][s] = in && a.want_dell ? kdA[rt][s] : 0.0;
+        }
+    // Kfu^T and dKfu^T / dell at (inducing point 4 s + kk, time point n): the arithmetic of cov_rows_body
+    double kf[8], dkf[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        double k = 0.0, dk = 0.0;
+        if (4 * s + kk < Mz && n < N) {
+            double rr = fabs(xn - zm[s]) / ell;
+            double ex = exp(-kSqrt5 * rr);
+            k = var * (1.0 + kSqrt5 * rr + (5.0 / 3.0) * rr * rr) * ex;
+            dk = var * ex * (5.0 * rr * rr / (3.0 * ell)) * (1.0 + kSqrt5 * rr);
+        }
+        kf[s] = k; dkf[s] = dk;
+    }
+    const vg_f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+    vg_f64x4 at[2], y[2], aell[2], avar[2];
+    // A^T = Ki Kfu^T: element q of at[rt] is A[n][m], m = 16 rt + 4 q + kk = 4 (4 rt + q) + kk -- the B operand of step 4 rt + q
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        vg_f64x4 acc = zero;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kiA[rt][s], kf[s], acc, 0, 0, 0);
+        at[rt] = acc;
+    }
+    // y^T = dKfu^T - dKuu/dell A^T
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        vg_f64x4 acc = zero;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kdA[rt][s], at[s >> 2][s & 3], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y[rt][q] = dkf[4 * rt + q] - acc[q];
+    }
+    // A_ell^T = Ki y^T,  A_var^T = jitter / var Ki A^T
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        vg_f64x4 acc = zero, acv = zero;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (a.want_dell) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kiA[rt][s], y[s >> 2][s & 3], acc, 0, 0, 0);
+            acv = __builtin_amdgcn_mfma_f64_16x16x4f64(kiA[rt][s], at[s >> 2][s & 3], acv, 0, 0, 0);
+        }
+        aell[rt] = acc; avar[rt] = acv;
+    }
+    float4* A4 = reinterpret_cast<float4*>(a.ws.A4) + pl * N * Mz;
+    float* AT = a.ws.AT + pl * N * Mz;
+    if (n < N) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = 16 * rt + 4 * q + kk;
+                if (m < Mz) {
+                    const float av0 = (float)at[rt][q];
+                    vg_stream(A4 + (size_t)n * Mz + m, make_float4(av0, (float)aell[rt][q], (float)(a.jitter / var * avar[rt][q]), 0.f));
+                    vg_stream(AT + (size_t)m * N + n, av0);
+                }
+            }
+    }
 }
 
 }  // namespace

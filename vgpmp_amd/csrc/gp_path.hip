@@ -470,6 +470,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     // batches (stage A and stage B are launches of their own, stage A off the critical path behind the generator roles): the
     // inverse once per latent in stage A (its two-panel form) instead of in every row-tile workgroup of stage B
     ca.ki_in_a = (!fused && ca.elim_wave && Mz > 16 && Mz <= 32) ? 1 : 0;
+    ca.rows_wave = ca.ki_in_a;      // ... and the rows role of stage B on one wave per 16 time points, in registers
     ca.tick = (fused && do_adam) ? ctr : nullptr;
     ca.lr = lr; ca.lr_dev = ws->lr_t;
     ca.rows_tpw = 1; ca.prologue = 0; ca.commit = 0; ca.keep_prev = (fused && backward) ? 1 : 0;
@@ -674,7 +675,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const bool fused_small = !fused && SK == 4 && S <= 32 && (B % 64) == 0 && !(what & VGPMP_GEMM_DIRECT);
     if (!fused && (rc = set_dyn_lds((const void*)mid_cov_a_rng_kernel, lds_cov_a))) return rc;      // (the large-batch schedule merges its small launches with these two as well)
     if ((rc = set_dyn_lds((const void*)mid_hyper_final_kernel, lds_fin))) return rc;
-    const dim3 cov_b_grid(kCovFixedRoles + (row_tiles + rows_tpw - 1) / rows_tpw, L, P);
+    const dim3 cov_b_grid(kCovFixedRoles + (ca.rows_wave ? (N + 63) / 64 : (row_tiles + rows_tpw - 1) / rows_tpw), L, P);
     // eps / eps' also as [P,L,S,Mz] wherever a consumer stages them per latent (the register-resident path kernels, stage B's U
     // role): drawn by rng_eps_t_body then, kEpsRows rows of (s, k) per workgroup
     // (only for noise drawn here: the caller's own eps -- generate = false -- come in the interface's layout alone)
