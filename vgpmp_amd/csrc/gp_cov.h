@@ -538,7 +538,7 @@ __device__ __forceinline__ int cov_role_rotated(int b, int roles) { return (b + 
 __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int p, int tid, int nt);
 __device__ void cov_rows_wave_body(const CovArgs& a, int wg_tile, int l, int p, int tid);
 
-template <bool TANGENTS>
+template <bool TANGENTS, bool WAVE = false>      // WAVE: the launch may use the one-wave register form of the rows role (cov_b_kernel; kept out of the stage-2 kernels' register budget)
 __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int role, int l, int p) {
     __shared__ double red[kCovThreads / VG_WAVE];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -565,7 +565,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
                 dst[pl] = src[pl];
             }
         }
-        if (a.rows_wave) cov_rows_wave_body(a, role - kCovFixedRoles, l, p, tid);
+        if (WAVE && a.rows_wave) cov_rows_wave_body(a, role - kCovFixedRoles, l, p, tid);
         else cov_rows_body(a, sm, role - kCovFixedRoles, l, p, tid, nt);
         return;
     }
@@ -839,7 +839,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
 template <bool TANGENTS>
 __global__ __launch_bounds__(kCovThreads, 4) void cov_b_kernel(CovArgs a) {
     extern __shared__ double sm[];
-    cov_b_body<TANGENTS>(a, sm, (int)((blockIdx.x + blockIdx.y + gridDim.y * blockIdx.z) % gridDim.x), blockIdx.y, blockIdx.z);
+    cov_b_body<TANGENTS, true>(a, sm, (int)((blockIdx.x + blockIdx.y + gridDim.y * blockIdx.z) % gridDim.x), blockIdx.y, blockIdx.z);
 }
 
 // A = Kfu (Kuu + jI)^-1 and its tangents for a tile of kRowTile time points:
