@@ -839,7 +839,15 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
 template <bool TANGENTS>
 __global__ __launch_bounds__(kCovThreads, 4) void cov_b_kernel(CovArgs a) {
     extern __shared__ double sm[];
-    cov_b_body<TANGENTS, true>(a, sm, (int)((blockIdx.x + blockIdx.y + gridDim.y * blockIdx.z) % gridDim.x), blockIdx.y, blockIdx.z);
+    // Workgroups are dispatched in linear order (x fastest): ROLE-major here, the long roles first -- d/dvar, d/dell, KL, q_sqrt,
+    // then the row tiles -- so that what is still running when the queue is empty is a 6 us rows workgroup, not a 16 us tangent
+    // (role-minor order left every latent's tangents of the last round as the launch's tail).  Consecutive workgroups are
+    // different latents of one role: the roles spread evenly over the XCDs whatever their count.
+    const unsigned roles = gridDim.x, latents = gridDim.y * gridDim.z;
+    const unsigned lin = blockIdx.x + roles * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned ord = lin / latents, lat = lin - ord * latents;
+    const int role = ord == 0 ? 2 : ord == 1 ? 1 : ord == 2 ? 0 : (int)ord;      // (3 = q_sqrt, 4.. = row tiles)
+    cov_b_body<TANGENTS, true>(a, sm, role, (int)(lat % gridDim.y), (int)(lat / gridDim.y));
 }
 
 // A = Kfu (Kuu + jI)^-1 and its tangents for a tile of kRowTile time points:
