@@ -242,6 +242,8 @@ typedef struct vgpmp_outputs {
 #define VGPMP_NOISE_AHEAD 32768  /* few problems: the call's last step also draws the NEXT step's omega, beta, w (beside its path assembly / reverse pass) */
 #define VGPMP_NOISE_READY 65536  /* ... and this call's first step finds its own already drawn (a previous call ran with NOISE_AHEAD at step - 1) */
 #define VGPMP_BWD_ONE_CHUNK 16384 /* measurement: reverse path pass with one sample chunk per workgroup (the values do not depend on it) */
+#define VGPMP_COV_LDS_ROWS 1024 /* measurement: batches keep stage B's rows role in its LDS form (four waves per 16 time points, the inverse
+                                 * formed by every row-tile workgroup) instead of one wave per 16 time points in registers: the same bits */
 #define VGPMP_ELIM_BLOCK 128    /* measurement: Kuu elimination by the whole workgroup through LDS instead of one wave in registers */
 
 /* ---- set-up -------------------------------------------------------------------------------- */

@@ -862,6 +862,32 @@ def test_f16_split_prior_kernel_against_float64_and_the_float32_kernels(robot, S
     assert float((sp.q_mu - fp.q_mu).abs().max()) < 3 * sp.lr * 2e-2
 
 
+@pytest.mark.parametrize("robot,S,M,N,P", [("franka", 7, 24, 70, 12), ("franka", 64, 30, 100, 6), ("ur10", 32, 18, 70, 13), ("franka", 20, 15, 37, 11)])
+def test_rows_role_in_registers_gives_the_bits_of_its_lds_form(robot, S, M, N, P):
+    """Batches run stage B's rows role -- A = Kfu (Kuu + jI)^-1 and its two tangents -- on one wave per 16 time points with the
+    products chained in registers (csrc/gp_cov.h::cov_rows_wave_body), the inverse formed once per latent by stage A;
+    VGPMP_COV_LDS_ROWS keeps the LDS form (cov_rows_body / cov_rows_padded_body, four waves and four barriers per 16 time points, the
+    inverse by every row-tile workgroup).  Same products in the same order: A4 (three planes), Kinv and three optimisation steps
+    agree bit for bit.  Mz = 26, 32, 20, 17; N a multiple of 16 or not."""
+    from vgpmp_amd import capi, engine
+    ps = rb.load_problemset(robot, "industrial")
+    spec = rb.load_robot(robot, *ps.robot_pos_and_orn)
+    grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
+    sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
+    qs = np.array([ps.queries[i % len(ps.queries)] for i in range(P)])
+    assert P * spec.dof > (64 if S <= 32 else 32)             # a batch schedule
+    kw = dict(num_samples=S, num_inducing=M, num_data=N, num_bases=256, lengthscales=[2.0] * spec.dof, variance=0.2, seed=3)
+    a, b = engine.PlannerBatch(sc, qs, **kw), engine.PlannerBatch(sc, qs, **kw)
+    b.extra_flags |= capi.COV_LDS_ROWS
+    a.run_steps(3); b.run_steps(3)
+    torch.cuda.synchronize()
+    for v in ("A4", "Kinv", "C"):
+        assert torch.equal(a.view(v), b.view(v)), v
+    for x, y in ((a.q_mu, b.q_mu), (a.q_sqrt, b.q_sqrt), (a.raw_ell, b.raw_ell), (a.raw_var, b.raw_var)):
+        assert torch.equal(x, y)
+    assert float(a.view("A4").abs().max()) > 0.0
+
+
 @pytest.mark.parametrize("robot,S", [("ur10", 1024), ("franka", 512)])
 def test_many_sample_gemm_role_on_the_f16_pipe_against_its_float32_form(robot, S):
     """A few problems of 512 samples or more (BASELINE config 4 on one rank: 1024) run stage 2's GEMM role with f16-split

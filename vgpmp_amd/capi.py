@@ -20,6 +20,7 @@ TRAIN_SIGMA_OBS, TRAIN_ALPHA = 16, 32      # need Problem.lik
 TRAIN_INDUCING = 64                       # needs Problem.ind
 DO_FORWARD, DO_BACKWARD, DO_ADAM, GEN_NOISE, NO_FUSE = 1, 2, 4, 8, 16
 GEMM_DIRECT, NO_SPLIT, ELIM_BLOCK, LIK_LANES, LIK_LDS_STATE, COV_ONLY, NO_FUSE_PRIOR, PRIOR_F32, BWD_ONE_CHUNK = 32, 64, 128, 256, 512, 2048, 4096, 8192, 16384
+COV_LDS_ROWS = 1024
 NOISE_AHEAD, NOISE_READY = 32768, 65536
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvgpmp_hip.so"

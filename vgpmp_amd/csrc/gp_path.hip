@@ -469,7 +469,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     ca.elim_wave = (what & VGPMP_ELIM_BLOCK) ? 0 : 1;
     // batches (stage A and stage B are launches of their own, stage A off the critical path behind the generator roles): the
     // inverse once per latent in stage A (its two-panel form) instead of in every row-tile workgroup of stage B
-    ca.ki_in_a = (!fused && ca.elim_wave && Mz > 16 && Mz <= 32) ? 1 : 0;
+    ca.ki_in_a = (!fused && ca.elim_wave && Mz > 16 && Mz <= 32 && !(what & VGPMP_COV_LDS_ROWS)) ? 1 : 0;
     ca.rows_wave = ca.ki_in_a;      // ... and the rows role of stage B on one wave per 16 time points, in registers
     ca.tick = (fused && do_adam) ? ctr : nullptr;
     ca.lr = lr; ca.lr_dev = ws->lr_t;
