@@ -94,7 +94,7 @@ def test_committed_traffic_table_is_this_rounds():
     t3 = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_config3.json")))
     assert t5["collected_at"] == t["collected_at"] == t3["collected_at"]
     assert t5["loglik_paths_mask_kernel<2>"]["hbm_bytes_per_launch"] > 1e8          # 2 GiB table: hundreds of MB of sectors per launch
-    assert any(k.startswith("prior_fused_small_kernel") for k in t3)
+    assert any(k.startswith("prior_fused_small16_kernel") for k in t3)       # (the f16-split few-sample kernel)
     stamp = open(os.path.join(ROOT, "profiles", "r04", "final", "COLLECTED_AT")).read().strip()
     assert stamp == t["collected_at"]
 
