@@ -519,7 +519,7 @@ def _compare_with_oracle(pl, k, p, scene, X, Zy, y, noise, alpha, S, N, M, L, sp
     return fw
 
 
-@pytest.mark.parametrize("config", ["config1", "config3", "config4"])
+@pytest.mark.parametrize("config", ["config1", "config3", "config4", "ur10_few_samples", "wam_twenty_samples"])
 def test_baseline_configs_at_full_size_against_oracle(config):
     """BASELINE configs 1, 3 and 4 at their FULL (S, M, N, B = 1024) against the oracle, not only
     through size-independent properties.  config1 = WAM / industrial, S=50 M=10 N=70 (data/problemsets/wam.py:93-106);
@@ -531,6 +531,10 @@ def test_baseline_configs_at_full_size_against_oracle(config):
         "config1": ("wam", "industrial", 50, 10, 70, 1, {}),
         "config3": ("franka", "bookshelves", 7, 24, 70, 10, {}),
         "config4": ("ur10", "industrial", 128, 18, 70, 1, dict(samples_total=1024, sample_offset=256, kl_scale=0.0)),
+        # the few-sample prior kernel's 6-joint form / its two-tile form at the reference's other sample count (20), both as batches
+        # beyond the few-problem schedule (data/problemsets/ur10.py:71-84, wam.py:107-120)
+        "ur10_few_samples": ("ur10", "industrial", 7, 18, 70, 12, {}),
+        "wam_twenty_samples": ("wam", "bookshelves", 20, 15, 100, 10, {}),
     }[config]
     B = 1024
     ps = rb.load_problemset(robot, problem)
