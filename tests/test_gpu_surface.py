@@ -862,8 +862,9 @@ def test_f16_split_prior_kernel_against_float64_and_the_float32_kernels(robot, S
     assert float((sp.q_mu - fp.q_mu).abs().max()) < 3 * sp.lr * 2e-2
 
 
-@pytest.mark.parametrize("robot,S,M,N,P", [("franka", 7, 24, 70, 12), ("franka", 64, 30, 100, 6), ("ur10", 32, 18, 70, 13), ("franka", 20, 15, 37, 11)])
-def test_rows_role_in_registers_gives_the_bits_of_its_lds_form(robot, S, M, N, P):
+@pytest.mark.parametrize("robot,S,M,N,P,ell", [("franka", 7, 24, 70, 12, True), ("franka", 64, 30, 100, 6, True), ("ur10", 32, 18, 70, 13, True),
+                                               ("franka", 20, 15, 37, 11, True), ("franka", 7, 24, 70, 12, False)])
+def test_rows_role_in_registers_gives_the_bits_of_its_lds_form(robot, S, M, N, P, ell):
     """Batches run stage B's rows role -- A = Kfu (Kuu + jI)^-1 and its two tangents -- on one wave per 16 time points with the
     products chained in registers (csrc/gp_cov.h::cov_rows_wave_body), the inverse formed once per latent by stage A;
     VGPMP_COV_LDS_ROWS keeps the LDS form (cov_rows_body / cov_rows_padded_body, four waves and four barriers per 16 time points, the
@@ -876,7 +877,8 @@ def test_rows_role_in_registers_gives_the_bits_of_its_lds_form(robot, S, M, N, P
     sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
     qs = np.array([ps.queries[i % len(ps.queries)] for i in range(P)])
     assert P * spec.dof > (64 if S <= 32 else 32)             # a batch schedule
-    kw = dict(num_samples=S, num_inducing=M, num_data=N, num_bases=256, lengthscales=[2.0] * spec.dof, variance=0.2, seed=3)
+    kw = dict(num_samples=S, num_inducing=M, num_data=N, num_bases=256, lengthscales=[2.0] * spec.dof, variance=0.2, seed=3,
+              trainable=dict(q_mu=True, q_sqrt=True, lengthscales=ell, kernel_variance=True))      # (ell False: no d/d ell plane)
     a, b = engine.PlannerBatch(sc, qs, **kw), engine.PlannerBatch(sc, qs, **kw)
     b.extra_flags |= capi.COV_LDS_ROWS
     a.run_steps(3); b.run_steps(3)
