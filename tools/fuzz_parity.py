@@ -20,7 +20,7 @@ def main():
         N = int(rng.choice([7, 12, 20, 40, 50]))
         M = int(rng.choice([3, 6, 10, 14, 22, 30]))
         B = int(rng.choice([64, 128, 256]))
-        P = int(rng.choice([1, 1, 2, 3, 5, 6]))
+        P = int(rng.choice([1, 1, 2, 3, 5, 6, 10, 12, 16]))      # (10 up: beyond the few-problem schedule at any sample count)
         robot = str(rng.choice(["franka", "wam", "ur10"]))
         pb = small_problem(robot=robot, S=S, N=N, M=M, B=B, seed=int(rng.integers(1000)), n_grid=32)
         sc = engine.DeviceScene(pb["spec"], pb["grid"], pb["offset"])
