@@ -222,29 +222,16 @@ typedef struct vgpmp_outputs {
 #define VGPMP_TRAIN_ALPHA 32          /* needs problem->lik */
 #define VGPMP_TRAIN_INDUCING 64       /* needs problem->ind */
 
+/* `what`: what a call computes.  (Bits not listed here are measurement and test switches: include/vgpmp_debug.h.) */
 #define VGPMP_DO_FORWARD 1      /* ELBO forward only (models/vgpmp.py:265-289)               */
 #define VGPMP_DO_BACKWARD 2     /* + gradient of -ELBO (utils/miscellaneous.py:77-80)        */
 #define VGPMP_DO_ADAM 4         /* + Adam.apply_gradients (utils/miscellaneous.py:82)        */
 #define VGPMP_GEN_NOISE 8       /* draw the noise with the device Philox generator first     */
-#define VGPMP_NO_FUSE 16        /* measurement: one launch per kernel even for small batches  */
-#define VGPMP_GEMM_DIRECT 32    /* measurement: stage-2 GEMM role with operands straight from L2; with VGPMP_NO_FUSE also the prior
-                                 * draws of few samples as stored features + GEMM instead of the few-sample kernel (which forms
-                                 * its features inside the product, with other float32 roundings): the tests' bitwise reference */
-#define VGPMP_NO_SPLIT 64       /* measurement: reverse path pass on one workgroup per (chunk, latent) */
-#define VGPMP_LIK_LANES 256     /* measurement: the batch form of the likelihood (one lane per configuration) at any batch size */
-#define VGPMP_LIK_LDS_STATE 512 /* measurement: that form with the per-frame force / moment sums in LDS instead of registers */
 #define VGPMP_COV_ONLY 2048     /* with VGPMP_DO_FORWARD alone: only the covariance stage -- Kuu, its Cholesky, q_sqrt, A and the
                                  * per-latent prior KL (kullback_leiblers/prior_kl.py:16-35) land in the workspace (views "kl_l", "C",
                                  * "Kinv", "A4"); no noise, no likelihood: dev_robot and sdf may be NULL, the members of `noise` and `out` too */
-#define VGPMP_NO_FUSE_PRIOR 4096 /* measurement: large batches with the generator, the feature kernel and the tiled GEMM as three launches */
-#define VGPMP_PRIOR_F32 8192   /* measurement: large batches form the prior draws with float32 MFMAs (the round-2 kernel) instead of
-                                 * the f16-split products of prior_fused_split_kernel */
 #define VGPMP_NOISE_AHEAD 32768  /* few problems: the call's last step also draws the NEXT step's omega, beta, w (beside its path assembly / reverse pass) */
 #define VGPMP_NOISE_READY 65536  /* ... and this call's first step finds its own already drawn (a previous call ran with NOISE_AHEAD at step - 1) */
-#define VGPMP_BWD_ONE_CHUNK 16384 /* measurement: reverse path pass with one sample chunk per workgroup (the values do not depend on it) */
-#define VGPMP_COV_LDS_ROWS 1024 /* measurement: batches keep stage B's rows role in its LDS form (four waves per 16 time points, the inverse
-                                 * formed by every row-tile workgroup) instead of one wave per 16 time points in registers: the same bits */
-#define VGPMP_ELIM_BLOCK 128    /* measurement: Kuu elimination by the whole workgroup through LDS instead of one wave in registers */
 
 /* ---- set-up -------------------------------------------------------------------------------- */
 

@@ -248,12 +248,18 @@ def joint_sigmoid_inverse(robot: RobotTable, g: np.ndarray) -> np.ndarray:
     return np.log(x) - np.log1p(-x)
 
 
-def log_prob(scene: Scene, g: np.ndarray, want_grad: bool = False):
-    """likelihood.py:57-176.  g [..., D] joint angles -> logp [...] (and dlogp/dg)."""
+def log_prob(scene: Scene, g: np.ndarray, want_grad: bool = False, lookup_pos: Optional[np.ndarray] = None):
+    """likelihood.py:57-176.  g [..., D] joint angles -> logp [...] (and dlogp/dg).
+
+    lookup_pos [..., P, 3] (tests only): sphere centres at which the VOXELS are looked up instead of this function's own float64
+    centres.  The nearest-voxel field is piecewise constant, so a float32 implementation whose centre lies within rounding of a
+    cell boundary may read the neighbouring voxel; handing its centres in here makes both sides read the same voxels, and the
+    comparison then measures arithmetic, not boundary luck.  Everything else (hinge, sums, the FK Jacobian of the reverse pass)
+    stays this function's own float64."""
     rb = scene.robot
     frames = forward_kinematics(rb, g)
     pos = sphere_positions(rb, g, frames)
-    rel = pos - scene.offset
+    rel = (pos if lookup_pos is None else np.asarray(lookup_pos, dtype=np.float64)) - scene.offset
     dist = sdf_distance(scene.sdf, rel) - rb.radii
     cost = np.maximum(scene.epsilon - dist, 0.0)                   # likelihood.py:131-143
     logp = -0.5 * np.sum(cost * cost / scene.sigma_obs, axis=-1)   # likelihood.py:99
@@ -404,8 +410,9 @@ def rff_features(noise: Noise, pts: np.ndarray, ell, var, want_dell=False):
 
 
 def elbo_forward(p: Params, scene: Scene, X, Zy, y, noise: Noise, alpha: float,
-                 jitter=JITTER, want_dell=True) -> Dict[str, np.ndarray]:
-    """models/vgpmp.py:265-289 with injected randomness.  y [2, D] start/goal joints."""
+                 jitter=JITTER, want_dell=True, lookup_pos: Optional[np.ndarray] = None) -> Dict[str, np.ndarray]:
+    """models/vgpmp.py:265-289 with injected randomness.  y [2, D] start/goal joints.
+    lookup_pos [S, N, P, 3]: see log_prob (tests: the voxels a float32 implementation read)."""
     rb = scene.robot
     y_u = joint_sigmoid_inverse(rb, y)                                 # vgpmp.py:75-76
     cv = cov_forward(p, X, Zy, y_u, jitter)
@@ -423,7 +430,7 @@ def elbo_forward(p: Params, scene: Scene, X, Zy, y, noise: Noise, alpha: float,
     f = F0[:, :, :N] + np.einsum('lnm,slm->sln', cv['A'], R)           # [S, L, N]
     fT = f.transpose(0, 2, 1)                                          # [S, N, L]
     g = joint_sigmoid(rb, fT)
-    logp, dlogp_dg = log_prob(scene, g, want_grad=True)                # [S, N], [S, N, D]
+    logp, dlogp_dg = log_prob(scene, g, want_grad=True, lookup_pos=lookup_pos)   # [S, N], [S, N, D]
     lik = alpha * logp.mean(0).sum()
     elbo = lik - cv['kl']
     return dict(cv=cv, y_u=y_u, F0=F0, H=H, R=R, f=f, g=g, logp=logp, dlogp_dg=dlogp_dg,

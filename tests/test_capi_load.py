@@ -21,6 +21,31 @@ def test_library_builds_loads_and_exports_header_symbols():
     for name in declared:
         assert hasattr(handle, name), name
     assert b"gfx950" in handle.vgpmp_version()
+    # test hooks and measurement switches live in their own header, outside the binding surface
+    dbg = (ROOT / "include" / "vgpmp_debug.h").read_text()
+    declared_dbg = set(re.findall(r"\b(vgpmp_[a-z_]+)\s*\(", dbg))
+    assert declared_dbg == set(capi.DEBUG_EXPORTS), declared_dbg ^ set(capi.DEBUG_EXPORTS)
+    for name in declared_dbg:
+        assert hasattr(handle, name), name
+
+
+def test_public_what_flags_are_the_seven_a_binder_needs():
+    """include/vgpmp.h advertises what a call computes (VGPMP_DO_*, GEN_NOISE, COV_ONLY, NOISE_AHEAD / _READY); every
+    measurement switch sits in include/vgpmp_debug.h on other bits, and capi.py carries the same values."""
+    def flags(text):
+        return {m.group(1): int(m.group(2)) for m in re.finditer(r"#define VGPMP_([A-Z0-9_]+) (\d+)\b", text)}
+    pub = flags((ROOT / "include" / "vgpmp.h").read_text())
+    what_pub = {k: v for k, v in pub.items() if k.startswith(("DO_", "GEN_", "COV_ONLY", "NOISE_"))}
+    assert sorted(what_pub) == ["COV_ONLY", "DO_ADAM", "DO_BACKWARD", "DO_FORWARD", "GEN_NOISE", "NOISE_AHEAD", "NOISE_READY"]
+    for name in ("NO_FUSE", "GEMM_DIRECT", "NO_SPLIT", "ELIM_BLOCK", "LIK_LANES", "LIK_LDS_STATE", "COV_LDS_ROWS", "NO_FUSE_PRIOR",
+                 "PRIOR_F32", "BWD_ONE_CHUNK"):
+        assert name not in pub, name
+    dbg = flags((ROOT / "include" / "vgpmp_debug.h").read_text())
+    assert len(dbg) == 10 and not set(dbg.values()) & set(what_pub.values())
+    bits = list(dbg.values()) + list(what_pub.values())
+    assert len(set(bits)) == len(bits) and all(b & (b - 1) == 0 for b in bits)
+    for name, value in {**dbg, **what_pub}.items():
+        assert getattr(capi, name) == value, name
 
 
 def test_struct_sizes_match_header_layout():
@@ -59,6 +84,24 @@ def test_argument_errors_without_gpu():
     assert handle.vgpmp_sdf_mask_words(130, 154, 80, 2, ctypes.byref(w)) == 0 and w.value == ((33 * 39 * 20 + 31) // 32 + 3) // 4 * 4
     assert handle.vgpmp_sdf_mask_words(8, 8, 8, 1, ctypes.byref(w)) == -2
     assert handle.vgpmp_sdf_free_mask(None, None) == -1
+    # mask fields are validated wherever a voxel table is taken (check_sdf), not only by the mask builder
+    sdf = capi.Sdf()
+    sdf.table, sdf.nx, sdf.ny, sdf.nz, sdf.delta, sdf.layout = 1 << 20, 100, 100, 100, 0.01, capi.SDF_BRICK4
+    sdf.free_mask, sdf.mask_shift, sdf.mask_count, sdf.mask_words = 1 << 21, 2, 2, 492
+    sdf.mask_clearance[0], sdf.mask_clearance[1] = 0.08, 0.10
+    call = lambda: handle.vgpmp_sdf_query(ctypes.byref(sdf), None, 0, None, None, None, None)
+    assert call() == 0
+    for field, bad, rc in (("mask_words", 488, -1), ("mask_shift", 1, -2), ("mask_shift", 13, -2), ("mask_count", 0, -2),
+                           ("mask_count", 5, -2), ("layout", capi.SDF_LINEAR, -1)):
+        keep = getattr(sdf, field)
+        setattr(sdf, field, bad)
+        assert call() == rc, (field, bad)
+        setattr(sdf, field, keep)
+    sdf.mask_clearance[1] = 0.05          # descending clearances
+    assert call() == -1
+    # the schedule log of a thread that has run nothing is empty; a short buffer is respected
+    assert handle.vgpmp_debug_last_schedule(None, 0) == 1
+    assert handle.vgpmp_debug_sphere_centres(None, None, 1, 1, 7, 1, 0, None, None) == -1
 
 
 def test_product_path_fails_loudly_without_library(monkeypatch, tmp_path):

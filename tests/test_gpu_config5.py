@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import vgpmp_oracle as orc
-from helpers import oracle_scene, synthetic_problem
+from helpers import TOL_GRAD, TOL_LIK, TOL_LOGP, assert_grads, device_centres, flipped_share, oracle_scene, synthetic_problem
 from vgpmp_amd import robots as rb
 from vgpmp_amd import scenes
 
@@ -117,22 +117,19 @@ def test_synthetic14_elbo_forward_backward_against_oracle(S, N, M, B, P):
     check = range(P) if S * N <= 2000 else (0, P - 1)      # the oracle takes seconds per full-size problem
     for k in check:
         p, y = pb["params"][k], pb["ys"][k]
-        fw = orc.elbo_forward(p, pb["scene"], pb["X"], pb["Zy"], y, nz[k], pb["alpha"])
+        # the oracle looks its voxels up at the device's own float32 sphere centres (include/vgpmp_debug.h): fixed tolerances
+        fw = orc.elbo_forward(p, pb["scene"], pb["X"], pb["Zy"], y, nz[k], pb["alpha"], lookup_pos=device_centres(pl, k))
         og, _ = orc.elbo_backward(p, pb["scene"], pb["X"], pb["Zy"], nz[k], pb["alpha"], fw)
         np.testing.assert_allclose(pl.f[k].cpu().numpy(), fw["f"], rtol=0, atol=1e-4)
         assert (fw["logp"] < 0).any()
-        ok = np.isclose(pl.logp[k].cpu().numpy(), fw["logp"], rtol=2e-3, atol=1e-4)
-        assert ok.mean() >= 0.95, f"logp agreement {ok.mean():.3f}"
-        flips = 1.0 - ok.mean()
+        logp = pl.logp[k].cpu().numpy()
+        np.testing.assert_allclose(logp, fw["logp"], rtol=0, atol=TOL_LOGP * np.abs(fw["logp"]).max())
         np.testing.assert_allclose(float(pl.kl[k]), fw["cv"]["kl"], rtol=1e-9)
-        np.testing.assert_allclose(float(pl.lik[k]), fw["lik"], rtol=50 * flips + 2e-4)
-        for got, name in zip(grads, ("q_mu", "q_sqrt", "raw_ell", "raw_var")):
-            want = getattr(og, name)
-            got = got[k].cpu().numpy()
-            if name == "q_mu":
-                got = got.T
-            scale = np.abs(want).max() + 1e-12
-            assert np.abs(got - want).max() / scale < 50 * flips + 3e-3, (name, k, np.abs(got - want).max(), scale, flips)
+        np.testing.assert_allclose(float(pl.lik[k]), fw["lik"], rtol=TOL_LIK)
+        tag = f"synthetic14[S={S},N={N},P={P},k={k}]"
+        assert_grads(tag, grads, og, k=k)
+        if k == 0:
+            flipped_share(tag, logp, orc.elbo_forward(p, pb["scene"], pb["X"], pb["Zy"], y, nz[k], pb["alpha"], want_dell=False))
 
 
 @pytest.mark.parametrize("S,N,P", [(8, 12, 1), (128, 100, 6)])
@@ -192,6 +189,46 @@ def test_free_space_masks_are_the_block_minima_against_the_clearances():
             bits = ((got[k][:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).astype(bool).reshape(-1)
             assert np.array_equal(bits, want), (shift, k)
             assert 0 < want.sum() < bmin.size
+
+
+def test_mask_builder_stays_inside_its_words_on_ragged_word_counts():
+    """mask_words is a multiple of 4 words, the builder's grid of 8 (256 threads): with mask_words % 8 == 4 the last
+    workgroup's upper waves lie beyond the mask and must write nothing -- neither into the first words of the next mask nor
+    past the caller's buffer (an exact-size C allocation).  Sentinel-filled buffer, two extents with that remainder."""
+    import ctypes as C
+    eng = _engine()
+    capi = eng.capi
+    rng = np.random.default_rng(5)
+    for shape in ((16, 16, 8), (100, 100, 100)):
+        g = np.stack(np.meshgrid(*[0.02 * np.arange(n) for n in shape], indexing="ij"), axis=-1)
+        data = np.linalg.norm(g - 0.01 * np.asarray(shape), axis=-1) - 0.35 * 0.02 * min(shape) + rng.normal(0.0, 0.002, shape)
+        spec = rb.synthetic_arm(14)
+        spec.sphere_radii = np.asarray([0.03, 0.05, 0.08] * 15, dtype=np.float64)
+        sc = eng.DeviceScene(spec, (data, np.zeros(3), 0.02), (0, 0, 0), free_space_mask=True, mask_budget_bytes=1 << 20)
+        words = int(sc.sdf.mask_words)
+        assert sc.mask_shift == 2 and words % 8 == 4
+        want = sc.free_mask.cpu().numpy().copy().reshape(3, words)
+        tail = 64
+        buf = torch.full((3 * words + tail,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+        full = capi.Sdf.from_buffer_copy(sc.sdf)
+        full.brick_min, full.free_mask = capi.ptr(sc.brick_min), capi.ptr(buf)
+        for _ in range(3):          # the lost bits of the unguarded form varied from run to run
+            buf.fill_(0x5A5A5A5A)
+            capi.check(sc.lib.vgpmp_sdf_free_mask(C.byref(full), sc._stream()), "vgpmp_sdf_free_mask")
+            got = buf.cpu().numpy()
+            assert np.all(got[3 * words:] == 0x5A5A5A5A), "wrote past the last mask"
+            assert np.array_equal(got[:3 * words].reshape(3, words), want)
+        # ... and the masks are the block minima (first words of masks 1, 2 included)
+        e = 4
+        nb = [(n + e - 1) // e for n in shape]
+        pad = np.full([e * b for b in nb], np.inf)
+        pad[:shape[0], :shape[1], :shape[2]] = data.astype(np.float32)
+        bmin = pad.reshape(nb[0], e, nb[1], e, nb[2], e).min(axis=(1, 3, 5)).reshape(-1)
+        for k, clr in enumerate(sc.mask_clearances):
+            ref = np.zeros(words * 32, dtype=bool)
+            ref[:bmin.size] = bmin >= np.float32(clr)
+            bits = ((want[k].view(np.uint32)[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).astype(bool).reshape(-1)
+            assert np.array_equal(bits, ref), (shape, k)
 
 
 def test_masks_with_several_radius_classes_are_bitwise_neutral():
@@ -290,15 +327,15 @@ def test_batch_form_of_the_likelihood_against_oracle_on_every_robot_shape(robot)
         torch.cuda.synchronize()
         outs[name] = [pl.logp.clone(), pl.view("G"), pl.lik.clone()] + [g.clone() for g in grads]
     for k in range(2):
-        fw = orc.elbo_forward(pb["params"][k], pb["scene"], pb["X"], pb["Zy"], pb["ys"][k], nz[k], pb["alpha"])
+        # (`pl` is the last planner of the loop above: same inputs, same one-lane form, hence the same sphere centres)
+        fw = orc.elbo_forward(pb["params"][k], pb["scene"], pb["X"], pb["Zy"], pb["ys"][k], nz[k], pb["alpha"],
+                              lookup_pos=device_centres(pl, k))
         og, Gw = orc.elbo_backward(pb["params"][k], pb["scene"], pb["X"], pb["Zy"], nz[k], pb["alpha"], fw)
         assert (fw["logp"] < 0).any()
-        ok = np.isclose(outs["regs"][0][k].cpu().numpy(), fw["logp"], rtol=2e-3, atol=1e-4)
-        assert ok.mean() >= 0.95, ok.mean()
-        flips = 1.0 - ok.mean()
-        np.testing.assert_allclose(float(outs["regs"][2][k]), fw["lik"], rtol=50 * flips + 2e-4)
+        np.testing.assert_allclose(outs["regs"][0][k].cpu().numpy(), fw["logp"], rtol=0, atol=TOL_LOGP * np.abs(fw["logp"]).max())
+        np.testing.assert_allclose(float(outs["regs"][2][k]), fw["lik"], rtol=TOL_LIK)
         got = outs["regs"][3][k].cpu().numpy().T
-        assert np.abs(got - og.q_mu).max() <= (50 * flips + 3e-3) * np.abs(og.q_mu).max()
+        assert np.abs(got - og.q_mu).max() <= TOL_GRAD * np.abs(og.q_mu).max()
     # Up to 8 joints the register form takes a joint's gradient as (its expression over the totals) - (the same over the frames
     # before it), the LDS form as the expression over (totals - per-frame sums): the same number up to float32 rounding of
     # the difference -- where nothing downstream of a joint collides the former leaves a residue of ~1e-7 of the largest

@@ -1,10 +1,12 @@
 """Parity of the HIP path (through the C ABI) with the float64 oracle.  Run with -m gpu on MI355X.
 
-Tolerances: integer voxel indices bit-exact on identical float64 inputs; float32 quantities within
-the tolerance written at each assertion.  The SDF is nearest-voxel (piecewise constant), so an
-end-to-end float32 path may land a handful of sphere queries in the neighbouring voxel; tests that
-go through float32 positions therefore bound the FRACTION of affected (sample, time) pairs instead
-of demanding every element.
+Tolerances: integer voxel indices bit-exact on identical inputs; float32 quantities within the tolerance written at
+each assertion.  The SDF is nearest-voxel (piecewise constant): a float32 sphere centre within rounding of a cell
+boundary may read the neighbouring voxel of what a float64 chain reads.  The end-to-end comparisons therefore hand the
+oracle the device's OWN float32 sphere centres for the voxel lookup (include/vgpmp_debug.h, vgpmp_debug_sphere_centres;
+oracle `lookup_pos`): both sides read the same voxels, every (sample, time) pair must agree, and the gradient tolerances are
+fixed numbers -- no allowance that grows with the number of disagreeing pairs.  How many pairs a float64 chain WOULD
+resolve differently is measured, printed and bounded separately (`_flipped_share`).
 """
 from pathlib import Path
 
@@ -13,7 +15,8 @@ import pytest
 import torch
 
 from oracle import vgpmp_oracle as orc
-from helpers import oracle_robot, oracle_scene, small_problem
+from helpers import (MAX_FLIPPED, TOL_GRAD, TOL_LIK, TOL_LOGP, assert_grads as _assert_grads, device_centres as _device_centres,
+                     flipped_share as _flipped_share, oracle_robot, oracle_scene, small_problem)
 from vgpmp_amd import robots as rb
 from vgpmp_amd import scenes
 
@@ -135,7 +138,8 @@ def test_elbo_forward_backward_against_oracle(robot, S, N, M, B, split_k):
     noise = _noise32(pb["noise"])
     _inject(pl, noise)
     loss, grads = pl.loss_and_grad(generate=False)
-    fw = orc.elbo_forward(pb["params"], pb["scene"], pb["X"], pb["Zy"], pb["y"], noise, pb["alpha"])
+    # the oracle looks its voxels up at the device's own float32 sphere centres: no query falls into a neighbouring cell
+    fw = orc.elbo_forward(pb["params"], pb["scene"], pb["X"], pb["Zy"], pb["y"], noise, pb["alpha"], lookup_pos=_device_centres(pl, 0))
     og, G = orc.elbo_backward(pb["params"], pb["scene"], pb["X"], pb["Zy"], noise, pb["alpha"], fw)
     L, Mz, J = pb["spec"].dof, M + 2, N + M + 2
     cv = fw["cv"]
@@ -153,33 +157,18 @@ def test_elbo_forward_backward_against_oracle(robot, S, N, M, B, split_k):
     np.testing.assert_allclose(pl.f[0].cpu().numpy(), fw["f"], rtol=0, atol=1e-4)
     logp = pl.logp[0].cpu().numpy()
     assert (fw["logp"] < 0).any()
-    ok = np.isclose(logp, fw["logp"], rtol=2e-3, atol=1e-4)
-    assert ok.mean() >= 0.97, f"logp agreement {ok.mean():.3f}"
-    if not ok.all():
-        # a few float32 sphere centres fell into the neighbouring voxel: the sums still agree to the share of
-        # configurations affected
-        flips = 1.0 - ok.mean()
-        np.testing.assert_allclose(float(pl.kl[0]), cv["kl"], rtol=1e-9)
-        np.testing.assert_allclose(float(pl.lik[0]), fw["lik"], rtol=50 * flips + 2e-4)
-        for got, name in zip(grads, ("q_mu", "q_sqrt", "raw_ell", "raw_var")):
-            want = getattr(og, name)
-            got = got[0].cpu().numpy()
-            if name == "q_mu":
-                got = got.T
-            scale = np.abs(want).max() + 1e-12
-            assert np.abs(got - want).max() / scale < 50 * flips + 3e-3, (name, np.abs(got - want).max(), scale, flips)
-    if ok.all():
-        # no voxel flips: the end-to-end numbers must agree to float32 accuracy
-        np.testing.assert_allclose(float(pl.kl[0]), cv["kl"], rtol=1e-9)
-        np.testing.assert_allclose(float(pl.lik[0]), fw["lik"], rtol=2e-4)
-        np.testing.assert_allclose(float(loss[0]), -fw["elbo"], rtol=2e-4)
-        for got, name in zip(grads, ("q_mu", "q_sqrt", "raw_ell", "raw_var")):
-            want = getattr(og, name)
-            got = got[0].cpu().numpy()
-            if name == "q_mu":
-                got = got.T
-            scale = np.abs(want).max() + 1e-12
-            assert np.abs(got - want).max() / scale < 3e-3, (name, np.abs(got - want).max(), scale)
+    tag = f"elbo[{robot},S={S},N={N},M={M}]"
+    top = np.abs(fw["logp"]).max()
+    print(f"PARITY {tag} logp={np.abs(logp - fw['logp']).max() / top:.2e} lik={abs(float(pl.lik[0]) - fw['lik']) / abs(fw['lik']):.2e}")
+    # same voxels on both sides: EVERY (sample, time) pair agrees to float32 accuracy, and so do the sums and the gradients
+    np.testing.assert_allclose(logp, fw["logp"], rtol=0, atol=TOL_LOGP * top)
+    np.testing.assert_allclose(float(pl.kl[0]), cv["kl"], rtol=1e-9)
+    np.testing.assert_allclose(float(pl.lik[0]), fw["lik"], rtol=TOL_LIK)
+    np.testing.assert_allclose(float(loss[0]), -fw["elbo"], rtol=2e-5)
+    _assert_grads(tag, grads, og)
+    # ... and how far a float64 chain's own voxels are from that: a measured, bounded share of the pairs
+    fw64 = orc.elbo_forward(pb["params"], pb["scene"], pb["X"], pb["Zy"], pb["y"], noise, pb["alpha"], want_dell=False)
+    _flipped_share(tag, logp, fw64)
 
 
 def test_kl_only_gradient_is_float64_exact():
@@ -409,21 +398,20 @@ def test_inducing_location_gradient_against_oracle(robot, S, N, M, B, P):
     for k in range(P):
         Zy = orc.zy_from_raw(raws[k])
         np.testing.assert_allclose(pl.Zy_all[k].cpu().numpy(), Zy, rtol=1e-13, atol=1e-15)
-        fw = orc.elbo_forward(p, pb["scene"], pb["X"], Zy, pb["y"], noise, pb["alpha"])
+        fw = orc.elbo_forward(p, pb["scene"], pb["X"], Zy, pb["y"], noise, pb["alpha"], lookup_pos=_device_centres(pl, k))
         og, _, g_zy = orc.elbo_backward(p, pb["scene"], pb["X"], Zy, noise, pb["alpha"], fw, want_z=True)
         want = orc.z_backward(raws[k], g_zy)
         assert (fw["logp"] < 0).any()
-        ok = np.isclose(pl.logp[k].cpu().numpy(), fw["logp"], rtol=2e-3, atol=1e-4)
-        flips = 1.0 - ok.mean()
+        tag = f"inducing[{robot},S={S},k={k}]"
+        # the device's own voxels on both sides: every pair agrees, fixed gradient tolerances
+        np.testing.assert_allclose(pl.logp[k].cpu().numpy(), fw["logp"], rtol=0, atol=TOL_LOGP * np.abs(fw["logp"]).max())
         np.testing.assert_allclose(float(pl.kl[k]), fw["cv"]["kl"], rtol=1e-9)
         got = pl.z_grad[k].cpu().numpy()
         scale = np.abs(want).max()
         assert scale > 1e-3
-        assert np.abs(got - want).max() / scale < 50 * flips + 3e-3, (np.abs(got - want).max(), scale, flips)
-        gq = grads[0][k].cpu().numpy().T
-        assert np.abs(gq - og.q_mu).max() <= (50 * flips + 3e-3) * np.abs(og.q_mu).max()
-        ge = grads[2][k].cpu().numpy()
-        assert np.abs(ge - og.raw_ell).max() <= (50 * flips + 3e-3) * np.abs(og.raw_ell).max()
+        print(f"PARITY {tag} raw_Z={np.abs(got - want).max() / scale:.2e}")
+        assert np.abs(got - want).max() / scale < TOL_GRAD, (np.abs(got - want).max(), scale)
+        _assert_grads(tag, grads, og, k=k)
 
 
 def test_inducing_location_kl_gradient_is_float64_exact():
@@ -481,11 +469,12 @@ def test_inducing_location_adam_trajectory_matches_oracle():
     assert float((a.raw_Z - torch.tensor(orc.init_raw_Z(M, 7), device=a.raw_Z.device)).abs().max()) > 0
 
 
-def _compare_with_oracle(pl, k, p, scene, X, Zy, y, noise, alpha, S, N, M, L, split_k, lik_scale=1.0, kl_scale=1.0):
-    """Problem k of the batch `pl` against the oracle, with the tolerances of test_elbo_forward_backward_against_oracle.
+def _compare_with_oracle(pl, k, p, scene, X, Zy, y, noise, alpha, S, N, M, L, split_k, lik_scale=1.0, kl_scale=1.0, tag="batch"):
+    """Problem k of the batch `pl` against the oracle on the device's own voxels, with the tolerances of
+    test_elbo_forward_backward_against_oracle.
     lik_scale / kl_scale: a rank's share of a sharded sample axis (S local of S_total samples, KL on rank 0 only)."""
     Mz, J = M + 2, N + M + 2
-    fw = orc.elbo_forward(p, scene, X, Zy, y, noise, alpha * lik_scale)
+    fw = orc.elbo_forward(p, scene, X, Zy, y, noise, alpha * lik_scale, lookup_pos=_device_centres(pl, k))
     og, _ = orc.elbo_backward(p, scene, X, Zy, noise, alpha * lik_scale, fw)
     if kl_scale != 1.0:
         fw0 = orc.elbo_forward(p, scene, X, Zy, y, noise, 0.0)
@@ -504,18 +493,14 @@ def _compare_with_oracle(pl, k, p, scene, X, Zy, y, noise, alpha, S, N, M, L, sp
     np.testing.assert_allclose(pl.view("R").reshape(pl.P, S, L, Mz)[k].cpu().numpy(), fw["R"], rtol=0, atol=5e-5)
     np.testing.assert_allclose(pl.f[k].cpu().numpy(), fw["f"], rtol=0, atol=1e-4)
     logp = pl.logp[k].cpu().numpy()
-    ok = np.isclose(logp, fw["logp"], rtol=2e-3, atol=1e-4)
-    assert ok.mean() >= 0.97, f"logp agreement {ok.mean():.3f}"
-    flips = 1.0 - ok.mean()
+    # the device's own voxels on both sides: every (sample, time) pair, fixed tolerances
+    top = np.abs(fw["logp"]).max()
+    np.testing.assert_allclose(logp, fw["logp"], rtol=0, atol=TOL_LOGP * top + 1e-30)
     np.testing.assert_allclose(float(pl.kl[k]), kl_scale * cv["kl"], rtol=1e-9, atol=1e-300)
-    np.testing.assert_allclose(float(pl.lik[k]), fw["lik"], rtol=50 * flips + 2e-4)
-    for got, name in zip(pl.grad, ("q_mu", "q_sqrt", "raw_ell", "raw_var")):
-        want = getattr(og, name)
-        got = got[k].cpu().numpy()
-        if name == "q_mu":
-            got = got.T
-        scale = np.abs(want).max() + 1e-12
-        assert np.abs(got - want).max() / scale < 50 * flips + 3e-3, (name, k, np.abs(got - want).max(), scale, flips)
+    np.testing.assert_allclose(float(pl.lik[k]), fw["lik"], rtol=TOL_LIK, atol=1e-12)
+    _assert_grads(f"{tag}[k={k}]", pl.grad, og, k=k)
+    if k == 0:      # one un-overridden forward per configuration: the share of pairs a float64 chain resolves differently
+        _flipped_share(tag, logp, orc.elbo_forward(p, scene, X, Zy, y, noise, alpha * lik_scale, want_dell=False))
     return fw
 
 
@@ -570,7 +555,7 @@ def test_baseline_configs_at_full_size_against_oracle(config):
     active = False
     for k in range(P):
         fw = _compare_with_oracle(pl, k, params[k], osc, X, Zy, qs[k], noises[k], float(pp["alpha"]), S, N, M, L, split_k,
-                                  lik_scale=lik_scale, kl_scale=float(extra.get("kl_scale", 1.0)))
+                                  lik_scale=lik_scale, kl_scale=float(extra.get("kl_scale", 1.0)), tag=config)
         active = active or bool((fw["logp"] < 0).any())
     assert active, "the scene must put spheres inside the hinge band for at least one problem"
 

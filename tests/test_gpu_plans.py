@@ -40,8 +40,9 @@ def test_generated_noise_trajectory_against_oracle(industrial, name, over, steps
     """-ELBO of every optimisation step, device (noise drawn by the device generator, seed 77) against the oracle
     (orc.philox_noise of the same seed / problem / step), eight problems in one batch.  The two differ by float32 arithmetic
     and by nearest-voxel flips of float32 sphere centres; Adam (which normalises every gradient entry) lets that grow slowly
-    with the step: tolerance 5e-4 relative at the first step, 5e-3 at the last (measured: 2 % of that at the reference's
-    parameters, 0.2 % at config 2's sizes)."""
+    with the step.  Tolerances within ten times what was measured (gpurun_out/r04/t_plans.txt: 1e-5 ... 1e-4 relative at the
+    reference's parameters, 1e-6 ... 1e-5 at config 2's sizes): 1e-4 at the first step to 1e-3 at the last, 2e-5 to 2e-4 at
+    config 2's sizes, where all eight problems are compared."""
     engine, ps, spec, grid = industrial
     pp = dict(ps.planner_params, **over)
     S, M, N, B, D = int(pp["num_samples"]), int(pp["num_inducing"]), int(pp["time_spacing_X"]), 1024, spec.dof
@@ -60,7 +61,8 @@ def test_generated_noise_trajectory_against_oracle(industrial, name, over, steps
         pl.step()
         dev_loss[t] = (-(pl.lik - pl.kl)).cpu().numpy()
     X, Zy = orc.init_trainset(N, D), orc.inducing_Zy(M, D)
-    check = range(len(pick)) if name != "config2" else (0, 3, 7)       # (the oracle takes ~0.2 s per config-2 step)
+    check = range(len(pick))                                 # (the oracle takes ~0.2 s per config-2 step: 13 s for the eight)
+    tol0, tol1 = (2e-5, 2e-4) if name == "config2" else (1e-4, 1e-3)
     worst = 0.0
     for k in check:
         y = qs[k]
@@ -69,7 +71,7 @@ def test_generated_noise_trajectory_against_oracle(industrial, name, over, steps
         for t in range(steps):
             nz = orc.philox_noise(seed, base + k, t, S, D, D, B, M + 2)
             want = orc.optimization_step(p, st, osc, X, Zy, y, nz, float(pp["alpha"]), float(pp["learning_rate"]))
-            tol = 5e-4 + (5e-3 - 5e-4) * t / max(steps - 1, 1)
+            tol = tol0 + (tol1 - tol0) * t / max(steps - 1, 1)
             rel = abs(dev_loss[t, k] - want) / abs(want)
             worst = max(worst, rel / tol)
             assert rel <= tol, (name, k, t, dev_loss[t, k], want, rel)
@@ -79,7 +81,7 @@ def test_generated_noise_trajectory_against_oracle(industrial, name, over, steps
         assert np.abs(pl.q_mu[k].cpu().numpy().T - p.q_mu).max() < tolp
         assert np.abs(pl.raw_ell[k].cpu().numpy() - p.raw_ell).max() < tolp
     assert dev_loss[-1].sum() < dev_loss[0].sum()
-    print(f"{name}: worst per-step loss deviation / tolerance = {worst:.3f}")
+    print(f"PARITY trajectory {name}: worst per-step loss deviation / tolerance = {worst:.3f}")
 
 
 def test_plans_on_the_industrial_problem_set(industrial):

@@ -846,12 +846,18 @@ def test_f16_split_prior_kernel_against_float64_and_the_float32_kernels(robot, S
     np.testing.assert_allclose(a["f"], b["f"], rtol=0, atol=2e-5)
     ok = np.isclose(a["logp"], b["logp"], rtol=2e-3, atol=1e-4)
     assert ok.mean() > 0.99
+    # two device forms whose paths differ by <= 2e-5: a few sphere centres resolve to neighbouring voxels.  The share is measured,
+    # printed and bounded, and the allowance it buys is capped (a wrong gradient cannot hide behind it)
     flips = 1.0 - ok.mean()
-    np.testing.assert_allclose(a["loss"], b["loss"], rtol=50 * flips + 1e-4)
+    worst_g = max(np.abs(ga - gb).max() / (np.abs(gb).max() + 1e-12) for k, (ga, gb) in enumerate(zip(a["grads"], b["grads"]))
+                  if not (k == 2 and not lengthscales))
+    print(f"PARITY split-vs-f32 flipped_share={flips:.5f} loss={np.abs(a['loss'] - b['loss']).max() / np.abs(b['loss']).max():.2e} grad={worst_g:.2e}")
+    assert flips <= 5e-3
+    np.testing.assert_allclose(a["loss"], b["loss"], rtol=min(10 * flips, 2e-2) + 1e-4)
     for k, (ga, gb) in enumerate(zip(a["grads"], b["grads"])):
         if k == 2 and not lengthscales:
             continue                                    # no lengthscale tangent: that gradient is not formed
-        assert np.abs(ga - gb).max() <= (50 * flips + 1e-3) * np.abs(gb).max() + 1e-12
+        assert np.abs(ga - gb).max() <= (min(10 * flips, 2e-2) + 1e-3) * np.abs(gb).max() + 1e-12
     # ... and three optimisation steps stay together (Adam normalises: float32-level gradient differences move a variable by
     # far less than lr per step)
     sp, fp = res["split"]["pl"], res["f32"]["pl"]
@@ -917,9 +923,12 @@ def test_many_sample_gemm_role_on_the_f16_pipe_against_its_float32_form(robot, S
     ok = np.isclose(a["logp"], b["logp"], rtol=2e-3, atol=1e-4)
     assert ok.mean() > 0.99
     flips = 1.0 - ok.mean()
-    np.testing.assert_allclose(a["loss"], b["loss"], rtol=50 * flips + 1e-4)
+    worst_g = max(np.abs(ga - gb).max() / (np.abs(gb).max() + 1e-12) for ga, gb in zip(a["grads"], b["grads"]))
+    print(f"PARITY gemm-f16-vs-f32 flipped_share={flips:.5f} loss={np.abs(a['loss'] - b['loss']).max() / np.abs(b['loss']).max():.2e} grad={worst_g:.2e}")
+    assert flips <= 5e-3
+    np.testing.assert_allclose(a["loss"], b["loss"], rtol=min(10 * flips, 2e-2) + 1e-4)
     for ga, gb in zip(a["grads"], b["grads"]):
-        assert np.abs(ga - gb).max() <= (50 * flips + 1e-3) * np.abs(gb).max() + 1e-12
+        assert np.abs(ga - gb).max() <= (min(10 * flips, 2e-2) + 1e-3) * np.abs(gb).max() + 1e-12
     sp, fp = a["pl"], b["pl"]
     for _ in range(3):
         sp.step(); fp.step()

@@ -18,10 +18,12 @@ COMM_ID_BYTES = 128
 TRAIN_Q_MU, TRAIN_Q_SQRT, TRAIN_LENGTHSCALES, TRAIN_KERNEL_VARIANCE = 1, 2, 4, 8
 TRAIN_SIGMA_OBS, TRAIN_ALPHA = 16, 32      # need Problem.lik
 TRAIN_INDUCING = 64                       # needs Problem.ind
-DO_FORWARD, DO_BACKWARD, DO_ADAM, GEN_NOISE, NO_FUSE = 1, 2, 4, 8, 16
-GEMM_DIRECT, NO_SPLIT, ELIM_BLOCK, LIK_LANES, LIK_LDS_STATE, COV_ONLY, NO_FUSE_PRIOR, PRIOR_F32, BWD_ONE_CHUNK = 32, 64, 128, 256, 512, 2048, 4096, 8192, 16384
-COV_LDS_ROWS = 1024
+# `what` of include/vgpmp.h: what a call computes
+DO_FORWARD, DO_BACKWARD, DO_ADAM, GEN_NOISE, COV_ONLY = 1, 2, 4, 8, 2048
 NOISE_AHEAD, NOISE_READY = 32768, 65536
+# include/vgpmp_debug.h: measurement / test switches in the same argument (other schedules and kernel forms of the same numbers)
+NO_FUSE, GEMM_DIRECT, NO_SPLIT, ELIM_BLOCK, LIK_LANES, LIK_LDS_STATE, COV_LDS_ROWS = 16, 32, 64, 128, 256, 512, 1024
+NO_FUSE_PRIOR, PRIOR_F32, BWD_ONE_CHUNK = 4096, 8192, 16384
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libvgpmp_hip.so"
 
@@ -29,6 +31,7 @@ EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_table_bytes", "vgpm
            "vgpmp_log_prob", "vgpmp_cov_matrices", "vgpmp_kernel_derivative", "vgpmp_velocity_kuu_kuf", "vgpmp_workspace_bytes", "vgpmp_lik_scratch_bytes", "vgpmp_inducing_scratch_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
            "vgpmp_elbo_steps", "vgpmp_elbo_step_profiled", "vgpmp_adam_step", "vgpmp_workspace_view", "vgpmp_sample_paths",
            "vgpmp_comm_unique_id", "vgpmp_comm_init", "vgpmp_allreduce_grads", "vgpmp_comm_destroy", "vgpmp_elbo_steps_reduced")
+DEBUG_EXPORTS = ("vgpmp_debug_sphere_centres", "vgpmp_debug_last_schedule")      # include/vgpmp_debug.h
 NUM_STAGES = 8
 NUM_TIMES = 10
 STAGE_NAMES = ("cov_fwd", "noise", "features", "prior_gemm", "paths_fwd", "loglik_fk_sdf", "paths_bwd", "final_adam")
@@ -165,10 +168,13 @@ def load(require: bool = True) -> Optional[C.CDLL]:
         "vgpmp_elbo_steps_reduced": [P(Dims), vp, P(Sdf), P(Problem), P(Params), P(Params), P(Params), P(Noise), P(Outputs),
                                      vp, C.c_size_t, i32, i32, dbl, i32, u32, u32, u32, i32, vp, vp, C.c_size_t, vp],
     }
+    sigs["vgpmp_debug_sphere_centres"] = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
     for name, args in sigs.items():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    lib.vgpmp_debug_last_schedule.argtypes = [C.c_char_p, C.c_size_t]
+    lib.vgpmp_debug_last_schedule.restype = C.c_int64
     _lib = lib
     return lib
 
@@ -217,3 +223,12 @@ def stream_ptr() -> int:
 
 def ptr(t) -> Optional[int]:
     return None if t is None else int(t.data_ptr())
+
+
+def last_schedule(lib=None) -> list:
+    """include/vgpmp_debug.h: the kernels the calling thread's last vgpmp_elbo_step* call enqueued for its last step."""
+    lib = lib or load(require=True)
+    need = int(lib.vgpmp_debug_last_schedule(None, 0))
+    buf = C.create_string_buffer(need)
+    lib.vgpmp_debug_last_schedule(buf, need)
+    return [n for n in buf.value.decode().split("\n") if n]

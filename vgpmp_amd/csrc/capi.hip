@@ -2,10 +2,42 @@
 #include "vgpmp_device.h"
 #include "gp_path.h"
 #include <string.h>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+// ---- schedule log ---------------------------------------------------------------------------------------------------
+namespace {
+std::mutex g_fn_mu;
+std::unordered_map<const void*, std::string>& fn_names() { static std::unordered_map<const void*, std::string> m; return m; }
+thread_local std::vector<std::string> t_sched;
+// the launch site's text -> the name a profiler prints: no enclosing parentheses, constants by value
+std::string sched_clean(const char* name) {
+    std::string n(name);
+    while (!n.empty() && n.front() == '(' && n.back() == ')') n = n.substr(1, n.size() - 2);
+    static const struct { const char* sym; const char* val; } consts[] = {{"kLikBatchBlock", "64"}};
+    for (const auto& c : consts)
+        for (size_t at; (at = n.find(c.sym)) != std::string::npos;) n.replace(at, strlen(c.sym), c.val);
+    return n;
+}
+}  // namespace
+void vg_sched_clear() { t_sched.clear(); }
+void vg_sched_note(const char* name) { t_sched.push_back(sched_clean(name)); }
+const void* vg_fn_reg(const void* fn, const char* name) {
+    std::lock_guard<std::mutex> lock(g_fn_mu);
+    fn_names()[fn] = sched_clean(name);
+    return fn;
+}
+void vg_sched_note_fn(const void* fn) {
+    std::lock_guard<std::mutex> lock(g_fn_mu);
+    auto it = fn_names().find(fn);
+    t_sched.push_back(it == fn_names().end() ? std::string("?") : it->second);
+}
 
 extern "C" {
 
-const char* vgpmp_version(void) { return "vgpmp-hip 0.1 (gfx950)"; }
+const char* vgpmp_version(void) { return "vgpmp-hip 0.2 (gfx950)"; }
 
 int vgpmp_robot_upload(const vgpmp_robot* host_robot, void* dev_robot, vgpmp_stream stream) {
     if (!host_robot || !dev_robot) return VGPMP_E_ARG;
@@ -47,6 +79,17 @@ static int check_sdf(const vgpmp_sdf* sdf) {
     if (sdf->nx < 1 || sdf->ny < 1 || sdf->nz < 1 || !(sdf->delta > 0.0)) return VGPMP_E_SHAPE;
     if (sdf->layout != VGPMP_SDF_LINEAR && sdf->layout != VGPMP_SDF_BRICK4) return VGPMP_E_ARG;
     if (sdf->brick_min && sdf->layout != VGPMP_SDF_BRICK4) return VGPMP_E_ARG;
+    if (sdf->free_mask) {       // the mask kernels size their LDS image and their bit indices from these fields
+        if (sdf->layout != VGPMP_SDF_BRICK4) return VGPMP_E_ARG;
+        if (sdf->mask_shift < 2 || sdf->mask_shift > 12 || sdf->mask_count < 1 || sdf->mask_count > VGPMP_MAX_MASKS)
+            return VGPMP_E_SHAPE;
+        const size_t e = (size_t)1 << sdf->mask_shift;
+        const size_t bits = ((sdf->nx + e - 1) >> sdf->mask_shift) * ((sdf->ny + e - 1) >> sdf->mask_shift) *
+                            ((sdf->nz + e - 1) >> sdf->mask_shift);
+        if ((size_t)sdf->mask_words != ((((bits + 31) / 32) + 3) & ~(size_t)3)) return VGPMP_E_ARG;
+        for (int k = 1; k < sdf->mask_count; ++k)
+            if (!(sdf->mask_clearance[k] >= sdf->mask_clearance[k - 1])) return VGPMP_E_ARG;
+    }
     return 0;
 }
 
@@ -105,6 +148,26 @@ int vgpmp_mesh_sdf(const double* dev_triangles, const int32_t* dev_part, int32_t
     if (num_triangles < 1 || nx < 1 || ny < 1 || nz < 1 || !(delta > 0.0)) return VGPMP_E_SHAPE;
     return vg_launch_mesh_sdf(dev_triangles, dev_part, num_triangles, nx, ny, nz, origin, delta, dev_grid,
                               (hipStream_t)stream);
+}
+
+int vgpmp_debug_sphere_centres(const vgpmp_robot* dev_robot, const float* dev_f, int32_t num_problems, int32_t S, int32_t L,
+                               int32_t N, int32_t what, float* dev_pos, vgpmp_stream stream) {
+    if (!dev_robot || num_problems < 0 || S < 0 || N < 0) return VGPMP_E_ARG;
+    if (L < 1 || L > VGPMP_MAX_DOF) return VGPMP_E_SHAPE;
+    if ((size_t)num_problems * S * N > 0 && (!dev_f || !dev_pos)) return VGPMP_E_ARG;
+    return vg_launch_sphere_centres(dev_robot, dev_f, num_problems, S, L, N,
+                                    (what & VGPMP_LIK_LDS_STATE) ? 2 : (what & VGPMP_LIK_LANES) ? 1 : 0, dev_pos, (hipStream_t)stream);
+}
+
+int64_t vgpmp_debug_last_schedule(char* buf, size_t buf_bytes) {
+    std::string all;
+    for (const auto& n : t_sched) { all += n; all += '\n'; }
+    if (buf && buf_bytes) {
+        const size_t k = all.size() < buf_bytes - 1 ? all.size() : buf_bytes - 1;
+        ::memcpy(buf, all.data(), k);
+        buf[k] = 0;
+    }
+    return (int64_t)all.size() + 1;
 }
 
 int vgpmp_fk_spheres(const vgpmp_robot* dev_robot, const float* dev_q, int64_t n, float* dev_pos, float* dev_frames,
@@ -293,6 +356,9 @@ int vgpmp_elbo_steps_reduced(const vgpmp_dims* dims, const vgpmp_robot* dev_robo
     if (num_steps < 1 || adam_t < 0 || !adam_m || !adam_v || (comm && (!dev_reduce_buf || !reduce_count))) return VGPMP_E_ARG;
     if (what & (VGPMP_DO_ADAM | VGPMP_COV_ONLY)) return VGPMP_E_ARG;      // the update follows the exchange: this call applies it
     if (problem && problem->step_counter) return VGPMP_E_ARG;             // (the step comes from the arguments)
+    // the exchange buffer and the update below carry q_mu, q_sqrt, lengthscales and kernel variance only (include/vgpmp.h:
+    // trainable sigma_obs / alpha / inducing locations do not shard over samples) -- refuse instead of leaving them untrained
+    if (trainable & (VGPMP_TRAIN_SIGMA_OBS | VGPMP_TRAIN_ALPHA | VGPMP_TRAIN_INDUCING)) return VGPMP_E_ARG;
     what |= VGPMP_DO_FORWARD | VGPMP_DO_BACKWARD | VGPMP_GEN_NOISE | VGPMP_NOISE_AHEAD;
     for (int i = 0; i < num_steps; ++i) {
         // local samples: forward + reverse into out->grad / lik / kl; every step but the caller's first finds its prior noise drawn

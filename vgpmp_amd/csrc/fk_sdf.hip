@@ -901,8 +901,10 @@ __global__ __launch_bounds__(kBlock) void sdf_free_mask_kernel(vgpmp_sdf sdfh) {
     for (int k = 0; k < s.mcount; ++k) {
         const unsigned long long bal = __ballot(b < nbits && m >= s.mclr[k]);
         const int lane = threadIdx.x & (VG_WAVE - 1);
-        if (lane == 0) out[(size_t)k * s.mwords + (b >> 5)] = (uint32_t)bal;
-        if (lane == 32) out[(size_t)k * s.mwords + (b >> 5)] = (uint32_t)(bal >> 32);
+        // mwords is a multiple of 4 words, the grid of 8: the last workgroup's upper waves may lie beyond the mask
+        const bool in_mask = (b >> 5) < (size_t)s.mwords;
+        if (lane == 0 && in_mask) out[(size_t)k * s.mwords + (b >> 5)] = (uint32_t)bal;
+        if (lane == 32 && in_mask) out[(size_t)k * s.mwords + (b >> 5)] = (uint32_t)(bal >> 32);
     }
 }
 
@@ -944,6 +946,32 @@ static int wide_paths_words(int L, int SK) { (void)SK; return L * 32 + L * 16; }
 // path-assembly launch wrote: r = U - f0(Z) - sqrt(jitter) eps' (U = m + C eps from stage B), f = f0(X) + r A^T by the MFMA
 // sequence of paths_fwd_split_body on row 0 of the tile (same operands, same order: the same bits); tile 0 of a sample
 // stores r for the reverse pass, every tile its f.  One launch and its hand-over fewer on the one-problem step.
+// The chain as a prefix product over the 8 lanes of a group (up to 8 joints): lane j holds link j (sin / cos of its own joint)
+// and ends with the product of links 0 .. j -- three rounds of (row shift, 3x4 product) instead of dof dependent products on
+// every lane.  Shared with the tests' sphere-centre kernel below: the same code, the same roundings.
+__device__ __forceinline__ Frame wide_scan_links(const vgpmp_robot* __restrict__ rb, int sub, int L, float st0, float ct0) {
+    Frame Pm;
+    if (sub < L) {
+        Pm = dh_link(rb, sub, st0, ct0);
+    } else {
+        Pm.cx = vg_make3(1.f, 0.f, 0.f); Pm.cy = vg_make3(0.f, 1.f, 0.f); Pm.cz = vg_make3(0.f, 0.f, 1.f);
+        Pm.t = vg_make3(0.f, 0.f, 0.f);
+    }
+    {
+        const Frame Lf = frame_shr<1>(Pm);
+        if (sub >= 1) Pm = frame_mul(Lf, Pm);
+    }
+    {
+        const Frame Lf = frame_shr<2>(Pm);
+        if (sub >= 2) Pm = frame_mul(Lf, Pm);
+    }
+    {
+        const Frame Lf = frame_shr<4>(Pm);
+        if (sub >= 4) Pm = frame_mul(Lf, Pm);
+    }
+    return Pm;
+}
+
 template <int LPC, bool SIG = false, int SK = 0>
 __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpmp_robot* __restrict__ rb_g, vgpmp_sdf sdfh,
                                                                        const float* __restrict__ f, int S, int L, int N,
@@ -1108,25 +1136,7 @@ __global__ __launch_bounds__(kLikBlock) void loglik_paths_wide_kernel(const vgpm
     // (row shift, 3x4 product) instead of dof dependent products on every lane
     const bool scan = LPC == 8 && L <= LPC;
     if (scan) {
-        Frame Pm;
-        if (sub < L) {
-            Pm = dh_link(rb, sub, st0, ct0);
-        } else {
-            Pm.cx = vg_make3(1.f, 0.f, 0.f); Pm.cy = vg_make3(0.f, 1.f, 0.f); Pm.cz = vg_make3(0.f, 0.f, 1.f);
-            Pm.t = vg_make3(0.f, 0.f, 0.f);
-        }
-        {
-            const Frame Lf = frame_shr<1>(Pm);
-            if (sub >= 1) Pm = frame_mul(Lf, Pm);
-        }
-        {
-            const Frame Lf = frame_shr<2>(Pm);
-            if (sub >= 2) Pm = frame_mul(Lf, Pm);
-        }
-        {
-            const Frame Lf = frame_shr<4>(Pm);
-            if (sub >= 4) Pm = frame_mul(Lf, Pm);
-        }
+        const Frame Pm = wide_scan_links(rb, sub, L, st0, ct0);
         const Frame B = base_frame(rb);
         if (sub < L) put_frame(sub + 1, frame_mul(B, Pm));
         if (sub == (L < LPC ? L : 0)) put_frame(0, B);
@@ -1293,6 +1303,69 @@ __global__ __launch_bounds__(kBlock) void fk_spheres_kernel(const vgpmp_robot* _
     }
 }
 
+// ---- the sphere centres the ELBO kernels form from latent paths (parity tests: include/vgpmp_debug.h) ----------
+// f [P, S, L, N] -> pos [P, S, N, Q, 3], by the arithmetic of the likelihood launch that vg_launch_loglik_paths selects for the
+// same (P, S, N, L, form): joint sigmoid with __expf, vg_sincos, then either the serial chain of the one-lane forms
+// (loglik_config*, dh_apply) or the 8-lane prefix product of loglik_paths_wide_kernel (wide_scan_links); the sphere offsets applied
+// in the kernels' order.  The nearest-voxel lookup is piecewise constant: a float64 oracle looks its voxels up at THESE centres,
+// so that no query of a comparison falls into a neighbouring cell.
+template <bool SCAN>
+__global__ __launch_bounds__(kLikBlock) void sphere_centres_paths_kernel(const vgpmp_robot* __restrict__ rb, const float* __restrict__ f,
+                                                                        int S, int L, int N, float* __restrict__ pos) {
+    constexpr int LPC = SCAN ? 8 : 1, CPB = kLikBlock / LPC;
+    __shared__ float fr_lds[SCAN ? CPB * 12 * (8 + 1) : 1];
+    const int pb = blockIdx.y, cl = threadIdx.x / LPC, sub = threadIdx.x % LPC;
+    const int idx = blockIdx.x * CPB + cl;
+    const bool live = idx < S * N;
+    const int ci = live ? idx : S * N - 1;
+    const int s = ci / N, n = ci - s * N;
+    const size_t base = ((size_t)pb * S + s) * L * N + n;
+    const int D = rb->dof, P = rb->num_spheres;
+    float* out = pos + (((size_t)pb * S + s) * N + n) * P * 3;
+    if (SCAN) {
+        float st0 = 0.f, ct0 = 1.f;
+        if (sub < D) {
+            const float sg = 1.0f / (1.0f + __expf(-f[base + (size_t)sub * N]));
+            const float span = rb->high[sub] - rb->low[sub];
+            vg_sincos(fmaf(span, sg, rb->low[sub]) + rb->twist[sub], &st0, &ct0);
+        }
+        const Frame Pm = wide_scan_links(rb, sub, L, st0, ct0);
+        const Frame B = base_frame(rb);
+        float* grp = fr_lds + cl * 12 * 9;
+        auto put = [&](int i, const Frame& T) {
+            float* o = grp + 12 * i;
+            o[0] = T.cx.x; o[1] = T.cx.y; o[2] = T.cx.z; o[3] = T.cy.x; o[4] = T.cy.y; o[5] = T.cy.z;
+            o[6] = T.cz.x; o[7] = T.cz.y; o[8] = T.cz.z; o[9] = T.t.x; o[10] = T.t.y; o[11] = T.t.z;
+        };
+        if (sub < L) put(sub + 1, frame_mul(B, Pm));
+        if (sub == (L < LPC ? L : 0)) put(0, B);
+        __syncthreads();
+        for (int q = sub; q < P; q += LPC) {
+            const float* o = grp + 12 * rb->sphere_frame[q];
+            const vg_float3 cx = vg_make3(o[0], o[1], o[2]), cy = vg_make3(o[3], o[4], o[5]);
+            const vg_float3 cz = vg_make3(o[6], o[7], o[8]), t = vg_make3(o[9], o[10], o[11]);
+            const vg_float3 x = axpy(rb->sphere_off[q][0], cx, axpy(rb->sphere_off[q][1], cy, axpy(rb->sphere_off[q][2], cz, t)));
+            if (live) { out[3 * q] = x.x; out[3 * q + 1] = x.y; out[3 * q + 2] = x.z; }
+        }
+    } else {
+        Frame T = base_frame(rb);
+        int cur = 0;
+        for (int q = 0; q < P; ++q) {
+            const float4 ca = *reinterpret_cast<const float4*>(rb->sphere_a[q]);
+            const int fr = __builtin_bit_cast(int, ca.w);
+            while (cur < fr) {
+                const float sg = 1.0f / (1.0f + __expf(-f[base + (size_t)cur * N]));
+                float st, ct;
+                vg_sincos(fmaf(rb->joint_tab[cur][7], sg, rb->joint_tab[cur][5]) + rb->joint_tab[cur][4], &st, &ct);
+                dh_apply(rb, cur, st, ct, T);
+                ++cur;
+            }
+            const vg_float3 x = axpy(ca.x, T.cx, axpy(ca.y, T.cy, axpy(ca.z, T.cz, T.t)));
+            if (live) { out[3 * q] = x.x; out[3 * q + 1] = x.y; out[3 * q + 2] = x.z; }
+        }
+    }
+}
+
 // ---- stand-alone SDF query on float64 relative positions -----------------------------------------
 __global__ __launch_bounds__(kBlock) void sdf_query_kernel(vgpmp_sdf sdfh, const double* __restrict__ rel, int64_t n,
                                                             int32_t* __restrict__ idx, float* __restrict__ dist,
@@ -1415,6 +1488,18 @@ int vg_launch_fk_spheres(const vgpmp_robot* rb, const float* q, int64_t n, float
     return (int)hipGetLastError();
 }
 
+int vg_launch_sphere_centres(const vgpmp_robot* rb, const float* f, int P, int S, int L, int N, int form, float* pos, hipStream_t st) {
+    if (P == 0 || S == 0 || N == 0) return 0;
+    int lpc = lik_lpc(P, S, N);      // as vg_launch_loglik_paths
+    if (form != 0) lpc = 1;
+    const bool scan = lpc == 8 && L <= 8;
+    const int cpb = kLikBlock / (scan ? 8 : 1);
+    const dim3 grid((unsigned)((S * N + cpb - 1) / cpb), (unsigned)P);
+    if (scan) hipLaunchKernelGGL((sphere_centres_paths_kernel<true>), grid, dim3(kLikBlock), 0, st, rb, f, S, L, N, pos);
+    else hipLaunchKernelGGL((sphere_centres_paths_kernel<false>), grid, dim3(kLikBlock), 0, st, rb, f, S, L, N, pos);
+    return (int)hipGetLastError();
+}
+
 int vg_launch_sdf_index_f32(const vgpmp_sdf* sdf, const double* offset, const float* pos, int64_t n, int32_t* idx, hipStream_t st) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(sdf_index_f32_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, *sdf, offset[0],
@@ -1444,6 +1529,7 @@ int vg_launch_log_prob_impl(const vgpmp_robot* rb, int dof, const vgpmp_sdf* sdf
 
 bool vg_lik_paths_fit(int L, int SK) { return L <= 8 && wide_paths_words(L, SK) <= 6 * (L + 1) * kLikBlock; }
 
+#define VG_GO(fn_, ...) fn_(__VA_ARGS__, #__VA_ARGS__)
 int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const float* f, int P, int S, int L, int N,
                            float scale, float* G, float* logp, float* lik_partial, int* nblk_out, hipStream_t st,
                            hipEvent_t k0, hipEvent_t k1, const float* alpha_eff, const float* sigma_eff,
@@ -1469,26 +1555,28 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
     // k0 / k1 (profiler): events stamped with the kernel's own start and end on the device
     if (lpc == 8) {
         const vg_lik_paths lp = paths ? *paths : vg_lik_paths{};
-        auto go = [&](auto kern) {
+        auto go = [&](auto kern, const char* name) {
             int rc = vg_grant_dyn_lds((const void*)kern, lds);
             if (rc) return rc;
+            vg_sched_note(name);
             hipExtLaunchKernelGGL(kern, dim3(nblk, P), dim3(kLikBlock), lds, st, k0, k1, 0, rb, *sdf, f, S, L, N, scale, G, logp,
                                   lik_partial, alpha_eff, sigma_eff, sig_partial, lp);
             return (int)hipGetLastError();
         };
         if (paths) {
             switch (paths->SK) {
-                case 2: return sig ? go(loglik_paths_wide_kernel<8, true, 2>) : go(loglik_paths_wide_kernel<8, false, 2>);
-                case 4: return sig ? go(loglik_paths_wide_kernel<8, true, 4>) : go(loglik_paths_wide_kernel<8, false, 4>);
-                case 8: return sig ? go(loglik_paths_wide_kernel<8, true, 8>) : go(loglik_paths_wide_kernel<8, false, 8>);
+                case 2: return sig ? VG_GO(go, loglik_paths_wide_kernel<8, true, 2>) : VG_GO(go, loglik_paths_wide_kernel<8, false, 2>);
+                case 4: return sig ? VG_GO(go, loglik_paths_wide_kernel<8, true, 4>) : VG_GO(go, loglik_paths_wide_kernel<8, false, 4>);
+                case 8: return sig ? VG_GO(go, loglik_paths_wide_kernel<8, true, 8>) : VG_GO(go, loglik_paths_wide_kernel<8, false, 8>);
                 default: return VGPMP_E_ARG;
             }
         }
-        return sig ? go(loglik_paths_wide_kernel<8, true>) : go(loglik_paths_wide_kernel<8, false>);
+        return sig ? VG_GO(go, loglik_paths_wide_kernel<8, true>) : VG_GO(go, loglik_paths_wide_kernel<8, false>);
     }
-    auto go = [&](auto kern) {
+    auto go = [&](auto kern, const char* name) {
         int rc = vg_grant_dyn_lds((const void*)kern, lds);
         if (rc) return rc;
+        vg_sched_note(name);
         hipExtLaunchKernelGGL(kern, dim3(nblk, P), dim3(kLikBatchBlock), lds, st, k0, k1, 0, rb, *sdf, f, S, L, N, scale, G, logp,
                               lik_partial, dbg, alpha_eff, sigma_eff, sig_partial);
         return (int)hipGetLastError();
@@ -1500,24 +1588,26 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
         const size_t lds_mask = (sdf->free_mask ? (size_t)sdf->mask_count * sdf->mask_words * 4 : 0) + (size_t)3 * L * kLikMaskBlock * sizeof(float);
         const bool masks = sdf->layout == VGPMP_SDF_BRICK4 && sdf->free_mask && sdf->mask_count > 0;
         if (!pfx && !sig && 2 * lds_mask <= 160 * 1024) {
-            auto gom = [&](auto kern) {
+            auto gom = [&](auto kern, const char* name) {
                 int rc = vg_grant_dyn_lds((const void*)kern, lds_mask);
                 if (rc) return rc;
+                vg_sched_note(name);
                 hipExtLaunchKernelGGL(kern, dim3((nblk + 3) / 4, P), dim3(kLikMaskBlock), lds_mask, st, k0, k1, 0, rb, *sdf, f, S, L, N,
                                       scale, G, logp, lik_partial, nblk);
                 return (int)hipGetLastError();
             };
             // masks in LDS where the scene has them (one dependent global load per sphere), else the summary, else every sphere
-            return masks ? gom(loglik_paths_mask_kernel<2>) : far ? gom(loglik_paths_mask_kernel<1>) : gom(loglik_paths_mask_kernel<0>);
+            return masks ? VG_GO(gom, loglik_paths_mask_kernel<2>) : far ? VG_GO(gom, loglik_paths_mask_kernel<1>) : VG_GO(gom, loglik_paths_mask_kernel<0>);
         }
         lds = (size_t)(pfx ? 4 : 3) * L * kLikBatchBlock * sizeof(float);
         if (pfx) {
-            if (sig) return far ? go(loglik_paths_kernel<1, kLikBatchBlock, true, true, true, true>) : go(loglik_paths_kernel<1, kLikBatchBlock, true, false, true, true>);
-            return far ? go(loglik_paths_kernel<1, kLikBatchBlock, false, true, true, true>) : go(loglik_paths_kernel<1, kLikBatchBlock, false, false, true, true>);
+            if (sig) return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, true, true, true>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, false, true, true>);
+            return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, true, true, true>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, false, true, true>);
         }
-        if (sig) return far ? go(loglik_paths_kernel<1, kLikBatchBlock, true, true, true>) : go(loglik_paths_kernel<1, kLikBatchBlock, true, false, true>);
-        return far ? go(loglik_paths_kernel<1, kLikBatchBlock, false, true, true>) : go(loglik_paths_kernel<1, kLikBatchBlock, false, false, true>);
+        if (sig) return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, true, true>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, false, true>);
+        return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, true, true>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, false, true>);
     }
-    if (sig) return far ? go(loglik_paths_kernel<1, kLikBatchBlock, true, true>) : go(loglik_paths_kernel<1, kLikBatchBlock, true, false>);
-    return far ? go(loglik_paths_kernel<1, kLikBatchBlock, false, true>) : go(loglik_paths_kernel<1, kLikBatchBlock, false, false>);
+    if (sig) return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, true>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, false>);
+    return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, true>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, false>);
 }
+#undef VG_GO

@@ -380,13 +380,13 @@ int vg_launch_rng(const vgpmp_dims* d, const vgpmp_noise* nz, uint32_t seed, uin
     const int P = d->num_problems;
     RngArgs r = make_rng_args(d, nz, seed, problem_base, step, ctr, 0u);
     r.epsT = epsT; r.eps2T = eps2T;
-    hipLaunchKernelGGL(rng_basis_kernel, dim3((r.L * r.B + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
+    VG_GGL(rng_basis_kernel, dim3((r.L * r.B + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
     if (epsT) {      // eps / eps' in both layouts by their own launch, w alone by the other
-        hipLaunchKernelGGL(rng_eps_t_kernel, dim3(rng_eps_t_blocks((uint32_t)r.S * r.Mz), P), dim3(kBlock), 0, st, r);
+        VG_GGL(rng_eps_t_kernel, dim3(rng_eps_t_blocks((uint32_t)r.S * r.Mz), P), dim3(kBlock), 0, st, r);
         r.nE = 0;
     }
     const uint32_t nthr = rng_normal_threads(r.nW, r.nE, r.eOff);
-    if (nthr) hipLaunchKernelGGL(rng_normals_kernel, dim3((nthr + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
+    if (nthr) VG_GGL(rng_normals_kernel, dim3((nthr + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
     return (int)hipGetLastError();
 }
 
@@ -407,7 +407,7 @@ int vg_launch_adam(const vgpmp_dims* d, const vgpmp_params* x, const vgpmp_param
     if (trainable & VGPMP_TRAIN_Q_SQRT) go(P * L * M * M, x->q_sqrt, g->q_sqrt, am->q_sqrt, av->q_sqrt, (int)M);
     if (trainable & VGPMP_TRAIN_LENGTHSCALES) go(P * L, x->raw_ell, g->raw_ell, am->raw_ell, av->raw_ell, 0);
     if (trainable & VGPMP_TRAIN_KERNEL_VARIANCE) go(P * L, x->raw_var, g->raw_var, am->raw_var, av->raw_var, 0);
-    if (aa.nseg > 0 && aa.first_block[aa.nseg] > 0) hipLaunchKernelGGL(adam_all_kernel, dim3(aa.first_block[aa.nseg]), dim3(kBlock), 0, st, aa);
+    if (aa.nseg > 0 && aa.first_block[aa.nseg] > 0) VG_GGL(adam_all_kernel, dim3(aa.first_block[aa.nseg]), dim3(kBlock), 0, st, aa);
     return (int)hipGetLastError();
 }
 
@@ -416,26 +416,29 @@ static int set_dyn_lds(const void* fn, size_t bytes) { return vg_grant_dyn_lds(f
 // `num_steps` consecutive steps.  Few problems (and not under the per-stage profiler): the role-dispatched
 // stage launches above, with the variational-parameter update of step t riding in stage 1 of step t+1.
 // Many problems: every kernel fills the chip by itself, plain launches in sequence.
-// Fork / join events of an auxiliary stream (vgpmp_problem.aux_stream), created once per stream and kept: an event pair per call
-// would cost two host calls per step.  Guarded like the dynamic-LDS table (several host threads may drive several GPUs).
-static int vg_aux_events(hipStream_t aux, hipEvent_t* fork, hipEvent_t* join) {
+// Fork / join events of an auxiliary stream (vgpmp_problem.aux_stream), created once per (calling stream, auxiliary stream) pair
+// and kept: an event pair per call would cost two host calls per step.  Keyed by BOTH streams: planners of one scene share its
+// auxiliary stream, and two host threads stepping them on different calling streams must not record into each other's fork
+// event between a record and its wait.  (Two threads on the SAME calling stream are the caller's race, as with any stream.)
+// Guarded like the dynamic-LDS table (several host threads may drive several GPUs).
+static int vg_aux_events(hipStream_t main_st, hipStream_t aux, hipEvent_t* fork, hipEvent_t* join) {
     constexpr int kSlots = 64;
-    static hipStream_t streams[kSlots];
+    static hipStream_t mains[kSlots], streams[kSlots];
     static hipEvent_t evs[kSlots][2];
     static int next = 0;
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
     for (int i = 0; i < kSlots; ++i)
-        if (streams[i] == aux && evs[i][0]) { *fork = evs[i][0]; *join = evs[i][1]; return 0; }
-    // a new stream: the next slot round robin (a process that has gone through more than kSlots auxiliary streams reuses the
-    // events of the oldest one -- events belong to no stream, and a caller that still uses that stream gets a fresh pair)
+        if (streams[i] == aux && mains[i] == main_st && evs[i][0]) { *fork = evs[i][0]; *join = evs[i][1]; return 0; }
+    // a new pair: the next slot round robin (a process that has gone through more than kSlots pairs reuses the events of the
+    // oldest one -- events belong to no stream, and a caller that still uses that pair gets a fresh slot)
     const int i = next;
     next = (next + 1) % kSlots;
     if (!evs[i][0]) {
         VG_CHECK_HIP(hipEventCreateWithFlags(&evs[i][0], hipEventDisableTiming));
         VG_CHECK_HIP(hipEventCreateWithFlags(&evs[i][1], hipEventDisableTiming));
     }
-    streams[i] = aux;
+    streams[i] = aux; mains[i] = main_st;
     *fork = evs[i][0]; *join = evs[i][1];
     return 0;
 }
@@ -593,12 +596,12 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const bool fin_split = fin_dma && Mz % (4 * kFinSplit) == 0 && (size_t)(M + M * (Mz / kFinSplit)) <= 2 * kBlock &&
                            !(what & VGPMP_NO_SPLIT);
     const size_t lds_s1 = lds_cov_a > lds_fin ? lds_cov_a : lds_fin;
-    const void* fn_cov_b = backward ? (const void*)cov_b_kernel<true> : (const void*)cov_b_kernel<false>;
+    const void* fn_cov_b = backward ? VG_FN(cov_b_kernel<true>) : VG_FN(cov_b_kernel<false>);
     const bool k8 = (B / SK) % 128 == 0;      // K-slice in passes of 8 steps of 16: a pass's operands in one request
     // K-slices of a multiple of 128 and enough samples: operands through LDS by DMA (needs 59 KB per workgroup)
     const bool glds = (B / SK) % kGK == 0 && S >= 48 && !(what & VGPMP_GEMM_DIRECT);      // 64-row tiles: few samples waste them
     const bool gemm_first = SK == 1;      // whole-K tiles (3 problems up) are the longest workgroups of stage 2: at its front
-#define VG_S2(T, K) (gemm_first ? (const void*)stage2_gemm_first_kernel<T, K> : (const void*)stage2_kernel<T, K>)
+#define VG_S2(T, K) (gemm_first ? VG_FN(stage2_gemm_first_kernel<T, K>) : VG_FN(stage2_kernel<T, K>))
     // many samples (the sample-sharded job on few ranks): the GEMM role is the step -- its products on the f16 matrix pipe
     const bool glds16 = glds && S >= kGemmF16MinSamples && !(what & VGPMP_PRIOR_F32);
     const void* fn_s2 = glds16 ? (backward ? VG_S2(true, -2) : VG_S2(false, -2))
@@ -608,10 +611,10 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     size_t lds_s2 = glds && kGemmLds > lds_cov_b ? kGemmLds : lds_cov_b;
     if (SC != 8) return VGPMP_E_SHAPE;
 #define VG_PICK(kernel, raw)                                                                                        \
-    (SK == 1 ? (raw ? (const void*)kernel<1, true> : (const void*)kernel<1, false>)                                 \
-     : SK == 2 ? (raw ? (const void*)kernel<2, true> : (const void*)kernel<2, false>)                               \
-     : SK == 4 ? (raw ? (const void*)kernel<4, true> : (const void*)kernel<4, false>)                               \
-               : (raw ? (const void*)kernel<8, true> : (const void*)kernel<8, false>))
+    (SK == 1 ? (raw ? VG_FN(kernel<1, true>) : VG_FN(kernel<1, false>))                                 \
+     : SK == 2 ? (raw ? VG_FN(kernel<2, true>) : VG_FN(kernel<2, false>))                               \
+     : SK == 4 ? (raw ? VG_FN(kernel<4, true>) : VG_FN(kernel<4, false>))                               \
+               : (raw ? VG_FN(kernel<8, true>) : VG_FN(kernel<8, false>)))
     const void* fn_pf = VG_PICK(paths_fwd_sc8, raw_fwd);
     const void* fn_s3 = VG_PICK(stage3_kernel, raw_fwd);
     const void* fn_pb = VG_PICK(paths_bwd_sc8, raw_bwd);
@@ -633,48 +636,48 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                            !(what & (VGPMP_LIK_LANES | VGPMP_LIK_LDS_STATE | VGPMP_NO_SPLIT)) && vg_lik_paths_fit(L, SK) &&
                            (long long)P * S * N <= 28672;
     ca.form_u = lik_paths ? 1 : 0; ca.S = S; ca.eps = ws->epsT;
-    const void* fn_s4 = SK == 2 ? (const void*)stage4_kernel<2, 32> : SK == 4 ? (const void*)stage4_kernel<4, 32> : (const void*)stage4_kernel<8, 32>;
+    const void* fn_s4 = SK == 2 ? VG_FN(stage4_kernel<2, 32>) : SK == 4 ? VG_FN(stage4_kernel<4, 32>) : VG_FN(stage4_kernel<8, 32>);
     if (split_bwd) {
-        fn_pb = Mz == 32 ? (SK == 2 ? (const void*)paths_bwd_split<2, 32> : SK == 4 ? (const void*)paths_bwd_split<4, 32>
-                                                                                        : (const void*)paths_bwd_split<8, 32>)
-                         : (SK == 2 ? (const void*)paths_bwd_split<2> : SK == 4 ? (const void*)paths_bwd_split<4>
-                                                                                  : (const void*)paths_bwd_split<8>);
+        fn_pb = Mz == 32 ? (SK == 2 ? VG_FN(paths_bwd_split<2, 32>) : SK == 4 ? VG_FN(paths_bwd_split<4, 32>)
+                                                                                        : VG_FN(paths_bwd_split<8, 32>))
+                         : (SK == 2 ? VG_FN(paths_bwd_split<2>) : SK == 4 ? VG_FN(paths_bwd_split<4>)
+                                                                                  : VG_FN(paths_bwd_split<8>));
         lds_pb = lds_pbs;
     }
     // large batches: the latent's constants in registers, pairs of chunks through 40 KB of LDS (paths_bwd_regs)
     const bool regs_bwd = backward && !split_bwd && SK == 1 && Mz == 32 && (N & 3) == 0 && N <= 100 && pa.cpw >= 2;
     if (regs_bwd) {
-        fn_pb = (const void*)paths_bwd_regs<25>;
+        fn_pb = VG_FN(paths_bwd_regs<25>);
         lds_pb = ((size_t)kPbrBufs * (16 * N + 32 * J + 2 * 16 * Mz + 16) + (size_t)6 * 16 * Mz + 8 * 4) * sizeof(float);
     }
     // ... and the forward assembly likewise (paths_fwd_regs); both take pa.cpw chunks per workgroup
     const bool regs_fwd = !fused && !split_fwd && SK == 1 && Mz == 32 && N <= 128 && pa.cpw >= 2;
     if (regs_fwd) {
-        fn_pf = (const void*)paths_fwd_regs<2>;
+        fn_pf = VG_FN(paths_fwd_regs<2>);
         lds_pf = ((size_t)16 * (3 * Mz + J) + 4 * 4) * sizeof(float);
     }
     if (backward && (rc = set_dyn_lds(fn_pb, lds_pb))) return rc;      // forward-only calls never launch the reverse pass
     if (lik_paths && (rc = set_dyn_lds(fn_s4, lds_pb))) return rc;
     if (fused) {
-        if ((rc = set_dyn_lds((const void*)stage1_kernel<false>, lds_s1))) return rc;
-        if ((rc = set_dyn_lds((const void*)stage1_kernel<true>, lds_s1))) return rc;
+        if ((rc = set_dyn_lds(VG_FN(stage1_kernel<false>), lds_s1))) return rc;
+        if ((rc = set_dyn_lds(VG_FN(stage1_kernel<true>), lds_s1))) return rc;
         if (lik_paths && lds_cov_b + (size_t)S * Mz * sizeof(float) > lds_s2) lds_s2 = lds_cov_b + (size_t)S * Mz * sizeof(float);
         if ((rc = set_dyn_lds(fn_s2, lds_s2))) return rc;
         if ((rc = set_dyn_lds(fn_s3, lds_pf))) return rc;
     } else {
-        if ((rc = set_dyn_lds((const void*)cov_a_kernel, lds_cov_a))) return rc;
-        if (glds && (rc = set_dyn_lds((const void*)prior_gemm_lds_kernel, kGemmLds))) return rc;
+        if ((rc = set_dyn_lds(VG_FN(cov_a_kernel), lds_cov_a))) return rc;
+        if (glds && (rc = set_dyn_lds(VG_FN(prior_gemm_lds_kernel), kGemmLds))) return rc;
         if ((rc = set_dyn_lds(fn_cov_b, lds_cov_b))) return rc;
         if ((rc = set_dyn_lds(fn_pf, lds_pf))) return rc;
     }
-    if ((rc = set_dyn_lds((const void*)final_kernel, lds_fin))) return rc;
+    if ((rc = set_dyn_lds(VG_FN(final_kernel), lds_fin))) return rc;
     // medium batches: merged launches (not while profiling stage by stage, not with the shared stage launches)
     // measured on config 2 shapes: 5 problems 197 -> 182 us per step, 9: 218 -> 205, 16: equal, 24 and 64: 2-6 % slower
     // (the chip is full by then, the merged kernels only cost registers) -- hence the bound
     // few samples, four K-slices: features inside the GEMM (prior_fused_small_kernel)
     const bool fused_small = !fused && SK == 4 && S <= 32 && (B % 64) == 0 && !(what & VGPMP_GEMM_DIRECT);
-    if (!fused && (rc = set_dyn_lds((const void*)mid_cov_a_rng_kernel, lds_cov_a))) return rc;      // (the large-batch schedule merges its small launches with these two as well)
-    if ((rc = set_dyn_lds((const void*)mid_hyper_final_kernel, lds_fin))) return rc;
+    if (!fused && (rc = set_dyn_lds(VG_FN(mid_cov_a_rng_kernel), lds_cov_a))) return rc;      // (the large-batch schedule merges its small launches with these two as well)
+    if ((rc = set_dyn_lds(VG_FN(mid_hyper_final_kernel), lds_fin))) return rc;
     const dim3 cov_b_grid(kCovFixedRoles + (ca.rows_wave ? (N + 63) / 64 : (row_tiles + rows_tpw - 1) / rows_tpw), L, P);
     // eps / eps' also as [P,L,S,Mz] wherever a consumer stages them per latent (the register-resident path kernels, stage B's U
     // role): drawn by rng_eps_t_body then, kEpsRows rows of (s, k) per workgroup
@@ -697,6 +700,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const uint32_t w_gx = (((uint32_t)S * L * B >> 3) + kBlock - 1) / kBlock;      // a thread per counter of the W stream: eight normals
     auto launch = [&](const void* fn, dim3 grid, void* arg, size_t lds) -> int {
         void* kargs[] = {arg};
+        vg_sched_note_fn(fn);
         return (int)hipLaunchKernel(fn, grid, dim3(kBlock), kargs, lds, st);
     };
     auto launch_fused_small = [&](hipEvent_t g0, hipEvent_t g1) {
@@ -707,17 +711,17 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         fp.tick = fe.tick;
         const dim3 fgrid(P * L, (J + kFNT * 16 - 1) / (kFNT * 16));
 #define VG_FUSED_SMALL(MT_, DM_)                                            \
-    (want_dell ? (void)hipExtLaunchKernelGGL((prior_fused_small_kernel<MT_, DM_, true>), fgrid, dim3(kBlock), 0, st, g0, g1, \
+    (want_dell ? VG_EXT_GGL((prior_fused_small_kernel<MT_, DM_, true>), fgrid, dim3(kBlock), 0, st, g0, g1, \
                              0, fp)                                  \
-               : (void)hipExtLaunchKernelGGL((prior_fused_small_kernel<MT_, DM_, false>), fgrid, dim3(kBlock), 0, st, g0, g1, \
+               : VG_EXT_GGL((prior_fused_small_kernel<MT_, DM_, false>), fgrid, dim3(kBlock), 0, st, g0, g1, \
                              0, fp))
         // the f16-split form (gp_prior_split.h): K steps of 32 bases (every K-slice a multiple of that); the float32-MFMA kernel
         // stays behind VGPMP_PRIOR_F32, as for the large batches
         if (!(what & VGPMP_PRIOR_F32) && (B / 4) % kHK == 0) {
 #define VG_FUSED_SMALL16(MT_, DM_)                                            \
-    (want_dell ? (void)hipExtLaunchKernelGGL((prior_fused_small16_kernel<MT_, DM_, true>), fgrid, dim3(kBlock), 0, st, g0, g1, \
+    (want_dell ? VG_EXT_GGL((prior_fused_small16_kernel<MT_, DM_, true>), fgrid, dim3(kBlock), 0, st, g0, g1, \
                              0, fp)                                  \
-               : (void)hipExtLaunchKernelGGL((prior_fused_small16_kernel<MT_, DM_, false>), fgrid, dim3(kBlock), 0, st, g0, g1, \
+               : VG_EXT_GGL((prior_fused_small16_kernel<MT_, DM_, false>), fgrid, dim3(kBlock), 0, st, g0, g1, \
                              0, fp))
             if (L == 7) { if (S <= 16) VG_FUSED_SMALL16(1, 7); else VG_FUSED_SMALL16(2, 7); }
             else if (L == 6) { if (S <= 16) VG_FUSED_SMALL16(1, 6); else VG_FUSED_SMALL16(2, 6); }
@@ -738,13 +742,13 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const bool fin_split_batch = fin_split && (size_t)L * P <= 128;
     fa.split = fin_split_batch ? 1 : 0;
     bool batch_merged = false;      // this call's steps run the large-batch schedule with its small launches merged
-    auto launch_final = [&]() -> int { return launch((const void*)final_kernel, dim3(L * (fin_split_batch ? kFinSplit : 1), P), &fa, lds_fin); };
+    auto launch_final = [&]() -> int { return launch(VG_FN(final_kernel), dim3(L * (fin_split_batch ? kFinSplit : 1), P), &fa, lds_fin); };
     // likelihood constants as variables (vgpmp_lik_params): effective values from the raw ones at the start of the call
     LikUpdArgs lu;
     if (lk) {
         LikConstArgs lc;
         lc.raw_alpha = lk->raw_alpha; lc.raw_sigma = lk->raw_sigma; lc.sc = lsc; lc.inv_s = 1.0 / (double)d->S_total;
-        hipLaunchKernelGGL(lik_consts_kernel, dim3(P), dim3(VGPMP_MAX_SPHERES), 0, st, lc);
+        VG_GGL(lik_consts_kernel, dim3(P), dim3(VGPMP_MAX_SPHERES), 0, st, lc);
         lu.rb = rb; lu.lik_partial = ws->lik_partial; lu.sig_partial = lsc.sig_partial; lu.nblk = 0;
         lu.inv_s = lc.inv_s;
         lu.raw_alpha = lk->raw_alpha; lu.raw_sigma = lk->raw_sigma; lu.m_alpha = lk->m_alpha; lu.v_alpha = lk->v_alpha;
@@ -758,6 +762,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     lpa.eps2 = nz->eps2; lpa.R = ws->R; lpa.f = out->f;
     for (int i = 0; i < num_steps; ++i) {
         const bool first = i == 0, more = i + 1 < num_steps;
+        vg_sched_clear();      // (include/vgpmp_debug.h: the log holds the launches of the call's last step)
         bool draw_next = false;      // (lik_paths) the reverse path launch also draws the next step's omega, beta, w
         const uint32_t step_i = step + (uint32_t)i;
         if (ind && (rc = vg_launch_inducing_build(d, ind, st))) return rc;       // Zy = [0; 1; Z(raw_Z)] of every problem
@@ -792,7 +797,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             s1.feat_gx = (int)feat_grid.x; s1.feat_gy = (int)feat_grid.y;
             s1.n_feat = (int)(feat_grid.x * feat_grid.y * feat_grid.z);
             const unsigned n1 = s1.n_cov + s1.n_fin + s1.n_eps + feat_grid.x * feat_grid.y * feat_grid.z;
-            if ((rc = launch(prologue ? (const void*)stage1_kernel<true> : (const void*)stage1_kernel<false>, dim3(n1), &s1, lds_s1)))
+            if ((rc = launch(prologue ? VG_FN(stage1_kernel<true>) : VG_FN(stage1_kernel<false>), dim3(n1), &s1, lds_s1)))
                 return rc;
             Stage2Args s2;
             s2.skip = skip2;
@@ -834,9 +839,9 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 if (fbatch) ma.rng.nW = 0;               // omega, beta, eps, eps2 only
                 ma.n_cov = L * P; ma.basis_gx = (int)((ma.rng.L * ma.rng.B + kBlock - 1) / kBlock); ma.n_basis = ma.basis_gx * P;
                 const unsigned n_draw = mid_normal_grid(ma);
-                if ((rc = launch((const void*)mid_cov_a_rng_kernel, dim3(ma.n_cov + ma.n_basis + n_draw), &ma, lds_cov_a))) return rc;
+                if ((rc = launch(VG_FN(mid_cov_a_rng_kernel), dim3(ma.n_cov + ma.n_basis + n_draw), &ma, lds_cov_a))) return rc;
             } else {
-                hipLaunchKernelGGL(cov_a_kernel, dim3(L, P), dim3(kCovThreads), lds_cov_a, st, ca);
+                VG_GGL(cov_a_kernel, dim3(L, P), dim3(kCovThreads), lds_cov_a, st, ca);
             }
             // stage B of the covariance path beside the prior draws on the caller's auxiliary stream: independent of each other,
             // both need only stage A | noise; joined before the path assembly.  (Merged into ONE launch the float64 roles queued
@@ -849,10 +854,11 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             hipEvent_t ev_fork = nullptr, ev_join = nullptr;
             if (cov_aside) {
                 hipStream_t aux = (hipStream_t)pb->aux_stream;
-                if ((rc = vg_aux_events(aux, &ev_fork, &ev_join))) return rc;
+                if ((rc = vg_aux_events(st, aux, &ev_fork, &ev_join))) return rc;
                 VG_CHECK_HIP(hipEventRecord(ev_fork, st));
                 VG_CHECK_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
                 void* kargs[] = {&ca};
+                vg_sched_note_fn(fn_cov_b);
                 VG_CHECK_HIP(hipLaunchKernel(fn_cov_b, cov_b_grid, dim3(kBlock), kargs, lds_cov_b, aux));
                 VG_CHECK_HIP(hipEventRecord(ev_join, aux));
             } else if ((rc = launch(fn_cov_b, cov_b_grid, &ca, lds_cov_b))) return rc;
@@ -861,17 +867,17 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             if (gen && !batch_merge) {
                 RngArgs r = make_rng_args(d, nz, seed, problem_base, step_i, ctr, 0u);
                 if (fbatch) r.nW = 0;                    // omega, beta, eps, eps2 only
-                hipLaunchKernelGGL(rng_basis_kernel, dim3((r.L * r.B + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
+                VG_GGL(rng_basis_kernel, dim3((r.L * r.B + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
                 if (eps_t) {
                     r.epsT = ws->epsT; r.eps2T = ws->eps2T;
-                    hipLaunchKernelGGL(rng_eps_t_kernel, dim3(rng_eps_t_blocks((uint32_t)S * Mz), P), dim3(kBlock), 0, st, r);
+                    VG_GGL(rng_eps_t_kernel, dim3(rng_eps_t_blocks((uint32_t)S * Mz), P), dim3(kBlock), 0, st, r);
                     r.nE = 0;
                 }
                 const uint32_t nthr = rng_normal_threads(r.nW, r.nE, r.eOff);
-                if (nthr) hipLaunchKernelGGL(rng_normals_kernel, dim3((nthr + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
+                if (nthr) VG_GGL(rng_normals_kernel, dim3((nthr + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
             }
             mark();
-            if (!fused_small && !fbatch) hipLaunchKernelGGL(features_kernel, feat_grid, dim3(kBlock), 0, st, fe);
+            if (!fused_small && !fbatch) VG_GGL(features_kernel, feat_grid, dim3(kBlock), 0, st, fe);
             mark();
             hipEvent_t g0 = ev ? ev[VG_NUM_STAGES + 3] : nullptr, g1 = ev ? ev[VG_NUM_STAGES + 4] : nullptr;
             if (fbatch) {
@@ -903,8 +909,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                     const dim3 hgrid((J + kTJ - 1) / kTJ, (S + kTS * hmt - 1) / (kTS * hmt), P * L);
 #define VG_FH(DELL_, MT_)                                                                                                 \
     do {                                                                                                                  \
-        if ((rc = set_dyn_lds((const void*)prior_fused_split_kernel<DELL_, MT_>, lds_h))) return rc;                      \
-        hipExtLaunchKernelGGL((prior_fused_split_kernel<DELL_, MT_>), hgrid, dim3(kHThreads), lds_h, st, g0, g1, 0, fb);   \
+        if ((rc = set_dyn_lds(VG_FN(prior_fused_split_kernel<DELL_, MT_>), lds_h))) return rc;                      \
+        VG_EXT_GGL((prior_fused_split_kernel<DELL_, MT_>), hgrid, dim3(kHThreads), lds_h, st, g0, g1, 0, fb);   \
     } while (0)
                     if (want_dell) { if (hmt == 2) VG_FH(true, 2); else VG_FH(true, 1); }
                     else { if (hmt == 2) VG_FH(false, 2); else VG_FH(false, 1); }
@@ -912,29 +918,29 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 } else {
 #define VG_FB(DELL_, DM_)                                                                                                 \
     do {                                                                                                                  \
-        if (fmt == 2) hipExtLaunchKernelGGL((prior_fused_batch_kernel<DELL_, DM_, 2>), fb_grid, dim3(kBlock), lds_fb, st, g0, g1, 0, fb); \
-        else hipExtLaunchKernelGGL((prior_fused_batch_kernel<DELL_, DM_, 1>), fb_grid, dim3(kBlock), lds_fb, st, g0, g1, 0, fb);          \
+        if (fmt == 2) VG_EXT_GGL((prior_fused_batch_kernel<DELL_, DM_, 2>), fb_grid, dim3(kBlock), lds_fb, st, g0, g1, 0, fb); \
+        else VG_EXT_GGL((prior_fused_batch_kernel<DELL_, DM_, 1>), fb_grid, dim3(kBlock), lds_fb, st, g0, g1, 0, fb);          \
     } while (0)
                     if (want_dell) { if (dm == 8) VG_FB(true, 8); else VG_FB(true, 16); }
                     else { if (dm == 8) VG_FB(false, 8); else VG_FB(false, 16); }
 #undef VG_FB
                 }
                 if (fe.tick && batch_merge) pa.tick = fe.tick;      // the feature kernel's tick: by paths_fwd (next launch), or alone
-                else if (fe.tick) hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(1), 0, st, fe.tick);
+                else if (fe.tick) VG_GGL(tick_kernel, dim3(1), dim3(1), 0, st, fe.tick);
             } else if (fused_small) {      // features formed inside the GEMM (few samples: Phi / dPhi traffic is the cost)
                 launch_fused_small(g0, g1);
             } else if (tiled_gemm) {
                 const int mt = 1;      // 128-sample tiles (mt = 2) measured slower: 90 vs 98 TF/s at 64 problems
                 const size_t lds_tg = (size_t)2 * (kTS * mt + kTJ) * kTLd * sizeof(float);
-                const void* fn_tg = mt == 2 ? (const void*)prior_gemm_tiled_kernel<2> : (const void*)prior_gemm_tiled_kernel<1>;
+                const void* fn_tg = mt == 2 ? VG_FN(prior_gemm_tiled_kernel<2>) : VG_FN(prior_gemm_tiled_kernel<1>);
                 if ((rc = set_dyn_lds(fn_tg, lds_tg))) return rc;
                 const dim3 tg_grid((J + kTJ - 1) / kTJ, (S + kTS * mt - 1) / (kTS * mt), P * L * ga.nsel);
-                if (mt == 2) hipExtLaunchKernelGGL(prior_gemm_tiled_kernel<2>, tg_grid, dim3(kBlock), lds_tg, st, g0, g1, 0, tga);
-                else hipExtLaunchKernelGGL(prior_gemm_tiled_kernel<1>, tg_grid, dim3(kBlock), lds_tg, st, g0, g1, 0, tga);
+                if (mt == 2) VG_EXT_GGL(prior_gemm_tiled_kernel<2>, tg_grid, dim3(kBlock), lds_tg, st, g0, g1, 0, tga);
+                else VG_EXT_GGL(prior_gemm_tiled_kernel<1>, tg_grid, dim3(kBlock), lds_tg, st, g0, g1, 0, tga);
             } else if (glds)
-                hipExtLaunchKernelGGL(prior_gemm_lds_kernel, gemm_grid, dim3(kBlock), kGemmLds, st, g0, g1, 0, ga);
+                VG_EXT_GGL(prior_gemm_lds_kernel, gemm_grid, dim3(kBlock), kGemmLds, st, g0, g1, 0, ga);
             else
-                hipExtLaunchKernelGGL(prior_gemm_kernel<0>, gemm_grid, dim3(kBlock), 0, st, g0, g1, 0, ga);
+                VG_EXT_GGL(prior_gemm_kernel<0>, gemm_grid, dim3(kBlock), 0, st, g0, g1, 0, ga);
             mark();
             if (cov_aside) VG_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
             if ((rc = launch(fn_pf, dim3(regs_fwd ? (NC + pa.cpw - 1) / pa.cpw : NC * pa.nsplit, L, P), &pa, lds_pf))) return rc;
@@ -953,7 +959,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         fa.nblk = nblk;
         mark();
         if (!backward) {
-            hipLaunchKernelGGL(elbo_pieces_kernel, dim3(P), dim3(kBlock), 0, st, L, nblk, ws->lik_partial, ws->kl_l, lik_scale,
+            VG_GGL(elbo_pieces_kernel, dim3(P), dim3(kBlock), 0, st, L, nblk, ws->lik_partial, ws->kl_l, lik_scale,
                                pb->kl_scale, out->lik, out->kl, fa.alpha_fin);
             return (int)hipGetLastError();
         }
@@ -980,7 +986,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         if (lk) {      // trainable likelihood constants: their gradient / update, and the constants of the next step
             lu.nblk = nblk;
             lu.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
-            hipLaunchKernelGGL(lik_update_kernel, dim3(P), dim3(kLikUpdWaves * VGPMP_MAX_SPHERES), 0, st, lu);
+            VG_GGL(lik_update_kernel, dim3(P), dim3(kLikUpdWaves * VGPMP_MAX_SPHERES), 0, st, lu);
         }
         mark();
         if (batch_merged || (fused && !more)) {      // (fused, more steps to come: both ride in stage 1 of the next step)
@@ -988,11 +994,11 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             hy.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
             fa.lr_t = hy.lr_t;
             mg.hy = hy; mg.fin = fa; mg.n_hyper = P;
-            if ((rc = launch((const void*)mid_hyper_final_kernel, dim3(P + L * P * (fin_split_batch ? kFinSplit : 1)), &mg, lds_fin))) return rc;
+            if ((rc = launch(VG_FN(mid_hyper_final_kernel), dim3(P + L * P * (fin_split_batch ? kFinSplit : 1)), &mg, lds_fin))) return rc;
         } else if (!fused) {
             hy.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
             fa.lr_t = hy.lr_t;
-            hipLaunchKernelGGL(hyper_kernel, dim3(P), dim3(64), 0, st, hy);
+            VG_GGL(hyper_kernel, dim3(P), dim3(64), 0, st, hy);
             if ((rc = launch_final())) return rc;
         }
         mark();

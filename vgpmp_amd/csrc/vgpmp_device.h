@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <mutex>
-#include "vgpmp.h"
+#include "vgpmp_debug.h"
 
 #define VG_WAVE 64
 
@@ -258,7 +258,7 @@ __device__ __forceinline__ float4 vg_normal4(uint32_t i, uint32_t stream, uint2 
 // The W stream (prior weights: by far the largest draw of a step, S L B normals per problem) spends ONE counter per EIGHT
 // normals: every 32-bit word of the Philox block gives one Box-Muller pair from two 16-bit uniforms, radius from the low half,
 // angle from the high half, u = (h + 1/2) 2^-16.  (Element 8 i + 2 j + {0, 1} of the stream comes from word j of counter i.)
-// Sixteen bits put 65 536 radii x 65 536 directions under every pair and bound |z| by 4.71; mean 0 exactly (the directions are
+// Sixteen bits put 65 536 radii x 65 536 directions under every pair and bound |z| by 4.855; mean 0 exactly (the directions are
 // symmetric), variance 1 - 4e-6.  Identical restatement: oracle/vgpmp_oracle.py::philox_normals8.
 __device__ __forceinline__ float vg_u01_16(uint32_t h) { return ((float)h + 0.5f) * 1.52587890625e-05f; }
 __device__ __forceinline__ void vg_normal8_from(uint4 r, float (&z)[8]) {
@@ -308,6 +308,18 @@ inline int vg_grant_dyn_lds(const void* fn, size_t bytes) {
     if (slot >= 0) granted[slot] = bytes;
     return 0;
 }
+
+// ---- schedule log (include/vgpmp_debug.h: vgpmp_debug_last_schedule) ---------------------------------------------
+// Per host thread: the names of the kernels a step enqueued, as written at the launch site (template arguments included; the
+// profiler prints the same text).  A push of a string pointer per launch -- nothing on the device.
+void vg_sched_clear();                                      // a new step begins
+void vg_sched_note(const char* name);                       // "(kernel<...>)" or "kernel<...>"
+const void* vg_fn_reg(const void* fn, const char* name);    // remembers the name of a kernel's host pointer, returns the pointer
+void vg_sched_note_fn(const void* fn);                      // a launch through such a pointer
+#define VG_FN(...) ([]() -> const void* { static const void* p_ = vg_fn_reg((const void*)(__VA_ARGS__), #__VA_ARGS__); return p_; }())
+#define VG_GGL(kernel, ...) do { vg_sched_note(#kernel); hipLaunchKernelGGL(kernel, __VA_ARGS__); } while (0)
+#define VG_EXT_GGL(kernel, ...) (vg_sched_note(#kernel), (void)hipExtLaunchKernelGGL(kernel, __VA_ARGS__))
+int vg_launch_sphere_centres(const vgpmp_robot* rb, const float* f, int P, int S, int L, int N, int form, float* pos, hipStream_t st);
 
 // launchers implemented in the .hip files
 int vg_launch_sdf_pack(const vgpmp_sdf* sdf, const double* rows, int row_lo, int row_hi, int x0, int x1, hipStream_t st);

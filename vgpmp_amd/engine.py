@@ -338,8 +338,9 @@ class PlannerBatch:
         self.extra_flags = 0      # e.g. capi.NO_SPLIT (measurement)
         # the f16-split prior kernel of large batches keeps x, omega and x . omega as f16 pairs: its range argument assumes time
         # stamps of order one (init_trainset: [0, 1]).  Stamps far outside that go to the float32-MFMA form instead.
-        if float(np.abs(Xn).max()) > 16.0:
-            self.extra_flags |= capi.PRIOR_F32
+        self._f32_by_stamps = False
+        self._guard_time_stamps(Xn)
+        self._fused_by_what = {}      # `what` -> did the library run the few-problem schedule (asked of it once: _run)
         self._graph = None
         self._graph_unroll = 0
         # the step whose omega / beta / w a call with VGPMP_NOISE_AHEAD has left in the noise buffers (None: nobody's); every
@@ -347,6 +348,23 @@ class PlannerBatch:
         self.noise_ahead_step = None
         self._initial = [(t, t.clone()) for t in self._variables()]
         self._pack()
+
+    def _guard_time_stamps(self, Xn) -> None:
+        """Whenever the time stamps change: |X| > 16 sends the prior draws of large batches to the float32-MFMA form (the
+        f16-split kernel's range argument assumes stamps of order one); back below the bound the guard's own flag goes again."""
+        far = float(np.abs(np.asarray(Xn, dtype=np.float64)).max()) > 16.0
+        if far and not (self.extra_flags & capi.PRIOR_F32):
+            self.extra_flags |= capi.PRIOR_F32
+            self._f32_by_stamps = True
+        elif not far and self._f32_by_stamps:
+            self.extra_flags &= ~capi.PRIOR_F32
+            self._f32_by_stamps = False
+
+    def set_time_stamps(self, Xn) -> None:
+        """Replace X [N, L] (same N) on the device; re-evaluates the range guard of the f16-split prior kernel."""
+        Xn = np.asarray(Xn, dtype=np.float64).reshape(tuple(self.X.shape))
+        self._guard_time_stamps(Xn)
+        self.X.copy_(torch.as_tensor(Xn, dtype=torch.float64))
 
     def _variables(self):
         """Every unconstrained variable this planner may train (the optional ones only when they exist)."""
@@ -424,12 +442,30 @@ class PlannerBatch:
         if (what & capi.NOISE_READY) and self.noise_ahead_step != int(step):
             what &= ~capi.NOISE_READY          # the buffers hold another step's draws (or none): this call draws its own
         ahead = bool(what & capi.NOISE_AHEAD) and bool(what & capi.GEN_NOISE)
-        self.noise_ahead_step = int(step) + 1 if ahead else None
+        self.noise_ahead_step = None
         capi.check(self.lib.vgpmp_elbo_step(
             C.byref(self.dims), capi.ptr(self.scene.dev_robot), C.byref(self.scene.sdf), C.byref(self._problem),
             C.byref(self._params), C.byref(self._am), C.byref(self._av), C.byref(self._noise), C.byref(self._out),
             capi.ptr(self.workspace), self.workspace.numel(), what, trainable_mask(self.trainable), self.lr,
             max(self.t, 1), self.seed, self.problem_base, int(step), self.scene._stream()), "vgpmp_elbo_step")
+        if ahead:
+            # only the few-problem schedule draws ahead (the large-batch one ignores both noise flags): ask the library what it
+            # ran for this `what` -- once, the answer depends on nothing else -- instead of mirroring its rule here
+            key = what & ~capi.NOISE_READY
+            fused = self._fused_by_what.get(key)
+            if fused is None:
+                fused = self._fused_by_what[key] = any(n.startswith("stage1_kernel") for n in capi.last_schedule(self.lib))
+            if fused:
+                self.noise_ahead_step = int(step) + 1
+
+    def sphere_centres(self) -> torch.Tensor:
+        """include/vgpmp_debug.h, vgpmp_debug_sphere_centres: the float32 sphere centres [P, S, N, spheres, 3] the likelihood launch
+        of the last evaluation formed from self.f (same kernel form: same batch rule, same flags).  For parity tests."""
+        pos = torch.empty((self.P, self.S, self.N, self.scene.spec.num_spheres, 3), dtype=torch.float32, device=self.device)
+        what = (0 if self.fuse else capi.NO_FUSE) | self.extra_flags
+        capi.check(self.lib.vgpmp_debug_sphere_centres(capi.ptr(self.scene.dev_robot), capi.ptr(self.f), self.P, self.S, self.L,
+                                                       self.N, what, capi.ptr(pos), self.scene._stream()), "vgpmp_debug_sphere_centres")
+        return pos
 
     def elbo(self, generate: bool = True, step: Optional[int] = None) -> torch.Tensor:
         """VGPMP.elbo (models/vgpmp.py:265-289) for every problem: alpha * sum_n mean_s logp - KL."""
@@ -556,7 +592,7 @@ class PlannerBatch:
             child._pack()
             child._view_of = weakref.ref(self)                # (no strong reference: the view must not keep a planner alive)
         Xn = np.tile(np.linspace(0.0, 1.0, n_new)[:, None], (1, self.L)) if Xnew is None else np.asarray(Xnew, dtype=np.float64)
-        child.X.copy_(torch.as_tensor(Xn, dtype=torch.float64).reshape(child.X.shape))
+        child.set_time_stamps(Xn)
         return child
 
     def extract_plans(self, want_samples: bool = True, compute_uncertainty: bool = False):

@@ -265,7 +265,7 @@ class VGPMP:
         assert data.ndim == 2 and data.shape[1] == self.num_latent_gps, "data must be [N, D] time stamps"
         pl = self._planner
         if pl is not None and self._n_train == data.shape[0]:
-            pl.X.copy_(torch.as_tensor(data))
+            pl.set_time_stamps(data)
         return data.shape[0]
 
     # -- reference surface -----------------------------------------------------------------------------------

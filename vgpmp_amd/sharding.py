@@ -125,6 +125,9 @@ class SampleShardedPlanner:
 
             from . import capi
             from .engine import trainable_mask
+            if pl.lik_variables or pl.z_variables:
+                # (the C call refuses them too: its exchange buffer and update carry q_mu, q_sqrt, lengthscales, variance only)
+                raise NotImplementedError("trainable sigma_obs / alpha / inducing locations do not shard over samples")
             what = (0 if pl.fuse else capi.NO_FUSE) | pl.extra_flags
             ready = pl.noise_ahead_step == pl.t
             capi.check(pl.lib.vgpmp_elbo_steps_reduced(
@@ -134,7 +137,9 @@ class SampleShardedPlanner:
                 int(steps), self.comm.handle if self.comm is not None else None, capi.ptr(pl.reduce_buf), pl.reduce_buf.numel(),
                 pl.scene._stream()), "vgpmp_elbo_steps_reduced")
             pl.t += int(steps)
-            pl.noise_ahead_step = pl.t
+            # the last step drew ahead only if the library ran the few-problem schedule (the large-batch one ignores the flags)
+            fused = any(n.startswith("stage1_kernel") for n in capi.last_schedule(pl.lib))
+            pl.noise_ahead_step = pl.t if fused else None
             return
         for _ in range(steps):
             self.step()
