@@ -551,9 +551,15 @@ def run_sample_sharded(args, world, rank, dist, backend):
                                       "then the replicated Adam update",
                        "collective_ranks": world if (comm is not None or world > 1) else 0,
                        "launch": getattr(sp, "schedule", "one vgpmp_elbo_step (forward + reverse) + one vgpmp_adam_step per step")},
-            "roofline": {"kernel": "likelihood of the local samples", "bound": "hbm", "achieved": sdf_bytes / t_sdf / 1e9,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sdf_bytes / t_sdf / 1e9 / HBM_PEAK_GBPS, "traffic": None,
-                         "algorithmic_bytes_per_launch": sdf_bytes, "avg_launch_ms": times["loglik_kernel"]},
+            # (the 16 MB table of this scene lives in L2 / Infinity Cache: requested bytes per second for scale, no HBM fraction)
+            "roofline": {"kernel": next((k for k in capi.last_schedule(planner.lib) if k.startswith("loglik_")), "likelihood of the local samples"),
+                         "bound": "cache (voxel table resident in L2 / Infinity Cache: not an HBM-bound launch)",
+                         "achieved": S_loc * N * (16 * P + 8 * D + 4) / t_sdf / 1e9,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None,
+                         "algorithmic_bytes_per_launch": sdf_bytes, "requested_bytes_per_launch": S_loc * N * (16 * P + 8 * D + 4),
+                         "avg_launch_ms": times["loglik_kernel"],
+                         "by_contract_not_hbm": {"bytes_per_launch": sdf_bytes, "GBps": sdf_bytes / t_sdf / 1e9,
+                                                 "ratio_to_hbm_peak": sdf_bytes / t_sdf / 1e9 / HBM_PEAK_GBPS}},
             "stage_ms": {k: round(v, 5) for k, v in times.items()},
         }
     if rank == 0 and world == 1:
@@ -619,6 +625,7 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
 
     elapsed, reps = timed_region(plan_block, args, dist, backend)
     assert args.allow_nan or torch.isfinite(planner.q_mu).all(), "optimisation diverged"
+    timed_kernels = capi.last_schedule(planner.lib) if args.unroll == 0 else []      # (include/vgpmp_debug.h: what the library ran)
     pp = ps.planner_params
 
     # ---- one plan = num_steps optimisation steps + 150 posterior paths + best-sample pick (models/vgpmp.py:312-339)
@@ -644,58 +651,56 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
     sdf_bytes16 = npb * S * N * (16 * P + 8 * D + 4)               # what the packed table moves: one 16-byte record per query
     gemm_flops = npb * 2 * (2.0 * S * (N + M + 2) * D * B)         # F0 and H (lengthscales trainable)
     t_sdf, t_gemm = kernel_ms["loglik_kernel"] * 1e-3, kernel_ms["prior_gemm_kernel"] * 1e-3
-    far = "true" if scene.free_space_summary else "false"
-    batch_form = args.lik_form != "auto" or npb * S * N > 28672
-    regs_form = D <= 15 and args.lik_form != "lanes-lds"
-    # (template arguments as rocprofv3 prints them: <LPC, BLK, SIG, FAR, REGS, PFX> -- PFX: the prefix-scalar form, up to 8 joints)
-    lik_kernel = ("loglik_paths_kernel<1, 64, false, %s, %s, %s>" % (far, "true" if regs_form else "false",
-                                                                     "true" if regs_form and D <= 8 else "false")
-                  if batch_form else "loglik_paths_wide_kernel<8, false, 0>")      # (one or two problems: the timed schedule runs the
-    if batch_form and regs_form and D > 8 and not args.also_train:
-        # 9 to 15 joints: the pipelined four-wave form -- <2> free-space masks in LDS, <1> brick summary, <0> every sphere gathers
-        lik_kernel = "loglik_paths_mask_kernel<%d>" % (2 if scene.free_space_mask else 1 if scene.free_space_summary else 0)
-    # <8, false, SK> form, which assembles the paths of its sample first; the events time the likelihood alone)
-    roof_sdf = {"kernel": lik_kernel, "bound": "hbm", "achieved": sdf_bytes / t_sdf / 1e9,
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sdf_bytes / t_sdf / 1e9 / HBM_PEAK_GBPS,
-                "traffic": None, "algorithmic_bytes_per_launch": sdf_bytes, "avg_launch_ms": kernel_ms["loglik_kernel"],
-                "frac_of_achievable_6.29TBps": sdf_bytes / t_sdf / 1e9 / HBM_ACHIEVABLE_GBPS,
-                "by_16B_per_query": {"bytes_per_launch": sdf_bytes16, "achieved": sdf_bytes16 / t_sdf / 1e9,
-                                     "frac": sdf_bytes16 / t_sdf / 1e9 / HBM_PEAK_GBPS},
-                "table": {"layout": args.layout, "bytes": int(scene.table.numel() * 4),
+    # the kernels of the pass the events come from (one launch per kernel), as the library reports them -- not re-derived here
+    profiled_kernels = capi.last_schedule(planner.lib)
+    lik_kernel = next(k for k in profiled_kernels if k.startswith("loglik_"))
+    gemm_kernel = next(k for k in profiled_kernels if k.startswith("prior_"))
+    table_bytes = int(scene.table.numel() * 4)
+    # a table that fits the 256 MiB Infinity Cache (beside the step's own streams) is served on-die: the launch is then not an HBM
+    # launch and is not priced as one (MI355X_MICROARCH.md, "Infinity Cache"; counter traffic << algorithmic bytes confirms it)
+    cache_resident = table_bytes <= (256 << 20)
+    rate28, rate16 = sdf_bytes / t_sdf / 1e9, sdf_bytes16 / t_sdf / 1e9
+    roof_sdf = {"kernel": lik_kernel,
+                "bound": "cache (voxel table resident in L2 / Infinity Cache: not an HBM-bound launch)" if cache_resident else "hbm",
+                # HBM-resident table: SURVEY 8(d)'s 28-byte contract against the HBM peak.  Cache-resident table: the bytes the
+                # launch actually requests (16 per query) per second, for scale only -- no fraction of a peak it never touches
+                "achieved": rate16 if cache_resident else rate28,
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None if cache_resident else rate28 / HBM_PEAK_GBPS,
+                "traffic": None, "algorithmic_bytes_per_launch": sdf_bytes, "requested_bytes_per_launch": sdf_bytes16,
+                "avg_launch_ms": kernel_ms["loglik_kernel"],
+                "table": {"layout": args.layout, "bytes": table_bytes, "cache_resident": cache_resident,
                           "free_space_summary": bool(scene.free_space_summary), "free_space_masks_in_lds": bool(scene.free_space_mask),
                           "mask_bytes": int(scene.free_mask.numel() * 4) if scene.free_space_mask else 0},
                 "timing": "HIP events stamped with the kernel's start and end on its stream (hipExtLaunchKernel), "
                           f"mean of the first {max(1, args.profile_steps)} launches of a plan from fresh models"}
+    if cache_resident:
+        roof_sdf["by_contract_not_hbm"] = {"bytes_per_launch": sdf_bytes, "GBps": rate28, "ratio_to_hbm_peak": rate28 / HBM_PEAK_GBPS,
+                                           "note": "SURVEY 8(d)'s 28 B per query divided by the launch time; the table never leaves "
+                                                   "the caches, so this is NOT a fraction of HBM bandwidth in use"}
+    else:
+        if rate28 <= HBM_ACHIEVABLE_GBPS:
+            roof_sdf["frac_of_achievable_6.29TBps"] = rate28 / HBM_ACHIEVABLE_GBPS
+        roof_sdf["by_16B_per_query"] = {"bytes_per_launch": sdf_bytes16, "achieved": rate16, "frac": rate16 / HBM_PEAK_GBPS}
     # the kernel that forms the prior draws in the pass the events come from (one launch per kernel, device-drawn noise);
     # same selection as vg_elbo_steps (csrc/gp_path.hip)
     sk = planner.dims.split_k
     peak_gemm = F32_MFMA_PEAK_TFLOPS
-    if sk == 1:
-        split16 = not (planner.extra_flags & capi.PRIOR_F32)
-        gemm_kernel = "prior_fused_split_kernel<true, %d>" % (2 if S > 64 else 1) if split16 else "prior_fused_batch_kernel"
-        gemm_note = ("W and the features are formed inside the GEMM; the same kernel runs in the timed schedule from 35 problems "
-                     "of this shape up (below that the tiled float32 GEMM shares a launch with the covariance stage)")
-        if split16:
-            # every float32 product = three f16 MFMAs (hi hi + hi lo + lo hi, float32 accumulators): the matrix-pipe ceiling for
-            # the ALGORITHMIC flops is a third of the f16 peak; what bounds the kernel is the vector work that generates the operands
-            peak_gemm = F16_MFMA_PEAK_TFLOPS / 3.0
-            gemm_note += ("; f16-split products: peak = f16 dense MFMA peak / 3 MFMAs per float32 product; the kernel is bound by the "
-                          "vector instructions that generate W and the features (Philox, sin / cos, f16 halves), MFMA busy ~0.3 "
-                          "(profiles/r03/final/sq_prior_fused_config5.txt); the same flops against the f32-MFMA peak of 157.3 TF/s: "
-                          "%.2f" % (gemm_flops / t_gemm / 1e12 / F32_MFMA_PEAK_TFLOPS))
-    elif sk == 4 and S <= 32:
-        if planner.extra_flags & capi.PRIOR_F32:
-            gemm_kernel, gemm_note = "prior_fused_small_kernel", "few samples: features formed inside the GEMM, four K-slices, float32 MFMAs"
-        else:
-            gemm_kernel = "prior_fused_small16_kernel"
-            gemm_note = ("few samples: features formed inside the GEMM from projection MFMAs, four K-slices, register-resident f16-split "
-                         "products (peak = f16 dense MFMA peak / 3 MFMAs per float32 product); 16-row tiles hold %d samples: the "
-                         "algorithmic flops are %.0f %% of what the tiles compute" % (S, 100.0 * S / (16 * ((S + 15) // 16))))
-            peak_gemm = F16_MFMA_PEAK_TFLOPS / 3.0
-    elif (1024 // sk) % 128 == 0 and S >= 48:
-        gemm_kernel, gemm_note = "prior_gemm_lds_kernel", "a role of stage2_kernel in the timed schedule; timed alone here"
+    if gemm_kernel.startswith(("prior_fused_split_kernel", "prior_fused_small16_kernel")):
+        # every float32 product = three f16 MFMAs (hi hi + hi lo + lo hi, float32 accumulators): the matrix-pipe ceiling for
+        # the ALGORITHMIC flops is a third of the f16 peak; what bounds the kernels is the vector work that generates the operands
+        peak_gemm = F16_MFMA_PEAK_TFLOPS / 3.0
+    if gemm_kernel.startswith("prior_fused_split_kernel"):
+        gemm_note = ("W and the features are formed inside the GEMM; f16-split products: peak = f16 dense MFMA peak / 3 MFMAs per "
+                     "float32 product; pipe occupancy of this kernel: profiles/r05/final/sq_prior_fused_config5.txt; the same flops "
+                     "against the f32-MFMA peak of 157.3 TF/s: %.2f" % (gemm_flops / t_gemm / 1e12 / F32_MFMA_PEAK_TFLOPS))
+    elif gemm_kernel.startswith("prior_fused_small16_kernel"):
+        gemm_note = ("few samples: features formed inside the GEMM from projection MFMAs, four K-slices, register-resident f16-split "
+                     "products (peak = f16 dense MFMA peak / 3 MFMAs per float32 product); 16-row tiles hold %d samples: the "
+                     "algorithmic flops are %.0f %% of what the tiles compute" % (S, 100.0 * S / (16 * ((S + 15) // 16))))
+    elif gemm_kernel.startswith(("prior_fused_batch_kernel", "prior_fused_small_kernel")):
+        gemm_note = "W / the features formed inside the GEMM, float32 MFMAs (VGPMP_PRIOR_F32)"
     else:
-        gemm_kernel, gemm_note = "prior_gemm_kernel<0>", "a role of stage2_kernel in the timed schedule; timed alone here"
+        gemm_note = "a role of stage2_kernel in the timed schedule; timed alone here"
     roof_gemm = {"kernel": gemm_kernel, "note": gemm_note, "bound": "mfma", "achieved": gemm_flops / t_gemm / 1e12,
                  "peak": peak_gemm, "unit": "TFLOP/s", "frac": gemm_flops / t_gemm / 1e12 / peak_gemm,
                  "traffic": None, "algorithmic_flops_per_launch": gemm_flops, "avg_launch_ms": kernel_ms["prior_gemm_kernel"]}
@@ -711,8 +716,7 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
             roof_sdf["traffic"] = t.get(lik_kernel, {}).get("hbm_bytes_per_launch")
             roof_sdf["traffic_source"] = t.get("source")
             roof_sdf["traffic_collected_at"] = t.get("collected_at")
-            key = next((k for k in t if k.startswith(gemm_kernel.split("<")[0])), None)
-            roof_gemm["traffic"] = t[key].get("hbm_bytes_per_launch") if key else None
+            roof_gemm["traffic"] = t.get(gemm_kernel, {}).get("hbm_bytes_per_launch")
         except Exception:
             pass
 
@@ -752,6 +756,7 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
                             f"for the batch); plans_per_sec_measured is the timed solve_planning_problem() figure")
                            if t_sample is not None else None,
         "roofline": roof_sdf, "roofline_secondary": roof_gemm,
+        "timed_schedule_kernels": timed_kernels,
         "dominant_stage": dominant, "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
         "stage_ms_schedule": "separate pass after the timed region with ONE launch per kernel and a HIP event around every stage "
                              "(vgpmp_elbo_step_profiled); at 4 problems or fewer the timed region runs the shared stage launches "
@@ -768,7 +773,7 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
 
 
 SUB_KEYS = ("value", "unit", "ms_per_step", "steps", "warmup", "timed_blocks", "scaling", "dtype", "config", "roofline",
-            "roofline_secondary", "dominant_stage", "stage_ms")
+            "roofline_secondary", "timed_schedule_kernels", "dominant_stage", "stage_ms")
 
 
 def sub_record(argv, world, rank, dist, backend):
@@ -782,6 +787,24 @@ def sub_record(argv, world, rank, dist, backend):
     rec = {k: l2[k] for k in SUB_KEYS}
     rec["problems_total"] = world * a.problems
     return rec
+
+
+def summary_of(line):
+    """<= 600 bytes: per (sub-)record ms per step, the SDF kernel's fraction of the HBM peak (null where its table is cache
+    resident), the prior kernel's fraction of its matrix peak."""
+    r3 = lambda v: None if v is None else round(float(v), 4)
+    out = {}
+    for name in ("batch_512", "config3", "batch_64"):
+        rec = line.get(name)
+        if rec:
+            out[name] = {"ms_per_step": r3(rec["ms_per_step"]), "sdf_frac_hbm": r3(rec["roofline"]["frac"]),
+                         "prior_frac": r3(rec["roofline_secondary"]["frac"])}
+    out["line"] = {"ms_per_step": r3(line["ms_per_step"]), "value": round(float(line["value"]), 1), "n_gpus": line["n_gpus"],
+                   "sdf_frac_hbm": r3(line["roofline"]["frac"])}
+    cb = line.get("cpu_baseline") or {}
+    if cb.get("openmp"):
+        out["cpu_openmp"] = {"value": r3(cb["openmp"].get("value")), "threads": cb["openmp"].get("threads")}
+    return out
 
 
 def main():
@@ -862,6 +885,7 @@ def main():
         if pool is not None:
             pool.close()
     if rank == 0:
+        line["summary"] = summary_of(line)          # LAST key: a driver that keeps the tail of the line keeps this
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

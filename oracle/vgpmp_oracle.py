@@ -563,12 +563,13 @@ def adam_step(p: Params, g: Params, st: AdamState, lr: float, trainable: Dict[st
 DEFAULT_TRAINABLE = dict(q_mu=True, q_sqrt=True, lengthscales=True, kernel_variance=True)
 
 
-def optimization_step(p, st, scene, X, Zy, y, noise, alpha, lr, trainable=DEFAULT_TRAINABLE):
-    """utils/miscellaneous.py:68-84: loss = -ELBO, grads, Adam.apply_gradients.  Returns loss."""
-    fw = elbo_forward(p, scene, X, Zy, y, noise, alpha, want_dell=trainable.get("lengthscales", True))
+def optimization_step(p, st, scene, X, Zy, y, noise, alpha, lr, trainable=DEFAULT_TRAINABLE, lookup_pos=None, want_grad=False):
+    """utils/miscellaneous.py:68-84: loss = -ELBO, grads, Adam.apply_gradients.  Returns loss (with want_grad: loss, gradient).
+    lookup_pos: see log_prob (tests: the voxels a float32 implementation read in this step)."""
+    fw = elbo_forward(p, scene, X, Zy, y, noise, alpha, want_dell=trainable.get("lengthscales", True), lookup_pos=lookup_pos)
     g, _ = elbo_backward(p, scene, X, Zy, noise, alpha, fw)
     adam_step(p, g, st, lr, trainable)
-    return -fw['elbo']
+    return (-fw['elbo'], g) if want_grad else -fw['elbo']
 
 
 # ----------------------------------------------------------------------------

@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from oracle import vgpmp_oracle as orc
-from helpers import oracle_scene
+from helpers import follow_device_trajectory, oracle_scene
 import plan_report
 from vgpmp_amd import robots as rb
 from vgpmp_amd import scenes
@@ -31,18 +31,18 @@ def industrial():
     return engine, ps, spec, grid
 
 
-# (planner parameters, steps compared, relative tolerance on the per-step loss at the first / last compared step)
+# (planner parameters, steps compared)
 @pytest.mark.parametrize("name,over,steps", [("reference", {}, 20),
                                              ("config2", dict(num_samples=128, num_inducing=30, time_spacing_X=100), 8),
                                              # config 3's sizes: the few-sample fused prior kernel, Mz = 26 (padded float64 tiles of stage B)
                                              ("config3", dict(num_samples=7, num_inducing=24, time_spacing_X=70), 12)])
 def test_generated_noise_trajectory_against_oracle(industrial, name, over, steps):
-    """-ELBO of every optimisation step, device (noise drawn by the device generator, seed 77) against the oracle
-    (orc.philox_noise of the same seed / problem / step), eight problems in one batch.  The two differ by float32 arithmetic
-    and by nearest-voxel flips of float32 sphere centres; Adam (which normalises every gradient entry) lets that grow slowly
-    with the step.  Tolerances within ten times what was measured (gpurun_out/r04/t_plans.txt: 1e-5 ... 1e-4 relative at the
-    reference's parameters, 1e-6 ... 1e-5 at config 2's sizes): 1e-4 at the first step to 1e-3 at the last, 2e-5 to 2e-4 at
-    config 2's sizes, where all eight problems are compared."""
+    """Optimisation trajectories on the device's own generated noise (device generator, seed 77), eight problems in one batch,
+    the oracle following step by step on orc.philox_noise of the same seed / problem / step from the device's own state and voxels
+    (tests/helpers.py::follow_device_trajectory): -ELBO of every step to 2e-6 relative, every gradient and first moment to 1e-4
+    of its largest entry, every updated variable to 2e-3 lr -- all eight problems at all three sizes (config 2's: the large-batch
+    schedule, whose prior kernel never materialises W: this is its end-to-end check).  The free-running pair (oracle on its own
+    state and voxels) is chaotic in the voxels and only bounded for sanity: 5e-3 relative on the per-step loss."""
     engine, ps, spec, grid = industrial
     pp = dict(ps.planner_params, **over)
     S, M, N, B, D = int(pp["num_samples"]), int(pp["num_inducing"]), int(pp["time_spacing_X"]), 1024, spec.dof
@@ -56,13 +56,9 @@ def test_generated_noise_trajectory_against_oracle(industrial, name, over, steps
                              problem_base=base)
     if name == "config2":
         assert pl.dims.split_k == 1                         # the large-batch schedule: prior draws by the f16-split kernel
-    dev_loss = np.zeros((steps, len(pick)))
-    for t in range(steps):
-        pl.step()
-        dev_loss[t] = (-(pl.lik - pl.kl)).cpu().numpy()
+    dev_loss = follow_device_trajectory(f"trajectory {name}", pl, osc, qs, pp, pp["variance"], steps, seed, base)
     X, Zy = orc.init_trainset(N, D), orc.inducing_Zy(M, D)
-    check = range(len(pick))                                 # (the oracle takes ~0.2 s per config-2 step: 13 s for the eight)
-    tol0, tol1 = (2e-5, 2e-4) if name == "config2" else (1e-4, 1e-3)
+    check = range(len(pick)) if name != "config2" else (0, 3, 7)       # (the free-running oracle: ~0.2 s per config-2 step)
     worst = 0.0
     for k in check:
         y = qs[k]
@@ -71,17 +67,13 @@ def test_generated_noise_trajectory_against_oracle(industrial, name, over, steps
         for t in range(steps):
             nz = orc.philox_noise(seed, base + k, t, S, D, D, B, M + 2)
             want = orc.optimization_step(p, st, osc, X, Zy, y, nz, float(pp["alpha"]), float(pp["learning_rate"]))
-            tol = tol0 + (tol1 - tol0) * t / max(steps - 1, 1)
-            rel = abs(dev_loss[t, k] - want) / abs(want)
-            worst = max(worst, rel / tol)
-            assert rel <= tol, (name, k, t, dev_loss[t, k], want, rel)
-        # the variables after the last step: Adam normalises every entry, float32-level gradient differences move one by
-        # ~lr * 1e-3 per step at most
+            worst = max(worst, abs(dev_loss[t, k] - want) / abs(want))
         tolp = steps * float(pp["learning_rate"]) * 2e-2
         assert np.abs(pl.q_mu[k].cpu().numpy().T - p.q_mu).max() < tolp
         assert np.abs(pl.raw_ell[k].cpu().numpy() - p.raw_ell).max() < tolp
     assert dev_loss[-1].sum() < dev_loss[0].sum()
-    print(f"PARITY trajectory {name}: worst per-step loss deviation / tolerance = {worst:.3f}")
+    print(f"PARITY trajectory {name}: free-running worst per-step loss deviation = {worst:.2e}")
+    assert worst <= 5e-3
 
 
 def test_plans_on_the_industrial_problem_set(industrial):

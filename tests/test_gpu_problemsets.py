@@ -8,15 +8,16 @@ six joints and sigma_obs down to 1e-4.  Per set: min(4, #queries) queries in one
 the reference's collision mesh at the set's object position);
   (a) one step with injected noise: log-density of every (sample, time) pair, ELBO pieces and every gradient against the oracle on
       the device's own voxels (tests/helpers.py: fixed tolerances, no allowance for neighbouring cells);
-  (b) ten optimisation steps with the device's own generated noise against the oracle on orc.philox_noise of the same key: -ELBO of
-      every step within 1e-4 (first step) ... 1e-3 (tenth) relative, the variables after the tenth within what Adam allows.
+  (b) ten optimisation steps with the device's own generated noise, the oracle following step by step on orc.philox_noise of the
+      same key from the device's own state and voxels: loss, gradients, moments and updated variables of EVERY step at the
+      one-step tolerances; plus a sanity bound on the free-running pair.
 """
 import numpy as np
 import pytest
 import torch
 
 from oracle import vgpmp_oracle as orc
-from helpers import TOL_LIK, TOL_LOGP, assert_grads, device_centres, flipped_share, oracle_scene
+from helpers import TOL_LIK, TOL_LOGP, assert_grads, device_centres, flipped_share, follow_device_trajectory, oracle_scene
 from vgpmp_amd import robots as rb
 from vgpmp_amd import scenes
 
@@ -44,17 +45,24 @@ def _setup(robot, problem):
     off = ps.object_positions[0]
     sc = engine.DeviceScene(spec, grid, off, sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"])
     osc = oracle_scene(spec, grid, off, sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"])
-    nq = min(4, len(ps.queries))
-    stride = max(1, len(ps.queries) // nq)
-    qs = np.array([ps.queries[(3 + i * stride) % len(ps.queries)] for i in range(nq)], dtype=np.float64)
     S, M, N = int(pp["num_samples"]), int(pp["num_inducing"]), int(pp["time_spacing_X"])
+    # the queries of the set whose initial straight line comes closest to (or deepest into) the obstacles: the ones that exercise
+    # the likelihood; plus whether ANY of them reaches the hinge band at all (a set may keep clear of its scene from the start)
+    allq = np.array(ps.queries, dtype=np.float64)
+    probe = engine.PlannerBatch(sc, allq, num_samples=1, num_inducing=M, num_data=N, num_bases=16, lengthscales=pp["lengthscales"],
+                                variance=pp["variance"])
+    line = probe.query_clearances(N)[2].cpu().numpy()
+    del probe
+    nq = min(4, len(allq))
+    qs = allq[np.argsort(line)[:nq]]
+    reaches_hinge = bool(line.min() < float(pp["epsilon"]) - 0.01)
     var = max(float(pp["variance"]), VARIANCE_FLOOR + 1e-6)         # wam / lab: 0.05 is below the floor
-    return engine, ps, spec, pp, sc, osc, qs, S, M, N, var
+    return engine, ps, spec, pp, sc, osc, qs, S, M, N, var, reaches_hinge
 
 
 @pytest.mark.parametrize("robot,problem", SETS)
 def test_injected_noise_step_against_oracle(robot, problem):
-    engine, ps, spec, pp, sc, osc, qs, S, M, N, var = _setup(robot, problem)
+    engine, ps, spec, pp, sc, osc, qs, S, M, N, var, reaches_hinge = _setup(robot, problem)
     P, L, B = len(qs), spec.dof, 1024
     assert len(ps.queries) == len(ps.states) * (len(ps.states) - 1) // 2
     pl = engine.PlannerBatch(sc, qs, num_samples=S, num_inducing=M, num_data=N, num_bases=B, lengthscales=pp["lengthscales"],
@@ -99,37 +107,34 @@ def test_injected_noise_step_against_oracle(robot, problem):
         assert_grads(tag, grads, og, k=k)
         if k == 0:
             flipped_share(tag, logp, orc.elbo_forward(params[k], osc, X, Zy, qs[k], noises[k], float(pp["alpha"]), want_dell=False))
-    assert active > 0, "at least one query of the set must reach into the hinge band of its scene"
+    if reaches_hinge:      # (ur10 / bookshelves and kuka / boxes start clear of their scenes by more than epsilon)
+        assert active > 0, "the queries closest to the obstacles must reach into the hinge band"
+    print(f"PARITY {robot}/{problem} queries_in_hinge_band={active}/{P}")
 
 
 @pytest.mark.parametrize("robot,problem", SETS)
 def test_generated_noise_trajectory_against_oracle(robot, problem):
-    engine, ps, spec, pp, sc, osc, qs, S, M, N, var = _setup(robot, problem)
+    """Ten optimisation steps on the device's own noise, the oracle following step by step from the device's state
+    (tests/helpers.py::follow_device_trajectory): loss 2e-6, gradients and first moments 1e-4 of their largest entry, updated
+    variables 2e-3 lr -- at every step of every problem; and the free-running oracle (its own state, its own voxels) stays
+    within 5e-3 of the device's loss over the ten steps."""
+    engine, ps, spec, pp, sc, osc, qs, S, M, N, var, _ = _setup(robot, problem)
     P, L, B, steps = len(qs), spec.dof, 1024, 10
     seed, base = 123, 17
     pl = engine.PlannerBatch(sc, qs, num_samples=S, num_inducing=M, num_data=N, num_bases=B, lengthscales=pp["lengthscales"],
                              variance=pp["variance"], alpha=pp["alpha"], learning_rate=pp["learning_rate"], seed=seed,
                              problem_base=base)
-    dev_loss = np.zeros((steps, P))
-    for t in range(steps):
-        pl.step()
-        dev_loss[t] = (-(pl.lik - pl.kl)).cpu().numpy()
-    assert np.isfinite(dev_loss).all()
+    dev_loss = follow_device_trajectory(f"{robot}/{problem}", pl, osc, qs, pp, var, steps, seed, base)
+    # the free-running pair: chaotic in the voxels (sigma_obs down to 1e-4 turns one neighbouring cell into 1e-3 of the loss), so
+    # only a sanity bound -- the step-by-step comparison above is the parity statement
     X, Zy = orc.init_trainset(N, L), orc.inducing_Zy(M, L)
-    lr = float(pp["learning_rate"])
     worst = 0.0
     for k in range(P):
         p = orc.init_params(osc.robot, qs[k], M, pp["lengthscales"], var)
         st = orc.adam_init(p)
         for t in range(steps):
             nz = orc.philox_noise(seed, base + k, t, S, L, L, B, M + 2)
-            want = orc.optimization_step(p, st, osc, X, Zy, qs[k], nz, float(pp["alpha"]), lr)
-            tol = 1e-4 + (1e-3 - 1e-4) * t / (steps - 1)
-            rel = abs(dev_loss[t, k] - want) / abs(want)
-            worst = max(worst, rel / tol)
-            assert rel <= tol, (robot, problem, k, t, dev_loss[t, k], want, rel)
-        tolp = steps * lr * 2e-2
-        assert np.abs(pl.q_mu[k].cpu().numpy().T - p.q_mu).max() < tolp
-        assert np.abs(pl.raw_ell[k].cpu().numpy() - p.raw_ell).max() < tolp
-        assert np.abs(pl.raw_var[k].cpu().numpy() - p.raw_var).max() < tolp
-    print(f"PARITY {robot}/{problem} trajectory worst deviation / tolerance = {worst:.3f}")
+            want = orc.optimization_step(p, st, osc, X, Zy, qs[k], nz, float(pp["alpha"]), float(pp["learning_rate"]))
+            worst = max(worst, abs(dev_loss[t, k] - want) / abs(want))
+    print(f"PARITY {robot}/{problem} free-running worst loss deviation = {worst:.2e}")
+    assert worst <= 5e-3
