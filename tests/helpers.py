@@ -72,7 +72,7 @@ def synthetic_problem(dof=14, S=8, N=12, M=6, B=64, seed=0, n_grid=48, n_problem
 # configs 1-4 at full size, the 14-joint arm, trainable inducing locations): the bounds below are within 10x of the worst case.
 TOL_LOGP = 2e-6       # per (sample, time) pair, relative to the largest |logp|                   (measured: <= 1.7e-7)
 TOL_LIK = 2e-6        # alpha / S * sum logp, relative                                             (measured: <= 2.2e-7)
-TOL_GRAD = 1e-4       # every gradient component, relative to the largest component of its tensor  (measured: <= 2.3e-5)
+TOL_GRAD = 3e-4       # every gradient component, relative to the largest component of its tensor  (measured: <= 5.8e-5)
 MAX_FLIPPED = 0.03    # share of (sample, time) pairs a float64 chain resolves to another voxel (coarse 0.05 m test grids)
 
 
@@ -138,7 +138,7 @@ def follow_device_trajectory(tag, pl, osc, qs, pp, var, steps, seed, base, probl
             want, g = orc.optimization_step(p, st, osc, X, Zy, qs[k], nz, alpha, lr, lookup_pos=device_centres(pl, k), want_grad=True)
             rel = abs(dev_loss[t, k] - want) / abs(want)
             worst["loss"] = max(worst["loss"], rel)
-            assert rel <= 2e-6, (tag, "loss", k, t, dev_loss[t, k], want, rel)
+            assert rel <= 5e-7, (tag, "loss", k, t, dev_loss[t, k], want, rel)       # (measured: <= 7e-8)
             after, m_dev = read([pl.q_mu, pl.q_sqrt, pl.raw_ell, pl.raw_var], k), read(pl.adam_m, k)
             g_dev = read(pl.grad, k)
             for name in names:
@@ -156,7 +156,7 @@ def follow_device_trajectory(tag, pl, osc, qs, pp, var, steps, seed, base, probl
                 big = np.abs(gw) >= 1e-3 * top
                 e = np.abs(getattr(after, name) - getattr(p, name))[big].max() / lr if big.any() else 0.0
                 worst["var"] = max(worst["var"], e)
-                assert e < 2e-3, (tag, "updated variable (in units of lr)", name, k, t, e)
+                assert e < 2e-4, (tag, "updated variable (in units of lr)", name, k, t, e)      # (measured: <= 1.7e-5)
     print(f"PARITY {tag} follow: " + " ".join(f"{a}={b:.2e}" for a, b in worst.items()))
     assert np.isfinite(dev_loss).all()
     return dev_loss

@@ -39,8 +39,8 @@ def industrial():
 def test_generated_noise_trajectory_against_oracle(industrial, name, over, steps):
     """Optimisation trajectories on the device's own generated noise (device generator, seed 77), eight problems in one batch,
     the oracle following step by step on orc.philox_noise of the same seed / problem / step from the device's own state and voxels
-    (tests/helpers.py::follow_device_trajectory): -ELBO of every step to 2e-6 relative, every gradient and first moment to 1e-4
-    of its largest entry, every updated variable to 2e-3 lr -- all eight problems at all three sizes (config 2's: the large-batch
+    (tests/helpers.py::follow_device_trajectory): -ELBO of every step to 5e-7 relative, every gradient and first moment to 3e-4
+    of its largest entry, every updated variable to 2e-4 lr -- all eight problems at all three sizes (config 2's: the large-batch
     schedule, whose prior kernel never materialises W: this is its end-to-end check).  The free-running pair (oracle on its own
     state and voxels) is chaotic in the voxels and only bounded for sanity: 5e-3 relative on the per-step loss."""
     engine, ps, spec, grid = industrial
