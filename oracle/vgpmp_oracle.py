@@ -819,18 +819,35 @@ def philox_normals(n: int, key: Tuple[int, int], stream: int) -> np.ndarray:
     return out.reshape(-1)[:n]
 
 
+W_TABLE_SIZE = 8192
+_w_table_cache = None
+
+
+def w_table() -> np.ndarray:
+    """The 8192 magnitudes of the W stream as float16 (restates tools/make_w_table.py -> csrc/gp_wtable.h): T[i] = mean of |z|,
+    z ~ N(0, 1), over the i-th of 8192 equally probable bins of the half-normal distribution,
+    16384 (phi(q_i) - phi(q_{i+1})), q_i = Phi^-1(1/2 + i / 16384), rounded to nearest even."""
+    global _w_table_cache
+    if _w_table_cache is None:
+        from scipy.stats import norm
+        q = norm.ppf(0.5 + np.arange(W_TABLE_SIZE + 1, dtype=np.float64) / (2 * W_TABLE_SIZE))
+        pdf = norm.pdf(q)
+        _w_table_cache = (2.0 * W_TABLE_SIZE * (pdf[:-1] - pdf[1:])).astype(np.float16)
+    return _w_table_cache
+
+
 def philox_normals8(n: int, key: Tuple[int, int], stream: int) -> np.ndarray:
-    """n standard normals, EIGHT per counter (the W stream; csrc/vgpmp_device.h::vg_normal8): word j of counter i // 8 gives the
-    Box-Muller pair (8 i + 2 j, 8 i + 2 j + 1) from two 16-bit uniforms u = (h + 1/2) 2^-16 -- radius from the low half of
-    the word, angle from the high half."""
+    """n prior weights, EIGHT per counter (the W stream; csrc/vgpmp_device.h, "The W stream", csrc/gp_common.h::vg_w8): each 16-bit
+    half of the four words of counter i // 8 is one weight -- element 8 i + 2 j + {0, 1} from the {low, high} half of word j --,
+    w = +-T[h & 0x1fff], sign from bit 15.  A stratified inverse-CDF draw with 16 384 equally likely float16 values: E[w] = 0,
+    Var[w] = 1 - 5e-6, |w| <= 4.074; exact integer / table arithmetic, so the device's weights are these bit for bit."""
     nc = (n + 7) // 8
     ctr = np.zeros((nc, 4), dtype=np.uint32)
     ctr[:, 0] = np.arange(nc, dtype=np.uint32); ctr[:, 1] = np.uint32(stream)
     r = philox4x32(ctr, key)
-    u_rad = ((r & np.uint32(0xFFFF)).astype(np.float64) + 0.5) * 2.0 ** -16
-    u_ang = ((r >> np.uint32(16)).astype(np.float64) + 0.5) * 2.0 ** -16
-    rad = np.sqrt(-2.0 * np.log(u_rad))
-    out = np.stack([rad * np.cos(2.0 * math.pi * u_ang), rad * np.sin(2.0 * math.pi * u_ang)], axis=-1)      # [nc, 4, 2]
+    halves = np.stack([r & np.uint32(0xFFFF), r >> np.uint32(16)], axis=-1)                       # [nc, 4, 2]
+    mag = w_table().astype(np.float64)[(halves & np.uint32(0x1FFF)).astype(np.int64)]
+    out = np.where((halves & np.uint32(0x8000)) != 0, -mag, mag)
     return out.reshape(-1)[:n]
 
 

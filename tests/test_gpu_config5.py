@@ -123,10 +123,10 @@ def test_synthetic14_elbo_forward_backward_against_oracle(S, N, M, B, P):
         np.testing.assert_allclose(pl.f[k].cpu().numpy(), fw["f"], rtol=0, atol=1e-4)
         assert (fw["logp"] < 0).any()
         logp = pl.logp[k].cpu().numpy()
-        np.testing.assert_allclose(logp, fw["logp"], rtol=0, atol=TOL_LOGP * np.abs(fw["logp"]).max())
+        tag = f"synthetic14[S={S},N={N},P={P},k={k}]"
+        np.testing.assert_allclose(logp, fw["logp"], rtol=0, atol=TOL_LOGP * np.abs(fw["logp"]).max(), err_msg=tag)
         np.testing.assert_allclose(float(pl.kl[k]), fw["cv"]["kl"], rtol=1e-9)
         np.testing.assert_allclose(float(pl.lik[k]), fw["lik"], rtol=TOL_LIK)
-        tag = f"synthetic14[S={S},N={N},P={P},k={k}]"
         assert_grads(tag, grads, og, k=k)
         if k == 0:
             flipped_share(tag, logp, orc.elbo_forward(p, pb["scene"], pb["X"], pb["Zy"], y, nz[k], pb["alpha"], want_dell=False))

@@ -86,4 +86,6 @@ def test_bench_starts_its_own_ranks(bench_gpus2):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 5
     assert d["config"]["collective_ranks"] == 2 and "512 on this rank" in d["config"]["workload"]
-    assert d["value"] > 0 and d["roofline"]["frac"] > 0
+    assert d["value"] > 0 and d["roofline"]["achieved"] > 0
+    # (config 4's 16 MB table is cache resident: the line prices no fraction of the HBM peak for it)
+    assert d["roofline"]["frac"] is None and d["roofline"]["bound"].startswith("cache")

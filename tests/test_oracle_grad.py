@@ -95,21 +95,35 @@ def test_philox_known_answer_and_moments():
     assert [int(v) for v in o] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     n = orc.philox_normals(200000, orc.philox_key(7, 3, 11), orc.STREAM_W)
     assert abs(n.mean()) < 0.01 and abs(n.std() - 1.0) < 0.01
-    # the W stream: eight normals per counter (a Box-Muller pair per 32-bit word, 16-bit uniforms): moments, the bound
-    # |z| <= sqrt(-2 ln 2^-17) of the coarser radius, independence of the two members of a pair and of neighbouring pairs,
-    # and the word -> element map (element 8 i + 2 j + {0, 1} from word j of counter i)
+    # the W stream: eight float16-valued weights per counter out of the 8192-entry table of half-normal bin means (a stratified
+    # inverse-CDF draw, 16 384 equally likely values): moments, the bound, independence of the two halves of a word and of
+    # neighbouring words, the distance from the normal distribution, and the half-word -> element map
     key = orc.philox_key(7, 3, 11)
     w = orc.philox_normals8(400000, key, orc.STREAM_W)
     assert abs(w.mean()) < 0.005 and abs(w.std() - 1.0) < 0.005
     assert abs((w ** 4).mean() - 3.0) < 0.06 and abs((w ** 3).mean()) < 0.03
-    assert np.abs(w).max() <= np.sqrt(-2.0 * np.log(2.0 ** -17)) + 1e-12
-    assert abs(np.corrcoef(w[0::2], w[1::2])[0, 1]) < 0.01 and abs(np.corrcoef(w[:-2:2], w[2::2])[0, 1]) < 0.01
+    t = orc.w_table()
+    assert t.dtype == np.float16 and t.shape == (8192,) and np.all(np.diff(t.astype(np.float64)) >= 0) and t[0] > 0
+    assert np.abs(w).max() <= float(t[-1]) == 4.07421875
+    assert np.array_equal(w, w.astype(np.float16).astype(np.float64))          # every weight IS a float16
+    # the table by itself: exact moments of the 16 384-point distribution, and its Kolmogorov distance from N(0, 1)
+    t64 = t.astype(np.float64)
+    assert abs((t64 * t64).mean() - 1.0) < 1e-5 and abs(t64.mean() - np.sqrt(2.0 / np.pi)) < 1e-6
+    assert abs((t64 ** 4).mean() - 3.0) < 2e-3
     from scipy import stats
+    cdf_gap = np.abs(stats.norm.cdf(t64) - (0.5 + (np.arange(8192) + 0.5) / 16384.0)).max()
+    assert cdf_gap < 2e-4       # (Kolmogorov distance: half a float16 step times the density, 4.9e-4 x 0.24 near |w| = 1; the bins are finer)
+    assert abs(np.corrcoef(w[0::2], w[1::2])[0, 1]) < 0.01 and abs(np.corrcoef(w[:-2:2], w[2::2])[0, 1]) < 0.01
     assert stats.kstest(w[:100000], "norm").pvalue > 1e-3
     r = orc.philox4x32(np.array([[5, orc.STREAM_W, 0, 0]], dtype=np.uint32), key)[0]
-    u_rad, u_ang = ((int(r[2]) & 0xFFFF) + 0.5) / 65536.0, ((int(r[2]) >> 16) + 0.5) / 65536.0
-    np.testing.assert_allclose(w[8 * 5 + 4: 8 * 5 + 6], np.sqrt(-2 * np.log(u_rad)) * np.array([np.cos(2 * np.pi * u_ang), np.sin(2 * np.pi * u_ang)]),
-                               rtol=1e-13)
+    lo, hi = int(r[2]) & 0xFFFF, int(r[2]) >> 16
+    want = [(-1.0 if h & 0x8000 else 1.0) * float(t[h & 0x1FFF]) for h in (lo, hi)]
+    np.testing.assert_array_equal(w[8 * 5 + 4: 8 * 5 + 6], want)
+    # the committed device table (csrc/gp_wtable.h, written by tools/make_w_table.py) is this table, bit for bit
+    import os, re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vgpmp_amd", "csrc", "gp_wtable.h")).read()
+    bits = np.array([int(v, 16) for v in re.findall(r"0x([0-9a-f]{4})", hdr)], dtype=np.uint16)
+    assert np.array_equal(bits, t.view(np.uint16))
     nz = orc.philox_noise(7, 0, 0, S=64, L=3, D=3, B=256, Mz=6)
     np.testing.assert_array_equal(nz.w.reshape(-1), orc.philox_normals8(64 * 3 * 256, orc.philox_key(7, 0, 0), orc.STREAM_W))
     # Student-t(5) spectral draw: variance nu/(nu-2) = 5/3

@@ -14,7 +14,7 @@ LIB = LIB_DIR / "libvgpmp_hip.so"
 SOURCES = ["fk_sdf.hip", "gp_path.hip", "mesh_sdf.hip", "deriv_kernels.hip", "plan.hip", "inducing.hip", "comm.hip", "capi.hip"]
 HEADERS = [CSRC / "vgpmp_device.h", CSRC / "gp_path.h", CSRC / "fk_chain.h", CSRC / "gp_math.h", ROOT / "include" / "vgpmp.h", ROOT / "include" / "vgpmp_debug.h"]
 # private parts of gp_path.hip (one translation unit: its stage launches dispatch these bodies by role)
-GP_PARTS = [CSRC / n for n in ("gp_common.h", "gp_rng.h", "gp_paths.h", "gp_update.h", "gp_cov.h", "gp_prior.h", "gp_prior_split.h", "gp_lik_consts.h")]
+GP_PARTS = [CSRC / n for n in ("gp_common.h", "gp_rng.h", "gp_paths.h", "gp_update.h", "gp_cov.h", "gp_prior.h", "gp_prior_split.h", "gp_lik_consts.h", "gp_wtable.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

@@ -1571,7 +1571,7 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
                 default: return VGPMP_E_ARG;
             }
         }
-        return sig ? VG_GO(go, loglik_paths_wide_kernel<8, true>) : VG_GO(go, loglik_paths_wide_kernel<8, false>);
+        return sig ? VG_GO(go, loglik_paths_wide_kernel<8, true, 0>) : VG_GO(go, loglik_paths_wide_kernel<8, false, 0>);
     }
     auto go = [&](auto kern, const char* name) {
         int rc = vg_grant_dyn_lds((const void*)kern, lds);
@@ -1604,10 +1604,10 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
             if (sig) return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, true, true, true>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, false, true, true>);
             return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, true, true, true>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, false, true, true>);
         }
-        if (sig) return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, true, true>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, false, true>);
-        return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, true, true>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, false, true>);
+        if (sig) return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, true, true, false>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, false, true, false>);
+        return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, true, true, false>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, false, true, false>);
     }
-    if (sig) return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, true>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, false>);
-    return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, true>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, false>);
+    if (sig) return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, true, false, false>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, false, false, false>);
+    return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, true, false, false>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, false, false, false>);
 }
 #undef VG_GO

@@ -1,6 +1,7 @@
 // Block size, schedule thresholds and the float64 dot / reduction helpers shared by the GP kernels.
 // Private part of gp_path.hip (one translation unit: the stage launches call these bodies by role).
 #pragma once
+#include "gp_wtable.h"
 
 namespace {
 
@@ -92,5 +93,27 @@ __device__ __forceinline__ void vg_split4(const vg_f32x4& x, vg_h4& hi, vg_h4& l
     lo = (vg_h4){l0[0], l0[1], l1[0], l1[1]};
 }
 
+
+
+// ---- the W stream (vgpmp_device.h, "The W stream"): eight float16 weights of one Philox block, packed in pairs
+// `tab`: the 8192 magnitudes -- kWTable in global memory (a 16 KB table: L1 / L2 resident) or a copy in LDS
+__device__ __forceinline__ uint32_t vg_w_pair(uint32_t word, const unsigned short* __restrict__ tab) {
+    const uint32_t lo = tab[word & 0x1fffu], hi = tab[(word >> 16) & 0x1fffu];
+    return (lo | (hi << 16)) ^ (word & 0x80008000u);
+}
+__device__ __forceinline__ vg_h8 vg_w8_from(uint4 r, const unsigned short* __restrict__ tab) {
+    typedef uint32_t vg_u32x4 __attribute__((ext_vector_type(4)));
+    const vg_u32x4 v = {vg_w_pair(r.x, tab), vg_w_pair(r.y, tab), vg_w_pair(r.z, tab), vg_w_pair(r.w, tab)};
+    return __builtin_bit_cast(vg_h8, v);
+}
+__device__ __forceinline__ vg_h8 vg_w8(uint32_t i, uint2 key, const unsigned short* __restrict__ tab) {
+    return vg_w8_from(vg_philox(make_uint4(i, (uint32_t)VG_STREAM_W, 0u, 0u), key), tab);
+}
+// the same eight weights as float32 (exact: every float16 is a float32)
+__device__ __forceinline__ void vg_w8_f32(uint32_t i, uint2 key, const unsigned short* __restrict__ tab, float (&z)[8]) {
+    const vg_h8 h = vg_w8(i, key, tab);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) z[k] = (float)h[k];
+}
 
 }  // namespace

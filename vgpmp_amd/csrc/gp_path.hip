@@ -491,7 +491,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     GemmArgs ga;
     ga.S = S; ga.L = L; ga.J = J; ga.B = B; ga.SK = SK; ga.nsel = want_dell ? 2 : 1;
     ga.W = nz->w; ga.Phi = ws->Phi; ga.dPhi = ws->dPhi; ga.F0 = ws->F0; ga.H = ws->H; ga.slab = slab;
-    ga.dbg = 0; ga.ell = ws->ell; ga.var = ws->var;
+    ga.dbg = 0; ga.w_exact = gen ? 1 : 0; ga.ell = ws->ell; ga.var = ws->var;
     TiledGemmArgs tga;
     tga.S = S; tga.L = L; tga.J = J; tga.B = B; tga.nsel = ga.nsel;
     tga.W = nz->w; tga.Phi = ws->Phi; tga.dPhi = ws->dPhi; tga.F0 = ws->F0; tga.H = ws->H;
@@ -640,8 +640,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     if (split_bwd) {
         fn_pb = Mz == 32 ? (SK == 2 ? VG_FN(paths_bwd_split<2, 32>) : SK == 4 ? VG_FN(paths_bwd_split<4, 32>)
                                                                                         : VG_FN(paths_bwd_split<8, 32>))
-                         : (SK == 2 ? VG_FN(paths_bwd_split<2>) : SK == 4 ? VG_FN(paths_bwd_split<4>)
-                                                                                  : VG_FN(paths_bwd_split<8>));
+                         : (SK == 2 ? VG_FN(paths_bwd_split<2, 0>) : SK == 4 ? VG_FN(paths_bwd_split<4, 0>)
+                                                                                  : VG_FN(paths_bwd_split<8, 0>));
         lds_pb = lds_pbs;
     }
     // large batches: the latent's constants in registers, pairs of chunks through 40 KB of LDS (paths_bwd_regs)
@@ -718,15 +718,18 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         // the f16-split form (gp_prior_split.h): K steps of 32 bases (every K-slice a multiple of that); the float32-MFMA kernel
         // stays behind VGPMP_PRIOR_F32, as for the large batches
         if (!(what & VGPMP_PRIOR_F32) && (B / 4) % kHK == 0) {
-#define VG_FUSED_SMALL16(MT_, DM_)                                            \
-    (want_dell ? VG_EXT_GGL((prior_fused_small16_kernel<MT_, DM_, true>), fgrid, dim3(kBlock), 0, st, g0, g1, \
+#define VG_FUSED_SMALL16_(MT_, DM_, WX_)                                        \
+    (want_dell ? VG_EXT_GGL((prior_fused_small16_kernel<MT_, DM_, true, WX_>), fgrid, dim3(kBlock), 0, st, g0, g1, \
                              0, fp)                                  \
-               : VG_EXT_GGL((prior_fused_small16_kernel<MT_, DM_, false>), fgrid, dim3(kBlock), 0, st, g0, g1, \
+               : VG_EXT_GGL((prior_fused_small16_kernel<MT_, DM_, false, WX_>), fgrid, dim3(kBlock), 0, st, g0, g1, \
                              0, fp))
+            // (weights drawn by the library are float16 values: no low half -- the WX form; a caller's own weights take the split)
+#define VG_FUSED_SMALL16(MT_, DM_) (gen ? VG_FUSED_SMALL16_(MT_, DM_, true) : VG_FUSED_SMALL16_(MT_, DM_, false))
             if (L == 7) { if (S <= 16) VG_FUSED_SMALL16(1, 7); else VG_FUSED_SMALL16(2, 7); }
             else if (L == 6) { if (S <= 16) VG_FUSED_SMALL16(1, 6); else VG_FUSED_SMALL16(2, 6); }
             else if (L <= 8) { if (S <= 16) VG_FUSED_SMALL16(1, 8); else VG_FUSED_SMALL16(2, 8); }
             else { if (S <= 16) VG_FUSED_SMALL16(1, 16); else VG_FUSED_SMALL16(2, 16); }
+#undef VG_FUSED_SMALL16_
 #undef VG_FUSED_SMALL16
             return;
         }

@@ -91,6 +91,7 @@ struct GemmArgs {
     float *F0, *H;
     size_t slab;
     int dbg;                 // measurement builds: 1 no stores, 2 no loads, 3 no MFMA
+    int w_exact;             // W was drawn by the library's generator: float16 values, no low half (the f16 form skips its MFMA)
     const double *ell, *var; // [P,L] of this step (stage A's): the f16 form takes the features' constant factors out of its operands
 };
 
@@ -261,11 +262,13 @@ __device__ __forceinline__ void prior_gemm_lds_body(const GemmArgs& a, float* ld
             for (int ks2 = 0; ks2 < kGK / 32; ++ks2) {
                 vg_h8 ah, al;
                 frag(As + (wave * 16 + r) * kGLd, ks2, 1.0f, ah, al);
+                // (weights drawn by the library's generator are float16 values -- vgpmp_device.h, "The W stream" --: `al` is zero then)
+                const bool w_lo = a.w_exact == 0;
 #pragma unroll
                 for (int t = 0; t < kNT; ++t) {
                     vg_h8 bh, bl;
                     frag(Bs + (16 * t + r) * kGLd, ks2, sc_in, bh, bl);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[t], 0, 0, 0);
+                    if (w_lo) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[t], 0, 0, 0);
                 }
@@ -502,10 +505,10 @@ __device__ __forceinline__ void prior_fused_batch_body(const FusedBatchArgs& a, 
             if ((is_om || is_bt) && k0 + kFBK < B) onext = osrc[(size_t)(k0 / kFBK + 1) * ostep];
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                // (a W counter holds eight normals: the threads of quads 2 h and 2 h + 1 draw the same one and keep a half each --
+                // (a W counter holds eight weights: the threads of quads 2 h and 2 h + 1 draw the same one and keep a half each --
                 //  this float32 form is the measurement / reference form of the large-batch draw, gp_prior_split.h the product)
                 float z[8];
-                vg_normal8(wbase[m] + (uint32_t)((k0 >> 3) + (wq >> 1)), VG_STREAM_W, key, z);
+                vg_w8_f32(wbase[m] + (uint32_t)((k0 >> 3) + (wq >> 1)), key, kWTable, z);
                 const float4 w4 = (wq & 1) ? make_float4(z[4], z[5], z[6], z[7]) : make_float4(z[0], z[1], z[2], z[3]);
                 *reinterpret_cast<float4*>(As + (wrow + kTS * m) * kFBLd + 4 * wq) = w4;
             }

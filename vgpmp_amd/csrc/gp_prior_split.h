@@ -16,18 +16,21 @@
 // accumulators are scaled by c = sqrt(2 var / B) and c / ell^2 when they are stored.
 //
 // Workgroup: 512 threads = 8 waves, a tile of 64 MT samples x 144 columns of BOTH products, K in steps of 32; two
-// workgroups per CU (<= 128 VGPRs, 76 KB of LDS) = four waves per SIMD -- the vector ALU needs that many to issue at its
+// workgroups per CU (<= 128 VGPRs, 74 KB of LDS) = four waves per SIMD -- the vector ALU needs that many to issue at its
 // full rate -- and the two workgroups drift apart, so one's product phase runs beside the other's generation phase.
 // Per K step:
-//   * W: a thread draws ONE Philox counter = eight normals of a W row (vg_normal8: a Box-Muller pair per 32-bit word; one
-//     v_mad_u64_u32 per 32 x 32 -> 64 product, one v_bitop3_b32 per three-way xor), splits them and stores 16 bytes into each
-//     half tile -- the generator was two thirds of the kernel's vector instructions with four normals per counter;
+//   * W: a thread draws ONE Philox counter = eight weights of a W row (vg_w8: one v_mad_u64_u32 per 32 x 32 -> 64 product, one
+//     v_bitop3_b32 per three-way xor, then eight reads of the 16 KB bin-mean table kept in LDS).  The weights of the W stream ARE
+//     float16 (vgpmp_device.h, "The W stream"): W has no low half, a product is  w b_hi + w b_lo  -- TWO MFMAs -- and with 128-row
+//     tiles the lane that draws a counter is the lane whose A fragment it is: W never touches LDS.  (Round 4 drew float32 normals
+//     by Box-Muller, split them and carried three MFMAs per product: the vector and the matrix pipe exclude each other on this
+//     part -- profiles/r05/prior_phases.txt --, so the kernel's time IS its instruction count; this form has a third fewer.)
 //   * features: the projections x . omega of the tile's 144 points on the step's 32 frequencies are themselves f16-split
 //     products: A = [omega_hi | omega_lo] (joint coordinates 0..15 twice along K = 32), B1 = [x_hi | x_hi], B2 = [x_lo | 0],
 //     so TWO MFMAs give omega_hi x_hi + omega_lo x_hi + omega_hi x_lo for a 16 x 16 block.  A lane then holds four adjacent
 //     frequencies of one point: phase, v_fract, v_cos / v_sin, the f16 halves (v_cvt_pk_f16_f32 + v_fma_mix_f32) and ONE
 //     8-byte LDS store per half tile.  (Formed by v_pk_fma_f32 chains this phase took half the kernel.)
-//   * products: each wave runs 54 MFMAs on its 16-row tile(s), the fragments of the next column tile requested before
+//   * products: each wave runs 36 MFMAs on its 16-row tile(s), the fragments of the next column tile requested before
 //     the MFMAs of the current one.
 // LDS tiles are [row][32 k] f16 with 64-byte rows and no padding: the 16-byte chunk c of row r sits at chunk
 // c ^ h[(r >> 2) & 3], h = (0, 2, 3, 1), which makes the ds_read_b128 fragment reads of a 16-row tile conflict-free
@@ -50,8 +53,10 @@ __device__ __forceinline__ float vg_uniform(float x) {
 }
 
 inline size_t vg_fused_split_lds(int MT) {
-    return (size_t)2 * kTS * MT * kHRowBytes + (size_t)4 * kTJ * kHRowBytes + (size_t)2 * kTJ * kHRowBytes +
-           (size_t)2 * kHK * kHRowBytes + (size_t)2 * kHK * sizeof(float);
+    // W tile (MT = 1 only: with MT = 2 the fragments stay in the registers of the wave that multiplies with them), the four feature
+    // tiles, the two point tiles, the double-buffered frequency tile and phases, the table of the W stream
+    return (MT == 2 ? 0 : (size_t)kTS * MT * kHRowBytes) + (size_t)4 * kTJ * kHRowBytes + (size_t)2 * kTJ * kHRowBytes +
+           (size_t)2 * kHK * kHRowBytes + (size_t)2 * kHK * sizeof(float) + (size_t)kWTableSize * sizeof(unsigned short);
 }
 
 template <bool DELL, int MT>      // d/d ell wanted; 64 MT sample rows per workgroup
@@ -61,15 +66,18 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l = blockIdx.z % L, p = blockIdx.z / L;
     constexpr int kRows = kTS * MT;
+    constexpr int kARows = MT == 2 ? 0 : kRows;
     const int s0 = blockIdx.y * kRows, j0 = blockIdx.x * kTJ;
     const size_t pl = (size_t)p * L + l;
-    unsigned char* Ah = hs_lds;                                   // [kRows][64 B]   W, high halves
-    unsigned char* Al = Ah + kRows * kHRowBytes;                  //                 W, low halves
-    unsigned char* Bt = Al + kRows * kHRowBytes;                  // [4][144][64 B]  cos hi, cos lo, (sin x.w) hi, (sin x.w) lo
+    unsigned char* Ah = hs_lds;                                   // [kRows][64 B]   W (float16 as drawn)   -- MT = 1 only
+    unsigned char* Bt = Ah + kARows * kHRowBytes;                 // [4][144][64 B]  cos hi, cos lo, (sin x.w) hi, (sin x.w) lo
     unsigned char* Xa = Bt + 4 * kTJ * kHRowBytes;                // [144][64 B]     the tile's points: [x_hi | x_hi]
     unsigned char* Xb = Xa + kTJ * kHRowBytes;                    //                                    [x_lo | 0]
     unsigned char* Om = Xb + kTJ * kHRowBytes;                    // [2][32][64 B]   the K step's frequencies [omega_hi | omega_lo], double buffered
     float* btp = reinterpret_cast<float*>(Om + 2 * kHK * kHRowBytes);      // [2][32]  their phases / 2 pi
+    unsigned short* wtab = reinterpret_cast<unsigned short*>(btp + 2 * kHK);   // [8192]    magnitudes of the W stream (gp_wtable.h)
+    for (int e = tid; e < kWTableSize / 8; e += kHThreads)
+        reinterpret_cast<uint4*>(wtab)[e] = reinterpret_cast<const uint4*>(kWTable)[e];
     for (int e = tid; e < kTJ * kHD; e += kHThreads) {
         const int jj = e >> 4, d = e & (kHD - 1), j = min(j0 + jj, J - 1);
         const double* pt = j < N ? a.X + (size_t)j * D : a.Zy + (size_t)p * a.zy_stride + (size_t)(j - N) * D;
@@ -90,9 +98,12 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
     const float rs = vg_uniform(inv_ell * kInv2Pi);
     const uint2 key = vg_key(a.seed, a.problem_base + p, a.ctr ? *a.ctr : a.step);
     // ---- generation roles
-    // W: thread (row = tid / 4, part = tid % 4) draws the 8 normals of k = 8 part .. 8 part + 7: ONE counter of the W stream
-    //    (vg_normal8).  MT = 2: all 512 threads (128 rows); MT = 1: the first four waves (64 rows), the others start on the features
-    const int wrow = (tid >> 2) & (kRows - 1), wpart = tid & 3;
+    // W: ONE counter of the W stream = the eight float16 weights k = 8 part .. 8 part + 7 of a row (vg_w8: forty Philox instructions
+    //    and eight table reads; the weights ARE float16, so W has no low half: two MFMAs per product, not three).
+    //    MT = 2: wave w multiplies with rows 16 w .. 16 w + 15 and lane (r, g)'s A fragment IS the counter (row 16 w + r, part g):
+    //            every lane draws its own fragment into registers -- no W tile, no LDS round trip;
+    //    MT = 1: two waves share a row tile (F0 / H): thread (row = tid / 4, part = tid % 4) of the first four waves draws into the tile
+    const int wrow = MT == 2 ? 16 * wave + (lane & 15) : (tid >> 2) & (kRows - 1), wpart = MT == 2 ? lane >> 4 : tid & 3;
     const bool draws_w = MT == 2 || wave < 4;
     const uint32_t wbase = ((a.wOff + ((uint32_t)min(s0 + wrow, S - 1) * L + l) * (uint32_t)B) >> 3) + (uint32_t)wpart;
     // frequencies: element e of the step's 32 contiguous rows of omega (32 D floats), then the 32 phases
@@ -134,26 +145,28 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
 #pragma unroll
         for (int t = 0; t < kTJ / 16; ++t) acc[u][t] = (vg_f32x4){0.f, 0.f, 0.f, 0.f};
     const int r = lane & 15, g = lane >> 4;
+    vg_h8 a_frag = {};                                            // MT = 2: this step's A fragment
     __syncthreads();
     om_fetch(0);
     om_store(0);
+    if (kHK < B) { om_fetch(kHK); om_store(1); }
     __syncthreads();
     int ob = 0;
+#ifdef VGPMP_BISECT
+    // phase stamps of workgroup (0, 0, 0), K steps 8..15, every wave: id = 640 + 48 (k - 8) + 8 phase + wave (tools/prior_trace.py)
+#define VG_PT(phase) do { const int ki_ = (k0 >> 5) - 8; if (lane == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && ki_ >= 0 && ki_ < 8) \
+        vg_tr_buf[640 + 48 * ki_ + 8 * (phase) + wave] = wall_clock64(); } while (0)
+#else
+#define VG_PT(phase) do { } while (0)
+#endif
     for (int k0 = 0; k0 < B; k0 += kHK) {
-        // ================= generate the K step's operands (the next step's frequencies are requested first, stored last)
-        const bool more = k0 + kHK < B;
-        if (more) om_fetch(k0 + kHK);
-        // ---- W: the thread's counter covers k = 8 wpart .. 8 wpart + 7: one 16-byte chunk of each half tile
-        if (draws_w) {      // (uniform per wave)
-            float z[8];
-            vg_normal8(wbase + (uint32_t)(k0 >> 3), VG_STREAM_W, key, z);
-            vg_h4 h0, l0, h1, l1;
-            vg_split4((vg_f32x4){z[0], z[1], z[2], z[3]}, h0, l0);
-            vg_split4((vg_f32x4){z[4], z[5], z[6], z[7]}, h1, l1);
-            const int off = wrow * kHRowBytes + vg_swz(wrow, wpart) * 16;
-            *reinterpret_cast<vg_h8*>(Ah + off) = (vg_h8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-            *reinterpret_cast<vg_h8*>(Al + off) = (vg_h8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-        }
+        VG_PT(0);
+        // ================= generate the K step's operands.  The frequency tile is double buffered two steps deep: the tile of step
+        // k + 1 is complete, step k + 2's values sit in two registers since the end of the previous generation phase (their
+        // requests flew under its products) and go into the buffer that step k just finished with -- so nothing requested from
+        // memory is live across the features, where registers are shortest
+        if (k0 > 0 && k0 + kHK < B) om_store(ob ^ 1);
+        VG_PT(1);
         // ---- features: unit u = (point tile t, frequency half h) -> a 16 x 16 block of projections by two MFMAs;
         //      lane (r, g) then holds point 16 t + r against the frequencies 16 h + 4 g .. + 3
         // (MT = 1: waves 4-7, which draw no W, take the first twelve units, three each; waves 0-3 the last six)
@@ -190,42 +203,57 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
                 *reinterpret_cast<vg_h4*>(Bt + 3 * kTJ * kHRowBytes + off) = lo;
             }
         }
-        if (more) om_store(ob ^ 1);
+        // ---- W: the thread's counter covers k = 8 wpart .. 8 wpart + 7: one 16-byte chunk of the row (drawn last: the fragment is
+        //      not live across the features)
+        if (draws_w) {      // (uniform per wave)
+            const vg_h8 w8 = vg_w8(wbase + (uint32_t)(k0 >> 3), key, wtab);
+            if (MT == 2) a_frag = w8;
+            else *reinterpret_cast<vg_h8*>(Ah + wrow * kHRowBytes + vg_swz(wrow, wpart) * 16) = w8;
+        }
+        if (k0 + 2 * kHK < B) om_fetch(k0 + 2 * kHK);
+        VG_PT(2);
         __syncthreads();
-        // ================= products: per 16 x 16 tile  hi hi + hi lo + lo hi, float32 accumulators
+        VG_PT(3);
+        // ================= products: per 16 x 16 tile  w hi + w lo (the weight is a float16: nothing else), float32 accumulators
         {
-            const int arow = 16 * rt + r;
-            const int aoff = arow * kHRowBytes + vg_swz(arow, g) * 16;
-            const vg_h8 ah = *reinterpret_cast<const vg_h8*>(Ah + aoff);
-            const vg_h8 al = *reinterpret_cast<const vg_h8*>(Al + aoff);
+            vg_h8 ah;
+            if (MT == 2) ah = a_frag;
+            else {
+                const int arow = 16 * rt + r;
+                ah = *reinterpret_cast<const vg_h8*>(Ah + arow * kHRowBytes + vg_swz(arow, g) * 16);
+            }
             const int boff0 = r * kHRowBytes + vg_swz(r, g) * 16;      // (16 t + r has the swizzle of r)
             constexpr int NT = kTJ / 16;
-            vg_h8 bh[2][NU], bl[2][NU];
-            auto load_b = [&](int t, int slot) {
-#pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    const int mat = MT == 2 ? u : mat0;
-                    bh[slot][u] = *reinterpret_cast<const vg_h8*>(Bt + (2 * mat) * kTJ * kHRowBytes + t * 16 * kHRowBytes + boff0);
-                    bl[slot][u] = *reinterpret_cast<const vg_h8*>(Bt + (2 * mat + 1) * kTJ * kHRowBytes + t * 16 * kHRowBytes + boff0);
-                }
+            // items (column tile t, product u) in sequence, the fragments of item i + 1 requested before the MFMAs of item i: a ring of
+            // two 8-register slots (a slot per column tile holding both products' fragments, 32 registers, left the allocator
+            // so little room at 128 that it moved every read next to its MFMA: one exposed LDS round trip per product)
+            constexpr int NI = (MT == 2 && DELL) ? 2 * NT : NT;
+            vg_h8 bh[2], bl[2];
+            auto load_i = [&](int i, int slot) {
+                const int t = (MT == 2 && DELL) ? i >> 1 : i, mat = MT == 2 ? (DELL ? i & 1 : 0) : mat0;
+                bh[slot] = *reinterpret_cast<const vg_h8*>(Bt + (2 * mat) * kTJ * kHRowBytes + t * 16 * kHRowBytes + boff0);
+                bl[slot] = *reinterpret_cast<const vg_h8*>(Bt + (2 * mat + 1) * kTJ * kHRowBytes + t * 16 * kHRowBytes + boff0);
             };
-            if (NT) load_b(0, 0);
+            if (DELL || MT == 2 || mat0 == 0) {      // (without d/d ell the H waves of the 64-row form have nothing to multiply)
+                load_i(0, 0);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (t + 1 < NT) load_b(t + 1, (t + 1) & 1);
-#pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    const int mat = MT == 2 ? u : mat0;
-                    if (!DELL && mat == 1) continue;
-                    acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[t & 1][u], acc[u][t], 0, 0, 0);
-                    acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[t & 1][u], acc[u][t], 0, 0, 0);
-                    acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[t & 1][u], acc[u][t], 0, 0, 0);
+                for (int i = 0; i < NI; ++i) {
+                    const int t = (MT == 2 && DELL) ? i >> 1 : i, u = (MT == 2 && DELL) ? i & 1 : 0;
+                    if (i + 1 < NI) load_i(i + 1, (i + 1) & 1);
+                    // (the scheduler, short of registers, otherwise sinks every read next to the MFMA that uses it)
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[i & 1], acc[u][t], 0, 0, 0);
+                    acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[i & 1], acc[u][t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
+        VG_PT(4);
         __syncthreads();
+        VG_PT(5);
         ob ^= 1;
     }
+#undef VG_PT
     // ---- D layout: col = lane & 15, row = (lane >> 4) * 4 + reg; the constant factors left out of the tiles go in here
     const float scale_f = c, scale_h = c * inv_ell * inv_ell;
 #pragma unroll
@@ -258,7 +286,9 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
 //     c / ell^2 go to the accumulators at the end, so the operands stay in f16's range as in prior_fused_split_kernel;
 //   * a lane's A fragment is 8 consecutive weights of one sample row: two 16-byte loads of W, split.
 // Four waves = the four K-slices whose slabs the path kernels sum; operands requested one K step ahead.
-template <int MT, int DM, bool DELL>    // 16-row sample tiles; joint extent DM = D for 6 / 7 joints, else padded to 8 or 16; d/d ell wanted
+// WX: the weights in a.W were drawn by the library's own generator -- float16 values (vgpmp_device.h, "The W stream") -- so W has no
+// low half: no split, two MFMAs per product.  Weights handed in by the caller (parity tests) are arbitrary float32: WX = false.
+template <int MT, int DM, bool DELL, bool WX>    // 16-row sample tiles; joint extent DM = D for 6 / 7 joints, else padded to 8 or 16; d/d ell wanted
 __global__ __launch_bounds__(kBlock, 2) void prior_fused_small16_kernel(FusedPriorArgs a) {
     __shared__ float pts[kFNT * 16][DM];
     const int S = a.S, L = a.L, J = a.J, N = a.N, D = a.D, B = a.B;
@@ -319,11 +349,17 @@ __global__ __launch_bounds__(kBlock, 2) void prior_fused_small16_kernel(FusedPri
         vg_h8 ah[MT], al[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            vg_h4 h0, l0, h1, l1;
-            vg_split4(x.w0[m], h0, l0);
-            vg_split4(x.w1[m], h1, l1);
-            ah[m] = (vg_h8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-            al[m] = (vg_h8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+            if (WX) {
+                const vg_h4 h0 = __builtin_convertvector(x.w0[m], vg_h4), h1 = __builtin_convertvector(x.w1[m], vg_h4);      // exact
+                ah[m] = (vg_h8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                al[m] = ah[m];                                    // (unused)
+            } else {
+                vg_h4 h0, l0, h1, l1;
+                vg_split4(x.w0[m], h0, l0);
+                vg_split4(x.w1[m], h1, l1);
+                ah[m] = (vg_h8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                al[m] = (vg_h8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+            }
         }
         const vg_f32x4 bt0 = x.b0 * 0.15915494309189535f, bt1 = x.b1 * 0.15915494309189535f;      // phases in revolutions
 #pragma unroll
@@ -349,7 +385,7 @@ __global__ __launch_bounds__(kBlock, 2) void prior_fused_small16_kernel(FusedPri
             const vg_h8 bl = (vg_h8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                accF[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh, accF[m][t], 0, 0, 0);
+                if (!WX) accF[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh, accF[m][t], 0, 0, 0);
                 accF[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl, accF[m][t], 0, 0, 0);
                 accF[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh, accF[m][t], 0, 0, 0);
             }
@@ -360,7 +396,7 @@ __global__ __launch_bounds__(kBlock, 2) void prior_fused_small16_kernel(FusedPri
                 const vg_h8 dl = (vg_h8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    accH[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], dh, accH[m][t], 0, 0, 0);
+                    if (!WX) accH[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], dh, accH[m][t], 0, 0, 0);
                     accH[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], dl, accH[m][t], 0, 0, 0);
                     accH[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], dh, accH[m][t], 0, 0, 0);
                 }

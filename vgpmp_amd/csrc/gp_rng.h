@@ -59,7 +59,7 @@ __device__ __forceinline__ void rng_basis_body(const RngArgs& a, int bx, int p, 
     }
 }
 
-// w [P, nW]: counter i of the stream yields global elements 8i..8i+7 (vg_normal8; wOff and nW are multiples of 16: B is);
+// w [P, nW]: counter i of the stream yields global elements 8i..8i+7 (vg_w8: float16-valued weights out of the bin-mean table; wOff and nW are multiples of 16: B is);
 // eps, eps2 [P, nE]: a thread per COUNTER of the stream as well -- elements eOff .. eOff + nE - 1 of the global sample axis,
 // which need not start on a counter (sample-sharded ranks): the first and last counters of a rank are partly its neighbours'.
 __host__ __device__ __forceinline__ uint32_t rng_eps_quads(uint32_t nE, uint32_t eOff) {
@@ -76,7 +76,7 @@ __device__ __forceinline__ void rng_normals_body(const RngArgs& a, int bx, int p
     const uint2 key = vg_key(a.seed, a.problem_base + p, rng_step(a));
     if (c < cW) {
         float z[8];
-        vg_normal8((a.wOff >> 3) + c, VG_STREAM_W, key, z);
+        vg_w8_f32((a.wOff >> 3) + c, key, kWTable, z);
         float4* dst = reinterpret_cast<float4*>(a.w + (size_t)p * nW + 8u * c);
         vg_stream(dst, make_float4(z[0], z[1], z[2], z[3]));
         vg_stream(dst + 1, make_float4(z[4], z[5], z[6], z[7]));

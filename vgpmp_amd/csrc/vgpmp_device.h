@@ -255,25 +255,18 @@ __device__ __forceinline__ float4 vg_normal4(uint32_t i, uint32_t stream, uint2 
     return make_float4(r0 * __builtin_amdgcn_cosf(u1), r0 * __builtin_amdgcn_sinf(u1),
                        r1 * __builtin_amdgcn_cosf(u3), r1 * __builtin_amdgcn_sinf(u3));
 }
-// The W stream (prior weights: by far the largest draw of a step, S L B normals per problem) spends ONE counter per EIGHT
-// normals: every 32-bit word of the Philox block gives one Box-Muller pair from two 16-bit uniforms, radius from the low half,
-// angle from the high half, u = (h + 1/2) 2^-16.  (Element 8 i + 2 j + {0, 1} of the stream comes from word j of counter i.)
-// Sixteen bits put 65 536 radii x 65 536 directions under every pair and bound |z| by 4.855; mean 0 exactly (the directions are
-// symmetric), variance 1 - 4e-6.  Identical restatement: oracle/vgpmp_oracle.py::philox_normals8.
-__device__ __forceinline__ float vg_u01_16(uint32_t h) { return ((float)h + 0.5f) * 1.52587890625e-05f; }
-__device__ __forceinline__ void vg_normal8_from(uint4 r, float (&z)[8]) {
-    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(vg_u01_16(w[j] & 0xffffu)));
-        const float ang = vg_u01_16(w[j] >> 16);
-        z[2 * j] = rad * __builtin_amdgcn_cosf(ang);
-        z[2 * j + 1] = rad * __builtin_amdgcn_sinf(ang);
-    }
-}
-__device__ __forceinline__ void vg_normal8(uint32_t i, uint32_t stream, uint2 key, float (&z)[8]) {
-    vg_normal8_from(vg_philox(make_uint4(i, stream, 0u, 0u), key), z);
-}
+// The W stream (prior weights: by far the largest draw of a step, S L B values per problem) spends ONE Philox counter per EIGHT
+// weights and no transcendental at all: every 16-bit half of the block's four words is one weight, w = +-T[h & 0x1fff] with the sign
+// from bit 15 of the half (bits 13, 14 unused).  T (csrc/gp_wtable.h, generated by tools/make_w_table.py) holds the means of |z|,
+// z ~ N(0, 1), over 8192 equally probable bins of the half-normal distribution, as float16: a stratified inverse-CDF draw with
+// 16 384 equally likely values -- E[w] = 0 exactly, Var[w] = 1 - 5e-6, |w| <= 4.074.  (Element 8 i + 2 j + {0, 1} of the stream
+// comes from the {low, high} half of word j of counter i.)  The values are float16 on purpose: the prior kernels of large batches
+// multiply W on the f16 matrix pipe (gp_prior_split.h), and a weight that IS a float16 has no low half to carry -- two MFMAs per
+// float32-accurate product instead of three -- and the draw itself is forty Philox instructions and eight table reads where
+// Box-Muller on hardware log / sqrt / sin / cos was a third of that kernel's vector time.  The reference draws float64 normals
+// from TensorFlow's generator (models/vgpmp.py:281 through GPflowSampling); no implementation can match those bits, the
+// restatement of THIS stream is oracle/vgpmp_oracle.py::philox_normals8 -- bit for bit, there is no rounding to disagree on.
+// (vg_w8 and the table live in gp_common.h / gp_wtable.h: only the gp_path.hip translation unit draws W.)
 __device__ __forceinline__ float vg_lane(const float4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
 __device__ __forceinline__ float vg_normal1(uint32_t e, uint32_t stream, uint2 key) {
     return vg_lane(vg_normal4(e >> 2, stream, key), (int)(e & 3u));
