@@ -595,6 +595,27 @@ def run_sample_sharded(args, world, rank, dist, backend):
                           "(16 KB), never run on more than one rank here -- every microsecond of it lowers the speed-up",
             "what_does_not_shrink": "stage 1 / stage 2's covariance roles, the gradient assembly (mid_hyper_final) and Adam are per "
                                     "problem, not per sample: they are the floor of the step as ranks are added"}
+    if world > 1:
+        # what the step costs WITHOUT its collective, measured by the same ranks (every rank runs the same local steps -- forward,
+        # reverse, Adam, nothing exchanged -- behind the same barriers; MAX over ranks): measured - local = what the all-reduce
+        # adds per step.  Held against the N = 1 line's projection_8_ranks, an N-rank run judges itself.  (Last thing on the
+        # planner: without the exchange the ranks' variables drift apart.)
+        sp_l = sharding.SampleShardedPlanner(planner)
+        sp_l._allreduce = lambda buf=None: None
+        sp_l._single_rank = True
+        sp_l.run_steps(args.warmup)
+        a_l = type(args)(**vars(args))
+        a_l.min_seconds = min(args.min_seconds, 1.0)
+        el_l, _ = timed_region(sp_l.run_steps, a_l, dist, backend)
+        if rank == 0:
+            local_us = 1e6 * el_l / args.steps
+            line["collective_breakdown"] = {
+                "ranks": world, "samples_per_rank": S_loc, "measured_us_per_step": round(1e3 * line["ms_per_step"], 2),
+                "rank_local_us_per_step": round(local_us, 2),
+                "collective_us_per_step": round(1e3 * line["ms_per_step"] - local_us, 2),
+                "how": "the same ranks ran the same number of steps without the all-reduce (vgpmp_elbo_steps_reduced, no communicator) "
+                       "behind the same barriers; the N = 1 line of this bench carries projection_8_ranks (one rank's share of the "
+                       "8-rank job timed alone) to hold rank_local_us_per_step against"}
     if comm is not None:
         comm.close()
     return line
@@ -801,6 +822,13 @@ def summary_of(line):
                          "prior_frac": r3(rec["roofline_secondary"]["frac"])}
     out["line"] = {"ms_per_step": r3(line["ms_per_step"]), "value": round(float(line["value"]), 1), "n_gpus": line["n_gpus"],
                    "sdf_frac_hbm": r3(line["roofline"]["frac"])}
+    if line.get("collective_breakdown"):
+        c8 = line["collective_breakdown"]
+        out["collective"] = {k: c8[k] for k in ("ranks", "rank_local_us_per_step", "collective_us_per_step")}
+    if line.get("projection_8_ranks"):
+        p8 = line["projection_8_ranks"]
+        out["projection_8_ranks"] = {"rank_local_us_per_step": p8["rank_local_us_per_step"],
+                                     "speedup_before_collective": p8["predicted_speedup_at_8_ranks_before_the_collective"]}
     cb = line.get("cpu_baseline") or {}
     if cb.get("openmp"):
         out["cpu_openmp"] = {"value": r3(cb["openmp"].get("value")), "threads": cb["openmp"].get("threads")}

@@ -43,6 +43,16 @@ def pytest_sessionstart(session):
     bench = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shard", "samples", "--steps", "5",
                               "--warmup", "2", "--min-seconds", "0", "--profile-steps", "1"], env=env, stdout=log, stderr=err)
     session.config._bench_gpus2 = (bench, out)
+    # ... and the two EIGHT-rank launches a SCALE run makes, rehearsed on this box's one GPU (ranks share
+    # the device, rendezvous over gloo): problem-sharded with batch_512 riding along, and sample-sharded.  One after the other
+    # (a shell chain: sixteen rank interpreters at once would starve the box's few cores).  No scaling number comes out of
+    # this -- eight ranks on one device measure nothing -- only that the N = 8 paths start, agree and print what a real run needs.
+    quick = ["--steps", "5", "--warmup", "1", "--min-seconds", "0", "--profile-steps", "1", "--no-solve"]
+    cmd8 = " ".join([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + quick) + \
+        f" > {out}/bench_gpus8_problems.out 2> {out}/bench_gpus8_problems.err; " + \
+        " ".join([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--shard", "samples"] + quick) + \
+        f" > {out}/bench_gpus8_samples.out 2> {out}/bench_gpus8_samples.err"
+    session.config._bench_gpus8 = (subprocess.Popen(["bash", "-c", cmd8], env=env), out)
 
 
 def pytest_sessionfinish(session, exitstatus):
@@ -51,13 +61,14 @@ def pytest_sessionfinish(session, exitstatus):
         for p in w[0]:
             if p.poll() is None:
                 p.kill()
-    b = getattr(session.config, "_bench_gpus2", None)
-    if b and b[0].poll() is None:
-        b[0].terminate()
-        try:
-            b[0].wait(timeout=5)
-        except subprocess.TimeoutExpired:
-            b[0].kill()
+    for name in ("_bench_gpus2", "_bench_gpus8"):
+        b = getattr(session.config, name, None)
+        if b and b[0].poll() is None:
+            b[0].terminate()
+            try:
+                b[0].wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                b[0].kill()
 
 
 @pytest.fixture(scope="session")
@@ -95,3 +106,19 @@ def bench_gpus2(request):
     se = open(os.path.join(out, "bench_gpus2.err")).read()
     assert proc.returncode == 0, se[-3000:]
     return so, se
+
+
+@pytest.fixture(scope="session")
+def bench_gpus8(request):
+    """{"problems" | "samples": (stdout, stderr)} of the two `python bench.py --gpus 8 ...` launches started at session start."""
+    b = getattr(request.config, "_bench_gpus8", None)
+    if not b:
+        pytest.skip("only started by `-m gpu` runs on a GPU box")
+    proc, out = b
+    try:
+        proc.wait(timeout=1500)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.wait()
+    return {k: (open(os.path.join(out, f"bench_gpus8_{k}.out")).read(), open(os.path.join(out, f"bench_gpus8_{k}.err")).read())
+            for k in ("problems", "samples")}

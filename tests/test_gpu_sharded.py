@@ -89,3 +89,31 @@ def test_bench_starts_its_own_ranks(bench_gpus2):
     assert d["value"] > 0 and d["roofline"]["achieved"] > 0
     # (config 4's 16 MB table is cache resident: the line prices no fraction of the HBM peak for it)
     assert d["roofline"]["frac"] is None and d["roofline"]["bound"].startswith("cache")
+
+
+def test_bench_eight_ranks_both_sharding_modes(bench_gpus8):
+    """What a SCALE run launches at N = 8, rehearsed on one GPU (eight ranks share the device over gloo: NO scaling number can be
+    earned this way, only that the paths start and agree): `python bench.py --gpus 8` -- problems sharded, no collective, the
+    config-5 share (batch_512: 64 problems per rank = the 512-problem batch) riding along -- and `--gpus 8 --shard samples` --
+    one all-reduce per step over eight ranks, with the collective's cost per step separated by the ranks themselves."""
+    import json
+    so, se = bench_gpus8["problems"]
+    lines = [l for l in so.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (so[-1500:], se[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    assert "problems sharded x8" in d["config"]["parallelism"]
+    b = d["batch_512"]
+    assert b["problems_total"] == 512 and b["value"] > 0 and b["roofline"]["bound"] == "hbm" and b["roofline"]["frac"] > 0
+    assert list(d)[-1] == "summary" and d["summary"]["batch_512"]["ms_per_step"] > 0 and d["summary"]["line"]["n_gpus"] == 8
+    so, se = bench_gpus8["samples"]
+    lines = [l for l in so.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (so[-1500:], se[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["collective_ranks"] == 8
+    assert "128 on this rank" in d["config"]["workload"]
+    cb = d["collective_breakdown"]
+    assert cb["ranks"] == 8 and cb["samples_per_rank"] == 128
+    assert cb["rank_local_us_per_step"] > 0 and abs(cb["measured_us_per_step"] - 1e3 * d["ms_per_step"]) < 0.02
+    assert abs(cb["collective_us_per_step"] - (cb["measured_us_per_step"] - cb["rank_local_us_per_step"])) < 0.02
+    assert list(d)[-1] == "summary"
