@@ -218,7 +218,10 @@ struct MidGArgs {            // hyper-parameter update | q_mu, q_sqrt update + E
     HyperArgs hy; FinalArgs fin;
     int n_hyper;             // = problems
 };
-__global__ __launch_bounds__(kBlock) void mid_hyper_final_kernel(MidGArgs a) {
+// MZCAP = 32 (Mz <= 32: every reference problem set): the gradient assembly's register arrays at half size, under 128 registers --
+// four workgroups per CU, so the 960 workgroups of 896 latent pairs (config-5 share) are ONE round instead of a full and a thin one
+template <int MZCAP>
+__global__ __launch_bounds__(kBlock, MZCAP <= 32 ? 4 : 1) void mid_hyper_final_kernel(MidGArgs a) {
     extern __shared__ double sm[];
     int b = blockIdx.x;
     const HyperArgs& h = a.hy;
@@ -227,6 +230,23 @@ __global__ __launch_bounds__(kBlock) void mid_hyper_final_kernel(MidGArgs a) {
     if (b < a.n_hyper) {
         const int p = b, l = threadIdx.x;
         if (own && p == 0 && l == 0) h.lr_store[0] = lr_own;
+        if constexpr (MZCAP <= 32) {
+            // the update by whole waves (hyper_update_wave: one load per lane, butterfly sums -- bit-identical to the one-lane form,
+            // which keeps 16 chunks x 3 partials in registers: 165 of them, the reason this launch ran three workgroups per CU)
+            for (int lw = threadIdx.x >> 6; lw < h.L; lw += kBlock / VG_WAVE) {
+                const size_t plw = (size_t)p * h.L + lw;
+                const HyperState o = hyper_update_wave(h, plw, own, lr_own);
+                if ((threadIdx.x & (VG_WAVE - 1)) == 0) {
+                    h.g_ell[plw] = o.g_ell;
+                    h.g_var[plw] = o.g_var;
+                    if (h.do_adam) {
+                        h.p_ell[plw] = o.raw_ell; h.m_ell[plw] = o.m_ell; h.v_ell[plw] = o.v_ell;
+                        h.p_var[plw] = o.raw_var; h.m_var[plw] = o.m_var; h.v_var[plw] = o.v_var;
+                    }
+                }
+            }
+            return;
+        }
         if (l >= h.L) return;
         const size_t pl = (size_t)p * h.L + l;
         const HyperState o = hyper_update(h, pl, own, lr_own);
@@ -241,12 +261,14 @@ __global__ __launch_bounds__(kBlock) void mid_hyper_final_kernel(MidGArgs a) {
     b -= a.n_hyper;
     FinalArgs fb = a.fin;      // the step size comes from the counter here: the update role that stores it runs alongside
     if (own) { fb.use_lr_dev = 0; fb.lr_t = lr_own; }
-    if (fb.split) {
+    if constexpr (MZCAP <= 32) {      // (large batches only: never the column-strip form of small launches)
+        final_body<MZCAP>(fb, sm, b % fb.L, b / fb.L);
+    } else if (fb.split) {
         const int q = b % kFinSplit;
         b /= kFinSplit;
         final_cols_body(fb, sm, q, b % fb.L, b / fb.L);
     } else {
-        final_body(fb, sm, b % fb.L, b / fb.L);
+        final_body<MZCAP>(fb, sm, b % fb.L, b / fb.L);
     }
 }
 
@@ -590,6 +612,9 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     // large batches: passes of eight chunks -- 46 instead of 80 KB of LDS, a third workgroup per CU; the same sums in the same order
     // (config-5 share: 51 -> 47 us for the launch)
     if (!fused && NC > 8 && (size_t)P * L >= 512) fin_pass = 8;
+    // ... and of four from 768 latent pairs (Mz <= 32: mid_hyper_final_kernel<32>, four workgroups per CU at 30 KB each): one round
+    // (config-5 share: 41 -> 3x us for the launch; half sums carried between passes: the same additions in the same order)
+    if (!fused && NC > 4 && Mz <= 32 && (size_t)P * L >= 768) fin_pass = 4;
     lds_fin += (size_t)fin_pass * row_fin;
     fa.dma = fin_pass;
     // few problems: the update role of stage 1 by column strips on kFinSplit workgroups (its LDS need is below lds_fin)
@@ -677,7 +702,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     // few samples, four K-slices: features inside the GEMM (prior_fused_small_kernel)
     const bool fused_small = !fused && SK == 4 && S <= 32 && (B % 64) == 0 && !(what & VGPMP_GEMM_DIRECT);
     if (!fused && (rc = set_dyn_lds(VG_FN(mid_cov_a_rng_kernel), lds_cov_a))) return rc;      // (the large-batch schedule merges its small launches with these two as well)
-    if ((rc = set_dyn_lds(VG_FN(mid_hyper_final_kernel), lds_fin))) return rc;
+    const void* fn_mhf = fin_pass == 4 ? VG_FN(mid_hyper_final_kernel<32>) : VG_FN(mid_hyper_final_kernel<48>);      // (fin_pass == 4: Mz <= 32, 768 latent pairs or more)
+    if ((rc = set_dyn_lds(fn_mhf, lds_fin))) return rc;
     const dim3 cov_b_grid(kCovFixedRoles + (ca.rows_wave ? (N + 63) / 64 : (row_tiles + rows_tpw - 1) / rows_tpw), L, P);
     // eps / eps' also as [P,L,S,Mz] wherever a consumer stages them per latent (the register-resident path kernels, stage B's U
     // role): drawn by rng_eps_t_body then, kEpsRows rows of (s, k) per workgroup
@@ -997,7 +1023,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             hy.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
             fa.lr_t = hy.lr_t;
             mg.hy = hy; mg.fin = fa; mg.n_hyper = P;
-            if ((rc = launch(VG_FN(mid_hyper_final_kernel), dim3(P + L * P * (fin_split_batch ? kFinSplit : 1)), &mg, lds_fin))) return rc;
+            if ((rc = launch(fn_mhf, dim3(P + L * P * (fin_split_batch ? kFinSplit : 1)), &mg, lds_fin))) return rc;
         } else if (!fused) {
             hy.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
             fa.lr_t = hy.lr_t;

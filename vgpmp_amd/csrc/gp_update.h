@@ -138,7 +138,7 @@ __device__ __forceinline__ double vg_dpp_f64(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ HyperState hyper_update_wave(const HyperArgs& h, size_t pl) {
+__device__ __forceinline__ HyperState hyper_update_wave(const HyperArgs& h, size_t pl, bool own_lr = false, double lr_own = 0.0) {
 #pragma clang fp contract(off)
     const int lane = threadIdx.x & (VG_WAVE - 1), j = min(lane >> 4, 2), k = lane & 15;
     const bool isv = lane >= 32;                 // upper half: variance, lower half: lengthscale
@@ -151,7 +151,7 @@ __device__ __forceinline__ HyperState hyper_update_wave(const HyperArgs& h, size
     double raw = (isv ? h.p_var : h.p_ell)[pl], m = mp[pl], v = vp[pl];
     const double gkl = (isv ? h.gkl_var : h.gkl_ell)[pl], sig = (isv ? h.sig_var : h.sig_ell)[pl], var = h.var[pl];
     const double lr_dev = h.lr_dev[0];
-    const double lr_t = (h.do_adam && h.use_lr_dev) ? lr_dev : h.lr_t;
+    const double lr_t = own_lr ? lr_own : ((h.do_adam && h.use_lr_dev) ? lr_dev : h.lr_t);
     if (!h.do_adam) m = v = 0.0;
     double s = 0.0;
     for (int c0 = 0; c0 < h.NC; c0 += 16) {
@@ -262,8 +262,11 @@ __device__ __forceinline__ void elbo_pieces(const float* lik_partial, int nblk, 
 // Gradient assembly of one (latent, problem).  Everything it reads is requested up front -- the chunk partials
 // and the Cholesky factor by DMA into LDS (when `dma`), the KL gradients and the Adam state of this thread's
 // elements into registers -- so the kernel waits for memory once, not once per loop iteration.
-constexpr int kFinRegs = ((VGPMP_MAX_MZ - 2) * (VGPMP_MAX_MZ - 1) + kBlock - 1) / kBlock;      // elements per thread
+// MZCAP: the largest Mz the instantiation serves -- its per-thread register arrays are sized for it (48: 9 + 10 elements per
+// thread, 138-167 registers: three workgroups per CU; 32 -- every reference problem set -- : 4 + 5 elements, under 128: four)
+template <int MZCAP = VGPMP_MAX_MZ>
 __device__ __forceinline__ void final_body(const FinalArgs& b, double* sm, int l, int p) {
+    constexpr int kFinRegs = ((MZCAP - 2) * (MZCAP - 1) + kBlock - 1) / kBlock;      // elements per thread
     VG_STOP(b, 7);
     const int tid = threadIdx.x, nt = blockDim.x;
     VG_T(l == 0 && p == 0, 110 + b.tshift);
@@ -307,10 +310,39 @@ __device__ __forceinline__ void final_body(const FinalArgs& b, double* sm, int l
     if (cpp) {
         // running sums of this thread's elements e = tid + j nt, passes of `cpp` chunks (sample-sharded runs on few ranks have
         // more chunks than LDS holds: 128 at S = 1024; summed from global memory that cost 16 dependent round trips)
-        constexpr int kSumRegs = (VGPMP_MAX_MZ + VGPMP_MAX_MZ * VGPMP_MAX_MZ + kBlock - 1) / kBlock;
+        constexpr int kSumRegs = (MZCAP + MZCAP * MZCAP + kBlock - 1) / kBlock;
         double sacc[kSumRegs];
 #pragma unroll
         for (int j = 0; j < kSumRegs; ++j) sacc[j] = 0.0;
+        if (cpp == 4) {
+            // passes of FOUR chunks (half the LDS of eight: a fourth workgroup per CU): sum_chunks() adds groups of eight as
+            // ((d0 + d1) + (d2 + d3)) + ((d4 + d5) + (d6 + d7)) -- the first half sum is carried from the even pass to the odd one,
+            // so the additions and their order are unchanged (a missing half is the +0.0 the eight-chunk form adds there)
+            double half[kSumRegs];
+            for (int cb = 0; cb < b.NC; cb += 4) {
+                const int nc = min(4, b.NC - cb);
+                const bool odd = (cb & 4) != 0;
+                if (cb > 0) {
+                    __syncthreads();                     // the previous pass has been read
+                    vg_stage_rows(raw, nc, np, tid, nt, [&](int c) -> const float* { return part + (size_t)(cb + c) * b.part_len; });
+                    vg_dma_wait();
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int j = 0; j < kSumRegs; ++j) {
+                    const int e = tid + j * nt;
+                    if (e < np) {
+                        double d[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) d[k] = k < nc ? (double)raw[(size_t)min(k, nc - 1) * np + e] : 0.0;
+                        const double h = (d[0] + d[1]) + (d[2] + d[3]);
+                        if (odd) sacc[j] += half[j] + h;
+                        else if (cb + 4 >= b.NC) sacc[j] += h + ((0.0 + 0.0) + (0.0 + 0.0));
+                        else half[j] = h;
+                    }
+                }
+            }
+        } else
         for (int cb = 0; cb < b.NC; cb += cpp) {
             const int nc = min(cpp, b.NC - cb);
             if (cb > 0) {
