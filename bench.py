@@ -227,6 +227,7 @@ def cpu_baseline(ps, spec, grid, args, budget_s: float = 10.0, pool=None):
         out["single_thread"] = {"value": n1 / el1, "cores": 1,
                                 "sample": f"{n1} steps in {el1:.1f} s with the BLAS pool limited to one thread"}
     if pool is not None:
+        out["openmp"] = pool.run_omp(min(budget_s, 6.0))
         out["problem_parallel"] = pool.run(budget_s)
     return out
 
@@ -282,6 +283,12 @@ class CpuPool:
         self.err = open(os.path.join(self.dir, "workers.err"), "w")
         self.procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", self.dir, str(i)], env=env,
                                        stdout=subprocess.DEVNULL, stderr=self.err) for i in range(self.n)]
+        # ... and ONE process for the compiled OpenMP restatement (oracle/cpu_step.cpp): its own interpreter so that its OpenMP
+        # runtime is the only one in the process, waiting passively between parallel regions (spinning threads of an idle pool
+        # cost a container with a CPU quota most of its cores)
+        env_omp = dict(os.environ, OMP_WAIT_POLICY="passive", OMP_NUM_THREADS=str(self.n), OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        self.omp = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", self.dir, "-1"], env=env_omp,
+                                    stdout=subprocess.DEVNULL, stderr=self.err)
 
     def go(self, ps, spec, grid, args) -> None:
         import numpy as np
@@ -305,6 +312,22 @@ class CpuPool:
 
     def wait_ready(self, timeout_s: float = 120.0):
         self.ready = self._wait("ready_%d", timeout_s)
+        t0 = time.time()      # (the compiled restatement builds its library for this host on first use: a few seconds of one core)
+        while not os.path.exists(os.path.join(self.dir, "ready_omp")) and self.omp.poll() is None and time.time() - t0 < timeout_s:
+            time.sleep(0.05)
+
+    def run_omp(self, budget_s: float):
+        """The compiled restatement (oracle/cpu_step.cpp) on one thread, on all usable cores (OpenMP inside one problem) and as
+        one single-threaded problem per core; the other workers sleep meanwhile."""
+        json.dump({"budget": budget_s, "threads": self.n}, open(os.path.join(self.dir, "start_omp.tmp"), "w"))
+        os.replace(os.path.join(self.dir, "start_omp.tmp"), os.path.join(self.dir, "start_omp.json"))
+        path = os.path.join(self.dir, "result_omp.json")
+        t0 = time.time()
+        while not os.path.exists(path) and self.omp.poll() is None and time.time() - t0 < 6 * budget_s + 120:
+            time.sleep(0.05)
+        if not os.path.exists(path):
+            return {"value": None, "error": "the OpenMP worker did not finish (see " + self.err.name + ")"}
+        return json.load(open(path))
 
     def run(self, budget_s: float):
         json.dump({"budget": budget_s}, open(os.path.join(self.dir, "start.tmp"), "w"))
@@ -326,7 +349,7 @@ class CpuPool:
 
     def close(self) -> None:
         open(os.path.join(self.dir, "cancel"), "w").close()
-        for p in self.procs:
+        for p in self.procs + [self.omp]:
             try:
                 p.wait(timeout=5)
             except Exception:
@@ -336,8 +359,97 @@ class CpuPool:
         shutil.rmtree(self.dir, ignore_errors=True)
 
 
+def cpu_omp_worker_main(jobdir: str) -> int:
+    """`bench.py --cpu-worker <dir> -1`: the compiled OpenMP restatement (oracle/cpu_step.cpp, kind "port") timed on the same
+    workload -- noise draw (compiled, std::mt19937_64) + forward + reverse + Adam per step: one thread; all usable cores inside
+    one problem; one single-threaded problem per core (Python threads around the GIL-free C call)."""
+    import threading
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_scene
+    from oracle import cpu_step
+    from oracle import vgpmp_oracle as orc
+    from vgpmp_amd import robots
+    parent = os.getppid()
+
+    def wait_for(name, timeout_s):
+        t0 = time.time()
+        path = os.path.join(jobdir, name)
+        while not os.path.exists(path):
+            if os.path.exists(os.path.join(jobdir, "cancel")) or os.getppid() != parent or time.time() - t0 > timeout_s:
+                return None
+            time.sleep(0.05)
+        return json.load(open(path))
+
+    job = wait_for("go.json", 3600.0)
+    if job is None:
+        return 0
+    cpu_step.load()                                           # (builds the library for this host's CPU if it is not there)
+    ps = robots.load_problemset(job["robot"], job["problemset"])
+    pp = ps.planner_params
+    spec = robots.load_robot(job["robot"], *ps.robot_pos_and_orn)
+    data = np.load(os.path.join(jobdir, "grid.npy"))
+    sc = oracle_scene(spec, (data, np.array(job["origin"]), job["delta"]), ps.object_positions[0], sigma_obs=pp["sigma_obs"],
+                      epsilon=pp["epsilon"])
+    S, N, M, B, D = job["S"], job["N"], job["M"], job["B"], spec.dof
+    X, Zy = orc.init_trainset(N, D), orc.inducing_Zy(M, D)
+    alpha, lr = float(pp["alpha"]), float(pp["learning_rate"])
+
+    def problem(k):
+        y = np.array(ps.queries[k % len(ps.queries)], dtype=np.float64)
+        return cpu_step.Problem(sc, X, Zy, y, orc.init_params(sc.robot, y, M, pp["lengthscales"], pp["variance"]))
+
+    def run(pr, nb, threads, budget, seed0):
+        pr.step(nb.draw(seed0, threads), alpha, lr, threads=threads)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            pr.step(nb.draw(seed0 + 1 + n, threads), alpha, lr, threads=threads)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget and n >= 3:
+                return n, el
+
+    problem(0).step(cpu_step.NoiseBuffers(S, D, D, B, M + 2).draw(0, 1), alpha, lr, threads=1)      # warm
+    open(os.path.join(jobdir, "ready_omp"), "w").close()
+    start = wait_for("start_omp.json", 3600.0)
+    if start is None:
+        return 0
+    budget, T = float(start["budget"]), int(start["threads"])
+    nb = cpu_step.NoiseBuffers(S, D, D, B, M + 2)
+    n1, e1 = run(problem(0), nb, 1, budget / 2, 0)
+    nT, eT = run(problem(0), nb, T, budget / 2, 1000)
+    counts, t_par = [0] * T, [0.0] * T
+
+    def worker(i):
+        counts[i], t_par[i] = run(problem(i), cpu_step.NoiseBuffers(S, D, D, B, M + 2), 1, budget / 2, 10000 * (i + 1))
+
+    c0 = time.process_time()
+    w0 = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(T)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    wall = time.perf_counter() - w0
+    busy = (time.process_time() - c0) / wall
+    res = {"value": nT / eT, "unit": "ELBO iters/sec", "threads": T, "kind": "port",
+           "single_thread": {"value": n1 / e1, "threads": 1},
+           "problem_parallel": {"value": sum(counts) / max(t_par), "unit": "problem-steps/sec", "threads": T,
+                                "cores_busy_measured": round(busy, 1)},
+           "sample": f"oracle/cpu_step.cpp (float64 C++ / OpenMP restatement of the same step, g++ -O3 -march=native; cross-checked against "
+                     f"the NumPy oracle to 1e-9 by tests/test_oracle_cpu_step.py): {n1} steps in {e1:.1f} s on one thread; {nT} steps in "
+                     f"{eT:.1f} s with {T} OpenMP threads inside the one problem; {sum(counts)} problem-steps in {max(t_par):.1f} s as {T} "
+                     f"single-threaded problems side by side; every step draws its own noise (compiled generator)"}
+    tmp = os.path.join(jobdir, "result_omp.tmp")
+    json.dump(res, open(tmp, "w"))
+    os.replace(tmp, os.path.join(jobdir, "result_omp.json"))
+    return 0
+
+
 def cpu_worker_main(jobdir: str, index: int) -> int:
     """`bench.py --cpu-worker <dir> <i>`: one process of CpuPool.  NumPy + the oracle only (no torch, no GPU)."""
+    if index < 0:
+        return cpu_omp_worker_main(jobdir)
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_scene

@@ -115,10 +115,13 @@ def test_cpu_pool_of_the_problem_parallel_baseline(tmp_path):
         pool.go(ps, spec, grid, args)
         pool.wait_ready(timeout_s=120)
         assert pool.ready == [0, 1]
+        omp = pool.run_omp(0.6)            # the compiled restatement: one thread, OpenMP over the pool's cores, a problem per core
         rec = pool.run(0.5)
     finally:
         if any(p.poll() is None for p in pool.procs):
             pool.close()
     assert rec["cores"] == 2 and rec["processes"] == 2 and rec["unit"] == "problem-steps/sec"
     assert rec["value"] > 0 and abs(rec["per_process"] * 2 - rec["value"]) < 1e-9
-    assert all(p.poll() == 0 for p in pool.procs)
+    assert all(p.poll() == 0 for p in pool.procs) and pool.omp.poll() == 0
+    assert omp["kind"] == "port" and omp["threads"] == 2 and omp["value"] > 0 and omp["single_thread"]["value"] > 0
+    assert omp["problem_parallel"]["value"] > 0 and omp["problem_parallel"]["threads"] == 2 and "cpu_step.cpp" in omp["sample"]
