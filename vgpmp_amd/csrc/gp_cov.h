@@ -440,7 +440,24 @@ __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, 
     if (tid < VG_WAVE) {
         const bool isv = tid >= 32;
         double raw;
-        if (a.prologue) {
+        if (a.prologue == 2) {
+            // large batches (mid_stage1_kernel): the hyper-parameter update of the previous step, committed here -- no other role of
+            // that launch reads the kernel hyper-parameters, and this workgroup is the only writer of its latent's
+            const HyperArgs& h = a.hy;
+            const bool own = h.ctr && h.do_adam;
+            const double lr_own = own ? adam_step_size(h.lr, (double)*h.ctr) : 0.0;
+            if (own && pl == 0 && tid == 0) h.lr_store[0] = lr_own;
+            const HyperState o = hyper_update_wave(h, pl, own, lr_own);
+            if (tid == 0) {
+                h.g_ell[pl] = o.g_ell;
+                if (h.do_adam) { h.p_ell[pl] = o.raw_ell; h.m_ell[pl] = o.m_ell; h.v_ell[pl] = o.v_ell; }
+            }
+            if (tid == 32) {
+                h.g_var[pl] = o.g_var;
+                if (h.do_adam) { h.p_var[pl] = o.raw_var; h.m_var[pl] = o.m_var; h.v_var[pl] = o.v_var; }
+            }
+            raw = isv ? o.raw_var : o.raw_ell;
+        } else if (a.prologue) {
             const HyperState o = hyper_update_wave(a.hy, pl);
             double* nx = a.hy.next + 6 * pl;
             if (tid == 0) { a.hy.g_ell[pl] = o.g_ell; nx[0] = o.raw_ell; nx[2] = o.m_ell; nx[3] = o.v_ell; }

@@ -214,6 +214,45 @@ __global__ __launch_bounds__(kCovThreads, 2) void mid_cov_a_rng_kernel(MidAArgs 
     rng_eps_t_body(a.rng, b % a.e_gx, b / a.e_gx, reinterpret_cast<float*>(sm));
 }
 
+// Steps after the first of a call: the updates of step t - 1 ride in the first launch of step t, as in the few-problem schedule --
+// the q_mu / q_sqrt gradient assembly + Adam as a role of its own BESIDE stage A and the draws, the hyper-parameter update as
+// the prologue of stage A (cov_a_body, prologue 2) -- instead of a launch of their own between two steps: one dependency level
+// and one launch boundary fewer per step, and the gradient assembly (per-CU ingest of the chunk partials) runs under the draws.
+struct MidS1Args {
+    MidAArgs a; FinalArgs fin; HyperArgs hy;
+    int n_fin;
+};
+template <int MZCAP>
+__global__ __launch_bounds__(kBlock, MZCAP <= 32 ? 4 : 1) void mid_stage1_kernel(MidS1Args s) {
+    extern __shared__ double sm[];
+    int b = blockIdx.x;
+    if (b < s.n_fin) {       // (the longest role first)
+        const HyperArgs& h = s.hy;
+        const bool own = h.ctr && h.do_adam;
+        FinalArgs fb = s.fin;      // the step size comes from the counter here, as in mid_hyper_final_kernel
+        if (own) { fb.use_lr_dev = 0; fb.lr_t = adam_step_size(h.lr, (double)*h.ctr); }
+        if constexpr (MZCAP <= 32) {
+            final_body<MZCAP>(fb, sm, b % fb.L, b / fb.L);
+        } else if (fb.split) {
+            const int q = b % kFinSplit;
+            b /= kFinSplit;
+            final_cols_body(fb, sm, q, b % fb.L, b / fb.L);
+        } else {
+            final_body<MZCAP>(fb, sm, b % fb.L, b / fb.L);
+        }
+        return;
+    }
+    b -= s.n_fin;
+    const MidAArgs& a = s.a;
+    if (b < a.n_cov) { cov_a_body(a.cov, sm, b % a.cov.L, b / a.cov.L); return; }
+    b -= a.n_cov;
+    if (b < a.n_basis) { rng_basis_body(a.rng, b % a.basis_gx, b / a.basis_gx, reinterpret_cast<float*>(sm)); return; }
+    b -= a.n_basis;
+    if (b < a.n_norm) { rng_normals_body(a.rng, b % a.n_gx, b / a.n_gx, a.rng.nW, a.rng.nE); return; }
+    b -= a.n_norm;
+    rng_eps_t_body(a.rng, b % a.e_gx, b / a.e_gx, reinterpret_cast<float*>(sm));
+}
+
 struct MidGArgs {            // hyper-parameter update | q_mu, q_sqrt update + ELBO pieces
     HyperArgs hy; FinalArgs fin;
     int n_hyper;             // = problems
@@ -614,7 +653,9 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     if (!fused && NC > 8 && (size_t)P * L >= 512) fin_pass = 8;
     // ... and of four from 768 latent pairs (Mz <= 32: mid_hyper_final_kernel<32>, four workgroups per CU at 30 KB each): one round
     // (config-5 share: 41 -> 3x us for the launch; half sums carried between passes: the same additions in the same order)
-    if (!fused && NC > 4 && Mz <= 32 && (size_t)P * L >= 768) fin_pass = 4;
+    // ... and wherever the assembly shares the first launch of the next step with stage A and the draws (mid_stage1_kernel: every
+    // role of a launch is granted the launch's LDS -- 80 KB of chunk partials per workgroup left two workgroups per CU for all of them)
+    if (!fused && NC > 4 && Mz <= 32 && (size_t)P * L > 128) fin_pass = 4;      // (up to 128 latent pairs: possibly the column-strip form)
     lds_fin += (size_t)fin_pass * row_fin;
     fa.dma = fin_pass;
     // few problems: the update role of stage 1 by column strips on kFinSplit workgroups (its LDS need is below lds_fin)
@@ -702,7 +743,10 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     // few samples, four K-slices: features inside the GEMM (prior_fused_small_kernel)
     const bool fused_small = !fused && SK == 4 && S <= 32 && (B % 64) == 0 && !(what & VGPMP_GEMM_DIRECT);
     if (!fused && (rc = set_dyn_lds(VG_FN(mid_cov_a_rng_kernel), lds_cov_a))) return rc;      // (the large-batch schedule merges its small launches with these two as well)
-    const void* fn_mhf = fin_pass == 4 ? VG_FN(mid_hyper_final_kernel<32>) : VG_FN(mid_hyper_final_kernel<48>);      // (fin_pass == 4: Mz <= 32, 768 latent pairs or more)
+    // (the register arrays of the gradient assembly at half size wherever Mz <= 32 -- every reference problem set -- and the assembly is
+    //  not the column-strip form of small launches: 99 instead of 167 registers)
+    const bool fin_mz32 = Mz <= 32 && !(fin_split && (size_t)L * P <= 128);
+    const void* fn_mhf = fin_mz32 ? VG_FN(mid_hyper_final_kernel<32>) : VG_FN(mid_hyper_final_kernel<48>);
     if ((rc = set_dyn_lds(fn_mhf, lds_fin))) return rc;
     const dim3 cov_b_grid(kCovFixedRoles + (ca.rows_wave ? (N + 63) / 64 : (row_tiles + rows_tpw - 1) / rows_tpw), L, P);
     // eps / eps' also as [P,L,S,Mz] wherever a consumer stages them per latent (the register-resident path kernels, stage B's U
@@ -868,7 +912,20 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 if (fbatch) ma.rng.nW = 0;               // omega, beta, eps, eps2 only
                 ma.n_cov = L * P; ma.basis_gx = (int)((ma.rng.L * ma.rng.B + kBlock - 1) / kBlock); ma.n_basis = ma.basis_gx * P;
                 const unsigned n_draw = mid_normal_grid(ma);
-                if ((rc = launch(VG_FN(mid_cov_a_rng_kernel), dim3(ma.n_cov + ma.n_basis + n_draw), &ma, lds_cov_a))) return rc;
+                if (!first && do_adam) {
+                    // the updates of step i - 1 (left out at its end, below) beside stage A and the draws of this step
+                    MidS1Args s1;
+                    s1.a = ma;
+                    s1.a.cov.prologue = 2;
+                    hy.lr_t = adam_lr_t(lr, adam_t + i - 1 > 0 ? adam_t + i - 1 : 1);
+                    fa.lr_t = hy.lr_t;
+                    s1.a.cov.hy = hy; s1.hy = hy; s1.fin = fa;
+                    s1.n_fin = L * P * (fin_split_batch ? kFinSplit : 1);
+                    const size_t lds_s1b = lds_cov_a > lds_fin ? lds_cov_a : lds_fin;
+                    const void* fn_ms1 = fin_mz32 ? VG_FN(mid_stage1_kernel<32>) : VG_FN(mid_stage1_kernel<48>);
+                    if ((rc = set_dyn_lds(fn_ms1, lds_s1b))) return rc;
+                    if ((rc = launch(fn_ms1, dim3(s1.n_fin + ma.n_cov + ma.n_basis + n_draw), &s1, lds_s1b))) return rc;
+                } else if ((rc = launch(VG_FN(mid_cov_a_rng_kernel), dim3(ma.n_cov + ma.n_basis + n_draw), &ma, lds_cov_a))) return rc;
             } else {
                 VG_GGL(cov_a_kernel, dim3(L, P), dim3(kCovThreads), lds_cov_a, st, ca);
             }
@@ -1018,7 +1075,9 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             VG_GGL(lik_update_kernel, dim3(P), dim3(kLikUpdWaves * VGPMP_MAX_SPHERES), 0, st, lu);
         }
         mark();
-        if (batch_merged || (fused && !more)) {      // (fused, more steps to come: both ride in stage 1 of the next step)
+        if (batch_merged && more && do_adam) {
+            // (more steps to come in this call: both updates ride in the first launch of the next step, mid_stage1_kernel)
+        } else if (batch_merged || (fused && !more)) {      // (fused, more steps to come: both ride in stage 1 of the next step)
             MidGArgs mg;
             hy.lr_t = do_adam ? adam_lr_t(lr, adam_t + i > 0 ? adam_t + i : 1) : 0.0;
             fa.lr_t = hy.lr_t;
