@@ -43,16 +43,24 @@ def pytest_sessionstart(session):
     bench = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shard", "samples", "--steps", "5",
                               "--warmup", "2", "--min-seconds", "0", "--profile-steps", "1"], env=env, stdout=log, stderr=err)
     session.config._bench_gpus2 = (bench, out)
-    # ... and the two EIGHT-rank launches a SCALE run makes, rehearsed on this box's one GPU (ranks share
-    # the device, rendezvous over gloo): problem-sharded with batch_512 riding along, and sample-sharded.  One after the other
-    # (a shell chain: sixteen rank interpreters at once would starve the box's few cores).  No scaling number comes out of
-    # this -- eight ranks on one device measure nothing -- only that the N = 8 paths start, agree and print what a real run needs.
+    # ... and a launcher that WAITS: the two eight-rank launches of a SCALE run (bench_gpus8 below) are started only when the test
+    # that needs them says so (a trigger file) -- by this child, forked here before this process touches the GPU, never by the
+    # GPU-initialised test process itself
     quick = ["--steps", "5", "--warmup", "1", "--min-seconds", "0", "--profile-steps", "1", "--no-solve"]
-    cmd8 = " ".join([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + quick) + \
-        f" > {out}/bench_gpus8_problems.out 2> {out}/bench_gpus8_problems.err; " + \
-        " ".join([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--shard", "samples"] + quick) + \
-        f" > {out}/bench_gpus8_samples.out 2> {out}/bench_gpus8_samples.err"
-    session.config._bench_gpus8 = (subprocess.Popen(["bash", "-c", cmd8], env=env), out)
+    code = (
+        "import os, subprocess, sys, time\n"
+        f"out, root, quick = {out!r}, {ROOT!r}, {quick!r}\n"
+        "parent = os.getppid()\n"
+        "while not os.path.exists(os.path.join(out, 'go8')):\n"
+        "    if os.getppid() != parent: sys.exit(0)\n"
+        "    time.sleep(0.2)\n"
+        "for key, extra in (('problems', []), ('samples', ['--shard', 'samples'])):\n"
+        "    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8'] + extra + quick, capture_output=True, text=True)\n"
+        "    open(os.path.join(out, 'bench_gpus8_%s.out' % key), 'w').write(p.stdout)\n"
+        "    open(os.path.join(out, 'bench_gpus8_%s.err' % key), 'w').write(p.stderr)\n"
+        "    open(os.path.join(out, 'bench_gpus8_%s.rc' % key), 'w').write(str(p.returncode))\n"
+        "open(os.path.join(out, 'done8'), 'w').close()\n")
+    session.config._bench_gpus8 = (subprocess.Popen([sys.executable, "-c", code], env=env), out)
 
 
 def pytest_sessionfinish(session, exitstatus):
@@ -110,15 +118,25 @@ def bench_gpus2(request):
 
 @pytest.fixture(scope="session")
 def bench_gpus8(request):
-    """{"problems" | "samples": (stdout, stderr)} of the two `python bench.py --gpus 8 ...` launches started at session start."""
+    """{"problems" | "samples": (stdout, stderr)} of the two EIGHT-rank launches a SCALE run makes, rehearsed on
+    this box's one GPU (ranks share the device, rendezvous over gloo): problem-sharded with batch_512 riding along, then
+    sample-sharded.  Triggered HERE, when the first test asks for them, and waited for (sixteen rank interpreters beside the
+    other tests would starve the box's few cores and share the GPU with every parity test); started by the waiting launcher of
+    pytest_sessionstart.  No scaling number comes out of this -- eight ranks on one device measure nothing -- only that the
+    N = 8 paths start, agree and print what a real run needs."""
+    import time
     b = getattr(request.config, "_bench_gpus8", None)
     if not b:
-        pytest.skip("only started by `-m gpu` runs on a GPU box")
+        pytest.skip("only run by `-m gpu` on a GPU box")
     proc, out = b
-    try:
-        proc.wait(timeout=1500)
-    except subprocess.TimeoutExpired:
-        proc.kill()
-        proc.wait()
-    return {k: (open(os.path.join(out, f"bench_gpus8_{k}.out")).read(), open(os.path.join(out, f"bench_gpus8_{k}.err")).read())
-            for k in ("problems", "samples")}
+    open(os.path.join(out, "go8"), "w").close()
+    t0 = time.time()
+    while not os.path.exists(os.path.join(out, "done8")) and proc.poll() is None and time.time() - t0 < 1500:
+        time.sleep(0.2)
+    res = {}
+    for key in ("problems", "samples"):
+        rd = lambda ext: open(os.path.join(out, f"bench_gpus8_{key}.{ext}")).read()
+        assert os.path.exists(os.path.join(out, f"bench_gpus8_{key}.rc")), "the eight-rank launcher did not finish"
+        assert rd("rc") == "0", rd("err")[-3000:]
+        res[key] = (rd("out"), rd("err"))
+    return res

@@ -21,7 +21,7 @@ pmc() {     # pmc <tag> <bench args...>: FETCH_SIZE and WRITE_SIZE in separate p
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_$c -- python3 bench.py "$@" --min-seconds 0 --profile-steps 2 > /dev/null 2> $out/${tag}_$c.err || ok=0
   done
-  if [ $ok = 1 ]; then python tools/pmc_aggregate.py $out/${tag}_FETCH_SIZE $out/${tag}_WRITE_SIZE $out/${tag}_pmc_fetch_write_kb.json $out/${tag}_pmc_traffic.json > /dev/null
+  if [ $ok = 1 ]; then python tools/pmc_aggregate.py $out/${tag}_FETCH_SIZE $out/${tag}_WRITE_SIZE $out/${tag}_pmc_fetch_write_kb.json $out/${tag}_pmc_traffic.json $tag > /dev/null
   else echo "pmc pass failed for $tag" >&2; fi
   rm -rf $out/${tag}_FETCH_SIZE $out/${tag}_WRITE_SIZE
 }

@@ -1,0 +1,80 @@
+"""Algorithmic bytes and flops per launch of the kernels of the batch schedule (every tensor a kernel reads or writes counted
+ONCE, at the size the data layout of DESIGN.md section 2 gives it), by workload.  tools/pmc_aggregate.py holds the FETCH_SIZE /
+WRITE_SIZE counters against these: the ratio counter / algorithmic is how the per-kernel FETCH multiplier is chosen (the gfx950
+correction of MI355X_MICROARCH.md: wide coalesced streams are tallied at half their bytes) and how wasted traffic shows.
+
+Workloads (P problems per GPU, S samples, N times, M inducing points, L joints, Q spheres, B bases):"""
+
+WORKLOADS = {
+    "config2": dict(P=1, S=128, N=100, M=30, L=7, Q=37, B=1024),
+    "config3": dict(P=55, S=7, N=70, M=24, L=7, Q=37, B=1024),
+    "config5": dict(P=64, S=128, N=100, M=30, L=14, Q=45, B=1024),
+    "franka64": dict(P=64, S=128, N=100, M=30, L=7, Q=37, B=1024),
+    "config4_1rank": dict(P=1, S=1024, N=70, M=18, L=6, Q=17, B=1024),
+}
+
+
+def workload_of(tag: str):
+    """config5_mask / config5_summary / ... -> config5."""
+    for name in sorted(WORKLOADS, key=len, reverse=True):
+        if tag.startswith(name):
+            return WORKLOADS[name]
+    return None
+
+
+def table(w):
+    """kernel-name prefix -> dict(read=bytes, write=bytes, access=..., flops=..., note=...).  access: "wide" = 16-byte-per-lane
+    coalesced streams / LDS-DMA rows (FETCH_SIZE tallies half), "gather" = scattered 16-byte records (tallied ~1:1, 65 B per
+    gather that misses: profiles/r02/final/gather_probe_calib.txt), "mixed"."""
+    P, S, N, M, L, Q, B = (w[k] for k in ("P", "S", "N", "M", "L", "Q", "B"))
+    Mz, J, NC, PL = M + 2, N + M + 2, -(-S // 8), P * L
+    f4, f8 = 4, 8
+    t = {}
+    t["prior_fused_split_kernel"] = dict(
+        read=PL * (B * L + B) * f4, write=2 * P * S * L * J * f4, access="wide", flops=2 * 2.0 * P * S * J * L * B,
+        note="reads omega, beta; writes F0, H (W and the features never exist in memory)")
+    t["prior_fused_small16_kernel"] = dict(
+        read=PL * (B * L + B) * f4 + P * S * L * B * f4, write=4 * 2 * P * S * L * J * f4, access="wide", flops=2 * 2.0 * P * S * J * L * B,
+        note="reads omega, beta, W; writes four K-slices of F0, H")
+    t["paths_fwd_regs"] = dict(
+        read=P * S * L * J * f4 + PL * (N * Mz + Mz * Mz + Mz) * f4 + 2 * PL * S * Mz * f4, write=P * S * L * (N + Mz) * f4, access="wide",
+        flops=2.0 * P * S * L * (Mz * Mz + N * Mz), note="reads F0, AT, C, m, epsT, eps2T; writes f, R")
+    t["paths_bwd_regs"] = dict(
+        read=P * S * L * (N + 2 * Mz + 2 * J) * f4 + PL * N * Mz * 16 + 2 * PL * Mz * Mz * f4, write=PL * NC * (Mz + Mz * Mz + 8) * f4,
+        access="wide", flops=2.0 * P * S * L * (3 * N * Mz + 2 * Mz * Mz + Mz * Mz),
+        note="reads G, R, epsT, F0, H once and A4 (+ the tangents of C) once per latent; the 4 workgroups of a latent each fetch A4")
+    t["cov_b_kernel"] = dict(
+        read=PL * (5 * Mz * Mz + M * M + M + 2 * Mz) * f8, write=PL * (N * Mz * 20 + 5 * Mz * Mz * f4 + Mz * f4 + (M * M + M + 3) * f8),
+        access="mixed", flops=PL * (2.0 * 3 * N * Mz * Mz + 2.0 * 6 * Mz ** 3),
+        note="reads Kuu, dKuu, Lk, Lk^-1, (Kuu + jI)^-1, q_sqrt, q_mu; writes A4 (16 B per entry, a quarter of it padding), AT, C, CT, "
+             "the two tangents, Lk32, m, the KL gradients; float64 MFMA products")
+    t["mid_hyper_final_kernel"] = dict(
+        read=PL * NC * (Mz + Mz * Mz + 8) * f4 + PL * (Mz * Mz * f4 + 4 * (M * M + M) * f8), write=PL * 4 * (M * M + M) * f8, access="wide",
+        flops=PL * (2.0 * M * M * Mz / 2), note="reads the chunk partials, Lk32, KL gradients, variables + moments; writes gradient, variables, moments")
+    t["mid_stage1_kernel"] = dict(t["mid_hyper_final_kernel"], note="gradient assembly of the previous step (as mid_hyper_final_kernel) beside stage A and the draws; "
+                                  "+ omega / beta / eps / eps' writes", write=t["mid_hyper_final_kernel"]["write"] + PL * (B * L + B) * f4 + 4 * P * S * Mz * L * f4)
+    t["mid_cov_a_rng_kernel"] = dict(read=PL * (2 * Mz) * f8, write=PL * (B * L + B) * f4 + 4 * P * S * Mz * L * f4 + PL * 5 * Mz * Mz * f8, access="wide",
+                                     flops=PL * 2.0 * Mz ** 3, note="writes omega, beta, eps / eps' in both layouts, Kuu, dKuu, Lk, Lk^-1, (Kuu + jI)^-1")
+    lik = dict(read=P * S * L * N * f4 + 16 * P * S * N * Q, write=P * S * L * N * f4 + P * S * N * f4, access="gather",
+               flops=P * S * N * (Q * 40.0 + L * 120.0),
+               note="reads f and ONE 16-byte record per sphere query that is not skipped (upper bound: every query); writes G, logp; "
+                    "SURVEY 8(d) prices 28 B per query: S N (28 Q + 8 L + 4) B per problem")
+    for name in ("loglik_paths_mask_kernel", "loglik_paths_kernel", "loglik_paths_wide_kernel"):
+        t[name] = dict(lik)
+    return t
+
+
+def lookup(name: str, w):
+    if w is None:
+        return None
+    for prefix, rec in table(w).items():
+        if name.startswith(prefix):
+            return rec
+    return None
+
+
+if __name__ == "__main__":
+    import json
+    import sys
+    w = workload_of(sys.argv[1] if len(sys.argv) > 1 else "config5")
+    print(json.dumps({k: {a: (round(b / 1e6, 2) if a in ("read", "write") else b) for a, b in v.items()} for k, v in table(w).items()}, indent=1))

@@ -8,6 +8,7 @@ import csv
 import glob
 import json
 import re
+import os
 import sys
 from collections import defaultdict
 
@@ -28,30 +29,52 @@ def averages(d, counter):
 
 def main():
     fdir, wdir, out, traffic = sys.argv[1:5]
+    tag = sys.argv[5] if len(sys.argv) > 5 else os.path.basename(out)       # workload: config2 / config3 / config5_mask / ...
     fetch, n = averages(fdir, "FETCH_SIZE")
     write, _ = averages(wdir, "WRITE_SIZE")
     table = {k: {"launches": n[k], "fetch_size_kb": round(fetch[k], 1), "write_size_kb": round(write.get(k, 0.0), 1)}
              for k in sorted(fetch)}
     json.dump(table, open(out, "w"), indent=1)
-    import os
     stamp = ""
     sp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "COLLECT_STAMP")
     if os.path.exists(sp):
         stamp = open(sp).read().strip()
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import kernel_bytes
+    w = kernel_bytes.workload_of(tag)
     t = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, plain launches) of the same bench.py command, "
-                   "aggregated per kernel by tools/pmc_aggregate.py; bytes = FETCH_SIZE*1024 x multiplier + WRITE_SIZE*1024, multiplier 2 "
-                   "for kernels whose reads are wide coalesced streams (the gfx950 correction of MI355X_MICROARCH.md), 1 for the "
-                   "likelihood's 16-byte gathers (FETCH_SIZE tallies 65 B per random 16-byte gather: profiles/r02/final/gather_probe_calib.txt)",
-         "collected_at": stamp}
-    wide16 = ("prior_gemm_kernel<0>", "prior_gemm_lds_kernel", "prior_gemm_tiled_kernel", "stage2_kernel<true, 0>", "stage2_kernel<true, 8>",
-              "paths_bwd_sc8", "stage3_kernel")
+                   "aggregated per kernel by tools/pmc_aggregate.py.  hbm_bytes_per_launch = FETCH_SIZE*1024 x fetch_multiplier + "
+                   "WRITE_SIZE*1024.  The multiplier is CALIBRATED PER KERNEL against the kernel's algorithmic read volume "
+                   "(tools/kernel_bytes.py, every tensor once): gfx950 tallies a wide coalesced stream (16 B per lane, LDS-DMA rows) at "
+                   "half its bytes (MI355X_MICROARCH.md, HBM) -- a kernel of that access pattern gets x2, and so does any kernel whose raw "
+                   "FETCH_SIZE is below 0.75 of what it cannot avoid reading; scattered 16-byte gathers are tallied ~1:1 (65 B per "
+                   "gather that misses: profiles/r02/final/gather_probe_calib.txt) and get x1; kernels without a stated volume get x1 "
+                   "and are marked uncalibrated.  traffic_over_algorithmic = (reads x multiplier + writes) / (algorithmic reads + "
+                   "writes): well above 1 is re-read or partial-sector traffic",
+         "collected_at": stamp, "workload": tag}
     for k, v in table.items():
-        mult = 2 if any(k.startswith(w.split("<")[0]) for w in wide16) else 1
-        t[k] = dict(v, hbm_bytes_per_launch=int(mult * v["fetch_size_kb"] * 1024 + v["write_size_kb"] * 1024),
-                    fetch_multiplier=mult)
+        rec = kernel_bytes.lookup(k, w)
+        f_bytes, w_bytes = v["fetch_size_kb"] * 1024, v["write_size_kb"] * 1024
+        if rec is None:
+            mult, why = 1, "uncalibrated (no algorithmic volume stated for this kernel)"
+            extra = {}
+        else:
+            raw = f_bytes / max(rec["read"], 1.0)
+            if rec["access"] == "gather":
+                mult, why = 1, "scattered 16-byte gathers"
+            elif rec["access"] == "wide" or raw < 0.75:
+                mult, why = 2, ("wide coalesced streams" if rec["access"] == "wide" else "raw FETCH_SIZE %.2f of the algorithmic reads: under-tallied" % raw)
+            else:
+                mult, why = 1, "raw FETCH_SIZE %.2f of the algorithmic reads" % raw
+            extra = {"algorithmic_read_bytes": int(rec["read"]), "algorithmic_write_bytes": int(rec["write"]),
+                     "fetch_over_algorithmic_reads_raw": round(raw, 3),
+                     "write_over_algorithmic_writes": round(w_bytes / max(rec["write"], 1.0), 3),
+                     "traffic_over_algorithmic": round((mult * f_bytes + w_bytes) / max(rec["read"] + rec["write"], 1.0), 3),
+                     "algorithmic_flops": rec.get("flops"), "what": rec["note"]}
+        t[k] = dict(v, hbm_bytes_per_launch=int(mult * f_bytes + w_bytes), fetch_multiplier=mult, multiplier_basis=why, **extra)
     json.dump(t, open(traffic, "w"), indent=1)
     for k, v in t.items():
-        if k not in ("source", "collected_at"):
+        if k not in ("source", "collected_at", "workload"):
             print(k, v)
 
 
