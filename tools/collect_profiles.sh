@@ -4,7 +4,7 @@
 # Every profiler run sits under `timeout`; the program stands directly behind `--`.
 set -uo pipefail
 : "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}"
-round=${ROUND:-r04}
+round=${ROUND:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/${round}final; rm -rf "$out"; mkdir -p "$out"
 stats() {   # stats <tag> <bench args...>: bench line under the kernel trace + the kernel statistics table
@@ -85,6 +85,7 @@ B5S="--workload stress --steps 20 --warmup 3 $Q --profile-steps 2"
 tools/pmc_sq.sh prior_fused_split $out/sq_prior_fused_config5 $B5S > /dev/null 2>&1
 tools/pmc_sq.sh "loglik_paths_mask_kernel<" $out/sq_loglik_config5 $B5S > /dev/null 2>&1
 tools/pmc_sq.sh paths_bwd_regs $out/sq_paths_bwd_config5 $B5S > /dev/null 2>&1
+tools/pmc_sq.sh cov_b_kernel $out/sq_cov_b_config5 $B5S > /dev/null 2>&1
 tools/pmc_sq.sh stage2_kernel $out/sq_stage2_config2 --steps 40 --warmup 5 $Q > /dev/null 2>&1
 # ---- the memory system's ceiling for 16-byte gathers
 if [ -x tools/gather_probe ]; then
@@ -103,6 +104,8 @@ fi
 #      durations above are the authority for totals, this shows where inside the launches the time goes)
 if [ -f tools/libvgpmp_bisect.so ]; then
   VGPMP_HIP_LIB=$PWD/tools/libvgpmp_bisect.so timeout 300 python tools/step_trace.py 1 > $out/step_trace_config2.txt 2>&1
+  # ... and the phases of one workgroup of the large-batch prior kernel at the config-5 share (draw | features | barrier | products | barrier)
+  VGPMP_HIP_LIB=$PWD/tools/libvgpmp_bisect.so timeout 300 python tools/prior_trace.py > $out/prior_trace_config5.txt 2>&1
 fi
 # ---- the driver's line: config 2 + sub-records (batch_512, config3, batch_64) + plan quality + CPU baselines, with this
 #      collection's traffic tables in place
