@@ -144,7 +144,8 @@ typedef struct vgpmp_params {
 typedef struct vgpmp_noise {
     float* omega;          /* dev [P, L, B, D]  Student-t spectral frequencies  */
     float* beta;           /* dev [P, L, B]     phases U(0, 2 pi)               */
-    float* w;              /* dev [P, S, L, B]  prior weights N(0,1)            */
+    float* w;              /* dev [P, S, L, B]  prior weights ~ N(0,1): any float32 when injected; drawn by the library they are float16
+                            *                   VALUES (a table draw: see vgpmp_generate_noise)          */
     float* eps;            /* dev [P, S, Mz, L] N(0,1) for u = q_mu + q_sqrt eps */
     float* eps2;           /* dev [P, S, Mz, L] N(0,1) jitter perturbation      */
 } vgpmp_noise;
@@ -324,7 +325,12 @@ int vgpmp_lik_scratch_bytes(const vgpmp_dims* dims, size_t* bytes);
 /* Size of vgpmp_inducing_params.scratch for these dimensions. */
 int vgpmp_inducing_scratch_bytes(const vgpmp_dims* dims, size_t* bytes);
 
-/* Fills `noise` with the Philox-4x32-10 draws of (seed, problem index, step). */
+/* Fills `noise` with the Philox-4x32-10 draws of (seed, problem index, step): this implementation's own random streams (TensorFlow's
+ * generator, models/vgpmp.py:281 through GPflowSampling, cannot be reproduced).  omega (Student-t spectral draw), eps, eps2: Box-Muller
+ * normals, four per counter.  The prior weights w are a TABLE draw, eight per counter: w = +-T[h & 0x1fff] for every 16-bit half h of
+ * the block (sign: bit 15), T = the means of |z|, z ~ N(0, 1), over 8192 equally probable bins of the half-normal distribution as
+ * float16 -- E[w] = 0, Var[w] = 1 - 5e-6, |w| <= 4.074 --, so that a generated weight is an exact f16 operand of the matrix pipe.
+ * Restated bit for bit by oracle/vgpmp_oracle.py::philox_noise. */
 int vgpmp_generate_noise(const vgpmp_dims* dims, const vgpmp_noise* noise, uint32_t seed,
                          uint32_t problem_base, uint32_t step, vgpmp_stream stream);
 
@@ -423,6 +429,8 @@ int vgpmp_elbo_steps_reduced(const vgpmp_dims* dims, const vgpmp_robot* dev_robo
 int vgpmp_workspace_view(const vgpmp_dims* dims, void* dev_workspace, const char* name,
                          void** dev_ptr, size_t* count, int32_t* is_double);
 
+/* "vgpmp-hip <major.minor> (gfx950)".  0.2: vgpmp_sdf gained the free-space mask fields and vgpmp_problem aux_stream (struct
+ * layouts changed against 0.1); the measurement bits of `what` moved to include/vgpmp_debug.h (same values). */
 const char* vgpmp_version(void);
 
 #ifdef __cplusplus

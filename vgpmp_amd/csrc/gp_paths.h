@@ -570,6 +570,9 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
             }
     }
     const int cp_end = min((int)(blockIdx.x + 1) * a.cpw, a.NC);
+    // (measurement build: phases of workgroup (0, 0, 0) -- id 900 + 10 pair + phase; tools/pbr_trace.py)
+#define VG_PBT(pair, phase) VG_T(blockIdx.x == 0 && l == 0 && p == 0, 900 + 10 * (pair) + (phase))
+    VG_PBT(0, 9);
     auto stage_pair = [&](int ch0, int b) {
         const int s_base = ch0 * SC;
         float *Gs2 = GsB[b], *f0s2 = f0B[b], *Rs2 = RsB[b], *Es2 = EsB[b];
@@ -602,9 +605,13 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
     if (kPbrBufs > 1) stage_pair(blockIdx.x * a.cpw, 0);
     int cb = 0;
     for (int ch0 = blockIdx.x * a.cpw; ch0 < cp_end; ch0 += 2) {
+        const int pair_i = (ch0 - blockIdx.x * a.cpw) >> 1;
+        VG_PBT(pair_i, 0);
         if (kPbrBufs == 1) stage_pair(ch0, 0);
+        VG_PBT(pair_i, 1);
         vg_dma_wait();
         __syncthreads();
+        VG_PBT(pair_i, 2);
         float *Gs2 = GsB[cb], *f0s2 = f0B[cb], *Rs2 = RsB[cb], *Es2 = EsB[cb];
         float* hs2 = f0s2 + R2 * J;
         // the next pair's rows into the other set while this pair is worked on (everybody has left that set: the barrier above)
@@ -644,6 +651,7 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
                 }
         }
         __syncthreads();
+        VG_PBT(pair_i, 3);
         // ---- per chunk: exactly the element-wise part and the partials of paths_bwd_sc8
         for (int c = 0; c < 2 && ch0 + c < a.NC; ++c) {
             const int ch = ch0 + c;
@@ -698,8 +706,10 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
                 os[4] = 0.f; os[5] = 0.f; os[6] = 0.f; os[7] = 0.f;      // second set: paths_bwd_split only
             }
             __syncthreads();      // `red` and the chunk's rows are reused
+            VG_PBT(pair_i, 4 + c);
         }
     }
+#undef VG_PBT
 }
 
 // The same reverse pass on TWO workgroups per (sample chunk, latent) for launches that leave half the chip idle:
