@@ -839,7 +839,8 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
                  "traffic": None, "algorithmic_flops_per_launch": gemm_flops, "avg_launch_ms": kernel_ms["prior_gemm_kernel"]}
     dominant = max(stage_ms, key=stage_ms.get)
     # counter traffic of THIS round's collection, per workload (tools/run_collect.sh copies the tables to these names)
-    own = {("config2", 1): "pmc_traffic.json", ("stress", 64): "pmc_traffic_config5.json", ("config3", 55): "pmc_traffic_config3.json"}
+    own = {("config2", 1): "pmc_traffic.json", ("stress", 64): "pmc_traffic_config5.json", ("config3", 55): "pmc_traffic_config3.json",
+           ("config2", 64): "pmc_traffic_franka64.json"}
     tfile = os.path.join(ROOT, "profiles", own.get((args.workload, npb), "none"))
     if args.traffic_file:
         tfile = args.traffic_file
@@ -1018,6 +1019,11 @@ def main():
                 if default_workload and not args.no_solve:
                     line["cpu_baseline"]["oracle_plan_check"] = oracle_plan_check()
                 line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+                omp_ = line["cpu_baseline"].get("openmp") or {}
+                if omp_.get("value"):      # the compiled restatement on all usable cores: the CPU figure to hold the GPU's against
+                    line["gpu_over_cpu_openmp"] = line["value"] / omp_["value"]
+                    if (omp_.get("problem_parallel") or {}).get("value") and "batch_64" in line:
+                        line["gpu_batch_over_cpu_openmp_problem_parallel"] = line["batch_64"]["value"] / omp_["problem_parallel"]["value"]
                 pp_ = line["cpu_baseline"].get("problem_parallel")
                 if pp_ and pp_.get("value") and "batch_64" in line:
                     line["gpu_batch_over_cpu_problem_parallel"] = line["batch_64"]["value"] / pp_["value"]

@@ -57,6 +57,8 @@ pmc config3 --workload config3 --steps 130 --warmup 10 $Q
 if [ -f $out/config3_pmc_traffic.json ]; then cp $out/config3_pmc_traffic.json profiles/pmc_traffic_config3.json; fi
 # ---- 64 Franka problems per GPU (batch regime, cache-resident table)
 stats franka64 $Q --problems 64 --scene synthetic --min-seconds 0.5 --steps 200
+pmc franka64 $Q --problems 64 --steps 200
+if [ -f $out/franka64_pmc_traffic.json ]; then cp $out/franka64_pmc_traffic.json profiles/pmc_traffic_franka64.json; fi
 python bench.py $Q --problems 64 --scene synthetic --steps 200 > $out/franka64_bench.json 2>> $out/franka64.err
 # ---- config 4: UR10, S = 1024 samples; one rank, and two ranks on this one GPU over gloo (rehearsal of the N > 1 path,
 #      started by bench.py itself: no external launcher)

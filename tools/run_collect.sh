@@ -19,6 +19,7 @@ echo "$stamp" > "$dst/COLLECTED_AT"
 cp "$dst/config2_pmc_traffic.json" profiles/pmc_traffic.json
 [ -f "$dst/config5_mask_pmc_traffic.json" ] && cp "$dst/config5_mask_pmc_traffic.json" profiles/pmc_traffic_config5.json
 [ -f "$dst/config3_pmc_traffic.json" ] && cp "$dst/config3_pmc_traffic.json" profiles/pmc_traffic_config3.json
+[ -f "$dst/franka64_pmc_traffic.json" ] && cp "$dst/franka64_pmc_traffic.json" profiles/pmc_traffic_franka64.json
 python - <<PY
 import json
 t = json.load(open("profiles/pmc_traffic.json"))
