@@ -714,7 +714,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const bool regs_bwd = backward && !split_bwd && SK == 1 && Mz == 32 && (N & 3) == 0 && N <= 100 && pa.cpw >= 2;
     if (regs_bwd) {
         fn_pb = VG_FN(paths_bwd_regs<25>);
-        lds_pb = ((size_t)kPbrBufs * (16 * N + 32 * J + 2 * 16 * Mz + 16) + (size_t)6 * 16 * Mz + 8 * 4) * sizeof(float);
+        lds_pb = ((size_t)kPbrBufs * (16 * N + (VG_PBR_DIRECT ? 0 : 32 * J) + 2 * 16 * Mz + 16) + (size_t)6 * 16 * Mz + 8 * 4) * sizeof(float);
     }
     // ... and the forward assembly likewise (paths_fwd_regs); both take pa.cpw chunks per workgroup
     const bool regs_fwd = !fused && !split_fwd && SK == 1 && Mz == 32 && N <= 128 && pa.cpw >= 2;

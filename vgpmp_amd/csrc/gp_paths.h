@@ -513,9 +513,19 @@ __global__ __launch_bounds__(kBlock, 2) void paths_bwd_sc8(PathArgs a) {
 // element-wise part, the partial sums and their order are those of paths_bwd_sc8: the same numbers, bit for bit
 // (tests/test_gpu_surface.py::test_reverse_path_pass_...).  Measured on paths_bwd_sc8 at the config-5 share (257 us): the
 // MFMA loops 82 us, per-chunk staging latency 73 us, staging the constants through LDS and the loop skeleton 46 us.
-constexpr int kPbrBufs = 1;       // sets of staged rows (2 = the next pair requested under the current pair's work: 67 KB of LDS, two workgroups
-                                 // per CU instead of three -- measured 198 against 131 us at the config-5 share: the resident workgroups ARE the overlap)
-constexpr int kPbrWaves = kPbrBufs > 1 ? 2 : 3;     // 168 registers: at 4 (128) the register-resident fragments spill (160 vs 132 us at the config-5 share)
+// VG_PBR_DIRECT (the product form since round 5): the prior draws F0 / H of a chunk's samples are NOT staged -- every element is used
+// once, by the thread that owns it, so it comes straight from memory into a register (10 per thread and chunk); their rows were 62 %
+// of a pair's LDS-DMA requests, and issuing those requests was 40 % of the kernel (profiles/r05/ab_runs.txt: 4.3 of 10.4 us per
+// pair).  131 -> 113 us at the config-5 share, bit-identical.  0 keeps the staged form (measurement).
+#ifndef VG_PBR_DIRECT
+#define VG_PBR_DIRECT 1
+#endif
+#ifndef VG_PBR_BUFS
+#define VG_PBR_BUFS 1
+#endif
+constexpr int kPbrBufs = VG_PBR_BUFS;   // sets of staged rows (2 = the next pair requested under the current pair's work; with F0 / H staged that was
+                                 // 67 KB of LDS, two workgroups per CU instead of three -- 198 against 131 us: the resident workgroups ARE the overlap)
+constexpr int kPbrWaves = 3;     // 168 registers: at 4 (128) the register-resident fragments spill (160 vs 132 us at the config-5 share)
 template <int KS>
 __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) {
     constexpr int SC = 8, Mz = 32, R2 = 2 * SC;
@@ -532,7 +542,7 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
 #pragma unroll
     for (int b = 0; b < kPbrBufs; ++b) {
         GsB[b] = take(R2 * N);                       // [16][N]      the pair's rows: chunk c at rows 8 c ..
-        f0B[b] = take(2 * R2 * J);                   // [16][J] prior draws, then [16][J] their d/dell
+        f0B[b] = take(VG_PBR_DIRECT ? 0 : 2 * R2 * J);      // [16][J] prior draws, then [16][J] their d/dell (staged form only)
         RsB[b] = take(R2 * Mz);                      // [16][Mz]
         EsB[b] = take(R2 * Mz);                      // [16][Mz]
     }
@@ -595,11 +605,13 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
                     const int sl = vg_div(w, iMz), mi = w - sl * Mz, s = s_base + sl;
                     return s < S ? a.eps + (((size_t)p * S + s) * Mz + mi) * L + l : nullptr;
                 });
+#if !VG_PBR_DIRECT
             vg_stage_rows(f0s2, 2 * R2, J, tid, nt, [&](int r) -> const float* {
                 const int second = r >= R2, s = min(s_base + (second ? r - R2 : r), S - 1);
                 if (second && !dell) return nullptr;
                 return (second ? a.H : a.F0) + (((size_t)p * S + s) * L + l) * J;
             });
+#endif
         }
     };
     if (kPbrBufs > 1) stage_pair(blockIdx.x * a.cpw, 0);
@@ -662,6 +674,27 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
             const float* Es = Es2 + c * SC * Mz;
             float* dRs = dRs2 + c * SC * Mz;
             float se = 0.f, sv = 0.f, sr = 0.f;
+#if VG_PBR_DIRECT
+            // the prior draws of the chunk's samples straight from memory into registers (each element is used once, by the thread that
+            // owns it: staging their rows through LDS was 62 % of a pair's DMA requests); requested here, used below
+            constexpr int kXE = (SC * 128 + kBlock - 1) / kBlock;      // elements per thread of the X part (N <= 128)
+            float fz = 0.f, hz = 0.f, fx[kXE], hx[kXE];
+            {
+                const int s_c = ch * SC;
+                auto row = [&](const float* base, int sl) { return base + (((size_t)p * S + min(s_c + sl, S - 1)) * L + l) * J; };
+                if (tid < SC * Mz) {
+                    const int sl = vg_div(tid, iMz), mi = tid - sl * Mz;
+                    fz = row(a.F0, sl)[N + mi];
+                    hz = dell ? row(a.H, sl)[N + mi] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < kXE; ++k) {
+                    const int e = min(tid + k * kBlock, SC * N - 1), sl = vg_div(e, iN), n = e - sl * N;
+                    fx[k] = row(a.F0, sl)[n];
+                    hx[k] = dell ? row(a.H, sl)[n] : 0.f;
+                }
+            }
+#endif
             for (int e = tid; e < SC * Mz; e += nt) {
                 const int sl = vg_div(e, iMz), mi = e - sl * Mz;
                 const int o = c * SC * Mz + e;
@@ -670,15 +703,32 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
                 const float uv = dGA[3 * R2 * Mz + o], ue = dGA[4 * R2 * Mz + o];
                 const float rv = Rs[e];
                 sv += rv * dv + d * uv;
+#if VG_PBR_DIRECT
+                se += rv * de + d * ue - d * hz;
+                sr -= d * fz;
+#else
                 se += rv * de + d * ue - d * hs[sl * J + N + mi];
                 sr -= d * f0s[sl * J + N + mi];
+#endif
             }
+#if VG_PBR_DIRECT
+#pragma unroll
+            for (int k = 0; k < kXE; ++k) {
+                const int e = tid + k * kBlock;
+                if (e < SC * N) {
+                    const float gv = Gs[e];
+                    sr = fmaf(gv, fx[k], sr);
+                    se = fmaf(gv, hx[k], se);
+                }
+            }
+#else
             for (int e = tid; e < SC * N; e += nt) {
                 const int sl = vg_div(e, iN), n = e - sl * N;
                 const float gv = Gs[e];             // zero for samples beyond S
                 sr = fmaf(gv, f0s[sl * J + n], sr);
                 se = fmaf(gv, hs[sl * J + n], se);
             }
+#endif
             __syncthreads();
             float* out = a.part + (pl * a.NC + ch) * a.part_len;
             for (int mi = tid; mi < Mz; mi += nt) {
