@@ -43,18 +43,24 @@ def table(w):
         read=P * S * L * (N + 2 * Mz + 2 * J) * f4 + PL * N * Mz * 16 + 2 * PL * Mz * Mz * f4, write=PL * NC * (Mz + Mz * Mz + 8) * f4,
         access="wide", flops=2.0 * P * S * L * (3 * N * Mz + 2 * Mz * Mz + Mz * Mz),
         note="reads G, R, epsT, F0, H once and A4 (+ the tangents of C) once per latent; the 4 workgroups of a latent each fetch A4")
+    # (round 5: the rows of A -- A4, AT: N Mz 20 B per latent, 3 N Mz^2 of the float64 products -- are formed by stage A's workgroups,
+    #  mid_stage1 / mid_cov_a_rng below; stage B keeps KL, the two tangents and q_sqrt)
+    rows_write, rows_flops = PL * N * Mz * 20, PL * 2.0 * 4 * N * 32 * 32
     t["cov_b_kernel"] = dict(
-        read=PL * (5 * Mz * Mz + M * M + M + 2 * Mz) * f8, write=PL * (N * Mz * 20 + 5 * Mz * Mz * f4 + Mz * f4 + (M * M + M + 3) * f8),
-        access="mixed", flops=PL * (2.0 * 3 * N * Mz * Mz + 2.0 * 6 * Mz ** 3),
-        note="reads Kuu, dKuu, Lk, Lk^-1, (Kuu + jI)^-1, q_sqrt, q_mu; writes A4 (16 B per entry, a quarter of it padding), AT, C, CT, "
-             "the two tangents, Lk32, m, the KL gradients; float64 MFMA products")
+        read=PL * (4 * Mz * Mz + M * M + M + 2 * Mz) * f8, write=PL * (5 * Mz * Mz * f4 + Mz * f4 + (M * M + M + 3) * f8),
+        access="mixed", flops=PL * 2.0 * 9 * 32 ** 3,
+        note="reads Kuu, dKuu, Lk, Lk^-1, q_sqrt, q_mu; writes C, CT, the two tangents, Lk32, m, the KL gradients; float64 MFMA products "
+             "(nine 32^3 ones per latent: four per tangent, one for q_sqrt)")
     t["mid_hyper_final_kernel"] = dict(
         read=PL * NC * (Mz + Mz * Mz + 8) * f4 + PL * (Mz * Mz * f4 + 4 * (M * M + M) * f8), write=PL * 4 * (M * M + M) * f8, access="wide",
         flops=PL * (2.0 * M * M * Mz / 2), note="reads the chunk partials, Lk32, KL gradients, variables + moments; writes gradient, variables, moments")
     t["mid_stage1_kernel"] = dict(t["mid_hyper_final_kernel"], note="gradient assembly of the previous step (as mid_hyper_final_kernel) beside stage A and the draws; "
-                                  "+ omega / beta / eps / eps' writes", write=t["mid_hyper_final_kernel"]["write"] + PL * (B * L + B) * f4 + 4 * P * S * Mz * L * f4)
-    t["mid_cov_a_rng_kernel"] = dict(read=PL * (2 * Mz) * f8, write=PL * (B * L + B) * f4 + 4 * P * S * Mz * L * f4 + PL * 5 * Mz * Mz * f8, access="wide",
-                                     flops=PL * 2.0 * Mz ** 3, note="writes omega, beta, eps / eps' in both layouts, Kuu, dKuu, Lk, Lk^-1, (Kuu + jI)^-1")
+                                  "+ omega / beta / eps / eps' writes + stage A's (Kuu, dKuu, Lk, Lk^-1, the inverse; A4, AT)",
+                                  write=t["mid_hyper_final_kernel"]["write"] + PL * (B * L + B) * f4 + 4 * P * S * Mz * L * f4 + PL * 5 * Mz * Mz * f8 + rows_write,
+                                  flops=t["mid_hyper_final_kernel"]["flops"] + PL * 2.0 * 2 * 32 ** 3 + rows_flops)
+    t["mid_cov_a_rng_kernel"] = dict(read=PL * (2 * Mz) * f8, write=PL * (B * L + B) * f4 + 4 * P * S * Mz * L * f4 + PL * 5 * Mz * Mz * f8 + rows_write, access="wide",
+                                     flops=PL * 2.0 * 2 * 32 ** 3 + rows_flops,
+                                     note="writes omega, beta, eps / eps' in both layouts, Kuu, dKuu, Lk, Lk^-1, (Kuu + jI)^-1, A4 (16 B per entry, a quarter of it padding), AT")
     lik = dict(read=P * S * L * N * f4 + 16 * P * S * N * Q, write=P * S * L * N * f4 + P * S * N * f4, access="gather",
                flops=P * S * N * (Q * 40.0 + L * 120.0),
                note="reads f and ONE 16-byte record per sphere query that is not skipped (upper bound: every query); writes G, logp; "

@@ -30,11 +30,11 @@ def main():
     st = {int(buf[2 * i]): int(buf[2 * i + 1]) for i in range(n)}
     names = {9: "B fragments requested (kernel start ~ here)", 0: "pair: top", 1: "staging requests issued", 2: "operands landed", 3: "five products done",
              4: "chunk 0 done", 5: "chunk 1 done"}
-    ev = sorted((t, k) for k, t in st.items() if 900 <= k < 1000)
+    ev = sorted((t, k) for k, t in st.items() if 1200 <= k < 1300)
     t0 = ev[0][0] if ev else 0
     prev = t0
     for t, k in ev:
-        pair, ph = (k - 900) // 10, (k - 900) % 10
+        pair, ph = (k - 1200) // 10, (k - 1200) % 10
         print(f"{(t - t0) / 100:7.2f} us  (+{(t - prev) / 100:5.2f})  pair {pair}  {names.get(ph, ph)}")
         prev = t
 

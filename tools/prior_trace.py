@@ -1,6 +1,8 @@
 """Measurement aid: phase timeline of ONE workgroup of prior_fused_split_kernel at the config-5 share (measurement build with the
 VG_PT stamps of csrc/gp_prior_split.h).   VGPMP_HIP_LIB=tools/libvgpmp_bisect.so python tools/prior_trace.py
-Per K step (8..15) and wave: microseconds spent in  draw W | features | wait at barrier 1 | products | wait at barrier 2."""
+Per K step (8..15) and wave: microseconds spent in  frequency-tile store | features + W draw | wait at barrier 1 | products | wait at
+barrier 2.  (The first column is an artefact of the stamps: the store of the tile waits on vmcnt(0), which in this build also drains the
+stamp's own global store -- ~0.3 us; in the product build the tile's values were requested a whole product phase earlier.)"""
 import ctypes as C
 import os
 import sys
@@ -28,7 +30,7 @@ def main():
     torch.cuda.synchronize()
     n = lib.vgpmp_debug_trace(buf.ctypes.data, 8192)
     st = {int(buf[2 * i]): int(buf[2 * i + 1]) for i in range(n)}
-    names = ("draw W", "features", "barrier 1", "products", "barrier 2")
+    names = ("om store*", "features + W", "barrier 1", "products", "barrier 2")
     tot = np.zeros((8, 5))
     steps = 0
     for ki in range(8):
@@ -39,6 +41,7 @@ def main():
         steps += 1
         for w in range(8):
             t = [st[640 + 48 * ki + 8 * ph + w] for ph in range(6)]
+            assert all(b >= a for a, b in zip(t, t[1:])), f"stamps of K step {8 + ki}, wave {w} out of order (ids shared with another kernel?): {t}"
             tot[w] += np.diff(t) / 100.0
         t0 = min(st[640 + 48 * ki + w] for w in range(8))
         t1 = max(st[640 + 48 * ki + 40 + w] for w in range(8))
@@ -46,6 +49,7 @@ def main():
     print("mean us per K step and wave:  " + " | ".join(names))
     for w in range(8):
         print(f"  wave {w}: " + " | ".join(f"{v / max(steps, 1):6.2f}" for v in tot[w]) + f"   sum {tot[w].sum() / max(steps, 1):6.2f}")
+    print("* includes the drain of the stamp's own store (vmcnt(0)): an artefact of this build")
 
 
 if __name__ == "__main__":

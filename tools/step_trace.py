@@ -35,7 +35,15 @@ NAMES = {100: "cov_a start", 101: "cov_a Kuu built", 102: "cov_a factorised", 10
          310: "rng basis start", 320: "rng w start", 321: "rng w first wg end", 325: "rng w last wg end",
          400: "loglik first wg start", 402: "loglik robot + f loaded", 403: "loglik frames done", 404: "loglik spheres done", 401: "loglik first wg end", 405: "loglik last wg end",
          500: "paths_bwd start", 501: "paths_bwd staged", 502: "paths_bwd loops", 503: "paths_bwd end",
-         505: "paths_bwd last wg end", 506: "paths_bwd requests issued", 507: "paths_bwd operands landed", 600: "hyper start", 601: "hyper end"}
+         505: "paths_bwd last wg end", 506: "paths_bwd requests issued", 507: "paths_bwd operands landed", 600: "hyper start", 601: "hyper end",
+         1300: "prior small16 first wg start", 1301: "prior small16 points staged", 1302: "prior small16 K loop done", 1303: "prior small16 first wg end",
+         **{1500 + 8 * o + i: f"cov_b order {o} ({('d/dvar', 'd/dell', 'KL', 'q_sqrt', 'rows 0', 'rows 1', 'rows 2', 'rows 3')[o]}) latent {64 * i} start" for o in range(8) for i in range(8)},
+         **{1400 + 8 * o + i: f"cov_b order {o} ({('d/dvar', 'd/dell', 'KL', 'q_sqrt', 'rows 0', 'rows 1', 'rows 2', 'rows 3')[o]}) latent {64 * i} end" for o in range(8) for i in range(8)},
+         142: "cov_a inverse formed", 143: "rows tail: dKuu/dell requested", 144: "rows tail: Kfu of tile 0", 145: "rows tail: operands stand", 146: "rows tail: tile 0 products start",
+         147: "rows tail: tile 0 products done", 148: "rows tail: tile 4 start", 149: "rows tail: tile 4 products done",
+         1600: "rows wave: loads issued", 1601: "rows wave: staged", 1602: "rows wave: Kfu formed", 1603: "rows wave: products done", 1604: "rows wave: stored",
+         **{1320 + 4 * i + y: f"prior small16 wg ({64 * i}, {y}) start" for i in range(8) for y in range(4)},
+         **{1360 + 4 * i + y: f"prior small16 wg ({64 * i}, {y}) end" for i in range(8) for y in range(4)}}
 
 
 def main():
@@ -50,7 +58,7 @@ def main():
     sc = engine.DeviceScene(spec, grid, ps.object_positions[0], sigma_obs=pp["sigma_obs"], epsilon=pp["epsilon"])
     qs = np.array([ps.queries[i % len(ps.queries)] for i in range(P)])
     env = lambda k, d: int(os.environ.get(k, d))      # SAMPLES / INDUCING / TIMESTEPS: other shapes than config 2's
-    pl = engine.PlannerBatch(sc, qs, num_samples=env("SAMPLES", 128), num_inducing=env("INDUCING", 30), num_data=env("TIMESTEPS", 100), num_bases=1024,
+    pl = engine.PlannerBatch(sc, qs, num_samples=env("SAMPLES", 128), num_inducing=env("INDUCING", 30), num_data=env("TIMESTEPS", 100), num_bases=env("BASES", 1024),
                              lengthscales=pp["lengthscales"], variance=pp["variance"], alpha=pp["alpha"],
                              learning_rate=pp["learning_rate"], seed=1)
     pl.fuse = os.environ.get("NO_FUSE") is None

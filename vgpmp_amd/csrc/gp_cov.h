@@ -34,7 +34,7 @@ struct CovArgs {
     // (Mz = 32): the MFMA sequence of paths_fwd_split_body on the float32 C it has just built
     int form_u, S;
     int rows_tpw;            // row tiles (kRowTile time points) per workgroup of the rows role
-    int rows_wave;           // batches (with ki_in_a): the rows role on one wave per 16 time points, in registers (cov_rows_wave_body)
+    int rows_wave;           // batches (with ki_in_a): the rows of A on the workgroup of stage A that formed the inverse, one wave per 16 time points, in registers (cov_rows_tail); stage B has no rows role then
     int ki_in_a;             // batches: (Kuu + jI)^-1 = Lk^-T Lk^-1 once per latent, by stage A (ws.Kinv), not by every row-tile workgroup of stage B
     const float* eps;        // [P,L,S,Mz]  (ws.epsT: the generator's second copy, a latent's rows contiguous)
     HyperArgs hy;
@@ -421,6 +421,142 @@ __device__ __forceinline__ void chol_inverse_panels(double* La, double* Li, doub
     }
 }
 
+// The rows of A = Kfu (Kuu + jI)^-1 and their tangents for ONE latent, on the workgroup that has just formed the inverse (stage A,
+// batches: CovArgs.rows_wave): wave w takes the 16-point tiles w, w + 4, ... entirely in registers -- Kfu^T by the Matern formula,
+// then three kinds of 64-bit MFMA product (cov_rows_body's arithmetic and order of summation: the same bits).  Until round 5 these
+// tiles were workgroups of stage B: they need nothing of stage B, only the inverse -- which stood in this workgroup's LDS when
+// it ended -- and as the last role of that launch their 10-13 us each (a memory round trip for the operands, then every wave of
+// the CU in its exponentials, then every wave in its MFMAs: lock step) were the launch's tail: 18 of its 32 us at 385 latents
+// (profiles/r05/ab_runs.txt).
+//   KiS: the inverse as a zero-padded Mp x ld image in LDS;  KdS: room for dKuu/dell's beside it;  zs: the latent's Mz inducing inputs in LDS
+__device__ __forceinline__ void cov_rows_tail(const CovArgs& a, const double* KiS, double* KdS, int ld, const double* zs, double ell, double var,
+                                              int l, int p, int tid, int nt) {
+    const int M = a.M, Mz = M + 2, N = a.N, L = a.L, D = a.D;
+    const int Mp = (Mz + 15) & ~15;
+    const int wave = tid >> 6, lane = tid & 63, j = lane & 15, kk = lane >> 4;
+    const size_t pl = (size_t)p * L + l;
+    const int ntile = (N + 15) >> 4;
+    // dKuu/dell back from memory (this workgroup wrote it while it built Kuu; the elimination needed the LDS since) as a zero-padded
+    // Mp x ld image like the inverse's: requested here, landing under the exponentials of the first tile
+    constexpr int kKdRegs = (32 * 33 + kCovThreads - 1) / kCovThreads;
+    const double* Kdg = a.ws.Kd_ell + pl * Mz * Mz;
+    const float ild = 1.0f / (float)ld;
+    double kdr[kKdRegs];
+    if (a.want_dell) {
+#pragma unroll
+        for (int k = 0; k < kKdRegs; ++k) {
+            const int e = tid + k * nt, r = vg_div(e, ild), c = e - r * ld;
+            kdr[k] = Kdg[min(r, Mz - 1) * Mz + min(c, Mz - 1)];
+        }
+    }
+    double kf[8], dkf[8];
+    // Kfu^T and dKfu^T / dell at (inducing point 4 s + kk, time point n): the arithmetic of cov_rows_body (and of stage A's Kuu: one
+    // division per thread, none per element)
+    const double inv_ell = 1.0 / ell, c3 = 5.0 / (3.0 * ell);
+    auto kfu = [&](int n, double xn) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            double k = 0.0, dk = 0.0;
+            const double zm = zs[min(4 * s + kk, Mz - 1)];
+            if (4 * s + kk < Mz && n < N) {
+                double rr = fabs(xn - zm) * inv_ell;
+                double ex = exp(-kSqrt5 * rr);
+                k = var * (1.0 + kSqrt5 * rr + (5.0 / 3.0) * rr * rr) * ex;
+                dk = var * ex * (rr * rr * c3) * (1.0 + kSqrt5 * rr);
+            }
+            kf[s] = k; dkf[s] = dk;
+        }
+    };
+    VG_T(l == 0 && p == 0, 143);
+    if (wave < ntile) kfu(16 * wave + j, a.X[(size_t)min(16 * wave + j, N - 1) * D + l]);
+    VG_T(l == 0 && p == 0, 144);
+    if (a.want_dell) {
+#pragma unroll
+        for (int k = 0; k < kKdRegs; ++k) {
+            const int e = tid + k * nt, r = vg_div(e, ild), c = e - r * ld;
+            if (e < Mp * ld) KdS[e] = r < Mz && c < Mz ? kdr[k] : 0.0;
+        }
+    }
+    __syncthreads();      // the inverse (emitted by the product before this call) and dKuu/dell stand
+    VG_T(l == 0 && p == 0, 145);
+    if (wave >= ntile) return;
+    // A operands of the three kinds of product: X[16 rt + j][4 s + kk] of the zero-padded images, read where they are used (held in
+    // registers -- 64 of them -- this routine would not fit the 128 of the launches it ends)
+    const double* kiP = KiS + j * ld + kk;
+    const double* kdP = KdS + j * ld + kk;
+    float4* A4 = reinterpret_cast<float4*>(a.ws.A4) + pl * N * Mz;
+    float* AT = a.ws.AT + pl * N * Mz;
+    // the time stamps of this wave's tiles now: a load behind the stores of a tile would wait for them (one counter)
+    constexpr int kMaxPass = 4;      // (N <= 256: the condition of CovArgs.ki_in_a)
+    double xns[kMaxPass];
+#pragma unroll
+    for (int ps = 0; ps < kMaxPass; ++ps) xns[ps] = a.X[(size_t)min(16 * (wave + ps * (nt >> 6)) + j, N - 1) * D + l];
+    (void)xns;
+#pragma unroll
+    for (int ps = 0; ps < kMaxPass; ++ps) {
+        const int wt = wave + ps * (nt >> 6);
+        if (wt >= ntile) break;
+        const int n = 16 * wt + j;
+        VG_T(l == 0 && p == 0, ps == 0 ? 146 : 148);
+        if (ps > 0) kfu(n, xns[ps]);
+        const vg_f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+        vg_f64x4 at[2], y[2], aell[2], avar[2];
+        double op[2][8];      // the A operands of ONE kind of product: requested together, the two row tiles' chains interleaved
+        auto fetch = [&](const double* P) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int s = 0; s < 8; ++s) op[rt][s] = P[16 * rt * ld + 4 * s];
+        };
+        // A^T = Ki Kfu^T: element q of at[rt] is A[n][m], m = 16 rt + 4 q + kk = 4 (4 rt + q) + kk -- the B operand of step 4 rt + q
+        fetch(kiP);
+        at[0] = zero; at[1] = zero;
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) at[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[rt][s], kf[s], at[rt], 0, 0, 0);
+        asm volatile("" ::: "memory");      // (the operand reads of the next product stay behind this one's: registers)
+        // y^T = dKfu^T - dKuu/dell A^T
+        y[0] = zero; y[1] = zero;
+        if (a.want_dell) {
+            fetch(kdP);
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) y[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[rt][s], at[s >> 2][s & 3], y[rt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) y[rt][q] = dkf[4 * rt + q] - y[rt][q];
+        asm volatile("" ::: "memory");
+        // A_ell^T = Ki y^T,  A_var^T = jitter / var Ki A^T
+        fetch(kiP);
+        aell[0] = zero; aell[1] = zero; avar[0] = zero; avar[1] = zero;
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                if (a.want_dell) aell[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[rt][s], y[s >> 2][s & 3], aell[rt], 0, 0, 0);
+                avar[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[rt][s], at[s >> 2][s & 3], avar[rt], 0, 0, 0);
+            }
+        VG_T(l == 0 && p == 0, ps == 0 ? 147 : 149);
+        if (n < N) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = 16 * rt + 4 * q + kk;
+                    if (m < Mz) {
+                        const float av0 = (float)at[rt][q];
+                        vg_stream(A4 + (size_t)n * Mz + m, make_float4(av0, (float)aell[rt][q], (float)(a.jitter / var * avar[rt][q]), 0.f));
+                        vg_stream(AT + (size_t)m * N + n, av0);
+                    }
+                }
+        }
+    }
+}
+
 // ---- stage A: Kuu, factorisation, inverse --------------------------------------------------------
 __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, int p) {
     __shared__ double scal[2];
@@ -517,9 +653,13 @@ __device__ __forceinline__ void cov_a_body(const CovArgs& a, double* sm, int l, 
             // stage B (which then stage the product instead of Lk^-1 and skip theirs) -- the same bits
             __syncthreads();
             double* Kig = a.ws.Kinv + pl * Mz * Mz;
+            double* KiS = Sc;      // (the elimination's scratch is free) the inverse stays here for the rows of A
             matmul_f64(MatView{Li, 1, ld}, MatView{Li, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
                 if (r < Mz && c < Mz) Kig[(size_t)r * Mz + c] = v;
+                KiS[r * ld + c] = v;      // (zero beyond Mz: Lk^-1 is zero padded)
             });
+            VG_T(l == 0 && p == 0, 142);
+            if (a.rows_wave) cov_rows_tail(a, KiS, Sc + Mp * ld, ld, zs, ell, var, l, p, tid, nt);
         }
     } else {
         if (Mz <= 32 && a.elim_wave) chol_inverse_wave(La, Li, Sc, rsd, Mz, ld, tid, nt);
@@ -553,40 +693,45 @@ constexpr int kCovRoleC = 3, kCovFixedRoles = 4;
 // the tangent roles, the longest, to two of them with 8 roles (config-5 share: 946 -> 985 us per step).
 __device__ __forceinline__ int cov_role_rotated(int b, int roles) { return (b + b / roles) % roles; }
 __device__ void cov_rows_body(const CovArgs& a, double* sm, int tile, int l, int p, int tid, int nt);
-__device__ void cov_rows_wave_body(const CovArgs& a, int wg_tile, int l, int p, int tid);
 
-template <bool TANGENTS, bool WAVE = false>      // WAVE: the launch may use the one-wave register form of the rows role (cov_b_kernel; kept out of the stage-2 kernels' register budget)
+// The small chores of the launch stage B belongs to, on ONE workgroup per latent (the first row tile; with the rows formed by stage A
+// -- CovArgs.rows_wave -- the q_sqrt role).
+__device__ __forceinline__ void cov_b_chores(const CovArgs& a, int l, int p, int tid) {
+    // The step counter ticks where no kernel that reads it runs alongside: noise drawn before this launch
+    // saw the old value, the noise of the next step and the Adam count see the new one.
+    if (a.tick && l == 0 && p == 0 && tid == 0) {
+        const uint32_t t = *a.tick + 1u;          // = 1-based Adam count of this step's update
+        *a.tick = t;
+        a.lr_dev[0] = adam_step_size(a.lr, (double)t);
+    }
+    // one word per thread, one round trip (on thread 0 of role 0 these were two serial ones on the role that
+    // ended the stage)
+    const size_t pl = (size_t)p * a.L + l;
+    if (a.commit && a.hy.do_adam && tid < 6) {      // staged hyper-parameters of the prologue -> their tensors
+        const HyperArgs& h = a.hy;
+        double* dst = tid == 0 ? h.p_ell : tid == 1 ? h.p_var : tid == 2 ? h.m_ell : tid == 3 ? h.v_ell : tid == 4 ? h.m_var : h.v_var;
+        dst[pl] = h.next[6 * pl + tid];
+    }
+    if (a.keep_prev && tid >= 8 && tid < 11) {      // this step's var / slopes for the prologue of the next step
+        const double* src = tid == 8 ? a.ws.var : tid == 9 ? a.ws.sig_ell : a.ws.sig_var;
+        double* dst = tid == 8 ? a.ws.prev_var : tid == 9 ? a.ws.prev_sig_ell : a.ws.prev_sig_var;
+        dst[pl] = src[pl];
+    }
+}
+
+template <bool TANGENTS, bool ROWS = true>      // ROWS: the launch has row-tile workgroups (false: the rows of A were stage A's, CovArgs.rows_wave)
 __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int role, int l, int p) {
     __shared__ double red[kCovThreads / VG_WAVE];
     const int tid = threadIdx.x, nt = blockDim.x;
     if (role >= kCovFixedRoles) {
-        if (role == kCovFixedRoles) {      // the first row tile of (l, p) carries the launch's small chores
-            // The step counter ticks where no kernel that reads it runs alongside: noise drawn before this launch
-            // saw the old value, the noise of the next step and the Adam count see the new one.
-            if (a.tick && l == 0 && p == 0 && tid == 0) {
-                const uint32_t t = *a.tick + 1u;          // = 1-based Adam count of this step's update
-                *a.tick = t;
-                a.lr_dev[0] = adam_step_size(a.lr, (double)t);
-            }
-            // one word per thread, one round trip (on thread 0 of role 0 these were two serial ones on the role that
-            // ended the stage)
-            const size_t pl = (size_t)p * a.L + l;
-            if (a.commit && a.hy.do_adam && tid < 6) {      // staged hyper-parameters of the prologue -> their tensors
-                const HyperArgs& h = a.hy;
-                double* dst = tid == 0 ? h.p_ell : tid == 1 ? h.p_var : tid == 2 ? h.m_ell : tid == 3 ? h.v_ell : tid == 4 ? h.m_var : h.v_var;
-                dst[pl] = h.next[6 * pl + tid];
-            }
-            if (a.keep_prev && tid >= 8 && tid < 11) {      // this step's var / slopes for the prologue of the next step
-                const double* src = tid == 8 ? a.ws.var : tid == 9 ? a.ws.sig_ell : a.ws.sig_var;
-                double* dst = tid == 8 ? a.ws.prev_var : tid == 9 ? a.ws.prev_sig_ell : a.ws.prev_sig_var;
-                dst[pl] = src[pl];
-            }
+        if (ROWS) {
+            if (role == kCovFixedRoles) cov_b_chores(a, l, p, tid);
+            cov_rows_body(a, sm, role - kCovFixedRoles, l, p, tid, nt);
         }
-        if (WAVE && a.rows_wave) cov_rows_wave_body(a, role - kCovFixedRoles, l, p, tid);
-        else cov_rows_body(a, sm, role - kCovFixedRoles, l, p, tid, nt);
         return;
     }
     const bool crole = role == kCovRoleC, form_u = crole && a.form_u != 0;
+    if (!ROWS && crole) cov_b_chores(a, l, p, tid);
     if ((role == 1 || role == 2) && (!TANGENTS || (role == 1 && !a.want_dell))) return;
     VG_T(l == 0 && p == 0, 200 + 10 * (crole ? 5 : role));
     const int M = a.M, Mz = M + 2, L = a.L;
@@ -853,7 +998,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     VG_T(l == 0 && p == 0, 203 + 10 * role);
 }
 
-template <bool TANGENTS>
+template <bool TANGENTS, bool ROWS>
 __global__ __launch_bounds__(kCovThreads, 4) void cov_b_kernel(CovArgs a) {
     extern __shared__ double sm[];
     // Workgroups are dispatched in linear order (x fastest): ROLE-major here, the long roles first -- d/dvar, d/dell, KL, q_sqrt,
@@ -864,7 +1009,10 @@ __global__ __launch_bounds__(kCovThreads, 4) void cov_b_kernel(CovArgs a) {
     const unsigned lin = blockIdx.x + roles * (blockIdx.y + gridDim.y * blockIdx.z);
     const unsigned ord = lin / latents, lat = lin - ord * latents;
     const int role = ord == 0 ? 2 : ord == 1 ? 1 : ord == 2 ? 0 : (int)ord;      // (3 = q_sqrt, 4.. = row tiles)
-    cov_b_body<TANGENTS, true>(a, sm, role, (int)(lat % gridDim.y), (int)(lat / gridDim.y));
+    // (measurement build: start / end of every 64th latent's workgroup of each role -- ids 1500 / 1400 + 8 order + latent / 64)
+    VG_T((lat & 63) == 0 && lat < 512 && ord < 8, 1500 + 8 * ord + (lat >> 6));
+    cov_b_body<TANGENTS, ROWS>(a, sm, role, (int)(lat % gridDim.y), (int)(lat / gridDim.y));
+    VG_T((lat & 63) == 0 && lat < 512 && ord < 8, 1400 + 8 * ord + (lat >> 6));
 }
 
 // A = Kfu (Kuu + jI)^-1 and its tangents for a tile of kRowTile time points:
@@ -891,6 +1039,7 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int wg_tile, int l, 
     double* xs = zs + Mz;                  // [tpw][RT] times of this workgroup's tiles
     double* Lt = xs + tpw * kRowTile;      // [Mz][ld] Lk^-1 as it arrives
     const double ell = a.ws.ell[pl], var = a.ws.var[pl];
+    const double inv_ell = 1.0 / ell, c3 = 5.0 / (3.0 * ell);      // (stage A's Kuu arithmetic: one division per thread, none per element)
     float4* A4 = reinterpret_cast<float4*>(a.ws.A4) + pl * N * Mz;
     float* AT = a.ws.AT + pl * N * Mz;
     const int n00 = tile * kRowTile;
@@ -953,10 +1102,10 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int wg_tile, int l, 
                 const int r = e >> 5, m = e & 31, n = n0 + r;
                 double k = 0.0, dk = 0.0;
                 if (n < N && r0 + r < rows_w) {
-                    double rr = fabs(xs[r0 + r] - zs[m]) / ell;
+                    double rr = fabs(xs[r0 + r] - zs[m]) * inv_ell;
                     double ex = exp(-kSqrt5 * rr);
                     k = var * (1.0 + kSqrt5 * rr + (5.0 / 3.0) * rr * rr) * ex;
-                    dk = var * ex * (5.0 * rr * rr / (3.0 * ell)) * (1.0 + kSqrt5 * rr);
+                    dk = var * ex * (rr * rr * c3) * (1.0 + kSqrt5 * rr);
                 }
                 kf2[e] = k; df2[e] = dk;
             }
@@ -1025,6 +1174,7 @@ __device__ void cov_rows_padded_body(const CovArgs& a, double* sm, int wg_tile, 
     double* kf2 = Mp >= 32 ? Lt : xs + tpw * kRowTile;      // [16][Mp]  Kfu rows
     double* df2 = kf2 + 16 * Mp;                            // [16][Mp]  dKfu/dell rows
     const double ell = a.ws.ell[pl], var = a.ws.var[pl];
+    const double inv_ell = 1.0 / ell, c3 = 5.0 / (3.0 * ell);      // (stage A's Kuu arithmetic: one division per thread, none per element)
     float4* A4 = reinterpret_cast<float4*>(a.ws.A4) + pl * N * Mz;
     float* AT = a.ws.AT + pl * N * Mz;
     const int n00 = tile * kRowTile;
@@ -1067,10 +1217,10 @@ __device__ void cov_rows_padded_body(const CovArgs& a, double* sm, int wg_tile, 
             const int r = vg_div(e, iMp), m = e - r * Mp, n = n0 + r;
             double k = 0.0, dk = 0.0;
             if (m < Mz && n < N && r0 + r < rows_w) {
-                double rr = fabs(xs[r0 + r] - zs[m]) / ell;
+                double rr = fabs(xs[r0 + r] - zs[m]) * inv_ell;
                 double ex = exp(-kSqrt5 * rr);
                 k = var * (1.0 + kSqrt5 * rr + (5.0 / 3.0) * rr * rr) * ex;
-                dk = var * ex * (5.0 * rr * rr / (3.0 * ell)) * (1.0 + kSqrt5 * rr);
+                dk = var * ex * (rr * rr * c3) * (1.0 + kSqrt5 * rr);
             }
             kf2[e] = k; df2[e] = dk;
         }
@@ -1123,97 +1273,5 @@ __device__ void cov_rows_padded_body(const CovArgs& a, double* sm, int wg_tile, 
 // evaluates the kernel at time point n0 + j against the 8 inducing points 4 s + kk: both the B operand of the first product and
 // the accumulator layout of dKfu^T.  Same products in the same k order as cov_rows_body: the same bits.
 // (The LDS form keeps four waves busy for ~5 us per 16 time points, most of it at its four barriers; this one wave for ~6.)
-__device__ void cov_rows_wave_body(const CovArgs& a, int wg_tile, int l, int p, int tid) {
-    const int M = a.M, Mz = M + 2, N = a.N, L = a.L, D = a.D;
-    const int wave = tid >> 6, lane = tid & 63, j = lane & 15, kk = lane >> 4;
-    const int n0 = (wg_tile * 4 + wave) * 16;
-    if (n0 >= N) return;
-    const size_t pl = (size_t)p * L + l;
-    const double ell = a.ws.ell[pl], var = a.ws.var[pl];
-    const double* Kig = a.ws.Kinv + pl * Mz * Mz;
-    const double* Kdg = a.ws.Kd_ell + pl * Mz * Mz;
-    // A operands of the three kinds of product: X[16 rt + j][4 s + kk], zero beyond Mz (loads first, selects afterwards)
-    double kiA[2][8], kdA[2][8];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int r = 16 * rt + j, c = 4 * s + kk;
-            const size_t o = (size_t)min(r, Mz - 1) * Mz + min(c, Mz - 1);
-            kiA[rt][s] = Kig[o];
-            kdA[rt][s] = Kdg[o];
-        }
-    const int n = n0 + j;
-    const double xn = a.X[(size_t)min(n, N - 1) * D + l];
-    double zm[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) zm[s] = a.Zy[(size_t)p * a.zy_stride + (size_t)min(4 * s + kk, Mz - 1) * D + l];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const bool in = 16 * rt + j < Mz && 4 * s + kk < Mz;
-            kiA[rt][s] = in ? kiA[rt][s] : 0.0;
-            kdA[rt][s] = in && a.want_dell ? kdA[rt][s] : 0.0;
-        }
-    // Kfu^T and dKfu^T / dell at (inducing point 4 s + kk, time point n): the arithmetic of cov_rows_body
-    double kf[8], dkf[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        double k = 0.0, dk = 0.0;
-        if (4 * s + kk < Mz && n < N) {
-            double rr = fabs(xn - zm[s]) / ell;
-            double ex = exp(-kSqrt5 * rr);
-            k = var * (1.0 + kSqrt5 * rr + (5.0 / 3.0) * rr * rr) * ex;
-            dk = var * ex * (5.0 * rr * rr / (3.0 * ell)) * (1.0 + kSqrt5 * rr);
-        }
-        kf[s] = k; dkf[s] = dk;
-    }
-    const vg_f64x4 zero = {0.0, 0.0, 0.0, 0.0};
-    vg_f64x4 at[2], y[2], aell[2], avar[2];
-    // A^T = Ki Kfu^T: element q of at[rt] is A[n][m], m = 16 rt + 4 q + kk = 4 (4 rt + q) + kk -- the B operand of step 4 rt + q
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        vg_f64x4 acc = zero;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kiA[rt][s], kf[s], acc, 0, 0, 0);
-        at[rt] = acc;
-    }
-    // y^T = dKfu^T - dKuu/dell A^T
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        vg_f64x4 acc = zero;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kdA[rt][s], at[s >> 2][s & 3], acc, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) y[rt][q] = dkf[4 * rt + q] - acc[q];
-    }
-    // A_ell^T = Ki y^T,  A_var^T = jitter / var Ki A^T
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        vg_f64x4 acc = zero, acv = zero;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            if (a.want_dell) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kiA[rt][s], y[s >> 2][s & 3], acc, 0, 0, 0);
-            acv = __builtin_amdgcn_mfma_f64_16x16x4f64(kiA[rt][s], at[s >> 2][s & 3], acv, 0, 0, 0);
-        }
-        aell[rt] = acc; avar[rt] = acv;
-    }
-    float4* A4 = reinterpret_cast<float4*>(a.ws.A4) + pl * N * Mz;
-    float* AT = a.ws.AT + pl * N * Mz;
-    if (n < N) {
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m = 16 * rt + 4 * q + kk;
-                if (m < Mz) {
-                    const float av0 = (float)at[rt][q];
-                    vg_stream(A4 + (size_t)n * Mz + m, make_float4(av0, (float)aell[rt][q], (float)(a.jitter / var * avar[rt][q]), 0.f));
-                    vg_stream(AT + (size_t)m * N + n, av0);
-                }
-            }
-    }
-}
 
 }  // namespace

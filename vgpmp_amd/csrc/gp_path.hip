@@ -226,7 +226,9 @@ template <int MZCAP>
 __global__ __launch_bounds__(kBlock, MZCAP <= 32 ? 4 : 1) void mid_stage1_kernel(MidS1Args s) {
     extern __shared__ double sm[];
     int b = blockIdx.x;
-    if (b < s.n_fin) {       // (the longest role first)
+    // (the gradient assembly first.  Stage A is the longer chain since it also forms the rows of A, but in front it measured +2 % at
+    //  896 latent pairs, -0.5 % at 385: its workgroups wait most of their time, the assembly's ingest is what fills the CUs)
+    if (b < s.n_fin) {
         const HyperArgs& h = s.hy;
         const bool own = h.ctr && h.do_adam;
         FinalArgs fb = s.fin;      // the step size comes from the counter here, as in mid_hyper_final_kernel
@@ -251,6 +253,31 @@ __global__ __launch_bounds__(kBlock, MZCAP <= 32 ? 4 : 1) void mid_stage1_kernel
     if (b < a.n_norm) { rng_normals_body(a.rng, b % a.n_gx, b / a.n_gx, a.rng.nW, a.rng.nE); return; }
     b -= a.n_norm;
     rng_eps_t_body(a.rng, b % a.e_gx, b / a.e_gx, reinterpret_cast<float*>(sm));
+}
+
+// Few samples per problem (the f16-split few-sample prior kernel, S <= 32) in the batch schedule: stage B and the prior draws need
+// only stage A and the noise, not each other -- ONE launch.  Stage B is four ~10 us chains per latent in 35 KB of LDS each (four
+// workgroups per CU), the prior draws are 3-4 us workgroups with no LDS to speak of: behind the chains in the grid, they fill
+// the slots the chains leave as they end instead of waiting for the launch boundary (config 3, 385 latents: stage B 19 us, then
+// 2.5 us of boundary, then 7 us of draws -> 20 us together; profiles/r05/ab_runs.txt).
+struct MidBArgs {
+    CovArgs cov; FusedPriorArgs fp;
+    int n_cov, latents, prior_gx;      // stage B: kCovFixedRoles x latents workgroups, role-major; then prior_gx x column-tile-pairs
+};
+template <int MT, int DM, bool DELL>
+__global__ __launch_bounds__(kBlock, 4) void mid_cov_b_prior16_kernel(MidBArgs a) {
+    extern __shared__ double sm[];
+    int b = blockIdx.x;
+    if (b < a.n_cov) {      // (order and roles of cov_b_kernel: the long roles first)
+        const int ord = b / a.latents, lat = b - ord * a.latents;
+        const int role = ord == 0 ? 2 : ord == 1 ? 1 : ord == 2 ? 0 : ord;
+        VG_T((lat & 63) == 0 && lat < 512 && ord < 8, 1500 + 8 * ord + (lat >> 6));
+        cov_b_body<true, false>(a.cov, sm, role, lat % a.cov.L, lat / a.cov.L);
+        VG_T((lat & 63) == 0 && lat < 512 && ord < 8, 1400 + 8 * ord + (lat >> 6));
+        return;
+    }
+    b -= a.n_cov;
+    prior_small16_body<MT, DM, DELL, true>(a.fp, b % a.prior_gx, b / a.prior_gx);
 }
 
 struct MidGArgs {            // hyper-parameter update | q_mu, q_sqrt update + ELBO pieces
@@ -533,8 +560,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     ca.elim_wave = (what & VGPMP_ELIM_BLOCK) ? 0 : 1;
     // batches (stage A and stage B are launches of their own, stage A off the critical path behind the generator roles): the
     // inverse once per latent in stage A (its two-panel form) instead of in every row-tile workgroup of stage B
-    ca.ki_in_a = (!fused && ca.elim_wave && Mz > 16 && Mz <= 32 && !(what & VGPMP_COV_LDS_ROWS)) ? 1 : 0;
-    ca.rows_wave = ca.ki_in_a;      // ... and the rows role of stage B on one wave per 16 time points, in registers
+    ca.ki_in_a = (!fused && ca.elim_wave && Mz > 16 && Mz <= 32 && N <= 256 && !(what & VGPMP_COV_LDS_ROWS)) ? 1 : 0;      // (N: cov_rows_tail's four passes)
+    ca.rows_wave = ca.ki_in_a;      // ... which then goes on to the rows of A itself, one wave per 16 time points, in registers
     ca.tick = (fused && do_adam) ? ctr : nullptr;
     ca.lr = lr; ca.lr_dev = ws->lr_t;
     ca.rows_tpw = 1; ca.prologue = 0; ca.commit = 0; ca.keep_prev = (fused && backward) ? 1 : 0;
@@ -662,7 +689,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const bool fin_split = fin_dma && Mz % (4 * kFinSplit) == 0 && (size_t)(M + M * (Mz / kFinSplit)) <= 2 * kBlock &&
                            !(what & VGPMP_NO_SPLIT);
     const size_t lds_s1 = lds_cov_a > lds_fin ? lds_cov_a : lds_fin;
-    const void* fn_cov_b = backward ? VG_FN(cov_b_kernel<true>) : VG_FN(cov_b_kernel<false>);
+    const void* fn_cov_b = ca.rows_wave ? (backward ? VG_FN(cov_b_kernel<true, false>) : VG_FN(cov_b_kernel<false, false>))
+                                        : (backward ? VG_FN(cov_b_kernel<true, true>) : VG_FN(cov_b_kernel<false, true>));
     const bool k8 = (B / SK) % 128 == 0;      // K-slice in passes of 8 steps of 16: a pass's operands in one request
     // K-slices of a multiple of 128 and enough samples: operands through LDS by DMA (needs 59 KB per workgroup)
     const bool glds = (B / SK) % kGK == 0 && S >= 48 && !(what & VGPMP_GEMM_DIRECT);      // 64-row tiles: few samples waste them
@@ -748,7 +776,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     const bool fin_mz32 = Mz <= 32 && !(fin_split && (size_t)L * P <= 128);
     const void* fn_mhf = fin_mz32 ? VG_FN(mid_hyper_final_kernel<32>) : VG_FN(mid_hyper_final_kernel<48>);
     if ((rc = set_dyn_lds(fn_mhf, lds_fin))) return rc;
-    const dim3 cov_b_grid(kCovFixedRoles + (ca.rows_wave ? (N + 63) / 64 : (row_tiles + rows_tpw - 1) / rows_tpw), L, P);
+    const dim3 cov_b_grid(kCovFixedRoles + (ca.rows_wave ? 0 : (row_tiles + rows_tpw - 1) / rows_tpw), L, P);      // (rows_wave: the rows of A are stage A's)
     // eps / eps' also as [P,L,S,Mz] wherever a consumer stages them per latent (the register-resident path kernels, stage B's U
     // role): drawn by rng_eps_t_body then, kEpsRows rows of (s, k) per workgroup
     // (only for noise drawn here: the caller's own eps -- generate = false -- come in the interface's layout alone)
@@ -773,13 +801,37 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         vg_sched_note_fn(fn);
         return (int)hipLaunchKernel(fn, grid, dim3(kBlock), kargs, lds, st);
     };
-    auto launch_fused_small = [&](hipEvent_t g0, hipEvent_t g1) {
+    auto fused_small_args = [&]() {
         FusedPriorArgs fp;
         fp.S = S; fp.L = L; fp.J = J; fp.N = N; fp.D = L; fp.B = B; fp.want_dell = want_dell ? 1 : 0;
         fp.X = pb->X; fp.Zy = zy; fp.zy_stride = zy_stride; fp.raw_ell = params->raw_ell; fp.raw_var = params->raw_var;
         fp.omega = nz->omega; fp.beta = nz->beta; fp.W = nz->w; fp.F0 = ws->F0; fp.H = ws->H; fp.slab = slab;
         fp.tick = fe.tick;
-        const dim3 fgrid(P * L, (J + kFNT * 16 - 1) / (kFNT * 16));
+        return fp;
+    };
+    const dim3 fgrid(P * L, (J + kFNT * 16 - 1) / (kFNT * 16));
+    const bool small16 = !(what & VGPMP_PRIOR_F32) && (B / 4) % kHK == 0;      // the f16-split form of the few-sample prior kernel
+    // stage B and the few-sample prior draws as ONE launch (mid_cov_b_prior16_kernel): the batch schedule drawing its own noise
+    auto launch_cov_b_prior16 = [&](const CovArgs& cb) -> int {
+        MidBArgs mb;
+        mb.cov = cb; mb.fp = fused_small_args();
+        mb.latents = L * P; mb.n_cov = kCovFixedRoles * L * P; mb.prior_gx = (int)fgrid.x;
+        const dim3 grid(mb.n_cov + fgrid.x * fgrid.y);
+        int rc = 0;
+#define VG_CBP(MT_, DM_)                                                                                                          \
+    do {                                                                                                                          \
+        const void* fn_ = want_dell ? VG_FN(mid_cov_b_prior16_kernel<MT_, DM_, true>) : VG_FN(mid_cov_b_prior16_kernel<MT_, DM_, false>); \
+        if (!(rc = set_dyn_lds(fn_, lds_cov_b))) rc = launch(fn_, grid, &mb, lds_cov_b);                                          \
+    } while (0)
+        if (L == 7) { if (S <= 16) VG_CBP(1, 7); else VG_CBP(2, 7); }
+        else if (L == 6) { if (S <= 16) VG_CBP(1, 6); else VG_CBP(2, 6); }
+        else if (L <= 8) { if (S <= 16) VG_CBP(1, 8); else VG_CBP(2, 8); }
+        else { if (S <= 16) VG_CBP(1, 16); else VG_CBP(2, 16); }
+#undef VG_CBP
+        return rc;
+    };
+    auto launch_fused_small = [&](hipEvent_t g0, hipEvent_t g1) {
+        const FusedPriorArgs fp = fused_small_args();
 #define VG_FUSED_SMALL(MT_, DM_)                                            \
     (want_dell ? VG_EXT_GGL((prior_fused_small_kernel<MT_, DM_, true>), fgrid, dim3(kBlock), 0, st, g0, g1, \
                              0, fp)                                  \
@@ -787,7 +839,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                              0, fp))
         // the f16-split form (gp_prior_split.h): K steps of 32 bases (every K-slice a multiple of that); the float32-MFMA kernel
         // stays behind VGPMP_PRIOR_F32, as for the large batches
-        if (!(what & VGPMP_PRIOR_F32) && (B / 4) % kHK == 0) {
+        if (small16) {
 #define VG_FUSED_SMALL16_(MT_, DM_, WX_)                                        \
     (want_dell ? VG_EXT_GGL((prior_fused_small16_kernel<MT_, DM_, true, WX_>), fgrid, dim3(kBlock), 0, st, g0, g1, \
                              0, fp)                                  \
@@ -937,6 +989,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             // (896 pairs of 14-joint latents) 0.920 / 0.907 -- there the prior kernel fills every round and the second queue only
             // takes CUs from it: hence the upper bound.
             const bool cov_aside = pb->aux_stream && batch_merge && fbatch && (size_t)P * L >= 64 && (size_t)P * L <= 512;
+            const bool b_prior16 = batch_merge && fused_small && small16 && ca.rows_wave && backward;      // (stage B here has no rows role)
             hipEvent_t ev_fork = nullptr, ev_join = nullptr;
             if (cov_aside) {
                 hipStream_t aux = (hipStream_t)pb->aux_stream;
@@ -947,6 +1000,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 vg_sched_note_fn(fn_cov_b);
                 VG_CHECK_HIP(hipLaunchKernel(fn_cov_b, cov_b_grid, dim3(kBlock), kargs, lds_cov_b, aux));
                 VG_CHECK_HIP(hipEventRecord(ev_join, aux));
+            } else if (b_prior16) {
+                if ((rc = launch_cov_b_prior16(ca))) return rc;      // ... and the few-sample prior draws with it
             } else if ((rc = launch(fn_cov_b, cov_b_grid, &ca, lds_cov_b))) return rc;
             if (what & VGPMP_COV_ONLY) return (int)hipGetLastError();     // Kuu, Cholesky, q_sqrt, A, per-latent KL: done
             mark();
@@ -1014,7 +1069,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 if (fe.tick && batch_merge) pa.tick = fe.tick;      // the feature kernel's tick: by paths_fwd (next launch), or alone
                 else if (fe.tick) VG_GGL(tick_kernel, dim3(1), dim3(1), 0, st, fe.tick);
             } else if (fused_small) {      // features formed inside the GEMM (few samples: Phi / dPhi traffic is the cost)
-                launch_fused_small(g0, g1);
+                if (!b_prior16) launch_fused_small(g0, g1);      // (b_prior16: they went with stage B)
             } else if (tiled_gemm) {
                 const int mt = 1;      // 128-sample tiles (mt = 2) measured slower: 90 vs 98 TF/s at 64 problems
                 const size_t lds_tg = (size_t)2 * (kTS * mt + kTJ) * kTLd * sizeof(float);

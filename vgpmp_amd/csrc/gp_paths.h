@@ -580,8 +580,8 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
             }
     }
     const int cp_end = min((int)(blockIdx.x + 1) * a.cpw, a.NC);
-    // (measurement build: phases of workgroup (0, 0, 0) -- id 900 + 10 pair + phase; tools/pbr_trace.py)
-#define VG_PBT(pair, phase) VG_T(blockIdx.x == 0 && l == 0 && p == 0, 900 + 10 * (pair) + (phase))
+    // (measurement build: phases of workgroup (0, 0, 0) -- id 1200 + 10 pair + phase; tools/pbr_trace.py)
+#define VG_PBT(pair, phase) VG_T(blockIdx.x == 0 && l == 0 && p == 0, 1200 + 10 * (pair) + (phase))
     VG_PBT(0, 9);
     auto stage_pair = [&](int ch0, int b) {
         const int s_base = ch0 * SC;

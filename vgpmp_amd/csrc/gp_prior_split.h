@@ -288,13 +288,17 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
 // Four waves = the four K-slices whose slabs the path kernels sum; operands requested one K step ahead.
 // WX: the weights in a.W were drawn by the library's own generator -- float16 values (vgpmp_device.h, "The W stream") -- so W has no
 // low half: no split, two MFMAs per product.  Weights handed in by the caller (parity tests) are arbitrary float32: WX = false.
+// (bx, by: latent pair and column-tile pair of this workgroup -- the kernel below, or a role of mid_cov_b_prior16_kernel, gp_path.hip)
 template <int MT, int DM, bool DELL, bool WX>    // 16-row sample tiles; joint extent DM = D for 6 / 7 joints, else padded to 8 or 16; d/d ell wanted
-__global__ __launch_bounds__(kBlock, 2) void prior_fused_small16_kernel(FusedPriorArgs a) {
+__device__ __forceinline__ void prior_small16_body(const FusedPriorArgs& a, int bx, int by) {
     __shared__ float pts[kFNT * 16][DM];
     const int S = a.S, L = a.L, J = a.J, N = a.N, D = a.D, B = a.B;
     const int tid = threadIdx.x, lane = tid & 63, sk = tid >> 6;      // 4 waves = 4 K-slices
-    const int pl = blockIdx.x, l = pl % L, p = pl / L, j0 = blockIdx.y * (kFNT * 16);
-    if (a.tick && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.tick += 1u;
+    const int pl = bx, l = pl % L, p = pl / L, j0 = by * (kFNT * 16);
+    if (a.tick && bx == 0 && by == 0 && tid == 0) *a.tick += 1u;
+    // (measurement build: phases of workgroup (0, 0) -- id 1300 + phase; starts / ends of a sample of workgroups; tools/step_trace.py)
+    VG_T(bx == 0 && by == 0, 1300);
+    VG_T((bx & 63) == 0 && bx < 512 && by < 4, 1320 + 4 * (bx >> 6) + by);
     for (int e = tid; e < kFNT * 16 * DM; e += kBlock) {
         const int jj = e / DM, d = e - jj * DM, j = min(j0 + jj, J - 1);
         const double* pt = j < N ? a.X + (size_t)j * D : a.Zy + (size_t)p * a.zy_stride + (size_t)(j - N) * D;
@@ -404,6 +408,7 @@ __global__ __launch_bounds__(kBlock, 2) void prior_fused_small16_kernel(FusedPri
         }
     };
     Ops xa, xb;
+    VG_T(bx == 0 && by == 0, 1301);
     fetch(0, xa);
     int k = 0;
     for (; k + 2 * kHK <= kchunk; k += 2 * kHK) {
@@ -413,6 +418,7 @@ __global__ __launch_bounds__(kBlock, 2) void prior_fused_small16_kernel(FusedPri
         step(xb);
     }
     if (k < kchunk) step(xa);      // (an odd number of K steps)
+    VG_T(bx == 0 && by == 0, 1302);
     // D layout: col = lane & 15, row = (lane >> 4) * 4 + reg; the constant factors left out of the operands go in here
     float* F0 = a.F0 + (size_t)sk * a.slab;
     float* H = a.H + (size_t)sk * a.slab;
@@ -431,6 +437,12 @@ __global__ __launch_bounds__(kBlock, 2) void prior_fused_small16_kernel(FusedPri
                 if (DELL) vg_stream(H + o, c_ell2 * accH[m][t][q]);
             }
         }
+    VG_T(bx == 0 && by == 0, 1303);
+    VG_T((bx & 63) == 0 && bx < 512 && by < 4, 1360 + 4 * (bx >> 6) + by);
+}
+template <int MT, int DM, bool DELL, bool WX>
+__global__ __launch_bounds__(kBlock, 2) void prior_fused_small16_kernel(FusedPriorArgs a) {
+    prior_small16_body<MT, DM, DELL, WX>(a, blockIdx.x, blockIdx.y);
 }
 
 }  // namespace

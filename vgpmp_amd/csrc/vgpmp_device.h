@@ -330,17 +330,17 @@ int vg_launch_log_prob_impl(const vgpmp_robot* rb, int dof, const vgpmp_sdf* sdf
 #ifdef VGPMP_BISECT
 // one fixed slot per stamp id: a plain store, nothing to wait for (an atomic slot counter costs the stamping
 // thread a memory round trip per stamp and stretches the phases it is meant to measure)
-static __device__ unsigned long long vg_tr_buf[1024];
-#define VG_T(cond, id) do { if (threadIdx.x == 0 && (cond)) vg_tr_buf[(id) & 1023] = wall_clock64(); } while (0)
+static __device__ unsigned long long vg_tr_buf[2048];
+#define VG_T(cond, id) do { if (threadIdx.x == 0 && (cond)) vg_tr_buf[(id) & 2047] = wall_clock64(); } while (0)
 // latest end over ALL workgroups that pass here (the slowest workgroup of a role)
-#define VG_TMAX(id) do { __syncthreads(); if (threadIdx.x == 0) atomicMax(&vg_tr_buf[(id) & 1023], (unsigned long long)wall_clock64()); } while (0)
+#define VG_TMAX(id) do { __syncthreads(); if (threadIdx.x == 0) atomicMax(&vg_tr_buf[(id) & 2047], (unsigned long long)wall_clock64()); } while (0)
 static int vg_trace_take(unsigned long long* host, int cap) {      // (id, stamp) pairs of this translation unit; clears them
-    static unsigned long long tmp[1024];
+    static unsigned long long tmp[2048];
     if (hipMemcpyFromSymbol(tmp, HIP_SYMBOL(vg_tr_buf), sizeof(tmp)) != hipSuccess) return -1;
     int n = 0;
-    for (int i = 0; i < 1024 && n < cap; ++i)
+    for (int i = 0; i < 2048 && n < cap; ++i)
         if (tmp[i]) { host[2 * n] = (unsigned long long)i; host[2 * n + 1] = tmp[i]; ++n; }
-    for (int i = 0; i < 1024; ++i) tmp[i] = 0;
+    for (int i = 0; i < 2048; ++i) tmp[i] = 0;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(vg_tr_buf), tmp, sizeof(tmp));
     return n;
 }
