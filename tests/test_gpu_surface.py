@@ -943,7 +943,8 @@ def test_many_sample_gemm_role_on_the_f16_pipe_against_its_float32_form(robot, S
 def test_reverse_path_pass_over_several_chunks_per_workgroup_is_bitwise_the_same(S, N, M, P):
     """paths_bwd_sc8 stages a latent's A / C tangents once and walks several 8-sample chunks (the
     per-chunk re-staging moved 3.6x the operand bytes); the per-chunk partial sums it leaves are the same numbers in the
-    same order as with one chunk per workgroup (flag BWD_ONE_CHUNK), so losses, gradients and updates agree bit for bit."""
+    same order as with one chunk per workgroup (flag BWD_ONE_CHUNK), so losses, gradients and updates agree bit for bit.
+    (Mz = 32, the first case: paths_bwd_regs -- one set of sums per WORKGROUP; agreement to float32 rounding of the chunk sum.)"""
     from vgpmp_amd import capi, engine
     ps = rb.load_problemset("franka", "industrial")
     spec = rb.load_robot("franka")
@@ -956,12 +957,20 @@ def test_reverse_path_pass_over_several_chunks_per_workgroup_is_bitwise_the_same
         pl = engine.PlannerBatch(sc, qs, **kw)
         pl.fuse = False
         pl.extra_flags = flag
-        pl.step(); pl.step()
+        regs = M + 2 == 32 and N <= 100 and N % 4 == 0      # (paths_bwd_regs: see the docstring)
+        if not regs:
+            pl.step(); pl.step()      # (not for the rounding comparison: Adam turns 1e-7 of a near-zero gradient into 1e-5 of a variable)
         loss, grads = pl.loss_and_grad(generate=True, step=5)
         torch.cuda.synchronize()
         # (the flag also keeps the forward assembly on paths_fwd_sc8; without it paths_fwd_regs forms the paths: f and R as well)
         outs.append([loss.clone(), pl.q_mu.clone(), pl.q_sqrt.clone(), pl.raw_ell.clone(), pl.raw_var.clone(), pl.f.clone(), pl.view("R")]
                     + [g.clone() for g in grads])
     assert float(outs[0][7].abs().max()) > 0
+    if regs:
+        # the register-resident kernel (paths_bwd_regs) adds its chunks' sums up itself and leaves ONE set per workgroup (round 5): per
+        # chunk the same numbers, their sum in float32 chunk order instead of the assembly's float64 -- rounding of a float32 sum
+        for a, b in zip(*outs):
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-30, float((a - b).abs().max()) / float(b.abs().max())
+        return
     for a, b in zip(*outs):
         assert torch.equal(a, b)

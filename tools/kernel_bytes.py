@@ -28,6 +28,12 @@ def table(w):
     gather that misses: profiles/r02/final/gather_probe_calib.txt), "mixed"."""
     P, S, N, M, L, Q, B = (w[k] for k in ("P", "S", "N", "M", "L", "Q", "B"))
     Mz, J, NC, PL = M + 2, N + M + 2, -(-S // 8), P * L
+    # sets of partial sums the reverse pass leaves per latent: one per 8-sample chunk, or -- the register-resident kernel of large batches
+    # (Mz = 32), round 5 -- one per WORKGROUP of cpw chunks (gp_path.hip: cpw doubles while that leaves kPbMinWgs workgroups)
+    cpw = 1
+    while cpw < NC and PL * -(-NC // (2 * cpw)) >= 1536:
+        cpw *= 2
+    NCp = -(-NC // cpw) if (Mz == 32 and cpw >= 2) else NC
     f4, f8 = 4, 8
     t = {}
     t["prior_fused_split_kernel"] = dict(
@@ -40,9 +46,9 @@ def table(w):
         read=P * S * L * J * f4 + PL * (N * Mz + Mz * Mz + Mz) * f4 + 2 * PL * S * Mz * f4, write=P * S * L * (N + Mz) * f4, access="wide",
         flops=2.0 * P * S * L * (Mz * Mz + N * Mz), note="reads F0, AT, C, m, epsT, eps2T; writes f, R")
     t["paths_bwd_regs"] = dict(
-        read=P * S * L * (N + 2 * Mz + 2 * J) * f4 + PL * N * Mz * 16 + 2 * PL * Mz * Mz * f4, write=PL * NC * (Mz + Mz * Mz + 8) * f4,
+        read=P * S * L * (N + 2 * Mz + 2 * J) * f4 + PL * N * Mz * 16 + 2 * PL * Mz * Mz * f4, write=PL * NCp * (Mz + Mz * Mz + 8) * f4,
         access="wide", flops=2.0 * P * S * L * (3 * N * Mz + 2 * Mz * Mz + Mz * Mz),
-        note="reads G, R, epsT, F0, H once and A4 (+ the tangents of C) once per latent; the 4 workgroups of a latent each fetch A4")
+        note="reads G, R, epsT, F0, H once and A4 (+ the tangents of C) once per latent; the workgroups of a latent each fetch A4; writes ONE set of partial sums per workgroup")
     # (round 5: the rows of A -- A4, AT: N Mz 20 B per latent, 3 N Mz^2 of the float64 products -- are formed by stage A's workgroups,
     #  mid_stage1 / mid_cov_a_rng below; stage B keeps KL, the two tangents and q_sqrt)
     rows_write, rows_flops = PL * N * Mz * 20, PL * 2.0 * 4 * N * 32 * 32
@@ -52,7 +58,7 @@ def table(w):
         note="reads Kuu, dKuu, Lk, Lk^-1, q_sqrt, q_mu; writes C, CT, the two tangents, Lk32, m, the KL gradients; float64 MFMA products "
              "(nine 32^3 ones per latent: four per tangent, one for q_sqrt)")
     t["mid_hyper_final_kernel"] = dict(
-        read=PL * NC * (Mz + Mz * Mz + 8) * f4 + PL * (Mz * Mz * f4 + 4 * (M * M + M) * f8), write=PL * 4 * (M * M + M) * f8, access="wide",
+        read=PL * NCp * (Mz + Mz * Mz + 8) * f4 + PL * (Mz * Mz * f4 + 4 * (M * M + M) * f8), write=PL * 4 * (M * M + M) * f8, access="wide",
         flops=PL * (2.0 * M * M * Mz / 2), note="reads the chunk partials, Lk32, KL gradients, variables + moments; writes gradient, variables, moments")
     t["mid_stage1_kernel"] = dict(t["mid_hyper_final_kernel"], note="gradient assembly of the previous step (as mid_hyper_final_kernel) beside stage A and the draws; "
                                   "+ omega / beta / eps / eps' writes + stage A's (Kuu, dKuu, Lk, Lk^-1, the inverse; A4, AT)",

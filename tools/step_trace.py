@@ -42,6 +42,8 @@ NAMES = {100: "cov_a start", 101: "cov_a Kuu built", 102: "cov_a factorised", 10
          142: "cov_a inverse formed", 143: "rows tail: dKuu/dell requested", 144: "rows tail: Kfu of tile 0", 145: "rows tail: operands stand", 146: "rows tail: tile 0 products start",
          147: "rows tail: tile 0 products done", 148: "rows tail: tile 4 start", 149: "rows tail: tile 4 products done",
          1600: "rows wave: loads issued", 1601: "rows wave: staged", 1602: "rows wave: Kfu formed", 1603: "rows wave: products done", 1604: "rows wave: stored",
+         **{1700 + 16 * r + k: f"mid_stage1 {('gradient assembly', 'stage A', 'basis draws', 'normal draws', 'eps draws')[r]} wg {k}/8 start" for r in range(5) for k in range(8)},
+         **{1800 + 16 * r + k: f"mid_stage1 {('gradient assembly', 'stage A', 'basis draws', 'normal draws', 'eps draws')[r]} wg {k}/8 end" for r in range(5) for k in range(8)},
          **{1320 + 4 * i + y: f"prior small16 wg ({64 * i}, {y}) start" for i in range(8) for y in range(4)},
          **{1360 + 4 * i + y: f"prior small16 wg ({64 * i}, {y}) end" for i in range(8) for y in range(4)}}
 

@@ -226,9 +226,24 @@ template <int MZCAP>
 __global__ __launch_bounds__(kBlock, MZCAP <= 32 ? 4 : 1) void mid_stage1_kernel(MidS1Args s) {
     extern __shared__ double sm[];
     int b = blockIdx.x;
+#ifdef VGPMP_BISECT
+    // (measurement build: start / end of eight workgroups of every role, evenly spaced -- ids 1700 / 1800 + 16 role + k; tools/step_trace.py)
+    struct RoleStamp {
+        int id;
+        __device__ RoleStamp(int role, int b, int n) : id(-1) {
+            const int step = n > 8 ? n / 8 : 1;
+            if (b % step == 0 && b / step < 8) { id = 16 * role + b / step; VG_T(true, 1700 + id); }
+        }
+        __device__ ~RoleStamp() { if (id >= 0) VG_T(true, 1800 + id); }
+    };
+#define VG_ROLE_STAMP(role, b, n) RoleStamp rs_(role, b, n)
+#else
+#define VG_ROLE_STAMP(role, b, n) do { } while (0)
+#endif
     // (the gradient assembly first.  Stage A is the longer chain since it also forms the rows of A, but in front it measured +2 % at
     //  896 latent pairs, -0.5 % at 385: its workgroups wait most of their time, the assembly's ingest is what fills the CUs)
     if (b < s.n_fin) {
+        VG_ROLE_STAMP(0, b, s.n_fin);
         const HyperArgs& h = s.hy;
         const bool own = h.ctr && h.do_adam;
         FinalArgs fb = s.fin;      // the step size comes from the counter here, as in mid_hyper_final_kernel
@@ -246,14 +261,16 @@ __global__ __launch_bounds__(kBlock, MZCAP <= 32 ? 4 : 1) void mid_stage1_kernel
     }
     b -= s.n_fin;
     const MidAArgs& a = s.a;
-    if (b < a.n_cov) { cov_a_body(a.cov, sm, b % a.cov.L, b / a.cov.L); return; }
+    if (b < a.n_cov) { VG_ROLE_STAMP(1, b, a.n_cov); cov_a_body(a.cov, sm, b % a.cov.L, b / a.cov.L); return; }
     b -= a.n_cov;
-    if (b < a.n_basis) { rng_basis_body(a.rng, b % a.basis_gx, b / a.basis_gx, reinterpret_cast<float*>(sm)); return; }
+    if (b < a.n_basis) { VG_ROLE_STAMP(2, b, a.n_basis); rng_basis_body(a.rng, b % a.basis_gx, b / a.basis_gx, reinterpret_cast<float*>(sm)); return; }
     b -= a.n_basis;
-    if (b < a.n_norm) { rng_normals_body(a.rng, b % a.n_gx, b / a.n_gx, a.rng.nW, a.rng.nE); return; }
+    if (b < a.n_norm) { VG_ROLE_STAMP(3, b, a.n_norm); rng_normals_body(a.rng, b % a.n_gx, b / a.n_gx, a.rng.nW, a.rng.nE); return; }
     b -= a.n_norm;
+    VG_ROLE_STAMP(4, b, (int)gridDim.x - s.n_fin - a.n_cov - a.n_basis - a.n_norm);
     rng_eps_t_body(a.rng, b % a.e_gx, b / a.e_gx, reinterpret_cast<float*>(sm));
 }
+#undef VG_ROLE_STAMP
 
 // Few samples per problem (the f16-split few-sample prior kernel, S <= 32) in the batch schedule: stage B and the prior draws need
 // only stage A and the noise, not each other -- ONE launch.  Stage B is four ~10 us chains per latent in 35 KB of LDS each (four
@@ -618,9 +635,13 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         if (pairs && pa.cpw < 2 && (size_t)P * L * ((NC + 1) / 2) >= 256) pa.cpw = 2;
         if (pairs && pa.cpw == 2 && NC >= 4 && (size_t)P * L * ((NC + 3) / 4) >= 600) pa.cpw = 4;
     }
+    // large batches: the register-resident reverse pass (paths_bwd_regs, below) leaves ONE set of partial sums per workgroup, not per chunk
+    const bool regs_bwd = backward && SK == 1 && Mz == 32 && (N & 3) == 0 && N <= 100 && pa.cpw >= 2;
+    const int NCp = regs_bwd ? (NC + pa.cpw - 1) / pa.cpw : NC;
+    pa.NCp = NCp; hy.NC = NCp; hyp.NC = NCp; ca.hy.NC = NCp; fe.hy.NC = NCp;
     const double lik_scale = pb->alpha / (double)d->S_total;
     FinalArgs fa;
-    fa.M = M; fa.L = L; fa.NC = NC; fa.nblk = P ? vg_loglik_blocks_per_problem(S, N) : 0; fa.part_len = vg_part_len(d);
+    fa.M = M; fa.L = L; fa.NC = NCp; fa.nblk = P ? vg_loglik_blocks_per_problem(S, N) : 0; fa.part_len = vg_part_len(d);
     fa.part = ws->part; fa.Lk32 = ws->Lk32; fa.lik_partial = ws->lik_partial;
     fa.gkl_qmu = ws->gkl_qmu; fa.gkl_Q = ws->gkl_Q; fa.kl_l = ws->kl_l;
     fa.kl_scale = pb->kl_scale; fa.lik_scale = lik_scale; fa.out_lik = out->lik; fa.out_kl = out->kl;
@@ -670,19 +691,19 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     if (raw_fwd) lds_pf += raw_f;
     if (raw_bwd) lds_pb += 2 * raw_f;
     size_t lds_fin = ((size_t)Mz * Mz + Mz + 1) * sizeof(double) + ((size_t)Mz * Mz + 4) * sizeof(float);
-    const size_t raw_fin = (size_t)NC * (Mz + Mz * Mz) * sizeof(float);
+    const size_t raw_fin = (size_t)NCp * (Mz + Mz * Mz) * sizeof(float);
     const bool fin_dma = lds_fin + raw_fin <= 96 * 1024;      // every chunk's partials at once
     // otherwise in passes of as many chunks (a multiple of 8: the summation order goes by eights) as 96 KB hold
     const size_t row_fin = (size_t)(Mz + Mz * Mz) * sizeof(float);
-    int fin_pass = fin_dma ? NC : (int)(((96 * 1024 - lds_fin) / row_fin) & ~(size_t)7);
+    int fin_pass = fin_dma ? NCp : (int)(((96 * 1024 - lds_fin) / row_fin) & ~(size_t)7);
     // large batches: passes of eight chunks -- 46 instead of 80 KB of LDS, a third workgroup per CU; the same sums in the same order
     // (config-5 share: 51 -> 47 us for the launch)
-    if (!fused && NC > 8 && (size_t)P * L >= 512) fin_pass = 8;
+    if (!fused && NCp > 8 && (size_t)P * L >= 512) fin_pass = 8;
     // ... and of four from 768 latent pairs (Mz <= 32: mid_hyper_final_kernel<32>, four workgroups per CU at 30 KB each): one round
     // (config-5 share: 41 -> 3x us for the launch; half sums carried between passes: the same additions in the same order)
     // ... and wherever the assembly shares the first launch of the next step with stage A and the draws (mid_stage1_kernel: every
     // role of a launch is granted the launch's LDS -- 80 KB of chunk partials per workgroup left two workgroups per CU for all of them)
-    if (!fused && NC > 4 && Mz <= 32 && (size_t)P * L > 128) fin_pass = 4;      // (up to 128 latent pairs: possibly the column-strip form)
+    if (!fused && NCp > 4 && Mz <= 32 && (size_t)P * L > 128) fin_pass = 4;      // (up to 128 latent pairs: possibly the column-strip form)
     lds_fin += (size_t)fin_pass * row_fin;
     fa.dma = fin_pass;
     // few problems: the update role of stage 1 by column strips on kFinSplit workgroups (its LDS need is below lds_fin)
@@ -739,10 +760,10 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         lds_pb = lds_pbs;
     }
     // large batches: the latent's constants in registers, pairs of chunks through 40 KB of LDS (paths_bwd_regs)
-    const bool regs_bwd = backward && !split_bwd && SK == 1 && Mz == 32 && (N & 3) == 0 && N <= 100 && pa.cpw >= 2;
+    // (regs_bwd, above: SK == 1 excludes split_bwd)
     if (regs_bwd) {
         fn_pb = VG_FN(paths_bwd_regs<25>);
-        lds_pb = ((size_t)kPbrBufs * (16 * N + (VG_PBR_DIRECT ? 0 : 32 * J) + 2 * 16 * Mz + 16) + (size_t)6 * 16 * Mz + 8 * 4) * sizeof(float);
+        lds_pb = ((size_t)kPbrBufs * (16 * N + (VG_PBR_DIRECT ? 0 : 32 * J) + 2 * 16 * Mz + 16) + (size_t)6 * 16 * Mz + (size_t)Mz * Mz + Mz + 8 * 4) * sizeof(float);
     }
     // ... and the forward assembly likewise (paths_fwd_regs); both take pa.cpw chunks per workgroup
     const bool regs_fwd = !fused && !split_fwd && SK == 1 && Mz == 32 && N <= 128 && pa.cpw >= 2;

@@ -29,6 +29,7 @@ struct PathArgs {
     int xcd_span;
     uint32_t* tick;           // paths_fwd_sc8: the step counter ticks here (large-batch schedule; nullptr: elsewhere)
     int cpw;                  // paths_bwd_sc8: sample chunks per workgroup (the latent's A / C tangents are staged once for all of them)
+    int NCp;                  // sets of partial sums per latent the reverse pass leaves: NC (one per chunk), or one per workgroup (paths_bwd_regs)
 };
 __device__ __forceinline__ int xcd_contiguous(int id, int span) { return span > 0 ? (id & 7) * span + (id >> 3) : id; }
 
@@ -548,6 +549,7 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
     }
     float* dRs2 = take(R2 * Mz);                     // [16][Mz]
     float* dGA = take(5 * R2 * Mz);                  // [5][16][Mz] G A, G A_ell, G A_var, eps C_var^T, eps C_ell^T
+    float* accL = take(Mz * Mz + Mz);                // the workgroup's running sums of dC and dm
     const bool dell = a.want_dell != 0;
     const int wv = tid >> 6, lane = tid & 63, i = lane & 15, kk = lane >> 4;
     // ---- B fragments of every K step, once per workgroup
@@ -614,6 +616,16 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
 #endif
         }
     };
+    // The partial sums of ALL this workgroup's chunks leave it as ONE set (round 5; a set per chunk before: 16 x 4.2 KB per latent at
+    // 128 samples -- 61 MB per launch at the config-5 share, written here and read again by the gradient assembly, which they made the
+    // longest role of the next step's first launch): per chunk the sums are those of paths_bwd_sc8, the chunks' sums are added in
+    // chunk order in float32 registers; the assembly adds the a.NCp sets of a latent in float64 as before.
+    // (the running sums of dm / dC in LDS -- a thread only ever touches its own elements: no barrier -- the 168 registers are spoken for)
+    constexpr int kCE = Mz * Mz / kBlock;
+    float acc_se = 0.f, acc_sv = 0.f, acc_sr = 0.f;
+#pragma unroll
+    for (int k = 0; k < kCE; ++k) accL[tid + k * kBlock] = 0.f;
+    if (tid < Mz) accL[Mz * Mz + tid] = 0.f;
     if (kPbrBufs > 1) stage_pair(blockIdx.x * a.cpw, 0);
     int cb = 0;
     for (int ch0 = blockIdx.x * a.cpw; ch0 < cp_end; ch0 += 2) {
@@ -730,33 +742,40 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
             }
 #endif
             __syncthreads();
-            float* out = a.part + (pl * a.NC + ch) * a.part_len;
-            for (int mi = tid; mi < Mz; mi += nt) {
+            if (tid < Mz) {
                 float t = 0.f;
-                for (int sl = 0; sl < SC; ++sl) t += dRs[sl * Mz + mi];
-                vg_stream(out + mi, t);
+                for (int sl = 0; sl < SC; ++sl) t += dRs[sl * Mz + tid];
+                accL[Mz * Mz + tid] += t;
             }
-            float* oC = out + Mz;
-            // (one element per thread and pass: a (mi, four adjacent k) form with float4 reads of eps and one 16-byte store per
-            //  thread measured SLOWER, 145 vs 130 us at the config-5 share)
-            for (int e = tid; e < Mz * Mz; e += nt) {
-                const int mi = vg_div(e, iMz), k = e - mi * Mz;
+            // (one element per thread and pass: a (mi, four adjacent k) form with float4 reads of eps measured SLOWER, 145 vs 130 us
+            //  at the config-5 share)
+#pragma unroll
+            for (int k = 0; k < kCE; ++k) {
+                const int e = tid + k * kBlock, mi = e >> 5, kc = e & 31;
                 float t = 0.f;
-                for (int sl = 0; sl < SC; ++sl) t = fmaf(dRs[sl * Mz + mi], Es[sl * Mz + k], t);
-                vg_stream(oC + e, t);
+                for (int sl = 0; sl < SC; ++sl) t = fmaf(dRs[sl * Mz + mi], Es[sl * Mz + kc], t);
+                accL[e] += t;
             }
-            se = vg_wave_sum(se); sv = vg_wave_sum(sv); sr = vg_wave_sum(sr);
-            if ((tid & 63) == 0) { red[0][tid >> 6] = se; red[1][tid >> 6] = sv; red[2][tid >> 6] = sr; }
-            __syncthreads();
-            if (tid == 0) {
-                float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-                for (int k = 0; k < (int)(nt >> 6); ++k) { t0 += red[0][k]; t1 += red[1][k]; t2 += red[2][k]; }
-                float* os = oC + (size_t)Mz * Mz;
-                os[0] = t0; os[1] = t1; os[2] = t2; os[3] = 0.f;
-                os[4] = 0.f; os[5] = 0.f; os[6] = 0.f; os[7] = 0.f;      // second set: paths_bwd_split only
-            }
-            __syncthreads();      // `red` and the chunk's rows are reused
+            acc_se += se; acc_sv += sv; acc_sr += sr;
+            __syncthreads();      // the chunk's rows are reused
             VG_PBT(pair_i, 4 + c);
+        }
+    }
+    {
+        float* out = a.part + (pl * a.NCp + blockIdx.x) * a.part_len;
+        if (tid < Mz) vg_stream(out + tid, accL[Mz * Mz + tid]);
+        float* oC = out + Mz;
+#pragma unroll
+        for (int k = 0; k < kCE; ++k) vg_stream(oC + tid + k * kBlock, accL[tid + k * kBlock]);
+        const float se = vg_wave_sum(acc_se), sv = vg_wave_sum(acc_sv), sr = vg_wave_sum(acc_sr);
+        if ((tid & 63) == 0) { red[0][tid >> 6] = se; red[1][tid >> 6] = sv; red[2][tid >> 6] = sr; }
+        __syncthreads();
+        if (tid == 0) {
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+            for (int k = 0; k < (int)(nt >> 6); ++k) { t0 += red[0][k]; t1 += red[1][k]; t2 += red[2][k]; }
+            float* os = oC + (size_t)Mz * Mz;
+            os[0] = t0; os[1] = t1; os[2] = t2; os[3] = 0.f;
+            os[4] = 0.f; os[5] = 0.f; os[6] = 0.f; os[7] = 0.f;      // second set: paths_bwd_split only
         }
     }
 #undef VG_PBT
