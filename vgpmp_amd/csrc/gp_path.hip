@@ -261,6 +261,8 @@ __global__ __launch_bounds__(kBlock, MZCAP <= 32 ? 4 : 1) void mid_stage1_kernel
     }
     b -= s.n_fin;
     const MidAArgs& a = s.a;
+    // (stage A dealt out AMONG the draws -- every stride-th position of the rest of the grid, so that a CU holds a mix of float64 chains
+    //  and float32 vector work -- starts its chains late: config 3 123 -> 202 us per step, config-5 share +1.6 %, 64 problems +6 %)
     if (b < a.n_cov) { VG_ROLE_STAMP(1, b, a.n_cov); cov_a_body(a.cov, sm, b % a.cov.L, b / a.cov.L); return; }
     b -= a.n_cov;
     if (b < a.n_basis) { VG_ROLE_STAMP(2, b, a.n_basis); rng_basis_body(a.rng, b % a.basis_gx, b / a.basis_gx, reinterpret_cast<float*>(sm)); return; }
@@ -477,6 +479,7 @@ static RngArgs make_rng_args(const vgpmp_dims* d, const vgpmp_noise* nz, uint32_
     r.omega = nz->omega; r.beta = nz->beta; r.w = nz->w; r.eps = nz->eps; r.eps2 = nz->eps2;
     r.seed = seed; r.problem_base = problem_base; r.step = step; r.bias = bias; r.ctr = ctr;
     r.epsT = nullptr; r.eps2T = nullptr; r.Mz = vg_mz(d); r.S = d->S;
+    r.eps_rows_log2 = 6;
     return r;
 }
 
@@ -487,7 +490,7 @@ int vg_launch_rng(const vgpmp_dims* d, const vgpmp_noise* nz, uint32_t seed, uin
     r.epsT = epsT; r.eps2T = eps2T;
     VG_GGL(rng_basis_kernel, dim3((r.L * r.B + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
     if (epsT) {      // eps / eps' in both layouts by their own launch, w alone by the other
-        VG_GGL(rng_eps_t_kernel, dim3(rng_eps_t_blocks((uint32_t)r.S * r.Mz), P), dim3(kBlock), 0, st, r);
+        VG_GGL(rng_eps_t_kernel, dim3(rng_eps_t_blocks((uint32_t)r.S * r.Mz, r.eps_rows_log2), P), dim3(kBlock), 0, st, r);
         r.nE = 0;
     }
     const uint32_t nthr = rng_normal_threads(r.nW, r.nE, r.eOff);
@@ -805,14 +808,17 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     pa.epsT = eps_t && (regs_fwd || regs_bwd) ? ws->epsT : nullptr; pa.eps2T = eps_t && regs_fwd ? ws->eps2T : nullptr;
     float* const eps_t1 = eps_t ? ws->epsT : nullptr;
     float* const eps_t2 = eps_t && regs_fwd ? ws->eps2T : nullptr;
-    const uint32_t eps_gx = eps_t ? rng_eps_t_blocks((uint32_t)S * Mz)
+    const uint32_t eps_gx = eps_t ? rng_eps_t_blocks((uint32_t)S * Mz, 6)
                                   : (2u * rng_eps_quads((uint32_t)S * Mz * L, (uint32_t)d->sample_offset * Mz * L) + kBlock - 1) / kBlock;
     auto mid_normal_grid = [&](MidAArgs& ma) -> unsigned {      // the normal-draw roles of mid_cov_a_rng_kernel
         if (eps_t) { ma.rng.epsT = eps_t1; ma.rng.eps2T = eps_t2; ma.rng.nE = 0; }
         const uint32_t n_thr = rng_normal_threads(ma.rng.nW, ma.rng.nE, ma.rng.eOff);
         ma.n_gx = (int)((n_thr + kBlock - 1) / kBlock);
         ma.n_norm = ma.n_gx * P;
-        ma.e_gx = eps_t ? (int)rng_eps_t_blocks((uint32_t)S * Mz) : 0;
+        // (256 rows per workgroup wherever that still leaves a workgroup per slot: 64-row workgroups are launch cost, 22 us of them
+        //  at 896 latent pairs)
+        if (eps_t && (size_t)P * rng_eps_t_blocks((uint32_t)S * Mz, 8) >= 1024) ma.rng.eps_rows_log2 = 8;
+        ma.e_gx = eps_t ? (int)rng_eps_t_blocks((uint32_t)S * Mz, ma.rng.eps_rows_log2) : 0;
         return (unsigned)ma.n_norm + (unsigned)ma.e_gx * P;
     };
     const uint32_t basis_gx = ((uint32_t)L * B + kBlock - 1) / kBlock;
@@ -1032,7 +1038,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                 VG_GGL(rng_basis_kernel, dim3((r.L * r.B + kBlock - 1) / kBlock, P), dim3(kBlock), 0, st, r);
                 if (eps_t) {
                     r.epsT = ws->epsT; r.eps2T = ws->eps2T;
-                    VG_GGL(rng_eps_t_kernel, dim3(rng_eps_t_blocks((uint32_t)S * Mz), P), dim3(kBlock), 0, st, r);
+                    VG_GGL(rng_eps_t_kernel, dim3(rng_eps_t_blocks((uint32_t)S * Mz, r.eps_rows_log2), P), dim3(kBlock), 0, st, r);
                     r.nE = 0;
                 }
                 const uint32_t nthr = rng_normal_threads(r.nW, r.nE, r.eOff);

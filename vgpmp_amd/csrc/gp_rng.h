@@ -16,6 +16,8 @@ struct RngArgs {
     float *epsT, *eps2T;      // optional second copies [P,L,S,Mz] (a latent's rows contiguous: what the per-latent consumers stage;
                               //  with epsT set, eps / eps' are drawn by rng_eps_t_body, not by rng_normals_body)
     int Mz, S;
+    int eps_rows_log2;        // rng_eps_t_body: rows (s, k) per workgroup, 64 (few problems: many short workgroups) or 256 (batches: a
+                              // 64-row workgroup is one counter on 112 of its 256 threads -- all launch cost; 16 384 of them at 896 latents)
 };
 
 __device__ __forceinline__ uint32_t rng_step(const RngArgs& a) { return a.ctr ? *a.ctr + a.bias : a.step; }
@@ -103,17 +105,18 @@ __device__ __forceinline__ void rng_normals_body(const RngArgs& a, int bx, int p
 }
 
 // eps, eps' in BOTH layouts: [P,S,Mz,L] (the interface's) and [P,L,S,Mz] (epsT / eps2T: the consumers work per latent -- from the
-// first layout each of their 4-byte requests pulled a 64-byte sector shared by the L latents).  A workgroup owns kEpsRows
+// first layout each of their 4-byte requests pulled a 64-byte sector shared by the L latents).  A workgroup owns 2^eps_rows_log2
 // rows (s, k) of one of the two streams: L kEpsRows consecutive elements, their counters one per thread and pass; the normals
 // go out in the first layout as they are drawn and through an LDS tile in the second, 64 consecutive floats per wave.
-constexpr int kEpsRows = 64;
-__host__ __device__ __forceinline__ uint32_t rng_eps_t_blocks(uint32_t rows) { return 2u * ((rows + kEpsRows - 1) / kEpsRows); }
-// (`tile`: kEpsRows L floats of the launch's dynamic LDS -- static arrays here would add to every role of the merged launches)
+constexpr int kEpsRowsMax = 256;
+__host__ __device__ __forceinline__ uint32_t rng_eps_t_blocks(uint32_t rows, int rows_log2) { return 2u * ((rows + (1u << rows_log2) - 1u) >> rows_log2); }
+// (`tile`: eps_rows L floats of the launch's dynamic LDS -- static arrays here would add to every role of the merged launches)
 __device__ __forceinline__ void rng_eps_t_body(const RngArgs& a, int bx, int p, float* tile) {
-    const int tid = threadIdx.x, L = a.L;
-    const uint32_t rows = (uint32_t)a.S * a.Mz, half = (rows + kEpsRows - 1) / kEpsRows, nE = rows * (uint32_t)L;
+    const int tid = threadIdx.x, L = a.L, sh = a.eps_rows_log2;
+    const uint32_t kEpsRows = 1u << sh;
+    const uint32_t rows = (uint32_t)a.S * a.Mz, half = (rows + kEpsRows - 1u) >> sh, nE = rows * (uint32_t)L;
     const bool second = (uint32_t)bx >= half;
-    const uint32_t r0 = ((uint32_t)bx - (second ? half : 0u)) * kEpsRows, nr = min((uint32_t)kEpsRows, rows - r0);
+    const uint32_t r0 = ((uint32_t)bx - (second ? half : 0u)) * kEpsRows, nr = min(kEpsRows, rows - r0);
     const uint32_t e_lo = r0 * L, e_hi = e_lo + nr * L;            // local elements of this workgroup
     VG_T(bx == 0 && p == 0, 120);
     const uint2 key = vg_key(a.seed, a.problem_base + p, rng_step(a));
@@ -141,7 +144,7 @@ __device__ __forceinline__ void rng_eps_t_body(const RngArgs& a, int bx, int p, 
     __syncthreads();
     // element (r, l) of the tile -> epsT[p][l][r0 + r]: lanes along r
     for (uint32_t idx = tid; idx < (uint32_t)L * kEpsRows; idx += kBlock) {
-        const uint32_t l = idx / kEpsRows, r = idx % kEpsRows;
+        const uint32_t l = idx >> sh, r = idx & (kEpsRows - 1u);
         if (r < nr) vg_stream(dstT + ((size_t)p * L + l) * rows + r0 + r, tile[r * L + l]);
     }
 }
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void rng_basis_kernel(RngArgs a) {
     rng_basis_body(a, blockIdx.x, blockIdx.y, sc_s);
 }
 __global__ __launch_bounds__(kBlock) void rng_eps_t_kernel(RngArgs a) {
-    __shared__ float tile[kEpsRows * VGPMP_MAX_DOF];
+    __shared__ float tile[kEpsRowsMax * VGPMP_MAX_DOF];
     rng_eps_t_body(a, blockIdx.x, blockIdx.y, tile);
 }
 __global__ __launch_bounds__(kBlock) void rng_normals_kernel(RngArgs a) {
