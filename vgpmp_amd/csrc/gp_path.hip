@@ -240,8 +240,13 @@ __global__ __launch_bounds__(kBlock, MZCAP <= 32 ? 4 : 1) void mid_stage1_kernel
 #else
 #define VG_ROLE_STAMP(role, b, n) do { } while (0)
 #endif
-    // (the gradient assembly first.  Stage A is the longer chain since it also forms the rows of A, but in front it measured +2 % at
-    //  896 latent pairs, -0.5 % at 385: its workgroups wait most of their time, the assembly's ingest is what fills the CUs)
+    const MidAArgs& a = s.a;
+    // Stage A first: the longest chain of the launch since it also forms the rows of A (25 us alone, 45 with four of them on a CU).
+    // (While the gradient assembly pulled sixteen sets of chunk partials per latent it belonged in front -- stage A first measured +2 %
+    //  at 896 latent pairs; with one set per workgroup of the reverse pass: config 3 123.1 -> 121.9 us per step, the batches unchanged.
+    //  Dealt out AMONG the draws -- every stride-th position of the rest of the grid -- the chains start late: config 3 202 us.)
+    if (b < a.n_cov) { VG_ROLE_STAMP(1, b, a.n_cov); cov_a_body(a.cov, sm, b % a.cov.L, b / a.cov.L); return; }
+    b -= a.n_cov;
     if (b < s.n_fin) {
         VG_ROLE_STAMP(0, b, s.n_fin);
         const HyperArgs& h = s.hy;
@@ -260,11 +265,6 @@ __global__ __launch_bounds__(kBlock, MZCAP <= 32 ? 4 : 1) void mid_stage1_kernel
         return;
     }
     b -= s.n_fin;
-    const MidAArgs& a = s.a;
-    // (stage A dealt out AMONG the draws -- every stride-th position of the rest of the grid, so that a CU holds a mix of float64 chains
-    //  and float32 vector work -- starts its chains late: config 3 123 -> 202 us per step, config-5 share +1.6 %, 64 problems +6 %)
-    if (b < a.n_cov) { VG_ROLE_STAMP(1, b, a.n_cov); cov_a_body(a.cov, sm, b % a.cov.L, b / a.cov.L); return; }
-    b -= a.n_cov;
     if (b < a.n_basis) { VG_ROLE_STAMP(2, b, a.n_basis); rng_basis_body(a.rng, b % a.basis_gx, b / a.basis_gx, reinterpret_cast<float*>(sm)); return; }
     b -= a.n_basis;
     if (b < a.n_norm) { VG_ROLE_STAMP(3, b, a.n_norm); rng_normals_body(a.rng, b % a.n_gx, b / a.n_gx, a.rng.nW, a.rng.nE); return; }
