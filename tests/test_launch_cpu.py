@@ -95,7 +95,7 @@ def test_committed_traffic_table_is_this_rounds():
     assert t5["collected_at"] == t["collected_at"] == t3["collected_at"]
     assert t5["loglik_paths_mask_kernel<2>"]["hbm_bytes_per_launch"] > 1e8          # 2 GiB table: hundreds of MB of sectors per launch
     # round 5: the FETCH multiplier is calibrated per kernel against its algorithmic read volume (tools/kernel_bytes.py), not by name
-    for k in ("paths_bwd_regs<25>", "paths_fwd_regs<2>", "cov_b_kernel<true>", "prior_fused_split_kernel<true, 2>"):
+    for k in ("paths_bwd_regs<25>", "paths_fwd_regs<2>", "cov_b_kernel<true, false>", "prior_fused_split_kernel<true, 2>"):
         assert t5[k]["fetch_multiplier"] in (1, 2) and t5[k]["algorithmic_read_bytes"] > 0 and "multiplier_basis" in t5[k], k
     assert t5["paths_bwd_regs<25>"]["fetch_multiplier"] == 2 and t5["loglik_paths_mask_kernel<2>"]["fetch_multiplier"] == 1
     assert any(k.startswith("prior_fused_small16_kernel") for k in t3)       # (the f16-split few-sample kernel)
