@@ -35,7 +35,8 @@ struct CovArgs {
     int form_u, S;
     int rows_tpw;            // row tiles (kRowTile time points) per workgroup of the rows role
     int rows_wave;           // batches (with ki_in_a): the rows of A on the workgroup of stage A that formed the inverse, one wave per 16 time points, in registers (cov_rows_tail); stage B has no rows role then
-    int ki_in_a;             // batches: (Kuu + jI)^-1 = Lk^-T Lk^-1 once per latent, by stage A (ws.Kinv), not by every row-tile workgroup of stage B
+    int ki_in_a;             // batches: (Kuu + jI)^-1 = Lk^-T Lk^-1 once per latent, by stage A (ws.Kinv) -- which then forms the rows of A as well (rows_wave);
+                             // otherwise every row-tile workgroup of stage B forms its own (cov_rows_body)
     const float* eps;        // [P,L,S,Mz]  (ws.epsT: the generator's second copy, a latent's rows contiguous)
     HyperArgs hy;
     vg_workspace ws;
@@ -1046,8 +1047,7 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int wg_tile, int l, 
     {
         auto all = [](int, int) { return true; };
         if ((Mz & 1) == 0) {
-            if (a.ki_in_a) vg_stage_f64_square(Ki, ld, a.ws.Kinv + pl * Mz * Mz, Mz, tid, nt);      // stage A formed it
-            else vg_stage_f64_square(Lt, ld, a.ws.Li64 + pl * Mz * Mz, Mz, tid, nt);
+            vg_stage_f64_square(Lt, ld, a.ws.Li64 + pl * Mz * Mz, Mz, tid, nt);
             if (a.want_dell) vg_stage_f64_square(Kd, ld, a.ws.Kd_ell + pl * Mz * Mz, Mz, tid, nt);
             else for (int e = tid; e < Mz * ld; e += nt) Kd[e] = 0.0;
         } else {
@@ -1067,7 +1067,7 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int wg_tile, int l, 
     // (Kuu + jI)^-1 = Lk^-T Lk^-1: on the float64 matrix cores when Mz is a multiple of 16 (no padding needed), else by
     // dot products over the non-zero part of the two columns; tile 0 keeps the copy the views / the inducing-location
     // reverse pass read
-    if (!a.ki_in_a) {
+    {
         double* Kig = tile == 0 ? a.ws.Kinv + pl * Mz * Mz : nullptr;
         if ((Mz & 15) == 0) {
             matmul_f64(MatView{Lt, 1, ld}, MatView{Lt, ld, 1}, Mz, tid, nt, [&](int r, int c, double v) {
@@ -1094,7 +1094,7 @@ __device__ void cov_rows_body(const CovArgs& a, double* sm, int wg_tile, int l, 
         double* ar2 = kf;                      // [16][32]  A rows
         double* yr2 = kf + 16 * 32;            // [16][32]  dKfu/dell - A dKuu/dell
         const int rows_w = tpw * kRowTile, wv = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
-        if (!a.ki_in_a) __syncthreads();       // every wave has read Lk^-1
+        __syncthreads();       // every wave has read Lk^-1
         for (int r0 = 0; r0 < rows_w; r0 += 16) {
             const int n0 = n00 + r0;
             if (n0 >= N) break;
@@ -1180,8 +1180,8 @@ __device__ void cov_rows_padded_body(const CovArgs& a, double* sm, int wg_tile, 
     const int n00 = tile * kRowTile;
     {
         auto all = [](int, int) { return true; };
-        double* first = a.ki_in_a ? Ki : Lt;      // stage A formed (Kuu + jI)^-1: it arrives instead of Lk^-1
-        const double* first_g = (a.ki_in_a ? a.ws.Kinv : a.ws.Li64) + pl * Mz * Mz;
+        double* first = Lt;
+        const double* first_g = a.ws.Li64 + pl * Mz * Mz;
         if (!(Mz & 1)) {
             vg_stage_f64_even(first, Mp, ld, first_g, Mz, Mz, tid, nt);
             vg_stage_f64_even(Kd, Mp, ld, a.ws.Kd_ell + pl * Mz * Mz, a.want_dell ? Mz : 0, Mz, tid, nt);
@@ -1200,7 +1200,7 @@ __device__ void cov_rows_padded_body(const CovArgs& a, double* sm, int wg_tile, 
     vg_dma_wait();
     __syncthreads();
     VG_T(tile == 0 && l == 0 && p == 0, 232);
-    if (!a.ki_in_a) {   // (Kuu + jI)^-1 = Lk^-T Lk^-1; tile 0 keeps the copy the views / the inducing-location reverse pass read
+    {   // (Kuu + jI)^-1 = Lk^-T Lk^-1; tile 0 keeps the copy the views / the inducing-location reverse pass read
         double* Kig = tile == 0 ? a.ws.Kinv + pl * Mz * Mz : nullptr;
         matmul_f64(MatView{Lt, 1, ld}, MatView{Lt, ld, 1}, Mp, tid, nt, [&](int r, int c, double v) {
             Ki[r * ld + c] = v;
@@ -1209,7 +1209,7 @@ __device__ void cov_rows_padded_body(const CovArgs& a, double* sm, int wg_tile, 
     }
     const int rows_w = tpw * kRowTile, wv = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
     const float iMp = 1.0f / (float)Mp;
-    if (!a.ki_in_a) __syncthreads();       // every wave has read Lk^-1; Ki stands
+    __syncthreads();       // every wave has read Lk^-1; Ki stands
     for (int r0 = 0; r0 < rows_w; r0 += 16) {
         const int n0 = n00 + r0;
         if (n0 >= N) break;
