@@ -2,7 +2,9 @@
 Every case: (a) one injected-noise evaluation -- log-density of every (sample, time) pair, ELBO pieces, every gradient on the device's
 own voxels at the fixed tolerances of tests/helpers.py; (b) a few optimisation steps on the device's own generated noise, the oracle
 following step by step (tests/helpers.py::follow_device_trajectory) -- multi-step calls, so the merged launches of a call's later
-steps run.      python tools/fuzz_parity.py [n_cases] [seed]"""
+steps run.      python tools/fuzz_parity.py [n_cases] [seed] [regs]
+(regs: shapes of the register-resident path kernels of large batches -- Mz = 32, 64 or 128 samples, 6-12 problems -- which the uniform
+draw of shapes meets once in a hundred cases)"""
 import os, sys
 import numpy as np
 import torch
@@ -24,6 +26,8 @@ def main():
         B = int(rng.choice([64, 128, 256]))
         P = int(rng.choice([1, 1, 2, 3, 5, 6, 10, 12, 16, 24]))
         robot = str(rng.choice(["franka", "wam", "ur10", "kuka"]))
+        if len(sys.argv) > 3 and sys.argv[3] == "regs":
+            S, M, N, P = int(rng.choice([64, 128])), 30, int(rng.choice([12, 20, 40])), int(rng.choice([6, 10, 12]))
         if S * N * P * (M + 2) > 2_000_000:      # keep the oracle in seconds
             P = max(1, 2_000_000 // (S * N * (M + 2)))
         pb = small_problem(robot=robot, S=S, N=N, M=M, B=B, seed=int(rng.integers(1000)), n_grid=32)
