@@ -69,7 +69,6 @@ def parse_args(argv=None):
                     help="free-space brick summary in the batch likelihood kernel (auto: tables beyond the Infinity Cache)")
     ap.add_argument("--mask", choices=("auto", "on", "off"), default="auto",
                     help="free-space bit masks held in LDS by the batch likelihood kernel (auto: as --summary)")
-    ap.add_argument("--one-stream", action="store_true", help="measurement: no second stream (stage B of the covariance path after, not beside, the prior draws)")
     ap.add_argument("--lik-form", choices=("auto", "lanes", "lanes-lds"), default="auto",
                     help="likelihood kernel form (measurement): lanes = the batch form at any batch size, lanes-lds = with its per-frame sums in LDS")
     ap.add_argument("--flags", type=int, default=0, help="extra VGPMP_* measurement flags (include/vgpmp.h) OR-ed into every step")
@@ -740,9 +739,6 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
     from vgpmp_amd import capi
     ps, spec, grid, scene, planner = build_problem(rank, args, world)
     planner.extra_flags |= {"auto": 0, "lanes": capi.LIK_LANES, "lanes-lds": capi.LIK_LDS_STATE}[args.lik_form] | args.flags
-    if args.one_stream:
-        planner.overlap_streams = False
-        planner._pack()
     for _ in range(args.warmup):
         planner.step()
     if args.unroll > 0:

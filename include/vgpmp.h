@@ -200,10 +200,8 @@ typedef struct vgpmp_problem {
                              * the steps can be replayed */
     const vgpmp_lik_params* lik; /* host pointer, optional (see vgpmp_lik_params) */
     const vgpmp_inducing_params* ind; /* host pointer, optional (see vgpmp_inducing_params) */
-    vgpmp_stream aux_stream; /* optional second stream of the caller (NULL: none).  Large batches run stage B of the covariance path
-                              * on it BESIDE the prior draws of the same step (the two are independent; the float64 roles are
-                              * latency-bound and fill what the prior kernel's last round of workgroups leaves idle); forked from
-                              * and joined back into the call's stream by events, so the caller still synchronises on that alone */
+    vgpmp_stream aux_stream; /* reserved (NULL).  Rounds 4-5 ran stage B of the covariance path on this second stream beside the prior
+                              * draws; stage B now rides in the prior kernel's launch and the field is ignored (kept: struct layout) */
 } vgpmp_problem;
 
 /* Outputs of an ELBO evaluation. */

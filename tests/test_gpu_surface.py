@@ -447,28 +447,35 @@ def test_reset_is_a_freshly_built_planner(extra):
     assert torch.equal(a.f, b.f) and torch.equal(a.lik, b.lik) and torch.equal(a.kl, b.kl)
 
 
-def test_stage_b_on_the_second_stream_changes_nothing():
-    """Large batches run stage B of the covariance path on the scene's auxiliary stream beside the prior draws (forked from and
-    joined into the call's stream by events): the same kernels on the same inputs -- every variable bit for bit what the
-    one-stream order gives, over a run long enough for a missing dependency to show."""
-    from vgpmp_amd import engine
+
+@pytest.mark.parametrize("S,M,N,P", [(64, 30, 40, 12), (7, 24, 70, 20)])
+def test_merged_launches_of_the_batch_schedule_change_nothing(S, M, N, P):
+    """Batches that draw their own noise merge what a dependency level allows into one launch: the previous step's updates beside
+    stage A and the draws (mid_stage1), the rows of A as stage A's tail, stage B behind the tiles of the prior kernel
+    (prior_split_cov_b_kernel; with few samples mid_cov_b_prior16_kernel).  VGPMP_NO_FUSE runs one launch per kernel in sequence: the
+    same kernels' arithmetic on the same inputs -- every variable, moment and the paths bit for bit, over a run long enough for a
+    missing dependency inside a merged launch to show."""
+    from vgpmp_amd import capi, engine
     ps = rb.load_problemset("franka", "industrial")
     spec = rb.load_robot("franka")
     grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
     sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
-    qs = np.array([ps.queries[i % 36] for i in range(12)])          # 84 (problem, latent) pairs: the large-batch schedule
-    kw = dict(num_samples=64, num_inducing=30, num_data=40, num_bases=256, lengthscales=[2.0] * 7, variance=0.2, seed=4)
+    qs = np.array([ps.queries[i % 36] for i in range(P)])          # 84 / 140 (problem, latent) pairs: the large-batch schedule
+    kw = dict(num_samples=S, num_inducing=M, num_data=N, num_bases=256, lengthscales=[2.0] * 7, variance=0.2, seed=4)
     a, b = engine.PlannerBatch(sc, qs, **kw), engine.PlannerBatch(sc, qs, **kw)
-    b.overlap_streams = False
-    b._pack()
-    assert a._problem.aux_stream and not b._problem.aux_stream
+    b.extra_flags |= capi.NO_FUSE
     for _ in range(3):
         a.run_steps(40); b.run_steps(40)
         a.step(); b.step()
     torch.cuda.synchronize()
+    a.step()
+    merged = [k for k in capi.last_schedule(a.lib) if "prior_split_cov_b_kernel" in k or "mid_cov_b_prior16_kernel" in k]
+    b.step()
+    apart = [k for k in capi.last_schedule(b.lib) if "cov_b_kernel<" in k and "prior" not in k]
+    assert merged and apart, (capi.last_schedule(a.lib), capi.last_schedule(b.lib))      # (the two schedules this test is about)
+    torch.cuda.synchronize()
     for x, y in zip(a._variables() + a._moments() + [a.f, a.lik, a.kl], b._variables() + b._moments() + [b.f, b.lik, b.kl]):
         assert torch.equal(x, y), float((x - y).abs().max())
-
 
 def test_noise_drawn_ahead_is_never_paired_with_another_step():
     """The sample-sharded step lets step t draw the prior noise of step t + 1 (VGPMP_NOISE_AHEAD / _READY).  Which step's

@@ -44,6 +44,10 @@ NAMES = {100: "cov_a start", 101: "cov_a Kuu built", 102: "cov_a factorised", 10
          1600: "rows wave: loads issued", 1601: "rows wave: staged", 1602: "rows wave: Kfu formed", 1603: "rows wave: products done", 1604: "rows wave: stored",
          **{1700 + 16 * r + k: f"mid_stage1 {('gradient assembly', 'stage A', 'basis draws', 'normal draws', 'eps draws')[r]} wg {k}/8 start" for r in range(5) for k in range(8)},
          **{1800 + 16 * r + k: f"mid_stage1 {('gradient assembly', 'stage A', 'basis draws', 'normal draws', 'eps draws')[r]} wg {k}/8 end" for r in range(5) for k in range(8)},
+         **{1900 + 2 * i + x: f"paths_bwd_regs wg (x={x}, latent 0, problem {16 * i}) start" for i in range(8) for x in range(2)},
+         **{1930 + 2 * i + x: f"paths_bwd_regs wg (x={x}, latent 0, problem {16 * i}) end" for i in range(8) for x in range(2)},
+         **{1960 + 2 * i + x: f"paths_fwd_regs wg (x={x}, latent 0, problem {16 * i}) start" for i in range(8) for x in range(2)},
+         **{1990 + 2 * i + x: f"paths_fwd_regs wg (x={x}, latent 0, problem {16 * i}) end" for i in range(8) for x in range(2)},
          **{1320 + 4 * i + y: f"prior small16 wg ({64 * i}, {y}) start" for i in range(8) for y in range(4)},
          **{1360 + 4 * i + y: f"prior small16 wg ({64 * i}, {y}) end" for i in range(8) for y in range(4)}}
 

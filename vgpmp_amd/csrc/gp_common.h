@@ -58,15 +58,18 @@ __device__ __forceinline__ double dot8(const double* a, int sa, const double* b,
     return s;
 }
 
-__device__ __forceinline__ double block_sum(double v, double* red) {
+// (tid, nt: the thread's index in and the size of the GROUP that sums -- the workgroup, or a half of one whose two halves run the same
+//  role side by side and pass the same barriers: prior_split_cov_b_kernel)
+__device__ __forceinline__ double block_sum(double v, double* red, int tid, int nt) {
     v = vg_wave_sum(v);
     __syncthreads();
-    if ((threadIdx.x & (VG_WAVE - 1)) == 0) red[threadIdx.x / VG_WAVE] = v;
+    if ((tid & (VG_WAVE - 1)) == 0) red[tid / VG_WAVE] = v;
     __syncthreads();
     double t = 0.0;
-    for (int k = 0; k < (int)(blockDim.x / VG_WAVE); ++k) t += red[k];
+    for (int k = 0; k < nt / VG_WAVE; ++k) t += red[k];
     return t;
 }
+__device__ __forceinline__ double block_sum(double v, double* red) { return block_sum(v, red, (int)threadIdx.x, (int)blockDim.x); }
 
 // ---- float32 = f16 hi + f16 lo (the operands of the f16-split products: gp_prior_split.h, the stage-2 GEMM role of many samples)
 typedef float vg_f32x4 __attribute__((ext_vector_type(4)));

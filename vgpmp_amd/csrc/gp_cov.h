@@ -721,9 +721,7 @@ __device__ __forceinline__ void cov_b_chores(const CovArgs& a, int l, int p, int
 }
 
 template <bool TANGENTS, bool ROWS = true>      // ROWS: the launch has row-tile workgroups (false: the rows of A were stage A's, CovArgs.rows_wave)
-__device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int role, int l, int p) {
-    __shared__ double red[kCovThreads / VG_WAVE];
-    const int tid = threadIdx.x, nt = blockDim.x;
+__device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int role, int l, int p, int tid, int nt, double* red) {
     if (role >= kCovFixedRoles) {
         if (ROWS) {
             if (role == kCovFixedRoles) cov_b_chores(a, l, p, tid);
@@ -935,7 +933,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
                 VG_HO(gklQ + e, gq);
             }
         }
-        const double kl = block_sum(klacc, red);
+        const double kl = block_sum(klacc, red, tid, nt);
         if (tid == 0) a.ws.kl_l[pl] = 0.5 * (kl - (double)M);
         // d KL / d q_mu = (Lk^-T [0, 0, a])[2:]
         for (int k = (tid >> 3) + 2; k < Mz; k += nt >> 3) {
@@ -994,9 +992,15 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
         const double s = dot8(Li + i * ld, 1, v1, 1, i + 1, sub);
         if (sub == 0) acc += af[i] * s;
     }
-    acc = block_sum(acc, red);
+    acc = block_sum(acc, red, tid, nt);
     if (tid == 0) (role == 1 ? a.ws.gkl_ell : a.ws.gkl_var)[pl] = acc;
     VG_T(l == 0 && p == 0, 203 + 10 * role);
+}
+
+template <bool TANGENTS, bool ROWS = true>
+__device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int role, int l, int p) {      // (the whole workgroup on one role)
+    __shared__ double red[kCovThreads / VG_WAVE];
+    cov_b_body<TANGENTS, ROWS>(a, sm, role, l, p, (int)threadIdx.x, (int)blockDim.x, red);
 }
 
 template <bool TANGENTS, bool ROWS>

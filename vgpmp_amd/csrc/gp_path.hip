@@ -27,6 +27,9 @@ constexpr int kJChunkOne = 8;          // points per workgroup of the feature ro
 constexpr int kHMt2MinTiles = 300;     // f16-split prior kernel: 128-row tiles above this many of them (36 problems: 330.5 -> 325.5 us per step)
 constexpr int kRowsTpwWgs = 256;       // stage B rows role: two tiles per workgroup once the launch has this many workgroups (24 problems: 405.6 -> 392.7 us)
 constexpr int kRowsTpwMax = 2;         // ... and never more (config-5 share: 976 / 965 / 1041 us per step with 1 / 2 / 4)
+#ifndef VG_B_SPLIT
+#define VG_B_SPLIT 1
+#endif
 constexpr int kPbMinWgs = 1536;        // reverse path pass: chunks per workgroup double while this many workgroups remain (six per CU)
 
 #include "gp_common.h"
@@ -299,6 +302,34 @@ __global__ __launch_bounds__(kBlock, 4) void mid_cov_b_prior16_kernel(MidBArgs a
     prior_small16_body<MT, DM, DELL, true>(a.fp, b % a.prior_gx, b / a.prior_gx);
 }
 
+// Large batches (the f16-split prior kernel, 512-thread workgroups): stage B -- KL, the two tangents, q_sqrt: 256-thread chains that need
+// only stage A -- rides in the prior kernel's launch, BEHIND its tiles in the grid, two latents' instances of one role side by side
+// in a workgroup (each half passes the same barriers; its own LDS region, reduction scratch and thread indices).  The prior tiles
+// come in whole rounds of two per CU: at 896 latent pairs the second round leaves a quarter of the slots empty for the length of a
+// tile (115 us), and a launch of its own for stage B (42 us, plus the boundary) follows -- here the chains take those slots.
+struct PriorCovArgs {
+    FusedBatchArgs fb; CovArgs cov;
+    int nz_prior;            // grid.z of the prior tiles; behind them the stage-B pairs, role-major, the long roles first
+    int latents, pairs;      // pairs = ceil(latents / 2) per role
+    unsigned lds_half;       // bytes of LDS of one half's stage-B instance
+};
+template <bool DELL, int MT>
+__global__ __launch_bounds__(kHThreads, 4) void prior_split_cov_b_kernel(PriorCovArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hs_lds[];
+    if ((int)blockIdx.z < a.nz_prior) {
+        prior_fused_split_body<DELL, MT>(a.fb, hs_lds, blockIdx.x, blockIdx.y, blockIdx.z);
+        return;
+    }
+    __shared__ double red2[2][kCovThreads / VG_WAVE];
+    const int b = (((int)blockIdx.z - a.nz_prior) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+    if (b >= kCovFixedRoles * a.pairs) return;
+    const int ord = b / a.pairs, pr = b - ord * a.pairs;
+    const int role = ord == 0 ? 2 : ord == 1 ? 1 : ord == 2 ? 0 : ord;      // (the order of cov_b_kernel)
+    const int half = (int)threadIdx.x >> 8, lat = min(2 * pr + half, a.latents - 1);      // (an odd count: the last latent twice, the same values)
+    cov_b_body<true, false>(a.cov, reinterpret_cast<double*>(hs_lds + (size_t)half * a.lds_half), role, lat % a.cov.L, lat / a.cov.L,
+                            (int)threadIdx.x & (kCovThreads - 1), kCovThreads, red2[half]);
+}
+
 struct MidGArgs {            // hyper-parameter update | q_mu, q_sqrt update + ELBO pieces
     HyperArgs hy; FinalArgs fin;
     int n_hyper;             // = problems
@@ -524,33 +555,6 @@ static int set_dyn_lds(const void* fn, size_t bytes) { return vg_grant_dyn_lds(f
 // `num_steps` consecutive steps.  Few problems (and not under the per-stage profiler): the role-dispatched
 // stage launches above, with the variational-parameter update of step t riding in stage 1 of step t+1.
 // Many problems: every kernel fills the chip by itself, plain launches in sequence.
-// Fork / join events of an auxiliary stream (vgpmp_problem.aux_stream), created once per (calling stream, auxiliary stream) pair
-// and kept: an event pair per call would cost two host calls per step.  Keyed by BOTH streams: planners of one scene share its
-// auxiliary stream, and two host threads stepping them on different calling streams must not record into each other's fork
-// event between a record and its wait.  (Two threads on the SAME calling stream are the caller's race, as with any stream.)
-// Guarded like the dynamic-LDS table (several host threads may drive several GPUs).
-static int vg_aux_events(hipStream_t main_st, hipStream_t aux, hipEvent_t* fork, hipEvent_t* join) {
-    constexpr int kSlots = 64;
-    static hipStream_t mains[kSlots], streams[kSlots];
-    static hipEvent_t evs[kSlots][2];
-    static int next = 0;
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    for (int i = 0; i < kSlots; ++i)
-        if (streams[i] == aux && mains[i] == main_st && evs[i][0]) { *fork = evs[i][0]; *join = evs[i][1]; return 0; }
-    // a new pair: the next slot round robin (a process that has gone through more than kSlots pairs reuses the events of the
-    // oldest one -- events belong to no stream, and a caller that still uses that pair gets a fresh slot)
-    const int i = next;
-    next = (next + 1) % kSlots;
-    if (!evs[i][0]) {
-        VG_CHECK_HIP(hipEventCreateWithFlags(&evs[i][0], hipEventDisableTiming));
-        VG_CHECK_HIP(hipEventCreateWithFlags(&evs[i][1], hipEventDisableTiming));
-    }
-    streams[i] = aux; mains[i] = main_st;
-    *fork = evs[i][0]; *join = evs[i][1];
-    return 0;
-}
-
 int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* sdf, const vgpmp_problem* pb,
                   const vgpmp_params* params, const vgpmp_params* am, const vgpmp_params* av, const vgpmp_noise* nz,
                   const vgpmp_outputs* out, const vg_workspace* ws, int what, int trainable, double lr, int adam_t,
@@ -1008,25 +1012,16 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             } else {
                 VG_GGL(cov_a_kernel, dim3(L, P), dim3(kCovThreads), lds_cov_a, st, ca);
             }
-            // stage B of the covariance path beside the prior draws on the caller's auxiliary stream: independent of each other,
-            // both need only stage A | noise; joined before the path assembly.  (Merged into ONE launch the float64 roles queued
-            // behind the prior tiles at their register budget and lost 7 %: lesson 39; as a kernel of its own on a second queue
-            // they take the CUs the prior kernel's last, thin round of workgroups leaves idle.)
-            // Measured (r04, ms per step, two streams / one): 16 Franka problems 0.192 / 0.199, 64: 0.445 / 0.449, config-5 share
-            // (896 pairs of 14-joint latents) 0.920 / 0.907 -- there the prior kernel fills every round and the second queue only
-            // takes CUs from it: hence the upper bound.
-            const bool cov_aside = pb->aux_stream && batch_merge && fbatch && (size_t)P * L >= 64 && (size_t)P * L <= 512;
+            // Stage B and the prior draws are independent of each other (both need only stage A | noise): they share a launch wherever the
+            // schedule draws its own noise.  (Rounds 4-5 ran stage B on a second stream of the caller's beside the prior kernel for 64-512
+            // latent pairs -- 0.192 / 0.199 ms per step at 16 Franka problems then; since the rows of A left stage B the second queue
+            // measures no gain at 16 / 32 / 64 problems and +4 % at 896 latent pairs: vgpmp_problem.aux_stream is ignored.)
             const bool b_prior16 = batch_merge && fused_small && small16 && ca.rows_wave && backward;      // (stage B here has no rows role)
-            hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-            if (cov_aside) {
-                hipStream_t aux = (hipStream_t)pb->aux_stream;
-                if ((rc = vg_aux_events(st, aux, &ev_fork, &ev_join))) return rc;
-                VG_CHECK_HIP(hipEventRecord(ev_fork, st));
-                VG_CHECK_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
-                void* kargs[] = {&ca};
-                vg_sched_note_fn(fn_cov_b);
-                VG_CHECK_HIP(hipLaunchKernel(fn_cov_b, cov_b_grid, dim3(kBlock), kargs, lds_cov_b, aux));
-                VG_CHECK_HIP(hipEventRecord(ev_join, aux));
+            // ... and with many samples behind the tiles of the f16-split prior kernel (prior_split_cov_b_kernel)
+            const bool b_split = batch_merge && fbatch && !(what & VGPMP_PRIOR_F32) && ca.rows_wave && backward &&
+                                 2 * lds_cov_b <= 80 * 1024 && VG_B_SPLIT;
+            if (b_split) {
+                // (launched with the prior tiles, below)
             } else if (b_prior16) {
                 if ((rc = launch_cov_b_prior16(ca))) return rc;      // ... and the few-sample prior draws with it
             } else if ((rc = launch(fn_cov_b, cov_b_grid, &ca, lds_cov_b))) return rc;
@@ -1080,8 +1075,25 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
         if ((rc = set_dyn_lds(VG_FN(prior_fused_split_kernel<DELL_, MT_>), lds_h))) return rc;                      \
         VG_EXT_GGL((prior_fused_split_kernel<DELL_, MT_>), hgrid, dim3(kHThreads), lds_h, st, g0, g1, 0, fb);   \
     } while (0)
-                    if (want_dell) { if (hmt == 2) VG_FH(true, 2); else VG_FH(true, 1); }
+#define VG_FHC(DELL_, MT_)                                                                                                \
+    do {                                                                                                                  \
+        const void* fn_ = VG_FN(prior_split_cov_b_kernel<DELL_, MT_>);                                                    \
+        if ((rc = set_dyn_lds(fn_, lds_hc))) return rc;                                                                   \
+        void* kargs_[] = {&pc};                                                                                           \
+        vg_sched_note_fn(fn_);                                                                                            \
+        const unsigned per_z_ = hgrid.x * hgrid.y;                                                                        \
+        VG_CHECK_HIP(hipLaunchKernel(fn_, dim3(hgrid.x, hgrid.y, hgrid.z + (kCovFixedRoles * pc.pairs + per_z_ - 1) / per_z_), dim3(kHThreads), kargs_, lds_hc, st)); \
+    } while (0)
+                    if (b_split) {      // stage B rides behind the prior tiles (prior_split_cov_b_kernel)
+                        PriorCovArgs pc;
+                        pc.fb = fb; pc.cov = ca; pc.nz_prior = (int)hgrid.z; pc.latents = L * P; pc.pairs = (L * P + 1) / 2;
+                        pc.lds_half = (unsigned)((lds_cov_b + 15) & ~(size_t)15);
+                        const size_t lds_hc = lds_h > 2 * (size_t)pc.lds_half ? lds_h : 2 * (size_t)pc.lds_half;
+                        if (want_dell) { if (hmt == 2) VG_FHC(true, 2); else VG_FHC(true, 1); }
+                        else { if (hmt == 2) VG_FHC(false, 2); else VG_FHC(false, 1); }
+                    } else if (want_dell) { if (hmt == 2) VG_FH(true, 2); else VG_FH(true, 1); }
                     else { if (hmt == 2) VG_FH(false, 2); else VG_FH(false, 1); }
+#undef VG_FHC
 #undef VG_FH
                 } else {
 #define VG_FB(DELL_, DM_)                                                                                                 \
@@ -1110,7 +1122,6 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             else
                 VG_EXT_GGL(prior_gemm_kernel<0>, gemm_grid, dim3(kBlock), 0, st, g0, g1, 0, ga);
             mark();
-            if (cov_aside) VG_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
             if ((rc = launch(fn_pf, dim3(regs_fwd ? (NC + pa.cpw - 1) / pa.cpw : NC * pa.nsplit, L, P), &pa, lds_pf))) return rc;
             pa.tick = nullptr;
             mark();

@@ -533,6 +533,14 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
     extern __shared__ float smf[];
     __shared__ float red[3][kBlock / VG_WAVE];
     const int l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = kBlock;
+#ifdef VGPMP_BISECT
+    // (measurement build: start / end of the workgroups of latent 0 of every 16th problem -- ids 1900 / 1930 + 2 (p / 16) + x; tools/step_trace.py)
+    struct WgStamp {
+        int id;
+        __device__ WgStamp(int base, int l, int p, int x) : id(-1) { if (l == 0 && (p & 15) == 0 && p < 128 && x < 2) { id = base + 2 * (p >> 4) + x; VG_T(true, id); } }
+        __device__ ~WgStamp() { if (id >= 0) VG_T(true, id + 30); }
+    } wg_stamp_(1900, l, p, (int)blockIdx.x);
+#endif
     const int S = a.S, N = a.N, L = a.L, J = N + Mz;
     const float iMz = 1.0f / (float)Mz, iN = 1.0f / (float)N;
     const size_t pl = (size_t)p * L + l;
@@ -1041,6 +1049,14 @@ __global__ __launch_bounds__(kBlock, 4) void paths_fwd_regs(PathArgs a) {
     extern __shared__ float smf[];
     if (a.tick && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *a.tick += 1u;
     const int l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = kBlock;
+#ifdef VGPMP_BISECT
+    // (measurement build: start / end of the workgroups of latent 0 of every 16th problem -- ids 1960 / 1990 + 2 (p / 16) + x; tools/step_trace.py)
+    struct WgStamp {
+        int id;
+        __device__ WgStamp(int base, int l, int p, int x) : id(-1) { if (l == 0 && (p & 15) == 0 && p < 128 && x < 2) { id = base + 2 * (p >> 4) + x; VG_T(true, id); } }
+        __device__ ~WgStamp() { if (id >= 0) VG_T(true, id + 30); }
+    } wg_stamp_(1960, l, p, (int)blockIdx.x);
+#endif
     const int S = a.S, N = a.N, L = a.L, J = N + Mz;
     const float iMz = 1.0f / (float)Mz;
     const size_t pl = (size_t)p * L + l;

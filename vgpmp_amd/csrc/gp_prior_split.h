@@ -59,15 +59,15 @@ inline size_t vg_fused_split_lds(int MT) {
            (size_t)2 * kHK * kHRowBytes + (size_t)2 * kHK * sizeof(float) + (size_t)kWTableSize * sizeof(unsigned short);
 }
 
+// (bx, by, bz: column tile, row tile and latent pair of this workgroup -- the kernel below, or a role of prior_split_cov_b_kernel, gp_path.hip)
 template <bool DELL, int MT>      // d/d ell wanted; 64 MT sample rows per workgroup
-__global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBatchArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char hs_lds[];
+__device__ __forceinline__ void prior_fused_split_body(const FusedBatchArgs& a, unsigned char* hs_lds, int bx, int by, int bz) {
     const int S = a.S, L = a.L, J = a.J, N = a.N, D = a.D, B = a.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l = blockIdx.z % L, p = blockIdx.z / L;
+    const int l = bz % L, p = bz / L;
     constexpr int kRows = kTS * MT;
     constexpr int kARows = MT == 2 ? 0 : kRows;
-    const int s0 = blockIdx.y * kRows, j0 = blockIdx.x * kTJ;
+    const int s0 = by * kRows, j0 = bx * kTJ;
     const size_t pl = (size_t)p * L + l;
     unsigned char* Ah = hs_lds;                                   // [kRows][64 B]   W (float16 as drawn)   -- MT = 1 only
     unsigned char* Bt = Ah + kARows * kHRowBytes;                 // [4][144][64 B]  cos hi, cos lo, (sin x.w) hi, (sin x.w) lo
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
     int ob = 0;
 #ifdef VGPMP_BISECT
     // phase stamps of workgroup (0, 0, 0), K steps 8..15, every wave: id = 640 + 48 (k - 8) + 8 phase + wave (tools/prior_trace.py)
-#define VG_PT(phase) do { const int ki_ = (k0 >> 5) - 8; if (lane == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && ki_ >= 0 && ki_ < 8) \
+#define VG_PT(phase) do { const int ki_ = (k0 >> 5) - 8; if (lane == 0 && bx == 0 && by == 0 && bz == 0 && ki_ >= 0 && ki_ < 8) \
         vg_tr_buf[640 + 48 * ki_ + 8 * (phase) + wave] = wall_clock64(); } while (0)
 #else
 #define VG_PT(phase) do { } while (0)
@@ -273,6 +273,12 @@ __global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBa
             }
         }
     }
+}
+
+template <bool DELL, int MT>
+__global__ __launch_bounds__(kHThreads, 4) void prior_fused_split_kernel(FusedBatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hs_lds[];
+    prior_fused_split_body<DELL, MT>(a, hs_lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Few samples (S <= 32), more than 64 latents: prior_fused_small_kernel's job (gp_prior.h) with the products on the f16 matrix

@@ -97,13 +97,6 @@ class DeviceScene:
         self._sampler_lock = threading.RLock()
         self._sampler_views: Dict = {}
 
-    def aux_stream(self):
-        """The scene's second HIP stream (created on first use; one per scene and device)."""
-        st = getattr(self, "_aux_stream", None)
-        if st is None:
-            st = self._aux_stream = torch.cuda.Stream(device=self.device)
-        return st
-
     def _stream(self) -> int:
         """torch's current stream on THIS scene's device; launches need that device current (LDS attributes and
         kernel modules are per device), so a caller driving several GPUs from one process is switched over."""
@@ -334,7 +327,6 @@ class PlannerBatch:
         # device-resident step counter: lets a captured hipGraph of the step be replayed
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.fuse = True          # False: one launch per kernel even for small batches (measurement)
-        self.overlap_streams = True      # False: everything on the one stream (measurement; set before the first step, then _pack())
         self.extra_flags = 0      # e.g. capi.NO_SPLIT (measurement)
         # the f16-split prior kernel of large batches keeps x, omega and x . omega as f16 pairs: its range argument assumes time
         # stamps of order one (init_trainset: [0, 1]).  Stamps far outside that go to the float32-MFMA form instead.
@@ -415,8 +407,7 @@ class PlannerBatch:
             self._ind = capi.InducingParams(capi.ptr(self.raw_Z), capi.ptr(self.z_adam_m), capi.ptr(self.z_adam_v),
                                             capi.ptr(self.z_grad), capi.ptr(self.Zy_all), capi.ptr(self.z_scratch))
             ind = C.pointer(self._ind)
-        # large batches: stage B of the covariance path runs on the scene's second stream beside the prior draws (include/vgpmp.h)
-        aux = int(self.scene.aux_stream().cuda_stream) if self.overlap_streams else None
+        aux = None      # (vgpmp_problem.aux_stream: reserved)
         self._problem = capi.Problem(capi.ptr(self.X), capi.ptr(self.Zy), capi.ptr(self.y_u), self.alpha, JITTER,
                                      self.kl_scale, None, lik, ind, aux)
         self._problem_ctr = capi.Problem(capi.ptr(self.X), capi.ptr(self.Zy), capi.ptr(self.y_u), self.alpha, JITTER,
