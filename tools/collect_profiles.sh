@@ -84,10 +84,12 @@ timeout 900 python tools/sdf_frames.py > $out/sdf_frames_config5.txt 2>&1
 timeout 900 python tests/plan_report.py franka industrial --json $out/plan_report_franka_industrial.json > $out/plan_report_franka_industrial.txt 2>&1
 # ---- SQ / MFMA counters: the fused prior kernel and the batch likelihood at config 5, the prior GEMM role at config 2
 B5S="--workload stress --steps 20 --warmup 3 $Q --profile-steps 2"
-tools/pmc_sq.sh prior_fused_split $out/sq_prior_fused_config5 $B5S > /dev/null 2>&1
+# (the prior kernel ALONE: the two event-timed steps of --profile-steps run one launch per kernel; the timed steps run it with stage B behind its tiles)
+tools/pmc_sq.sh "::prior_fused_split_kernel" $out/sq_prior_fused_config5 $B5S > /dev/null 2>&1
+tools/pmc_sq.sh "::prior_split_cov_b_kernel" $out/sq_prior_cov_b_config5 $B5S > /dev/null 2>&1
 tools/pmc_sq.sh "loglik_paths_mask_kernel<" $out/sq_loglik_config5 $B5S > /dev/null 2>&1
 tools/pmc_sq.sh paths_bwd_regs $out/sq_paths_bwd_config5 $B5S > /dev/null 2>&1
-tools/pmc_sq.sh cov_b_kernel $out/sq_cov_b_config5 $B5S > /dev/null 2>&1
+tools/pmc_sq.sh "::cov_b_kernel<" $out/sq_cov_b_config5 $B5S > /dev/null 2>&1
 tools/pmc_sq.sh stage2_kernel $out/sq_stage2_config2 --steps 40 --warmup 5 $Q > /dev/null 2>&1
 # ---- the memory system's ceiling for 16-byte gathers
 if [ -x tools/gather_probe ]; then
