@@ -409,6 +409,7 @@ __device__ __forceinline__ void chol_inverse_panels(double* La, double* Li, doub
     VG_T(blockIdx.x == 0, 141);
     if (tid < Mz) rsd[tid] = rsqrt(rsd[tid]);
     __syncthreads();
+    VG_T(blockIdx.x == 0, 1100);
     for (int e = tid; e < 32 * 32; e += nt) {
         const int r = e >> 5, j = e & 31;
         const bool in = j <= r && r < Mz;
@@ -420,6 +421,7 @@ __device__ __forceinline__ void chol_inverse_panels(double* La, double* Li, doub
         }
         if (li_img) Li[r * ld + j] = in ? li : 0.0;      // (the wave's scratch tiles in this region are dead behind the barriers above)
     }
+    VG_T(blockIdx.x == 0, 1101);
 }
 
 // The rows of A = Kfu (Kuu + jI)^-1 and their tangents for ONE latent, on the workgroup that has just formed the inverse (stage A,
