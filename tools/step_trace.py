@@ -39,6 +39,7 @@ NAMES = {100: "cov_a start", 101: "cov_a Kuu built", 102: "cov_a factorised", 10
          1300: "prior small16 first wg start", 1301: "prior small16 points staged", 1302: "prior small16 K loop done", 1303: "prior small16 first wg end",
          **{1500 + 8 * o + i: f"cov_b order {o} ({('d/dvar', 'd/dell', 'KL', 'q_sqrt', 'rows 0', 'rows 1', 'rows 2', 'rows 3')[o]}) latent {64 * i} start" for o in range(8) for i in range(8)},
          **{1400 + 8 * o + i: f"cov_b order {o} ({('d/dvar', 'd/dell', 'KL', 'q_sqrt', 'rows 0', 'rows 1', 'rows 2', 'rows 3')[o]}) latent {64 * i} end" for o in range(8) for i in range(8)},
+         1110: "cov_b KL: a = Lk^-1 delta", 1111: "cov_b KL: Q terms", 1112: "cov_b KL: summed",
          1100: "cov_a diagonal scales ready", 1101: "cov_a factors written", 142: "cov_a inverse formed", 143: "rows tail: dKuu/dell requested", 144: "rows tail: Kfu of tile 0", 145: "rows tail: operands stand", 146: "rows tail: tile 0 products start",
          147: "rows tail: tile 0 products done", 148: "rows tail: tile 4 start", 149: "rows tail: tile 4 products done",
          1600: "rows wave: loads issued", 1601: "rows wave: staged", 1602: "rows wave: Kfu formed", 1603: "rows wave: products done", 1604: "rows wave: stored",

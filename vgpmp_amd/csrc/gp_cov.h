@@ -764,6 +764,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
     const double* Kg = a.ws.Ks64 + pl * Mz * Mz;
     constexpr int kQRegs = (VGPMP_MAX_MZ - 2) * (VGPMP_MAX_MZ - 2) / kCovThreads + 1;
     double qreg[kQRegs];
+    double qdiag = 1.0;               // (role 0) Q[tid][tid]
     double mine_qmu = 0.0;            // (role 3) q_mu of row tid
     static_assert(VGPMP_MAX_MZ <= kCovThreads, "one row of m per thread");
     {
@@ -809,6 +810,9 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
             // once Lk has been used
 #pragma unroll
             for (int k = 0; k < kQRegs; ++k) qreg[k] = Qg[min(tid + k * nt, M * M - 1)];
+            // (role 0: the diagonal once more, one entry per thread of the first wave -- its logarithm and reciprocal are then ONE pass of one
+            //  wave, not a branch every wave takes in every pass of the element-wise loop: 3.1-3.7 us of the role's 8-10)
+            if (role == 0) qdiag = Qg[(size_t)min(tid, M - 1) * (M + 1)];
         }
         if (!crole) {
             // k0 | k1: the first two columns of Kuu;  qm: q_mu at [2:]
@@ -917,6 +921,7 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
             if (i >= 2) klacc += s * s;
         }
     }
+    VG_T(l == 0 && p == 0 && role == 0, 1110);
     if (role == 0) {
         // ---- role 0: KL and its gradient wrt q_mu / q_sqrt (Q from this thread's registers: element-wise terms)
         double* gklQ = a.ws.gkl_Q + pl * M * M;
@@ -930,12 +935,17 @@ __device__ __forceinline__ void cov_b_body(const CovArgs& a, double* sm, int rol
                     const double q = qreg[k];
                     klacc += q * q;
                     gq = q;
-                    if (c == r) { klacc -= log(q * q); gq -= 1.0 / q; }
                 }
-                VG_HO(gklQ + e, gq);
+                if (c != r) VG_HO(gklQ + e, gq);      // (the diagonal: below)
             }
         }
+        if (tid < M) {
+            klacc -= log(qdiag * qdiag);
+            VG_HO(gklQ + (size_t)tid * (M + 1), qdiag - 1.0 / qdiag);
+        }
+        VG_T(l == 0 && p == 0, 1111);
         const double kl = block_sum(klacc, red, tid, nt);
+        VG_T(l == 0 && p == 0, 1112);
         if (tid == 0) a.ws.kl_l[pl] = 0.5 * (kl - (double)M);
         // d KL / d q_mu = (Lk^-T [0, 0, a])[2:]
         for (int k = (tid >> 3) + 2; k < Mz; k += nt >> 3) {
