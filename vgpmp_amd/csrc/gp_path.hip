@@ -30,7 +30,10 @@ constexpr int kRowsTpwMax = 2;         // ... and never more (config-5 share: 97
 #ifndef VG_B_SPLIT
 #define VG_B_SPLIT 1
 #endif
-constexpr int kPbMinWgs = 1536;        // reverse path pass: chunks per workgroup double while this many workgroups remain (six per CU)
+#ifndef VG_PB_MIN_WGS
+#define VG_PB_MIN_WGS 1536
+#endif
+constexpr int kPbMinWgs = VG_PB_MIN_WGS;        // reverse path pass: chunks per workgroup double while this many workgroups remain (six per CU)
 
 #include "gp_common.h"
 #include "gp_rng.h"
