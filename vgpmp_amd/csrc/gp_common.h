@@ -9,7 +9,10 @@ constexpr int kBlock = 256;
 // shared launches (the few-problem schedule) up to this many (problem, latent) pairs: measured on config 2's shape (S = 128): they win
 // up to 4 problems x 7 latents, one launch per kernel from 5 (5 problems 147 vs 143 us, 8: 198 vs 150); with few samples (config 3's
 // shape, S = 7) up to 64 pairs (5 problems 71 vs 86 us per step, 8: 80 vs 86; 16 problems 117 vs 101)
-constexpr int kFuseMaxPL = 32, kFuseMaxPLFewSamples = 64;
+#ifndef VG_FUSE_MAX_PL
+#define VG_FUSE_MAX_PL 32
+#endif
+constexpr int kFuseMaxPL = VG_FUSE_MAX_PL, kFuseMaxPLFewSamples = 64;
 constexpr int kGemmF16MinSamples = 512;      // few problems of this many samples: stage 2's GEMM role in its f16-split form
 __host__ __device__ inline int vg_fuse_max_pl(int S) { return S <= 32 ? kFuseMaxPLFewSamples : kFuseMaxPL; }
 __device__ __forceinline__ double matern52_dell(double t1, double t2, double ell, double var) {
