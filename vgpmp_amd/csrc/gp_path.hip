@@ -23,7 +23,10 @@ int vg_trace_take_gp(unsigned long long* host, int cap) { return vg_trace_take(h
 #define VG_STOP(args, k) do { } while (0)
 #endif
 // ---- schedule constants (each measured; the sweeps are in profiles/r03/final/problems_sweep.txt and DESIGN section 3)
-constexpr int kJChunkOne = 8;          // points per workgroup of the feature role at one problem
+#ifndef VG_JCHUNK_ONE
+#define VG_JCHUNK_ONE 8
+#endif
+constexpr int kJChunkOne = VG_JCHUNK_ONE;          // points per workgroup of the feature role at one problem
 constexpr int kHMt2MinTiles = 300;     // f16-split prior kernel: 128-row tiles above this many of them (36 problems: 330.5 -> 325.5 us per step)
 constexpr int kRowsTpwWgs = 256;       // stage B rows role: two tiles per workgroup once the launch has this many workgroups (24 problems: 405.6 -> 392.7 us)
 constexpr int kRowsTpwMax = 2;         // ... and never more (config-5 share: 976 / 965 / 1041 us per step with 1 / 2 / 4)
