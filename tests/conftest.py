@@ -25,7 +25,7 @@ def pytest_sessionstart(session):
     """The two ranks of tests/test_gpu_sharded.py are started HERE, before any test of this process makes a GPU call:
     fresh child interpreters, one per rank, rendezvous on 127.0.0.1 (gloo)."""
     session.config._shard_workers = None
-    if not _gpu_run(session.config):
+    if not _gpu_run(session.config) or os.environ.get("VGPMP_TEST_NO_SPAWN"):      # (the variable: a run of selected tests without the rank processes)
         return
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -61,6 +61,14 @@ def pytest_sessionstart(session):
         "    open(os.path.join(out, 'bench_gpus8_%s.rc' % key), 'w').write(str(p.returncode))\n"
         "open(os.path.join(out, 'done8'), 'w').close()\n")
     session.config._bench_gpus8 = (subprocess.Popen([sys.executable, "-c", code], env=env), out)
+    # The tests start only when the two-rank bench has finished (and the shard workers, which initialise beside it, idle): while other
+    # processes START on the same device -- queue creation makes the hardware scheduler preempt and resume every queue -- 2 of 40 runs of a
+    # 123-step bit-for-bit comparison differed, 0 of 295 without (tools/dbg_fresh.py, profiles/r05/ab_runs.txt; the one unexplained
+    # failure of round 5, test_synthetic14 in the first file of the session, was in that window too).  Bit-for-bit tests need the device alone.
+    try:
+        bench.wait(timeout=600)
+    except subprocess.TimeoutExpired:
+        pass
 
 
 def pytest_sessionfinish(session, exitstatus):

@@ -33,6 +33,9 @@ constexpr int kRowsTpwMax = 2;         // ... and never more (config-5 share: 97
 #ifndef VG_B_SPLIT
 #define VG_B_SPLIT 1
 #endif
+#ifndef VG_FUSE_FWD
+#define VG_FUSE_FWD 1
+#endif
 #ifndef VG_PB_MIN_WGS
 #define VG_PB_MIN_WGS 1536
 #endif
@@ -314,16 +317,16 @@ __global__ __launch_bounds__(kBlock, 4) void mid_cov_b_prior16_kernel(MidBArgs a
 // come in whole rounds of two per CU: at 896 latent pairs the second round leaves a quarter of the slots empty for the length of a
 // tile (115 us), and a launch of its own for stage B (42 us, plus the boundary) follows -- here the chains take those slots.
 struct PriorCovArgs {
-    FusedBatchArgs fb; CovArgs cov;
+    FusedBatchArgs fb; CovArgs cov; FusedFwdArgs fw;      // (fw: the path assembly as the tiles' epilogue, FWD)
     int nz_prior;            // grid.z of the prior tiles; behind them the stage-B pairs, role-major, the long roles first
     int latents, pairs;      // pairs = ceil(latents / 2) per role
     unsigned lds_half;       // bytes of LDS of one half's stage-B instance
 };
-template <bool DELL, int MT>
+template <bool DELL, int MT, bool FWD>
 __global__ __launch_bounds__(kHThreads, 4) void prior_split_cov_b_kernel(PriorCovArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char hs_lds[];
     if ((int)blockIdx.z < a.nz_prior) {
-        prior_fused_split_body<DELL, MT>(a.fb, hs_lds, blockIdx.x, blockIdx.y, blockIdx.z);
+        prior_fused_split_body<DELL, MT, FWD>(a.fb, hs_lds, blockIdx.x, blockIdx.y, blockIdx.z, &a.fw);
         return;
     }
     __shared__ double red2[2][kCovThreads / VG_WAVE];
@@ -1026,6 +1029,8 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             // ... and with many samples behind the tiles of the f16-split prior kernel (prior_split_cov_b_kernel)
             const bool b_split = batch_merge && fbatch && !(what & VGPMP_PRIOR_F32) && ca.rows_wave && backward &&
                                  2 * lds_cov_b <= 80 * 1024 && VG_B_SPLIT;
+            // ... and the path assembly as those tiles' epilogue (one column tile per latent: J <= 144; the register-resident assembly's shapes)
+            const bool fuse_fwd = b_split && regs_fwd && regs_bwd && eps_t && J <= kTJ && VG_FUSE_FWD;      // (regs_bwd: it carries the tick)
             if (b_split) {
                 // (launched with the prior tiles, below)
             } else if (b_prior16) {
@@ -1083,7 +1088,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     } while (0)
 #define VG_FHC(DELL_, MT_)                                                                                                \
     do {                                                                                                                  \
-        const void* fn_ = VG_FN(prior_split_cov_b_kernel<DELL_, MT_>);                                                    \
+        const void* fn_ = fuse_fwd ? VG_FN(prior_split_cov_b_kernel<DELL_, MT_, true>) : VG_FN(prior_split_cov_b_kernel<DELL_, MT_, false>); \
         if ((rc = set_dyn_lds(fn_, lds_hc))) return rc;                                                                   \
         void* kargs_[] = {&pc};                                                                                           \
         vg_sched_note_fn(fn_);                                                                                            \
@@ -1094,6 +1099,11 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
                         PriorCovArgs pc;
                         pc.fb = fb; pc.cov = ca; pc.nz_prior = (int)hgrid.z; pc.latents = L * P; pc.pairs = (L * P + 1) / 2;
                         pc.lds_half = (unsigned)((lds_cov_b + 15) & ~(size_t)15);
+                        if (fuse_fwd) {
+                            pc.fw.Lk64 = ws->Lk64; pc.fw.q_sqrt = params->q_sqrt; pc.fw.q_mu = params->q_mu; pc.fw.y_u = pb->y_u;
+                            pc.fw.jitter = pb->jitter; pc.fw.AT = ws->AT; pc.fw.epsT = ws->epsT; pc.fw.eps2T = ws->eps2T;
+                            pc.fw.sqrt_jitter = pa.sqrt_jitter; pc.fw.f = out->f; pc.fw.R = ws->R;
+                        }
                         const size_t lds_hc = lds_h > 2 * (size_t)pc.lds_half ? lds_h : 2 * (size_t)pc.lds_half;
                         if (want_dell) { if (hmt == 2) VG_FHC(true, 2); else VG_FHC(true, 1); }
                         else { if (hmt == 2) VG_FHC(false, 2); else VG_FHC(false, 1); }
@@ -1128,8 +1138,12 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             else
                 VG_EXT_GGL(prior_gemm_kernel<0>, gemm_grid, dim3(kBlock), 0, st, g0, g1, 0, ga);
             mark();
-            if ((rc = launch(fn_pf, dim3(regs_fwd ? (NC + pa.cpw - 1) / pa.cpw : NC * pa.nsplit, L, P), &pa, lds_pf))) return rc;
-            pa.tick = nullptr;
+            if (fuse_fwd) {
+                // (f and R came with the prior tiles; the counter's tick rides with the reverse pass: pa.tick stays set until then)
+            } else {
+                if ((rc = launch(fn_pf, dim3(regs_fwd ? (NC + pa.cpw - 1) / pa.cpw : NC * pa.nsplit, L, P), &pa, lds_pf))) return rc;
+                pa.tick = nullptr;
+            }
             mark();
             batch_merged = batch_merge;
         }
@@ -1160,6 +1174,7 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
             const unsigned n4 = (unsigned)s4.n_bwd + (unsigned)s4.n_basis + (draw_next ? w_gx * P : 0u);
             if ((rc = launch(fn_s4, dim3(n4), &s4, lds_pb))) return rc;
         } else if ((rc = launch(fn_pb, dim3(split_bwd ? 2 * NC : (NC + pa.cpw - 1) / pa.cpw, L, P), &pa, lds_pb))) return rc;
+        pa.tick = nullptr;
         if (ind) {     // inducing locations as variables: reverse through the covariance path and the prior draw at Zy
             vg_ind_launch il;
             il.d = d; il.ind = ind; il.ws = ws; il.nz = nz; il.params = params; il.X = pb->X; il.y_u = pb->y_u;

@@ -533,6 +533,8 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
     extern __shared__ float smf[];
     __shared__ float red[3][kBlock / VG_WAVE];
     const int l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = kBlock;
+    // (the step counter's tick when the path assembly was the prior kernel's epilogue: nothing in this launch reads the counter)
+    if (a.tick && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *a.tick += 1u;
 #ifdef VGPMP_BISECT
     // (measurement build: start / end of the workgroups of latent 0 of every 16th problem -- ids 1900 / 1930 + 2 (p / 16) + x; tools/step_trace.py)
     struct WgStamp {

@@ -59,9 +59,24 @@ inline size_t vg_fused_split_lds(int MT) {
            (size_t)2 * kHK * kHRowBytes + (size_t)2 * kHK * sizeof(float) + (size_t)kWTableSize * sizeof(unsigned short);
 }
 
+// The path assembly as this kernel's epilogue (FWD; large batches, Mz = 32): what a workgroup ends with in its accumulators -- F0 of
+// sixteen samples per wave at every point of the latent -- is what paths_fwd_regs (gp_paths.h) reads back from memory to form
+//     u = m + eps C^T,   r = u - f0(Z) - sqrt(jitter) eps',   f = f0(X) + r A^T.
+// The same float32 MFMAs on the same operands in the same order, F0's tile as the initial accumulator: f and r bit for bit what that
+// kernel writes.  C = Lk pad(Q) (+ jitter on its first two diagonal entries) and m are formed HERE from stage A's Lk and the variables
+// (stage B's q_sqrt role, which forms them for the reverse pass, runs behind this kernel's tiles in the same launch): the same routine
+// on the same operands, the same bits.
+struct FusedFwdArgs {
+    const double *Lk64, *q_sqrt, *q_mu, *y_u;      // [P,L,Mz,Mz], [P,L,M,M], [P,L,M], [P,2,L]
+    double jitter;
+    const float *AT, *epsT, *eps2T;               // [P,L,Mz,N], [P,L,S,Mz] x 2
+    float sqrt_jitter;
+    float *f, *R;                                  // [P,S,L,N], [P,S,L,Mz]
+};
 // (bx, by, bz: column tile, row tile and latent pair of this workgroup -- the kernel below, or a role of prior_split_cov_b_kernel, gp_path.hip)
-template <bool DELL, int MT>      // d/d ell wanted; 64 MT sample rows per workgroup
-__device__ __forceinline__ void prior_fused_split_body(const FusedBatchArgs& a, unsigned char* hs_lds, int bx, int by, int bz) {
+template <bool DELL, int MT, bool FWD = false>      // d/d ell wanted; 64 MT sample rows per workgroup; the path assembly as epilogue
+__device__ __forceinline__ void prior_fused_split_body(const FusedBatchArgs& a, unsigned char* hs_lds, int bx, int by, int bz,
+                                                       const FusedFwdArgs* fw = nullptr) {
     const int S = a.S, L = a.L, J = a.J, N = a.N, D = a.D, B = a.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l = bz % L, p = bz / L;
@@ -256,6 +271,42 @@ __device__ __forceinline__ void prior_fused_split_body(const FusedBatchArgs& a, 
 #undef VG_PT
     // ---- D layout: col = lane & 15, row = (lane >> 4) * 4 + reg; the constant factors left out of the tiles go in here
     const float scale_f = c, scale_h = c * inv_ell * inv_ell;
+    if constexpr (FWD) {
+        // (the K loop ended behind a barrier: its LDS is free)
+        constexpr int Mz = 32, ldc = 34;
+        const int M = Mz - 2;
+        double* LkS = reinterpret_cast<double*>(hs_lds);               // [32][ldc]  Lk
+        double* QpS = LkS + Mz * ldc;                                  // [32][ldc]  pad(Q): Q's lower triangle at [2:, 2:]
+        float* Cs = reinterpret_cast<float*>(QpS + Mz * ldc);          // [32][33]   C (float32, as stage B writes it)
+        float* ms = Cs + Mz * 33;                                      // [32]       m
+        float* ATs = ms + Mz;                                          // [32][N]    A^T
+        // (behind A^T, per wave: [16][32] F0 at the inducing points and [16][32] r of its sixteen samples)
+        const double* Lkg = fw->Lk64 + pl * Mz * Mz;
+        const double* Qg = fw->q_sqrt + pl * M * M;
+        for (int e = tid; e < Mz * Mz; e += kHThreads) {
+            const int i = e >> 5, jx = e & 31;
+            LkS[i * ldc + jx] = Lkg[e];
+            const int qi = i - 2, qj = jx - 2;
+            QpS[i * ldc + jx] = (qi >= 0 && qj >= 0 && qj <= qi) ? Qg[min(qi, M - 1) * M + min(qj, M - 1)] : 0.0;
+        }
+        if (tid < Mz) {
+            const double y0 = fw->y_u[((size_t)p * 2 + 0) * L + l], y1 = fw->y_u[((size_t)p * 2 + 1) * L + l];
+            const double qm = fw->q_mu[pl * M + min(max(tid - 2, 0), M - 1)];
+            ms[tid] = (float)(tid == 0 ? y0 : (tid == 1 ? y1 : qm));
+        }
+        {
+            const float* ATg = fw->AT + pl * N * Mz;
+            for (int e = tid; e < Mz * N; e += kHThreads) ATs[e] = ATg[e];
+        }
+        __syncthreads();
+        if (tid < kCovThreads) {      // four waves, a 16 x 16 tile of C each: stage B's product (cov_b_body role 3), the same bits
+            const double jit = fw->jitter;
+            matmul_f64(MatView{LkS, ldc, 1}, MatView{QpS, ldc, 1}, Mz, tid, kCovThreads, [&](int rr, int cc, double v) {
+                Cs[rr * 33 + cc] = (float)(v + (rr == cc && rr < 2 ? jit : 0.0));
+            });
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int mat = MT == 2 ? u : mat0;
@@ -269,7 +320,74 @@ __device__ __forceinline__ void prior_fused_split_body(const FusedBatchArgs& a, 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int s = s0 + 16 * rt + g * 4 + q;
-                if (s < S) vg_stream(dst + (((size_t)p * S + s) * L + l) * J + jc, acc[u][t][q] * sc);
+                const float v = acc[u][t][q] * sc;
+                if (s < S) vg_stream(dst + (((size_t)p * S + s) * L + l) * J + jc, v);
+                if (FWD && mat == 0) acc[u][t][q] = v;      // (the tile as paths_fwd_regs would read it back)
+            }
+        }
+    }
+    if constexpr (FWD) {
+        if (MT == 2 || mat0 == 0) {      // the waves that hold F0: sixteen samples each
+            constexpr int Mz = 32;
+            float* Cs = reinterpret_cast<float*>(reinterpret_cast<double*>(hs_lds) + 2 * Mz * 34);
+            float* ms = Cs + Mz * 33;
+            float* ATs = ms + Mz;
+            float* f0z = ATs + ((Mz * N + 3) & ~3) + wave * 2 * 16 * Mz;
+            float* rs = f0z + 16 * Mz;
+            const int i = r, kk = g;      // (the names of paths_fwd_regs)
+            const int srow0 = s0 + 16 * rt;
+            // F0 at the inducing points, rows 4 kk + q of this wave's sixteen samples: out of the column tiles that hold points N ..
+#pragma unroll
+            for (int t = 0; t < kTJ / 16; ++t) {
+                const int zc = 16 * t + i - N;
+                if (zc >= 0 && zc < Mz) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) f0z[(4 * kk + q) * Mz + zc] = acc[0][t][q];
+                }
+            }
+            // u = m + eps C^T, r = u - f0(Z) - sqrt(jitter) eps'
+            const float* er = fw->epsT + (pl * S + min(srow0 + i, S - 1)) * Mz;
+            float av[8];
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) av[k8] = er[4 * k8 + kk];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int mi = 16 * h + i;
+                float bC[8];
+#pragma unroll
+                for (int k8 = 0; k8 < 8; ++k8) bC[k8] = Cs[mi * 33 + 4 * k8 + kk];
+                const float m0 = ms[mi];
+                vg_f32x4_t au = {m0, m0, m0, m0};
+#pragma unroll
+                for (int k8 = 0; k8 < 8; ++k8) au = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k8], bC[k8], au, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int sl = 4 * kk + q, s = srow0 + sl;
+                    const float e2 = fw->eps2T[(pl * S + min(s, S - 1)) * Mz + mi];
+                    const float rr = vg_path_r(au[q], f0z[sl * Mz + mi], fw->sqrt_jitter, e2);
+                    rs[sl * Mz + mi] = rr;
+                    if (s < S) vg_stream(fw->R + (((size_t)p * S + s) * L + l) * Mz + mi, rr);
+                }
+            }
+            // f = f0(X) + r A^T
+            float rv[8];
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) rv[k8] = rs[i * Mz + 4 * k8 + kk];
+#pragma unroll
+            for (int t = 0; t < kTJ / 16; ++t) {
+                if (16 * t < N) {
+                    const int n = min(16 * t + i, N - 1);
+                    vg_f32x4_t af = {acc[0][t][0], acc[0][t][1], acc[0][t][2], acc[0][t][3]};
+#pragma unroll
+                    for (int k8 = 0; k8 < 8; ++k8) af = __builtin_amdgcn_mfma_f32_16x16x4f32(rv[k8], ATs[(4 * k8 + kk) * N + n], af, 0, 0, 0);
+                    if (16 * t + i < N) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int s = srow0 + 4 * kk + q;
+                            if (s < S) vg_stream(fw->f + (((size_t)p * S + s) * L + l) * N + n, af[q]);
+                        }
+                    }
+                }
             }
         }
     }
