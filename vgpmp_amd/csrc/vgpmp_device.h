@@ -378,3 +378,17 @@ int vg_launch_velocity_kuu_kuf(int kind, const double* Zy, const double* X, int 
                                const double* var, double jitter, double* Kuu, double* Kuf, hipStream_t st);
 int vg_launch_mesh_sdf(const double* tri, const int* part, int T, int nx, int ny, int nz, const double* origin,
                        double delta, double* grid, hipStream_t st);
+
+// ---- race hunt build (-DVGPMP_RACE; tools/build_variant.sh race WORK -DVGPMP_RACE): behind EVERY workgroup barrier each wave sleeps a
+// pseudo-random 0 .. ~4000 cycles, so the waves of a workgroup leave barriers in scrambled order and at scrambled distances -- what a
+// preemption by the hardware scheduler does to them once in a while.  Code that is correct only because its waves
+// happen to run in lock step between two barriers then differs from run to run (tools/dbg_rep.py with VGPMP_HIP_LIB set).
+#ifdef VGPMP_RACE
+static __device__ __forceinline__ void vg_real_syncthreads() { __syncthreads(); }
+static __device__ __forceinline__ void vg_jitter() {
+    const unsigned h = ((unsigned)wall_clock64() * 2654435761u) ^ ((unsigned)(threadIdx.x >> 6) * 40503u) ^ ((unsigned)blockIdx.x * 7919u);
+    const int n = (int)((h >> 9) & 63u);
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+}
+#define __syncthreads() do { vg_real_syncthreads(); vg_jitter(); } while (0)
+#endif
