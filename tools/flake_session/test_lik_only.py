@@ -1,0 +1,54 @@
+import os, sys, time
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def test_likelihood_alone_repeats():
+    """ONE kernel: the stand-alone likelihood (vgpmp_log_prob: FK + spheres + voxel gathers + hinge and its gradient) on FIXED joint
+    configurations, over and over for 12 s beside the starting rank processes; every result against the first.  FLAKE_LIK=torch runs a
+    plain torch gather from the same table instead (no library kernel at all)."""
+    from vgpmp_amd import engine, robots as rb, scenes
+    ps = rb.load_problemset("franka", "industrial"); spec = rb.load_robot("franka")
+    grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
+    sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
+    rng = np.random.default_rng(0)
+    n = 200000
+    g = torch.tensor(rng.uniform(spec.low, spec.high, size=(n, spec.dof)).astype(np.float32), device="cuda")
+    mode = os.environ.get("FLAKE_LIK", "lib")
+    table = torch.tensor(rng.standard_normal(1 << 22).astype(np.float32), device="cuda")
+    idx = torch.tensor(rng.integers(0, 1 << 22, size=4_000_000), device="cuda")
+    import ctypes as C
+    from vgpmp_amd import capi
+    logp_buf = torch.empty(n, dtype=torch.float32, device="cuda")
+    dl_buf = torch.empty((n, spec.dof), dtype=torch.float32, device="cuda")
+    SENT = 12345.0
+    def run():
+        if mode == "torch":
+            return (table[idx].clone(),)
+        # the library's call on buffers filled with a sentinel first: a row that keeps it was never written
+        logp_buf.fill_(SENT); dl_buf.fill_(SENT)
+        capi.check(sc.lib.vgpmp_log_prob(capi.ptr(sc.dev_robot), spec.dof, C.byref(sc.sdf), capi.ptr(g), n, capi.ptr(logp_buf), capi.ptr(dl_buf),
+                                         sc._stream()), "vgpmp_log_prob")
+        return (logp_buf.clone(), dl_buf.clone())
+    ref = [t.clone() for t in run()]
+    torch.cuda.synchronize()
+    t_end = time.time() + float(os.environ.get("FLAKE_SECONDS", "12"))
+    k = 0
+    while time.time() < t_end:
+        k += 1
+        out = run()
+        torch.cuda.synchronize()
+        for i, (x, y) in enumerate(zip(out, ref)):
+            if not torch.equal(x, y):
+                d = (x.double() - y.double()).abs()
+                bad = torch.nonzero(d.reshape(d.shape[0], -1).max(dim=1).values > 0).flatten()
+                print("\nLIKELIHOOD ALONE DIFFERS", mode, "repetition", k, "output", i, "entries", int((x != y).sum()), "max", float(d.max()),
+                      "rows", [int(v) for v in bad[:12]], "of", len(bad), "| entries still holding the sentinel:", int((x == 12345.0).sum()),
+                      "| wrong entries that are NOT the sentinel:", int(((x != y) & (x != 12345.0)).sum()), flush=True)
+                # the same call again, at once: transient?
+                again = run(); torch.cuda.synchronize()
+                print("   repeated at once: equal to the reference again:", all(torch.equal(a, b) for a, b in zip(again, ref)), flush=True)
+                assert False
+    print("\nlikelihood alone:", mode, k, "repetitions, all equal", flush=True)
