@@ -6,6 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 
 
 def pytest_sessionstart(session):
+    if os.environ.get("FLAKE_NO_SPAWN"):      # (the tests alone, e.g. beside a process that only RUNS kernels)
+        return
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = tempfile.mkdtemp(prefix="vgpmp_flake_")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")

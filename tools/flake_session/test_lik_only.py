@@ -47,6 +47,15 @@ def test_likelihood_alone_repeats():
                 print("\nLIKELIHOOD ALONE DIFFERS", mode, "repetition", k, "output", i, "entries", int((x != y).sum()), "max", float(d.max()),
                       "rows", [int(v) for v in bad[:12]], "of", len(bad), "| entries still holding the sentinel:", int((x == 12345.0).sum()),
                       "| wrong entries that are NOT the sentinel:", int(((x != y) & (x != 12345.0)).sum()), flush=True)
+                if x.dim() == 2:
+                    for r in [int(v) for v in bad[:3]]:
+                        print("   row", r, "got ", [round(float(v), 4) for v in x[r]], "\n           want", [round(float(v), 4) for v in y[r]], flush=True)
+                        near = (y - x[r]).abs().max(dim=1).values
+                        j = int(near.argmin())
+                        print("           nearest reference row:", j, "at max |diff|", float(near[j]), flush=True)
+                    # which joints are wrong, over all bad rows
+                    cols = (x[bad] != y[bad]).sum(dim=0)
+                    print("   wrong entries per joint over the bad rows:", [int(v) for v in cols], flush=True)
                 # the same call again, at once: transient?
                 again = run(); torch.cuda.synchronize()
                 print("   repeated at once: equal to the reference again:", all(torch.equal(a, b) for a, b in zip(again, ref)), flush=True)
