@@ -56,6 +56,13 @@ def test_likelihood_alone_repeats():
                     # which joints are wrong, over all bad rows
                     cols = (x[bad] != y[bad]).sum(dim=0)
                     print("   wrong entries per joint over the bad rows:", [int(v) for v in cols], flush=True)
+                # (measurement build only: lanes whose parked LDS sums did not come back as written -- trace slot 2040)
+                if hasattr(sc.lib, "vgpmp_debug_trace"):
+                    buf = np.zeros(2 * 8192, dtype=np.uint64)
+                    sc.lib.vgpmp_debug_trace.argtypes = [C.c_void_p, C.c_int32]; sc.lib.vgpmp_debug_trace.restype = C.c_int
+                    nn = sc.lib.vgpmp_debug_trace(buf.ctypes.data, 8192)
+                    tr = {int(buf[2 * q]): int(buf[2 * q + 1]) for q in range(max(nn, 0))}
+                    print("   LDS checksum mismatches counted by the kernel (since the run began):", tr.get(2040, 0), flush=True)
                 # the same call again, at once: transient?
                 again = run(); torch.cuda.synchronize()
                 print("   repeated at once: equal to the reference again:", all(torch.equal(a, b) for a, b in zip(again, ref)), flush=True)

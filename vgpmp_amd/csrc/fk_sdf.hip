@@ -230,10 +230,19 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
     vg_float3 F = vg_make3(0.f, 0.f, 0.f), Mo = vg_make3(0.f, 0.f, 0.f);
     vg_float3 Ft = vg_make3(0.f, 0.f, 0.f), Mt = vg_make3(0.f, 0.f, 0.f);
     float acc = 0.f;
+#ifdef VGPMP_BISECT
+    unsigned chk_w = 0u, chk_r = 0u;
+#endif
     auto flush = [&]() {                                 // sums of frame pcur are complete
         const int o = 2 * D + 6 * pcur;
         sc.at(o) = F.x; sc.at(o + 1) = F.y; sc.at(o + 2) = F.z;
         sc.at(o + 3) = Mo.x; sc.at(o + 4) = Mo.y; sc.at(o + 5) = Mo.z;
+#ifdef VGPMP_BISECT
+        // (measurement build, the flake hunt of DESIGN section 4: do the parked sums come back as they were written?  An exact checksum of
+        //  what goes in, compared below with what the second sweep reads; lanes whose checksums differ are counted in trace slot 2040)
+        if (pcur < D) chk_w += __float_as_uint(F.x) ^ (__float_as_uint(F.y) * 3u) ^ (__float_as_uint(F.z) * 5u) ^
+                               (__float_as_uint(Mo.x) * 7u) ^ (__float_as_uint(Mo.y) * 11u) ^ (__float_as_uint(Mo.z) * 13u);
+#endif
         Ft = vg_make3(Ft.x + F.x, Ft.y + F.y, Ft.z + F.z);
         Mt = vg_make3(Mt.x + Mo.x, Mt.y + Mo.y, Mt.z + Mo.z);
         F = vg_make3(0.f, 0.f, 0.f); Mo = vg_make3(0.f, 0.f, 0.f);
@@ -313,6 +322,10 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
 #pragma nounroll
         for (int i = 1; i <= D; ++i) {
             const int o = 2 * D + 6 * (i - 1);
+#ifdef VGPMP_BISECT
+            chk_r += __float_as_uint(sc.at(o)) ^ (__float_as_uint(sc.at(o + 1)) * 3u) ^ (__float_as_uint(sc.at(o + 2)) * 5u) ^
+                     (__float_as_uint(sc.at(o + 3)) * 7u) ^ (__float_as_uint(sc.at(o + 4)) * 11u) ^ (__float_as_uint(sc.at(o + 5)) * 13u);
+#endif
             Fs = vg_make3(Fs.x - sc.at(o), Fs.y - sc.at(o + 1), Fs.z - sc.at(o + 2));
             Ms = vg_make3(Ms.x - sc.at(o + 3), Ms.y - sc.at(o + 4), Ms.z - sc.at(o + 5));
             vg_float3 z = T.cz, org = T.t;
@@ -321,6 +334,9 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
             const vg_float3 oxF = vg_cross(org, Fs);
             emit(i - 1, vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)));
         }
+#ifdef VGPMP_BISECT
+        if (chk_r != chk_w) atomicAdd(&vg_tr_buf[2040], 1ull);
+#endif
     }
     return -0.5f * acc;
 }
