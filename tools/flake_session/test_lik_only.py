@@ -62,7 +62,8 @@ def test_likelihood_alone_repeats():
                     sc.lib.vgpmp_debug_trace.argtypes = [C.c_void_p, C.c_int32]; sc.lib.vgpmp_debug_trace.restype = C.c_int
                     nn = sc.lib.vgpmp_debug_trace(buf.ctypes.data, 8192)
                     tr = {int(buf[2 * q]): int(buf[2 * q + 1]) for q in range(max(nn, 0))}
-                    print("   LDS checksum mismatches counted by the kernel (since the run began):", tr.get(2040, 0), flush=True)
+                    print("   mismatching lanes counted by the kernel since the run began: parked sums", tr.get(2040, 0), "| sin / cos", tr.get(2041, 0),
+                          "| DH constants (sweep vs walk)", tr.get(2042, 0), "| launches counted", tr.get(2043, 0), flush=True)
                 # the same call again, at once: transient?
                 again = run(); torch.cuda.synchronize()
                 print("   repeated at once: equal to the reference again:", all(torch.equal(a, b) for a, b in zip(again, ref)), flush=True)

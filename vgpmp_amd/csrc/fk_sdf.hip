@@ -213,6 +213,9 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
     float raw[VGPMP_MAX_DOF];
 #pragma unroll
     for (int j = 0; j < VGPMP_MAX_DOF; ++j) raw[j] = load_raw(min(j, D - 1));
+#ifdef VGPMP_BISECT
+    unsigned chk_sw = 0u, chk_sr = 0u, chk_cw = 0u, chk_cr = 0u;      // sin / cos written, read back; DH constants of the walk, of the sweep
+#endif
     const float eps = rb->epsilon;
     const double offx = rb->scene_offset[0], offy = rb->scene_offset[1], offz = rb->scene_offset[2];
     const SdfFast fs = make_fast(sdf, offx, offy, offz);
@@ -222,6 +225,9 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
             float st, ct;
             vg_sincos(to_angle(j, raw[j]) + rb->joint_tab[j][4], &st, &ct);
             sc.at(j) = st; sc.at(D + j) = ct;
+#ifdef VGPMP_BISECT
+            chk_sw += __float_as_uint(st) * (2u * j + 1u) ^ __float_as_uint(ct) * (2u * j + 2u);
+#endif
         }
     }
     Frame T = base_frame(rb);
@@ -267,6 +273,10 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
             if (q < P) {                                 // uniform
                 const int fr = __builtin_bit_cast(int, ca[u].w);
                 while (cur < fr) {
+#ifdef VGPMP_BISECT
+                    { const float4 jt = *reinterpret_cast<const float4*>(rb->joint_tab[cur]);
+                      chk_cw += (__float_as_uint(jt.x) ^ __float_as_uint(jt.y) * 3u ^ __float_as_uint(jt.z) * 5u ^ __float_as_uint(jt.w) * 7u) * (2u * cur + 1u); }
+#endif
                     dh_apply(rb, cur, sc.at(cur), sc.at(D + cur), T);
                     ++cur;
                 }
@@ -329,13 +339,21 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
             Fs = vg_make3(Fs.x - sc.at(o), Fs.y - sc.at(o + 1), Fs.z - sc.at(o + 2));
             Ms = vg_make3(Ms.x - sc.at(o + 3), Ms.y - sc.at(o + 4), Ms.z - sc.at(o + 5));
             vg_float3 z = T.cz, org = T.t;
+#ifdef VGPMP_BISECT
+            { const float4 jt = *reinterpret_cast<const float4*>(rb->joint_tab[i - 1]);
+              if (i - 1 < cur) chk_cr += (__float_as_uint(jt.x) ^ __float_as_uint(jt.y) * 3u ^ __float_as_uint(jt.z) * 5u ^ __float_as_uint(jt.w) * 7u) * (2u * (i - 1) + 1u);
+              chk_sr += __float_as_uint(sc.at(i - 1)) * (2u * (i - 1) + 1u) ^ __float_as_uint(sc.at(D + i - 1)) * (2u * (i - 1) + 2u); }
+#endif
             dh_apply(rb, i - 1, sc.at(i - 1), sc.at(D + i - 1), T);
             if (craig) { z = T.cz; org = T.t; }
             const vg_float3 oxF = vg_cross(org, Fs);
             emit(i - 1, vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)));
         }
 #ifdef VGPMP_BISECT
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&vg_tr_buf[2043], 1ull);      // (the counters live: launches seen)
         if (chk_r != chk_w) atomicAdd(&vg_tr_buf[2040], 1ull);
+        if (chk_sr != chk_sw) atomicAdd(&vg_tr_buf[2041], 1ull);      // sin / cos read back differently
+        if (chk_cr != chk_cw) atomicAdd(&vg_tr_buf[2042], 1ull);      // the DH constants of the sweep differ from those of the walk
 #endif
     }
     return -0.5f * acc;
