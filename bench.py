@@ -216,10 +216,10 @@ def cpu_baseline(ps, spec, grid, args, budget_s: float = 10.0, pool=None):
     n, el, busy = timed(budget_s)
     out = {"value": n / el, "unit": "ELBO iters/sec", "cores": max(1, int(round(busy))), "kind": "port",
            "blas_threads": int(threads), "cores_busy_measured": round(busy, 2), "logical_cores": os.cpu_count(),
-           "sample": f"{n} full optimisation steps of the same workload (noise draw + forward + reverse + Adam) "
-                     f"by the float64 NumPy oracle in {el:.1f} s, one process, BLAS pool of {threads} threads of which {busy:.1f} cores "
-                     f"were busy on average (process CPU time / wall time: the restatement is element-wise NumPy, it does not "
-                     f"thread); host has {os.cpu_count()} logical cores"}
+           "sample": f"{n} full steps of the same workload (draw + forward + reverse + Adam), float64 NumPy oracle, {el:.1f} s, one process, "
+                     f"{busy:.1f} cores busy",
+           "sample_detail": f"BLAS pool of {threads} threads of which {busy:.1f} cores were busy on average (process CPU time / wall time: "
+                            f"the restatement is element-wise NumPy, it does not thread); host has {os.cpu_count()} logical cores"}
     if threadpool_limits is not None:
         with threadpool_limits(limits=1):
             n1, el1, _ = timed(budget_s)
@@ -644,22 +644,20 @@ def run_sample_sharded(args, world, rank, dist, backend):
     if rank == 0:
         how = ("nothing (one rank)" if world == 1 and comm is None else
                f"RCCL via the C ABI (vgpmp_allreduce_grads), {world} rank(s) in the communicator" if comm is not None else
-               f"torch.distributed ({backend}{' = RCCL' if backend == 'nccl' else ', host-staged: ranks share a device'}), "
-               f"{world} ranks in the group")
+               f"torch.distributed ({backend}{' = RCCL' if backend == 'nccl' else ', host-staged: ranks share a device'}), {world} ranks")
         line = {
             "metric": "ELBO iters/sec, BASELINE config 4: UR10-6DoF industrial S=1024 M=18 T=70, samples sharded over the GPUs",
             "value": args.steps / elapsed, "unit": "ELBO iters/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "timed_blocks": reps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": ("f32; prior products f16-split x3, f32 accumulate (512 samples or more on this rank); covariance path and Adam f64"
+            "dtype": ("f32; prior products f16-split x2, f32 accumulate (512 samples or more on this rank); covariance path and Adam f64"
                       if S_loc >= 512 and not (planner.extra_flags & capi.PRIOR_F32) else "f32 (f32 MFMA prior products; covariance path and Adam f64)"),
             "data": "synthetic",
-            "config": {"workload": f"BASELINE config 4: UR10 6-DoF, industrial scene, SDF {'x'.join(str(v) for v in scene.shape)}, "
-                                   f"ONE start-goal problem, S={args.samples} Monte-Carlo samples in total ({S_loc} on this rank), "
-                                   f"M={planner.M} T={N} B={planner.B}",
-                       "parallelism": f"samples sharded x{world}; per step one in-place all-reduce(sum) of "
-                                      f"{planner.reduce_buf.numel()} float64 (gradient + ELBO pieces) over {how}, "
+            "config": {"workload": f"BASELINE config 4: UR10 6-DoF, industrial, SDF {'x'.join(str(v) for v in scene.shape)}, ONE problem, "
+                                   f"S={args.samples} samples in total ({S_loc} on this rank), M={planner.M} T={N} B={planner.B}",
+                       "parallelism": f"samples sharded x{world}; one in-place all-reduce(sum) of {planner.reduce_buf.numel()} float64 per step, "
                                       "then the replicated Adam update",
+                       "collective": how,
                        "collective_ranks": world if (comm is not None or world > 1) else 0,
                        "launch": getattr(sp, "schedule", "one vgpmp_elbo_step (forward + reverse) + one vgpmp_adam_step per step")},
             # (the 16 MB table of this scene lives in L2 / Infinity Cache: requested bytes per second for scale, no HBM fraction)
@@ -814,25 +812,25 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
     # same selection as vg_elbo_steps (csrc/gp_path.hip)
     sk = planner.dims.split_k
     peak_gemm = F32_MFMA_PEAK_TFLOPS
-    if gemm_kernel.startswith(("prior_fused_split_kernel", "prior_fused_small16_kernel")):
-        # every float32 product = three f16 MFMAs (hi hi + hi lo + lo hi, float32 accumulators): the matrix-pipe ceiling for
-        # the ALGORITHMIC flops is a third of the f16 peak; what bounds the kernels is the vector work that generates the operands
-        peak_gemm = F16_MFMA_PEAK_TFLOPS / 3.0
-    if gemm_kernel.startswith("prior_fused_split_kernel"):
-        gemm_note = ("W and the features are formed inside the GEMM; f16-split products: peak = f16 dense MFMA peak / 3 MFMAs per "
-                     "float32 product; pipe occupancy of this kernel: profiles/r05/final/sq_prior_fused_config5.txt; the same flops "
-                     "against the f32-MFMA peak of 157.3 TF/s: %.2f" % (gemm_flops / t_gemm / 1e12 / F32_MFMA_PEAK_TFLOPS))
-    elif gemm_kernel.startswith("prior_fused_small16_kernel"):
-        gemm_note = ("few samples: features formed inside the GEMM from projection MFMAs, four K-slices, register-resident f16-split "
-                     "products (peak = f16 dense MFMA peak / 3 MFMAs per float32 product); 16-row tiles hold %d samples: the "
-                     "algorithmic flops are %.0f %% of what the tiles compute" % (S, 100.0 * S / (16 * ((S + 15) // 16))))
+    if gemm_kernel.startswith(("prior_fused_split_kernel", "prior_fused_small16_kernel", "prior_split_", "mid_cov_b_prior16")):
+        # the library's own W stream is float16 (vgpmp_device.h, "The W stream"): a float32 product = TWO f16 MFMAs (w b_hi + w b_lo,
+        # float32 accumulators; gp_prior_split.h:22-27, WX = true in the few-sample form), so the matrix-pipe ceiling for the
+        # ALGORITHMIC flops is half the f16 peak.  (Weights injected by a caller are arbitrary float32: three MFMAs -- not timed here.)
+        peak_gemm = F16_MFMA_PEAK_TFLOPS / 2.0
+    vs_f32 = gemm_flops / t_gemm / 1e12 / F32_MFMA_PEAK_TFLOPS
+    if gemm_kernel.startswith(("prior_fused_split_kernel", "prior_split_")):
+        gemm_note = "W + features formed inside the GEMM; f16-split x2: peak = f16 MFMA peak / 2 (NOT an f32-MFMA kernel; see profiles/README.md)"
+    elif gemm_kernel.startswith(("prior_fused_small16_kernel", "mid_cov_b_prior16")):
+        gemm_note = ("few samples, register-resident f16-split x2 products, peak = f16 MFMA peak / 2; 16-row tiles hold %d samples "
+                     "(%.0f %% of the tile flops are algorithmic)" % (S, 100.0 * S / (16 * ((S + 15) // 16))))
     elif gemm_kernel.startswith(("prior_fused_batch_kernel", "prior_fused_small_kernel")):
         gemm_note = "W / the features formed inside the GEMM, float32 MFMAs (VGPMP_PRIOR_F32)"
     else:
         gemm_note = "a role of stage2_kernel in the timed schedule; timed alone here"
     roof_gemm = {"kernel": gemm_kernel, "note": gemm_note, "bound": "mfma", "achieved": gemm_flops / t_gemm / 1e12,
                  "peak": peak_gemm, "unit": "TFLOP/s", "frac": gemm_flops / t_gemm / 1e12 / peak_gemm,
-                 "traffic": None, "algorithmic_flops_per_launch": gemm_flops, "avg_launch_ms": kernel_ms["prior_gemm_kernel"]}
+                 "traffic": None, "algorithmic_flops_per_launch": gemm_flops, "avg_launch_ms": kernel_ms["prior_gemm_kernel"],
+                 "ratio_to_f32_mfma_peak_157TF": vs_f32}
     dominant = max(stage_ms, key=stage_ms.get)
     # counter traffic of THIS round's collection, per workload (tools/run_collect.sh copies the tables to these names)
     own = {("config2", 1): "pmc_traffic.json", ("stress", 64): "pmc_traffic_config5.json", ("config3", 55): "pmc_traffic_config3.json",
@@ -850,35 +848,32 @@ def run_problem_sharded(args, world, rank, dist, backend, want_extras=True):
         except Exception:
             pass
 
-    names = {"config2": "BASELINE config 2: Franka 7-DoF, industrial scene",
-             "config3": "BASELINE config 3: Franka 7-DoF, bookshelves scene, the full C(11,2) start-goal batch",
-             "stress": "BASELINE config 5 per-GPU share: synthetic 14-DoF arm"}
+    names = {"config2": "BASELINE config 2: Franka 7-DoF, industrial",
+             "config3": "BASELINE config 3: Franka 7-DoF, bookshelves, all C(11,2)=55 pairs",
+             "stress": "BASELINE config 5: synthetic 14-DoF arm" + (" (per-GPU share of the 512-problem batch)" if npb * world <= 512 and npb < 512 else "")}
     line = {
         "metric": METRIC,
         "value": world * npb * args.steps / elapsed, "unit": "ELBO iters/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "timed_blocks": reps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("f32; prior products f16-split x3, f32 accumulate (v_mfma_f32_16x16x32_f16); covariance path and Adam f64"
+        "dtype": ("f32; prior products f16-split x2, f32 accumulate (v_mfma_f32_16x16x32_f16); covariance path and Adam f64"
                   # (batches beyond the few-problem schedule: the f16-split kernels -- large-batch or few-sample form)
                   if (not (planner.extra_flags & capi.PRIOR_F32) and not (planner.fuse and npb * D <= (64 if S <= 32 else 32))
                       and (sk == 1 or S <= 32))
                   else "f32 (f32 MFMA prior products; covariance path and Adam f64)"),
         "data": "synthetic",
         "config": {"workload": names[args.workload] + ", SDF " + "x".join(str(v) for v in scene.shape)
-                               + (" from the reference's collision mesh" if args.workload != "stress" and args.scene != "synthetic"
-                                  else " synthetic boxes/spheres")
-                               + f", {npb} start-goal problem(s) per GPU, S={S} M={M} T={N} B={B}, "
-                               "q_mu/q_sqrt/lengthscales/kernel_variance trainable"
-                               + (" + " + args.also_train if args.also_train else ""),
+                               + (" (from the scene's collision mesh)" if args.workload != "stress" and args.scene != "synthetic"
+                                  else " (synthetic boxes/spheres)")
+                               + f", {npb} problem(s)/GPU, S={S} M={M} T={N} B={B}"
+                               + (", also trained: " + args.also_train if args.also_train else ""),
                    "parallelism": f"problems sharded x{world}, no collective"
-                                  + ("; this line is ONE problem per GPU (weak scaling reads ~N x by construction): the figure that "
-                                     "carries the multi-GPU claim is batch_512 below (64 problems per GPU)" if world > 1 and npb == 1 else ""),
+                                  + ("; ONE problem per GPU here: the multi-GPU figure is summary.batch_512 (64 problems per GPU)"
+                                     if world > 1 and npb == 1 else ""),
                    "launch": (f"hipGraph x{args.unroll} steps" if args.unroll else "plain launches")
-                             + ("; independent kernels of a step share launches (stage1 / stage2 / likelihood + path assembly / stage4 for"
-                                " one or two problems, stage1/2/3_kernel + likelihood + reverse pass from three), the prior GEMM is a"
-                                " role of stage2_kernel there and is timed alone for roofline_secondary"
-                                if planner.fuse and npb * D <= (64 if S <= 32 else 32) else "")},
+                             + ("; few-problem schedule: the step's kernels share 4-5 launches (timed_schedule_kernels)"
+                                if planner.fuse and npb * D <= (64 if S <= 32 else 32) else "; batch schedule (timed_schedule_kernels)")},
         "plans_per_sec": (world * npb / (float(pp["num_steps"]) * elapsed / args.steps + t_sample)
                           if t_sample is not None else None),
         "plan_definition": (f"computed: {pp['num_steps']} optimisation steps at the timed rate + 150 posterior paths at "
@@ -920,15 +915,18 @@ def sub_record(argv, world, rank, dist, backend):
 
 
 def summary_of(line):
-    """<= 600 bytes: per (sub-)record ms per step, the SDF kernel's fraction of the HBM peak (null where its table is cache
+    """<= 800 bytes: per (sub-)record ms per step, the SDF kernel's fraction of the HBM peak (null where its table is cache
     resident), the prior kernel's fraction of its matrix peak."""
     r3 = lambda v: None if v is None else round(float(v), 4)
     out = {}
-    for name in ("batch_512", "config3", "batch_64"):
+    for name in ("batch_512", "batch_512_one_gpu", "config3", "batch_64"):
         rec = line.get(name)
         if rec:
             out[name] = {"ms_per_step": r3(rec["ms_per_step"]), "sdf_frac_hbm": r3(rec["roofline"]["frac"]),
-                         "prior_frac": r3(rec["roofline_secondary"]["frac"])}
+                         "prior_frac": r3(rec["roofline_secondary"]["frac"]), "problems_total": rec.get("problems_total")}
+    if out.get("batch_512") and out.get("batch_512_one_gpu"):
+        # (at N = 1 this is 8 -- 64 against 512 problems on the same device -- only when the step is perfectly linear in the batch)
+        out["batch_512_one_gpu"]["over_64_problem_share"] = r3(out["batch_512_one_gpu"]["ms_per_step"] / out["batch_512"]["ms_per_step"])
     out["line"] = {"ms_per_step": r3(line["ms_per_step"]), "value": round(float(line["value"]), 1), "n_gpus": line["n_gpus"],
                    "sdf_frac_hbm": r3(line["roofline"]["frac"])}
     if line.get("collective_breakdown"):
@@ -942,6 +940,111 @@ def summary_of(line):
     if cb.get("openmp"):
         out["cpu_openmp"] = {"value": r3(cb["openmp"].get("value")), "threads": cb["openmp"].get("threads")}
     return out
+
+
+LINE_LIMIT = 6000          # bytes of the ONE stdout line (the r05 line had grown to 20.7 KB and the driver's parser gave up on it)
+STR_LIMIT = 200            # ... and no string value in it longer than this
+DETAIL_FILE = os.path.join(ROOT, "bench_detail.json")
+
+
+def _num(v, nd=6):
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    try:
+        return float(f"{float(v):.{nd}g}")
+    except Exception:
+        return v
+
+
+def _pick(d, keys, nd=6):
+    return {k: _num(d[k], nd) for k in keys if d is not None and k in d}
+
+
+def _short(s, n=STR_LIMIT):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def compact_roofline(r):
+    """Numbers + kernel + bound; the prose (how the counters were collected and corrected) is profiles/README.md."""
+    if not r:
+        return r
+    out = _pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "algorithmic_bytes_per_launch",
+                    "requested_bytes_per_launch", "algorithmic_flops_per_launch", "traffic_collected_at", "ratio_to_f32_mfma_peak_157TF"))
+    out["bound"] = _short(out.get("bound", ""), 40).split(" (")[0]
+    out["kernel"] = _short(out.get("kernel", ""), 80)
+    if "table" in r:
+        out["table"] = _pick(r["table"], ("layout", "bytes", "cache_resident", "free_space_masks_in_lds"))
+    if "by_contract_not_hbm" in r:
+        out["by_contract_not_hbm"] = _pick(r["by_contract_not_hbm"], ("GBps", "ratio_to_hbm_peak"))
+    if "by_16B_per_query" in r:
+        out["by_16B_per_query"] = _pick(r["by_16B_per_query"], ("achieved", "frac"))
+    out["notes"] = "profiles/README.md"
+    return out
+
+
+def compact_cpu_baseline(cb):
+    if not cb:
+        return cb
+    out = _pick(cb, ("value", "unit", "cores", "kind", "logical_cores"))
+    out["sample"] = _short(cb.get("sample", ""), 160)
+    if cb.get("single_thread"):
+        out["single_thread"] = _pick(cb["single_thread"], ("value",))
+    om = cb.get("openmp")
+    if om:
+        out["openmp"] = _pick(om, ("value", "threads", "kind", "error"))
+        if om.get("single_thread"):
+            out["openmp"]["single_thread"] = _num(om["single_thread"].get("value"))
+        if om.get("problem_parallel"):
+            out["openmp"]["problem_parallel"] = _num(om["problem_parallel"].get("value"))
+    if cb.get("problem_parallel"):
+        out["problem_parallel"] = _pick(cb["problem_parallel"], ("value", "cores", "error"))
+    return out
+
+
+def compact_line(line):
+    """The ONE stdout line: <= LINE_LIMIT bytes, no string longer than STR_LIMIT.  Everything else (the sub-records' full rooflines,
+    plan-quality arrays, the oracle plan check, stage tables, the sentences) is bench_detail.json beside this script."""
+    out = {k: _num(line.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "timed_blocks",
+                                          "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out["dtype"] = _short(out["dtype"], 120)
+    out["config"] = {k: _short(v) for k, v in line["config"].items() if isinstance(v, str)}
+    out["config"].update({k: v for k, v in line["config"].items() if isinstance(v, (int, float))})
+    out["roofline"] = compact_roofline(line.get("roofline"))
+    if line.get("roofline_secondary"):
+        out["roofline_secondary"] = compact_roofline(line["roofline_secondary"])
+    if line.get("cpu_baseline"):
+        out["cpu_baseline"] = compact_cpu_baseline(line["cpu_baseline"])
+    for k in ("gpu_over_cpu", "gpu_over_cpu_openmp", "gpu_batch_over_cpu_openmp_problem_parallel", "gpu_batch_over_cpu_problem_parallel",
+              "plans_per_sec", "plans_per_sec_measured", "plans_per_sec_batched_measured"):
+        if line.get(k) is not None:
+            out[k] = _num(line[k], 5)
+    if line.get("timed_schedule_kernels"):
+        out["timed_schedule_kernels"] = [_short(k, 60) for k in line["timed_schedule_kernels"]][:8]
+    if line.get("stage_ms"):
+        out["stage_ms"] = {k: _num(v, 4) for k, v in line["stage_ms"].items()}
+    for k in ("projection_8_ranks", "collective_breakdown"):
+        if line.get(k):
+            out[k] = {a: b for a, b in line[k].items() if not isinstance(b, (str, dict))}
+    out["detail"] = "bench_detail.json"
+    out["summary"] = line["summary"]          # LAST key: a driver that keeps the tail of the line keeps this
+    return out
+
+
+def emit(line):
+    """Full record -> bench_detail.json (and gpurun_out/ when it exists); compact record -> the one stdout line."""
+    text = json.dumps(line)
+    for path in (DETAIL_FILE, os.path.join(ROOT, "gpurun_out", "bench_detail.json")):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path + ".tmp", "w") as f:
+                    f.write(text + "\n")
+                os.replace(path + ".tmp", path)
+        except OSError as e:                                     # (a read-only tree: the line itself still goes out)
+            print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
+    out = json.dumps(compact_line(line))
+    assert len(out) <= LINE_LIMIT, f"bench line grew to {len(out)} bytes (> {LINE_LIMIT}): trim compact_line()"
+    print(out, flush=True)
 
 
 def main():
@@ -998,6 +1101,13 @@ def main():
                 rec = sub_record(["--workload", "stress", "--steps", "200", "--profile-steps", "200"] + quick, world, rank, dist, backend)
                 if rank == 0:
                     line["batch_512"] = rec
+                if world == 1:
+                    # ... and the whole 512-problem batch on ONE device: the denominator of the north star's ">= 6x at 8 GPUs on a
+                    # 512-problem batch" (an N = 8 line's batch_512 is the same 512 problems, 64 per GPU: strong scaling = this / that)
+                    rec = sub_record(["--workload", "stress", "--problems", "512", "--steps", "200", "--profile-steps", "40",
+                                      "--no-cpu-baseline", "--no-solve", "--warmup", "3", "--min-seconds", "2.0"], world, rank, dist, backend)
+                    if rank == 0:
+                        line["batch_512_one_gpu"] = rec
             if args.also_config3 == "on" or (args.also_config3 == "auto" and auto and world == 1):
                 # BASELINE config 3, the reference's literal benchmark workload: 55 Franka / bookshelves pairs, S=7, 130 steps
                 rec = sub_record(["--workload", "config3", "--steps", "130", "--profile-steps", "130"] + quick, world, rank, dist, backend)
@@ -1027,8 +1137,8 @@ def main():
         if pool is not None:
             pool.close()
     if rank == 0:
-        line["summary"] = summary_of(line)          # LAST key: a driver that keeps the tail of the line keeps this
-        print(json.dumps(line), flush=True)
+        line["summary"] = summary_of(line)
+        emit(line)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

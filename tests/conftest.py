@@ -61,6 +61,8 @@ def pytest_sessionstart(session):
         "    open(os.path.join(out, 'bench_gpus8_%s.rc' % key), 'w').write(str(p.returncode))\n"
         "open(os.path.join(out, 'done8'), 'w').close()\n")
     session.config._bench_gpus8 = (subprocess.Popen([sys.executable, "-c", code], env=env), out)
+    # ... and the launcher of tests/test_gpu_attach.py's visitors (processes that arrive on and leave the device while that test runs)
+    session.config._attach = (subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "attach_worker.py"), "wait", out, "6", "2"], env=env), out)
     # The tests start only when the two-rank bench has finished (and the shard workers, which initialise beside it, idle): while other
     # processes START on the same device -- queue creation makes the hardware scheduler preempt and resume every queue -- 2 of 40 runs of a
     # 123-step bit-for-bit comparison differed, 0 of 295 without (tools/dbg_fresh.py, profiles/r05/ab_runs.txt; the one unexplained
@@ -77,7 +79,7 @@ def pytest_sessionfinish(session, exitstatus):
         for p in w[0]:
             if p.poll() is None:
                 p.kill()
-    for name in ("_bench_gpus2", "_bench_gpus8"):
+    for name in ("_bench_gpus2", "_bench_gpus8", "_attach"):
         b = getattr(session.config, name, None)
         if b and b[0].poll() is None:
             b[0].terminate()
@@ -104,6 +106,17 @@ def shard_workers(request):
         logs.append(o.decode(errors="replace"))
         assert p.returncode == 0, logs[-1][-3000:]
     return out, logs
+
+
+@pytest.fixture(scope="session")
+def attach_visitors(request):
+    """(directory for the trigger file, the waiting launcher) of tests/attach_worker.py."""
+    a = getattr(request.config, "_attach", None)
+    if not a:
+        pytest.skip("only started by `-m gpu` runs on a GPU box")
+    proc, out = a
+    assert proc.poll() is None, "the visitors' launcher is gone"
+    return out, proc
 
 
 @pytest.fixture(scope="session")

@@ -73,7 +73,9 @@ def synthetic_problem(dof=14, S=8, N=12, M=6, B=64, seed=0, n_grid=48, n_problem
 TOL_LOGP = 2e-6       # per (sample, time) pair, relative to the largest |logp|                   (measured: <= 1.7e-7)
 TOL_LIK = 2e-6        # alpha / S * sum logp, relative                                             (measured: <= 2.2e-7)
 TOL_GRAD = 3e-4       # every gradient component, relative to the largest component of its tensor  (measured: <= 5.8e-5)
-MAX_FLIPPED = 0.03    # share of (sample, time) pairs a float64 chain resolves to another voxel (coarse 0.05 m test grids)
+MAX_FLIPPED = 5e-3    # share of (sample, time) pairs a float64 chain resolves to another voxel (measured: <= 5e-4; r05 allowed 0.03).
+                      # The one assertion that notices a wrong FK chain INSIDE the ELBO launch: the logp comparison itself looks
+                      # its voxels up at the device's own centres.
 
 
 def device_centres(pl, k):

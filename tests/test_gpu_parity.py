@@ -522,6 +522,12 @@ def test_baseline_configs_at_full_size_against_oracle(config):
         "ur10_few_samples": ("ur10", "industrial", 7, 18, 70, 12, {}),
         "wam_twenty_samples": ("wam", "bookshelves", 20, 15, 100, 10, {}),
     }[config]
+    _injected_batch_against_oracle(config, robot, problem, S, M, N, P, extra)
+
+
+def _injected_batch_against_oracle(tag, robot, problem, S, M, N, P, extra, check=None):
+    """A batch of P problems of a reference problem set at B = 1024 on INJECTED noise (arbitrary float32 draws of the host) against the
+    oracle: every problem, or the problems `check` names.  Returns the kernels the library ran."""
     B = 1024
     ps = rb.load_problemset(robot, problem)
     spec = rb.load_robot(robot, *ps.robot_pos_and_orn)
@@ -539,26 +545,53 @@ def test_baseline_configs_at_full_size_against_oracle(config):
     split_k = pl.dims.split_k
     rng = np.random.default_rng(21)
     X, Zy = orc.init_trainset(N, L), orc.inducing_Zy(M, L)
-    params, noises = [], []
+    check = list(range(P)) if check is None else list(check)
+    params, noises = {}, {}
     for k in range(P):
         p = orc.init_params(osc.robot, qs[k], M, pp["lengthscales"], max(pp["variance"], 0.1 + 1e-6))
         p.q_sqrt = np.tril(p.q_sqrt + 0.05 * rng.standard_normal(p.q_sqrt.shape))
         p.q_mu = p.q_mu + 0.05 * rng.standard_normal(p.q_mu.shape)
-        params.append(p)
-        noises.append(_noise32(orc.draw_noise(rng, S, L, L, B, M + 2)))
+        nz = _noise32(orc.draw_noise(rng, S, L, L, B, M + 2))
         pl.q_mu[k].copy_(torch.tensor(p.q_mu.T)); pl.q_sqrt[k].copy_(torch.tensor(p.q_sqrt))
         pl.raw_ell[k].copy_(torch.tensor(p.raw_ell)); pl.raw_var[k].copy_(torch.tensor(p.raw_var))
-    st = lambda name: np.stack([getattr(nz, name) for nz in noises])
-    pl.set_noise(st("omega"), st("beta"), st("w"), st("eps"), st("eps2"))
+        # (one problem's draws at a time: 64 problems of config 2's shape are 0.5 GB of float64 on the host)
+        for dst, src in ((pl.omega, nz.omega), (pl.beta, nz.beta), (pl.w, nz.w), (pl.eps, nz.eps), (pl.eps2, nz.eps2)):
+            dst[k].copy_(torch.as_tensor(src, dtype=torch.float32).reshape(dst[k].shape))
+        if k in check:
+            params[k], noises[k] = p, nz
+    pl.noise_ahead_step = None
     pl.loss_and_grad(generate=False)
     torch.cuda.synchronize()
+    from vgpmp_amd import capi
+    ran = capi.last_schedule(pl.lib)
     lik_scale = S / float(extra.get("samples_total", S))
     active = False
-    for k in range(P):
+    for k in check:
         fw = _compare_with_oracle(pl, k, params[k], osc, X, Zy, qs[k], noises[k], float(pp["alpha"]), S, N, M, L, split_k,
-                                  lik_scale=lik_scale, kl_scale=float(extra.get("kl_scale", 1.0)), tag=config)
+                                  lik_scale=lik_scale, kl_scale=float(extra.get("kl_scale", 1.0)), tag=tag)
         active = active or bool((fw["logp"] < 0).any())
     assert active, "the scene must put spheres inside the hinge band for at least one problem"
+    return ran
+
+
+@pytest.mark.parametrize("shape", ["config3_x64", "config2_x64"])
+def test_callers_own_weights_at_batch_size_against_oracle(shape):
+    """the library's own W stream is a float16 table draw (two MFMAs per product); a binder that supplies its OWN weights
+    hands over arbitrary float32 normals (generate = False).  That path at batch size, 64 problems: config 3's shape (S = 7: the
+    few-sample prior kernel in its three-MFMA form, WX = false -- W split into two f16 halves) and config 2's shape (S = 128: the
+    stored-W schedule -- features kernel + float32-MFMA tiled GEMM), four of the 64 problems against the oracle with the fixed
+    tolerances of the one-step tests (models/vgpmp.py:281-282)."""
+    robot, problem, S, M, N = {"config3_x64": ("franka", "bookshelves", 7, 24, 70),
+                               "config2_x64": ("franka", "industrial", 128, 30, 100)}[shape]
+    ran = _injected_batch_against_oracle(shape, robot, problem, S, M, N, 64, {}, check=(0, 21, 42, 63))
+    print(f"PARITY {shape} kernels: {ran}")
+    prior = [k for k in ran if k.startswith(("prior_", "mid_cov_b_prior16"))]
+    assert prior, ran
+    if shape == "config3_x64":
+        # (template arguments <MT, DM, DELL, WX>: the caller's weights take the split form)
+        assert any(k.startswith("prior_fused_small16_kernel") and k.rstrip(">").endswith("false") for k in prior), prior
+    else:
+        assert any(k.startswith("prior_gemm") for k in prior) and not any("split" in k for k in prior), prior
 
 
 def test_adam_update_arithmetic_is_float64_exact():

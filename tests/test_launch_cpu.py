@@ -81,6 +81,52 @@ def test_bench_gloo_world2_rendezvous_of_the_timed_region(tmp_path):
     assert abs(r0["elapsed"] - r1["elapsed"]) < 1e-12 and r0["elapsed"] >= 0.03       # MAX over ranks: rank 1 sleeps 30 ms
 
 
+def _strings(o, path=""):
+    if isinstance(o, str):
+        yield path, o
+    elif isinstance(o, dict):
+        for k, v in o.items():
+            yield from _strings(v, f"{path}.{k}")
+    elif isinstance(o, (list, tuple)):
+        for i, v in enumerate(o):
+            yield from _strings(v, f"{path}[{i}]")
+
+
+def test_bench_line_is_compact_and_carries_the_contract_keys():
+    """the r05 line had grown to 20.7 KB and the driver could not parse it.  The ONE stdout line is the compact
+    form (<= 6000 bytes, no string longer than 200 characters, `summary` last); everything else goes to bench_detail.json.  Checked
+    on a committed full record of a real run (tests/golden/bench_detail_r05.json: the r05 line) and on a worst case with every
+    optional sub-record present."""
+    import copy
+    import bench
+    full = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_detail_r05.json")))
+    worst = copy.deepcopy(full)
+    worst["batch_512_one_gpu"] = copy.deepcopy(worst["batch_512"])
+    worst["projection_8_ranks"] = {"rank_local_us_per_step": 73.0, "samples_per_rank": 128, "one_rank_us_per_step": 129.6,
+                                   "predicted_speedup_at_8_ranks_before_the_collective": 1.77, "collective": "x" * 400,
+                                   "stage_ms_one_of_8": {"a": 1.0}}
+    worst["collective_breakdown"] = {"ranks": 8, "samples_per_rank": 128, "measured_us_per_step": 1.0, "rank_local_us_per_step": 1.0,
+                                     "collective_us_per_step": 0.0, "how": "y" * 400}
+    worst["config"] = {k: v + " " + "z" * 300 for k, v in worst["config"].items()}
+    for rec in (full, worst):
+        rec["summary"] = bench.summary_of(rec)
+        line = bench.compact_line(rec)
+        text = json.dumps(line)
+        assert len(text) <= bench.LINE_LIMIT == 6000, len(text)
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                    "dtype", "data", "config", "roofline", "cpu_baseline", "summary"):
+            assert key in line, key
+        assert line["config"]["workload"] and "model" not in line["config"]
+        assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
+        assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"])
+        assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["openmp"]["value"] > 0
+        assert list(line)[-1] == "summary"
+        too_long = [(p, len(v)) for p, v in _strings(line) if len(v) > bench.STR_LIMIT]
+        assert not too_long, too_long
+        assert json.loads(text)["value"] == line["value"]
+    assert "batch_512_one_gpu" in bench.compact_line(worst)["summary"]
+
+
 def test_committed_traffic_table_is_this_rounds():
     """profiles/pmc_traffic.json (read by bench.py for roofline.traffic) must be a table produced by
     tools/pmc_aggregate.py with its commit stamp, not the round-1 file (which listed rocBLAS / ATen kernels)."""

@@ -16,10 +16,10 @@ __device__ __forceinline__ vg_float3 lin2(float a, vg_float3 x, float b, vg_floa
 }
 
 // T_i = T_{i-1} * A_i for joint j = i-1 (0-based table index), given sin/cos of theta_j + twist_j
-__device__ __forceinline__ void dh_apply(const vgpmp_robot* __restrict__ rb, int j, float st, float ct, Frame& T) {
-    const float4 jt = *reinterpret_cast<const float4*>(rb->joint_tab[j]);
+// (jt = {cos alpha, sin alpha, d, a}: the first four entries of the joint's row of vgpmp_robot::joint_tab, wherever the caller keeps it)
+__device__ __forceinline__ void dh_apply_row(const float4 jt, bool craig, float st, float ct, Frame& T) {
     const float ca = jt.x, sa = jt.y, d = jt.z, a = jt.w;
-    if (rb->craig) {
+    if (craig) {
         // Rx(alpha) Tx(a) Rz(theta) Tz(d)      (utils/sampler.py:190-214)
         vg_float3 y1 = lin2(ca, T.cy, sa, T.cz);
         vg_float3 z1 = lin2(-sa, T.cy, ca, T.cz);
@@ -37,6 +37,10 @@ __device__ __forceinline__ void dh_apply(const vgpmp_robot* __restrict__ rb, int
         vg_float3 z2 = lin2(-sa, y1, ca, T.cz);
         T.cx = x1; T.cy = y2; T.cz = z2;
     }
+}
+
+__device__ __forceinline__ void dh_apply(const vgpmp_robot* __restrict__ rb, int j, float st, float ct, Frame& T) {
+    dh_apply_row(*reinterpret_cast<const float4*>(rb->joint_tab[j]), rb->craig != 0, st, ct, T);
 }
 
 __device__ __forceinline__ void dh_step(const vgpmp_robot* __restrict__ rb, int j, float theta, Frame& T) {

@@ -141,6 +141,9 @@ __device__ __forceinline__ Frame dh_link(const vgpmp_robot* __restrict__ rb, int
     return o;
 }
 
+#ifndef VG_SWEEP_VARIANT
+#define VG_SWEEP_VARIANT 0
+#endif
 __device__ __forceinline__ void lik_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -206,7 +209,7 @@ template <bool GRAD, int U, bool SIG = false, bool FAR = false, typename LoadRaw
 __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ rb, const vg_sdf_dev& sdf,
                                                const LikScratch sc, LoadRaw load_raw, ToAngle to_angle, Emit emit,
                                                const float* __restrict__ sig = nullptr, float sig_w = 0.f,
-                                               EmitSig emit_sig = NoSig()) {
+                                               EmitSig emit_sig = NoSig(), const float4* jt_rows = nullptr) {
     static_assert(VGPMP_MAX_SPHERES % U == 0, "a batch of sphere constants never leaves the table");
     const int D = rb->dof, P = rb->num_spheres;
     // every joint's input requested before the first is used (one memory round trip, not one per joint)
@@ -344,7 +347,50 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
               if (i - 1 < cur) chk_cr += (__float_as_uint(jt.x) ^ __float_as_uint(jt.y) * 3u ^ __float_as_uint(jt.z) * 5u ^ __float_as_uint(jt.w) * 7u) * (2u * (i - 1) + 1u);
               chk_sr += __float_as_uint(sc.at(i - 1)) * (2u * (i - 1) + 1u) ^ __float_as_uint(sc.at(D + i - 1)) * (2u * (i - 1) + 2u); }
 #endif
+#if VG_SWEEP_VARIANT == 1
+            dh_apply_row(jt_rows[i - 1], craig, sc.at(i - 1), sc.at(D + i - 1), T);      // rows staged in LDS by the kernel
+#elif VG_SWEEP_VARIANT == 2
+            {   // the row by its scalar load, copied to vector registers behind an explicit wait
+                const float4 js = *reinterpret_cast<const float4*>(rb->joint_tab[i - 1]);
+                float4 jv;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\tv_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                             : "=v"(jv.x), "=v"(jv.y), "=v"(jv.z), "=v"(jv.w) : "s"(js.x), "s"(js.y), "s"(js.z), "s"(js.w));
+                dh_apply_row(jv, craig, sc.at(i - 1), sc.at(D + i - 1), T);
+            }
+#elif VG_SWEEP_VARIANT == 3
+            {   // the row by its scalar load; ~64 idle cycles between the wait and the first use
+                float4 js = *reinterpret_cast<const float4*>(rb->joint_tab[i - 1]);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+                             : "+s"(js.x), "+s"(js.y), "+s"(js.z), "+s"(js.w));
+                dh_apply_row(js, craig, sc.at(i - 1), sc.at(D + i - 1), T);
+            }
+#elif VG_SWEEP_VARIANT == 4
+            {   // explicit full wait only (and the schedule pinned by the asm statement)
+                float4 js = *reinterpret_cast<const float4*>(rb->joint_tab[i - 1]);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(js.x), "+s"(js.y), "+s"(js.z), "+s"(js.w));
+                dh_apply_row(js, craig, sc.at(i - 1), sc.at(D + i - 1), T);
+            }
+#elif VG_SWEEP_VARIANT == 5
+            {   // rows from LDS + explicit full wait
+                float4 jl = jt_rows[i - 1];
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(jl.x), "+v"(jl.y), "+v"(jl.z), "+v"(jl.w));
+                dh_apply_row(jl, craig, sc.at(i - 1), sc.at(D + i - 1), T);
+            }
+#elif VG_SWEEP_VARIANT == 6
+            {   // a scheduling barrier only: no instruction added
+                const float4 js = *reinterpret_cast<const float4*>(rb->joint_tab[i - 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                dh_apply_row(js, craig, sc.at(i - 1), sc.at(D + i - 1), T);
+            }
+#elif VG_SWEEP_VARIANT == 7
+            {   // idle cycles only (behind the compiler's own wait)
+                float4 js = *reinterpret_cast<const float4*>(rb->joint_tab[i - 1]);
+                asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+s"(js.x), "+s"(js.y), "+s"(js.z), "+s"(js.w));
+                dh_apply_row(js, craig, sc.at(i - 1), sc.at(D + i - 1), T);
+            }
+#else
             dh_apply(rb, i - 1, sc.at(i - 1), sc.at(D + i - 1), T);
+#endif
             if (craig) { z = T.cz; org = T.t; }
             const vg_float3 oxF = vg_cross(org, Fs);
             emit(i - 1, vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)));
@@ -779,6 +825,14 @@ __global__ __launch_bounds__(kLikBlock) void log_prob_kernel(const vgpmp_robot* 
                                                               float* __restrict__ logp, float* __restrict__ dlogp) {
     extern __shared__ float lik_lds[];
     const int64_t i = (int64_t)blockIdx.x * kLikBlock + threadIdx.x;
+#if VG_SWEEP_VARIANT == 1 || VG_SWEEP_VARIANT == 5
+    __shared__ float4 jt_s[VGPMP_MAX_DOF];
+    if (threadIdx.x < VGPMP_MAX_DOF) jt_s[threadIdx.x] = *reinterpret_cast<const float4*>(rb->joint_tab[threadIdx.x]);
+    __syncthreads();
+    const float4* jt_rows = jt_s;
+#else
+    const float4* jt_rows = nullptr;
+#endif
     if (i >= n) return;
     const vg_sdf_dev sdf = load_sdf(sdfh);
     const int D = rb->dof;
@@ -786,7 +840,7 @@ __global__ __launch_bounds__(kLikBlock) void log_prob_kernel(const vgpmp_robot* 
     const float* g = gq + i * D;
     float* dg = dlogp + i * D;
     logp[i] = loglik_config<GRAD, 8>(rb, sdf, sc, [&](int j) { return g[j]; }, [&](int, float x) { return x; },
-                                     [&](int j, float v) { dg[j] = v; });
+                                     [&](int j, float v) { dg[j] = v; }, nullptr, 0.f, NoSig(), jt_rows);
 }
 
 // ---- ELBO path: f [P,S,L,N] -> logp [P,S,N], G = dloss/df [P,S,L,N], block partial sums ----------

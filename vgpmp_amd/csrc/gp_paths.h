@@ -597,7 +597,8 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
     VG_PBT(0, 9);
     auto stage_pair = [&](int ch0, int b) {
         const int s_base = ch0 * SC;
-        float *Gs2 = GsB[b], *f0s2 = f0B[b], *Rs2 = RsB[b], *Es2 = EsB[b];
+        float *Gs2 = GsB[b], *Rs2 = RsB[b], *Es2 = EsB[b];
+        [[maybe_unused]] float* f0s2 = f0B[b];      // (staged only without VG_PBR_DIRECT)
         {
             vg_stage_rows(Gs2, R2, N, tid, nt, [&](int r) -> const float* {
                 const int s = s_base + r;
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
     if (kPbrBufs > 1) stage_pair(blockIdx.x * a.cpw, 0);
     int cb = 0;
     for (int ch0 = blockIdx.x * a.cpw; ch0 < cp_end; ch0 += 2) {
-        const int pair_i = (ch0 - blockIdx.x * a.cpw) >> 1;
+        [[maybe_unused]] const int pair_i = (ch0 - blockIdx.x * a.cpw) >> 1;      // (measurement build's phase stamps)
         VG_PBT(pair_i, 0);
         if (kPbrBufs == 1) stage_pair(ch0, 0);
         VG_PBT(pair_i, 1);
@@ -690,8 +691,8 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
         for (int c = 0; c < 2 && ch0 + c < a.NC; ++c) {
             const int ch = ch0 + c;
             const float* Gs = Gs2 + c * SC * N;
-            const float* f0s = f0s2 + c * SC * J;
-            const float* hs = hs2 + c * SC * J;
+            [[maybe_unused]] const float* f0s = f0s2 + c * SC * J;
+            [[maybe_unused]] const float* hs = hs2 + c * SC * J;
             const float* Rs = Rs2 + c * SC * Mz;
             const float* Es = Es2 + c * SC * Mz;
             float* dRs = dRs2 + c * SC * Mz;
@@ -718,7 +719,7 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
             }
 #endif
             for (int e = tid; e < SC * Mz; e += nt) {
-                const int sl = vg_div(e, iMz), mi = e - sl * Mz;
+                [[maybe_unused]] const int sl = vg_div(e, iMz), mi = e - sl * Mz;
                 const int o = c * SC * Mz + e;
                 const float d = dGA[o], de = dGA[R2 * Mz + o], dv = dGA[2 * R2 * Mz + o];
                 dRs[e] = d;
