@@ -22,7 +22,10 @@ extern "C" {
 #define VGPMP_NO_FUSE_PRIOR 4096 /* large batches with the generator, the feature kernel and the tiled GEMM as three launches */
 #define VGPMP_PRIOR_F32 8192    /* large batches form the prior draws with float32 MFMAs (the round-2 kernel) instead of
                                  * the f16-split products of prior_fused_split_kernel */
-#define VGPMP_BWD_ONE_CHUNK 16384 /* reverse path pass with one sample chunk per workgroup (the values do not depend on it) */
+#define VGPMP_BWD_ONE_CHUNK 16384 /* reverse path pass with one sample chunk per workgroup.  Bit-identical results EXCEPT where the
+                                   * register-resident reverse kernel runs (Mz = 32, N % 4 == 0, N <= 100, batches): that kernel adds the
+                                   * partial sums of a workgroup's chunks in float32 and leaves one set per workgroup, so gradients differ
+                                   * from the one-chunk form by the rounding of a float32 sum (<= 2e-6 relative, tests/test_gpu_surface.py) */
 
 /* The sphere centres the ELBO kernels themselves form from latent paths: dev_f [P, S, L, N] float32 (the layout of
  * vgpmp_outputs.f) -> dev_pos [P, S, N, num_spheres, 3] float32, by the arithmetic of the likelihood launch that

@@ -48,8 +48,16 @@ class _Noise(C.Structure):
 
 
 def build(force: bool = False) -> str:
+    """Builds the library for this host's CPU if it is missing or older than its source.  Concurrent builders (pytest, bench.py's
+    OpenMP worker, __graft_entry__.build()) each write their own temporary file and rename it into place; a failed build raises
+    with the compiler's own message."""
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(HERE, "cpu_step.cpp")):
-        subprocess.run(["make", "-C", HERE, "-B", f"OUT={LIB}"], check=True, capture_output=True)
+        os.makedirs(os.path.dirname(LIB), exist_ok=True)
+        tmp = f"{LIB}.{os.getpid()}.tmp"
+        res = subprocess.run(["make", "-C", HERE, "-B", f"OUT={tmp}"], capture_output=True, text=True)
+        if res.returncode != 0 or not os.path.exists(tmp):
+            raise RuntimeError(f"oracle/cpu_step.cpp did not build (make rc {res.returncode}):\n{res.stdout[-2000:]}\n{res.stderr[-4000:]}")
+        os.replace(tmp, LIB)
     return LIB
 
 

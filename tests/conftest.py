@@ -62,11 +62,12 @@ def pytest_sessionstart(session):
         "open(os.path.join(out, 'done8'), 'w').close()\n")
     session.config._bench_gpus8 = (subprocess.Popen([sys.executable, "-c", code], env=env), out)
     # ... and the launcher of tests/test_gpu_attach.py's visitors (processes that arrive on and leave the device while that test runs)
-    session.config._attach = (subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "attach_worker.py"), "wait", out, "6", "2"], env=env), out)
-    # The tests start only when the two-rank bench has finished (and the shard workers, which initialise beside it, idle): while other
-    # processes START on the same device -- queue creation makes the hardware scheduler preempt and resume every queue -- 2 of 40 runs of a
-    # 123-step bit-for-bit comparison differed, 0 of 295 without (tools/dbg_fresh.py, profiles/r05/ab_runs.txt; the one unexplained
-    # failure of round 5, test_synthetic14 in the first file of the session, was in that window too).  Bit-for-bit tests need the device alone.
+    session.config._attach = (subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "attach_worker.py"), "wait", out], env=env), out)
+    # The tests start only when the two-rank bench has finished (and the shard workers, which initialise beside it, idle): the bit-for-bit
+    # tests need the device alone.  A likelihood launch in flight while another process ARRIVES on or LEAVES the device can return wrong
+    # values for a quarter wave (profiles/r06/flake.md; INTEGRATION.md, "Deployment constraints").  That is not hidden by this wait:
+    # tests/test_gpu_attach.py runs the kernels ON PURPOSE beside the same process mix (the stand-alone likelihood: fixed, a plain test;
+    # two planners stepped side by side: still parting ways, an expected failure).
     try:
         bench.wait(timeout=600)
     except subprocess.TimeoutExpired:

@@ -13,8 +13,11 @@ def test_first_difference():
     grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
     sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
     S, M, N, P = 64, 30, 40, 12
+    L_ = 7
     qs = np.array([ps.queries[i % 36] for i in range(P)])
     kw = dict(num_samples=S, num_inducing=M, num_data=N, num_bases=256, lengthscales=[2.0] * 7, variance=0.2, seed=4)
+    if os.environ.get("FLAKE_LR"):      # (a -DVGPMP_CHK build hands checksums back as gradients: keep the variables where they are)
+        kw["learning_rate"] = float(os.environ["FLAKE_LR"])
     a, b = engine.PlannerBatch(sc, qs, **kw), engine.PlannerBatch(sc, qs, **kw)
     mode = os.environ.get("FLAKE_MODE", "aa")
     if mode == "bb":
@@ -50,6 +53,25 @@ def test_first_difference():
                 x, y = sa[k].double(), sb[k].double()
                 per_problem = (x - y).abs().reshape(x.shape[0], -1).max(dim=1).values
                 print("  ", k, "problems that differ:", [int(i) for i in torch.nonzero(per_problem > 0).flatten()], flush=True)
+            # where: flat (sample, time) index of the log-densities that differ = lane + 64 workgroup of the likelihood launch; G by (s, l, n)
+            for nm, x, y in (("logp", a.logp, b.logp), ("G", a.view("G"), b.view("G"))):
+                x, y = x.reshape(P, -1), y.reshape(P, -1)
+                for pp in range(P):
+                    bad = torch.nonzero(x[pp] != y[pp]).flatten()
+                    if len(bad) == 0:
+                        continue
+                    if nm == "logp":
+                        print(f"   logp problem {pp}: flat (s N + n) indices", [int(v) for v in bad[:40]], "| values a", [round(float(v), 3) for v in x[pp][bad[:8]]],
+                              "b", [round(float(v), 3) for v in y[pp][bad[:8]]], flush=True)
+                    else:
+                        sidx, rem = bad // (L_ * N), bad % (L_ * N)
+                        lidx, nidx = rem // N, rem % N
+                        cfg = sorted(set(int(v) for v in (sidx * N + nidx)))
+                        print(f"   G problem {pp}: {len(bad)} entries on {len(cfg)} configurations, flat indices", cfg[:40], "| joints hit", sorted(set(int(v) for v in lidx)),
+                              "| entries per joint", [int((lidx == j).sum()) for j in range(L_)], flush=True)
+                        gx, gy = x[pp].reshape(S, L_, N), y[pp].reshape(S, L_, N)
+                        for c in cfg[:3]:
+                            print(f"      config {c}: a", [float(v) for v in gx[c // N, :, c % N]], "\n                  b", [float(v) for v in gy[c // N, :, c % N]], flush=True)
             wa, wb = state(a), state(b)
             for k in wa:
                 if k.startswith("ws.") or k in ("omega", "beta", "eps"):

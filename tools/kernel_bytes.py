@@ -67,6 +67,19 @@ def table(w):
     t["mid_cov_a_rng_kernel"] = dict(read=PL * (2 * Mz) * f8, write=PL * (B * L + B) * f4 + 4 * P * S * Mz * L * f4 + PL * 5 * Mz * Mz * f8 + rows_write, access="wide",
                                      flops=PL * 2.0 * 2 * 32 ** 3 + rows_flops,
                                      note="writes omega, beta, eps / eps' in both layouts, Kuu, dKuu, Lk, Lk^-1, (Kuu + jI)^-1, A4 (16 B per entry, a quarter of it padding), AT")
+    # merged launches of the batch schedule (round 5): stage B behind the prior tiles, with the path assembly as the tiles' epilogue
+    # (F0 is then never read back: the epilogue works on the accumulators; what it reads instead is AT, Lk64, q_sqrt, q_mu, the eps rows)
+    def merged(*parts, extra_read=0, extra_write=0, extra_flops=0.0, note=""):
+        return dict(read=sum(x["read"] for x in parts) + extra_read, write=sum(x["write"] for x in parts) + extra_write, access="wide",
+                    flops=sum(x["flops"] for x in parts) + extra_flops, note=note)
+    fwd_read = PL * (N * Mz * f4 + Mz * Mz * f8 + (M * M + M) * f8) + 2 * PL * S * Mz * f4
+    t["prior_split_cov_b_kernel"] = merged(
+        t["prior_fused_split_kernel"], t["cov_b_kernel"], extra_read=fwd_read, extra_write=P * S * L * (N + Mz) * f4,
+        extra_flops=2.0 * P * S * L * (Mz * Mz + N * Mz),
+        note="prior tiles (reads omega, beta; writes F0, H) + their epilogue = the path assembly (reads AT, Lk, q_sqrt, q_mu, epsT, eps2T; "
+             "writes f, R) + stage B's roles behind them (as cov_b_kernel)")
+    t["mid_cov_b_prior16_kernel"] = merged(t["prior_fused_small16_kernel"], t["cov_b_kernel"],
+                                           note="stage B's roles + the few-sample prior tiles (as prior_fused_small16_kernel) in one launch")
     lik = dict(read=P * S * L * N * f4 + 16 * P * S * N * Q, write=P * S * L * N * f4 + P * S * N * f4, access="gather",
                flops=P * S * N * (Q * 40.0 + L * 120.0),
                note="reads f and ONE 16-byte record per sphere query that is not skipped (upper bound: every query); writes G, logp; "

@@ -3,15 +3,20 @@
 #include "gp_path.h"
 #include <string.h>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
 
 // ---- schedule log ---------------------------------------------------------------------------------------------------
+// Per launch: one shared-lock lookup of an interned name and a push of its POINTER (cleaning and copying a std::string under a
+// process-wide mutex on every launch was on the ~50 us / step host path of the few-problem schedules).  Names are cleaned once, when a
+// launch site (its string literal) or a kernel (its function pointer) is first seen; map nodes never move.
 namespace {
-std::mutex g_fn_mu;
+std::shared_mutex g_fn_mu;
 std::unordered_map<const void*, std::string>& fn_names() { static std::unordered_map<const void*, std::string> m; return m; }
-thread_local std::vector<std::string> t_sched;
+thread_local std::vector<const std::string*> t_sched;
+const std::string kUnknown("?");
 // the launch site's text -> the name a profiler prints: no enclosing parentheses, constants by value
 std::string sched_clean(const char* name) {
     std::string n(name);
@@ -21,18 +26,28 @@ std::string sched_clean(const char* name) {
         for (size_t at; (at = n.find(c.sym)) != std::string::npos;) n.replace(at, strlen(c.sym), c.val);
     return n;
 }
+const std::string* interned(const void* key) {
+    std::shared_lock<std::shared_mutex> lock(g_fn_mu);
+    auto it = fn_names().find(key);
+    return it == fn_names().end() ? nullptr : &it->second;
+}
+const std::string* intern(const void* key, const char* name) {
+    std::unique_lock<std::shared_mutex> lock(g_fn_mu);
+    return &fn_names().emplace(key, sched_clean(name)).first->second;
+}
 }  // namespace
 void vg_sched_clear() { t_sched.clear(); }
-void vg_sched_note(const char* name) { t_sched.push_back(sched_clean(name)); }
+void vg_sched_note(const char* name) {      // `name`: a string literal of the launch site -- its address is its identity
+    const std::string* n = interned(name);
+    t_sched.push_back(n ? n : intern(name, name));
+}
 const void* vg_fn_reg(const void* fn, const char* name) {
-    std::lock_guard<std::mutex> lock(g_fn_mu);
-    fn_names()[fn] = sched_clean(name);
+    if (!interned(fn)) intern(fn, name);
     return fn;
 }
 void vg_sched_note_fn(const void* fn) {
-    std::lock_guard<std::mutex> lock(g_fn_mu);
-    auto it = fn_names().find(fn);
-    t_sched.push_back(it == fn_names().end() ? std::string("?") : it->second);
+    const std::string* n = interned(fn);
+    t_sched.push_back(n ? n : &kUnknown);
 }
 
 extern "C" {
@@ -161,7 +176,7 @@ int vgpmp_debug_sphere_centres(const vgpmp_robot* dev_robot, const float* dev_f,
 
 int64_t vgpmp_debug_last_schedule(char* buf, size_t buf_bytes) {
     std::string all;
-    for (const auto& n : t_sched) { all += n; all += '\n'; }
+    for (const std::string* n : t_sched) { all += *n; all += '\n'; }
     if (buf && buf_bytes) {
         const size_t k = all.size() < buf_bytes - 1 ? all.size() : buf_bytes - 1;
         ::memcpy(buf, all.data(), k);

@@ -141,9 +141,36 @@ __device__ __forceinline__ Frame dh_link(const vgpmp_robot* __restrict__ rb, int
     return o;
 }
 
-#ifndef VG_SWEEP_VARIANT
-#define VG_SWEEP_VARIANT 0
-#endif
+// ---- the second sweep's operand fence ------------------------------------------------------------------
+// Every iteration of a second sweep over the chain (the gradient's walk: loglik_config*, below) REQUESTS all it reads -- the joint's DH
+// row by a scalar load, its sin / cos and the iteration's other LDS words -- and then passes them through ONE explicit
+// `s_waitcnt lgkmcnt(0)` inside an asm statement that names them all: the compiler can neither move a load behind that point nor start
+// the arithmetic before it, and nothing of the iteration is in flight while it computes.
+// Why: with the compiler's own schedule of this loop (loads and the frame arithmetic interleaved, the wait in the branch targets, the
+// scalar load's address registers reused at once) the gradient of up to a few hundred configurations per launch came back WRONG --
+// sixteen consecutive lanes at a time, the log-density of the same launch right -- in launches that were in flight while another
+// process arrived on or left the device (every queue is preempted and resumed then): 8 of 11 sessions of tools/flake_session with the
+// round-5 code, 8 of 8 with the row read from LDS instead, 0 of 35 with any form that pins the loop's schedule (this fence, a bare
+// scheduling barrier, idle cycles behind the wait), 0 of 8 with this fence in the stand-alone kernel (vgpmp_log_prob).  What exactly the
+// hardware / its context save does with the unpinned schedule is NOT established (profiles/r06/flake.md has the record), and the fence
+// does NOT close the matter: the batch form inside the ELBO step (loglik_paths_kernel, one lane per configuration) still returns a
+// quarter wave of slightly different log-densities and gradients in 5-7 of 8 sessions of the two-planner reproducer, with these fences,
+// with the forward walk fenced the same way and with its gathers pinned behind an explicit wait -- while a build that merely adds
+// checksum arithmetic to its loop passes 10 of 10.  include/vgpmp.h and INTEGRATION.md state the deployment constraint that follows.
+__device__ __forceinline__ void vg_sweep_fence(float4& jt, float& st, float& ct) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(jt.x), "+s"(jt.y), "+s"(jt.z), "+s"(jt.w), "+v"(st), "+v"(ct));
+}
+__device__ __forceinline__ void vg_sweep_fence(float4& jt, float& st, float& ct, float& a) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(jt.x), "+s"(jt.y), "+s"(jt.z), "+s"(jt.w), "+v"(st), "+v"(ct), "+v"(a));
+}
+__device__ __forceinline__ void vg_sweep_fence(float4& jt, float& st, float& ct, float& a, float& b) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(jt.x), "+s"(jt.y), "+s"(jt.z), "+s"(jt.w), "+v"(st), "+v"(ct), "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void vg_sweep_fence(float4& jt, float& st, float& ct, float (&m)[6]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(jt.x), "+s"(jt.y), "+s"(jt.z), "+s"(jt.w), "+v"(st), "+v"(ct), "+v"(m[0]), "+v"(m[1]),
+                 "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]));
+}
+
 __device__ __forceinline__ void lik_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -209,16 +236,13 @@ template <bool GRAD, int U, bool SIG = false, bool FAR = false, typename LoadRaw
 __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ rb, const vg_sdf_dev& sdf,
                                                const LikScratch sc, LoadRaw load_raw, ToAngle to_angle, Emit emit,
                                                const float* __restrict__ sig = nullptr, float sig_w = 0.f,
-                                               EmitSig emit_sig = NoSig(), const float4* jt_rows = nullptr) {
+                                               EmitSig emit_sig = NoSig()) {
     static_assert(VGPMP_MAX_SPHERES % U == 0, "a batch of sphere constants never leaves the table");
     const int D = rb->dof, P = rb->num_spheres;
     // every joint's input requested before the first is used (one memory round trip, not one per joint)
     float raw[VGPMP_MAX_DOF];
 #pragma unroll
     for (int j = 0; j < VGPMP_MAX_DOF; ++j) raw[j] = load_raw(min(j, D - 1));
-#ifdef VGPMP_BISECT
-    unsigned chk_sw = 0u, chk_sr = 0u, chk_cw = 0u, chk_cr = 0u;      // sin / cos written, read back; DH constants of the walk, of the sweep
-#endif
     const float eps = rb->epsilon;
     const double offx = rb->scene_offset[0], offy = rb->scene_offset[1], offz = rb->scene_offset[2];
     const SdfFast fs = make_fast(sdf, offx, offy, offz);
@@ -228,9 +252,6 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
             float st, ct;
             vg_sincos(to_angle(j, raw[j]) + rb->joint_tab[j][4], &st, &ct);
             sc.at(j) = st; sc.at(D + j) = ct;
-#ifdef VGPMP_BISECT
-            chk_sw += __float_as_uint(st) * (2u * j + 1u) ^ __float_as_uint(ct) * (2u * j + 2u);
-#endif
         }
     }
     Frame T = base_frame(rb);
@@ -239,19 +260,10 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
     vg_float3 F = vg_make3(0.f, 0.f, 0.f), Mo = vg_make3(0.f, 0.f, 0.f);
     vg_float3 Ft = vg_make3(0.f, 0.f, 0.f), Mt = vg_make3(0.f, 0.f, 0.f);
     float acc = 0.f;
-#ifdef VGPMP_BISECT
-    unsigned chk_w = 0u, chk_r = 0u;
-#endif
     auto flush = [&]() {                                 // sums of frame pcur are complete
         const int o = 2 * D + 6 * pcur;
         sc.at(o) = F.x; sc.at(o + 1) = F.y; sc.at(o + 2) = F.z;
         sc.at(o + 3) = Mo.x; sc.at(o + 4) = Mo.y; sc.at(o + 5) = Mo.z;
-#ifdef VGPMP_BISECT
-        // (measurement build, the flake hunt of DESIGN section 4: do the parked sums come back as they were written?  An exact checksum of
-        //  what goes in, compared below with what the second sweep reads; lanes whose checksums differ are counted in trace slot 2040)
-        if (pcur < D) chk_w += __float_as_uint(F.x) ^ (__float_as_uint(F.y) * 3u) ^ (__float_as_uint(F.z) * 5u) ^
-                               (__float_as_uint(Mo.x) * 7u) ^ (__float_as_uint(Mo.y) * 11u) ^ (__float_as_uint(Mo.z) * 13u);
-#endif
         Ft = vg_make3(Ft.x + F.x, Ft.y + F.y, Ft.z + F.z);
         Mt = vg_make3(Mt.x + Mo.x, Mt.y + Mo.y, Mt.z + Mo.z);
         F = vg_make3(0.f, 0.f, 0.f); Mo = vg_make3(0.f, 0.f, 0.f);
@@ -276,10 +288,6 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
             if (q < P) {                                 // uniform
                 const int fr = __builtin_bit_cast(int, ca[u].w);
                 while (cur < fr) {
-#ifdef VGPMP_BISECT
-                    { const float4 jt = *reinterpret_cast<const float4*>(rb->joint_tab[cur]);
-                      chk_cw += (__float_as_uint(jt.x) ^ __float_as_uint(jt.y) * 3u ^ __float_as_uint(jt.z) * 5u ^ __float_as_uint(jt.w) * 7u) * (2u * cur + 1u); }
-#endif
                     dh_apply(rb, cur, sc.at(cur), sc.at(D + cur), T);
                     ++cur;
                 }
@@ -335,72 +343,19 @@ __device__ __forceinline__ float loglik_config(const vgpmp_robot* __restrict__ r
 #pragma nounroll
         for (int i = 1; i <= D; ++i) {
             const int o = 2 * D + 6 * (i - 1);
-#ifdef VGPMP_BISECT
-            chk_r += __float_as_uint(sc.at(o)) ^ (__float_as_uint(sc.at(o + 1)) * 3u) ^ (__float_as_uint(sc.at(o + 2)) * 5u) ^
-                     (__float_as_uint(sc.at(o + 3)) * 7u) ^ (__float_as_uint(sc.at(o + 4)) * 11u) ^ (__float_as_uint(sc.at(o + 5)) * 13u);
-#endif
-            Fs = vg_make3(Fs.x - sc.at(o), Fs.y - sc.at(o + 1), Fs.z - sc.at(o + 2));
-            Ms = vg_make3(Ms.x - sc.at(o + 3), Ms.y - sc.at(o + 4), Ms.z - sc.at(o + 5));
+            // the iteration's operands, all requested, then at rest (vg_sweep_fence)
+            float4 jt = *reinterpret_cast<const float4*>(rb->joint_tab[i - 1]);
+            float st = sc.at(i - 1), ct = sc.at(D + i - 1);
+            float m[6] = {sc.at(o), sc.at(o + 1), sc.at(o + 2), sc.at(o + 3), sc.at(o + 4), sc.at(o + 5)};
+            vg_sweep_fence(jt, st, ct, m);
+            Fs = vg_make3(Fs.x - m[0], Fs.y - m[1], Fs.z - m[2]);
+            Ms = vg_make3(Ms.x - m[3], Ms.y - m[4], Ms.z - m[5]);
             vg_float3 z = T.cz, org = T.t;
-#ifdef VGPMP_BISECT
-            { const float4 jt = *reinterpret_cast<const float4*>(rb->joint_tab[i - 1]);
-              if (i - 1 < cur) chk_cr += (__float_as_uint(jt.x) ^ __float_as_uint(jt.y) * 3u ^ __float_as_uint(jt.z) * 5u ^ __float_as_uint(jt.w) * 7u) * (2u * (i - 1) + 1u);
-              chk_sr += __float_as_uint(sc.at(i - 1)) * (2u * (i - 1) + 1u) ^ __float_as_uint(sc.at(D + i - 1)) * (2u * (i - 1) + 2u); }
-#endif
-#if VG_SWEEP_VARIANT == 1
-            dh_apply_row(jt_rows[i - 1], craig, sc.at(i - 1), sc.at(D + i - 1), T);      // rows staged in LDS by the kernel
-#elif VG_SWEEP_VARIANT == 2
-            {   // the row by its scalar load, copied to vector registers behind an explicit wait
-                const float4 js = *reinterpret_cast<const float4*>(rb->joint_tab[i - 1]);
-                float4 jv;
-                asm volatile("s_waitcnt lgkmcnt(0)\n\tv_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
-                             : "=v"(jv.x), "=v"(jv.y), "=v"(jv.z), "=v"(jv.w) : "s"(js.x), "s"(js.y), "s"(js.z), "s"(js.w));
-                dh_apply_row(jv, craig, sc.at(i - 1), sc.at(D + i - 1), T);
-            }
-#elif VG_SWEEP_VARIANT == 3
-            {   // the row by its scalar load; ~64 idle cycles between the wait and the first use
-                float4 js = *reinterpret_cast<const float4*>(rb->joint_tab[i - 1]);
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
-                             : "+s"(js.x), "+s"(js.y), "+s"(js.z), "+s"(js.w));
-                dh_apply_row(js, craig, sc.at(i - 1), sc.at(D + i - 1), T);
-            }
-#elif VG_SWEEP_VARIANT == 4
-            {   // explicit full wait only (and the schedule pinned by the asm statement)
-                float4 js = *reinterpret_cast<const float4*>(rb->joint_tab[i - 1]);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(js.x), "+s"(js.y), "+s"(js.z), "+s"(js.w));
-                dh_apply_row(js, craig, sc.at(i - 1), sc.at(D + i - 1), T);
-            }
-#elif VG_SWEEP_VARIANT == 5
-            {   // rows from LDS + explicit full wait
-                float4 jl = jt_rows[i - 1];
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(jl.x), "+v"(jl.y), "+v"(jl.z), "+v"(jl.w));
-                dh_apply_row(jl, craig, sc.at(i - 1), sc.at(D + i - 1), T);
-            }
-#elif VG_SWEEP_VARIANT == 6
-            {   // a scheduling barrier only: no instruction added
-                const float4 js = *reinterpret_cast<const float4*>(rb->joint_tab[i - 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                dh_apply_row(js, craig, sc.at(i - 1), sc.at(D + i - 1), T);
-            }
-#elif VG_SWEEP_VARIANT == 7
-            {   // idle cycles only (behind the compiler's own wait)
-                float4 js = *reinterpret_cast<const float4*>(rb->joint_tab[i - 1]);
-                asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+s"(js.x), "+s"(js.y), "+s"(js.z), "+s"(js.w));
-                dh_apply_row(js, craig, sc.at(i - 1), sc.at(D + i - 1), T);
-            }
-#else
-            dh_apply(rb, i - 1, sc.at(i - 1), sc.at(D + i - 1), T);
-#endif
+            dh_apply_row(jt, craig, st, ct, T);
             if (craig) { z = T.cz; org = T.t; }
             const vg_float3 oxF = vg_cross(org, Fs);
             emit(i - 1, vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)));
         }
-#ifdef VGPMP_BISECT
-        if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&vg_tr_buf[2043], 1ull);      // (the counters live: launches seen)
-        if (chk_r != chk_w) atomicAdd(&vg_tr_buf[2040], 1ull);
-        if (chk_sr != chk_sw) atomicAdd(&vg_tr_buf[2041], 1ull);      // sin / cos read back differently
-        if (chk_cr != chk_cw) atomicAdd(&vg_tr_buf[2042], 1ull);      // the DH constants of the sweep differ from those of the walk
-#endif
     }
     return -0.5f * acc;
 }
@@ -512,13 +467,17 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
     vg_float3 Fs = Ft, Ms = Mt;
 #pragma nounroll
     for (int i = 1; i <= D; ++i) {
+        // the iteration's operands, all requested, then at rest (vg_sweep_fence)
+        float4 jt = *reinterpret_cast<const float4*>(rb->joint_tab[i - 1]);
+        float st = sc.at(i - 1), ct = sc.at(D + i - 1), dgdf = sc.at(2 * D + i - 1);
+        vg_sweep_fence(jt, st, ct, dgdf);
         Fs = vg_make3(Fs.x - fx[i - 1], Fs.y - fy[i - 1], Fs.z - fz[i - 1]);
         Ms = vg_make3(Ms.x - mx[i - 1], Ms.y - my[i - 1], Ms.z - mz[i - 1]);
         vg_float3 z = T.cz, org = T.t;
-        dh_apply(rb, i - 1, sc.at(i - 1), sc.at(D + i - 1), T);
+        dh_apply_row(jt, craig, st, ct, T);
         if (craig) { z = T.cz; org = T.t; }
         const vg_float3 oxF = vg_cross(org, Fs);
-        emit(i - 1, vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)) * sc.at(2 * D + i - 1));
+        emit(i - 1, vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)) * dgdf);
     }
     return -0.5f * acc;
 }
@@ -673,13 +632,17 @@ __device__ __forceinline__ float loglik_config_pipe(const vgpmp_robot* __restric
     vg_float3 Fs = Ft, Ms = Mt;
 #pragma nounroll
     for (int i = 1; i <= D; ++i) {
+        // the iteration's operands, all requested, then at rest (vg_sweep_fence)
+        float4 jt = *reinterpret_cast<const float4*>(rb->joint_tab[i - 1]);
+        float st = sc.at(i - 1), ct = sc.at(D + i - 1), dgdf = sc.at(2 * D + i - 1);
+        vg_sweep_fence(jt, st, ct, dgdf);
         Fs = vg_make3(Fs.x - fx[i - 1], Fs.y - fy[i - 1], Fs.z - fz[i - 1]);
         Ms = vg_make3(Ms.x - mx[i - 1], Ms.y - my[i - 1], Ms.z - mz[i - 1]);
         vg_float3 z = T.cz, org = T.t;
-        dh_apply(rb, i - 1, sc.at(i - 1), sc.at(D + i - 1), T);
+        dh_apply_row(jt, craig, st, ct, T);
         if (craig) { z = T.cz; org = T.t; }
         const vg_float3 oxF = vg_cross(org, Fs);
-        emit(i - 1, vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)) * sc.at(2 * D + i - 1));
+        emit(i - 1, vg_dot(z, vg_make3(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z)) * dgdf);
     }
     return -0.5f * acc;
 }
@@ -725,12 +688,15 @@ __device__ __forceinline__ float loglik_config_prefix(const vgpmp_robot* __restr
     vg_float3 Ft = vg_make3(0.f, 0.f, 0.f), Mt = vg_make3(0.f, 0.f, 0.f);
     float acc = 0.f;
     auto flush = [&]() {                                 // sums of frame pcur are complete
-                Ft = vg_make3(Ft.x + F.x, Ft.y + F.y, Ft.z + F.z);
+        Ft = vg_make3(Ft.x + F.x, Ft.y + F.y, Ft.z + F.z);
         Mt = vg_make3(Mt.x + Mo.x, Mt.y + Mo.y, Mt.z + Mo.z);
         F = vg_make3(0.f, 0.f, 0.f); Mo = vg_make3(0.f, 0.f, 0.f);
         if (pcur < D) {                                  // (uniform) joint pcur + 1: its axis and origin, the prefix of frames <= pcur
             vg_float3 z = T2.cz, org = T2.t;
-            dh_apply(rb, pcur, sc.at(pcur), sc.at(D + pcur), T2);
+            float4 jt = *reinterpret_cast<const float4*>(rb->joint_tab[pcur]);      // (the second chain's step: fenced like the sweeps)
+            float st = sc.at(pcur), ct = sc.at(D + pcur);
+            vg_sweep_fence(jt, st, ct);
+            dh_apply_row(jt, craig, st, ct, T2);
             if (craig) { z = T2.cz; org = T2.t; }
             const vg_float3 oxF = vg_cross(org, Ft);
             sc.at(3 * D + pcur) = vg_dot(z, vg_make3(Mt.x - oxF.x, Mt.y - oxF.y, Mt.z - oxF.z));
@@ -804,12 +770,16 @@ __device__ __forceinline__ float loglik_config_prefix(const vgpmp_robot* __restr
     T = base_frame(rb);
 #pragma nounroll
     for (int i = 1; i <= D; ++i) {
+        // the iteration's operands, all requested, then at rest (vg_sweep_fence)
+        float4 jt = *reinterpret_cast<const float4*>(rb->joint_tab[i - 1]);
+        float st = sc.at(i - 1), ct = sc.at(D + i - 1), dgdf = sc.at(2 * D + i - 1), pre = sc.at(3 * D + i - 1);
+        vg_sweep_fence(jt, st, ct, dgdf, pre);
         vg_float3 z = T.cz, org = T.t;
-        dh_apply(rb, i - 1, sc.at(i - 1), sc.at(D + i - 1), T);
+        dh_apply_row(jt, craig, st, ct, T);
         if (craig) { z = T.cz; org = T.t; }
         const vg_float3 oxF = vg_cross(org, Ft);
         const float tot = vg_dot(z, vg_make3(Mt.x - oxF.x, Mt.y - oxF.y, Mt.z - oxF.z));
-        emit(i - 1, (tot - sc.at(3 * D + i - 1)) * sc.at(2 * D + i - 1));
+        emit(i - 1, (tot - pre) * dgdf);
     }
     return -0.5f * acc;
 }
@@ -825,14 +795,6 @@ __global__ __launch_bounds__(kLikBlock) void log_prob_kernel(const vgpmp_robot* 
                                                               float* __restrict__ logp, float* __restrict__ dlogp) {
     extern __shared__ float lik_lds[];
     const int64_t i = (int64_t)blockIdx.x * kLikBlock + threadIdx.x;
-#if VG_SWEEP_VARIANT == 1 || VG_SWEEP_VARIANT == 5
-    __shared__ float4 jt_s[VGPMP_MAX_DOF];
-    if (threadIdx.x < VGPMP_MAX_DOF) jt_s[threadIdx.x] = *reinterpret_cast<const float4*>(rb->joint_tab[threadIdx.x]);
-    __syncthreads();
-    const float4* jt_rows = jt_s;
-#else
-    const float4* jt_rows = nullptr;
-#endif
     if (i >= n) return;
     const vg_sdf_dev sdf = load_sdf(sdfh);
     const int D = rb->dof;
@@ -840,7 +802,7 @@ __global__ __launch_bounds__(kLikBlock) void log_prob_kernel(const vgpmp_robot* 
     const float* g = gq + i * D;
     float* dg = dlogp + i * D;
     logp[i] = loglik_config<GRAD, 8>(rb, sdf, sc, [&](int j) { return g[j]; }, [&](int, float x) { return x; },
-                                     [&](int j, float v) { dg[j] = v; }, nullptr, 0.f, NoSig(), jt_rows);
+                                     [&](int j, float v) { dg[j] = v; });
 }
 
 // ---- ELBO path: f [P,S,L,N] -> logp [P,S,N], G = dloss/df [P,S,L,N], block partial sums ----------

@@ -640,7 +640,9 @@ int vg_elbo_steps(const vgpmp_dims* d, const vgpmp_robot* rb, const vgpmp_sdf* s
     pa.stop = -1;
     pa.xcd_span = 0;
     pa.tick = nullptr;
-    // paths_bwd_sc8: sample chunks per workgroup -- as many as leave six workgroups per CU (the values do not depend on it)
+    // paths_bwd_sc8: sample chunks per workgroup -- as many as leave six workgroups per CU.  (paths_bwd_sc8's values do not depend on it: a
+    // set of sums per CHUNK, added in float64 by the assembly.  paths_bwd_regs leaves one set per WORKGROUP, its chunks added in float32: cpw
+    // -- chosen from P L and NC -- then decides where float32 roundings fall, and a problem's gradient bits depend on the batch it rides in.)
     pa.cpw = 1;
     if (!(what & VGPMP_BWD_ONE_CHUNK)) {
         while (pa.cpw < NC && (size_t)P * L * ((NC + 2 * pa.cpw - 1) / (2 * pa.cpw)) >= kPbMinWgs) pa.cpw *= 2;

@@ -511,7 +511,9 @@ __global__ __launch_bounds__(kBlock, 2) void paths_bwd_sc8(PathArgs a) {
 // eps C^T), read from global memory once per workgroup; LDS then holds only the operands of the current PAIR of 8-sample
 // chunks (40 KB: four workgroups per CU instead of two), the 16 x 16 MFMA tiles use all sixteen rows (two chunks at once;
 // paths_bwd_sc8 leaves eight of them empty) and no product waits on an LDS read of a B operand.  Per chunk the
-// element-wise part, the partial sums and their order are those of paths_bwd_sc8: the same numbers, bit for bit
+// element-wise part, the partial sums and their order are those of paths_bwd_sc8 -- the same numbers per CHUNK; since round 5
+// the chunks of a workgroup are then added in float32 here (one set of sums per workgroup), where paths_bwd_sc8 leaves a set per
+// chunk for the assembly's float64 sum: agreement to the rounding of that float32 sum, 2e-6 relative, not bit for bit
 // (tests/test_gpu_surface.py::test_reverse_path_pass_...).  Measured on paths_bwd_sc8 at the config-5 share (257 us): the
 // MFMA loops 82 us, per-chunk staging latency 73 us, staging the constants through LDS and the loop skeleton 46 us.
 // VG_PBR_DIRECT (the product form since round 5): the prior draws F0 / H of a chunk's samples are NOT staged -- every element is used
@@ -524,6 +526,9 @@ __global__ __launch_bounds__(kBlock, 2) void paths_bwd_sc8(PathArgs a) {
 #ifndef VG_PBR_BUFS
 #define VG_PBR_BUFS 1
 #endif
+#ifndef VG_PBR_XCD
+#define VG_PBR_XCD 0
+#endif
 constexpr int kPbrBufs = VG_PBR_BUFS;   // sets of staged rows (2 = the next pair requested under the current pair's work; with F0 / H staged that was
                                  // 67 KB of LDS, two workgroups per CU instead of three -- 198 against 131 us: the resident workgroups ARE the overlap)
 constexpr int kPbrWaves = 3;     // 168 registers: at 4 (128) the register-resident fragments spill (160 vs 132 us at the config-5 share)
@@ -532,16 +537,25 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
     constexpr int SC = 8, Mz = 32, R2 = 2 * SC;
     extern __shared__ float smf[];
     __shared__ float red[3][kBlock / VG_WAVE];
-    const int l = blockIdx.y, p = blockIdx.z, tid = threadIdx.x, nt = kBlock;
     // (the step counter's tick when the path assembly was the prior kernel's epilogue: nothing in this launch reads the counter)
     if (a.tick && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *a.tick += 1u;
+    // Workgroups are handed to the eight XCDs round robin by linear id, and the workgroups of ONE latent (adjacent ids) each fetch its A4
+    // planes and the tangents of C (51 KB + 8 KB): with VG_PBR_XCD the ids are re-read so that a latent's workgroups share an XCD -- and
+    // its L2 -- (logical id = (id % 8) (n / 8) + id / 8; every workgroup writes its own set of sums: the same bits)
+    unsigned wg_lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    {
+        const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+        if (VG_PBR_XCD && (nwg & 7u) == 0u) wg_lin = (wg_lin & 7u) * (nwg >> 3) + (wg_lin >> 3);
+    }
+    const int bx = (int)(wg_lin % gridDim.x), l = (int)((wg_lin / gridDim.x) % gridDim.y), p = (int)(wg_lin / (gridDim.x * gridDim.y));
+    const int tid = threadIdx.x, nt = kBlock;
 #ifdef VGPMP_BISECT
     // (measurement build: start / end of the workgroups of latent 0 of every 16th problem -- ids 1900 / 1930 + 2 (p / 16) + x; tools/step_trace.py)
     struct WgStamp {
         int id;
         __device__ WgStamp(int base, int l, int p, int x) : id(-1) { if (l == 0 && (p & 15) == 0 && p < 128 && x < 2) { id = base + 2 * (p >> 4) + x; VG_T(true, id); } }
         __device__ ~WgStamp() { if (id >= 0) VG_T(true, id + 30); }
-    } wg_stamp_(1900, l, p, (int)blockIdx.x);
+    } wg_stamp_(1900, l, p, bx);
 #endif
     const int S = a.S, N = a.N, L = a.L, J = N + Mz;
     const float iMz = 1.0f / (float)Mz, iN = 1.0f / (float)N;
@@ -591,9 +605,9 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
                 bCe[2 * k8 + h] = dell ? e : 0.f;
             }
     }
-    const int cp_end = min((int)(blockIdx.x + 1) * a.cpw, a.NC);
+    const int cp_end = min((int)(bx + 1) * a.cpw, a.NC);
     // (measurement build: phases of workgroup (0, 0, 0) -- id 1200 + 10 pair + phase; tools/pbr_trace.py)
-#define VG_PBT(pair, phase) VG_T(blockIdx.x == 0 && l == 0 && p == 0, 1200 + 10 * (pair) + (phase))
+#define VG_PBT(pair, phase) VG_T(bx == 0 && l == 0 && p == 0, 1200 + 10 * (pair) + (phase))
     VG_PBT(0, 9);
     auto stage_pair = [&](int ch0, int b) {
         const int s_base = ch0 * SC;
@@ -637,10 +651,10 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
 #pragma unroll
     for (int k = 0; k < kCE; ++k) accL[tid + k * kBlock] = 0.f;
     if (tid < Mz) accL[Mz * Mz + tid] = 0.f;
-    if (kPbrBufs > 1) stage_pair(blockIdx.x * a.cpw, 0);
+    if (kPbrBufs > 1) stage_pair(bx * a.cpw, 0);
     int cb = 0;
-    for (int ch0 = blockIdx.x * a.cpw; ch0 < cp_end; ch0 += 2) {
-        [[maybe_unused]] const int pair_i = (ch0 - blockIdx.x * a.cpw) >> 1;      // (measurement build's phase stamps)
+    for (int ch0 = bx * a.cpw; ch0 < cp_end; ch0 += 2) {
+        [[maybe_unused]] const int pair_i = (ch0 - bx * a.cpw) >> 1;      // (measurement build's phase stamps)
         VG_PBT(pair_i, 0);
         if (kPbrBufs == 1) stage_pair(ch0, 0);
         VG_PBT(pair_i, 1);
@@ -773,7 +787,7 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
         }
     }
     {
-        float* out = a.part + (pl * a.NCp + blockIdx.x) * a.part_len;
+        float* out = a.part + (pl * a.NCp + bx) * a.part_len;
         if (tid < Mz) vg_stream(out + tid, accL[Mz * Mz + tid]);
         float* oC = out + Mz;
 #pragma unroll
