@@ -64,10 +64,9 @@ def pytest_sessionstart(session):
     # ... and the launcher of tests/test_gpu_attach.py's visitors (processes that arrive on and leave the device while that test runs)
     session.config._attach = (subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "attach_worker.py"), "wait", out], env=env), out)
     # The tests start only when the two-rank bench has finished (and the shard workers, which initialise beside it, idle): the bit-for-bit
-    # tests need the device alone.  A likelihood launch in flight while another process ARRIVES on or LEAVES the device can return wrong
-    # values for a quarter wave (profiles/r06/flake.md; INTEGRATION.md, "Deployment constraints").  That is not hidden by this wait:
-    # tests/test_gpu_attach.py runs the kernels ON PURPOSE beside the same process mix (the stand-alone likelihood: fixed, a plain test;
-    # two planners stepped side by side: still parting ways, an expected failure).
+    # tests get the device alone, as a deployed planner does ("Deployment constraints").  What a launch in flight did when
+    # another process ARRIVED on or LEFT the device -- wrong values for a quarter wave, profiles/r06/flake.md -- is not hidden by this wait:
+    # tests/test_gpu_attach.py runs the kernels ON PURPOSE beside the same process mix and compares bit for bit.
     try:
         bench.wait(timeout=600)
     except subprocess.TimeoutExpired:

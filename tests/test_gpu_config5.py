@@ -303,8 +303,8 @@ def test_config5_full_size_properties():
 
 @pytest.mark.parametrize("robot", ["franka", "wam", "ur10", "kuka", "synthetic14", "synthetic15", "synthetic9"])
 def test_batch_form_of_the_likelihood_against_oracle_on_every_robot_shape(robot):
-    """The batch form (one lane per configuration, sphere gathers in batches of 8 across frames; per-joint prefix
-    terms as scalars in LDS up to 8 joints, per-frame sums in indexed registers beyond; or -- measurement flag -- the sums in LDS) forced on small problems of every robot shape: Craig and classic DH,
+    """The batch form (one lane per configuration, sphere gathers in batches across frames; per-frame sums in indexed registers --
+    the pipelined form -- or, measurement flag, in LDS) forced on small problems of every robot shape: Craig and classic DH,
     6 / 7 / 9 / 14 / 15 joints, ragged sphere counts per frame.  Against the oracle, and the two state placements and the
     free-space summary against each other bit for bit."""
     from vgpmp_amd import capi
@@ -336,17 +336,11 @@ def test_batch_form_of_the_likelihood_against_oracle_on_every_robot_shape(robot)
         np.testing.assert_allclose(float(outs["regs"][2][k]), fw["lik"], rtol=TOL_LIK)
         got = outs["regs"][3][k].cpu().numpy().T
         assert np.abs(got - og.q_mu).max() <= TOL_GRAD * np.abs(og.q_mu).max()
-    # Up to 8 joints the register form takes a joint's gradient as (its expression over the totals) - (the same over the frames
-    # before it), the LDS form as the expression over (totals - per-frame sums): the same number up to float32 rounding of
-    # the difference -- where nothing downstream of a joint collides the former leaves a residue of ~1e-7 of the largest
-    # gradient instead of an exact zero.  Beyond 8 joints both keep the sums per frame: bit for bit.
-    prefix_form = pb["spec"].dof <= 8
+    # every form keeps the force / moment sums per frame (the prefix-scalar form of up to 8 joints, whose gradients agreed with these only
+    # to float32 rounding, was retired in round 6: profiles/r06/flake.md): bit for bit
     for other in ("regs+summary", "lds", "lds+summary"):
         for a, b in zip(outs["regs"], outs[other]):
-            if prefix_form and other.startswith("lds"):
-                assert float((a - b).abs().max()) <= 4e-6 * float(b.abs().max()) + 1e-12, other
-            else:
-                assert torch.equal(a, b), other
+            assert torch.equal(a, b), other
 
 
 @pytest.mark.parametrize("n,delta,origin,offset", [(512, 2.0 / 512, (-1.0, -1.0, -1.0), (0.0, 0.0, 0.0)),        # config 5: a power of two

@@ -11,15 +11,22 @@ def test_first_difference():
     from vgpmp_amd import capi, engine, robots as rb, scenes
     ps = rb.load_problemset("franka", "industrial"); spec = rb.load_robot("franka")
     grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -0.6), seed=0)
-    sc = engine.DeviceScene(spec, grid, ps.object_positions[0])
-    S, M, N, P = 64, 30, 40, 12
+    off = ps.object_positions[0]
+    if os.environ.get("FLAKE_ROBOT") == "synthetic14":      # (the 14-joint arm of config 5: the register / pipelined forms of the likelihood)
+        spec, off = rb.synthetic_arm(14), (0.05, -0.03, 0.02)
+    sc = engine.DeviceScene(spec, grid, off)
+    S, M, N, P = 64, 30, 40, int(os.environ.get("FLAKE_P", "12"))
     L_ = 7
     qs = np.array([ps.queries[i % 36] for i in range(P)])
-    kw = dict(num_samples=S, num_inducing=M, num_data=N, num_bases=256, lengthscales=[2.0] * 7, variance=0.2, seed=4)
+    if spec.dof != 7:
+        L_ = spec.dof
+        qs = np.random.default_rng(3).uniform(-2.0, 2.0, (P, 2, L_))
+    kw = dict(num_samples=S, num_inducing=M, num_data=N, num_bases=256, lengthscales=[2.0] * L_, variance=0.2, seed=4)
     if os.environ.get("FLAKE_LR"):      # (a -DVGPMP_CHK build hands checksums back as gradients: keep the variables where they are)
         kw["learning_rate"] = float(os.environ["FLAKE_LR"])
     a, b = engine.PlannerBatch(sc, qs, **kw), engine.PlannerBatch(sc, qs, **kw)
     mode = os.environ.get("FLAKE_MODE", "aa")
+    a.extra_flags |= int(os.environ.get("FLAKE_FLAGS", "0")); b.extra_flags |= int(os.environ.get("FLAKE_FLAGS", "0"))
     if mode == "bb":
         a.extra_flags |= capi.NO_FUSE; b.extra_flags |= capi.NO_FUSE
     views = ("R", "G", "A4", "C", "m", "F0", "H", "epsT", "eps2T", "kl_l", "Kinv")
@@ -48,6 +55,7 @@ def test_first_difference():
             sa, sb = state(a), state(b)
         diff = [(k, float((sa[k].double() - sb[k].double()).abs().max()), int((sa[k] != sb[k]).sum())) for k in sa if not torch.equal(sa[k], sb[k])]
         if diff:
+            print("\nkernels:", [k for k in capi.last_schedule(a.lib) if k.startswith("loglik")], flush=True)
             print("\nFIRST DIFFERENCE", mode, "steps per call", nper, "after call", call, diff, flush=True)
             for k in ("q_mu", "lik", "kl", "raw_ell", "f"):
                 x, y = sa[k].double(), sb[k].double()

@@ -20,9 +20,6 @@ static int lik_bisect_mode() { const char* e = getenv("VGPMP_STOP_LIK"); return 
 int vg_trace_take_lik(unsigned long long* host, int cap) { return vg_trace_take(host, cap); }
 #endif
 
-constexpr int kLikPfxWaves = 3;           // waves per SIMD of the prefix-scalar form (151 registers)
-constexpr int kLikPrefixMaxDof = 8;       // batch likelihood: up to this many joints the prefix-scalar form (three waves per SIMD), beyond
-                                          // it the per-frame sums in registers (two): measured crossover, DESIGN section 3
 
 namespace {
 
@@ -152,11 +149,8 @@ __device__ __forceinline__ Frame dh_link(const vgpmp_robot* __restrict__ rb, int
 // process arrived on or left the device (every queue is preempted and resumed then): 8 of 11 sessions of tools/flake_session with the
 // round-5 code, 8 of 8 with the row read from LDS instead, 0 of 35 with any form that pins the loop's schedule (this fence, a bare
 // scheduling barrier, idle cycles behind the wait), 0 of 8 with this fence in the stand-alone kernel (vgpmp_log_prob).  What exactly the
-// hardware / its context save does with the unpinned schedule is NOT established (profiles/r06/flake.md has the record), and the fence
-// does NOT close the matter: the batch form inside the ELBO step (loglik_paths_kernel, one lane per configuration) still returns a
-// quarter wave of slightly different log-densities and gradients in 5-7 of 8 sessions of the two-planner reproducer, with these fences,
-// with the forward walk fenced the same way and with its gathers pinned behind an explicit wait -- while a build that merely adds
-// checksum arithmetic to its loop passes 10 of 10.  include/vgpmp.h and INTEGRATION.md state the deployment constraint that follows.
+// hardware / its context save does with the unpinned schedule is NOT established (profiles/r06/flake.md has the record).  The one batch
+// form that kept failing with every fence tried -- loglik_config_prefix -- was retired (see the note where it stood).
 __device__ __forceinline__ void vg_sweep_fence(float4& jt, float& st, float& ct) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(jt.x), "+s"(jt.y), "+s"(jt.z), "+s"(jt.w), "+v"(st), "+v"(ct));
 }
@@ -647,142 +641,11 @@ __device__ __forceinline__ float loglik_config_pipe(const vgpmp_robot* __restric
     return -0.5f * acc;
 }
 
-// The same with the prefix term of every joint's gradient as a scalar in LDS instead of per-frame sums in registers (up to
-// kLikPrefixMaxDof joints).  A function of its own: folded into loglik_config_regs as a template switch, the form WITHOUT
-// the prefix terms came out 22 % slower at the config-5 share -- same numbers, same register count, a different schedule of
-// its gathers.
-template <int U, bool SIG, bool FAR, typename LoadRaw, typename ToAngle, typename Emit, typename EmitSig = NoSig>
-__device__ __forceinline__ float loglik_config_prefix(const vgpmp_robot* __restrict__ rb, const vg_sdf_dev& sdf,
-                                                    const LikScratch sc, LoadRaw load_raw, ToAngle to_angle, Emit emit,
-                                                    const float* __restrict__ sig = nullptr, float sig_w = 0.f,
-                                                    EmitSig emit_sig = NoSig()) {
-    static_assert(VGPMP_MAX_SPHERES % U == 0, "a batch of sphere constants never leaves the table");
-    const int D = rb->dof, P = rb->num_spheres;          // D <= 15: frames 0 .. 15
-    float raw[VGPMP_MAX_DOF];
-#pragma unroll
-    for (int j = 0; j < VGPMP_MAX_DOF; ++j) raw[j] = load_raw(min(j, D - 1));
-    const float eps = rb->epsilon;
-    const double offx = rb->scene_offset[0], offy = rb->scene_offset[1], offz = rb->scene_offset[2];
-    const SdfFast fs = make_fast(sdf, offx, offy, offz);
-    // sin / cos / d g / d f of every joint: LDS slots [0, D), [D, 2D), [2D, 3D) of this lane
-#pragma unroll
-    for (int j = 0; j < VGPMP_MAX_DOF; ++j) {
-        if (j < D) {                                     // uniform
-            float st, ct, d;
-            vg_sincos(to_angle(j, raw[j], d) + rb->joint_tab[j][4], &st, &ct);
-            sc.at(j) = st; sc.at(D + j) = ct; sc.at(2 * D + j) = d;
-        }
-    }
-    // Joint i moves every sphere on frames >= i: its gradient is z_i . (M - o_i x F) over the totals MINUS the same expression
-    // over the prefix of frames < i.  The prefix term is a scalar the moment frame i - 1 is complete: a second copy of the
-    // chain (T2) follows the consumer side and leaves it in LDS slot 3 D + i - 1.  (Per-frame sums in registers -- six
-    // 16-wide vectors, 96 VGPRs -- held the kernel at two waves per SIMD; it is bound by the latency of its gathers.)
-    // With many joints the two extra chain sweeps cost what the third wave buys (14 joints: +1.8 % on the 2 GiB table, 7: -4 %):
-    // loglik_config_regs keeps the sums per frame.
-    Frame T2 = base_frame(rb);
-    const bool craig = rb->craig != 0;
-    Frame T = base_frame(rb);
-    int cur = 0;                                         // frame T stands at (issue side)
-    int pcur = 0;                                        // frame of the running sums (consumer side)
-    vg_float3 F = vg_make3(0.f, 0.f, 0.f), Mo = vg_make3(0.f, 0.f, 0.f);
-    vg_float3 Ft = vg_make3(0.f, 0.f, 0.f), Mt = vg_make3(0.f, 0.f, 0.f);
-    float acc = 0.f;
-    auto flush = [&]() {                                 // sums of frame pcur are complete
-        Ft = vg_make3(Ft.x + F.x, Ft.y + F.y, Ft.z + F.z);
-        Mt = vg_make3(Mt.x + Mo.x, Mt.y + Mo.y, Mt.z + Mo.z);
-        F = vg_make3(0.f, 0.f, 0.f); Mo = vg_make3(0.f, 0.f, 0.f);
-        if (pcur < D) {                                  // (uniform) joint pcur + 1: its axis and origin, the prefix of frames <= pcur
-            vg_float3 z = T2.cz, org = T2.t;
-            float4 jt = *reinterpret_cast<const float4*>(rb->joint_tab[pcur]);      // (the second chain's step: fenced like the sweeps)
-            float st = sc.at(pcur), ct = sc.at(D + pcur);
-            vg_sweep_fence(jt, st, ct);
-            dh_apply_row(jt, craig, st, ct, T2);
-            if (craig) { z = T2.cz; org = T2.t; }
-            const vg_float3 oxF = vg_cross(org, Ft);
-            sc.at(3 * D + pcur) = vg_dot(z, vg_make3(Mt.x - oxF.x, Mt.y - oxF.y, Mt.z - oxF.z));
-        }
-        ++pcur;
-    };
-#pragma nounroll
-    for (int q0 = 0; q0 < P; q0 += U) {
-        float4 v[U];
-        vg_float3 pos[U];
-        uint32_t at[U];
-        float4 ca[U];
-        float2 cb[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            ca[u] = *reinterpret_cast<const float4*>(rb->sphere_a[q0 + u]);      // {offset, frame}; rows >= P: frame = D
-            cb[u] = *reinterpret_cast<const float2*>(rb->sphere_b[q0 + u]);      // {radius, 1 / sigma}
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int q = q0 + u;
-            if (q < P) {                                 // uniform
-                const int fr = __builtin_bit_cast(int, ca[u].w);
-                while (cur < fr) {
-                    dh_apply(rb, cur, sc.at(cur), sc.at(D + cur), T);
-                    ++cur;
-                }
-                pos[u] = axpy(ca[u].x, T.cx, axpy(ca[u].y, T.cy, axpy(ca[u].z, T.cz, T.t)));
-                const Vox3 ix = voxel3(pos[u], fs, sdf, offx, offy, offz);
-                at[u] = (uint32_t)vg_table_offset(sdf, ix.ix, ix.iy, ix.iz);
-                if (FAR) v[u].x = sdf.brick_min[vg_brick_of(sdf, ix.ix, ix.iy, ix.iz)];
-                else v[u] = sdf.table[at[u]];
-            } else {
-                v[u] = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);       // hinge exactly 0
-                pos[u] = vg_make3(0.f, 0.f, 0.f);
-                at[u] = 0u;
-            }
-        }
-        if (FAR) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (q0 + u < P) {
-                    // free space: the hinge is exactly 0 on every voxel of the brick -> no table access
-                    // (an unconditional load from a shared "far" record instead -- no divergent branch -- was measured: equal on
-                    //  a cache-resident table, 7 % slower per step on the 2 GiB one)
-                    const float bm = v[u].x;
-                    v[u] = make_float4(bm, 0.f, 0.f, 0.f);
-                    if (eps - (bm - cb[u].x) > 0.f) v[u] = sdf.table[at[u]];
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int q = q0 + u;
-            if (q < P) {                                 // uniform
-                const int fr = __builtin_bit_cast(int, ca[u].w);
-                while (pcur < fr) flush();
-                const float c = fmaxf(eps - (v[u].x - cb[u].x), 0.f);           // likelihood.py:131-143
-                const float cs = SIG ? c / sig[q] : c * cb[u].y;
-                acc = fmaf(cs, c, acc);                                          // likelihood.py:99
-                if (SIG) emit_sig(q, vg_wave_sum(cs * c * sig_w));               // one total per sphere
-                const vg_float3 gp = vg_make3(cs * v[u].y, cs * v[u].z, cs * v[u].w);   // d logp / d pos
-                F = vg_make3(F.x + gp.x, F.y + gp.y, F.z + gp.z);
-                Mo = vg_cross_acc(Mo, pos[u], gp);
-            }
-        }
-    }
-    while (pcur <= D) flush();
-    // second sweep over the chain: joint i turns about z of frame i (Craig) or frame i-1 (classic) and moves every
-    // sphere on frames >= i, i.e. the totals minus the prefix < i
-    T = base_frame(rb);
-#pragma nounroll
-    for (int i = 1; i <= D; ++i) {
-        // the iteration's operands, all requested, then at rest (vg_sweep_fence)
-        float4 jt = *reinterpret_cast<const float4*>(rb->joint_tab[i - 1]);
-        float st = sc.at(i - 1), ct = sc.at(D + i - 1), dgdf = sc.at(2 * D + i - 1), pre = sc.at(3 * D + i - 1);
-        vg_sweep_fence(jt, st, ct, dgdf, pre);
-        vg_float3 z = T.cz, org = T.t;
-        dh_apply_row(jt, craig, st, ct, T);
-        if (craig) { z = T.cz; org = T.t; }
-        const vg_float3 oxF = vg_cross(org, Ft);
-        const float tot = vg_dot(z, vg_make3(Mt.x - oxF.x, Mt.y - oxF.y, Mt.z - oxF.z));
-        emit(i - 1, (tot - pre) * dgdf);
-    }
-    return -0.5f * acc;
-}
+// (Until round 6 batches of up to 8 joints ran a third one-lane form, loglik_config_prefix: the prefix term of every joint's gradient as a
+//  scalar in LDS, formed by a second copy of the chain inside the forward loop -- three waves per SIMD, 4-7 % faster than the forms above
+//  at 7 joints.  It was the ONE batch form whose results differed when the queue was preempted mid-launch (two same-seed planners parted
+//  ways in 29 of 38 reproducer sessions, with the round-5 code and with every fence tried; the LDS-state form 0 of 8, the 8-lane form
+//  0 of 8, the pipelined form 0 of 12 at 7 joints and 0 of 8 at 14): retired, profiles/r06/flake.md.)
 
 constexpr int kLikBlock = 128;
 constexpr int kLikBatchBlock = 64;
@@ -808,8 +671,8 @@ __global__ __launch_bounds__(kLikBlock) void log_prob_kernel(const vgpmp_robot* 
 // ---- ELBO path: f [P,S,L,N] -> logp [P,S,N], G = dloss/df [P,S,L,N], block partial sums ----------
 // LPC lanes per (sample, time) configuration; BLK / LPC configurations per workgroup.  Large batches run one-wave
 // workgroups (kLikBatchBlock): 188 instead of 204 us per launch at 64 problems (finer tail).
-template <int LPC, int BLK, bool SIG = false, bool FAR = false, bool REGS = false, bool PFX = false>
-__global__ __launch_bounds__(BLK, REGS ? (PFX ? kLikPfxWaves : 2) : 1) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
+template <int LPC, int BLK, bool SIG = false, bool FAR = false, bool REGS = false>
+__global__ __launch_bounds__(BLK, REGS ? 2 : 1) void loglik_paths_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
                                                                   const float* __restrict__ f, int S, int L, int N,
                                                                   float scale, float* __restrict__ G,
                                                                   float* __restrict__ logp,
@@ -844,10 +707,7 @@ __global__ __launch_bounds__(BLK, REGS ? (PFX ? kLikPfxWaves : 2) : 1) void logl
         const float* sigp = SIG ? sigma_eff + (size_t)pb * VGPMP_MAX_SPHERES : nullptr;
         auto put_sig = [&](int q, float t) { if (threadIdx.x == 0) sp[q] = t; };
         if (REGS) {
-            auto regs_form = [&](auto&&... a) {
-                if constexpr (PFX) return loglik_config_prefix<kLikBatchU, SIG, FAR>(a...);
-                else return loglik_config_regs<kLikBatchU, SIG, FAR>(a...);
-            };
+            auto regs_form = [&](auto&&... a) { return loglik_config_regs<kLikBatchU, SIG, FAR>(a...); };
             lp = regs_form(
                 rb, sdf, sc, raw_f,
                 [&](int j, float x, float& d) {
@@ -1633,11 +1493,10 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
     };
     const bool regs = L <= 15 && form != 2;              // per-frame sums in registers (form 2, measurement: in LDS)
     if (regs) {
-        const bool pfx = L <= kLikPrefixMaxDof;      // the prefix-scalar form of the reverse sweep (a fourth LDS slot row)
         // free-space masks in LDS (four-wave workgroups; the per-wave partial sums and their count stay those of the one-wave form)
         const size_t lds_mask = (sdf->free_mask ? (size_t)sdf->mask_count * sdf->mask_words * 4 : 0) + (size_t)3 * L * kLikMaskBlock * sizeof(float);
         const bool masks = sdf->layout == VGPMP_SDF_BRICK4 && sdf->free_mask && sdf->mask_count > 0;
-        if (!pfx && !sig && 2 * lds_mask <= 160 * 1024) {
+        if (!sig && 2 * lds_mask <= 160 * 1024) {      // the pipelined form: every robot of up to 15 joints (round 6: the 7-joint arms as well)
             auto gom = [&](auto kern, const char* name) {
                 int rc = vg_grant_dyn_lds((const void*)kern, lds_mask);
                 if (rc) return rc;
@@ -1649,15 +1508,11 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
             // masks in LDS where the scene has them (one dependent global load per sphere), else the summary, else every sphere
             return masks ? VG_GO(gom, loglik_paths_mask_kernel<2>) : far ? VG_GO(gom, loglik_paths_mask_kernel<1>) : VG_GO(gom, loglik_paths_mask_kernel<0>);
         }
-        lds = (size_t)(pfx ? 4 : 3) * L * kLikBatchBlock * sizeof(float);
-        if (pfx) {
-            if (sig) return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, true, true, true>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, false, true, true>);
-            return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, true, true, true>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, false, true, true>);
-        }
-        if (sig) return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, true, true, false>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, false, true, false>);
-        return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, true, true, false>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, false, true, false>);
+        lds = (size_t)3 * L * kLikBatchBlock * sizeof(float);
+        if (sig) return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, true, true>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, false, true>);
+        return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, true, true>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, false, true>);
     }
-    if (sig) return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, true, false, false>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, false, false, false>);
-    return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, true, false, false>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, false, false, false>);
+    if (sig) return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, true, false>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, false, false>);
+    return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, true, false>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, false, false, false>);
 }
 #undef VG_GO

@@ -526,9 +526,6 @@ __global__ __launch_bounds__(kBlock, 2) void paths_bwd_sc8(PathArgs a) {
 #ifndef VG_PBR_BUFS
 #define VG_PBR_BUFS 1
 #endif
-#ifndef VG_PBR_XCD
-#define VG_PBR_XCD 0
-#endif
 constexpr int kPbrBufs = VG_PBR_BUFS;   // sets of staged rows (2 = the next pair requested under the current pair's work; with F0 / H staged that was
                                  // 67 KB of LDS, two workgroups per CU instead of three -- 198 against 131 us: the resident workgroups ARE the overlap)
 constexpr int kPbrWaves = 3;     // 168 registers: at 4 (128) the register-resident fragments spill (160 vs 132 us at the config-5 share)
@@ -539,15 +536,9 @@ __global__ __launch_bounds__(kBlock, kPbrWaves) void paths_bwd_regs(PathArgs a) 
     __shared__ float red[3][kBlock / VG_WAVE];
     // (the step counter's tick when the path assembly was the prior kernel's epilogue: nothing in this launch reads the counter)
     if (a.tick && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *a.tick += 1u;
-    // Workgroups are handed to the eight XCDs round robin by linear id, and the workgroups of ONE latent (adjacent ids) each fetch its A4
-    // planes and the tangents of C (51 KB + 8 KB): with VG_PBR_XCD the ids are re-read so that a latent's workgroups share an XCD -- and
-    // its L2 -- (logical id = (id % 8) (n / 8) + id / 8; every workgroup writes its own set of sums: the same bits)
-    unsigned wg_lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    {
-        const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
-        if (VG_PBR_XCD && (nwg & 7u) == 0u) wg_lin = (wg_lin & 7u) * (nwg >> 3) + (wg_lin >> 3);
-    }
-    const int bx = (int)(wg_lin % gridDim.x), l = (int)((wg_lin / gridDim.x) % gridDim.y), p = (int)(wg_lin / (gridDim.x * gridDim.y));
+    // (re-reading the workgroup ids so that the two workgroups of a latent -- each fetches its A4 planes and the tangents of C, 59 KB --
+    //  share an XCD and its L2 was measured in round 6: 725.6 against 726.1 us per step at the config-5 share, nothing; not kept)
+    const int bx = (int)blockIdx.x, l = (int)blockIdx.y, p = (int)blockIdx.z;
     const int tid = threadIdx.x, nt = kBlock;
 #ifdef VGPMP_BISECT
     // (measurement build: start / end of the workgroups of latent 0 of every 16th problem -- ids 1900 / 1930 + 2 (p / 16) + x; tools/step_trace.py)

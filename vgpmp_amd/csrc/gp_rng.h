@@ -108,9 +108,6 @@ __device__ __forceinline__ void rng_normals_body(const RngArgs& a, int bx, int p
 // first layout each of their 4-byte requests pulled a 64-byte sector shared by the L latents).  A workgroup owns 2^eps_rows_log2
 // rows (s, k) of one of the two streams: L kEpsRows consecutive elements, their counters one per thread and pass; the normals
 // go out in the first layout as they are drawn and through an LDS tile in the second, 64 consecutive floats per wave.
-#ifndef VG_EPS_IFACE
-#define VG_EPS_IFACE 1      // (measurement: 0 leaves out the interface-layout copy of eps / eps' where the transposed copy is written)
-#endif
 constexpr int kEpsRowsMax = 256;
 __host__ __device__ __forceinline__ uint32_t rng_eps_t_blocks(uint32_t rows, int rows_log2) { return 2u * ((rows + (1u << rows_log2) - 1u) >> rows_log2); }
 // (`tile`: eps_rows L floats of the launch's dynamic LDS -- static arrays here would add to every role of the merged launches)
@@ -130,7 +127,7 @@ __device__ __forceinline__ void rng_eps_t_body(const RngArgs& a, int bx, int p, 
         const float4 v = vg_normal4(q, second ? VG_STREAM_EPS2 : VG_STREAM_EPS, key);
         const uint32_t first = 4u * q - a.eOff;           // local element of lane 0 (wraps below zero on a rank's first counter)
         if (4u * q >= a.eOff + e_lo && first + 3u < e_hi && ((((size_t)p * nE + first) & 3u) == 0u)) {
-            if (VG_EPS_IFACE || !dstT) vg_stream(reinterpret_cast<float4*>(dst + first), v);
+            vg_stream(reinterpret_cast<float4*>(dst + first), v);
             if (dstT) {
                 float* t = tile + (first - e_lo);
                 t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
@@ -139,7 +136,7 @@ __device__ __forceinline__ void rng_eps_t_body(const RngArgs& a, int bx, int p, 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t e = first + (uint32_t)k;   // unsigned: an element below the range compares >= e_hi
-                if (e >= e_lo && e < e_hi) { if (VG_EPS_IFACE || !dstT) vg_stream(dst + e, vg_lane(v, k)); if (dstT) tile[e - e_lo] = vg_lane(v, k); }
+                if (e >= e_lo && e < e_hi) { vg_stream(dst + e, vg_lane(v, k)); if (dstT) tile[e - e_lo] = vg_lane(v, k); }
             }
         }
     }
