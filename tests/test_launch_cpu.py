@@ -145,7 +145,7 @@ def test_committed_traffic_table_is_this_rounds():
         assert t5[k]["fetch_multiplier"] in (1, 2) and t5[k]["algorithmic_read_bytes"] > 0 and "multiplier_basis" in t5[k], k
     assert t5["paths_bwd_regs<25>"]["fetch_multiplier"] == 2 and t5["loglik_paths_mask_kernel<2>"]["fetch_multiplier"] == 1
     assert any(k.startswith("prior_fused_small16_kernel") for k in t3)       # (the f16-split few-sample kernel)
-    stamp = open(os.path.join(ROOT, "profiles", "r05", "final", "COLLECTED_AT")).read().strip()
+    stamp = open(os.path.join(ROOT, "profiles", "r06", "final", "COLLECTED_AT")).read().strip()
     assert stamp == t["collected_at"]
 
 

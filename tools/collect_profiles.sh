@@ -4,7 +4,7 @@
 # Every profiler run sits under `timeout`; the program stands directly behind `--`.
 set -uo pipefail
 : "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}"
-round=${ROUND:-r05}
+round=${ROUND:-r06}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/${round}final; rm -rf "$out"; mkdir -p "$out"
 stats() {   # stats <tag> <bench args...>: bench line under the kernel trace + the kernel statistics table
@@ -114,5 +114,6 @@ fi
 # ---- the driver's line: config 2 + sub-records (batch_512, config3, batch_64) + plan quality + CPU baselines, with this
 #      collection's traffic tables in place
 python bench.py > $out/config2_bench.json 2> $out/config2_bench.err; tail -c 600 $out/config2_bench.json; echo
+cp bench_detail.json $out/config2_bench_detail.json 2>/dev/null      # (the full record behind the compact line)
 find $out -name "*.err" -size 0 -delete
 ls -la $out | head -80

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Run tools/collect_profiles.sh on a GPU box and file the results under profiles/<round>/final, stamped with the commit they
-# were taken at (the GPU box has no .git).  From the repo root, in the build container.  ROUND=r05 by default.
+# were taken at (the GPU box has no .git).  From the repo root, in the build container.  ROUND=r06 by default.
 set -euo pipefail
-round=${ROUND:-r05}
+round=${ROUND:-r06}
 head=$(git rev-parse --short HEAD); dirty=$(git status --porcelain | grep -v '^??' | wc -l || true)
 stamp="commit $head"; if [ "$dirty" != 0 ]; then stamp="$stamp + $dirty uncommitted file(s)"; fi
 echo "$stamp" > profiles/COLLECT_STAMP
