@@ -8,6 +8,7 @@
 // utils/sdf_utils.py:62-136.
 #include "vgpmp_device.h"
 #include "fk_chain.h"
+#include <type_traits>
 #include <hip/hip_ext.h>
 
 // No implicit contraction in this file: every fused multiply-add is written as fmaf, so that template instantiations
@@ -488,28 +489,35 @@ __device__ __forceinline__ float loglik_config_regs(const vgpmp_robot* __restric
 // with every sphere gathering: the pass sits at what the memory system serves in scattered 64-byte sectors, profiles/r04.)
 // FAR: 0 every sphere reads the table; 1 brick summary (requested for batch b + 1 under the gathers of batch b: straight-line
 // loads, so the compiler's wait for the gathers leaves them in flight); 2 free-space masks in LDS.
-template <int U, int FAR, typename LoadRaw, typename ToAngle, typename Emit>
+// SMALL (up to 7 joints: frames 0 .. 7; round 6): the per-frame sums as six 8-wide vectors and the joint loops to 8 -- 168 instead of 222-238
+// registers (32-64 bytes of scratch), three waves per SIMD: the 7-joint arms at the speed of the retired prefix-scalar form (64 Franka
+// problems 354 us per step; 378 with the 16-wide sums at two waves), the same arithmetic in the same order (bit-identical to the LDS form:
+// tests/test_gpu_config5.py), 0 of 12 sessions of the preemption reproducer.
+typedef float vg_f32x8 __attribute__((ext_vector_type(8)));
+template <int U, int FAR, bool SMALL = false, typename LoadRaw, typename ToAngle, typename Emit>
 __device__ __forceinline__ float loglik_config_pipe(const vgpmp_robot* __restrict__ rb, const vg_sdf_dev& sdf,
                                                     const LikScratch sc, LoadRaw load_raw, ToAngle to_angle, Emit emit,
                                                     const uint32_t* lmask = nullptr) {
     static_assert(VGPMP_MAX_SPHERES % (2 * U) == 0, "two batches of sphere constants never leave the table");
     static_assert(FAR >= 0 && FAR <= 2, "none, summary or masks");
-    const int D = rb->dof, P = rb->num_spheres;          // D <= 15: frames 0 .. 15
-    float raw[VGPMP_MAX_DOF];
+    const int D = rb->dof, P = rb->num_spheres;          // D <= 15: frames 0 .. 15 (SMALL: D <= 7)
+    constexpr int kJ = SMALL ? 8 : VGPMP_MAX_DOF;
+    using SumVec = typename std::conditional<SMALL, vg_f32x8, vg_f32x16>::type;
+    float raw[kJ];
 #pragma unroll
-    for (int j = 0; j < VGPMP_MAX_DOF; ++j) raw[j] = load_raw(min(j, D - 1));
+    for (int j = 0; j < kJ; ++j) raw[j] = load_raw(min(j, D - 1));
     const float eps = rb->epsilon;
     const double offx = rb->scene_offset[0], offy = rb->scene_offset[1], offz = rb->scene_offset[2];
     const SdfFast fs = make_fast(sdf, offx, offy, offz);
 #pragma unroll
-    for (int j = 0; j < VGPMP_MAX_DOF; ++j) {
+    for (int j = 0; j < kJ; ++j) {
         if (j < D) {                                     // uniform
             float st, ct, d;
             vg_sincos(to_angle(j, raw[j], d) + rb->joint_tab[j][4], &st, &ct);
             sc.at(j) = st; sc.at(D + j) = ct; sc.at(2 * D + j) = d;
         }
     }
-    vg_f32x16 fx = 0.f, fy = 0.f, fz = 0.f, mx = 0.f, my = 0.f, mz = 0.f;      // per-frame sums
+    SumVec fx = 0.f, fy = 0.f, fz = 0.f, mx = 0.f, my = 0.f, mz = 0.f;      // per-frame sums
     Frame T = base_frame(rb);
     int cur = 0;                                         // frame T stands at (issue side)
     int pcur = 0;                                        // frame of the running sums (consumer side)
@@ -643,7 +651,7 @@ __device__ __forceinline__ float loglik_config_pipe(const vgpmp_robot* __restric
 
 // (Until round 6 batches of up to 8 joints ran a third one-lane form, loglik_config_prefix: the prefix term of every joint's gradient as a
 //  scalar in LDS, formed by a second copy of the chain inside the forward loop -- three waves per SIMD, 4-7 % faster than the forms above
-//  at 7 joints.  It was the ONE batch form whose results differed when the queue was preempted mid-launch (two same-seed planners parted
+//  at 7 joints (a speed the 8-wide pipelined form, loglik_config_pipe<.., SMALL>, has since matched).  It was the ONE batch form whose results differed when the queue was preempted mid-launch (two same-seed planners parted
 //  ways in 29 of 38 reproducer sessions, with the round-5 code and with every fence tried; the LDS-state form 0 of 8, the 8-lane form
 //  0 of 8, the pipelined form 0 of 12 at 7 joints and 0 of 8 at 14): retired, profiles/r06/flake.md.)
 
@@ -744,7 +752,7 @@ __global__ __launch_bounds__(BLK, REGS ? 2 : 1) void loglik_paths_kernel(const v
     VG_T(blockIdx.x == gridDim.x - 1 && pb == 0, 405);
 }
 
-// ---- ELBO path, batch form of 9 to 15 joints: pipelined, free-space masks in LDS ------------------------------
+// ---- ELBO path, batch form of up to 15 joints: pipelined, free-space masks in LDS -----------------------------
 // FARM = the pipelined form's FAR: 0 every sphere gathers, 1 brick summary, 2 free-space masks (the scene's default).
 // Four waves per workgroup share ONE copy of the scene's free-space masks (include/vgpmp.h: a bit per block of voxels, a few KB
 // to 32 KB) staged into LDS by DMA while the waves load their joint values; each wave then runs the register form on its own 64
@@ -754,8 +762,8 @@ __global__ __launch_bounds__(BLK, REGS ? 2 : 1) void loglik_paths_kernel(const v
 // at the config-5 share) before its 16-byte gather.  Results are bit-identical (skipped spheres cost exactly 0).
 constexpr int kLikMaskBlock = 256;
 constexpr int kLikPipeU = 4;      // spheres per batch of the pipelined form (two batches in registers; 8 spills 190 registers)
-template <int FARM>
-__global__ __launch_bounds__(kLikMaskBlock, 2) void loglik_paths_mask_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
+template <int FARM, bool SMALL = false>
+__global__ __launch_bounds__(kLikMaskBlock, SMALL ? 3 : 2) void loglik_paths_mask_kernel(const vgpmp_robot* __restrict__ rb, vgpmp_sdf sdfh,
                                                                             const float* __restrict__ f, int S, int L, int N,
                                                                             float scale, float* __restrict__ G,
                                                                             float* __restrict__ logp,
@@ -785,7 +793,7 @@ __global__ __launch_bounds__(kLikMaskBlock, 2) void loglik_paths_mask_kernel(con
         return fmaf(span, sg, rb->joint_tab[j][5]);
     };
     auto put = [&](int j, float v) { if (live) G[base + (size_t)j * N] = scale * v; };
-    const float lp = loglik_config_pipe<kLikPipeU, FARM>(rb, sdf, sc, raw_f, angle, put, lmask);
+    const float lp = loglik_config_pipe<kLikPipeU, FARM, SMALL>(rb, sdf, sc, raw_f, angle, put, lmask);
     if (live) logp[((size_t)pb * S + s) * N + n] = lp;
     const float w = vg_wave_sum(live ? lp : 0.f);
     if (lane == 0 && wv < nwaves) lik_partial[(size_t)pb * nwaves + wv] = w;
@@ -1506,6 +1514,8 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
                 return (int)hipGetLastError();
             };
             // masks in LDS where the scene has them (one dependent global load per sphere), else the summary, else every sphere
+            if (L <= 7)      // frames 0 .. 7: the 8-wide sums, three waves per SIMD (64 Franka problems: 378 -> 354 us per step)
+                return masks ? VG_GO(gom, loglik_paths_mask_kernel<2, true>) : far ? VG_GO(gom, loglik_paths_mask_kernel<1, true>) : VG_GO(gom, loglik_paths_mask_kernel<0, true>);
             return masks ? VG_GO(gom, loglik_paths_mask_kernel<2>) : far ? VG_GO(gom, loglik_paths_mask_kernel<1>) : VG_GO(gom, loglik_paths_mask_kernel<0>);
         }
         lds = (size_t)3 * L * kLikBatchBlock * sizeof(float);
