@@ -11,7 +11,7 @@ visitors) comes and goes WHILE the kernels run over and over, and every output i
   * the batch form inside the ELBO step: ONE of its forms -- the prefix-scalar form that batches of up to 8 joints ran -- parted two
     same-seed planners in 29 of 38 reproducer sessions whatever was fenced; every other form (LDS state, 8 lanes per configuration,
     the pipelined register form at 7 and at 14 joints) 0 of 36.  The prefix form was retired; batches of 7-joint arms run the
-    pipelined form (+7 % on the 64-problem step).
+    pipelined form with 8-wide per-frame sums (the retired form's speed).
 
 What the hardware does to the two schedules that failed is NOT established; these tests are the standing check, and one process per
 GPU remains the stated deployment rule ("Deployment constraints").
