@@ -139,11 +139,11 @@ def test_committed_traffic_table_is_this_rounds():
     t5 = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_config5.json")))
     t3 = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_config3.json")))
     assert t5["collected_at"] == t["collected_at"] == t3["collected_at"]
-    assert t5["loglik_paths_mask_kernel<2>"]["hbm_bytes_per_launch"] > 1e8          # 2 GiB table: hundreds of MB of sectors per launch
+    assert t5["loglik_paths_mask_kernel<2, false>"]["hbm_bytes_per_launch"] > 1e8          # 2 GiB table: hundreds of MB of sectors per launch
     # round 5: the FETCH multiplier is calibrated per kernel against its algorithmic read volume (tools/kernel_bytes.py), not by name
     for k in ("paths_bwd_regs<25>", "paths_fwd_regs<2>", "cov_b_kernel<true, false>", "prior_fused_split_kernel<true, 2>"):
         assert t5[k]["fetch_multiplier"] in (1, 2) and t5[k]["algorithmic_read_bytes"] > 0 and "multiplier_basis" in t5[k], k
-    assert t5["paths_bwd_regs<25>"]["fetch_multiplier"] == 2 and t5["loglik_paths_mask_kernel<2>"]["fetch_multiplier"] == 1
+    assert t5["paths_bwd_regs<25>"]["fetch_multiplier"] == 2 and t5["loglik_paths_mask_kernel<2, false>"]["fetch_multiplier"] == 1
     assert any(k.startswith("prior_fused_small16_kernel") for k in t3)       # (the f16-split few-sample kernel)
     stamp = open(os.path.join(ROOT, "profiles", "r06", "final", "COLLECTED_AT")).read().strip()
     assert stamp == t["collected_at"]

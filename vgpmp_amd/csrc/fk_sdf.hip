@@ -1516,7 +1516,8 @@ int vg_launch_loglik_paths(const vgpmp_robot* rb, const vgpmp_sdf* sdf, const fl
             // masks in LDS where the scene has them (one dependent global load per sphere), else the summary, else every sphere
             if (L <= 7)      // frames 0 .. 7: the 8-wide sums, three waves per SIMD (64 Franka problems: 378 -> 354 us per step)
                 return masks ? VG_GO(gom, loglik_paths_mask_kernel<2, true>) : far ? VG_GO(gom, loglik_paths_mask_kernel<1, true>) : VG_GO(gom, loglik_paths_mask_kernel<0, true>);
-            return masks ? VG_GO(gom, loglik_paths_mask_kernel<2>) : far ? VG_GO(gom, loglik_paths_mask_kernel<1>) : VG_GO(gom, loglik_paths_mask_kernel<0>);
+            // (both template arguments spelled out: the schedule log carries the launch site's text, and a profiler prints `<2, false>`)
+            return masks ? VG_GO(gom, loglik_paths_mask_kernel<2, false>) : far ? VG_GO(gom, loglik_paths_mask_kernel<1, false>) : VG_GO(gom, loglik_paths_mask_kernel<0, false>);
         }
         lds = (size_t)3 * L * kLikBatchBlock * sizeof(float);
         if (sig) return far ? VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, true, true>) : VG_GO(go, loglik_paths_kernel<1, kLikBatchBlock, true, false, true>);
