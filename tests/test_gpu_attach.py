@@ -9,7 +9,7 @@ visitors) comes and goes WHILE the kernels run over and over, and every output i
   * the stand-alone likelihood (`vgpmp_log_prob`): the damage sat in the gradient's second sweep and went with the SCHEDULE of that
     loop; an operand fence pins it (csrc/fk_sdf.hip, `vg_sweep_fence`): 0 of 8 reproducer sessions, 7 of 8 before;
   * the batch form inside the ELBO step: ONE of its forms -- the prefix-scalar form that batches of up to 8 joints ran -- parted two
-    same-seed planners in 29 of 38 reproducer sessions whatever was fenced; every other form (LDS state, 8 lanes per configuration,
+    same-seed planners in 31 of 38 reproducer sessions whatever was fenced; every other form (LDS state, 8 lanes per configuration,
     the pipelined register form at 7 and at 14 joints) 0 of 36.  The prefix form was retired; batches of 7-joint arms run the
     pipelined form with 8-wide per-frame sums (the retired form's speed).
 
