@@ -1,7 +1,9 @@
 /* vgpmp_debug.h -- measurement switches and test hooks of libvgpmp_hip.so.  NOT part of the binding surface: a binder of
  * include/vgpmp.h never needs this file.  The bits below share the `what` argument of vgpmp_elbo_step* with the public VGPMP_DO_* /
- * VGPMP_GEN_NOISE / VGPMP_COV_ONLY / VGPMP_NOISE_* flags; every one of them selects another schedule or kernel form for the SAME
- * numbers (the tests hold the forms against each other), none changes what a call computes. */
+ * VGPMP_GEN_NOISE / VGPMP_COV_ONLY / VGPMP_NOISE_* flags; every one of them selects another schedule or kernel form of the same
+ * computation (the tests hold the forms against each other), none changes what a call computes.  Bit-identical results except where a
+ * switch says otherwise: VGPMP_PRIOR_F32 / VGPMP_NO_FUSE_PRIOR (float32-MFMA prior products: agreement to float32 rounding with the
+ * f16-split kernels) and VGPMP_BWD_ONE_CHUNK where the register-resident reverse kernel runs (a float32 sum of chunk sums). */
 #ifndef VGPMP_DEBUG_H
 #define VGPMP_DEBUG_H
 #include "vgpmp.h"
