@@ -109,3 +109,17 @@ def test_product_path_fails_loudly_without_library(monkeypatch, tmp_path):
     monkeypatch.setattr(capi, "_lib", None)
     with pytest.raises(capi.VgpmpError):
         capi.load(require=True)
+
+
+def test_library_holds_no_packed_fp32_instruction():
+    """The shipped code objects contain no v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (vgpmp_amd/build.py, FLAGS): on MI355X / ROCm 7.0.2
+    those instructions leave wrong results in lanes 48-63 of a wave preempted while they are in flight (tools/sweep_probe.hip,
+    profiles/r06/flake.md) -- the likelihood's wrong gradients of round 5.  Disassembles the built library (no GPU needed)."""
+    import os
+    from vgpmp_amd import build
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        import pytest
+        pytest.skip("llvm-objdump of the ROCm toolchain is not installed here")
+    lib = build.build(force=False, verbose=False)
+    assert build.packed_fp32_instructions(lib, objdump) == {}

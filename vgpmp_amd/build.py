@@ -12,10 +12,17 @@ CSRC = PKG / "csrc"
 LIB_DIR = PKG / "lib"
 LIB = LIB_DIR / "libvgpmp_hip.so"
 SOURCES = ["fk_sdf.hip", "gp_path.hip", "mesh_sdf.hip", "deriv_kernels.hip", "plan.hip", "inducing.hip", "comm.hip", "capi.hip"]
-HEADERS = [CSRC / "vgpmp_device.h", CSRC / "gp_path.h", CSRC / "fk_chain.h", CSRC / "gp_math.h", ROOT / "include" / "vgpmp.h", ROOT / "include" / "vgpmp_debug.h"]
+HEADERS = [CSRC / "vgpmp_device.h", CSRC / "gp_path.h", CSRC / "fk_chain.h", CSRC / "gp_math.h", ROOT / "include" / "vgpmp.h", ROOT / "include" / "vgpmp_debug.h",
+           Path(__file__).resolve()]      # (this file: a change of FLAGS rebuilds everything)
 # private parts of gp_path.hip (one translation unit: its stage launches dispatch these bodies by role)
 GP_PARTS = [CSRC / n for n in ("gp_common.h", "gp_rng.h", "gp_paths.h", "gp_update.h", "gp_cov.h", "gp_prior.h", "gp_prior_split.h", "gp_lik_consts.h", "gp_wtable.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize -fno-vectorize: NO packed-FP32 VALU instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) in the library.  On
+# MI355X / ROCm 7.0.2 such instructions leave wrong results in lanes 48-63 of a wave that is preempted while they are in flight
+# (another process arriving on or leaving the device): tools/sweep_probe.hip reproduces it in plain HIP, 18 of 18 sessions with packed
+# instructions, 0 of 12 without (profiles/r06/flake.md).  The compiler's vectorisers are where all but three of the library's 8 687
+# packed instructions came from; they bought no time (config 2 50.2 / 50.2 us, config-5 share 735 / 732, 64 problems 362 / 355, config 3
+# 121.6 / 122.0 us per step with / without).  packed_fp32_instructions() below is what tests/test_capi_load.py holds at zero.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize", "-fno-vectorize"]
 
 
 def hipcc() -> str:
@@ -68,6 +75,38 @@ def build(force: bool = False, verbose: bool = True, measurement: bool = False) 
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     return lib
+
+
+def packed_fp32_instructions(lib: Path = LIB, objdump: str = "/opt/rocm/lib/llvm/bin/llvm-objdump") -> dict:
+    """{instruction: count} of the packed-FP32 VALU instructions in the gfx950 code objects embedded in `lib` (the clang offload bundles
+    of its .hip_fatbin section, disassembled by llvm-objdump).  The library's policy is an empty dict (see FLAGS)."""
+    import re
+    import struct
+    import tempfile
+    blob = Path(lib).read_bytes()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    found, objects = {}, 0
+    for m in re.finditer(re.escape(magic), blob):
+        p = m.start()
+        n = struct.unpack_from("<Q", blob, p + 24)[0]
+        off = p + 32
+        for _ in range(n):
+            o, size, tl = struct.unpack_from("<QQQ", blob, off)
+            off += 24
+            triple = blob[off:off + tl].decode(errors="replace")
+            off += tl
+            if "gfx950" not in triple or not size:
+                continue
+            objects += 1
+            with tempfile.NamedTemporaryFile(suffix=".co") as f:
+                f.write(blob[p + o:p + o + size])
+                f.flush()
+                text = subprocess.run([objdump, "-d", "--mcpu=gfx950", f.name], capture_output=True, text=True, check=True).stdout
+            for ins in re.findall(r"\bv_pk_(?:fma|mul|add)_f32\b", text):
+                found[ins] = found.get(ins, 0) + 1
+    if not objects:
+        raise RuntimeError(f"no gfx950 code object found in {lib}")
+    return found
 
 
 if __name__ == "__main__":

@@ -250,8 +250,8 @@ __device__ __forceinline__ void prior_gemm_lds_body(const GemmArgs& a, float* ld
             // constant factors (Phi = c cos, dPhi = c / ell^2 sin (x . omega): a lengthscale of 0.01 puts the latter beyond f16's
             // 65504): `sc` takes them out -- cos and sin (x . omega) are f16-safe -- and the accumulators get them back at the end
             auto frag = [&](const float* row, int ks2, float sc, vg_h8& hi, vg_h8& lo) {
-                const vg_f32x4 x0 = *reinterpret_cast<const vg_f32x4*>(row + 32 * ks2 + 8 * g) * sc;
-                const vg_f32x4 x1 = *reinterpret_cast<const vg_f32x4*>(row + 32 * ks2 + 8 * g + 4) * sc;
+                const vg_f32x4 x0 = vg_scale4(*reinterpret_cast<const vg_f32x4*>(row + 32 * ks2 + 8 * g), sc);
+                const vg_f32x4 x1 = vg_scale4(*reinterpret_cast<const vg_f32x4*>(row + 32 * ks2 + 8 * g + 4), sc);
                 vg_h4 h0, l0, h1, l1;
                 vg_split4(x0, h0, l0);
                 vg_split4(x1, h1, l1);
@@ -667,7 +667,7 @@ void prior_fused_small_kernel(FusedPriorArgs a) {
     // between the products of tile t (independent work next to each other in the instruction stream), not after them
     auto pass = [&](const float (&o)[kDQ], const vg_f32x4& bb, const vg_f32x4 (&aa)[MT]) {
         float ph[2][4], dh[2][4];
-        vg_f32x4 btr = bb * 0.15915494309189535f;        // phases in revolutions
+        vg_f32x4 btr = vg_scale4(bb, 0.15915494309189535f);        // phases in revolutions
         auto feats = [&](int t, float (&pc)[4], float (&dc)[4]) {
             vg_f32x4 proj = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -489,7 +489,7 @@ __device__ __forceinline__ void prior_small16_body(const FusedPriorArgs& a, int 
                 al[m] = (vg_h8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
             }
         }
-        const vg_f32x4 bt0 = x.b0 * 0.15915494309189535f, bt1 = x.b1 * 0.15915494309189535f;      // phases in revolutions
+        const vg_f32x4 bt0 = vg_scale4(x.b0, 0.15915494309189535f), bt1 = vg_scale4(x.b1, 0.15915494309189535f);      // phases in revolutions
 #pragma unroll
         for (int t = 0; t < kFNT; ++t) {
             vg_f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
