@@ -16,7 +16,7 @@
 #define VARIANT 0
 #endif
 #ifndef MODE
-#define MODE 0      // 0 the sweep; 1 the sweep without LDS (operands in registers); 2 without the scalar load; 3 LDS reads only
+#define MODE 0      // 0 the sweep; 1 the sweep without LDS (operands in registers); 2 without the scalar load; 3 LDS reads only; 4 as 1 with explicit two-wide float vectors
 #endif
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
@@ -27,8 +27,23 @@ struct Robot {
 };
 struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk(float x, float y, float z) { return f3{x, y, z}; }
+#if MODE == 4
+// MODE 4 (built WITHOUT the compiler's vectorisers): the x / y components of the chain's products as explicit two-wide float vectors --
+// the compiler emits v_pk_mul_f32 / v_pk_fma_f32 for them whatever the vectorisers are told: packed instructions by construction
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f3 axpy(float a, f3 x, f3 y) {
+    const f2v r = __builtin_elementwise_fma((f2v){a, a}, (f2v){x.x, x.y}, (f2v){y.x, y.y});
+    return mk(r[0], r[1], fmaf(a, x.z, y.z));
+}
+__device__ __forceinline__ f3 lin2(float a, f3 x, float b, f3 y) {
+    const f2v t = (f2v){b, b} * (f2v){y.x, y.y};
+    const f2v r = __builtin_elementwise_fma((f2v){a, a}, (f2v){x.x, x.y}, t);
+    return mk(r[0], r[1], fmaf(a, x.z, b * y.z));
+}
+#else
 __device__ __forceinline__ f3 axpy(float a, f3 x, f3 y) { return mk(fmaf(a, x.x, y.x), fmaf(a, x.y, y.y), fmaf(a, x.z, y.z)); }
 __device__ __forceinline__ f3 lin2(float a, f3 x, float b, f3 y) { return mk(fmaf(a, x.x, b * y.x), fmaf(a, x.y, b * y.y), fmaf(a, x.z, b * y.z)); }
+#endif
 __device__ __forceinline__ f3 cross(f3 a, f3 b) { return mk(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))); }
 __device__ __forceinline__ float dot(f3 a, f3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
 struct Frame { f3 cx, cy, cz, t; };
@@ -79,7 +94,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const Robot* __restrict__
         sc[0] = sc[0] * 0.999f + 1e-3f * (float)(r & 7);
         for (int k = 0; k < 2 * D + 6 * (D + 1); ++k) chk = chk * 1664525u + __float_as_uint(sc[k * kBlock]) + (unsigned)k;
     }
-#elif MODE == 1
+#elif MODE == 1 || MODE == 4
     // NO LDS in the loop: the lane's operands in registers (the sweep unrolled: seven joints)
     float rs[7], rc[7], rm[8][6];
 #pragma unroll
