@@ -335,11 +335,12 @@ int vgpmp_generate_noise(const vgpmp_dims* dims, const vgpmp_noise* noise, uint3
 /* One evaluation of VGPMP.elbo (models/vgpmp.py:265-289) for every problem of the batch and,
  * depending on `what` (VGPMP_DO_*), its reverse pass and the Adam update of
  * utils/miscellaneous.py:68-84.  `adam_t` is the 1-based step count after this update.
- * DEPLOYMENT CONSTRAINT (profiles/r06/flake.md): the calling process should have the GPU to itself while this
- * runs.  Up to round 5 a likelihood launch in flight while ANOTHER process arrived on or left the device (every queue is preempted and
- * resumed then) could silently return wrong log-densities / gradients for sixteen consecutive configurations (MI355X, ROCm 7.0.2).  The
- * two instruction schedules that did so are gone (0 of 52 reproducer sessions since), but the cause below the ISA is not established:
- * tests/test_gpu_attach.py is the standing check.  Applies to every vgpmp_elbo_step* entry and to vgpmp_log_prob. */
+ * DEPLOYMENT NOTE (profiles/r06/flake.md): give the calling process the GPU to itself.  Up to round 5 a
+ * likelihood launch in flight while ANOTHER process arrived on or left the device (every queue is preempted and resumed then) could
+ * silently return wrong values for sixteen consecutive configurations: packed-FP32 instruction sequences (v_pk_*_f32, formed by the
+ * compiler's SLP vectoriser) come back wrong in lanes 48-63 of a wave preempted mid-sequence (MI355X, ROCm 7.0.2).  This library is
+ * built without such instructions (a test holds the count at zero); other code on the same GPU may not be.  Applies to every
+ * vgpmp_elbo_step* entry and to vgpmp_log_prob. */
 int vgpmp_elbo_step(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,
                     const vgpmp_problem* problem, const vgpmp_params* params,
                     const vgpmp_params* adam_m, const vgpmp_params* adam_v,

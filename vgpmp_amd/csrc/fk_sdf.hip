@@ -144,14 +144,13 @@ __device__ __forceinline__ Frame dh_link(const vgpmp_robot* __restrict__ rb, int
 // row by a scalar load, its sin / cos and the iteration's other LDS words -- and then passes them through ONE explicit
 // `s_waitcnt lgkmcnt(0)` inside an asm statement that names them all: the compiler can neither move a load behind that point nor start
 // the arithmetic before it, and nothing of the iteration is in flight while it computes.
-// Why: with the compiler's own schedule of this loop (loads and the frame arithmetic interleaved, the wait in the branch targets, the
-// scalar load's address registers reused at once) the gradient of up to a few hundred configurations per launch came back WRONG --
-// sixteen consecutive lanes at a time, the log-density of the same launch right -- in launches that were in flight while another
-// process arrived on or left the device (every queue is preempted and resumed then): 8 of 11 sessions of tools/flake_session with the
-// round-5 code, 8 of 8 with the row read from LDS instead, 0 of 35 with any form that pins the loop's schedule (this fence, a bare
-// scheduling barrier, idle cycles behind the wait), 0 of 8 with this fence in the stand-alone kernel (vgpmp_log_prob).  What exactly the
-// hardware / its context save does with the unpinned schedule is NOT established (profiles/r06/flake.md has the record).  The one batch
-// form that kept failing with every fence tried -- loglik_config_prefix -- was retired (see the note where it stood).
+// History (profiles/r06/flake.md): round 5's gradients came back WRONG for sixteen consecutive lanes in launches that were in flight
+// while another process arrived on or left the device (every queue is preempted and resumed then).  In this kernel every form that
+// pinned the loop's schedule cured it (0 of 35 sessions against 8 of 11), which is how the fence came to be.  The cause's class was found
+// later with a hand-reduced copy of the loop (tools/sweep_probe.hip): floating-point code that the SLP vectoriser packs into v_pk_*_f32
+// sequences comes back wrong in lanes 48-63 when the wave is preempted mid-sequence -- fence or no fence.  The library is therefore built
+// WITHOUT the vectorisers (vgpmp_amd/build.py: no packed-FP32 instruction in the binary, held at zero by a CPU test); the fence stays as
+// a second line: it costs nothing and keeps the sweep's operands at rest.
 __device__ __forceinline__ void vg_sweep_fence(float4& jt, float& st, float& ct) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(jt.x), "+s"(jt.y), "+s"(jt.z), "+s"(jt.w), "+v"(st), "+v"(ct));
 }
@@ -651,9 +650,10 @@ __device__ __forceinline__ float loglik_config_pipe(const vgpmp_robot* __restric
 
 // (Until round 6 batches of up to 8 joints ran a third one-lane form, loglik_config_prefix: the prefix term of every joint's gradient as a
 //  scalar in LDS, formed by a second copy of the chain inside the forward loop -- three waves per SIMD, 4-7 % faster than the forms above
-//  at 7 joints (a speed the 8-wide pipelined form, loglik_config_pipe<.., SMALL>, has since matched).  It was the ONE batch form whose results differed when the queue was preempted mid-launch (two same-seed planners parted
-//  ways in 29 of 38 reproducer sessions, with the round-5 code and with every fence tried; the LDS-state form 0 of 8, the 8-lane form
-//  0 of 8, the pipelined form 0 of 12 at 7 joints and 0 of 8 at 14): retired, profiles/r06/flake.md.)
+//  at 7 joints (a speed the 8-wide pipelined form, loglik_config_pipe<.., SMALL>, has since matched).  It was the ONE batch form whose results
+//  differed when the queue was preempted mid-launch (two same-seed planners parted ways in 31 of 38 reproducer sessions whatever was
+//  fenced; every other form 0 of 36): the form richest in three-component arithmetic that the SLP vectoriser packs -- the class of code
+//  that misbehaves under preemption (see vg_sweep_fence above).  Retired before that was known; nothing to bring back.)
 
 constexpr int kLikBlock = 128;
 constexpr int kLikBatchBlock = 64;
