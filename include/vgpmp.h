@@ -337,9 +337,10 @@ int vgpmp_generate_noise(const vgpmp_dims* dims, const vgpmp_noise* noise, uint3
  * utils/miscellaneous.py:68-84.  `adam_t` is the 1-based step count after this update.
  * DEPLOYMENT NOTE (profiles/r06/flake.md): give the calling process the GPU to itself.  Up to round 5 a
  * likelihood launch in flight while ANOTHER process arrived on or left the device (every queue is preempted and resumed then) could
- * silently return wrong values for sixteen consecutive configurations: packed-FP32 instruction sequences (v_pk_*_f32, formed by the
- * compiler's SLP vectoriser) come back wrong in lanes 48-63 of a wave preempted mid-sequence (MI355X, ROCm 7.0.2).  This library is
- * built without such instructions (a test holds the count at zero); other code on the same GPU may not be.  Applies to every
+ * silently return wrong values for sixteen consecutive configurations: a packed-FP32 instruction (v_pk_fma / mul / add_f32, formed by
+ * the compiler's SLP vectoriser) whose op_sel and op_sel_hi both select source 1's high register reads 0.0 for it in lanes 48-63 once
+ * per preemption of its wave (MI355X, ROCm 7.0.2; tools/pk_probe.hip).  This library is built without packed instructions (a test
+ * holds the count at zero); other code on the same GPU may not be.  Applies to every
  * vgpmp_elbo_step* entry and to vgpmp_log_prob. */
 int vgpmp_elbo_step(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,
                     const vgpmp_problem* problem, const vgpmp_params* params,

@@ -16,7 +16,8 @@
 #define VARIANT 0
 #endif
 #ifndef MODE
-#define MODE 0      // 0 the sweep; 1 the sweep without LDS (operands in registers); 2 without the scalar load; 3 LDS reads only; 4 as 1 with explicit two-wide float vectors
+#define MODE 0      // 0 the sweep; 1 the sweep without LDS (operands in registers); 2 without the scalar load; 3 LDS reads only; 4 as 1 with explicit two-wide float vectors;
+                    // 5 + packed subtraction; 6 + half-swapping shuffles; 7 as 1 with the DH row's scalar-register PAIRS as packed operands (two different halves)
 #endif
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
@@ -27,10 +28,12 @@ struct Robot {
 };
 struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk(float x, float y, float z) { return f3{x, y, z}; }
-#if MODE == 4
+#if MODE >= 4
+typedef float f2v __attribute__((ext_vector_type(2)));
+#endif
+#if MODE >= 4 && MODE <= 6
 // MODE 4 (built WITHOUT the compiler's vectorisers): the x / y components of the chain's products as explicit two-wide float vectors --
 // the compiler emits v_pk_mul_f32 / v_pk_fma_f32 for them whatever the vectorisers are told: packed instructions by construction
-typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f3 axpy(float a, f3 x, f3 y) {
     const f2v r = __builtin_elementwise_fma((f2v){a, a}, (f2v){x.x, x.y}, (f2v){y.x, y.y});
     return mk(r[0], r[1], fmaf(a, x.z, y.z));
@@ -67,6 +70,26 @@ __device__ __forceinline__ float hashf(unsigned x) {      // a float in (-1, 1) 
     return (float)(int)(x >> 8) * (1.0f / 8388608.0f) - 1.0f;
 }
 
+#if MODE == 7 || MODE == 8
+// MODE 7 (built WITHOUT the vectorisers): what the SLP build has and modes 4-6 lack -- packed instructions whose scalar-register operand is a
+// PAIR with two different halves ({cos alpha, sin alpha}, {d, a}: v_pk_mul_f32 / v_pk_fma_f32 v, s[n:n+1], v ... with no op_sel_hi broadcast)
+__device__ __forceinline__ void dh_row_pairs(const float4 jt, float st, float ct, Frame& T) {
+    f2v cs = (f2v){jt.x, jt.y}, da = (f2v){jt.z, jt.w};
+#if MODE == 8
+    asm volatile("" : "+v"(cs), "+v"(da));      // MODE 8: the same arithmetic with the pairs copied to vector registers first
+#endif
+    f3 y1, z1, t1;
+    {   const f2v p = cs * (f2v){T.cy.x, T.cz.x}, q = cs * (f2v){T.cz.x, T.cy.x}; y1.x = p[0] + p[1]; z1.x = q[0] - q[1]; }
+    {   const f2v p = cs * (f2v){T.cy.y, T.cz.y}, q = cs * (f2v){T.cz.y, T.cy.y}; y1.y = p[0] + p[1]; z1.y = q[0] - q[1]; }
+    {   const f2v p = cs * (f2v){T.cy.z, T.cz.z}, q = cs * (f2v){T.cz.z, T.cy.z}; y1.z = p[0] + p[1]; z1.z = q[0] - q[1]; }
+    {   const f2v r = __builtin_elementwise_fma(da, (f2v){z1.x, T.cx.x}, (f2v){T.t.x, 0.0f}); t1.x = r[0] + r[1]; }
+    {   const f2v r = __builtin_elementwise_fma(da, (f2v){z1.y, T.cx.y}, (f2v){T.t.y, 0.0f}); t1.y = r[0] + r[1]; }
+    {   const f2v r = __builtin_elementwise_fma(da, (f2v){z1.z, T.cx.z}, (f2v){T.t.z, 0.0f}); t1.z = r[0] + r[1]; }
+    const f3 x2 = lin2(ct, T.cx, st, y1), y2 = lin2(-st, T.cx, ct, y1);
+    T.cx = x2; T.cy = y2; T.cz = z1; T.t = t1;
+}
+#endif
+
 constexpr int kBlock = 128;
 __global__ __launch_bounds__(kBlock) void sweep_kernel(const Robot* __restrict__ rb, int rep, unsigned* __restrict__ out) {
     extern __shared__ float lds[];
@@ -94,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const Robot* __restrict__
         sc[0] = sc[0] * 0.999f + 1e-3f * (float)(r & 7);
         for (int k = 0; k < 2 * D + 6 * (D + 1); ++k) chk = chk * 1664525u + __float_as_uint(sc[k * kBlock]) + (unsigned)k;
     }
-#elif MODE == 1 || MODE == 4
+#elif MODE == 1 || MODE >= 4
     // NO LDS in the loop: the lane's operands in registers (the sweep unrolled: seven joints)
     float rs[7], rc[7], rm[8][6];
 #pragma unroll
@@ -112,10 +135,28 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const Robot* __restrict__
         f3 Fs = Ft, Ms = Mt;
 #pragma unroll
         for (int i = 1; i <= 7; ++i) {
+#if MODE == 5 || MODE == 6
+            {   // the x / y components of the prefix subtraction as two-wide vectors: v_pk_add_f32 with negated operands
+                f2v fxy = (f2v){Fs.x, Fs.y} - (f2v){rm[i - 1][0], rm[i - 1][1]}, mxy = (f2v){Ms.x, Ms.y} - (f2v){rm[i - 1][3], rm[i - 1][4]};
+#if MODE >= 6
+                // ... and a half-swapping shuffle of two pairs (v_pk_mov_b32 with op_sel), undone again: the values do not change
+                f2v sw = __builtin_shufflevector(fxy, mxy, 1, 2), sw2 = __builtin_shufflevector(fxy, mxy, 0, 3);
+                asm volatile("" : "+v"(sw), "+v"(sw2));
+                fxy = __builtin_shufflevector(sw2, sw, 0, 2); mxy = __builtin_shufflevector(sw, sw2, 1, 3);
+#endif
+                Fs = mk(fxy[0], fxy[1], Fs.z - rm[i - 1][2]);
+                Ms = mk(mxy[0], mxy[1], Ms.z - rm[i - 1][5]);
+            }
+#else
             Fs = mk(Fs.x - rm[i - 1][0], Fs.y - rm[i - 1][1], Fs.z - rm[i - 1][2]);
             Ms = mk(Ms.x - rm[i - 1][3], Ms.y - rm[i - 1][4], Ms.z - rm[i - 1][5]);
+#endif
             f3 z = T.cz, org = T.t;
+#if MODE == 7 || MODE == 8
+            dh_row_pairs(*reinterpret_cast<const float4*>(rb->joint_tab[i - 1]), rs[i - 1], rc[i - 1], T);
+#else
             dh_row(*reinterpret_cast<const float4*>(rb->joint_tab[i - 1]), craig, rs[i - 1], rc[i - 1], T);
+#endif
             if (craig) { z = T.cz; org = T.t; }
             const f3 oxF = cross(org, Fs);
             const float g = dot(z, mk(Ms.x - oxF.x, Ms.y - oxF.y, Ms.z - oxF.z));
@@ -184,14 +225,35 @@ int main(int argc, char** argv) {
     const size_t lds = (size_t)(2 * 7 + 6 * 8) * kBlock * sizeof(float);
     CHECK(hipFuncSetAttribute((const void*)sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipStream_t st; CHECK(hipStreamCreate(&st));
-    hipLaunchKernelGGL(sweep_kernel, dim3(wgs), dim3(kBlock), lds, st, rb, rep, ref);
+    // SWEEP_HSACO=<code object>: the kernel comes from that file instead (tools/depack_pk.py: the failing build's assembly with chosen
+    // packed instructions rewritten as two plain ones, assembled with clang -x assembler + ld.lld) -- same symbol, same arguments
+    hipFunction_t modf = nullptr;
+    if (const char* path = getenv("SWEEP_HSACO")) {
+        hipModule_t mod; CHECK(hipModuleLoad(&mod, path)); CHECK(hipModuleGetFunction(&modf, mod, "_Z12sweep_kernelPK5RobotiPj"));
+        printf("kernel from %s\n", path);
+    }
+    auto launch = [&](unsigned* dst) -> hipError_t {
+        if (!modf) { hipLaunchKernelGGL(sweep_kernel, dim3(wgs), dim3(kBlock), lds, st, rb, rep, dst); return hipGetLastError(); }
+        struct { const Robot* rb; int rep; int pad; unsigned* out; } a{rb, rep, 0, dst};
+        size_t sz = sizeof(a);
+        void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+        return hipModuleLaunchKernel(modf, wgs, 1, 1, kBlock, 1, 1, (unsigned)lds, st, nullptr, cfg);
+    };
+    CHECK(launch(ref));
+    {   // a checksum of the reference launch: equal across code objects that compute the same thing (the rewritten ones must)
+        CHECK(hipStreamSynchronize(st));
+        std::vector<unsigned> r0(n); CHECK(hipMemcpy(r0.data(), ref, n * 4, hipMemcpyDeviceToHost));
+        unsigned long long hsh = 1469598103934665603ull;
+        for (size_t i = 0; i < n; ++i) { hsh ^= r0[i]; hsh *= 1099511628211ull; }
+        printf("reference launch checksum %016llx\n", hsh);
+    }
     CHECK(hipStreamSynchronize(st));
     const auto t0 = std::chrono::steady_clock::now();
     unsigned launches = 0, events = 0;
     while (true) {
         ++launches;
         CHECK(hipMemsetAsync(out, 0xff, n * 4, st)); CHECK(hipMemsetAsync(bad, 0, 4, st));
-        hipLaunchKernelGGL(sweep_kernel, dim3(wgs), dim3(kBlock), lds, st, rb, rep, out);
+        CHECK(launch(out));
         hipLaunchKernelGGL(count_diff, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, ref, n, bad, first);
         unsigned hb = 0, hf = 0;
         CHECK(hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, st)); CHECK(hipMemcpyAsync(&hf, first, 4, hipMemcpyDeviceToHost, st));

@@ -21,7 +21,9 @@ GP_PARTS = [CSRC / n for n in ("gp_common.h", "gp_rng.h", "gp_paths.h", "gp_upda
 # (another process arriving on or leaving the device): tools/sweep_probe.hip reproduces it in plain HIP, 18 of 18 sessions with packed
 # instructions, 0 of 12 without (profiles/r06/flake.md).  The compiler's vectorisers are where all but three of the library's 8 687
 # packed instructions came from; they bought no time (config 2 50.2 / 50.2 us, config-5 share 735 / 732, 64 problems 362 / 355, config 3
-# 121.6 / 122.0 us per step with / without).  packed_fp32_instructions() below is what tests/test_capi_load.py holds at zero.
+# 121.6 / 122.0 us per step with / without).  packed_fp32_instructions() below is what tests/test_capi_load.py holds at zero.  The ONE form
+# that misbehaves was pinned afterwards (tools/depack_pk.py, tools/pk_probe.hip: op_sel and op_sel_hi both on source 1's high half reads
+# 0.0 there in lanes 48-63 after a preemption); src1_high_half_instructions() lists it for any library, this one holds none of any type.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize", "-fno-vectorize"]
 
 
@@ -77,15 +79,14 @@ def build(force: bool = False, verbose: bool = True, measurement: bool = False) 
     return lib
 
 
-def packed_fp32_instructions(lib: Path = LIB, objdump: str = "/opt/rocm/lib/llvm/bin/llvm-objdump") -> dict:
-    """{instruction: count} of the packed-FP32 VALU instructions in the gfx950 code objects embedded in `lib` (the clang offload bundles
-    of its .hip_fatbin section, disassembled by llvm-objdump).  The library's policy is an empty dict (see FLAGS)."""
+def _gfx950_disassemblies(lib: Path, objdump: str):
+    """The disassembly (text) of every gfx950 code object embedded in `lib`: the clang offload bundles of its .hip_fatbin section."""
     import re
     import struct
     import tempfile
     blob = Path(lib).read_bytes()
     magic = b"__CLANG_OFFLOAD_BUNDLE__"
-    found, objects = {}, 0
+    objects = 0
     for m in re.finditer(re.escape(magic), blob):
         p = m.start()
         n = struct.unpack_from("<Q", blob, p + 24)[0]
@@ -101,12 +102,40 @@ def packed_fp32_instructions(lib: Path = LIB, objdump: str = "/opt/rocm/lib/llvm
             with tempfile.NamedTemporaryFile(suffix=".co") as f:
                 f.write(blob[p + o:p + o + size])
                 f.flush()
-                text = subprocess.run([objdump, "-d", "--mcpu=gfx950", f.name], capture_output=True, text=True, check=True).stdout
-            for ins in re.findall(r"\bv_pk_(?:fma|mul|add)_f32\b", text):
-                found[ins] = found.get(ins, 0) + 1
+                yield subprocess.run([objdump, "-d", "--mcpu=gfx950", f.name], capture_output=True, text=True, check=True).stdout
     if not objects:
         raise RuntimeError(f"no gfx950 code object found in {lib}")
+
+
+def packed_fp32_instructions(lib: Path = LIB, objdump: str = "/opt/rocm/lib/llvm/bin/llvm-objdump") -> dict:
+    """{instruction: count} of the packed-FP32 VALU instructions in the gfx950 code objects embedded in `lib`.  The library's policy is
+    an empty dict (see FLAGS)."""
+    import re
+    found = {}
+    for text in _gfx950_disassemblies(lib, objdump):
+        for ins in re.findall(r"\bv_pk_(?:fma|mul|add)_f32\b", text):
+            found[ins] = found.get(ins, 0) + 1
     return found
+
+
+def src1_high_half_instructions(lib: Path = LIB, objdump: str = "/opt/rocm/lib/llvm/bin/llvm-objdump") -> list:
+    """The packed (VOP3P, `v_pk_*`) instructions of `lib` whose op_sel AND op_sel_hi both select the high half of SOURCE 1 -- the one form
+    that tools/pk_probe.hip shows reading 0.0 for that operand in lanes 48-63 after a preemption (profiles/r06/flake.md, "The
+    instruction": v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[x,1,x] with op_sel_hi:[x,1,x], the default).  Policy: empty."""
+    import re
+    hits = []
+    for text in _gfx950_disassemblies(lib, objdump):
+        for line in text.split("\n"):
+            m = re.search(r"\b(v_pk_\w+)\s+([^/]*)", line)
+            if not m:
+                continue
+            sel = re.search(r"op_sel:\[([01,]+)\]", m.group(2))
+            sel_hi = re.search(r"op_sel_hi:\[([01,]+)\]", m.group(2))
+            lo = sel.group(1).split(",") if sel else ["0", "0", "0"]
+            hi = sel_hi.group(1).split(",") if sel_hi else ["1", "1", "1"]
+            if len(lo) > 1 and len(hi) > 1 and lo[1] == "1" and hi[1] == "1":
+                hits.append((m.group(1) + " " + m.group(2)).strip())
+    return hits
 
 
 if __name__ == "__main__":
