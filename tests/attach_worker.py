@@ -7,7 +7,9 @@ which the likelihood kernels of round 5 returned wrong gradients in 7 of 8 sessi
 two rank processes of the sample-sharding test (tests/shard_worker.py, gloo) and `bench.py --gpus 2 --shard samples` (which starts two
 more ranks), then two plain visitors (`attach_worker.py visit`: open the device, build a planner, twenty steps, exit).  Every arrival
 and every exit makes the hardware scheduler rebuild its run list: each queue of the device is preempted and resumed.  When all have
-exited it writes <dir>/done_attach_<k> with their exit codes."""
+exited it writes <dir>/done_attach_<k> with their exit codes.  <dir>/go_mfma_<j> starts ONE process instead that runs nothing but f16 matrix
+instructions (`attach_worker.py mfma`: vgpmp_debug_mfma_load) until <dir>/stop_mfma_<j> appears -- the neighbour beside which the round-5
+library was wrong at every step (profiles/r06/flake.md, "What triggers it")."""
 import os
 import subprocess
 import sys
@@ -57,17 +59,56 @@ def mix(out: str, tag: str, log) -> list:
     return rcs
 
 
+def mfma(out: str, tag: str, seconds: float) -> int:
+    """A process that does nothing but f16 matrix instructions (vgpmp_debug_mfma_load, include/vgpmp_debug.h) until <out>/stop_mfma_<tag>
+    appears or `seconds` have passed; <out>/ready_mfma_<tag> says when its kernels are running."""
+    sys.path.insert(0, ROOT)
+    import torch
+    from vgpmp_amd import capi
+    lib = capi.load(require=True)
+    torch.cuda.set_device(0)
+    sink = torch.zeros(4, dtype=torch.float32, device="cuda")
+    stream = int(torch.cuda.current_stream().cuda_stream)
+    # the matrix kernels in bursts on a second stream, a small vector kernel on the first one synchronised every round: kernels of
+    # this process start and end all the time, as those of tools/pk_probe.hip's aggressor mode do (the pattern beside which the
+    # round-5 ELBO step was wrong at every step; a single stream of back-to-back matrix kernels left it alone)
+    second = torch.cuda.Stream()
+    x = torch.linspace(0.0, 1.0, 1 << 16, device="cuda")
+    t0, ready, n = time.time(), False, 0
+    while time.time() - t0 < seconds and not os.path.exists(os.path.join(out, f"stop_mfma_{tag}")):
+        capi.check(lib.vgpmp_debug_mfma_load(capi.ptr(sink), 1024, 2000, int(second.cuda_stream)), "vgpmp_debug_mfma_load")
+        x = torch.sin(x) * 0.999 + 1e-3
+        torch.cuda.current_stream().synchronize()
+        n += 1
+        if n % 8 == 0:
+            second.synchronize()
+        if not ready and n >= 8:
+            open(os.path.join(out, f"ready_mfma_{tag}"), "w").close()
+            ready = True
+    torch.cuda.synchronize()
+    return 0
+
+
 def wait(out: str) -> int:
     """Serves the trigger files <out>/go_attach_1, go_attach_2, ... in turn (one mix each, answered by done_attach_<k>) until the parent goes."""
     parent = os.getppid()
     log = open(os.path.join(out, "attach_visitors.log"), "w")
-    k = 1
+    k = j = 1
     while True:
-        go = os.path.join(out, f"go_attach_{k}")
-        while not os.path.exists(go):
+        go, go_m = os.path.join(out, f"go_attach_{k}"), os.path.join(out, f"go_mfma_{j}")
+        while not os.path.exists(go) and not os.path.exists(go_m):
             if os.getppid() != parent:
                 return 0
             time.sleep(0.05)
+        if os.path.exists(go_m):      # <out>/go_mfma_<j>: ONE process that runs f16 matrix instructions until <out>/stop_mfma_<j> (at most 120 s)
+            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+            rc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "mfma", out, str(j), "120"], env=env, stdout=log, stderr=log).wait()
+            log.flush()
+            with open(os.path.join(out, f"done_mfma_{j}.tmp"), "w") as f:
+                f.write(str(rc))
+            os.replace(os.path.join(out, f"done_mfma_{j}.tmp"), os.path.join(out, f"done_mfma_{j}"))
+            j += 1
+            continue
         rcs = mix(out, str(k), log)
         log.flush()
         with open(os.path.join(out, f"done_attach_{k}.tmp"), "w") as f:
@@ -79,4 +120,6 @@ def wait(out: str) -> int:
 if __name__ == "__main__":
     if sys.argv[1] == "visit":
         sys.exit(visit())
+    if sys.argv[1] == "mfma":
+        sys.exit(mfma(sys.argv[2], sys.argv[3], float(sys.argv[4])))
     sys.exit(wait(sys.argv[2]))

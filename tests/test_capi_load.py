@@ -102,6 +102,7 @@ def test_argument_errors_without_gpu():
     # the schedule log of a thread that has run nothing is empty; a short buffer is respected
     assert handle.vgpmp_debug_last_schedule(None, 0) == 1
     assert handle.vgpmp_debug_sphere_centres(None, None, 1, 1, 7, 1, 0, None, None) == -1
+    assert handle.vgpmp_debug_mfma_load(None, 1, 1, None) == -1
 
 
 def test_product_path_fails_loudly_without_library(monkeypatch, tmp_path):

@@ -1,23 +1,32 @@
-"""The likelihood kernels while other processes arrive on and leave the device.
+"""The likelihood kernels beside what made them return wrong values up to round 5.
 
 Round 5 found that `vgpmp_log_prob` / the likelihood launch of the ELBO step returned WRONG GRADIENTS (by up to 150, sixteen
-consecutive configurations at a time) in a launch that was in flight while another process attached to or left the GPU; the suite
-stayed green only because tests/conftest.py waits for its rank processes before the first test.  These tests do the opposite on
-purpose: the SAME process mix (tests/attach_worker.py: two gloo rank processes, a two-rank `bench.py --shard samples`, then plain
-visitors) comes and goes WHILE the kernels run over and over, and every output is compared bit for bit.
+consecutive configurations at a time) in a launch that ran while another process used the GPU; the suite stayed green only because
+tests/conftest.py waited for its rank processes before the first test.  Round 6 took the failure apart (profiles/r06/flake.md):
 
-  * the stand-alone likelihood (`vgpmp_log_prob`): the damage sat in the gradient's second sweep and went with the SCHEDULE of that
-    loop; an operand fence pins it (csrc/fk_sdf.hip, `vg_sweep_fence`): 0 of 8 reproducer sessions, 7 of 8 before;
-  * the batch form inside the ELBO step: ONE of its forms -- the prefix-scalar form that batches of up to 8 joints ran -- parted two
-    same-seed planners in 31 of 38 reproducer sessions whatever was fenced; every other form (LDS state, 8 lanes per configuration,
-    the pipelined register form at 7 and at 14 joints) 0 of 36.  The prefix form was retired; batches of 7-joint arms run the
-    pipelined form with 8-wide per-frame sums (the retired form's speed).
+  * the victim is ONE instruction form: a packed-FP32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 -- what the compiler's
+    SLP vectoriser makes of three-component arithmetic) whose op_sel and op_sel_hi both select the HIGH register of source 1 reads
+    0.0 for that operand in the low result of lanes 48-63 (tools/depack_pk.py, tools/pk_probe.hip);
+  * the trigger is not a process arriving or a preemption but a NEIGHBOUR ON THE COMPUTE UNIT: while another wave of the same unit runs
+    one of gfx950's wide f16 / bf16 matrix instructions (v_mfma_f32_16x16x32_f16, 32x32x16_f16, 16x16x32_bf16) -- from another
+    process OR from another stream of the same process -- every launch of the probe is wrong; with the two streams on disjoint halves
+    of the compute units none is (tools/trigger_probe.py).  The "other process" of round 5 was a bench running this library's own
+    prior draws, which ARE such instructions.
 
-What the hardware does to the two schedules that failed is NOT established; these tests are the standing check, and one process per
-GPU remains the stated deployment rule ("Deployment constraints").
-History, what was tried and the deployment constraint that follows: profiles/r06/flake.md, INTEGRATION.md ("Deployment constraints"),
-include/vgpmp.h (vgpmp_elbo_step).  Semantics protected: likelihoods/likelihood.py:146-176, utils/sampler.py:103-120 (deterministic
-given the inputs)."""
+The library is built without packed instructions (vgpmp_amd/build.py; tests/test_capi_load.py holds the disassembly at zero), so it
+has no victim.  These tests hold that where it matters, on the device, both ways:
+
+  * beside the matrix instructions themselves: `vgpmp_debug_mfma_load` (include/vgpmp_debug.h) keeps a second stream of THIS process
+    busy with nothing but v_mfma_f32_16x16x32_f16 while the stand-alone likelihood and the ELBO step run over and over -- the
+    condition under which a library WITH the packed form is wrong in every launch (checked on a build with the vectorisers on:
+    profiles/r06/flake.md);
+  * beside the process mix of round 5 (tests/attach_worker.py: two gloo rank processes, a two-rank `bench.py --shard samples`, plain
+    visitors), as VERDICT r5 asked.
+
+Every output is compared bit for bit.  Also kept from the hunt: an operand fence in the gradient's second sweep, and the
+prefix-scalar batch form retired for the pipelined form with 8-wide per-frame sums.  Deployment: INTEGRATION.md ("Deployment
+constraints"), include/vgpmp.h (vgpmp_elbo_step).  Semantics protected: likelihoods/likelihood.py:146-176, utils/sampler.py:103-120
+(deterministic given the inputs)."""
 import ctypes as C
 import os
 import time
@@ -113,3 +122,187 @@ def test_two_planners_stay_together_while_processes_attach(attach_visitors):
     reps, secs, bad = _visitors(out_dir, 2, body)
     print(f"PARITY attach (two planners): {reps} repetitions in {secs:.1f} s beside the visiting processes; first differences: {bad[:1]}")
     assert not bad, bad[:2]
+
+
+class _MatrixLoad:
+    """Work kept running on a second stream of this process: by default `launches` kernels of vgpmp_debug_mfma_load (~10 ms each) per
+    start(); with `planner`, that many optimisation steps of another planner batch (the library's own kernels, prior draws included)."""
+
+    def __init__(self, lib, launches=40, workgroups=1024, iterations=20000, planner=None):
+        iterations = int(os.environ.get("VGPMP_TEST_MFMA_ITERS", iterations))      # (measurement knobs: profiles/r06/flake.md)
+        workgroups = int(os.environ.get("VGPMP_TEST_MFMA_WGS", workgroups))
+        self.lib, self.launches, self.workgroups, self.iterations, self.planner = lib, launches, workgroups, iterations, planner
+        self.stream = torch.cuda.Stream()
+        self.sink = torch.zeros(4, dtype=torch.float32, device="cuda")
+        self.end = None
+
+    def start(self):
+        if self.planner is not None:
+            with torch.cuda.stream(self.stream):
+                for _ in range(self.launches):
+                    self.planner.run_steps(1)
+        else:
+            for _ in range(self.launches):
+                capi.check(self.lib.vgpmp_debug_mfma_load(capi.ptr(self.sink), self.workgroups, self.iterations, int(self.stream.cuda_stream)),
+                           "vgpmp_debug_mfma_load")
+        self.end = torch.cuda.Event()
+        self.end.record(self.stream)
+
+    def running(self) -> bool:
+        return self.end is not None and not self.end.query()
+
+
+def _beside_matrix_load(lib, body, seconds=4.0, max_reps=1 << 30, **load_kw):
+    """body() over and over while the matrix kernel runs on the other stream; returns (repetitions, repetitions that ended while the
+    matrix kernel was still running, differences)."""
+    load = _MatrixLoad(lib, **load_kw)
+    t0, reps, beside, bad = time.time(), 0, 0, []
+    while time.time() - t0 < seconds and len(bad) < 5 and reps < max_reps:
+        if not load.running():
+            load.start()
+        d = body()
+        reps += 1
+        beside += load.running()
+        if d:
+            bad.append((reps, d))
+    load.stream.synchronize()
+    return reps, beside, bad
+
+
+def test_likelihood_is_bit_stable_beside_f16_matrix_kernels():
+    """The stand-alone likelihood on 200 000 fixed joint configurations while a second stream of this process runs f16 matrix
+    instructions and nothing else: every repetition against the first one (taken on an idle device)."""
+    ps, spec, sc = _scene()
+    rng = np.random.default_rng(0)
+    n = 200000
+    g = torch.tensor(rng.uniform(spec.low, spec.high, size=(n, spec.dof)).astype(np.float32), device="cuda")
+    logp = torch.empty(n, dtype=torch.float32, device="cuda")
+    dl = torch.empty((n, spec.dof), dtype=torch.float32, device="cuda")
+
+    def run():
+        logp.fill_(12345.0); dl.fill_(12345.0)
+        capi.check(sc.lib.vgpmp_log_prob(capi.ptr(sc.dev_robot), spec.dof, C.byref(sc.sdf), capi.ptr(g), n, capi.ptr(logp),
+                                         capi.ptr(dl), sc._stream()), "vgpmp_log_prob")
+        torch.cuda.current_stream().synchronize()
+        return logp.clone(), dl.clone()
+
+    torch.cuda.synchronize()
+    ref = run()
+
+    def body():
+        out = run()
+        return [(i, int((x != y).sum()), float((x.double() - y.double()).abs().max())) for i, (x, y) in enumerate(zip(out, ref))
+                if not torch.equal(x, y)]
+
+    reps, beside, bad = _beside_matrix_load(sc.lib, body)
+    print(f"PARITY matrix load (vgpmp_log_prob): {reps} repetitions, {beside} of them beside the running f16 matrix kernel; repetitions that differed: {len(bad)}")
+    assert not bad, bad[:5]
+    assert beside >= 20, (reps, beside)
+
+
+@pytest.mark.parametrize("tag,robot,num_problems", [("franka_x12", "franka", 12), ("franka_x2", "franka", 2)])
+def test_elbo_steps_are_bit_stable_beside_f16_matrix_kernels(tag, robot, num_problems):
+    """Two planners of the same seed: one takes its steps on an idle device first, the other the same steps while the f16 matrix kernel
+    runs on the second stream; variables, paths, log-densities and gradients bit for bit after every step (12 problems: the
+    large-batch schedule with the pipelined likelihood; 2 problems: the few-problem schedule with 8 lanes per configuration)."""
+    ps, spec, sc = _scene()
+    qs = np.array([ps.queries[i % 36] for i in range(num_problems)])
+    kw = dict(num_samples=64, num_inducing=30, num_data=40, num_bases=256, lengthscales=[2.0] * 7, variance=0.2, seed=4)
+    a, b = engine.PlannerBatch(sc, qs, **kw), engine.PlannerBatch(sc, qs, **kw)
+    names = ("q_mu", "q_sqrt", "f", "logp")
+    steps, alone = 60, []
+    for _ in range(steps):
+        a.run_steps(1)
+        torch.cuda.current_stream().synchronize()
+        alone.append({k: getattr(a, k).clone() for k in names} | {"G": a.view("G")})
+    it = iter(alone)
+
+    def body():
+        want = next(it)
+        b.run_steps(1)
+        torch.cuda.current_stream().synchronize()
+        got = {k: getattr(b, k) for k in names} | {"G": b.view("G")}
+        return [(k, int((got[k] != want[k]).sum())) for k in want if not torch.equal(got[k], want[k])]
+
+    reps, beside, bad = _beside_matrix_load(sc.lib, body, seconds=30.0, max_reps=steps)
+    print(f"PARITY matrix load (ELBO steps, {tag}): {reps} steps, {beside} repetitions beside the running f16 matrix kernel; first differences: {bad[:1]}")
+    assert not bad, bad[:2]
+    assert beside >= 20, (reps, beside)
+
+
+def test_elbo_steps_are_bit_stable_beside_another_planner_on_a_second_stream():
+    """One process, two streams, two planner batches: 12 problems take their steps while 64 OTHER problems (the large-batch schedule:
+    f16 matrix instructions in the prior draws, float64 matrix instructions in the covariance path, the masked likelihood) step on a
+    second stream.  The 12 problems' variables, paths, log-densities and gradients against the same steps taken on an idle device."""
+    ps, spec, sc = _scene()
+    qs = np.array([ps.queries[i % 36] for i in range(12)])
+    kw = dict(num_samples=64, num_inducing=30, num_data=40, num_bases=256, lengthscales=[2.0] * 7, variance=0.2)
+    a, b = engine.PlannerBatch(sc, qs, seed=4, **kw), engine.PlannerBatch(sc, qs, seed=4, **kw)
+    other = engine.PlannerBatch(sc, np.array([ps.queries[(5 * i + 1) % 36] for i in range(64)]), seed=9, **kw)
+    names = ("q_mu", "q_sqrt", "f", "logp")
+    steps, alone = 80, []
+    for _ in range(steps):
+        a.run_steps(1)
+        torch.cuda.current_stream().synchronize()
+        alone.append({k: getattr(a, k).clone() for k in names} | {"G": a.view("G")})
+    it = iter(alone)
+
+    def body():
+        want = next(it)
+        b.run_steps(1)
+        torch.cuda.current_stream().synchronize()
+        got = {k: getattr(b, k) for k in names} | {"G": b.view("G")}
+        return [(k, int((got[k] != want[k]).sum())) for k in want if not torch.equal(got[k], want[k])]
+
+    reps, beside, bad = _beside_matrix_load(sc.lib, body, seconds=60.0, max_reps=steps, planner=other, launches=150)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(other.q_mu).all())
+    print(f"PARITY second stream (ELBO steps beside another planner batch): {reps} steps, {beside} of them while the other batch was stepping; first differences: {bad[:1]}")
+    assert not bad, bad[:2]
+    assert beside >= 20, (reps, beside)
+
+
+def test_elbo_steps_are_bit_stable_beside_a_process_running_f16_matrix_kernels(attach_visitors):
+    """ANOTHER PROCESS keeps the device busy with f16 matrix instructions (tests/attach_worker.py mfma: bursts on a second stream, a
+    small vector kernel on the first) while 12 problems take 60 steps: against the same steps taken before that process started.  A
+    scenario check, not a proven detector: the library as round 5 shipped it was wrong at EVERY step beside tools/pk_probe_dflt in its
+    aggressor mode (PK_AGG=2; thousands of wrong log-densities and gradients per step, profiles/r06/flake_sessions/matrix_load_tests_r5.txt)
+    but not beside this visitor; the detectors with proven teeth are the in-process test of the stand-alone likelihood above (wrong in
+    every repetition on that library) and the two process-mix tests (wrong in every session)."""
+    out_dir, _ = attach_visitors
+    ps, spec, sc = _scene()
+    qs = np.array([ps.queries[i % 36] for i in range(12)])
+    kw = dict(num_samples=64, num_inducing=30, num_data=40, num_bases=256, lengthscales=[2.0] * 7, variance=0.2, seed=4)
+    a, b = engine.PlannerBatch(sc, qs, **kw), engine.PlannerBatch(sc, qs, **kw)
+    names = ("q_mu", "q_sqrt", "f", "logp")
+    steps, alone = 60, []
+    for _ in range(steps):
+        a.run_steps(1)
+        torch.cuda.current_stream().synchronize()
+        alone.append({k: getattr(a, k).clone() for k in names} | {"G": a.view("G")})
+    open(os.path.join(out_dir, "go_mfma_1"), "w").close()
+    t0 = time.time()
+    while not os.path.exists(os.path.join(out_dir, "ready_mfma_1")) and time.time() - t0 < 180:
+        time.sleep(0.05)
+    try:
+        assert os.path.exists(os.path.join(out_dir, "ready_mfma_1")), open(os.path.join(out_dir, "attach_visitors.log")).read()[-2000:]
+        bad = []
+        for i, want in enumerate(alone):
+            b.run_steps(1)
+            torch.cuda.current_stream().synchronize()
+            got = {k: getattr(b, k) for k in names} | {"G": b.view("G")}
+            d = [(k, int((got[k] != want[k]).sum())) for k in want if not torch.equal(got[k], want[k])]
+            if d:
+                bad.append((i + 1, d))
+                if len(bad) >= 3:
+                    break
+        still = not os.path.exists(os.path.join(out_dir, "done_mfma_1"))
+    finally:
+        open(os.path.join(out_dir, "stop_mfma_1"), "w").close()
+        t1 = time.time()
+        while not os.path.exists(os.path.join(out_dir, "done_mfma_1")) and time.time() - t1 < 180:
+            time.sleep(0.05)
+    print(f"PARITY matrix process (ELBO steps): {steps} steps beside a process running f16 matrix kernels (still running at the end: {still}); first differences: {bad[:1]}")
+    assert not bad, bad[:2]
+    assert still, "the matrix-kernel process had gone before the steps were taken"
+    assert open(os.path.join(out_dir, "done_mfma_1")).read().strip() == "0", open(os.path.join(out_dir, "attach_visitors.log")).read()[-2000:]

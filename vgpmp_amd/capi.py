@@ -31,7 +31,7 @@ EXPORTS = ("vgpmp_version", "vgpmp_robot_upload", "vgpmp_sdf_table_bytes", "vgpm
            "vgpmp_log_prob", "vgpmp_cov_matrices", "vgpmp_kernel_derivative", "vgpmp_velocity_kuu_kuf", "vgpmp_workspace_bytes", "vgpmp_lik_scratch_bytes", "vgpmp_inducing_scratch_bytes", "vgpmp_generate_noise", "vgpmp_elbo_step",
            "vgpmp_elbo_steps", "vgpmp_elbo_step_profiled", "vgpmp_adam_step", "vgpmp_workspace_view", "vgpmp_sample_paths",
            "vgpmp_comm_unique_id", "vgpmp_comm_init", "vgpmp_allreduce_grads", "vgpmp_comm_destroy", "vgpmp_elbo_steps_reduced")
-DEBUG_EXPORTS = ("vgpmp_debug_sphere_centres", "vgpmp_debug_last_schedule")      # include/vgpmp_debug.h
+DEBUG_EXPORTS = ("vgpmp_debug_sphere_centres", "vgpmp_debug_last_schedule", "vgpmp_debug_mfma_load")      # include/vgpmp_debug.h
 NUM_STAGES = 8
 NUM_TIMES = 10
 STAGE_NAMES = ("cov_fwd", "noise", "features", "prior_gemm", "paths_fwd", "loglik_fk_sdf", "paths_bwd", "final_adam")
@@ -169,6 +169,7 @@ def load(require: bool = True) -> Optional[C.CDLL]:
                                      vp, C.c_size_t, i32, i32, dbl, i32, u32, u32, u32, i32, vp, vp, C.c_size_t, vp],
     }
     sigs["vgpmp_debug_sphere_centres"] = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    sigs["vgpmp_debug_mfma_load"] = [vp, i32, i32, vp]
     for name, args in sigs.items():
         fn = getattr(lib, name)
         fn.argtypes = args

@@ -50,6 +50,21 @@ void vg_sched_note_fn(const void* fn) {
     t_sched.push_back(n ? n : &kUnknown);
 }
 
+namespace {
+// vgpmp_debug_mfma_load (include/vgpmp_debug.h): f16 matrix instructions and nothing else
+typedef _Float16 vg_dbg_h8 __attribute__((ext_vector_type(8)));
+typedef float vg_dbg_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void debug_mfma_load_kernel(float* __restrict__ sink, int iterations) {
+    const float seed = (float)((blockIdx.x * 256u + threadIdx.x) & 1023u) * (1.0f / 1024.0f);
+    vg_dbg_h8 a, b;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a[k] = (_Float16)(seed + 0.125f * k); b[k] = (_Float16)(0.5f - seed); }
+    vg_dbg_f4 c = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < iterations * 16; ++i) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    if (c[0] + c[1] + c[2] + c[3] == 123.456f) sink[0] = c[0];      // (never true: the products stay in the kernel)
+}
+}  // namespace
+
 extern "C" {
 
 const char* vgpmp_version(void) { return "vgpmp-hip 0.2 (gfx950)"; }
@@ -172,6 +187,13 @@ int vgpmp_debug_sphere_centres(const vgpmp_robot* dev_robot, const float* dev_f,
     if ((size_t)num_problems * S * N > 0 && (!dev_f || !dev_pos)) return VGPMP_E_ARG;
     return vg_launch_sphere_centres(dev_robot, dev_f, num_problems, S, L, N,
                                     (what & VGPMP_LIK_LDS_STATE) ? 2 : (what & VGPMP_LIK_LANES) ? 1 : 0, dev_pos, (hipStream_t)stream);
+}
+
+int vgpmp_debug_mfma_load(float* dev_sink, int32_t workgroups, int32_t iterations, vgpmp_stream stream) {
+    if (!dev_sink) return VGPMP_E_ARG;
+    if (workgroups < 1 || iterations < 1) return VGPMP_E_SHAPE;
+    hipLaunchKernelGGL(debug_mfma_load_kernel, dim3((unsigned)workgroups), dim3(256), 0, (hipStream_t)stream, dev_sink, (int)iterations);
+    return (int)hipGetLastError();
 }
 
 int64_t vgpmp_debug_last_schedule(char* buf, size_t buf_bytes) {
