@@ -335,13 +335,13 @@ int vgpmp_generate_noise(const vgpmp_dims* dims, const vgpmp_noise* noise, uint3
 /* One evaluation of VGPMP.elbo (models/vgpmp.py:265-289) for every problem of the batch and,
  * depending on `what` (VGPMP_DO_*), its reverse pass and the Adam update of
  * utils/miscellaneous.py:68-84.  `adam_t` is the 1-based step count after this update.
- * DEPLOYMENT NOTE (profiles/r06/flake.md): give the calling process the GPU to itself.  Up to round 5 a
- * likelihood launch in flight while ANOTHER process arrived on or left the device (every queue is preempted and resumed then) could
- * silently return wrong values for sixteen consecutive configurations: a packed-FP32 instruction (v_pk_fma / mul / add_f32, formed by
- * the compiler's SLP vectoriser) whose op_sel and op_sel_hi both select source 1's high register reads 0.0 for it in lanes 48-63 once
- * per preemption of its wave (MI355X, ROCm 7.0.2; tools/pk_probe.hip).  This library is built without packed instructions (a test
- * holds the count at zero); other code on the same GPU may not be.  Applies to every
- * vgpmp_elbo_step* entry and to vgpmp_log_prob. */
+ * DEPLOYMENT NOTE (profiles/r06/flake.md).  On MI355X a packed-FP32 instruction (v_pk_fma / mul / add_f32, which
+ * compilers form from ordinary float arithmetic) whose op_sel and op_sel_hi both select source 1's high register reads 0.0 for it in
+ * lanes 48-63 while ANOTHER wave of the same compute unit runs a wide f16 / bf16 matrix instruction (v_mfma_f32_16x16x32_f16 ...), whether
+ * that wave belongs to another process or to another stream of this one (tools/pk_probe.hip).  This library contains no packed
+ * instruction (a test holds the disassembly at zero), so its results do not depend on what runs beside it; but its prior draws ARE such
+ * matrix instructions: other code that shares the GPU with a running planner and holds the packed form computes wrong values.  Audit it
+ * (tools/audit_packed.py) or keep it off this GPU.  Applies to every vgpmp_elbo_step* entry. */
 int vgpmp_elbo_step(const vgpmp_dims* dims, const vgpmp_robot* dev_robot, const vgpmp_sdf* sdf,
                     const vgpmp_problem* problem, const vgpmp_params* params,
                     const vgpmp_params* adam_m, const vgpmp_params* adam_v,

@@ -5,8 +5,8 @@
 The waiting launcher never touches the GPU itself; whenever a test writes <dir>/go_attach_<k> (k = 1, 2, ...) it starts, side by side, the process mix beside
 which the likelihood kernels of round 5 returned wrong gradients in 7 of 8 sessions (tools/flake_session, profiles/r06/flake.md): the
 two rank processes of the sample-sharding test (tests/shard_worker.py, gloo) and `bench.py --gpus 2 --shard samples` (which starts two
-more ranks), then two plain visitors (`attach_worker.py visit`: open the device, build a planner, twenty steps, exit).  Every arrival
-and every exit makes the hardware scheduler rebuild its run list: each queue of the device is preempted and resumed.  When all have
+more ranks), then two plain visitors (`attach_worker.py visit`: open the device, build a planner, twenty steps, exit).  What mattered about that mix
+turned out to be the bench's KERNELS (this library's prior draws: wide f16 matrix instructions) beside the test's, not the arrivals.  When all have
 exited it writes <dir>/done_attach_<k> with their exit codes.  <dir>/go_mfma_<j> starts ONE process instead that runs nothing but f16 matrix
 instructions (`attach_worker.py mfma`: vgpmp_debug_mfma_load) until <dir>/stop_mfma_<j> appears -- the neighbour beside which the round-5
 library was wrong at every step (profiles/r06/flake.md, "What triggers it")."""

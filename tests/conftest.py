@@ -63,10 +63,11 @@ def pytest_sessionstart(session):
     session.config._bench_gpus8 = (subprocess.Popen([sys.executable, "-c", code], env=env), out)
     # ... and the launcher of tests/test_gpu_attach.py's visitors (processes that arrive on and leave the device while that test runs)
     session.config._attach = (subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "attach_worker.py"), "wait", out], env=env), out)
-    # The tests start only when the two-rank bench has finished (and the shard workers, which initialise beside it, idle): the bit-for-bit
-    # tests get the device alone, as a deployed planner does ("Deployment constraints").  What a launch in flight did when
-    # another process ARRIVED on or LEFT the device -- wrong values for a quarter wave, profiles/r06/flake.md -- is not hidden by this wait:
-    # tests/test_gpu_attach.py runs the kernels ON PURPOSE beside the same process mix and compares bit for bit.
+    # The tests start only when the two-rank bench has finished (and the shard workers, which initialise beside it, idle): the timing-
+    # sensitive tests get the device alone, as a deployed planner does ("Deployment constraints").  What a launch did up to
+    # round 5 beside another process's kernels -- wrong values for a quarter wave: a packed-FP32 instruction form beside a wide f16 matrix
+    # instruction on the same compute unit, profiles/r06/flake.md -- is not hidden by this wait: tests/test_gpu_attach.py runs the kernels ON
+    # PURPOSE beside the same process mix AND beside the matrix instructions themselves, and compares bit for bit.
     try:
         bench.wait(timeout=600)
     except subprocess.TimeoutExpired:

@@ -17,13 +17,14 @@ HEADERS = [CSRC / "vgpmp_device.h", CSRC / "gp_path.h", CSRC / "fk_chain.h", CSR
 # private parts of gp_path.hip (one translation unit: its stage launches dispatch these bodies by role)
 GP_PARTS = [CSRC / n for n in ("gp_common.h", "gp_rng.h", "gp_paths.h", "gp_update.h", "gp_cov.h", "gp_prior.h", "gp_prior_split.h", "gp_lik_consts.h", "gp_wtable.h")]
 # -fno-slp-vectorize -fno-vectorize: NO packed-FP32 VALU instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) in the library.  On
-# MI355X / ROCm 7.0.2 such instructions leave wrong results in lanes 48-63 of a wave that is preempted while they are in flight
-# (another process arriving on or leaving the device): tools/sweep_probe.hip reproduces it in plain HIP, 18 of 18 sessions with packed
-# instructions, 0 of 12 without (profiles/r06/flake.md).  The compiler's vectorisers are where all but three of the library's 8 687
-# packed instructions came from; they bought no time (config 2 50.2 / 50.2 us, config-5 share 735 / 732, 64 problems 362 / 355, config 3
-# 121.6 / 122.0 us per step with / without).  packed_fp32_instructions() below is what tests/test_capi_load.py holds at zero.  The ONE form
-# that misbehaves was pinned afterwards (tools/depack_pk.py, tools/pk_probe.hip: op_sel and op_sel_hi both on source 1's high half reads
-# 0.0 there in lanes 48-63 after a preemption); src1_high_half_instructions() lists it for any library, this one holds none of any type.
+# MI355X / ROCm 7.0.2 such an instruction, when its op_sel and op_sel_hi both select source 1's high register, reads 0.0 for that operand
+# in lanes 48-63 while another wave of the same compute unit runs a wide f16 / bf16 matrix instruction (v_mfma_f32_16x16x32_f16 ...: this
+# library's own prior draws, in another process or on another stream) -- tools/pk_probe.hip, tools/trigger_probe.py, profiles/r06/flake.md;
+# the likelihood's wrong gradients of round 5.  The compiler's vectorisers are where all but three of the library's 8 687 packed
+# instructions came from; they bought no time (config 2 50.2 / 50.2 us, config-5 share 735 / 732, 64 problems 362 / 355, config 3
+# 121.6 / 122.0 us per step with / without).  packed_fp32_instructions() below is what tests/test_capi_load.py holds at zero;
+# src1_high_half_instructions() lists the one form that misbehaves, for any library (tools/audit_packed.py): this one holds no packed
+# instruction of any type.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize", "-fno-vectorize"]
 
 
@@ -120,8 +121,8 @@ def packed_fp32_instructions(lib: Path = LIB, objdump: str = "/opt/rocm/lib/llvm
 
 def src1_high_half_instructions(lib: Path = LIB, objdump: str = "/opt/rocm/lib/llvm/bin/llvm-objdump") -> list:
     """The packed (VOP3P, `v_pk_*`) instructions of `lib` whose op_sel AND op_sel_hi both select the high half of SOURCE 1 -- the one form
-    that tools/pk_probe.hip shows reading 0.0 for that operand in lanes 48-63 after a preemption (profiles/r06/flake.md, "The
-    instruction": v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[x,1,x] with op_sel_hi:[x,1,x], the default).  Policy: empty."""
+    that tools/pk_probe.hip shows reading 0.0 for that operand in lanes 48-63 beside a wide f16 matrix instruction (profiles/r06/flake.md, "The
+    instruction", "What triggers it": v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[x,1,x] with op_sel_hi:[x,1,x], the default).  Policy: empty."""
     import re
     hits = []
     for text in _gfx950_disassemblies(lib, objdump):

@@ -80,9 +80,9 @@ typedef _Float16 vg_h2 __attribute__((ext_vector_type(2)));
 typedef _Float16 vg_h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 vg_h8 __attribute__((ext_vector_type(8)));
 typedef float vg_f2 __attribute__((ext_vector_type(2)));
-// No packed-FP32 VALU instruction in this library (profiles/r06/flake.md: v_pk_fma / v_pk_mul / v_pk_add_f32 in flight when a wave is
-// preempted leave wrong results in lanes 48-63 on MI355X / ROCm 7.0.2; the build passes -fno-slp-vectorize and tests/test_capi_load.py
-// scans the code objects).  Arithmetic on float vectors is therefore written per component: the compiler turns `v * s` on an
+// No packed-FP32 VALU instruction in this library (profiles/r06/flake.md: on MI355X / ROCm 7.0.2 v_pk_fma / v_pk_mul / v_pk_add_f32 that take
+// source 1's high register for both results read 0.0 there in lanes 48-63 while another wave of the compute unit runs a wide f16 matrix
+// instruction; the build passes -fno-slp-vectorize and tests/test_capi_load.py scans the code objects).  Arithmetic on float vectors is therefore written per component: the compiler turns `v * s` on an
 // ext_vector_type into v_pk_mul_f32 whatever the vectoriser is told.
 template <typename V> __device__ __forceinline__ V vg_scale4(V v, float s) { return V{v[0] * s, v[1] * s, v[2] * s, v[3] * s}; }
 

@@ -381,7 +381,7 @@ int vg_launch_mesh_sdf(const double* tri, const int* part, int T, int nx, int ny
 
 // ---- race hunt build (-DVGPMP_RACE; tools/build_variant.sh race WORK -DVGPMP_RACE): behind EVERY workgroup barrier each wave sleeps a
 // pseudo-random 0 .. ~4000 cycles, so the waves of a workgroup leave barriers in scrambled order and at scrambled distances -- what a
-// preemption by the hardware scheduler does to them once in a while.  Code that is correct only because its waves
+// busy neighbour on the device does to them once in a while (round 5's hunt for a race; there was none: DESIGN section 4).  Code that is correct only because its waves
 // happen to run in lock step between two barriers then differs from run to run (tools/dbg_rep.py with VGPMP_HIP_LIB set).
 #ifdef VGPMP_RACE
 static __device__ __forceinline__ void vg_real_syncthreads() { __syncthreads(); }
