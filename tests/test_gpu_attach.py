@@ -21,7 +21,10 @@ has no victim.  These tests hold that where it matters, on the device, both ways
     condition under which a library WITH the packed form is wrong in every launch (checked on a build with the vectorisers on:
     profiles/r06/flake.md);
   * beside the process mix of round 5 (tests/attach_worker.py: two gloo rank processes, a two-rank `bench.py --shard samples`, plain
-    visitors), as VERDICT r5 asked.
+    visitors), as VERDICT r5 asked; beside another planner batch on a second stream; beside another process that runs matrix kernels;
+    and beside the in-process matrix kernel AND the process mix together -- the neighbourhood in which the library as round 5 shipped
+    it fails fastest (which waves meet on a compute unit is a matter of placement that other processes' work changes:
+    profiles/r06/flake.md, "What triggers it").
 
 Every output is compared bit for bit.  Also kept from the hunt: an operand fence in the gradient's second sweep, and the
 prefix-scalar batch form retired for the pipelined form with 8-wide per-frame sums.  Deployment: INTEGRATION.md ("Deployment
@@ -306,3 +309,33 @@ def test_elbo_steps_are_bit_stable_beside_a_process_running_f16_matrix_kernels(a
     assert not bad, bad[:2]
     assert still, "the matrix-kernel process had gone before the steps were taken"
     assert open(os.path.join(out_dir, "done_mfma_1")).read().strip() == "0", open(os.path.join(out_dir, "attach_visitors.log")).read()[-2000:]
+
+
+def test_two_planners_stay_together_beside_matrix_load_and_visiting_processes(attach_visitors):
+    """The strongest neighbourhood found (profiles/r06/flake_sessions/neighbour_vs_r5.txt): f16 matrix kernels on a second stream of THIS
+    process AND other processes running kernels of any kind on the device -- the library as round 5 shipped it parts two same-seed planners
+    within seven steps there (within one step beside a process that runs matrix kernels itself).  Two planners of the same seed, 12
+    problems, one step each per repetition, bit for bit, while the round-5 process mix comes and goes and the matrix kernel runs."""
+    out_dir, _ = attach_visitors
+    ps, spec, sc = _scene()
+    qs = np.array([ps.queries[i % 36] for i in range(12)])
+    kw = dict(num_samples=64, num_inducing=30, num_data=40, num_bases=256, lengthscales=[2.0] * 7, variance=0.2, seed=4)
+    a, b = engine.PlannerBatch(sc, qs, **kw), engine.PlannerBatch(sc, qs, **kw)
+    load = _MatrixLoad(sc.lib)
+    beside = [0]
+
+    def body():
+        if not load.running():
+            load.start()
+        a.run_steps(1); b.run_steps(1)
+        torch.cuda.current_stream().synchronize()
+        beside[0] += load.running()
+        pairs = {"q_mu": (a.q_mu, b.q_mu), "q_sqrt": (a.q_sqrt, b.q_sqrt), "f": (a.f, b.f), "logp": (a.logp, b.logp), "G": (a.view("G"), b.view("G"))}
+        return [(k, int((x != y).sum())) for k, (x, y) in pairs.items() if not torch.equal(x, y)]
+
+    reps, secs, bad = _visitors(out_dir, 3, body)
+    load.stream.synchronize()
+    print(f"PARITY matrix load + attach (two planners): {reps} repetitions in {secs:.1f} s, {beside[0]} of them beside the running f16 matrix kernel "
+          f"and the visiting processes; first differences: {bad[:1]}")
+    assert not bad, bad[:2]
+    assert beside[0] >= 20, (reps, beside[0])
