@@ -203,14 +203,29 @@ def test_likelihood_is_bit_stable_beside_f16_matrix_kernels():
     assert beside >= 20, (reps, beside)
 
 
-@pytest.mark.parametrize("tag,robot,num_problems", [("franka_x12", "franka", 12), ("franka_x2", "franka", 2)])
-def test_elbo_steps_are_bit_stable_beside_f16_matrix_kernels(tag, robot, num_problems):
+_STEP_CASES = [      # one per schedule of vg_elbo_steps and likelihood form
+    ("franka_x12", "franka", 12, dict(num_samples=64, num_inducing=30, num_data=40, num_bases=256)),      # large batch, pipelined likelihood (8-wide sums)
+    ("franka_x2", "franka", 2, dict(num_samples=64, num_inducing=30, num_data=40, num_bases=256)),        # few problems: 8 lanes per configuration
+    ("franka_x4", "franka", 4, dict(num_samples=64, num_inducing=30, num_data=40, num_bases=256)),        # 3-4 problems: stage3 + batch form
+    ("franka_x9_s7", "franka", 9, dict(num_samples=7, num_inducing=24, num_data=70, num_bases=256)),      # few samples: small16 prior, sc8 paths
+    ("arm14_x8", "arm14", 8, dict(num_samples=64, num_inducing=30, num_data=40, num_bases=256)),          # 14 joints: 16-wide pipelined likelihood
+]
+
+
+@pytest.mark.parametrize("tag,robot,num_problems,shape", _STEP_CASES, ids=[c[0] for c in _STEP_CASES])
+def test_elbo_steps_are_bit_stable_beside_f16_matrix_kernels(tag, robot, num_problems, shape):
     """Two planners of the same seed: one takes its steps on an idle device first, the other the same steps while the f16 matrix kernel
-    runs on the second stream; variables, paths, log-densities and gradients bit for bit after every step (12 problems: the
-    large-batch schedule with the pipelined likelihood; 2 problems: the few-problem schedule with 8 lanes per configuration)."""
-    ps, spec, sc = _scene()
-    qs = np.array([ps.queries[i % 36] for i in range(num_problems)])
-    kw = dict(num_samples=64, num_inducing=30, num_data=40, num_bases=256, lengthscales=[2.0] * 7, variance=0.2, seed=4)
+    runs on the second stream; variables, paths, log-densities and gradients bit for bit after every step -- one case per launch
+    schedule and likelihood form."""
+    if robot == "arm14":
+        spec = rb.synthetic_arm(14)
+        grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -1.2), seed=0)
+        sc = engine.DeviceScene(spec, grid, (0, 0, 0))
+        qs = np.random.default_rng(0).uniform(-2.0, 2.0, (num_problems, 2, 14))
+    else:
+        ps, spec, sc = _scene()
+        qs = np.array([ps.queries[i % 36] for i in range(num_problems)])
+    kw = dict(lengthscales=[2.0] * spec.dof, variance=0.2, seed=4, **shape)
     a, b = engine.PlannerBatch(sc, qs, **kw), engine.PlannerBatch(sc, qs, **kw)
     names = ("q_mu", "q_sqrt", "f", "logp")
     steps, alone = 60, []
