@@ -137,22 +137,39 @@ class _MatrixLoad:
         self.lib, self.launches, self.workgroups, self.iterations, self.planner = lib, launches, workgroups, iterations, planner
         self.stream = torch.cuda.Stream()
         self.sink = torch.zeros(4, dtype=torch.float32, device="cuda")
-        self.end = None
+        self.end, self.stop = None, False
 
     def start(self):
-        if self.planner is not None:
-            with torch.cuda.stream(self.stream):
-                for _ in range(self.launches):
-                    self.planner.run_steps(1)
-        else:
-            for _ in range(self.launches):
-                capi.check(self.lib.vgpmp_debug_mfma_load(capi.ptr(self.sink), self.workgroups, self.iterations, int(self.stream.cuda_stream)),
-                           "vgpmp_debug_mfma_load")
+        if self.planner is not None:      # a thread of its own keeps the other batch stepping (the host side of a step is most of its time)
+            import threading
+
+            def steps():      # until finish(): the queue kept at most `launches` steps deep
+                torch.cuda.set_device(0)
+                with torch.cuda.stream(self.stream):
+                    while not self.stop:
+                        for _ in range(self.launches):
+                            self.planner.run_steps(1)
+                        self.stream.synchronize()
+
+            self.thread = threading.Thread(target=steps, daemon=True)
+            self.thread.start()
+            return
+        for _ in range(self.launches):
+            capi.check(self.lib.vgpmp_debug_mfma_load(capi.ptr(self.sink), self.workgroups, self.iterations, int(self.stream.cuda_stream)),
+                       "vgpmp_debug_mfma_load")
         self.end = torch.cuda.Event()
         self.end.record(self.stream)
 
     def running(self) -> bool:
+        if self.planner is not None:
+            return getattr(self, "thread", None) is not None and self.thread.is_alive()
         return self.end is not None and not self.end.query()
+
+    def finish(self):
+        self.stop = True
+        if getattr(self, "thread", None) is not None:
+            self.thread.join()
+        self.stream.synchronize()
 
 
 def _beside_matrix_load(lib, body, seconds=4.0, max_reps=1 << 30, **load_kw):
@@ -168,7 +185,7 @@ def _beside_matrix_load(lib, body, seconds=4.0, max_reps=1 << 30, **load_kw):
         beside += load.running()
         if d:
             bad.append((reps, d))
-    load.stream.synchronize()
+    load.finish()
     return reps, beside, bad
 
 
@@ -216,7 +233,8 @@ _STEP_CASES = [      # one per schedule of vg_elbo_steps and 
 def test_elbo_steps_are_bit_stable_beside_f16_matrix_kernels(tag, robot, num_problems, shape):
     """Two planners of the same seed: one takes its steps on an idle device first, the other the same steps while the f16 matrix kernel
     runs on the second stream; variables, paths, log-densities and gradients bit for bit after every step -- one case per launch
-    schedule and likelihood form."""
+    schedule and likelihood form.  (On the library as round 5 shipped it the 14-joint case is wrong at the first step; the 7-joint
+    cases need a second process on the device as well: profiles/r06/flake.md, "What triggers it".)"""
     if robot == "arm14":
         spec = rb.synthetic_arm(14)
         grid = scenes.synthetic_boxes_sdf(n=48, delta=0.05, origin=(-1.2, -1.2, -1.2), seed=0)
@@ -272,7 +290,7 @@ def test_elbo_steps_are_bit_stable_beside_another_planner_on_a_second_stream():
         got = {k: getattr(b, k) for k in names} | {"G": b.view("G")}
         return [(k, int((got[k] != want[k]).sum())) for k in want if not torch.equal(got[k], want[k])]
 
-    reps, beside, bad = _beside_matrix_load(sc.lib, body, seconds=60.0, max_reps=steps, planner=other, launches=150)
+    reps, beside, bad = _beside_matrix_load(sc.lib, body, seconds=60.0, max_reps=steps, planner=other, launches=50)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(other.q_mu).all())
     print(f"PARITY second stream (ELBO steps beside another planner batch): {reps} steps, {beside} of them while the other batch was stepping; first differences: {bad[:1]}")
@@ -349,7 +367,7 @@ def test_two_planners_stay_together_beside_matrix_load_and_visiting_processes(at
         return [(k, int((x != y).sum())) for k, (x, y) in pairs.items() if not torch.equal(x, y)]
 
     reps, secs, bad = _visitors(out_dir, 3, body)
-    load.stream.synchronize()
+    load.finish()
     print(f"PARITY matrix load + attach (two planners): {reps} repetitions in {secs:.1f} s, {beside[0]} of them beside the running f16 matrix kernel "
           f"and the visiting processes; first differences: {bad[:1]}")
     assert not bad, bad[:2]
